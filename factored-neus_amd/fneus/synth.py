@@ -1,0 +1,136 @@
+"""Deterministic synthetic inputs for the hot path: network weights and DTU-shaped ray batches.
+
+Used by bench.py, the tests and tests/golden/gen_golden.py.  numpy RandomState streams only, so the
+same seed gives bit-identical arrays in the build container and on the GPU box (no torch RNG).
+
+Weight distributions follow the reference initialisers:
+  SDFNetwork geometric init ........ models/fields.py:47-65 (then weight_norm, :67-68)
+  RenderingNetwork / NeRF / RefColor  default nn.Linear init (kaiming-uniform(a=sqrt 5) = U(+-1/sqrt(fan_in)))
+  SingleVarianceNetwork ............ init_val 0.3 (confs/wmask.conf:75)
+plus a small deterministic perturbation so the SDF is not an exact sphere and g != ||v||.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+
+SDF_DIMS = [39, 256, 256, 256, 256, 256, 256, 256, 256, 257]   # fields.py:26-34 with multires=6
+SDF_SKIP = (4,)
+COLOR_DIMS = [289, 256, 256, 256, 256, 3]                       # fields.py:127-133 (9+256+24)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def sdf_state_dict(seed: int = 0, perturb: float = 0.02, bias: float = 0.5) -> "OrderedDict[str, np.ndarray]":
+    """lin{l}.bias / weight_g / weight_v in the reference's state_dict order (fields.py:67-70)."""
+    rs = np.random.RandomState(seed)
+    dims = SDF_DIMS
+    n_lin = len(dims) - 1
+    sd = OrderedDict()
+    for l in range(n_lin):
+        out_dim = dims[l + 1] - dims[0] if (l + 1) in SDF_SKIP else dims[l + 1]
+        in_dim = dims[l]
+        if l == n_lin - 1:
+            w = rs.normal(math.sqrt(math.pi) / math.sqrt(in_dim), 1e-4, size=(out_dim, in_dim))
+            b = np.full((out_dim,), -bias)
+        elif l == 0:
+            w = np.zeros((out_dim, in_dim))
+            w[:, :3] = rs.normal(0.0, math.sqrt(2) / math.sqrt(out_dim), size=(out_dim, 3))
+            b = np.zeros((out_dim,))
+        elif l in SDF_SKIP:
+            w = rs.normal(0.0, math.sqrt(2) / math.sqrt(out_dim), size=(out_dim, in_dim))
+            w[:, -(dims[0] - 3):] = 0.0
+            b = np.zeros((out_dim,))
+        else:
+            w = rs.normal(0.0, math.sqrt(2) / math.sqrt(out_dim), size=(out_dim, in_dim))
+            b = np.zeros((out_dim,))
+        if perturb > 0:
+            scale = np.abs(w).mean() + 1e-3
+            w = w + perturb * scale * rs.standard_normal(w.shape)
+            b = b + perturb * 0.05 * rs.standard_normal(b.shape)
+        g = np.linalg.norm(w, axis=1, keepdims=True)
+        if perturb > 0:
+            g = g * (1.0 + perturb * rs.standard_normal(g.shape))
+        sd[f"lin{l}.bias"] = _f32(b)
+        sd[f"lin{l}.weight_g"] = _f32(g)
+        sd[f"lin{l}.weight_v"] = _f32(w)
+    return sd
+
+
+def _linear_default(rs, out_dim, in_dim):
+    k = 1.0 / math.sqrt(in_dim)
+    return rs.uniform(-k, k, size=(out_dim, in_dim)), rs.uniform(-k, k, size=(out_dim,))
+
+
+def color_state_dict(seed: int = 1) -> "OrderedDict[str, np.ndarray]":
+    rs = np.random.RandomState(seed)
+    sd = OrderedDict()
+    for l in range(len(COLOR_DIMS) - 1):
+        w, b = _linear_default(rs, COLOR_DIMS[l + 1], COLOR_DIMS[l])
+        g = np.linalg.norm(w, axis=1, keepdims=True) * (1.0 + 0.02 * rs.standard_normal((w.shape[0], 1)))
+        sd[f"lin{l}.bias"] = _f32(b)
+        sd[f"lin{l}.weight_g"] = _f32(g)
+        sd[f"lin{l}.weight_v"] = _f32(w)
+    return sd
+
+
+def refcolor_state_dict(seed: int = 2) -> "OrderedDict[str, np.ndarray]":
+    """RefColor (fields.py:271-300): net_cd.{0,2,4,6,8}, viewdir_mlp.{0..3}, net_cs.0."""
+    rs = np.random.RandomState(seed)
+    sd = OrderedDict()
+    dims_cd = [286, 256, 256, 256, 256, 3]
+    for i in range(5):
+        w, b = _linear_default(rs, dims_cd[i + 1], dims_cd[i])
+        sd[f"net_cd.{2 * i}.weight"], sd[f"net_cd.{2 * i}.bias"] = _f32(w), _f32(b)
+    dims_vm = [289, 256, 256, 256, 256]
+    for i in range(4):
+        # NB the reference builds four LazyLinear(256); layers 1..3 therefore take 256 inputs (fields.py:295-297)
+        w, b = _linear_default(rs, dims_vm[i + 1], dims_vm[i])
+        sd[f"viewdir_mlp.{i}.weight"], sd[f"viewdir_mlp.{i}.bias"] = _f32(w), _f32(b)
+    w, b = _linear_default(rs, 1, 256)
+    sd["net_cs.0.weight"], sd["net_cs.0.bias"] = _f32(w), _f32(b)
+    return sd
+
+
+def nerf_state_dict(seed: int = 3, D=8, W=256, input_ch=84, input_ch_view=27) -> "OrderedDict[str, np.ndarray]":
+    """NeRF (fields.py:178-231) with use_viewdirs=True, skips=[4]."""
+    rs = np.random.RandomState(seed)
+    sd = OrderedDict()
+    for i in range(D):
+        in_dim = input_ch if i == 0 else (W + input_ch if (i - 1) == 4 else W)
+        w, b = _linear_default(rs, W, in_dim)
+        sd[f"pts_linears.{i}.weight"], sd[f"pts_linears.{i}.bias"] = _f32(w), _f32(b)
+    w, b = _linear_default(rs, W // 2, input_ch_view + W)
+    sd["views_linears.0.weight"], sd["views_linears.0.bias"] = _f32(w), _f32(b)
+    w, b = _linear_default(rs, W, W)
+    sd["feature_linear.weight"], sd["feature_linear.bias"] = _f32(w), _f32(b)
+    w, b = _linear_default(rs, 1, W)
+    sd["alpha_linear.weight"], sd["alpha_linear.bias"] = _f32(w), _f32(b)
+    w, b = _linear_default(rs, 3, W // 2)
+    sd["rgb_linear.weight"], sd["rgb_linear.bias"] = _f32(w), _f32(b)
+    return sd
+
+
+def ray_batch(batch: int, seed: int = 0, radius: float = 2.8, half_extent: float = 0.4,
+              mask_prob: float = 0.7, n_miss: int = 0) -> np.ndarray:
+    """DTU-shaped batch [B,10] = rays_o(3), rays_d(3), rgb(3), mask(1) from ONE camera (dataset.py:133-151).
+
+    Camera centre uniform on the sphere of `radius`; pixel targets uniform in [-h,h]^3; the last `n_miss`
+    rays are aimed away from the unit sphere (they never enter it).
+    """
+    rs = np.random.RandomState(seed)
+    c = rs.standard_normal(3)
+    c = c / np.linalg.norm(c) * radius
+    tgt = rs.uniform(-half_extent, half_extent, size=(batch, 3))
+    if n_miss > 0:
+        tgt[-n_miss:] = c[None, :] * 0.5 + rs.uniform(1.5, 2.5, size=(n_miss, 3)) * np.sign(rs.standard_normal((n_miss, 3)))
+    d = tgt - c[None, :]
+    d = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rgb = rs.uniform(0, 1, size=(batch, 3))
+    mask = (rs.uniform(0, 1, size=(batch, 1)) < mask_prob).astype(np.float64)
+    o = np.broadcast_to(c[None, :], (batch, 3))
+    return _f32(np.concatenate([o, d, rgb, mask], axis=1))
