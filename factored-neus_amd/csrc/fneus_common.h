@@ -1,0 +1,72 @@
+// Common device helpers for the fneus HIP kernels (gfx950 / CDNA4 only).
+//
+// Data-flow convention of the fused MLP kernels ("transposed, wave-local" formulation):
+//   * one wavefront owns 32 ray-samples; sample index = lane & 31, lane half h = lane >> 5;
+//   * a dense layer computes Z^T[o][n] = sum_k W[o][k] * H^T[k][n] with v_mfma_f32_32x32x16_bf16:
+//       A operand = weight fragment (row = output feature, pre-packed on the device by pack.hip),
+//       B operand = activations   (k = input feature in registers, column = sample on the lane),
+//       C/D       = 32 output features x 32 samples, fp32;
+//   * the C/D layout (col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*h) lets the activated accumulator of
+//     output tile t feed the next layer's B operand for k-steps 2t and 2t+1 with NO cross-lane movement:
+//     k-slot (ks, h, j) holds feature phi(ks,h,j) = 16*ks + 8*(j>>2) + 4*h + (j&3); the weight packer applies
+//     the same permutation to the K index of every A fragment.
+//   * PREC = 1: plain bf16 operands (fast mode).  PREC = 3: every operand is split x = hi + lo (two bf16,
+//     17 significant bits) and a product is hi*hi + hi*lo + lo*hi with fp32 accumulation (parity mode).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define FN_DEV __device__ __forceinline__
+
+namespace fneus {
+
+constexpr float kBeta = 100.0f;                 // Softplus(beta=100), reference models/fields.py:72
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+// feature index held by k-slot (ks, h, j) of a B fragment / accumulator register mapping
+FN_DEV constexpr int phi(int ks, int h, int j) { return 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3); }
+// row (within a 32-row tile) held by accumulator register r of lane half h
+FN_DEV constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+FN_DEV float bf16_to_f32(__bf16 v) { return (float)v; }
+
+// x = hi + lo split (round-to-nearest-even both times)
+FN_DEV void split_bf16(float x, __bf16& hi, __bf16& lo) {
+    hi = (__bf16)x;
+    lo = (__bf16)(x - (float)hi);
+}
+
+template <int PREC>
+struct BFrag {
+    bf16x8 hi;
+    bf16x8 lo;   // unused when PREC == 1
+};
+
+FN_DEV f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+FN_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+FN_DEV float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+FN_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// softplus_beta(z) = max(z,0) + log(1 + exp(-beta|z|)) / beta      (== torch softplus incl. its threshold rule to fp32)
+FN_DEV float softplus100(float z) {
+    float e = fast_exp2(-fabsf(z) * (kBeta * kLog2e));
+    return fmaxf(z, 0.0f) + fast_log2(1.0f + e) * (kLn2 / kBeta);
+}
+// s = sigmoid(beta z) recovered from h = softplus_beta(z):  s = 1 - exp(-beta h)
+FN_DEV float sig_from_softplus(float h) { return 1.0f - fast_exp2(-h * (kBeta * kLog2e)); }
+
+FN_DEV float sigmoidf_acc(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// exchange with the other lane half (lane ^ 32)
+FN_DEV float xor32(float v) { return __shfl_xor(v, 32, 64); }
+
+}  // namespace fneus

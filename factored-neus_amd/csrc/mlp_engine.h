@@ -1,0 +1,262 @@
+// Wave-local fused-MLP building blocks (see fneus_common.h for the data-flow convention).
+#pragma once
+#include "fneus_common.h"
+#include "fneus_layout.h"
+
+namespace fneus {
+
+constexpr int kMaxKS = 19;   // widest layer input on the path: colour layer 0 (289 -> 19 k-steps)
+
+// acc[i] (tile T0+i) += sum_{ks<KS} A(ks, T0+i) * B(KS0 + ks)
+// A fragments: blob + off_{hi,lo} + ((ks*NT_TOTAL + t)*64 + lane)*16 bytes, streamed from L2 through a small
+// register ring: work is cut into stages of GT tiles of one k-step; stage s+D is requested before stage s is
+// multiplied, and a scheduling barrier per stage stops hipcc from hoisting every load of the layer (which spills).
+template <int PREC, int KS, int NT_TOTAL, int T0, int TN, int KS0 = 0>
+FN_DEV void dense(const unsigned char* __restrict__ blob, uint32_t off_hi, uint32_t off_lo,
+                  const BFrag<PREC> (&b)[kMaxKS], f32x16 (&acc)[TN], int lane) {
+    constexpr int GT = TN < 4 ? TN : 4;                 // tiles per stage
+    constexpr int NG = (TN + GT - 1) / GT;              // stages per k-step
+    constexpr int NS = KS * NG;                         // stages
+    constexpr int D = PREC == 3 ? 2 : 4;                // prefetch distance (stages)
+    const bf16x8* __restrict__ whi = reinterpret_cast<const bf16x8*>(blob + off_hi) + lane;
+    const bf16x8* __restrict__ wlo = reinterpret_cast<const bf16x8*>(blob + off_lo) + lane;
+    bf16x8 ah[D + 1][GT], al[D + 1][GT];
+#pragma unroll
+    for (int s = 0; s < D; ++s) {
+        if (s < NS) {
+#pragma unroll
+            for (int i = 0; i < GT; ++i) {
+                const int t = (s % NG) * GT + i;
+                if (t < TN) {
+                    const int f = ((s / NG) * NT_TOTAL + T0 + t) * 64;
+                    ah[s % (D + 1)][i] = whi[f];
+                    if constexpr (PREC == 3) al[s % (D + 1)][i] = wlo[f];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (s + D < NS) {
+#pragma unroll
+            for (int i = 0; i < GT; ++i) {
+                const int t = ((s + D) % NG) * GT + i;
+                if (t < TN) {
+                    const int f = (((s + D) / NG) * NT_TOTAL + T0 + t) * 64;
+                    ah[(s + D) % (D + 1)][i] = whi[f];
+                    if constexpr (PREC == 3) al[(s + D) % (D + 1)][i] = wlo[f];
+                }
+            }
+        }
+        const int ks = s / NG;
+#pragma unroll
+        for (int i = 0; i < GT; ++i) {
+            const int t = (s % NG) * GT + i;
+            if (t < TN) {
+                if constexpr (PREC == 3) {
+                    acc[t] = mfma32(al[s % (D + 1)][i], b[KS0 + ks].hi, acc[t]);
+                    acc[t] = mfma32(ah[s % (D + 1)][i], b[KS0 + ks].lo, acc[t]);
+                }
+                acc[t] = mfma32(ah[s % (D + 1)][i], b[KS0 + ks].hi, acc[t]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// accumulators <- packed fp32 vector in accumulator layout ([t][h][16])
+template <int NT_TOTAL, int T0, int TN>
+FN_DEV void load_accvec(const unsigned char* __restrict__ blob, uint32_t off, f32x16 (&acc)[TN], int lane) {
+    const f32x16* __restrict__ p = reinterpret_cast<const f32x16*>(blob + off);
+    const int h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) acc[i] = p[(T0 + i) * 2 + h];
+}
+
+template <int TN>
+FN_DEV void zero_acc(f32x16 (&acc)[TN]) {
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+}
+
+// accumulator tiles 0..TN-1 (after an elementwise map already applied in place) -> B fragments KS0.. (2 per tile)
+template <int PREC, int TN, int KS0 = 0>
+FN_DEV void acc_to_bfrag(const f32x16 (&acc)[TN], BFrag<PREC> (&b)[kMaxKS]) {
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = acc[t][8 * s + j];
+                if constexpr (PREC == 3) {
+                    __bf16 hi, lo;
+                    split_bf16(v, hi, lo);
+                    b[KS0 + 2 * t + s].hi[j] = hi;
+                    b[KS0 + 2 * t + s].lo[j] = lo;
+                } else {
+                    b[KS0 + 2 * t + s].hi[j] = (__bf16)v;
+                }
+            }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Row-major [N][LD] bf16 "stash" matrices (hi plane / lo plane) in accumulator-register order:
+// lane (n, h), tile t, register group g = reg>>2 holds 4 consecutive features 32t + 8g + 4h .. +3  -> one 8-byte access.
+// These matrices are the operands of the weight-gradient GEMM (dw_gemm.hip) and are read back by the chain kernels.
+// ---------------------------------------------------------------------------------------------------------
+template <int PREC, int TN>
+FN_DEV void store_stash(const f32x16 (&acc)[TN], __bf16* __restrict__ hi, __bf16* __restrict__ lo, int ld, long n,
+                        int h, bool valid, int col_limit) {
+    if (!valid) return;
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int col = 32 * t + 8 * g + 4 * h;
+            if (col >= col_limit) continue;   // col_limit is a multiple of 4 or handled by the caller
+            bf16x4 vh, vl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = acc[t][4 * g + e];
+                if constexpr (PREC == 3) {
+                    __bf16 a, b2;
+                    split_bf16(v, a, b2);
+                    vh[e] = a;
+                    vl[e] = b2;
+                } else {
+                    vh[e] = (__bf16)v;
+                }
+            }
+            *reinterpret_cast<bf16x4*>(hi + n * ld + col) = vh;
+            if constexpr (PREC == 3) *reinterpret_cast<bf16x4*>(lo + n * ld + col) = vl;
+        }
+}
+
+template <int PREC, int TN>
+FN_DEV void load_stash(f32x16 (&acc)[TN], const __bf16* __restrict__ hi, const __bf16* __restrict__ lo, int ld, long n,
+                       int h, int col_limit) {
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int col = 32 * t + 8 * g + 4 * h;
+            if (col >= col_limit) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[t][4 * g + e] = 0.0f;
+                continue;
+            }
+            const bf16x4 vh = *reinterpret_cast<const bf16x4*>(hi + n * ld + col);
+            if constexpr (PREC == 3) {
+                const bf16x4 vl = *reinterpret_cast<const bf16x4*>(lo + n * ld + col);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[t][4 * g + e] = (float)vh[e] + (float)vl[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[t][4 * g + e] = (float)vh[e];
+            }
+        }
+}
+
+// row-major fp32 [N][LD] store / load of accumulator tiles (4 consecutive floats per access)
+template <int TN>
+FN_DEV void store_f32(const f32x16 (&acc)[TN], float* __restrict__ dst, int ld, long n, int h, bool valid) {
+    if (!valid) return;
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[t][4 * g + e];
+            *reinterpret_cast<f32x4*>(dst + n * ld + 32 * t + 8 * g + 4 * h) = v;
+        }
+}
+
+template <int TN>
+FN_DEV void load_f32(f32x16 (&acc)[TN], const float* __restrict__ src, int ld, long n, int h) {
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + n * ld + 32 * t + 8 * g + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t][4 * g + e] = v[e];
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Positional encoding (reference models/embedder.py:23-36): feature order [x, sin(2^0 x), cos(2^0 x), ...]
+// pe[3 + 6k + c] = sin(2^k x_c), pe[3 + 6k + 3 + c] = cos(2^k x_c).  Accurate sincosf (parity <= 1e-6).
+// jc[f] = d pe[f] / d x_{f's coordinate}.
+// ---------------------------------------------------------------------------------------------------------
+template <int L, bool WITH_JAC>
+FN_DEV void posenc(const float (&x)[3], float (&pe)[3 + 6 * L], float (&jc)[3 + 6 * L]) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        pe[c] = x[c];
+        if constexpr (WITH_JAC) jc[c] = 1.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        const float f = (float)(1 << k);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float s, co;
+            sincosf(x[c] * f, &s, &co);
+            pe[3 + 6 * k + c] = s;
+            pe[3 + 6 * k + 3 + c] = co;
+            if constexpr (WITH_JAC) {
+                jc[3 + 6 * k + c] = f * co;
+                jc[3 + 6 * k + 3 + c] = -f * s;
+            }
+        }
+    }
+}
+
+// vector v[NF] (feature order) -> B fragments KS0.. in k-slot order (zero padded)
+template <int PREC, int NF, int KS, int KS0>
+FN_DEV void vec_to_bfrag(const float (&v)[NF], BFrag<PREC> (&b)[kMaxKS], int h) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int f0 = phi(ks, 0, j), f1 = phi(ks, 1, j);
+            const float a0 = f0 < NF ? v[f0 < NF ? f0 : 0] : 0.0f;
+            const float a1 = f1 < NF ? v[f1 < NF ? f1 : 0] : 0.0f;
+            const float val = h ? a1 : a0;
+            if constexpr (PREC == 3) {
+                __bf16 hi, lo;
+                split_bf16(val, hi, lo);
+                b[KS0 + ks].hi[j] = hi;
+                b[KS0 + ks].lo[j] = lo;
+            } else {
+                b[KS0 + ks].hi[j] = (__bf16)val;
+            }
+        }
+}
+
+// accumulator tiles (feature-in-register layout) -> plain feature-order vector v[NF] needs both lane halves;
+// instead the consumers below work on the accumulator layout directly:
+// sum over features of coef[f] * acc-feature f, features 32*t + acc_row(reg,h); returns this lane's partial
+// (caller adds the other half with xor32).
+template <int TN, int NF>
+FN_DEV float acc_dot_partial(const f32x16 (&acc)[TN], const float (&coef)[NF], int h) {
+    float s = 0.0f;
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f0 = 32 * t + acc_row(r, 0), f1 = 32 * t + acc_row(r, 1);
+            const float c0 = f0 < NF ? coef[f0 < NF ? f0 : 0] : 0.0f;
+            const float c1 = f1 < NF ? coef[f1 < NF ? f1 : 0] : 0.0f;
+            s = fmaf(h ? c1 : c0, acc[t][r], s);
+        }
+    return s;
+}
+
+}  // namespace fneus

@@ -1,0 +1,313 @@
+// SDF-network kernels (reference models/fields.py:74-111 SDFNetwork.forward/.sdf/.gradient and their autograd).
+//   K1 sdf_fwd        : PE -> 9 dense layers (Softplus beta=100) -> sdf                      (no-grad sampler path)
+//   K2 sdf_fwd_grad   : sdf, feature[256], normal = d sdf/dx (analytic reverse sweep) + bf16 stash for backward
+//   K3 sdf_bwd_chain  : double-backward chains (ascending + descending); writes the
+//                       operand matrices of the weight-gradient GEMM (dw_gemm.hip)
+// One wavefront = 32 samples, whole chain register resident; weights come pre-packed from pack.hip (L2 resident).
+#include "mlp_engine.h"
+#include "fneus_kernels.h"
+
+namespace fneus {
+
+FN_DEV void load_point(const PointSrc& s, long n, float (&x)[3]) {
+    if (s.pts) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) x[c] = s.pts[n * 3 + c];
+    } else {
+        const long ray = n / s.m;
+        const float t = s.t[n];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)   // mul then add, separately rounded, like torch (renderer.py:233, 428)
+            x[c] = __fadd_rn(s.rays_o[ray * 3 + c], __fmul_rn(s.rays_d[ray * 3 + c], t));
+    }
+}
+
+template <int TN>
+FN_DEV void softplus_inplace(f32x16 (&acc)[TN]) {
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = softplus100(acc[t][r]);
+}
+
+// ---- forward chain shared by K1/K2 -----------------------------------------------------------------------
+// On return acc9 holds z_8: tiles 0..7 = feature (natural order), tile 8 row 0 (reg 0 of lane half 0) = sdf.
+// If SDF_ONLY only tile 8 is computed (acc9[8]).  If STASH, H_{l+1} (l = 0..7) and PE are written.
+template <int PREC, bool SDF_ONLY, bool STASH>
+FN_DEV void sdf_forward_chain(const unsigned char* __restrict__ blob, const float (&pe)[39],
+                              BFrag<PREC> (&bf)[kMaxKS], f32x16 (&acc)[9], const SdfStash& st, long N, long n,
+                              int lane, bool valid) {
+    const int h = lane >> 5;
+    constexpr auto& LY = kSdfLayout;
+    BFrag<PREC> pef[3];
+    vec_to_bfrag<PREC, 39, 3, 0>(pe, bf, h);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pef[i] = bf[i];
+    if constexpr (STASH) {
+        if (valid) {   // PE rows [N][48]; lane half h writes k-step features phi(ks,h,*) -> 8-byte pieces
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const int col = 16 * ks + 8 * g + 4 * h;
+                    bf16x4 vh, vl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        vh[e] = bf[ks].hi[4 * g + e];
+                        if constexpr (PREC == 3) vl[e] = bf[ks].lo[4 * g + e];
+                    }
+                    *reinterpret_cast<bf16x4*>(st.pe_hi + n * 48 + col) = vh;
+                    if constexpr (PREC == 3) *reinterpret_cast<bf16x4*>(st.pe_lo + n * 48 + col) = vl;
+                }
+        }
+    }
+    f32x16(&a8)[8] = reinterpret_cast<f32x16(&)[8]>(acc);
+    // layer 0
+    load_accvec<8, 0, 8>(blob, LY.L[0].bias, a8, lane);
+    dense<PREC, 3, 8, 0, 8>(blob, LY.L[0].fwd_hi, LY.L[0].fwd_lo, bf, a8, lane);
+    softplus_inplace(a8);
+    if constexpr (STASH) store_stash<PREC, 8>(a8, st.h_hi, st.h_lo, 256, n, h, valid, 256);
+    acc_to_bfrag<PREC, 8>(a8, bf);
+    // layers 1, 2
+    for (int l = 1; l <= 2; ++l) {
+        load_accvec<8, 0, 8>(blob, LY.L[l].bias, a8, lane);
+        dense<PREC, 16, 8, 0, 8>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, bf, a8, lane);
+        softplus_inplace(a8);
+        if constexpr (STASH)
+            store_stash<PREC, 8>(a8, st.h_hi + (size_t)l * N * 256, st.h_lo + (size_t)l * N * 256, 256, n, h, valid, 256);
+        acc_to_bfrag<PREC, 8>(a8, bf);
+    }
+    // layer 3: 256 -> 217 (7 tiles); its output + PE is the input of layer 4 (skip connection, fields.py:83-84)
+    {
+        f32x16(&a7)[7] = reinterpret_cast<f32x16(&)[7]>(acc);
+        load_accvec<7, 0, 7>(blob, LY.L[3].bias, a7, lane);
+        dense<PREC, 16, 7, 0, 7>(blob, LY.L[3].fwd_hi, LY.L[3].fwd_lo, bf, a7, lane);
+        softplus_inplace(a7);
+        if constexpr (STASH)
+            store_stash<PREC, 7>(a7, st.h_hi + (size_t)3 * N * 256, st.h_lo + (size_t)3 * N * 256, 256, n, h, valid, 224);
+        acc_to_bfrag<PREC, 7>(a7, bf);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) bf[14 + i] = pef[i];
+    }
+    // layer 4 (17 k-steps; 1/sqrt2 folded into the pack)
+    load_accvec<8, 0, 8>(blob, LY.L[4].bias, a8, lane);
+    dense<PREC, 17, 8, 0, 8>(blob, LY.L[4].fwd_hi, LY.L[4].fwd_lo, bf, a8, lane);
+    softplus_inplace(a8);
+    if constexpr (STASH)
+        store_stash<PREC, 8>(a8, st.h_hi + (size_t)4 * N * 256, st.h_lo + (size_t)4 * N * 256, 256, n, h, valid, 256);
+    acc_to_bfrag<PREC, 8>(a8, bf);
+    // layers 5, 6, 7
+    for (int l = 5; l <= 7; ++l) {
+        load_accvec<8, 0, 8>(blob, LY.L[l].bias, a8, lane);
+        dense<PREC, 16, 8, 0, 8>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, bf, a8, lane);
+        softplus_inplace(a8);
+        if constexpr (STASH)
+            store_stash<PREC, 8>(a8, st.h_hi + (size_t)l * N * 256, st.h_lo + (size_t)l * N * 256, 256, n, h, valid, 256);
+        acc_to_bfrag<PREC, 8>(a8, bf);
+    }
+    // layer 8 (linear)
+    if constexpr (SDF_ONLY) {
+        f32x16(&a1)[1] = reinterpret_cast<f32x16(&)[1]>(acc[8]);
+        load_accvec<9, 8, 1>(blob, LY.L[8].bias, a1, lane);
+        dense<PREC, 16, 9, 8, 1>(blob, LY.L[8].fwd_hi, LY.L[8].fwd_lo, bf, a1, lane);
+    } else {
+        load_accvec<9, 0, 9>(blob, LY.L[8].bias, acc, lane);
+        dense<PREC, 16, 9, 0, 9>(blob, LY.L[8].fwd_hi, LY.L[8].fwd_lo, bf, acc, lane);
+    }
+}
+
+// ---- K1 ----------------------------------------------------------------------------------------------------
+template <int PREC>
+__global__ void __launch_bounds__(64, 1) sdf_fwd_kernel(const unsigned char* blob, PointSrc src, long N,
+                                                        float* __restrict__ sdf_out) {
+    const int lane = threadIdx.x;
+    const int r = lane & 31;
+    SdfStash st{};
+    for (long tile = blockIdx.x; tile * 32 < N; tile += gridDim.x) {
+        // launder the blob pointer: otherwise LICM hoists every statically addressed weight load out of the tile loop
+        // (hundreds of VGPRs -> scratch spills)
+        asm volatile("" : "+s"(blob));
+        const long n = tile * 32 + r;
+        const bool valid = n < N;
+        const long nc = valid ? n : N - 1;
+        float x[3], pe[39], jc[39];
+        load_point(src, nc, x);
+        posenc<6, false>(x, pe, jc);
+        BFrag<PREC> bf[kMaxKS];
+        f32x16 acc[9];
+        sdf_forward_chain<PREC, true, false>(blob, pe, bf, acc, st, N, nc, lane, valid);
+        if (valid && lane < 32) sdf_out[n] = acc[8][0];
+    }
+}
+
+// ---- K2 ----------------------------------------------------------------------------------------------------
+// g[t] *= s where s = sigmoid(beta z_l) recovered from the stashed h_{l+1}
+template <int PREC, int TN>
+FN_DEV void mul_sig_from_stash(f32x16 (&g)[TN], const __bf16* __restrict__ hi, const __bf16* __restrict__ lo, long n, int h) {
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = 32 * t + 8 * q + 4 * h;
+            const bf16x4 vh = *reinterpret_cast<const bf16x4*>(hi + n * 256 + col);
+            bf16x4 vl;
+            if constexpr (PREC == 3) vl = *reinterpret_cast<const bf16x4*>(lo + n * 256 + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float hv = (float)vh[e];
+                if constexpr (PREC == 3) hv += (float)vl[e];
+                g[t][4 * q + e] *= sig_from_softplus(hv);
+            }
+        }
+}
+
+template <int PREC, bool TRAIN>
+__global__ void __launch_bounds__(64, 1) sdf_fwd_grad_kernel(const unsigned char* blob, PointSrc src, long N,
+                                                             SdfStash st, float* __restrict__ sdf_out,
+                                                             float* __restrict__ feat_out, float* __restrict__ normal_out) {
+    const int lane = threadIdx.x;
+    const int r = lane & 31, h = lane >> 5;
+    constexpr auto& LY = kSdfLayout;
+    for (long tile = blockIdx.x; tile * 32 < N; tile += gridDim.x) {
+        // launder the blob pointer: otherwise LICM hoists every statically addressed weight load out of the tile loop
+        // (hundreds of VGPRs -> scratch spills)
+        asm volatile("" : "+s"(blob));
+        const long n = tile * 32 + r;
+        const bool valid = n < N;
+        const long nc = valid ? n : N - 1;
+        float x[3], pe[39], jc[39];
+        load_point(src, nc, x);
+        posenc<6, true>(x, pe, jc);
+        BFrag<PREC> bf[kMaxKS];
+        f32x16 acc[9];
+        sdf_forward_chain<PREC, false, true>(blob, pe, bf, acc, st, N, nc, lane, valid);
+        if (valid && lane < 32) sdf_out[n] = acc[8][0];
+        {
+            f32x16(&a8)[8] = reinterpret_cast<f32x16(&)[8]>(acc);
+            store_f32<8>(a8, feat_out, 256, nc, h, valid);
+            if constexpr (TRAIN) store_stash<PREC, 8>(a8, st.feat_hi, st.feat_lo, 256, nc, h, valid, 256);
+        }
+        // ---- reverse sweep: g = d sdf / d u_l   ----
+        f32x16(&g8)[8] = reinterpret_cast<f32x16(&)[8]>(acc);
+        load_accvec<8, 0, 8>(blob, LY.extra, g8, lane);                      // g_hat(h_8) = row 0 of W_8
+        for (int l = 7; l >= 5; --l) {
+            mul_sig_from_stash<PREC, 8>(g8, st.h_hi + (size_t)l * N * 256, st.h_lo + (size_t)l * N * 256, nc, h);   // a_l
+            if constexpr (TRAIN)
+                store_stash<PREC, 8>(g8, st.a_hi + (size_t)l * N * 256, st.a_lo + (size_t)l * N * 256, 256, nc, h, valid, 256);
+            acc_to_bfrag<PREC, 8>(g8, bf);
+            zero_acc(g8);
+            dense<PREC, 16, 8, 0, 8>(blob, LY.L[l].rev_hi, LY.L[l].rev_lo, bf, g8, lane);
+        }
+        // layer 4: outputs 9 row tiles: 0..6 -> g_hat(h_4), 7..8 -> q_skip (PE part of the skip input)
+        f32x16 qskip[2];
+        {
+            mul_sig_from_stash<PREC, 8>(g8, st.h_hi + (size_t)4 * N * 256, st.h_lo + (size_t)4 * N * 256, nc, h);
+            if constexpr (TRAIN)
+                store_stash<PREC, 8>(g8, st.a_hi + (size_t)4 * N * 256, st.a_lo + (size_t)4 * N * 256, 256, nc, h, valid, 256);
+            acc_to_bfrag<PREC, 8>(g8, bf);
+            zero_acc(acc);
+            dense<PREC, 16, 9, 0, 9>(blob, LY.L[4].rev_hi, LY.L[4].rev_lo, bf, acc, lane);
+            qskip[0] = acc[7];
+            qskip[1] = acc[8];
+        }
+        // layer 3 (7 tiles of outputs -> 14 k-steps)
+        {
+            f32x16(&g7)[7] = reinterpret_cast<f32x16(&)[7]>(acc);
+            mul_sig_from_stash<PREC, 7>(g7, st.h_hi + (size_t)3 * N * 256, st.h_lo + (size_t)3 * N * 256, nc, h);
+            if constexpr (TRAIN)
+                store_stash<PREC, 7>(g7, st.a_hi + (size_t)3 * N * 256, st.a_lo + (size_t)3 * N * 256, 256, nc, h, valid, 224);
+            acc_to_bfrag<PREC, 7>(g7, bf);
+            zero_acc(g8);
+            dense<PREC, 14, 8, 0, 8>(blob, LY.L[3].rev_hi, LY.L[3].rev_lo, bf, g8, lane);
+        }
+        for (int l = 2; l >= 1; --l) {
+            mul_sig_from_stash<PREC, 8>(g8, st.h_hi + (size_t)l * N * 256, st.h_lo + (size_t)l * N * 256, nc, h);
+            if constexpr (TRAIN)
+                store_stash<PREC, 8>(g8, st.a_hi + (size_t)l * N * 256, st.a_lo + (size_t)l * N * 256, 256, nc, h, valid, 256);
+            acc_to_bfrag<PREC, 8>(g8, bf);
+            zero_acc(g8);
+            dense<PREC, 16, 8, 0, 8>(blob, LY.L[l].rev_hi, LY.L[l].rev_lo, bf, g8, lane);
+        }
+        // layer 0: 2 row tiles (39 PE inputs)
+        f32x16 q[2];
+        {
+            mul_sig_from_stash<PREC, 8>(g8, st.h_hi, st.h_lo, nc, h);
+            if constexpr (TRAIN) store_stash<PREC, 8>(g8, st.a_hi, st.a_lo, 256, nc, h, valid, 256);
+            acc_to_bfrag<PREC, 8>(g8, bf);
+            zero_acc(q);
+            dense<PREC, 16, 2, 0, 2>(blob, LY.L[0].rev_hi, LY.L[0].rev_lo, bf, q, lane);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) q[t][rr] += qskip[t][rr];
+        }
+        // normal = J^T q
+        float nrm[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float coef[39];
+#pragma unroll
+            for (int f = 0; f < 39; ++f) coef[f] = ((f % 3) == c) ? jc[f] : 0.0f;
+            const float part = acc_dot_partial<2, 39>(q, coef, h);
+            nrm[c] = part + xor32(part);
+        }
+        if (valid && lane < 32) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) normal_out[n * 3 + c] = nrm[c];
+        }
+    }
+}
+
+}  // namespace fneus
+
+// ---------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------
+using namespace fneus;
+
+static inline int grid_for(long n_tiles) {
+    long g = n_tiles;
+    const long cap = 256 * 8;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+extern "C" int fneus_sdf_fwd(const void* blob, const float* pts, const float* rays_o, const float* rays_d,
+                             const float* t, int m, long n_pts, float* sdf_out, int prec, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_pts <= 0) return 0;
+    PointSrc src{pts, rays_o, rays_d, t, m > 0 ? m : 1};
+    const long tiles = (n_pts + 31) / 32;
+    const unsigned char* b = reinterpret_cast<const unsigned char*>(blob);
+    if (prec == 3)
+        hipLaunchKernelGGL(sdf_fwd_kernel<3>, dim3(grid_for(tiles)), dim3(64), 0, stream, b, src, n_pts, sdf_out);
+    else if (prec == 1)
+        hipLaunchKernelGGL(sdf_fwd_kernel<1>, dim3(grid_for(tiles)), dim3(64), 0, stream, b, src, n_pts, sdf_out);
+    else
+        return -2;
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+extern "C" int fneus_sdf_fwd_grad(const void* blob, const float* pts, const float* rays_o, const float* rays_d,
+                                  const float* t, int m, long n_pts, const FneusSdfStash* stash, float* sdf_out,
+                                  float* feat_out, float* normal_out, int prec, int train, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_pts <= 0) return 0;
+    PointSrc src{pts, rays_o, rays_d, t, m > 0 ? m : 1};
+    const long tiles = (n_pts + 31) / 32;
+    const unsigned char* b = reinterpret_cast<const unsigned char*>(blob);
+    SdfStash st = *stash;
+    dim3 grid(grid_for(tiles)), blk(64);
+    if (prec == 3 && train)
+        hipLaunchKernelGGL((sdf_fwd_grad_kernel<3, true>), grid, blk, 0, stream, b, src, n_pts, st, sdf_out, feat_out, normal_out);
+    else if (prec == 3)
+        hipLaunchKernelGGL((sdf_fwd_grad_kernel<3, false>), grid, blk, 0, stream, b, src, n_pts, st, sdf_out, feat_out, normal_out);
+    else if (prec == 1 && train)
+        hipLaunchKernelGGL((sdf_fwd_grad_kernel<1, true>), grid, blk, 0, stream, b, src, n_pts, st, sdf_out, feat_out, normal_out);
+    else if (prec == 1)
+        hipLaunchKernelGGL((sdf_fwd_grad_kernel<1, false>), grid, blk, 0, stream, b, src, n_pts, st, sdf_out, feat_out, normal_out);
+    else
+        return -2;
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

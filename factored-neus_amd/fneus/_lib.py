@@ -1,0 +1,81 @@
+"""ctypes binding of libfneus_hip.so (C ABI declared in include/fneus.h).
+
+The product path has no CPU / PyTorch fallback: if the shared library is missing or a symbol cannot be
+resolved, importing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfneus_hip.so")
+
+
+class FneusSdfStash(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("pe_hi", "pe_lo", "h_hi", "h_lo", "a_hi", "a_lo", "feat_hi", "feat_lo")]
+
+
+class FneusSdfBwdBufs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("qbar_hi", "qbar_lo", "adj_hi", "adj_lo", "zbar_hi", "zbar_lo", "cscratch")]
+
+
+class FneusColStash(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("side_hi", "side_lo", "u_hi", "u_lo", "zbar_hi", "zbar_lo")]
+
+
+class FneusGemmJob(C.Structure):
+    _fields_ = [("a_hi", C.c_void_p), ("a_lo", C.c_void_p), ("b_hi", C.c_void_p), ("b_lo", C.c_void_p),
+                ("a2_hi", C.c_void_p), ("a2_lo", C.c_void_p), ("b2_hi", C.c_void_p), ("b2_lo", C.c_void_p),
+                ("c", C.c_void_p), ("bias", C.c_void_p),
+                ("lda", C.c_int), ("ldb", C.c_int), ("lda2", C.c_int), ("ldb2", C.c_int), ("ldc", C.c_int),
+                ("m", C.c_int), ("n", C.c_int), ("a_col0", C.c_int), ("a2_mode", C.c_int),
+                ("scale", C.c_float), ("tile_base", C.c_int), ("pad", C.c_int)]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `make -C factored-neus_amd/csrc` (or __graft_entry__.build()). "
+            "The fneus product path has no fallback implementation.")
+    lib = C.CDLL(LIB_PATH)
+    vp, ip, f, l = C.c_void_p, C.c_int, C.c_float, C.c_long
+    sigs = {
+        "fneus_version": (C.c_int, []),
+        "fneus_last_error": (C.c_char_p, []),
+        "fneus_layout": (C.c_int, [ip, vp, ip]),
+        "fneus_pack": (C.c_int, [vp, ip, ip, vp, vp, vp, vp]),
+        "fneus_sdf_fwd": (C.c_int, [vp, vp, vp, vp, vp, ip, l, vp, ip, vp]),
+        "fneus_sdf_fwd_grad": (C.c_int, [vp, vp, vp, vp, vp, ip, l, C.POINTER(FneusSdfStash), vp, vp, vp, ip, ip, vp]),
+    }
+    optional = {
+        "fneus_sdf_bwd": (C.c_int, [vp, vp, vp, vp, vp, ip, l, C.POINTER(FneusSdfStash), C.POINTER(FneusSdfBwdBufs),
+                                    vp, vp, vp, ip, vp]),
+        "fneus_color_fwd": (C.c_int, [vp, vp, vp, vp, vp, ip, l, vp, vp, vp, C.POINTER(FneusColStash), vp, ip, ip, vp]),
+        "fneus_color_bwd": (C.c_int, [vp, l, vp, vp, C.POINTER(FneusColStash), vp, vp, ip, vp]),
+        "fneus_dw_gemm": (C.c_int, [vp, ip, ip, l, ip, vp]),
+        "fneus_upsample_step": (C.c_int, [vp, vp, vp, vp, vp, vp, ip, ip, ip, f, ip, vp, vp, vp, vp, vp]),
+        "fneus_merge_mid": (C.c_int, [vp, vp, ip, ip, ip, f, vp, vp, vp, vp]),
+        "fneus_composite_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, ip, ip, f, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "fneus_composite_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ip, ip, f, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    for name, (res, args) in optional.items():
+        if hasattr(lib, name):
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib.fneus_last_error()
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,182 @@
+"""Host-side description of the two packed MLPs: flat parameter layouts, index maps and pack-job tables.
+
+The device packer (csrc/pack.hip) is generic; everything network specific (skip connection, the 1/sqrt(2) fold,
+the row order of the last SDF layer, the input order of the colour network) lives in the index maps built here,
+once per process.  Geometry and blob offsets come from the library itself (fneus_layout), not from duplicated
+constants.
+
+Reference: SDFNetwork (models/fields.py:9-91), RenderingNetwork (models/fields.py:114-175).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import List
+
+import numpy as np
+
+from . import _lib
+
+PACK_FRAG, PACK_ACCVEC = 0, 1
+JOB_DTYPE = np.dtype([("kind", "<i4"), ("unit_base", "<i4"), ("dst_hi", "<u4"), ("dst_lo", "<u4"), ("src", "<u4"),
+                      ("ld", "<i4"), ("ks", "<i4"), ("nt", "<i4"), ("transposed", "<i4"), ("rowmap", "<u4"),
+                      ("kmap", "<u4"), ("scale", "<f4")])
+
+SDF_IN = [39, 256, 256, 256, 256, 256, 256, 256, 256]
+SDF_OUT = [256, 256, 256, 217, 256, 256, 256, 256, 257]
+COL_IN = [289, 256, 256, 256, 256]
+COL_OUT = [256, 256, 256, 256, 3]
+N_PE = 39          # SDF positional encoding width (multires 6)
+N_SIDE = 33        # colour-network inputs besides the feature: pts 3 + PE4(view) 27 + normal 3
+
+
+def phi(ks, h, j):
+    return 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3)
+
+
+def slot_features(ks_count):
+    """feature index held by k-slot kappa = 16*ks + 8*h + j"""
+    out = np.empty(ks_count * 16, dtype=np.int64)
+    for ks in range(ks_count):
+        for h in range(2):
+            for j in range(8):
+                out[16 * ks + 8 * h + j] = phi(ks, h, j)
+    return out
+
+
+@dataclass
+class Layout:
+    n_layers: int
+    total: int
+    extra: int
+    off: np.ndarray      # [L, 5] fwd_hi, fwd_lo, rev_hi, rev_lo, bias
+    geom: np.ndarray     # [L, 4] ksf, ntf, ksr, ntr
+
+
+def query_layout(which: int) -> Layout:
+    buf = (C.c_int32 * 256)()
+    n = _lib.lib.fneus_layout(which, buf, 256)
+    if n <= 0:
+        raise RuntimeError("fneus_layout failed")
+    a = np.frombuffer(buf, dtype=np.int32, count=n).copy()
+    L = int(a[0])
+    per = a[3:3 + 9 * L].reshape(L, 9)
+    return Layout(L, int(a[1]), int(a[2]), per[:, :5].copy(), per[:, 5:].copy())
+
+
+def flat_offsets(ins, outs):
+    """(offW, offb, total) of the flat fp32 parameter buffer: per layer W[out][in] then b[out]."""
+    offW, offb, o = [], [], 0
+    for i, k in zip(ins, outs):
+        offW.append(o)
+        o += i * k
+        offb.append(o)
+        o += k
+    return offW, offb, o
+
+
+class _Builder:
+    def __init__(self):
+        self.maps: List[np.ndarray] = []
+        self.n_map = 0
+        self.jobs = []
+        self.units = 0
+
+    def add_map(self, arr):
+        arr = np.asarray(arr, dtype=np.int32)
+        off = self.n_map
+        self.maps.append(arr)
+        self.n_map += arr.size
+        return off
+
+    def frag(self, dst_hi, dst_lo, src, ld, ks, nt, transposed, rowmap, kmap, scale=1.0):
+        assert len(rowmap) == nt * 32 and len(kmap) == ks * 16
+        self.jobs.append((PACK_FRAG, self.units, dst_hi, dst_lo, src, ld, ks, nt, transposed,
+                          self.add_map(rowmap), self.add_map(kmap), scale))
+        self.units += ks * nt
+
+    def accvec(self, dst, src, ld, nt, rowmap, scale=1.0):
+        assert len(rowmap) == nt * 32
+        self.jobs.append((PACK_ACCVEC, self.units, dst, 0, src, ld, 0, nt, 0, self.add_map(rowmap), 0, scale))
+        self.units += nt
+
+    def finish(self):
+        jobs = np.array(self.jobs, dtype=JOB_DTYPE)
+        maps = np.concatenate(self.maps).astype(np.int32)
+        return jobs, maps, self.units
+
+
+def _lim(idx, n):
+    idx = np.asarray(idx, dtype=np.int64)
+    return np.where(idx < n, idx, -1)
+
+
+def build_sdf_jobs():
+    ly = query_layout(0)
+    offW, offb, total = flat_offsets(SDF_IN, SDF_OUT)
+    b = _Builder()
+    inv_sqrt2 = 1.0 / math.sqrt(2.0)
+    for l in range(9):
+        ksf, ntf, ksr, ntr = [int(v) for v in ly.geom[l]]
+        fwd_hi, fwd_lo, rev_hi, rev_lo, bias = [int(v) for v in ly.off[l]]
+        n_in, n_out = SDF_IN[l], SDF_OUT[l]
+        scale = inv_sqrt2 if l == 4 else 1.0
+        # ---- forward: rows = outputs, k-slots = inputs
+        rows = np.arange(ntf * 32)
+        if l == 8:
+            rowmap = np.where(rows < 256, rows + 1, np.where(rows == 256, 0, -1))
+        else:
+            rowmap = _lim(rows, n_out)
+        feat = slot_features(ksf)
+        if l == 4:
+            kmap = np.where(feat < 224, _lim(feat, 217), np.where(feat - 224 < N_PE, 217 + (feat - 224), -1))
+        else:
+            kmap = _lim(feat, n_in)
+        b.frag(fwd_hi, fwd_lo, offW[l], n_in, ksf, ntf, 0, rowmap, kmap, scale)
+        # ---- reverse (A = W^T): rows = inputs, k-slots = outputs (accumulator order of a_l / zbar_l)
+        ofeat = slot_features(ksr)
+        if l == 8:
+            kmap_r = np.where(ofeat < 256, ofeat + 1, np.where(ofeat == 256, 0, -1))
+        else:
+            kmap_r = _lim(ofeat, n_out)
+        rin = np.arange(ntr * 32)
+        if l == 4:
+            rowmap_r = np.where(rin < 224, _lim(rin, 217), np.where(rin - 224 < N_PE, 217 + (rin - 224), -1))
+        else:
+            rowmap_r = _lim(rin, n_in)
+        b.frag(rev_hi, rev_lo, offW[l], n_in, ksr, ntr, 1, rowmap_r, kmap_r, scale)
+        b.accvec(bias, offb[l], 1, ntf, rowmap)
+    # row 0 of the last layer in accumulator layout: g_hat(h_8) of the reverse sweep
+    b.accvec(ly.extra, offW[8], 1, 8, np.arange(256))
+    jobs, maps, units = b.finish()
+    return {"layout": ly, "jobs": jobs, "maps": maps, "units": units, "n_params": total, "offW": offW, "offb": offb,
+            "ins": SDF_IN, "outs": SDF_OUT}
+
+
+def build_color_jobs():
+    ly = query_layout(1)
+    offW, offb, total = flat_offsets(COL_IN, COL_OUT)
+    b = _Builder()
+    for l in range(5):
+        ksf, ntf, ksr, ntr = [int(v) for v in ly.geom[l]]
+        fwd_hi, fwd_lo, rev_hi, rev_lo, bias = [int(v) for v in ly.off[l]]
+        n_in, n_out = COL_IN[l], COL_OUT[l]
+        rowmap = _lim(np.arange(ntf * 32), n_out)
+        feat = slot_features(ksf)
+        if l == 0:   # k-slots: 256 feature slots first, then the 33 side inputs (reference column order: side | feature)
+            kmap = np.where(feat < 256, feat + N_SIDE, np.where(feat - 256 < N_SIDE, feat - 256, -1))
+        else:
+            kmap = _lim(feat, n_in)
+        b.frag(fwd_hi, fwd_lo, offW[l], n_in, ksf, ntf, 0, rowmap, kmap)
+        kmap_r = _lim(slot_features(ksr), n_out)
+        rin = np.arange(ntr * 32)
+        if l == 0:
+            rowmap_r = np.where(rin < 256, rin + N_SIDE, np.where(rin - 256 < N_SIDE, rin - 256, -1))
+        else:
+            rowmap_r = _lim(rin, n_in)
+        b.frag(rev_hi, rev_lo, offW[l], n_in, ksr, ntr, 1, rowmap_r, kmap_r)
+        b.accvec(bias, offb[l], 1, ntf, rowmap)
+    jobs, maps, units = b.finish()
+    return {"layout": ly, "jobs": jobs, "maps": maps, "units": units, "n_params": total, "offW": offW, "offb": offb,
+            "ins": COL_IN, "outs": COL_OUT}

@@ -1,0 +1,68 @@
+/* fneus.h -- C ABI of libfneus_hip.so: the MI355X (gfx950) implementation of the Factored-NeuS stage-1
+ * volume-rendering hot path.
+ *
+ * The reference (yiqun-wang/Factored-NeuS) has no FFI / operator registry: its hot path is eager PyTorch behind
+ * the Python class API  models.renderer.NeuSRenderer  (renderer.py:80-500) and  models.fields.*  (fields.py).
+ * Each entry point below replaces one group of reference ATen op sequences (cited per function); the Python host
+ * side (factored-neus_amd/models/, factored-neus_amd/fneus/) binds them with ctypes and keeps the reference's class
+ * API.  INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless noted; the caller owns all memory (no allocation inside);
+ *   - `stream` is a hipStream_t (passed as void*); kernels are enqueued, never synchronised;
+ *   - return 0 = ok, <0 = error (-1 launch failure, -2 bad argument);  fneus_last_error() gives a message;
+ *   - `prec` selects the MFMA numerics: 1 = bf16 operands (fast), 3 = split-bf16 x3 (hi*hi+hi*lo+lo*hi, ~fp32
+ *     parity mode); accumulation is always fp32;
+ *   - network "blobs" are produced by fneus_pack() from flat fp32 parameter buffers (natural layout:
+ *     per layer W[out][in] row-major then b[out]) according to a job table built by the host.
+ *   - points can be given explicitly (`pts` [n][3]) or as rays: p = rays_o[n/m] + rays_d[n/m] * t[n]  (pts == NULL).
+ */
+#ifndef FNEUS_H
+#define FNEUS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* fneus_stream_t; /* hipStream_t */
+
+/* bf16 planes of the activation stash written by fneus_sdf_fwd_grad and consumed by the backward kernels.
+ * All matrices are row-major, one row per sample.  *_lo planes are only touched when prec == 3. */
+typedef struct FneusSdfStash {
+    uint16_t* pe_hi;   uint16_t* pe_lo;   /* [N][48]      positional encoding (cols >= 39 zero)            */
+    uint16_t* h_hi;    uint16_t* h_lo;    /* [8][N][256]  slot l = softplus output of layer l (= input of l+1) */
+    uint16_t* a_hi;    uint16_t* a_lo;    /* [8][N][256]  slot l = a_l = sigma'(z_l) * d sdf/d h_{l+1}      */
+    uint16_t* feat_hi; uint16_t* feat_lo; /* [N][256]     feature vector (colour-network input)             */
+} FneusSdfStash;
+
+/* ---- library ------------------------------------------------------------------------------------------------ */
+int fneus_version(void);                 /* 100*major + minor */
+const char* fneus_last_error(void);      /* host pointer, static storage */
+
+/* Blob geometry, so the host needs no duplicated constants.  which: 0 = SDF network, 1 = colour network.
+ * out[0] = n_layers, out[1] = total blob bytes, out[2] = extra offset, then per layer 9 ints:
+ * fwd_hi, fwd_lo, rev_hi, rev_lo, bias (byte offsets), ksf, ntf, ksr, ntr.  Returns number of ints written. */
+int fneus_layout(int which, int32_t* out, int cap);
+
+/* ---- weight packing (every optimiser step) --------------------------------------------------------------- */
+/* jobs: device array of PackJob (csrc/fneus_pack.h), maps: device int32 index maps, params: flat fp32 parameters. */
+int fneus_pack(const void* jobs, int n_jobs, int n_units, const int32_t* maps, const float* params, void* blob,
+               fneus_stream_t stream);
+
+/* ---- K1: SDFNetwork.sdf under no_grad  (fields.py:93-95 via renderer.py:199, 430, 515) -------------------- */
+int fneus_sdf_fwd(const void* sdf_blob, const float* pts, const float* rays_o, const float* rays_d, const float* t,
+                  int m, long n_pts, float* sdf_out /*[n]*/, int prec, fneus_stream_t stream);
+
+/* ---- K2: SDFNetwork.forward + SDFNetwork.gradient  (fields.py:74-111 via renderer.py:238-242) ------------- */
+/* train != 0 additionally writes the a_l / feature planes needed by fneus_sdf_bwd. */
+int fneus_sdf_fwd_grad(const void* sdf_blob, const float* pts, const float* rays_o, const float* rays_d,
+                       const float* t, int m, long n_pts, const FneusSdfStash* stash /*host struct*/,
+                       float* sdf_out /*[n]*/, float* feat_out /*[n][256]*/, float* normal_out /*[n][3]*/, int prec,
+                       int train, fneus_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FNEUS_H */

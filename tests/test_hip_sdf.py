@@ -1,0 +1,84 @@
+"""GPU parity: SDF-network kernels (K1 sdf_fwd, K2 sdf_fwd_grad) vs the CPU oracle, through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope="module")
+def env():
+    from fneus import ops, synth
+    from oracle import ref_torch as R
+    dev = torch.device("cuda:0")
+    sd = {k: T(v) for k, v in synth.sdf_state_dict(20).items()}
+    p = R.sdf_params_from_state_dict(sd)
+    net = ops.PackedNet("sdf", dev)
+    flat = net.flat_from_lists([w.to(dev) for w in p["W"]], [b.to(dev) for b in p["b"]]).contiguous()
+    net.pack(flat)
+    rs = np.random.RandomState(7)
+    x = rs.uniform(-1.1, 1.1, size=(1000, 3)).astype(np.float32)   # 1000: not a multiple of 32
+    x[0] = 0.0
+    return dict(ops=ops, R=R, dev=dev, p=p, net=net, x=T(x))
+
+
+# tolerance (abs): parity mode prec=3 must meet the 1e-4 bar of BASELINE.json north_star; fast mode is reported
+@pytest.mark.parametrize("prec,tol", [(3, 1e-4), (1, 5e-2)])
+def test_sdf_fwd(env, prec, tol):
+    ops, R = env["ops"], env["R"]
+    x = env["x"]
+    ref = R.sdf_only(x.double(), {"W": [w.double() for w in env["p"]["W"]], "b": [b.double() for b in env["p"]["b"]],
+                                  "scale": 1.0})[:, 0]
+    out = ops.sdf_fwd(env["net"].blob, x.shape[0], prec, pts=x.to(env["dev"]).contiguous())
+    err = (out.cpu().double() - ref).abs().max().item()
+    print(f"sdf_fwd prec={prec} max abs err {err:.3e}")
+    assert err <= tol
+
+
+def test_sdf_fwd_ray_mode(env):
+    ops, R = env["ops"], env["R"]
+    dev = env["dev"]
+    rs = np.random.RandomState(3)
+    B, m = 37, 24
+    o = T(rs.uniform(-0.5, 0.5, size=(B, 3)).astype(np.float32))
+    d = T(rs.standard_normal((B, 3)).astype(np.float32))
+    d = d / d.norm(dim=-1, keepdim=True)
+    t = T(np.sort(rs.uniform(0, 1.0, size=(B, m)).astype(np.float32), axis=1))
+    pts = (o[:, None, :] + d[:, None, :] * t[..., None]).reshape(-1, 3)
+    ref = R.sdf_only(pts, env["p"])[:, 0]
+    out = ops.sdf_fwd(env["net"].blob, B * m, 3, rays_o=o.to(dev), rays_d=d.to(dev), t=t.to(dev).reshape(-1), m=m)
+    assert (out.cpu() - ref).abs().max().item() <= 1e-4
+
+
+@pytest.mark.parametrize("prec,tol", [(3, 1e-4), (1, 1e-1)])
+def test_sdf_fwd_grad(env, prec, tol):
+    ops, R = env["ops"], env["R"]
+    x = env["x"]
+    p64 = {"W": [w.double() for w in env["p"]["W"]], "b": [b.double() for b in env["p"]["b"]], "scale": 1.0}
+    sdf_r, feat_r, nrm_r, aux = R.sdf_value_feature_normal(x.double(), p64)
+    n = x.shape[0]
+    stash = ops.SdfStash(n, env["dev"], prec, train=True)
+    sdf, feat, nrm = ops.sdf_fwd_grad(env["net"].blob, n, prec, stash, True, pts=x.to(env["dev"]).contiguous())
+    e_sdf = (sdf.cpu().double() - sdf_r[:, 0]).abs().max().item()
+    e_feat = (feat.cpu().double() - feat_r).abs().max().item()
+    e_nrm = (nrm.cpu().double() - nrm_r).abs().max().item()
+    print(f"sdf_fwd_grad prec={prec}: sdf {e_sdf:.3e} feat {e_feat:.3e} normal {e_nrm:.3e}")
+    assert e_sdf <= tol and e_feat <= tol and e_nrm <= tol
+    # stash planes are the operands of the weight-gradient GEMM: check them against the oracle's intermediates
+    stol = 2e-5 if prec == 3 else 2e-2
+    h = stash.plane(stash.h).cpu().double()
+    a = stash.plane(stash.a).cpu().double()
+    for l in range(8):
+        width = 217 if l == 3 else 256
+        h_ref = torch.nn.functional.softplus(aux["z"][l], beta=100)
+        assert (h[l][:, :width] - h_ref[:, :width]).abs().max().item() <= stol * 10, f"h{l}"
+        assert (a[l][:, :width] - aux["a"][l][:, :width]).abs().max().item() <= stol * 10, f"a{l}"
+    pe = stash.plane(stash.pe).cpu().double()
+    assert (pe[:, :39] - aux["h0"]).abs().max().item() <= stol
+    assert pe[:, 39:].abs().max().item() == 0.0
+    f = stash.plane(stash.feat).cpu().double()
+    assert (f - feat_r).abs().max().item() <= stol * 10
