@@ -1,0 +1,235 @@
+// Colour-network kernels (reference models/fields.py:150-175 RenderingNetwork.forward, mode 'idr', and its autograd):
+//   K4 color_fwd : [pts3 | PE4(view)27 | normal3 | feature256] -> 4 x (Linear 256 + ReLU) -> Linear 3 -> sigmoid
+//   K4 color_bwd : descending chain; returns d feature, d normal and writes the weight-gradient GEMM operands
+// Same wave-local MFMA engine as the SDF kernels.  K-slot order of layer 0: 256 feature slots, then the 33 "side"
+// inputs in the reference's column order (pts, PE(view), normal).
+#include "mlp_engine.h"
+#include "fneus_kernels.h"
+
+namespace fneus {
+
+template <int TN>
+FN_DEV void relu_inplace(f32x16 (&acc)[TN]) {
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = fmaxf(acc[t][r], 0.0f);
+}
+
+// value of feature `idx` (compile-time) of an accumulator-layout vector, valid in every lane of the sample pair
+template <int TN, int IDX>
+FN_DEV float acc_extract(const f32x16 (&acc)[TN], int h) {
+    constexpr int t = IDX / 32, row = IDX % 32;
+    constexpr int hh = (row >> 2) & 1;
+    constexpr int reg = (row & 3) + 4 * (row >> 3);
+    static_assert(acc_row(reg, hh) == row, "accumulator row mapping");
+    const float v = (h == hh) ? acc[t][reg] : 0.0f;
+    return v + xor32(v);
+}
+
+template <int PREC, bool TRAIN>
+__global__ void __launch_bounds__(64, 1) color_fwd_kernel(const unsigned char* blob, PointSrc src, long N,
+                                                          const float* __restrict__ dirs,      // [N][3] or nullptr (ray mode)
+                                                          const float* __restrict__ normal,    // [N][3]
+                                                          const float* __restrict__ feat,      // [N][256]
+                                                          ColStash st, float* __restrict__ rgb_out) {
+    const int lane = threadIdx.x;
+    const int r = lane & 31, h = lane >> 5;
+    constexpr auto& LY = kColLayout;
+    for (long tile = blockIdx.x; tile * 32 < N; tile += gridDim.x) {
+        asm volatile("" : "+s"(blob));
+        const long n = tile * 32 + r;
+        const bool valid = n < N;
+        const long nc = valid ? n : N - 1;
+        float side[33];
+        {
+            float x[3], d[3], pe[27], jc[27];
+            load_point(src, nc, x);
+            if (dirs) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) d[c] = dirs[nc * 3 + c];
+            } else {
+                const long ray = nc / src.m;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) d[c] = src.rays_d[ray * 3 + c];
+            }
+            posenc<4, false>(d, pe, jc);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) side[c] = x[c];
+#pragma unroll
+            for (int f = 0; f < 27; ++f) side[3 + f] = pe[f];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) side[30 + c] = normal[nc * 3 + c];
+        }
+        BFrag<PREC> bf[kMaxKS];
+        f32x16 acc[8];
+        load_f32<8>(acc, feat, 256, nc, h);
+        acc_to_bfrag<PREC, 8>(acc, bf);
+        vec_to_bfrag<PREC, 33, 3, 16>(side, bf, h);
+        if constexpr (TRAIN) {
+            if (valid) {
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        const int col = 16 * ks + 8 * g + 4 * h;
+                        bf16x4 vh, vl;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            vh[e] = bf[16 + ks].hi[4 * g + e];
+                            if constexpr (PREC == 3) vl[e] = bf[16 + ks].lo[4 * g + e];
+                        }
+                        *reinterpret_cast<bf16x4*>(st.side_hi + nc * 48 + col) = vh;
+                        if constexpr (PREC == 3) *reinterpret_cast<bf16x4*>(st.side_lo + nc * 48 + col) = vl;
+                    }
+            }
+        }
+        // layer 0: 19 k-steps
+        load_accvec<8, 0, 8>(blob, LY.L[0].bias, acc, lane);
+        dense<PREC, 19, 8, 0, 8>(blob, LY.L[0].fwd_hi, LY.L[0].fwd_lo, bf, acc, lane);
+        relu_inplace(acc);
+        if constexpr (TRAIN) store_stash<PREC, 8>(acc, st.u_hi, st.u_lo, 256, nc, h, valid, 256);
+        acc_to_bfrag<PREC, 8>(acc, bf);
+        for (int l = 1; l <= 3; ++l) {
+            load_accvec<8, 0, 8>(blob, LY.L[l].bias, acc, lane);
+            dense<PREC, 16, 8, 0, 8>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, bf, acc, lane);
+            relu_inplace(acc);
+            if constexpr (TRAIN)
+                store_stash<PREC, 8>(acc, st.u_hi + (size_t)l * N * 256, st.u_lo + (size_t)l * N * 256, 256, nc, h, valid, 256);
+            acc_to_bfrag<PREC, 8>(acc, bf);
+        }
+        f32x16 o[1];
+        load_accvec<1, 0, 1>(blob, LY.L[4].bias, o, lane);
+        dense<PREC, 16, 1, 0, 1>(blob, LY.L[4].fwd_hi, LY.L[4].fwd_lo, bf, o, lane);
+        // rows 0..2 of the single output tile live in registers 0..2 of lane half 0
+        if (valid && lane < 32) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) rgb_out[n * 3 + c] = 1.0f / (1.0f + expf(-o[0][c]));   // fields.py:173-174
+        }
+    }
+}
+
+template <int PREC>
+__global__ void __launch_bounds__(64, 1) color_bwd_kernel(const unsigned char* blob, long N,
+                                                          const float* __restrict__ d_rgb,   // [N][3]
+                                                          const float* __restrict__ rgb,     // [N][3] forward output
+                                                          ColStash st, float* __restrict__ d_feat /*[N][256]*/,
+                                                          float* __restrict__ d_normal /*[N][3]*/) {
+    const int lane = threadIdx.x;
+    const int r = lane & 31, h = lane >> 5;
+    constexpr auto& LY = kColLayout;
+    for (long tile = blockIdx.x; tile * 32 < N; tile += gridDim.x) {
+        asm volatile("" : "+s"(blob));
+        const long n = tile * 32 + r;
+        const bool valid = n < N;
+        const long nc = valid ? n : N - 1;
+        BFrag<PREC> bf[kMaxKS];
+        f32x16 acc[10];
+        // zbar_4 = d rgb * sigmoid'  (3 rows of one tile)
+        {
+            f32x16 z[1];
+            zero_acc(z);
+            if (h == 0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float y = rgb[nc * 3 + c];
+                    z[0][c] = valid ? d_rgb[nc * 3 + c] * y * (1.0f - y) : 0.0f;
+                }
+            }
+            store_stash<PREC, 1>(z, st.zbar_hi + (size_t)4 * N * 256, st.zbar_lo + (size_t)4 * N * 256, 32, nc, h, valid, 32);
+            acc_to_bfrag<PREC, 1>(z, bf);
+        }
+        f32x16(&a8)[8] = reinterpret_cast<f32x16(&)[8]>(acc);
+        // layer 4 reverse: 2 k-steps -> 8 row tiles
+        zero_acc(a8);
+        dense<PREC, 2, 8, 0, 8>(blob, LY.L[4].rev_hi, LY.L[4].rev_lo, bf, a8, lane);
+        for (int l = 3; l >= 0; --l) {
+            // zbar_l = relu'(z_l) * ubar_{l+1};  relu mask from the stashed u_{l+1} = relu(z_l) (hi plane suffices: sign only)
+            {
+                const __bf16* uh = st.u_hi + (size_t)l * N * 256;
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bf16x4 v = *reinterpret_cast<const bf16x4*>(uh + nc * 256 + 32 * t + 8 * q + 4 * h);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            a8[t][4 * q + e] = ((float)v[e] > 0.0f && valid) ? a8[t][4 * q + e] : 0.0f;
+                    }
+            }
+            store_stash<PREC, 8>(a8, st.zbar_hi + (size_t)l * N * 256, st.zbar_lo + (size_t)l * N * 256, 256, nc, h, valid, 256);
+            acc_to_bfrag<PREC, 8>(a8, bf);
+            if (l > 0) {
+                zero_acc(a8);
+                dense<PREC, 16, 8, 0, 8>(blob, LY.L[l].rev_hi, LY.L[l].rev_lo, bf, a8, lane);
+            }
+        }
+        // layer 0 reverse: 10 row tiles (8 feature tiles + 2 side tiles)
+        zero_acc(acc);
+        dense<PREC, 16, 10, 0, 10>(blob, LY.L[0].rev_hi, LY.L[0].rev_lo, bf, acc, lane);
+        store_f32<8>(a8, d_feat, 256, nc, h, valid);
+        {
+            f32x16(&s2)[2] = reinterpret_cast<f32x16(&)[2]>(acc[8]);
+            const float g0 = acc_extract<2, 30>(s2, h), g1 = acc_extract<2, 31>(s2, h), g2 = acc_extract<2, 32>(s2, h);
+            if (valid && lane < 32) {
+                d_normal[n * 3 + 0] = g0;
+                d_normal[n * 3 + 1] = g1;
+                d_normal[n * 3 + 2] = g2;
+            }
+        }
+    }
+}
+
+}  // namespace fneus
+
+using namespace fneus;
+
+static inline int grid_for(long n_tiles) {
+    long g = n_tiles;
+    const long cap = 256 * 8;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+extern "C" int fneus_color_fwd(const void* blob, const float* pts, const float* rays_o, const float* rays_d,
+                               const float* t, int m, long n_pts, const float* dirs, const float* normal,
+                               const float* feat, const FneusColStash* stash, float* rgb_out, int prec, int train,
+                               fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_pts <= 0) return 0;
+    PointSrc src{pts, rays_o, rays_d, t, m > 0 ? m : 1};
+    if (!pts && !rays_d) return -2;
+    if (pts && !dirs && !rays_d) return -2;
+    const unsigned char* b = reinterpret_cast<const unsigned char*>(blob);
+    ColStash st = stash ? ColStash(*stash) : ColStash();
+    dim3 grid(grid_for((n_pts + 31) / 32)), blk(64);
+    if (prec == 3 && train)
+        hipLaunchKernelGGL((color_fwd_kernel<3, true>), grid, blk, 0, stream, b, src, n_pts, dirs, normal, feat, st, rgb_out);
+    else if (prec == 3)
+        hipLaunchKernelGGL((color_fwd_kernel<3, false>), grid, blk, 0, stream, b, src, n_pts, dirs, normal, feat, st, rgb_out);
+    else if (prec == 1 && train)
+        hipLaunchKernelGGL((color_fwd_kernel<1, true>), grid, blk, 0, stream, b, src, n_pts, dirs, normal, feat, st, rgb_out);
+    else if (prec == 1)
+        hipLaunchKernelGGL((color_fwd_kernel<1, false>), grid, blk, 0, stream, b, src, n_pts, dirs, normal, feat, st, rgb_out);
+    else
+        return -2;
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+extern "C" int fneus_color_bwd(const void* blob, long n_pts, const float* d_rgb, const float* rgb,
+                               const FneusColStash* stash, float* d_feat, float* d_normal, int prec,
+                               fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_pts <= 0) return 0;
+    const unsigned char* b = reinterpret_cast<const unsigned char*>(blob);
+    ColStash st(*stash);
+    dim3 grid(grid_for((n_pts + 31) / 32)), blk(64);
+    if (prec == 3)
+        hipLaunchKernelGGL(color_bwd_kernel<3>, grid, blk, 0, stream, b, n_pts, d_rgb, rgb, st, d_feat, d_normal);
+    else if (prec == 1)
+        hipLaunchKernelGGL(color_bwd_kernel<1>, grid, blk, 0, stream, b, n_pts, d_rgb, rgb, st, d_feat, d_normal);
+    else
+        return -2;
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

@@ -24,6 +24,42 @@ struct SdfStash {
           a_hi((__bf16*)s.a_hi), a_lo((__bf16*)s.a_lo), feat_hi((__bf16*)s.feat_hi), feat_lo((__bf16*)s.feat_lo) {}
 };
 
+struct SdfBwdBufs {
+    __bf16* qbar_hi; __bf16* qbar_lo;   // [N][48]      adj_0 = J nbar
+    __bf16* adj_hi;  __bf16* adj_lo;    // [8][N][256]  slot l = adj_{l+1}  (slot 3: 224 valid columns)
+    __bf16* zbar_hi; __bf16* zbar_lo;   // [9][N][256]  slot l = zbar_l     (slot 8: feature rows of the last layer)
+    __bf16* zsdf_hi; __bf16* zsdf_lo;   // [N][32]      column 0 = dL/dsdf  (sdf row of the last layer)
+    f32x4* cscratch;                    // [tiles][8][32][64] fp32x4 coupling terms (lane-private layout)
+    SdfBwdBufs() = default;
+    SdfBwdBufs(const FneusSdfBwdBufs& s)
+        : qbar_hi((__bf16*)s.qbar_hi), qbar_lo((__bf16*)s.qbar_lo), adj_hi((__bf16*)s.adj_hi), adj_lo((__bf16*)s.adj_lo),
+          zbar_hi((__bf16*)s.zbar_hi), zbar_lo((__bf16*)s.zbar_lo), zsdf_hi((__bf16*)s.zsdf_hi),
+          zsdf_lo((__bf16*)s.zsdf_lo), cscratch((f32x4*)s.cscratch) {}
+};
+
+struct ColStash {
+    __bf16* side_hi; __bf16* side_lo;   // [N][48]      pts | PE4(view) | normal (cols >= 33 zero)
+    __bf16* u_hi;    __bf16* u_lo;      // [4][N][256]  slot l = relu output of layer l (= input of l+1)
+    __bf16* zbar_hi; __bf16* zbar_lo;   // [5][N][256]  slot l = dL/dz_l (slot 4 uses 32-wide rows)
+    ColStash() : side_hi(nullptr), side_lo(nullptr), u_hi(nullptr), u_lo(nullptr), zbar_hi(nullptr), zbar_lo(nullptr) {}
+    ColStash(const FneusColStash& s)
+        : side_hi((__bf16*)s.side_hi), side_lo((__bf16*)s.side_lo), u_hi((__bf16*)s.u_hi), u_lo((__bf16*)s.u_lo),
+          zbar_hi((__bf16*)s.zbar_hi), zbar_lo((__bf16*)s.zbar_lo) {}
+};
+
+FN_DEV void load_point(const PointSrc& s, long n, float (&x)[3]) {
+    if (s.pts) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) x[c] = s.pts[n * 3 + c];
+    } else {
+        const long ray = n / s.m;
+        const float t = s.t[n];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)   // mul then add, separately rounded, like torch (renderer.py:233, 428)
+            x[c] = __fadd_rn(s.rays_o[ray * 3 + c], __fmul_rn(s.rays_d[ray * 3 + c], t));
+    }
+}
+
 void set_last_error(const char* msg);
 
 }  // namespace fneus

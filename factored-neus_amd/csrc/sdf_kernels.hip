@@ -9,19 +9,6 @@
 
 namespace fneus {
 
-FN_DEV void load_point(const PointSrc& s, long n, float (&x)[3]) {
-    if (s.pts) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) x[c] = s.pts[n * 3 + c];
-    } else {
-        const long ray = n / s.m;
-        const float t = s.t[n];
-#pragma unroll
-        for (int c = 0; c < 3; ++c)   // mul then add, separately rounded, like torch (renderer.py:233, 428)
-            x[c] = __fadd_rn(s.rays_o[ray * 3 + c], __fmul_rn(s.rays_d[ray * 3 + c], t));
-    }
-}
-
 template <int TN>
 FN_DEV void softplus_inplace(f32x16 (&acc)[TN]) {
 #pragma unroll
@@ -258,6 +245,201 @@ __global__ void __launch_bounds__(64, 1) sdf_fwd_grad_kernel(const unsigned char
     }
 }
 
+// ---- K3 ----------------------------------------------------------------------------------------------------
+// Backward of (sdf, feature, normal) w.r.t. the SDF-network weights: the two chains of SURVEY.md Appendix A.
+//   ascending  (tangent of the reverse sweep): adj_0 = J nbar;  abar_l = W_l adj_l;  adj_{l+1} = s_l * abar_l;
+//               coupling c_l = beta (1 - s_l) a_l abar_l   (= softplus'' * g_hat * abar)
+//   descending (ordinary backprop):            zbar_8 = [fbar ; sbar];  ubar_l = W_l^T zbar_l;
+//               zbar_{l-1} = s_{l-1} * ubar_l + c_{l-1}
+// The operand matrices of dW_l = zbar_l^T u_l + a_l^T adj_l are written as bf16 planes for dw_gemm.hip.
+template <int PREC, int TN>
+FN_DEV void asc_post(f32x16 (&acc)[TN], const __bf16* __restrict__ hhi, const __bf16* __restrict__ hlo,
+                     const __bf16* __restrict__ ahi, const __bf16* __restrict__ alo, f32x4* __restrict__ cs, long n,
+                     int h, int lane) {
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = 32 * t + 8 * q + 4 * h;
+            const bf16x4 hv = *reinterpret_cast<const bf16x4*>(hhi + n * 256 + col);
+            const bf16x4 av = *reinterpret_cast<const bf16x4*>(ahi + n * 256 + col);
+            bf16x4 hl, al;
+            if constexpr (PREC == 3) {
+                hl = *reinterpret_cast<const bf16x4*>(hlo + n * 256 + col);
+                al = *reinterpret_cast<const bf16x4*>(alo + n * 256 + col);
+            }
+            f32x4 c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float hh = (float)hv[e], aa = (float)av[e];
+                if constexpr (PREC == 3) {
+                    hh += (float)hl[e];
+                    aa += (float)al[e];
+                }
+                const float one_minus_s = fast_exp2(-hh * (kBeta * kLog2e));
+                const float abar = acc[t][4 * q + e];
+                c[e] = kBeta * one_minus_s * aa * abar;
+                acc[t][4 * q + e] = (1.0f - one_minus_s) * abar;
+            }
+            cs[(t * 4 + q) * 64 + lane] = c;
+        }
+}
+
+template <int PREC, int TN>
+FN_DEV void desc_post(f32x16 (&acc)[TN], const __bf16* __restrict__ hhi, const __bf16* __restrict__ hlo,
+                      const f32x4* __restrict__ cs, long n, int h, int lane) {
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = 32 * t + 8 * q + 4 * h;
+            const bf16x4 hv = *reinterpret_cast<const bf16x4*>(hhi + n * 256 + col);
+            bf16x4 hl;
+            if constexpr (PREC == 3) hl = *reinterpret_cast<const bf16x4*>(hlo + n * 256 + col);
+            const f32x4 c = cs[(t * 4 + q) * 64 + lane];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float hh = (float)hv[e];
+                if constexpr (PREC == 3) hh += (float)hl[e];
+                acc[t][4 * q + e] = sig_from_softplus(hh) * acc[t][4 * q + e] + c[e];
+            }
+        }
+}
+
+template <int PREC>
+__global__ void __launch_bounds__(64, 1) sdf_bwd_kernel(const unsigned char* blob, PointSrc src, long N, SdfStash st,
+                                                        SdfBwdBufs bb, const float* __restrict__ d_sdf,
+                                                        const float* __restrict__ d_feat,
+                                                        const float* __restrict__ d_normal) {
+    const int lane = threadIdx.x;
+    const int r = lane & 31, h = lane >> 5;
+    constexpr auto& LY = kSdfLayout;
+    const size_t LS = (size_t)N * 256;   // layer stride of the [L][N][256] planes
+    for (long tile = blockIdx.x; tile * 32 < N; tile += gridDim.x) {
+        asm volatile("" : "+s"(blob));
+        const long n = tile * 32 + r;
+        const bool valid = n < N;
+        const long nc = valid ? n : N - 1;
+        f32x4* cs = bb.cscratch + (size_t)tile * 8 * 32 * 64;
+        BFrag<PREC> bf[kMaxKS];
+        BFrag<PREC> qf[3];
+        f32x16 acc[9];
+        f32x16(&a8)[8] = reinterpret_cast<f32x16(&)[8]>(acc);
+        f32x16(&a7)[7] = reinterpret_cast<f32x16(&)[7]>(acc);
+        // ---- qbar = J nbar ----
+        {
+            float x[3], pe[39], jc[39], qb[39];
+            load_point(src, nc, x);
+            posenc<6, true>(x, pe, jc);
+            float nb[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) nb[c] = valid ? d_normal[nc * 3 + c] : 0.0f;
+#pragma unroll
+            for (int f = 0; f < 39; ++f) qb[f] = jc[f] * nb[f % 3];
+            vec_to_bfrag<PREC, 39, 3, 0>(qb, bf, h);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) qf[i] = bf[i];
+            if (valid) {
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        const int col = 16 * ks + 8 * g + 4 * h;
+                        bf16x4 vh, vl;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            vh[e] = bf[ks].hi[4 * g + e];
+                            if constexpr (PREC == 3) vl[e] = bf[ks].lo[4 * g + e];
+                        }
+                        *reinterpret_cast<bf16x4*>(bb.qbar_hi + nc * 48 + col) = vh;
+                        if constexpr (PREC == 3) *reinterpret_cast<bf16x4*>(bb.qbar_lo + nc * 48 + col) = vl;
+                    }
+            }
+        }
+        // ---- ascending chain ----
+        zero_acc(a8);
+        dense<PREC, 3, 8, 0, 8>(blob, LY.L[0].fwd_hi, LY.L[0].fwd_lo, bf, a8, lane);
+        asc_post<PREC, 8>(a8, st.h_hi, st.h_lo, st.a_hi, st.a_lo, cs, nc, h, lane);
+        store_stash<PREC, 8>(a8, bb.adj_hi, bb.adj_lo, 256, nc, h, valid, 256);
+        acc_to_bfrag<PREC, 8>(a8, bf);
+        for (int l = 1; l <= 2; ++l) {
+            zero_acc(a8);
+            dense<PREC, 16, 8, 0, 8>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, bf, a8, lane);
+            asc_post<PREC, 8>(a8, st.h_hi + l * LS, st.h_lo + l * LS, st.a_hi + l * LS, st.a_lo + l * LS,
+                              cs + (size_t)l * 32 * 64, nc, h, lane);
+            store_stash<PREC, 8>(a8, bb.adj_hi + l * LS, bb.adj_lo + l * LS, 256, nc, h, valid, 256);
+            acc_to_bfrag<PREC, 8>(a8, bf);
+        }
+        {
+            zero_acc(a7);
+            dense<PREC, 16, 7, 0, 7>(blob, LY.L[3].fwd_hi, LY.L[3].fwd_lo, bf, a7, lane);
+            asc_post<PREC, 7>(a7, st.h_hi + 3 * LS, st.h_lo + 3 * LS, st.a_hi + 3 * LS, st.a_lo + 3 * LS,
+                              cs + (size_t)3 * 32 * 64, nc, h, lane);
+            store_stash<PREC, 7>(a7, bb.adj_hi + 3 * LS, bb.adj_lo + 3 * LS, 256, nc, h, valid, 224);
+            acc_to_bfrag<PREC, 7>(a7, bf);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) bf[14 + i] = qf[i];
+        }
+        {
+            zero_acc(a8);
+            dense<PREC, 17, 8, 0, 8>(blob, LY.L[4].fwd_hi, LY.L[4].fwd_lo, bf, a8, lane);
+            asc_post<PREC, 8>(a8, st.h_hi + 4 * LS, st.h_lo + 4 * LS, st.a_hi + 4 * LS, st.a_lo + 4 * LS,
+                              cs + (size_t)4 * 32 * 64, nc, h, lane);
+            store_stash<PREC, 8>(a8, bb.adj_hi + 4 * LS, bb.adj_lo + 4 * LS, 256, nc, h, valid, 256);
+            acc_to_bfrag<PREC, 8>(a8, bf);
+        }
+        for (int l = 5; l <= 7; ++l) {
+            zero_acc(a8);
+            dense<PREC, 16, 8, 0, 8>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, bf, a8, lane);
+            asc_post<PREC, 8>(a8, st.h_hi + l * LS, st.h_lo + l * LS, st.a_hi + l * LS, st.a_lo + l * LS,
+                              cs + (size_t)l * 32 * 64, nc, h, lane);
+            store_stash<PREC, 8>(a8, bb.adj_hi + l * LS, bb.adj_lo + l * LS, 256, nc, h, valid, 256);
+            acc_to_bfrag<PREC, 8>(a8, bf);
+        }
+        // ---- descending chain ----
+        load_f32<8>(a8, d_feat, 256, nc, h);
+        if (!valid) zero_acc(a8);
+        zero_acc(reinterpret_cast<f32x16(&)[1]>(acc[8]));
+        if (h == 0 && valid) acc[8][0] = d_sdf[nc];
+        store_stash<PREC, 8>(a8, bb.zbar_hi + 8 * LS, bb.zbar_lo + 8 * LS, 256, nc, h, valid, 256);
+        store_stash<PREC, 1>(reinterpret_cast<f32x16(&)[1]>(acc[8]), bb.zsdf_hi, bb.zsdf_lo, 32, nc, h, valid, 32);
+        acc_to_bfrag<PREC, 9>(acc, bf);
+        zero_acc(a8);
+        dense<PREC, 18, 8, 0, 8>(blob, LY.L[8].rev_hi, LY.L[8].rev_lo, bf, a8, lane);
+        for (int l = 7; l >= 5; --l) {
+            // here a8 = ubar_{l+1} = hbar_{l+1};  zbar_l = s_l * hbar_{l+1} + c_l
+            desc_post<PREC, 8>(a8, st.h_hi + l * LS, st.h_lo + l * LS, cs + (size_t)l * 32 * 64, nc, h, lane);
+            store_stash<PREC, 8>(a8, bb.zbar_hi + l * LS, bb.zbar_lo + l * LS, 256, nc, h, valid, 256);
+            acc_to_bfrag<PREC, 8>(a8, bf);
+            zero_acc(a8);
+            dense<PREC, 16, 8, 0, 8>(blob, LY.L[l].rev_hi, LY.L[l].rev_lo, bf, a8, lane);
+        }
+        {   // zbar_4, then ubar_4 restricted to the h_4 rows (7 tiles of the 9-tile reverse pack)
+            desc_post<PREC, 8>(a8, st.h_hi + 4 * LS, st.h_lo + 4 * LS, cs + (size_t)4 * 32 * 64, nc, h, lane);
+            store_stash<PREC, 8>(a8, bb.zbar_hi + 4 * LS, bb.zbar_lo + 4 * LS, 256, nc, h, valid, 256);
+            acc_to_bfrag<PREC, 8>(a8, bf);
+            zero_acc(a7);
+            dense<PREC, 16, 9, 0, 7>(blob, LY.L[4].rev_hi, LY.L[4].rev_lo, bf, a7, lane);
+        }
+        {   // zbar_3 (7 tiles), ubar_3
+            desc_post<PREC, 7>(a7, st.h_hi + 3 * LS, st.h_lo + 3 * LS, cs + (size_t)3 * 32 * 64, nc, h, lane);
+            store_stash<PREC, 7>(a7, bb.zbar_hi + 3 * LS, bb.zbar_lo + 3 * LS, 256, nc, h, valid, 224);
+            acc_to_bfrag<PREC, 7>(a7, bf);
+            zero_acc(a8);
+            dense<PREC, 14, 8, 0, 8>(blob, LY.L[3].rev_hi, LY.L[3].rev_lo, bf, a8, lane);
+        }
+        for (int l = 2; l >= 1; --l) {
+            desc_post<PREC, 8>(a8, st.h_hi + l * LS, st.h_lo + l * LS, cs + (size_t)l * 32 * 64, nc, h, lane);
+            store_stash<PREC, 8>(a8, bb.zbar_hi + l * LS, bb.zbar_lo + l * LS, 256, nc, h, valid, 256);
+            acc_to_bfrag<PREC, 8>(a8, bf);
+            zero_acc(a8);
+            dense<PREC, 16, 8, 0, 8>(blob, LY.L[l].rev_hi, LY.L[l].rev_lo, bf, a8, lane);
+        }
+        desc_post<PREC, 8>(a8, st.h_hi, st.h_lo, cs, nc, h, lane);
+        store_stash<PREC, 8>(a8, bb.zbar_hi, bb.zbar_lo, 256, nc, h, valid, 256);
+    }
+}
+
 }  // namespace fneus
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -307,6 +489,26 @@ extern "C" int fneus_sdf_fwd_grad(const void* blob, const float* pts, const floa
         hipLaunchKernelGGL((sdf_fwd_grad_kernel<1, true>), grid, blk, 0, stream, b, src, n_pts, st, sdf_out, feat_out, normal_out);
     else if (prec == 1)
         hipLaunchKernelGGL((sdf_fwd_grad_kernel<1, false>), grid, blk, 0, stream, b, src, n_pts, st, sdf_out, feat_out, normal_out);
+    else
+        return -2;
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+extern "C" int fneus_sdf_bwd(const void* blob, const float* pts, const float* rays_o, const float* rays_d,
+                             const float* t, int m, long n_pts, const FneusSdfStash* stash, const FneusSdfBwdBufs* bufs,
+                             const float* d_sdf, const float* d_feat, const float* d_normal, int prec,
+                             fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_pts <= 0) return 0;
+    PointSrc src{pts, rays_o, rays_d, t, m > 0 ? m : 1};
+    const unsigned char* b = reinterpret_cast<const unsigned char*>(blob);
+    SdfStash st = *stash;
+    SdfBwdBufs bb = *bufs;
+    dim3 grid(grid_for((n_pts + 31) / 32)), blk(64);
+    if (prec == 3)
+        hipLaunchKernelGGL(sdf_bwd_kernel<3>, grid, blk, 0, stream, b, src, n_pts, st, bb, d_sdf, d_feat, d_normal);
+    else if (prec == 1)
+        hipLaunchKernelGGL(sdf_bwd_kernel<1>, grid, blk, 0, stream, b, src, n_pts, st, bb, d_sdf, d_feat, d_normal);
     else
         return -2;
     return hipGetLastError() == hipSuccess ? 0 : -1;

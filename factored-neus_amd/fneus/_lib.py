@@ -19,7 +19,7 @@ class FneusSdfStash(C.Structure):
 
 class FneusSdfBwdBufs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
-                ("qbar_hi", "qbar_lo", "adj_hi", "adj_lo", "zbar_hi", "zbar_lo", "cscratch")]
+                ("qbar_hi", "qbar_lo", "adj_hi", "adj_lo", "zbar_hi", "zbar_lo", "zsdf_hi", "zsdf_lo", "cscratch")]
 
 
 class FneusColStash(C.Structure):
@@ -32,8 +32,8 @@ class FneusGemmJob(C.Structure):
                 ("a2_hi", C.c_void_p), ("a2_lo", C.c_void_p), ("b2_hi", C.c_void_p), ("b2_lo", C.c_void_p),
                 ("c", C.c_void_p), ("bias", C.c_void_p),
                 ("lda", C.c_int), ("ldb", C.c_int), ("lda2", C.c_int), ("ldb2", C.c_int), ("ldc", C.c_int),
-                ("m", C.c_int), ("n", C.c_int), ("a_col0", C.c_int), ("a2_mode", C.c_int),
-                ("scale", C.c_float), ("tile_base", C.c_int), ("pad", C.c_int)]
+                ("m", C.c_int), ("n", C.c_int), ("a_w", C.c_int), ("a2_mode", C.c_int),
+                ("scale", C.c_float), ("tile_base", C.c_int), ("b_w", C.c_int)]
 
 
 def _load():

@@ -111,3 +111,156 @@ def sdf_fwd_grad(blob, n_pts: int, prec: int, stash: SdfStash, train: bool, pts=
                                  C.byref(stash.c), _ptr(sdf), _ptr(feat), _ptr(normal), prec, int(train), _stream()),
           "fneus_sdf_fwd_grad")
     return sdf, feat, normal
+
+
+# ------------------------------------------------------------------------------------------------------------
+# backward-side buffers and the weight-gradient GEMM
+# ------------------------------------------------------------------------------------------------------------
+class SdfBwdBufs:
+    def __init__(self, n: int, device, prec: int):
+        bf = torch.bfloat16
+        planes = 2 if prec == 3 else 1
+        self.qbar = torch.zeros((planes, n, 48), dtype=bf, device=device)
+        self.adj = torch.empty((planes, 8, n, 256), dtype=bf, device=device)
+        self.zbar = torch.empty((planes, 9, n, 256), dtype=bf, device=device)
+        self.zsdf = torch.zeros((planes, n, 32), dtype=bf, device=device)
+        self.cscratch = torch.empty(((n + 31) // 32) * 8 * 32 * 64 * 4, dtype=torch.float32, device=device)
+        s = _lib.FneusSdfBwdBufs()
+        for name, t in (("qbar", self.qbar), ("adj", self.adj), ("zbar", self.zbar), ("zsdf", self.zsdf)):
+            setattr(s, name + "_hi", t[0].data_ptr())
+            setattr(s, name + "_lo", t[1].data_ptr() if planes == 2 else None)
+        s.cscratch = self.cscratch.data_ptr()
+        self.c = s
+
+
+class ColStash:
+    def __init__(self, n: int, device, prec: int):
+        bf = torch.bfloat16
+        planes = 2 if prec == 3 else 1
+        self.side = torch.zeros((planes, n, 48), dtype=bf, device=device)
+        self.u = torch.empty((planes, 4, n, 256), dtype=bf, device=device)
+        self.zbar = torch.zeros((planes, 5, n, 256), dtype=bf, device=device)
+        s = _lib.FneusColStash()
+        for name, t in (("side", self.side), ("u", self.u), ("zbar", self.zbar)):
+            setattr(s, name + "_hi", t[0].data_ptr())
+            setattr(s, name + "_lo", t[1].data_ptr() if planes == 2 else None)
+        self.c = s
+
+
+def sdf_bwd(blob, n_pts, prec, stash: SdfStash, bufs: SdfBwdBufs, d_sdf, d_feat, d_normal, pts=None, rays_o=None,
+            rays_d=None, t=None, m: int = 1):
+    for x, nm in ((d_sdf, "d_sdf"), (d_feat, "d_feat"), (d_normal, "d_normal")):
+        _chk_f32(x, nm)
+    check(lib.fneus_sdf_bwd(_ptr(blob), _ptr(pts), _ptr(rays_o), _ptr(rays_d), _ptr(t), m, n_pts, C.byref(stash.c),
+                            C.byref(bufs.c), _ptr(d_sdf), _ptr(d_feat), _ptr(d_normal), prec, _stream()),
+          "fneus_sdf_bwd")
+
+
+def color_fwd(blob, n_pts, prec, normal, feat, stash: Optional[ColStash], train: bool, pts=None, rays_o=None,
+              rays_d=None, t=None, m: int = 1, dirs=None):
+    _chk_f32(normal, "normal")
+    _chk_f32(feat, "feat")
+    rgb = torch.empty(n_pts, 3, dtype=torch.float32, device=blob.device)
+    check(lib.fneus_color_fwd(_ptr(blob), _ptr(pts), _ptr(rays_o), _ptr(rays_d), _ptr(t), m, n_pts, _ptr(dirs),
+                              _ptr(normal), _ptr(feat), C.byref(stash.c) if stash is not None else None, _ptr(rgb),
+                              prec, int(train), _stream()), "fneus_color_fwd")
+    return rgb
+
+
+def color_bwd(blob, n_pts, prec, d_rgb, rgb, stash: ColStash):
+    _chk_f32(d_rgb, "d_rgb")
+    d_feat = torch.empty(n_pts, 256, dtype=torch.float32, device=blob.device)
+    d_normal = torch.empty(n_pts, 3, dtype=torch.float32, device=blob.device)
+    check(lib.fneus_color_bwd(_ptr(blob), n_pts, _ptr(d_rgb), _ptr(rgb), C.byref(stash.c), _ptr(d_feat),
+                              _ptr(d_normal), prec, _stream()), "fneus_color_bwd")
+    return d_feat, d_normal
+
+
+class GemmJobs:
+    """Device job table for fneus_dw_gemm.  Built once per (buffers, N); pointers refer to live stash tensors."""
+
+    def __init__(self, device):
+        self.jobs = []
+        self.tiles = 0
+        self.device = device
+        self.dev_table = None
+
+    @staticmethod
+    def _pl(t, plane, off=0):
+        """address of plane `plane` of a [planes, ...] bf16 tensor view + element offset"""
+        if t is None:
+            return None
+        if plane >= t.shape[0]:
+            return None
+        return t[plane].data_ptr() + 2 * off
+
+    def add(self, A, B, c_ptr, ldc, m, n, lda, ldb, a_w, b_w, A2=None, B2=None, lda2=0, ldb2=0, a2_mode=0,
+            bias_ptr=None, scale=1.0, a_off=0, b_off=0, a2_off=0, b2_off=0):
+        j = _lib.FneusGemmJob()
+        j.a_hi, j.a_lo = self._pl(A, 0, a_off), self._pl(A, 1, a_off)
+        j.b_hi, j.b_lo = self._pl(B, 0, b_off), self._pl(B, 1, b_off)
+        j.a2_hi, j.a2_lo = self._pl(A2, 0, a2_off), self._pl(A2, 1, a2_off)
+        j.b2_hi, j.b2_lo = self._pl(B2, 0, b2_off), self._pl(B2, 1, b2_off)
+        j.c, j.bias = c_ptr, bias_ptr
+        j.lda, j.ldb, j.lda2, j.ldb2, j.ldc = lda, ldb, lda2, ldb2, ldc
+        j.m, j.n, j.a_w, j.b_w, j.a2_mode, j.scale = m, n, a_w, b_w, a2_mode, scale
+        j.tile_base = self.tiles
+        self.tiles += ((m + 127) // 128) * ((n + 127) // 128)
+        self.jobs.append(j)
+
+    def finalize(self):
+        arr = (_lib.FneusGemmJob * len(self.jobs))(*self.jobs)
+        raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+        self.dev_table = torch.from_numpy(raw).to(self.device)
+        return self
+
+    def run(self, n_samples: int, prec: int):
+        check(lib.fneus_dw_gemm(_ptr(self.dev_table), len(self.jobs), self.tiles, n_samples, prec, _stream()),
+              "fneus_dw_gemm")
+
+
+def sdf_dw_jobs(net: PackedNet, stash: SdfStash, bufs: SdfBwdBufs, grad_flat: torch.Tensor, n: int) -> GemmJobs:
+    """dW_l = zbar_l^T u_l + a_l^T adj_l for the 9 SDF layers, into the flat fp32 grad buffer."""
+    import math
+    g = GemmJobs(grad_flat.device)
+    offW, offb = net.desc["offW"], net.desc["offb"]
+    base = grad_flat.data_ptr()
+    isq2 = 1.0 / math.sqrt(2.0)
+
+    def L(t, slot):            # layer slot view of a [planes, L, n, 256] tensor -> [planes, n, 256]
+        return t[:, slot]
+
+    for l in (1, 2, 3, 5, 6, 7):
+        m = 217 if l == 3 else 256
+        g.add(L(bufs.zbar, l), L(stash.h, l - 1), base + 4 * offW[l], 256, m, 256, 256, 256, 256, 256,
+              A2=L(stash.a, l), B2=L(bufs.adj, l - 1), lda2=256, ldb2=256, bias_ptr=base + 4 * offb[l])
+    # layer 0: inputs = PE
+    g.add(L(bufs.zbar, 0), stash.pe, base + 4 * offW[0], 39, 256, 39, 256, 48, 256, 48,
+          A2=L(stash.a, 0), B2=bufs.qbar, lda2=256, ldb2=48, bias_ptr=base + 4 * offb[0])
+    # layer 4: [h_4 (217) ; PE (39)] / sqrt(2)
+    g.add(L(bufs.zbar, 4), L(stash.h, 3), base + 4 * offW[4], 256, 256, 217, 256, 256, 256, 256,
+          A2=L(stash.a, 4), B2=L(bufs.adj, 3), lda2=256, ldb2=256, bias_ptr=base + 4 * offb[4], scale=isq2)
+    g.add(L(bufs.zbar, 4), stash.pe, base + 4 * (offW[4] + 217), 256, 256, 39, 256, 48, 256, 48,
+          A2=L(stash.a, 4), B2=bufs.qbar, lda2=256, ldb2=48, scale=isq2)
+    # layer 8: rows 1..256 (feature), row 0 (sdf; its ascending term is sum_n adj_8[n])
+    g.add(L(bufs.zbar, 8), L(stash.h, 7), base + 4 * (offW[8] + 256), 256, 256, 256, 256, 256, 256, 256,
+          bias_ptr=base + 4 * (offb[8] + 1))
+    g.add(bufs.zsdf, L(stash.h, 7), base + 4 * offW[8], 256, 1, 256, 32, 256, 32, 256,
+          A2=bufs.zsdf, B2=L(bufs.adj, 7), lda2=32, ldb2=256, a2_mode=1, bias_ptr=base + 4 * offb[8])
+    return g.finalize()
+
+
+def color_dw_jobs(net: PackedNet, sdf_stash: SdfStash, stash: ColStash, grad_flat: torch.Tensor, n: int) -> GemmJobs:
+    g = GemmJobs(grad_flat.device)
+    offW, offb = net.desc["offW"], net.desc["offb"]
+    base = grad_flat.data_ptr()
+    # layer 0: columns 0..32 = side inputs, 33..288 = feature
+    g.add(stash.zbar[:, 0], sdf_stash.feat, base + 4 * (offW[0] + 33), 289, 256, 256, 256, 256, 256, 256,
+          bias_ptr=base + 4 * offb[0])
+    g.add(stash.zbar[:, 0], stash.side, base + 4 * offW[0], 289, 256, 33, 256, 48, 256, 48)
+    for l in (1, 2, 3):
+        g.add(stash.zbar[:, l], stash.u[:, l - 1], base + 4 * offW[l], 256, 256, 256, 256, 256, 256, 256,
+              bias_ptr=base + 4 * offb[l])
+    g.add(stash.zbar[:, 4], stash.u[:, 3], base + 4 * offW[4], 256, 3, 256, 32, 256, 32, 256,
+          bias_ptr=base + 4 * offb[4])
+    return g.finalize()

@@ -37,6 +37,37 @@ typedef struct FneusSdfStash {
     uint16_t* feat_hi; uint16_t* feat_lo; /* [N][256]     feature vector (colour-network input)             */
 } FneusSdfStash;
 
+/* bf16 planes of the colour network (written by fneus_color_fwd with train != 0 / fneus_color_bwd). */
+typedef struct FneusColStash {
+    uint16_t* side_hi; uint16_t* side_lo; /* [N][48]     pts | PE4(view) | normal (cols >= 33 zero)           */
+    uint16_t* u_hi;    uint16_t* u_lo;    /* [4][N][256] slot l = ReLU output of layer l (= input of l+1)     */
+    uint16_t* zbar_hi; uint16_t* zbar_lo; /* [5][N][256] slot l = dL/dz_l  (slot 4: 32-wide rows, 3 valid)   */
+} FneusColStash;
+
+/* work buffers of fneus_sdf_bwd (operands of the weight-gradient GEMM + private scratch). */
+typedef struct FneusSdfBwdBufs {
+    uint16_t* qbar_hi; uint16_t* qbar_lo; /* [N][48]     adj_0 = J^T-transposed normal adjoint                 */
+    uint16_t* adj_hi;  uint16_t* adj_lo;  /* [8][N][256] slot l = adj_{l+1}                                    */
+    uint16_t* zbar_hi; uint16_t* zbar_lo; /* [9][N][256] slot l = dL/dz_l (slot 8: feature rows of layer 8)    */
+    uint16_t* zsdf_hi; uint16_t* zsdf_lo; /* [N][32]     column 0 = dL/dsdf                                    */
+    float* cscratch;                      /* [ceil(N/32)][8][32][64][4] fp32                                   */
+} FneusSdfBwdBufs;
+
+/* One product of fneus_dw_gemm: C[m][n] += scale * sum_s (A[s][:m]^T B[s][:n] + A2^T B2); bias[m] += sum_s A[s][:m]. */
+typedef struct FneusGemmJob {
+    const uint16_t *a_hi, *a_lo, *b_hi, *b_lo;     /* segment 1 (bf16 planes, row-major, one row per sample)   */
+    const uint16_t *a2_hi, *a2_lo, *b2_hi, *b2_lo; /* segment 2 or NULL                                        */
+    float* c;                                      /* fp32 [m][ldc], accumulated with atomics                  */
+    float* bias;                                   /* fp32 [m] or NULL                                         */
+    int32_t lda, ldb, lda2, ldb2, ldc;
+    int32_t m, n;
+    int32_t a_w;       /* readable row width (elements, multiple of 8) of A / A2 from the given pointer         */
+    int32_t a2_mode;   /* 1: A2 is implicit (column 0 == 1)                                                      */
+    float scale;
+    int32_t tile_base; /* index of this job's first 128x128 tile in the launch                                  */
+    int32_t b_w;       /* readable row width of B / B2                                                           */
+} FneusGemmJob;
+
 /* ---- library ------------------------------------------------------------------------------------------------ */
 int fneus_version(void);                 /* 100*major + minor */
 const char* fneus_last_error(void);      /* host pointer, static storage */
@@ -61,6 +92,28 @@ int fneus_sdf_fwd_grad(const void* sdf_blob, const float* pts, const float* rays
                        const float* t, int m, long n_pts, const FneusSdfStash* stash /*host struct*/,
                        float* sdf_out /*[n]*/, float* feat_out /*[n][256]*/, float* normal_out /*[n][3]*/, int prec,
                        int train, fneus_stream_t stream);
+
+/* ---- K3: autograd of K2 w.r.t. the SDF weights, incl. the double backward through SDFNetwork.gradient
+ *      (create_graph=True, fields.py:104-110).  Consumes the K2 stash, writes the planes in `bufs`; the weight
+ *      gradients themselves are produced by fneus_dw_gemm from those planes. */
+int fneus_sdf_bwd(const void* sdf_blob, const float* pts, const float* rays_o, const float* rays_d, const float* t,
+                  int m, long n_pts, const FneusSdfStash* stash, const FneusSdfBwdBufs* bufs, const float* d_sdf /*[n]*/,
+                  const float* d_feat /*[n][256]*/, const float* d_normal /*[n][3]*/, int prec, fneus_stream_t stream);
+
+/* ---- weight-gradient GEMM (split-K over samples, fp32 atomics into zero-initialised C / bias) ------------------ */
+int fneus_dw_gemm(const void* jobs_dev /*FneusGemmJob[n_jobs] on the device*/, int n_jobs, int n_tiles, long n_samples,
+                  int prec, fneus_stream_t stream);
+
+/* ---- K4: RenderingNetwork.forward, mode 'idr'  (fields.py:150-175 via renderer.py:278) ---------------------- */
+/* view directions: `dirs` [n][3], or NULL -> rays_d[n/m].  train != 0 writes the stash planes for the backward.   */
+int fneus_color_fwd(const void* col_blob, const float* pts, const float* rays_o, const float* rays_d, const float* t,
+                    int m, long n_pts, const float* dirs, const float* normal /*[n][3]*/, const float* feat /*[n][256]*/,
+                    const FneusColStash* stash /*host struct, may be NULL when !train*/, float* rgb_out /*[n][3]*/,
+                    int prec, int train, fneus_stream_t stream);
+
+/* autograd of the above: d_rgb -> d_feat [n][256], d_normal [n][3]; writes zbar planes (weight-gradient operands). */
+int fneus_color_bwd(const void* col_blob, long n_pts, const float* d_rgb, const float* rgb, const FneusColStash* stash,
+                    float* d_feat, float* d_normal, int prec, fneus_stream_t stream);
 
 #ifdef __cplusplus
 }

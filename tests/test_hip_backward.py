@@ -1,0 +1,125 @@
+"""GPU parity: colour network fwd/bwd, SDF double-backward chain and the weight-gradient GEMM vs fp64 autograd of the
+CPU oracle.  Gradients are compared relative to the per-tensor scale (they span many orders of magnitude)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def rel_err(a, b):
+    """relative L2 error.  (A max-norm would be dominated by the rare samples whose ReLU pre-activation sits within
+    rounding of zero: the ReLU derivative is discontinuous there, for the reference as much as for us.)"""
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def bad_row_fraction(a, b, thr=1e-3):
+    a, b = a.double().cpu(), b.double().cpu()
+    e = (a - b).abs().max(dim=1)[0] / (b.abs().max() + 1e-30)
+    return (e > thr).double().mean().item()
+
+
+@pytest.fixture(scope="module")
+def env():
+    from fneus import ops, synth
+    from oracle import ref_torch as R
+    dev = torch.device("cuda:0")
+    sdf_sd = {k: T(v) for k, v in synth.sdf_state_dict(20).items()}
+    col_sd = {k: T(v) for k, v in synth.color_state_dict(21).items()}
+    sp = R.sdf_params_from_state_dict(sdf_sd)
+    cp = R.color_params_from_state_dict(col_sd)
+    snet, cnet = ops.PackedNet("sdf", dev), ops.PackedNet("color", dev)
+    snet.pack(snet.flat_from_lists([w.to(dev) for w in sp["W"]], [b.to(dev) for b in sp["b"]]).contiguous())
+    cnet.pack(cnet.flat_from_lists([w.to(dev) for w in cp["W"]], [b.to(dev) for b in cp["b"]]).contiguous())
+    rs = np.random.RandomState(11)
+    n = 1500
+    x = T(rs.uniform(-1.1, 1.1, size=(n, 3)).astype(np.float32))
+    d = T(rs.standard_normal((n, 3)).astype(np.float32))
+    d = d / d.norm(dim=-1, keepdim=True)
+    return dict(ops=ops, R=R, dev=dev, sp=sp, cp=cp, snet=snet, cnet=cnet, x=x, d=d, n=n, rs=rs)
+
+
+@pytest.mark.parametrize("prec,tol", [(3, 1e-4), (1, 3e-2)])
+def test_color_fwd_bwd(env, prec, tol):
+    ops, R, dev, n = env["ops"], env["R"], env["dev"], env["n"]
+    rs = np.random.RandomState(5)
+    x, d = env["x"], env["d"]
+    normal = T(rs.standard_normal((n, 3)).astype(np.float32))
+    feat = T((rs.standard_normal((n, 256)) * 0.3).astype(np.float32))
+    c_rgb = T(rs.standard_normal((n, 3)).astype(np.float32))
+    # oracle, fp64
+    cp64 = {"W": [w.double().requires_grad_(True) for w in env["cp"]["W"]],
+            "b": [b.double().requires_grad_(True) for b in env["cp"]["b"]]}
+    nrm64 = normal.double().requires_grad_(True)
+    feat64 = feat.double().requires_grad_(True)
+    rgb_ref, _, zs = R.color_forward(x.double(), nrm64, d.double(), feat64, cp64, keep=True)
+    # samples with a ReLU pre-activation within rounding of zero have an ill-defined derivative (for the reference as
+    # much as for us): give them a zero cotangent so that they drop out of every gradient
+    zmin = torch.stack([z.detach().abs().min(dim=1)[0] for z in zs[:4]]).min(dim=0)[0]
+    ok = zmin > (3e-6 if prec == 3 else 0.0)
+    c_rgb = c_rgb * ok[:, None].float()
+    (rgb_ref * c_rgb.double()).sum().backward()
+    # HIP
+    sdf_stash = ops.SdfStash(n, dev, prec, train=True)
+    # the colour dW jobs read the feature planes of the SDF stash: fill them from `feat`
+    fh = feat.to(dev).bfloat16()
+    sdf_stash.feat[0].copy_(fh)
+    if prec == 3:
+        sdf_stash.feat[1].copy_((feat.to(dev) - fh.float()).bfloat16())
+    cst = ops.ColStash(n, dev, prec)
+    rgb = ops.color_fwd(env["cnet"].blob, n, prec, normal.to(dev), feat.to(dev), cst, True,
+                        pts=x.to(dev).contiguous(), dirs=d.to(dev).contiguous())
+    e = (rgb.cpu().double() - rgb_ref.detach()).abs().max().item()
+    print(f"color_fwd prec={prec} max abs err {e:.3e}")
+    assert e <= tol
+    d_feat, d_normal = ops.color_bwd(env["cnet"].blob, n, prec, c_rgb.to(dev), rgb, cst)
+    gtol = 2e-4 if prec == 3 else 0.15
+    e_f = rel_err(d_feat.cpu()[ok], feat64.grad[ok])
+    e_n = rel_err(d_normal.cpu()[ok], nrm64.grad[ok])
+    print(f"color_bwd prec={prec} rel err d_feat {e_f:.3e} d_normal {e_n:.3e} (kept {int(ok.sum())}/{n} samples)")
+    assert int(ok.sum()) > 0.8 * n
+    assert e_f <= gtol and e_n <= gtol
+    grad = torch.zeros(env["cnet"].n_params, dtype=torch.float32, device=dev)
+    jobs = ops.color_dw_jobs(env["cnet"], sdf_stash, cst, grad, n)
+    jobs.run(n, prec)
+    dWs, dbs = env["cnet"].split_flat(grad)
+    for l in range(5):
+        eW, eb = rel_err(dWs[l], cp64["W"][l].grad), rel_err(dbs[l], cp64["b"][l].grad)
+        print(f"  color dW{l} rel {eW:.3e} db{l} rel {eb:.3e}")
+        assert eW <= gtol and eb <= gtol, l
+
+
+@pytest.mark.parametrize("prec,gtol", [(3, 3e-4), (1, 8e-2)])
+def test_sdf_double_backward(env, prec, gtol):
+    ops, R, dev, n = env["ops"], env["R"], env["dev"], env["n"]
+    rs = np.random.RandomState(6)
+    x = env["x"]
+    c_s = T(rs.standard_normal((n, 1)).astype(np.float32))
+    c_f = T((rs.standard_normal((n, 256)) * 0.05).astype(np.float32))
+    c_n = T(rs.standard_normal((n, 3)).astype(np.float32))
+    p64 = {"W": [w.double().requires_grad_(True) for w in env["sp"]["W"]],
+           "b": [b.double().requires_grad_(True) for b in env["sp"]["b"]], "scale": 1.0}
+    sdf_r, feat_r, nrm_r, _ = R.sdf_value_feature_normal(x.double(), p64)
+    ((sdf_r * c_s.double()).sum() + (feat_r * c_f.double()).sum() + (nrm_r * c_n.double()).sum()).backward()
+    stash = ops.SdfStash(n, dev, prec, train=True)
+    xd = x.to(dev).contiguous()
+    ops.sdf_fwd_grad(env["snet"].blob, n, prec, stash, True, pts=xd)
+    bufs = ops.SdfBwdBufs(n, dev, prec)
+    ops.sdf_bwd(env["snet"].blob, n, prec, stash, bufs, c_s.to(dev).reshape(-1).contiguous(), c_f.to(dev).contiguous(),
+                c_n.to(dev).contiguous(), pts=xd)
+    grad = torch.zeros(env["snet"].n_params, dtype=torch.float32, device=dev)
+    jobs = ops.sdf_dw_jobs(env["snet"], stash, bufs, grad, n)
+    jobs.run(n, prec)
+    torch.cuda.synchronize()
+    dWs, dbs = env["snet"].split_flat(grad)
+    worst = 0.0
+    for l in range(9):
+        eW, eb = rel_err(dWs[l], p64["W"][l].grad), rel_err(dbs[l], p64["b"][l].grad)
+        print(f"  sdf prec={prec} dW{l} rel {eW:.3e} db{l} rel {eb:.3e}")
+        worst = max(worst, eW, eb)
+    assert worst <= gtol
