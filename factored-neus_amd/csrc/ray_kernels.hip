@@ -1,0 +1,478 @@
+// Per-ray kernels: hierarchical sampler and NeuS alpha / compositing (reference models/renderer.py).
+//   K6a upsample      : NeuSRenderer.up_sample + sample_pdf(det=True)            renderer.py:152-189, 43-77
+//   K6b merge         : cat_z_vals sort-merge of z (and sdf)                     renderer.py:191-205
+//       sections      : dists / mid_z of render_core                              renderer.py:223-226
+//   K5  composite_fwd : SDF -> alpha -> weights -> colour, eikonal sums, first sign change, inside-sphere weights
+//                                                                                renderer.py:245-274, 290-293, 328-332, 360-372
+//   K5  composite_bwd : hand-written adjoint of the above (SURVEY.md Appendix A reminders)
+// One wavefront (64 lanes) per ray; each lane owns a contiguous chunk of <= 4 samples (n <= 256); scans are
+// chunk-serial + wave-level.  All arithmetic fp32; these kernels are latency/HBM bound (< 1 % of the step).
+#include "fneus_common.h"
+#include "fneus_kernels.h"
+
+namespace fneus {
+
+constexpr int MAXN = 256;
+constexpr int PER = 4;
+
+FN_DEV float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// inclusive wave scans over 64 lanes
+FN_DEV float wave_incl_prod(float v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float o = __shfl_up(v, d, 64);
+        if (lane >= d) v *= o;
+    }
+    return v;
+}
+FN_DEV float wave_incl_sum(float v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+FN_DEV float wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+FN_DEV int wave_min_i(int v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d, 64));
+    return v;
+}
+FN_DEV float wave_max(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
+    return v;
+}
+
+FN_DEV float pt_norm(const float* o, const float* d, float z) {
+    float s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float p = __fadd_rn(o[c], __fmul_rn(d[c], z));
+        s = __fadd_rn(s, __fmul_rn(p, p));
+    }
+    return sqrtf(s);
+}
+
+// exclusive cumulative product over the ray: vals[j] for this lane's chunk [lane*PER, lane*PER+PER) -> T[j]
+FN_DEV void excl_cumprod(const float (&f)[PER], float (&T)[PER], int lane) {
+    float loc = 1.0f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) loc *= f[j];
+    const float inc = wave_incl_prod(loc, lane);
+    float run = __shfl_up(inc, 1, 64);
+    if (lane == 0) run = 1.0f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        T[j] = run;
+        run *= f[j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K6a: new z by inverse-CDF sampling of the NeuS weights at a fixed inv_s
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) upsample_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                      const float* __restrict__ z_in, const float* __restrict__ sdf_in,
+                                                      int m, int k, float inv_s, float* __restrict__ z_new) {
+    __shared__ float zs[MAXN], ss[MAXN], cdf[MAXN + 1];
+    const int ray = blockIdx.x, lane = threadIdx.x;
+    float o[3], d[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        o[c] = rays_o[ray * 3 + c];
+        d[c] = rays_d[ray * 3 + c];
+    }
+    for (int i = lane; i < m; i += 64) {
+        zs[i] = z_in[(size_t)ray * m + i];
+        ss[i] = sdf_in[(size_t)ray * m + i];
+    }
+    __syncthreads();
+    const int ns = m - 1;   // sections
+    float alpha[PER], fac[PER], T[PER], w[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = lane * PER + j;
+        float a = 0.0f;
+        if (i < ns) {
+            const float z0 = zs[i], z1 = zs[i + 1], s0 = ss[i], s1 = ss[i + 1];
+            const bool inside = (pt_norm(o, d, z0) < 1.0f) || (pt_norm(o, d, z1) < 1.0f);
+            const float cosv = (s1 - s0) / (z1 - z0 + 1e-5f);
+            float prev = 0.0f;
+            if (i > 0) prev = (s0 - ss[i - 1]) / (z0 - zs[i - 1] + 1e-5f);
+            float cv = fminf(prev, cosv);
+            cv = fminf(fmaxf(cv, -1e3f), 0.0f) * (inside ? 1.0f : 0.0f);
+            const float dist = z1 - z0;
+            const float mid = (s0 + s1) * 0.5f;
+            const float pe = mid - cv * dist * 0.5f, ne = mid + cv * dist * 0.5f;
+            const float pc = sigmoid_acc(pe * inv_s), nc = sigmoid_acc(ne * inv_s);
+            a = (pc - nc + 1e-5f) / (pc + 1e-5f);
+        }
+        alpha[j] = a;
+        fac[j] = (i < ns) ? (1.0f - a + 1e-7f) : 1.0f;
+    }
+    excl_cumprod(fac, T, lane);
+    float loc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = lane * PER + j;
+        w[j] = (i < ns) ? alpha[j] * T[j] + 1e-5f : 0.0f;   // sample_pdf: weights + 1e-5
+        loc += w[j];
+    }
+    const float total = wave_sum(loc);
+    // cdf = [0, cumsum(pdf)]
+    float locp = 0.0f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        w[j] = w[j] / total;
+        locp += w[j];
+    }
+    const float inc = wave_incl_sum(locp, lane);
+    float run = inc - locp;
+    if (lane == 0) cdf[0] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = lane * PER + j;
+        run += w[j];
+        if (i < ns) cdf[i + 1] = run;
+    }
+    __syncthreads();
+    for (int q = lane; q < k; q += 64) {
+        // torch.linspace(0.5/k, 1-0.5/k, k)
+        const float start = 0.5f / k, end = 1.0f - 0.5f / k;
+        const float step = (k > 1) ? (end - start) / (float)(k - 1) : 0.0f;
+        const float u = (q < k / 2) ? start + step * q : end - step * (k - 1 - q);
+        // searchsorted(cdf, u, right=True) = number of entries <= u
+        int lo = 0, hi = m;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+        }
+        const int below = max(lo - 1, 0), above = min(lo, m - 1);
+        const float cb = cdf[below], ca = cdf[above];
+        float den = ca - cb;
+        if (den < 1e-5f) den = 1.0f;
+        const float t = (u - cb) / den;
+        z_new[(size_t)ray * k + q] = zs[below] + t * (zs[above] - zs[below]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K6b: stable rank merge of (z_old | z_new); sdf rides along when given
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) merge_kernel(const float* __restrict__ z_old, const float* __restrict__ s_old, int m,
+                                                   const float* __restrict__ z_new, const float* __restrict__ s_new, int k,
+                                                   float* __restrict__ z_out, float* __restrict__ s_out) {
+    __shared__ float zs[MAXN];
+    const int ray = blockIdx.x, lane = threadIdx.x;
+    const int n = m + k;
+    for (int i = lane; i < n; i += 64) zs[i] = (i < m) ? z_old[(size_t)ray * m + i] : z_new[(size_t)ray * k + (i - m)];
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) {
+        const float z = zs[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const float zj = zs[j];
+            rank += (zj < z) || (zj == z && j < i);
+        }
+        z_out[(size_t)ray * n + rank] = z;
+        if (s_out) s_out[(size_t)ray * n + rank] = (i < m) ? s_old[(size_t)ray * m + i] : s_new[(size_t)ray * k + (i - m)];
+    }
+}
+
+__global__ void __launch_bounds__(256) sections_kernel(const float* __restrict__ z, int n_rays, int n, float sample_dist,
+                                                       float* __restrict__ dists, float* __restrict__ mid_z) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)n_rays * n) return;
+    const int i = (int)(idx % n);
+    const float z0 = z[idx];
+    const float dd = (i + 1 < n) ? z[idx + 1] - z0 : sample_dist;
+    dists[idx] = dd;
+    mid_z[idx] = z0 + dd * 0.5f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K5 forward
+// ---------------------------------------------------------------------------------------------------------------
+struct SecVals {   // per-sample quantities shared by forward and backward
+    float sdf, tc, dist, pc, nc, raw, alpha, inside, relax, gn;
+};
+
+FN_DEV SecVals section_values(const float* o, const float* d, float mz, float dist, float sdf, const float* g,
+                              float inv_s, float car) {
+    SecVals v;
+    v.sdf = sdf;
+    v.dist = dist;
+    v.tc = d[0] * g[0] + d[1] * g[1] + d[2] * g[2];                       // renderer.py:248
+    const float ic = -(fmaxf(-v.tc * 0.5f + 0.5f, 0.0f) * (1.0f - car) + fmaxf(-v.tc, 0.0f) * car);   // :250-251
+    const float en = sdf + ic * dist * 0.5f, ep = sdf - ic * dist * 0.5f;  // :255-256
+    v.pc = sigmoid_acc(ep * inv_s);
+    v.nc = sigmoid_acc(en * inv_s);
+    v.raw = (v.pc - v.nc + 1e-5f) / (v.pc + 1e-5f);                         // :268
+    v.alpha = fminf(fmaxf(v.raw, 0.0f), 1.0f);
+    const float pn = pt_norm(o, d, mz);
+    v.inside = pn < 1.0f ? 1.0f : 0.0f;                                     // :270-272
+    v.relax = pn < 1.2f ? 1.0f : 0.0f;
+    v.gn = sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+    return v;
+}
+
+__global__ void __launch_bounds__(64) composite_fwd_kernel(
+    const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ mid_z,
+    const float* __restrict__ dists, const float* __restrict__ sdf, const float* __restrict__ normal,
+    const float* __restrict__ rgb, const float* __restrict__ inv_s_ptr, int n, float car,
+    float* __restrict__ weights, float* __restrict__ color, float* __restrict__ wsum, float* __restrict__ wmax,
+    float* __restrict__ cdf_out, float* __restrict__ inside_out, float* __restrict__ eik /*[B][2]*/,
+    int* __restrict__ min_idx_out, unsigned char* __restrict__ mask_out, float* __restrict__ wpair /*[B][2]*/) {
+    const int ray = blockIdx.x, lane = threadIdx.x;
+    const float inv_s = *inv_s_ptr;
+    float o[3], d[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        o[c] = rays_o[ray * 3 + c];
+        d[c] = rays_d[ray * 3 + c];
+    }
+    const size_t base = (size_t)ray * n;
+    float fac[PER], fin[PER], T[PER], Tin[PER], al[PER], ins[PER];
+    float csum[3] = {0, 0, 0}, ws = 0.0f, wm = 0.0f, en = 0.0f, ed = 0.0f, insum = 0.0f;
+    int firstneg = 1 << 30;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = lane * PER + j;
+        fac[j] = 1.0f; fin[j] = 1.0f; al[j] = 0.0f; ins[j] = 0.0f;
+        if (i < n) {
+            const float g[3] = {normal[(base + i) * 3], normal[(base + i) * 3 + 1], normal[(base + i) * 3 + 2]};
+            const SecVals v = section_values(o, d, mid_z[base + i], dists[base + i], sdf[base + i], g, inv_s, car);
+            al[j] = v.alpha;
+            ins[j] = v.inside;
+            fac[j] = 1.0f - v.alpha + 1e-7f;
+            fin[j] = 1.0f - v.alpha * v.inside + 1e-7f;
+            cdf_out[base + i] = v.pc;
+            inside_out[base + i] = v.inside;
+            en += v.relax * (v.gn - 1.0f) * (v.gn - 1.0f);   // :370-372
+            ed += v.relax;
+            insum += v.inside;
+            if (v.sdf < 0.0f) firstneg = min(firstneg, i);     // first index with sign(sdf) = -1   (:290-291)
+        }
+    }
+    excl_cumprod(fac, T, lane);
+    excl_cumprod(fin, Tin, lane);
+    const int idx = wave_min_i(firstneg);
+    const float in_total = wave_sum(insum);
+    const bool mask = (idx < n) && (idx >= 1) && (in_total > 0.0f);    // :292
+    float wlo = 0.0f, whi = 0.0f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = lane * PER + j;
+        if (i < n) {
+            const float w = al[j] * T[j];
+            weights[base + i] = w;
+            ws += w;
+            wm = fmaxf(wm, w);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) csum[c] += w * rgb[(base + i) * 3 + c];
+            if (mask) {
+                const float win = al[j] * ins[j] * Tin[j];
+                if (i == idx - 1) wlo = win;
+                if (i == idx) whi = win;
+            }
+        }
+    }
+    ws = wave_sum(ws);
+    wm = wave_max(wm);
+    en = wave_sum(en);
+    ed = wave_sum(ed);
+    wlo = wave_sum(wlo);
+    whi = wave_sum(whi);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) csum[c] = wave_sum(csum[c]);
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) color[ray * 3 + c] = csum[c];
+        wsum[ray] = ws;
+        wmax[ray] = wm;
+        eik[ray * 2] = en;
+        eik[ray * 2 + 1] = ed;
+        min_idx_out[ray] = (idx < n) ? idx : 0;
+        mask_out[ray] = mask ? 1 : 0;
+        wpair[ray * 2] = wlo;
+        wpair[ray * 2 + 1] = whi;
+    }
+}
+
+// exclusive suffix sum over the ray of per-sample values (chunk layout)
+FN_DEV void excl_suffix_sum(const float (&v)[PER], float (&S)[PER], int lane) {
+    float loc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) loc += v[j];
+    const float inc = wave_incl_sum(loc, lane);
+    const float total = __shfl(inc, 63, 64);
+    float run = total - inc;   // sum of all chunks after this lane
+#pragma unroll
+    for (int j = PER - 1; j >= 0; --j) {
+        S[j] = run;
+        run += v[j];
+    }
+}
+
+__global__ void __launch_bounds__(64) composite_bwd_kernel(
+    const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ mid_z,
+    const float* __restrict__ dists, const float* __restrict__ sdf, const float* __restrict__ normal,
+    const float* __restrict__ rgb, const float* __restrict__ inv_s_ptr, int n, float car,
+    const int* __restrict__ min_idx, const unsigned char* __restrict__ mask_in,
+    const float* __restrict__ d_color /*[B][3]*/, const float* __restrict__ d_wsum /*[B]*/,
+    const float* __restrict__ d_weights /*[B][n] or null*/, const float* __restrict__ d_wpair /*[B][2]*/,
+    const float* __restrict__ d_eiknum /*[B]*/, float* __restrict__ d_sdf, float* __restrict__ d_normal,
+    float* __restrict__ d_rgb, float* __restrict__ d_inv_s /*[B]*/) {
+    const int ray = blockIdx.x, lane = threadIdx.x;
+    const float inv_s = *inv_s_ptr;
+    float o[3], d[3], dc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        o[c] = rays_o[ray * 3 + c];
+        d[c] = rays_d[ray * 3 + c];
+        dc[c] = d_color[ray * 3 + c];
+    }
+    const float dws = d_wsum[ray];
+    const float deik = d_eiknum[ray];
+    const bool mask = mask_in[ray] != 0;
+    const int idx = min_idx[ray];
+    const float dlo = mask ? d_wpair[ray * 2] : 0.0f, dhi = mask ? d_wpair[ray * 2 + 1] : 0.0f;
+    const size_t base = (size_t)ray * n;
+    SecVals sv[PER];
+    float fac[PER], fin[PER], T[PER], Tin[PER], ww[PER], wwin[PER], S[PER], Sin[PER], wbar[PER], wbin[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = lane * PER + j;
+        fac[j] = 1.0f; fin[j] = 1.0f;
+        sv[j] = SecVals{};
+        if (i < n) {
+            const float g[3] = {normal[(base + i) * 3], normal[(base + i) * 3 + 1], normal[(base + i) * 3 + 2]};
+            sv[j] = section_values(o, d, mid_z[base + i], dists[base + i], sdf[base + i], g, inv_s, car);
+            fac[j] = 1.0f - sv[j].alpha + 1e-7f;
+            fin[j] = 1.0f - sv[j].alpha * sv[j].inside + 1e-7f;
+        }
+    }
+    excl_cumprod(fac, T, lane);
+    excl_cumprod(fin, Tin, lane);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = lane * PER + j;
+        wbar[j] = 0.0f; wbin[j] = 0.0f; ww[j] = 0.0f; wwin[j] = 0.0f;
+        if (i < n) {
+            const float w = sv[j].alpha * T[j];
+            float wb = dws + dc[0] * rgb[(base + i) * 3] + dc[1] * rgb[(base + i) * 3 + 1] + dc[2] * rgb[(base + i) * 3 + 2];
+            if (d_weights) wb += d_weights[base + i];
+            wbar[j] = wb;
+            ww[j] = wb * w;
+            const float win = sv[j].alpha * sv[j].inside * Tin[j];
+            const float wbi = (i == idx - 1) ? dlo : ((i == idx) ? dhi : 0.0f);
+            wbin[j] = wbi;
+            wwin[j] = wbi * win;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) d_rgb[(base + i) * 3 + c] = w * dc[c];
+        }
+    }
+    excl_suffix_sum(ww, S, lane);
+    excl_suffix_sum(wwin, Sin, lane);
+    float dinv = 0.0f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = lane * PER + j;
+        if (i < n) {
+            const SecVals& v = sv[j];
+            float abar = T[j] * wbar[j] - S[j] / fac[j];
+            const float abar_in = Tin[j] * wbin[j] - Sin[j] / fin[j];
+            abar += v.inside * abar_in;
+            const float rbar = (v.raw >= 0.0f && v.raw <= 1.0f) ? abar : 0.0f;     // clip(0,1) backward
+            const float cden = v.pc + 1e-5f;
+            const float pcbar = rbar * (1.0f / cden - (v.pc - v.nc + 1e-5f) / (cden * cden));
+            const float ncbar = -rbar / cden;
+            const float dpc = v.pc * (1.0f - v.pc), dnc = v.nc * (1.0f - v.nc);
+            const float ic = -(fmaxf(-v.tc * 0.5f + 0.5f, 0.0f) * (1.0f - car) + fmaxf(-v.tc, 0.0f) * car);
+            const float ep = v.sdf - ic * v.dist * 0.5f, en = v.sdf + ic * v.dist * 0.5f;
+            const float epbar = pcbar * dpc * inv_s, enbar = ncbar * dnc * inv_s;
+            dinv += pcbar * dpc * ep + ncbar * dnc * en;
+            d_sdf[base + i] = epbar + enbar;
+            const float icbar = (enbar - epbar) * v.dist * 0.5f;
+            const float dic_dtc = 0.5f * (1.0f - car) * ((-v.tc * 0.5f + 0.5f) > 0.0f ? 1.0f : 0.0f) +
+                                  car * ((-v.tc) > 0.0f ? 1.0f : 0.0f);
+            const float tcbar = icbar * dic_dtc;
+            const float g[3] = {normal[(base + i) * 3], normal[(base + i) * 3 + 1], normal[(base + i) * 3 + 2]};
+            const float ek = (v.gn > 0.0f) ? deik * v.relax * 2.0f * (v.gn - 1.0f) / v.gn : 0.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) d_normal[(base + i) * 3 + c] = tcbar * d[c] + ek * g[c];
+        }
+    }
+    dinv = wave_sum(dinv);
+    if (lane == 0) d_inv_s[ray] = dinv;
+}
+
+}  // namespace fneus
+
+using namespace fneus;
+
+#define FN_CHECK_N(n) if ((n) > MAXN || (n) < 2) { set_last_error("samples per ray must be in [2, 256]"); return -2; }
+
+extern "C" int fneus_upsample(const float* rays_o, const float* rays_d, const float* z, const float* sdf, int n_rays, int m,
+                              int k, float inv_s, float* z_new, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_rays <= 0) return 0;
+    FN_CHECK_N(m);
+    hipLaunchKernelGGL(upsample_kernel, dim3(n_rays), dim3(64), 0, stream, rays_o, rays_d, z, sdf, m, k, inv_s, z_new);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+extern "C" int fneus_merge(const float* z_old, const float* s_old, int m, const float* z_new, const float* s_new, int k,
+                           int n_rays, float* z_out, float* s_out, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_rays <= 0) return 0;
+    FN_CHECK_N(m + k);
+    hipLaunchKernelGGL(merge_kernel, dim3(n_rays), dim3(64), 0, stream, z_old, s_old, m, z_new, s_new, k, z_out, s_out);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+extern "C" int fneus_sections(const float* z, int n_rays, int n, float sample_dist, float* dists, float* mid_z,
+                              fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const long total = (long)n_rays * n;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(sections_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, z, n_rays, n, sample_dist,
+                       dists, mid_z);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+extern "C" int fneus_composite_fwd(const float* rays_o, const float* rays_d, const float* mid_z, const float* dists,
+                                   const float* sdf, const float* normal, const float* rgb, const float* inv_s,
+                                   int n_rays, int n, float cos_anneal_ratio, float* weights, float* color, float* wsum,
+                                   float* wmax, float* cdf, float* inside, float* eik, int32_t* min_idx,
+                                   unsigned char* sdf_mask, float* wpair, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_rays <= 0) return 0;
+    FN_CHECK_N(n);
+    hipLaunchKernelGGL(composite_fwd_kernel, dim3(n_rays), dim3(64), 0, stream, rays_o, rays_d, mid_z, dists, sdf, normal,
+                       rgb, inv_s, n, cos_anneal_ratio, weights, color, wsum, wmax, cdf, inside, eik, min_idx, sdf_mask,
+                       wpair);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+extern "C" int fneus_composite_bwd(const float* rays_o, const float* rays_d, const float* mid_z, const float* dists,
+                                   const float* sdf, const float* normal, const float* rgb, const float* inv_s,
+                                   int n_rays, int n, float cos_anneal_ratio, const int32_t* min_idx,
+                                   const unsigned char* sdf_mask, const float* d_color, const float* d_wsum,
+                                   const float* d_weights, const float* d_wpair, const float* d_eiknum, float* d_sdf,
+                                   float* d_normal, float* d_rgb, float* d_inv_s, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_rays <= 0) return 0;
+    FN_CHECK_N(n);
+    hipLaunchKernelGGL(composite_bwd_kernel, dim3(n_rays), dim3(64), 0, stream, rays_o, rays_d, mid_z, dists, sdf, normal,
+                       rgb, inv_s, n, cos_anneal_ratio, min_idx, sdf_mask, d_color, d_wsum, d_weights, d_wpair, d_eiknum,
+                       d_sdf, d_normal, d_rgb, d_inv_s);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

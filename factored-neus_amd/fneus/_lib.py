@@ -57,10 +57,11 @@ def _load():
         "fneus_color_fwd": (C.c_int, [vp, vp, vp, vp, vp, ip, l, vp, vp, vp, C.POINTER(FneusColStash), vp, ip, ip, vp]),
         "fneus_color_bwd": (C.c_int, [vp, l, vp, vp, C.POINTER(FneusColStash), vp, vp, ip, vp]),
         "fneus_dw_gemm": (C.c_int, [vp, ip, ip, l, ip, vp]),
-        "fneus_upsample_step": (C.c_int, [vp, vp, vp, vp, vp, vp, ip, ip, ip, f, ip, vp, vp, vp, vp, vp]),
-        "fneus_merge_mid": (C.c_int, [vp, vp, ip, ip, ip, f, vp, vp, vp, vp]),
-        "fneus_composite_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, ip, ip, f, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
-        "fneus_composite_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ip, ip, f, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "fneus_upsample": (C.c_int, [vp, vp, vp, vp, ip, ip, ip, f, vp, vp]),
+        "fneus_merge": (C.c_int, [vp, vp, ip, vp, vp, ip, ip, vp, vp, vp]),
+        "fneus_sections": (C.c_int, [vp, ip, ip, f, vp, vp, vp]),
+        "fneus_composite_fwd": (C.c_int, [vp] * 8 + [ip, ip, f] + [vp] * 10 + [vp]),
+        "fneus_composite_bwd": (C.c_int, [vp] * 8 + [ip, ip, f] + [vp] * 11 + [vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)

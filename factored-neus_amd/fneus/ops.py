@@ -264,3 +264,66 @@ def color_dw_jobs(net: PackedNet, sdf_stash: SdfStash, stash: ColStash, grad_fla
     g.add(stash.zbar[:, 4], stash.u[:, 3], base + 4 * offW[4], 256, 3, 256, 32, 256, 32, 256,
           bias_ptr=base + 4 * offb[4])
     return g.finalize()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# per-ray kernels
+# ------------------------------------------------------------------------------------------------------------
+def upsample(rays_o, rays_d, z, sdf, k: int, inv_s: float):
+    B, m = z.shape
+    out = torch.empty(B, k, dtype=torch.float32, device=z.device)
+    check(lib.fneus_upsample(_ptr(rays_o), _ptr(rays_d), _ptr(z), _ptr(sdf), B, m, k, float(inv_s), _ptr(out),
+                             _stream()), "fneus_upsample")
+    return out
+
+
+def merge(z_old, s_old, z_new, s_new):
+    B, m = z_old.shape
+    k = z_new.shape[1]
+    z_out = torch.empty(B, m + k, dtype=torch.float32, device=z_old.device)
+    s_out = torch.empty_like(z_out) if s_new is not None else None
+    check(lib.fneus_merge(_ptr(z_old), _ptr(s_old) if s_new is not None else None, m, _ptr(z_new), _ptr(s_new), k, B,
+                          _ptr(z_out), _ptr(s_out), _stream()), "fneus_merge")
+    return z_out, s_out
+
+
+def sections(z, sample_dist: float):
+    B, n = z.shape
+    dists = torch.empty_like(z)
+    mid_z = torch.empty_like(z)
+    check(lib.fneus_sections(_ptr(z), B, n, float(sample_dist), _ptr(dists), _ptr(mid_z), _stream()), "fneus_sections")
+    return dists, mid_z
+
+
+def composite_fwd(rays_o, rays_d, mid_z, dists, sdf, normal, rgb, inv_s, car: float):
+    B, n = mid_z.shape
+    dev = mid_z.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    out = {
+        "weights": torch.empty(B, n, **f32), "color": torch.empty(B, 3, **f32), "wsum": torch.empty(B, **f32),
+        "wmax": torch.empty(B, **f32), "cdf": torch.empty(B, n, **f32), "inside": torch.empty(B, n, **f32),
+        "eik": torch.empty(B, 2, **f32), "min_idx": torch.empty(B, dtype=torch.int32, device=dev),
+        "sdf_mask": torch.empty(B, dtype=torch.uint8, device=dev), "wpair": torch.empty(B, 2, **f32),
+    }
+    check(lib.fneus_composite_fwd(_ptr(rays_o), _ptr(rays_d), _ptr(mid_z), _ptr(dists), _ptr(sdf), _ptr(normal),
+                                  _ptr(rgb), _ptr(inv_s), B, n, float(car), _ptr(out["weights"]), _ptr(out["color"]),
+                                  _ptr(out["wsum"]), _ptr(out["wmax"]), _ptr(out["cdf"]), _ptr(out["inside"]),
+                                  _ptr(out["eik"]), _ptr(out["min_idx"]), _ptr(out["sdf_mask"]), _ptr(out["wpair"]),
+                                  _stream()), "fneus_composite_fwd")
+    return out
+
+
+def composite_bwd(rays_o, rays_d, mid_z, dists, sdf, normal, rgb, inv_s, car, min_idx, sdf_mask, d_color, d_wsum,
+                  d_weights, d_wpair, d_eiknum):
+    B, n = mid_z.shape
+    dev = mid_z.device
+    d_sdf = torch.empty(B * n, dtype=torch.float32, device=dev)
+    d_normal = torch.empty(B * n, 3, dtype=torch.float32, device=dev)
+    d_rgb = torch.empty(B * n, 3, dtype=torch.float32, device=dev)
+    d_inv_s = torch.empty(B, dtype=torch.float32, device=dev)
+    check(lib.fneus_composite_bwd(_ptr(rays_o), _ptr(rays_d), _ptr(mid_z), _ptr(dists), _ptr(sdf), _ptr(normal),
+                                  _ptr(rgb), _ptr(inv_s), B, n, float(car), _ptr(min_idx), _ptr(sdf_mask),
+                                  _ptr(d_color), _ptr(d_wsum), _ptr(d_weights), _ptr(d_wpair), _ptr(d_eiknum),
+                                  _ptr(d_sdf), _ptr(d_normal), _ptr(d_rgb), _ptr(d_inv_s), _stream()),
+          "fneus_composite_bwd")
+    return d_sdf, d_normal, d_rgb, d_inv_s

@@ -115,6 +115,33 @@ int fneus_color_fwd(const void* col_blob, const float* pts, const float* rays_o,
 int fneus_color_bwd(const void* col_blob, long n_pts, const float* d_rgb, const float* rgb, const FneusColStash* stash,
                     float* d_feat, float* d_normal, int prec, fneus_stream_t stream);
 
+/* ---- K6: hierarchical sampler pieces (one wavefront per ray, 2 <= samples per ray <= 256) ---------------------- */
+/* NeuSRenderer.up_sample + sample_pdf(det=True)  (renderer.py:152-189, 43-77): z [B][m], sdf [B][m] -> z_new [B][k]  */
+int fneus_upsample(const float* rays_o, const float* rays_d, const float* z, const float* sdf, int n_rays, int m, int k,
+                   float inv_s, float* z_new, fneus_stream_t stream);
+/* cat_z_vals (renderer.py:191-205): stable sort-merge of (z_old | z_new); s_old/s_new/s_out may be NULL (last step) */
+int fneus_merge(const float* z_old, const float* s_old, int m, const float* z_new, const float* s_new, int k, int n_rays,
+                float* z_out, float* s_out, fneus_stream_t stream);
+/* section lengths and mid points of render_core (renderer.py:223-226) */
+int fneus_sections(const float* z, int n_rays, int n, float sample_dist, float* dists, float* mid_z, fneus_stream_t stream);
+
+/* ---- K5: NeuS SDF->alpha, front-to-back compositing, eikonal sums, first sign change
+ *      (renderer.py:245-274, 290-293, 328-332, 360-372).  Per-ray outputs: color [B][3], wsum/wmax [B],
+ *      eik [B][2] = (sum relax*(|g|-1)^2, sum relax), min_idx [B], sdf_mask [B] (u8), wpair [B][2] = inside-sphere
+ *      weights at min_idx-1 / min_idx (0 when !sdf_mask).  inv_s is a device scalar. */
+int fneus_composite_fwd(const float* rays_o, const float* rays_d, const float* mid_z, const float* dists, const float* sdf,
+                        const float* normal, const float* rgb, const float* inv_s, int n_rays, int n,
+                        float cos_anneal_ratio, float* weights, float* color, float* wsum, float* wmax, float* cdf,
+                        float* inside, float* eik, int32_t* min_idx, unsigned char* sdf_mask, float* wpair,
+                        fneus_stream_t stream);
+/* adjoint of fneus_composite_fwd; d_weights may be NULL; d_inv_s is per ray (caller sums). */
+int fneus_composite_bwd(const float* rays_o, const float* rays_d, const float* mid_z, const float* dists, const float* sdf,
+                        const float* normal, const float* rgb, const float* inv_s, int n_rays, int n,
+                        float cos_anneal_ratio, const int32_t* min_idx, const unsigned char* sdf_mask,
+                        const float* d_color, const float* d_wsum, const float* d_weights, const float* d_wpair,
+                        const float* d_eiknum, float* d_sdf, float* d_normal, float* d_rgb, float* d_inv_s,
+                        fneus_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -582,3 +582,37 @@ def near_far_from_sphere(rays_o, rays_d):
     b = 2.0 * (rays_o * rays_d).sum(-1, keepdim=True)
     mid = 0.5 * (-b) / a
     return mid - 1.0, mid + 1.0
+
+
+# --------------------------------------------------------------------------------------
+# The per-ray part of render_core on given per-sample fields (checker for the HIP compositing kernel):
+# renderer.py:245-274 (alpha, inside), :290-293 (first sign change), :328-332 (inside-sphere weights),
+# :360-367 (weights, colour), :370-372 (eikonal sums)
+# --------------------------------------------------------------------------------------
+def composite_from_fields(rays_o, rays_d, mid_z, dists, sdf, normal, rgb, inv_s, cos_anneal_ratio):
+    B, n = mid_z.shape
+    pts = (rays_o[:, None, :] + rays_d[:, None, :] * mid_z[..., None]).reshape(-1, 3)
+    dirs = rays_d[:, None, :].expand(B, n, 3).reshape(-1, 3)
+    true_cos = (dirs * normal.reshape(-1, 3)).sum(-1, keepdim=True)
+    alpha, prev_cdf = neus_alpha(sdf.reshape(-1, 1), true_cos, dists.reshape(-1, 1),
+                                 inv_s.reshape(1, 1).expand(B * n, 1), cos_anneal_ratio)
+    alpha = alpha.reshape(B, n)
+    pts_norm = torch.linalg.norm(pts, dim=-1).reshape(B, n)
+    inside = (pts_norm < 1.0).to(mid_z.dtype)
+    relax = (pts_norm < 1.2).to(mid_z.dtype)
+    weights = alpha * exclusive_transmittance(alpha)
+    color = (rgb.reshape(B, n, 3) * weights[..., None]).sum(1)
+    gnorm = torch.linalg.norm(normal.reshape(B, n, 3), dim=-1)
+    eik_num = (relax * (gnorm - 1.0) ** 2).sum(-1)
+    eik_den = relax.sum(-1)
+    ramp = torch.arange(n, 0, -1, dtype=mid_z.dtype).reshape(1, n)
+    min_val, min_idx = torch.min(torch.sign(sdf.reshape(B, n)) * ramp, dim=-1)
+    sdf_mask = (min_val < 0.0) & (min_idx >= 1) & (inside.sum(-1) > 0.0)
+    alpha_in = alpha * inside
+    w_in = alpha_in * exclusive_transmittance(alpha_in)
+    idx = torch.where(sdf_mask, min_idx, torch.ones_like(min_idx))
+    w_lo = torch.gather(w_in, 1, (idx - 1)[:, None])[:, 0] * sdf_mask
+    w_hi = torch.gather(w_in, 1, idx[:, None])[:, 0] * sdf_mask
+    return {"weights": weights, "color": color, "wsum": weights.sum(-1), "wmax": weights.max(-1)[0],
+            "cdf": prev_cdf.reshape(B, n), "inside": inside, "eik_num": eik_num, "eik_den": eik_den,
+            "min_idx": min_idx, "sdf_mask": sdf_mask, "wpair": torch.stack([w_lo, w_hi], -1), "alpha": alpha}

@@ -1,0 +1,128 @@
+"""GPU parity of the per-ray kernels (sampler pieces, NeuS alpha/compositing fwd+bwd) vs the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_upsample_and_merge_golden(golden_dir):
+    """reference fixtures (tests/golden/units.npz): up_sample new z, and cat_z_vals-style merge"""
+    from fneus import ops
+    from oracle import ref_torch as R
+    g = dict(np.load(os.path.join(golden_dir, "units.npz")))
+    ro, rd, z, s = (T(g[k]).to(DEV).contiguous() for k in ("ups_rays_o", "ups_rays_d", "ups_z", "ups_sdf"))
+    for inv_s in (64, 512):
+        out = ops.upsample(ro, rd, z, s, 8, inv_s).cpu()
+        err = (out - T(g[f"ups_new_z_{inv_s}"])).abs()
+        assert err.max().item() <= 5e-4 and err.median().item() <= 2e-6, (inv_s, err.max(), err.median())
+        # merge: compare with torch.sort of the concatenation
+        new_z = T(g[f"ups_new_z_{inv_s}"]).to(DEV).contiguous()
+        new_s = torch.sin(new_z * 3.0).contiguous()
+        zm, sm = ops.merge(z, s, new_z, new_s)
+        zc, idx = torch.sort(torch.cat([z, new_z], -1), dim=-1, stable=True)
+        sc = torch.gather(torch.cat([s, new_s], -1), 1, idx)
+        assert torch.equal(zm, zc) and torch.equal(sm, sc)
+        zm2, none = ops.merge(z, None, new_z, None)
+        assert torch.equal(zm2, zc) and none is None
+
+
+@pytest.mark.parametrize("m,k", [(64, 16), (80, 16), (112, 16), (16, 4), (33, 7)])
+def test_upsample_random(m, k):
+    from fneus import ops, synth
+    from oracle import ref_torch as R
+    rs = np.random.RandomState(m)
+    B = 50
+    data = T(synth.ray_batch(B, seed=m, n_miss=3))
+    ro, rd = data[:, :3].contiguous(), data[:, 3:6].contiguous()
+    near, far = R.near_far_from_sphere(ro, rd)
+    z = near + (far - near) * torch.linspace(0, 1, m)[None, :]
+    pts = ro[:, None, :] + rd[:, None, :] * z[..., None]
+    sdf = (pts.norm(dim=-1) - 0.5 + 0.05 * torch.sin(7 * pts[..., 0])).float()
+    for inv_s in (64.0, 256.0):
+        ref = R.up_sample(ro, rd, z, sdf, k, inv_s)
+        out = ops.upsample(ro.to(DEV), rd.to(DEV), z.to(DEV).contiguous(), sdf.to(DEV).contiguous(), k, inv_s).cpu()
+        err = (out - ref).abs()
+        assert err.max().item() <= 1e-3 and err.median().item() <= 5e-6, (err.max(), err.median())
+
+
+def test_sections():
+    from fneus import ops
+    z = torch.sort(torch.rand(7, 40), dim=-1)[0]
+    dists, mid = ops.sections(z.to(DEV), 2.0 / 16)
+    d_ref = torch.cat([z[:, 1:] - z[:, :-1], torch.full((7, 1), 2.0 / 16)], -1)
+    assert torch.equal(dists.cpu(), d_ref) and torch.equal(mid.cpu(), z + d_ref * 0.5)
+
+
+def make_fields(B, n, seed):
+    from fneus import synth
+    from oracle import ref_torch as R
+    rs = np.random.RandomState(seed)
+    data = T(synth.ray_batch(B, seed=seed, n_miss=2))
+    ro, rd = data[:, :3].contiguous(), data[:, 3:6].contiguous()
+    near, far = R.near_far_from_sphere(ro, rd)
+    z = torch.sort(near + (far - near) * T(rs.uniform(0, 1, size=(B, n)).astype(np.float32)), dim=-1)[0]
+    dists = torch.cat([z[:, 1:] - z[:, :-1], torch.full((B, 1), 2.0 / 64)], -1)
+    mid_z = z + dists * 0.5
+    pts = ro[:, None, :] + rd[:, None, :] * mid_z[..., None]
+    sdf = (pts.norm(dim=-1) - 0.6 + 0.03 * torch.sin(9 * pts[..., 1])).reshape(-1)
+    sdf[: n] = sdf[:n].abs() + 0.01          # ray 0: never negative
+    normal = pts.reshape(-1, 3) / pts.reshape(-1, 3).norm(dim=-1, keepdim=True) * T(rs.uniform(0.7, 1.3, size=(B * n, 1)).astype(np.float32))
+    normal = normal + 0.1 * T(rs.standard_normal((B * n, 3)).astype(np.float32))
+    rgb = T(rs.uniform(0, 1, size=(B * n, 3)).astype(np.float32))
+    return ro, rd, mid_z.contiguous(), dists.contiguous(), sdf.contiguous(), normal.contiguous(), rgb
+
+
+@pytest.mark.parametrize("n,car,inv_s", [(128, 1.0, 20.0), (32, 0.3, 80.0), (160, 0.0, 300.0), (37, 1.0, 50.0)])
+def test_composite_fwd_bwd(n, car, inv_s):
+    from fneus import ops
+    from oracle import ref_torch as R
+    B = 24
+    ro, rd, mid_z, dists, sdf, normal, rgb = make_fields(B, n, seed=n)
+    rs = np.random.RandomState(n + 1)
+    # oracle in fp64 with autograd
+    sdf64 = sdf.double().requires_grad_(True)
+    nrm64 = normal.double().requires_grad_(True)
+    rgb64 = rgb.double().requires_grad_(True)
+    s64 = torch.tensor(inv_s, dtype=torch.float64, requires_grad=True)
+    ref = R.composite_from_fields(ro.double(), rd.double(), mid_z.double(), dists.double(), sdf64, nrm64, rgb64, s64, car)
+    c_col = T(rs.standard_normal((B, 3)))
+    c_ws = T(rs.standard_normal(B))
+    c_w = T(rs.standard_normal((B, n)) * 0.1)
+    c_pair = T(rs.standard_normal((B, 2)))
+    c_eik = T(rs.standard_normal(B) * 0.01)
+    L = (ref["color"] * c_col).sum() + (ref["wsum"] * c_ws).sum() + (ref["weights"] * c_w).sum() + \
+        (ref["wpair"] * c_pair).sum() + (ref["eik_num"] * c_eik).sum()
+    L.backward()
+    # HIP
+    d = lambda t: t.float().to(DEV).contiguous()
+    inv_s_dev = torch.tensor([inv_s], dtype=torch.float32, device=DEV)
+    out = ops.composite_fwd(d(ro), d(rd), d(mid_z), d(dists), d(sdf), d(normal), d(rgb), inv_s_dev, car)
+    assert torch.equal(out["sdf_mask"].cpu().bool(), ref["sdf_mask"])
+    m = ref["sdf_mask"]
+    assert torch.equal(out["min_idx"].cpu().long()[m], ref["min_idx"][m])
+    assert torch.equal(out["inside"].cpu().double(), ref["inside"])
+    for k, rk in (("weights", "weights"), ("color", "color"), ("wsum", "wsum"), ("wmax", "wmax"), ("cdf", "cdf"),
+                  ("wpair", "wpair")):
+        e = (out[k].cpu().double() - ref[rk].detach()).abs().max().item()
+        assert e <= 2e-6, (k, e)
+    assert (out["eik"][:, 0].cpu().double() - ref["eik_num"].detach()).abs().max().item() <= 1e-5
+    assert torch.equal(out["eik"][:, 1].cpu().double(), ref["eik_den"])
+    d_sdf, d_nrm, d_rgb, d_inv = ops.composite_bwd(d(ro), d(rd), d(mid_z), d(dists), d(sdf), d(normal), d(rgb), inv_s_dev, car,
+                                                   out["min_idx"], out["sdf_mask"], d(c_col), d(c_ws), d(c_w), d(c_pair),
+                                                   d(c_eik))
+
+    def rel(a, b):
+        return ((a.cpu().double() - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+    e1, e2, e3 = rel(d_sdf, sdf64.grad), rel(d_nrm, nrm64.grad), rel(d_rgb, rgb64.grad)
+    e4 = abs(d_inv.sum().item() - s64.grad.item()) / (abs(s64.grad.item()) + 1e-30)
+    print(f"composite_bwd n={n}: d_sdf {e1:.2e} d_normal {e2:.2e} d_rgb {e3:.2e} d_inv_s {e4:.2e}")
+    assert e1 <= 2e-4 and e2 <= 2e-4 and e3 <= 1e-5 and e4 <= 2e-4
