@@ -1,0 +1,123 @@
+"""torch.autograd glue between the HIP ops (torch is plumbing: it owns memory, streams and the graph).
+
+Each Function wraps one forward kernel and its hand-written backward kernels; the maths lives in csrc/.
+Points are never differentiated (all z values are produced under no_grad in the reference, renderer.py:188, 426).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+
+
+class RaySamples:
+    """Sample positions p = rays_o[n // m] + rays_d[n // m] * t[n]  (or explicit pts)."""
+
+    def __init__(self, rays_o=None, rays_d=None, t=None, m: int = 1, pts=None, dirs=None):
+        self.rays_o, self.rays_d, self.t, self.m, self.pts, self.dirs = rays_o, rays_d, t, m, pts, dirs
+        self.n = int(pts.shape[0]) if pts is not None else int(t.numel())
+
+    def kw(self):
+        return dict(pts=self.pts, rays_o=self.rays_o, rays_d=self.rays_d, t=self.t, m=self.m)
+
+
+class _Workspace:
+    """Per-network cache of stash / work buffers keyed by (n, prec): allocated once, reused every step."""
+
+    def __init__(self):
+        self.cache = {}
+
+    def get(self, key, factory):
+        if key not in self.cache:
+            self.cache[key] = factory()
+        return self.cache[key]
+
+
+class SdfValueGradFn(torch.autograd.Function):
+    """K2 forward, K3 + weight-gradient GEMM backward.  Inputs: flat effective parameters (for the graph only; the
+    blob was packed from the same tensor by SDFNetwork.refresh)."""
+
+    @staticmethod
+    def forward(ctx, flat, net, samples: RaySamples, prec: int, ws: _Workspace, train: bool):
+        n = samples.n
+        stash = ws.get(("sdf_stash", n, prec, train), lambda: ops.SdfStash(n, flat.device, prec, train))
+        sdf, feat, normal = ops.sdf_fwd_grad(net.blob, n, prec, stash, train, **samples.kw())
+        ctx.net, ctx.samples, ctx.prec, ctx.ws, ctx.stash, ctx.n = net, samples, prec, ws, stash, n
+        ctx.mark_non_differentiable()
+        return sdf, feat, normal
+
+    @staticmethod
+    def backward(ctx, d_sdf, d_feat, d_normal):
+        n, prec, net, ws = ctx.n, ctx.prec, ctx.net, ctx.ws
+        dev = d_feat.device if d_feat is not None else (d_sdf.device if d_sdf is not None else d_normal.device)
+        d_sdf = torch.zeros(n, device=dev) if d_sdf is None else d_sdf.contiguous()
+        d_feat = torch.zeros(n, 256, device=dev) if d_feat is None else d_feat.contiguous()
+        d_normal = torch.zeros(n, 3, device=dev) if d_normal is None else d_normal.contiguous()
+        bufs = ws.get(("sdf_bwd", n, prec), lambda: ops.SdfBwdBufs(n, dev, prec))
+        ops.sdf_bwd(net.blob, n, prec, ctx.stash, bufs, d_sdf, d_feat, d_normal, **ctx.samples.kw())
+        grad = ws.get(("sdf_grad", n), lambda: torch.empty(net.n_params, dtype=torch.float32, device=dev))
+        grad.zero_()
+        jobs = ws.get(("sdf_jobs", n, prec), lambda: ops.sdf_dw_jobs(net, ctx.stash, bufs, grad, n))
+        jobs.run(n, prec)
+        return grad.clone(), None, None, None, None, None
+
+
+class ColorFn(torch.autograd.Function):
+    """K4 forward / backward (+ weight-gradient GEMM).  Differentiable inputs: flat params, normal, feature."""
+
+    @staticmethod
+    def forward(ctx, flat, normal, feat, net, samples: RaySamples, prec: int, ws: _Workspace, sdf_ws: _Workspace,
+                train: bool):
+        n = samples.n
+        stash = ws.get(("col_stash", n, prec), lambda: ops.ColStash(n, flat.device, prec)) if train else None
+        rgb = ops.color_fwd(net.blob, n, prec, normal.contiguous(), feat.contiguous(), stash, train, dirs=samples.dirs,
+                            **samples.kw())
+        ctx.net, ctx.prec, ctx.ws, ctx.sdf_ws, ctx.stash, ctx.n = net, prec, ws, sdf_ws, stash, n
+        ctx.save_for_backward(rgb)
+        return rgb
+
+    @staticmethod
+    def backward(ctx, d_rgb):
+        (rgb,) = ctx.saved_tensors
+        n, prec, net, ws = ctx.n, ctx.prec, ctx.net, ctx.ws
+        d_feat, d_normal = ops.color_bwd(net.blob, n, prec, d_rgb.contiguous(), rgb, ctx.stash)
+        grad = ws.get(("col_grad", n), lambda: torch.empty(net.n_params, dtype=torch.float32, device=rgb.device))
+        grad.zero_()
+        sdf_stash = ctx.sdf_ws.cache[("sdf_stash", n, prec, True)]
+        jobs = ws.get(("col_jobs", n, prec), lambda: ops.color_dw_jobs(net, sdf_stash, ctx.stash, grad, n))
+        jobs.run(n, prec)
+        return grad.clone(), d_normal, d_feat, None, None, None, None, None, None
+
+
+class CompositeFn(torch.autograd.Function):
+    """K5 forward / backward.  Differentiable inputs: sdf [N], normal [N,3], rgb [N,3], inv_s [1].
+    Differentiable outputs: color [B,3], weights [B,n], wsum [B], wpair [B,2], eik_num [B]."""
+
+    @staticmethod
+    def forward(ctx, sdf, normal, rgb, inv_s, rays_o, rays_d, mid_z, dists, car: float):
+        out = ops.composite_fwd(rays_o, rays_d, mid_z, dists, sdf.contiguous(), normal.contiguous(), rgb.contiguous(),
+                                inv_s.contiguous(), car)
+        ctx.car = car
+        ctx.save_for_backward(sdf, normal, rgb, inv_s, rays_o, rays_d, mid_z, dists, out["min_idx"], out["sdf_mask"])
+        eik_num, eik_den = out["eik"][:, 0].contiguous(), out["eik"][:, 1].contiguous()
+        nd = (out["wmax"], out["cdf"], out["inside"], eik_den, out["min_idx"], out["sdf_mask"])
+        ctx.mark_non_differentiable(*nd)
+        return (out["color"], out["weights"], out["wsum"], out["wpair"], eik_num) + nd
+
+    @staticmethod
+    def backward(ctx, d_color, d_weights, d_wsum, d_wpair, d_eiknum, *unused):
+        sdf, normal, rgb, inv_s, rays_o, rays_d, mid_z, dists, min_idx, sdf_mask = ctx.saved_tensors
+        B, n = mid_z.shape
+        dev = mid_z.device
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        d_color = z(B, 3) if d_color is None else d_color.contiguous()
+        d_wsum = z(B) if d_wsum is None else d_wsum.contiguous()
+        d_wpair = z(B, 2) if d_wpair is None else d_wpair.contiguous()
+        d_eiknum = z(B) if d_eiknum is None else d_eiknum.contiguous()
+        d_weights = None if d_weights is None else d_weights.contiguous()
+        d_sdf, d_normal, d_rgb, d_inv = ops.composite_bwd(rays_o, rays_d, mid_z, dists, sdf, normal, rgb, inv_s, ctx.car,
+                                                          min_idx, sdf_mask, d_color, d_wsum, d_weights, d_wpair,
+                                                          d_eiknum)
+        return d_sdf, d_normal, d_rgb, d_inv.sum().reshape(1), None, None, None, None, None

@@ -1,0 +1,279 @@
+"""Network modules with the reference's class API and state_dict keys (models/fields.py), HIP backend.
+
+  SDFNetwork / RenderingNetwork : parameters live here as torch Parameters named exactly like the reference
+      (lin{l}.weight_g / weight_v / bias: old-style nn.utils.weight_norm, fields.py:67-70, 139-140) so checkpoints
+      interchange; the maths runs in libfneus_hip.so.  Only the architecture of confs/wmask.conf / womask.conf is
+      supported by the fused kernels -- anything else raises (there is no fallback path).
+  SingleVarianceNetwork, RefColor, NeRF : small torch modules (scalar / <= 2 samples per ray / womask background).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from fneus import ops
+from fneus.autograd import RaySamples, SdfValueGradFn, ColorFn, _Workspace
+from models.embedder import get_embedder
+
+
+class WNLinear(nn.Module):
+    """Parameters of a weight-normalised Linear with the reference's names: weight_g [out,1], weight_v [out,in], bias."""
+
+    def __init__(self, in_dim, out_dim, weight_norm=True):
+        super().__init__()
+        self.weight_norm = weight_norm
+        w = torch.empty(out_dim, in_dim)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        bound = 1 / math.sqrt(in_dim)
+        b = torch.empty(out_dim).uniform_(-bound, bound)
+        self.bias = nn.Parameter(b)
+        if weight_norm:
+            self.weight_g = nn.Parameter(w.norm(dim=1, keepdim=True))
+            self.weight_v = nn.Parameter(w)
+        else:
+            self.weight = nn.Parameter(w)
+
+    def set_weight(self, w, b):
+        with torch.no_grad():
+            self.bias.copy_(b)
+            if self.weight_norm:
+                self.weight_v.copy_(w)
+                self.weight_g.copy_(w.norm(dim=1, keepdim=True))
+            else:
+                self.weight.copy_(w)
+
+    def effective_weight(self):
+        if not self.weight_norm:
+            return self.weight
+        return self.weight_v * (self.weight_g / self.weight_v.norm(dim=1, keepdim=True))
+
+
+class _HipMLP(nn.Module):
+    """Shared plumbing: flat effective parameters -> packed blob (once per optimiser step)."""
+
+    kind = None
+
+    def _init_backend(self):
+        self._net = None
+        self._ws = _Workspace()
+        self._flat = None
+        self.prec = ops.PREC_PARITY
+
+    def set_precision(self, prec: int):
+        assert prec in (ops.PREC_FAST, ops.PREC_PARITY)
+        self.prec = prec
+
+    def _lins(self):
+        return [getattr(self, f"lin{l}") for l in range(self.num_layers - 1)]
+
+    def refresh(self):
+        """Fold weight-norm (torch, differentiable) and pack for the kernels.  Call once per step before rendering."""
+        dev = self.lin0.bias.device
+        if dev.type != "cuda":
+            raise RuntimeError("the fneus HIP backend needs the module on a GPU (there is no CPU fallback)")
+        if self._net is None or self._net.device != dev:
+            self._net = ops.PackedNet(self.kind, dev)
+        parts = []
+        for lin in self._lins():
+            parts.append(lin.effective_weight().reshape(-1))
+            parts.append(lin.bias.reshape(-1))
+        self._flat = torch.cat(parts)
+        self._net.pack(self._flat.detach().contiguous())
+        return self._flat
+
+    def _ensure(self):
+        if self._flat is None:
+            self.refresh()
+
+
+class SDFNetwork(_HipMLP):
+    kind = "sdf"
+
+    def __init__(self, d_in, d_out, d_hidden, n_layers, skip_in=(4,), multires=0, bias=0.5, scale=1, geometric_init=True,
+                 weight_norm=True, inside_outside=False):
+        super().__init__()
+        if not (d_in == 3 and d_out == 257 and d_hidden == 256 and n_layers == 8 and tuple(skip_in) == (4,)
+                and multires == 6 and float(scale) == 1.0):
+            raise NotImplementedError("fneus HIP kernels are specialised for the reference SDF architecture "
+                                      "(confs/wmask.conf:60-71: 3->PE6->8x256 skip 4 ->257, scale 1)")
+        dims = [39] + [d_hidden] * n_layers + [d_out]
+        self.num_layers = len(dims)
+        self.skip_in = tuple(skip_in)
+        self.scale = scale
+        for l in range(self.num_layers - 1):
+            out_dim = dims[l + 1] - dims[0] if (l + 1) in self.skip_in else dims[l + 1]
+            lin = WNLinear(dims[l], out_dim, weight_norm)
+            if geometric_init:      # fields.py:47-65
+                w = torch.empty(out_dim, dims[l])
+                b = torch.zeros(out_dim)
+                if l == self.num_layers - 2:
+                    sgn = -1.0 if inside_outside else 1.0
+                    nn.init.normal_(w, mean=sgn * math.sqrt(math.pi) / math.sqrt(dims[l]), std=0.0001)
+                    b.fill_(-sgn * bias)
+                elif l == 0:
+                    w.zero_()
+                    nn.init.normal_(w[:, :3], 0.0, math.sqrt(2) / math.sqrt(out_dim))
+                elif l in self.skip_in:
+                    nn.init.normal_(w, 0.0, math.sqrt(2) / math.sqrt(out_dim))
+                    w[:, -(dims[0] - 3):] = 0.0
+                else:
+                    nn.init.normal_(w, 0.0, math.sqrt(2) / math.sqrt(out_dim))
+                lin.set_weight(w, b)
+            setattr(self, "lin" + str(l), lin)
+        self._init_backend()
+
+    # ---- hot-path entry points used by NeuSRenderer ----
+    def sdf_samples(self, samples: RaySamples) -> torch.Tensor:
+        """no-grad SDF values [n] (K1)"""
+        self._ensure()
+        return ops.sdf_fwd(self._net.blob, samples.n, self.prec, **samples.kw())
+
+    def value_feature_normal(self, samples: RaySamples, train: bool):
+        """sdf [n], feature [n,256], normal [n,3] in one fused pass (K2), differentiable w.r.t. the parameters"""
+        self._ensure()
+        return SdfValueGradFn.apply(self._flat, self._net, samples, self.prec, self._ws, train)
+
+    # ---- reference API (fields.py:74-111) ----
+    def forward(self, inputs, iter_step=0):
+        pts = inputs.detach().reshape(-1, 3).float().contiguous()
+        sdf, feat, _ = self.value_feature_normal(RaySamples(pts=pts), train=torch.is_grad_enabled())
+        return torch.cat([sdf[:, None], feat], dim=-1)
+
+    def sdf(self, x):
+        pts = x.detach().reshape(-1, 3).float().contiguous()
+        return self.sdf_samples(RaySamples(pts=pts))[:, None]
+
+    def sdf_hidden_appearance(self, x):
+        return self.forward(x)
+
+    def gradient(self, x):
+        pts = x.detach().reshape(-1, 3).float().contiguous()
+        _, _, normal = self.value_feature_normal(RaySamples(pts=pts), train=torch.is_grad_enabled())
+        return normal.unsqueeze(1)
+
+
+class RenderingNetwork(_HipMLP):
+    kind = "color"
+
+    def __init__(self, d_feature, mode, d_in, d_out, d_hidden, n_layers, weight_norm=True, multires_view=0,
+                 squeeze_out=True):
+        super().__init__()
+        if not (d_feature == 256 and mode == "idr" and d_in == 9 and d_out == 3 and d_hidden == 256 and n_layers == 4
+                and multires_view == 4 and squeeze_out):
+            raise NotImplementedError("fneus HIP kernels are specialised for the reference colour architecture "
+                                      "(confs/wmask.conf:77-87: idr, 289->4x256->3, PE4 view, sigmoid)")
+        self.mode, self.squeeze_out = mode, squeeze_out
+        dims = [d_in + d_feature + 24] + [d_hidden] * n_layers + [d_out]
+        self.num_layers = len(dims)
+        for l in range(self.num_layers - 1):
+            setattr(self, "lin" + str(l), WNLinear(dims[l], dims[l + 1], weight_norm))
+        self._init_backend()
+
+    def color_samples(self, samples: RaySamples, normal, feat, sdf_net: SDFNetwork, train: bool):
+        self._ensure()
+        return ColorFn.apply(self._flat, normal, feat, self._net, samples, self.prec, self._ws, sdf_net._ws, train)
+
+    def forward(self, points, normals, view_dirs, feature_vectors):
+        s = RaySamples(pts=points.detach().float().contiguous(), dirs=view_dirs.detach().float().contiguous())
+        self._ensure()
+        # stand-alone use (not through the renderer): no weight gradients, activations are not stashed
+        with torch.no_grad():
+            return ops.color_fwd(self._net.blob, s.n, self.prec, normals.float().contiguous(),
+                                 feature_vectors.float().contiguous(), None, False, dirs=s.dirs, **s.kw())
+
+
+class SingleVarianceNetwork(nn.Module):
+    """fields.py:262-268"""
+
+    def __init__(self, init_val):
+        super().__init__()
+        self.register_parameter("variance", nn.Parameter(torch.tensor(float(init_val))))
+
+    def forward(self, x):
+        return torch.ones([len(x), 1], device=self.variance.device) * torch.exp(self.variance * 10.0)
+
+    def inv_s(self):
+        return torch.exp(self.variance * 10.0).clip(1e-6, 1e6).reshape(1)      # renderer.py:245
+
+
+def _l2_normalize(x):
+    eps = torch.finfo(torch.float32).eps
+    return x / torch.sqrt(torch.clamp(torch.sum(x * x, dim=-1, keepdim=True), min=eps))
+
+
+def _linear_to_srgb(linear):
+    eps = torch.finfo(torch.float32).eps
+    srgb0 = 323.0 / 25.0 * linear
+    srgb1 = (211.0 * torch.clamp(linear, min=eps) ** (5.0 / 12.0) - 11.0) / 200.0
+    return torch.where(linear <= 0.0031308, srgb0, srgb1)
+
+
+class RefColor(nn.Module):
+    """Diffuse + specular surface colour at the two samples bracketing the first SDF sign change (fields.py:271-335).
+    <= 2 samples per ray: plain torch.  state_dict keys as in the reference (net_cd.*, viewdir_mlp.*, net_cs.0)."""
+
+    def __init__(self):
+        super().__init__()
+        self.embedview_fn, _ = get_embedder(4)
+        self.net_cd = nn.Sequential(nn.Linear(286, 256), nn.ReLU(), nn.Linear(256, 256), nn.ReLU(), nn.Linear(256, 256),
+                                    nn.ReLU(), nn.Linear(256, 256), nn.ReLU(), nn.Linear(256, 3), nn.Sigmoid())
+        self.viewdir_mlp = nn.ModuleList([nn.Linear(289, 256)] + [nn.Linear(256, 256) for _ in range(3)])
+        self.net_cs = nn.Sequential(nn.Linear(256, 1), nn.Sigmoid())
+
+    def forward(self, pts, x, dirs, n):
+        normals = _l2_normalize(n)
+        n_enc = self.embedview_fn(n)
+        ref_dirs = 2.0 * torch.sum(-dirs * normals, dim=-1, keepdim=True) * normals + dirs
+        ref_enc = self.embedview_fn(ref_dirs)
+        diffuse = self.net_cd(torch.cat([pts, n_enc, x], dim=-1))
+        x2 = torch.cat([n, pts, ref_enc, x], dim=-1)
+        for layer in self.viewdir_mlp:
+            x2 = F.relu(layer(x2))
+        spec = self.net_cs(x2).repeat(1, 3)
+        return {"rgb": torch.clip(_linear_to_srgb(spec + diffuse), 0.0, 1.0),
+                "specular_rgb": torch.clip(_linear_to_srgb(spec), 0.0, 1.0),
+                "diffuse_rgb": torch.clip(_linear_to_srgb(diffuse), 0.0, 1.0)}
+
+
+class NeRF(nn.Module):
+    """Background NeRF++ (fields.py:178-259); only evaluated when n_outside > 0 (womask)."""
+
+    def __init__(self, D=8, W=256, d_in=3, d_in_view=3, multires=0, multires_view=0, output_ch=4, skips=(4,),
+                 use_viewdirs=False):
+        super().__init__()
+        self.D, self.W, self.skips, self.use_viewdirs = D, W, tuple(skips), use_viewdirs
+        self.embed_fn, self.input_ch = (get_embedder(multires, input_dims=d_in) if multires > 0 else (None, 3))
+        self.embed_fn_view, self.input_ch_view = (get_embedder(multires_view, input_dims=d_in_view)
+                                                  if multires_view > 0 else (None, 3))
+        self.pts_linears = nn.ModuleList(
+            [nn.Linear(self.input_ch, W)] +
+            [nn.Linear(W, W) if i not in self.skips else nn.Linear(W + self.input_ch, W) for i in range(D - 1)])
+        self.views_linears = nn.ModuleList([nn.Linear(self.input_ch_view + W, W // 2)])
+        if use_viewdirs:
+            self.feature_linear = nn.Linear(W, W)
+            self.alpha_linear = nn.Linear(W, 1)
+            self.rgb_linear = nn.Linear(W // 2, 3)
+        else:
+            self.output_linear = nn.Linear(W, output_ch)
+
+    def forward(self, input_pts, input_views):
+        if self.embed_fn is not None:
+            input_pts = self.embed_fn(input_pts)
+        if self.embed_fn_view is not None:
+            input_views = self.embed_fn_view(input_views)
+        h = input_pts
+        for i in range(len(self.pts_linears)):
+            h = F.relu(self.pts_linears[i](h))
+            if i in self.skips:
+                h = torch.cat([input_pts, h], -1)
+        if not self.use_viewdirs:
+            raise AssertionError("NeRF without view directions is not used by the reference (fields.py:258-259)")
+        alpha = self.alpha_linear(h)
+        feature = self.feature_linear(h)
+        h = torch.cat([feature, input_views], -1)
+        h = F.relu(self.views_linears[0](h))
+        return alpha, self.rgb_linear(h)

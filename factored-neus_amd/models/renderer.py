@@ -1,0 +1,193 @@
+"""NeuSRenderer with the reference's API (models/renderer.py:80-500), stage-1 hot path on HIP kernels.
+
+render() produces the reference's 13-key dict.  Every per-ray-sample operation runs in libfneus_hip.so:
+  sampler  : fneus_sdf_fwd (K1) + fneus_upsample / fneus_merge (K6)              renderer.py:425-449
+  core     : fneus_sections, fneus_sdf_fwd_grad (K2), fneus_color_fwd (K4), fneus_composite_fwd (K5)   :208-389
+  backward : the hand-written adjoints, reached through torch.autograd (fneus/autograd.py)
+torch only allocates, wires the graph, runs the <= 2-samples-per-ray RefColor branch and the scalar losses.
+
+Differences from the reference that a caller can observe:
+  * tensors live on the device of the networks (no global default-device trick, exp_runner.py:638-641);
+  * the surface branch is evaluated at fixed shape (all rays, masked) so there is no host sync per step; rows outside
+    sdf_mask are 1.0 exactly as in the reference (renderer.py:280-282).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from fneus import ops
+from fneus.autograd import CompositeFn, RaySamples
+
+
+def sample_pdf(bins, weights, n_samples, det=False):
+    """reference module-level helper (renderer.py:43-77); the hot path uses the fused fneus_upsample instead."""
+    weights = weights + 1e-5
+    pdf = weights / torch.sum(weights, -1, keepdim=True)
+    cdf = torch.cumsum(pdf, -1)
+    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
+    if det:
+        u = torch.linspace(0.5 / n_samples, 1.0 - 0.5 / n_samples, steps=n_samples, device=bins.device)
+        u = u.expand(list(cdf.shape[:-1]) + [n_samples])
+    else:
+        u = torch.rand(list(cdf.shape[:-1]) + [n_samples], device=bins.device)
+    u = u.contiguous()
+    inds = torch.searchsorted(cdf, u, right=True)
+    below = (inds - 1).clamp(min=0)
+    above = inds.clamp(max=cdf.shape[-1] - 1)
+    cdf_b, cdf_a = torch.gather(cdf, -1, below), torch.gather(cdf, -1, above)
+    bin_b, bin_a = torch.gather(bins, -1, below), torch.gather(bins, -1, above)
+    denom = cdf_a - cdf_b
+    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
+    return bin_b + (u - cdf_b) / denom * (bin_a - bin_b)
+
+
+class NeuSRenderer:
+    def __init__(self, n_samples, n_importance, n_outside, up_sample_steps, perturb, nerf=None, sdf_network=None,
+                 deviation_network=None, color_network=None, refColor_network=None, lvis_network=None,
+                 indiLgt_network=None, mateIllu_network=None):
+        self.nerf = nerf
+        self.sdf_network = sdf_network
+        self.deviation_network = deviation_network
+        self.color_network = color_network
+        self.refColor_network = refColor_network
+        self.lvis_network = lvis_network
+        self.indiLgt_network = indiLgt_network
+        self.mateIllu_network = mateIllu_network
+        self.n_samples = n_samples
+        self.n_importance = n_importance
+        self.n_outside = n_outside
+        self.up_sample_steps = up_sample_steps
+        self.perturb = perturb
+
+    # ---- reference-compatible pieces (renderer.py:152-205) ------------------------------------------------------
+    def up_sample(self, rays_o, rays_d, z_vals, sdf, n_importance, inv_s):
+        B, m = z_vals.shape
+        return ops.upsample(rays_o.contiguous(), rays_d.contiguous(), z_vals.contiguous(),
+                            sdf.reshape(B, m).contiguous(), n_importance, float(inv_s))
+
+    def cat_z_vals(self, rays_o, rays_d, z_vals, new_z_vals, sdf, last=False):
+        B, k = new_z_vals.shape
+        if last:
+            z, _ = ops.merge(z_vals.contiguous(), None, new_z_vals.contiguous(), None)
+            return z, sdf
+        new_sdf = self.sdf_network.sdf_samples(
+            RaySamples(rays_o, rays_d, new_z_vals.reshape(-1).contiguous(), k)).reshape(B, k)
+        return ops.merge(z_vals.contiguous(), sdf.contiguous(), new_z_vals.contiguous(), new_sdf)
+
+    def _hierarchical_z(self, rays_o, rays_d, z_vals):
+        B, n = z_vals.shape
+        with torch.no_grad():
+            sdf = self.sdf_network.sdf_samples(RaySamples(rays_o, rays_d, z_vals.reshape(-1).contiguous(), n)).reshape(B, n)
+            k = self.n_importance // self.up_sample_steps
+            for i in range(self.up_sample_steps):
+                new_z = self.up_sample(rays_o, rays_d, z_vals, sdf, k, 64 * 2 ** i)
+                z_vals, sdf = self.cat_z_vals(rays_o, rays_d, z_vals, new_z, sdf, last=(i + 1 == self.up_sample_steps))
+        return z_vals
+
+    # ---- render_core (renderer.py:208-389) ------------------------------------------------------------------------
+    def render_core(self, rays_o, rays_d, z_vals, sample_dist, sdf_network, deviation_network, color_network,
+                    refColor_network, background_alpha=None, background_sampled_color=None, background_rgb=None,
+                    cos_anneal_ratio=0.0):
+        if background_alpha is not None:
+            raise NotImplementedError("n_outside > 0 (womask background NeRF) is not on the HIP path yet")
+        B, n = z_vals.shape
+        train = torch.is_grad_enabled()
+        dists, mid_z = ops.sections(z_vals.contiguous(), sample_dist)
+        samples = RaySamples(rays_o, rays_d, mid_z.reshape(-1), n)
+        sdf, feat, normal = sdf_network.value_feature_normal(samples, train)
+        inv_s = deviation_network.inv_s()
+        rgb = color_network.color_samples(samples, normal, feat, sdf_network, train)
+        (color, weights, wsum, wpair, eik_num, wmax, cdf, inside, eik_den, min_idx, sdf_mask_u8) = CompositeFn.apply(
+            sdf, normal, rgb, inv_s, rays_o, rays_d, mid_z, dists, float(cos_anneal_ratio))
+        sdf_mask = sdf_mask_u8.bool()
+        gradient_error = eik_num.sum() / (eik_den.sum() + 1e-5)                        # renderer.py:370-372
+
+        # surface branch at fixed shape (renderer.py:284-343): the two samples bracketing the first sign change
+        ones = torch.ones(B, 3, device=z_vals.device)
+        specular_color = diffuse_color = surface_color = ones
+        if refColor_network is not None:
+            hi = torch.where(sdf_mask, min_idx.long(), torch.ones_like(min_idx, dtype=torch.long))
+            rows = torch.arange(B, device=z_vals.device) * n
+            sel = torch.stack([rows + hi - 1, rows + hi], dim=1).reshape(-1)                # low, high interleaved
+            pts_sel = rays_o.repeat_interleave(2, 0) + rays_d.repeat_interleave(2, 0) * mid_z.reshape(-1)[sel][:, None]
+            ref = refColor_network(pts_sel, feat[sel], rays_d.repeat_interleave(2, 0), normal[sel])
+            w_lo, w_hi = wpair[:, 0:1] + 1e-5, wpair[:, 1:2] + 1e-5
+
+            def blend(v):
+                v = v.reshape(B, 2, 3)
+                return torch.where(sdf_mask[:, None], (v[:, 0] * w_lo + v[:, 1] * w_hi) / (w_lo + w_hi), ones)
+
+            specular_color, diffuse_color, surface_color = blend(ref["specular_rgb"]), blend(ref["diffuse_rgb"]), blend(ref["rgb"])
+
+        if background_rgb is not None:
+            color = color + background_rgb * (1.0 - wsum[:, None])
+        return {
+            "color": color, "surface_color": surface_color, "sdf_mask": sdf_mask, "sdf": sdf[:, None], "dists": dists,
+            "gradients": normal.reshape(B, n, 3), "s_val": (1.0 / inv_s).expand(B * n, 1), "mid_z_vals": mid_z,
+            "weights": weights, "cdf": cdf, "gradient_error": gradient_error, "inside_sphere": inside,
+            "specular_color": specular_color, "diffuse_color": diffuse_color, "weight_max": wmax, "weight_sum": wsum,
+        }
+
+    # ---- render (renderer.py:391-500) -------------------------------------------------------------------------------
+    def render(self, rays_o, rays_d, near, far, perturb_overwrite=-1, background_rgb=None, cos_anneal_ratio=0.0,
+               z_vals_override=None):
+        dev = rays_o.device
+        rays_o, rays_d = rays_o.float().contiguous(), rays_d.float().contiguous()
+        B = len(rays_o)
+        sample_dist = 2.0 / self.n_samples
+        z_vals = torch.linspace(0.0, 1.0, self.n_samples, device=dev)
+        z_vals = near + (far - near) * z_vals[None, :]
+        if self.n_outside > 0:
+            raise NotImplementedError("n_outside > 0 (womask background NeRF) is not on the HIP path yet")
+        perturb = self.perturb if perturb_overwrite < 0 else perturb_overwrite
+        if perturb > 0:
+            t_rand = torch.rand([B, 1], device=dev) - 0.5
+            z_vals = z_vals + t_rand * 2.0 / self.n_samples
+        # networks changed since the last call (optimiser step): fold weight-norm and re-pack once
+        self.sdf_network.refresh()
+        self.color_network.refresh()
+        n = self.n_samples
+        if self.n_importance > 0:
+            if z_vals_override is not None:
+                z_vals = z_vals_override
+            else:
+                z_vals = self._hierarchical_z(rays_o, rays_d, z_vals.contiguous())
+            n = self.n_samples + self.n_importance
+        ret = self.render_core(rays_o, rays_d, z_vals, sample_dist, self.sdf_network, self.deviation_network,
+                               self.color_network, self.refColor_network, background_rgb=background_rgb,
+                               cos_anneal_ratio=cos_anneal_ratio)
+        weights = ret["weights"]
+        return {
+            "color_fine": ret["color"],
+            "surface_color": ret["surface_color"],
+            "sdf_mask": ret["sdf_mask"],
+            "s_val": ret["s_val"].reshape(B, n).mean(dim=-1, keepdim=True),
+            "cdf_fine": ret["cdf"],
+            "weight_sum": ret["weight_sum"][:, None],
+            "weight_max": ret["weight_max"][:, None],
+            "gradients": ret["gradients"],
+            "weights": weights,
+            "gradient_error": ret["gradient_error"],
+            "inside_sphere": ret["inside_sphere"],
+            "specular_color": ret["specular_color"],
+            "diffuse_color": ret["diffuse_color"],
+            # extras (not in the reference dict; used by the parity tests)
+            "_z_vals": z_vals, "_sdf": ret["sdf"], "_mid_z_vals": ret["mid_z_vals"],
+        }
+
+    def extract_sdf_grid(self, bound_min, bound_max, resolution):
+        """SDF on a regular grid (the compute part of extract_fields, renderer.py:14-29), chunked through K1."""
+        dev = self.sdf_network.lin0.bias.device
+        self.sdf_network.refresh()
+        xs = [torch.linspace(float(bound_min[i]), float(bound_max[i]), resolution, device=dev) for i in range(3)]
+        u = torch.empty(resolution, resolution, resolution, device=dev)
+        N = 64
+        with torch.no_grad():
+            for xi in range(0, resolution, N):
+                for yi in range(0, resolution, N):
+                    xx, yy, zz = torch.meshgrid(xs[0][xi:xi + N], xs[1][yi:yi + N], xs[2], indexing="ij")
+                    pts = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], -1).contiguous()
+                    val = self.sdf_network.sdf_samples(RaySamples(pts=pts))
+                    u[xi:xi + N, yi:yi + N, :] = -val.reshape(xx.shape)
+        return u

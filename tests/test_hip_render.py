@@ -1,0 +1,137 @@
+"""GPU parity of the whole NeuSRenderer.render (HIP backend) against fixtures produced by the reference itself
+(tests/golden/render_*.npz) and against the CPU oracle.  Tolerances: 1e-4 absolute on colours / weights / sdf in
+parity mode (BASELINE.json north_star); gradients relative to each tensor's scale."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+RAY_KEYS = ("color_fine", "surface_color", "weight_sum", "gradient_error", "specular_color", "diffuse_color", "s_val")
+SAMPLE_KEYS = ("cdf_fine", "weight_max", "gradients", "weights", "inside_sphere")
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name + ".npz")))
+
+
+def build(g, prec):
+    from fneus import synth
+    from models.fields import SDFNetwork, RenderingNetwork, SingleVarianceNetwork, RefColor, NeRF
+    from models.renderer import NeuSRenderer
+    sdf = SDFNetwork(d_out=257, d_in=3, d_hidden=256, n_layers=8, skip_in=[4], multires=6, bias=0.5, scale=1.0,
+                     geometric_init=True, weight_norm=True)
+    col = RenderingNetwork(d_feature=256, mode="idr", d_in=9, d_out=3, d_hidden=256, n_layers=4, weight_norm=True,
+                           multires_view=4, squeeze_out=True)
+    var = SingleVarianceNetwork(0.3)
+    ref = RefColor()
+    sdf.load_state_dict({k: T(v) for k, v in synth.sdf_state_dict(int(g["seed_sdf"])).items()})
+    col.load_state_dict({k: T(v) for k, v in synth.color_state_dict(int(g["seed_color"])).items()})
+    ref.load_state_dict({k: T(v) for k, v in synth.refcolor_state_dict(int(g["seed_refcolor"])).items()})
+    for m in (sdf, col, var, ref):
+        m.to(DEV)
+    sdf.set_precision(prec)
+    col.set_precision(prec)
+    rnd = NeuSRenderer(int(g["n_samples"]), int(g["n_importance"]), int(g["n_outside"]), 4, 1.0, nerf=None,
+                       sdf_network=sdf, deviation_network=var, color_network=col, refColor_network=ref)
+    return rnd, dict(sdf=sdf, color=col, var=var, refcolor=ref)
+
+
+def run(g, prec, teacher_z):
+    from oracle import ref_torch as R
+    rnd, nets = build(g, prec)
+    data = T(g["data"]).to(DEV)
+    rays_o, rays_d, rgb, mask = data[:, :3], data[:, 3:6], data[:, 6:9], data[:, 9:10]
+    near, far = R.near_far_from_sphere(rays_o, rays_d)
+    out = rnd.render(rays_o, rays_d, near, far, perturb_overwrite=0, cos_anneal_ratio=float(g["cos_anneal_ratio"]),
+                     z_vals_override=T(g["trace/z_3"]).to(DEV) if teacher_z else None)
+    return out, nets, (rgb, mask)
+
+
+def maxerr(a, b):
+    return (a.detach().cpu().double().reshape(-1) - T(b).double().reshape(-1)).abs().max().item()
+
+
+WMASK = ["render_wmask_b16_n16", "render_wmask_b8_n64", "render_wmask_b16_n16_c0"]
+
+
+@pytest.mark.parametrize("name", WMASK)
+def test_render_core_teacher_forced(golden_dir, name):
+    g = load(golden_dir, name)
+    out, _, _ = run(g, 3, teacher_z=True)
+    assert np.array_equal(out["sdf_mask"].cpu().numpy(), g["out/sdf_mask"])
+    for k in RAY_KEYS + SAMPLE_KEYS:
+        e = maxerr(out[k], g["out/" + k])
+        assert e <= 1e-4, (k, e)
+    assert maxerr(out["_sdf"], g["core/sdf"]) <= 1e-4
+    assert maxerr(out["_mid_z_vals"], g["core/mid_z_vals"]) <= 1e-6
+
+
+@pytest.mark.parametrize("name", WMASK)
+def test_render_end_to_end(golden_dir, name):
+    """own sampler: ray-integrated outputs within 1e-4 (per-sample outputs sit at slightly different z: the inverse
+    CDF is ill-conditioned where the pdf is flat, see tests/test_oracle_golden.py)"""
+    g = load(golden_dir, name)
+    out, _, _ = run(g, 3, teacher_z=False)
+    assert np.array_equal(out["sdf_mask"].cpu().numpy(), g["out/sdf_mask"])
+    # 64+64 samples (the reference configuration): 1e-4.  The 16+16 toy cases integrate so coarsely that a z shift
+    # of 1e-4 moves a ray integral by a few 1e-4 -- the reference shows the same sensitivity against its own
+    # restatement (tests/test_oracle_golden.py::test_render_end_to_end uses the same split).
+    tol = 1e-4 if int(g["n_samples"]) >= 64 else 5e-4
+    errs = {k: maxerr(out[k], g["out/" + k]) for k in RAY_KEYS}
+    print(name, {k: f"{v:.1e}" for k, v in errs.items()}, "z", f"{maxerr(out['_z_vals'], g['trace/z_3']):.1e}")
+    for k, e in errs.items():
+        assert e <= tol, (k, e)
+    assert maxerr(out["_z_vals"], g["trace/z_3"]) <= 3e-3
+
+
+@pytest.mark.parametrize("name", WMASK[:2])
+def test_loss_and_gradients(golden_dir, name):
+    from fneus.losses import stage1_loss
+    g = load(golden_dir, name)
+    out, nets, (rgb, mask) = run(g, 3, teacher_z=True)
+    losses = stage1_loss(out, rgb, mask, igr_weight=0.1, mask_weight=float(g["mask_weight"]), surface_weight=0.1)
+    for k, key in (("loss", "loss"), ("color", "color_loss"), ("surface", "surface_loss"), ("eikonal", "eikonal_loss"),
+                   ("mask", "mask_loss")):
+        assert abs(losses[key].item() - float(g["loss/" + k])) <= 1e-4, k
+    losses["loss"].backward()
+    checked = 0
+    worst = 0.0
+    for key in g:
+        if not key.startswith("grad_norm/"):
+            continue
+        pname = key[len("grad_norm/"):]
+        net, rest = pname.split(".", 1)
+        if net == "nerf":
+            continue
+        prm = dict(nets[net].named_parameters())[rest]
+        assert prm.grad is not None, pname
+        ref_norm = float(g[key])
+        ref_sub = g["grad_sub/" + pname]
+        sub = prm.grad.detach().cpu().reshape(-1)[::997].numpy()
+        scale = max(ref_norm / np.sqrt(prm.numel()), np.abs(ref_sub).max(), 1e-7)
+        e_sub = np.abs(sub - ref_sub).max() / scale
+        e_norm = abs(prm.grad.double().norm().item() - ref_norm) / (ref_norm + 1e-12)
+        worst = max(worst, e_sub, e_norm)
+        # RefColor is a ReLU MLP evaluated on only 2 samples per masked ray: a single unit whose pre-activation sits
+        # within rounding of zero shows up in an individual weight-gradient entry
+        lim_sub = 3e-2 if net == "refcolor" else 5e-3
+        assert e_sub <= lim_sub and e_norm <= 2e-3, (pname, e_sub, e_norm)
+        checked += 1
+    print(f"{name}: {checked} parameter tensors, worst relative gradient error {worst:.2e}")
+    assert checked >= 40
+
+
+def test_fast_mode_reports_error(golden_dir):
+    """bf16 fast mode: not a parity mode; its observed error is printed and loosely bounded"""
+    g = load(golden_dir, "render_wmask_b8_n64")
+    out, _, _ = run(g, 1, teacher_z=True)
+    errs = {k: maxerr(out[k], g["out/" + k]) for k in ("color_fine", "weights", "gradients", "weight_sum")}
+    print("bf16 fast mode max abs errors:", {k: f"{v:.2e}" for k, v in errs.items()})
+    assert errs["color_fine"] <= 5e-2 and errs["weight_sum"] <= 5e-2
