@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Benchmark of the Factored-NeuS stage-1 training hot path on MI355X (HIP backend).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--prec parity|fast] [--no-cpu-baseline] [--no-profile]
+
+N > 1 is launched by the driver as
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+(one rank per GPU, RCCL; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).
+
+A "step" = one pass of the hot path over one synthetic DTU-shaped batch that is already resident in HBM:
+render (hierarchical sampler, SDF + normal, colour, compositing) -> 4-term loss -> backward -> [gradient all-reduce]
+-> Adam, for BASELINE.json configs[1]: 512 rays x (64+64) samples, confs/wmask.conf networks, random-init weights of
+the reference's distributions.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "factored-neus_amd"))
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+RAYS, N_SAMPLES, N_IMPORTANCE = 512, 64, 64
+SAMPLES_PER_STEP = RAYS * (N_SAMPLES + N_IMPORTANCE)
+
+# algorithmic work, SURVEY.md section 8(d): GEMM MACs per ray-sample (1 MAC = 2 FLOP)
+F_SDF = 524544 * 2.0       # one SDF-network forward
+F_COL = 271360 * 2.0       # one colour-network forward
+FLOP_TRAIN_PER_SAMPLE = (0.875 + 2 + 4) * F_SDF + 3 * F_COL      # = 8.84 MFLOP
+# per-kernel algorithmic FLOPs per launch at N = 65 536 samples (used for the dominant-kernel roofline)
+KERNEL_FLOPS = {
+    "fneus_sdf_fwd_grad": 2 * F_SDF * SAMPLES_PER_STEP,           # value+feature forward and the reverse sweep
+    "fneus_sdf_bwd": 2 * F_SDF * SAMPLES_PER_STEP,                # ascending + descending chains
+    "fneus_dw_gemm:sdf": 2 * F_SDF * SAMPLES_PER_STEP,            # dW = zbar^T u + a^T adj for the 9 SDF layers
+    "fneus_dw_gemm:color": F_COL * SAMPLES_PER_STEP,
+    "fneus_color_fwd": F_COL * SAMPLES_PER_STEP,
+    "fneus_color_bwd": F_COL * SAMPLES_PER_STEP,
+}
+PEAK_BF16_MFMA_TFLOPS = 2500.0       # MI355X dense bf16 (MI355X_MICROARCH.md)
+
+
+CPU_RAYS = 128          # bounded CPU sample: a quarter batch of the same workload (same samples per ray, same nets)
+
+
+def cpu_baseline(budget_s: float = 20.0):
+    """The oracle (CPU port of the reference algorithm) timed on the host cores: same workload, bounded sample."""
+    from oracle import ref_torch as R
+    from fneus import synth
+    threads = min(32, os.cpu_count() or 1)     # eager torch on small ops gets slower, not faster, beyond ~32 threads
+    torch.set_num_threads(threads)
+    T = lambda sd: {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in sd.items()}
+    sd_sdf, sd_col, sd_ref = T(synth.sdf_state_dict(0)), T(synth.color_state_dict(1)), T(synth.refcolor_state_dict(2))
+    variance = torch.tensor(0.3, requires_grad=True)
+    leaves = list(sd_sdf.values()) + list(sd_col.values()) + list(sd_ref.values()) + [variance]
+    opt = torch.optim.Adam(leaves, lr=5e-4)
+    times = []
+    t_start = time.time()
+    step = 0
+    while True:
+        data = torch.from_numpy(synth.ray_batch(CPU_RAYS, seed=1000 + step))
+        rays_o, rays_d, rgb, mask = data[:, :3], data[:, 3:6], data[:, 6:9], data[:, 9:10]
+        t0 = time.time()
+        near, far = R.near_far_from_sphere(rays_o, rays_d)
+        out = R.render(rays_o, rays_d, near, far, R.sdf_params_from_state_dict(sd_sdf), R.inv_s_from_variance(variance),
+                       R.color_params_from_state_dict(sd_col), sd_ref, None, n_samples=N_SAMPLES,
+                       n_importance=N_IMPORTANCE, t_rand=torch.rand(CPU_RAYS, 1), cos_anneal_ratio=1.0)
+        losses = R.stage1_loss(out, rgb, mask, 0.1, 0.1, 0.1)
+        opt.zero_grad()
+        losses["loss"].backward()
+        opt.step()
+        dt = time.time() - t0
+        if step > 0 or budget_s <= 0:
+            times.append(dt)
+        step += 1
+        if (time.time() - t_start > budget_s and len(times) >= 1) or step >= 5 or (step >= 1 and dt > budget_s):
+            break
+    if not times:
+        times = [dt]
+    t = float(np.median(times))
+    return {"value": CPU_RAYS * (N_SAMPLES + N_IMPORTANCE) / t, "unit": "ray-samples/s", "cores": threads, "kind": "port",
+            "sample": f"{len(times)} train steps of {CPU_RAYS} rays x {N_SAMPLES + N_IMPORTANCE} samples (1/4 batch of the "
+                      f"same workload) after 1 warm-up, oracle/ref_torch.py fp32, {threads} torch threads of "
+                      f"{os.cpu_count()} host cores, median {t:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--prec", choices=["parity", "fast"], default="parity")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-fast-extra", action="store_true")
+    args = ap.parse_args()
+
+    from fneus import ops
+    from fneus.parallel import init_from_env, broadcast_parameters
+    from fneus.trainer import Stage1Trainer, synthetic_batches
+
+    rank, world, local = init_from_env("nccl")
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    def run(prec, steps, warmup, profile):
+        tr = Stage1Trainer(device, prec=prec, distributed=(world > 1))
+        broadcast_parameters(tr.modules)
+        batches = synthetic_batches(steps + warmup + (3 if profile else 0), RAYS, device, rank=rank)
+        for i in range(warmup):
+            tr.train_step(batches[i])
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            tr.train_step(batches[warmup + i])
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        prof = None
+        if profile:
+            ops.profile_begin()
+            for i in range(3):
+                tr.train_step(batches[warmup + steps + i])
+            prof = ops.profile_end()
+        return dt, prof, tr
+
+    prec = ops.PREC_PARITY if args.prec == "parity" else ops.PREC_FAST
+    dt, prof, tr = run(prec, args.steps, args.warmup, profile=not args.no_profile)
+    ms_per_step = dt / args.steps * 1e3
+    value = world * SAMPLES_PER_STEP * args.steps / dt
+
+    result = {
+        "metric": "train-step ray-samples/s (stage-1, 512x128)",
+        "value": value,
+        "unit": "ray-samples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16x3 split MFMA, fp32 accumulate (1e-4 parity mode)" if prec == 3 else "bf16 MFMA, fp32 accumulate",
+        "data": "synthetic DTU-shaped rays (one camera per step), random-init weights of the reference distributions",
+        "config": {"workload": "dtu_scan97-shaped wmask.conf stage-1 SDF+radiance train step, 512 rays x (64+64) samples, "
+                               "1xMI355X per rank", "rays_per_gpu": RAYS, "samples_per_ray": N_SAMPLES + N_IMPORTANCE,
+                   "parallelism": f"dp{world} (ray-sharded replicas, flat-bucket gradient all-reduce)"},
+        "mfma_roofline_frac_step": value / world * FLOP_TRAIN_PER_SAMPLE / (PEAK_BF16_MFMA_TFLOPS * 1e12),
+    }
+
+    if rank == 0 and prof:
+        per = {}
+        for name, (n, ms) in prof.items():
+            per[name] = {"launches_per_step": n / 3.0, "ms_per_step": ms / 3.0, "avg_ms": ms / n}
+        result["kernels_ms_per_step"] = {k: round(v["ms_per_step"], 4) for k, v in sorted(per.items(), key=lambda kv: -kv[1]["ms_per_step"])}
+        dom = max((k for k in per if k in KERNEL_FLOPS), key=lambda k: per[k]["ms_per_step"])
+        flops_per_launch = KERNEL_FLOPS[dom] / max(round(per[dom]["launches_per_step"]), 1)
+        achieved = flops_per_launch / (per[dom]["avg_ms"] * 1e-3) / 1e12
+        result["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS,
+                              "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_MFMA_TFLOPS, "traffic": None,
+                              "avg_launch_ms": per[dom]["avg_ms"],
+                              "note": "algorithmic (fp32-equivalent) FLOPs per launch / HIP-event launch duration; "
+                                      "parity mode issues 3 bf16 MFMAs per algorithmic product"}
+
+    if rank == 0 and world == 1 and not args.no_fast_extra and prec == ops.PREC_PARITY:
+        dt_f, _, _ = run(ops.PREC_FAST, max(args.steps // 2, 5), 3, profile=False)
+        v = SAMPLES_PER_STEP * max(args.steps // 2, 5) / dt_f
+        result["fast_bf16"] = {"value": v, "unit": "ray-samples/s", "ms_per_step": dt_f / max(args.steps // 2, 5) * 1e3,
+                               "mfma_roofline_frac_step": v * FLOP_TRAIN_PER_SAMPLE / (PEAK_BF16_MFMA_TFLOPS * 1e12),
+                               "note": "same step with plain bf16 MFMA operands; NOT a 1e-4 parity mode "
+                                       "(observed errors: tests/test_hip_render.py::test_fast_mode_reports_error)"}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            result["cpu_baseline"] = cpu_baseline()
+        except Exception as e:   # the baseline must never take the GPU number down with it
+            result["cpu_baseline"] = {"value": None, "error": repr(e)}
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -197,6 +197,7 @@ extern "C" int fneus_color_fwd(const void* blob, const float* pts, const float* 
                                const float* feat, const FneusColStash* stash, float* rgb_out, int prec, int train,
                                fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
     if (n_pts <= 0) return 0;
     PointSrc src{pts, rays_o, rays_d, t, m > 0 ? m : 1};
     if (!pts && !rays_d) return -2;
@@ -214,13 +215,14 @@ extern "C" int fneus_color_fwd(const void* blob, const float* pts, const float* 
         hipLaunchKernelGGL((color_fwd_kernel<1, false>), grid, blk, 0, stream, b, src, n_pts, dirs, normal, feat, st, rgb_out);
     else
         return -2;
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return fneus::launch_status();
 }
 
 extern "C" int fneus_color_bwd(const void* blob, long n_pts, const float* d_rgb, const float* rgb,
                                const FneusColStash* stash, float* d_feat, float* d_normal, int prec,
                                fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
     if (n_pts <= 0) return 0;
     const unsigned char* b = reinterpret_cast<const unsigned char*>(blob);
     ColStash st(*stash);
@@ -231,5 +233,5 @@ extern "C" int fneus_color_bwd(const void* blob, long n_pts, const float* d_rgb,
         hipLaunchKernelGGL(color_bwd_kernel<1>, grid, blk, 0, stream, b, n_pts, d_rgb, rgb, st, d_feat, d_normal);
     else
         return -2;
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return fneus::launch_status();
 }

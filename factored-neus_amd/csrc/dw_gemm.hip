@@ -188,6 +188,7 @@ using namespace fneus;
 extern "C" int fneus_dw_gemm(const void* jobs_dev, int n_jobs, int n_tiles, long n_samples, int prec,
                              fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
     if (n_tiles <= 0 || n_samples <= 0) return 0;
     // split-K so that the grid holds ~1024 workgroups (2 per CU resident at 80 KiB LDS each in parity mode)
     int split = 1024 / n_tiles;
@@ -209,5 +210,5 @@ extern "C" int fneus_dw_gemm(const void* jobs_dev, int n_jobs, int n_tiles, long
     } else {
         return -2;
     }
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return fneus::launch_status();
 }

@@ -62,4 +62,14 @@ FN_DEV void load_point(const PointSrc& s, long n, float (&x)[3]) {
 
 void set_last_error(const char* msg);
 
+// HIP keeps a sticky per-thread "last error" that other libraries (e.g. PyTorch's own runtime probing) may have set:
+// clear it before a launch, then report only what this launch produced.
+inline void clear_status() { (void)hipGetLastError(); }
+inline int launch_status() {
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return 0;
+    set_last_error(hipGetErrorString(e));
+    return -1;
+}
+
 }  // namespace fneus

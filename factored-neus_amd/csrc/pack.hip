@@ -55,9 +55,10 @@ __global__ void __launch_bounds__(64) pack_kernel(const PackJob* __restrict__ jo
 extern "C" int fneus_pack(const void* jobs, int n_jobs, int n_units, const int* maps, const float* params,
                           void* blob, fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
     if (n_units <= 0) return 0;
     hipLaunchKernelGGL(fneus::pack_kernel, dim3(n_units), dim3(64), 0, stream,
                        reinterpret_cast<const fneus::PackJob*>(jobs), n_jobs, maps, params,
                        reinterpret_cast<unsigned char*>(blob));
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return fneus::launch_status();
 }

@@ -423,29 +423,32 @@ using namespace fneus;
 extern "C" int fneus_upsample(const float* rays_o, const float* rays_d, const float* z, const float* sdf, int n_rays, int m,
                               int k, float inv_s, float* z_new, fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
     if (n_rays <= 0) return 0;
     FN_CHECK_N(m);
     hipLaunchKernelGGL(upsample_kernel, dim3(n_rays), dim3(64), 0, stream, rays_o, rays_d, z, sdf, m, k, inv_s, z_new);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return fneus::launch_status();
 }
 
 extern "C" int fneus_merge(const float* z_old, const float* s_old, int m, const float* z_new, const float* s_new, int k,
                            int n_rays, float* z_out, float* s_out, fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
     if (n_rays <= 0) return 0;
     FN_CHECK_N(m + k);
     hipLaunchKernelGGL(merge_kernel, dim3(n_rays), dim3(64), 0, stream, z_old, s_old, m, z_new, s_new, k, z_out, s_out);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return fneus::launch_status();
 }
 
 extern "C" int fneus_sections(const float* z, int n_rays, int n, float sample_dist, float* dists, float* mid_z,
                               fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
     const long total = (long)n_rays * n;
     if (total <= 0) return 0;
     hipLaunchKernelGGL(sections_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, z, n_rays, n, sample_dist,
                        dists, mid_z);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return fneus::launch_status();
 }
 
 extern "C" int fneus_composite_fwd(const float* rays_o, const float* rays_d, const float* mid_z, const float* dists,
@@ -454,12 +457,13 @@ extern "C" int fneus_composite_fwd(const float* rays_o, const float* rays_d, con
                                    float* wmax, float* cdf, float* inside, float* eik, int32_t* min_idx,
                                    unsigned char* sdf_mask, float* wpair, fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
     if (n_rays <= 0) return 0;
     FN_CHECK_N(n);
     hipLaunchKernelGGL(composite_fwd_kernel, dim3(n_rays), dim3(64), 0, stream, rays_o, rays_d, mid_z, dists, sdf, normal,
                        rgb, inv_s, n, cos_anneal_ratio, weights, color, wsum, wmax, cdf, inside, eik, min_idx, sdf_mask,
                        wpair);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return fneus::launch_status();
 }
 
 extern "C" int fneus_composite_bwd(const float* rays_o, const float* rays_d, const float* mid_z, const float* dists,
@@ -469,10 +473,11 @@ extern "C" int fneus_composite_bwd(const float* rays_o, const float* rays_d, con
                                    const float* d_weights, const float* d_wpair, const float* d_eiknum, float* d_sdf,
                                    float* d_normal, float* d_rgb, float* d_inv_s, fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
     if (n_rays <= 0) return 0;
     FN_CHECK_N(n);
     hipLaunchKernelGGL(composite_bwd_kernel, dim3(n_rays), dim3(64), 0, stream, rays_o, rays_d, mid_z, dists, sdf, normal,
                        rgb, inv_s, n, cos_anneal_ratio, min_idx, sdf_mask, d_color, d_wsum, d_weights, d_wpair, d_eiknum,
                        d_sdf, d_normal, d_rgb, d_inv_s);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return fneus::launch_status();
 }

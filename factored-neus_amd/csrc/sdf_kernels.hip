@@ -458,6 +458,7 @@ static inline int grid_for(long n_tiles) {
 extern "C" int fneus_sdf_fwd(const void* blob, const float* pts, const float* rays_o, const float* rays_d,
                              const float* t, int m, long n_pts, float* sdf_out, int prec, fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
     if (n_pts <= 0) return 0;
     PointSrc src{pts, rays_o, rays_d, t, m > 0 ? m : 1};
     const long tiles = (n_pts + 31) / 32;
@@ -468,13 +469,14 @@ extern "C" int fneus_sdf_fwd(const void* blob, const float* pts, const float* ra
         hipLaunchKernelGGL(sdf_fwd_kernel<1>, dim3(grid_for(tiles)), dim3(64), 0, stream, b, src, n_pts, sdf_out);
     else
         return -2;
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return fneus::launch_status();
 }
 
 extern "C" int fneus_sdf_fwd_grad(const void* blob, const float* pts, const float* rays_o, const float* rays_d,
                                   const float* t, int m, long n_pts, const FneusSdfStash* stash, float* sdf_out,
                                   float* feat_out, float* normal_out, int prec, int train, fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
     if (n_pts <= 0) return 0;
     PointSrc src{pts, rays_o, rays_d, t, m > 0 ? m : 1};
     const long tiles = (n_pts + 31) / 32;
@@ -491,7 +493,7 @@ extern "C" int fneus_sdf_fwd_grad(const void* blob, const float* pts, const floa
         hipLaunchKernelGGL((sdf_fwd_grad_kernel<1, false>), grid, blk, 0, stream, b, src, n_pts, st, sdf_out, feat_out, normal_out);
     else
         return -2;
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return fneus::launch_status();
 }
 
 extern "C" int fneus_sdf_bwd(const void* blob, const float* pts, const float* rays_o, const float* rays_d,
@@ -499,6 +501,7 @@ extern "C" int fneus_sdf_bwd(const void* blob, const float* pts, const float* ra
                              const float* d_sdf, const float* d_feat, const float* d_normal, int prec,
                              fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
     if (n_pts <= 0) return 0;
     PointSrc src{pts, rays_o, rays_d, t, m > 0 ? m : 1};
     const unsigned char* b = reinterpret_cast<const unsigned char*>(blob);
@@ -511,5 +514,5 @@ extern "C" int fneus_sdf_bwd(const void* blob, const float* pts, const float* ra
         hipLaunchKernelGGL(sdf_bwd_kernel<1>, grid, blk, 0, stream, b, src, n_pts, st, bb, d_sdf, d_feat, d_normal);
     else
         return -2;
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return fneus::launch_status();
 }

@@ -8,6 +8,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# Import torch BEFORE loading the library: both link libamdhip64, and the process must end up with ONE HIP runtime
+# (the one PyTorch ships).  Loading ours first binds it to /opt/rocm's copy and the two runtimes then disagree about
+# devices ("no ROCm-capable device is detected").
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfneus_hip.so")
 

@@ -12,6 +12,39 @@ from ._lib import lib, check
 
 PREC_FAST, PREC_PARITY = 1, 3
 
+# Optional per-kernel timing with HIP events on the launch stream (used by bench.py for the roofline figures).
+# PROFILE = None disables it (default; the hot path then records nothing and never synchronises).
+PROFILE = None
+
+
+def profile_begin():
+    global PROFILE
+    PROFILE = []
+
+
+def profile_end():
+    """-> {kernel name: (launches, total milliseconds)}"""
+    global PROFILE
+    rec, PROFILE = PROFILE, None
+    torch.cuda.synchronize()
+    out = {}
+    for name, e0, e1 in rec:
+        n, t = out.get(name, (0, 0.0))
+        out[name] = (n + 1, t + e0.elapsed_time(e1))
+    return out
+
+
+def _launch(name, fn, *args):
+    if PROFILE is None:
+        check(fn(*args), name)
+        return
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(fn(*args), name)
+    e1.record()
+    PROFILE.append((name, e0, e1))
+
 
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
@@ -59,8 +92,8 @@ class PackedNet:
     def pack(self, flat: torch.Tensor):
         _chk_f32(flat, "flat params")
         assert flat.numel() == self.n_params
-        check(lib.fneus_pack(_ptr(self.jobs), self.n_jobs, self.units, _ptr(self.maps), _ptr(flat), _ptr(self.blob),
-                             _stream()), "fneus_pack")
+        _launch("fneus_pack", lib.fneus_pack, _ptr(self.jobs), self.n_jobs, self.units, _ptr(self.maps), _ptr(flat), _ptr(self.blob),
+                             _stream())
         return self.blob
 
 
@@ -96,8 +129,8 @@ def sdf_fwd(blob, n_pts: int, prec: int, pts=None, rays_o=None, rays_d=None, t=N
     dev = blob.device
     if out is None:
         out = torch.empty(n_pts, dtype=torch.float32, device=dev)
-    check(lib.fneus_sdf_fwd(_ptr(blob), _ptr(pts), _ptr(rays_o), _ptr(rays_d), _ptr(t), m, n_pts, _ptr(out), prec,
-                            _stream()), "fneus_sdf_fwd")
+    _launch("fneus_sdf_fwd", lib.fneus_sdf_fwd, _ptr(blob), _ptr(pts), _ptr(rays_o), _ptr(rays_d), _ptr(t), m, n_pts, _ptr(out), prec,
+                            _stream())
     return out
 
 
@@ -107,9 +140,8 @@ def sdf_fwd_grad(blob, n_pts: int, prec: int, stash: SdfStash, train: bool, pts=
     sdf = torch.empty(n_pts, dtype=torch.float32, device=dev)
     feat = torch.empty(n_pts, 256, dtype=torch.float32, device=dev)
     normal = torch.empty(n_pts, 3, dtype=torch.float32, device=dev)
-    check(lib.fneus_sdf_fwd_grad(_ptr(blob), _ptr(pts), _ptr(rays_o), _ptr(rays_d), _ptr(t), m, n_pts,
-                                 C.byref(stash.c), _ptr(sdf), _ptr(feat), _ptr(normal), prec, int(train), _stream()),
-          "fneus_sdf_fwd_grad")
+    _launch("fneus_sdf_fwd_grad", lib.fneus_sdf_fwd_grad, _ptr(blob), _ptr(pts), _ptr(rays_o), _ptr(rays_d), _ptr(t), m, n_pts,
+                                 C.byref(stash.c), _ptr(sdf), _ptr(feat), _ptr(normal), prec, int(train), _stream())
     return sdf, feat, normal
 
 
@@ -151,9 +183,8 @@ def sdf_bwd(blob, n_pts, prec, stash: SdfStash, bufs: SdfBwdBufs, d_sdf, d_feat,
             rays_d=None, t=None, m: int = 1):
     for x, nm in ((d_sdf, "d_sdf"), (d_feat, "d_feat"), (d_normal, "d_normal")):
         _chk_f32(x, nm)
-    check(lib.fneus_sdf_bwd(_ptr(blob), _ptr(pts), _ptr(rays_o), _ptr(rays_d), _ptr(t), m, n_pts, C.byref(stash.c),
-                            C.byref(bufs.c), _ptr(d_sdf), _ptr(d_feat), _ptr(d_normal), prec, _stream()),
-          "fneus_sdf_bwd")
+    _launch("fneus_sdf_bwd", lib.fneus_sdf_bwd, _ptr(blob), _ptr(pts), _ptr(rays_o), _ptr(rays_d), _ptr(t), m, n_pts, C.byref(stash.c),
+                            C.byref(bufs.c), _ptr(d_sdf), _ptr(d_feat), _ptr(d_normal), prec, _stream())
 
 
 def color_fwd(blob, n_pts, prec, normal, feat, stash: Optional[ColStash], train: bool, pts=None, rays_o=None,
@@ -161,9 +192,9 @@ def color_fwd(blob, n_pts, prec, normal, feat, stash: Optional[ColStash], train:
     _chk_f32(normal, "normal")
     _chk_f32(feat, "feat")
     rgb = torch.empty(n_pts, 3, dtype=torch.float32, device=blob.device)
-    check(lib.fneus_color_fwd(_ptr(blob), _ptr(pts), _ptr(rays_o), _ptr(rays_d), _ptr(t), m, n_pts, _ptr(dirs),
+    _launch("fneus_color_fwd", lib.fneus_color_fwd, _ptr(blob), _ptr(pts), _ptr(rays_o), _ptr(rays_d), _ptr(t), m, n_pts, _ptr(dirs),
                               _ptr(normal), _ptr(feat), C.byref(stash.c) if stash is not None else None, _ptr(rgb),
-                              prec, int(train), _stream()), "fneus_color_fwd")
+                              prec, int(train), _stream())
     return rgb
 
 
@@ -171,15 +202,16 @@ def color_bwd(blob, n_pts, prec, d_rgb, rgb, stash: ColStash):
     _chk_f32(d_rgb, "d_rgb")
     d_feat = torch.empty(n_pts, 256, dtype=torch.float32, device=blob.device)
     d_normal = torch.empty(n_pts, 3, dtype=torch.float32, device=blob.device)
-    check(lib.fneus_color_bwd(_ptr(blob), n_pts, _ptr(d_rgb), _ptr(rgb), C.byref(stash.c), _ptr(d_feat),
-                              _ptr(d_normal), prec, _stream()), "fneus_color_bwd")
+    _launch("fneus_color_bwd", lib.fneus_color_bwd, _ptr(blob), n_pts, _ptr(d_rgb), _ptr(rgb), C.byref(stash.c), _ptr(d_feat),
+                              _ptr(d_normal), prec, _stream())
     return d_feat, d_normal
 
 
 class GemmJobs:
     """Device job table for fneus_dw_gemm.  Built once per (buffers, N); pointers refer to live stash tensors."""
 
-    def __init__(self, device):
+    def __init__(self, device, tag=""):
+        self.tag = tag
         self.jobs = []
         self.tiles = 0
         self.device = device
@@ -215,14 +247,13 @@ class GemmJobs:
         return self
 
     def run(self, n_samples: int, prec: int):
-        check(lib.fneus_dw_gemm(_ptr(self.dev_table), len(self.jobs), self.tiles, n_samples, prec, _stream()),
-              "fneus_dw_gemm")
+        _launch("fneus_dw_gemm:" + self.tag, lib.fneus_dw_gemm, _ptr(self.dev_table), len(self.jobs), self.tiles, n_samples, prec, _stream())
 
 
 def sdf_dw_jobs(net: PackedNet, stash: SdfStash, bufs: SdfBwdBufs, grad_flat: torch.Tensor, n: int) -> GemmJobs:
     """dW_l = zbar_l^T u_l + a_l^T adj_l for the 9 SDF layers, into the flat fp32 grad buffer."""
     import math
-    g = GemmJobs(grad_flat.device)
+    g = GemmJobs(grad_flat.device, "sdf")
     offW, offb = net.desc["offW"], net.desc["offb"]
     base = grad_flat.data_ptr()
     isq2 = 1.0 / math.sqrt(2.0)
@@ -251,7 +282,7 @@ def sdf_dw_jobs(net: PackedNet, stash: SdfStash, bufs: SdfBwdBufs, grad_flat: to
 
 
 def color_dw_jobs(net: PackedNet, sdf_stash: SdfStash, stash: ColStash, grad_flat: torch.Tensor, n: int) -> GemmJobs:
-    g = GemmJobs(grad_flat.device)
+    g = GemmJobs(grad_flat.device, "color")
     offW, offb = net.desc["offW"], net.desc["offb"]
     base = grad_flat.data_ptr()
     # layer 0: columns 0..32 = side inputs, 33..288 = feature
@@ -272,8 +303,8 @@ def color_dw_jobs(net: PackedNet, sdf_stash: SdfStash, stash: ColStash, grad_fla
 def upsample(rays_o, rays_d, z, sdf, k: int, inv_s: float):
     B, m = z.shape
     out = torch.empty(B, k, dtype=torch.float32, device=z.device)
-    check(lib.fneus_upsample(_ptr(rays_o), _ptr(rays_d), _ptr(z), _ptr(sdf), B, m, k, float(inv_s), _ptr(out),
-                             _stream()), "fneus_upsample")
+    _launch("fneus_upsample", lib.fneus_upsample, _ptr(rays_o), _ptr(rays_d), _ptr(z), _ptr(sdf), B, m, k, float(inv_s), _ptr(out),
+                             _stream())
     return out
 
 
@@ -282,8 +313,8 @@ def merge(z_old, s_old, z_new, s_new):
     k = z_new.shape[1]
     z_out = torch.empty(B, m + k, dtype=torch.float32, device=z_old.device)
     s_out = torch.empty_like(z_out) if s_new is not None else None
-    check(lib.fneus_merge(_ptr(z_old), _ptr(s_old) if s_new is not None else None, m, _ptr(z_new), _ptr(s_new), k, B,
-                          _ptr(z_out), _ptr(s_out), _stream()), "fneus_merge")
+    _launch("fneus_merge", lib.fneus_merge, _ptr(z_old), _ptr(s_old) if s_new is not None else None, m, _ptr(z_new), _ptr(s_new), k, B,
+                          _ptr(z_out), _ptr(s_out), _stream())
     return z_out, s_out
 
 
@@ -291,7 +322,7 @@ def sections(z, sample_dist: float):
     B, n = z.shape
     dists = torch.empty_like(z)
     mid_z = torch.empty_like(z)
-    check(lib.fneus_sections(_ptr(z), B, n, float(sample_dist), _ptr(dists), _ptr(mid_z), _stream()), "fneus_sections")
+    _launch("fneus_sections", lib.fneus_sections, _ptr(z), B, n, float(sample_dist), _ptr(dists), _ptr(mid_z), _stream())
     return dists, mid_z
 
 
@@ -305,11 +336,11 @@ def composite_fwd(rays_o, rays_d, mid_z, dists, sdf, normal, rgb, inv_s, car: fl
         "eik": torch.empty(B, 2, **f32), "min_idx": torch.empty(B, dtype=torch.int32, device=dev),
         "sdf_mask": torch.empty(B, dtype=torch.uint8, device=dev), "wpair": torch.empty(B, 2, **f32),
     }
-    check(lib.fneus_composite_fwd(_ptr(rays_o), _ptr(rays_d), _ptr(mid_z), _ptr(dists), _ptr(sdf), _ptr(normal),
+    _launch("fneus_composite_fwd", lib.fneus_composite_fwd, _ptr(rays_o), _ptr(rays_d), _ptr(mid_z), _ptr(dists), _ptr(sdf), _ptr(normal),
                                   _ptr(rgb), _ptr(inv_s), B, n, float(car), _ptr(out["weights"]), _ptr(out["color"]),
                                   _ptr(out["wsum"]), _ptr(out["wmax"]), _ptr(out["cdf"]), _ptr(out["inside"]),
                                   _ptr(out["eik"]), _ptr(out["min_idx"]), _ptr(out["sdf_mask"]), _ptr(out["wpair"]),
-                                  _stream()), "fneus_composite_fwd")
+                                  _stream())
     return out
 
 
@@ -321,9 +352,8 @@ def composite_bwd(rays_o, rays_d, mid_z, dists, sdf, normal, rgb, inv_s, car, mi
     d_normal = torch.empty(B * n, 3, dtype=torch.float32, device=dev)
     d_rgb = torch.empty(B * n, 3, dtype=torch.float32, device=dev)
     d_inv_s = torch.empty(B, dtype=torch.float32, device=dev)
-    check(lib.fneus_composite_bwd(_ptr(rays_o), _ptr(rays_d), _ptr(mid_z), _ptr(dists), _ptr(sdf), _ptr(normal),
+    _launch("fneus_composite_bwd", lib.fneus_composite_bwd, _ptr(rays_o), _ptr(rays_d), _ptr(mid_z), _ptr(dists), _ptr(sdf), _ptr(normal),
                                   _ptr(rgb), _ptr(inv_s), B, n, float(car), _ptr(min_idx), _ptr(sdf_mask),
                                   _ptr(d_color), _ptr(d_wsum), _ptr(d_weights), _ptr(d_wpair), _ptr(d_eiknum),
-                                  _ptr(d_sdf), _ptr(d_normal), _ptr(d_rgb), _ptr(d_inv_s), _stream()),
-          "fneus_composite_bwd")
+                                  _ptr(d_sdf), _ptr(d_normal), _ptr(d_rgb), _ptr(d_inv_s), _stream())
     return d_sdf, d_normal, d_rgb, d_inv_s

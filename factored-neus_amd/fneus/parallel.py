@@ -1,0 +1,70 @@
+"""Data-parallel ray sharding: one process per GPU, full replicas, one flat-bucket all-reduce per step.
+
+The reference is single-GPU (exp_runner.py:651-661); rays are independent, so rank r renders its own B rays and the
+only exchange is the gradient sum.  backend "nccl" is RCCL over xGMI on ROCm; "gloo" is used
+by the CPU tests.
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None):
+    """Initialise torch.distributed from torchrun's environment; returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend=backend or ("nccl" if torch.cuda.is_available() else "gloo"),
+                                rank=rank, world_size=world)
+    return rank, world, local
+
+
+class FlatGradBucket:
+    """All parameter gradients in ONE contiguous fp32 buffer (<= 8 MB on this path): a single collective per step."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        self.numel = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self.views = []
+        off = 0
+        for p in self.params:
+            self.views.append(self.flat[off: off + p.numel()].view_as(p))
+            off += p.numel()
+
+    def gather(self):
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()
+            else:
+                v.copy_(p.grad)
+
+    def scatter(self):
+        for p, v in zip(self.params, self.views):
+            if p.grad is not None:
+                p.grad.copy_(v)
+
+    def allreduce_mean(self, group=None):
+        """sum over ranks, divide by world size (every rank must call this every step: no data-dependent skipping)"""
+        if not dist.is_initialized() or dist.get_world_size(group) == 1:
+            return
+        self.gather()
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        self.flat.div_(dist.get_world_size(group))
+        self.scatter()
+
+
+def broadcast_parameters(modules, src: int = 0, group=None):
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    for m in modules:
+        for t in list(m.parameters()) + list(m.buffers()):
+            dist.broadcast(t.data, src=src, group=group)

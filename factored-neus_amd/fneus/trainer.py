@@ -1,0 +1,90 @@
+"""Stage-1 training step on the HIP backend: render -> 4-term loss -> backward -> (gradient all-reduce) -> Adam.
+
+Mirrors the body of the reference hot loop (exp_runner.py:131-181) without its per-step host synchronisations.
+Used by exp_runner.py and bench.py.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from fneus import ops, synth
+from fneus.losses import stage1_loss
+from fneus.parallel import FlatGradBucket
+
+WMASK_MODEL = {   # confs/wmask.conf:49-97
+    "sdf_network": dict(d_out=257, d_in=3, d_hidden=256, n_layers=8, skip_in=[4], multires=6, bias=0.5, scale=1.0,
+                        geometric_init=True, weight_norm=True),
+    "variance_network": dict(init_val=0.3),
+    "rendering_network": dict(d_feature=256, mode="idr", d_in=9, d_out=3, d_hidden=256, n_layers=4, weight_norm=True,
+                              multires_view=4, squeeze_out=True),
+    "neus_renderer": dict(n_samples=64, n_importance=64, n_outside=0, up_sample_steps=4, perturb=1.0),
+}
+
+
+class Stage1Trainer:
+    def __init__(self, device, model_conf: Optional[dict] = None, prec: int = ops.PREC_PARITY, lr: float = 5e-4,
+                 igr_weight: float = 0.1, mask_weight: float = 0.1, surface_weight: float = 0.1, seed: int = 0,
+                 synthetic_init: bool = True, distributed: bool = False):
+        from models.fields import SDFNetwork, RenderingNetwork, SingleVarianceNetwork, RefColor
+        from models.renderer import NeuSRenderer
+        conf = model_conf or WMASK_MODEL
+        self.device = device
+        self.sdf_network = SDFNetwork(**conf["sdf_network"])
+        self.color_network = RenderingNetwork(**conf["rendering_network"])
+        self.deviation_network = SingleVarianceNetwork(**conf["variance_network"])
+        self.refColor_network = RefColor()
+        if synthetic_init:   # deterministic numpy-stream weights (same on every box), reference distributions
+            T = lambda sd: {k: torch.from_numpy(v) for k, v in sd.items()}
+            self.sdf_network.load_state_dict(T(synth.sdf_state_dict(seed)))
+            self.color_network.load_state_dict(T(synth.color_state_dict(seed + 1)))
+            self.refColor_network.load_state_dict(T(synth.refcolor_state_dict(seed + 2)))
+        self.modules = [self.sdf_network, self.deviation_network, self.color_network, self.refColor_network]
+        for m in self.modules:
+            m.to(device)
+        self.sdf_network.set_precision(prec)
+        self.color_network.set_precision(prec)
+        self.params = [p for m in self.modules for p in m.parameters()]
+        self.optimizer = torch.optim.Adam(self.params, lr=lr, fused=(device.type == "cuda"))
+        self.renderer = NeuSRenderer(**conf["neus_renderer"], nerf=None, sdf_network=self.sdf_network,
+                                     deviation_network=self.deviation_network, color_network=self.color_network,
+                                     refColor_network=self.refColor_network)
+        self.igr_weight, self.mask_weight, self.surface_weight = igr_weight, mask_weight, surface_weight
+        self.bucket = FlatGradBucket(self.params) if distributed else None
+        self.iter_step = 0
+
+    def train_step(self, data: torch.Tensor, cos_anneal_ratio: float = 1.0, background_rgb=None):
+        """data [B,10] = rays_o, rays_d, rgb, mask (dataset.py:133-151).  Returns the loss dict (device tensors)."""
+        rays_o, rays_d, true_rgb, mask = data[:, :3], data[:, 3:6], data[:, 6:9], data[:, 9:10]
+        a = (rays_d ** 2).sum(-1, keepdim=True)                       # near_far_from_sphere, dataset.py:186-192
+        b = 2.0 * (rays_o * rays_d).sum(-1, keepdim=True)
+        mid = 0.5 * (-b) / a
+        out = self.renderer.render(rays_o, rays_d, mid - 1.0, mid + 1.0, background_rgb=background_rgb,
+                                   cos_anneal_ratio=cos_anneal_ratio)
+        losses = stage1_loss(out, true_rgb, mask, self.igr_weight, self.mask_weight, self.surface_weight)
+        self.optimizer.zero_grad(set_to_none=False)
+        losses["loss"].backward()
+        if self.bucket is not None:
+            self.bucket.allreduce_mean()
+        self.optimizer.step()
+        self.iter_step += 1
+        return losses
+
+    def render_only(self, data: torch.Tensor, cos_anneal_ratio: float = 1.0):
+        rays_o, rays_d = data[:, :3], data[:, 3:6]
+        a = (rays_d ** 2).sum(-1, keepdim=True)
+        b = 2.0 * (rays_o * rays_d).sum(-1, keepdim=True)
+        mid = 0.5 * (-b) / a
+        with torch.no_grad():
+            return self.renderer.render(rays_o, rays_d, mid - 1.0, mid + 1.0, perturb_overwrite=0,
+                                        cos_anneal_ratio=cos_anneal_ratio)
+
+
+def synthetic_batches(n_batches: int, batch: int, device, seed0: int = 1000, rank: int = 0):
+    """DTU-shaped batches, one synthetic camera per step; resident on the device."""
+    out = []
+    for i in range(n_batches):
+        out.append(torch.from_numpy(synth.ray_batch(batch, seed=seed0 + 7919 * rank + i)).to(device))
+    return out
