@@ -198,6 +198,7 @@ extern "C" int fneus_color_fwd(const void* blob, const float* pts, const float* 
                                fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     fneus::clear_status();
+    fneus::clear_status();
     if (n_pts <= 0) return 0;
     PointSrc src{pts, rays_o, rays_d, t, m > 0 ? m : 1};
     if (!pts && !rays_d) return -2;
@@ -222,6 +223,7 @@ extern "C" int fneus_color_bwd(const void* blob, long n_pts, const float* d_rgb,
                                const FneusColStash* stash, float* d_feat, float* d_normal, int prec,
                                fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
     fneus::clear_status();
     if (n_pts <= 0) return 0;
     const unsigned char* b = reinterpret_cast<const unsigned char*>(blob);

@@ -62,6 +62,12 @@ FN_DEV void load_point(const PointSrc& s, long n, float (&x)[3]) {
 
 void set_last_error(const char* msg);
 
+// the fused-MLP kernels use 130 KiB of dynamic LDS (> the 64 KiB default limit)
+template <class K>
+inline void allow_big_lds(K kernel) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
 // HIP keeps a sticky per-thread "last error" that other libraries (e.g. PyTorch's own runtime probing) may have set:
 // clear it before a launch, then report only what this launch produced.
 inline void clear_status() { (void)hipGetLastError(); }

@@ -459,6 +459,7 @@ extern "C" int fneus_sdf_fwd(const void* blob, const float* pts, const float* ra
                              const float* t, int m, long n_pts, float* sdf_out, int prec, fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     fneus::clear_status();
+    fneus::clear_status();
     if (n_pts <= 0) return 0;
     PointSrc src{pts, rays_o, rays_d, t, m > 0 ? m : 1};
     const long tiles = (n_pts + 31) / 32;
@@ -476,6 +477,7 @@ extern "C" int fneus_sdf_fwd_grad(const void* blob, const float* pts, const floa
                                   const float* t, int m, long n_pts, const FneusSdfStash* stash, float* sdf_out,
                                   float* feat_out, float* normal_out, int prec, int train, fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
     fneus::clear_status();
     if (n_pts <= 0) return 0;
     PointSrc src{pts, rays_o, rays_d, t, m > 0 ? m : 1};
@@ -501,6 +503,7 @@ extern "C" int fneus_sdf_bwd(const void* blob, const float* pts, const float* ra
                              const float* d_sdf, const float* d_feat, const float* d_normal, int prec,
                              fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
     fneus::clear_status();
     if (n_pts <= 0) return 0;
     PointSrc src{pts, rays_o, rays_d, t, m > 0 ? m : 1};

@@ -156,7 +156,7 @@ class SdfBwdBufs:
         self.adj = torch.empty((planes, 8, n, 256), dtype=bf, device=device)
         self.zbar = torch.empty((planes, 9, n, 256), dtype=bf, device=device)
         self.zsdf = torch.zeros((planes, n, 32), dtype=bf, device=device)
-        self.cscratch = torch.empty(((n + 31) // 32) * 8 * 32 * 64 * 4, dtype=torch.float32, device=device)
+        self.cscratch = torch.empty((((n + 31) // 32 + 3) // 4 * 4) * 8 * 32 * 64 * 4, dtype=torch.float32, device=device)
         s = _lib.FneusSdfBwdBufs()
         for name, t in (("qbar", self.qbar), ("adj", self.adj), ("zbar", self.zbar), ("zsdf", self.zsdf)):
             setattr(s, name + "_hi", t[0].data_ptr())
