@@ -1,0 +1,139 @@
+"""Ray feeders for the stage-1 hot path.
+
+Dataset           : DTU-format scenes (reference models/dataset.py:41-196): image/*.png, mask/*.png,
+                    cameras_sphere.npz (world_mat_i, scale_mat_i).  Images and cameras live ON THE DEVICE and rays are
+                    generated there, so a training step has no host->device copy (the reference indexes CPU images and
+                    uploads every step, dataset.py:133-151).  Colours are BGR/256 like the reference (cv2 order).
+SyntheticDataset  : DTU-shaped synthetic scene (random images, cameras on a sphere) for smoke runs and benchmarks.
+The other reference loaders (Sk3d / Shiny / Glossy*) are data-format variety outside the hot path and are not provided.
+"""
+from __future__ import annotations
+
+import os
+from glob import glob
+
+import numpy as np
+import torch
+
+
+def load_K_Rt_from_P(P):
+    """K, pose from a 3x4 projection (reference dataset.py:17-38 uses cv2.decomposeProjectionMatrix; here RQ)."""
+    from scipy.linalg import rq
+    M = P[:3, :3]
+    K, R = rq(M)
+    S = np.diag(np.sign(np.diag(K)))
+    K, R = K @ S, S @ R
+    if np.linalg.det(R) < 0:
+        R = -R
+    c = -np.linalg.inv(M) @ P[:3, 3]
+    K = K / K[2, 2]
+    intrinsics = np.eye(4, dtype=np.float32)
+    intrinsics[:3, :3] = K
+    pose = np.eye(4, dtype=np.float32)
+    pose[:3, :3] = R.T
+    pose[:3, 3] = c
+    return intrinsics, pose
+
+
+class _RayMixin:
+    def gen_rays_at(self, img_idx, resolution_level=1):
+        """all rays of one camera, [H/l, W/l, 3] each (dataset.py:115-131)"""
+        l = resolution_level
+        tx = torch.linspace(0, self.W - 1, self.W // l, device=self.device)
+        ty = torch.linspace(0, self.H - 1, self.H // l, device=self.device)
+        px, py = torch.meshgrid(tx, ty, indexing="ij")
+        p = torch.stack([px, py, torch.ones_like(py)], dim=-1)
+        p = torch.matmul(self.intrinsics_all_inv[img_idx, None, None, :3, :3], p[:, :, :, None]).squeeze(-1)
+        v = p / torch.linalg.norm(p, ord=2, dim=-1, keepdim=True)
+        v = torch.matmul(self.pose_all[img_idx, None, None, :3, :3], v[:, :, :, None]).squeeze(-1)
+        o = self.pose_all[img_idx, None, None, :3, 3].expand(v.shape)
+        return o.transpose(0, 1), v.transpose(0, 1)
+
+    def gen_random_rays_at(self, img_idx, batch_size):
+        """[B,10] = rays_o, rays_d, rgb, mask of random pixels of one camera (dataset.py:133-151), all on the device"""
+        img_idx = int(img_idx)
+        px = torch.randint(low=0, high=self.W, size=[batch_size], device=self.device)
+        py = torch.randint(low=0, high=self.H, size=[batch_size], device=self.device)
+        color = self.images[img_idx][(py, px)]
+        mask = self.masks[img_idx][(py, px)]
+        p = torch.stack([px, py, torch.ones_like(py)], dim=-1).float()
+        p = torch.matmul(self.intrinsics_all_inv[img_idx, None, :3, :3], p[:, :, None]).squeeze(-1)
+        v = p / torch.linalg.norm(p, ord=2, dim=-1, keepdim=True)
+        v = torch.matmul(self.pose_all[img_idx, None, :3, :3], v[:, :, None]).squeeze(-1)
+        o = self.pose_all[img_idx, None, :3, 3].expand(v.shape)
+        return torch.cat([o, v, color, mask[:, :1]], dim=-1)
+
+    @staticmethod
+    def near_far_from_sphere(rays_o, rays_d):
+        a = torch.sum(rays_d ** 2, dim=-1, keepdim=True)
+        b = 2.0 * torch.sum(rays_o * rays_d, dim=-1, keepdim=True)
+        mid = 0.5 * (-b) / a
+        return mid - 1.0, mid + 1.0
+
+
+class Dataset(_RayMixin):
+    def __init__(self, conf, device=None):
+        from PIL import Image
+        self.device = device or torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.conf = conf
+        self.data_dir = conf.get_string("data_dir")
+        cams = np.load(os.path.join(self.data_dir, conf.get_string("render_cameras_name")))
+        self.images_lis = sorted(glob(os.path.join(self.data_dir, "image/*.png")))
+        self.masks_lis = sorted(glob(os.path.join(self.data_dir, "mask/*.png")))
+        self.n_images = len(self.images_lis)
+
+        def read(path):     # RGB file -> BGR array / 256, like cv2.imread (dataset.py:61-63)
+            return np.asarray(Image.open(path).convert("RGB"), dtype=np.float32)[..., ::-1] / 256.0
+
+        self.images = torch.from_numpy(np.stack([read(p) for p in self.images_lis]).copy()).to(self.device)
+        self.masks = torch.from_numpy(np.stack([read(p) for p in self.masks_lis]).copy()).to(self.device)
+        self.scale_mats_np = [cams["scale_mat_%d" % i].astype(np.float32) for i in range(self.n_images)]
+        self.world_mats_np = [cams["world_mat_%d" % i].astype(np.float32) for i in range(self.n_images)]
+        intr, poses = [], []
+        for s, w in zip(self.scale_mats_np, self.world_mats_np):
+            K, pose = load_K_Rt_from_P((w @ s)[:3, :4])
+            intr.append(torch.from_numpy(K))
+            poses.append(torch.from_numpy(pose))
+        self.intrinsics_all = torch.stack(intr).to(self.device)
+        self.intrinsics_all_inv = torch.inverse(self.intrinsics_all)
+        self.pose_all = torch.stack(poses).to(self.device)
+        self.focal = self.intrinsics_all[0][0, 0]
+        self.H, self.W = self.images.shape[1], self.images.shape[2]
+        self.image_pixels = self.H * self.W
+        self.object_bbox_min = np.array([-1.01, -1.01, -1.01], dtype=np.float32)
+        self.object_bbox_max = np.array([1.01, 1.01, 1.01], dtype=np.float32)
+
+    def image_at(self, idx, resolution_level):
+        img = (self.images[idx] * 256.0).clip(0, 255)
+        l = resolution_level
+        return img[::l, ::l].cpu().numpy()
+
+
+class SyntheticDataset(_RayMixin):
+    """DTU-shaped synthetic scene: n_images cameras on a sphere of radius 2.8 looking at the origin."""
+
+    def __init__(self, n_images=8, H=120, W=160, device=None, seed=0):
+        self.device = device or torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        rs = np.random.RandomState(seed)
+        self.n_images, self.H, self.W = n_images, H, W
+        self.images = torch.from_numpy(rs.uniform(0, 1, size=(n_images, H, W, 3)).astype(np.float32)).to(self.device)
+        self.masks = torch.from_numpy((rs.uniform(0, 1, size=(n_images, H, W, 3)) < 0.7).astype(np.float32)).to(self.device)
+        f = 1.2 * W
+        K = np.array([[f, 0, W / 2, 0], [0, f, H / 2, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float32)
+        poses = []
+        for i in range(n_images):
+            c = rs.standard_normal(3)
+            c = c / np.linalg.norm(c) * 2.8
+            z = -c / np.linalg.norm(c)
+            x = np.cross(z, np.array([0.0, 0.0, 1.0]))
+            x = x / (np.linalg.norm(x) + 1e-9)
+            y = np.cross(z, x)
+            pose = np.eye(4, dtype=np.float32)
+            pose[:3, 0], pose[:3, 1], pose[:3, 2], pose[:3, 3] = x, y, z, c
+            poses.append(pose)
+        self.intrinsics_all = torch.from_numpy(np.stack([K] * n_images)).to(self.device)
+        self.intrinsics_all_inv = torch.inverse(self.intrinsics_all)
+        self.pose_all = torch.from_numpy(np.stack(poses)).to(self.device)
+        self.scale_mats_np = [np.eye(4, dtype=np.float32)] * n_images
+        self.object_bbox_min = np.array([-1.01, -1.01, -1.01], dtype=np.float32)
+        self.object_bbox_max = np.array([1.01, 1.01, 1.01], dtype=np.float32)
