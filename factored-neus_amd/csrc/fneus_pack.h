@@ -18,6 +18,16 @@ struct PackJob {
     uint32_t rowmap;     // int offset into maps: nt*32 entries, source row (or -1)
     uint32_t kmap;       // int offset into maps: ks*16 entries in k-slot order, source k (or -1)
     float scale;
+    int32_t rs_base;     // first entry of this layer in the row-scale table (g/||v|| per output row), or -1
+    int32_t rs_mode;     // 0: scale by the fragment row, 1: by the k index (transposed packs), 2: by rs_base itself
+};
+
+// One weight-normalised row: v[row][0..n_in), g[row]  ->  rowscale = g/||v||, inv_norm = 1/||v||
+struct RowInfo {
+    uint32_t off_v;      // float offset of the row of weight_v in the raw parameter buffer
+    uint32_t off_g;      // float offset of weight_g[row]; 0xFFFFFFFF = plain Linear (scale 1)
+    int32_t n_in;
+    uint32_t off_w_eff;  // float offset of the same row in the effective-parameter (gradient) buffer
 };
 
 }  // namespace fneus

@@ -8,9 +8,71 @@
 
 namespace fneus {
 
+// rowscale[r] = g/||v||, invnorm[r] = 1/||v|| for every weight-normalised row (nn.utils.weight_norm, dim=0:
+// reference models/fields.py:67-68, 139-140).  One wavefront per row.
+__global__ void __launch_bounds__(64) rowscale_kernel(const RowInfo* __restrict__ rows, int n_rows,
+                                                      const float* __restrict__ raw, float* __restrict__ rowscale,
+                                                      float* __restrict__ invnorm) {
+    const int row = blockIdx.x, lane = threadIdx.x;
+    if (row >= n_rows) return;
+    const RowInfo ri = rows[row];
+    float s = 0.0f;
+    for (int i = lane; i < ri.n_in; i += 64) {
+        const float v = raw[ri.off_v + i];
+        s += v * v;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if (lane == 0) {
+        if (ri.off_g == 0xFFFFFFFFu) {
+            rowscale[row] = 1.0f;
+            invnorm[row] = 0.0f;
+        } else {
+            const float inv = 1.0f / sqrtf(s);
+            rowscale[row] = raw[ri.off_g] * inv;
+            invnorm[row] = inv;
+        }
+    }
+}
+
+// Backward of the fold W = g v/||v|| (+ bias pass-through): d_eff (effective layout: W then b per layer) -> raw grads.
+//   dg = <dW, v>/||v|| ;  dv = (g/||v||) (dW - v <dW, v>/||v||^2)
+__global__ void __launch_bounds__(64) wn_backward_kernel(const RowInfo* __restrict__ rows, int n_rows,
+                                                         const float* __restrict__ raw, const float* __restrict__ rowscale,
+                                                         const float* __restrict__ invnorm, const float* __restrict__ d_eff,
+                                                         float* __restrict__ d_raw) {
+    const int row = blockIdx.x, lane = threadIdx.x;
+    if (row >= n_rows) return;
+    const RowInfo ri = rows[row];
+    if (ri.off_g == 0xFFFFFFFFu) {
+        for (int i = lane; i < ri.n_in; i += 64) d_raw[ri.off_v + i] += d_eff[ri.off_w_eff + i];
+        return;
+    }
+    float dot = 0.0f;
+    for (int i = lane; i < ri.n_in; i += 64) dot += d_eff[ri.off_w_eff + i] * raw[ri.off_v + i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) dot += __shfl_xor(dot, d, 64);
+    const float inv = invnorm[row], rs = rowscale[row];
+    const float c = dot * inv * inv;
+    for (int i = lane; i < ri.n_in; i += 64)
+        d_raw[ri.off_v + i] += rs * (d_eff[ri.off_w_eff + i] - raw[ri.off_v + i] * c);
+    if (lane == 0) d_raw[ri.off_g] += dot * inv;
+}
+
+__global__ void __launch_bounds__(256) add_segments_kernel(const int4* __restrict__ segs, int n_segs,
+                                                           const float* __restrict__ src, float* __restrict__ dst) {
+    // segs[i] = (src_off, dst_off, count, _): dst[dst_off + j] += src[src_off + j]   (bias gradients)
+    const int seg = blockIdx.y;
+    if (seg >= n_segs) return;
+    const int4 sg = segs[seg];
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < sg.z; j += gridDim.x * blockDim.x)
+        dst[sg.y + j] += src[sg.x + j];
+}
+
 __global__ void __launch_bounds__(64) pack_kernel(const PackJob* __restrict__ jobs, int n_jobs,
                                                   const int* __restrict__ maps,
                                                   const float* __restrict__ params,
+                                                  const float* __restrict__ rowscale,
                                                   unsigned char* __restrict__ blob) {
     const int unit = blockIdx.x;
     const int lane = threadIdx.x;
@@ -29,9 +91,11 @@ __global__ void __launch_bounds__(64) pack_kernel(const PackJob* __restrict__ jo
         for (int j = 0; j < 8; ++j) {
             const int k = maps[jb.kmap + 16 * ks + 8 * h + j];
             float v = 0.0f;
-            if (row >= 0 && k >= 0)
+            if (row >= 0 && k >= 0) {
                 v = jb.scale * (jb.transposed ? params[jb.src + (size_t)k * jb.ld + row]
                                               : params[jb.src + (size_t)row * jb.ld + k]);
+                if (jb.rs_base >= 0) v *= rowscale[jb.rs_base + (jb.rs_mode == 1 ? k : row)];
+            }
             __bf16 a, b;
             split_bf16(v, a, b);
             hi[j] = a;
@@ -44,7 +108,8 @@ __global__ void __launch_bounds__(64) pack_kernel(const PackJob* __restrict__ jo
         if (lane < 32) {
             const int hh = lane >> 4, reg = lane & 15;
             const int idx = maps[jb.rowmap + 32 * t + acc_row(reg, hh)];
-            const float v = idx >= 0 ? jb.scale * params[jb.src + (size_t)idx * jb.ld] : 0.0f;
+            float v = idx >= 0 ? jb.scale * params[jb.src + (size_t)idx * jb.ld] : 0.0f;
+            if (jb.rs_base >= 0 && idx >= 0) v *= rowscale[jb.rs_mode == 2 ? jb.rs_base : jb.rs_base + idx];
             reinterpret_cast<float*>(blob + jb.dst_hi)[(t * 2 + hh) * 16 + reg] = v;
         }
     }
@@ -53,12 +118,36 @@ __global__ void __launch_bounds__(64) pack_kernel(const PackJob* __restrict__ jo
 }  // namespace fneus
 
 extern "C" int fneus_pack(const void* jobs, int n_jobs, int n_units, const int* maps, const float* params,
-                          void* blob, fneus_stream_t stream_) {
+                          const float* rowscale, void* blob, fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     fneus::clear_status();
     if (n_units <= 0) return 0;
     hipLaunchKernelGGL(fneus::pack_kernel, dim3(n_units), dim3(64), 0, stream,
-                       reinterpret_cast<const fneus::PackJob*>(jobs), n_jobs, maps, params,
+                       reinterpret_cast<const fneus::PackJob*>(jobs), n_jobs, maps, params, rowscale,
                        reinterpret_cast<unsigned char*>(blob));
+    return fneus::launch_status();
+}
+
+extern "C" int fneus_rowscale(const void* rows, int n_rows, const float* raw, float* rowscale, float* invnorm,
+                              fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (n_rows <= 0) return 0;
+    hipLaunchKernelGGL(fneus::rowscale_kernel, dim3(n_rows), dim3(64), 0, stream,
+                       reinterpret_cast<const fneus::RowInfo*>(rows), n_rows, raw, rowscale, invnorm);
+    return fneus::launch_status();
+}
+
+extern "C" int fneus_wn_backward(const void* rows, int n_rows, const void* bias_segs, int n_segs, const float* raw,
+                                 const float* rowscale, const float* invnorm, const float* d_eff, float* d_raw,
+                                 fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (n_rows > 0)
+        hipLaunchKernelGGL(fneus::wn_backward_kernel, dim3(n_rows), dim3(64), 0, stream,
+                           reinterpret_cast<const fneus::RowInfo*>(rows), n_rows, raw, rowscale, invnorm, d_eff, d_raw);
+    if (n_segs > 0)
+        hipLaunchKernelGGL(fneus::add_segments_kernel, dim3(2, n_segs), dim3(256), 0, stream,
+                           reinterpret_cast<const int4*>(bias_segs), n_segs, d_eff, d_raw);
     return fneus::launch_status();
 }

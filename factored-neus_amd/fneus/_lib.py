@@ -52,7 +52,9 @@ def _load():
         "fneus_version": (C.c_int, []),
         "fneus_last_error": (C.c_char_p, []),
         "fneus_layout": (C.c_int, [ip, vp, ip]),
-        "fneus_pack": (C.c_int, [vp, ip, ip, vp, vp, vp, vp]),
+        "fneus_pack": (C.c_int, [vp, ip, ip, vp, vp, vp, vp, vp]),
+        "fneus_rowscale": (C.c_int, [vp, ip, vp, vp, vp, vp]),
+        "fneus_wn_backward": (C.c_int, [vp, ip, vp, ip, vp, vp, vp, vp, vp, vp]),
         "fneus_sdf_fwd": (C.c_int, [vp, vp, vp, vp, vp, ip, l, vp, ip, vp]),
         "fneus_sdf_fwd_grad": (C.c_int, [vp, vp, vp, vp, vp, ip, l, C.POINTER(FneusSdfStash), vp, vp, vp, ip, ip, vp]),
     }

@@ -36,16 +36,16 @@ class _Workspace:
 
 
 class SdfValueGradFn(torch.autograd.Function):
-    """K2 forward, K3 + weight-gradient GEMM backward.  Inputs: flat effective parameters (for the graph only; the
-    blob was packed from the same tensor by SDFNetwork.refresh)."""
+    """K2 forward; backward = K3 + weight-gradient GEMM + weight-norm backward.  The parameters are not autograd
+    inputs: their gradients are ACCUMULATED into the network's flat gradient buffer (which the Parameters' .grad
+    alias); `anchor` is a dummy leaf that makes autograd call backward."""
 
     @staticmethod
-    def forward(ctx, flat, net, samples: RaySamples, prec: int, ws: _Workspace, train: bool):
+    def forward(ctx, anchor, net, samples: RaySamples, prec: int, ws: _Workspace, train: bool):
         n = samples.n
-        stash = ws.get(("sdf_stash", n, prec, train), lambda: ops.SdfStash(n, flat.device, prec, train))
+        stash = ws.get(("sdf_stash", n, prec, train), lambda: ops.SdfStash(n, anchor.device, prec, train))
         sdf, feat, normal = ops.sdf_fwd_grad(net.blob, n, prec, stash, train, **samples.kw())
         ctx.net, ctx.samples, ctx.prec, ctx.ws, ctx.stash, ctx.n = net, samples, prec, ws, stash, n
-        ctx.mark_non_differentiable()
         return sdf, feat, normal
 
     @staticmethod
@@ -61,17 +61,18 @@ class SdfValueGradFn(torch.autograd.Function):
         grad.zero_()
         jobs = ws.get(("sdf_jobs", n, prec), lambda: ops.sdf_dw_jobs(net, ctx.stash, bufs, grad, n))
         jobs.run(n, prec)
-        return grad.clone(), None, None, None, None, None
+        net.wn_backward(grad)
+        return None, None, None, None, None, None
 
 
 class ColorFn(torch.autograd.Function):
     """K4 forward / backward (+ weight-gradient GEMM).  Differentiable inputs: flat params, normal, feature."""
 
     @staticmethod
-    def forward(ctx, flat, normal, feat, net, samples: RaySamples, prec: int, ws: _Workspace, sdf_ws: _Workspace,
+    def forward(ctx, anchor, normal, feat, net, samples: RaySamples, prec: int, ws: _Workspace, sdf_ws: _Workspace,
                 train: bool):
         n = samples.n
-        stash = ws.get(("col_stash", n, prec), lambda: ops.ColStash(n, flat.device, prec)) if train else None
+        stash = ws.get(("col_stash", n, prec), lambda: ops.ColStash(n, anchor.device, prec)) if train else None
         rgb = ops.color_fwd(net.blob, n, prec, normal.contiguous(), feat.contiguous(), stash, train, dirs=samples.dirs,
                             **samples.kw())
         ctx.net, ctx.prec, ctx.ws, ctx.sdf_ws, ctx.stash, ctx.n = net, prec, ws, sdf_ws, stash, n
@@ -88,7 +89,8 @@ class ColorFn(torch.autograd.Function):
         sdf_stash = ctx.sdf_ws.cache[("sdf_stash", n, prec, True)]
         jobs = ws.get(("col_jobs", n, prec), lambda: ops.color_dw_jobs(net, sdf_stash, ctx.stash, grad, n))
         jobs.run(n, prec)
-        return grad.clone(), d_normal, d_feat, None, None, None, None, None, None
+        net.wn_backward(grad)
+        return None, d_normal, d_feat, None, None, None, None, None, None
 
 
 class CompositeFn(torch.autograd.Function):

@@ -21,7 +21,8 @@ from . import _lib
 PACK_FRAG, PACK_ACCVEC = 0, 1
 JOB_DTYPE = np.dtype([("kind", "<i4"), ("unit_base", "<i4"), ("dst_hi", "<u4"), ("dst_lo", "<u4"), ("src", "<u4"),
                       ("ld", "<i4"), ("ks", "<i4"), ("nt", "<i4"), ("transposed", "<i4"), ("rowmap", "<u4"),
-                      ("kmap", "<u4"), ("scale", "<f4")])
+                      ("kmap", "<u4"), ("scale", "<f4"), ("rs_base", "<i4"), ("rs_mode", "<i4")])
+ROW_DTYPE = np.dtype([("off_v", "<u4"), ("off_g", "<u4"), ("n_in", "<i4"), ("off_w_eff", "<u4")])
 
 SDF_IN = [39, 256, 256, 256, 256, 256, 256, 256, 256]
 SDF_OUT = [256, 256, 256, 217, 256, 256, 256, 256, 257]
@@ -65,6 +66,30 @@ def query_layout(which: int) -> Layout:
     return Layout(L, int(a[1]), int(a[2]), per[:, :5].copy(), per[:, 5:].copy())
 
 
+def raw_offsets(ins, outs):
+    """Raw (module) parameter layout, state_dict order per layer: bias[out], weight_g[out], weight_v[out][in]."""
+    offB, offG, offV, o = [], [], [], 0
+    for i, k in zip(ins, outs):
+        offB.append(o)
+        o += k
+        offG.append(o)
+        o += k
+        offV.append(o)
+        o += i * k
+    return offB, offG, offV, o
+
+
+def row_table(ins, outs, offW_eff):
+    """RowInfo per weight-normalised output row + the first row index of each layer"""
+    offB, offG, offV, _ = raw_offsets(ins, outs)
+    rows, base = [], []
+    for l, (i, k) in enumerate(zip(ins, outs)):
+        base.append(len(rows))
+        for r in range(k):
+            rows.append((offV[l] + r * i, offG[l] + r, i, offW_eff[l] + r * i))
+    return np.array(rows, dtype=ROW_DTYPE), base
+
+
 def flat_offsets(ins, outs):
     """(offW, offb, total) of the flat fp32 parameter buffer: per layer W[out][in] then b[out]."""
     offW, offb, o = [], [], 0
@@ -90,15 +115,16 @@ class _Builder:
         self.n_map += arr.size
         return off
 
-    def frag(self, dst_hi, dst_lo, src, ld, ks, nt, transposed, rowmap, kmap, scale=1.0):
+    def frag(self, dst_hi, dst_lo, src, ld, ks, nt, transposed, rowmap, kmap, scale=1.0, rs_base=-1):
         assert len(rowmap) == nt * 32 and len(kmap) == ks * 16
         self.jobs.append((PACK_FRAG, self.units, dst_hi, dst_lo, src, ld, ks, nt, transposed,
-                          self.add_map(rowmap), self.add_map(kmap), scale))
+                          self.add_map(rowmap), self.add_map(kmap), scale, rs_base, 1 if transposed else 0))
         self.units += ks * nt
 
-    def accvec(self, dst, src, ld, nt, rowmap, scale=1.0):
+    def accvec(self, dst, src, ld, nt, rowmap, scale=1.0, rs_base=-1, rs_mode=0):
         assert len(rowmap) == nt * 32
-        self.jobs.append((PACK_ACCVEC, self.units, dst, 0, src, ld, 0, nt, 0, self.add_map(rowmap), 0, scale))
+        self.jobs.append((PACK_ACCVEC, self.units, dst, 0, src, ld, 0, nt, 0, self.add_map(rowmap), 0, scale,
+                          rs_base, rs_mode))
         self.units += nt
 
     def finish(self):
@@ -114,7 +140,9 @@ def _lim(idx, n):
 
 def build_sdf_jobs():
     ly = query_layout(0)
-    offW, offb, total = flat_offsets(SDF_IN, SDF_OUT)
+    offW, offb, total = flat_offsets(SDF_IN, SDF_OUT)          # effective layout (gradients of W_eff, b)
+    offB, offG, offV, total_raw = raw_offsets(SDF_IN, SDF_OUT)  # module parameters (bias, weight_g, weight_v)
+    row_tab, rbase = row_table(SDF_IN, SDF_OUT, offW)
     b = _Builder()
     inv_sqrt2 = 1.0 / math.sqrt(2.0)
     for l in range(9):
@@ -133,7 +161,7 @@ def build_sdf_jobs():
             kmap = np.where(feat < 224, _lim(feat, 217), np.where(feat - 224 < N_PE, 217 + (feat - 224), -1))
         else:
             kmap = _lim(feat, n_in)
-        b.frag(fwd_hi, fwd_lo, offW[l], n_in, ksf, ntf, 0, rowmap, kmap, scale)
+        b.frag(fwd_hi, fwd_lo, offV[l], n_in, ksf, ntf, 0, rowmap, kmap, scale, rbase[l])
         # ---- reverse (A = W^T): rows = inputs, k-slots = outputs (accumulator order of a_l / zbar_l)
         ofeat = slot_features(ksr)
         if l == 8:
@@ -145,18 +173,22 @@ def build_sdf_jobs():
             rowmap_r = np.where(rin < 224, _lim(rin, 217), np.where(rin - 224 < N_PE, 217 + (rin - 224), -1))
         else:
             rowmap_r = _lim(rin, n_in)
-        b.frag(rev_hi, rev_lo, offW[l], n_in, ksr, ntr, 1, rowmap_r, kmap_r, scale)
-        b.accvec(bias, offb[l], 1, ntf, rowmap)
+        b.frag(rev_hi, rev_lo, offV[l], n_in, ksr, ntr, 1, rowmap_r, kmap_r, scale, rbase[l])
+        b.accvec(bias, offB[l], 1, ntf, rowmap)
     # row 0 of the last layer in accumulator layout: g_hat(h_8) of the reverse sweep
-    b.accvec(ly.extra, offW[8], 1, 8, np.arange(256))
+    b.accvec(ly.extra, offV[8], 1, 8, np.arange(256), rs_base=rbase[8], rs_mode=2)
     jobs, maps, units = b.finish()
+    segs = np.array([(offb[l], offB[l], SDF_OUT[l], 0) for l in range(9)], dtype=np.int32)
     return {"layout": ly, "jobs": jobs, "maps": maps, "units": units, "n_params": total, "offW": offW, "offb": offb,
-            "ins": SDF_IN, "outs": SDF_OUT}
+            "ins": SDF_IN, "outs": SDF_OUT, "n_raw": total_raw, "offB": offB, "offG": offG, "offV": offV,
+            "rows": row_tab, "bias_segs": segs}
 
 
 def build_color_jobs():
     ly = query_layout(1)
     offW, offb, total = flat_offsets(COL_IN, COL_OUT)
+    offB, offG, offV, total_raw = raw_offsets(COL_IN, COL_OUT)
+    row_tab, rbase = row_table(COL_IN, COL_OUT, offW)
     b = _Builder()
     for l in range(5):
         ksf, ntf, ksr, ntr = [int(v) for v in ly.geom[l]]
@@ -168,15 +200,17 @@ def build_color_jobs():
             kmap = np.where(feat < 256, feat + N_SIDE, np.where(feat - 256 < N_SIDE, feat - 256, -1))
         else:
             kmap = _lim(feat, n_in)
-        b.frag(fwd_hi, fwd_lo, offW[l], n_in, ksf, ntf, 0, rowmap, kmap)
+        b.frag(fwd_hi, fwd_lo, offV[l], n_in, ksf, ntf, 0, rowmap, kmap, 1.0, rbase[l])
         kmap_r = _lim(slot_features(ksr), n_out)
         rin = np.arange(ntr * 32)
         if l == 0:
             rowmap_r = np.where(rin < 256, rin + N_SIDE, np.where(rin - 256 < N_SIDE, rin - 256, -1))
         else:
             rowmap_r = _lim(rin, n_in)
-        b.frag(rev_hi, rev_lo, offW[l], n_in, ksr, ntr, 1, rowmap_r, kmap_r)
-        b.accvec(bias, offb[l], 1, ntf, rowmap)
+        b.frag(rev_hi, rev_lo, offV[l], n_in, ksr, ntr, 1, rowmap_r, kmap_r, 1.0, rbase[l])
+        b.accvec(bias, offB[l], 1, ntf, rowmap)
     jobs, maps, units = b.finish()
+    segs = np.array([(offb[l], offB[l], COL_OUT[l], 0) for l in range(5)], dtype=np.int32)
     return {"layout": ly, "jobs": jobs, "maps": maps, "units": units, "n_params": total, "offW": offW, "offb": offb,
-            "ins": COL_IN, "outs": COL_OUT}
+            "ins": COL_IN, "outs": COL_OUT, "n_raw": total_raw, "offB": offB, "offG": offG, "offV": offV,
+            "rows": row_tab, "bias_segs": segs}

@@ -60,27 +60,46 @@ def _chk_f32(t: torch.Tensor, name: str):
 
 
 class PackedNet:
-    """Device-side packed weights of one MLP ('sdf' or 'color') + its pack-job tables."""
+    """Device-side packed weights of one MLP ('sdf' or 'color'), its pack-job tables and the flat RAW parameter /
+    gradient buffers (bias, weight_g, weight_v per layer, state_dict order).  The weight-norm fold runs inside the
+    packer and its backward in fneus_wn_backward, so a step needs 2 + 2 small launches per network instead of ~150
+    torch element-wise kernels."""
 
     def __init__(self, kind: str, device):
         desc = netdesc.build_sdf_jobs() if kind == "sdf" else netdesc.build_color_jobs()
         self.kind, self.desc, self.device = kind, desc, device
         self.layout = desc["layout"]
-        self.n_params = desc["n_params"]
+        self.n_params = desc["n_params"]            # effective (W, b) layout: gradient buffer of the dW GEMM
+        self.n_raw = desc["n_raw"]
         self.jobs = torch.from_numpy(desc["jobs"].view(np.uint8).copy()).to(device)
         self.maps = torch.from_numpy(desc["maps"]).to(device)
+        self.rows = torch.from_numpy(desc["rows"].view(np.uint8).copy()).to(device)
+        self.bias_segs = torch.from_numpy(desc["bias_segs"].copy()).to(device)
+        self.n_rows = len(desc["rows"])
         self.n_jobs = len(desc["jobs"])
         self.units = desc["units"]
         self.blob = torch.zeros(self.layout.total, dtype=torch.uint8, device=device)
+        self.rowscale = torch.zeros(self.n_rows, dtype=torch.float32, device=device)
+        self.invnorm = torch.zeros(self.n_rows, dtype=torch.float32, device=device)
+        self.raw = torch.zeros(self.n_raw, dtype=torch.float32, device=device)
+        self.raw_grad = torch.zeros(self.n_raw, dtype=torch.float32, device=device)
 
-    def flat_from_lists(self, Ws, bs) -> torch.Tensor:
-        parts = []
-        for W, b in zip(Ws, bs):
-            parts.append(W.reshape(-1))
-            parts.append(b.reshape(-1))
-        flat = torch.cat(parts)
-        assert flat.numel() == self.n_params
-        return flat
+    # ---- raw parameter views (what the nn.Parameters of the module alias) ----
+    def raw_views(self, buf):
+        d = self.desc
+        out = []
+        for l, (i, o) in enumerate(zip(d["ins"], d["outs"])):
+            out.append({"bias": buf[d["offB"][l]: d["offB"][l] + o],
+                        "weight_g": buf[d["offG"][l]: d["offG"][l] + o].view(o, 1),
+                        "weight_v": buf[d["offV"][l]: d["offV"][l] + o * i].view(o, i)})
+        return out
+
+    def set_raw_from_effective(self, Ws, bs):
+        """test helper: load effective weights as (g = ||W||, v = W)"""
+        for view, W, b in zip(self.raw_views(self.raw), Ws, bs):
+            view["bias"].copy_(b)
+            view["weight_v"].copy_(W)
+            view["weight_g"].copy_(W.norm(dim=1, keepdim=True))
 
     def split_flat(self, flat: torch.Tensor):
         Ws, bs = [], []
@@ -89,12 +108,19 @@ class PackedNet:
             bs.append(flat[self.desc["offb"][l]: self.desc["offb"][l] + o])
         return Ws, bs
 
-    def pack(self, flat: torch.Tensor):
-        _chk_f32(flat, "flat params")
-        assert flat.numel() == self.n_params
-        _launch("fneus_pack", lib.fneus_pack, _ptr(self.jobs), self.n_jobs, self.units, _ptr(self.maps), _ptr(flat), _ptr(self.blob),
-                             _stream())
+    def pack(self):
+        """fold weight-norm + pack the current raw parameters (once per optimiser step)"""
+        _launch("fneus_rowscale", lib.fneus_rowscale, _ptr(self.rows), self.n_rows, _ptr(self.raw), _ptr(self.rowscale),
+                _ptr(self.invnorm), _stream())
+        _launch("fneus_pack", lib.fneus_pack, _ptr(self.jobs), self.n_jobs, self.units, _ptr(self.maps), _ptr(self.raw),
+                _ptr(self.rowscale), _ptr(self.blob), _stream())
         return self.blob
+
+    def wn_backward(self, d_eff: torch.Tensor):
+        """accumulate raw-parameter gradients from the effective-parameter gradients"""
+        _launch("fneus_wn_backward", lib.fneus_wn_backward, _ptr(self.rows), self.n_rows, _ptr(self.bias_segs),
+                int(self.bias_segs.shape[0]), _ptr(self.raw), _ptr(self.rowscale), _ptr(self.invnorm), _ptr(d_eff),
+                _ptr(self.raw_grad), _stream())
 
 
 class SdfStash:

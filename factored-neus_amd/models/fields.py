@@ -53,14 +53,20 @@ class WNLinear(nn.Module):
 
 
 class _HipMLP(nn.Module):
-    """Shared plumbing: flat effective parameters -> packed blob (once per optimiser step)."""
+    """Shared plumbing of the two fused MLPs.
+
+    The nn.Parameters (reference names lin{l}.bias / weight_g / weight_v) are VIEWS into one flat fp32 buffer owned by
+    the PackedNet, and their .grad are views into one flat gradient buffer: the packer reads the flat buffer directly
+    (weight-norm fold inside the kernel) and the backward kernels accumulate into the flat gradient, so the module
+    costs a handful of launches per step; the data-parallel all-reduce and Adam see ordinary Parameters."""
 
     kind = None
 
     def _init_backend(self):
         self._net = None
         self._ws = _Workspace()
-        self._flat = None
+        self._anchor = None
+        self._packed = False
         self.prec = ops.PREC_PARITY
 
     def set_precision(self, prec: int):
@@ -70,23 +76,45 @@ class _HipMLP(nn.Module):
     def _lins(self):
         return [getattr(self, f"lin{l}") for l in range(self.num_layers - 1)]
 
-    def refresh(self):
-        """Fold weight-norm (torch, differentiable) and pack for the kernels.  Call once per step before rendering."""
+    def _attach(self):
+        """(re)create the device backend and alias the Parameters onto its flat buffers"""
         dev = self.lin0.bias.device
         if dev.type != "cuda":
             raise RuntimeError("the fneus HIP backend needs the module on a GPU (there is no CPU fallback)")
-        if self._net is None or self._net.device != dev:
-            self._net = ops.PackedNet(self.kind, dev)
-        parts = []
-        for lin in self._lins():
-            parts.append(lin.effective_weight().reshape(-1))
-            parts.append(lin.bias.reshape(-1))
-        self._flat = torch.cat(parts)
-        self._net.pack(self._flat.detach().contiguous())
-        return self._flat
+        if any(not lin.weight_norm for lin in self._lins()):
+            raise NotImplementedError("the fused packer expects weight_norm=True as in confs/wmask.conf")
+        net = ops.PackedNet(self.kind, dev)
+        with torch.no_grad():
+            for lin, view, gview in zip(self._lins(), net.raw_views(net.raw), net.raw_views(net.raw_grad)):
+                for name in ("bias", "weight_g", "weight_v"):
+                    prm = getattr(lin, name)
+                    view[name].copy_(prm.data)
+                    if prm.grad is not None:
+                        gview[name].copy_(prm.grad)
+                    prm.data = view[name]
+                    prm.grad = gview[name]
+        self._net = net
+        self._anchor = torch.zeros(1, device=dev, requires_grad=True)
+
+    def _attached(self):
+        return (self._net is not None and self.lin0.bias.device == self._net.device
+                and self.lin0.bias.data_ptr() == self._net.raw_views(self._net.raw)[0]["bias"].data_ptr())
+
+    def refresh(self):
+        """Fold weight-norm and pack the current parameters for the kernels.  Call once per step before rendering."""
+        if not self._attached():
+            self._attach()
+        for lin, gview in zip(self._lins(), self._net.raw_views(self._net.raw_grad)):
+            for name in ("bias", "weight_g", "weight_v"):      # optimizer.zero_grad(set_to_none=True) drops the views
+                prm = getattr(lin, name)
+                if prm.grad is None:
+                    gview[name].zero_()
+                    prm.grad = gview[name]
+        self._net.pack()
+        self._packed = True
 
     def _ensure(self):
-        if self._flat is None:
+        if not self._packed or not self._attached():
             self.refresh()
 
 
@@ -135,7 +163,7 @@ class SDFNetwork(_HipMLP):
     def value_feature_normal(self, samples: RaySamples, train: bool):
         """sdf [n], feature [n,256], normal [n,3] in one fused pass (K2), differentiable w.r.t. the parameters"""
         self._ensure()
-        return SdfValueGradFn.apply(self._flat, self._net, samples, self.prec, self._ws, train)
+        return SdfValueGradFn.apply(self._anchor, self._net, samples, self.prec, self._ws, train)
 
     # ---- reference API (fields.py:74-111) ----
     def forward(self, inputs, iter_step=0):
@@ -175,7 +203,7 @@ class RenderingNetwork(_HipMLP):
 
     def color_samples(self, samples: RaySamples, normal, feat, sdf_net: SDFNetwork, train: bool):
         self._ensure()
-        return ColorFn.apply(self._flat, normal, feat, self._net, samples, self.prec, self._ws, sdf_net._ws, train)
+        return ColorFn.apply(self._anchor, normal, feat, self._net, samples, self.prec, self._ws, sdf_net._ws, train)
 
     def forward(self, points, normals, view_dirs, feature_vectors):
         s = RaySamples(pts=points.detach().float().contiguous(), dirs=view_dirs.detach().float().contiguous())

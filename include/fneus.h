@@ -78,9 +78,19 @@ const char* fneus_last_error(void);      /* host pointer, static storage */
 int fneus_layout(int which, int32_t* out, int cap);
 
 /* ---- weight packing (every optimiser step) --------------------------------------------------------------- */
-/* jobs: device array of PackJob (csrc/fneus_pack.h), maps: device int32 index maps, params: flat fp32 parameters. */
-int fneus_pack(const void* jobs, int n_jobs, int n_units, const int32_t* maps, const float* params, void* blob,
-               fneus_stream_t stream);
+/* jobs: device array of PackJob (csrc/fneus_pack.h), maps: device int32 index maps, params: flat fp32 parameters
+ * (raw weight_v / weight_g / bias when `rowscale` is given: the weight-norm fold W = g v/||v|| of
+ * nn.utils.weight_norm, fields.py:67-68, happens inside the packer), rowscale: per-row g/||v|| or NULL. */
+int fneus_pack(const void* jobs, int n_jobs, int n_units, const int32_t* maps, const float* params,
+               const float* rowscale, void* blob, fneus_stream_t stream);
+/* rows: device array of RowInfo (csrc/fneus_pack.h), one per weight-normalised output row. */
+int fneus_rowscale(const void* rows, int n_rows, const float* raw, float* rowscale, float* invnorm,
+                   fneus_stream_t stream);
+/* backward of the fold: effective-parameter gradients d_eff (W then b per layer) -> ACCUMULATED into the raw
+ * parameter gradients d_raw (weight_v, weight_g, bias); bias_segs: device int4 (src_off, dst_off, count, 0). */
+int fneus_wn_backward(const void* rows, int n_rows, const void* bias_segs, int n_segs, const float* raw,
+                      const float* rowscale, const float* invnorm, const float* d_eff, float* d_raw,
+                      fneus_stream_t stream);
 
 /* ---- K1: SDFNetwork.sdf under no_grad  (fields.py:93-95 via renderer.py:199, 430, 515) -------------------- */
 int fneus_sdf_fwd(const void* sdf_blob, const float* pts, const float* rays_o, const float* rays_d, const float* t,

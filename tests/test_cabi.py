@@ -39,8 +39,11 @@ def test_pack_job_tables():
     from fneus import netdesc
     for d in (netdesc.build_sdf_jobs(), netdesc.build_color_jobs()):
         jobs, maps = d["jobs"], d["maps"]
-        assert jobs.dtype.itemsize == 48
+        assert jobs.dtype.itemsize == 56
         assert (np.diff(jobs["unit_base"]) > 0).all()
         # every parameter is referenced by at least one forward fragment map
         assert maps.max() < max(max(d["ins"]), max(d["outs"]))
         assert d["units"] == int(jobs["unit_base"][-1]) + int(jobs["nt"][-1])
+        rows = d["rows"]
+        assert rows.dtype.itemsize == 16 and len(rows) == sum(d["outs"])
+        assert d["n_raw"] == sum(o * i + 2 * o for i, o in zip(d["ins"], d["outs"]))

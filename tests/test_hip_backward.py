@@ -34,8 +34,10 @@ def env():
     sp = R.sdf_params_from_state_dict(sdf_sd)
     cp = R.color_params_from_state_dict(col_sd)
     snet, cnet = ops.PackedNet("sdf", dev), ops.PackedNet("color", dev)
-    snet.pack(snet.flat_from_lists([w.to(dev) for w in sp["W"]], [b.to(dev) for b in sp["b"]]).contiguous())
-    cnet.pack(cnet.flat_from_lists([w.to(dev) for w in cp["W"]], [b.to(dev) for b in cp["b"]]).contiguous())
+    snet.set_raw_from_effective([w.to(dev) for w in sp["W"]], [b.to(dev) for b in sp["b"]])
+    snet.pack()
+    cnet.set_raw_from_effective([w.to(dev) for w in cp["W"]], [b.to(dev) for b in cp["b"]])
+    cnet.pack()
     rs = np.random.RandomState(11)
     n = 1500
     x = T(rs.uniform(-1.1, 1.1, size=(n, 3)).astype(np.float32))

@@ -18,8 +18,8 @@ def env():
     sd = {k: T(v) for k, v in synth.sdf_state_dict(20).items()}
     p = R.sdf_params_from_state_dict(sd)
     net = ops.PackedNet("sdf", dev)
-    flat = net.flat_from_lists([w.to(dev) for w in p["W"]], [b.to(dev) for b in p["b"]]).contiguous()
-    net.pack(flat)
+    net.set_raw_from_effective([w.to(dev) for w in p["W"]], [b.to(dev) for b in p["b"]])
+    net.pack()
     rs = np.random.RandomState(7)
     x = rs.uniform(-1.1, 1.1, size=(1000, 3)).astype(np.float32)   # 1000: not a multiple of 32
     x[0] = 0.0

@@ -8,7 +8,8 @@ dev = torch.device("cuda:0")
 col_sd = {k: T(v) for k, v in synth.color_state_dict(21).items()}
 cp = R.color_params_from_state_dict(col_sd)
 cnet = ops.PackedNet("color", dev)
-cnet.pack(cnet.flat_from_lists([w.to(dev) for w in cp["W"]], [b.to(dev) for b in cp["b"]]).contiguous())
+cnet.set_raw_from_effective([w.to(dev) for w in cp["W"]], [b.to(dev) for b in cp["b"]])
+    cnet.pack()
 rs = np.random.RandomState(5); n = int(sys.argv[1]); prec = 3
 x = T(rs.uniform(-1, 1, size=(n, 3)).astype(np.float32)); d = T(rs.standard_normal((n, 3)).astype(np.float32)); d = d / d.norm(dim=-1, keepdim=True)
 normal = T(rs.standard_normal((n, 3)).astype(np.float32)); feat = T((rs.standard_normal((n, 256)) * 0.3).astype(np.float32)); c_rgb = T(rs.standard_normal((n, 3)).astype(np.float32))
