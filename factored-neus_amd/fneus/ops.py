@@ -263,7 +263,7 @@ class GemmJobs:
         j.lda, j.ldb, j.lda2, j.ldb2, j.ldc = lda, ldb, lda2, ldb2, ldc
         j.m, j.n, j.a_w, j.b_w, j.a2_mode, j.scale = m, n, a_w, b_w, a2_mode, scale
         j.tile_base = self.tiles
-        self.tiles += ((m + 127) // 128) * ((n + 127) // 128)
+        self.tiles += ((m + 255) // 256) * ((n + 255) // 256)
         self.jobs.append(j)
 
     def finalize(self):
