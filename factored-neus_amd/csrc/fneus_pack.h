@@ -20,6 +20,8 @@ struct PackJob {
     float scale;
     int32_t rs_base;     // first entry of this layer in the row-scale table (g/||v|| per output row), or -1
     int32_t rs_mode;     // 0: scale by the fragment row, 1: by the k index (transposed packs), 2: by rs_base itself
+    int32_t geom;        // 0: 32-row tiles / 16-deep k-steps (mfma 32x32x16)   1: 16-row tiles / 32-deep (mfma 16x16x32)
+    int32_t pad;
 };
 
 // One weight-normalised row: v[row][0..n_in), g[row]  ->  rowscale = g/||v||, inv_norm = 1/||v||

@@ -85,11 +85,14 @@ __global__ void __launch_bounds__(64) pack_kernel(const PackJob* __restrict__ jo
     const int r = lane & 31, h = lane >> 5;
     if (jb.kind == PACK_FRAG) {
         const int ks = u / jb.nt, t = u % jb.nt;
-        const int row = maps[jb.rowmap + 32 * t + r];
+        // geometry 0: lane = (row r = lane&31, half h): k-slot 16ks + 8h + j ; geometry 1: (row c = lane&15, quarter q): 32ks + 8q + j
+        const int rr = jb.geom ? (lane & 15) : r;
+        const int row = maps[jb.rowmap + (jb.geom ? 16 : 32) * t + rr];
+        const int kbase = jb.geom ? 32 * ks + 8 * (lane >> 4) : 16 * ks + 8 * h;
         bf16x8 hi, lo;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int k = maps[jb.kmap + 16 * ks + 8 * h + j];
+            const int k = maps[jb.kmap + kbase + j];
             float v = 0.0f;
             if (row >= 0 && k >= 0) {
                 v = jb.scale * (jb.transposed ? params[jb.src + (size_t)k * jb.ld + row]
@@ -103,7 +106,7 @@ __global__ void __launch_bounds__(64) pack_kernel(const PackJob* __restrict__ jo
         }
         *reinterpret_cast<bf16x8*>(blob + jb.dst_hi + (size_t)u * kFragBytes + lane * 16) = hi;
         *reinterpret_cast<bf16x8*>(blob + jb.dst_lo + (size_t)u * kFragBytes + lane * 16) = lo;
-    } else {  // PACK_ACCVEC: fp32 vector in accumulator layout [t][h][16]
+    } else if (jb.geom == 0) {  // PACK_ACCVEC: fp32 vector in accumulator layout [t][h][16]
         const int t = u;
         if (lane < 32) {
             const int hh = lane >> 4, reg = lane & 15;
@@ -111,6 +114,14 @@ __global__ void __launch_bounds__(64) pack_kernel(const PackJob* __restrict__ jo
             float v = idx >= 0 ? jb.scale * params[jb.src + (size_t)idx * jb.ld] : 0.0f;
             if (jb.rs_base >= 0 && idx >= 0) v *= rowscale[jb.rs_mode == 2 ? jb.rs_base : jb.rs_base + idx];
             reinterpret_cast<float*>(blob + jb.dst_hi)[(t * 2 + hh) * 16 + reg] = v;
+        }
+    } else {                    // 16-row tiles: natural order, 16 floats per tile
+        const int t = u;
+        if (lane < 16) {
+            const int idx = maps[jb.rowmap + 16 * t + lane];
+            float v = idx >= 0 ? jb.scale * params[jb.src + (size_t)idx * jb.ld] : 0.0f;
+            if (jb.rs_base >= 0 && idx >= 0) v *= rowscale[jb.rs_mode == 2 ? jb.rs_base : jb.rs_base + idx];
+            reinterpret_cast<float*>(blob + jb.dst_hi)[t * 16 + lane] = v;
         }
     }
 }

@@ -21,7 +21,8 @@ from . import _lib
 PACK_FRAG, PACK_ACCVEC = 0, 1
 JOB_DTYPE = np.dtype([("kind", "<i4"), ("unit_base", "<i4"), ("dst_hi", "<u4"), ("dst_lo", "<u4"), ("src", "<u4"),
                       ("ld", "<i4"), ("ks", "<i4"), ("nt", "<i4"), ("transposed", "<i4"), ("rowmap", "<u4"),
-                      ("kmap", "<u4"), ("scale", "<f4"), ("rs_base", "<i4"), ("rs_mode", "<i4")])
+                      ("kmap", "<u4"), ("scale", "<f4"), ("rs_base", "<i4"), ("rs_mode", "<i4"), ("geom", "<i4"),
+                      ("pad", "<i4")])
 ROW_DTYPE = np.dtype([("off_v", "<u4"), ("off_g", "<u4"), ("n_in", "<i4"), ("off_w_eff", "<u4")])
 
 SDF_IN = [39, 256, 256, 256, 256, 256, 256, 256, 256]
@@ -102,7 +103,9 @@ def flat_offsets(ins, outs):
 
 
 class _Builder:
-    def __init__(self):
+    def __init__(self, geom=0):
+        self.geom = geom                       # 0: 32-row tiles / 16-deep k-steps, 1: 16-row tiles / 32-deep k-steps
+        self.tr, self.kd = (16, 32) if geom else (32, 16)
         self.maps: List[np.ndarray] = []
         self.n_map = 0
         self.jobs = []
@@ -116,15 +119,15 @@ class _Builder:
         return off
 
     def frag(self, dst_hi, dst_lo, src, ld, ks, nt, transposed, rowmap, kmap, scale=1.0, rs_base=-1):
-        assert len(rowmap) == nt * 32 and len(kmap) == ks * 16
+        assert len(rowmap) == nt * self.tr and len(kmap) == ks * self.kd
         self.jobs.append((PACK_FRAG, self.units, dst_hi, dst_lo, src, ld, ks, nt, transposed,
-                          self.add_map(rowmap), self.add_map(kmap), scale, rs_base, 1 if transposed else 0))
+                          self.add_map(rowmap), self.add_map(kmap), scale, rs_base, 1 if transposed else 0, self.geom, 0))
         self.units += ks * nt
 
     def accvec(self, dst, src, ld, nt, rowmap, scale=1.0, rs_base=-1, rs_mode=0):
-        assert len(rowmap) == nt * 32
+        assert len(rowmap) == nt * self.tr
         self.jobs.append((PACK_ACCVEC, self.units, dst, 0, src, ld, 0, nt, 0, self.add_map(rowmap), 0, scale,
-                          rs_base, rs_mode))
+                          rs_base, rs_mode, self.geom, 0))
         self.units += nt
 
     def finish(self):
@@ -214,3 +217,4 @@ def build_color_jobs():
     return {"layout": ly, "jobs": jobs, "maps": maps, "units": units, "n_params": total, "offW": offW, "offb": offb,
             "ins": COL_IN, "outs": COL_OUT, "n_raw": total_raw, "offB": offB, "offG": offG, "offV": offV,
             "rows": row_tab, "bias_segs": segs}
+

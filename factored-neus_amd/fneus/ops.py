@@ -66,7 +66,8 @@ class PackedNet:
     torch element-wise kernels."""
 
     def __init__(self, kind: str, device):
-        desc = netdesc.build_sdf_jobs() if kind == "sdf" else netdesc.build_color_jobs()
+        builders = {"sdf": netdesc.build_sdf_jobs, "color": netdesc.build_color_jobs}
+        desc = builders[kind]()
         self.kind, self.desc, self.device = kind, desc, device
         self.layout = desc["layout"]
         self.n_params = desc["n_params"]            # effective (W, b) layout: gradient buffer of the dW GEMM

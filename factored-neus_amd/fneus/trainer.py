@@ -64,13 +64,22 @@ class Stage1Trainer:
         out = self.renderer.render(rays_o, rays_d, mid - 1.0, mid + 1.0, background_rgb=background_rgb,
                                    cos_anneal_ratio=cos_anneal_ratio)
         losses = stage1_loss(out, true_rgb, mask, self.igr_weight, self.mask_weight, self.surface_weight)
-        self.optimizer.zero_grad(set_to_none=False)
+        self.zero_grad()
         losses["loss"].backward()
         if self.bucket is not None:
             self.bucket.allreduce_mean()
         self.optimizer.step()
         self.iter_step += 1
         return losses
+
+    def zero_grad(self):
+        """two memsets for the fused MLPs (their .grad alias flat buffers), set_to_none for the small torch modules"""
+        for net in (self.sdf_network, self.color_network):
+            if net._net is not None:
+                net._net.raw_grad.zero_()
+        for m in (self.deviation_network, self.refColor_network):
+            for p in m.parameters():
+                p.grad = None
 
     def render_only(self, data: torch.Tensor, cos_anneal_ratio: float = 1.0):
         rays_o, rays_d = data[:, :3], data[:, 3:6]

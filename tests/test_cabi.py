@@ -39,7 +39,7 @@ def test_pack_job_tables():
     from fneus import netdesc
     for d in (netdesc.build_sdf_jobs(), netdesc.build_color_jobs()):
         jobs, maps = d["jobs"], d["maps"]
-        assert jobs.dtype.itemsize == 56
+        assert jobs.dtype.itemsize == 64
         assert (np.diff(jobs["unit_base"]) > 0).all()
         # every parameter is referenced by at least one forward fragment map
         assert maps.max() < max(max(d["ins"]), max(d["outs"]))
