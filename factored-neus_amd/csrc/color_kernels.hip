@@ -8,6 +8,20 @@
 
 namespace fneus {
 
+// ReLU in place; returns this lane's 128 sign bits (bit 16*t + reg) for the backward pass
+FN_DEV u32x4 relu_mask8(f32x16 (&acc)[8]) {
+    u32x4 m = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool pos = acc[t][r] > 0.0f;
+            acc[t][r] = pos ? acc[t][r] : 0.0f;
+            m[t >> 1] |= (pos ? 1u : 0u) << ((t & 1) * 16 + r);
+        }
+    return m;
+}
+
 template <int TN>
 FN_DEV void relu_inplace(f32x16 (&acc)[TN]) {
 #pragma unroll
@@ -33,6 +47,7 @@ __global__ void __launch_bounds__(64, 1) color_fwd_kernel(const unsigned char* b
                                                           const float* __restrict__ normal,    // [N][3]
                                                           const float* __restrict__ feat,      // [N][256]
                                                           ColStash st, float* __restrict__ rgb_out) {
+    __shared__ __attribute__((aligned(16))) unsigned char scr[kWaveScr];
     const int lane = threadIdx.x;
     const int r = lane & 31, h = lane >> 5;
     constexpr auto& LY = kColLayout;
@@ -41,6 +56,7 @@ __global__ void __launch_bounds__(64, 1) color_fwd_kernel(const unsigned char* b
         const long n = tile * 32 + r;
         const bool valid = n < N;
         const long nc = valid ? n : N - 1;
+        const long n0 = tile * 32;
         float side[33];
         {
             float x[3], d[3], pe[27], jc[27];
@@ -87,15 +103,22 @@ __global__ void __launch_bounds__(64, 1) color_fwd_kernel(const unsigned char* b
         // layer 0: 19 k-steps
         load_accvec<8, 0, 8>(blob, LY.L[0].bias, acc, lane);
         dense<PREC, 19, 8, 0, 8>(blob, LY.L[0].fwd_hi, LY.L[0].fwd_lo, bf, acc, lane);
-        relu_inplace(acc);
-        if constexpr (TRAIN) store_stash<PREC, 8>(acc, st.u_hi, st.u_lo, 256, nc, h, valid, 256);
+        if constexpr (TRAIN) {
+            st.mask[(size_t)tile * 4 * 64 + lane] = relu_mask8(acc);
+            store_stash<PREC, 8>(scr, lane, acc, st.u_hi, st.u_lo, 256, n0, N, 256);
+        } else {
+            relu_inplace(acc);
+        }
         acc_to_bfrag<PREC, 8>(acc, bf);
         for (int l = 1; l <= 3; ++l) {
             load_accvec<8, 0, 8>(blob, LY.L[l].bias, acc, lane);
             dense<PREC, 16, 8, 0, 8>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, bf, acc, lane);
-            relu_inplace(acc);
-            if constexpr (TRAIN)
-                store_stash<PREC, 8>(acc, st.u_hi + (size_t)l * N * 256, st.u_lo + (size_t)l * N * 256, 256, nc, h, valid, 256);
+            if constexpr (TRAIN) {
+                st.mask[((size_t)tile * 4 + l) * 64 + lane] = relu_mask8(acc);
+                store_stash<PREC, 8>(scr, lane, acc, st.u_hi + (size_t)l * N * 256, st.u_lo + (size_t)l * N * 256, 256, n0, N, 256);
+            } else {
+                relu_inplace(acc);
+            }
             acc_to_bfrag<PREC, 8>(acc, bf);
         }
         f32x16 o[1];
@@ -115,6 +138,7 @@ __global__ void __launch_bounds__(64, 1) color_bwd_kernel(const unsigned char* b
                                                           const float* __restrict__ rgb,     // [N][3] forward output
                                                           ColStash st, float* __restrict__ d_feat /*[N][256]*/,
                                                           float* __restrict__ d_normal /*[N][3]*/) {
+    __shared__ __attribute__((aligned(16))) unsigned char scr[kWaveScr];
     const int lane = threadIdx.x;
     const int r = lane & 31, h = lane >> 5;
     constexpr auto& LY = kColLayout;
@@ -123,6 +147,7 @@ __global__ void __launch_bounds__(64, 1) color_bwd_kernel(const unsigned char* b
         const long n = tile * 32 + r;
         const bool valid = n < N;
         const long nc = valid ? n : N - 1;
+        const long n0 = tile * 32;
         BFrag<PREC> bf[kMaxKS];
         f32x16 acc[10];
         // zbar_4 = d rgb * sigmoid'  (3 rows of one tile)
@@ -136,7 +161,7 @@ __global__ void __launch_bounds__(64, 1) color_bwd_kernel(const unsigned char* b
                     z[0][c] = valid ? d_rgb[nc * 3 + c] * y * (1.0f - y) : 0.0f;
                 }
             }
-            store_stash<PREC, 1>(z, st.zbar_hi + (size_t)4 * N * 256, st.zbar_lo + (size_t)4 * N * 256, 32, nc, h, valid, 32);
+            store_stash<PREC, 1>(scr, lane, z, st.zbar_hi + (size_t)4 * N * 256, st.zbar_lo + (size_t)4 * N * 256, 32, n0, N, 32);
             acc_to_bfrag<PREC, 1>(z, bf);
         }
         f32x16(&a8)[8] = reinterpret_cast<f32x16(&)[8]>(acc);
@@ -144,20 +169,18 @@ __global__ void __launch_bounds__(64, 1) color_bwd_kernel(const unsigned char* b
         zero_acc(a8);
         dense<PREC, 2, 8, 0, 8>(blob, LY.L[4].rev_hi, LY.L[4].rev_lo, bf, a8, lane);
         for (int l = 3; l >= 0; --l) {
-            // zbar_l = relu'(z_l) * ubar_{l+1};  relu mask from the stashed u_{l+1} = relu(z_l) (hi plane suffices: sign only)
+            // zbar_l = relu'(z_l) * ubar_{l+1}: sign bits from the forward pass (lane-private, one 16-byte load)
             {
-                const __bf16* uh = st.u_hi + (size_t)l * N * 256;
+                const u32x4 m = st.mask[((size_t)tile * 4 + l) * 64 + lane];
 #pragma unroll
                 for (int t = 0; t < 8; ++t)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const bf16x4 v = *reinterpret_cast<const bf16x4*>(uh + nc * 256 + 32 * t + 8 * q + 4 * h);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            a8[t][4 * q + e] = ((float)v[e] > 0.0f && valid) ? a8[t][4 * q + e] : 0.0f;
+                    for (int rr = 0; rr < 16; ++rr) {
+                        const bool pos = (m[t >> 1] >> ((t & 1) * 16 + rr)) & 1u;
+                        a8[t][rr] = (pos && valid) ? a8[t][rr] : 0.0f;
                     }
             }
-            store_stash<PREC, 8>(a8, st.zbar_hi + (size_t)l * N * 256, st.zbar_lo + (size_t)l * N * 256, 256, nc, h, valid, 256);
+            store_stash<PREC, 8>(scr, lane, a8, st.zbar_hi + (size_t)l * N * 256, st.zbar_lo + (size_t)l * N * 256, 256, n0, N, 256);
             acc_to_bfrag<PREC, 8>(a8, bf);
             if (l > 0) {
                 zero_acc(a8);

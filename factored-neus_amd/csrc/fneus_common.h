@@ -62,6 +62,13 @@ FN_DEV float softplus100(float z) {
     float e = fast_exp2(-fabsf(z) * (kBeta * kLog2e));
     return fmaxf(z, 0.0f) + fast_log2(1.0f + e) * (kLn2 / kBeta);
 }
+// h = softplus_beta(z) and s = sigmoid(beta z) = d h / d z from one exponential
+FN_DEV void softplus_sig(float z, float& h, float& s) {
+    const float e = fast_exp2(-fabsf(z) * (kBeta * kLog2e));
+    h = fmaxf(z, 0.0f) + fast_log2(1.0f + e) * (kLn2 / kBeta);
+    const float inv = fast_rcp(1.0f + e);
+    s = z >= 0.0f ? inv : e * inv;
+}
 // s = sigmoid(beta z) recovered from h = softplus_beta(z):  s = 1 - exp(-beta h)
 FN_DEV float sig_from_softplus(float h) { return 1.0f - fast_exp2(-h * (kBeta * kLog2e)); }
 

@@ -18,10 +18,13 @@ struct SdfStash {
     __bf16* h_hi;    __bf16* h_lo;
     __bf16* a_hi;    __bf16* a_lo;
     __bf16* feat_hi; __bf16* feat_lo;
+    unsigned char* ps;   // lane-private sigma'(z_l):  [tiles][8][32][64] x 4 values (fp32 in parity mode, bf16 in fast mode)
+    unsigned char* pa;   // lane-private a_l, same layout (training only)
     SdfStash() = default;
     SdfStash(const FneusSdfStash& s)
         : pe_hi((__bf16*)s.pe_hi), pe_lo((__bf16*)s.pe_lo), h_hi((__bf16*)s.h_hi), h_lo((__bf16*)s.h_lo),
-          a_hi((__bf16*)s.a_hi), a_lo((__bf16*)s.a_lo), feat_hi((__bf16*)s.feat_hi), feat_lo((__bf16*)s.feat_lo) {}
+          a_hi((__bf16*)s.a_hi), a_lo((__bf16*)s.a_lo), feat_hi((__bf16*)s.feat_hi), feat_lo((__bf16*)s.feat_lo),
+          ps((unsigned char*)s.ps), pa((unsigned char*)s.pa) {}
 };
 
 struct SdfBwdBufs {
@@ -41,10 +44,12 @@ struct ColStash {
     __bf16* side_hi; __bf16* side_lo;   // [N][48]      pts | PE4(view) | normal (cols >= 33 zero)
     __bf16* u_hi;    __bf16* u_lo;      // [4][N][256]  slot l = relu output of layer l (= input of l+1)
     __bf16* zbar_hi; __bf16* zbar_lo;   // [5][N][256]  slot l = dL/dz_l (slot 4 uses 32-wide rows)
-    ColStash() : side_hi(nullptr), side_lo(nullptr), u_hi(nullptr), u_lo(nullptr), zbar_hi(nullptr), zbar_lo(nullptr) {}
+    u32x4* mask;                        // lane-private ReLU masks: [tiles][4][64] x 128 bits
+    ColStash() : side_hi(nullptr), side_lo(nullptr), u_hi(nullptr), u_lo(nullptr), zbar_hi(nullptr), zbar_lo(nullptr),
+                 mask(nullptr) {}
     ColStash(const FneusColStash& s)
         : side_hi((__bf16*)s.side_hi), side_lo((__bf16*)s.side_lo), u_hi((__bf16*)s.u_hi), u_lo((__bf16*)s.u_lo),
-          zbar_hi((__bf16*)s.zbar_hi), zbar_lo((__bf16*)s.zbar_lo) {}
+          zbar_hi((__bf16*)s.zbar_hi), zbar_lo((__bf16*)s.zbar_lo), mask((u32x4*)s.mask) {}
 };
 
 FN_DEV void load_point(const PointSrc& s, long n, float (&x)[3]) {

@@ -103,20 +103,73 @@ FN_DEV void acc_to_bfrag(const f32x16 (&acc)[TN], BFrag<PREC> (&b)[kMaxKS]) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Row-major [N][LD] bf16 "stash" matrices (hi plane / lo plane) in accumulator-register order:
-// lane (n, h), tile t, register group g = reg>>2 holds 4 consecutive features 32t + 8g + 4h .. +3  -> one 8-byte access.
-// These matrices are the operands of the weight-gradient GEMM (dw_gemm.hip) and are read back by the chain kernels.
+// Row-major [N][LD] bf16 "stash" matrices (hi plane / lo plane): the operands of the weight-gradient GEMM
+// (dw_gemm.hip).  In accumulator layout a lane holds 4 consecutive features of ONE sample per register group, i.e.
+// 8-byte pieces scattered over 32 rows; written directly that costs one memory-pipeline pass per 64-byte line
+// (measured: the stash traffic, not the MFMA chain, dominates K2/K3).  Stores therefore go through a per-wave LDS
+// image [32 samples][256 features] (+8 bytes row padding: conflict-free both ways) and leave as whole 512-byte rows.
 // ---------------------------------------------------------------------------------------------------------
+constexpr int kScrStride = 520;
+constexpr int kScrPlane = 32 * kScrStride;               // 16 640
+constexpr int kWaveScr = 2 * kScrPlane;                  // 33 280 bytes of LDS per wavefront (hi and lo image)
+
+// order this wave's LDS accesses (compiler + hardware) without draining global memory traffic
+FN_DEV void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+#ifndef FNEUS_STASH_VIA_LDS
+#define FNEUS_STASH_VIA_LDS 1
+#endif
 template <int PREC, int TN>
-FN_DEV void store_stash(const f32x16 (&acc)[TN], __bf16* __restrict__ hi, __bf16* __restrict__ lo, int ld, long n,
-                        int h, bool valid, int col_limit) {
-    if (!valid) return;
+FN_DEV void store_stash(unsigned char* __restrict__ wscr, int lane, const f32x16 (&acc)[TN], __bf16* __restrict__ hi,
+                        __bf16* __restrict__ lo, int ld, long n0, long N, int ncols) {
+    const int r = lane & 31, h = lane >> 5;
+    constexpr int NPL = PREC == 3 ? 2 : 1;
+#if FNEUS_STASH_VIA_LDS
+    lds_fence();     // earlier readers of the scratch are done
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16x4 vh, vl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = acc[t][4 * g + e];
+                if constexpr (PREC == 3) {
+                    __bf16 a, b2;
+                    split_bf16(v, a, b2);
+                    vh[e] = a;
+                    vl[e] = b2;
+                } else {
+                    vh[e] = (__bf16)v;
+                }
+            }
+            unsigned char* dst = wscr + r * kScrStride + (32 * t + 8 * g + 4 * h) * 2;
+            *reinterpret_cast<bf16x4*>(dst) = vh;
+            if constexpr (PREC == 3) *reinterpret_cast<bf16x4*>(dst + kScrPlane) = vl;
+        }
+    lds_fence();
+    const int P = ncols >> 2;            // 8-byte pieces per row
+    const int total = 32 * P;
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) {
+        __bf16* __restrict__ plane = pl ? lo : hi;
+        for (int idx = lane; idx < total; idx += 64) {
+            const int row = idx / P, pc = idx - row * P;
+            if (n0 + row < N)
+                *reinterpret_cast<uint2*>(plane + (n0 + row) * ld + pc * 4) =
+                    *reinterpret_cast<const uint2*>(wscr + pl * kScrPlane + row * kScrStride + pc * 8);
+        }
+    }
+#else
+    (void)wscr; (void)NPL;
+    const long n = n0 + r;
+    if (n >= N) return;
 #pragma unroll
     for (int t = 0; t < TN; ++t)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int col = 32 * t + 8 * g + 4 * h;
-            if (col >= col_limit) continue;   // col_limit is a multiple of 4 or handled by the caller
+            if (col >= ncols) continue;
             bf16x4 vh, vl;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -133,7 +186,55 @@ FN_DEV void store_stash(const f32x16 (&acc)[TN], __bf16* __restrict__ hi, __bf16
             *reinterpret_cast<bf16x4*>(hi + n * ld + col) = vh;
             if constexpr (PREC == 3) *reinterpret_cast<bf16x4*>(lo + n * ld + col) = vl;
         }
+#endif
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Lane-private stash: values that only the SAME lane of the SAME tile reads back later (sigma'(z_l) for the reverse
+// sweep and the backward chains, a_l for the coupling term) live in a lane-linear layout
+//   [tile][layer][t*4+g][lane] x 4 values  ->  every access is one fully coalesced wave instruction.
+// Parity mode keeps them in fp32 (exact), fast mode in bf16.
+// ---------------------------------------------------------------------------------------------------------
+template <int PREC> struct PrivT { typedef f32x4 v4; };
+template <> struct PrivT<1> { typedef bf16x4 v4; };
+
+template <int PREC>
+FN_DEV void priv_put(void* __restrict__ base, int slot, int lane, const float (&v)[4]) {
+    typename PrivT<PREC>::v4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if constexpr (PREC == 3) o[e] = v[e];
+        else o[e] = (__bf16)v[e];
+    }
+    reinterpret_cast<typename PrivT<PREC>::v4*>(base)[slot * 64 + lane] = o;
+}
+
+template <int PREC>
+FN_DEV void priv_get(const void* __restrict__ base, int slot, int lane, float (&v)[4]) {
+    const typename PrivT<PREC>::v4 o = reinterpret_cast<const typename PrivT<PREC>::v4*>(base)[slot * 64 + lane];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (float)o[e];
+}
+
+// sigma'(z) in [0,1] as 16-bit fixed point (abs. error 7.6e-6): halves the hottest private plane, which is written once
+// and read three times (reverse sweep, ascending and descending backward chains)
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+FN_DEV void sig_put(void* __restrict__ base, int slot, int lane, const float (&v)[4]) {
+    u16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (unsigned short)__float2uint_rn(fminf(fmaxf(v[e], 0.0f), 1.0f) * 65535.0f);
+    reinterpret_cast<u16x4*>(base)[slot * 64 + lane] = o;
+}
+FN_DEV void sig_get(const void* __restrict__ base, int slot, int lane, float (&v)[4]) {
+    const u16x4 o = reinterpret_cast<const u16x4*>(base)[slot * 64 + lane];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (float)o[e] * (1.0f / 65535.0f);
+}
+constexpr size_t kSigBlockBytes = 32 * 64 * sizeof(u16x4);   // one (tile, layer) block of the sigma' plane
+
+// bytes of one (tile, layer) block of a private stash
+template <int PREC>
+FN_DEV constexpr size_t priv_block_bytes() { return 32 * 64 * sizeof(typename PrivT<PREC>::v4); }
 
 template <int PREC, int TN>
 FN_DEV void load_stash(f32x16 (&acc)[TN], const __bf16* __restrict__ hi, const __bf16* __restrict__ lo, int ld, long n,

@@ -9,6 +9,24 @@
 
 namespace fneus {
 
+// softplus in place; sigma'(z) goes to the lane-private stash block `ps` of this (tile, layer)
+template <int PREC, int TN>
+FN_DEV void softplus_ps(f32x16 (&acc)[TN], unsigned char* __restrict__ ps, int lane) {
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float sv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float hh;
+                softplus_sig(acc[t][4 * g + e], hh, sv[e]);
+                acc[t][4 * g + e] = hh;
+            }
+            sig_put(ps, t * 4 + g, lane, sv);
+        }
+}
+
 template <int TN>
 FN_DEV void softplus_inplace(f32x16 (&acc)[TN]) {
 #pragma unroll
@@ -23,8 +41,10 @@ FN_DEV void softplus_inplace(f32x16 (&acc)[TN]) {
 template <int PREC, bool SDF_ONLY, bool STASH>
 FN_DEV void sdf_forward_chain(const unsigned char* __restrict__ blob, const float (&pe)[39],
                               BFrag<PREC> (&bf)[kMaxKS], f32x16 (&acc)[9], const SdfStash& st, long N, long n,
-                              int lane, bool valid) {
+                              int lane, bool valid, unsigned char* scr, long tile) {
     const int h = lane >> 5;
+    const long n0 = tile * 32;
+    unsigned char* psb = STASH ? st.ps + (size_t)tile * 8 * kSigBlockBytes : nullptr;
     constexpr auto& LY = kSdfLayout;
     BFrag<PREC> pef[3];
     vec_to_bfrag<PREC, 39, 3, 0>(pe, bf, h);
@@ -52,16 +72,23 @@ FN_DEV void sdf_forward_chain(const unsigned char* __restrict__ blob, const floa
     // layer 0
     load_accvec<8, 0, 8>(blob, LY.L[0].bias, a8, lane);
     dense<PREC, 3, 8, 0, 8>(blob, LY.L[0].fwd_hi, LY.L[0].fwd_lo, bf, a8, lane);
-    softplus_inplace(a8);
-    if constexpr (STASH) store_stash<PREC, 8>(a8, st.h_hi, st.h_lo, 256, n, h, valid, 256);
+    if constexpr (STASH) {
+        softplus_ps<PREC, 8>(a8, psb, lane);
+        store_stash<PREC, 8>(scr, lane, a8, st.h_hi, st.h_lo, 256, n0, N, 256);
+    } else {
+        softplus_inplace(a8);
+    }
     acc_to_bfrag<PREC, 8>(a8, bf);
     // layers 1, 2
     for (int l = 1; l <= 2; ++l) {
         load_accvec<8, 0, 8>(blob, LY.L[l].bias, a8, lane);
         dense<PREC, 16, 8, 0, 8>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, bf, a8, lane);
-        softplus_inplace(a8);
-        if constexpr (STASH)
-            store_stash<PREC, 8>(a8, st.h_hi + (size_t)l * N * 256, st.h_lo + (size_t)l * N * 256, 256, n, h, valid, 256);
+        if constexpr (STASH) {
+            softplus_ps<PREC, 8>(a8, psb + (size_t)l * kSigBlockBytes, lane);
+            store_stash<PREC, 8>(scr, lane, a8, st.h_hi + (size_t)l * N * 256, st.h_lo + (size_t)l * N * 256, 256, n0, N, 256);
+        } else {
+            softplus_inplace(a8);
+        }
         acc_to_bfrag<PREC, 8>(a8, bf);
     }
     // layer 3: 256 -> 217 (7 tiles); its output + PE is the input of layer 4 (skip connection, fields.py:83-84)
@@ -69,9 +96,12 @@ FN_DEV void sdf_forward_chain(const unsigned char* __restrict__ blob, const floa
         f32x16(&a7)[7] = reinterpret_cast<f32x16(&)[7]>(acc);
         load_accvec<7, 0, 7>(blob, LY.L[3].bias, a7, lane);
         dense<PREC, 16, 7, 0, 7>(blob, LY.L[3].fwd_hi, LY.L[3].fwd_lo, bf, a7, lane);
-        softplus_inplace(a7);
-        if constexpr (STASH)
-            store_stash<PREC, 7>(a7, st.h_hi + (size_t)3 * N * 256, st.h_lo + (size_t)3 * N * 256, 256, n, h, valid, 224);
+        if constexpr (STASH) {
+            softplus_ps<PREC, 7>(a7, psb + (size_t)3 * kSigBlockBytes, lane);
+            store_stash<PREC, 7>(scr, lane, a7, st.h_hi + (size_t)3 * N * 256, st.h_lo + (size_t)3 * N * 256, 256, n0, N, 224);
+        } else {
+            softplus_inplace(a7);
+        }
         acc_to_bfrag<PREC, 7>(a7, bf);
 #pragma unroll
         for (int i = 0; i < 3; ++i) bf[14 + i] = pef[i];
@@ -79,17 +109,23 @@ FN_DEV void sdf_forward_chain(const unsigned char* __restrict__ blob, const floa
     // layer 4 (17 k-steps; 1/sqrt2 folded into the pack)
     load_accvec<8, 0, 8>(blob, LY.L[4].bias, a8, lane);
     dense<PREC, 17, 8, 0, 8>(blob, LY.L[4].fwd_hi, LY.L[4].fwd_lo, bf, a8, lane);
-    softplus_inplace(a8);
-    if constexpr (STASH)
-        store_stash<PREC, 8>(a8, st.h_hi + (size_t)4 * N * 256, st.h_lo + (size_t)4 * N * 256, 256, n, h, valid, 256);
+    if constexpr (STASH) {
+        softplus_ps<PREC, 8>(a8, psb + (size_t)4 * kSigBlockBytes, lane);
+        store_stash<PREC, 8>(scr, lane, a8, st.h_hi + (size_t)4 * N * 256, st.h_lo + (size_t)4 * N * 256, 256, n0, N, 256);
+    } else {
+        softplus_inplace(a8);
+    }
     acc_to_bfrag<PREC, 8>(a8, bf);
     // layers 5, 6, 7
     for (int l = 5; l <= 7; ++l) {
         load_accvec<8, 0, 8>(blob, LY.L[l].bias, a8, lane);
         dense<PREC, 16, 8, 0, 8>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, bf, a8, lane);
-        softplus_inplace(a8);
-        if constexpr (STASH)
-            store_stash<PREC, 8>(a8, st.h_hi + (size_t)l * N * 256, st.h_lo + (size_t)l * N * 256, 256, n, h, valid, 256);
+        if constexpr (STASH) {
+            softplus_ps<PREC, 8>(a8, psb + (size_t)l * kSigBlockBytes, lane);
+            store_stash<PREC, 8>(scr, lane, a8, st.h_hi + (size_t)l * N * 256, st.h_lo + (size_t)l * N * 256, 256, n0, N, 256);
+        } else {
+            softplus_inplace(a8);
+        }
         acc_to_bfrag<PREC, 8>(a8, bf);
     }
     // layer 8 (linear)
@@ -117,34 +153,33 @@ __global__ void __launch_bounds__(64, 1) sdf_fwd_kernel(const unsigned char* blo
         const long n = tile * 32 + r;
         const bool valid = n < N;
         const long nc = valid ? n : N - 1;
+        const long n0 = tile * 32;
         float x[3], pe[39], jc[39];
         load_point(src, nc, x);
         posenc<6, false>(x, pe, jc);
         BFrag<PREC> bf[kMaxKS];
         f32x16 acc[9];
-        sdf_forward_chain<PREC, true, false>(blob, pe, bf, acc, st, N, nc, lane, valid);
+        sdf_forward_chain<PREC, true, false>(blob, pe, bf, acc, st, N, nc, lane, valid, nullptr, tile);
         if (valid && lane < 32) sdf_out[n] = acc[8][0];
     }
 }
 
 // ---- K2 ----------------------------------------------------------------------------------------------------
-// g[t] *= s where s = sigmoid(beta z_l) recovered from the stashed h_{l+1}
-template <int PREC, int TN>
-FN_DEV void mul_sig_from_stash(f32x16 (&g)[TN], const __bf16* __restrict__ hi, const __bf16* __restrict__ lo, long n, int h) {
+// g[t] *= sigma'(z_l) from the lane-private stash block; with TRAIN the product a_l also goes to its private block
+template <int PREC, int TN, bool TRAIN>
+FN_DEV void mul_sig_priv(f32x16 (&g)[TN], const unsigned char* __restrict__ ps, unsigned char* __restrict__ pa, int lane) {
 #pragma unroll
     for (int t = 0; t < TN; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int col = 32 * t + 8 * q + 4 * h;
-            const bf16x4 vh = *reinterpret_cast<const bf16x4*>(hi + n * 256 + col);
-            bf16x4 vl;
-            if constexpr (PREC == 3) vl = *reinterpret_cast<const bf16x4*>(lo + n * 256 + col);
+            float sv[4], av[4];
+            sig_get(ps, t * 4 + q, lane, sv);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float hv = (float)vh[e];
-                if constexpr (PREC == 3) hv += (float)vl[e];
-                g[t][4 * q + e] *= sig_from_softplus(hv);
+                av[e] = g[t][4 * q + e] * sv[e];
+                g[t][4 * q + e] = av[e];
             }
+            if constexpr (TRAIN) priv_put<PREC>(pa, t * 4 + q, lane, av);
         }
 }
 
@@ -152,6 +187,7 @@ template <int PREC, bool TRAIN>
 __global__ void __launch_bounds__(64, 1) sdf_fwd_grad_kernel(const unsigned char* blob, PointSrc src, long N,
                                                              SdfStash st, float* __restrict__ sdf_out,
                                                              float* __restrict__ feat_out, float* __restrict__ normal_out) {
+    __shared__ __attribute__((aligned(16))) unsigned char scr[kWaveScr];
     const int lane = threadIdx.x;
     const int r = lane & 31, h = lane >> 5;
     constexpr auto& LY = kSdfLayout;
@@ -162,25 +198,29 @@ __global__ void __launch_bounds__(64, 1) sdf_fwd_grad_kernel(const unsigned char
         const long n = tile * 32 + r;
         const bool valid = n < N;
         const long nc = valid ? n : N - 1;
+        const long n0 = tile * 32;
         float x[3], pe[39], jc[39];
         load_point(src, nc, x);
         posenc<6, true>(x, pe, jc);
         BFrag<PREC> bf[kMaxKS];
         f32x16 acc[9];
-        sdf_forward_chain<PREC, false, true>(blob, pe, bf, acc, st, N, nc, lane, valid);
+        sdf_forward_chain<PREC, false, true>(blob, pe, bf, acc, st, N, nc, lane, valid, scr, tile);
+        constexpr size_t PB = priv_block_bytes<PREC>();
+        const unsigned char* psb = st.ps + (size_t)tile * 8 * kSigBlockBytes;
+        unsigned char* pab = TRAIN ? st.pa + (size_t)tile * 8 * PB : nullptr;
         if (valid && lane < 32) sdf_out[n] = acc[8][0];
         {
             f32x16(&a8)[8] = reinterpret_cast<f32x16(&)[8]>(acc);
             store_f32<8>(a8, feat_out, 256, nc, h, valid);
-            if constexpr (TRAIN) store_stash<PREC, 8>(a8, st.feat_hi, st.feat_lo, 256, nc, h, valid, 256);
+            if constexpr (TRAIN) store_stash<PREC, 8>(scr, lane, a8, st.feat_hi, st.feat_lo, 256, n0, N, 256);
         }
         // ---- reverse sweep: g = d sdf / d u_l   ----
         f32x16(&g8)[8] = reinterpret_cast<f32x16(&)[8]>(acc);
         load_accvec<8, 0, 8>(blob, LY.extra, g8, lane);                      // g_hat(h_8) = row 0 of W_8
         for (int l = 7; l >= 5; --l) {
-            mul_sig_from_stash<PREC, 8>(g8, st.h_hi + (size_t)l * N * 256, st.h_lo + (size_t)l * N * 256, nc, h);   // a_l
+            mul_sig_priv<PREC, 8, TRAIN>(g8, psb + (size_t)(l) * kSigBlockBytes, pab + (size_t)(l) * PB, lane);   // a_l
             if constexpr (TRAIN)
-                store_stash<PREC, 8>(g8, st.a_hi + (size_t)l * N * 256, st.a_lo + (size_t)l * N * 256, 256, nc, h, valid, 256);
+                store_stash<PREC, 8>(scr, lane, g8, st.a_hi + (size_t)l * N * 256, st.a_lo + (size_t)l * N * 256, 256, n0, N, 256);
             acc_to_bfrag<PREC, 8>(g8, bf);
             zero_acc(g8);
             dense<PREC, 16, 8, 0, 8>(blob, LY.L[l].rev_hi, LY.L[l].rev_lo, bf, g8, lane);
@@ -188,9 +228,9 @@ __global__ void __launch_bounds__(64, 1) sdf_fwd_grad_kernel(const unsigned char
         // layer 4: outputs 9 row tiles: 0..6 -> g_hat(h_4), 7..8 -> q_skip (PE part of the skip input)
         f32x16 qskip[2];
         {
-            mul_sig_from_stash<PREC, 8>(g8, st.h_hi + (size_t)4 * N * 256, st.h_lo + (size_t)4 * N * 256, nc, h);
+            mul_sig_priv<PREC, 8, TRAIN>(g8, psb + (size_t)(4) * kSigBlockBytes, pab + (size_t)(4) * PB, lane);
             if constexpr (TRAIN)
-                store_stash<PREC, 8>(g8, st.a_hi + (size_t)4 * N * 256, st.a_lo + (size_t)4 * N * 256, 256, nc, h, valid, 256);
+                store_stash<PREC, 8>(scr, lane, g8, st.a_hi + (size_t)4 * N * 256, st.a_lo + (size_t)4 * N * 256, 256, n0, N, 256);
             acc_to_bfrag<PREC, 8>(g8, bf);
             zero_acc(acc);
             dense<PREC, 16, 9, 0, 9>(blob, LY.L[4].rev_hi, LY.L[4].rev_lo, bf, acc, lane);
@@ -200,17 +240,17 @@ __global__ void __launch_bounds__(64, 1) sdf_fwd_grad_kernel(const unsigned char
         // layer 3 (7 tiles of outputs -> 14 k-steps)
         {
             f32x16(&g7)[7] = reinterpret_cast<f32x16(&)[7]>(acc);
-            mul_sig_from_stash<PREC, 7>(g7, st.h_hi + (size_t)3 * N * 256, st.h_lo + (size_t)3 * N * 256, nc, h);
+            mul_sig_priv<PREC, 7, TRAIN>(g7, psb + (size_t)(3) * kSigBlockBytes, pab + (size_t)(3) * PB, lane);
             if constexpr (TRAIN)
-                store_stash<PREC, 7>(g7, st.a_hi + (size_t)3 * N * 256, st.a_lo + (size_t)3 * N * 256, 256, nc, h, valid, 224);
+                store_stash<PREC, 7>(scr, lane, g7, st.a_hi + (size_t)3 * N * 256, st.a_lo + (size_t)3 * N * 256, 256, n0, N, 224);
             acc_to_bfrag<PREC, 7>(g7, bf);
             zero_acc(g8);
             dense<PREC, 14, 8, 0, 8>(blob, LY.L[3].rev_hi, LY.L[3].rev_lo, bf, g8, lane);
         }
         for (int l = 2; l >= 1; --l) {
-            mul_sig_from_stash<PREC, 8>(g8, st.h_hi + (size_t)l * N * 256, st.h_lo + (size_t)l * N * 256, nc, h);
+            mul_sig_priv<PREC, 8, TRAIN>(g8, psb + (size_t)(l) * kSigBlockBytes, pab + (size_t)(l) * PB, lane);
             if constexpr (TRAIN)
-                store_stash<PREC, 8>(g8, st.a_hi + (size_t)l * N * 256, st.a_lo + (size_t)l * N * 256, 256, nc, h, valid, 256);
+                store_stash<PREC, 8>(scr, lane, g8, st.a_hi + (size_t)l * N * 256, st.a_lo + (size_t)l * N * 256, 256, n0, N, 256);
             acc_to_bfrag<PREC, 8>(g8, bf);
             zero_acc(g8);
             dense<PREC, 16, 8, 0, 8>(blob, LY.L[l].rev_hi, LY.L[l].rev_lo, bf, g8, lane);
@@ -218,8 +258,8 @@ __global__ void __launch_bounds__(64, 1) sdf_fwd_grad_kernel(const unsigned char
         // layer 0: 2 row tiles (39 PE inputs)
         f32x16 q[2];
         {
-            mul_sig_from_stash<PREC, 8>(g8, st.h_hi, st.h_lo, nc, h);
-            if constexpr (TRAIN) store_stash<PREC, 8>(g8, st.a_hi, st.a_lo, 256, nc, h, valid, 256);
+            mul_sig_priv<PREC, 8, TRAIN>(g8, psb, pab, lane);
+            if constexpr (TRAIN) store_stash<PREC, 8>(scr, lane, g8, st.a_hi, st.a_lo, 256, n0, N, 256);
             acc_to_bfrag<PREC, 8>(g8, bf);
             zero_acc(q);
             dense<PREC, 16, 2, 0, 2>(blob, LY.L[0].rev_hi, LY.L[0].rev_lo, bf, q, lane);
@@ -253,56 +293,37 @@ __global__ void __launch_bounds__(64, 1) sdf_fwd_grad_kernel(const unsigned char
 //               zbar_{l-1} = s_{l-1} * ubar_l + c_{l-1}
 // The operand matrices of dW_l = zbar_l^T u_l + a_l^T adj_l are written as bf16 planes for dw_gemm.hip.
 template <int PREC, int TN>
-FN_DEV void asc_post(f32x16 (&acc)[TN], const __bf16* __restrict__ hhi, const __bf16* __restrict__ hlo,
-                     const __bf16* __restrict__ ahi, const __bf16* __restrict__ alo, f32x4* __restrict__ cs, long n,
-                     int h, int lane) {
+FN_DEV void asc_post(f32x16 (&acc)[TN], const unsigned char* __restrict__ ps, const unsigned char* __restrict__ pa,
+                     f32x4* __restrict__ cs, int lane) {
 #pragma unroll
     for (int t = 0; t < TN; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int col = 32 * t + 8 * q + 4 * h;
-            const bf16x4 hv = *reinterpret_cast<const bf16x4*>(hhi + n * 256 + col);
-            const bf16x4 av = *reinterpret_cast<const bf16x4*>(ahi + n * 256 + col);
-            bf16x4 hl, al;
-            if constexpr (PREC == 3) {
-                hl = *reinterpret_cast<const bf16x4*>(hlo + n * 256 + col);
-                al = *reinterpret_cast<const bf16x4*>(alo + n * 256 + col);
-            }
+            float sv[4], av[4];
+            sig_get(ps, t * 4 + q, lane, sv);
+            priv_get<PREC>(pa, t * 4 + q, lane, av);
             f32x4 c;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float hh = (float)hv[e], aa = (float)av[e];
-                if constexpr (PREC == 3) {
-                    hh += (float)hl[e];
-                    aa += (float)al[e];
-                }
-                const float one_minus_s = fast_exp2(-hh * (kBeta * kLog2e));
                 const float abar = acc[t][4 * q + e];
-                c[e] = kBeta * one_minus_s * aa * abar;
-                acc[t][4 * q + e] = (1.0f - one_minus_s) * abar;
+                c[e] = kBeta * (1.0f - sv[e]) * av[e] * abar;      // softplus'' * g_hat * abar  (a = s * g_hat)
+                acc[t][4 * q + e] = sv[e] * abar;
             }
             cs[(t * 4 + q) * 64 + lane] = c;
         }
 }
 
 template <int PREC, int TN>
-FN_DEV void desc_post(f32x16 (&acc)[TN], const __bf16* __restrict__ hhi, const __bf16* __restrict__ hlo,
-                      const f32x4* __restrict__ cs, long n, int h, int lane) {
+FN_DEV void desc_post(f32x16 (&acc)[TN], const unsigned char* __restrict__ ps, const f32x4* __restrict__ cs, int lane) {
 #pragma unroll
     for (int t = 0; t < TN; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int col = 32 * t + 8 * q + 4 * h;
-            const bf16x4 hv = *reinterpret_cast<const bf16x4*>(hhi + n * 256 + col);
-            bf16x4 hl;
-            if constexpr (PREC == 3) hl = *reinterpret_cast<const bf16x4*>(hlo + n * 256 + col);
+            float sv[4];
+            sig_get(ps, t * 4 + q, lane, sv);
             const f32x4 c = cs[(t * 4 + q) * 64 + lane];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float hh = (float)hv[e];
-                if constexpr (PREC == 3) hh += (float)hl[e];
-                acc[t][4 * q + e] = sig_from_softplus(hh) * acc[t][4 * q + e] + c[e];
-            }
+            for (int e = 0; e < 4; ++e) acc[t][4 * q + e] = sv[e] * acc[t][4 * q + e] + c[e];
         }
 }
 
@@ -311,6 +332,7 @@ __global__ void __launch_bounds__(64, 1) sdf_bwd_kernel(const unsigned char* blo
                                                         SdfBwdBufs bb, const float* __restrict__ d_sdf,
                                                         const float* __restrict__ d_feat,
                                                         const float* __restrict__ d_normal) {
+    __shared__ __attribute__((aligned(16))) unsigned char scr[kWaveScr];
     const int lane = threadIdx.x;
     const int r = lane & 31, h = lane >> 5;
     constexpr auto& LY = kSdfLayout;
@@ -320,7 +342,11 @@ __global__ void __launch_bounds__(64, 1) sdf_bwd_kernel(const unsigned char* blo
         const long n = tile * 32 + r;
         const bool valid = n < N;
         const long nc = valid ? n : N - 1;
+        const long n0 = tile * 32;
         f32x4* cs = bb.cscratch + (size_t)tile * 8 * 32 * 64;
+        constexpr size_t PB = priv_block_bytes<PREC>();
+        const unsigned char* psb = st.ps + (size_t)tile * 8 * kSigBlockBytes;
+        const unsigned char* pab = st.pa + (size_t)tile * 8 * PB;
         BFrag<PREC> bf[kMaxKS];
         BFrag<PREC> qf[3];
         f32x16 acc[9];
@@ -359,23 +385,21 @@ __global__ void __launch_bounds__(64, 1) sdf_bwd_kernel(const unsigned char* blo
         // ---- ascending chain ----
         zero_acc(a8);
         dense<PREC, 3, 8, 0, 8>(blob, LY.L[0].fwd_hi, LY.L[0].fwd_lo, bf, a8, lane);
-        asc_post<PREC, 8>(a8, st.h_hi, st.h_lo, st.a_hi, st.a_lo, cs, nc, h, lane);
-        store_stash<PREC, 8>(a8, bb.adj_hi, bb.adj_lo, 256, nc, h, valid, 256);
+        asc_post<PREC, 8>(a8, psb, pab, cs, lane);
+        store_stash<PREC, 8>(scr, lane, a8, bb.adj_hi, bb.adj_lo, 256, n0, N, 256);
         acc_to_bfrag<PREC, 8>(a8, bf);
         for (int l = 1; l <= 2; ++l) {
             zero_acc(a8);
             dense<PREC, 16, 8, 0, 8>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, bf, a8, lane);
-            asc_post<PREC, 8>(a8, st.h_hi + l * LS, st.h_lo + l * LS, st.a_hi + l * LS, st.a_lo + l * LS,
-                              cs + (size_t)l * 32 * 64, nc, h, lane);
-            store_stash<PREC, 8>(a8, bb.adj_hi + l * LS, bb.adj_lo + l * LS, 256, nc, h, valid, 256);
+            asc_post<PREC, 8>(a8, psb + (size_t)(l) * kSigBlockBytes, pab + (size_t)(l) * PB, cs + (size_t)l * 32 * 64, lane);
+            store_stash<PREC, 8>(scr, lane, a8, bb.adj_hi + l * LS, bb.adj_lo + l * LS, 256, n0, N, 256);
             acc_to_bfrag<PREC, 8>(a8, bf);
         }
         {
             zero_acc(a7);
             dense<PREC, 16, 7, 0, 7>(blob, LY.L[3].fwd_hi, LY.L[3].fwd_lo, bf, a7, lane);
-            asc_post<PREC, 7>(a7, st.h_hi + 3 * LS, st.h_lo + 3 * LS, st.a_hi + 3 * LS, st.a_lo + 3 * LS,
-                              cs + (size_t)3 * 32 * 64, nc, h, lane);
-            store_stash<PREC, 7>(a7, bb.adj_hi + 3 * LS, bb.adj_lo + 3 * LS, 256, nc, h, valid, 224);
+            asc_post<PREC, 7>(a7, psb + (size_t)(3) * kSigBlockBytes, pab + (size_t)(3) * PB, cs + (size_t)3 * 32 * 64, lane);
+            store_stash<PREC, 7>(scr, lane, a7, bb.adj_hi + 3 * LS, bb.adj_lo + 3 * LS, 256, n0, N, 224);
             acc_to_bfrag<PREC, 7>(a7, bf);
 #pragma unroll
             for (int i = 0; i < 3; ++i) bf[14 + i] = qf[i];
@@ -383,17 +407,15 @@ __global__ void __launch_bounds__(64, 1) sdf_bwd_kernel(const unsigned char* blo
         {
             zero_acc(a8);
             dense<PREC, 17, 8, 0, 8>(blob, LY.L[4].fwd_hi, LY.L[4].fwd_lo, bf, a8, lane);
-            asc_post<PREC, 8>(a8, st.h_hi + 4 * LS, st.h_lo + 4 * LS, st.a_hi + 4 * LS, st.a_lo + 4 * LS,
-                              cs + (size_t)4 * 32 * 64, nc, h, lane);
-            store_stash<PREC, 8>(a8, bb.adj_hi + 4 * LS, bb.adj_lo + 4 * LS, 256, nc, h, valid, 256);
+            asc_post<PREC, 8>(a8, psb + (size_t)(4) * kSigBlockBytes, pab + (size_t)(4) * PB, cs + (size_t)4 * 32 * 64, lane);
+            store_stash<PREC, 8>(scr, lane, a8, bb.adj_hi + 4 * LS, bb.adj_lo + 4 * LS, 256, n0, N, 256);
             acc_to_bfrag<PREC, 8>(a8, bf);
         }
         for (int l = 5; l <= 7; ++l) {
             zero_acc(a8);
             dense<PREC, 16, 8, 0, 8>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, bf, a8, lane);
-            asc_post<PREC, 8>(a8, st.h_hi + l * LS, st.h_lo + l * LS, st.a_hi + l * LS, st.a_lo + l * LS,
-                              cs + (size_t)l * 32 * 64, nc, h, lane);
-            store_stash<PREC, 8>(a8, bb.adj_hi + l * LS, bb.adj_lo + l * LS, 256, nc, h, valid, 256);
+            asc_post<PREC, 8>(a8, psb + (size_t)(l) * kSigBlockBytes, pab + (size_t)(l) * PB, cs + (size_t)l * 32 * 64, lane);
+            store_stash<PREC, 8>(scr, lane, a8, bb.adj_hi + l * LS, bb.adj_lo + l * LS, 256, n0, N, 256);
             acc_to_bfrag<PREC, 8>(a8, bf);
         }
         // ---- descending chain ----
@@ -401,42 +423,42 @@ __global__ void __launch_bounds__(64, 1) sdf_bwd_kernel(const unsigned char* blo
         if (!valid) zero_acc(a8);
         zero_acc(reinterpret_cast<f32x16(&)[1]>(acc[8]));
         if (h == 0 && valid) acc[8][0] = d_sdf[nc];
-        store_stash<PREC, 8>(a8, bb.zbar_hi + 8 * LS, bb.zbar_lo + 8 * LS, 256, nc, h, valid, 256);
-        store_stash<PREC, 1>(reinterpret_cast<f32x16(&)[1]>(acc[8]), bb.zsdf_hi, bb.zsdf_lo, 32, nc, h, valid, 32);
+        store_stash<PREC, 8>(scr, lane, a8, bb.zbar_hi + 8 * LS, bb.zbar_lo + 8 * LS, 256, n0, N, 256);
+        store_stash<PREC, 1>(scr, lane, reinterpret_cast<f32x16(&)[1]>(acc[8]), bb.zsdf_hi, bb.zsdf_lo, 32, n0, N, 32);
         acc_to_bfrag<PREC, 9>(acc, bf);
         zero_acc(a8);
         dense<PREC, 18, 8, 0, 8>(blob, LY.L[8].rev_hi, LY.L[8].rev_lo, bf, a8, lane);
         for (int l = 7; l >= 5; --l) {
             // here a8 = ubar_{l+1} = hbar_{l+1};  zbar_l = s_l * hbar_{l+1} + c_l
-            desc_post<PREC, 8>(a8, st.h_hi + l * LS, st.h_lo + l * LS, cs + (size_t)l * 32 * 64, nc, h, lane);
-            store_stash<PREC, 8>(a8, bb.zbar_hi + l * LS, bb.zbar_lo + l * LS, 256, nc, h, valid, 256);
+            desc_post<PREC, 8>(a8, psb + (size_t)(l) * kSigBlockBytes, cs + (size_t)l * 32 * 64, lane);
+            store_stash<PREC, 8>(scr, lane, a8, bb.zbar_hi + l * LS, bb.zbar_lo + l * LS, 256, n0, N, 256);
             acc_to_bfrag<PREC, 8>(a8, bf);
             zero_acc(a8);
             dense<PREC, 16, 8, 0, 8>(blob, LY.L[l].rev_hi, LY.L[l].rev_lo, bf, a8, lane);
         }
         {   // zbar_4, then ubar_4 restricted to the h_4 rows (7 tiles of the 9-tile reverse pack)
-            desc_post<PREC, 8>(a8, st.h_hi + 4 * LS, st.h_lo + 4 * LS, cs + (size_t)4 * 32 * 64, nc, h, lane);
-            store_stash<PREC, 8>(a8, bb.zbar_hi + 4 * LS, bb.zbar_lo + 4 * LS, 256, nc, h, valid, 256);
+            desc_post<PREC, 8>(a8, psb + (size_t)(4) * kSigBlockBytes, cs + (size_t)4 * 32 * 64, lane);
+            store_stash<PREC, 8>(scr, lane, a8, bb.zbar_hi + 4 * LS, bb.zbar_lo + 4 * LS, 256, n0, N, 256);
             acc_to_bfrag<PREC, 8>(a8, bf);
             zero_acc(a7);
             dense<PREC, 16, 9, 0, 7>(blob, LY.L[4].rev_hi, LY.L[4].rev_lo, bf, a7, lane);
         }
         {   // zbar_3 (7 tiles), ubar_3
-            desc_post<PREC, 7>(a7, st.h_hi + 3 * LS, st.h_lo + 3 * LS, cs + (size_t)3 * 32 * 64, nc, h, lane);
-            store_stash<PREC, 7>(a7, bb.zbar_hi + 3 * LS, bb.zbar_lo + 3 * LS, 256, nc, h, valid, 224);
+            desc_post<PREC, 7>(a7, psb + (size_t)(3) * kSigBlockBytes, cs + (size_t)3 * 32 * 64, lane);
+            store_stash<PREC, 7>(scr, lane, a7, bb.zbar_hi + 3 * LS, bb.zbar_lo + 3 * LS, 256, n0, N, 224);
             acc_to_bfrag<PREC, 7>(a7, bf);
             zero_acc(a8);
             dense<PREC, 14, 8, 0, 8>(blob, LY.L[3].rev_hi, LY.L[3].rev_lo, bf, a8, lane);
         }
         for (int l = 2; l >= 1; --l) {
-            desc_post<PREC, 8>(a8, st.h_hi + l * LS, st.h_lo + l * LS, cs + (size_t)l * 32 * 64, nc, h, lane);
-            store_stash<PREC, 8>(a8, bb.zbar_hi + l * LS, bb.zbar_lo + l * LS, 256, nc, h, valid, 256);
+            desc_post<PREC, 8>(a8, psb + (size_t)(l) * kSigBlockBytes, cs + (size_t)l * 32 * 64, lane);
+            store_stash<PREC, 8>(scr, lane, a8, bb.zbar_hi + l * LS, bb.zbar_lo + l * LS, 256, n0, N, 256);
             acc_to_bfrag<PREC, 8>(a8, bf);
             zero_acc(a8);
             dense<PREC, 16, 8, 0, 8>(blob, LY.L[l].rev_hi, LY.L[l].rev_lo, bf, a8, lane);
         }
-        desc_post<PREC, 8>(a8, st.h_hi, st.h_lo, cs, nc, h, lane);
-        store_stash<PREC, 8>(a8, bb.zbar_hi, bb.zbar_lo, 256, nc, h, valid, 256);
+        desc_post<PREC, 8>(a8, psb, cs, lane);
+        store_stash<PREC, 8>(scr, lane, a8, bb.zbar_hi, bb.zbar_lo, 256, n0, N, 256);
     }
 }
 

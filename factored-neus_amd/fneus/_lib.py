@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libfneus_hip.so")
 
 class FneusSdfStash(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
-                ("pe_hi", "pe_lo", "h_hi", "h_lo", "a_hi", "a_lo", "feat_hi", "feat_lo")]
+                ("pe_hi", "pe_lo", "h_hi", "h_lo", "a_hi", "a_lo", "feat_hi", "feat_lo", "ps", "pa")]
 
 
 class FneusSdfBwdBufs(C.Structure):
@@ -29,7 +29,7 @@ class FneusSdfBwdBufs(C.Structure):
 
 class FneusColStash(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
-                ("side_hi", "side_lo", "u_hi", "u_lo", "zbar_hi", "zbar_lo")]
+                ("side_hi", "side_lo", "u_hi", "u_lo", "zbar_hi", "zbar_lo", "mask")]
 
 
 class FneusGemmJob(C.Structure):

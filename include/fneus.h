@@ -35,6 +35,8 @@ typedef struct FneusSdfStash {
     uint16_t* h_hi;    uint16_t* h_lo;    /* [8][N][256]  slot l = softplus output of layer l (= input of l+1) */
     uint16_t* a_hi;    uint16_t* a_lo;    /* [8][N][256]  slot l = a_l = sigma'(z_l) * d sdf/d h_{l+1}      */
     uint16_t* feat_hi; uint16_t* feat_lo; /* [N][256]     feature vector (colour-network input)             */
+    void* ps; /* lane-private sigma'(z_l): [ceil(N/32)][8][32][64] x 4 values, fp32 (prec 3) or bf16 (prec 1)  */
+    void* pa; /* lane-private a_l, same layout; written when train != 0                                        */
 } FneusSdfStash;
 
 /* bf16 planes of the colour network (written by fneus_color_fwd with train != 0 / fneus_color_bwd). */
@@ -42,6 +44,7 @@ typedef struct FneusColStash {
     uint16_t* side_hi; uint16_t* side_lo; /* [N][48]     pts | PE4(view) | normal (cols >= 33 zero)           */
     uint16_t* u_hi;    uint16_t* u_lo;    /* [4][N][256] slot l = ReLU output of layer l (= input of l+1)     */
     uint16_t* zbar_hi; uint16_t* zbar_lo; /* [5][N][256] slot l = dL/dz_l  (slot 4: 32-wide rows, 3 valid)   */
+    void* mask;                           /* lane-private ReLU masks: [ceil(N/32)][4][64] x 16 bytes           */
 } FneusColStash;
 
 /* work buffers of fneus_sdf_bwd (operands of the weight-gradient GEMM + private scratch). */
