@@ -140,7 +140,7 @@ class SdfStash:
         self.a = alloc(8, n, 256) if train else None
         self.feat = alloc(n, 256) if train else None
         # lane-private planes: [tiles][8 layers][32 groups][64 lanes] x 4 values (fp32 in parity mode, bf16 in fast mode)
-        tiles = (n + 31) // 32
+        tiles = ((n + 31) // 32 + 3) // 4 * 4          # workgroups hold 4 wave tiles
         pdt = torch.float32 if prec == 3 else bf
         self.ps = torch.empty(tiles * 8 * 32 * 64 * 4, dtype=torch.int16, device=device)    # sigma' as u16 fixed point
         self.pa = torch.empty(tiles * 8 * 32 * 64 * 4, dtype=pdt, device=device) if train else None
@@ -206,7 +206,7 @@ class ColStash:
         self.side = torch.zeros((planes, n, 48), dtype=bf, device=device)
         self.u = torch.empty((planes, 4, n, 256), dtype=bf, device=device)
         self.zbar = torch.zeros((planes, 5, n, 256), dtype=bf, device=device)
-        self.mask = torch.zeros(((n + 31) // 32) * 4 * 64 * 4, dtype=torch.int32, device=device)
+        self.mask = torch.zeros((((n + 31) // 32 + 3) // 4 * 4) * 4 * 64 * 4, dtype=torch.int32, device=device)
         s = _lib.FneusColStash()
         s.mask = self.mask.data_ptr()
         for name, t in (("side", self.side), ("u", self.u), ("zbar", self.zbar)):
