@@ -60,6 +60,11 @@ FN_DEV void dense(const unsigned char* __restrict__ blob, uint32_t off_hi, uint3
                 acc[t] = mfma32(ah[s % (D + 1)][i], b[KS0 + ks].hi, acc[t]);
             }
         }
+#ifdef FNEUS_WAVE_SYNC_STAGES
+        // keep the 4 waves of a workgroup within a few hundred cycles of each other so that their identical weight
+        // loads coalesce in the CU's vector L1 instead of each going to L2 (raw barrier: no memory waits)
+        if ((s % FNEUS_WAVE_SYNC_STAGES) == FNEUS_WAVE_SYNC_STAGES - 1) __builtin_amdgcn_s_barrier();
+#endif
         __builtin_amdgcn_sched_barrier(0);
     }
 }

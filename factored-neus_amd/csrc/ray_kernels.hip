@@ -223,35 +223,41 @@ FN_DEV SecVals section_values(const float* o, const float* d, float mz, float di
     return v;
 }
 
+// Background model (womask, renderer.py:350-356): when bg_alpha / bg_color [B][n + n_out] are given, inside the unit
+// sphere the SDF branch is used, outside the NeRF++ background, and n_out extra background samples are appended:
+//   alpha_i = alpha_i*inside_i + bg_alpha_i*(1 - inside_i)  (i < n),   alpha_i = bg_alpha_i  (n <= i < n + n_out)
 __global__ void __launch_bounds__(64) composite_fwd_kernel(
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ mid_z,
     const float* __restrict__ dists, const float* __restrict__ sdf, const float* __restrict__ normal,
     const float* __restrict__ rgb, const float* __restrict__ inv_s_ptr, int n, float car,
+    const float* __restrict__ bg_alpha, const float* __restrict__ bg_color, int n_out,
     float* __restrict__ weights, float* __restrict__ color, float* __restrict__ wsum, float* __restrict__ wmax,
     float* __restrict__ cdf_out, float* __restrict__ inside_out, float* __restrict__ eik /*[B][2]*/,
     int* __restrict__ min_idx_out, unsigned char* __restrict__ mask_out, float* __restrict__ wpair /*[B][2]*/) {
     const int ray = blockIdx.x, lane = threadIdx.x;
     const float inv_s = *inv_s_ptr;
+    const bool bg = bg_alpha != nullptr;
+    const int nt = n + (bg ? n_out : 0);
     float o[3], d[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         o[c] = rays_o[ray * 3 + c];
         d[c] = rays_d[ray * 3 + c];
     }
-    const size_t base = (size_t)ray * n;
-    float fac[PER], fin[PER], T[PER], Tin[PER], al[PER], ins[PER];
+    const size_t base = (size_t)ray * n, baset = (size_t)ray * nt;
+    float fac[PER], fin[PER], T[PER], Tin[PER], al[PER], alpre[PER], ins[PER];
     float csum[3] = {0, 0, 0}, ws = 0.0f, wm = 0.0f, en = 0.0f, ed = 0.0f, insum = 0.0f;
     int firstneg = 1 << 30;
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
         const int i = lane * PER + j;
-        fac[j] = 1.0f; fin[j] = 1.0f; al[j] = 0.0f; ins[j] = 0.0f;
+        fac[j] = 1.0f; fin[j] = 1.0f; al[j] = 0.0f; alpre[j] = 0.0f; ins[j] = 0.0f;
         if (i < n) {
             const float g[3] = {normal[(base + i) * 3], normal[(base + i) * 3 + 1], normal[(base + i) * 3 + 2]};
             const SecVals v = section_values(o, d, mid_z[base + i], dists[base + i], sdf[base + i], g, inv_s, car);
-            al[j] = v.alpha;
+            alpre[j] = v.alpha;
             ins[j] = v.inside;
-            fac[j] = 1.0f - v.alpha + 1e-7f;
+            al[j] = bg ? v.alpha * v.inside + bg_alpha[baset + i] * (1.0f - v.inside) : v.alpha;
             fin[j] = 1.0f - v.alpha * v.inside + 1e-7f;
             cdf_out[base + i] = v.pc;
             inside_out[base + i] = v.inside;
@@ -259,7 +265,10 @@ __global__ void __launch_bounds__(64) composite_fwd_kernel(
             ed += v.relax;
             insum += v.inside;
             if (v.sdf < 0.0f) firstneg = min(firstneg, i);     // first index with sign(sdf) = -1   (:290-291)
+        } else if (i < nt) {
+            al[j] = bg_alpha[baset + i];
         }
+        if (i < nt) fac[j] = 1.0f - al[j] + 1e-7f;
     }
     excl_cumprod(fac, T, lane);
     excl_cumprod(fin, Tin, lane);
@@ -270,15 +279,21 @@ __global__ void __launch_bounds__(64) composite_fwd_kernel(
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
         const int i = lane * PER + j;
-        if (i < n) {
+        if (i < nt) {
             const float w = al[j] * T[j];
-            weights[base + i] = w;
+            weights[baset + i] = w;
             ws += w;
             wm = fmaxf(wm, w);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) csum[c] += w * rgb[(base + i) * 3 + c];
-            if (mask) {
-                const float win = al[j] * ins[j] * Tin[j];
+            for (int c = 0; c < 3; ++c) {
+                float cf;
+                if (i < n) cf = bg ? rgb[(base + i) * 3 + c] * ins[j] + bg_color[(baset + i) * 3 + c] * (1.0f - ins[j])
+                                   : rgb[(base + i) * 3 + c];
+                else cf = bg_color[(baset + i) * 3 + c];
+                csum[c] += w * cf;
+            }
+            if (mask && i < n) {
+                const float win = alpre[j] * ins[j] * Tin[j];
                 if (i == idx - 1) wlo = win;
                 if (i == idx) whi = win;
             }
@@ -325,13 +340,17 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ mid_z,
     const float* __restrict__ dists, const float* __restrict__ sdf, const float* __restrict__ normal,
     const float* __restrict__ rgb, const float* __restrict__ inv_s_ptr, int n, float car,
+    const float* __restrict__ bg_alpha, const float* __restrict__ bg_color, int n_out,
     const int* __restrict__ min_idx, const unsigned char* __restrict__ mask_in,
     const float* __restrict__ d_color /*[B][3]*/, const float* __restrict__ d_wsum /*[B]*/,
-    const float* __restrict__ d_weights /*[B][n] or null*/, const float* __restrict__ d_wpair /*[B][2]*/,
+    const float* __restrict__ d_weights /*[B][nt] or null*/, const float* __restrict__ d_wpair /*[B][2]*/,
     const float* __restrict__ d_eiknum /*[B]*/, float* __restrict__ d_sdf, float* __restrict__ d_normal,
-    float* __restrict__ d_rgb, float* __restrict__ d_inv_s /*[B]*/) {
+    float* __restrict__ d_rgb, float* __restrict__ d_inv_s /*[B]*/, float* __restrict__ d_bg_alpha /*[B][nt]*/,
+    float* __restrict__ d_bg_color /*[B][nt][3]*/) {
     const int ray = blockIdx.x, lane = threadIdx.x;
     const float inv_s = *inv_s_ptr;
+    const bool bg = bg_alpha != nullptr;
+    const int nt = n + (bg ? n_out : 0);
     float o[3], d[3], dc[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -344,20 +363,23 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(
     const bool mask = mask_in[ray] != 0;
     const int idx = min_idx[ray];
     const float dlo = mask ? d_wpair[ray * 2] : 0.0f, dhi = mask ? d_wpair[ray * 2 + 1] : 0.0f;
-    const size_t base = (size_t)ray * n;
+    const size_t base = (size_t)ray * n, baset = (size_t)ray * nt;
     SecVals sv[PER];
-    float fac[PER], fin[PER], T[PER], Tin[PER], ww[PER], wwin[PER], S[PER], Sin[PER], wbar[PER], wbin[PER];
+    float fac[PER], fin[PER], T[PER], Tin[PER], ww[PER], wwin[PER], S[PER], Sin[PER], wbar[PER], wbin[PER], al[PER];
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
         const int i = lane * PER + j;
-        fac[j] = 1.0f; fin[j] = 1.0f;
+        fac[j] = 1.0f; fin[j] = 1.0f; al[j] = 0.0f;
         sv[j] = SecVals{};
         if (i < n) {
             const float g[3] = {normal[(base + i) * 3], normal[(base + i) * 3 + 1], normal[(base + i) * 3 + 2]};
             sv[j] = section_values(o, d, mid_z[base + i], dists[base + i], sdf[base + i], g, inv_s, car);
-            fac[j] = 1.0f - sv[j].alpha + 1e-7f;
+            al[j] = bg ? sv[j].alpha * sv[j].inside + bg_alpha[baset + i] * (1.0f - sv[j].inside) : sv[j].alpha;
             fin[j] = 1.0f - sv[j].alpha * sv[j].inside + 1e-7f;
+        } else if (i < nt) {
+            al[j] = bg_alpha[baset + i];
         }
+        if (i < nt) fac[j] = 1.0f - al[j] + 1e-7f;
     }
     excl_cumprod(fac, T, lane);
     excl_cumprod(fin, Tin, lane);
@@ -365,18 +387,34 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(
     for (int j = 0; j < PER; ++j) {
         const int i = lane * PER + j;
         wbar[j] = 0.0f; wbin[j] = 0.0f; ww[j] = 0.0f; wwin[j] = 0.0f;
-        if (i < n) {
-            const float w = sv[j].alpha * T[j];
-            float wb = dws + dc[0] * rgb[(base + i) * 3] + dc[1] * rgb[(base + i) * 3 + 1] + dc[2] * rgb[(base + i) * 3 + 2];
-            if (d_weights) wb += d_weights[base + i];
+        if (i < nt) {
+            const float w = al[j] * T[j];
+            const float ins = (i < n) ? sv[j].inside : 0.0f;
+            float cf[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (i < n) cf[c] = bg ? rgb[(base + i) * 3 + c] * ins + bg_color[(baset + i) * 3 + c] * (1.0f - ins)
+                                      : rgb[(base + i) * 3 + c];
+                else cf[c] = bg_color[(baset + i) * 3 + c];
+            }
+            float wb = dws + dc[0] * cf[0] + dc[1] * cf[1] + dc[2] * cf[2];
+            if (d_weights) wb += d_weights[baset + i];
             wbar[j] = wb;
             ww[j] = wb * w;
-            const float win = sv[j].alpha * sv[j].inside * Tin[j];
-            const float wbi = (i == idx - 1) ? dlo : ((i == idx) ? dhi : 0.0f);
-            wbin[j] = wbi;
-            wwin[j] = wbi * win;
+            if (i < n) {
+                const float win = sv[j].alpha * ins * Tin[j];
+                const float wbi = (i == idx - 1) ? dlo : ((i == idx) ? dhi : 0.0f);
+                wbin[j] = wbi;
+                wwin[j] = wbi * win;
+                const float kr = bg ? ins : 1.0f;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) d_rgb[(base + i) * 3 + c] = w * dc[c];
+                for (int c = 0; c < 3; ++c) d_rgb[(base + i) * 3 + c] = w * dc[c] * kr;
+            }
+            if (bg) {
+                const float kb = (i < n) ? (1.0f - ins) : 1.0f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) d_bg_color[(baset + i) * 3 + c] = w * dc[c] * kb;
+            }
         }
     }
     excl_suffix_sum(ww, S, lane);
@@ -385,29 +423,33 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
         const int i = lane * PER + j;
-        if (i < n) {
-            const SecVals& v = sv[j];
-            float abar = T[j] * wbar[j] - S[j] / fac[j];
-            const float abar_in = Tin[j] * wbin[j] - Sin[j] / fin[j];
-            abar += v.inside * abar_in;
-            const float rbar = (v.raw >= 0.0f && v.raw <= 1.0f) ? abar : 0.0f;     // clip(0,1) backward
-            const float cden = v.pc + 1e-5f;
-            const float pcbar = rbar * (1.0f / cden - (v.pc - v.nc + 1e-5f) / (cden * cden));
-            const float ncbar = -rbar / cden;
-            const float dpc = v.pc * (1.0f - v.pc), dnc = v.nc * (1.0f - v.nc);
-            const float ic = -(fmaxf(-v.tc * 0.5f + 0.5f, 0.0f) * (1.0f - car) + fmaxf(-v.tc, 0.0f) * car);
-            const float ep = v.sdf - ic * v.dist * 0.5f, en = v.sdf + ic * v.dist * 0.5f;
-            const float epbar = pcbar * dpc * inv_s, enbar = ncbar * dnc * inv_s;
-            dinv += pcbar * dpc * ep + ncbar * dnc * en;
-            d_sdf[base + i] = epbar + enbar;
-            const float icbar = (enbar - epbar) * v.dist * 0.5f;
-            const float dic_dtc = 0.5f * (1.0f - car) * ((-v.tc * 0.5f + 0.5f) > 0.0f ? 1.0f : 0.0f) +
-                                  car * ((-v.tc) > 0.0f ? 1.0f : 0.0f);
-            const float tcbar = icbar * dic_dtc;
-            const float g[3] = {normal[(base + i) * 3], normal[(base + i) * 3 + 1], normal[(base + i) * 3 + 2]};
-            const float ek = (v.gn > 0.0f) ? deik * v.relax * 2.0f * (v.gn - 1.0f) / v.gn : 0.0f;
+        if (i < nt) {
+            const float afin_bar = T[j] * wbar[j] - S[j] / fac[j];
+            if (bg) d_bg_alpha[baset + i] = afin_bar * ((i < n) ? (1.0f - sv[j].inside) : 1.0f);
+            if (i < n) {
+                const SecVals& v = sv[j];
+                float abar = afin_bar * (bg ? v.inside : 1.0f);
+                const float abar_in = Tin[j] * wbin[j] - Sin[j] / fin[j];
+                abar += v.inside * abar_in;
+                const float rbar = (v.raw >= 0.0f && v.raw <= 1.0f) ? abar : 0.0f;     // clip(0,1) backward
+                const float cden = v.pc + 1e-5f;
+                const float pcbar = rbar * (1.0f / cden - (v.pc - v.nc + 1e-5f) / (cden * cden));
+                const float ncbar = -rbar / cden;
+                const float dpc = v.pc * (1.0f - v.pc), dnc = v.nc * (1.0f - v.nc);
+                const float ic = -(fmaxf(-v.tc * 0.5f + 0.5f, 0.0f) * (1.0f - car) + fmaxf(-v.tc, 0.0f) * car);
+                const float ep = v.sdf - ic * v.dist * 0.5f, en = v.sdf + ic * v.dist * 0.5f;
+                const float epbar = pcbar * dpc * inv_s, enbar = ncbar * dnc * inv_s;
+                dinv += pcbar * dpc * ep + ncbar * dnc * en;
+                d_sdf[base + i] = epbar + enbar;
+                const float icbar = (enbar - epbar) * v.dist * 0.5f;
+                const float dic_dtc = 0.5f * (1.0f - car) * ((-v.tc * 0.5f + 0.5f) > 0.0f ? 1.0f : 0.0f) +
+                                      car * ((-v.tc) > 0.0f ? 1.0f : 0.0f);
+                const float tcbar = icbar * dic_dtc;
+                const float g[3] = {normal[(base + i) * 3], normal[(base + i) * 3 + 1], normal[(base + i) * 3 + 2]};
+                const float ek = (v.gn > 0.0f) ? deik * v.relax * 2.0f * (v.gn - 1.0f) / v.gn : 0.0f;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) d_normal[(base + i) * 3 + c] = tcbar * d[c] + ek * g[c];
+                for (int c = 0; c < 3; ++c) d_normal[(base + i) * 3 + c] = tcbar * d[c] + ek * g[c];
+            }
         }
     }
     dinv = wave_sum(dinv);
@@ -453,31 +495,34 @@ extern "C" int fneus_sections(const float* z, int n_rays, int n, float sample_di
 
 extern "C" int fneus_composite_fwd(const float* rays_o, const float* rays_d, const float* mid_z, const float* dists,
                                    const float* sdf, const float* normal, const float* rgb, const float* inv_s,
-                                   int n_rays, int n, float cos_anneal_ratio, float* weights, float* color, float* wsum,
+                                   int n_rays, int n, float cos_anneal_ratio, const float* bg_alpha,
+                                   const float* bg_color, int n_out, float* weights, float* color, float* wsum,
                                    float* wmax, float* cdf, float* inside, float* eik, int32_t* min_idx,
                                    unsigned char* sdf_mask, float* wpair, fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     fneus::clear_status();
     if (n_rays <= 0) return 0;
-    FN_CHECK_N(n);
+    FN_CHECK_N(n + (bg_alpha ? n_out : 0));
     hipLaunchKernelGGL(composite_fwd_kernel, dim3(n_rays), dim3(64), 0, stream, rays_o, rays_d, mid_z, dists, sdf, normal,
-                       rgb, inv_s, n, cos_anneal_ratio, weights, color, wsum, wmax, cdf, inside, eik, min_idx, sdf_mask,
-                       wpair);
+                       rgb, inv_s, n, cos_anneal_ratio, bg_alpha, bg_color, n_out, weights, color, wsum, wmax, cdf, inside,
+                       eik, min_idx, sdf_mask, wpair);
     return fneus::launch_status();
 }
 
 extern "C" int fneus_composite_bwd(const float* rays_o, const float* rays_d, const float* mid_z, const float* dists,
                                    const float* sdf, const float* normal, const float* rgb, const float* inv_s,
-                                   int n_rays, int n, float cos_anneal_ratio, const int32_t* min_idx,
+                                   int n_rays, int n, float cos_anneal_ratio, const float* bg_alpha,
+                                   const float* bg_color, int n_out, const int32_t* min_idx,
                                    const unsigned char* sdf_mask, const float* d_color, const float* d_wsum,
                                    const float* d_weights, const float* d_wpair, const float* d_eiknum, float* d_sdf,
-                                   float* d_normal, float* d_rgb, float* d_inv_s, fneus_stream_t stream_) {
+                                   float* d_normal, float* d_rgb, float* d_inv_s, float* d_bg_alpha, float* d_bg_color,
+                                   fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     fneus::clear_status();
     if (n_rays <= 0) return 0;
-    FN_CHECK_N(n);
+    FN_CHECK_N(n + (bg_alpha ? n_out : 0));
     hipLaunchKernelGGL(composite_bwd_kernel, dim3(n_rays), dim3(64), 0, stream, rays_o, rays_d, mid_z, dists, sdf, normal,
-                       rgb, inv_s, n, cos_anneal_ratio, min_idx, sdf_mask, d_color, d_wsum, d_weights, d_wpair, d_eiknum,
-                       d_sdf, d_normal, d_rgb, d_inv_s);
+                       rgb, inv_s, n, cos_anneal_ratio, bg_alpha, bg_color, n_out, min_idx, sdf_mask, d_color, d_wsum,
+                       d_weights, d_wpair, d_eiknum, d_sdf, d_normal, d_rgb, d_inv_s, d_bg_alpha, d_bg_color);
     return fneus::launch_status();
 }

@@ -55,12 +55,12 @@ class Runner:
         self.warm_up_end, self.anneal_end = tc.get_float("warm_up_end", 0.0), tc.get_float("anneal_end", 0.0)
         self.igr_weight, self.mask_weight = tc.get_float("igr_weight"), tc.get_float("mask_weight")
         model_conf = {k: dict(self.conf["model"][k]) for k in ("sdf_network", "variance_network", "rendering_network",
-                                                                "neus_renderer")}
+                                                                "neus_renderer", "nerf")}
         self.trainer = Stage1Trainer(self.device, model_conf=model_conf, prec=prec, lr=self.learning_rate,
                                      igr_weight=self.igr_weight, mask_weight=self.mask_weight,
                                      surface_weight=surface_weight, synthetic_init=False, distributed=distributed)
-        # the reference also constructs, optimises-over and checkpoints the background NeRF even when n_outside == 0
-        self.nerf_outside = NeRF(**dict(self.conf["model.nerf"])).to(self.device)
+        # the reference also constructs and checkpoints the background NeRF when n_outside == 0 (it is never evaluated then)
+        self.nerf_outside = self.trainer.nerf_outside or NeRF(**dict(self.conf["model.nerf"])).to(self.device)
         self.iter_step = 0
         if is_continue:
             names = sorted(n for n in os.listdir(os.path.join(self.base_exp_dir, "checkpoints"))

@@ -28,7 +28,7 @@ class Stage1Trainer:
     def __init__(self, device, model_conf: Optional[dict] = None, prec: int = ops.PREC_PARITY, lr: float = 5e-4,
                  igr_weight: float = 0.1, mask_weight: float = 0.1, surface_weight: float = 0.1, seed: int = 0,
                  synthetic_init: bool = True, distributed: bool = False):
-        from models.fields import SDFNetwork, RenderingNetwork, SingleVarianceNetwork, RefColor
+        from models.fields import SDFNetwork, RenderingNetwork, SingleVarianceNetwork, RefColor, NeRF
         from models.renderer import NeuSRenderer
         conf = model_conf or WMASK_MODEL
         self.device = device
@@ -41,14 +41,22 @@ class Stage1Trainer:
             self.sdf_network.load_state_dict(T(synth.sdf_state_dict(seed)))
             self.color_network.load_state_dict(T(synth.color_state_dict(seed + 1)))
             self.refColor_network.load_state_dict(T(synth.refcolor_state_dict(seed + 2)))
+        self.nerf_outside = None
+        if conf["neus_renderer"].get("n_outside", 0) > 0:          # womask: background NeRF++ (renderer.py:452-458)
+            self.nerf_outside = NeRF(**conf.get("nerf", dict(D=8, d_in=4, d_in_view=3, W=256, multires=10,
+                                                             multires_view=4, output_ch=4, skips=[4], use_viewdirs=True)))
+            if synthetic_init:
+                self.nerf_outside.load_state_dict({k: torch.from_numpy(v) for k, v in synth.nerf_state_dict(seed + 3).items()})
         self.modules = [self.sdf_network, self.deviation_network, self.color_network, self.refColor_network]
+        if self.nerf_outside is not None:
+            self.modules.append(self.nerf_outside)
         for m in self.modules:
             m.to(device)
         self.sdf_network.set_precision(prec)
         self.color_network.set_precision(prec)
         self.params = [p for m in self.modules for p in m.parameters()]
         self.optimizer = torch.optim.Adam(self.params, lr=lr, fused=(device.type == "cuda"))
-        self.renderer = NeuSRenderer(**conf["neus_renderer"], nerf=None, sdf_network=self.sdf_network,
+        self.renderer = NeuSRenderer(**conf["neus_renderer"], nerf=self.nerf_outside, sdf_network=self.sdf_network,
                                      deviation_network=self.deviation_network, color_network=self.color_network,
                                      refColor_network=self.refColor_network)
         self.igr_weight, self.mask_weight, self.surface_weight = igr_weight, mask_weight, surface_weight
@@ -77,9 +85,10 @@ class Stage1Trainer:
         for net in (self.sdf_network, self.color_network):
             if net._net is not None:
                 net._net.raw_grad.zero_()
-        for m in (self.deviation_network, self.refColor_network):
-            for p in m.parameters():
-                p.grad = None
+        for m in (self.deviation_network, self.refColor_network, self.nerf_outside):
+            if m is not None:
+                for p in m.parameters():
+                    p.grad = None
 
     def render_only(self, data: torch.Tensor, cos_anneal_ratio: float = 1.0):
         rays_o, rays_d = data[:, :3], data[:, 3:6]

@@ -85,12 +85,32 @@ class NeuSRenderer:
                 z_vals, sdf = self.cat_z_vals(rays_o, rays_d, z_vals, new_z, sdf, last=(i + 1 == self.up_sample_steps))
         return z_vals
 
+    # ---- render_core_outside (renderer.py:112-149): inverted-sphere background NeRF++, womask configs only --------
+    def render_core_outside(self, rays_o, rays_d, z_vals, sample_dist, nerf, background_rgb=None):
+        """The background network is a plain torch module (models/fields.py NeRF): it is evaluated only for womask
+        configurations and is not one of the fused kernels yet; alpha / compositing of its samples runs in the HIP
+        compositing kernel together with the SDF branch."""
+        B, n = z_vals.shape
+        dists = torch.cat([z_vals[:, 1:] - z_vals[:, :-1], torch.full_like(z_vals[:, :1], sample_dist)], -1)
+        mid_z = z_vals + dists * 0.5
+        pts = rays_o[:, None, :] + rays_d[:, None, :] * mid_z[..., None]
+        dis = torch.linalg.norm(pts, ord=2, dim=-1, keepdim=True).clip(1.0, 1e10)
+        pts4 = torch.cat([pts / dis, 1.0 / dis], dim=-1).reshape(-1, 4)
+        dirs = rays_d[:, None, :].expand(B, n, 3).reshape(-1, 3)
+        density, rgb = nerf(pts4, dirs)
+        rgb = torch.sigmoid(rgb).reshape(B, n, 3)
+        alpha = 1.0 - torch.exp(-F.softplus(density.reshape(B, n)) * dists)
+        one = torch.ones([B, 1], device=z_vals.device)
+        weights = alpha * torch.cumprod(torch.cat([one, 1.0 - alpha + 1e-7], -1), -1)[:, :-1]
+        color = (weights[:, :, None] * rgb).sum(dim=1)
+        if background_rgb is not None:
+            color = color + background_rgb * (1.0 - weights.sum(dim=-1, keepdim=True))
+        return {"color": color, "sampled_color": rgb, "alpha": alpha, "weights": weights}
+
     # ---- render_core (renderer.py:208-389) ------------------------------------------------------------------------
     def render_core(self, rays_o, rays_d, z_vals, sample_dist, sdf_network, deviation_network, color_network,
                     refColor_network, background_alpha=None, background_sampled_color=None, background_rgb=None,
                     cos_anneal_ratio=0.0):
-        if background_alpha is not None:
-            raise NotImplementedError("n_outside > 0 (womask background NeRF) is not on the HIP path yet")
         B, n = z_vals.shape
         train = torch.is_grad_enabled()
         dists, mid_z = ops.sections(z_vals.contiguous(), sample_dist)
@@ -99,7 +119,8 @@ class NeuSRenderer:
         inv_s = deviation_network.inv_s()
         rgb = color_network.color_samples(samples, normal, feat, sdf_network, train)
         (color, weights, wsum, wpair, eik_num, wmax, cdf, inside, eik_den, min_idx, sdf_mask_u8) = CompositeFn.apply(
-            sdf, normal, rgb, inv_s, rays_o, rays_d, mid_z, dists, float(cos_anneal_ratio))
+            sdf, normal, rgb, inv_s, rays_o, rays_d, mid_z, dists, float(cos_anneal_ratio), background_alpha,
+            background_sampled_color)
         sdf_mask = sdf_mask_u8.bool()
         gradient_error = eik_num.sum() / (eik_den.sum() + 1e-5)                        # renderer.py:370-372
 
@@ -138,12 +159,20 @@ class NeuSRenderer:
         sample_dist = 2.0 / self.n_samples
         z_vals = torch.linspace(0.0, 1.0, self.n_samples, device=dev)
         z_vals = near + (far - near) * z_vals[None, :]
-        if self.n_outside > 0:
-            raise NotImplementedError("n_outside > 0 (womask background NeRF) is not on the HIP path yet")
+        z_vals_outside = None
+        if self.n_outside > 0:                                                    # renderer.py:397-400
+            z_vals_outside = torch.linspace(1e-3, 1.0 - 1.0 / (self.n_outside + 1.0), self.n_outside, device=dev)
         perturb = self.perturb if perturb_overwrite < 0 else perturb_overwrite
         if perturb > 0:
             t_rand = torch.rand([B, 1], device=dev) - 0.5
             z_vals = z_vals + t_rand * 2.0 / self.n_samples
+            if self.n_outside > 0:                                                # renderer.py:411-416
+                mids = 0.5 * (z_vals_outside[1:] + z_vals_outside[:-1])
+                upper = torch.cat([mids, z_vals_outside[-1:]], -1)
+                lower = torch.cat([z_vals_outside[:1], mids], -1)
+                z_vals_outside = lower[None, :] + (upper - lower)[None, :] * torch.rand([B, self.n_outside], device=dev)
+        if self.n_outside > 0:                                                    # renderer.py:418-419
+            z_vals_outside = far / torch.flip(z_vals_outside, dims=[-1]) + 1.0 / self.n_samples
         # networks changed since the last call (optimiser step): fold weight-norm and re-pack once
         self.sdf_network.refresh()
         self.color_network.refresh()
@@ -154,8 +183,14 @@ class NeuSRenderer:
             else:
                 z_vals = self._hierarchical_z(rays_o, rays_d, z_vals.contiguous())
             n = self.n_samples + self.n_importance
+        background_alpha = background_sampled_color = None
+        if self.n_outside > 0:                                                    # renderer.py:452-458
+            z_vals_feed, _ = torch.sort(torch.cat([z_vals, z_vals_outside.expand(B, -1)], dim=-1), dim=-1)
+            ret_outside = self.render_core_outside(rays_o, rays_d, z_vals_feed, sample_dist, self.nerf)
+            background_sampled_color, background_alpha = ret_outside["sampled_color"], ret_outside["alpha"]
         ret = self.render_core(rays_o, rays_d, z_vals, sample_dist, self.sdf_network, self.deviation_network,
                                self.color_network, self.refColor_network, background_rgb=background_rgb,
+                               background_alpha=background_alpha, background_sampled_color=background_sampled_color,
                                cos_anneal_ratio=cos_anneal_ratio)
         weights = ret["weights"]
         return {

@@ -141,18 +141,24 @@ int fneus_sections(const float* z, int n_rays, int n, float sample_dist, float* 
 /* ---- K5: NeuS SDF->alpha, front-to-back compositing, eikonal sums, first sign change
  *      (renderer.py:245-274, 290-293, 328-332, 360-372).  Per-ray outputs: color [B][3], wsum/wmax [B],
  *      eik [B][2] = (sum relax*(|g|-1)^2, sum relax), min_idx [B], sdf_mask [B] (u8), wpair [B][2] = inside-sphere
- *      weights at min_idx-1 / min_idx (0 when !sdf_mask).  inv_s is a device scalar. */
+ *      weights at min_idx-1 / min_idx (0 when !sdf_mask).  inv_s is a device scalar.
+ *      With bg_alpha / bg_color (womask, renderer.py:350-356) samples outside the unit sphere take the background
+ *      NeRF's alpha / colour and n_out background samples are appended (weights then have n + n_out columns). */
 int fneus_composite_fwd(const float* rays_o, const float* rays_d, const float* mid_z, const float* dists, const float* sdf,
                         const float* normal, const float* rgb, const float* inv_s, int n_rays, int n,
-                        float cos_anneal_ratio, float* weights, float* color, float* wsum, float* wmax, float* cdf,
+                        float cos_anneal_ratio, const float* bg_alpha /*[B][n+n_out] or NULL*/,
+                        const float* bg_color /*[B][n+n_out][3] or NULL*/, int n_out,
+                        float* weights /*[B][n (+n_out)]*/, float* color, float* wsum, float* wmax, float* cdf,
                         float* inside, float* eik, int32_t* min_idx, unsigned char* sdf_mask, float* wpair,
                         fneus_stream_t stream);
 /* adjoint of fneus_composite_fwd; d_weights may be NULL; d_inv_s is per ray (caller sums). */
 int fneus_composite_bwd(const float* rays_o, const float* rays_d, const float* mid_z, const float* dists, const float* sdf,
                         const float* normal, const float* rgb, const float* inv_s, int n_rays, int n,
-                        float cos_anneal_ratio, const int32_t* min_idx, const unsigned char* sdf_mask,
+                        float cos_anneal_ratio, const float* bg_alpha, const float* bg_color, int n_out,
+                        const int32_t* min_idx, const unsigned char* sdf_mask,
                         const float* d_color, const float* d_wsum, const float* d_weights, const float* d_wpair,
                         const float* d_eiknum, float* d_sdf, float* d_normal, float* d_rgb, float* d_inv_s,
+                        float* d_bg_alpha /*[B][n+n_out] or NULL*/, float* d_bg_color /*or NULL*/,
                         fneus_stream_t stream);
 
 #ifdef __cplusplus

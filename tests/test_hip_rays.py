@@ -115,9 +115,9 @@ def test_composite_fwd_bwd(n, car, inv_s):
         assert e <= 2e-6, (k, e)
     assert (out["eik"][:, 0].cpu().double() - ref["eik_num"].detach()).abs().max().item() <= 1e-5
     assert torch.equal(out["eik"][:, 1].cpu().double(), ref["eik_den"])
-    d_sdf, d_nrm, d_rgb, d_inv = ops.composite_bwd(d(ro), d(rd), d(mid_z), d(dists), d(sdf), d(normal), d(rgb), inv_s_dev, car,
-                                                   out["min_idx"], out["sdf_mask"], d(c_col), d(c_ws), d(c_w), d(c_pair),
-                                                   d(c_eik))
+    d_sdf, d_nrm, d_rgb, d_inv, _, _ = ops.composite_bwd(d(ro), d(rd), d(mid_z), d(dists), d(sdf), d(normal), d(rgb),
+                                                         inv_s_dev, car, out["min_idx"], out["sdf_mask"], d(c_col),
+                                                         d(c_ws), d(c_w), d(c_pair), d(c_eik))
 
     def rel(a, b):
         return ((a.cpu().double() - b).abs().max() / (b.abs().max() + 1e-30)).item()
@@ -126,3 +126,44 @@ def test_composite_fwd_bwd(n, car, inv_s):
     e4 = abs(d_inv.sum().item() - s64.grad.item()) / (abs(s64.grad.item()) + 1e-30)
     print(f"composite_bwd n={n}: d_sdf {e1:.2e} d_normal {e2:.2e} d_rgb {e3:.2e} d_inv_s {e4:.2e}")
     assert e1 <= 2e-4 and e2 <= 2e-4 and e3 <= 1e-5 and e4 <= 2e-4
+
+
+@pytest.mark.parametrize("n,n_out", [(32, 8), (128, 32)])
+def test_composite_with_background(n, n_out):
+    """womask blend (renderer.py:350-356): composite of the SDF branch with background alpha / colours, fwd + bwd,
+    against torch autograd of the oracle's formulas in fp64"""
+    from fneus import ops
+    from oracle import ref_torch as R
+    B = 16
+    ro, rd, mid_z, dists, sdf, normal, rgb = make_fields(B, n, seed=100 + n)
+    rs = np.random.RandomState(n)
+    nt = n + n_out
+    bga = T(rs.uniform(0.0, 0.3, size=(B, nt)).astype(np.float32))
+    bgc = T(rs.uniform(0, 1, size=(B, nt, 3)).astype(np.float32))
+    inv_s, car = 40.0, 0.5
+    sdf64, nrm64, rgb64 = (t.double().requires_grad_(True) for t in (sdf, normal, rgb))
+    bga64, bgc64 = bga.double().requires_grad_(True), bgc.double().requires_grad_(True)
+    s64 = torch.tensor(inv_s, dtype=torch.float64, requires_grad=True)
+    ref = R.composite_from_fields(ro.double(), rd.double(), mid_z.double(), dists.double(), sdf64, nrm64, rgb64, s64, car)
+    ins = ref["inside"]
+    alpha = torch.cat([ref["alpha"] * ins + bga64[:, :n] * (1.0 - ins), bga64[:, n:]], -1)
+    col = torch.cat([rgb64.reshape(B, n, 3) * ins[..., None] + bgc64[:, :n] * (1.0 - ins)[..., None], bgc64[:, n:]], 1)
+    w = alpha * R.exclusive_transmittance(alpha)
+    color = (col * w[..., None]).sum(1)
+    c_col, c_w, c_pair = T(rs.standard_normal((B, 3))), T(rs.standard_normal((B, nt)) * 0.1), T(rs.standard_normal((B, 2)))
+    L = (color * c_col).sum() + (w * c_w).sum() + (ref["wpair"] * c_pair).sum() + w.sum(-1).sum() * 0.3
+    L.backward()
+    d = lambda t: t.float().to(DEV).contiguous()
+    inv_s_dev = torch.tensor([inv_s], dtype=torch.float32, device=DEV)
+    out = ops.composite_fwd(d(ro), d(rd), d(mid_z), d(dists), d(sdf), d(normal), d(rgb), inv_s_dev, car, d(bga), d(bgc))
+    assert (out["weights"].cpu().double() - w.detach()).abs().max().item() <= 2e-6
+    assert (out["color"].cpu().double() - color.detach()).abs().max().item() <= 2e-6
+    assert (out["wpair"].cpu().double() - ref["wpair"].detach()).abs().max().item() <= 2e-6
+    g = ops.composite_bwd(d(ro), d(rd), d(mid_z), d(dists), d(sdf), d(normal), d(rgb), inv_s_dev, car, out["min_idx"],
+                          out["sdf_mask"], d(c_col), torch.full((B,), 0.3, device=DEV), d(c_w), d(c_pair),
+                          torch.zeros(B, device=DEV), d(bga), d(bgc))
+    rel = lambda a, b: ((a.cpu().double() - b).abs().max() / (b.abs().max() + 1e-30)).item()
+    errs = [rel(g[0], sdf64.grad), rel(g[1], nrm64.grad), rel(g[2], rgb64.grad), rel(g[4], bga64.grad), rel(g[5], bgc64.grad)]
+    e_s = abs(g[3].sum().item() - s64.grad.item()) / (abs(s64.grad.item()) + 1e-30)
+    print("composite+bg rel errs", ["%.1e" % e for e in errs], "inv_s %.1e" % e_s)
+    assert max(errs) <= 2e-4 and e_s <= 2e-4

@@ -38,9 +38,14 @@ def build(g, prec):
         m.to(DEV)
     sdf.set_precision(prec)
     col.set_precision(prec)
-    rnd = NeuSRenderer(int(g["n_samples"]), int(g["n_importance"]), int(g["n_outside"]), 4, 1.0, nerf=None,
+    nerf = None
+    if int(g["n_outside"]) > 0:
+        nerf = NeRF(D=8, d_in=4, d_in_view=3, W=256, multires=10, multires_view=4, output_ch=4, skips=[4], use_viewdirs=True)
+        nerf.load_state_dict({k: T(v) for k, v in synth.nerf_state_dict(int(g["seed_nerf"])).items()})
+        nerf.to(DEV)
+    rnd = NeuSRenderer(int(g["n_samples"]), int(g["n_importance"]), int(g["n_outside"]), 4, 1.0, nerf=nerf,
                        sdf_network=sdf, deviation_network=var, color_network=col, refColor_network=ref)
-    return rnd, dict(sdf=sdf, color=col, var=var, refcolor=ref)
+    return rnd, dict(sdf=sdf, color=col, var=var, refcolor=ref, nerf=nerf)
 
 
 def run(g, prec, teacher_z):
@@ -49,8 +54,9 @@ def run(g, prec, teacher_z):
     data = T(g["data"]).to(DEV)
     rays_o, rays_d, rgb, mask = data[:, :3], data[:, 3:6], data[:, 6:9], data[:, 9:10]
     near, far = R.near_far_from_sphere(rays_o, rays_d)
+    bg = torch.ones(1, 3, device=DEV) if int(g["white_bkgd"]) else None
     out = rnd.render(rays_o, rays_d, near, far, perturb_overwrite=0, cos_anneal_ratio=float(g["cos_anneal_ratio"]),
-                     z_vals_override=T(g["trace/z_3"]).to(DEV) if teacher_z else None)
+                     background_rgb=bg, z_vals_override=T(g["trace/z_3"]).to(DEV) if teacher_z else None)
     return out, nets, (rgb, mask)
 
 
@@ -59,9 +65,10 @@ def maxerr(a, b):
 
 
 WMASK = ["render_wmask_b16_n16", "render_wmask_b8_n64", "render_wmask_b16_n16_c0"]
+WOMASK = ["render_womask_b16_n16_o8"]       # n_outside = 8, white background, cos_anneal 0.3
 
 
-@pytest.mark.parametrize("name", WMASK)
+@pytest.mark.parametrize("name", WMASK + WOMASK)
 def test_render_core_teacher_forced(golden_dir, name):
     g = load(golden_dir, name)
     out, _, _ = run(g, 3, teacher_z=True)
@@ -91,7 +98,7 @@ def test_render_end_to_end(golden_dir, name):
     assert maxerr(out["_z_vals"], g["trace/z_3"]) <= 3e-3
 
 
-@pytest.mark.parametrize("name", WMASK[:2])
+@pytest.mark.parametrize("name", WMASK[:2] + WOMASK)
 def test_loss_and_gradients(golden_dir, name):
     from fneus.losses import stage1_loss
     g = load(golden_dir, name)
@@ -108,7 +115,7 @@ def test_loss_and_gradients(golden_dir, name):
             continue
         pname = key[len("grad_norm/"):]
         net, rest = pname.split(".", 1)
-        if net == "nerf":
+        if nets.get(net) is None:
             continue
         prm = dict(nets[net].named_parameters())[rest]
         assert prm.grad is not None, pname
@@ -121,8 +128,9 @@ def test_loss_and_gradients(golden_dir, name):
         worst = max(worst, e_sub, e_norm)
         # RefColor is a ReLU MLP evaluated on only 2 samples per masked ray: a single unit whose pre-activation sits
         # within rounding of zero shows up in an individual weight-gradient entry
-        lim_sub = 3e-2 if net == "refcolor" else 5e-3
-        assert e_sub <= lim_sub and e_norm <= 2e-3, (pname, e_sub, e_norm)
+        lim_sub = 3e-2 if net in ("refcolor", "nerf") else 5e-3
+        lim_norm = 1e-2 if net == "nerf" else 2e-3     # background NeRF: plain torch ReLU MLP (rocBLAS GEMMs)
+        assert e_sub <= lim_sub and e_norm <= lim_norm, (pname, e_sub, e_norm)
         checked += 1
     print(f"{name}: {checked} parameter tensors, worst relative gradient error {worst:.2e}")
     assert checked >= 40
