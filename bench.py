@@ -173,8 +173,15 @@ def main():
         dom = max((k for k in per if k in KERNEL_FLOPS), key=lambda k: per[k]["ms_per_step"])
         flops_per_launch = KERNEL_FLOPS[dom] / max(round(per[dom]["launches_per_step"]), 1)
         achieved = flops_per_launch / (per[dom]["avg_ms"] * 1e-3) / 1e12
+        traffic = None      # HBM bytes per launch from the committed PMC passes (profiles/r01_traffic.json), parity mode only
+        try:
+            if prec == ops.PREC_PARITY:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"]
+                traffic = tj[dom.split(":")[0]]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         result["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS,
-                              "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_MFMA_TFLOPS, "traffic": None,
+                              "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_MFMA_TFLOPS, "traffic": traffic,
                               "avg_launch_ms": per[dom]["avg_ms"],
                               "note": "algorithmic (fp32-equivalent) FLOPs per launch / HIP-event launch duration; "
                                       "parity mode issues 3 bf16 MFMAs per algorithmic product"}
