@@ -23,6 +23,11 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define FN_DEV __device__ __forceinline__
+// Weight blobs are read through explicit GLOBAL-address-space pointers: the kernels launder the blob pointer per tile
+// (to stop LICM hoisting the weight stream), which also hides its address space from the compiler, and the resulting
+// FLAT loads would tick lgkmcnt as well as vmcnt -- every LDS wait would then drain the weight prefetch.
+#define FN_GLOBAL __attribute__((address_space(1)))
+typedef const unsigned char FN_GLOBAL* gblob_t;
 
 namespace fneus {
 

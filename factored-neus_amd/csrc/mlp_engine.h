@@ -18,8 +18,8 @@ FN_DEV void dense(const unsigned char* __restrict__ blob, uint32_t off_hi, uint3
     constexpr int NG = (TN + GT - 1) / GT;              // stages per k-step
     constexpr int NS = KS * NG;                         // stages
     constexpr int D = PREC == 3 ? 2 : 4;                // prefetch distance (stages)
-    const bf16x8* __restrict__ whi = reinterpret_cast<const bf16x8*>(blob + off_hi) + lane;
-    const bf16x8* __restrict__ wlo = reinterpret_cast<const bf16x8*>(blob + off_lo) + lane;
+    const bf16x8 FN_GLOBAL* __restrict__ whi = reinterpret_cast<const bf16x8 FN_GLOBAL*>((gblob_t)blob + off_hi) + lane;
+    const bf16x8 FN_GLOBAL* __restrict__ wlo = reinterpret_cast<const bf16x8 FN_GLOBAL*>((gblob_t)blob + off_lo) + lane;
     bf16x8 ah[D + 1][GT], al[D + 1][GT];
 #pragma unroll
     for (int s = 0; s < D; ++s) {
@@ -72,7 +72,7 @@ FN_DEV void dense(const unsigned char* __restrict__ blob, uint32_t off_hi, uint3
 // accumulators <- packed fp32 vector in accumulator layout ([t][h][16])
 template <int NT_TOTAL, int T0, int TN>
 FN_DEV void load_accvec(const unsigned char* __restrict__ blob, uint32_t off, f32x16 (&acc)[TN], int lane) {
-    const f32x16* __restrict__ p = reinterpret_cast<const f32x16*>(blob + off);
+    const f32x16 FN_GLOBAL* __restrict__ p = reinterpret_cast<const f32x16 FN_GLOBAL*>((gblob_t)blob + off);
     const int h = lane >> 5;
 #pragma unroll
     for (int i = 0; i < TN; ++i) acc[i] = p[(T0 + i) * 2 + h];
@@ -160,7 +160,11 @@ FN_DEV void store_stash(unsigned char* __restrict__ wscr, int lane, const f32x16
         __bf16* __restrict__ plane = pl ? lo : hi;
         for (int idx = lane; idx < total; idx += 64) {
             const int row = idx / P, pc = idx - row * P;
+#ifdef FNEUS_DBG_NO_ROWSTORE   // timing experiments only (tools/experiments): keep the LDS traffic, drop the global stores
+            if (n0 + row < N && pc < 0)
+#else
             if (n0 + row < N)
+#endif
                 *reinterpret_cast<uint2*>(plane + (n0 + row) * ld + pc * 4) =
                     *reinterpret_cast<const uint2*>(wscr + pl * kScrPlane + row * kScrStride + pc * 8);
         }
@@ -211,6 +215,9 @@ FN_DEV void priv_put(void* __restrict__ base, int slot, int lane, const float (&
         if constexpr (PREC == 3) o[e] = v[e];
         else o[e] = (__bf16)v[e];
     }
+#ifdef FNEUS_DBG_NO_PRIV
+    if (lane < 0)
+#endif
     reinterpret_cast<typename PrivT<PREC>::v4*>(base)[slot * 64 + lane] = o;
 }
 
@@ -228,6 +235,9 @@ FN_DEV void sig_put(void* __restrict__ base, int slot, int lane, const float (&v
     u16x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = (unsigned short)__float2uint_rn(fminf(fmaxf(v[e], 0.0f), 1.0f) * 65535.0f);
+#ifdef FNEUS_DBG_NO_PRIV
+    if (lane < 0)
+#endif
     reinterpret_cast<u16x4*>(base)[slot * 64 + lane] = o;
 }
 FN_DEV void sig_get(const void* __restrict__ base, int slot, int lane, float (&v)[4]) {

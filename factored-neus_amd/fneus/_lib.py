@@ -14,7 +14,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfneus_hip.so")
+# FNEUS_LIB selects another build of the same library (kernel experiments, tools/experiments/build_variant.sh)
+LIB_PATH = os.environ.get("FNEUS_LIB") or os.path.join(_HERE, "libfneus_hip.so")
 
 
 class FneusSdfStash(C.Structure):
