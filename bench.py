@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-fast-extra", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels eagerly instead of replaying a hipGraph")
     args = ap.parse_args()
 
     from fneus import ops
@@ -112,11 +113,14 @@ def main():
     device = torch.device("cuda", local)
 
     def run(prec, steps, warmup, profile):
-        tr = Stage1Trainer(device, prec=prec, distributed=(world > 1))
+        tr = Stage1Trainer(device, prec=prec, distributed=(world > 1), use_graph=not args.no_graph)
         broadcast_parameters(tr.modules)
         batches = synthetic_batches(steps + warmup + (3 if profile else 0), RAYS, device, rank=rank)
         for i in range(warmup):
             tr.train_step(batches[i])
+        if tr.use_graph and not tr._graphs:      # too few warm-up steps to have captured: capture now, untimed
+            for i in range(tr.graph_warmup_steps + 1):
+                tr.train_step(batches[i % len(batches)])
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -161,7 +165,8 @@ def main():
         "data": "synthetic DTU-shaped rays (one camera per step), random-init weights of the reference distributions",
         "config": {"workload": "dtu_scan97-shaped wmask.conf stage-1 SDF+radiance train step, 512 rays x (64+64) samples, "
                                "1xMI355X per rank", "rays_per_gpu": RAYS, "samples_per_ray": N_SAMPLES + N_IMPORTANCE,
-                   "parallelism": f"dp{world} (ray-sharded replicas, flat-bucket gradient all-reduce)"},
+                   "parallelism": f"dp{world} (ray-sharded replicas, flat-bucket gradient all-reduce)",
+                   "launch": "one hipGraph replay per step" if tr.use_graph and tr._graphs else "eager kernel launches"},
         "mfma_roofline_frac_step": value / world * FLOP_TRAIN_PER_SAMPLE / (PEAK_BF16_MFMA_TFLOPS * 1e12),
     }
 

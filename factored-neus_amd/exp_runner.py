@@ -32,7 +32,7 @@ from models.fields import NeRF                    # noqa: E402
 
 class Runner:
     def __init__(self, conf_path, mode="train", case="CASE_NAME", is_continue=False, type="dtu", surface_weight=0.1,
-                 device=None, prec=ops.PREC_PARITY, distributed=False):
+                 device=None, prec=ops.PREC_PARITY, distributed=False, use_graph=True):
         self.device = device or torch.device("cuda")
         self.conf_path = conf_path
         self.conf = hocon.parse_file(conf_path, case)
@@ -58,7 +58,8 @@ class Runner:
                                                                 "neus_renderer", "nerf")}
         self.trainer = Stage1Trainer(self.device, model_conf=model_conf, prec=prec, lr=self.learning_rate,
                                      igr_weight=self.igr_weight, mask_weight=self.mask_weight,
-                                     surface_weight=surface_weight, synthetic_init=False, distributed=distributed)
+                                     surface_weight=surface_weight, synthetic_init=False, distributed=distributed,
+                                     use_graph=use_graph and self.anneal_end == 0.0)   # constant cos_anneal_ratio only
         # the reference also constructs and checkpoints the background NeRF when n_outside == 0 (it is never evaluated then)
         self.nerf_outside = self.trainer.nerf_outside or NeRF(**dict(self.conf["model.nerf"])).to(self.device)
         self.iter_step = 0
@@ -81,8 +82,7 @@ class Runner:
             alpha = self.learning_rate_alpha
             progress = (self.iter_step - self.warm_up_end) / (self.end_iter - self.warm_up_end)
             factor = (np.cos(np.pi * progress) + 1.0) * 0.5 * (1 - alpha) + alpha
-        for g in self.trainer.optimizer.param_groups:
-            g["lr"] = self.learning_rate * factor
+        self.trainer.set_lr(self.learning_rate * factor)
 
     def train(self, max_steps=None, rank=0):
         self.update_learning_rate()
@@ -96,7 +96,7 @@ class Runner:
             if rank == 0 and self.iter_step % self.report_freq == 0:
                 print(self.base_exp_dir)
                 print("iter:{:8>d} loss = {} lr={}".format(self.iter_step, losses["loss"].item(),
-                                                           self.trainer.optimizer.param_groups[0]["lr"]))
+                                                           self.trainer.get_lr()))
             if rank == 0 and self.iter_step % self.save_freq == 0:
                 self.save_checkpoint()
             self.update_learning_rate()
@@ -173,13 +173,14 @@ def main():
     ap.add_argument("--idx", type=int, default=0)
     ap.add_argument("--prec", choices=["parity", "fast"], default="parity")
     ap.add_argument("--max_steps", type=int, default=None)
+    ap.add_argument("--no_graph", action="store_true", help="launch every kernel of the step eagerly (no hipGraph replay)")
     args = ap.parse_args()
     rank, world, local = init_from_env("nccl")
     gpu = local if world > 1 else args.gpu
     torch.cuda.set_device(gpu)
     runner = Runner(args.conf, args.mode, args.case, args.is_continue, args.type, args.surface_weight,
                     device=torch.device("cuda", gpu), prec=ops.PREC_PARITY if args.prec == "parity" else ops.PREC_FAST,
-                    distributed=world > 1)
+                    distributed=world > 1, use_graph=not args.no_graph)
     if args.mode == "train":
         runner.train(max_steps=args.max_steps, rank=rank)
     elif args.mode == "validate_mesh":

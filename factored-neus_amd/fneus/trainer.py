@@ -2,6 +2,11 @@
 
 Mirrors the body of the reference hot loop (exp_runner.py:131-181) without its per-step host synchronisations.
 Used by exp_runner.py and bench.py.
+
+With use_graph the whole step (about 20 fneus kernels and ~500 small PyTorch kernels of the RefColor head, the losses
+and the optimiser) is captured once into a hipGraph and replayed: every shape on the path is static (fixed ray batch,
+fixed-size sampler, no data-dependent indexing), and at ~6 ms per step the ~1.5 ms of launch gaps were the largest
+single item left outside the fused kernels.
 """
 from __future__ import annotations
 
@@ -27,7 +32,7 @@ WMASK_MODEL = {   # confs/wmask.conf:49-97
 class Stage1Trainer:
     def __init__(self, device, model_conf: Optional[dict] = None, prec: int = ops.PREC_PARITY, lr: float = 5e-4,
                  igr_weight: float = 0.1, mask_weight: float = 0.1, surface_weight: float = 0.1, seed: int = 0,
-                 synthetic_init: bool = True, distributed: bool = False):
+                 synthetic_init: bool = True, distributed: bool = False, use_graph: bool = False):
         from models.fields import SDFNetwork, RenderingNetwork, SingleVarianceNetwork, RefColor, NeRF
         from models.renderer import NeuSRenderer
         conf = model_conf or WMASK_MODEL
@@ -55,7 +60,15 @@ class Stage1Trainer:
         self.sdf_network.set_precision(prec)
         self.color_network.set_precision(prec)
         self.params = [p for m in self.modules for p in m.parameters()]
-        self.optimizer = torch.optim.Adam(self.params, lr=lr, fused=(device.type == "cuda"))
+        self.use_graph = bool(use_graph) and device.type == "cuda"
+        if self.use_graph:   # capturable Adam: step counters and the learning rate live on the device
+            self.optimizer = torch.optim.Adam(self.params, lr=torch.tensor(float(lr), device=device), fused=True,
+                                              capturable=True)
+        else:
+            self.optimizer = torch.optim.Adam(self.params, lr=lr, fused=(device.type == "cuda"))
+        self._graphs = {}            # (batch shape, cos_anneal_ratio) -> (CUDAGraph, static input, static losses)
+        self._eager_steps = 0
+        self.graph_warmup_steps = 2  # eager steps before the first capture (workspaces, job tables, LDS attributes)
         self.renderer = NeuSRenderer(**conf["neus_renderer"], nerf=self.nerf_outside, sdf_network=self.sdf_network,
                                      deviation_network=self.deviation_network, color_network=self.color_network,
                                      refColor_network=self.refColor_network)
@@ -63,8 +76,57 @@ class Stage1Trainer:
         self.bucket = FlatGradBucket(self.params) if distributed else None
         self.iter_step = 0
 
+    def set_lr(self, lr: float):
+        for g in self.optimizer.param_groups:
+            if torch.is_tensor(g["lr"]):
+                g["lr"].fill_(float(lr))
+            else:
+                g["lr"] = float(lr)
+
+    def get_lr(self) -> float:
+        lr = self.optimizer.param_groups[0]["lr"]
+        return float(lr.item()) if torch.is_tensor(lr) else float(lr)
+
     def train_step(self, data: torch.Tensor, cos_anneal_ratio: float = 1.0, background_rgb=None):
-        """data [B,10] = rays_o, rays_d, rgb, mask (dataset.py:133-151).  Returns the loss dict (device tensors)."""
+        """data [B,10] = rays_o, rays_d, rgb, mask (dataset.py:133-151).  Returns the loss dict (device tensors; with
+        use_graph they are static buffers that the next step overwrites)."""
+        if not self.use_graph or background_rgb is not None or ops.PROFILE is not None:
+            return self._eager_step(data, cos_anneal_ratio, background_rgb)
+        key = (tuple(data.shape), float(cos_anneal_ratio))
+        entry = self._graphs.get(key)
+        if entry is None:
+            if self._eager_steps < self.graph_warmup_steps or len(self._graphs) >= 4:
+                # (a cos_anneal_ratio that changes every step would mean one capture per step: stay eager)
+                return self._eager_step(data, cos_anneal_ratio, background_rgb)
+            entry = self._capture(data, float(cos_anneal_ratio))
+            self._graphs[key] = entry
+        graph, static_data, losses = entry
+        static_data.copy_(data)
+        graph.replay()
+        if self.bucket is not None:      # the collective and the (fused, few-launch) optimiser step stay outside
+            self.bucket.allreduce_mean()
+            self.optimizer.step()
+        self.iter_step += 1
+        return losses
+
+    def _capture(self, data: torch.Tensor, cos_anneal_ratio: float):
+        static_data = data.clone()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            losses = self._step_body(static_data, cos_anneal_ratio, None, with_optimizer=self.bucket is None)
+        return graph, static_data, losses
+
+    def _eager_step(self, data, cos_anneal_ratio, background_rgb):
+        losses = self._step_body(data, cos_anneal_ratio, background_rgb, with_optimizer=False)
+        if self.bucket is not None:
+            self.bucket.allreduce_mean()
+        self.optimizer.step()
+        self.iter_step += 1
+        self._eager_steps += 1
+        return losses
+
+    def _step_body(self, data, cos_anneal_ratio, background_rgb, with_optimizer: bool):
         rays_o, rays_d, true_rgb, mask = data[:, :3], data[:, 3:6], data[:, 6:9], data[:, 9:10]
         a = (rays_d ** 2).sum(-1, keepdim=True)                       # near_far_from_sphere, dataset.py:186-192
         b = 2.0 * (rays_o * rays_d).sum(-1, keepdim=True)
@@ -74,10 +136,8 @@ class Stage1Trainer:
         losses = stage1_loss(out, true_rgb, mask, self.igr_weight, self.mask_weight, self.surface_weight)
         self.zero_grad()
         losses["loss"].backward()
-        if self.bucket is not None:
-            self.bucket.allreduce_mean()
-        self.optimizer.step()
-        self.iter_step += 1
+        if with_optimizer:
+            self.optimizer.step()
         return losses
 
     def zero_grad(self):
