@@ -3,6 +3,13 @@
 //   K4 color_bwd : descending chain; returns d feature, d normal and writes the weight-gradient GEMM operands
 // Same wave-local MFMA engine as the SDF kernels.  K-slot order of layer 0: 256 feature slots, then the 33 "side"
 // inputs in the reference's column order (pts, PE(view), normal).
+//
+// The two MLPs of the surface head RefColor (fields.py:271-335) have the same shape -- 256 features + <= 33 side
+// inputs -> 4 x 256 ReLU -> <= 3 sigmoid outputs -- and run on the same kernels (template parameter VAR):
+//   VAR 1  net_cd               : [pts3 | PE4(n)27 | feature]           -> diffuse rgb (3)
+//   VAR 2  viewdir_mlp + net_cs : [n3 | pts3 | PE4(reflect(-d, n^))27 | feature] -> specular (1; rows 1,2 of the output
+//          tile are padding with zero weights)
+// They differ in how the side inputs are built and in how the side gradients map back to d normal.
 #include "mlp_engine.h"
 #include "fneus_kernels.h"
 
@@ -41,7 +48,58 @@ FN_DEV float acc_extract(const f32x16 (&acc)[TN], int h) {
     return v + xor32(v);
 }
 
-template <int PREC, bool TRAIN>
+enum { VAR_COLOR = 0, VAR_REF_DIFFUSE = 1, VAR_REF_SPECULAR = 2 };
+
+// n^ = n / max(|n|, sqrt(eps)) and the reflected view direction 2 (n^ . (-d)) n^ + d   (fields.py:277-283, 305-308)
+FN_DEV void reflect_dir(const float (&d)[3], const float (&nrm)[3], float (&nh)[3], float (&ref)[3], float& inv_len,
+                        float& s) {
+    const float eps = 1.1920928955078125e-07f;
+    const float len2 = fmaxf(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2], eps);
+    inv_len = 1.0f / sqrtf(len2);
+    s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        nh[c] = nrm[c] * inv_len;
+        s -= d[c] * nh[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ref[c] = 2.0f * s * nh[c] + d[c];
+}
+
+// the <= 33 inputs of layer 0 besides the feature vector, in the reference's column order
+template <int VAR>
+FN_DEV void make_side(const float (&x)[3], const float (&d)[3], const float (&nrm)[3], float (&side)[33]) {
+    float pe[27], jc[27];
+    if constexpr (VAR == VAR_COLOR) {             // pts | PE4(view) | normal
+        posenc<4, false>(d, pe, jc);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) side[c] = x[c];
+#pragma unroll
+        for (int f = 0; f < 27; ++f) side[3 + f] = pe[f];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) side[30 + c] = nrm[c];
+    } else if constexpr (VAR == VAR_REF_DIFFUSE) {  // pts | PE4(n)   (the raw normal is encoded, fields.py:306)
+        posenc<4, false>(nrm, pe, jc);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) side[c] = x[c];
+#pragma unroll
+        for (int f = 0; f < 27; ++f) side[3 + f] = pe[f];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) side[30 + c] = 0.0f;
+    } else {                                        // n | pts | PE4(reflected direction)
+        float nh[3], ref[3], inv_len, sdot;
+        reflect_dir(d, nrm, nh, ref, inv_len, sdot);
+        posenc<4, false>(ref, pe, jc);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) side[c] = nrm[c];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) side[3 + c] = x[c];
+#pragma unroll
+        for (int f = 0; f < 27; ++f) side[6 + f] = pe[f];
+    }
+}
+
+template <int PREC, bool TRAIN, int VAR>
 __global__ void __launch_bounds__(64, 1) color_fwd_kernel(const unsigned char* blob, PointSrc src, long N,
                                                           const float* __restrict__ dirs,      // [N][3] or nullptr (ray mode)
                                                           const float* __restrict__ normal,    // [N][3]
@@ -59,7 +117,7 @@ __global__ void __launch_bounds__(64, 1) color_fwd_kernel(const unsigned char* b
         const long n0 = tile * 32;
         float side[33];
         {
-            float x[3], d[3], pe[27], jc[27];
+            float x[3], d[3], nrm[3];
             load_point(src, nc, x);
             if (dirs) {
 #pragma unroll
@@ -69,17 +127,15 @@ __global__ void __launch_bounds__(64, 1) color_fwd_kernel(const unsigned char* b
 #pragma unroll
                 for (int c = 0; c < 3; ++c) d[c] = src.rays_d[ray * 3 + c];
             }
-            posenc<4, false>(d, pe, jc);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) side[c] = x[c];
-#pragma unroll
-            for (int f = 0; f < 27; ++f) side[3 + f] = pe[f];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) side[30 + c] = normal[nc * 3 + c];
+            for (int c = 0; c < 3; ++c) nrm[c] = normal[nc * 3 + c];
+            make_side<VAR>(x, d, nrm, side);
         }
         BFrag<PREC> bf[kMaxKS];
         f32x16 acc[8];
         load_f32<8>(acc, feat, 256, nc, h);
+        if constexpr (TRAIN && VAR != VAR_COLOR)   // the surface head keeps its own copy of the gathered features
+            store_stash<PREC, 8>(scr, lane, acc, st.feat_hi, st.feat_lo, 256, n0, N, 256);
         acc_to_bfrag<PREC, 8>(acc, bf);
         vec_to_bfrag<PREC, 33, 3, 16>(side, bf, h);
         if constexpr (TRAIN) {
@@ -132,12 +188,15 @@ __global__ void __launch_bounds__(64, 1) color_fwd_kernel(const unsigned char* b
     }
 }
 
-template <int PREC>
+template <int PREC, int VAR>
 __global__ void __launch_bounds__(64, 1) color_bwd_kernel(const unsigned char* blob, long N,
                                                           const float* __restrict__ d_rgb,   // [N][3]
                                                           const float* __restrict__ rgb,     // [N][3] forward output
                                                           ColStash st, float* __restrict__ d_feat /*[N][256]*/,
-                                                          float* __restrict__ d_normal /*[N][3]*/) {
+                                                          float* __restrict__ d_normal /*[N][3]*/,
+                                                          // surface head only: the inputs the side vector was built from
+                                                          const float* __restrict__ normal, const float* __restrict__ dirs,
+                                                          const float* __restrict__ rays_d, int m) {
     __shared__ __attribute__((aligned(16))) unsigned char scr[kWaveScr];
     const int lane = threadIdx.x;
     const int r = lane & 31, h = lane >> 5;
@@ -191,13 +250,68 @@ __global__ void __launch_bounds__(64, 1) color_bwd_kernel(const unsigned char* b
         zero_acc(acc);
         dense<PREC, 16, 10, 0, 10>(blob, LY.L[0].rev_hi, LY.L[0].rev_lo, bf, acc, lane);
         store_f32<8>(a8, d_feat, 256, nc, h, valid);
-        {
-            f32x16(&s2)[2] = reinterpret_cast<f32x16(&)[2]>(acc[8]);
+        f32x16(&s2)[2] = reinterpret_cast<f32x16(&)[2]>(acc[8]);      // gradient of the 33 side inputs
+        if constexpr (VAR == VAR_COLOR) {
             const float g0 = acc_extract<2, 30>(s2, h), g1 = acc_extract<2, 31>(s2, h), g2 = acc_extract<2, 32>(s2, h);
             if (valid && lane < 32) {
                 d_normal[n * 3 + 0] = g0;
                 d_normal[n * 3 + 1] = g1;
                 d_normal[n * 3 + 2] = g2;
+            }
+        } else {
+            float nrm[3], d[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) nrm[c] = normal[nc * 3 + c];
+            if (dirs) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) d[c] = dirs[nc * 3 + c];
+            } else {
+                const long ray = nc / m;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) d[c] = rays_d[ray * 3 + c];
+            }
+            float pe[27], jc[27], dn[3];
+            if constexpr (VAR == VAR_REF_DIFFUSE) {    // side = pts | PE4(n):  d n = J_PE(n)^T g[3..29]
+                posenc<4, true>(nrm, pe, jc);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float coef[33];
+#pragma unroll
+                    for (int f = 0; f < 33; ++f) coef[f] = (f >= 3 && f < 30 && ((f - 3) % 3) == c) ? jc[f - 3] : 0.0f;
+                    const float part = acc_dot_partial<2, 33>(s2, coef, h);
+                    dn[c] = part + xor32(part);
+                }
+            } else {                                   // side = n | pts | PE4(ref),  ref = 2 (n^ . -d) n^ + d
+                float nh[3], ref[3], inv_len, sdot, dref[3], gdir[3];
+                reflect_dir(d, nrm, nh, ref, inv_len, sdot);
+                posenc<4, true>(ref, pe, jc);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float coef[33], one[33];
+#pragma unroll
+                    for (int f = 0; f < 33; ++f) {
+                        coef[f] = (f >= 6 && ((f - 6) % 3) == c) ? jc[f - 6] : 0.0f;
+                        one[f] = (f == c) ? 1.0f : 0.0f;
+                    }
+                    const float p1 = acc_dot_partial<2, 33>(s2, coef, h);
+                    const float p2 = acc_dot_partial<2, 33>(s2, one, h);
+                    dref[c] = p1 + xor32(p1);
+                    gdir[c] = p2 + xor32(p2);
+                }
+                // d n^_j = 2 s dref_j - 2 d_j (dref . n^);  n^ = n / |n|  ->  d n = (d n^ - n^ (n^ . d n^)) / |n|
+                const float dr_n = dref[0] * nh[0] + dref[1] * nh[1] + dref[2] * nh[2];
+                float dnh[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) dnh[c] = 2.0f * sdot * dref[c] - 2.0f * d[c] * dr_n;
+                const float proj = dnh[0] * nh[0] + dnh[1] * nh[1] + dnh[2] * nh[2];
+                const float eps = 1.1920928955078125e-07f;
+                const bool clamped = (nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]) < eps;   // torch.clamp: zero slope
+#pragma unroll
+                for (int c = 0; c < 3; ++c) dn[c] = gdir[c] + (clamped ? dnh[c] : dnh[c] - nh[c] * proj) * inv_len;
+            }
+            if (valid && lane < 32) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) d_normal[n * 3 + c] = dn[c];
             }
         }
     }
@@ -215,48 +329,87 @@ static inline int grid_for(long n_tiles) {
     return (int)g;
 }
 
-extern "C" int fneus_color_fwd(const void* blob, const float* pts, const float* rays_o, const float* rays_d,
-                               const float* t, int m, long n_pts, const float* dirs, const float* normal,
-                               const float* feat, const FneusColStash* stash, float* rgb_out, int prec, int train,
-                               fneus_stream_t stream_) {
+template <int VAR>
+static int launch_fwd(const void* blob, const float* pts, const float* rays_o, const float* rays_d, const float* t, int m,
+                      long n_pts, const float* dirs, const float* normal, const float* feat, const FneusColStash* stash,
+                      float* out, int prec, int train, fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    fneus::clear_status();
     fneus::clear_status();
     if (n_pts <= 0) return 0;
     PointSrc src{pts, rays_o, rays_d, t, m > 0 ? m : 1};
     if (!pts && !rays_d) return -2;
     if (pts && !dirs && !rays_d) return -2;
+    if (train && !stash) return -2;
     const unsigned char* b = reinterpret_cast<const unsigned char*>(blob);
     ColStash st = stash ? ColStash(*stash) : ColStash();
+    if (train && VAR != VAR_COLOR && !st.feat_hi) return -2;
     dim3 grid(grid_for((n_pts + 31) / 32)), blk(64);
     if (prec == 3 && train)
-        hipLaunchKernelGGL((color_fwd_kernel<3, true>), grid, blk, 0, stream, b, src, n_pts, dirs, normal, feat, st, rgb_out);
+        hipLaunchKernelGGL((color_fwd_kernel<3, true, VAR>), grid, blk, 0, stream, b, src, n_pts, dirs, normal, feat, st, out);
     else if (prec == 3)
-        hipLaunchKernelGGL((color_fwd_kernel<3, false>), grid, blk, 0, stream, b, src, n_pts, dirs, normal, feat, st, rgb_out);
+        hipLaunchKernelGGL((color_fwd_kernel<3, false, VAR>), grid, blk, 0, stream, b, src, n_pts, dirs, normal, feat, st, out);
     else if (prec == 1 && train)
-        hipLaunchKernelGGL((color_fwd_kernel<1, true>), grid, blk, 0, stream, b, src, n_pts, dirs, normal, feat, st, rgb_out);
+        hipLaunchKernelGGL((color_fwd_kernel<1, true, VAR>), grid, blk, 0, stream, b, src, n_pts, dirs, normal, feat, st, out);
     else if (prec == 1)
-        hipLaunchKernelGGL((color_fwd_kernel<1, false>), grid, blk, 0, stream, b, src, n_pts, dirs, normal, feat, st, rgb_out);
+        hipLaunchKernelGGL((color_fwd_kernel<1, false, VAR>), grid, blk, 0, stream, b, src, n_pts, dirs, normal, feat, st, out);
     else
         return -2;
     return fneus::launch_status();
 }
 
-extern "C" int fneus_color_bwd(const void* blob, long n_pts, const float* d_rgb, const float* rgb,
-                               const FneusColStash* stash, float* d_feat, float* d_normal, int prec,
-                               fneus_stream_t stream_) {
+template <int VAR>
+static int launch_bwd(const void* blob, long n_pts, const float* d_out, const float* out, const FneusColStash* stash,
+                      float* d_feat, float* d_normal, const float* normal, const float* dirs, const float* rays_d, int m,
+                      int prec, fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     fneus::clear_status();
-    fneus::clear_status();
     if (n_pts <= 0) return 0;
+    if (!stash) return -2;
+    if (VAR != VAR_COLOR && (!normal || (!dirs && !rays_d))) return -2;
     const unsigned char* b = reinterpret_cast<const unsigned char*>(blob);
     ColStash st(*stash);
     dim3 grid(grid_for((n_pts + 31) / 32)), blk(64);
     if (prec == 3)
-        hipLaunchKernelGGL(color_bwd_kernel<3>, grid, blk, 0, stream, b, n_pts, d_rgb, rgb, st, d_feat, d_normal);
+        hipLaunchKernelGGL((color_bwd_kernel<3, VAR>), grid, blk, 0, stream, b, n_pts, d_out, out, st, d_feat, d_normal,
+                           normal, dirs, rays_d, m > 0 ? m : 1);
     else if (prec == 1)
-        hipLaunchKernelGGL(color_bwd_kernel<1>, grid, blk, 0, stream, b, n_pts, d_rgb, rgb, st, d_feat, d_normal);
+        hipLaunchKernelGGL((color_bwd_kernel<1, VAR>), grid, blk, 0, stream, b, n_pts, d_out, out, st, d_feat, d_normal,
+                           normal, dirs, rays_d, m > 0 ? m : 1);
     else
         return -2;
     return fneus::launch_status();
+}
+
+extern "C" int fneus_color_fwd(const void* blob, const float* pts, const float* rays_o, const float* rays_d,
+                               const float* t, int m, long n_pts, const float* dirs, const float* normal,
+                               const float* feat, const FneusColStash* stash, float* rgb_out, int prec, int train,
+                               fneus_stream_t stream) {
+    return launch_fwd<VAR_COLOR>(blob, pts, rays_o, rays_d, t, m, n_pts, dirs, normal, feat, stash, rgb_out, prec, train, stream);
+}
+
+extern "C" int fneus_color_bwd(const void* blob, long n_pts, const float* d_rgb, const float* rgb,
+                               const FneusColStash* stash, float* d_feat, float* d_normal, int prec,
+                               fneus_stream_t stream) {
+    return launch_bwd<VAR_COLOR>(blob, n_pts, d_rgb, rgb, stash, d_feat, d_normal, nullptr, nullptr, nullptr, 1, prec, stream);
+}
+
+extern "C" int fneus_refcolor_fwd(const void* blob, int head, const float* pts, const float* rays_o, const float* rays_d,
+                                  const float* t, int m, long n_pts, const float* dirs, const float* normal,
+                                  const float* feat, const FneusColStash* stash, float* out, int prec, int train,
+                                  fneus_stream_t stream) {
+    if (head == VAR_REF_DIFFUSE)
+        return launch_fwd<VAR_REF_DIFFUSE>(blob, pts, rays_o, rays_d, t, m, n_pts, dirs, normal, feat, stash, out, prec, train, stream);
+    if (head == VAR_REF_SPECULAR)
+        return launch_fwd<VAR_REF_SPECULAR>(blob, pts, rays_o, rays_d, t, m, n_pts, dirs, normal, feat, stash, out, prec, train, stream);
+    return -2;
+}
+
+extern "C" int fneus_refcolor_bwd(const void* blob, int head, long n_pts, const float* rays_d, int m, const float* dirs,
+                                  const float* normal, const float* d_out, const float* out, const FneusColStash* stash,
+                                  float* d_feat, float* d_normal, int prec, fneus_stream_t stream) {
+    if (head == VAR_REF_DIFFUSE)
+        return launch_bwd<VAR_REF_DIFFUSE>(blob, n_pts, d_out, out, stash, d_feat, d_normal, normal, dirs, rays_d, m, prec, stream);
+    if (head == VAR_REF_SPECULAR)
+        return launch_bwd<VAR_REF_SPECULAR>(blob, n_pts, d_out, out, stash, d_feat, d_normal, normal, dirs, rays_d, m, prec, stream);
+    return -2;
 }

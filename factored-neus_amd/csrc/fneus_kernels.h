@@ -45,11 +45,13 @@ struct ColStash {
     __bf16* u_hi;    __bf16* u_lo;      // [4][N][256]  slot l = relu output of layer l (= input of l+1)
     __bf16* zbar_hi; __bf16* zbar_lo;   // [5][N][256]  slot l = dL/dz_l (slot 4 uses 32-wide rows)
     u32x4* mask;                        // lane-private ReLU masks: [tiles][4][64] x 128 bits
+    __bf16* feat_hi; __bf16* feat_lo;   // [N][256]     surface head only: its (gathered) input features
     ColStash() : side_hi(nullptr), side_lo(nullptr), u_hi(nullptr), u_lo(nullptr), zbar_hi(nullptr), zbar_lo(nullptr),
-                 mask(nullptr) {}
+                 mask(nullptr), feat_hi(nullptr), feat_lo(nullptr) {}
     ColStash(const FneusColStash& s)
         : side_hi((__bf16*)s.side_hi), side_lo((__bf16*)s.side_lo), u_hi((__bf16*)s.u_hi), u_lo((__bf16*)s.u_lo),
-          zbar_hi((__bf16*)s.zbar_hi), zbar_lo((__bf16*)s.zbar_lo), mask((u32x4*)s.mask) {}
+          zbar_hi((__bf16*)s.zbar_hi), zbar_lo((__bf16*)s.zbar_lo), mask((u32x4*)s.mask), feat_hi((__bf16*)s.feat_hi),
+          feat_lo((__bf16*)s.feat_lo) {}
 };
 
 FN_DEV void load_point(const PointSrc& s, long n, float (&x)[3]) {

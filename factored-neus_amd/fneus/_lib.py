@@ -30,7 +30,7 @@ class FneusSdfBwdBufs(C.Structure):
 
 class FneusColStash(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
-                ("side_hi", "side_lo", "u_hi", "u_lo", "zbar_hi", "zbar_lo", "mask")]
+                ("side_hi", "side_lo", "u_hi", "u_lo", "zbar_hi", "zbar_lo", "mask", "feat_hi", "feat_lo")]
 
 
 class FneusGemmJob(C.Structure):
@@ -64,6 +64,8 @@ def _load():
                                     vp, vp, vp, ip, vp]),
         "fneus_color_fwd": (C.c_int, [vp, vp, vp, vp, vp, ip, l, vp, vp, vp, C.POINTER(FneusColStash), vp, ip, ip, vp]),
         "fneus_color_bwd": (C.c_int, [vp, l, vp, vp, C.POINTER(FneusColStash), vp, vp, ip, vp]),
+        "fneus_refcolor_fwd": (C.c_int, [vp, ip, vp, vp, vp, vp, ip, l, vp, vp, vp, C.POINTER(FneusColStash), vp, ip, ip, vp]),
+        "fneus_refcolor_bwd": (C.c_int, [vp, ip, l, vp, ip, vp, vp, vp, vp, C.POINTER(FneusColStash), vp, vp, ip, vp]),
         "fneus_dw_gemm": (C.c_int, [vp, ip, ip, l, ip, vp]),
         "fneus_upsample": (C.c_int, [vp, vp, vp, vp, ip, ip, ip, f, vp, vp]),
         "fneus_merge": (C.c_int, [vp, vp, ip, vp, vp, ip, ip, vp, vp, vp]),

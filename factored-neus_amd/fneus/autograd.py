@@ -66,31 +66,43 @@ class SdfValueGradFn(torch.autograd.Function):
 
 
 class ColorFn(torch.autograd.Function):
-    """K4 forward / backward (+ weight-gradient GEMM).  Differentiable inputs: flat params, normal, feature."""
+    """K4 forward / backward (+ weight-gradient GEMM) of a colour-shaped MLP: the colour network (head 0, features
+    stashed by the SDF kernel) or one of the two RefColor MLPs (head 1 / 2, features stashed by the kernel itself).
+    Differentiable inputs: normal, feature; parameter gradients are accumulated into the network's flat buffer."""
 
     @staticmethod
     def forward(ctx, anchor, normal, feat, net, samples: RaySamples, prec: int, ws: _Workspace, sdf_ws: _Workspace,
-                train: bool):
+                train: bool, head: int = 0):
         n = samples.n
-        stash = ws.get(("col_stash", n, prec), lambda: ops.ColStash(n, anchor.device, prec)) if train else None
-        rgb = ops.color_fwd(net.blob, n, prec, normal.contiguous(), feat.contiguous(), stash, train, dirs=samples.dirs,
-                            **samples.kw())
-        ctx.net, ctx.prec, ctx.ws, ctx.sdf_ws, ctx.stash, ctx.n = net, prec, ws, sdf_ws, stash, n
-        ctx.save_for_backward(rgb)
+        normal, feat = normal.contiguous(), feat.contiguous()
+        stash = ws.get(("col_stash", n, prec), lambda: ops.ColStash(n, anchor.device, prec, with_feat=head != 0)) if train else None
+        rgb = ops.color_fwd(net.blob, n, prec, normal, feat, stash, train, dirs=samples.dirs, head=head, **samples.kw())
+        ctx.net, ctx.prec, ctx.ws, ctx.sdf_ws, ctx.stash, ctx.n, ctx.head, ctx.samples = net, prec, ws, sdf_ws, stash, n, head, samples
+        if head != 0:
+            ctx.save_for_backward(rgb, normal)
+        else:
+            ctx.save_for_backward(rgb)
         return rgb
 
     @staticmethod
     def backward(ctx, d_rgb):
-        (rgb,) = ctx.saved_tensors
-        n, prec, net, ws = ctx.n, ctx.prec, ctx.net, ctx.ws
-        d_feat, d_normal = ops.color_bwd(net.blob, n, prec, d_rgb.contiguous(), rgb, ctx.stash)
+        n, prec, net, ws, head = ctx.n, ctx.prec, ctx.net, ctx.ws, ctx.head
+        if head != 0:
+            rgb, normal = ctx.saved_tensors
+            sm = ctx.samples
+            d_feat, d_normal = ops.color_bwd(net.blob, n, prec, d_rgb.contiguous(), rgb, ctx.stash, head=head, normal=normal,
+                                             dirs=sm.dirs, rays_d=sm.rays_d, m=sm.m)
+            feat_planes = ctx.stash.feat
+        else:
+            (rgb,) = ctx.saved_tensors
+            d_feat, d_normal = ops.color_bwd(net.blob, n, prec, d_rgb.contiguous(), rgb, ctx.stash)
+            feat_planes = ctx.sdf_ws.cache[("sdf_stash", n, prec, True)].feat
         grad = ws.get(("col_grad", n), lambda: torch.empty(net.n_params, dtype=torch.float32, device=rgb.device))
         grad.zero_()
-        sdf_stash = ctx.sdf_ws.cache[("sdf_stash", n, prec, True)]
-        jobs = ws.get(("col_jobs", n, prec), lambda: ops.color_dw_jobs(net, sdf_stash, ctx.stash, grad, n))
+        jobs = ws.get(("col_jobs", n, prec), lambda: ops.color_dw_jobs(net, feat_planes, ctx.stash, grad, n))
         jobs.run(n, prec)
         net.wn_backward(grad)
-        return None, d_normal, d_feat, None, None, None, None, None, None
+        return None, d_normal, d_feat, None, None, None, None, None, None, None
 
 
 class CompositeFn(torch.autograd.Function):

@@ -67,27 +67,34 @@ def query_layout(which: int) -> Layout:
     return Layout(L, int(a[1]), int(a[2]), per[:, :5].copy(), per[:, 5:].copy())
 
 
-def raw_offsets(ins, outs):
-    """Raw (module) parameter layout, state_dict order per layer: bias[out], weight_g[out], weight_v[out][in]."""
+NO_G = 0xFFFFFFFF      # RowInfo.off_g of a plain nn.Linear row (csrc/fneus_pack.h)
+
+
+def raw_offsets(ins, outs, weight_norm=True):
+    """Raw (module) parameter layout per layer: bias[out], weight_g[out] (weight-normalised layers only),
+    weight_v / weight [out][in]."""
     offB, offG, offV, o = [], [], [], 0
     for i, k in zip(ins, outs):
         offB.append(o)
         o += k
-        offG.append(o)
-        o += k
+        if weight_norm:
+            offG.append(o)
+            o += k
+        else:
+            offG.append(None)
         offV.append(o)
         o += i * k
     return offB, offG, offV, o
 
 
-def row_table(ins, outs, offW_eff):
-    """RowInfo per weight-normalised output row + the first row index of each layer"""
-    offB, offG, offV, _ = raw_offsets(ins, outs)
+def row_table(ins, outs, offW_eff, weight_norm=True):
+    """RowInfo per output row + the first row index of each layer"""
+    offB, offG, offV, _ = raw_offsets(ins, outs, weight_norm)
     rows, base = [], []
     for l, (i, k) in enumerate(zip(ins, outs)):
         base.append(len(rows))
         for r in range(k):
-            rows.append((offV[l] + r * i, offG[l] + r, i, offW_eff[l] + r * i))
+            rows.append((offV[l] + r * i, offG[l] + r if weight_norm else NO_G, i, offW_eff[l] + r * i))
     return np.array(rows, dtype=ROW_DTYPE), base
 
 
@@ -187,11 +194,18 @@ def build_sdf_jobs():
             "rows": row_tab, "bias_segs": segs}
 
 
-def build_color_jobs():
+# the two MLPs of the surface head RefColor (reference models/fields.py:285-301): colour-network geometry, plain Linear
+REFCD_IN, REFCD_OUT, REFCD_SIDE = [286, 256, 256, 256, 256], [256, 256, 256, 256, 3], 30    # net_cd: pts | PE4(n) | feat
+REFVD_IN, REFVD_OUT, REFVD_SIDE = [289, 256, 256, 256, 256], [256, 256, 256, 256, 1], 33    # viewdir_mlp + net_cs
+
+
+def build_color_jobs(COL_IN=COL_IN, COL_OUT=COL_OUT, N_SIDE=N_SIDE, weight_norm=True):
+    """Pack tables of a colour-shaped MLP: layer 0 takes N_SIDE side inputs (reference columns 0..N_SIDE-1) followed by
+    the 256 features; the kernels keep the features in the first 16 k-steps and the side inputs in the last 3."""
     ly = query_layout(1)
     offW, offb, total = flat_offsets(COL_IN, COL_OUT)
-    offB, offG, offV, total_raw = raw_offsets(COL_IN, COL_OUT)
-    row_tab, rbase = row_table(COL_IN, COL_OUT, offW)
+    offB, offG, offV, total_raw = raw_offsets(COL_IN, COL_OUT, weight_norm)
+    row_tab, rbase = row_table(COL_IN, COL_OUT, offW, weight_norm)
     b = _Builder()
     for l in range(5):
         ksf, ntf, ksr, ntr = [int(v) for v in ly.geom[l]]
@@ -216,5 +230,13 @@ def build_color_jobs():
     segs = np.array([(offb[l], offB[l], COL_OUT[l], 0) for l in range(5)], dtype=np.int32)
     return {"layout": ly, "jobs": jobs, "maps": maps, "units": units, "n_params": total, "offW": offW, "offb": offb,
             "ins": COL_IN, "outs": COL_OUT, "n_raw": total_raw, "offB": offB, "offG": offG, "offV": offV,
-            "rows": row_tab, "bias_segs": segs}
+            "rows": row_tab, "bias_segs": segs, "n_side": N_SIDE, "weight_norm": weight_norm}
+
+
+def build_refcd_jobs():
+    return build_color_jobs(REFCD_IN, REFCD_OUT, REFCD_SIDE, weight_norm=False)
+
+
+def build_refvd_jobs():
+    return build_color_jobs(REFVD_IN, REFVD_OUT, REFVD_SIDE, weight_norm=False)
 

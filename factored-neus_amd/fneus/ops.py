@@ -66,7 +66,8 @@ class PackedNet:
     torch element-wise kernels."""
 
     def __init__(self, kind: str, device):
-        builders = {"sdf": netdesc.build_sdf_jobs, "color": netdesc.build_color_jobs}
+        builders = {"sdf": netdesc.build_sdf_jobs, "color": netdesc.build_color_jobs,
+                    "refcd": netdesc.build_refcd_jobs, "refvd": netdesc.build_refvd_jobs}
         desc = builders[kind]()
         self.kind, self.desc, self.device = kind, desc, device
         self.layout = desc["layout"]
@@ -90,17 +91,24 @@ class PackedNet:
         d = self.desc
         out = []
         for l, (i, o) in enumerate(zip(d["ins"], d["outs"])):
-            out.append({"bias": buf[d["offB"][l]: d["offB"][l] + o],
-                        "weight_g": buf[d["offG"][l]: d["offG"][l] + o].view(o, 1),
-                        "weight_v": buf[d["offV"][l]: d["offV"][l] + o * i].view(o, i)})
+            if d.get("weight_norm", True):
+                out.append({"bias": buf[d["offB"][l]: d["offB"][l] + o],
+                            "weight_g": buf[d["offG"][l]: d["offG"][l] + o].view(o, 1),
+                            "weight_v": buf[d["offV"][l]: d["offV"][l] + o * i].view(o, i)})
+            else:       # plain nn.Linear
+                out.append({"bias": buf[d["offB"][l]: d["offB"][l] + o],
+                            "weight": buf[d["offV"][l]: d["offV"][l] + o * i].view(o, i)})
         return out
 
     def set_raw_from_effective(self, Ws, bs):
         """test helper: load effective weights as (g = ||W||, v = W)"""
         for view, W, b in zip(self.raw_views(self.raw), Ws, bs):
             view["bias"].copy_(b)
-            view["weight_v"].copy_(W)
-            view["weight_g"].copy_(W.norm(dim=1, keepdim=True))
+            if "weight" in view:
+                view["weight"].copy_(W)
+            else:
+                view["weight_v"].copy_(W)
+                view["weight_g"].copy_(W.norm(dim=1, keepdim=True))
 
     def split_flat(self, flat: torch.Tensor):
         Ws, bs = [], []
@@ -200,16 +208,19 @@ class SdfBwdBufs:
 
 
 class ColStash:
-    def __init__(self, n: int, device, prec: int):
+    def __init__(self, n: int, device, prec: int, with_feat: bool = False):
         bf = torch.bfloat16
         planes = 2 if prec == 3 else 1
+        self.feat = torch.empty((planes, n, 256), dtype=bf, device=device) if with_feat else None
         self.side = torch.zeros((planes, n, 48), dtype=bf, device=device)
         self.u = torch.empty((planes, 4, n, 256), dtype=bf, device=device)
         self.zbar = torch.zeros((planes, 5, n, 256), dtype=bf, device=device)
         self.mask = torch.zeros((((n + 31) // 32 + 3) // 4 * 4) * 4 * 64 * 4, dtype=torch.int32, device=device)
         s = _lib.FneusColStash()
         s.mask = self.mask.data_ptr()
-        for name, t in (("side", self.side), ("u", self.u), ("zbar", self.zbar)):
+        for name, t in (("side", self.side), ("u", self.u), ("zbar", self.zbar), ("feat", self.feat)):
+            if t is None:
+                continue
             setattr(s, name + "_hi", t[0].data_ptr())
             setattr(s, name + "_lo", t[1].data_ptr() if planes == 2 else None)
         self.c = s
@@ -223,23 +234,37 @@ def sdf_bwd(blob, n_pts, prec, stash: SdfStash, bufs: SdfBwdBufs, d_sdf, d_feat,
                             C.byref(bufs.c), _ptr(d_sdf), _ptr(d_feat), _ptr(d_normal), prec, _stream())
 
 
+HEAD_COLOR, HEAD_REF_DIFFUSE, HEAD_REF_SPECULAR = 0, 1, 2     # csrc/color_kernels.hip VAR_*
+
+
 def color_fwd(blob, n_pts, prec, normal, feat, stash: Optional[ColStash], train: bool, pts=None, rays_o=None,
-              rays_d=None, t=None, m: int = 1, dirs=None):
+              rays_d=None, t=None, m: int = 1, dirs=None, head: int = HEAD_COLOR):
+    """colour network (head 0) or one of the two RefColor MLPs (head 1: diffuse rgb, head 2: specular in column 0)"""
     _chk_f32(normal, "normal")
     _chk_f32(feat, "feat")
     rgb = torch.empty(n_pts, 3, dtype=torch.float32, device=blob.device)
-    _launch("fneus_color_fwd", lib.fneus_color_fwd, _ptr(blob), _ptr(pts), _ptr(rays_o), _ptr(rays_d), _ptr(t), m, n_pts, _ptr(dirs),
-                              _ptr(normal), _ptr(feat), C.byref(stash.c) if stash is not None else None, _ptr(rgb),
-                              prec, int(train), _stream())
+    sp = C.byref(stash.c) if stash is not None else None
+    if head == HEAD_COLOR:
+        _launch("fneus_color_fwd", lib.fneus_color_fwd, _ptr(blob), _ptr(pts), _ptr(rays_o), _ptr(rays_d), _ptr(t), m, n_pts,
+                _ptr(dirs), _ptr(normal), _ptr(feat), sp, _ptr(rgb), prec, int(train), _stream())
+    else:
+        _launch("fneus_refcolor_fwd", lib.fneus_refcolor_fwd, _ptr(blob), head, _ptr(pts), _ptr(rays_o), _ptr(rays_d), _ptr(t),
+                m, n_pts, _ptr(dirs), _ptr(normal), _ptr(feat), sp, _ptr(rgb), prec, int(train), _stream())
     return rgb
 
 
-def color_bwd(blob, n_pts, prec, d_rgb, rgb, stash: ColStash):
+def color_bwd(blob, n_pts, prec, d_rgb, rgb, stash: ColStash, head: int = HEAD_COLOR, normal=None, dirs=None, rays_d=None,
+              m: int = 1):
     _chk_f32(d_rgb, "d_rgb")
     d_feat = torch.empty(n_pts, 256, dtype=torch.float32, device=blob.device)
     d_normal = torch.empty(n_pts, 3, dtype=torch.float32, device=blob.device)
-    _launch("fneus_color_bwd", lib.fneus_color_bwd, _ptr(blob), n_pts, _ptr(d_rgb), _ptr(rgb), C.byref(stash.c), _ptr(d_feat),
-                              _ptr(d_normal), prec, _stream())
+    if head == HEAD_COLOR:
+        _launch("fneus_color_bwd", lib.fneus_color_bwd, _ptr(blob), n_pts, _ptr(d_rgb), _ptr(rgb), C.byref(stash.c),
+                _ptr(d_feat), _ptr(d_normal), prec, _stream())
+    else:
+        _chk_f32(normal, "normal")
+        _launch("fneus_refcolor_bwd", lib.fneus_refcolor_bwd, _ptr(blob), head, n_pts, _ptr(rays_d), m, _ptr(dirs), _ptr(normal),
+                _ptr(d_rgb), _ptr(rgb), C.byref(stash.c), _ptr(d_feat), _ptr(d_normal), prec, _stream())
     return d_feat, d_normal
 
 
@@ -317,18 +342,20 @@ def sdf_dw_jobs(net: PackedNet, stash: SdfStash, bufs: SdfBwdBufs, grad_flat: to
     return g.finalize()
 
 
-def color_dw_jobs(net: PackedNet, sdf_stash: SdfStash, stash: ColStash, grad_flat: torch.Tensor, n: int) -> GemmJobs:
-    g = GemmJobs(grad_flat.device, "color")
+def color_dw_jobs(net: PackedNet, feat_planes: torch.Tensor, stash: ColStash, grad_flat: torch.Tensor, n: int) -> GemmJobs:
+    """dW of a colour-shaped MLP (colour network: feat_planes = SdfStash.feat; RefColor heads: their own ColStash.feat)"""
+    g = GemmJobs(grad_flat.device, net.kind)
     offW, offb = net.desc["offW"], net.desc["offb"]
+    n_side, ld0, n_out = net.desc["n_side"], net.desc["ins"][0], net.desc["outs"][4]
     base = grad_flat.data_ptr()
-    # layer 0: columns 0..32 = side inputs, 33..288 = feature
-    g.add(stash.zbar[:, 0], sdf_stash.feat, base + 4 * (offW[0] + 33), 289, 256, 256, 256, 256, 256, 256,
+    # layer 0: columns 0..n_side-1 = side inputs, then the 256 features
+    g.add(stash.zbar[:, 0], feat_planes, base + 4 * (offW[0] + n_side), ld0, 256, 256, 256, 256, 256, 256,
           bias_ptr=base + 4 * offb[0])
-    g.add(stash.zbar[:, 0], stash.side, base + 4 * offW[0], 289, 256, 33, 256, 48, 256, 48)
+    g.add(stash.zbar[:, 0], stash.side, base + 4 * offW[0], ld0, 256, n_side, 256, 48, 256, 48)
     for l in (1, 2, 3):
         g.add(stash.zbar[:, l], stash.u[:, l - 1], base + 4 * offW[l], 256, 256, 256, 256, 256, 256, 256,
               bias_ptr=base + 4 * offb[l])
-    g.add(stash.zbar[:, 4], stash.u[:, 3], base + 4 * offW[4], 256, 3, 256, 32, 256, 32, 256,
+    g.add(stash.zbar[:, 4], stash.u[:, 3], base + 4 * offW[4], 256, n_out, 256, 32, 256, 32, 256,
           bias_ptr=base + 4 * offb[4])
     return g.finalize()
 

@@ -59,6 +59,7 @@ class Stage1Trainer:
             m.to(device)
         self.sdf_network.set_precision(prec)
         self.color_network.set_precision(prec)
+        self.refColor_network.set_precision(prec)
         self.params = [p for m in self.modules for p in m.parameters()]
         self.use_graph = bool(use_graph) and device.type == "cuda"
         if self.use_graph:   # capturable Adam: step counters and the learning rate live on the device
@@ -141,11 +142,13 @@ class Stage1Trainer:
         return losses
 
     def zero_grad(self):
-        """two memsets for the fused MLPs (their .grad alias flat buffers), set_to_none for the small torch modules"""
+        """one memset per fused MLP (their .grad alias flat buffers), set_to_none for the small torch modules"""
         for net in (self.sdf_network, self.color_network):
             if net._net is not None:
                 net._net.raw_grad.zero_()
-        for m in (self.deviation_network, self.refColor_network, self.nerf_outside):
+        for g in self.refColor_network.flat_grads():
+            g.zero_()
+        for m in (self.deviation_network, self.nerf_outside):
             if m is not None:
                 for p in m.parameters():
                     p.grad = None

@@ -4,7 +4,8 @@
       (lin{l}.weight_g / weight_v / bias: old-style nn.utils.weight_norm, fields.py:67-70, 139-140) so checkpoints
       interchange; the maths runs in libfneus_hip.so.  Only the architecture of confs/wmask.conf / womask.conf is
       supported by the fused kernels -- anything else raises (there is no fallback path).
-  SingleVarianceNetwork, RefColor, NeRF : small torch modules (scalar / <= 2 samples per ray / womask background).
+  RefColor : the surface head; its two MLPs run on the colour-network kernels (plain Linear layers).
+  SingleVarianceNetwork, NeRF : small torch modules (a scalar / the womask background).
 """
 from __future__ import annotations
 
@@ -240,9 +241,61 @@ def _linear_to_srgb(linear):
     return torch.where(linear <= 0.0031308, srgb0, srgb1)
 
 
+class _PlainBackend:
+    """Device backend of one RefColor MLP: five plain nn.Linear layers whose weight / bias (and their .grad) are
+    aliased onto the flat buffers of a PackedNet, exactly like _HipMLP does for the weight-normalised networks."""
+
+    def __init__(self, kind: str, layers):
+        self.kind, self.layers = kind, list(layers)
+        self.net = None
+        self.ws = _Workspace()
+        self.anchor = None
+        self.packed = False
+
+    def attached(self):
+        return (self.net is not None and self.layers[0].bias.device == self.net.device
+                and self.layers[0].bias.data_ptr() == self.net.raw_views(self.net.raw)[0]["bias"].data_ptr())
+
+    def attach(self):
+        dev = self.layers[0].bias.device
+        if dev.type != "cuda":
+            raise RuntimeError("the fneus HIP backend needs the module on a GPU (there is no CPU fallback)")
+        net = ops.PackedNet(self.kind, dev)
+        with torch.no_grad():
+            for lin, view, gview in zip(self.layers, net.raw_views(net.raw), net.raw_views(net.raw_grad)):
+                for name in ("bias", "weight"):
+                    prm = getattr(lin, name)
+                    view[name].copy_(prm.data)
+                    if prm.grad is not None:
+                        gview[name].copy_(prm.grad)
+                    prm.data = view[name]
+                    prm.grad = gview[name]
+        self.net = net
+        self.anchor = torch.zeros(1, device=dev, requires_grad=True)
+
+    def refresh(self):
+        if not self.attached():
+            self.attach()
+        for lin, gview in zip(self.layers, self.net.raw_views(self.net.raw_grad)):
+            for name in ("bias", "weight"):
+                prm = getattr(lin, name)
+                if prm.grad is None:
+                    gview[name].zero_()
+                    prm.grad = gview[name]
+        self.net.pack()
+        self.packed = True
+
+    def ensure(self):
+        if not self.packed or not self.attached():
+            self.refresh()
+
+
 class RefColor(nn.Module):
     """Diffuse + specular surface colour at the two samples bracketing the first SDF sign change (fields.py:271-335).
-    <= 2 samples per ray: plain torch.  state_dict keys as in the reference (net_cd.*, viewdir_mlp.*, net_cs.0)."""
+
+    state_dict keys as in the reference (net_cd.*, viewdir_mlp.*, net_cs.0).  Both MLPs (net_cd; viewdir_mlp + net_cs)
+    have the colour network's shape and run on the same fused HIP kernels (fneus_refcolor_fwd / _bwd); the sRGB
+    transfer and the clipping are element-wise torch ops on [2B,3] tensors."""
 
     def __init__(self):
         super().__init__()
@@ -251,20 +304,46 @@ class RefColor(nn.Module):
                                     nn.ReLU(), nn.Linear(256, 256), nn.ReLU(), nn.Linear(256, 3), nn.Sigmoid())
         self.viewdir_mlp = nn.ModuleList([nn.Linear(289, 256)] + [nn.Linear(256, 256) for _ in range(3)])
         self.net_cs = nn.Sequential(nn.Linear(256, 1), nn.Sigmoid())
+        self.prec = ops.PREC_PARITY
+        self._cd = _PlainBackend("refcd", [self.net_cd[i] for i in (0, 2, 4, 6, 8)])
+        self._vd = _PlainBackend("refvd", list(self.viewdir_mlp) + [self.net_cs[0]])
 
-    def forward(self, pts, x, dirs, n):
-        normals = _l2_normalize(n)
-        n_enc = self.embedview_fn(n)
-        ref_dirs = 2.0 * torch.sum(-dirs * normals, dim=-1, keepdim=True) * normals + dirs
-        ref_enc = self.embedview_fn(ref_dirs)
-        diffuse = self.net_cd(torch.cat([pts, n_enc, x], dim=-1))
-        x2 = torch.cat([n, pts, ref_enc, x], dim=-1)
-        for layer in self.viewdir_mlp:
-            x2 = F.relu(layer(x2))
-        spec = self.net_cs(x2).repeat(1, 3)
+    def set_precision(self, prec: int):
+        assert prec in (ops.PREC_FAST, ops.PREC_PARITY)
+        self.prec = prec
+
+    def refresh(self):
+        """pack the current parameters of both MLPs (once per optimiser step, before rendering)"""
+        self._cd.refresh()
+        self._vd.refresh()
+
+    def flat_grads(self):
+        return [b.net.raw_grad for b in (self._cd, self._vd) if b.net is not None]
+
+    def heads(self, samples: RaySamples, x, n, train: bool):
+        """-> diffuse [M,3], specular [M,1] (both after their sigmoid), differentiable w.r.t. x, n and the parameters"""
+        self._cd.ensure()
+        self._vd.ensure()
+        diffuse = ColorFn.apply(self._cd.anchor, n, x, self._cd.net, samples, self.prec, self._cd.ws, None, train,
+                                ops.HEAD_REF_DIFFUSE)
+        spec = ColorFn.apply(self._vd.anchor, n, x, self._vd.net, samples, self.prec, self._vd.ws, None, train,
+                             ops.HEAD_REF_SPECULAR)
+        return diffuse, spec[:, :1]
+
+    @staticmethod
+    def shade(diffuse, spec):
+        spec = spec.repeat(1, 3)
         return {"rgb": torch.clip(_linear_to_srgb(spec + diffuse), 0.0, 1.0),
                 "specular_rgb": torch.clip(_linear_to_srgb(spec), 0.0, 1.0),
                 "diffuse_rgb": torch.clip(_linear_to_srgb(diffuse), 0.0, 1.0)}
+
+    def forward_samples(self, samples: RaySamples, x, n):
+        """hot-path entry: sample positions given as (rays_o, rays_d, t) like the other fused kernels"""
+        return self.shade(*self.heads(samples, x, n, torch.is_grad_enabled()))
+
+    def forward(self, pts, x, dirs, n):
+        s = RaySamples(pts=pts.detach().float().contiguous(), dirs=dirs.detach().float().contiguous())
+        return self.forward_samples(s, x.float(), n.float())
 
 
 class NeRF(nn.Module):

@@ -131,8 +131,9 @@ class NeuSRenderer:
             hi = torch.where(sdf_mask, min_idx.long(), torch.ones_like(min_idx, dtype=torch.long))
             rows = torch.arange(B, device=z_vals.device) * n
             sel = torch.stack([rows + hi - 1, rows + hi], dim=1).reshape(-1)                # low, high interleaved
-            pts_sel = rays_o.repeat_interleave(2, 0) + rays_d.repeat_interleave(2, 0) * mid_z.reshape(-1)[sel][:, None]
-            ref = refColor_network(pts_sel, feat[sel], rays_d.repeat_interleave(2, 0), normal[sel])
+            # 2 samples per ray in the (rays_o, rays_d, t) form of the fused kernels (pts = o + d * t, renderer.py:322)
+            surf = RaySamples(rays_o, rays_d, mid_z.reshape(-1)[sel].contiguous(), 2)
+            ref = refColor_network.forward_samples(surf, feat[sel], normal[sel])
             w_lo, w_hi = wpair[:, 0:1] + 1e-5, wpair[:, 1:2] + 1e-5
 
             def blend(v):
@@ -176,6 +177,8 @@ class NeuSRenderer:
         # networks changed since the last call (optimiser step): fold weight-norm and re-pack once
         self.sdf_network.refresh()
         self.color_network.refresh()
+        if self.refColor_network is not None:
+            self.refColor_network.refresh()
         n = self.n_samples
         if self.n_importance > 0:
             if z_vals_override is not None:

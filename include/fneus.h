@@ -45,6 +45,8 @@ typedef struct FneusColStash {
     uint16_t* u_hi;    uint16_t* u_lo;    /* [4][N][256] slot l = ReLU output of layer l (= input of l+1)     */
     uint16_t* zbar_hi; uint16_t* zbar_lo; /* [5][N][256] slot l = dL/dz_l  (slot 4: 32-wide rows, 3 valid)   */
     void* mask;                           /* lane-private ReLU masks: [ceil(N/32)][4][64] x 16 bytes           */
+    uint16_t* feat_hi; uint16_t* feat_lo; /* [N][256]    fneus_refcolor_* only: copy of the input features; NULL for
+                                                          the colour network (its features are FneusSdfStash.feat)    */
 } FneusColStash;
 
 /* work buffers of fneus_sdf_bwd (operands of the weight-gradient GEMM + private scratch). */
@@ -127,6 +129,22 @@ int fneus_color_fwd(const void* col_blob, const float* pts, const float* rays_o,
 /* autograd of the above: d_rgb -> d_feat [n][256], d_normal [n][3]; writes zbar planes (weight-gradient operands). */
 int fneus_color_bwd(const void* col_blob, long n_pts, const float* d_rgb, const float* rgb, const FneusColStash* stash,
                     float* d_feat, float* d_normal, int prec, fneus_stream_t stream);
+
+/* ---- K4': RefColor.forward, the surface colour head  (fields.py:271-335 via renderer.py:330-339) ------------- */
+/* Its two MLPs have the colour network's shape and run on the same kernels.  head 1 = net_cd: [pts | PE4(n) | feature]
+ * -> diffuse rgb out[n][3];  head 2 = viewdir_mlp + net_cs: [n | pts | PE4(reflect(-d, n/|n|)) | feature] -> specular
+ * out[n][0] (columns 1, 2 are padding).  Plain nn.Linear layers (no weight norm); blobs come from fneus_pack.  The
+ * sRGB transfer, clipping and the two-sample blend of renderer.py:336-339 stay with the caller.                       */
+int fneus_refcolor_fwd(const void* blob, int head, const float* pts, const float* rays_o, const float* rays_d,
+                       const float* t, int m, long n_pts, const float* dirs, const float* normal /*[n][3]*/,
+                       const float* feat /*[n][256]*/, const FneusColStash* stash, float* out /*[n][3]*/, int prec,
+                       int train, fneus_stream_t stream);
+
+/* autograd of the above: d_out [n][3] (head 2: columns 1, 2 must be zero) -> d_feat [n][256], d_normal [n][3] (through
+ * PE4(n), the reflection and the normalisation); view directions as in the forward call (dirs, or rays_d[n/m]).      */
+int fneus_refcolor_bwd(const void* blob, int head, long n_pts, const float* rays_d, int m, const float* dirs,
+                       const float* normal, const float* d_out, const float* out, const FneusColStash* stash,
+                       float* d_feat, float* d_normal, int prec, fneus_stream_t stream);
 
 /* ---- K6: hierarchical sampler pieces (one wavefront per ray, 2 <= samples per ray <= 256) ---------------------- */
 /* NeuSRenderer.up_sample + sample_pdf(det=True)  (renderer.py:152-189, 43-77): z [B][m], sdf [B][m] -> z_new [B][k]  */

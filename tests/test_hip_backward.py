@@ -87,7 +87,7 @@ def test_color_fwd_bwd(env, prec, tol):
     assert int(ok.sum()) > 0.8 * n
     assert e_f <= gtol and e_n <= gtol
     grad = torch.zeros(env["cnet"].n_params, dtype=torch.float32, device=dev)
-    jobs = ops.color_dw_jobs(env["cnet"], sdf_stash, cst, grad, n)
+    jobs = ops.color_dw_jobs(env["cnet"], sdf_stash.feat, cst, grad, n)
     jobs.run(n, prec)
     dWs, dbs = env["cnet"].split_flat(grad)
     for l in range(5):
