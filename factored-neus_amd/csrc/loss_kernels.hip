@@ -1,0 +1,244 @@
+// Per-ray tail of the stage-1 step, fused:
+//   surface_gather : the two samples bracketing the first SDF sign change of every ray (renderer.py:290-293, 316-327):
+//                    their index, depth, feature row and normal, packed as [2B] rows for the RefColor heads
+//   stage1_loss    : RefColor shading (linear -> sRGB, clip; fields.py:262-268, 331-335), the two-sample blend
+//                    (renderer.py:336-343), the four loss terms of the training loop (exp_runner.py:141-177) AND their
+//                    gradients with respect to every differentiable input, in one launch.
+// In PyTorch this tail was ~230 element-wise / reduction kernels on [512]-ray tensors (0.7 ms of a 5.2 ms step).
+// The loss needs batch-wide normalisers before any per-ray gradient can be formed, so it runs as ONE workgroup that
+// sweeps the rays twice (B is a few hundred to a few thousand); sums are reduced in a fixed order (deterministic).
+#include "fneus_common.h"
+#include "fneus_kernels.h"
+
+namespace fneus {
+
+// one wavefront per ray: sel[2b], sel[2b+1] = b*n + hi - 1, b*n + hi  with hi = sdf_mask ? min_idx : 1
+__global__ void __launch_bounds__(64) surface_gather_kernel(const int32_t* __restrict__ min_idx,
+                                                            const unsigned char* __restrict__ sdf_mask,
+                                                            const float* __restrict__ mid_z,    // [B][n]
+                                                            const float* __restrict__ feat,     // [B*n][256]
+                                                            const float* __restrict__ normal,   // [B*n][3]
+                                                            int n, int32_t* __restrict__ sel, float* __restrict__ t_sel,
+                                                            float* __restrict__ feat_sel, float* __restrict__ normal_sel) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int hi = sdf_mask[b] ? min_idx[b] : 1;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const long src = (long)b * n + hi - 1 + k;
+        const long dst = 2L * b + k;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(feat + src * 256 + lane * 4);
+        *reinterpret_cast<f32x4*>(feat_sel + dst * 256 + lane * 4) = v;
+        if (lane < 3) normal_sel[dst * 3 + lane] = normal[src * 3 + lane];
+        if (lane == 3) t_sel[dst] = mid_z[src];
+        if (lane == 4) sel[dst] = (int32_t)src;
+    }
+}
+
+struct LossArgs {
+    // inputs
+    const float* color;      // [B][3]  composited colour
+    const float* true_rgb;   // [B][3]
+    const float* mask_in;    // [B]
+    const float* wsum;       // [B]     weight sum
+    const float* eik_num;    // [B]     eikonal numerator / denominator per ray (renderer.py:370-372)
+    const float* eik_den;    // [B]
+    const float* diffuse;    // [2B][3] net_cd output (after sigmoid)
+    const float* spec;       // [2B][3] column 0 = net_cs output (after sigmoid)
+    const float* wpair;      // [B][2]  compositing weights of the two bracketing samples
+    const unsigned char* sdf_mask;   // [B]
+    int B;
+    float igr_weight, mask_weight, surface_weight;
+    // outputs
+    float* losses;           // [8] loss, color, surface, eikonal, mask, psnr, mask_sum, mask_sdf_sum
+    float* surface_color;    // [B][3]
+    float* specular_color;   // [B][3]
+    float* diffuse_color;    // [B][3]
+    float* d_color;          // [B][3]
+    float* d_wsum;           // [B]
+    float* d_eiknum;         // [B]
+    float* d_wpair;          // [B][2]
+    float* d_diffuse;        // [2B][3]
+    float* d_spec;           // [2B][3] (column 0; 1, 2 zero)
+};
+
+// linear -> sRGB (fields.py:262-268) and its derivative on the selected branch
+FN_DEV float srgb(float x) {
+    const float eps = 1.1920928955078125e-07f;
+    return x <= 0.0031308f ? (323.0f / 25.0f) * x : (211.0f * powf(fmaxf(x, eps), 5.0f / 12.0f) - 11.0f) / 200.0f;
+}
+FN_DEV float dsrgb(float x) {
+    return x <= 0.0031308f ? (323.0f / 25.0f) : (211.0f / 200.0f) * (5.0f / 12.0f) * powf(x, -7.0f / 12.0f);
+}
+FN_DEV float clip01(float y) { return fminf(fmaxf(y, 0.0f), 1.0f); }
+FN_DEV float sgn(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); }
+
+constexpr int kLossThreads = 1024;
+
+// block-wide sum of NV values per thread, fixed reduction order; result valid in every thread
+template <int NV>
+FN_DEV void block_sum(float (&v)[NV], float* sm /*[NV][16]*/) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v[i] += __shfl_xor(v[i], d, 64);
+        if (lane == 0) sm[i * 16 + wave] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float s = 0.0f;
+        for (int w = 0; w < kLossThreads / 64; ++w) s += sm[i * 16 + w];
+        v[i] = s;
+    }
+    __syncthreads();
+}
+
+// shading of one ray: blend of the two bracketing samples; returns surface colour (and optionally the parts)
+struct Shade {
+    float brdf[2][3], y[2][3], w[2], W;
+    float surf[3];
+};
+FN_DEV void shade_ray(const LossArgs& a, int b, bool sm, Shade& s, float (&spec_c)[3], float (&diff_c)[3]) {
+    s.w[0] = a.wpair[b * 2 + 0] + 1e-5f;
+    s.w[1] = a.wpair[b * 2 + 1] + 1e-5f;
+    s.W = s.w[0] + s.w[1];
+    float ys[2], yd[2][3];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float sp = a.spec[(2 * b + k) * 3];
+        ys[k] = clip01(srgb(sp));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float df = a.diffuse[(2 * b + k) * 3 + c];
+            s.brdf[k][c] = sp + df;
+            s.y[k][c] = srgb(s.brdf[k][c]);
+            yd[k][c] = clip01(srgb(df));
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        s.surf[c] = sm ? (clip01(s.y[0][c]) * s.w[0] + clip01(s.y[1][c]) * s.w[1]) / s.W : 1.0f;
+        spec_c[c] = sm ? (ys[0] * s.w[0] + ys[1] * s.w[1]) / s.W : 1.0f;
+        diff_c[c] = sm ? (yd[0][c] * s.w[0] + yd[1][c] * s.w[1]) / s.W : 1.0f;
+    }
+}
+
+__global__ void __launch_bounds__(kLossThreads) stage1_loss_kernel(LossArgs a) {
+    __shared__ float red[8 * 16];
+    const int tid = threadIdx.x;
+    const bool use_mask = a.mask_weight > 0.0f;
+    // ---- sweep 1: batch sums ----
+    // 0 mask_sum, 1 mask*sdf_mask, 2 |colour error|, 3 |surface error| (unweighted by 1/sum), 4 eik num, 5 eik den,
+    // 6 BCE sum, 7 squared colour error
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = tid; b < a.B; b += kLossThreads) {
+        const float m = use_mask ? (a.mask_in[b] > 0.5f ? 1.0f : 0.0f) : 1.0f;
+        const bool sm = a.sdf_mask[b] != 0;
+        Shade s;
+        float spec_c[3], diff_c[3];
+        shade_ray(a, b, sm, s, spec_c, diff_c);
+        acc[0] += m;
+        acc[1] += sm ? m : 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float ce = (a.color[b * 3 + c] - a.true_rgb[b * 3 + c]) * m;
+            acc[2] += fabsf(ce);
+            acc[7] += ce * (a.color[b * 3 + c] - a.true_rgb[b * 3 + c]);
+            if (sm) acc[3] += fabsf(a.surface_weight * (s.surf[c] - a.true_rgb[b * 3 + c]) * m);
+            a.surface_color[b * 3 + c] = s.surf[c];
+            a.specular_color[b * 3 + c] = spec_c[c];
+            a.diffuse_color[b * 3 + c] = diff_c[c];
+        }
+        acc[4] += a.eik_num[b];
+        acc[5] += a.eik_den[b];
+        const float w = fminf(fmaxf(a.wsum[b], 1e-3f), 1.0f - 1e-3f);
+        acc[6] += -(m * logf(w) + (1.0f - m) * logf(1.0f - w));      // F.binary_cross_entropy (its -100 log clamp is moot here)
+    }
+    block_sum<8>(acc, red);
+    const float mask_sum = acc[0] + 1e-5f, mask_sdf_sum = acc[1] + 1e-5f, eik_den = acc[5] + 1e-5f;
+    const float color_loss = acc[2] / mask_sum;
+    const float surface_loss = acc[3] / mask_sdf_sum;
+    const float eik_loss = acc[4] / eik_den;
+    const float mask_loss = acc[6] / (float)a.B;
+    if (tid == 0) {
+        a.losses[0] = color_loss + surface_loss + eik_loss * a.igr_weight + mask_loss * a.mask_weight;
+        a.losses[1] = color_loss;
+        a.losses[2] = surface_loss;
+        a.losses[3] = eik_loss;
+        a.losses[4] = mask_loss;
+        a.losses[5] = 20.0f * log10f(1.0f / sqrtf(acc[7] / (mask_sum * 3.0f)));
+        a.losses[6] = mask_sum;
+        a.losses[7] = mask_sdf_sum;
+    }
+    // ---- sweep 2: gradients of the total loss ----
+    for (int b = tid; b < a.B; b += kLossThreads) {
+        const float m = use_mask ? (a.mask_in[b] > 0.5f ? 1.0f : 0.0f) : 1.0f;
+        const bool sm = a.sdf_mask[b] != 0;
+        Shade s;
+        float spec_c[3], diff_c[3];
+        shade_ray(a, b, sm, s, spec_c, diff_c);
+        float dw[2] = {0.0f, 0.0f}, dsp[2] = {0.0f, 0.0f};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float t = a.true_rgb[b * 3 + c];
+            a.d_color[b * 3 + c] = sgn((a.color[b * 3 + c] - t) * m) * m / mask_sum;
+            // surface term: |surface_weight (surf - t) m| / mask_sdf_sum over rays with a sign change
+            const float dsurf = sm ? sgn(a.surface_weight * (s.surf[c] - t) * m) * a.surface_weight * m / mask_sdf_sum : 0.0f;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float yk = s.y[k][c];
+                const float inside = (yk >= 0.0f && yk <= 1.0f) ? 1.0f : 0.0f;          // torch.clip passes the gradient on [0, 1]
+                const float dy = dsurf * s.w[k] / s.W * inside;
+                const float dx = dy != 0.0f ? dy * dsrgb(s.brdf[k][c]) : 0.0f;
+                a.d_diffuse[(2 * b + k) * 3 + c] = dx;
+                dsp[k] += dx;
+                dw[k] += dsurf * (clip01(yk) - s.surf[c]) / s.W;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            a.d_wpair[b * 2 + k] = dw[k];
+            a.d_spec[(2 * b + k) * 3 + 0] = dsp[k];
+            a.d_spec[(2 * b + k) * 3 + 1] = 0.0f;
+            a.d_spec[(2 * b + k) * 3 + 2] = 0.0f;
+        }
+        a.d_eiknum[b] = a.igr_weight / eik_den;
+        const float wr = a.wsum[b];
+        const bool in = wr >= 1e-3f && wr <= 1.0f - 1e-3f;
+        const float w = fminf(fmaxf(wr, 1e-3f), 1.0f - 1e-3f);
+        a.d_wsum[b] = in ? a.mask_weight / (float)a.B * (-m / w + (1.0f - m) / (1.0f - w)) : 0.0f;
+    }
+}
+
+}  // namespace fneus
+
+using namespace fneus;
+
+extern "C" int fneus_surface_gather(const int32_t* min_idx, const unsigned char* sdf_mask, const float* mid_z,
+                                    const float* feat, const float* normal, int n_rays, int n, int32_t* sel, float* t_sel,
+                                    float* feat_sel, float* normal_sel, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (n_rays <= 0) return 0;
+    if (n < 2) return -2;
+    hipLaunchKernelGGL(surface_gather_kernel, dim3(n_rays), dim3(64), 0, stream, min_idx, sdf_mask, mid_z, feat, normal, n, sel,
+                       t_sel, feat_sel, normal_sel);
+    return fneus::launch_status();
+}
+
+extern "C" int fneus_stage1_loss(const float* color, const float* true_rgb, const float* mask_in, const float* wsum,
+                                 const float* eik_num, const float* eik_den, const float* diffuse, const float* spec, const float* wpair,
+                                 const unsigned char* sdf_mask, int n_rays, float igr_weight, float mask_weight,
+                                 float surface_weight, float* losses, float* surface_color, float* specular_color,
+                                 float* diffuse_color, float* d_color, float* d_wsum, float* d_eiknum, float* d_wpair,
+                                 float* d_diffuse, float* d_spec, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (n_rays <= 0) return -2;
+    LossArgs a{color, true_rgb, mask_in, wsum, eik_num, eik_den, diffuse, spec, wpair, sdf_mask, n_rays, igr_weight, mask_weight,
+               surface_weight, losses, surface_color, specular_color, diffuse_color, d_color, d_wsum, d_eiknum, d_wpair,
+               d_diffuse, d_spec};
+    hipLaunchKernelGGL(stage1_loss_kernel, dim3(1), dim3(kLossThreads), 0, stream, a);
+    return fneus::launch_status();
+}

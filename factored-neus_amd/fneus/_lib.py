@@ -67,6 +67,8 @@ def _load():
         "fneus_refcolor_fwd": (C.c_int, [vp, ip, vp, vp, vp, vp, ip, l, vp, vp, vp, C.POINTER(FneusColStash), vp, ip, ip, vp]),
         "fneus_refcolor_bwd": (C.c_int, [vp, ip, l, vp, ip, vp, vp, vp, vp, C.POINTER(FneusColStash), vp, vp, ip, vp]),
         "fneus_dw_gemm": (C.c_int, [vp, ip, ip, l, ip, vp]),
+        "fneus_surface_gather": (C.c_int, [vp, vp, vp, vp, vp, ip, ip, vp, vp, vp, vp, vp]),
+        "fneus_stage1_loss": (C.c_int, [vp] * 10 + [ip, f, f, f] + [vp] * 10 + [vp]),
         "fneus_upsample": (C.c_int, [vp, vp, vp, vp, ip, ip, ip, f, vp, vp]),
         "fneus_merge": (C.c_int, [vp, vp, ip, vp, vp, ip, ip, vp, vp, vp]),
         "fneus_sections": (C.c_int, [vp, ip, ip, f, vp, vp, vp]),

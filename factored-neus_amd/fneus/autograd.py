@@ -55,6 +55,15 @@ class SdfValueGradFn(torch.autograd.Function):
         d_sdf = torch.zeros(n, device=dev) if d_sdf is None else d_sdf.contiguous()
         d_feat = torch.zeros(n, 256, device=dev) if d_feat is None else d_feat.contiguous()
         d_normal = torch.zeros(n, 3, device=dev) if d_normal is None else d_normal.contiguous()
+        # gradients of the two gathered surface samples per ray arrive on the side (SurfaceGatherFn): 2B rows to add
+        # instead of a dense, mostly zero [n,256] tensor for autograd to allocate and sum
+        pending = ws.cache.pop("surface_grads", None)
+        if pending is not None:
+            sel, dfs, dns = pending
+            if dfs is not None:
+                d_feat.index_add_(0, sel, dfs)
+            if dns is not None:
+                d_normal.index_add_(0, sel, dns)
         bufs = ws.get(("sdf_bwd", n, prec), lambda: ops.SdfBwdBufs(n, dev, prec))
         ops.sdf_bwd(net.blob, n, prec, ctx.stash, bufs, d_sdf, d_feat, d_normal, **ctx.samples.kw())
         grad = ws.get(("sdf_grad", n), lambda: torch.empty(net.n_params, dtype=torch.float32, device=dev))
@@ -143,3 +152,47 @@ class CompositeFn(torch.autograd.Function):
             rays_o, rays_d, mid_z, dists, sdf, normal, rgb, inv_s, ctx.car, min_idx, sdf_mask, d_color, d_wsum, d_weights,
             d_wpair, d_eiknum, bga, bgc)
         return d_sdf, d_normal, d_rgb, d_inv.sum().reshape(1), None, None, None, None, None, d_bga, d_bgc
+
+
+class SurfaceGatherFn(torch.autograd.Function):
+    """Rows of (feature, normal, depth) at the two samples bracketing the first SDF sign change of every ray
+    (renderer.py:290-293, 316-327), one launch.  Its backward hands the 2B gradient rows to the SDF network's backward
+    through the workspace (see SdfValueGradFn.backward) and returns no dense gradient."""
+
+    @staticmethod
+    def forward(ctx, feat, normal, mid_z, min_idx, sdf_mask, sdf_ws: _Workspace):
+        sel, t_sel, feat_sel, normal_sel = ops.surface_gather(min_idx, sdf_mask, mid_z.contiguous(), feat.contiguous(),
+                                                              normal.contiguous())
+        ctx.sdf_ws = sdf_ws
+        ctx.save_for_backward(sel)
+        ctx.mark_non_differentiable(t_sel, sel)
+        return feat_sel, normal_sel, t_sel, sel
+
+    @staticmethod
+    def backward(ctx, d_feat_sel, d_normal_sel, _t, _s):
+        (sel,) = ctx.saved_tensors
+        ctx.sdf_ws.cache["surface_grads"] = (sel, None if d_feat_sel is None else d_feat_sel.contiguous(),
+                                             None if d_normal_sel is None else d_normal_sel.contiguous())
+        return None, None, None, None, None, None
+
+
+class Stage1LossFn(torch.autograd.Function):
+    """RefColor shading + two-sample blend + the four training losses, with the gradients of the total loss computed in
+    the same launch (csrc/loss_kernels.hip).  Differentiable inputs: color [B,3], wsum [B], eik_num [B], wpair [B,2],
+    diffuse [2B,3], spec [2B,3] (column 0).  Returns loss (scalar), losses [8], surface / specular / diffuse colour."""
+
+    @staticmethod
+    def forward(ctx, color, wsum, eik_num, wpair, diffuse, spec, eik_den, true_rgb, mask_in, sdf_mask, igr_weight,
+                mask_weight, surface_weight):
+        o = ops.stage1_loss(color.contiguous(), true_rgb.contiguous(), mask_in.contiguous().reshape(-1), wsum.contiguous(),
+                            eik_num.contiguous(), eik_den.contiguous(), diffuse.contiguous(), spec.contiguous(),
+                            wpair.contiguous(), sdf_mask, igr_weight, mask_weight, surface_weight)
+        ctx.save_for_backward(o["d_color"], o["d_wsum"], o["d_eiknum"], o["d_wpair"], o["d_diffuse"], o["d_spec"])
+        aux = (o["losses"], o["surface_color"], o["specular_color"], o["diffuse_color"])
+        ctx.mark_non_differentiable(*aux)
+        return (o["losses"][0].clone(),) + aux
+
+    @staticmethod
+    def backward(ctx, g, *unused):
+        grads = torch._foreach_mul(list(ctx.saved_tensors), g)
+        return tuple(grads) + (None,) * 7

@@ -363,6 +363,40 @@ def color_dw_jobs(net: PackedNet, feat_planes: torch.Tensor, stash: ColStash, gr
 # ------------------------------------------------------------------------------------------------------------
 # per-ray kernels
 # ------------------------------------------------------------------------------------------------------------
+def surface_gather(min_idx, sdf_mask, mid_z, feat, normal):
+    """-> sel [2B] int32, t_sel [2B], feat_sel [2B,256], normal_sel [2B,3]"""
+    B, n = mid_z.shape
+    dev = mid_z.device
+    sel = torch.empty(2 * B, dtype=torch.int32, device=dev)
+    t_sel = torch.empty(2 * B, dtype=torch.float32, device=dev)
+    feat_sel = torch.empty(2 * B, 256, dtype=torch.float32, device=dev)
+    normal_sel = torch.empty(2 * B, 3, dtype=torch.float32, device=dev)
+    _launch("fneus_surface_gather", lib.fneus_surface_gather, _ptr(min_idx), _ptr(sdf_mask), _ptr(mid_z), _ptr(feat), _ptr(normal),
+            B, n, _ptr(sel), _ptr(t_sel), _ptr(feat_sel), _ptr(normal_sel), _stream())
+    return sel, t_sel, feat_sel, normal_sel
+
+
+def stage1_loss(color, true_rgb, mask_in, wsum, eik_num, eik_den, diffuse, spec, wpair, sdf_mask, igr_weight, mask_weight,
+                surface_weight):
+    """fused shading + losses + gradients (include/fneus.h fneus_stage1_loss); returns a dict of device tensors"""
+    B = color.shape[0]
+    dev = color.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    for x, nm in ((color, "color"), (true_rgb, "true_rgb"), (mask_in, "mask"), (wsum, "wsum"), (eik_num, "eik_num"),
+                  (eik_den, "eik_den"), (diffuse, "diffuse"), (spec, "spec"), (wpair, "wpair")):
+        _chk_f32(x, nm)
+    o = {"losses": torch.empty(8, **f32), "surface_color": torch.empty(B, 3, **f32), "specular_color": torch.empty(B, 3, **f32),
+         "diffuse_color": torch.empty(B, 3, **f32), "d_color": torch.empty(B, 3, **f32), "d_wsum": torch.empty(B, **f32),
+         "d_eiknum": torch.empty(B, **f32), "d_wpair": torch.empty(B, 2, **f32), "d_diffuse": torch.empty(2 * B, 3, **f32),
+         "d_spec": torch.empty(2 * B, 3, **f32)}
+    _launch("fneus_stage1_loss", lib.fneus_stage1_loss, _ptr(color), _ptr(true_rgb), _ptr(mask_in), _ptr(wsum), _ptr(eik_num),
+            _ptr(eik_den), _ptr(diffuse), _ptr(spec), _ptr(wpair), _ptr(sdf_mask), B, float(igr_weight), float(mask_weight),
+            float(surface_weight), _ptr(o["losses"]), _ptr(o["surface_color"]), _ptr(o["specular_color"]),
+            _ptr(o["diffuse_color"]), _ptr(o["d_color"]), _ptr(o["d_wsum"]), _ptr(o["d_eiknum"]), _ptr(o["d_wpair"]),
+            _ptr(o["d_diffuse"]), _ptr(o["d_spec"]), _stream())
+    return o
+
+
 def upsample(rays_o, rays_d, z, sdf, k: int, inv_s: float):
     B, m = z.shape
     out = torch.empty(B, k, dtype=torch.float32, device=z.device)

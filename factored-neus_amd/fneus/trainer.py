@@ -16,7 +16,6 @@ import numpy as np
 import torch
 
 from fneus import ops, synth
-from fneus.losses import stage1_loss
 from fneus.parallel import FlatGradBucket
 
 WMASK_MODEL = {   # confs/wmask.conf:49-97
@@ -132,9 +131,12 @@ class Stage1Trainer:
         a = (rays_d ** 2).sum(-1, keepdim=True)                       # near_far_from_sphere, dataset.py:186-192
         b = 2.0 * (rays_o * rays_d).sum(-1, keepdim=True)
         mid = 0.5 * (-b) / a
+        # the losses of exp_runner.py:141-177 are evaluated inside render (fused with the surface shading and their own
+        # gradients: one launch instead of ~200 element-wise kernels on [B]-ray tensors)
         out = self.renderer.render(rays_o, rays_d, mid - 1.0, mid + 1.0, background_rgb=background_rgb,
-                                   cos_anneal_ratio=cos_anneal_ratio)
-        losses = stage1_loss(out, true_rgb, mask, self.igr_weight, self.mask_weight, self.surface_weight)
+                                   cos_anneal_ratio=cos_anneal_ratio,
+                                   loss_args=(true_rgb, mask, self.igr_weight, self.mask_weight, self.surface_weight))
+        losses = out["losses"]
         self.zero_grad()
         losses["loss"].backward()
         if with_optimizer:

@@ -321,18 +321,19 @@ class RefColor(nn.Module):
         return [b.net.raw_grad for b in (self._cd, self._vd) if b.net is not None]
 
     def heads(self, samples: RaySamples, x, n, train: bool):
-        """-> diffuse [M,3], specular [M,1] (both after their sigmoid), differentiable w.r.t. x, n and the parameters"""
+        """-> diffuse [M,3], specular [M,3] with the value in column 0 (both after their sigmoid), differentiable w.r.t.
+        x, n and the parameters"""
         self._cd.ensure()
         self._vd.ensure()
         diffuse = ColorFn.apply(self._cd.anchor, n, x, self._cd.net, samples, self.prec, self._cd.ws, None, train,
                                 ops.HEAD_REF_DIFFUSE)
         spec = ColorFn.apply(self._vd.anchor, n, x, self._vd.net, samples, self.prec, self._vd.ws, None, train,
                              ops.HEAD_REF_SPECULAR)
-        return diffuse, spec[:, :1]
+        return diffuse, spec
 
     @staticmethod
     def shade(diffuse, spec):
-        spec = spec.repeat(1, 3)
+        spec = spec[:, :1].repeat(1, 3)
         return {"rgb": torch.clip(_linear_to_srgb(spec + diffuse), 0.0, 1.0),
                 "specular_rgb": torch.clip(_linear_to_srgb(spec), 0.0, 1.0),
                 "diffuse_rgb": torch.clip(_linear_to_srgb(diffuse), 0.0, 1.0)}

@@ -17,7 +17,7 @@ import torch
 import torch.nn.functional as F
 
 from fneus import ops
-from fneus.autograd import CompositeFn, RaySamples
+from fneus.autograd import CompositeFn, RaySamples, SurfaceGatherFn, Stage1LossFn
 
 
 def sample_pdf(bins, weights, n_samples, det=False):
@@ -110,7 +110,7 @@ class NeuSRenderer:
     # ---- render_core (renderer.py:208-389) ------------------------------------------------------------------------
     def render_core(self, rays_o, rays_d, z_vals, sample_dist, sdf_network, deviation_network, color_network,
                     refColor_network, background_alpha=None, background_sampled_color=None, background_rgb=None,
-                    cos_anneal_ratio=0.0):
+                    cos_anneal_ratio=0.0, loss_args=None):
         B, n = z_vals.shape
         train = torch.is_grad_enabled()
         dists, mid_z = ops.sections(z_vals.contiguous(), sample_dist)
@@ -122,38 +122,52 @@ class NeuSRenderer:
             sdf, normal, rgb, inv_s, rays_o, rays_d, mid_z, dists, float(cos_anneal_ratio), background_alpha,
             background_sampled_color)
         sdf_mask = sdf_mask_u8.bool()
-        gradient_error = eik_num.sum() / (eik_den.sum() + 1e-5)                        # renderer.py:370-372
+        if background_rgb is not None:
+            color = color + background_rgb * (1.0 - wsum[:, None])
 
         # surface branch at fixed shape (renderer.py:284-343): the two samples bracketing the first sign change
         ones = torch.ones(B, 3, device=z_vals.device)
         specular_color = diffuse_color = surface_color = ones
+        losses = None
         if refColor_network is not None:
-            hi = torch.where(sdf_mask, min_idx.long(), torch.ones_like(min_idx, dtype=torch.long))
-            rows = torch.arange(B, device=z_vals.device) * n
-            sel = torch.stack([rows + hi - 1, rows + hi], dim=1).reshape(-1)                # low, high interleaved
+            feat_sel, normal_sel, t_sel, _sel = SurfaceGatherFn.apply(feat, normal, mid_z, min_idx, sdf_mask_u8,
+                                                                      sdf_network._ws)
             # 2 samples per ray in the (rays_o, rays_d, t) form of the fused kernels (pts = o + d * t, renderer.py:322)
-            surf = RaySamples(rays_o, rays_d, mid_z.reshape(-1)[sel].contiguous(), 2)
-            ref = refColor_network.forward_samples(surf, feat[sel], normal[sel])
-            w_lo, w_hi = wpair[:, 0:1] + 1e-5, wpair[:, 1:2] + 1e-5
+            surf = RaySamples(rays_o, rays_d, t_sel, 2)
+            diffuse, spec = refColor_network.heads(surf, feat_sel, normal_sel, train)
+            if loss_args is not None:     # shading, blend, losses and their gradients in one launch (training step)
+                true_rgb, mask_in, igr_w, mask_w, surf_w = loss_args
+                loss, lvec, surface_color, specular_color, diffuse_color = Stage1LossFn.apply(
+                    color, wsum, eik_num, wpair, diffuse, spec, eik_den, true_rgb, mask_in, sdf_mask_u8, float(igr_w),
+                    float(mask_w), float(surf_w))
+                losses = {"loss": loss, "color_loss": lvec[1], "surface_loss": lvec[2], "eikonal_loss": lvec[3],
+                          "mask_loss": lvec[4], "psnr": lvec[5]}
+            else:
+                ref = refColor_network.shade(diffuse, spec)
+                w_lo, w_hi = wpair[:, 0:1] + 1e-5, wpair[:, 1:2] + 1e-5
 
-            def blend(v):
-                v = v.reshape(B, 2, 3)
-                return torch.where(sdf_mask[:, None], (v[:, 0] * w_lo + v[:, 1] * w_hi) / (w_lo + w_hi), ones)
+                def blend(v):
+                    v = v.reshape(B, 2, 3)
+                    return torch.where(sdf_mask[:, None], (v[:, 0] * w_lo + v[:, 1] * w_hi) / (w_lo + w_hi), ones)
 
-            specular_color, diffuse_color, surface_color = blend(ref["specular_rgb"]), blend(ref["diffuse_rgb"]), blend(ref["rgb"])
+                specular_color, diffuse_color, surface_color = blend(ref["specular_rgb"]), blend(ref["diffuse_rgb"]), blend(ref["rgb"])
+        elif loss_args is not None:
+            raise NotImplementedError("the fused training loss needs the RefColor head (surface term)")
+        gradient_error = losses["eikonal_loss"] if losses is not None else eik_num.sum() / (eik_den.sum() + 1e-5)   # renderer.py:370-372
 
-        if background_rgb is not None:
-            color = color + background_rgb * (1.0 - wsum[:, None])
         return {
             "color": color, "surface_color": surface_color, "sdf_mask": sdf_mask, "sdf": sdf[:, None], "dists": dists,
             "gradients": normal.reshape(B, n, 3), "s_val": (1.0 / inv_s).expand(B * n, 1), "mid_z_vals": mid_z,
             "weights": weights, "cdf": cdf, "gradient_error": gradient_error, "inside_sphere": inside,
             "specular_color": specular_color, "diffuse_color": diffuse_color, "weight_max": wmax, "weight_sum": wsum,
+            "losses": losses,
         }
 
     # ---- render (renderer.py:391-500) -------------------------------------------------------------------------------
     def render(self, rays_o, rays_d, near, far, perturb_overwrite=-1, background_rgb=None, cos_anneal_ratio=0.0,
-               z_vals_override=None):
+               z_vals_override=None, loss_args=None):
+        """loss_args = (true_rgb [B,3], mask [B,1], igr_weight, mask_weight, surface_weight): also evaluate the training
+        losses of exp_runner.py:141-177 (fused with the surface shading, fneus_stage1_loss) -> out["losses"]"""
         dev = rays_o.device
         rays_o, rays_d = rays_o.float().contiguous(), rays_d.float().contiguous()
         B = len(rays_o)
@@ -194,7 +208,7 @@ class NeuSRenderer:
         ret = self.render_core(rays_o, rays_d, z_vals, sample_dist, self.sdf_network, self.deviation_network,
                                self.color_network, self.refColor_network, background_rgb=background_rgb,
                                background_alpha=background_alpha, background_sampled_color=background_sampled_color,
-                               cos_anneal_ratio=cos_anneal_ratio)
+                               cos_anneal_ratio=cos_anneal_ratio, loss_args=loss_args)
         weights = ret["weights"]
         return {
             "color_fine": ret["color"],
@@ -210,6 +224,7 @@ class NeuSRenderer:
             "inside_sphere": ret["inside_sphere"],
             "specular_color": ret["specular_color"],
             "diffuse_color": ret["diffuse_color"],
+            "losses": ret["losses"],
             # extras (not in the reference dict; used by the parity tests)
             "_z_vals": z_vals, "_sdf": ret["sdf"], "_mid_z_vals": ret["mid_z_vals"],
         }

@@ -146,6 +146,26 @@ int fneus_refcolor_bwd(const void* blob, int head, long n_pts, const float* rays
                        const float* normal, const float* d_out, const float* out, const FneusColStash* stash,
                        float* d_feat, float* d_normal, int prec, fneus_stream_t stream);
 
+/* ---- per-ray tail of the training step ------------------------------------------------------------------------ */
+/* The two samples bracketing the first SDF sign change of every ray (renderer.py:290-293, 316-327), packed for the
+ * RefColor heads: sel [2B] (row index into the B*n samples), t_sel [2B], feat_sel [2B][256], normal_sel [2B][3].
+ * Rays without a sign change (sdf_mask 0) select samples 0 and 1, as the reference's dense formulation does.           */
+int fneus_surface_gather(const int32_t* min_idx, const unsigned char* sdf_mask, const float* mid_z /*[B][n]*/,
+                         const float* feat /*[B*n][256]*/, const float* normal /*[B*n][3]*/, int n_rays, int n,
+                         int32_t* sel, float* t_sel, float* feat_sel, float* normal_sel, fneus_stream_t stream);
+
+/* RefColor shading (linear->sRGB, clip: fields.py:262-268, 331-335), the two-sample blend (renderer.py:336-343), the
+ * training losses (exp_runner.py:141-177: colour L1, surface L1, eikonal, mask BCE) and the gradient of the total loss
+ * with respect to every differentiable input, in one launch.  diffuse / spec are the outputs of fneus_refcolor_fwd
+ * heads 1 / 2 on the gathered samples.  losses[8] = total, colour, surface, eikonal, mask, psnr, mask_sum, mask_sdf_sum. */
+int fneus_stage1_loss(const float* color /*[B][3]*/, const float* true_rgb /*[B][3]*/, const float* mask_in /*[B]*/,
+                      const float* wsum /*[B]*/, const float* eik_num /*[B]*/, const float* eik_den /*[B]*/,
+                      const float* diffuse /*[2B][3]*/, const float* spec /*[2B][3], column 0*/, const float* wpair /*[B][2]*/,
+                      const unsigned char* sdf_mask /*[B]*/, int n_rays, float igr_weight, float mask_weight,
+                      float surface_weight, float* losses, float* surface_color /*[B][3]*/, float* specular_color,
+                      float* diffuse_color, float* d_color, float* d_wsum, float* d_eiknum, float* d_wpair,
+                      float* d_diffuse /*[2B][3]*/, float* d_spec /*[2B][3]*/, fneus_stream_t stream);
+
 /* ---- K6: hierarchical sampler pieces (one wavefront per ray, 2 <= samples per ray <= 256) ---------------------- */
 /* NeuSRenderer.up_sample + sample_pdf(det=True)  (renderer.py:152-189, 43-77): z [B][m], sdf [B][m] -> z_new [B][k]  */
 int fneus_upsample(const float* rays_o, const float* rays_d, const float* z, const float* sdf, int n_rays, int m, int k,

@@ -48,7 +48,7 @@ def build(g, prec):
     return rnd, dict(sdf=sdf, color=col, var=var, refcolor=ref, nerf=nerf)
 
 
-def run(g, prec, teacher_z):
+def run(g, prec, teacher_z, fused_loss=False):
     from oracle import ref_torch as R
     rnd, nets = build(g, prec)
     data = T(g["data"]).to(DEV)
@@ -56,7 +56,8 @@ def run(g, prec, teacher_z):
     near, far = R.near_far_from_sphere(rays_o, rays_d)
     bg = torch.ones(1, 3, device=DEV) if int(g["white_bkgd"]) else None
     out = rnd.render(rays_o, rays_d, near, far, perturb_overwrite=0, cos_anneal_ratio=float(g["cos_anneal_ratio"]),
-                     background_rgb=bg, z_vals_override=T(g["trace/z_3"]).to(DEV) if teacher_z else None)
+                     background_rgb=bg, z_vals_override=T(g["trace/z_3"]).to(DEV) if teacher_z else None,
+                     loss_args=(rgb, mask, 0.1, float(g["mask_weight"]), 0.1) if fused_loss else None)
     return out, nets, (rgb, mask)
 
 
@@ -98,12 +99,19 @@ def test_render_end_to_end(golden_dir, name):
     assert maxerr(out["_z_vals"], g["trace/z_3"]) <= 3e-3
 
 
+@pytest.mark.parametrize("fused", [False, True], ids=["torch_loss", "fused_loss"])
 @pytest.mark.parametrize("name", WMASK[:2] + WOMASK)
-def test_loss_and_gradients(golden_dir, name):
+def test_loss_and_gradients(golden_dir, name, fused):
+    """fused: shading + blend + losses + their gradients from fneus_stage1_loss (what the training step uses);
+    otherwise the same terms written with torch ops on the render dict"""
     from fneus.losses import stage1_loss
     g = load(golden_dir, name)
-    out, nets, (rgb, mask) = run(g, 3, teacher_z=True)
-    losses = stage1_loss(out, rgb, mask, igr_weight=0.1, mask_weight=float(g["mask_weight"]), surface_weight=0.1)
+    out, nets, (rgb, mask) = run(g, 3, teacher_z=True, fused_loss=fused)
+    if fused:
+        losses = out["losses"]
+        assert maxerr(out["surface_color"], g["out/surface_color"]) <= 1e-4
+    else:
+        losses = stage1_loss(out, rgb, mask, igr_weight=0.1, mask_weight=float(g["mask_weight"]), surface_weight=0.1)
     for k, key in (("loss", "loss"), ("color", "color_loss"), ("surface", "surface_loss"), ("eikonal", "eikonal_loss"),
                    ("mask", "mask_loss")):
         assert abs(losses[key].item() - float(g["loss/" + k])) <= 1e-4, k
