@@ -10,6 +10,9 @@
 //   VAR 2  viewdir_mlp + net_cs : [n3 | pts3 | PE4(reflect(-d, n^))27 | feature] -> specular (1; rows 1,2 of the output
 //          tile are padding with zero weights)
 // They differ in how the side inputs are built and in how the side gradients map back to d normal.
+// weight-prefetch depth of this file's kernels (stages; see dense() in mlp_engine.h): measured best at 4 / 8
+#define FNEUS_PREFETCH_X3 4
+#define FNEUS_PREFETCH_X1 8
 #include "mlp_engine.h"
 #include "fneus_kernels.h"
 

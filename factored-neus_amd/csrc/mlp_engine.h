@@ -11,13 +11,20 @@ constexpr int kMaxKS = 19;   // widest layer input on the path: colour layer 0 (
 // A fragments: blob + off_{hi,lo} + ((ks*NT_TOTAL + t)*64 + lane)*16 bytes, streamed from L2 through a small
 // register ring: work is cut into stages of GT tiles of one k-step; stage s+D is requested before stage s is
 // multiplied, and a scheduling barrier per stage stops hipcc from hoisting every load of the layer (which spills).
-template <int PREC, int KS, int NT_TOTAL, int T0, int TN, int KS0 = 0>
+// DEPTH = prefetch distance in stages (0: the default of the precision mode).  The chain-only kernel K1 is best at 2
+// (parity) / 4 (bf16); the kernels that interleave stash traffic with the chain (K2, K3) gain 8-12 % from 4 / 8 even
+// though the deeper register ring costs them a few more spills (measured, tools/experiments/README.md).
+template <int PREC, int KS, int NT_TOTAL, int T0, int TN, int KS0 = 0, int DEPTH = 0>
 FN_DEV void dense(const unsigned char* __restrict__ blob, uint32_t off_hi, uint32_t off_lo,
                   const BFrag<PREC> (&b)[kMaxKS], f32x16 (&acc)[TN], int lane) {
     constexpr int GT = TN < 4 ? TN : 4;                 // tiles per stage
     constexpr int NG = (TN + GT - 1) / GT;              // stages per k-step
     constexpr int NS = KS * NG;                         // stages
-    constexpr int D = PREC == 3 ? 2 : 4;                // prefetch distance (stages)
+#ifndef FNEUS_PREFETCH_X3
+#define FNEUS_PREFETCH_X3 2
+#define FNEUS_PREFETCH_X1 4
+#endif
+    constexpr int D = DEPTH > 0 ? DEPTH : (PREC == 3 ? FNEUS_PREFETCH_X3 : FNEUS_PREFETCH_X1);   // prefetch distance (stages)
     const bf16x8 FN_GLOBAL* __restrict__ whi = reinterpret_cast<const bf16x8 FN_GLOBAL*>((gblob_t)blob + off_hi) + lane;
     const bf16x8 FN_GLOBAL* __restrict__ wlo = reinterpret_cast<const bf16x8 FN_GLOBAL*>((gblob_t)blob + off_lo) + lane;
     bf16x8 ah[D + 1][GT], al[D + 1][GT];

@@ -38,6 +38,9 @@ FN_DEV void softplus_inplace(f32x16 (&acc)[TN]) {
 // ---- forward chain shared by K1/K2 -----------------------------------------------------------------------
 // On return acc9 holds z_8: tiles 0..7 = feature (natural order), tile 8 row 0 (reg 0 of lane half 0) = sdf.
 // If SDF_ONLY only tile 8 is computed (acc9[8]).  If STASH, H_{l+1} (l = 0..7) and PE are written.
+// prefetch depth of the kernels that carry stash traffic (K2, K3)
+template <int PREC> constexpr int kDeep = PREC == 3 ? 4 : 8;
+
 template <int PREC, bool SDF_ONLY, bool STASH>
 FN_DEV void sdf_forward_chain(const unsigned char* __restrict__ blob, const float (&pe)[39],
                               BFrag<PREC> (&bf)[kMaxKS], f32x16 (&acc)[9], const SdfStash& st, long N, long n,
@@ -46,6 +49,7 @@ FN_DEV void sdf_forward_chain(const unsigned char* __restrict__ blob, const floa
     const long n0 = tile * 32;
     unsigned char* psb = STASH ? st.ps + (size_t)tile * 8 * kSigBlockBytes : nullptr;
     constexpr auto& LY = kSdfLayout;
+    constexpr int DD = STASH ? kDeep<PREC> : 0;
     BFrag<PREC> pef[3];
     vec_to_bfrag<PREC, 39, 3, 0>(pe, bf, h);
 #pragma unroll
@@ -71,7 +75,7 @@ FN_DEV void sdf_forward_chain(const unsigned char* __restrict__ blob, const floa
     f32x16(&a8)[8] = reinterpret_cast<f32x16(&)[8]>(acc);
     // layer 0
     load_accvec<8, 0, 8>(blob, LY.L[0].bias, a8, lane);
-    dense<PREC, 3, 8, 0, 8>(blob, LY.L[0].fwd_hi, LY.L[0].fwd_lo, bf, a8, lane);
+    dense<PREC, 3, 8, 0, 8, 0, DD>(blob, LY.L[0].fwd_hi, LY.L[0].fwd_lo, bf, a8, lane);
     if constexpr (STASH) {
         softplus_ps<PREC, 8>(a8, psb, lane);
         store_stash<PREC, 8>(scr, lane, a8, st.h_hi, st.h_lo, 256, n0, N, 256);
@@ -82,7 +86,7 @@ FN_DEV void sdf_forward_chain(const unsigned char* __restrict__ blob, const floa
     // layers 1, 2
     for (int l = 1; l <= 2; ++l) {
         load_accvec<8, 0, 8>(blob, LY.L[l].bias, a8, lane);
-        dense<PREC, 16, 8, 0, 8>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, bf, a8, lane);
+        dense<PREC, 16, 8, 0, 8, 0, DD>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, bf, a8, lane);
         if constexpr (STASH) {
             softplus_ps<PREC, 8>(a8, psb + (size_t)l * kSigBlockBytes, lane);
             store_stash<PREC, 8>(scr, lane, a8, st.h_hi + (size_t)l * N * 256, st.h_lo + (size_t)l * N * 256, 256, n0, N, 256);
@@ -95,7 +99,7 @@ FN_DEV void sdf_forward_chain(const unsigned char* __restrict__ blob, const floa
     {
         f32x16(&a7)[7] = reinterpret_cast<f32x16(&)[7]>(acc);
         load_accvec<7, 0, 7>(blob, LY.L[3].bias, a7, lane);
-        dense<PREC, 16, 7, 0, 7>(blob, LY.L[3].fwd_hi, LY.L[3].fwd_lo, bf, a7, lane);
+        dense<PREC, 16, 7, 0, 7, 0, DD>(blob, LY.L[3].fwd_hi, LY.L[3].fwd_lo, bf, a7, lane);
         if constexpr (STASH) {
             softplus_ps<PREC, 7>(a7, psb + (size_t)3 * kSigBlockBytes, lane);
             store_stash<PREC, 7>(scr, lane, a7, st.h_hi + (size_t)3 * N * 256, st.h_lo + (size_t)3 * N * 256, 256, n0, N, 224);
@@ -108,7 +112,7 @@ FN_DEV void sdf_forward_chain(const unsigned char* __restrict__ blob, const floa
     }
     // layer 4 (17 k-steps; 1/sqrt2 folded into the pack)
     load_accvec<8, 0, 8>(blob, LY.L[4].bias, a8, lane);
-    dense<PREC, 17, 8, 0, 8>(blob, LY.L[4].fwd_hi, LY.L[4].fwd_lo, bf, a8, lane);
+    dense<PREC, 17, 8, 0, 8, 0, DD>(blob, LY.L[4].fwd_hi, LY.L[4].fwd_lo, bf, a8, lane);
     if constexpr (STASH) {
         softplus_ps<PREC, 8>(a8, psb + (size_t)4 * kSigBlockBytes, lane);
         store_stash<PREC, 8>(scr, lane, a8, st.h_hi + (size_t)4 * N * 256, st.h_lo + (size_t)4 * N * 256, 256, n0, N, 256);
@@ -119,7 +123,7 @@ FN_DEV void sdf_forward_chain(const unsigned char* __restrict__ blob, const floa
     // layers 5, 6, 7
     for (int l = 5; l <= 7; ++l) {
         load_accvec<8, 0, 8>(blob, LY.L[l].bias, a8, lane);
-        dense<PREC, 16, 8, 0, 8>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, bf, a8, lane);
+        dense<PREC, 16, 8, 0, 8, 0, DD>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, bf, a8, lane);
         if constexpr (STASH) {
             softplus_ps<PREC, 8>(a8, psb + (size_t)l * kSigBlockBytes, lane);
             store_stash<PREC, 8>(scr, lane, a8, st.h_hi + (size_t)l * N * 256, st.h_lo + (size_t)l * N * 256, 256, n0, N, 256);
@@ -132,10 +136,10 @@ FN_DEV void sdf_forward_chain(const unsigned char* __restrict__ blob, const floa
     if constexpr (SDF_ONLY) {
         f32x16(&a1)[1] = reinterpret_cast<f32x16(&)[1]>(acc[8]);
         load_accvec<9, 8, 1>(blob, LY.L[8].bias, a1, lane);
-        dense<PREC, 16, 9, 8, 1>(blob, LY.L[8].fwd_hi, LY.L[8].fwd_lo, bf, a1, lane);
+        dense<PREC, 16, 9, 8, 1, 0, DD>(blob, LY.L[8].fwd_hi, LY.L[8].fwd_lo, bf, a1, lane);
     } else {
         load_accvec<9, 0, 9>(blob, LY.L[8].bias, acc, lane);
-        dense<PREC, 16, 9, 0, 9>(blob, LY.L[8].fwd_hi, LY.L[8].fwd_lo, bf, acc, lane);
+        dense<PREC, 16, 9, 0, 9, 0, DD>(blob, LY.L[8].fwd_hi, LY.L[8].fwd_lo, bf, acc, lane);
     }
 }
 
@@ -223,7 +227,7 @@ __global__ void __launch_bounds__(64, 1) sdf_fwd_grad_kernel(const unsigned char
                 store_stash<PREC, 8>(scr, lane, g8, st.a_hi + (size_t)l * N * 256, st.a_lo + (size_t)l * N * 256, 256, n0, N, 256);
             acc_to_bfrag<PREC, 8>(g8, bf);
             zero_acc(g8);
-            dense<PREC, 16, 8, 0, 8>(blob, LY.L[l].rev_hi, LY.L[l].rev_lo, bf, g8, lane);
+            dense<PREC, 16, 8, 0, 8, 0, kDeep<PREC>>(blob, LY.L[l].rev_hi, LY.L[l].rev_lo, bf, g8, lane);
         }
         // layer 4: outputs 9 row tiles: 0..6 -> g_hat(h_4), 7..8 -> q_skip (PE part of the skip input)
         f32x16 qskip[2];
@@ -233,7 +237,7 @@ __global__ void __launch_bounds__(64, 1) sdf_fwd_grad_kernel(const unsigned char
                 store_stash<PREC, 8>(scr, lane, g8, st.a_hi + (size_t)4 * N * 256, st.a_lo + (size_t)4 * N * 256, 256, n0, N, 256);
             acc_to_bfrag<PREC, 8>(g8, bf);
             zero_acc(acc);
-            dense<PREC, 16, 9, 0, 9>(blob, LY.L[4].rev_hi, LY.L[4].rev_lo, bf, acc, lane);
+            dense<PREC, 16, 9, 0, 9, 0, kDeep<PREC>>(blob, LY.L[4].rev_hi, LY.L[4].rev_lo, bf, acc, lane);
             qskip[0] = acc[7];
             qskip[1] = acc[8];
         }
@@ -245,7 +249,7 @@ __global__ void __launch_bounds__(64, 1) sdf_fwd_grad_kernel(const unsigned char
                 store_stash<PREC, 7>(scr, lane, g7, st.a_hi + (size_t)3 * N * 256, st.a_lo + (size_t)3 * N * 256, 256, n0, N, 224);
             acc_to_bfrag<PREC, 7>(g7, bf);
             zero_acc(g8);
-            dense<PREC, 14, 8, 0, 8>(blob, LY.L[3].rev_hi, LY.L[3].rev_lo, bf, g8, lane);
+            dense<PREC, 14, 8, 0, 8, 0, kDeep<PREC>>(blob, LY.L[3].rev_hi, LY.L[3].rev_lo, bf, g8, lane);
         }
         for (int l = 2; l >= 1; --l) {
             mul_sig_priv<PREC, 8, TRAIN>(g8, psb + (size_t)(l) * kSigBlockBytes, pab + (size_t)(l) * PB, lane);
@@ -253,7 +257,7 @@ __global__ void __launch_bounds__(64, 1) sdf_fwd_grad_kernel(const unsigned char
                 store_stash<PREC, 8>(scr, lane, g8, st.a_hi + (size_t)l * N * 256, st.a_lo + (size_t)l * N * 256, 256, n0, N, 256);
             acc_to_bfrag<PREC, 8>(g8, bf);
             zero_acc(g8);
-            dense<PREC, 16, 8, 0, 8>(blob, LY.L[l].rev_hi, LY.L[l].rev_lo, bf, g8, lane);
+            dense<PREC, 16, 8, 0, 8, 0, kDeep<PREC>>(blob, LY.L[l].rev_hi, LY.L[l].rev_lo, bf, g8, lane);
         }
         // layer 0: 2 row tiles (39 PE inputs)
         f32x16 q[2];
@@ -262,7 +266,7 @@ __global__ void __launch_bounds__(64, 1) sdf_fwd_grad_kernel(const unsigned char
             if constexpr (TRAIN) store_stash<PREC, 8>(scr, lane, g8, st.a_hi, st.a_lo, 256, n0, N, 256);
             acc_to_bfrag<PREC, 8>(g8, bf);
             zero_acc(q);
-            dense<PREC, 16, 2, 0, 2>(blob, LY.L[0].rev_hi, LY.L[0].rev_lo, bf, q, lane);
+            dense<PREC, 16, 2, 0, 2, 0, kDeep<PREC>>(blob, LY.L[0].rev_hi, LY.L[0].rev_lo, bf, q, lane);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -384,20 +388,20 @@ __global__ void __launch_bounds__(64, 1) sdf_bwd_kernel(const unsigned char* blo
         }
         // ---- ascending chain ----
         zero_acc(a8);
-        dense<PREC, 3, 8, 0, 8>(blob, LY.L[0].fwd_hi, LY.L[0].fwd_lo, bf, a8, lane);
+        dense<PREC, 3, 8, 0, 8, 0, kDeep<PREC>>(blob, LY.L[0].fwd_hi, LY.L[0].fwd_lo, bf, a8, lane);
         asc_post<PREC, 8>(a8, psb, pab, cs, lane);
         store_stash<PREC, 8>(scr, lane, a8, bb.adj_hi, bb.adj_lo, 256, n0, N, 256);
         acc_to_bfrag<PREC, 8>(a8, bf);
         for (int l = 1; l <= 2; ++l) {
             zero_acc(a8);
-            dense<PREC, 16, 8, 0, 8>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, bf, a8, lane);
+            dense<PREC, 16, 8, 0, 8, 0, kDeep<PREC>>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, bf, a8, lane);
             asc_post<PREC, 8>(a8, psb + (size_t)(l) * kSigBlockBytes, pab + (size_t)(l) * PB, cs + (size_t)l * 32 * 64, lane);
             store_stash<PREC, 8>(scr, lane, a8, bb.adj_hi + l * LS, bb.adj_lo + l * LS, 256, n0, N, 256);
             acc_to_bfrag<PREC, 8>(a8, bf);
         }
         {
             zero_acc(a7);
-            dense<PREC, 16, 7, 0, 7>(blob, LY.L[3].fwd_hi, LY.L[3].fwd_lo, bf, a7, lane);
+            dense<PREC, 16, 7, 0, 7, 0, kDeep<PREC>>(blob, LY.L[3].fwd_hi, LY.L[3].fwd_lo, bf, a7, lane);
             asc_post<PREC, 7>(a7, psb + (size_t)(3) * kSigBlockBytes, pab + (size_t)(3) * PB, cs + (size_t)3 * 32 * 64, lane);
             store_stash<PREC, 7>(scr, lane, a7, bb.adj_hi + 3 * LS, bb.adj_lo + 3 * LS, 256, n0, N, 224);
             acc_to_bfrag<PREC, 7>(a7, bf);
@@ -406,14 +410,14 @@ __global__ void __launch_bounds__(64, 1) sdf_bwd_kernel(const unsigned char* blo
         }
         {
             zero_acc(a8);
-            dense<PREC, 17, 8, 0, 8>(blob, LY.L[4].fwd_hi, LY.L[4].fwd_lo, bf, a8, lane);
+            dense<PREC, 17, 8, 0, 8, 0, kDeep<PREC>>(blob, LY.L[4].fwd_hi, LY.L[4].fwd_lo, bf, a8, lane);
             asc_post<PREC, 8>(a8, psb + (size_t)(4) * kSigBlockBytes, pab + (size_t)(4) * PB, cs + (size_t)4 * 32 * 64, lane);
             store_stash<PREC, 8>(scr, lane, a8, bb.adj_hi + 4 * LS, bb.adj_lo + 4 * LS, 256, n0, N, 256);
             acc_to_bfrag<PREC, 8>(a8, bf);
         }
         for (int l = 5; l <= 7; ++l) {
             zero_acc(a8);
-            dense<PREC, 16, 8, 0, 8>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, bf, a8, lane);
+            dense<PREC, 16, 8, 0, 8, 0, kDeep<PREC>>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, bf, a8, lane);
             asc_post<PREC, 8>(a8, psb + (size_t)(l) * kSigBlockBytes, pab + (size_t)(l) * PB, cs + (size_t)l * 32 * 64, lane);
             store_stash<PREC, 8>(scr, lane, a8, bb.adj_hi + l * LS, bb.adj_lo + l * LS, 256, n0, N, 256);
             acc_to_bfrag<PREC, 8>(a8, bf);
@@ -427,35 +431,35 @@ __global__ void __launch_bounds__(64, 1) sdf_bwd_kernel(const unsigned char* blo
         store_stash<PREC, 1>(scr, lane, reinterpret_cast<f32x16(&)[1]>(acc[8]), bb.zsdf_hi, bb.zsdf_lo, 32, n0, N, 32);
         acc_to_bfrag<PREC, 9>(acc, bf);
         zero_acc(a8);
-        dense<PREC, 18, 8, 0, 8>(blob, LY.L[8].rev_hi, LY.L[8].rev_lo, bf, a8, lane);
+        dense<PREC, 18, 8, 0, 8, 0, kDeep<PREC>>(blob, LY.L[8].rev_hi, LY.L[8].rev_lo, bf, a8, lane);
         for (int l = 7; l >= 5; --l) {
             // here a8 = ubar_{l+1} = hbar_{l+1};  zbar_l = s_l * hbar_{l+1} + c_l
             desc_post<PREC, 8>(a8, psb + (size_t)(l) * kSigBlockBytes, cs + (size_t)l * 32 * 64, lane);
             store_stash<PREC, 8>(scr, lane, a8, bb.zbar_hi + l * LS, bb.zbar_lo + l * LS, 256, n0, N, 256);
             acc_to_bfrag<PREC, 8>(a8, bf);
             zero_acc(a8);
-            dense<PREC, 16, 8, 0, 8>(blob, LY.L[l].rev_hi, LY.L[l].rev_lo, bf, a8, lane);
+            dense<PREC, 16, 8, 0, 8, 0, kDeep<PREC>>(blob, LY.L[l].rev_hi, LY.L[l].rev_lo, bf, a8, lane);
         }
         {   // zbar_4, then ubar_4 restricted to the h_4 rows (7 tiles of the 9-tile reverse pack)
             desc_post<PREC, 8>(a8, psb + (size_t)(4) * kSigBlockBytes, cs + (size_t)4 * 32 * 64, lane);
             store_stash<PREC, 8>(scr, lane, a8, bb.zbar_hi + 4 * LS, bb.zbar_lo + 4 * LS, 256, n0, N, 256);
             acc_to_bfrag<PREC, 8>(a8, bf);
             zero_acc(a7);
-            dense<PREC, 16, 9, 0, 7>(blob, LY.L[4].rev_hi, LY.L[4].rev_lo, bf, a7, lane);
+            dense<PREC, 16, 9, 0, 7, 0, kDeep<PREC>>(blob, LY.L[4].rev_hi, LY.L[4].rev_lo, bf, a7, lane);
         }
         {   // zbar_3 (7 tiles), ubar_3
             desc_post<PREC, 7>(a7, psb + (size_t)(3) * kSigBlockBytes, cs + (size_t)3 * 32 * 64, lane);
             store_stash<PREC, 7>(scr, lane, a7, bb.zbar_hi + 3 * LS, bb.zbar_lo + 3 * LS, 256, n0, N, 224);
             acc_to_bfrag<PREC, 7>(a7, bf);
             zero_acc(a8);
-            dense<PREC, 14, 8, 0, 8>(blob, LY.L[3].rev_hi, LY.L[3].rev_lo, bf, a8, lane);
+            dense<PREC, 14, 8, 0, 8, 0, kDeep<PREC>>(blob, LY.L[3].rev_hi, LY.L[3].rev_lo, bf, a8, lane);
         }
         for (int l = 2; l >= 1; --l) {
             desc_post<PREC, 8>(a8, psb + (size_t)(l) * kSigBlockBytes, cs + (size_t)l * 32 * 64, lane);
             store_stash<PREC, 8>(scr, lane, a8, bb.zbar_hi + l * LS, bb.zbar_lo + l * LS, 256, n0, N, 256);
             acc_to_bfrag<PREC, 8>(a8, bf);
             zero_acc(a8);
-            dense<PREC, 16, 8, 0, 8>(blob, LY.L[l].rev_hi, LY.L[l].rev_lo, bf, a8, lane);
+            dense<PREC, 16, 8, 0, 8, 0, kDeep<PREC>>(blob, LY.L[l].rev_hi, LY.L[l].rev_lo, bf, a8, lane);
         }
         desc_post<PREC, 8>(a8, psb, cs, lane);
         store_stash<PREC, 8>(scr, lane, a8, bb.zbar_hi, bb.zbar_lo, 256, n0, N, 256);

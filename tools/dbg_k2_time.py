@@ -23,3 +23,8 @@ for prec in (3, 1):
     bufs = ops.SdfBwdBufs(n, dev, prec)
     ds, df, dn = torch.randn(n, device=dev), torch.randn(n, 256, device=dev), torch.randn(n, 3, device=dev)
     print("prec", prec, "K3", timeit(lambda: ops.sdf_bwd(net.blob, n, prec, st_t, bufs, ds, df, dn, pts=xx)))
+# small launches of K1 (the 16-new-samples evaluations of the hierarchical sampler: 8192 points)
+for prec in (3, 1):
+    for n_small in (8192, 32768):
+        xs = xx[:n_small].contiguous()
+        print("prec", prec, f"K1 n={n_small}", timeit(lambda: ops.sdf_fwd(net.blob, n_small, prec, pts=xs)))
