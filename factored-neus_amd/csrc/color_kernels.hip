@@ -103,12 +103,11 @@ FN_DEV void make_side(const float (&x)[3], const float (&d)[3], const float (&nr
 }
 
 template <int PREC, bool TRAIN, int VAR>
-__global__ void __launch_bounds__(64, 1) color_fwd_kernel(const unsigned char* blob, PointSrc src, long N,
-                                                          const float* __restrict__ dirs,      // [N][3] or nullptr (ray mode)
-                                                          const float* __restrict__ normal,    // [N][3]
-                                                          const float* __restrict__ feat,      // [N][256]
-                                                          ColStash st, float* __restrict__ rgb_out) {
-    __shared__ __attribute__((aligned(16))) unsigned char scr[kWaveScr];
+FN_DEV void color_fwd_body(unsigned char* scr, const unsigned char* blob, const PointSrc& src, long N,
+                           const float* __restrict__ dirs,      // [N][3] or nullptr (ray mode)
+                           const float* __restrict__ normal,    // [N][3]
+                           const float* __restrict__ feat,      // [N][256]
+                           const ColStash& st, float* __restrict__ rgb_out) {
     const int lane = threadIdx.x;
     const int r = lane & 31, h = lane >> 5;
     constexpr auto& LY = kColLayout;
@@ -191,16 +190,47 @@ __global__ void __launch_bounds__(64, 1) color_fwd_kernel(const unsigned char* b
     }
 }
 
-template <int PREC, int VAR>
-__global__ void __launch_bounds__(64, 1) color_bwd_kernel(const unsigned char* blob, long N,
-                                                          const float* __restrict__ d_rgb,   // [N][3]
-                                                          const float* __restrict__ rgb,     // [N][3] forward output
-                                                          ColStash st, float* __restrict__ d_feat /*[N][256]*/,
-                                                          float* __restrict__ d_normal /*[N][3]*/,
-                                                          // surface head only: the inputs the side vector was built from
-                                                          const float* __restrict__ normal, const float* __restrict__ dirs,
-                                                          const float* __restrict__ rays_d, int m) {
+template <int PREC, bool TRAIN, int VAR>
+__global__ void __launch_bounds__(64, 1) color_fwd_kernel(const unsigned char* blob, PointSrc src, long N,
+                                                          const float* __restrict__ dirs, const float* __restrict__ normal,
+                                                          const float* __restrict__ feat, ColStash st,
+                                                          float* __restrict__ rgb_out) {
     __shared__ __attribute__((aligned(16))) unsigned char scr[kWaveScr];
+    color_fwd_body<PREC, TRAIN, VAR>(scr, blob, src, N, dirs, normal, feat, st, rgb_out);
+}
+
+// both RefColor heads in one launch (blockIdx.y = head): at 2 samples per ray a head is 32 workgroups, i.e. the launch
+// is as long as ONE tile's chain whatever it contains; side by side the two heads cost one such latency instead of two
+struct HeadArgs {
+    const unsigned char* blob;
+    ColStash st;
+    float* out;            // forward: [N][3] output;  backward: d_feat [N][256]
+    const float* d_out;    // backward only: cotangent of the head's output [N][3]
+    const float* fwd_out;  // backward only: the head's forward output [N][3]
+    float* d_normal;       // backward only: [N][3]
+};
+
+template <int PREC, bool TRAIN>
+__global__ void __launch_bounds__(64, 1) refcolor_fwd_both_kernel(HeadArgs cd, HeadArgs vd, PointSrc src, long N,
+                                                                  const float* __restrict__ dirs,
+                                                                  const float* __restrict__ normal,
+                                                                  const float* __restrict__ feat) {
+    __shared__ __attribute__((aligned(16))) unsigned char scr[kWaveScr];
+    if (blockIdx.y == 0)
+        color_fwd_body<PREC, TRAIN, VAR_REF_DIFFUSE>(scr, cd.blob, src, N, dirs, normal, feat, cd.st, cd.out);
+    else
+        color_fwd_body<PREC, TRAIN, VAR_REF_SPECULAR>(scr, vd.blob, src, N, dirs, normal, feat, vd.st, vd.out);
+}
+
+template <int PREC, int VAR>
+FN_DEV void color_bwd_body(unsigned char* scr, const unsigned char* blob, long N,
+                           const float* __restrict__ d_rgb,   // [N][3]
+                           const float* __restrict__ rgb,     // [N][3] forward output
+                           const ColStash& st, float* __restrict__ d_feat /*[N][256]*/,
+                           float* __restrict__ d_normal /*[N][3]*/,
+                           // surface head only: the inputs the side vector was built from
+                           const float* __restrict__ normal, const float* __restrict__ dirs,
+                           const float* __restrict__ rays_d, int m) {
     const int lane = threadIdx.x;
     const int r = lane & 31, h = lane >> 5;
     constexpr auto& LY = kColLayout;
@@ -320,6 +350,28 @@ __global__ void __launch_bounds__(64, 1) color_bwd_kernel(const unsigned char* b
     }
 }
 
+template <int PREC, int VAR>
+__global__ void __launch_bounds__(64, 1) color_bwd_kernel(const unsigned char* blob, long N, const float* __restrict__ d_rgb,
+                                                          const float* __restrict__ rgb, ColStash st,
+                                                          float* __restrict__ d_feat, float* __restrict__ d_normal,
+                                                          const float* __restrict__ normal, const float* __restrict__ dirs,
+                                                          const float* __restrict__ rays_d, int m) {
+    __shared__ __attribute__((aligned(16))) unsigned char scr[kWaveScr];
+    color_bwd_body<PREC, VAR>(scr, blob, N, d_rgb, rgb, st, d_feat, d_normal, normal, dirs, rays_d, m);
+}
+
+template <int PREC>
+__global__ void __launch_bounds__(64, 1) refcolor_bwd_both_kernel(HeadArgs cd, HeadArgs vd, long N,
+                                                                  const float* __restrict__ normal,
+                                                                  const float* __restrict__ dirs,
+                                                                  const float* __restrict__ rays_d, int m) {
+    __shared__ __attribute__((aligned(16))) unsigned char scr[kWaveScr];
+    if (blockIdx.y == 0)
+        color_bwd_body<PREC, VAR_REF_DIFFUSE>(scr, cd.blob, N, cd.d_out, cd.fwd_out, cd.st, cd.out, cd.d_normal, normal, dirs, rays_d, m);
+    else
+        color_bwd_body<PREC, VAR_REF_SPECULAR>(scr, vd.blob, N, vd.d_out, vd.fwd_out, vd.st, vd.out, vd.d_normal, normal, dirs, rays_d, m);
+}
+
 }  // namespace fneus
 
 using namespace fneus;
@@ -415,4 +467,57 @@ extern "C" int fneus_refcolor_bwd(const void* blob, int head, long n_pts, const 
     if (head == VAR_REF_SPECULAR)
         return launch_bwd<VAR_REF_SPECULAR>(blob, n_pts, d_out, out, stash, d_feat, d_normal, normal, dirs, rays_d, m, prec, stream);
     return -2;
+}
+
+extern "C" int fneus_refcolor_fwd_both(const void* blob_cd, const void* blob_vd, const float* pts, const float* rays_o,
+                                       const float* rays_d, const float* t, int m, long n_pts, const float* dirs,
+                                       const float* normal, const float* feat, const FneusColStash* stash_cd,
+                                       const FneusColStash* stash_vd, float* diffuse_out, float* spec_out, int prec,
+                                       int train, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (n_pts <= 0) return 0;
+    PointSrc src{pts, rays_o, rays_d, t, m > 0 ? m : 1};
+    if (!pts && !rays_d) return -2;
+    if (pts && !dirs && !rays_d) return -2;
+    if (train && (!stash_cd || !stash_vd)) return -2;
+    HeadArgs cd{reinterpret_cast<const unsigned char*>(blob_cd), stash_cd ? ColStash(*stash_cd) : ColStash(), diffuse_out,
+                nullptr, nullptr, nullptr};
+    HeadArgs vd{reinterpret_cast<const unsigned char*>(blob_vd), stash_vd ? ColStash(*stash_vd) : ColStash(), spec_out,
+                nullptr, nullptr, nullptr};
+    if (train && (!cd.st.feat_hi || !vd.st.feat_hi)) return -2;
+    dim3 grid(grid_for((n_pts + 31) / 32), 2), blk(64);
+    if (prec == 3 && train)
+        hipLaunchKernelGGL((refcolor_fwd_both_kernel<3, true>), grid, blk, 0, stream, cd, vd, src, n_pts, dirs, normal, feat);
+    else if (prec == 3)
+        hipLaunchKernelGGL((refcolor_fwd_both_kernel<3, false>), grid, blk, 0, stream, cd, vd, src, n_pts, dirs, normal, feat);
+    else if (prec == 1 && train)
+        hipLaunchKernelGGL((refcolor_fwd_both_kernel<1, true>), grid, blk, 0, stream, cd, vd, src, n_pts, dirs, normal, feat);
+    else if (prec == 1)
+        hipLaunchKernelGGL((refcolor_fwd_both_kernel<1, false>), grid, blk, 0, stream, cd, vd, src, n_pts, dirs, normal, feat);
+    else
+        return -2;
+    return fneus::launch_status();
+}
+
+extern "C" int fneus_refcolor_bwd_both(const void* blob_cd, const void* blob_vd, long n_pts, const float* rays_d, int m,
+                                       const float* dirs, const float* normal, const float* d_diffuse, const float* d_spec,
+                                       const float* diffuse, const float* spec, const FneusColStash* stash_cd,
+                                       const FneusColStash* stash_vd, float* d_feat2, float* d_normal2, int prec,
+                                       fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (n_pts <= 0) return 0;
+    if (!stash_cd || !stash_vd || !normal || (!dirs && !rays_d)) return -2;
+    HeadArgs cd{reinterpret_cast<const unsigned char*>(blob_cd), ColStash(*stash_cd), d_feat2, d_diffuse, diffuse, d_normal2};
+    HeadArgs vd{reinterpret_cast<const unsigned char*>(blob_vd), ColStash(*stash_vd), d_feat2 + n_pts * 256, d_spec, spec,
+                d_normal2 + n_pts * 3};
+    dim3 grid(grid_for((n_pts + 31) / 32), 2), blk(64);
+    if (prec == 3)
+        hipLaunchKernelGGL(refcolor_bwd_both_kernel<3>, grid, blk, 0, stream, cd, vd, n_pts, normal, dirs, rays_d, m > 0 ? m : 1);
+    else if (prec == 1)
+        hipLaunchKernelGGL(refcolor_bwd_both_kernel<1>, grid, blk, 0, stream, cd, vd, n_pts, normal, dirs, rays_d, m > 0 ? m : 1);
+    else
+        return -2;
+    return fneus::launch_status();
 }

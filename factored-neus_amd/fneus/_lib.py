@@ -66,6 +66,10 @@ def _load():
         "fneus_color_bwd": (C.c_int, [vp, l, vp, vp, C.POINTER(FneusColStash), vp, vp, ip, vp]),
         "fneus_refcolor_fwd": (C.c_int, [vp, ip, vp, vp, vp, vp, ip, l, vp, vp, vp, C.POINTER(FneusColStash), vp, ip, ip, vp]),
         "fneus_refcolor_bwd": (C.c_int, [vp, ip, l, vp, ip, vp, vp, vp, vp, C.POINTER(FneusColStash), vp, vp, ip, vp]),
+        "fneus_refcolor_fwd_both": (C.c_int, [vp, vp, vp, vp, vp, vp, ip, l, vp, vp, vp, C.POINTER(FneusColStash),
+                                              C.POINTER(FneusColStash), vp, vp, ip, ip, vp]),
+        "fneus_refcolor_bwd_both": (C.c_int, [vp, vp, l, vp, ip, vp, vp, vp, vp, vp, vp, C.POINTER(FneusColStash),
+                                              C.POINTER(FneusColStash), vp, vp, ip, vp]),
         "fneus_dw_gemm": (C.c_int, [vp, ip, ip, l, ip, vp]),
         "fneus_surface_gather": (C.c_int, [vp, vp, vp, vp, vp, ip, ip, vp, vp, vp, vp, vp]),
         "fneus_stage1_loss": (C.c_int, [vp] * 10 + [ip, f, f, f] + [vp] * 10 + [vp]),

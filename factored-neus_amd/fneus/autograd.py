@@ -114,6 +114,47 @@ class ColorFn(torch.autograd.Function):
         return None, d_normal, d_feat, None, None, None, None, None, None, None
 
 
+class RefHeadsFn(torch.autograd.Function):
+    """Both MLPs of RefColor (fields.py:303-330) on the gathered surface samples: one forward launch, one backward
+    launch, one weight-gradient GEMM launch for the two networks.  Differentiable inputs: normal, feature."""
+
+    @staticmethod
+    def forward(ctx, anchor, normal, feat, net_cd, net_vd, samples: RaySamples, prec: int, ws: _Workspace, train: bool):
+        n = samples.n
+        normal, feat = normal.contiguous(), feat.contiguous()
+        st = ws.get(("ref_stash", n, prec), lambda: (ops.ColStash(n, anchor.device, prec, with_feat=True),
+                                                     ops.ColStash(n, anchor.device, prec, with_feat=True))) if train else (None, None)
+        diffuse, spec = ops.refcolor_fwd_both(net_cd.blob, net_vd.blob, n, prec, normal, feat, st[0], st[1], train,
+                                              dirs=samples.dirs, **samples.kw())
+        ctx.nets, ctx.prec, ctx.ws, ctx.st, ctx.n, ctx.samples = (net_cd, net_vd), prec, ws, st, n, samples
+        ctx.save_for_backward(diffuse, spec, normal)
+        return diffuse, spec
+
+    @staticmethod
+    def backward(ctx, d_diffuse, d_spec):
+        diffuse, spec, normal = ctx.saved_tensors
+        (net_cd, net_vd), n, prec, ws, st, sm = ctx.nets, ctx.n, ctx.prec, ctx.ws, ctx.st, ctx.samples
+        z = lambda g: torch.zeros(n, 3, device=normal.device) if g is None else g.contiguous()
+        d_feat2, d_normal2 = ops.refcolor_bwd_both(net_cd.blob, net_vd.blob, n, prec, z(d_diffuse), z(d_spec), diffuse, spec,
+                                                   st[0], st[1], normal, dirs=sm.dirs, rays_d=sm.rays_d, m=sm.m)
+        # one zeroed gradient buffer and one GEMM launch for both networks
+        grad = ws.get(("ref_grad", n), lambda: torch.empty(net_cd.n_params + net_vd.n_params, dtype=torch.float32,
+                                                           device=normal.device))
+        grad.zero_()
+        g_cd, g_vd = grad[:net_cd.n_params], grad[net_cd.n_params:]
+
+        def build():
+            jobs = ops.GemmJobs(grad.device, "refcolor")
+            ops.color_dw_jobs(net_cd, st[0].feat, st[0], g_cd, n, into=jobs)
+            ops.color_dw_jobs(net_vd, st[1].feat, st[1], g_vd, n, into=jobs)
+            return jobs.finalize()
+
+        ws.get(("ref_jobs", n, prec), build).run(n, prec)
+        net_cd.wn_backward(g_cd)
+        net_vd.wn_backward(g_vd)
+        return None, d_normal2.sum(0), d_feat2.sum(0), None, None, None, None, None, None
+
+
 class CompositeFn(torch.autograd.Function):
     """K5 forward / backward.  Differentiable inputs: sdf [N], normal [N,3], rgb [N,3], inv_s [1] and, for the womask
     background model, bg_alpha [B,n+n_out], bg_color [B,n+n_out,3].

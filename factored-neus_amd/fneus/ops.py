@@ -268,6 +268,32 @@ def color_bwd(blob, n_pts, prec, d_rgb, rgb, stash: ColStash, head: int = HEAD_C
     return d_feat, d_normal
 
 
+def refcolor_fwd_both(blob_cd, blob_vd, n_pts, prec, normal, feat, stash_cd, stash_vd, train: bool, pts=None, rays_o=None,
+                      rays_d=None, t=None, m: int = 1, dirs=None):
+    """both RefColor heads in one launch -> diffuse [n,3], spec [n,3] (column 0)"""
+    _chk_f32(normal, "normal")
+    _chk_f32(feat, "feat")
+    diffuse = torch.empty(n_pts, 3, dtype=torch.float32, device=feat.device)
+    spec = torch.empty(n_pts, 3, dtype=torch.float32, device=feat.device)
+    _launch("fneus_refcolor_fwd", lib.fneus_refcolor_fwd_both, _ptr(blob_cd), _ptr(blob_vd), _ptr(pts), _ptr(rays_o), _ptr(rays_d),
+            _ptr(t), m, n_pts, _ptr(dirs), _ptr(normal), _ptr(feat), C.byref(stash_cd.c) if stash_cd is not None else None,
+            C.byref(stash_vd.c) if stash_vd is not None else None, _ptr(diffuse), _ptr(spec), prec, int(train), _stream())
+    return diffuse, spec
+
+
+def refcolor_bwd_both(blob_cd, blob_vd, n_pts, prec, d_diffuse, d_spec, diffuse, spec, stash_cd, stash_vd, normal, dirs=None,
+                      rays_d=None, m: int = 1):
+    """-> d_feat2 [2,n,256], d_normal2 [2,n,3] (slice 0: diffuse head, slice 1: specular head)"""
+    for x, nm in ((d_diffuse, "d_diffuse"), (d_spec, "d_spec"), (normal, "normal")):
+        _chk_f32(x, nm)
+    d_feat2 = torch.empty(2, n_pts, 256, dtype=torch.float32, device=normal.device)
+    d_normal2 = torch.empty(2, n_pts, 3, dtype=torch.float32, device=normal.device)
+    _launch("fneus_refcolor_bwd", lib.fneus_refcolor_bwd_both, _ptr(blob_cd), _ptr(blob_vd), n_pts, _ptr(rays_d), m, _ptr(dirs),
+            _ptr(normal), _ptr(d_diffuse), _ptr(d_spec), _ptr(diffuse), _ptr(spec), C.byref(stash_cd.c), C.byref(stash_vd.c),
+            _ptr(d_feat2), _ptr(d_normal2), prec, _stream())
+    return d_feat2, d_normal2
+
+
 class GemmJobs:
     """Device job table for fneus_dw_gemm.  Built once per (buffers, N); pointers refer to live stash tensors."""
 
@@ -342,9 +368,11 @@ def sdf_dw_jobs(net: PackedNet, stash: SdfStash, bufs: SdfBwdBufs, grad_flat: to
     return g.finalize()
 
 
-def color_dw_jobs(net: PackedNet, feat_planes: torch.Tensor, stash: ColStash, grad_flat: torch.Tensor, n: int) -> GemmJobs:
-    """dW of a colour-shaped MLP (colour network: feat_planes = SdfStash.feat; RefColor heads: their own ColStash.feat)"""
-    g = GemmJobs(grad_flat.device, net.kind)
+def color_dw_jobs(net: PackedNet, feat_planes: torch.Tensor, stash: ColStash, grad_flat: torch.Tensor, n: int,
+                  into: Optional[GemmJobs] = None) -> GemmJobs:
+    """dW of a colour-shaped MLP (colour network: feat_planes = SdfStash.feat; RefColor heads: their own ColStash.feat).
+    `into`: append to that job table instead of finalising a new one (several small networks in one launch)."""
+    g = into if into is not None else GemmJobs(grad_flat.device, net.kind)
     offW, offb = net.desc["offW"], net.desc["offb"]
     n_side, ld0, n_out = net.desc["n_side"], net.desc["ins"][0], net.desc["outs"][4]
     base = grad_flat.data_ptr()
@@ -357,7 +385,7 @@ def color_dw_jobs(net: PackedNet, feat_planes: torch.Tensor, stash: ColStash, gr
               bias_ptr=base + 4 * offb[l])
     g.add(stash.zbar[:, 4], stash.u[:, 3], base + 4 * offW[4], 256, n_out, 256, 32, 256, 32, 256,
           bias_ptr=base + 4 * offb[4])
-    return g.finalize()
+    return g if into is not None else g.finalize()
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -17,7 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from fneus import ops
-from fneus.autograd import RaySamples, SdfValueGradFn, ColorFn, _Workspace
+from fneus.autograd import RaySamples, SdfValueGradFn, ColorFn, RefHeadsFn, _Workspace
 from models.embedder import get_embedder
 
 
@@ -325,11 +325,7 @@ class RefColor(nn.Module):
         x, n and the parameters"""
         self._cd.ensure()
         self._vd.ensure()
-        diffuse = ColorFn.apply(self._cd.anchor, n, x, self._cd.net, samples, self.prec, self._cd.ws, None, train,
-                                ops.HEAD_REF_DIFFUSE)
-        spec = ColorFn.apply(self._vd.anchor, n, x, self._vd.net, samples, self.prec, self._vd.ws, None, train,
-                             ops.HEAD_REF_SPECULAR)
-        return diffuse, spec
+        return RefHeadsFn.apply(self._cd.anchor, n, x, self._cd.net, self._vd.net, samples, self.prec, self._cd.ws, train)
 
     @staticmethod
     def shade(diffuse, spec):

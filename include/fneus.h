@@ -146,6 +146,19 @@ int fneus_refcolor_bwd(const void* blob, int head, long n_pts, const float* rays
                        const float* normal, const float* d_out, const float* out, const FneusColStash* stash,
                        float* d_feat, float* d_normal, int prec, fneus_stream_t stream);
 
+/* Both heads in ONE launch (the training step uses these: at 2 samples per ray a head is 32 workgroups, so a launch
+ * lasts one tile's chain whatever it contains).  spec_out [n][3] (column 0); d_feat2 [2][n][256] and d_normal2 [2][n][3]
+ * hold the diffuse head's input gradients in slice 0 and the specular head's in slice 1 (the caller adds them).          */
+int fneus_refcolor_fwd_both(const void* blob_cd, const void* blob_vd, const float* pts, const float* rays_o,
+                            const float* rays_d, const float* t, int m, long n_pts, const float* dirs, const float* normal,
+                            const float* feat, const FneusColStash* stash_cd, const FneusColStash* stash_vd,
+                            float* diffuse_out, float* spec_out, int prec, int train, fneus_stream_t stream);
+int fneus_refcolor_bwd_both(const void* blob_cd, const void* blob_vd, long n_pts, const float* rays_d, int m,
+                            const float* dirs, const float* normal, const float* d_diffuse, const float* d_spec,
+                            const float* diffuse, const float* spec, const FneusColStash* stash_cd,
+                            const FneusColStash* stash_vd, float* d_feat2, float* d_normal2, int prec,
+                            fneus_stream_t stream);
+
 /* ---- per-ray tail of the training step ------------------------------------------------------------------------ */
 /* The two samples bracketing the first SDF sign change of every ray (renderer.py:290-293, 316-327), packed for the
  * RefColor heads: sel [2B] (row index into the B*n samples), t_sel [2B], feat_sel [2B][256], normal_sel [2B][3].
