@@ -223,19 +223,31 @@ FN_DEV SecVals section_values(const float* o, const float* d, float mz, float di
     return v;
 }
 
+// inv_s_mode 0: *p is inv_s itself.  inv_s_mode 1: *p is the `variance` parameter of SingleVarianceNetwork and
+// inv_s = clip(exp(10 variance), 1e-6, 1e6) (fields.py:262-268, renderer.py:245); the backward kernel then returns the
+// per-ray gradient with respect to `variance` (clip passes the gradient on [1e-6, 1e6]).
+FN_DEV float load_inv_s(const float* p, int mode) {
+    return mode ? fminf(fmaxf(expf(10.0f * *p), 1e-6f), 1e6f) : *p;
+}
+FN_DEV float inv_s_chain(const float* p, int mode) {
+    if (!mode) return 1.0f;
+    const float e = expf(10.0f * *p);
+    return (e >= 1e-6f && e <= 1e6f) ? 10.0f * e : 0.0f;
+}
+
 // Background model (womask, renderer.py:350-356): when bg_alpha / bg_color [B][n + n_out] are given, inside the unit
 // sphere the SDF branch is used, outside the NeRF++ background, and n_out extra background samples are appended:
 //   alpha_i = alpha_i*inside_i + bg_alpha_i*(1 - inside_i)  (i < n),   alpha_i = bg_alpha_i  (n <= i < n + n_out)
 __global__ void __launch_bounds__(64) composite_fwd_kernel(
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ mid_z,
     const float* __restrict__ dists, const float* __restrict__ sdf, const float* __restrict__ normal,
-    const float* __restrict__ rgb, const float* __restrict__ inv_s_ptr, int n, float car,
+    const float* __restrict__ rgb, const float* __restrict__ inv_s_ptr, int inv_s_mode, int n, float car,
     const float* __restrict__ bg_alpha, const float* __restrict__ bg_color, int n_out,
     float* __restrict__ weights, float* __restrict__ color, float* __restrict__ wsum, float* __restrict__ wmax,
-    float* __restrict__ cdf_out, float* __restrict__ inside_out, float* __restrict__ eik /*[B][2]*/,
+    float* __restrict__ cdf_out, float* __restrict__ inside_out, float* __restrict__ eik /*[2][B]*/,
     int* __restrict__ min_idx_out, unsigned char* __restrict__ mask_out, float* __restrict__ wpair /*[B][2]*/) {
     const int ray = blockIdx.x, lane = threadIdx.x;
-    const float inv_s = *inv_s_ptr;
+    const float inv_s = load_inv_s(inv_s_ptr, inv_s_mode);
     const bool bg = bg_alpha != nullptr;
     const int nt = n + (bg ? n_out : 0);
     float o[3], d[3];
@@ -312,8 +324,8 @@ __global__ void __launch_bounds__(64) composite_fwd_kernel(
         for (int c = 0; c < 3; ++c) color[ray * 3 + c] = csum[c];
         wsum[ray] = ws;
         wmax[ray] = wm;
-        eik[ray * 2] = en;
-        eik[ray * 2 + 1] = ed;
+        eik[ray] = en;                       // planar: both rows are contiguous [B] vectors for the loss kernel
+        eik[gridDim.x + ray] = ed;
         min_idx_out[ray] = (idx < n) ? idx : 0;
         mask_out[ray] = mask ? 1 : 0;
         wpair[ray * 2] = wlo;
@@ -339,7 +351,7 @@ FN_DEV void excl_suffix_sum(const float (&v)[PER], float (&S)[PER], int lane) {
 __global__ void __launch_bounds__(64) composite_bwd_kernel(
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ mid_z,
     const float* __restrict__ dists, const float* __restrict__ sdf, const float* __restrict__ normal,
-    const float* __restrict__ rgb, const float* __restrict__ inv_s_ptr, int n, float car,
+    const float* __restrict__ rgb, const float* __restrict__ inv_s_ptr, int inv_s_mode, int n, float car,
     const float* __restrict__ bg_alpha, const float* __restrict__ bg_color, int n_out,
     const int* __restrict__ min_idx, const unsigned char* __restrict__ mask_in,
     const float* __restrict__ d_color /*[B][3]*/, const float* __restrict__ d_wsum /*[B]*/,
@@ -348,7 +360,7 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(
     float* __restrict__ d_rgb, float* __restrict__ d_inv_s /*[B]*/, float* __restrict__ d_bg_alpha /*[B][nt]*/,
     float* __restrict__ d_bg_color /*[B][nt][3]*/) {
     const int ray = blockIdx.x, lane = threadIdx.x;
-    const float inv_s = *inv_s_ptr;
+    const float inv_s = load_inv_s(inv_s_ptr, inv_s_mode);
     const bool bg = bg_alpha != nullptr;
     const int nt = n + (bg ? n_out : 0);
     float o[3], d[3], dc[3];
@@ -453,7 +465,41 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(
         }
     }
     dinv = wave_sum(dinv);
-    if (lane == 0) d_inv_s[ray] = dinv;
+    if (lane == 0) d_inv_s[ray] = dinv * inv_s_chain(inv_s_ptr, inv_s_mode);
+}
+
+// Coarse depths of a batch of rays: near / far of the unit sphere (dataset.py:186-192, near_far_from_sphere), the
+// n_samples uniform depths of renderer.py:393-395 and the per-ray jitter of renderer.py:405-409 in one launch
+// (the PyTorch formulation is 17 element-wise kernels on [B] / [B,64] tensors).  torch.linspace is reproduced
+// exactly: step * i from the start for the first half, end - step * (n - 1 - i) for the second.
+__global__ void __launch_bounds__(256) ray_setup_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                        const float* __restrict__ near_in, const float* __restrict__ far_in,
+                                                        const float* __restrict__ t_rand, int n_rays, int n,
+                                                        float* __restrict__ z_vals) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)n_rays * n) return;
+    const int ray = (int)(idx / n), i = (int)(idx - (long)ray * n);
+    float near, far;
+    if (near_in) {
+        near = near_in[ray];
+        far = far_in[ray];
+    } else {
+        float a = 0.0f, b = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float o = rays_o[ray * 3 + c], d = rays_d[ray * 3 + c];
+            a = __fadd_rn(a, __fmul_rn(d, d));
+            b = __fadd_rn(b, __fmul_rn(o, d));
+        }
+        const float mid = __fdiv_rn(__fmul_rn(0.5f, -__fmul_rn(2.0f, b)), a);
+        near = __fadd_rn(mid, -1.0f);
+        far = __fadd_rn(mid, 1.0f);
+    }
+    const float step = __fdiv_rn(1.0f, (float)(n - 1));
+    const float u = i < n / 2 ? __fmul_rn(step, (float)i) : __fadd_rn(1.0f, -__fmul_rn(step, (float)(n - 1 - i)));
+    float z = __fadd_rn(near, __fmul_rn(__fadd_rn(far, -near), u));
+    if (t_rand) z = __fadd_rn(z, __fdiv_rn(__fmul_rn(__fadd_rn(t_rand[ray], -0.5f), 2.0f), (float)n));
+    z_vals[idx] = z;
 }
 
 }  // namespace fneus
@@ -495,7 +541,7 @@ extern "C" int fneus_sections(const float* z, int n_rays, int n, float sample_di
 
 extern "C" int fneus_composite_fwd(const float* rays_o, const float* rays_d, const float* mid_z, const float* dists,
                                    const float* sdf, const float* normal, const float* rgb, const float* inv_s,
-                                   int n_rays, int n, float cos_anneal_ratio, const float* bg_alpha,
+                                   int inv_s_mode, int n_rays, int n, float cos_anneal_ratio, const float* bg_alpha,
                                    const float* bg_color, int n_out, float* weights, float* color, float* wsum,
                                    float* wmax, float* cdf, float* inside, float* eik, int32_t* min_idx,
                                    unsigned char* sdf_mask, float* wpair, fneus_stream_t stream_) {
@@ -504,14 +550,14 @@ extern "C" int fneus_composite_fwd(const float* rays_o, const float* rays_d, con
     if (n_rays <= 0) return 0;
     FN_CHECK_N(n + (bg_alpha ? n_out : 0));
     hipLaunchKernelGGL(composite_fwd_kernel, dim3(n_rays), dim3(64), 0, stream, rays_o, rays_d, mid_z, dists, sdf, normal,
-                       rgb, inv_s, n, cos_anneal_ratio, bg_alpha, bg_color, n_out, weights, color, wsum, wmax, cdf, inside,
+                       rgb, inv_s, inv_s_mode, n, cos_anneal_ratio, bg_alpha, bg_color, n_out, weights, color, wsum, wmax, cdf, inside,
                        eik, min_idx, sdf_mask, wpair);
     return fneus::launch_status();
 }
 
 extern "C" int fneus_composite_bwd(const float* rays_o, const float* rays_d, const float* mid_z, const float* dists,
                                    const float* sdf, const float* normal, const float* rgb, const float* inv_s,
-                                   int n_rays, int n, float cos_anneal_ratio, const float* bg_alpha,
+                                   int inv_s_mode, int n_rays, int n, float cos_anneal_ratio, const float* bg_alpha,
                                    const float* bg_color, int n_out, const int32_t* min_idx,
                                    const unsigned char* sdf_mask, const float* d_color, const float* d_wsum,
                                    const float* d_weights, const float* d_wpair, const float* d_eiknum, float* d_sdf,
@@ -522,7 +568,19 @@ extern "C" int fneus_composite_bwd(const float* rays_o, const float* rays_d, con
     if (n_rays <= 0) return 0;
     FN_CHECK_N(n + (bg_alpha ? n_out : 0));
     hipLaunchKernelGGL(composite_bwd_kernel, dim3(n_rays), dim3(64), 0, stream, rays_o, rays_d, mid_z, dists, sdf, normal,
-                       rgb, inv_s, n, cos_anneal_ratio, bg_alpha, bg_color, n_out, min_idx, sdf_mask, d_color, d_wsum,
+                       rgb, inv_s, inv_s_mode, n, cos_anneal_ratio, bg_alpha, bg_color, n_out, min_idx, sdf_mask, d_color, d_wsum,
                        d_weights, d_wpair, d_eiknum, d_sdf, d_normal, d_rgb, d_inv_s, d_bg_alpha, d_bg_color);
+    return fneus::launch_status();
+}
+
+extern "C" int fneus_ray_setup(const float* rays_o, const float* rays_d, const float* near, const float* far,
+                               const float* t_rand, int n_rays, int n_samples, float* z_vals, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    const long total = (long)n_rays * n_samples;
+    if (total <= 0) return 0;
+    if (n_samples < 2 || (near == nullptr) != (far == nullptr) || (!near && (!rays_o || !rays_d))) return -2;
+    hipLaunchKernelGGL(ray_setup_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, rays_o, rays_d, near, far,
+                       t_rand, n_rays, n_samples, z_vals);
     return fneus::launch_status();
 }

@@ -156,22 +156,25 @@ class RefHeadsFn(torch.autograd.Function):
 
 
 class CompositeFn(torch.autograd.Function):
-    """K5 forward / backward.  Differentiable inputs: sdf [N], normal [N,3], rgb [N,3], inv_s [1] and, for the womask
+    """K5 forward / backward.  Differentiable inputs: sdf [N], normal [N,3], rgb [N,3], variance (the scalar parameter
+    of SingleVarianceNetwork; inv_s = clip(exp(10 variance)) is applied inside the kernels) and, for the womask
     background model, bg_alpha [B,n+n_out], bg_color [B,n+n_out,3].
     Differentiable outputs: color [B,3], weights [B,n(+n_out)], wsum [B], wpair [B,2], eik_num [B]."""
 
     @staticmethod
-    def forward(ctx, sdf, normal, rgb, inv_s, rays_o, rays_d, mid_z, dists, car: float, bg_alpha=None, bg_color=None):
+    def forward(ctx, sdf, normal, rgb, variance, rays_o, rays_d, mid_z, dists, car: float, bg_alpha=None, bg_color=None):
         bga = None if bg_alpha is None else bg_alpha.contiguous()
         bgc = None if bg_color is None else bg_color.contiguous()
+        var1 = variance.detach().reshape(1).contiguous()
         out = ops.composite_fwd(rays_o, rays_d, mid_z, dists, sdf.contiguous(), normal.contiguous(), rgb.contiguous(),
-                                inv_s.contiguous(), car, bga, bgc)
-        ctx.car, ctx.has_bg = car, bga is not None
-        saved = [sdf, normal, rgb, inv_s, rays_o, rays_d, mid_z, dists, out["min_idx"], out["sdf_mask"]]
+                                var1, car, bga, bgc, inv_s_mode=1)
+        ctx.car, ctx.has_bg, ctx.var_shape = car, bga is not None, variance.shape
+        ctx.set_materialize_grads(False)        # unused outputs (e.g. `weights`) must not be zero-filled for us
+        saved = [sdf, normal, rgb, var1, rays_o, rays_d, mid_z, dists, out["min_idx"], out["sdf_mask"]]
         if ctx.has_bg:
             saved += [bga, bgc]
         ctx.save_for_backward(*saved)
-        eik_num, eik_den = out["eik"][:, 0].contiguous(), out["eik"][:, 1].contiguous()
+        eik_num, eik_den = out["eik"][0], out["eik"][1]
         nd = (out["wmax"], out["cdf"], out["inside"], eik_den, out["min_idx"], out["sdf_mask"])
         ctx.mark_non_differentiable(*nd)
         return (out["color"], out["weights"], out["wsum"], out["wpair"], eik_num) + nd
@@ -179,7 +182,7 @@ class CompositeFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_color, d_weights, d_wsum, d_wpair, d_eiknum, *unused):
         sv = ctx.saved_tensors
-        sdf, normal, rgb, inv_s, rays_o, rays_d, mid_z, dists, min_idx, sdf_mask = sv[:10]
+        sdf, normal, rgb, var1, rays_o, rays_d, mid_z, dists, min_idx, sdf_mask = sv[:10]
         bga, bgc = (sv[10], sv[11]) if ctx.has_bg else (None, None)
         B, n = mid_z.shape
         dev = mid_z.device
@@ -189,10 +192,10 @@ class CompositeFn(torch.autograd.Function):
         d_wpair = z(B, 2) if d_wpair is None else d_wpair.contiguous()
         d_eiknum = z(B) if d_eiknum is None else d_eiknum.contiguous()
         d_weights = None if d_weights is None else d_weights.contiguous()
-        d_sdf, d_normal, d_rgb, d_inv, d_bga, d_bgc = ops.composite_bwd(
-            rays_o, rays_d, mid_z, dists, sdf, normal, rgb, inv_s, ctx.car, min_idx, sdf_mask, d_color, d_wsum, d_weights,
-            d_wpair, d_eiknum, bga, bgc)
-        return d_sdf, d_normal, d_rgb, d_inv.sum().reshape(1), None, None, None, None, None, d_bga, d_bgc
+        d_sdf, d_normal, d_rgb, d_var, d_bga, d_bgc = ops.composite_bwd(
+            rays_o, rays_d, mid_z, dists, sdf, normal, rgb, var1, ctx.car, min_idx, sdf_mask, d_color, d_wsum, d_weights,
+            d_wpair, d_eiknum, bga, bgc, inv_s_mode=1)
+        return d_sdf, d_normal, d_rgb, d_var.sum().reshape(ctx.var_shape), None, None, None, None, None, d_bga, d_bgc
 
 
 class SurfaceGatherFn(torch.autograd.Function):

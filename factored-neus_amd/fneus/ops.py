@@ -443,6 +443,15 @@ def merge(z_old, s_old, z_new, s_new):
     return z_out, s_out
 
 
+def ray_setup(rays_o, rays_d, n_samples: int, near=None, far=None, t_rand=None):
+    """coarse depths z_vals [B, n_samples]; near / far None -> unit-sphere bounds computed from the rays"""
+    B = rays_o.shape[0]
+    z = torch.empty(B, n_samples, dtype=torch.float32, device=rays_o.device)
+    _launch("fneus_ray_setup", lib.fneus_ray_setup, _ptr(rays_o), _ptr(rays_d), _ptr(near), _ptr(far), _ptr(t_rand), B, n_samples,
+            _ptr(z), _stream())
+    return z
+
+
 def sections(z, sample_dist: float):
     B, n = z.shape
     dists = torch.empty_like(z)
@@ -451,7 +460,9 @@ def sections(z, sample_dist: float):
     return dists, mid_z
 
 
-def composite_fwd(rays_o, rays_d, mid_z, dists, sdf, normal, rgb, inv_s, car: float, bg_alpha=None, bg_color=None):
+def composite_fwd(rays_o, rays_d, mid_z, dists, sdf, normal, rgb, inv_s, car: float, bg_alpha=None, bg_color=None,
+                  inv_s_mode: int = 0):
+    """inv_s_mode 1: `inv_s` is the variance parameter (see include/fneus.h).  out["eik"] is [2, B]."""
     B, n = mid_z.shape
     n_out = 0 if bg_alpha is None else bg_alpha.shape[1] - n
     nt = n + n_out
@@ -460,11 +471,11 @@ def composite_fwd(rays_o, rays_d, mid_z, dists, sdf, normal, rgb, inv_s, car: fl
     out = {
         "weights": torch.empty(B, nt, **f32), "color": torch.empty(B, 3, **f32), "wsum": torch.empty(B, **f32),
         "wmax": torch.empty(B, **f32), "cdf": torch.empty(B, n, **f32), "inside": torch.empty(B, n, **f32),
-        "eik": torch.empty(B, 2, **f32), "min_idx": torch.empty(B, dtype=torch.int32, device=dev),
+        "eik": torch.empty(2, B, **f32), "min_idx": torch.empty(B, dtype=torch.int32, device=dev),
         "sdf_mask": torch.empty(B, dtype=torch.uint8, device=dev), "wpair": torch.empty(B, 2, **f32),
     }
     _launch("fneus_composite_fwd", lib.fneus_composite_fwd, _ptr(rays_o), _ptr(rays_d), _ptr(mid_z), _ptr(dists), _ptr(sdf),
-            _ptr(normal), _ptr(rgb), _ptr(inv_s), B, n, float(car), _ptr(bg_alpha), _ptr(bg_color), n_out,
+            _ptr(normal), _ptr(rgb), _ptr(inv_s), int(inv_s_mode), B, n, float(car), _ptr(bg_alpha), _ptr(bg_color), n_out,
             _ptr(out["weights"]), _ptr(out["color"]), _ptr(out["wsum"]), _ptr(out["wmax"]), _ptr(out["cdf"]),
             _ptr(out["inside"]), _ptr(out["eik"]), _ptr(out["min_idx"]), _ptr(out["sdf_mask"]), _ptr(out["wpair"]),
             _stream())
@@ -472,7 +483,7 @@ def composite_fwd(rays_o, rays_d, mid_z, dists, sdf, normal, rgb, inv_s, car: fl
 
 
 def composite_bwd(rays_o, rays_d, mid_z, dists, sdf, normal, rgb, inv_s, car, min_idx, sdf_mask, d_color, d_wsum,
-                  d_weights, d_wpair, d_eiknum, bg_alpha=None, bg_color=None):
+                  d_weights, d_wpair, d_eiknum, bg_alpha=None, bg_color=None, inv_s_mode: int = 0):
     B, n = mid_z.shape
     n_out = 0 if bg_alpha is None else bg_alpha.shape[1] - n
     dev = mid_z.device
@@ -483,7 +494,7 @@ def composite_bwd(rays_o, rays_d, mid_z, dists, sdf, normal, rgb, inv_s, car, mi
     d_bga = torch.empty_like(bg_alpha) if bg_alpha is not None else None
     d_bgc = torch.empty_like(bg_color) if bg_color is not None else None
     _launch("fneus_composite_bwd", lib.fneus_composite_bwd, _ptr(rays_o), _ptr(rays_d), _ptr(mid_z), _ptr(dists), _ptr(sdf),
-            _ptr(normal), _ptr(rgb), _ptr(inv_s), B, n, float(car), _ptr(bg_alpha), _ptr(bg_color), n_out, _ptr(min_idx),
+            _ptr(normal), _ptr(rgb), _ptr(inv_s), int(inv_s_mode), B, n, float(car), _ptr(bg_alpha), _ptr(bg_color), n_out, _ptr(min_idx),
             _ptr(sdf_mask), _ptr(d_color), _ptr(d_wsum), _ptr(d_weights), _ptr(d_wpair), _ptr(d_eiknum), _ptr(d_sdf),
             _ptr(d_normal), _ptr(d_rgb), _ptr(d_inv_s), _ptr(d_bga), _ptr(d_bgc), _stream())
     return d_sdf, d_normal, d_rgb, d_inv_s, d_bga, d_bgc

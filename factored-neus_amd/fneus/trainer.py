@@ -128,12 +128,10 @@ class Stage1Trainer:
 
     def _step_body(self, data, cos_anneal_ratio, background_rgb, with_optimizer: bool):
         rays_o, rays_d, true_rgb, mask = data[:, :3], data[:, 3:6], data[:, 6:9], data[:, 9:10]
-        a = (rays_d ** 2).sum(-1, keepdim=True)                       # near_far_from_sphere, dataset.py:186-192
-        b = 2.0 * (rays_o * rays_d).sum(-1, keepdim=True)
-        mid = 0.5 * (-b) / a
+        # near / far = None: near_far_from_sphere (dataset.py:186-192) is evaluated inside render's ray set-up launch
         # the losses of exp_runner.py:141-177 are evaluated inside render (fused with the surface shading and their own
         # gradients: one launch instead of ~200 element-wise kernels on [B]-ray tensors)
-        out = self.renderer.render(rays_o, rays_d, mid - 1.0, mid + 1.0, background_rgb=background_rgb,
+        out = self.renderer.render(rays_o, rays_d, None, None, background_rgb=background_rgb,
                                    cos_anneal_ratio=cos_anneal_ratio,
                                    loss_args=(true_rgb, mask, self.igr_weight, self.mask_weight, self.surface_weight))
         losses = out["losses"]

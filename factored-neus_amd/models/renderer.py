@@ -42,6 +42,22 @@ def sample_pdf(bins, weights, n_samples, det=False):
     return bin_b + (u - cdf_b) / denom * (bin_a - bin_b)
 
 
+class _LazySVal:
+    """`s_val` = 1 / inv_s for every sample (renderer.py:380) is a logging quantity: it is materialised on demand instead
+    of costing three element-wise launches in every training step."""
+
+    def __init__(self, deviation_network, B, n):
+        self.net, self.B, self.n = deviation_network, B, n
+
+    def per_sample(self):
+        with torch.no_grad():
+            return (1.0 / self.net.inv_s()).expand(self.B * self.n, 1)
+
+    def per_ray(self):      # mean over the samples of a ray (renderer.py:488) of identical values
+        with torch.no_grad():
+            return (1.0 / self.net.inv_s()).expand(self.B, 1)
+
+
 class NeuSRenderer:
     def __init__(self, n_samples, n_importance, n_outside, up_sample_steps, perturb, nerf=None, sdf_network=None,
                  deviation_network=None, color_network=None, refColor_network=None, lvis_network=None,
@@ -116,11 +132,11 @@ class NeuSRenderer:
         dists, mid_z = ops.sections(z_vals.contiguous(), sample_dist)
         samples = RaySamples(rays_o, rays_d, mid_z.reshape(-1), n)
         sdf, feat, normal = sdf_network.value_feature_normal(samples, train)
-        inv_s = deviation_network.inv_s()
         rgb = color_network.color_samples(samples, normal, feat, sdf_network, train)
+        # inv_s = clip(exp(10 variance)) (renderer.py:245) is applied inside the compositing kernels
         (color, weights, wsum, wpair, eik_num, wmax, cdf, inside, eik_den, min_idx, sdf_mask_u8) = CompositeFn.apply(
-            sdf, normal, rgb, inv_s, rays_o, rays_d, mid_z, dists, float(cos_anneal_ratio), background_alpha,
-            background_sampled_color)
+            sdf, normal, rgb, deviation_network.variance, rays_o, rays_d, mid_z, dists, float(cos_anneal_ratio),
+            background_alpha, background_sampled_color)
         sdf_mask = sdf_mask_u8.bool()
         if background_rgb is not None:
             color = color + background_rgb * (1.0 - wsum[:, None])
@@ -157,7 +173,7 @@ class NeuSRenderer:
 
         return {
             "color": color, "surface_color": surface_color, "sdf_mask": sdf_mask, "sdf": sdf[:, None], "dists": dists,
-            "gradients": normal.reshape(B, n, 3), "s_val": (1.0 / inv_s).expand(B * n, 1), "mid_z_vals": mid_z,
+            "gradients": normal.reshape(B, n, 3), "s_val": _LazySVal(deviation_network, B, n), "mid_z_vals": mid_z,
             "weights": weights, "cdf": cdf, "gradient_error": gradient_error, "inside_sphere": inside,
             "specular_color": specular_color, "diffuse_color": diffuse_color, "weight_max": wmax, "weight_sum": wsum,
             "losses": losses,
@@ -166,26 +182,33 @@ class NeuSRenderer:
     # ---- render (renderer.py:391-500) -------------------------------------------------------------------------------
     def render(self, rays_o, rays_d, near, far, perturb_overwrite=-1, background_rgb=None, cos_anneal_ratio=0.0,
                z_vals_override=None, loss_args=None):
-        """loss_args = (true_rgb [B,3], mask [B,1], igr_weight, mask_weight, surface_weight): also evaluate the training
+        """near / far [B,1], or both None for the unit-sphere bounds of dataset.py:186-192 (computed on the device).
+        loss_args = (true_rgb [B,3], mask [B,1], igr_weight, mask_weight, surface_weight): also evaluate the training
         losses of exp_runner.py:141-177 (fused with the surface shading, fneus_stage1_loss) -> out["losses"]"""
         dev = rays_o.device
         rays_o, rays_d = rays_o.float().contiguous(), rays_d.float().contiguous()
         B = len(rays_o)
         sample_dist = 2.0 / self.n_samples
-        z_vals = torch.linspace(0.0, 1.0, self.n_samples, device=dev)
-        z_vals = near + (far - near) * z_vals[None, :]
         z_vals_outside = None
         if self.n_outside > 0:                                                    # renderer.py:397-400
             z_vals_outside = torch.linspace(1e-3, 1.0 - 1.0 / (self.n_outside + 1.0), self.n_outside, device=dev)
         perturb = self.perturb if perturb_overwrite < 0 else perturb_overwrite
-        if perturb > 0:
-            t_rand = torch.rand([B, 1], device=dev) - 0.5
-            z_vals = z_vals + t_rand * 2.0 / self.n_samples
-            if self.n_outside > 0:                                                # renderer.py:411-416
-                mids = 0.5 * (z_vals_outside[1:] + z_vals_outside[:-1])
-                upper = torch.cat([mids, z_vals_outside[-1:]], -1)
-                lower = torch.cat([z_vals_outside[:1], mids], -1)
-                z_vals_outside = lower[None, :] + (upper - lower)[None, :] * torch.rand([B, self.n_outside], device=dev)
+        t_rand = torch.rand([B, 1], device=dev) if perturb > 0 else None
+        # z = near + (far - near) * linspace(0, 1, n) (+ jitter), renderer.py:393-409; near = None: unit-sphere bounds
+        # (dataset.py:186-192) computed in the same launch
+        if near is None:
+            z_vals = ops.ray_setup(rays_o, rays_d, self.n_samples, t_rand=t_rand)
+            if self.n_outside > 0:
+                a = (rays_d ** 2).sum(-1, keepdim=True)
+                far = 0.5 * (-2.0 * (rays_o * rays_d).sum(-1, keepdim=True)) / a + 1.0
+        else:
+            z_vals = ops.ray_setup(rays_o, rays_d, self.n_samples, near=near.float().reshape(-1).contiguous(),
+                                   far=far.float().reshape(-1).contiguous(), t_rand=t_rand)
+        if perturb > 0 and self.n_outside > 0:                                    # renderer.py:411-416
+            mids = 0.5 * (z_vals_outside[1:] + z_vals_outside[:-1])
+            upper = torch.cat([mids, z_vals_outside[-1:]], -1)
+            lower = torch.cat([z_vals_outside[:1], mids], -1)
+            z_vals_outside = lower[None, :] + (upper - lower)[None, :] * torch.rand([B, self.n_outside], device=dev)
         if self.n_outside > 0:                                                    # renderer.py:418-419
             z_vals_outside = far / torch.flip(z_vals_outside, dims=[-1]) + 1.0 / self.n_samples
         # networks changed since the last call (optimiser step): fold weight-norm and re-pack once
@@ -214,7 +237,7 @@ class NeuSRenderer:
             "color_fine": ret["color"],
             "surface_color": ret["surface_color"],
             "sdf_mask": ret["sdf_mask"],
-            "s_val": ret["s_val"].reshape(B, n).mean(dim=-1, keepdim=True),
+            "s_val": None if loss_args is not None else ret["s_val"].per_ray(),    # logging quantity: skipped in training steps
             "cdf_fine": ret["cdf"],
             "weight_sum": ret["weight_sum"][:, None],
             "weight_max": ret["weight_max"][:, None],

@@ -186,17 +186,27 @@ int fneus_upsample(const float* rays_o, const float* rays_d, const float* z, con
 /* cat_z_vals (renderer.py:191-205): stable sort-merge of (z_old | z_new); s_old/s_new/s_out may be NULL (last step) */
 int fneus_merge(const float* z_old, const float* s_old, int m, const float* z_new, const float* s_new, int k, int n_rays,
                 float* z_out, float* s_out, fneus_stream_t stream);
+/* Coarse depths: z_vals [B][n_samples] = near + (far - near) * linspace(0, 1, n_samples) (renderer.py:393-395), plus the
+ * per-ray jitter (t_rand[b] - 0.5) * 2 / n_samples when t_rand [B] (uniform in [0,1)) is given (renderer.py:405-409).
+ * near / far [B] as passed to NeuSRenderer.render, or both NULL: the unit-sphere bounds of dataset.py:186-192
+ * (near_far_from_sphere) are computed from the rays.                                                                 */
+int fneus_ray_setup(const float* rays_o, const float* rays_d, const float* near, const float* far, const float* t_rand,
+                    int n_rays, int n_samples, float* z_vals, fneus_stream_t stream);
+
 /* section lengths and mid points of render_core (renderer.py:223-226) */
 int fneus_sections(const float* z, int n_rays, int n, float sample_dist, float* dists, float* mid_z, fneus_stream_t stream);
 
 /* ---- K5: NeuS SDF->alpha, front-to-back compositing, eikonal sums, first sign change
  *      (renderer.py:245-274, 290-293, 328-332, 360-372).  Per-ray outputs: color [B][3], wsum/wmax [B],
- *      eik [B][2] = (sum relax*(|g|-1)^2, sum relax), min_idx [B], sdf_mask [B] (u8), wpair [B][2] = inside-sphere
- *      weights at min_idx-1 / min_idx (0 when !sdf_mask).  inv_s is a device scalar.
+ *      eik [2][B] = (sum relax*(|g|-1)^2 ; sum relax), min_idx [B], sdf_mask [B] (u8), wpair [B][2] = inside-sphere
+ *      weights at min_idx-1 / min_idx (0 when !sdf_mask).  inv_s is a device scalar: the value itself
+ *      (inv_s_mode 0), or the `variance` parameter of SingleVarianceNetwork (inv_s_mode 1; the kernels then apply
+ *      inv_s = clip(exp(10 variance), 1e-6, 1e6), fields.py:262-268 / renderer.py:245, and the backward returns the
+ *      gradient with respect to `variance`).
  *      With bg_alpha / bg_color (womask, renderer.py:350-356) samples outside the unit sphere take the background
  *      NeRF's alpha / colour and n_out background samples are appended (weights then have n + n_out columns). */
 int fneus_composite_fwd(const float* rays_o, const float* rays_d, const float* mid_z, const float* dists, const float* sdf,
-                        const float* normal, const float* rgb, const float* inv_s, int n_rays, int n,
+                        const float* normal, const float* rgb, const float* inv_s, int inv_s_mode, int n_rays, int n,
                         float cos_anneal_ratio, const float* bg_alpha /*[B][n+n_out] or NULL*/,
                         const float* bg_color /*[B][n+n_out][3] or NULL*/, int n_out,
                         float* weights /*[B][n (+n_out)]*/, float* color, float* wsum, float* wmax, float* cdf,
@@ -204,7 +214,7 @@ int fneus_composite_fwd(const float* rays_o, const float* rays_d, const float* m
                         fneus_stream_t stream);
 /* adjoint of fneus_composite_fwd; d_weights may be NULL; d_inv_s is per ray (caller sums). */
 int fneus_composite_bwd(const float* rays_o, const float* rays_d, const float* mid_z, const float* dists, const float* sdf,
-                        const float* normal, const float* rgb, const float* inv_s, int n_rays, int n,
+                        const float* normal, const float* rgb, const float* inv_s, int inv_s_mode, int n_rays, int n,
                         float cos_anneal_ratio, const float* bg_alpha, const float* bg_color, int n_out,
                         const int32_t* min_idx, const unsigned char* sdf_mask,
                         const float* d_color, const float* d_wsum, const float* d_weights, const float* d_wpair,

@@ -61,7 +61,7 @@ def test_fused_loss_matches_torch_formulation(B, mask_weight):
     (2.0 * loss).backward()                 # a non-unit cotangent must scale every gradient
     names = ["loss", "color_loss", "surface_loss", "eikonal_loss", "mask_loss", "psnr"]
     for i, k in enumerate(names):
-        a, b = float(lvec[i]), float(ref_losses[k])
+        a, b = float(lvec[i]), float(ref_losses[k].detach())
         assert abs(a - b) <= 2e-5 * max(1.0, abs(b)), (k, a, b)
     assert abs(float(loss) - float(ref_losses["loss"])) <= 2e-5
     assert (surf - ref_out["surface_color"]).abs().max().item() <= 1e-5

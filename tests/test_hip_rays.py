@@ -113,8 +113,8 @@ def test_composite_fwd_bwd(n, car, inv_s):
                   ("wpair", "wpair")):
         e = (out[k].cpu().double() - ref[rk].detach()).abs().max().item()
         assert e <= 2e-6, (k, e)
-    assert (out["eik"][:, 0].cpu().double() - ref["eik_num"].detach()).abs().max().item() <= 1e-5
-    assert torch.equal(out["eik"][:, 1].cpu().double(), ref["eik_den"])
+    assert (out["eik"][0].cpu().double() - ref["eik_num"].detach()).abs().max().item() <= 1e-5
+    assert torch.equal(out["eik"][1].cpu().double(), ref["eik_den"])
     d_sdf, d_nrm, d_rgb, d_inv, _, _ = ops.composite_bwd(d(ro), d(rd), d(mid_z), d(dists), d(sdf), d(normal), d(rgb),
                                                          inv_s_dev, car, out["min_idx"], out["sdf_mask"], d(c_col),
                                                          d(c_ws), d(c_w), d(c_pair), d(c_eik))
@@ -167,3 +167,24 @@ def test_composite_with_background(n, n_out):
     e_s = abs(g[3].sum().item() - s64.grad.item()) / (abs(s64.grad.item()) + 1e-30)
     print("composite+bg rel errs", ["%.1e" % e for e in errs], "inv_s %.1e" % e_s)
     assert max(errs) <= 2e-4 and e_s <= 2e-4
+
+
+@pytest.mark.parametrize("n,perturb", [(64, True), (64, False), (17, True)])
+def test_ray_setup_matches_torch_formulation(n, perturb):
+    """near_far_from_sphere (dataset.py:186-192) + the coarse depths and jitter of renderer.py:393-409 in one launch"""
+    from fneus import ops
+    from oracle import ref_torch as R
+    rs = np.random.RandomState(5)
+    B = 300
+    ro = torch.from_numpy(rs.uniform(-2, 2, size=(B, 3)).astype(np.float32)).to(DEV)
+    rd = torch.from_numpy(rs.standard_normal((B, 3)).astype(np.float32)).to(DEV)
+    rd = rd / rd.norm(dim=-1, keepdim=True)
+    t_rand = torch.from_numpy(rs.uniform(size=(B, 1)).astype(np.float32)).to(DEV) if perturb else None
+    near, far = R.near_far_from_sphere(ro, rd)
+    z = near + (far - near) * torch.linspace(0.0, 1.0, n, device=DEV)[None, :]
+    if perturb:
+        z = z + (t_rand - 0.5) * 2.0 / n
+    got = ops.ray_setup(ro, rd, n, t_rand=t_rand)
+    assert (got - z).abs().max().item() <= 5e-7
+    got2 = ops.ray_setup(ro, rd, n, near=near.reshape(-1).contiguous(), far=far.reshape(-1).contiguous(), t_rand=t_rand)
+    assert (got2 - z).abs().max().item() <= 2.5e-7      # given near / far: the same roundings as torch
