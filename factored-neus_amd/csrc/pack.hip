@@ -37,15 +37,20 @@ __global__ void __launch_bounds__(64) rowscale_kernel(const RowInfo* __restrict_
 
 // Backward of the fold W = g v/||v|| (+ bias pass-through): d_eff (effective layout: W then b per layer) -> raw grads.
 //   dg = <dW, v>/||v|| ;  dv = (g/||v||) (dW - v <dW, v>/||v||^2)
+// d_eff is CONSUMED: every value is cleared once it has been read, so the weight-gradient GEMM of the next step
+// accumulates (fp32 atomics) into a zeroed buffer without a memset.
 __global__ void __launch_bounds__(64) wn_backward_kernel(const RowInfo* __restrict__ rows, int n_rows,
                                                          const float* __restrict__ raw, const float* __restrict__ rowscale,
-                                                         const float* __restrict__ invnorm, const float* __restrict__ d_eff,
+                                                         const float* __restrict__ invnorm, float* __restrict__ d_eff,
                                                          float* __restrict__ d_raw) {
     const int row = blockIdx.x, lane = threadIdx.x;
     if (row >= n_rows) return;
     const RowInfo ri = rows[row];
     if (ri.off_g == 0xFFFFFFFFu) {
-        for (int i = lane; i < ri.n_in; i += 64) d_raw[ri.off_v + i] += d_eff[ri.off_w_eff + i];
+        for (int i = lane; i < ri.n_in; i += 64) {
+            d_raw[ri.off_v + i] += d_eff[ri.off_w_eff + i];
+            d_eff[ri.off_w_eff + i] = 0.0f;
+        }
         return;
     }
     float dot = 0.0f;
@@ -54,19 +59,23 @@ __global__ void __launch_bounds__(64) wn_backward_kernel(const RowInfo* __restri
     for (int d = 32; d >= 1; d >>= 1) dot += __shfl_xor(dot, d, 64);
     const float inv = invnorm[row], rs = rowscale[row];
     const float c = dot * inv * inv;
-    for (int i = lane; i < ri.n_in; i += 64)
+    for (int i = lane; i < ri.n_in; i += 64) {
         d_raw[ri.off_v + i] += rs * (d_eff[ri.off_w_eff + i] - raw[ri.off_v + i] * c);
+        d_eff[ri.off_w_eff + i] = 0.0f;
+    }
     if (lane == 0) d_raw[ri.off_g] += dot * inv;
 }
 
 __global__ void __launch_bounds__(256) add_segments_kernel(const int4* __restrict__ segs, int n_segs,
-                                                           const float* __restrict__ src, float* __restrict__ dst) {
-    // segs[i] = (src_off, dst_off, count, _): dst[dst_off + j] += src[src_off + j]   (bias gradients)
+                                                           float* __restrict__ src, float* __restrict__ dst) {
+    // segs[i] = (src_off, dst_off, count, _): dst[dst_off + j] += src[src_off + j]; src[...] = 0   (bias gradients)
     const int seg = blockIdx.y;
     if (seg >= n_segs) return;
     const int4 sg = segs[seg];
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < sg.z; j += gridDim.x * blockDim.x)
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < sg.z; j += gridDim.x * blockDim.x) {
         dst[sg.y + j] += src[sg.x + j];
+        src[sg.x + j] = 0.0f;
+    }
 }
 
 __global__ void __launch_bounds__(64) pack_kernel(const PackJob* __restrict__ jobs, int n_jobs,
@@ -150,7 +159,7 @@ extern "C" int fneus_rowscale(const void* rows, int n_rows, const float* raw, fl
 }
 
 extern "C" int fneus_wn_backward(const void* rows, int n_rows, const void* bias_segs, int n_segs, const float* raw,
-                                 const float* rowscale, const float* invnorm, const float* d_eff, float* d_raw,
+                                 const float* rowscale, const float* invnorm, float* d_eff, float* d_raw,
                                  fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     fneus::clear_status();

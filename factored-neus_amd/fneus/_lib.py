@@ -33,6 +33,11 @@ class FneusColStash(C.Structure):
                 ("side_hi", "side_lo", "u_hi", "u_lo", "zbar_hi", "zbar_lo", "mask", "feat_hi", "feat_lo")]
 
 
+class FneusAdamSegment(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("count", C.c_long)]
+
+
 class FneusGemmJob(C.Structure):
     _fields_ = [("a_hi", C.c_void_p), ("a_lo", C.c_void_p), ("b_hi", C.c_void_p), ("b_lo", C.c_void_p),
                 ("a2_hi", C.c_void_p), ("a2_lo", C.c_void_p), ("b2_hi", C.c_void_p), ("b2_lo", C.c_void_p),
@@ -71,6 +76,7 @@ def _load():
         "fneus_refcolor_bwd_both": (C.c_int, [vp, vp, l, vp, ip, vp, vp, vp, vp, vp, vp, C.POINTER(FneusColStash),
                                               C.POINTER(FneusColStash), vp, vp, ip, vp]),
         "fneus_dw_gemm": (C.c_int, [vp, ip, ip, l, ip, vp]),
+        "fneus_adam": (C.c_int, [C.POINTER(FneusAdamSegment), ip, vp, vp, C.c_double, C.c_double, C.c_double, ip, vp]),
         "fneus_surface_gather": (C.c_int, [vp, vp, vp, vp, vp, ip, ip, vp, vp, vp, vp, vp]),
         "fneus_stage1_loss": (C.c_int, [vp] * 10 + [ip, f, f, f] + [vp] * 10 + [vp]),
         "fneus_upsample": (C.c_int, [vp, vp, vp, vp, ip, ip, ip, f, vp, vp]),

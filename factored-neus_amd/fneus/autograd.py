@@ -66,8 +66,8 @@ class SdfValueGradFn(torch.autograd.Function):
                 d_normal.index_add_(0, sel, dns)
         bufs = ws.get(("sdf_bwd", n, prec), lambda: ops.SdfBwdBufs(n, dev, prec))
         ops.sdf_bwd(net.blob, n, prec, ctx.stash, bufs, d_sdf, d_feat, d_normal, **ctx.samples.kw())
-        grad = ws.get(("sdf_grad", n), lambda: torch.empty(net.n_params, dtype=torch.float32, device=dev))
-        grad.zero_()
+        # zeroed once: fneus_wn_backward clears what it reads, so the buffer is zero again after every step
+        grad = ws.get(("sdf_grad", n), lambda: torch.zeros(net.n_params, dtype=torch.float32, device=dev))
         jobs = ws.get(("sdf_jobs", n, prec), lambda: ops.sdf_dw_jobs(net, ctx.stash, bufs, grad, n))
         jobs.run(n, prec)
         net.wn_backward(grad)
@@ -106,8 +106,7 @@ class ColorFn(torch.autograd.Function):
             (rgb,) = ctx.saved_tensors
             d_feat, d_normal = ops.color_bwd(net.blob, n, prec, d_rgb.contiguous(), rgb, ctx.stash)
             feat_planes = ctx.sdf_ws.cache[("sdf_stash", n, prec, True)].feat
-        grad = ws.get(("col_grad", n), lambda: torch.empty(net.n_params, dtype=torch.float32, device=rgb.device))
-        grad.zero_()
+        grad = ws.get(("col_grad", n), lambda: torch.zeros(net.n_params, dtype=torch.float32, device=rgb.device))
         jobs = ws.get(("col_jobs", n, prec), lambda: ops.color_dw_jobs(net, feat_planes, ctx.stash, grad, n))
         jobs.run(n, prec)
         net.wn_backward(grad)
@@ -138,9 +137,8 @@ class RefHeadsFn(torch.autograd.Function):
         d_feat2, d_normal2 = ops.refcolor_bwd_both(net_cd.blob, net_vd.blob, n, prec, z(d_diffuse), z(d_spec), diffuse, spec,
                                                    st[0], st[1], normal, dirs=sm.dirs, rays_d=sm.rays_d, m=sm.m)
         # one zeroed gradient buffer and one GEMM launch for both networks
-        grad = ws.get(("ref_grad", n), lambda: torch.empty(net_cd.n_params + net_vd.n_params, dtype=torch.float32,
+        grad = ws.get(("ref_grad", n), lambda: torch.zeros(net_cd.n_params + net_vd.n_params, dtype=torch.float32,
                                                            device=normal.device))
-        grad.zero_()
         g_cd, g_vd = grad[:net_cd.n_params], grad[net_cd.n_params:]
 
         def build():

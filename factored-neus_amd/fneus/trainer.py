@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from fneus import ops, synth
+from fneus.optim import FlatAdam
 from fneus.parallel import FlatGradBucket
 
 WMASK_MODEL = {   # confs/wmask.conf:49-97
@@ -61,11 +62,13 @@ class Stage1Trainer:
         self.refColor_network.set_precision(prec)
         self.params = [p for m in self.modules for p in m.parameters()]
         self.use_graph = bool(use_graph) and device.type == "cuda"
-        if self.use_graph:   # capturable Adam: step counters and the learning rate live on the device
-            self.optimizer = torch.optim.Adam(self.params, lr=torch.tensor(float(lr), device=device), fused=True,
-                                              capturable=True)
-        else:
-            self.optimizer = torch.optim.Adam(self.params, lr=lr, fused=(device.type == "cuda"))
+        # the small torch modules get persistent gradient buffers (autograd accumulates into them in place): FlatAdam
+        # addresses parameters and gradients by pointer and clears the gradients itself
+        for m in (self.deviation_network, self.nerf_outside):
+            if m is not None:
+                for p in m.parameters():
+                    p.grad = torch.zeros_like(p)
+        self.optimizer = FlatAdam(self.params, lr=lr)
         self._graphs = {}            # (batch shape, cos_anneal_ratio) -> (CUDAGraph, static input, static losses)
         self._eager_steps = 0
         self.graph_warmup_steps = 2  # eager steps before the first capture (workspaces, job tables, LDS attributes)
@@ -77,15 +80,10 @@ class Stage1Trainer:
         self.iter_step = 0
 
     def set_lr(self, lr: float):
-        for g in self.optimizer.param_groups:
-            if torch.is_tensor(g["lr"]):
-                g["lr"].fill_(float(lr))
-            else:
-                g["lr"] = float(lr)
+        self.optimizer.set_lr(lr)
 
     def get_lr(self) -> float:
-        lr = self.optimizer.param_groups[0]["lr"]
-        return float(lr.item()) if torch.is_tensor(lr) else float(lr)
+        return float(self.optimizer.param_groups[0]["lr"])
 
     def train_step(self, data: torch.Tensor, cos_anneal_ratio: float = 1.0, background_rgb=None):
         """data [B,10] = rays_o, rays_d, rgb, mask (dataset.py:133-151).  Returns the loss dict (device tensors; with
@@ -142,16 +140,13 @@ class Stage1Trainer:
         return losses
 
     def zero_grad(self):
-        """one memset per fused MLP (their .grad alias flat buffers), set_to_none for the small torch modules"""
-        for net in (self.sdf_network, self.color_network):
-            if net._net is not None:
-                net._net.raw_grad.zero_()
-        for g in self.refColor_network.flat_grads():
-            g.zero_()
+        """nothing to launch: FlatAdam clears every gradient in its own pass, fneus_wn_backward the effective-gradient
+        buffers; only gradients that something else set to None get their buffer back"""
         for m in (self.deviation_network, self.nerf_outside):
             if m is not None:
                 for p in m.parameters():
-                    p.grad = None
+                    if p.grad is None:
+                        p.grad = torch.zeros_like(p)
 
     def render_only(self, data: torch.Tensor, cos_anneal_ratio: float = 1.0):
         rays_o, rays_d = data[:, :3], data[:, 3:6]

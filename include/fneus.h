@@ -73,6 +73,15 @@ typedef struct FneusGemmJob {
     int32_t b_w;       /* readable row width of B / B2                                                           */
 } FneusGemmJob;
 
+/* one contiguous run of parameters for fneus_adam (all device pointers) */
+typedef struct FneusAdamSegment {
+    float* param;
+    float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    long count;
+} FneusAdamSegment;
+
 /* ---- library ------------------------------------------------------------------------------------------------ */
 int fneus_version(void);                 /* 100*major + minor */
 const char* fneus_last_error(void);      /* host pointer, static storage */
@@ -92,9 +101,10 @@ int fneus_pack(const void* jobs, int n_jobs, int n_units, const int32_t* maps, c
 int fneus_rowscale(const void* rows, int n_rows, const float* raw, float* rowscale, float* invnorm,
                    fneus_stream_t stream);
 /* backward of the fold: effective-parameter gradients d_eff (W then b per layer) -> ACCUMULATED into the raw
- * parameter gradients d_raw (weight_v, weight_g, bias); bias_segs: device int4 (src_off, dst_off, count, 0). */
+ * parameter gradients d_raw (weight_v, weight_g, bias); bias_segs: device int4 (src_off, dst_off, count, 0).
+ * d_eff is consumed: it is all zeros afterwards (ready for the atomics of the next fneus_dw_gemm). */
 int fneus_wn_backward(const void* rows, int n_rows, const void* bias_segs, int n_segs, const float* raw,
-                      const float* rowscale, const float* invnorm, const float* d_eff, float* d_raw,
+                      const float* rowscale, const float* invnorm, float* d_eff, float* d_raw,
                       fneus_stream_t stream);
 
 /* ---- K1: SDFNetwork.sdf under no_grad  (fields.py:93-95 via renderer.py:199, 430, 515) -------------------- */
@@ -221,6 +231,12 @@ int fneus_composite_bwd(const float* rays_o, const float* rays_d, const float* m
                         const float* d_eiknum, float* d_sdf, float* d_normal, float* d_rgb, float* d_inv_s,
                         float* d_bg_alpha /*[B][n+n_out] or NULL*/, float* d_bg_color /*or NULL*/,
                         fneus_stream_t stream);
+
+/* ---- optimiser: torch.optim.Adam.step() over the whole model in one launch (exp_runner.py:108, 179-181) ---------- */
+/* segs: HOST array of contiguous parameter runs (32 per launch).  lr and step are device scalars (step is incremented first,
+ * then used for the bias corrections); no weight decay, no amsgrad.  zero_grad != 0 clears each gradient after use. */
+int fneus_adam(const FneusAdamSegment* segs, int n_segs, const float* lr, float* step, double beta1, double beta2,
+               double eps, int zero_grad, fneus_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -63,7 +63,7 @@ def test_fused_loss_matches_torch_formulation(B, mask_weight):
     for i, k in enumerate(names):
         a, b = float(lvec[i]), float(ref_losses[k].detach())
         assert abs(a - b) <= 2e-5 * max(1.0, abs(b)), (k, a, b)
-    assert abs(float(loss) - float(ref_losses["loss"])) <= 2e-5
+    assert abs(float(loss.detach()) - float(ref_losses["loss"].detach())) <= 2e-5
     assert (surf - ref_out["surface_color"]).abs().max().item() <= 1e-5
     assert (specc - ref_spec).abs().max().item() <= 1e-5
     assert (diffc - ref_diff).abs().max().item() <= 1e-5
