@@ -46,6 +46,7 @@ struct LossArgs {
     const float* spec;       // [2B][3] column 0 = net_cs output (after sigmoid)
     const float* wpair;      // [B][2]  compositing weights of the two bracketing samples
     const unsigned char* sdf_mask;   // [B]
+    const float* norms;      // optional [4]: sum mask, sum mask*sdf_mask, sum eik_den, ray count over the GLOBAL batch
     int B;
     float igr_weight, mask_weight, surface_weight;
     // outputs
@@ -156,18 +157,23 @@ __global__ void __launch_bounds__(kLossThreads) stage1_loss_kernel(LossArgs a) {
         acc[6] += -(m * logf(w) + (1.0f - m) * logf(1.0f - w));      // F.binary_cross_entropy (its -100 log clamp is moot here)
     }
     block_sum<8>(acc, red);
-    const float mask_sum = acc[0] + 1e-5f, mask_sdf_sum = acc[1] + 1e-5f, eik_den = acc[5] + 1e-5f;
+    // Normalisers: of this batch, or -- data parallel -- of the global batch (summed over the ranks by the caller), so
+    // that R ranks x B rays give exactly the loss and gradient of one R*B-ray batch once the ranks' results are summed.
+    const float mask_sum = (a.norms ? a.norms[0] : acc[0]) + 1e-5f;
+    const float mask_sdf_sum = (a.norms ? a.norms[1] : acc[1]) + 1e-5f;
+    const float eik_den = (a.norms ? a.norms[2] : acc[5]) + 1e-5f;
+    const float n_rays = a.norms ? a.norms[3] : (float)a.B;
     const float color_loss = acc[2] / mask_sum;
     const float surface_loss = acc[3] / mask_sdf_sum;
     const float eik_loss = acc[4] / eik_den;
-    const float mask_loss = acc[6] / (float)a.B;
+    const float mask_loss = acc[6] / n_rays;
     if (tid == 0) {
         a.losses[0] = color_loss + surface_loss + eik_loss * a.igr_weight + mask_loss * a.mask_weight;
         a.losses[1] = color_loss;
         a.losses[2] = surface_loss;
         a.losses[3] = eik_loss;
         a.losses[4] = mask_loss;
-        a.losses[5] = 20.0f * log10f(1.0f / sqrtf(acc[7] / (mask_sum * 3.0f)));
+        a.losses[5] = 20.0f * log10f(1.0f / sqrtf(acc[7] / ((acc[0] + 1e-5f) * 3.0f)));     // psnr of THIS batch
         a.losses[6] = mask_sum;
         a.losses[7] = mask_sdf_sum;
     }
@@ -207,7 +213,29 @@ __global__ void __launch_bounds__(kLossThreads) stage1_loss_kernel(LossArgs a) {
         const float wr = a.wsum[b];
         const bool in = wr >= 1e-3f && wr <= 1.0f - 1e-3f;
         const float w = fminf(fmaxf(wr, 1e-3f), 1.0f - 1e-3f);
-        a.d_wsum[b] = in ? a.mask_weight / (float)a.B * (-m / w + (1.0f - m) / (1.0f - w)) : 0.0f;
+        a.d_wsum[b] = in ? a.mask_weight / n_rays * (-m / w + (1.0f - m) / (1.0f - w)) : 0.0f;
+    }
+}
+
+// the batch sums that normalise the loss terms: [sum mask, sum mask*sdf_mask, sum eik_den, ray count]
+__global__ void __launch_bounds__(kLossThreads) stage1_norms_kernel(const float* __restrict__ mask_in,
+                                                                    const unsigned char* __restrict__ sdf_mask,
+                                                                    const float* __restrict__ eik_den, int B,
+                                                                    float mask_weight, float* __restrict__ norms) {
+    __shared__ float red[3 * 16];
+    float acc[3] = {0, 0, 0};
+    for (int b = threadIdx.x; b < B; b += kLossThreads) {
+        const float m = mask_weight > 0.0f ? (mask_in[b] > 0.5f ? 1.0f : 0.0f) : 1.0f;
+        acc[0] += m;
+        acc[1] += sdf_mask[b] ? m : 0.0f;
+        acc[2] += eik_den[b];
+    }
+    block_sum<3>(acc, red);
+    if (threadIdx.x == 0) {
+        norms[0] = acc[0];
+        norms[1] = acc[1];
+        norms[2] = acc[2];
+        norms[3] = (float)B;
     }
 }
 
@@ -229,16 +257,26 @@ extern "C" int fneus_surface_gather(const int32_t* min_idx, const unsigned char*
 
 extern "C" int fneus_stage1_loss(const float* color, const float* true_rgb, const float* mask_in, const float* wsum,
                                  const float* eik_num, const float* eik_den, const float* diffuse, const float* spec, const float* wpair,
-                                 const unsigned char* sdf_mask, int n_rays, float igr_weight, float mask_weight,
-                                 float surface_weight, float* losses, float* surface_color, float* specular_color,
+                                 const unsigned char* sdf_mask, const float* norms, int n_rays, float igr_weight,
+                                 float mask_weight, float surface_weight, float* losses, float* surface_color, float* specular_color,
                                  float* diffuse_color, float* d_color, float* d_wsum, float* d_eiknum, float* d_wpair,
                                  float* d_diffuse, float* d_spec, fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     fneus::clear_status();
     if (n_rays <= 0) return -2;
-    LossArgs a{color, true_rgb, mask_in, wsum, eik_num, eik_den, diffuse, spec, wpair, sdf_mask, n_rays, igr_weight, mask_weight,
+    LossArgs a{color, true_rgb, mask_in, wsum, eik_num, eik_den, diffuse, spec, wpair, sdf_mask, norms, n_rays, igr_weight, mask_weight,
                surface_weight, losses, surface_color, specular_color, diffuse_color, d_color, d_wsum, d_eiknum, d_wpair,
                d_diffuse, d_spec};
     hipLaunchKernelGGL(stage1_loss_kernel, dim3(1), dim3(kLossThreads), 0, stream, a);
+    return fneus::launch_status();
+}
+
+extern "C" int fneus_stage1_norms(const float* mask_in, const unsigned char* sdf_mask, const float* eik_den, int n_rays,
+                                  float mask_weight, float* norms, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (n_rays <= 0) return -2;
+    hipLaunchKernelGGL(stage1_norms_kernel, dim3(1), dim3(kLossThreads), 0, stream, mask_in, sdf_mask, eik_den, n_rays,
+                       mask_weight, norms);
     return fneus::launch_status();
 }

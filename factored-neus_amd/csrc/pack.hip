@@ -42,9 +42,22 @@ __global__ void __launch_bounds__(64) rowscale_kernel(const RowInfo* __restrict_
 __global__ void __launch_bounds__(64) wn_backward_kernel(const RowInfo* __restrict__ rows, int n_rows,
                                                          const float* __restrict__ raw, const float* __restrict__ rowscale,
                                                          const float* __restrict__ invnorm, float* __restrict__ d_eff,
-                                                         float* __restrict__ d_raw) {
+                                                         float* __restrict__ d_raw, const int4* __restrict__ segs,
+                                                         int n_segs) {
     const int row = blockIdx.x, lane = threadIdx.x;
-    if (row >= n_rows) return;
+    if (row >= n_rows) {
+        // workgroups behind the rows: bias gradients pass straight through,
+        // segs[i] = (src_off, dst_off, count, _): d_raw[dst_off + j] += d_eff[src_off + j]
+        const int seg = row - n_rows;
+        if (seg < n_segs) {
+            const int4 sg = segs[seg];
+            for (int j = lane; j < sg.z; j += 64) {
+                d_raw[sg.y + j] += d_eff[sg.x + j];
+                d_eff[sg.x + j] = 0.0f;
+            }
+        }
+        return;
+    }
     const RowInfo ri = rows[row];
     if (ri.off_g == 0xFFFFFFFFu) {
         for (int i = lane; i < ri.n_in; i += 64) {
@@ -64,18 +77,6 @@ __global__ void __launch_bounds__(64) wn_backward_kernel(const RowInfo* __restri
         d_eff[ri.off_w_eff + i] = 0.0f;
     }
     if (lane == 0) d_raw[ri.off_g] += dot * inv;
-}
-
-__global__ void __launch_bounds__(256) add_segments_kernel(const int4* __restrict__ segs, int n_segs,
-                                                           float* __restrict__ src, float* __restrict__ dst) {
-    // segs[i] = (src_off, dst_off, count, _): dst[dst_off + j] += src[src_off + j]; src[...] = 0   (bias gradients)
-    const int seg = blockIdx.y;
-    if (seg >= n_segs) return;
-    const int4 sg = segs[seg];
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < sg.z; j += gridDim.x * blockDim.x) {
-        dst[sg.y + j] += src[sg.x + j];
-        src[sg.x + j] = 0.0f;
-    }
 }
 
 __global__ void __launch_bounds__(64) pack_kernel(const PackJob* __restrict__ jobs, int n_jobs,
@@ -163,11 +164,9 @@ extern "C" int fneus_wn_backward(const void* rows, int n_rows, const void* bias_
                                  fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     fneus::clear_status();
-    if (n_rows > 0)
-        hipLaunchKernelGGL(fneus::wn_backward_kernel, dim3(n_rows), dim3(64), 0, stream,
-                           reinterpret_cast<const fneus::RowInfo*>(rows), n_rows, raw, rowscale, invnorm, d_eff, d_raw);
-    if (n_segs > 0)
-        hipLaunchKernelGGL(fneus::add_segments_kernel, dim3(2, n_segs), dim3(256), 0, stream,
-                           reinterpret_cast<const int4*>(bias_segs), n_segs, d_eff, d_raw);
+    if (n_rows + n_segs > 0)
+        hipLaunchKernelGGL(fneus::wn_backward_kernel, dim3(n_rows + n_segs), dim3(64), 0, stream,
+                           reinterpret_cast<const fneus::RowInfo*>(rows), n_rows, raw, rowscale, invnorm, d_eff, d_raw,
+                           reinterpret_cast<const int4*>(bias_segs), n_segs);
     return fneus::launch_status();
 }

@@ -93,6 +93,8 @@ class Runner:
             data = self.dataset.gen_random_rays_at(perm[self.iter_step % len(perm)], self.batch_size)
             losses = self.trainer.train_step(data, cos_anneal_ratio=self.get_cos_anneal_ratio(), background_rgb=bg)
             self.iter_step += 1
+            if self.iter_step % self.report_freq == 0:
+                losses = self.trainer.global_losses(losses)      # data parallel: every rank joins this small all-reduce
             if rank == 0 and self.iter_step % self.report_freq == 0:
                 print(self.base_exp_dir)
                 print("iter:{:8>d} loss = {} lr={}".format(self.iter_step, losses["loss"].item(),

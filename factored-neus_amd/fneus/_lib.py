@@ -78,7 +78,8 @@ def _load():
         "fneus_dw_gemm": (C.c_int, [vp, ip, ip, l, ip, vp]),
         "fneus_adam": (C.c_int, [C.POINTER(FneusAdamSegment), ip, vp, vp, C.c_double, C.c_double, C.c_double, ip, vp]),
         "fneus_surface_gather": (C.c_int, [vp, vp, vp, vp, vp, ip, ip, vp, vp, vp, vp, vp]),
-        "fneus_stage1_loss": (C.c_int, [vp] * 10 + [ip, f, f, f] + [vp] * 10 + [vp]),
+        "fneus_stage1_loss": (C.c_int, [vp] * 11 + [ip, f, f, f] + [vp] * 10 + [vp]),
+        "fneus_stage1_norms": (C.c_int, [vp, vp, vp, ip, f, vp, vp]),
         "fneus_upsample": (C.c_int, [vp, vp, vp, vp, ip, ip, ip, f, vp, vp]),
         "fneus_merge": (C.c_int, [vp, vp, ip, vp, vp, ip, ip, vp, vp, vp]),
         "fneus_sections": (C.c_int, [vp, ip, ip, f, vp, vp, vp]),

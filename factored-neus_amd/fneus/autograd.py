@@ -225,10 +225,14 @@ class Stage1LossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, color, wsum, eik_num, wpair, diffuse, spec, eik_den, true_rgb, mask_in, sdf_mask, igr_weight,
-                mask_weight, surface_weight):
-        o = ops.stage1_loss(color.contiguous(), true_rgb.contiguous(), mask_in.contiguous().reshape(-1), wsum.contiguous(),
+                mask_weight, surface_weight, reduce_norms=None):
+        mask_flat = mask_in.contiguous().reshape(-1)
+        norms = None
+        if reduce_norms is not None:       # data parallel: normalisers of the global batch
+            norms = reduce_norms(ops.stage1_norms(mask_flat, sdf_mask, eik_den.contiguous(), mask_weight))
+        o = ops.stage1_loss(color.contiguous(), true_rgb.contiguous(), mask_flat, wsum.contiguous(),
                             eik_num.contiguous(), eik_den.contiguous(), diffuse.contiguous(), spec.contiguous(),
-                            wpair.contiguous(), sdf_mask, igr_weight, mask_weight, surface_weight)
+                            wpair.contiguous(), sdf_mask, igr_weight, mask_weight, surface_weight, norms=norms)
         ctx.save_for_backward(o["d_color"], o["d_wsum"], o["d_eiknum"], o["d_wpair"], o["d_diffuse"], o["d_spec"])
         aux = (o["losses"], o["surface_color"], o["specular_color"], o["diffuse_color"])
         ctx.mark_non_differentiable(*aux)
@@ -237,4 +241,4 @@ class Stage1LossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, *unused):
         grads = torch._foreach_mul(list(ctx.saved_tensors), g)
-        return tuple(grads) + (None,) * 7
+        return tuple(grads) + (None,) * 8

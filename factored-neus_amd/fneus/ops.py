@@ -404,8 +404,16 @@ def surface_gather(min_idx, sdf_mask, mid_z, feat, normal):
     return sel, t_sel, feat_sel, normal_sel
 
 
+def stage1_norms(mask_in, sdf_mask, eik_den, mask_weight):
+    """[sum mask, sum mask*sdf_mask, sum eik_den, ray count] of this batch (to be summed over the ranks)"""
+    norms = torch.empty(4, dtype=torch.float32, device=mask_in.device)
+    _launch("fneus_stage1_norms", lib.fneus_stage1_norms, _ptr(mask_in), _ptr(sdf_mask), _ptr(eik_den), int(mask_in.numel()),
+            float(mask_weight), _ptr(norms), _stream())
+    return norms
+
+
 def stage1_loss(color, true_rgb, mask_in, wsum, eik_num, eik_den, diffuse, spec, wpair, sdf_mask, igr_weight, mask_weight,
-                surface_weight):
+                surface_weight, norms=None):
     """fused shading + losses + gradients (include/fneus.h fneus_stage1_loss); returns a dict of device tensors"""
     B = color.shape[0]
     dev = color.device
@@ -418,7 +426,7 @@ def stage1_loss(color, true_rgb, mask_in, wsum, eik_num, eik_den, diffuse, spec,
          "d_eiknum": torch.empty(B, **f32), "d_wpair": torch.empty(B, 2, **f32), "d_diffuse": torch.empty(2 * B, 3, **f32),
          "d_spec": torch.empty(2 * B, 3, **f32)}
     _launch("fneus_stage1_loss", lib.fneus_stage1_loss, _ptr(color), _ptr(true_rgb), _ptr(mask_in), _ptr(wsum), _ptr(eik_num),
-            _ptr(eik_den), _ptr(diffuse), _ptr(spec), _ptr(wpair), _ptr(sdf_mask), B, float(igr_weight), float(mask_weight),
+            _ptr(eik_den), _ptr(diffuse), _ptr(spec), _ptr(wpair), _ptr(sdf_mask), _ptr(norms), B, float(igr_weight), float(mask_weight),
             float(surface_weight), _ptr(o["losses"]), _ptr(o["surface_color"]), _ptr(o["specular_color"]),
             _ptr(o["diffuse_color"]), _ptr(o["d_color"]), _ptr(o["d_wsum"]), _ptr(o["d_eiknum"]), _ptr(o["d_wpair"]),
             _ptr(o["d_diffuse"]), _ptr(o["d_spec"]), _stream())

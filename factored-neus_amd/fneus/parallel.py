@@ -52,6 +52,15 @@ class FlatGradBucket:
             if p.grad is not None:
                 p.grad.copy_(v)
 
+    def allreduce_sum(self, group=None):
+        """plain sum over ranks: with global loss normalisers (reduce_loss_norms) every rank's gradient is already its
+        share of the global batch's gradient"""
+        if not dist.is_initialized() or dist.get_world_size(group) == 1:
+            return
+        self.gather()
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        self.scatter()
+
     def allreduce_mean(self, group=None):
         """sum over ranks, divide by world size (every rank must call this every step: no data-dependent skipping)"""
         if not dist.is_initialized() or dist.get_world_size(group) == 1:
@@ -60,6 +69,14 @@ class FlatGradBucket:
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
         self.flat.div_(dist.get_world_size(group))
         self.scatter()
+
+
+def reduce_loss_norms(norms: torch.Tensor, group=None) -> torch.Tensor:
+    """[sum mask, sum mask*sdf_mask, sum eik_den, ray count] of this rank -> of the global batch (SURVEY.md section 8(e):
+    the small all-reduce BEFORE the loss that makes R ranks x B rays equal to one R*B-ray batch).  In place."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(norms, op=dist.ReduceOp.SUM, group=group)
+    return norms
 
 
 def broadcast_parameters(modules, src: int = 0, group=None):

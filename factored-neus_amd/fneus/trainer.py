@@ -17,7 +17,7 @@ import torch
 
 from fneus import ops, synth
 from fneus.optim import FlatAdam
-from fneus.parallel import FlatGradBucket
+from fneus.parallel import FlatGradBucket, reduce_loss_norms
 
 WMASK_MODEL = {   # confs/wmask.conf:49-97
     "sdf_network": dict(d_out=257, d_in=3, d_hidden=256, n_layers=8, skip_in=[4], multires=6, bias=0.5, scale=1.0,
@@ -61,7 +61,10 @@ class Stage1Trainer:
         self.color_network.set_precision(prec)
         self.refColor_network.set_precision(prec)
         self.params = [p for m in self.modules for p in m.parameters()]
-        self.use_graph = bool(use_graph) and device.type == "cuda"
+        # data parallel: a 4-float all-reduce of the loss normalisers sits in the middle of the step, so the step is not
+        # captured as one graph there (eager launches run ahead of the GPU anyway)
+        self.use_graph = bool(use_graph) and device.type == "cuda" and not distributed
+        self.reduce_norms = reduce_loss_norms if distributed else None
         # the small torch modules get persistent gradient buffers (autograd accumulates into them in place): FlatAdam
         # addresses parameters and gradients by pointer and clears the gradients itself
         for m in (self.deviation_network, self.nerf_outside):
@@ -101,8 +104,8 @@ class Stage1Trainer:
         graph, static_data, losses = entry
         static_data.copy_(data)
         graph.replay()
-        if self.bucket is not None:      # the collective and the (fused, few-launch) optimiser step stay outside
-            self.bucket.allreduce_mean()
+        if self.bucket is not None:      # (not reached today: distributed runs are eager, see __init__)
+            self.bucket.allreduce_sum()
             self.optimizer.step()
         self.iter_step += 1
         return losses
@@ -118,7 +121,7 @@ class Stage1Trainer:
     def _eager_step(self, data, cos_anneal_ratio, background_rgb):
         losses = self._step_body(data, cos_anneal_ratio, background_rgb, with_optimizer=False)
         if self.bucket is not None:
-            self.bucket.allreduce_mean()
+            self.bucket.allreduce_sum()      # losses are normalised by the GLOBAL batch: the rank gradients just add up
         self.optimizer.step()
         self.iter_step += 1
         self._eager_steps += 1
@@ -131,13 +134,28 @@ class Stage1Trainer:
         # gradients: one launch instead of ~200 element-wise kernels on [B]-ray tensors)
         out = self.renderer.render(rays_o, rays_d, None, None, background_rgb=background_rgb,
                                    cos_anneal_ratio=cos_anneal_ratio,
-                                   loss_args=(true_rgb, mask, self.igr_weight, self.mask_weight, self.surface_weight))
+                                   loss_args=(true_rgb, mask, self.igr_weight, self.mask_weight, self.surface_weight,
+                                              self.reduce_norms))
         losses = out["losses"]
         self.zero_grad()
         losses["loss"].backward()
         if with_optimizer:
             self.optimizer.step()
         return losses
+
+    def global_losses(self, losses: dict) -> dict:
+        """data parallel: the loss terms of a step are this rank's SHARE of the global batch's; sum them over the ranks
+        (one small all-reduce; call it on every rank, e.g. only when logging)"""
+        import torch.distributed as dist
+        if self.bucket is None or not dist.is_initialized() or dist.get_world_size() == 1:
+            return losses
+        keys = ["loss", "color_loss", "surface_loss", "eikonal_loss", "mask_loss"]
+        v = torch.stack([losses[k].detach().reshape(()) for k in keys])
+        dist.all_reduce(v, op=dist.ReduceOp.SUM)
+        out = dict(losses)
+        for i, k in enumerate(keys):
+            out[k] = v[i]
+        return out
 
     def zero_grad(self):
         """nothing to launch: FlatAdam clears every gradient in its own pass, fneus_wn_backward the effective-gradient

@@ -152,10 +152,11 @@ class NeuSRenderer:
             surf = RaySamples(rays_o, rays_d, t_sel, 2)
             diffuse, spec = refColor_network.heads(surf, feat_sel, normal_sel, train)
             if loss_args is not None:     # shading, blend, losses and their gradients in one launch (training step)
-                true_rgb, mask_in, igr_w, mask_w, surf_w = loss_args
+                true_rgb, mask_in, igr_w, mask_w, surf_w = loss_args[:5]
+                reduce_norms = loss_args[5] if len(loss_args) > 5 else None
                 loss, lvec, surface_color, specular_color, diffuse_color = Stage1LossFn.apply(
                     color, wsum, eik_num, wpair, diffuse, spec, eik_den, true_rgb, mask_in, sdf_mask_u8, float(igr_w),
-                    float(mask_w), float(surf_w))
+                    float(mask_w), float(surf_w), reduce_norms)
                 losses = {"loss": loss, "color_loss": lvec[1], "surface_loss": lvec[2], "eikonal_loss": lvec[3],
                           "mask_loss": lvec[4], "psnr": lvec[5]}
             else:
@@ -183,8 +184,10 @@ class NeuSRenderer:
     def render(self, rays_o, rays_d, near, far, perturb_overwrite=-1, background_rgb=None, cos_anneal_ratio=0.0,
                z_vals_override=None, loss_args=None):
         """near / far [B,1], or both None for the unit-sphere bounds of dataset.py:186-192 (computed on the device).
-        loss_args = (true_rgb [B,3], mask [B,1], igr_weight, mask_weight, surface_weight): also evaluate the training
-        losses of exp_runner.py:141-177 (fused with the surface shading, fneus_stage1_loss) -> out["losses"]"""
+        loss_args = (true_rgb [B,3], mask [B,1], igr_weight, mask_weight, surface_weight[, reduce_norms]): also evaluate
+        the training losses of exp_runner.py:141-177 (fused with the surface shading, fneus_stage1_loss) ->
+        out["losses"].  reduce_norms(norms[4]) -> norms[4]: data parallel, sums the loss normalisers over the ranks;
+        the loss terms are then this rank's share of the global batch's (sum them, and the gradients, over the ranks)."""
         dev = rays_o.device
         rays_o, rays_d = rays_o.float().contiguous(), rays_d.float().contiguous()
         B = len(rays_o)

@@ -184,10 +184,16 @@ int fneus_surface_gather(const int32_t* min_idx, const unsigned char* sdf_mask, 
 int fneus_stage1_loss(const float* color /*[B][3]*/, const float* true_rgb /*[B][3]*/, const float* mask_in /*[B]*/,
                       const float* wsum /*[B]*/, const float* eik_num /*[B]*/, const float* eik_den /*[B]*/,
                       const float* diffuse /*[2B][3]*/, const float* spec /*[2B][3], column 0*/, const float* wpair /*[B][2]*/,
-                      const unsigned char* sdf_mask /*[B]*/, int n_rays, float igr_weight, float mask_weight,
-                      float surface_weight, float* losses, float* surface_color /*[B][3]*/, float* specular_color,
+                      const unsigned char* sdf_mask /*[B]*/, const float* norms /*[4] or NULL*/, int n_rays,
+                      float igr_weight, float mask_weight, float surface_weight, float* losses, float* surface_color /*[B][3]*/, float* specular_color,
                       float* diffuse_color, float* d_color, float* d_wsum, float* d_eiknum, float* d_wpair,
                       float* d_diffuse /*[2B][3]*/, float* d_spec /*[2B][3]*/, fneus_stream_t stream);
+
+/* Data parallel: norms[4] = (sum mask, sum mask*sdf_mask, sum eik_den, ray count) of this rank's batch.  Sum them over
+ * the ranks (a 4-float all-reduce) and pass the result to fneus_stage1_loss: its loss terms and gradients are then this
+ * rank's share of the GLOBAL batch's, and the gradient all-reduce is a plain sum.  norms = NULL: one batch, one rank. */
+int fneus_stage1_norms(const float* mask_in, const unsigned char* sdf_mask, const float* eik_den, int n_rays,
+                       float mask_weight, float* norms, fneus_stream_t stream);
 
 /* ---- K6: hierarchical sampler pieces (one wavefront per ray, 2 <= samples per ray <= 256) ---------------------- */
 /* NeuSRenderer.up_sample + sample_pdf(det=True)  (renderer.py:152-189, 43-77): z [B][m], sdf [B][m] -> z_new [B][k]  */

@@ -1,0 +1,63 @@
+"""Data-parallel semantics on ONE GPU: two half batches evaluated with the normalisers of the whole batch must add up
+to exactly the loss and the parameter gradients of the whole batch (R ranks x B rays == one
+R*B-ray batch).  The collectives themselves are covered by the gloo tests in tests/test_host_cpu.py."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _trainer():
+    from fneus import ops
+    from fneus.trainer import Stage1Trainer, WMASK_MODEL
+    conf = copy.deepcopy(WMASK_MODEL)
+    conf["neus_renderer"]["perturb"] = 0.0
+    return Stage1Trainer(torch.device("cuda:0"), model_conf=conf, prec=ops.PREC_PARITY, seed=5, use_graph=False)
+
+
+def _grads(tr):
+    return [p.grad.detach().clone() for p in tr.params]
+
+
+def _clear(tr):
+    for p in tr.params:
+        p.grad.zero_()
+
+
+def test_two_half_batches_with_global_normalisers_equal_the_full_batch():
+    from fneus.trainer import synthetic_batches
+    dev = torch.device("cuda:0")
+    full = synthetic_batches(1, 256, dev, seed0=777)[0]
+    halves = [full[:128].contiguous(), full[128:].contiguous()]
+    tr = _trainer()
+    # reference: the whole batch on one "rank"
+    tr._step_body(full, 1.0, None, with_optimizer=False)          # first call attaches the flat gradient buffers
+    _clear(tr)
+    ref_losses = tr._step_body(full, 1.0, None, with_optimizer=False)
+    ref_losses = {k: float(v.detach()) for k, v in ref_losses.items()}
+    ref = _grads(tr)
+    _clear(tr)
+    # "rank 0" and "rank 1": first collect each half's normalisers (what the all-reduce would sum) ...
+    seen = []
+    tr.reduce_norms = lambda n: (seen.append(n.clone()), n)[1]
+    for h in halves:
+        tr._step_body(h, 1.0, None, with_optimizer=False)
+    _clear(tr)
+    total = seen[0] + seen[1]
+    assert float(total[3]) == 256.0
+    # ... then run both halves against the global normalisers; the gradients accumulate like an all-reduce(SUM)
+    tr.reduce_norms = lambda n: total
+    parts = [tr._step_body(h, 1.0, None, with_optimizer=False) for h in halves]
+    got = _grads(tr)
+    for k in ("loss", "color_loss", "surface_loss", "eikonal_loss", "mask_loss"):
+        s = sum(float(p[k].detach()) for p in parts)
+        assert abs(s - ref_losses[k]) <= 2e-6 * max(1.0, abs(ref_losses[k])), (k, s, ref_losses[k])
+    worst = 0.0
+    for g, r, p in zip(got, ref, tr.params):
+        scale = r.abs().max().item() + 1e-12
+        worst = max(worst, (g - r).abs().max().item() / scale)
+    print(f"  two half batches vs full batch: worst relative gradient difference {worst:.2e}")
+    assert worst <= 2e-3        # fp32 atomics / summation order only (the K2-K3 chains are evaluated per sample)

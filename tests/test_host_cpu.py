@@ -131,9 +131,16 @@ def _dp_worker(rank, world, port, q):
     local = [p.grad.clone() for p in net.parameters()]
     bucket = FlatGradBucket(net.parameters())
     bucket.allreduce_mean()
+    mean = [p.grad.numpy().copy() for p in net.parameters()]
+    # the training step's own pattern: loss normalisers summed before the loss, gradients summed after the backward
+    from fneus.parallel import reduce_loss_norms
+    norms = reduce_loss_norms(torch.tensor([3.0 + rank, 1.0 + rank, 10.0 * (rank + 1), 6.0]))
+    for p, g in zip(net.parameters(), local):
+        p.grad = g.clone()
+    bucket.allreduce_sum()
     # by value (numpy), not shared-memory tensor handles: the worker may exit before the parent reads the queue
-    q.put((rank, [p.detach().numpy().copy() for p in net.parameters()], [g.numpy().copy() for g in local],
-           [p.grad.numpy().copy() for p in net.parameters()]))
+    q.put((rank, [p.detach().numpy().copy() for p in net.parameters()], [g.numpy().copy() for g in local], mean,
+           [p.grad.numpy().copy() for p in net.parameters()], norms.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -151,9 +158,12 @@ def test_data_parallel_bucket_gloo_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, p0, l0, g0), (_, p1, l1, g1) = res
+    (_, p0, l0, g0, s0, n0), (_, p1, l1, g1, s1, n1) = res
     for a, b in zip(p0, p1):
         assert np.array_equal(a, b)                       # identical replicas after the broadcast
     for a, b, m0, m1 in zip(g0, g1, l0, l1):
         assert np.array_equal(a, b)                       # identical reduced gradients on both ranks
         assert np.allclose(a, (m0 + m1) / 2, atol=1e-6)
+    for a, b, m0, m1 in zip(s0, s1, l0, l1):
+        assert np.array_equal(a, b) and np.allclose(a, m0 + m1, atol=1e-6)       # allreduce_sum
+    assert np.array_equal(n0, n1) and np.array_equal(n0, np.array([7.0, 3.0, 30.0, 12.0], dtype=np.float32))
