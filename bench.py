@@ -165,7 +165,7 @@ def main():
         "data": "synthetic DTU-shaped rays (one camera per step), random-init weights of the reference distributions",
         "config": {"workload": "dtu_scan97-shaped wmask.conf stage-1 SDF+radiance train step, 512 rays x (64+64) samples, "
                                "1xMI355X per rank", "rays_per_gpu": RAYS, "samples_per_ray": N_SAMPLES + N_IMPORTANCE,
-                   "parallelism": f"dp{world} (ray-sharded replicas, flat-bucket gradient all-reduce)",
+                   "parallelism": f"dp{world} (ray-sharded replicas, one in-place all-reduce of the gradient arena)",
                    "launch": "one hipGraph replay per step" if tr.use_graph and tr._graphs else "eager kernel launches"},
         "mfma_roofline_frac_step": value / world * FLOP_TRAIN_PER_SAMPLE / (PEAK_BF16_MFMA_TFLOPS * 1e12),
     }
@@ -190,6 +190,21 @@ def main():
                               "avg_launch_ms": per[dom]["avg_ms"],
                               "note": "algorithmic (fp32-equivalent) FLOPs per launch / HIP-event launch duration; "
                                       "parity mode issues 3 bf16 MFMAs per algorithmic product"}
+
+    if rank == 0 and world == 1 and not args.no_fast_extra:
+        # forward-only render of the same batch (what validate_image runs per ray chunk), SURVEY.md section 8(d)
+        fb = synthetic_batches(4, RAYS, device, rank=rank)
+        for b in fb[:2]:
+            tr.render_only(b)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_fwd = 20
+        for i in range(n_fwd):
+            tr.render_only(fb[i % len(fb)])
+        torch.cuda.synchronize()
+        dt_r = (time.perf_counter() - t0) / n_fwd
+        result["forward_only_render"] = {"value": SAMPLES_PER_STEP / dt_r, "unit": "ray-samples/s", "ms_per_call": dt_r * 1e3,
+                                         "note": "NeuSRenderer.render under no_grad, eager launches, no stash written"}
 
     if rank == 0 and world == 1 and not args.no_fast_extra and prec == ops.PREC_PARITY:
         dt_f, _, _ = run(ops.PREC_FAST, max(args.steps // 2, 5), 3, profile=False)

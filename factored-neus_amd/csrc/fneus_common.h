@@ -64,6 +64,9 @@ FN_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // softplus_beta(z) = max(z,0) + log(1 + exp(-beta|z|)) / beta      (== torch softplus incl. its threshold rule to fp32)
 FN_DEV float softplus100(float z) {
+#ifdef FNEUS_DBG_CHEAP_ACT     // timing experiment only: how much of K1 is activation VALU work
+    return fmaxf(z, 0.0f);
+#endif
     float e = fast_exp2(-fabsf(z) * (kBeta * kLog2e));
     return fmaxf(z, 0.0f) + fast_log2(1.0f + e) * (kLn2 / kBeta);
 }

@@ -65,7 +65,7 @@ class PackedNet:
     packer and its backward in fneus_wn_backward, so a step needs 2 + 2 small launches per network instead of ~150
     torch element-wise kernels."""
 
-    def __init__(self, kind: str, device):
+    def __init__(self, kind: str, device, raw_grad: Optional[torch.Tensor] = None):
         builders = {"sdf": netdesc.build_sdf_jobs, "color": netdesc.build_color_jobs,
                     "refcd": netdesc.build_refcd_jobs, "refvd": netdesc.build_refvd_jobs}
         desc = builders[kind]()
@@ -84,7 +84,11 @@ class PackedNet:
         self.rowscale = torch.zeros(self.n_rows, dtype=torch.float32, device=device)
         self.invnorm = torch.zeros(self.n_rows, dtype=torch.float32, device=device)
         self.raw = torch.zeros(self.n_raw, dtype=torch.float32, device=device)
-        self.raw_grad = torch.zeros(self.n_raw, dtype=torch.float32, device=device)
+        if raw_grad is None:
+            raw_grad = torch.zeros(self.n_raw, dtype=torch.float32, device=device)
+        elif raw_grad.numel() != self.n_raw or raw_grad.dtype != torch.float32 or not raw_grad.is_contiguous():
+            raise ValueError(f"raw_grad must be a contiguous fp32 tensor of {self.n_raw} values")
+        self.raw_grad = raw_grad      # may be a slice of a model-wide gradient arena (fneus/parallel.py GradArena)
 
     # ---- raw parameter views (what the nn.Parameters of the module alias) ----
     def raw_views(self, buf):

@@ -71,6 +71,44 @@ class FlatGradBucket:
         self.scatter()
 
 
+class GradArena:
+    """ONE contiguous fp32 buffer holding the gradient of every parameter of the model.  The fused MLPs put their flat
+    gradient buffers into slices of it, the small torch modules get persistent `.grad` views: the data-parallel exchange
+    is a single in-place all-reduce of `flat` with no gather / scatter copies, and the optimiser sees adjacent segments."""
+
+    def __init__(self, device, fused_modules, ref_color, small_modules):
+        sizes = [m.n_raw() for m in fused_modules] + (ref_color.n_raw() if ref_color is not None else [])
+        small = [p for m in small_modules if m is not None for p in m.parameters()]
+        total = sum(sizes) + sum(p.numel() for p in small)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=device)
+        off = 0
+        slices = []
+        for n in sizes:
+            slices.append(self.flat[off: off + n])
+            off += n
+        for m, sl in zip(fused_modules, slices):
+            m.use_grad_buffer(sl)
+        if ref_color is not None:
+            ref_color.use_grad_buffers(slices[-2], slices[-1])
+        for p in small:
+            p.grad = self.flat[off: off + p.numel()].view_as(p)
+            off += p.numel()
+        self.small = small
+        self._small_views = [p.grad for p in small]
+
+    def restore_small_grads(self):
+        """something set a small parameter's .grad to None (or replaced it): point it back at its arena view"""
+        for p, v in zip(self.small, self._small_views):
+            if p.grad is not v:
+                if p.grad is not None:
+                    v.copy_(p.grad)
+                p.grad = v
+
+    def allreduce_sum(self, group=None):
+        if dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+
+
 def reduce_loss_norms(norms: torch.Tensor, group=None) -> torch.Tensor:
     """[sum mask, sum mask*sdf_mask, sum eik_den, ray count] of this rank -> of the global batch (SURVEY.md section 8(e):
     the small all-reduce BEFORE the loss that makes R ranks x B rays equal to one R*B-ray batch).  In place."""

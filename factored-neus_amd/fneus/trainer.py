@@ -17,7 +17,7 @@ import torch
 
 from fneus import ops, synth
 from fneus.optim import FlatAdam
-from fneus.parallel import FlatGradBucket, reduce_loss_norms
+from fneus.parallel import GradArena, reduce_loss_norms
 
 WMASK_MODEL = {   # confs/wmask.conf:49-97
     "sdf_network": dict(d_out=257, d_in=3, d_hidden=256, n_layers=8, skip_in=[4], multires=6, bias=0.5, scale=1.0,
@@ -65,12 +65,11 @@ class Stage1Trainer:
         # captured as one graph there (eager launches run ahead of the GPU anyway)
         self.use_graph = bool(use_graph) and device.type == "cuda" and not distributed
         self.reduce_norms = reduce_loss_norms if distributed else None
-        # the small torch modules get persistent gradient buffers (autograd accumulates into them in place): FlatAdam
-        # addresses parameters and gradients by pointer and clears the gradients itself
-        for m in (self.deviation_network, self.nerf_outside):
-            if m is not None:
-                for p in m.parameters():
-                    p.grad = torch.zeros_like(p)
+        # every gradient of the model lives in ONE arena: the fused MLPs accumulate into slices of it, the small torch
+        # modules get persistent .grad views (autograd accumulates into them in place).  FlatAdam addresses parameters
+        # and gradients by pointer and clears the gradients itself; data parallel = one in-place all-reduce of the arena.
+        self.grads = GradArena(device, [self.sdf_network, self.color_network], self.refColor_network,
+                               [self.deviation_network, self.nerf_outside])
         self.optimizer = FlatAdam(self.params, lr=lr)
         self._graphs = {}            # (batch shape, cos_anneal_ratio) -> (CUDAGraph, static input, static losses)
         self._eager_steps = 0
@@ -79,7 +78,7 @@ class Stage1Trainer:
                                      deviation_network=self.deviation_network, color_network=self.color_network,
                                      refColor_network=self.refColor_network)
         self.igr_weight, self.mask_weight, self.surface_weight = igr_weight, mask_weight, surface_weight
-        self.bucket = FlatGradBucket(self.params) if distributed else None
+        self.bucket = self.grads if distributed else None
         self.iter_step = 0
 
     def set_lr(self, lr: float):
@@ -159,21 +158,13 @@ class Stage1Trainer:
 
     def zero_grad(self):
         """nothing to launch: FlatAdam clears every gradient in its own pass, fneus_wn_backward the effective-gradient
-        buffers; only gradients that something else set to None get their buffer back"""
-        for m in (self.deviation_network, self.nerf_outside):
-            if m is not None:
-                for p in m.parameters():
-                    if p.grad is None:
-                        p.grad = torch.zeros_like(p)
+        buffers; only gradients that something else set to None get their arena view back"""
+        self.grads.restore_small_grads()
 
     def render_only(self, data: torch.Tensor, cos_anneal_ratio: float = 1.0):
         rays_o, rays_d = data[:, :3], data[:, 3:6]
-        a = (rays_d ** 2).sum(-1, keepdim=True)
-        b = 2.0 * (rays_o * rays_d).sum(-1, keepdim=True)
-        mid = 0.5 * (-b) / a
         with torch.no_grad():
-            return self.renderer.render(rays_o, rays_d, mid - 1.0, mid + 1.0, perturb_overwrite=0,
-                                        cos_anneal_ratio=cos_anneal_ratio)
+            return self.renderer.render(rays_o, rays_d, None, None, perturb_overwrite=0, cos_anneal_ratio=cos_anneal_ratio)
 
 
 def synthetic_batches(n_batches: int, batch: int, device, seed0: int = 1000, rank: int = 0):

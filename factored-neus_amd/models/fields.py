@@ -68,6 +68,7 @@ class _HipMLP(nn.Module):
         self._ws = _Workspace()
         self._anchor = None
         self._packed = False
+        self._ext_grad = None          # optional slice of a model-wide gradient arena (set before the first refresh)
         self.prec = ops.PREC_PARITY
 
     def set_precision(self, prec: int):
@@ -84,7 +85,7 @@ class _HipMLP(nn.Module):
             raise RuntimeError("the fneus HIP backend needs the module on a GPU (there is no CPU fallback)")
         if any(not lin.weight_norm for lin in self._lins()):
             raise NotImplementedError("the fused packer expects weight_norm=True as in confs/wmask.conf")
-        net = ops.PackedNet(self.kind, dev)
+        net = ops.PackedNet(self.kind, dev, raw_grad=self._ext_grad)
         with torch.no_grad():
             for lin, view, gview in zip(self._lins(), net.raw_views(net.raw), net.raw_views(net.raw_grad)):
                 for name in ("bias", "weight_g", "weight_v"):
@@ -96,6 +97,15 @@ class _HipMLP(nn.Module):
                     prm.grad = gview[name]
         self._net = net
         self._anchor = torch.zeros(1, device=dev, requires_grad=True)
+
+    def n_raw(self) -> int:
+        """number of raw parameter values (= size of the flat gradient buffer)"""
+        return sum(p.numel() for p in self.parameters())
+
+    def use_grad_buffer(self, buf: torch.Tensor):
+        """put the flat gradient buffer into `buf` (a slice of a model-wide arena); call before the first refresh()"""
+        self._ext_grad = buf
+        self._net = None
 
     def _attached(self):
         return (self._net is not None and self.lin0.bias.device == self._net.device
@@ -247,6 +257,7 @@ class _PlainBackend:
 
     def __init__(self, kind: str, layers):
         self.kind, self.layers = kind, list(layers)
+        self.ext_grad = None
         self.net = None
         self.ws = _Workspace()
         self.anchor = None
@@ -260,7 +271,7 @@ class _PlainBackend:
         dev = self.layers[0].bias.device
         if dev.type != "cuda":
             raise RuntimeError("the fneus HIP backend needs the module on a GPU (there is no CPU fallback)")
-        net = ops.PackedNet(self.kind, dev)
+        net = ops.PackedNet(self.kind, dev, raw_grad=self.ext_grad)
         with torch.no_grad():
             for lin, view, gview in zip(self.layers, net.raw_views(net.raw), net.raw_views(net.raw_grad)):
                 for name in ("bias", "weight"):
@@ -319,6 +330,13 @@ class RefColor(nn.Module):
 
     def flat_grads(self):
         return [b.net.raw_grad for b in (self._cd, self._vd) if b.net is not None]
+
+    def n_raw(self):
+        return [sum(p.numel() for l in b.layers for p in l.parameters()) for b in (self._cd, self._vd)]
+
+    def use_grad_buffers(self, buf_cd: torch.Tensor, buf_vd: torch.Tensor):
+        self._cd.ext_grad, self._vd.ext_grad = buf_cd, buf_vd
+        self._cd.net = self._vd.net = None
 
     def heads(self, samples: RaySamples, x, n, train: bool):
         """-> diffuse [M,3], specular [M,3] with the value in column 0 (both after their sigmoid), differentiable w.r.t.

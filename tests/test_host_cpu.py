@@ -138,6 +138,16 @@ def _dp_worker(rank, world, port, q):
     for p, g in zip(net.parameters(), local):
         p.grad = g.clone()
     bucket.allreduce_sum()
+    # the trainer's zero-copy variant: every .grad is a view of one arena, the exchange is one in-place all-reduce
+    from fneus.parallel import GradArena
+    net2 = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 2))
+    net2.load_state_dict(net.state_dict())
+    arena = GradArena(torch.device("cpu"), [], None, [net2])
+    net2(x).square().sum().backward()
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(arena.small, arena._small_views)), "in-place accumulation"
+    arena.allreduce_sum()
+    for p2, p in zip(net2.parameters(), net.parameters()):
+        assert torch.allclose(p2.grad, p.grad, atol=1e-6)
     # by value (numpy), not shared-memory tensor handles: the worker may exit before the parent reads the queue
     q.put((rank, [p.detach().numpy().copy() for p in net.parameters()], [g.numpy().copy() for g in local], mean,
            [p.grad.numpy().copy() for p in net.parameters()], norms.numpy().copy()))
