@@ -105,7 +105,10 @@ def main():
     from fneus.parallel import init_from_env, broadcast_parameters
     from fneus.trainer import Stage1Trainer, synthetic_batches
 
-    rank, world, local = init_from_env("nccl")
+    # backend "nccl" = RCCL over xGMI.  FNEUS_DIST_BACKEND=gloo exists so that the N > 1 code path can be exercised with
+    # several ranks sharing ONE GPU (RCCL refuses two ranks per device); it is not a benchmark configuration.
+    rank, world, local = init_from_env(os.environ.get("FNEUS_DIST_BACKEND", "nccl"))
+    local = local % max(torch.cuda.device_count(), 1)
     if world != args.gpus:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Two (or more) data-parallel ranks of the stage-1 trainer, all on GPU 0 over gloo (RCCL refuses several ranks per
+device): a functional check of the N > 1 code path -- the replicas must stay bit-identical.
+    python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 tools/dp_check.py"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "factored-neus_amd"))
+import torch
+import torch.distributed as dist
+
+from fneus.parallel import broadcast_parameters, init_from_env
+from fneus.trainer import Stage1Trainer, synthetic_batches
+
+rank, world, _ = init_from_env("gloo")
+dev = torch.device("cuda:0")
+torch.cuda.set_device(0)
+tr = Stage1Trainer(dev, seed=rank, distributed=True)          # different initial weights per rank on purpose ...
+broadcast_parameters(tr.modules)                               # ... rank 0's must win
+losses = None
+for b in synthetic_batches(4, 128, dev, rank=rank):
+    losses = tr.global_losses(tr.train_step(b))
+flat = torch.cat([p.detach().reshape(-1) for p in tr.params])
+gathered = [torch.empty_like(flat) for _ in range(world)]
+dist.all_gather(gathered, flat)
+worst = max((g - gathered[0]).abs().max().item() for g in gathered)
+ok = worst == 0.0 and bool(torch.isfinite(losses["loss"]))
+if rank == 0:
+    print(f"DP_CHECK world={world} max replica difference {worst:.3e} global loss {float(losses['loss']):.6f} "
+          f"{'OK' if ok else 'FAILED'}")
+dist.barrier()
+dist.destroy_process_group()
+sys.exit(0 if ok else 1)
