@@ -16,7 +16,7 @@ constexpr int kMaxKS = 19;   // widest layer input on the path: colour layer 0 (
 // though the deeper register ring costs them a few more spills (measured, tools/experiments/README.md).
 template <int PREC, int KS, int NT_TOTAL, int T0, int TN, int KS0 = 0, int DEPTH = 0>
 FN_DEV void dense(const unsigned char* __restrict__ blob, uint32_t off_hi, uint32_t off_lo,
-                  const BFrag<PREC> (&b)[kMaxKS], f32x16 (&acc)[TN], int lane) {
+                  const BFrag<PREC> (&b)[kMaxKS], f32x16 (&acc)[TN], int lane, int t0_rt = 0) {
     constexpr int GT = TN < 4 ? TN : 4;                 // tiles per stage
     constexpr int NG = (TN + GT - 1) / GT;              // stages per k-step
     constexpr int NS = KS * NG;                         // stages
@@ -25,8 +25,9 @@ FN_DEV void dense(const unsigned char* __restrict__ blob, uint32_t off_hi, uint3
 #define FNEUS_PREFETCH_X1 4
 #endif
     constexpr int D = DEPTH > 0 ? DEPTH : (PREC == 3 ? FNEUS_PREFETCH_X3 : FNEUS_PREFETCH_X1);   // prefetch distance (stages)
-    const bf16x8 FN_GLOBAL* __restrict__ whi = reinterpret_cast<const bf16x8 FN_GLOBAL*>((gblob_t)blob + off_hi) + lane;
-    const bf16x8 FN_GLOBAL* __restrict__ wlo = reinterpret_cast<const bf16x8 FN_GLOBAL*>((gblob_t)blob + off_lo) + lane;
+    // t0_rt: additional (run-time) first tile, for kernels whose waves own different output tiles
+    const bf16x8 FN_GLOBAL* __restrict__ whi = reinterpret_cast<const bf16x8 FN_GLOBAL*>((gblob_t)blob + off_hi) + lane + t0_rt * 64;
+    const bf16x8 FN_GLOBAL* __restrict__ wlo = reinterpret_cast<const bf16x8 FN_GLOBAL*>((gblob_t)blob + off_lo) + lane + t0_rt * 64;
     bf16x8 ah[D + 1][GT], al[D + 1][GT];
 #pragma unroll
     for (int s = 0; s < D; ++s) {
@@ -78,11 +79,11 @@ FN_DEV void dense(const unsigned char* __restrict__ blob, uint32_t off_hi, uint3
 
 // accumulators <- packed fp32 vector in accumulator layout ([t][h][16])
 template <int NT_TOTAL, int T0, int TN>
-FN_DEV void load_accvec(const unsigned char* __restrict__ blob, uint32_t off, f32x16 (&acc)[TN], int lane) {
+FN_DEV void load_accvec(const unsigned char* __restrict__ blob, uint32_t off, f32x16 (&acc)[TN], int lane, int t0_rt = 0) {
     const f32x16 FN_GLOBAL* __restrict__ p = reinterpret_cast<const f32x16 FN_GLOBAL*>((gblob_t)blob + off);
     const int h = lane >> 5;
 #pragma unroll
-    for (int i = 0; i < TN; ++i) acc[i] = p[(T0 + i) * 2 + h];
+    for (int i = 0; i < TN; ++i) acc[i] = p[(T0 + t0_rt + i) * 2 + h];
 }
 
 template <int TN>

@@ -4,6 +4,7 @@
 //   K3 sdf_bwd_chain  : double-backward chains (ascending + descending); writes the
 //                       operand matrices of the weight-gradient GEMM (dw_gemm.hip)
 // One wavefront = 32 samples, whole chain register resident; weights come pre-packed from pack.hip (L2 resident).
+#include <stdlib.h>
 #include "mlp_engine.h"
 #include "fneus_kernels.h"
 
@@ -165,6 +166,128 @@ __global__ void __launch_bounds__(64, 1) sdf_fwd_kernel(const unsigned char* blo
         f32x16 acc[9];
         sdf_forward_chain<PREC, true, false>(blob, pe, bf, acc, st, N, nc, lane, valid, nullptr, tile);
         if (valid && lane < 32) sdf_out[n] = acc[8][0];
+    }
+}
+
+// ---- K1, small launches -------------------------------------------------------------------------------------
+// The hierarchical sampler evaluates only the 16 NEW depths of every ray three times per step (renderer.py:430): 8192
+// points = 256 tiles, a quarter of the wave slots, so such a launch lasts as long as ONE wave needs for a tile (72 us:
+// 42 us of back-to-back MFMAs + activation work, all serial).  Here the 4 wavefronts of a workgroup share one
+// 32-sample tile instead: wave w computes output tiles 2w, 2w+1 of every layer (a quarter of the MFMAs, of the
+// activation work and of the weight stream), the activated tiles are exchanged through LDS as ready-made B fragments
+// (k-step 2t+s of the next layer = half s of tile t), two LDS-only barriers per layer.
+constexpr int kTpLds = 17 * 2 * kFragBytes;      // up to 17 k-steps x (hi, lo) fragments
+#ifndef FNEUS_TP_WAVES
+#define FNEUS_TP_WAVES 1
+#define FNEUS_TP_MAX_TILES 256
+#endif
+
+template <int PREC, int TN>
+FN_DEV void tp_publish(unsigned char* __restrict__ frag, int lane, int t0, const f32x16 (&acc)[TN]) {
+    constexpr int NPL = PREC == 3 ? 2 : 1;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // everyone has fetched the previous layer's fragments
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int sh = 0; sh < 2; ++sh) {
+            bf16x8 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if constexpr (PREC == 3) {
+                    __bf16 a, b2;
+                    split_bf16(acc[i][8 * sh + j], a, b2);
+                    hi[j] = a;
+                    lo[j] = b2;
+                } else {
+                    hi[j] = (__bf16)acc[i][8 * sh + j];
+                }
+            }
+            const int ks = 2 * (t0 + i) + sh;
+            *reinterpret_cast<bf16x8*>(frag + (ks * NPL) * kFragBytes + lane * 16) = hi;
+            if constexpr (PREC == 3) *reinterpret_cast<bf16x8*>(frag + (ks * NPL + 1) * kFragBytes + lane * 16) = lo;
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // all fragments of the layer are in LDS
+}
+
+template <int PREC, int KS>
+FN_DEV void tp_gather(const unsigned char* __restrict__ frag, int lane, BFrag<PREC> (&bf)[kMaxKS]) {
+    constexpr int NPL = PREC == 3 ? 2 : 1;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        bf[ks].hi = *reinterpret_cast<const bf16x8*>(frag + (ks * NPL) * kFragBytes + lane * 16);
+        if constexpr (PREC == 3) bf[ks].lo = *reinterpret_cast<const bf16x8*>(frag + (ks * NPL + 1) * kFragBytes + lane * 16);
+    }
+}
+
+template <int PREC>
+__global__ void __launch_bounds__(256, FNEUS_TP_WAVES) sdf_fwd_tp_kernel(const unsigned char* blob, PointSrc src, long N,
+                                                            float* __restrict__ sdf_out) {
+    __shared__ __attribute__((aligned(16))) unsigned char frag[kTpLds];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    constexpr auto& LY = kSdfLayout;
+    for (long tile = blockIdx.x; tile * 32 < N; tile += gridDim.x) {
+        asm volatile("" : "+s"(blob));
+        const long n = tile * 32 + r;
+        const bool valid = n < N;
+        const long nc = valid ? n : N - 1;
+        float x[3], pe[39], jc[39];
+        load_point(src, nc, x);
+        posenc<6, false>(x, pe, jc);
+        BFrag<PREC> bf[kMaxKS], pef[3];
+        vec_to_bfrag<PREC, 39, 3, 0>(pe, bf, h);       // every wave encodes the (same) 32 points itself
+#pragma unroll
+        for (int i = 0; i < 3; ++i) pef[i] = bf[i];
+        f32x16 acc[2];
+        f32x16(&a1)[1] = reinterpret_cast<f32x16(&)[1]>(acc);
+        const int t0 = 2 * wave;
+        // layer 0
+        load_accvec<8, 0, 2>(blob, LY.L[0].bias, acc, lane, t0);
+        dense<PREC, 3, 8, 0, 2>(blob, LY.L[0].fwd_hi, LY.L[0].fwd_lo, bf, acc, lane, t0);
+        softplus_inplace(acc);
+        tp_publish<PREC, 2>(frag, lane, t0, acc);
+        tp_gather<PREC, 16>(frag, lane, bf);
+        for (int l = 1; l <= 2; ++l) {
+            load_accvec<8, 0, 2>(blob, LY.L[l].bias, acc, lane, t0);
+            dense<PREC, 16, 8, 0, 2>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, bf, acc, lane, t0);
+            softplus_inplace(acc);
+            tp_publish<PREC, 2>(frag, lane, t0, acc);
+            tp_gather<PREC, 16>(frag, lane, bf);
+        }
+        // layer 3: 7 output tiles (217 features): wave 3 owns only tile 6
+        if (wave < 3) {
+            load_accvec<7, 0, 2>(blob, LY.L[3].bias, acc, lane, t0);
+            dense<PREC, 16, 7, 0, 2>(blob, LY.L[3].fwd_hi, LY.L[3].fwd_lo, bf, acc, lane, t0);
+            softplus_inplace(acc);
+            tp_publish<PREC, 2>(frag, lane, t0, acc);
+        } else {
+            load_accvec<7, 0, 1>(blob, LY.L[3].bias, a1, lane, t0);
+            dense<PREC, 16, 7, 0, 1>(blob, LY.L[3].fwd_hi, LY.L[3].fwd_lo, bf, a1, lane, t0);
+            softplus_inplace(a1);
+            tp_publish<PREC, 1>(frag, lane, t0, a1);
+        }
+        tp_gather<PREC, 14>(frag, lane, bf);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) bf[14 + i] = pef[i];      // skip connection (fields.py:83-84)
+        // layer 4 (17 k-steps)
+        load_accvec<8, 0, 2>(blob, LY.L[4].bias, acc, lane, t0);
+        dense<PREC, 17, 8, 0, 2>(blob, LY.L[4].fwd_hi, LY.L[4].fwd_lo, bf, acc, lane, t0);
+        softplus_inplace(acc);
+        tp_publish<PREC, 2>(frag, lane, t0, acc);
+        tp_gather<PREC, 16>(frag, lane, bf);
+        for (int l = 5; l <= 7; ++l) {
+            load_accvec<8, 0, 2>(blob, LY.L[l].bias, acc, lane, t0);
+            dense<PREC, 16, 8, 0, 2>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, bf, acc, lane, t0);
+            softplus_inplace(acc);
+            tp_publish<PREC, 2>(frag, lane, t0, acc);
+            tp_gather<PREC, 16>(frag, lane, bf);
+        }
+        // layer 8: only the sdf row (tile 8 of 9) is needed; wave 0 computes it
+        if (wave == 0) {
+            load_accvec<9, 8, 1>(blob, LY.L[8].bias, a1, lane);
+            dense<PREC, 16, 9, 8, 1>(blob, LY.L[8].fwd_hi, LY.L[8].fwd_lo, bf, a1, lane);
+            if (valid && lane < 32) sdf_out[n] = a1[0][0];
+        }
     }
 }
 
@@ -490,7 +613,14 @@ extern "C" int fneus_sdf_fwd(const void* blob, const float* pts, const float* ra
     PointSrc src{pts, rays_o, rays_d, t, m > 0 ? m : 1};
     const long tiles = (n_pts + 31) / 32;
     const unsigned char* b = reinterpret_cast<const unsigned char*>(blob);
-    if (prec == 3)
+    // up to one workgroup per CU: 4 waves share a tile (latency-bound launches); beyond that one wave per tile
+    static const bool no_tp = getenv("FNEUS_K1_NO_TP") != nullptr;
+    const bool tp = tiles <= FNEUS_TP_MAX_TILES && !no_tp;
+    if (prec == 3 && tp)
+        hipLaunchKernelGGL(sdf_fwd_tp_kernel<3>, dim3((unsigned)(tiles < 512 ? tiles : 512)), dim3(256), 0, stream, b, src, n_pts, sdf_out);
+    else if (prec == 1 && tp)
+        hipLaunchKernelGGL(sdf_fwd_tp_kernel<1>, dim3((unsigned)(tiles < 512 ? tiles : 512)), dim3(256), 0, stream, b, src, n_pts, sdf_out);
+    else if (prec == 3)
         hipLaunchKernelGGL(sdf_fwd_kernel<3>, dim3(grid_for(tiles)), dim3(64), 0, stream, b, src, n_pts, sdf_out);
     else if (prec == 1)
         hipLaunchKernelGGL(sdf_fwd_kernel<1>, dim3(grid_for(tiles)), dim3(64), 0, stream, b, src, n_pts, sdf_out);
