@@ -25,9 +25,14 @@ FN_DEV void dense(const unsigned char* __restrict__ blob, uint32_t off_hi, uint3
 #define FNEUS_PREFETCH_X1 4
 #endif
     constexpr int D = DEPTH > 0 ? DEPTH : (PREC == 3 ? FNEUS_PREFETCH_X3 : FNEUS_PREFETCH_X1);   // prefetch distance (stages)
-    // t0_rt: additional (run-time) first tile, for kernels whose waves own different output tiles
-    const bf16x8 FN_GLOBAL* __restrict__ whi = reinterpret_cast<const bf16x8 FN_GLOBAL*>((gblob_t)blob + off_hi) + lane + t0_rt * 64;
-    const bf16x8 FN_GLOBAL* __restrict__ wlo = reinterpret_cast<const bf16x8 FN_GLOBAL*>((gblob_t)blob + off_lo) + lane + t0_rt * 64;
+    // Addressing: UNIFORM 64-bit base (blob + plane offset + fragment offset: scalar registers) + ONE 32-bit per-lane
+    // byte offset.  Written as a per-lane 64-bit pointer plus constants, every fragment beyond the 4 KiB immediate range
+    // gets its own 64-bit vector address, and hipcc computes dozens of them ahead of the layer loops (spills).
+    // t0_rt: additional (run-time) first tile, for kernels whose waves own different output tiles.
+    const unsigned voff = (unsigned)(lane + t0_rt * 64) * 16u;
+    const gblob_t bhi = (gblob_t)blob + off_hi, blo = (gblob_t)blob + off_lo;
+    auto whi = [&](int f) { return *reinterpret_cast<const bf16x8 FN_GLOBAL*>(bhi + (size_t)f * 16 + voff); };
+    auto wlo = [&](int f) { return *reinterpret_cast<const bf16x8 FN_GLOBAL*>(blo + (size_t)f * 16 + voff); };
     bf16x8 ah[D + 1][GT], al[D + 1][GT];
 #pragma unroll
     for (int s = 0; s < D; ++s) {
@@ -37,8 +42,8 @@ FN_DEV void dense(const unsigned char* __restrict__ blob, uint32_t off_hi, uint3
                 const int t = (s % NG) * GT + i;
                 if (t < TN) {
                     const int f = ((s / NG) * NT_TOTAL + T0 + t) * 64;
-                    ah[s % (D + 1)][i] = whi[f];
-                    if constexpr (PREC == 3) al[s % (D + 1)][i] = wlo[f];
+                    ah[s % (D + 1)][i] = whi(f);
+                    if constexpr (PREC == 3) al[s % (D + 1)][i] = wlo(f);
                 }
             }
         }
@@ -51,8 +56,8 @@ FN_DEV void dense(const unsigned char* __restrict__ blob, uint32_t off_hi, uint3
                 const int t = ((s + D) % NG) * GT + i;
                 if (t < TN) {
                     const int f = (((s + D) / NG) * NT_TOTAL + T0 + t) * 64;
-                    ah[(s + D) % (D + 1)][i] = whi[f];
-                    if constexpr (PREC == 3) al[(s + D) % (D + 1)][i] = wlo[f];
+                    ah[(s + D) % (D + 1)][i] = whi(f);
+                    if constexpr (PREC == 3) al[(s + D) % (D + 1)][i] = wlo(f);
                 }
             }
         }
@@ -73,6 +78,62 @@ FN_DEV void dense(const unsigned char* __restrict__ blob, uint32_t off_hi, uint3
         // loads coalesce in the CU's vector L1 instead of each going to L2 (raw barrier: no memory waits)
         if ((s % FNEUS_WAVE_SYNC_STAGES) == FNEUS_WAVE_SYNC_STAGES - 1) __builtin_amdgcn_s_barrier();
 #endif
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// dense() for tensor-parallel workgroups in parity mode: the B fragments (activations of the whole tile, produced by all
+// waves of the workgroup) stay in LDS -- frag + (ks * NPL + plane) * 1 KiB + lane * 16 -- and are fetched one k-step
+// ahead of their MFMAs instead of being held in 8 registers per k-step (136 registers for a 17-k-step layer: with them
+// a parity-mode wave does not fit the 256 registers that two workgroups per CU leave it).
+template <int PREC, int KS, int NT_TOTAL, int T0, int TN, int DEPTH = 0>
+FN_DEV void dense_ldsb(const unsigned char* __restrict__ blob, uint32_t off_hi, uint32_t off_lo,
+                       const unsigned char* frag /*LDS, written by other helpers: no restrict*/, f32x16 (&acc)[TN], int lane,
+                       int t0_rt = 0) {
+    static_assert(TN <= 4, "one stage per k-step");
+    constexpr int NPL = PREC == 3 ? 2 : 1;
+    constexpr int D = DEPTH > 0 ? DEPTH : (PREC == 3 ? FNEUS_PREFETCH_X3 : FNEUS_PREFETCH_X1);
+    const unsigned voff = (unsigned)(lane + t0_rt * 64) * 16u;
+    const gblob_t bhi = (gblob_t)blob + off_hi, blo = (gblob_t)blob + off_lo;
+    auto whi = [&](int f) { return *reinterpret_cast<const bf16x8 FN_GLOBAL*>(bhi + (size_t)f * 16 + voff); };
+    auto wlo = [&](int f) { return *reinterpret_cast<const bf16x8 FN_GLOBAL*>(blo + (size_t)f * 16 + voff); };
+    const unsigned char* fl = frag + lane * 16;
+    bf16x8 ah[D + 1][TN], al[D + 1][TN];
+    bf16x8 bh[2], bl[2];
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+        if (s < KS) {
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int f = (s * NT_TOTAL + T0 + i) * 64;
+                ah[s % (D + 1)][i] = whi(f);
+                if constexpr (PREC == 3) al[s % (D + 1)][i] = wlo(f);
+            }
+        }
+    bh[0] = *reinterpret_cast<const bf16x8*>(fl);
+    if constexpr (PREC == 3) bl[0] = *reinterpret_cast<const bf16x8*>(fl + kFragBytes);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        if (s + D < KS) {
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int f = ((s + D) * NT_TOTAL + T0 + i) * 64;
+                ah[(s + D) % (D + 1)][i] = whi(f);
+                if constexpr (PREC == 3) al[(s + D) % (D + 1)][i] = wlo(f);
+            }
+        }
+        if (s + 1 < KS) {
+            bh[(s + 1) & 1] = *reinterpret_cast<const bf16x8*>(fl + ((s + 1) * NPL) * kFragBytes);
+            if constexpr (PREC == 3) bl[(s + 1) & 1] = *reinterpret_cast<const bf16x8*>(fl + ((s + 1) * NPL + 1) * kFragBytes);
+        }
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            if constexpr (PREC == 3) {
+                acc[i] = mfma32(al[s % (D + 1)][i], bh[s & 1], acc[i]);
+                acc[i] = mfma32(ah[s % (D + 1)][i], bl[s & 1], acc[i]);
+            }
+            acc[i] = mfma32(ah[s % (D + 1)][i], bh[s & 1], acc[i]);
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
 }

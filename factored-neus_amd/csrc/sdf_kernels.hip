@@ -169,6 +169,8 @@ __global__ void __launch_bounds__(64, 1) sdf_fwd_kernel(const unsigned char* blo
     }
 }
 
+// NOTE on the LDS pointers of the tensor-parallel helpers below: no __restrict__ -- fragments written through one helper
+// are read through another.
 // ---- K1, small launches -------------------------------------------------------------------------------------
 // The hierarchical sampler evaluates only the 16 NEW depths of every ray three times per step (renderer.py:430): 8192
 // points = 256 tiles, a quarter of the wave slots, so such a launch lasts as long as ONE wave needs for a tile (72 us:
@@ -183,7 +185,7 @@ constexpr int kTpLds = 17 * 2 * kFragBytes;      // up to 17 k-steps x (hi, lo) 
 #endif
 
 template <int PREC, int TN>
-FN_DEV void tp_publish(unsigned char* __restrict__ frag, int lane, int t0, const f32x16 (&acc)[TN]) {
+FN_DEV void tp_publish(unsigned char* frag, int lane, int t0, const f32x16 (&acc)[TN]) {
     constexpr int NPL = PREC == 3 ? 2 : 1;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // everyone has fetched the previous layer's fragments
 #pragma unroll
@@ -210,7 +212,7 @@ FN_DEV void tp_publish(unsigned char* __restrict__ frag, int lane, int t0, const
 }
 
 template <int PREC, int KS>
-FN_DEV void tp_gather(const unsigned char* __restrict__ frag, int lane, BFrag<PREC> (&bf)[kMaxKS]) {
+FN_DEV void tp_gather(const unsigned char* frag, int lane, BFrag<PREC> (&bf)[kMaxKS]) {
     constexpr int NPL = PREC == 3 ? 2 : 1;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -408,6 +410,305 @@ __global__ void __launch_bounds__(64, 1) sdf_fwd_grad_kernel(const unsigned char
         if (valid && lane < 32) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) normal_out[n * 3 + c] = nrm[c];
+        }
+    }
+}
+
+// ---- K2, tensor-parallel workgroups --------------------------------------------------------------------------------
+// Same maths, same stash layouts and the same results as sdf_fwd_grad_kernel, organised like sdf_fwd_tp_kernel: the 4
+// wavefronts of a workgroup share one 32-sample tile, wave w owns output tiles 2w, 2w+1 of every layer.  A wave then
+// needs ~250 registers instead of ~450, so TWO workgroups fit a CU (2 waves per SIMD): while one workgroup sits in a
+// barrier or in its stash-store phase the other one feeds the matrix pipe -- the overlap the one-wave-per-SIMD kernel
+// cannot have (measured there: 650 of 1111 us were un-overlapped store phases).
+// Per layer: barrier, own tiles -> LDS (B fragments for the exchange + the [32][256] row image of the stash), barrier,
+// every wave fetches all k-steps of the next layer and stores a quarter of the image rows.
+constexpr int kTp2Lds = kTpLds + kWaveScr;       // fragments + row image (hi and lo planes): 68 096 bytes
+
+template <int PREC, int TN, bool FRAGS, bool IMG>
+FN_DEV void tp_exchange(unsigned char* frag, unsigned char* img, int lane, int t0,
+                        const f32x16 (&acc)[TN], const BFrag<PREC>* skip_frags = nullptr) {
+    constexpr int NPL = PREC == 3 ? 2 : 1;
+    const int r = lane & 31, h = lane >> 5;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // previous fragments / image rows are consumed
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int sh = 0; sh < 2; ++sh) {
+            bf16x8 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if constexpr (PREC == 3) {
+                    __bf16 a, b2;
+                    split_bf16(acc[i][8 * sh + j], a, b2);
+                    hi[j] = a;
+                    lo[j] = b2;
+                } else {
+                    hi[j] = (__bf16)acc[i][8 * sh + j];
+                }
+            }
+            if constexpr (FRAGS) {
+                const int ks = 2 * (t0 + i) + sh;
+                *reinterpret_cast<bf16x8*>(frag + (ks * NPL) * kFragBytes + lane * 16) = hi;
+                if constexpr (PREC == 3) *reinterpret_cast<bf16x8*>(frag + (ks * NPL + 1) * kFragBytes + lane * 16) = lo;
+            }
+            if constexpr (IMG) {   // registers 8sh + 4gg + e hold features 32t + 8(2sh + gg) + 4h + e of sample r
+#pragma unroll
+                for (int gg = 0; gg < 2; ++gg) {
+                    unsigned char* dst = img + r * kScrStride + (32 * (t0 + i) + 8 * (2 * sh + gg) + 4 * h) * 2;
+                    bf16x4 vh, vl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        vh[e] = hi[4 * gg + e];
+                        if constexpr (PREC == 3) vl[e] = lo[4 * gg + e];
+                    }
+                    *reinterpret_cast<bf16x4*>(dst) = vh;
+                    if constexpr (PREC == 3) *reinterpret_cast<bf16x4*>(dst + kScrPlane) = vl;
+                }
+            }
+        }
+    if (skip_frags) {      // k-steps 14..16 of the next layer: the positional encoding (skip connection, fields.py:83-84)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            *reinterpret_cast<bf16x8*>(frag + ((14 + i) * NPL) * kFragBytes + lane * 16) = skip_frags[i].hi;
+            if constexpr (PREC == 3)
+                *reinterpret_cast<bf16x8*>(frag + ((14 + i) * NPL + 1) * kFragBytes + lane * 16) = skip_frags[i].lo;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // fragments and image are complete
+}
+
+#ifndef FNEUS_TP_DEPTH
+#define FNEUS_TP_DEPTH 4        // weight-prefetch depth of the tensor-parallel K2 (stages of 2 tiles); measured 2 / 3 / 4
+#endif
+#ifndef FNEUS_TP_LDSB_BF16
+#define FNEUS_TP_LDSB_BF16 0
+#endif
+template <int PREC> constexpr bool kTpLdsB = PREC == 3 || FNEUS_TP_LDSB_BF16;
+
+// B operand of a tensor-parallel layer: parity mode reads the fragments from LDS k-step by k-step (dense_ldsb), bf16
+// mode has the registers to hold them all (tp_gather + dense)
+template <int PREC, int KS, int NT_TOTAL, int T0, int TN>
+FN_DEV void tp_dense(const unsigned char* __restrict__ blob, uint32_t off_hi, uint32_t off_lo,
+                     const unsigned char* frag, const BFrag<PREC> (&bf)[kMaxKS], f32x16 (&acc)[TN], int lane,
+                     int t0_rt = 0) {
+    if constexpr (kTpLdsB<PREC>)
+        dense_ldsb<PREC, KS, NT_TOTAL, T0, TN, FNEUS_TP_DEPTH>(blob, off_hi, off_lo, frag, acc, lane, t0_rt);
+    else
+        dense<PREC, KS, NT_TOTAL, T0, TN, 0, FNEUS_TP_DEPTH>(blob, off_hi, off_lo, bf, acc, lane, t0_rt);
+}
+template <int PREC, int KS>
+FN_DEV void tp_operands(const unsigned char* frag, int lane, BFrag<PREC> (&bf)[kMaxKS]) {
+    if constexpr (!kTpLdsB<PREC>) tp_gather<PREC, KS>(frag, lane, bf);
+}
+
+// image rows -> row-major global planes; every wave takes a quarter of the 512-byte row units
+template <int PREC, int NCOLS>
+FN_DEV void tp_store_rows(const unsigned char* img, int lane, int wave, __bf16* __restrict__ hi,
+                          __bf16* __restrict__ lo, long n0, long N) {
+    constexpr int NPL = PREC == 3 ? 2 : 1;
+    constexpr int P = NCOLS / 4, UPP = 32 * P / 64;
+    for (int u = wave; u < UPP * NPL; u += 4) {
+        const int pl = u / UPP, idx = (u - pl * UPP) * 64 + lane;
+        const int row = idx / P, pc = idx - row * P;
+        __bf16* __restrict__ plane = pl ? lo : hi;
+        if (n0 + row < N)
+            *reinterpret_cast<uint2*>(plane + (n0 + row) * 256 + pc * 4) =
+                *reinterpret_cast<const uint2*>(img + pl * kScrPlane + row * kScrStride + pc * 8);
+    }
+}
+
+// positional encoding of x as B fragments KS0..KS0+2, recomputed where needed (the point is laundered so that the
+// evaluations are not merged and kept in 24 registers)
+template <int PREC, int KS0>
+FN_DEV void pe_frags_tp(const float (&x)[3], BFrag<PREC> (&bf)[kMaxKS], int h) {
+    float xx[3] = {x[0], x[1], x[2]};
+    asm volatile("" : "+v"(xx[0]), "+v"(xx[1]), "+v"(xx[2]));
+    float pe[39], jc[39];
+    posenc<6, false>(xx, pe, jc);
+    vec_to_bfrag<PREC, 39, 3, KS0>(pe, bf, h);
+}
+
+constexpr int kTp2LdsTotal = kTp2Lds + 2 * 64 * 64;     // + q_skip of wave 0 (2 tiles x 64 lanes x 16 floats)
+
+template <int PREC, bool TRAIN>
+__global__ void __launch_bounds__(256, 2) sdf_fwd_grad_tp_kernel(const unsigned char* blob, PointSrc src, long N,
+                                                                 SdfStash st, float* __restrict__ sdf_out,
+                                                                 float* __restrict__ feat_out,
+                                                                 float* __restrict__ normal_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
+    unsigned char* frag = lds_;
+    unsigned char* img = lds_ + kTpLds;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int t0 = 2 * wave;
+    constexpr auto& LY = kSdfLayout;
+    constexpr size_t PB = priv_block_bytes<PREC>();
+    const size_t LS = (size_t)N * 256;
+    for (long tile = blockIdx.x; tile * 32 < N; tile += gridDim.x) {
+        asm volatile("" : "+s"(blob));
+        const long n = tile * 32 + r;
+        const bool valid = n < N;
+        const long nc = valid ? n : N - 1;
+        const long n0 = tile * 32;
+        // this wave's part of the lane-private blocks of the tile: slots 4*t0 .. 4*t0+7 of each layer
+        unsigned char* psb = st.ps + (size_t)tile * 8 * kSigBlockBytes + (size_t)t0 * (kSigBlockBytes / 8);
+        unsigned char* pab = TRAIN ? st.pa + (size_t)tile * 8 * PB + (size_t)t0 * (PB / 8) : nullptr;
+        float x[3];
+        load_point(src, nc, x);
+        BFrag<PREC> bf[kMaxKS];
+        pe_frags_tp<PREC, 0>(x, bf, h);             // every wave encodes the (same) 32 points itself
+        if (wave == 0 && valid) {   // PE rows [N][48]
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const int col = 16 * ks + 8 * g + 4 * h;
+                    bf16x4 vh, vl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        vh[e] = bf[ks].hi[4 * g + e];
+                        if constexpr (PREC == 3) vl[e] = bf[ks].lo[4 * g + e];
+                    }
+                    *reinterpret_cast<bf16x4*>(st.pe_hi + nc * 48 + col) = vh;
+                    if constexpr (PREC == 3) *reinterpret_cast<bf16x4*>(st.pe_lo + nc * 48 + col) = vl;
+                }
+        }
+        f32x16 acc[2];
+        f32x16(&a1)[1] = reinterpret_cast<f32x16(&)[1]>(acc);
+        // ---------------- forward chain ----------------
+#pragma unroll 1
+        for (int l = 0; l <= 7; ++l) {
+            asm volatile("" : "+s"(blob));      // per layer as well: keeps the static-offset addresses of the branches
+                                                // below from being hoisted out of this loop (and spilled)
+            unsigned char* ps_l = psb + (size_t)l * kSigBlockBytes;
+            __bf16* h_hi = st.h_hi + l * LS;
+            __bf16* h_lo = st.h_lo + l * LS;
+            if (l == 3) {               // 7 output tiles (217 features): wave 3 owns tile 6 only
+                if (wave < 3) {
+                    load_accvec<7, 0, 2>(blob, LY.L[3].bias, acc, lane, t0);
+                    tp_dense<PREC, 16, 7, 0, 2>(blob, LY.L[3].fwd_hi, LY.L[3].fwd_lo, frag, bf, acc, lane, t0);
+                    softplus_ps<PREC, 2>(acc, ps_l, lane);
+                    tp_exchange<PREC, 2, true, true>(frag, img, lane, t0, acc);
+                } else {
+                    load_accvec<7, 0, 1>(blob, LY.L[3].bias, a1, lane, t0);
+                    tp_dense<PREC, 16, 7, 0, 1>(blob, LY.L[3].fwd_hi, LY.L[3].fwd_lo, frag, bf, a1, lane, t0);
+                    softplus_ps<PREC, 1>(a1, ps_l, lane);
+                    BFrag<PREC>* skip = nullptr;
+                    if constexpr (kTpLdsB<PREC>) {      // the owner of the short tile also publishes the skip input
+                        pe_frags_tp<PREC, 14>(x, bf, h);
+                        skip = &bf[14];
+                    }
+                    tp_exchange<PREC, 1, true, true>(frag, img, lane, t0, a1, skip);
+                }
+                tp_operands<PREC, 14>(frag, lane, bf);
+                if constexpr (!kTpLdsB<PREC>) pe_frags_tp<PREC, 14>(x, bf, h);   // skip connection (fields.py:83-84)
+                tp_store_rows<PREC, 224>(img, lane, wave, h_hi, h_lo, n0, N);
+            } else {
+                load_accvec<8, 0, 2>(blob, LY.L[l].bias, acc, lane, t0);
+                if (l == 0)
+                    dense<PREC, 3, 8, 0, 2>(blob, LY.L[0].fwd_hi, LY.L[0].fwd_lo, bf, acc, lane, t0);
+                else if (l == 4)
+                    tp_dense<PREC, 17, 8, 0, 2>(blob, LY.L[4].fwd_hi, LY.L[4].fwd_lo, frag, bf, acc, lane, t0);
+                else
+                    tp_dense<PREC, 16, 8, 0, 2>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, frag, bf, acc, lane, t0);
+                softplus_ps<PREC, 2>(acc, ps_l, lane);
+                tp_exchange<PREC, 2, true, true>(frag, img, lane, t0, acc);
+                tp_operands<PREC, 16>(frag, lane, bf);
+                tp_store_rows<PREC, 256>(img, lane, wave, h_hi, h_lo, n0, N);
+            }
+        }
+        // layer 8 (linear): feature tiles 0..7 (two per wave) and the sdf row (tile 8, wave 0)
+        load_accvec<9, 0, 2>(blob, LY.L[8].bias, acc, lane, t0);
+        tp_dense<PREC, 16, 9, 0, 2>(blob, LY.L[8].fwd_hi, LY.L[8].fwd_lo, frag, bf, acc, lane, t0);
+        store_f32<2>(acc, feat_out + 32 * t0, 256, nc, h, valid);
+        if constexpr (TRAIN) {
+            tp_exchange<PREC, 2, false, true>(frag, img, lane, t0, acc);
+            tp_store_rows<PREC, 256>(img, lane, wave, st.feat_hi, st.feat_lo, n0, N);
+        }
+        if (wave == 0) {
+            f32x16 s1[1];
+            load_accvec<9, 8, 1>(blob, LY.L[8].bias, s1, lane);
+            tp_dense<PREC, 16, 9, 8, 1>(blob, LY.L[8].fwd_hi, LY.L[8].fwd_lo, frag, bf, s1, lane);
+            if (valid && lane < 32) sdf_out[n] = s1[0][0];
+        }
+        // ---------------- reverse sweep: g = d sdf / d u_l   ----------------
+        load_accvec<8, 0, 2>(blob, LY.extra, acc, lane, t0);                 // g_hat(h_8) = row 0 of W_8
+        f32x16* qskip_lds = reinterpret_cast<f32x16*>(lds_ + kTp2Lds);     // [2][64] accumulator registers of wave 0
+#pragma unroll 1
+        for (int l = 7; l >= 1; --l) {
+            asm volatile("" : "+s"(blob));
+            const unsigned char* ps_l = psb + (size_t)l * kSigBlockBytes;
+            unsigned char* pa_l = TRAIN ? pab + (size_t)l * PB : nullptr;
+            __bf16* a_hi = st.a_hi + l * LS;
+            __bf16* a_lo = st.a_lo + l * LS;
+            if (l == 3) {   // g_hat(h_4): 7 tiles
+                if (wave < 3) {
+                    mul_sig_priv<PREC, 2, TRAIN>(acc, ps_l, pa_l, lane);
+                    tp_exchange<PREC, 2, true, TRAIN>(frag, img, lane, t0, acc);
+                } else {
+                    mul_sig_priv<PREC, 1, TRAIN>(a1, ps_l, pa_l, lane);
+                    tp_exchange<PREC, 1, true, TRAIN>(frag, img, lane, t0, a1);
+                }
+                tp_operands<PREC, 14>(frag, lane, bf);
+                if constexpr (TRAIN) tp_store_rows<PREC, 224>(img, lane, wave, a_hi, a_lo, n0, N);
+                zero_acc(acc);
+                tp_dense<PREC, 14, 8, 0, 2>(blob, LY.L[3].rev_hi, LY.L[3].rev_lo, frag, bf, acc, lane, t0);
+            } else {
+                mul_sig_priv<PREC, 2, TRAIN>(acc, ps_l, pa_l, lane);                                     // a_l
+                tp_exchange<PREC, 2, true, TRAIN>(frag, img, lane, t0, acc);
+                tp_operands<PREC, 16>(frag, lane, bf);
+                if constexpr (TRAIN) tp_store_rows<PREC, 256>(img, lane, wave, a_hi, a_lo, n0, N);
+                if (l == 4) {   // 9 row tiles: 0..6 -> g_hat(h_4), 7..8 -> q_skip (PE part of the skip input; wave 0)
+                    if (wave == 0) {   // parked in LDS until the end of the sweep (32 registers for 4 layers otherwise)
+                        f32x16 qs[2];
+                        zero_acc(qs);
+                        tp_dense<PREC, 16, 9, 7, 2>(blob, LY.L[4].rev_hi, LY.L[4].rev_lo, frag, bf, qs, lane);
+                        qskip_lds[lane] = qs[0];
+                        qskip_lds[64 + lane] = qs[1];
+                    }
+                    if (wave < 3) {
+                        zero_acc(acc);
+                        tp_dense<PREC, 16, 9, 0, 2>(blob, LY.L[4].rev_hi, LY.L[4].rev_lo, frag, bf, acc, lane, t0);
+                    } else {
+                        zero_acc(a1);
+                        tp_dense<PREC, 16, 9, 0, 1>(blob, LY.L[4].rev_hi, LY.L[4].rev_lo, frag, bf, a1, lane, t0);
+                    }
+                } else {
+                    zero_acc(acc);
+                    tp_dense<PREC, 16, 8, 0, 2>(blob, LY.L[l].rev_hi, LY.L[l].rev_lo, frag, bf, acc, lane, t0);
+                }
+            }
+        }
+        // layer 0: a_0, then the 2 row tiles of the 39 PE inputs (wave 0) and normal = J^T q
+        mul_sig_priv<PREC, 2, TRAIN>(acc, psb, pab, lane);
+        tp_exchange<PREC, 2, true, TRAIN>(frag, img, lane, t0, acc);
+        tp_operands<PREC, 16>(frag, lane, bf);
+        if constexpr (TRAIN) tp_store_rows<PREC, 256>(img, lane, wave, st.a_hi, st.a_lo, n0, N);
+        if (wave == 0) {
+            f32x16 q[2];
+            zero_acc(q);
+            tp_dense<PREC, 16, 2, 0, 2>(blob, LY.L[0].rev_hi, LY.L[0].rev_lo, frag, bf, q, lane);
+            q[0] += qskip_lds[lane];
+            q[1] += qskip_lds[64 + lane];
+            float pe[39], jc[39];       // Jacobian coefficients of the encoding, recomputed (39 registers otherwise)
+            {
+                float xx[3] = {x[0], x[1], x[2]};
+                asm volatile("" : "+v"(xx[0]), "+v"(xx[1]), "+v"(xx[2]));
+                posenc<6, true>(xx, pe, jc);
+            }
+            float nrm[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float coef[39];
+#pragma unroll
+                for (int f = 0; f < 39; ++f) coef[f] = ((f % 3) == c) ? jc[f] : 0.0f;
+                const float part = acc_dot_partial<2, 39>(q, coef, h);
+                nrm[c] = part + xor32(part);
+            }
+            if (valid && lane < 32) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) normal_out[n * 3 + c] = nrm[c];
+            }
         }
     }
 }
@@ -640,6 +941,30 @@ extern "C" int fneus_sdf_fwd_grad(const void* blob, const float* pts, const floa
     const long tiles = (n_pts + 31) / 32;
     const unsigned char* b = reinterpret_cast<const unsigned char*>(blob);
     SdfStash st = *stash;
+    // tensor-parallel workgroups by default (FNEUS_K2_TP=0 selects the one-wave-per-tile kernel, kept for comparison):
+    // N = 65 536, parity mode: train 970 vs 1000-1040 us, inference 615 vs 770 us; bf16 mode: 530 vs 730, 325 vs 485 us
+    static const int tp_mode = getenv("FNEUS_K2_TP") ? atoi(getenv("FNEUS_K2_TP")) : 1;
+    if (tp_mode) {
+        const long cap = 256 * 2 * 4;
+        dim3 g2((unsigned)(tiles < cap ? tiles : cap)), b2(256);
+#define FNEUS_K2TP(P, T)                                                                                              \
+    do {                                                                                                              \
+        static bool attr_done = false;                                                                                \
+        if (!attr_done) {                                                                                             \
+            allow_big_lds(sdf_fwd_grad_tp_kernel<P, T>);                                                              \
+            attr_done = true;                                                                                         \
+        }                                                                                                             \
+        hipLaunchKernelGGL((sdf_fwd_grad_tp_kernel<P, T>), g2, b2, kTp2LdsTotal, stream, b, src, n_pts, st, sdf_out,       \
+                           feat_out, normal_out);                                                                     \
+    } while (0)
+        if (prec == 3 && train) FNEUS_K2TP(3, true);
+        else if (prec == 3) FNEUS_K2TP(3, false);
+        else if (prec == 1 && train) FNEUS_K2TP(1, true);
+        else if (prec == 1) FNEUS_K2TP(1, false);
+        else return -2;
+#undef FNEUS_K2TP
+        return fneus::launch_status();
+    }
     dim3 grid(grid_for(tiles)), blk(64);
     if (prec == 3 && train)
         hipLaunchKernelGGL((sdf_fwd_grad_kernel<3, true>), grid, blk, 0, stream, b, src, n_pts, st, sdf_out, feat_out, normal_out);
