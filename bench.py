@@ -43,6 +43,15 @@ KERNEL_FLOPS = {
     "fneus_color_bwd": F_COL * SAMPLES_PER_STEP,
 }
 PEAK_BF16_MFMA_TFLOPS = 2500.0       # MI355X dense bf16 (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0                # HBM3E (MI355X_MICROARCH.md)
+# Algorithmic HBM bytes per sample of the stash design in parity mode: what a launch must move
+# even with perfect caching.  K3: reads sigma' twice 2 x 4096 + a_l 8192 + coupling 8192 + d_feat 1024, writes coupling
+# 8192 + adj planes 8192 + zbar planes 9216 + qbar 192.
+KERNEL_BYTES_PARITY = {
+    "fneus_sdf_bwd": (2 * 4096 + 8192 + 8192 + 1024 + 8192 + 8192 + 9216 + 192) * SAMPLES_PER_STEP,
+    "fneus_sdf_fwd_grad": (8192 + 8192 + 2048 + 1024 + 4096 + 8192 + 4096 + 192) * SAMPLES_PER_STEP,   # h, a, feat planes, feat fp32,
+                                                                          # sigma' written + read back, a_l private, PE rows
+}
 
 
 CPU_RAYS = 128          # bounded CPU sample: a quarter batch of the same workload (same samples per ray, same nets)
@@ -188,6 +197,13 @@ def main():
                 traffic = tj[dom.split(":")[0]]["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
+        if prec == ops.PREC_PARITY and dom in KERNEL_BYTES_PARITY:
+            # the same launch seen against the HBM roofline: these kernels move their whole activation stash
+            gbs = KERNEL_BYTES_PARITY[dom] / max(round(per[dom]["launches_per_step"]), 1) / (per[dom]["avg_ms"] * 1e-3) / 1e9
+            result["roofline_hbm"] = {"kernel": dom, "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                      "frac": gbs / PEAK_HBM_GBS, "traffic": traffic,
+                                      "note": "algorithmic stash bytes per launch (DESIGN.md 4.1) / launch duration; "
+                                              "streaming torch kernels reach 4.0 (read) - 6.8 (write) TB/s on this part"}
         result["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS,
                               "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_MFMA_TFLOPS, "traffic": traffic,
                               "avg_launch_ms": per[dom]["avg_ms"],
