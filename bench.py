@@ -190,10 +190,10 @@ def main():
         dom = max((k for k in per if k in KERNEL_FLOPS), key=lambda k: per[k]["ms_per_step"])
         flops_per_launch = KERNEL_FLOPS[dom] / max(round(per[dom]["launches_per_step"]), 1)
         achieved = flops_per_launch / (per[dom]["avg_ms"] * 1e-3) / 1e12
-        traffic = None      # HBM bytes per launch from the committed PMC passes (profiles/r01_traffic.json), parity mode only
+        traffic = None      # HBM bytes per launch from the committed PMC passes (profiles/r01_c_traffic.json), parity mode only
         try:
             if prec == ops.PREC_PARITY:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"]
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_c_traffic.json")))["kernels"]
                 traffic = tj[dom.split(":")[0]]["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
