@@ -110,7 +110,9 @@ class Stage1Trainer:
         return losses
 
     def _capture(self, data: torch.Tensor, cos_anneal_ratio: float):
+        import gc
         static_data = data.clone()
+        gc.collect()                 # drop autograd graphs of earlier eager steps that are only kept alive by cycles
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
@@ -140,7 +142,10 @@ class Stage1Trainer:
         losses["loss"].backward()
         if with_optimizer:
             self.optimizer.step()
-        return losses
+        # Hand out DETACHED values: a caller that keeps the loss of the previous step (for logging) would otherwise keep
+        # that step's autograd graph -- and its AccumulateGrad nodes, bound to the stream they were created on -- alive
+        # into the graph capture, which then records cross-stream work and crashes hipStreamEndCapture.
+        return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in losses.items()}
 
     def global_losses(self, losses: dict) -> dict:
         """data parallel: the loss terms of a step are this rank's SHARE of the global batch's; sum them over the ranks
