@@ -1,0 +1,56 @@
+"""exp_runner.Runner end to end on the GPU with the synthetic dataset: train a few steps (graph replay), write a
+checkpoint in the reference's format, resume from it, render a validation image and an SDF grid."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _conf(tmp_path):
+    src = open(os.path.join(ROOT, "factored-neus_amd", "confs", "wmask.conf")).read()
+    src = src.replace("./exp/CASE_NAME/", str(tmp_path) + "/exp/CASE_NAME/")
+    path = os.path.join(tmp_path, "wmask_test.conf")
+    open(path, "w").write(src)
+    return path
+
+
+def test_runner_train_checkpoint_resume_validate(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "factored-neus_amd"))
+    import exp_runner
+    dev = torch.device("cuda:0")
+    conf = _conf(str(tmp_path))
+    r = exp_runner.Runner(conf, mode="train", case="synth", type="synthetic", device=dev)
+    r.batch_size = 128
+    r.save_freq, r.report_freq = 5, 3
+    r.train(max_steps=5)
+    assert r.iter_step == 5 and r.trainer.iter_step == 5
+    assert len(r.trainer._graphs) == 1                     # wmask.conf: anneal_end = 0 -> the step is replayed as a graph
+    ckpts = sorted(os.listdir(os.path.join(r.base_exp_dir, "checkpoints")))
+    assert ckpts == ["ckpt_000005.pth"]
+    ck = torch.load(os.path.join(r.base_exp_dir, "checkpoints", ckpts[0]), map_location="cpu")
+    assert set(ck.keys()) >= {"nerf", "sdf_network_fine", "variance_network_fine", "color_network_fine", "refColor_network",
+                              "optimizer", "iter_step"}                         # exp_runner.py:266-278
+    assert "lin0.weight_g" in ck["sdf_network_fine"] and "net_cd.0.weight" in ck["refColor_network"]
+    before = {k: v.clone() for k, v in r.trainer.sdf_network.state_dict().items()}
+    step_before = float(r.trainer.optimizer.state[r.trainer.params[0]]["step"])
+    # resume in a fresh runner: weights, optimiser moments and the step counter come back
+    r2 = exp_runner.Runner(conf, mode="train", case="synth", is_continue=True, type="synthetic", device=dev)
+    assert r2.iter_step == 5
+    for k, v in r2.trainer.sdf_network.state_dict().items():
+        assert torch.equal(v.cpu(), before[k].cpu()), k
+    r2.batch_size = 128
+    r2.train(max_steps=2)
+    assert r2.iter_step == 7
+    assert float(r2.trainer.optimizer.state[r2.trainer.params[0]]["step"]) == step_before + 2
+    moved = max((a.cpu() - before[k].cpu()).abs().max().item() for k, a in r2.trainer.sdf_network.state_dict().items())
+    assert 0.0 < moved < 1e-2
+    img = r2.validate_image(idx=0, resolution_level=8)
+    assert os.path.exists(img)
+    grid = np.load(r2.validate_mesh(resolution=32))
+    assert grid["u"].shape == (32, 32, 32) and np.isfinite(grid["u"]).all()
+    assert (grid["u"] < 0).any() and (grid["u"] > 0).any()          # the SDF grid straddles the surface
