@@ -21,6 +21,7 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 #define FN_DEV __device__ __forceinline__
 // Weight blobs are read through explicit GLOBAL-address-space pointers: the kernels launder the blob pointer per tile

@@ -99,7 +99,11 @@ FN_DEV void dense_ldsb(const unsigned char* __restrict__ blob, uint32_t off_hi, 
     auto wlo = [&](int f) { return *reinterpret_cast<const bf16x8 FN_GLOBAL*>(blo + (size_t)f * 16 + voff); };
     const unsigned char* fl = frag + lane * 16;
     bf16x8 ah[D + 1][TN], al[D + 1][TN];
-    bf16x8 bh[2], bl[2];
+    // THREE B buffers: an LDS load returns within ~100 cycles, and it must not land in registers that an MFMA issued just
+    // before it is still reading as its B operand (the matrix pipe reads a 64-lane operand over several passes; observed
+    // as 16 consecutive samples -- one quarter-wave -- with a wrong result, a few times per launch).  With three buffers
+    // the one being refilled was last used two stages (>= 4 MFMAs) earlier.
+    bf16x8 bh[3], bl[3];
 #pragma unroll
     for (int s = 0; s < D; ++s)
         if (s < KS) {
@@ -123,19 +127,21 @@ FN_DEV void dense_ldsb(const unsigned char* __restrict__ blob, uint32_t off_hi, 
             }
         }
         if (s + 1 < KS) {
-            bh[(s + 1) & 1] = *reinterpret_cast<const bf16x8*>(fl + ((s + 1) * NPL) * kFragBytes);
-            if constexpr (PREC == 3) bl[(s + 1) & 1] = *reinterpret_cast<const bf16x8*>(fl + ((s + 1) * NPL + 1) * kFragBytes);
+            bh[(s + 1) % 3] = *reinterpret_cast<const bf16x8*>(fl + ((s + 1) * NPL) * kFragBytes);
+            if constexpr (PREC == 3) bl[(s + 1) % 3] = *reinterpret_cast<const bf16x8*>(fl + ((s + 1) * NPL + 1) * kFragBytes);
         }
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
             if constexpr (PREC == 3) {
-                acc[i] = mfma32(al[s % (D + 1)][i], bh[s & 1], acc[i]);
-                acc[i] = mfma32(ah[s % (D + 1)][i], bl[s & 1], acc[i]);
+                acc[i] = mfma32(al[s % (D + 1)][i], bh[s % 3], acc[i]);
+                acc[i] = mfma32(ah[s % (D + 1)][i], bl[s % 3], acc[i]);
             }
-            acc[i] = mfma32(ah[s % (D + 1)][i], bh[s & 1], acc[i]);
+            acc[i] = mfma32(ah[s % (D + 1)][i], bh[s % 3], acc[i]);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    // the caller is free to reuse the operand registers at once (e.g. for LDS loads): let the last MFMAs read them first
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 }
 
 // accumulators <- packed fp32 vector in accumulator layout ([t][h][16])
@@ -183,6 +189,28 @@ FN_DEV void acc_to_bfrag(const f32x16 (&acc)[TN], BFrag<PREC> (&b)[kMaxKS]) {
 // (measured: the stash traffic, not the MFMA chain, dominates K2/K3).  Stores therefore go through a per-wave LDS
 // image [32 samples][256 features] (+8 bytes row padding: conflict-free both ways) and leave as whole 512-byte rows.
 // ---------------------------------------------------------------------------------------------------------
+// Stash stores stream out of the chip (nothing re-reads them within the kernel, except through their own lane-private
+// path much later): FNEUS_NT_STORES marks them non-temporal so that they do not displace the packed weights in L2.
+#ifndef FNEUS_NT_STORES
+#define FNEUS_NT_STORES 13     // measured (N = 65 536, parity mode): K2 961 -> 801 us, K3 1077 -> 931 us; with bit 1 as well K2 +4 %
+#endif
+// bit 0: row-major planes and the lane-private a_l (read by later kernels only), bit 1: sigma' (re-read by the reverse
+// sweep of the same kernel), bit 2: K3's coupling scratch (re-read by its descending chain)
+template <int KIND, class T>
+FN_DEV T stream_load(const T* p) {      // bit 3: the lane-private planes are read once per pass and never hit a cache
+    if constexpr ((FNEUS_NT_STORES >> KIND) & 1)
+        return __builtin_nontemporal_load(p);
+    else
+        return *p;
+}
+template <int KIND, class T>
+FN_DEV void stream_store(T* p, T v) {
+    if constexpr ((FNEUS_NT_STORES >> KIND) & 1)
+        __builtin_nontemporal_store(v, p);
+    else
+        *p = v;
+}
+
 constexpr int kScrStride = 520;
 constexpr int kScrPlane = 32 * kScrStride;               // 16 640
 constexpr int kWaveScr = 2 * kScrPlane;                  // 33 280 bytes of LDS per wavefront (hi and lo image)
@@ -234,8 +262,8 @@ FN_DEV void store_stash(unsigned char* __restrict__ wscr, int lane, const f32x16
 #else
             if (n0 + row < N)
 #endif
-                *reinterpret_cast<uint2*>(plane + (n0 + row) * ld + pc * 4) =
-                    *reinterpret_cast<const uint2*>(wscr + pl * kScrPlane + row * kScrStride + pc * 8);
+                stream_store<0>(reinterpret_cast<u32x2*>(plane + (n0 + row) * ld + pc * 4),
+                             *reinterpret_cast<const u32x2*>(wscr + pl * kScrPlane + row * kScrStride + pc * 8));
         }
     }
 #else
@@ -287,12 +315,12 @@ FN_DEV void priv_put(void* __restrict__ base, int slot, int lane, const float (&
 #ifdef FNEUS_DBG_NO_PRIV
     if (lane < 0)
 #endif
-    reinterpret_cast<typename PrivT<PREC>::v4*>(base)[slot * 64 + lane] = o;
+    stream_store<0>(reinterpret_cast<typename PrivT<PREC>::v4*>(base) + slot * 64 + lane, o);
 }
 
 template <int PREC>
 FN_DEV void priv_get(const void* __restrict__ base, int slot, int lane, float (&v)[4]) {
-    const typename PrivT<PREC>::v4 o = reinterpret_cast<const typename PrivT<PREC>::v4*>(base)[slot * 64 + lane];
+    const typename PrivT<PREC>::v4 o = stream_load<3>(reinterpret_cast<const typename PrivT<PREC>::v4*>(base) + slot * 64 + lane);
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = (float)o[e];
 }
@@ -307,10 +335,13 @@ FN_DEV void sig_put(void* __restrict__ base, int slot, int lane, const float (&v
 #ifdef FNEUS_DBG_NO_PRIV
     if (lane < 0)
 #endif
-    reinterpret_cast<u16x4*>(base)[slot * 64 + lane] = o;
+    stream_store<1>(reinterpret_cast<u16x4*>(base) + slot * 64 + lane, o);
 }
+// STREAM: non-temporal load, for data written by an EARLIER kernel (K2 re-reads the sigma' it wrote itself: plain load)
+template <bool STREAM = false>
 FN_DEV void sig_get(const void* __restrict__ base, int slot, int lane, float (&v)[4]) {
-    const u16x4 o = reinterpret_cast<const u16x4*>(base)[slot * 64 + lane];
+    const u16x4* p = reinterpret_cast<const u16x4*>(base) + slot * 64 + lane;
+    const u16x4 o = STREAM ? stream_load<3>(p) : *p;
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = (float)o[e] * (1.0f / 65535.0f);
 }
@@ -356,7 +387,7 @@ FN_DEV void store_f32(const f32x16 (&acc)[TN], float* __restrict__ dst, int ld, 
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = acc[t][4 * g + e];
-            *reinterpret_cast<f32x4*>(dst + n * ld + 32 * t + 8 * g + 4 * h) = v;
+            stream_store<0>(reinterpret_cast<f32x4*>(dst + n * ld + 32 * t + 8 * g + 4 * h), v);
         }
 }
 
@@ -366,7 +397,7 @@ FN_DEV void load_f32(f32x16 (&acc)[TN], const float* __restrict__ src, int ld, l
     for (int t = 0; t < TN; ++t)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(src + n * ld + 32 * t + 8 * g + 4 * h);
+            const f32x4 v = stream_load<3>(reinterpret_cast<const f32x4*>(src + n * ld + 32 * t + 8 * g + 4 * h));
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[t][4 * g + e] = v[e];
         }
