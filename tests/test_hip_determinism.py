@@ -1,0 +1,52 @@
+"""Repeated launches of the chain kernels must be bit-identical (no atomics on these paths): a guard against data races
+between the wavefronts of a workgroup (tools/dbg_race.py found one in the opt-in tensor-parallel K2 this way)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _net():
+    from fneus import ops, synth
+    from oracle import ref_torch as R
+    dev = torch.device("cuda:0")
+    sd = {k: torch.from_numpy(v) for k, v in synth.sdf_state_dict(20).items()}
+    p = R.sdf_params_from_state_dict(sd)
+    net = ops.PackedNet("sdf", dev)
+    net.set_raw_from_effective([w.to(dev) for w in p["W"]], [b.to(dev) for b in p["b"]])
+    net.pack()
+    return net, dev
+
+
+@pytest.mark.parametrize("n", [8192, 40000])          # tensor-parallel small launch / one wave per tile
+def test_sdf_fwd_is_reproducible(n):
+    from fneus import ops
+    net, dev = _net()
+    x = (torch.rand(n, 3, device=dev) * 2 - 1).contiguous()
+    ref = ops.sdf_fwd(net.blob, n, 3, pts=x).clone()
+    for _ in range(40):
+        assert torch.equal(ops.sdf_fwd(net.blob, n, 3, pts=x), ref)
+
+
+def test_sdf_fwd_grad_and_bwd_are_reproducible():
+    from fneus import ops
+    net, dev = _net()
+    n = 32768
+    x = (torch.rand(n, 3, device=dev) * 2 - 1).contiguous()
+    ds, df, dn = torch.randn(n, device=dev), torch.randn(n, 256, device=dev), torch.randn(n, 3, device=dev)
+
+    def run():
+        st = ops.SdfStash(n, dev, 3, True)
+        bufs = ops.SdfBwdBufs(n, dev, 3)
+        for t in (st.h, st.a, bufs.adj, bufs.zbar):      # slot 3 of these planes has 224 valid columns: define the rest
+            t.zero_()
+        sdf, feat, nrm = ops.sdf_fwd_grad(net.blob, n, 3, st, True, pts=x)
+        ops.sdf_bwd(net.blob, n, 3, st, bufs, ds, df, dn, pts=x)
+        torch.cuda.synchronize()
+        return [t.clone() for t in (sdf, feat, nrm, st.h, st.a, bufs.adj, bufs.zbar)]
+
+    ref = run()
+    for _ in range(12):
+        for a, b, name in zip(run(), ref, ("sdf", "feat", "normal", "h", "a", "adj", "zbar")):
+            assert torch.equal(a, b), name
