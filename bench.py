@@ -98,6 +98,10 @@ def cpu_baseline(budget_s: float = 20.0):
                       f"{os.cpu_count()} host cores, median {t:.2f} s/step"}
 
 
+# newest first: the PMC passes are re-collected whenever a kernel's memory behaviour changes (tools/collect_profiles.sh)
+TRAFFIC_FILES = ("r01_d_traffic.json", "r01_c_traffic.json")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -190,13 +194,15 @@ def main():
         dom = max((k for k in per if k in KERNEL_FLOPS), key=lambda k: per[k]["ms_per_step"])
         flops_per_launch = KERNEL_FLOPS[dom] / max(round(per[dom]["launches_per_step"]), 1)
         achieved = flops_per_launch / (per[dom]["avg_ms"] * 1e-3) / 1e12
-        traffic = None      # HBM bytes per launch from the committed PMC passes (profiles/r01_c_traffic.json), parity mode only
-        try:
-            if prec == ops.PREC_PARITY:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_c_traffic.json")))["kernels"]
-                traffic = tj[dom.split(":")[0]]["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
+        traffic = None      # HBM bytes per launch from the committed PMC passes (profiles/*_traffic.json), parity mode only
+        if prec == ops.PREC_PARITY:
+            for tag in TRAFFIC_FILES:
+                try:
+                    tj = json.load(open(os.path.join(ROOT, "profiles", tag)))["kernels"]
+                    traffic = tj[dom.split(":")[0]]["hbm_bytes_per_launch"]
+                    break
+                except Exception:
+                    continue
         if prec == ops.PREC_PARITY and dom in KERNEL_BYTES_PARITY:
             # the same launch seen against the HBM roofline: these kernels move their whole activation stash
             gbs = KERNEL_BYTES_PARITY[dom] / max(round(per[dom]["launches_per_step"]), 1) / (per[dom]["avg_ms"] * 1e-3) / 1e9

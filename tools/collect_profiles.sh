@@ -1,0 +1,28 @@
+#!/bin/bash
+# Collect one round's judged artefacts on the GPU box into gpurun_out/<tag>_* (copy the ones to keep into profiles/):
+#   tools/collect_profiles.sh r01_d
+# bench line, the same command under rocprofv3 --kernel-trace --stats, one eager step's timeline, and the HBM traffic
+# counters (FETCH_SIZE and WRITE_SIZE in separate --pmc passes, no trace domains alongside).
+set -u
+tag=${1:-r01_x}
+root=$(cd "$(dirname "$0")/.." && pwd)
+out=$root/gpurun_out
+mkdir -p "$out"
+export TMPDIR=/tmp
+cd /tmp
+python3 "$root/bench.py" --steps 30 --warmup 5 > "$out/${tag}_bench.json" 2> "$out/${tag}_bench.err"
+tail -1 "$out/${tag}_bench.json"
+rm -rf /tmp/prof_k /tmp/prof_t /tmp/pmc_f /tmp/pmc_w
+rocprofv3 --kernel-trace --stats -d /tmp/prof_k -o k --output-format csv -- python3 "$root/bench.py" --steps 16 --warmup 3 --no-cpu-baseline --no-fast-extra \
+    > "$out/${tag}_bench_under_rocprof.json" 2> "$out/${tag}_rocprof.err"
+ks=$(find /tmp/prof_k -name '*kernel_stats.csv' | head -1)
+python3 "$root/tools/summarize_prof.py" "$ks" 22 > "$out/${tag}_kernel_stats.txt"
+head -16 "$out/${tag}_kernel_stats.txt"
+rocprofv3 --kernel-trace -d /tmp/prof_t -o t --output-format csv -- python3 "$root/bench.py" --steps 4 --warmup 2 --no-graph --no-cpu-baseline --no-fast-extra --no-profile \
+    > /dev/null 2> "$out/${tag}_rocprof_t.err"
+kt=$(find /tmp/prof_t -name '*kernel_trace.csv' | head -1)
+python3 "$root/tools/step_timeline.py" "$kt" > "$out/${tag}_step_timeline.txt" 2>&1
+rocprofv3 --pmc FETCH_SIZE -d /tmp/pmc_f -o f --output-format csv -- python3 "$root/tools/pmc_run.py" parity 2 > /dev/null 2> "$out/${tag}_pmc_f.err"
+rocprofv3 --pmc WRITE_SIZE -d /tmp/pmc_w -o w --output-format csv -- python3 "$root/tools/pmc_run.py" parity 2 > /dev/null 2> "$out/${tag}_pmc_w.err"
+python3 "$root/tools/pmc_summary.py" --json "$out/${tag}_traffic.json" /tmp/pmc_f /tmp/pmc_w > "$out/${tag}_pmc_fetch_write.txt"
+grep -A2 -E "^(sdf_bwd|sdf_fwd_grad|dw_gemm)" "$out/${tag}_pmc_fetch_write.txt"

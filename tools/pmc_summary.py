@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
 """Average rocprofv3 --pmc counter_collection.csv values per kernel (fneus kernels only)."""
-import csv, sys, collections, glob
+import csv, sys, collections, glob, json
+json_out = None
+if "--json" in sys.argv:
+    i = sys.argv.index("--json")
+    json_out = sys.argv[i + 1]
+    del sys.argv[i:i + 2]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for path in sys.argv[1:]:
     for f in glob.glob(path + "/**/*counter_collection.csv", recursive=True):
@@ -14,3 +19,25 @@ for k in sorted(acc):
     for c in sorted(acc[k]):
         v = acc[k][c]
         print(f"   {c:32s} {sum(v) / len(v):16.0f}  (n={len(v)})")
+
+if json_out:
+    # HBM bytes per launch: FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE under-counts wide coalesced reads 2x on gfx950
+    # (MI355X_MICROARCH.md, HBM section).  Keys are the C-ABI entry points bench.py reports its kernels under.
+    entry = {"sdf_bwd_kernel": "fneus_sdf_bwd", "sdf_fwd_grad": "fneus_sdf_fwd_grad", "dw_gemm_kernel": "fneus_dw_gemm",
+             "color_fwd_kernel": "fneus_color_fwd", "color_bwd_kernel": "fneus_color_bwd", "sdf_fwd": "fneus_sdf_fwd",
+             "refcolor_fwd": "fneus_refcolor_fwd", "refcolor_bwd": "fneus_refcolor_bwd"}
+    ks = {}
+    for k in sorted(acc):
+        for pre, name in entry.items():
+            if not k.startswith(pre):
+                continue
+            if name not in ks and "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
+                f = sum(acc[k]["FETCH_SIZE"]) / len(acc[k]["FETCH_SIZE"])
+                w = sum(acc[k]["WRITE_SIZE"]) / len(acc[k]["WRITE_SIZE"])
+                ks[name] = {"kernel": k, "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "hbm_bytes_per_launch": (2 * f + w) * 1024}
+            break           # first entry wins: sdf_fwd_grad_* must not also file under sdf_fwd
+    json.dump({"_note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/collect_profiles.sh, "
+                        "tools/pmc_run.py parity 2, N = 65536 samples per launch); hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: "
+                        "FETCH_SIZE under-counts wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md, HBM section). "
+                        "A kernel with several launch shapes per step (dw_gemm, sdf_fwd) is the average over them.",
+               "kernels": ks}, open(json_out, "w"), indent=1)
