@@ -57,41 +57,54 @@ KERNEL_BYTES_PARITY = {
 CPU_RAYS = 128          # bounded CPU sample: a quarter batch of the same workload (same samples per ray, same nets)
 
 
-def cpu_baseline(budget_s: float = 20.0):
-    """The oracle (CPU port of the reference algorithm) timed on the host cores: same workload, bounded sample."""
+def cpu_baseline(budget_s: float = 20.0, device=None):
+    """The oracle (CPU port of the reference algorithm) timed on the host cores: same workload, bounded sample.
+    With `device` = the GPU the same port runs through stock PyTorch-ROCm ops on the full batch: the "unfused GPU" figure
+    the reference itself would get on this box; reported inside the cpu_baseline object."""
     from oracle import ref_torch as R
     from fneus import synth
     threads = min(32, os.cpu_count() or 1)     # eager torch on small ops gets slower, not faster, beyond ~32 threads
     torch.set_num_threads(threads)
-    T = lambda sd: {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in sd.items()}
+    on_gpu = device is not None
+    n_rays = RAYS if on_gpu else CPU_RAYS
+    dev = device if on_gpu else torch.device("cpu")
+    T = lambda sd: {k: torch.from_numpy(v).clone().to(dev).requires_grad_(True) for k, v in sd.items()}
     sd_sdf, sd_col, sd_ref = T(synth.sdf_state_dict(0)), T(synth.color_state_dict(1)), T(synth.refcolor_state_dict(2))
-    variance = torch.tensor(0.3, requires_grad=True)
+    variance = torch.tensor(0.3, device=dev, requires_grad=True)
     leaves = list(sd_sdf.values()) + list(sd_col.values()) + list(sd_ref.values()) + [variance]
     opt = torch.optim.Adam(leaves, lr=5e-4)
     times = []
     t_start = time.time()
     step = 0
     while True:
-        data = torch.from_numpy(synth.ray_batch(CPU_RAYS, seed=1000 + step))
+        data = torch.from_numpy(synth.ray_batch(n_rays, seed=1000 + step)).to(dev)
         rays_o, rays_d, rgb, mask = data[:, :3], data[:, 3:6], data[:, 6:9], data[:, 9:10]
+        if on_gpu:
+            torch.cuda.synchronize()
         t0 = time.time()
         near, far = R.near_far_from_sphere(rays_o, rays_d)
         out = R.render(rays_o, rays_d, near, far, R.sdf_params_from_state_dict(sd_sdf), R.inv_s_from_variance(variance),
                        R.color_params_from_state_dict(sd_col), sd_ref, None, n_samples=N_SAMPLES,
-                       n_importance=N_IMPORTANCE, t_rand=torch.rand(CPU_RAYS, 1), cos_anneal_ratio=1.0)
+                       n_importance=N_IMPORTANCE, t_rand=torch.rand(n_rays, 1, device=dev), cos_anneal_ratio=1.0)
         losses = R.stage1_loss(out, rgb, mask, 0.1, 0.1, 0.1)
         opt.zero_grad()
         losses["loss"].backward()
         opt.step()
+        if on_gpu:
+            torch.cuda.synchronize()
         dt = time.time() - t0
         if step > 0 or budget_s <= 0:
             times.append(dt)
         step += 1
-        if (time.time() - t_start > budget_s and len(times) >= 1) or step >= 5 or (step >= 1 and dt > budget_s):
+        if (time.time() - t_start > budget_s and len(times) >= 1) or step >= (8 if on_gpu else 5) or (step >= 1 and dt > budget_s):
             break
     if not times:
         times = [dt]
     t = float(np.median(times))
+    if on_gpu:
+        return {"value": n_rays * (N_SAMPLES + N_IMPORTANCE) / t, "unit": "ray-samples/s", "ms_per_step": t * 1e3,
+                "sample": f"{len(times)} full {n_rays}-ray train steps of oracle/ref_torch.py (fp32, eager stock PyTorch-ROCm "
+                          f"ops, autograd double backward) on the same GPU after 1 warm-up"}
     return {"value": CPU_RAYS * (N_SAMPLES + N_IMPORTANCE) / t, "unit": "ray-samples/s", "cores": threads, "kind": "port",
             "sample": f"{len(times)} train steps of {CPU_RAYS} rays x {N_SAMPLES + N_IMPORTANCE} samples (1/4 batch of the "
                       f"same workload) after 1 warm-up, oracle/ref_torch.py fp32, {threads} torch threads of "
@@ -242,6 +255,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             result["cpu_baseline"] = cpu_baseline()
+            try:
+                result["cpu_baseline"]["same_port_on_this_gpu"] = cpu_baseline(device=device)
+            except Exception as e:
+                result["cpu_baseline"]["same_port_on_this_gpu"] = {"value": None, "error": repr(e)}
         except Exception as e:   # the baseline must never take the GPU number down with it
             result["cpu_baseline"] = {"value": None, "error": repr(e)}
 

@@ -1,7 +1,9 @@
-// Packed-weight blob layouts (compile-time) for the two MLPs on the stage-1 hot path.
+// Packed-weight blob layouts (compile-time) for the MLPs on the stage-1 hot path.
 //
 // SDF network   : reference models/fields.py:9-91   dims [39,256,256,256,256(217 out),256,256,256,256,257], skip at 4
 // colour network: reference models/fields.py:114-175 dims [289,256,256,256,256,3]
+// background NeRF++ (womask): reference models/fields.py:178-259  84 -> 8 x 256 (input re-concatenated before layer 5)
+//                 -> alpha 1 | feature 256 -> [feature | PE4(view) 27] -> 128 -> rgb 3
 //
 // A "fragment" is one MFMA A operand: 64 lanes x 8 bf16 = 1 KiB.  A layer's forward pack holds KS*NT fragments
 // ordered [ks][t] (hi plane, then lo plane); the reverse pack (A = W^T) likewise.  Bias packs are fp32 in
@@ -40,6 +42,25 @@ constexpr LayerGeom kColGeom[kColLayers] = {
     {16, 1, 2, 8},    // 4: 256 -> 3 (one tile)
 };
 
+// One entry per PACK (not per nn.Linear): pts_linears.5 takes [PE 84 | h 256] and is packed as two operand groups
+// (entries 5 and 6) that accumulate into the same tiles; feature_linear and alpha_linear share entry 9 (257 rows).
+constexpr int kNerfLayers = 12;
+constexpr LayerGeom kNerfGeom[kNerfLayers] = {
+    {6, 8, 0, 0},     // 0: pts_linears.0   PE10(4-D point) 84 -> 96 k-slots
+    {16, 8, 16, 8},   // 1: pts_linears.1
+    {16, 8, 16, 8},   // 2
+    {16, 8, 16, 8},   // 3
+    {16, 8, 16, 8},   // 4: pts_linears.4
+    {16, 8, 16, 8},   // 5: pts_linears.5, columns of h (reference columns 84..339)
+    {6, 8, 0, 0},     // 6: pts_linears.5, columns of the re-concatenated PE (reference columns 0..83); no reverse: the
+                      //    encoding has no trainable ancestor
+    {16, 8, 16, 8},   // 7: pts_linears.6
+    {16, 8, 16, 8},   // 8: pts_linears.7
+    {16, 9, 18, 8},   // 9: feature_linear (tiles 0..7) + alpha_linear (tile 8, row 0)
+    {18, 4, 8, 8},    // 10: views_linears.0  [feature 256 ; PE4(view) 27 -> 32] -> 128; reverse rows: the 256 feature inputs
+    {8, 1, 2, 4},     // 11: rgb_linear 128 -> 3 (one tile)
+};
+
 struct LayerOff {
     uint32_t fwd_hi, fwd_lo, rev_hi, rev_lo, bias;
 };
@@ -69,6 +90,7 @@ constexpr NetLayout<NL> make_layout(const LayerGeom (&g)[NL], int extra_bytes) {
 
 constexpr NetLayout<kSdfLayers> kSdfLayout = make_layout<kSdfLayers>(kSdfGeom, 8 * 2 * 16 * 4);
 constexpr NetLayout<kColLayers> kColLayout = make_layout<kColLayers>(kColGeom, 0);
+constexpr NetLayout<kNerfLayers> kNerfLayout = make_layout<kNerfLayers>(kNerfGeom, 0);
 
 // flat fp32 parameter layouts (natural order): for each layer W[out][in] row-major, then b[out]
 constexpr int kSdfIn[kSdfLayers]  = {39, 256, 256, 256, 256, 256, 256, 256, 256};

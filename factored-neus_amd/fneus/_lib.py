@@ -33,6 +33,12 @@ class FneusColStash(C.Structure):
                 ("side_hi", "side_lo", "u_hi", "u_lo", "zbar_hi", "zbar_lo", "mask", "feat_hi", "feat_lo")]
 
 
+class FneusNerfStash(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("pe_hi", "pe_lo", "h_hi", "h_lo", "feat_hi", "feat_lo", "dpe_hi", "dpe_lo", "hv_hi", "hv_lo", "mask",
+                 "zbar_hi", "zbar_lo", "zfeat_hi", "zfeat_lo", "zhv_hi", "zhv_lo", "zout_hi", "zout_lo")]
+
+
 class FneusAdamSegment(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("count", C.c_long)]
@@ -76,6 +82,8 @@ def _load():
         "fneus_refcolor_bwd_both": (C.c_int, [vp, vp, l, vp, ip, vp, vp, vp, vp, vp, vp, C.POINTER(FneusColStash),
                                               C.POINTER(FneusColStash), vp, vp, ip, vp]),
         "fneus_dw_gemm": (C.c_int, [vp, ip, ip, l, ip, vp]),
+        "fneus_nerf_bg_fwd": (C.c_int, [vp, vp, vp, l, C.POINTER(FneusNerfStash), vp, vp, ip, ip, vp]),
+        "fneus_nerf_bg_bwd": (C.c_int, [vp, l, vp, vp, C.POINTER(FneusNerfStash), ip, vp]),
         "fneus_adam": (C.c_int, [C.POINTER(FneusAdamSegment), ip, vp, vp, C.c_double, C.c_double, C.c_double, ip, vp]),
         "fneus_surface_gather": (C.c_int, [vp, vp, vp, vp, vp, ip, ip, vp, vp, vp, vp, vp]),
         "fneus_stage1_loss": (C.c_int, [vp] * 11 + [ip, f, f, f] + [vp] * 10 + [vp]),

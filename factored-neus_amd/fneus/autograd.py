@@ -113,6 +113,30 @@ class ColorFn(torch.autograd.Function):
         return None, d_normal, d_feat, None, None, None, None, None, None, None
 
 
+class NerfFn(torch.autograd.Function):
+    """K7: the background NeRF++ (fields.py:233-259).  Its inputs are constants (sample positions and view directions);
+    the backward writes the dL/dz planes and accumulates the parameter gradients into the network's flat buffer."""
+
+    @staticmethod
+    def forward(ctx, anchor, net, pts4, dirs, prec: int, ws: _Workspace, train: bool):
+        n = int(pts4.shape[0])
+        stash = ws.get(("nerf_stash", n, prec), lambda: ops.NerfStash(n, anchor.device, prec)) if train else None
+        density, rgb = ops.nerf_fwd(net.blob, n, prec, pts4, dirs, stash, train)
+        ctx.net, ctx.prec, ctx.ws, ctx.stash, ctx.n = net, prec, ws, stash, n
+        return density, rgb
+
+    @staticmethod
+    def backward(ctx, d_density, d_rgb):
+        n, prec, net, ws = ctx.n, ctx.prec, ctx.net, ctx.ws
+        dev = net.blob.device
+        d_density = torch.zeros(n, device=dev) if d_density is None else d_density.contiguous()
+        d_rgb = torch.zeros(n, 3, device=dev) if d_rgb is None else d_rgb.contiguous()
+        ops.nerf_bwd(net.blob, n, prec, d_density, d_rgb, ctx.stash)
+        jobs = ws.get(("nerf_jobs", n, prec), lambda: ops.nerf_dw_jobs(net, ctx.stash, n))
+        jobs.run(n, prec)
+        return None, None, None, None, None, None, None
+
+
 class RefHeadsFn(torch.autograd.Function):
     """Both MLPs of RefColor (fields.py:303-330) on the gathered surface samples: one forward launch, one backward
     launch, one weight-gradient GEMM launch for the two networks.  Differentiable inputs: normal, feature."""

@@ -240,3 +240,76 @@ def build_refcd_jobs():
 def build_refvd_jobs():
     return build_color_jobs(REFVD_IN, REFVD_OUT, REFVD_SIDE, weight_norm=False)
 
+
+
+# ---- background NeRF++ (reference models/fields.py:178-259), plain nn.Linear layers ------------------------------------
+# parameter layers in the order of NERF_NAMES; feature_linear and alpha_linear are adjacent in the flat buffer so that
+# their weights form ONE [257][256] matrix (and their biases one [257] vector) for the shared pack entry 9
+NERF_NAMES = [f"pts_linears.{i}" for i in range(8)] + ["feature_linear", "alpha_linear", "views_linears.0", "rgb_linear"]
+NERF_IN = [84, 256, 256, 256, 256, 340, 256, 256, 256, 256, 283, 128]
+NERF_OUT = [256, 256, 256, 256, 256, 256, 256, 256, 256, 1, 128, 3]
+NERF_PE, NERF_VIEW_PE = 84, 27
+
+
+def nerf_raw_offsets():
+    offB, offV, o = [], [], 0
+    for l, (i, k) in enumerate(zip(NERF_IN, NERF_OUT)):
+        if NERF_NAMES[l] == "feature_linear":       # b_feature[256] b_alpha[1] W_feature[256][256] W_alpha[1][256]
+            offB += [o, o + 256]
+            offV += [o + 257, o + 257 + 256 * 256]
+            o += 257 + 257 * 256
+        elif NERF_NAMES[l] == "alpha_linear":
+            continue
+        else:
+            offB.append(o)
+            o += k
+            offV.append(o)
+            o += i * k
+    return offB, offV, o
+
+
+def build_nerf_jobs():
+    """Pack tables of the background NeRF++ (csrc/fneus_layout.h kNerfGeom: one entry per pack).  There is no separate
+    effective-parameter buffer: the layers are plain Linear, the weight-gradient GEMM accumulates straight into the raw
+    gradient (offW / offb = offV / offB)."""
+    ly = query_layout(2)
+    offB, offV, total_raw = nerf_raw_offsets()
+    b = _Builder()
+    P = {name: i for i, name in enumerate(NERF_NAMES)}
+    # pack entry -> (parameter layer, forward k-map as reference column per feature slot index, reverse row map)
+    for e in range(12):
+        ksf, ntf, ksr, ntr = [int(v) for v in ly.geom[e]]
+        fwd_hi, fwd_lo, rev_hi, rev_lo, bias = [int(v) for v in ly.off[e]]
+        feat = slot_features(ksf)
+        rows = np.arange(ntf * 32)
+        rin = np.arange(ntr * 32)
+        with_bias, n_rows_src = True, None
+        if e == 0:
+            pl, kmap, rowmap_r = P["pts_linears.0"], _lim(feat, NERF_PE), None
+        elif e in (1, 2, 3, 4):
+            pl, kmap, rowmap_r = e, _lim(feat, 256), _lim(rin, 256)
+        elif e == 5:        # pts_linears.5, h columns: reference input = cat([input_pts 84, h 256]) (fields.py:245)
+            pl, kmap, rowmap_r = 5, np.where(feat < 256, feat + NERF_PE, -1), np.where(rin < 256, rin + NERF_PE, -1)
+        elif e == 6:        # pts_linears.5, encoding columns (accumulates into the same tiles; bias lives in entry 5)
+            pl, kmap, rowmap_r, with_bias = 5, _lim(feat, NERF_PE), None, False
+        elif e in (7, 8):
+            pl, kmap, rowmap_r = e - 1, _lim(feat, 256), _lim(rin, 256)
+        elif e == 9:        # rows 0..255 feature_linear, row 256 alpha_linear: one [257][256] matrix in the flat buffer
+            pl, kmap, rowmap_r, n_rows_src = P["feature_linear"], _lim(feat, 256), _lim(rin, 256), 257
+        elif e == 10:       # views_linears.0: columns [feature 256 | PE4(view) 27]; reverse only onto the feature inputs
+            pl, kmap, rowmap_r = P["views_linears.0"], _lim(feat, 256 + NERF_VIEW_PE), _lim(rin, 256)
+        else:
+            pl, kmap, rowmap_r = P["rgb_linear"], _lim(feat, 128), _lim(rin, 128)
+        n_in = NERF_IN[pl]
+        n_out = n_rows_src if n_rows_src else NERF_OUT[pl]
+        rowmap = _lim(rows, n_out)
+        b.frag(fwd_hi, fwd_lo, offV[pl], n_in, ksf, ntf, 0, rowmap, kmap, 1.0, -1)
+        if rowmap_r is not None:
+            b.frag(rev_hi, rev_lo, offV[pl], n_in, ksr, ntr, 1, rowmap_r, _lim(slot_features(ksr), n_out), 1.0, -1)
+        if with_bias:
+            b.accvec(bias, offB[pl], 1, ntf, rowmap)
+    jobs, maps, units = b.finish()
+    return {"layout": ly, "jobs": jobs, "maps": maps, "units": units, "n_params": 0, "offW": offV, "offb": offB,
+            "ins": NERF_IN, "outs": NERF_OUT, "n_raw": total_raw, "offB": offB, "offG": [None] * 12, "offV": offV,
+            "rows": np.zeros(0, dtype=ROW_DTYPE), "bias_segs": np.zeros((0, 4), dtype=np.int32), "weight_norm": False,
+            "names": NERF_NAMES}

@@ -67,7 +67,8 @@ class PackedNet:
 
     def __init__(self, kind: str, device, raw_grad: Optional[torch.Tensor] = None):
         builders = {"sdf": netdesc.build_sdf_jobs, "color": netdesc.build_color_jobs,
-                    "refcd": netdesc.build_refcd_jobs, "refvd": netdesc.build_refvd_jobs}
+                    "refcd": netdesc.build_refcd_jobs, "refvd": netdesc.build_refvd_jobs,
+                    "nerf": netdesc.build_nerf_jobs}
         desc = builders[kind]()
         self.kind, self.desc, self.device = kind, desc, device
         self.layout = desc["layout"]
@@ -390,6 +391,72 @@ def color_dw_jobs(net: PackedNet, feat_planes: torch.Tensor, stash: ColStash, gr
     g.add(stash.zbar[:, 4], stash.u[:, 3], base + 4 * offW[4], 256, n_out, 256, 32, 256, 32, 256,
           bias_ptr=base + 4 * offb[4])
     return g if into is not None else g.finalize()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# K7: background NeRF++ (womask)
+# ------------------------------------------------------------------------------------------------------------
+class NerfStash:
+    """bf16 activation planes of fneus_nerf_bg_fwd / _bwd (include/fneus.h FneusNerfStash)."""
+
+    def __init__(self, n: int, device, prec: int):
+        bf = torch.bfloat16
+        planes = 2 if prec == 3 else 1
+        z = lambda *shape: torch.zeros((planes,) + shape, dtype=bf, device=device)
+        self.pe, self.h, self.feat, self.dpe, self.hv = z(n, 96), z(8, n, 256), z(n, 256), z(n, 32), z(n, 128)
+        self.zbar, self.zfeat, self.zhv, self.zout = z(8, n, 256), z(n, 256), z(n, 128), z(n, 64)
+        self.mask = torch.zeros(((n + 31) // 32) * 9 * 64 * 4, dtype=torch.int32, device=device)
+        s = _lib.FneusNerfStash()
+        s.mask = self.mask.data_ptr()
+        for name in ("pe", "h", "feat", "dpe", "hv", "zbar", "zfeat", "zhv", "zout"):
+            t = getattr(self, name)
+            setattr(s, name + "_hi", t[0].data_ptr())
+            setattr(s, name + "_lo", t[1].data_ptr() if planes == 2 else None)
+        self.c = s
+
+
+def nerf_fwd(blob, n_pts, prec, pts4, dirs, stash: Optional[NerfStash], train: bool):
+    """NeRF.forward (fields.py:233-259) on the HIP engine -> raw density [n], raw rgb [n,3]"""
+    _chk_f32(pts4, "pts4")
+    _chk_f32(dirs, "dirs")
+    density = torch.empty(n_pts, dtype=torch.float32, device=blob.device)
+    rgb = torch.empty(n_pts, 3, dtype=torch.float32, device=blob.device)
+    _launch("fneus_nerf_bg_fwd", lib.fneus_nerf_bg_fwd, _ptr(blob), _ptr(pts4), _ptr(dirs), n_pts,
+            C.byref(stash.c) if stash is not None else None, _ptr(density), _ptr(rgb), prec, int(train), _stream())
+    return density, rgb
+
+
+def nerf_bwd(blob, n_pts, prec, d_density, d_rgb, stash: NerfStash):
+    _chk_f32(d_density, "d_density")
+    _chk_f32(d_rgb, "d_rgb")
+    _launch("fneus_nerf_bg_bwd", lib.fneus_nerf_bg_bwd, _ptr(blob), n_pts, _ptr(d_density), _ptr(d_rgb), C.byref(stash.c), prec,
+            _stream())
+
+
+def nerf_dw_jobs(net: PackedNet, st: NerfStash, n: int) -> GemmJobs:
+    """weight / bias gradients of the 12 Linear layers, accumulated straight into net.raw_grad (plain layers: the raw
+    layout IS the effective one)"""
+    g = GemmJobs(net.raw_grad.device, "nerf")
+    d = net.desc
+    P = {name: i for i, name in enumerate(d["names"])}
+    base = net.raw_grad.data_ptr()
+    W = lambda name, col=0: base + 4 * (d["offV"][P[name]] + col)
+    Bv = lambda name: base + 4 * d["offB"][P[name]]
+    zb = lambda l: st.zbar[:, l]
+    hh = lambda l: st.h[:, l]
+    g.add(zb(0), st.pe, W("pts_linears.0"), 84, 256, 84, 256, 96, 256, 96, bias_ptr=Bv("pts_linears.0"))
+    for l in (1, 2, 3, 4, 6, 7):
+        g.add(zb(l), hh(l - 1), W(f"pts_linears.{l}"), 256, 256, 256, 256, 256, 256, 256, bias_ptr=Bv(f"pts_linears.{l}"))
+    # pts_linears.5: columns [PE 84 | h 256] (fields.py:245)
+    g.add(zb(5), st.pe, W("pts_linears.5"), 340, 256, 84, 256, 96, 256, 96, bias_ptr=Bv("pts_linears.5"))
+    g.add(zb(5), hh(4), W("pts_linears.5", 84), 340, 256, 256, 256, 256, 256, 256)
+    g.add(st.zfeat, hh(7), W("feature_linear"), 256, 256, 256, 256, 256, 256, 256, bias_ptr=Bv("feature_linear"))
+    g.add(st.zout, hh(7), W("alpha_linear"), 256, 1, 256, 64, 256, 32, 256, bias_ptr=Bv("alpha_linear"), a_off=32)
+    # views_linears.0: columns [feature 256 | PE4(view) 27]
+    g.add(st.zhv, st.feat, W("views_linears.0"), 283, 128, 256, 128, 256, 128, 256, bias_ptr=Bv("views_linears.0"))
+    g.add(st.zhv, st.dpe, W("views_linears.0", 256), 283, 128, 27, 128, 32, 128, 32)
+    g.add(st.zout, st.hv, W("rgb_linear"), 128, 3, 128, 64, 128, 32, 128, bias_ptr=Bv("rgb_linear"))
+    return g.finalize()
 
 
 # ------------------------------------------------------------------------------------------------------------

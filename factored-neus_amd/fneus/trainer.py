@@ -60,6 +60,8 @@ class Stage1Trainer:
         self.sdf_network.set_precision(prec)
         self.color_network.set_precision(prec)
         self.refColor_network.set_precision(prec)
+        if self.nerf_outside is not None:
+            self.nerf_outside.set_precision(prec)
         self.params = [p for m in self.modules for p in m.parameters()]
         # data parallel: a 4-float all-reduce of the loss normalisers sits in the middle of the step, so the step is not
         # captured as one graph there (eager launches run ahead of the GPU anyway)
@@ -68,8 +70,8 @@ class Stage1Trainer:
         # every gradient of the model lives in ONE arena: the fused MLPs accumulate into slices of it, the small torch
         # modules get persistent .grad views (autograd accumulates into them in place).  FlatAdam addresses parameters
         # and gradients by pointer and clears the gradients itself; data parallel = one in-place all-reduce of the arena.
-        self.grads = GradArena(device, [self.sdf_network, self.color_network], self.refColor_network,
-                               [self.deviation_network, self.nerf_outside])
+        fused = [self.sdf_network, self.color_network] + ([self.nerf_outside] if self.nerf_outside is not None else [])
+        self.grads = GradArena(device, fused, self.refColor_network, [self.deviation_network])
         self.optimizer = FlatAdam(self.params, lr=lr)
         self._graphs = {}            # (batch shape, cos_anneal_ratio) -> (CUDAGraph, static input, static losses)
         self._eager_steps = 0

@@ -5,7 +5,8 @@
       interchange; the maths runs in libfneus_hip.so.  Only the architecture of confs/wmask.conf / womask.conf is
       supported by the fused kernels -- anything else raises (there is no fallback path).
   RefColor : the surface head; its two MLPs run on the colour-network kernels (plain Linear layers).
-  SingleVarianceNetwork, NeRF : small torch modules (a scalar / the womask background).
+  NeRF : the womask background NeRF++, plain Linear layers on the fused K7 kernels.
+  SingleVarianceNetwork : a scalar.
 """
 from __future__ import annotations
 
@@ -17,7 +18,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from fneus import ops
-from fneus.autograd import RaySamples, SdfValueGradFn, ColorFn, RefHeadsFn, _Workspace
+from fneus.autograd import RaySamples, SdfValueGradFn, ColorFn, RefHeadsFn, NerfFn, _Workspace
 from models.embedder import get_embedder
 
 
@@ -362,7 +363,12 @@ class RefColor(nn.Module):
 
 
 class NeRF(nn.Module):
-    """Background NeRF++ (fields.py:178-259); only evaluated when n_outside > 0 (womask)."""
+    """Background NeRF++ (fields.py:178-259); only evaluated when n_outside > 0 (womask).
+
+    Parameters are plain nn.Linear modules named as in the reference (pts_linears.{i}, views_linears.0, feature_linear,
+    alpha_linear, rgb_linear); weights and gradients are aliased onto the flat buffers of a PackedNet and the forward /
+    backward run on the fused HIP kernels fneus_nerf_bg_fwd / _bwd (K7).  Only the architecture of confs/womask.conf is
+    supported (there is no fallback path)."""
 
     def __init__(self, D=8, W=256, d_in=3, d_in_view=3, multires=0, multires_view=0, output_ch=4, skips=(4,),
                  use_viewdirs=False):
@@ -381,21 +387,36 @@ class NeRF(nn.Module):
             self.rgb_linear = nn.Linear(W // 2, 3)
         else:
             self.output_linear = nn.Linear(W, output_ch)
+        self.prec = ops.PREC_PARITY
+        self._fused = (D == 8 and W == 256 and d_in == 4 and d_in_view == 3 and multires == 10 and multires_view == 4
+                       and self.skips == (4,) and use_viewdirs)
+        self._be = None
+        if self._fused:       # parameter layers in the order of fneus/netdesc.py NERF_NAMES
+            self._be = _PlainBackend("nerf", list(self.pts_linears) + [self.feature_linear, self.alpha_linear,
+                                                                       self.views_linears[0], self.rgb_linear])
+
+    def set_precision(self, prec: int):
+        assert prec in (ops.PREC_FAST, ops.PREC_PARITY)
+        self.prec = prec
+
+    def n_raw(self) -> int:
+        return sum(p.numel() for p in self.parameters())
+
+    def use_grad_buffer(self, buf: torch.Tensor):
+        self._be.ext_grad = buf
+        self._be.net = None
+
+    def refresh(self):
+        """pack the current parameters (once per optimiser step, before rendering)"""
+        self._be.refresh()
 
     def forward(self, input_pts, input_views):
-        if self.embed_fn is not None:
-            input_pts = self.embed_fn(input_pts)
-        if self.embed_fn_view is not None:
-            input_views = self.embed_fn_view(input_views)
-        h = input_pts
-        for i in range(len(self.pts_linears)):
-            h = F.relu(self.pts_linears[i](h))
-            if i in self.skips:
-                h = torch.cat([input_pts, h], -1)
-        if not self.use_viewdirs:
-            raise AssertionError("NeRF without view directions is not used by the reference (fields.py:258-259)")
-        alpha = self.alpha_linear(h)
-        feature = self.feature_linear(h)
-        h = torch.cat([feature, input_views], -1)
-        h = F.relu(self.views_linears[0](h))
-        return alpha, self.rgb_linear(h)
+        """input_pts [N,4] inverted-sphere points, input_views [N,3] -> raw density [N,1], raw rgb [N,3]"""
+        if not self._fused:
+            raise NotImplementedError("the fused background-NeRF kernels are specialised for confs/womask.conf "
+                                      "(D=8, W=256, d_in=4, multires=10, multires_view=4, skips=[4], use_viewdirs)")
+        self._be.ensure()
+        density, rgb = NerfFn.apply(self._be.anchor, self._be.net, input_pts.detach().float().contiguous(),
+                                    input_views.detach().float().contiguous(), self.prec, self._be.ws,
+                                    torch.is_grad_enabled())
+        return density.reshape(-1, 1), rgb

@@ -103,9 +103,9 @@ class NeuSRenderer:
 
     # ---- render_core_outside (renderer.py:112-149): inverted-sphere background NeRF++, womask configs only --------
     def render_core_outside(self, rays_o, rays_d, z_vals, sample_dist, nerf, background_rgb=None):
-        """The background network is a plain torch module (models/fields.py NeRF): it is evaluated only for womask
-        configurations and is not one of the fused kernels yet; alpha / compositing of its samples runs in the HIP
-        compositing kernel together with the SDF branch."""
+        """The background network runs on the fused K7 kernels (models/fields.py NeRF -> fneus_nerf_bg_fwd / _bwd); the
+        inverted-sphere points, softplus / sigmoid and this branch's own weights are element-wise torch ops on
+        [B, n] tensors; the blend with the foreground is inside the HIP compositing kernels."""
         B, n = z_vals.shape
         dists = torch.cat([z_vals[:, 1:] - z_vals[:, :-1], torch.full_like(z_vals[:, :1], sample_dist)], -1)
         mid_z = z_vals + dists * 0.5
@@ -219,6 +219,8 @@ class NeuSRenderer:
         self.color_network.refresh()
         if self.refColor_network is not None:
             self.refColor_network.refresh()
+        if self.n_outside > 0 and self.nerf is not None and hasattr(self.nerf, "refresh"):
+            self.nerf.refresh()
         n = self.n_samples
         if self.n_importance > 0:
             if z_vals_override is not None:

@@ -58,6 +58,21 @@ typedef struct FneusSdfBwdBufs {
     float* cscratch;                      /* [ceil(N/32)][8][32][64][4] fp32                                   */
 } FneusSdfBwdBufs;
 
+/* Activation planes of the background NeRF++ (fneus_nerf_bg_fwd / _bwd); bf16 hi / lo planes, row-major, one row per
+ * sample (the operands of the weight-gradient GEMM).  The *_lo pointers are NULL in bf16 mode. */
+typedef struct FneusNerfStash {
+    uint16_t *pe_hi, *pe_lo;       /* [n][96]     PE10 of the 4-D point, 84 columns used                           */
+    uint16_t *h_hi, *h_lo;         /* [8][n][256] slot l = relu output of pts_linears.l                           */
+    uint16_t *feat_hi, *feat_lo;   /* [n][256]    feature_linear output                                           */
+    uint16_t *dpe_hi, *dpe_lo;     /* [n][32]     PE4 of the view direction, 27 columns used                      */
+    uint16_t *hv_hi, *hv_lo;       /* [n][128]    relu output of views_linears.0                                  */
+    uint32_t* mask;                /* [tiles][9][64] x 4 words: ReLU sign bits, lane-private                      */
+    uint16_t *zbar_hi, *zbar_lo;   /* [8][n][256] dL/dz of pts_linears.l                 (written by the backward) */
+    uint16_t *zfeat_hi, *zfeat_lo; /* [n][256]    dL/d feature                                                    */
+    uint16_t *zhv_hi, *zhv_lo;     /* [n][128]    dL/dz of views_linears.0                                        */
+    uint16_t *zout_hi, *zout_lo;   /* [n][64]     columns 0..2 = dL/d rgb, column 32 = dL/d density               */
+} FneusNerfStash;
+
 /* One product of fneus_dw_gemm: C[m][n] += scale * sum_s (A[s][:m]^T B[s][:n] + A2^T B2); bias[m] += sum_s A[s][:m]. */
 typedef struct FneusGemmJob {
     const uint16_t *a_hi, *a_lo, *b_hi, *b_lo;     /* segment 1 (bf16 planes, row-major, one row per sample)   */
@@ -86,7 +101,8 @@ typedef struct FneusAdamSegment {
 int fneus_version(void);                 /* 100*major + minor */
 const char* fneus_last_error(void);      /* host pointer, static storage */
 
-/* Blob geometry, so the host needs no duplicated constants.  which: 0 = SDF network, 1 = colour network.
+/* Blob geometry, so the host needs no duplicated constants.  which: 0 = SDF network, 1 = colour network (and the two
+ * RefColor MLPs), 2 = background NeRF++ (one entry per pack, csrc/fneus_layout.h).
  * out[0] = n_layers, out[1] = total blob bytes, out[2] = extra offset, then per layer 9 ints:
  * fwd_hi, fwd_lo, rev_hi, rev_lo, bias (byte offsets), ksf, ntf, ksr, ntr.  Returns number of ints written. */
 int fneus_layout(int which, int32_t* out, int cap);
@@ -211,6 +227,19 @@ int fneus_ray_setup(const float* rays_o, const float* rays_d, const float* near,
 
 /* section lengths and mid points of render_core (renderer.py:223-226) */
 int fneus_sections(const float* z, int n_rays, int n, float sample_dist, float* dists, float* mid_z, fneus_stream_t stream);
+
+/* ---- K7: background NeRF++ of the womask configurations  (fields.py:233-259 NeRF.forward via renderer.py:112-149) ---- */
+/* pts4 [n][4] = (p/|p|, 1/|p|) of the background samples, dirs [n][3]; outputs are RAW: density [n] (alpha_linear) and
+ * rgb [n][3] (rgb_linear) -- softplus, sigmoid and the compositing of renderer.py:139-149 stay with the caller.
+ * nerf_blob: fneus_pack output for layout 2.  train != 0 writes the stash planes for the backward.                     */
+int fneus_nerf_bg_fwd(const void* nerf_blob, const float* pts4, const float* dirs, long n_pts,
+                      const FneusNerfStash* stash /*host struct, may be NULL when !train*/, float* density /*[n]*/,
+                      float* rgb /*[n][3]*/, int prec, int train, fneus_stream_t stream);
+
+/* autograd of the above w.r.t. the parameters (the inputs are constants: every z is sampled under no_grad): writes the
+ * dL/dz planes of the stash; the weight / bias gradients are then ONE fneus_dw_gemm launch over stash planes.          */
+int fneus_nerf_bg_bwd(const void* nerf_blob, long n_pts, const float* d_density /*[n]*/, const float* d_rgb /*[n][3]*/,
+                      const FneusNerfStash* stash, int prec, fneus_stream_t stream);
 
 /* ---- K5: NeuS SDF->alpha, front-to-back compositing, eikonal sums, first sign change
  *      (renderer.py:245-274, 290-293, 328-332, 360-372).  Per-ray outputs: color [B][3], wsum/wmax [B],
