@@ -150,14 +150,19 @@ class Runner:
         Image.fromarray(img[..., ::-1]).save(path)
         return path
 
-    def validate_mesh(self, resolution=512, threshold=0.0):
-        """SDF grid through the HIP K1 kernel (the compute of extract_fields, renderer.py:14-29).  Marching cubes is not
-        available in this image (PyMCubes); the grid is saved for an external mesher."""
-        u = self.trainer.renderer.extract_sdf_grid(self.dataset.object_bbox_min, self.dataset.object_bbox_max, resolution)
+    def validate_mesh(self, world_space=False, resolution=512, threshold=0.0):
+        """exp_runner.py:518-532: iso-surface of the SDF inside the object's bounding box -> meshes/{iter:0>8d}.ply
+        (the grid through the HIP K1 kernel, the surface through models/mesh.py)"""
+        from models.mesh import write_ply
+        vertices, triangles = self.trainer.renderer.extract_geometry(self.dataset.object_bbox_min, self.dataset.object_bbox_max,
+                                                                     resolution=resolution, threshold=threshold)
         os.makedirs(os.path.join(self.base_exp_dir, "meshes"), exist_ok=True)
-        path = os.path.join(self.base_exp_dir, "meshes", "{:0>8d}_sdf_grid.npz".format(self.iter_step))
-        np.savez_compressed(path, u=u.cpu().numpy(), bound_min=self.dataset.object_bbox_min,
-                            bound_max=self.dataset.object_bbox_max, threshold=threshold)
+        if world_space:
+            sm = np.asarray(self.dataset.scale_mats_np[0])
+            vertices = vertices * sm[0, 0] + sm[:3, 3][None]
+        path = os.path.join(self.base_exp_dir, "meshes", "{:0>8d}.ply".format(self.iter_step))
+        write_ply(path, vertices, triangles)
+        logging.info("mesh: %d vertices, %d triangles -> %s", len(vertices), len(triangles), path)
         return path
 
 
@@ -186,7 +191,7 @@ def main():
     if args.mode == "train":
         runner.train(max_steps=args.max_steps, rank=rank)
     elif args.mode == "validate_mesh":
-        print(runner.validate_mesh(resolution=512, threshold=args.mcube_threshold))
+        print(runner.validate_mesh(world_space=True, resolution=512, threshold=args.mcube_threshold))   # exp_runner.py:668
     elif args.mode == "validate_image":
         print(runner.validate_image(idx=args.idx))
     else:

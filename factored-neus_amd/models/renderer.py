@@ -13,6 +13,7 @@ Differences from the reference that a caller can observe:
 """
 from __future__ import annotations
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -257,8 +258,20 @@ class NeuSRenderer:
             "_z_vals": z_vals, "_sdf": ret["sdf"], "_mid_z_vals": ret["mid_z_vals"],
         }
 
+    def extract_geometry(self, bound_min, bound_max, resolution, threshold=0.0):
+        """renderer.py:729-734: iso-surface of -sdf at `threshold`; the grid goes through K1 (fneus_sdf_fwd), the surface
+        is extracted on the device by models/mesh.py (marching tetrahedra; PyMCubes is not a dependency).
+        -> (vertices [V,3] float64 numpy, triangles [T,3] int64 numpy)"""
+        from models.mesh import marching_tetrahedra
+        u = self.extract_sdf_grid(bound_min, bound_max, resolution)
+        verts, tris = marching_tetrahedra(u, threshold)
+        b_min = np.asarray([float(bound_min[i]) for i in range(3)])
+        b_max = np.asarray([float(bound_max[i]) for i in range(3)])
+        vertices = verts.cpu().numpy().astype(np.float64) / (resolution - 1.0) * (b_max - b_min)[None, :] + b_min[None, :]
+        return vertices, tris.cpu().numpy()
+
     def extract_sdf_grid(self, bound_min, bound_max, resolution):
-        """SDF on a regular grid (the compute part of extract_fields, renderer.py:14-29), chunked through K1."""
+        """-SDF on a regular grid (extract_fields with the query function of renderer.py:733), chunked through K1."""
         dev = self.sdf_network.lin0.bias.device
         self.sdf_network.refresh()
         xs = [torch.linspace(float(bound_min[i]), float(bound_max[i]), resolution, device=dev) for i in range(3)]

@@ -51,6 +51,12 @@ def test_runner_train_checkpoint_resume_validate(tmp_path):
     assert 0.0 < moved < 1e-2
     img = r2.validate_image(idx=0, resolution_level=8)
     assert os.path.exists(img)
-    grid = np.load(r2.validate_mesh(resolution=32))
-    assert grid["u"].shape == (32, 32, 32) and np.isfinite(grid["u"]).all()
-    assert (grid["u"] < 0).any() and (grid["u"] > 0).any()          # the SDF grid straddles the surface
+    from models.mesh import read_ply
+    ply = r2.validate_mesh(resolution=48)
+    assert ply.endswith("meshes/{:0>8d}.ply".format(r2.iter_step))  # exp_runner.py:530
+    v, f = read_ply(ply)
+    assert len(v) > 100 and len(f) > 100 and f.max() < len(v)
+    # every vertex lies on the zero level set of the trained SDF (to the grid's interpolation error)
+    with torch.no_grad():
+        sdf_v = r2.trainer.sdf_network.sdf(torch.from_numpy(v).float().to(dev))
+    assert sdf_v.abs().max().item() < 5e-3

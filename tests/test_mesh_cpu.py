@@ -1,0 +1,87 @@
+"""Iso-surface extraction (models/mesh.py, the build's stand-in for PyMCubes: reference renderer.py:14-40) and the
+Chamfer harness (evaluation/chamfer.py, reference evaluation/dtu_eval.py) on analytic SDFs -- SURVEY.md section 8(c):
+mesh vertices are unpinned by the reference, so the extractor is validated on surfaces whose answer is known."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "factored-neus_amd"))
+
+
+def _sphere_mesh(res=40, radius=0.7, centre=(0.05, -0.1, 0.02)):
+    from models.mesh import extract_geometry
+    c = torch.tensor(centre)
+    q = lambda pts: -(torch.linalg.norm(pts - c, dim=-1) - radius)          # the reference queries u = -sdf
+    return extract_geometry(torch.tensor([-1.0, -1.0, -1.0]), torch.tensor([1.0, 1.0, 1.0]), res, 0.0, q), np.array(centre), radius
+
+
+def test_sphere_vertices_lie_on_the_surface_and_mesh_is_closed():
+    (v, f), c, r = _sphere_mesh()
+    h = 2.0 / 39
+    d = np.linalg.norm(v - c, axis=1) - r
+    assert np.abs(d).max() < 0.5 * h * h / r + 1e-6            # linear interpolation of a curved field: O(h^2 / r)
+    # watertight 2-manifold: every undirected edge belongs to exactly two triangles, consistently oriented
+    e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]], 0)
+    und = np.sort(e, 1)
+    _, counts = np.unique(und, axis=0, return_counts=True)
+    assert (counts == 2).all()
+    _, dcounts = np.unique(e, axis=0, return_counts=True)
+    assert (dcounts == 1).all()                                 # each directed edge once -> consistent winding
+    assert len(v) - len(und) // 2 + len(f) == 2                 # Euler characteristic of a sphere
+    # outward normals (u = -sdf decreases outwards) and area -> 4 pi r^2
+    p = v[f]
+    n = np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0])
+    assert (np.einsum("ij,ij->i", n, p.mean(1) - c) > 0).all()
+    area = 0.5 * np.linalg.norm(n, axis=1).sum()
+    assert abs(area - 4 * np.pi * r * r) / (4 * np.pi * r * r) < 5e-3
+
+
+def test_threshold_and_box_mapping():
+    from models.mesh import extract_geometry
+    q = lambda pts: -(pts.abs().max(dim=-1)[0] - 0.5)                         # a cube of half-size 0.5, u = -sdf
+    v, f = extract_geometry([-1.0, -0.8, -0.9], [1.0, 0.9, 1.1], 33, -0.1, q)   # level u = -0.1 -> half-size 0.6
+    assert len(f) > 0
+    assert np.abs(np.abs(v).max(1) - 0.6).max() < 0.08
+    assert np.abs(v).max() <= 0.6 + 1e-5
+
+
+def test_empty_field_gives_empty_mesh():
+    from models.mesh import marching_tetrahedra
+    v, f = marching_tetrahedra(torch.full((8, 8, 8), -1.0), 0.0)
+    assert v.shape == (0, 3) and f.shape == (0, 3)
+
+
+def test_ply_round_trip(tmp_path):
+    from models.mesh import write_ply, read_ply
+    (v, f), _, _ = _sphere_mesh(res=16)
+    path = str(tmp_path / "m.ply")
+    write_ply(path, v, f)
+    v2, f2 = read_ply(path)
+    assert np.allclose(v2, v.astype(np.float32)) and np.array_equal(f2, f)
+
+
+def test_chamfer_of_extracted_sphere_against_analytic_points():
+    from evaluation.chamfer import evaluate_mesh, sample_mesh, thin, chamfer_l1
+    (v, f), c, r = _sphere_mesh(res=48)
+    rs = np.random.RandomState(0)
+    g = rs.standard_normal((60000, 3))
+    ref = c + r * g / np.linalg.norm(g, axis=1, keepdims=True)
+    d2s, s2d, overall = evaluate_mesh(v, f, ref, thresh=0.01, max_dist=1.0)
+    assert d2s < 8e-3 and s2d < 8e-3          # = the spacing of the two point sets, not a surface error
+    assert abs(overall - 0.5 * (d2s + s2d)) < 1e-12
+    # a sphere that is 0.05 too large is 0.05 away in both directions
+    ref_big = c + (r + 0.05) * g / np.linalg.norm(g, axis=1, keepdims=True)
+    d2s_b, s2d_b, _ = evaluate_mesh(v, f, ref_big, thresh=0.01, max_dist=1.0)
+    assert abs(d2s_b - 0.05) < 5e-3 and abs(s2d_b - 0.05) < 5e-3
+    # thinning leaves no pair closer than the threshold; max_dist drops outliers
+    pts = thin(sample_mesh(v, f, 0.05), 0.05)
+    from scipy.spatial import cKDTree
+    dd, _ = cKDTree(pts).query(pts, k=2)
+    assert dd[:, 1].min() >= 0.05
+    far = np.concatenate([pts, [[50.0, 0, 0]]], 0)
+    a, _, _ = chamfer_l1(far, ref, max_dist=1.0)
+    b, _, _ = chamfer_l1(pts, ref, max_dist=1.0)
+    assert abs(a - b) < 1e-12
