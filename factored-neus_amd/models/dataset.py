@@ -4,7 +4,8 @@ Dataset           : DTU-format scenes (reference models/dataset.py:41-196): imag
                     cameras_sphere.npz (world_mat_i, scale_mat_i).  Images and cameras live ON THE DEVICE and rays are
                     generated there, so a training step has no host->device copy (the reference indexes CPU images and
                     uploads every step, dataset.py:133-151).  Colours are BGR/256 like the reference (cv2 order).
-SyntheticDataset  : DTU-shaped synthetic scene (random images, cameras on a sphere) for smoke runs and benchmarks.
+SyntheticDataset  : DTU-shaped synthetic scene (two analytic spheres traced per pixel, cameras on a sphere) for smoke runs
+                    and the end-to-end reconstruction test.
 The other reference loaders (Sk3d / Shiny / Glossy*) are data-format variety outside the hot path and are not provided.
 """
 from __future__ import annotations
@@ -109,16 +110,61 @@ class Dataset(_RayMixin):
         return img[::l, ::l].cpu().numpy()
 
 
+# analytic test scene inside the unit sphere: the union of two diffuse spheres (centre, radius, albedo in the image's
+# channel order) under one directional light -- something a few hundred training steps can actually fit
+SCENE_SPHERES = [((0.15, 0.0, 0.0), 0.45, (0.8, 0.3, 0.2)), ((-0.30, 0.20, 0.10), 0.30, (0.2, 0.5, 0.8))]
+SCENE_LIGHT = (0.3, 0.5, 1.0)
+
+
+def scene_sdf(p: np.ndarray) -> np.ndarray:
+    """signed distance of the analytic scene (exact outside, a lower bound inside the overlap)"""
+    return np.min([np.linalg.norm(p - np.asarray(c), axis=-1) - r for c, r, _ in SCENE_SPHERES], axis=0)
+
+
+def scene_surface_points(n: int, seed: int = 0) -> np.ndarray:
+    """~n points uniformly on the visible surface of the union (for Chamfer against extracted meshes)"""
+    rs = np.random.RandomState(seed)
+    area = np.array([r * r for _, r, _ in SCENE_SPHERES])
+    out = []
+    for k, (c, r, _) in enumerate(SCENE_SPHERES):
+        g = rs.standard_normal((int(2 * n * area[k] / area.sum()), 3))
+        p = np.asarray(c) + r * g / np.linalg.norm(g, axis=1, keepdims=True)
+        keep = np.ones(len(p), dtype=bool)
+        for j, (c2, r2, _) in enumerate(SCENE_SPHERES):
+            if j != k:
+                keep &= np.linalg.norm(p - np.asarray(c2), axis=1) > r2
+        out.append(p[keep])
+    p = np.concatenate(out, 0)
+    return p[rs.permutation(len(p))[:n]]
+
+
+def render_scene(rays_o: np.ndarray, rays_d: np.ndarray):
+    """closest ray / sphere hit -> (rgb [M,3], mask [M]); rays_d unit length"""
+    best_t = np.full(len(rays_o), np.inf)
+    rgb = np.zeros((len(rays_o), 3), dtype=np.float64)
+    light = np.asarray(SCENE_LIGHT) / np.linalg.norm(SCENE_LIGHT)
+    for c, r, albedo in SCENE_SPHERES:
+        oc = rays_o - np.asarray(c)
+        b = (oc * rays_d).sum(-1)
+        disc = b * b - ((oc * oc).sum(-1) - r * r)
+        t = -b - np.sqrt(np.maximum(disc, 0.0))
+        hit = (disc > 0) & (t > 0) & (t < best_t)
+        nrm = (oc + rays_d * t[:, None]) / r
+        shade = 0.35 + 0.65 * np.maximum((nrm * light).sum(-1), 0.0)
+        rgb[hit] = np.asarray(albedo)[None, :] * shade[hit, None]
+        best_t[hit] = t[hit]
+    return rgb.astype(np.float32), np.isfinite(best_t).astype(np.float32)
+
+
 class SyntheticDataset(_RayMixin):
-    """DTU-shaped synthetic scene: n_images cameras on a sphere of radius 2.8 looking at the origin."""
+    """DTU-shaped synthetic scene: n_images pinhole cameras on a sphere of radius 2.8 looking at the origin, images and
+    masks rendered analytically from SCENE_SPHERES (no files involved)."""
 
     def __init__(self, n_images=8, H=120, W=160, device=None, seed=0):
         self.device = device or torch.device("cuda" if torch.cuda.is_available() else "cpu")
         rs = np.random.RandomState(seed)
         self.n_images, self.H, self.W = n_images, H, W
-        self.images = torch.from_numpy(rs.uniform(0, 1, size=(n_images, H, W, 3)).astype(np.float32)).to(self.device)
-        self.masks = torch.from_numpy((rs.uniform(0, 1, size=(n_images, H, W, 3)) < 0.7).astype(np.float32)).to(self.device)
-        f = 1.2 * W
+        f = 2.2 * W
         K = np.array([[f, 0, W / 2, 0], [0, f, H / 2, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float32)
         poses = []
         for i in range(n_images):
@@ -131,6 +177,21 @@ class SyntheticDataset(_RayMixin):
             pose = np.eye(4, dtype=np.float32)
             pose[:3, 0], pose[:3, 1], pose[:3, 2], pose[:3, 3] = x, y, z, c
             poses.append(pose)
+        # images: the pixel rays of gen_rays_at (dataset.py:119-131) traced against the analytic scene
+        Kinv = np.linalg.inv(K.astype(np.float64))[:3, :3]
+        px, py = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64), indexing="xy")
+        pix = np.stack([px, py, np.ones_like(px)], -1).reshape(-1, 3)
+        images, masks = [], []
+        for pose in poses:
+            v = pix @ Kinv.T
+            v = v / np.linalg.norm(v, axis=-1, keepdims=True)
+            d = v @ pose[:3, :3].astype(np.float64).T
+            o = np.broadcast_to(pose[:3, 3].astype(np.float64), d.shape)
+            rgb, m = render_scene(o, d)
+            images.append(rgb.reshape(H, W, 3))
+            masks.append(np.repeat(m.reshape(H, W, 1), 3, axis=2))
+        self.images = torch.from_numpy(np.stack(images)).to(self.device)
+        self.masks = torch.from_numpy(np.stack(masks)).to(self.device)
         self.intrinsics_all = torch.from_numpy(np.stack([K] * n_images)).to(self.device)
         self.intrinsics_all_inv = torch.inverse(self.intrinsics_all)
         self.pose_all = torch.from_numpy(np.stack(poses)).to(self.device)
