@@ -105,6 +105,13 @@ class PackedNet:
                             "weight": buf[d["offV"][l]: d["offV"][l] + o * i].view(o, i)})
         return out
 
+    def load_state_dict(self, sd, prefix="lin"):
+        """raw parameters from a module-style dict (lin{l}.bias / weight_g / weight_v, or .weight for plain layers)"""
+        for l, view in enumerate(self.raw_views(self.raw)):
+            for name, dst in view.items():
+                dst.copy_(torch.as_tensor(sd[f"{prefix}{l}.{name}"]).reshape(dst.shape).to(dst.device))
+        return self
+
     def set_raw_from_effective(self, Ws, bs):
         """test helper: load effective weights as (g = ||W||, v = W)"""
         for view, W, b in zip(self.raw_views(self.raw), Ws, bs):

@@ -2,12 +2,10 @@ import sys, os, time, ctypes as C
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "factored-neus_amd"))
 import numpy as np, torch
 from fneus import ops, synth
-from oracle import ref_torch as R
 T = lambda a: torch.from_numpy(np.asarray(a))
 dev = torch.device("cuda:0")
 sd = {k: T(v) for k, v in synth.sdf_state_dict(20).items()}
-p = R.sdf_params_from_state_dict(sd)
-net = ops.PackedNet("sdf", dev); net.set_raw_from_effective([w.to(dev) for w in p["W"]], [b.to(dev) for b in p["b"]]); net.pack()
+net = ops.PackedNet("sdf", dev).load_state_dict(sd); net.pack()
 n = 65536
 xx = (torch.rand(n, 3, device=dev) * 2 - 1).contiguous()
 ref = ops.sdf_fwd(net.blob, n, 3, pts=xx)
