@@ -195,7 +195,9 @@ def main():
         "config": {"workload": "dtu_scan97-shaped wmask.conf stage-1 SDF+radiance train step, 512 rays x (64+64) samples, "
                                "1xMI355X per rank", "rays_per_gpu": RAYS, "samples_per_ray": N_SAMPLES + N_IMPORTANCE,
                    "parallelism": f"dp{world} (ray-sharded replicas, one in-place all-reduce of the gradient arena)",
-                   "launch": "one hipGraph replay per step" if tr.use_graph and tr._graphs else "eager kernel launches"},
+                   "launch": ("eager kernel launches" if not (tr.use_graph and tr._graphs) else
+                              "three hipGraph replays per step around the two collectives" if world > 1 else
+                              "one hipGraph replay per step")},
         "mfma_roofline_frac_step": value / world * FLOP_TRAIN_PER_SAMPLE / (PEAK_BF16_MFMA_TFLOPS * 1e12),
     }
 

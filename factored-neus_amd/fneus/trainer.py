@@ -63,10 +63,15 @@ class Stage1Trainer:
         if self.nerf_outside is not None:
             self.nerf_outside.set_precision(prec)
         self.params = [p for m in self.modules for p in m.parameters()]
-        # data parallel: a 4-float all-reduce of the loss normalisers sits in the middle of the step, so the step is not
-        # captured as one graph there (eager launches run ahead of the GPU anyway)
-        self.use_graph = bool(use_graph) and device.type == "cuda" and not distributed
-        self.reduce_norms = reduce_loss_norms if distributed else None
+        # data parallel: two collectives sit inside the step (the 4-float all-reduce of the loss normalisers before the
+        # loss, the gradient arena after the backward), so the step is captured as THREE hipGraphs with the collectives
+        # launched eagerly between their replays (_capture_dp).  FNEUS_DP_GRAPH=0 keeps such runs on eager launches.
+        import os
+        self.distributed = bool(distributed)
+        self.use_graph = bool(use_graph) and device.type == "cuda" and (
+            not distributed or os.environ.get("FNEUS_DP_GRAPH", "1") != "0")
+        self._capturing = None
+        self.reduce_norms = self._reduce_norms_hook if distributed else None
         # every gradient of the model lives in ONE arena: the fused MLPs accumulate into slices of it, the small torch
         # modules get persistent .grad views (autograd accumulates into them in place).  FlatAdam addresses parameters
         # and gradients by pointer and clears the gradients itself; data parallel = one in-place all-reduce of the arena.
@@ -100,16 +105,86 @@ class Stage1Trainer:
             if self._eager_steps < self.graph_warmup_steps or len(self._graphs) >= 4:
                 # (a cos_anneal_ratio that changes every step would mean one capture per step: stay eager)
                 return self._eager_step(data, cos_anneal_ratio, background_rgb)
-            entry = self._capture(data, float(cos_anneal_ratio))
+            entry = (self._capture_dp if self.distributed else self._capture)(data, float(cos_anneal_ratio))
             self._graphs[key] = entry
+            if entry is None:            # capture failed (data parallel only): this and every later step runs eagerly
+                return self._eager_step(data, cos_anneal_ratio, background_rgb)
         graph, static_data, losses = entry
         static_data.copy_(data)
-        graph.replay()
-        if self.bucket is not None:      # (not reached today: distributed runs are eager, see __init__)
+        if self.distributed:
+            g1, g2, g3, norms = graph
+            g1.replay()                      # packs, sampler, K2, colour, compositing, surface gather, RefColor, batch sums
+            reduce_loss_norms(norms)         # in place on the static buffer that the loss kernel of g2 reads
+            g2.replay()                      # losses + the whole backward
             self.bucket.allreduce_sum()
-            self.optimizer.step()
+            g3.replay()                      # Adam
+        else:
+            graph.replay()
         self.iter_step += 1
         return losses
+
+    def _reduce_norms_hook(self, norms: torch.Tensor) -> torch.Tensor:
+        """called by the fused loss (Stage1LossFn) with this rank's batch sums; while _capture_dp records a step this is
+        the point where the first graph ends and the second begins"""
+        st = self._capturing
+        if st is None:
+            return reduce_loss_norms(norms)
+        st["g1"].capture_end()
+        st["open"] = None
+        st["norms"] = norms
+        reduce_loss_norms(norms)             # eager: nothing recorded has run yet, the values are meaningless, but every
+        st["g2"].capture_begin(pool=st["pool"], capture_error_mode="thread_local")   # rank issues the same collectives
+        st["open"] = st["g2"]
+        return norms
+
+    def _capture_dp(self, data: torch.Tensor, cos_anneal_ratio: float):
+        """data parallel: three graphs per step with the two collectives between them.  Returns None when the capture
+        fails for any reason (the caller then stays on eager launches)."""
+        import gc
+        static_data = data.clone()
+        gc.collect()
+        torch.cuda.synchronize()
+        g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        st = {"g1": g1, "g2": g2, "pool": torch.cuda.graph_pool_handle(), "open": None, "norms": None}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        ok, losses = False, None
+        try:
+            with torch.cuda.stream(side):
+                # thread_local: the process group's watchdog thread may query events while this thread records
+                g1.capture_begin(pool=st["pool"], capture_error_mode="thread_local")
+                st["open"] = g1
+                self._capturing = st
+                losses = self._step_body(static_data, cos_anneal_ratio, None, with_optimizer=False)
+                self._capturing = None
+                if st["open"] is not g2:
+                    raise RuntimeError("the step did not reach the loss-normaliser exchange")
+                g2.capture_end()
+                st["open"] = None
+                self.bucket.allreduce_sum()          # eager, like the exchange above
+                g3.capture_begin(pool=st["pool"], capture_error_mode="thread_local")
+                st["open"] = g3
+                self.optimizer.step()
+                g3.capture_end()
+                st["open"] = None
+            ok = True
+        except Exception as e:      # noqa: BLE001 -- any failure here must leave a working (eager) trainer behind
+            import sys
+            print(f"[fneus] data-parallel graph capture failed ({e!r}); continuing with eager launches", file=sys.stderr)
+        finally:
+            self._capturing = None
+            if st["open"] is not None:
+                try:
+                    st["open"].capture_end()
+                except Exception:   # noqa: BLE001
+                    pass
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+        if not ok:
+            self.use_graph = False
+            self.grads.flat.zero_()
+            return None
+        return (g1, g2, g3, st["norms"]), static_data, losses
 
     def _capture(self, data: torch.Tensor, cos_anneal_ratio: float):
         import gc
@@ -118,7 +193,7 @@ class Stage1Trainer:
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            losses = self._step_body(static_data, cos_anneal_ratio, None, with_optimizer=self.bucket is None)
+            losses = self._step_body(static_data, cos_anneal_ratio, None, with_optimizer=True)
         return graph, static_data, losses
 
     def _eager_step(self, data, cos_anneal_ratio, background_rgb):

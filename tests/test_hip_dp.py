@@ -63,17 +63,28 @@ def test_two_half_batches_with_global_normalisers_equal_the_full_batch():
     assert worst <= 2e-3        # fp32 atomics / summation order only (the K2-K3 chains are evaluated per sample)
 
 
-def test_two_ranks_sharing_the_gpu_stay_identical():
-    """the real N > 1 code path (broadcast, loss-normaliser all-reduce, arena all-reduce, FlatAdam) with two processes;
-    gloo instead of RCCL because both ranks have to share the one GPU of the test box"""
+def _two_ranks(graph: bool):
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    port = 29600 + os.getpid() % 300
+    port = 29600 + (os.getpid() + 151 * int(graph)) % 300
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "tools", "dp_check.py")]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    env = dict(os.environ, DP_CHECK_GRAPH="1" if graph else "0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     line = [l for l in r.stdout.splitlines() if l.startswith("DP_CHECK")]
     assert r.returncode == 0 and line and line[0].endswith("OK"), (r.stdout[-2000:], r.stderr[-2000:])
     print(" ", line[0])
+    return [float(v) for v in [l for l in r.stdout.splitlines() if l.startswith("DP_TRACE")][0].split()[1:]]
+
+
+def test_two_ranks_sharing_the_gpu_stay_identical():
+    """the real N > 1 code path (broadcast, loss-normaliser all-reduce, arena all-reduce, FlatAdam) with two processes;
+    gloo instead of RCCL because both ranks have to share the one GPU of the test box.  Eager launches, then the same run
+    with the step replayed as three hipGraphs around the two collectives: the global loss trajectories must agree."""
+    eager = _two_ranks(graph=False)
+    graphed = _two_ranks(graph=True)
+    assert len(eager) == len(graphed) == 7
+    for i, (a, b) in enumerate(zip(eager, graphed)):
+        assert abs(a - b) <= 2e-3 * max(abs(a), 1e-2), (i, a, b)       # Adam amplifies fp32 summation-order differences

@@ -12,23 +12,30 @@ import torch
 import torch.distributed as dist
 
 from fneus.parallel import broadcast_parameters, init_from_env
-from fneus.trainer import Stage1Trainer, synthetic_batches
+from fneus.trainer import Stage1Trainer, synthetic_batches, WMASK_MODEL
 
 rank, world, _ = init_from_env("gloo")
 dev = torch.device("cuda:0")
 torch.cuda.set_device(0)
-tr = Stage1Trainer(dev, seed=rank, distributed=True)          # different initial weights per rank on purpose ...
+use_graph = os.environ.get("DP_CHECK_GRAPH", "0") == "1"      # three hipGraphs per step around the two collectives
+import copy
+conf = copy.deepcopy(WMASK_MODEL)
+conf["neus_renderer"]["perturb"] = 0.0                         # no depth jitter: eager and replayed runs draw it differently
+tr = Stage1Trainer(dev, model_conf=conf, seed=rank, distributed=True, use_graph=use_graph)   # different initial weights per rank on purpose ...
 broadcast_parameters(tr.modules)                               # ... rank 0's must win
 losses = None
-for b in synthetic_batches(4, 128, dev, rank=rank):
+trace = []
+for b in synthetic_batches(7, 128, dev, rank=rank):
     losses = tr.global_losses(tr.train_step(b))
+    trace.append(float(losses["loss"]))
 flat = torch.cat([p.detach().reshape(-1) for p in tr.params])
 gathered = [torch.empty_like(flat) for _ in range(world)]
 dist.all_gather(gathered, flat)
 worst = max((g - gathered[0]).abs().max().item() for g in gathered)
-ok = worst == 0.0 and bool(torch.isfinite(losses["loss"]))
+ok = worst == 0.0 and bool(torch.isfinite(losses["loss"])) and (not use_graph or (tr.use_graph and len(tr._graphs) == 1))
 if rank == 0:
-    print(f"DP_CHECK world={world} max replica difference {worst:.3e} global loss {float(losses['loss']):.6f} "
+    print("DP_TRACE " + " ".join(f"{v:.6f}" for v in trace))
+    print(f"DP_CHECK world={world} graphs={int(use_graph)} max replica difference {worst:.3e} global loss {float(losses['loss']):.6f} "
           f"{'OK' if ok else 'FAILED'}")
 dist.barrier()
 dist.destroy_process_group()
