@@ -241,11 +241,12 @@ FN_DEV float inv_s_chain(const float* p, int mode) {
 __global__ void __launch_bounds__(64) composite_fwd_kernel(
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ mid_z,
     const float* __restrict__ dists, const float* __restrict__ sdf, const float* __restrict__ normal,
-    const float* __restrict__ rgb, const float* __restrict__ inv_s_ptr, int inv_s_mode, int n, float car,
+    const float* __restrict__ rgb, const float* __restrict__ inv_s_ptr, int inv_s_mode, int n, float car_host, const float* __restrict__ car_dev,
     const float* __restrict__ bg_alpha, const float* __restrict__ bg_color, int n_out,
     float* __restrict__ weights, float* __restrict__ color, float* __restrict__ wsum, float* __restrict__ wmax,
     float* __restrict__ cdf_out, float* __restrict__ inside_out, float* __restrict__ eik /*[2][B]*/,
     int* __restrict__ min_idx_out, unsigned char* __restrict__ mask_out, float* __restrict__ wpair /*[B][2]*/) {
+    const float car = car_dev ? *car_dev : car_host;     // device scalar: the value can change between replays of a captured step
     const int ray = blockIdx.x, lane = threadIdx.x;
     const float inv_s = load_inv_s(inv_s_ptr, inv_s_mode);
     const bool bg = bg_alpha != nullptr;
@@ -351,7 +352,7 @@ FN_DEV void excl_suffix_sum(const float (&v)[PER], float (&S)[PER], int lane) {
 __global__ void __launch_bounds__(64) composite_bwd_kernel(
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ mid_z,
     const float* __restrict__ dists, const float* __restrict__ sdf, const float* __restrict__ normal,
-    const float* __restrict__ rgb, const float* __restrict__ inv_s_ptr, int inv_s_mode, int n, float car,
+    const float* __restrict__ rgb, const float* __restrict__ inv_s_ptr, int inv_s_mode, int n, float car_host, const float* __restrict__ car_dev,
     const float* __restrict__ bg_alpha, const float* __restrict__ bg_color, int n_out,
     const int* __restrict__ min_idx, const unsigned char* __restrict__ mask_in,
     const float* __restrict__ d_color /*[B][3]*/, const float* __restrict__ d_wsum /*[B]*/,
@@ -359,6 +360,7 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(
     const float* __restrict__ d_eiknum /*[B]*/, float* __restrict__ d_sdf, float* __restrict__ d_normal,
     float* __restrict__ d_rgb, float* __restrict__ d_inv_s /*[B]*/, float* __restrict__ d_bg_alpha /*[B][nt]*/,
     float* __restrict__ d_bg_color /*[B][nt][3]*/) {
+    const float car = car_dev ? *car_dev : car_host;     // device scalar: the value can change between replays of a captured step
     const int ray = blockIdx.x, lane = threadIdx.x;
     const float inv_s = load_inv_s(inv_s_ptr, inv_s_mode);
     const bool bg = bg_alpha != nullptr;
@@ -541,7 +543,8 @@ extern "C" int fneus_sections(const float* z, int n_rays, int n, float sample_di
 
 extern "C" int fneus_composite_fwd(const float* rays_o, const float* rays_d, const float* mid_z, const float* dists,
                                    const float* sdf, const float* normal, const float* rgb, const float* inv_s,
-                                   int inv_s_mode, int n_rays, int n, float cos_anneal_ratio, const float* bg_alpha,
+                                   int inv_s_mode, int n_rays, int n, float cos_anneal_ratio, const float* cos_anneal_dev,
+                                   const float* bg_alpha,
                                    const float* bg_color, int n_out, float* weights, float* color, float* wsum,
                                    float* wmax, float* cdf, float* inside, float* eik, int32_t* min_idx,
                                    unsigned char* sdf_mask, float* wpair, fneus_stream_t stream_) {
@@ -550,14 +553,15 @@ extern "C" int fneus_composite_fwd(const float* rays_o, const float* rays_d, con
     if (n_rays <= 0) return 0;
     FN_CHECK_N(n + (bg_alpha ? n_out : 0));
     hipLaunchKernelGGL(composite_fwd_kernel, dim3(n_rays), dim3(64), 0, stream, rays_o, rays_d, mid_z, dists, sdf, normal,
-                       rgb, inv_s, inv_s_mode, n, cos_anneal_ratio, bg_alpha, bg_color, n_out, weights, color, wsum, wmax, cdf, inside,
+                       rgb, inv_s, inv_s_mode, n, cos_anneal_ratio, cos_anneal_dev, bg_alpha, bg_color, n_out, weights, color, wsum, wmax, cdf, inside,
                        eik, min_idx, sdf_mask, wpair);
     return fneus::launch_status();
 }
 
 extern "C" int fneus_composite_bwd(const float* rays_o, const float* rays_d, const float* mid_z, const float* dists,
                                    const float* sdf, const float* normal, const float* rgb, const float* inv_s,
-                                   int inv_s_mode, int n_rays, int n, float cos_anneal_ratio, const float* bg_alpha,
+                                   int inv_s_mode, int n_rays, int n, float cos_anneal_ratio, const float* cos_anneal_dev,
+                                   const float* bg_alpha,
                                    const float* bg_color, int n_out, const int32_t* min_idx,
                                    const unsigned char* sdf_mask, const float* d_color, const float* d_wsum,
                                    const float* d_weights, const float* d_wpair, const float* d_eiknum, float* d_sdf,
@@ -568,7 +572,7 @@ extern "C" int fneus_composite_bwd(const float* rays_o, const float* rays_d, con
     if (n_rays <= 0) return 0;
     FN_CHECK_N(n + (bg_alpha ? n_out : 0));
     hipLaunchKernelGGL(composite_bwd_kernel, dim3(n_rays), dim3(64), 0, stream, rays_o, rays_d, mid_z, dists, sdf, normal,
-                       rgb, inv_s, inv_s_mode, n, cos_anneal_ratio, bg_alpha, bg_color, n_out, min_idx, sdf_mask, d_color, d_wsum,
+                       rgb, inv_s, inv_s_mode, n, cos_anneal_ratio, cos_anneal_dev, bg_alpha, bg_color, n_out, min_idx, sdf_mask, d_color, d_wsum,
                        d_weights, d_wpair, d_eiknum, d_sdf, d_normal, d_rgb, d_inv_s, d_bg_alpha, d_bg_color);
     return fneus::launch_status();
 }

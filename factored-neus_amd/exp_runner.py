@@ -59,7 +59,7 @@ class Runner:
         self.trainer = Stage1Trainer(self.device, model_conf=model_conf, prec=prec, lr=self.learning_rate,
                                      igr_weight=self.igr_weight, mask_weight=self.mask_weight,
                                      surface_weight=surface_weight, synthetic_init=False, distributed=distributed,
-                                     use_graph=use_graph and self.anneal_end == 0.0)   # constant cos_anneal_ratio only
+                                     use_graph=use_graph)   # cos_anneal_ratio is a device scalar: a ramp replays too
         # the reference also constructs and checkpoints the background NeRF when n_outside == 0 (it is never evaluated then)
         self.nerf_outside = self.trainer.nerf_outside or NeRF(**dict(self.conf["model.nerf"])).to(self.device)
         self.iter_step = 0

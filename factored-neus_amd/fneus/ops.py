@@ -546,6 +546,15 @@ def sections(z, sample_dist: float):
     return dists, mid_z
 
 
+def _car(car):
+    """cos_anneal_ratio as (float, device pointer): a 1-element device tensor is read by the kernel at run time (so that
+    a captured step can be replayed with a new value), a Python number is passed by value"""
+    if torch.is_tensor(car):
+        _chk_f32(car, "cos_anneal_ratio")
+        return 0.0, _ptr(car)
+    return float(car), None
+
+
 def composite_fwd(rays_o, rays_d, mid_z, dists, sdf, normal, rgb, inv_s, car: float, bg_alpha=None, bg_color=None,
                   inv_s_mode: int = 0):
     """inv_s_mode 1: `inv_s` is the variance parameter (see include/fneus.h).  out["eik"] is [2, B]."""
@@ -561,7 +570,7 @@ def composite_fwd(rays_o, rays_d, mid_z, dists, sdf, normal, rgb, inv_s, car: fl
         "sdf_mask": torch.empty(B, dtype=torch.uint8, device=dev), "wpair": torch.empty(B, 2, **f32),
     }
     _launch("fneus_composite_fwd", lib.fneus_composite_fwd, _ptr(rays_o), _ptr(rays_d), _ptr(mid_z), _ptr(dists), _ptr(sdf),
-            _ptr(normal), _ptr(rgb), _ptr(inv_s), int(inv_s_mode), B, n, float(car), _ptr(bg_alpha), _ptr(bg_color), n_out,
+            _ptr(normal), _ptr(rgb), _ptr(inv_s), int(inv_s_mode), B, n, *_car(car), _ptr(bg_alpha), _ptr(bg_color), n_out,
             _ptr(out["weights"]), _ptr(out["color"]), _ptr(out["wsum"]), _ptr(out["wmax"]), _ptr(out["cdf"]),
             _ptr(out["inside"]), _ptr(out["eik"]), _ptr(out["min_idx"]), _ptr(out["sdf_mask"]), _ptr(out["wpair"]),
             _stream())
@@ -580,7 +589,7 @@ def composite_bwd(rays_o, rays_d, mid_z, dists, sdf, normal, rgb, inv_s, car, mi
     d_bga = torch.empty_like(bg_alpha) if bg_alpha is not None else None
     d_bgc = torch.empty_like(bg_color) if bg_color is not None else None
     _launch("fneus_composite_bwd", lib.fneus_composite_bwd, _ptr(rays_o), _ptr(rays_d), _ptr(mid_z), _ptr(dists), _ptr(sdf),
-            _ptr(normal), _ptr(rgb), _ptr(inv_s), int(inv_s_mode), B, n, float(car), _ptr(bg_alpha), _ptr(bg_color), n_out, _ptr(min_idx),
+            _ptr(normal), _ptr(rgb), _ptr(inv_s), int(inv_s_mode), B, n, *_car(car), _ptr(bg_alpha), _ptr(bg_color), n_out, _ptr(min_idx),
             _ptr(sdf_mask), _ptr(d_color), _ptr(d_wsum), _ptr(d_weights), _ptr(d_wpair), _ptr(d_eiknum), _ptr(d_sdf),
             _ptr(d_normal), _ptr(d_rgb), _ptr(d_inv_s), _ptr(d_bga), _ptr(d_bgc), _stream())
     return d_sdf, d_normal, d_rgb, d_inv_s, d_bga, d_bgc

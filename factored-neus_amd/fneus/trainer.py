@@ -78,7 +78,8 @@ class Stage1Trainer:
         fused = [self.sdf_network, self.color_network] + ([self.nerf_outside] if self.nerf_outside is not None else [])
         self.grads = GradArena(device, fused, self.refColor_network, [self.deviation_network])
         self.optimizer = FlatAdam(self.params, lr=lr)
-        self._graphs = {}            # (batch shape, cos_anneal_ratio) -> (CUDAGraph, static input, static losses)
+        self._graphs = {}            # (batch shape, background shape) -> (graph(s), static input, static background, losses)
+        self._cos = torch.ones(1, dtype=torch.float32, device=device)    # cos_anneal_ratio of the replayed step
         self._eager_steps = 0
         self.graph_warmup_steps = 2  # eager steps before the first capture (workspaces, job tables, LDS attributes)
         self.renderer = NeuSRenderer(**conf["neus_renderer"], nerf=self.nerf_outside, sdf_network=self.sdf_network,
@@ -97,20 +98,24 @@ class Stage1Trainer:
     def train_step(self, data: torch.Tensor, cos_anneal_ratio: float = 1.0, background_rgb=None):
         """data [B,10] = rays_o, rays_d, rgb, mask (dataset.py:133-151).  Returns the loss dict (device tensors; with
         use_graph they are static buffers that the next step overwrites)."""
-        if not self.use_graph or background_rgb is not None or ops.PROFILE is not None:
+        if not self.use_graph or ops.PROFILE is not None:
             return self._eager_step(data, cos_anneal_ratio, background_rgb)
-        key = (tuple(data.shape), float(cos_anneal_ratio))
+        # one capture per batch shape: cos_anneal_ratio is a device scalar that the compositing kernels read at run time
+        # (it ramps every step in the womask configuration), the background colour a static buffer
+        key = (tuple(data.shape), None if background_rgb is None else tuple(background_rgb.shape))
         entry = self._graphs.get(key)
         if entry is None:
             if self._eager_steps < self.graph_warmup_steps or len(self._graphs) >= 4:
-                # (a cos_anneal_ratio that changes every step would mean one capture per step: stay eager)
                 return self._eager_step(data, cos_anneal_ratio, background_rgb)
-            entry = (self._capture_dp if self.distributed else self._capture)(data, float(cos_anneal_ratio))
+            entry = (self._capture_dp if self.distributed else self._capture)(data, background_rgb)
             self._graphs[key] = entry
             if entry is None:            # capture failed (data parallel only): this and every later step runs eagerly
                 return self._eager_step(data, cos_anneal_ratio, background_rgb)
-        graph, static_data, losses = entry
+        graph, static_data, static_bg, losses = entry
         static_data.copy_(data)
+        self._cos.fill_(float(cos_anneal_ratio))
+        if static_bg is not None:
+            static_bg.copy_(background_rgb)
         if self.distributed:
             g1, g2, g3, norms = graph
             g1.replay()                      # packs, sampler, K2, colour, compositing, surface gather, RefColor, batch sums
@@ -137,11 +142,12 @@ class Stage1Trainer:
         st["open"] = st["g2"]
         return norms
 
-    def _capture_dp(self, data: torch.Tensor, cos_anneal_ratio: float):
+    def _capture_dp(self, data: torch.Tensor, background_rgb):
         """data parallel: three graphs per step with the two collectives between them.  Returns None when the capture
         fails for any reason (the caller then stays on eager launches)."""
         import gc
         static_data = data.clone()
+        static_bg = None if background_rgb is None else background_rgb.clone()
         gc.collect()
         torch.cuda.synchronize()
         g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
@@ -155,7 +161,7 @@ class Stage1Trainer:
                 g1.capture_begin(pool=st["pool"], capture_error_mode="thread_local")
                 st["open"] = g1
                 self._capturing = st
-                losses = self._step_body(static_data, cos_anneal_ratio, None, with_optimizer=False)
+                losses = self._step_body(static_data, self._cos, static_bg, with_optimizer=False)
                 self._capturing = None
                 if st["open"] is not g2:
                     raise RuntimeError("the step did not reach the loss-normaliser exchange")
@@ -184,17 +190,18 @@ class Stage1Trainer:
             self.use_graph = False
             self.grads.flat.zero_()
             return None
-        return (g1, g2, g3, st["norms"]), static_data, losses
+        return (g1, g2, g3, st["norms"]), static_data, static_bg, losses
 
-    def _capture(self, data: torch.Tensor, cos_anneal_ratio: float):
+    def _capture(self, data: torch.Tensor, background_rgb):
         import gc
         static_data = data.clone()
+        static_bg = None if background_rgb is None else background_rgb.clone()
         gc.collect()                 # drop autograd graphs of earlier eager steps that are only kept alive by cycles
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            losses = self._step_body(static_data, cos_anneal_ratio, None, with_optimizer=True)
-        return graph, static_data, losses
+            losses = self._step_body(static_data, self._cos, static_bg, with_optimizer=True)
+        return graph, static_data, static_bg, losses
 
     def _eager_step(self, data, cos_anneal_ratio, background_rgb):
         losses = self._step_body(data, cos_anneal_ratio, background_rgb, with_optimizer=False)

@@ -136,7 +136,8 @@ class NeuSRenderer:
         rgb = color_network.color_samples(samples, normal, feat, sdf_network, train)
         # inv_s = clip(exp(10 variance)) (renderer.py:245) is applied inside the compositing kernels
         (color, weights, wsum, wpair, eik_num, wmax, cdf, inside, eik_den, min_idx, sdf_mask_u8) = CompositeFn.apply(
-            sdf, normal, rgb, deviation_network.variance, rays_o, rays_d, mid_z, dists, float(cos_anneal_ratio),
+            sdf, normal, rgb, deviation_network.variance, rays_o, rays_d, mid_z, dists,
+            cos_anneal_ratio if torch.is_tensor(cos_anneal_ratio) else float(cos_anneal_ratio),
             background_alpha, background_sampled_color)
         sdf_mask = sdf_mask_u8.bool()
         if background_rgb is not None:

@@ -252,7 +252,8 @@ int fneus_nerf_bg_bwd(const void* nerf_blob, long n_pts, const float* d_density 
  *      NeRF's alpha / colour and n_out background samples are appended (weights then have n + n_out columns). */
 int fneus_composite_fwd(const float* rays_o, const float* rays_d, const float* mid_z, const float* dists, const float* sdf,
                         const float* normal, const float* rgb, const float* inv_s, int inv_s_mode, int n_rays, int n,
-                        float cos_anneal_ratio, const float* bg_alpha /*[B][n+n_out] or NULL*/,
+                        float cos_anneal_ratio, const float* cos_anneal_dev /*device scalar overriding the float, or NULL*/,
+                        const float* bg_alpha /*[B][n+n_out] or NULL*/,
                         const float* bg_color /*[B][n+n_out][3] or NULL*/, int n_out,
                         float* weights /*[B][n (+n_out)]*/, float* color, float* wsum, float* wmax, float* cdf,
                         float* inside, float* eik, int32_t* min_idx, unsigned char* sdf_mask, float* wpair,
@@ -260,7 +261,8 @@ int fneus_composite_fwd(const float* rays_o, const float* rays_d, const float* m
 /* adjoint of fneus_composite_fwd; d_weights may be NULL; d_inv_s is per ray (caller sums). */
 int fneus_composite_bwd(const float* rays_o, const float* rays_d, const float* mid_z, const float* dists, const float* sdf,
                         const float* normal, const float* rgb, const float* inv_s, int inv_s_mode, int n_rays, int n,
-                        float cos_anneal_ratio, const float* bg_alpha, const float* bg_color, int n_out,
+                        float cos_anneal_ratio, const float* cos_anneal_dev /*device scalar overriding the float, or NULL*/,
+                        const float* bg_alpha, const float* bg_color, int n_out,
                         const int32_t* min_idx, const unsigned char* sdf_mask,
                         const float* d_color, const float* d_wsum, const float* d_weights, const float* d_wpair,
                         const float* d_eiknum, float* d_sdf, float* d_normal, float* d_rgb, float* d_inv_s,

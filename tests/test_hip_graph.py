@@ -56,3 +56,33 @@ def test_graph_lr_update_is_seen_by_replays():
     tr.train_step(batches[3])
     for p, q in zip(tr.params, before):
         assert torch.equal(p.detach(), q), "a replay with lr = 0 must not move the parameters"
+
+
+def test_replay_follows_a_ramping_cos_anneal_ratio_and_a_background_colour():
+    """womask configuration: cos_anneal_ratio changes every step (exp_runner.py:223-227) and a white background is
+    blended in; the captured step reads both from device buffers, so ONE graph serves the whole ramp"""
+    from fneus import ops
+    from fneus.trainer import Stage1Trainer, WMASK_MODEL, synthetic_batches
+    dev = torch.device("cuda:0")
+    conf = copy.deepcopy(WMASK_MODEL)
+    conf["neus_renderer"].update(perturb=0.0, n_samples=32, n_importance=32, n_outside=16)
+    batches = synthetic_batches(7, 128, dev, seed0=77)
+    bg = torch.ones(1, 3, device=dev)
+    runs = []
+    for use_graph in (False, True):
+        tr = Stage1Trainer(dev, model_conf=conf, prec=ops.PREC_PARITY, seed=9, use_graph=use_graph)
+        rows = []
+        for i, b in enumerate(batches):
+            out = tr.train_step(b, cos_anneal_ratio=min(1.0, 0.15 * i), background_rgb=bg)
+            rows.append([float(out[k]) for k in ("loss", "color_loss", "eikonal_loss", "mask_loss")])
+        runs.append(np.array(rows))
+        if use_graph:
+            assert len(tr._graphs) == 1
+    worst = np.abs(runs[0] - runs[1]).max() / np.abs(runs[0]).max()
+    print(f"  eager vs replayed womask steps over a cos_anneal ramp: worst relative loss-term difference {worst:.2e}")
+    assert worst <= 2e-3
+    # the ratio matters on this data (otherwise the check above would be empty): same weights, two ratios
+    tr = Stage1Trainer(dev, model_conf=conf, prec=ops.PREC_PARITY, seed=9, use_graph=False)
+    a = float(tr._step_body(batches[0], 0.0, bg, with_optimizer=False)["loss"])
+    b = float(tr._step_body(batches[0], 1.0, bg, with_optimizer=False)["loss"])
+    assert abs(a - b) > 1e-4 * abs(a)
