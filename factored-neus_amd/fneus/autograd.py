@@ -108,8 +108,9 @@ class ColorFn(torch.autograd.Function):
             feat_planes = ctx.sdf_ws.cache[("sdf_stash", n, prec, True)].feat
         grad = ws.get(("col_grad", n), lambda: torch.zeros(net.n_params, dtype=torch.float32, device=rgb.device))
         jobs = ws.get(("col_jobs", n, prec), lambda: ops.color_dw_jobs(net, feat_planes, ctx.stash, grad, n))
-        jobs.run(n, prec)
-        net.wn_backward(grad)
+        with ops.on_side_stream(4 if head == 0 else 2):
+            jobs.run(n, prec)
+            net.wn_backward(grad)
         return None, d_normal, d_feat, None, None, None, None, None, None, None
 
 
@@ -171,9 +172,10 @@ class RefHeadsFn(torch.autograd.Function):
             ops.color_dw_jobs(net_vd, st[1].feat, st[1], g_vd, n, into=jobs)
             return jobs.finalize()
 
-        ws.get(("ref_jobs", n, prec), build).run(n, prec)
-        net_cd.wn_backward(g_cd)
-        net_vd.wn_backward(g_vd)
+        with ops.on_side_stream(2):          # only Adam consumes these: off the critical path of the backward
+            ws.get(("ref_jobs", n, prec), build).run(n, prec)
+            net_cd.wn_backward(g_cd)
+            net_vd.wn_backward(g_vd)
         return None, d_normal2.sum(0), d_feat2.sum(0), None, None, None, None, None, None
 
 

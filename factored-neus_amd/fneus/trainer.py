@@ -214,6 +214,7 @@ class Stage1Trainer:
 
     def _step_body(self, data, cos_anneal_ratio, background_rgb, with_optimizer: bool):
         rays_o, rays_d, true_rgb, mask = data[:, :3], data[:, 3:6], data[:, 6:9], data[:, 9:10]
+        ops.overlap_begin(self.device)       # window for side-stream work (fneus/ops.py); joined below, before Adam
         # near / far = None: near_far_from_sphere (dataset.py:186-192) is evaluated inside render's ray set-up launch
         # the losses of exp_runner.py:141-177 are evaluated inside render (fused with the surface shading and their own
         # gradients: one launch instead of ~200 element-wise kernels on [B]-ray tensors)
@@ -224,6 +225,7 @@ class Stage1Trainer:
         losses = out["losses"]
         self.zero_grad()
         losses["loss"].backward()
+        ops.overlap_end()                    # the weight gradients issued on the side stream are complete from here on
         if with_optimizer:
             self.optimizer.step()
         # Hand out DETACHED values: a caller that keeps the loss of the previous step (for logging) would otherwise keep

@@ -218,11 +218,12 @@ class NeuSRenderer:
             z_vals_outside = far / torch.flip(z_vals_outside, dims=[-1]) + 1.0 / self.n_samples
         # networks changed since the last call (optimiser step): fold weight-norm and re-pack once
         self.sdf_network.refresh()
-        self.color_network.refresh()
-        if self.refColor_network is not None:
-            self.refColor_network.refresh()
-        if self.n_outside > 0 and self.nerf is not None and hasattr(self.nerf, "refresh"):
-            self.nerf.refresh()
+        with ops.on_side_stream(1):          # the sampler only needs the SDF network: these packs run beside it
+            self.color_network.refresh()
+            if self.refColor_network is not None:
+                self.refColor_network.refresh()
+            if self.n_outside > 0 and self.nerf is not None and hasattr(self.nerf, "refresh"):
+                self.nerf.refresh()
         n = self.n_samples
         if self.n_importance > 0:
             if z_vals_override is not None:
@@ -230,6 +231,7 @@ class NeuSRenderer:
             else:
                 z_vals = self._hierarchical_z(rays_o, rays_d, z_vals.contiguous())
             n = self.n_samples + self.n_importance
+        ops.overlap_join()                   # the packs issued beside the sampler are needed from here on
         background_alpha = background_sampled_color = None
         if self.n_outside > 0:                                                    # renderer.py:452-458
             z_vals_feed, _ = torch.sort(torch.cat([z_vals, z_vals_outside.expand(B, -1)], dim=-1), dim=-1)
