@@ -105,7 +105,13 @@ def cpu_baseline(budget_s: float = 20.0, device=None):
         return {"value": n_rays * (N_SAMPLES + N_IMPORTANCE) / t, "unit": "ray-samples/s", "ms_per_step": t * 1e3,
                 "sample": f"{len(times)} full {n_rays}-ray train steps of oracle/ref_torch.py (fp32, eager stock PyTorch-ROCm "
                           f"ops, autograd double backward) on the same GPU after 1 warm-up"}
+    cpu_model = ""
+    try:
+        cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except Exception:
+        pass
     return {"value": CPU_RAYS * (N_SAMPLES + N_IMPORTANCE) / t, "unit": "ray-samples/s", "cores": threads, "kind": "port",
+            "cpu_model": cpu_model,
             "sample": f"{len(times)} train steps of {CPU_RAYS} rays x {N_SAMPLES + N_IMPORTANCE} samples (1/4 batch of the "
                       f"same workload) after 1 warm-up, oracle/ref_torch.py fp32, {threads} torch threads of "
                       f"{os.cpu_count()} host cores, median {t:.2f} s/step"}
