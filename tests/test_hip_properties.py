@@ -1,0 +1,124 @@
+"""Properties that do not depend on the batch size, checked at the size BASELINE.json quotes (512 rays x 128 samples),
+where the oracle is too slow to be the checker: ray-permutation equivariance, compositing invariants, linearity of the
+backward in its cotangent, repeatability.  Plus the ragged / degenerate launch sizes of the per-sample kernels against
+the oracle (1, 31, 33 samples; empty launches)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _trainer(seed=11):
+    from fneus import ops
+    from fneus.trainer import Stage1Trainer, WMASK_MODEL
+    conf = copy.deepcopy(WMASK_MODEL)
+    conf["neus_renderer"]["perturb"] = 0.0
+    return Stage1Trainer(DEV, model_conf=conf, prec=ops.PREC_PARITY, seed=seed, use_graph=False)
+
+
+def test_full_size_render_is_equivariant_under_ray_permutation_and_keeps_the_compositing_invariants():
+    from fneus.trainer import synthetic_batches
+    tr = _trainer()
+    data = synthetic_batches(1, 512, DEV, seed0=31)[0]
+    perm = torch.randperm(512, device=DEV, generator=torch.Generator(device=DEV).manual_seed(0))
+    a = tr.render_only(data)
+    b = tr.render_only(data[perm].contiguous())
+    for k in ("color_fine", "weights", "weight_sum", "gradients", "cdf_fine", "inside_sphere", "surface_color", "sdf_mask",
+              "_z_vals", "_sdf"):
+        va = a[k].reshape(512, -1)[perm]
+        vb = b[k].reshape(512, -1)
+        assert torch.equal(va, vb), k              # every kernel on the path works ray by ray / tile by tile: bit-exact
+    w, z = a["weights"], a["_z_vals"]
+    assert w.shape == (512, 128) and (w >= 0).all() and (a["weight_sum"] <= 1.0 + 1e-5).all()
+    assert (z[:, 1:] >= z[:, :-1]).all()                                      # merged depths stay sorted
+    ins = a["inside_sphere"]
+    assert ((ins == 0) | (ins == 1)).all()
+    assert ((a["cdf_fine"] >= 0) & (a["cdf_fine"] <= 1)).all()
+    sc, m = a["surface_color"], a["sdf_mask"]
+    assert (sc[~m] == 1.0).all()                                              # rows outside sdf_mask stay 1.0 (renderer.py:280-282)
+    assert int(m.sum()) > 50                                                  # ... and the branch is exercised
+    again = tr.render_only(data)
+    for k in ("color_fine", "weights", "gradients", "surface_color"):
+        assert torch.equal(a[k], again[k]), k                                 # repeatable bit for bit
+
+
+def test_full_size_backward_is_linear_in_its_cotangent():
+    from fneus import ops, synth
+    n = 65536
+    net = ops.PackedNet("sdf", DEV).load_state_dict({k: T(v) for k, v in synth.sdf_state_dict(5).items()})
+    net.pack()
+    g = torch.Generator(device=DEV).manual_seed(1)
+    x = (torch.rand(n, 3, device=DEV, generator=g) * 2 - 1).contiguous()
+    stash = ops.SdfStash(n, DEV, 3, train=True)
+    ops.sdf_fwd_grad(net.blob, n, 3, stash, True, pts=x)
+    bufs = ops.SdfBwdBufs(n, DEV, 3)
+    c_s = torch.randn(n, device=DEV, generator=g)
+    c_f = torch.randn(n, 256, device=DEV, generator=g) * 0.05
+    c_n = torch.randn(n, 3, device=DEV, generator=g)
+
+    def grads(scale):
+        ops.sdf_bwd(net.blob, n, 3, stash, bufs, (c_s * scale).contiguous(), (c_f * scale).contiguous(), (c_n * scale).contiguous(), pts=x)
+        grad = torch.zeros(net.n_params, dtype=torch.float32, device=DEV)
+        ops.sdf_dw_jobs(net, stash, bufs, grad, n).run(n, 3)
+        torch.cuda.synchronize()
+        return grad
+
+    g1, g4 = grads(1.0), grads(4.0)
+    assert torch.isfinite(g1).all() and g1.abs().max() > 0
+    rel = ((g4 - 4.0 * g1).norm() / g4.norm()).item()
+    print(f"  dW(4 c) vs 4 dW(c) at N = 65536: relative difference {rel:.2e}")
+    assert rel <= 2e-6            # powers of two scale exactly; what is left is the order of the fp32 atomics
+
+
+@pytest.mark.parametrize("n", [1, 31, 33])
+def test_ragged_launch_sizes_match_the_oracle(n):
+    from fneus import ops, synth
+    from oracle import ref_torch as R
+    sd = {k: T(v) for k, v in synth.sdf_state_dict(20).items()}
+    p = R.sdf_params_from_state_dict(sd)
+    p64 = {"W": [w.double() for w in p["W"]], "b": [b.double() for b in p["b"]], "scale": 1.0}
+    net = ops.PackedNet("sdf", DEV).load_state_dict(sd)
+    net.pack()
+    rs = np.random.RandomState(n)
+    x = T(rs.uniform(-1, 1, size=(n, 3)).astype(np.float32))
+    sdf_r, feat_r, nrm_r, _ = R.sdf_value_feature_normal(x.double(), p64)
+    xd = x.to(DEV).contiguous()
+    guard = torch.full((n + 64,), 7.0, device=DEV)                             # nothing may be written behind row n
+    ops.sdf_fwd(net.blob, n, 3, pts=xd, out=guard[:n])
+    assert (guard[n:] == 7.0).all()
+    assert (guard[:n].cpu().double() - sdf_r[:, 0]).abs().max().item() <= 1e-4
+    stash = ops.SdfStash(n, DEV, 3, train=True)
+    sdf, feat, nrm = ops.sdf_fwd_grad(net.blob, n, 3, stash, True, pts=xd)
+    assert (sdf.cpu().double() - sdf_r[:, 0]).abs().max().item() <= 1e-4
+    assert (feat.cpu().double() - feat_r).abs().max().item() <= 1e-4
+    assert (nrm.cpu().double() - nrm_r).abs().max().item() <= 1e-4
+    # colour network on the same ragged tile
+    csd = {k: T(v) for k, v in synth.color_state_dict(21).items()}
+    cnet = ops.PackedNet("color", DEV).load_state_dict(csd)
+    cnet.pack()
+    d = T(rs.standard_normal((n, 3)).astype(np.float32))
+    d = d / d.norm(dim=-1, keepdim=True)
+    rgb_ref = R.color_forward(x.double(), nrm_r, d.double(), feat_r, {k: [t.double() for t in v] for k, v in
+                                                                        R.color_params_from_state_dict(csd).items()})
+    rgb = ops.color_fwd(cnet.blob, n, 3, nrm, feat, None, False, pts=xd, dirs=d.to(DEV).contiguous())
+    assert (rgb.cpu().double() - rgb_ref).abs().max().item() <= 1e-4
+
+
+def test_empty_launches_are_no_ops():
+    from fneus import ops, synth
+    net = ops.PackedNet("sdf", DEV).load_state_dict({k: T(v) for k, v in synth.sdf_state_dict(20).items()})
+    net.pack()
+    x = torch.zeros(0, 3, device=DEV)
+    assert ops.sdf_fwd(net.blob, 0, 3, pts=x).shape == (0,)
+    stash = ops.SdfStash(32, DEV, 3, train=True)
+    sdf, feat, nrm = ops.sdf_fwd_grad(net.blob, 0, 3, stash, True, pts=x)
+    assert sdf.shape == (0,) and feat.shape == (0, 256) and nrm.shape == (0, 3)
+    torch.cuda.synchronize()
