@@ -124,8 +124,11 @@ __global__ void __launch_bounds__(NTHREADS) dw_gemm_kernel(const GemmJob* __rest
     float bias_acc = 0.0f;
     const bool do_bias = (jb.bias != nullptr) && (tn == 0) && (tid < TM);
 
-    u32x4 ra_h[CHUNKS], rb_h[CHUNKS], ra_l[CHUNKS], rb_l[CHUNKS];
-    auto fetch = [&](int b) {
+    struct Stage {
+        u32x4 ah[CHUNKS], bh[CHUNKS], al[CHUNKS], bl[CHUNKS];
+    };
+    Stage S0;
+    auto fetch = [&](int b, Stage& S) {
         const int seg = (b >= nb1) ? 1 : 0;
         const long s0 = s_begin + (long)(b - seg * nb1) * KB;
         const __bf16* ah = seg ? jb.a2_hi : jb.a_hi;
@@ -134,35 +137,51 @@ __global__ void __launch_bounds__(NTHREADS) dw_gemm_kernel(const GemmJob* __rest
         const __bf16* bl = seg ? jb.b2_lo : jb.b_lo;
         const int lda = seg ? jb.lda2 : jb.lda, ldb = seg ? jb.ldb2 : jb.ldb;
         const bool e0 = seg && jb.a2_mode == 1;
-        if (e0) load_e0(ra_h, s0, s_end, tm * TM, tid);
-        else load_plane(ra_h, ah, lda, jb.a_w, s0, s_end, tm * TM, tid);
-        load_plane(rb_h, bh, ldb, jb.b_w, s0, s_end, tn * TN, tid);
+        if (e0) load_e0(S.ah, s0, s_end, tm * TM, tid);
+        else load_plane(S.ah, ah, lda, jb.a_w, s0, s_end, tm * TM, tid);
+        load_plane(S.bh, bh, ldb, jb.b_w, s0, s_end, tn * TN, tid);
         if constexpr (PREC == 3) {
-            if (e0) load_plane(ra_l, nullptr, 0, 0, s0, s_end, 0, tid);
-            else load_plane(ra_l, al, lda, jb.a_w, s0, s_end, tm * TM, tid);
-            load_plane(rb_l, bl, ldb, jb.b_w, s0, s_end, tn * TN, tid);
+            if (e0) load_plane(S.al, nullptr, 0, 0, s0, s_end, 0, tid);
+            else load_plane(S.al, al, lda, jb.a_w, s0, s_end, tm * TM, tid);
+            load_plane(S.bl, bl, ldb, jb.b_w, s0, s_end, tn * TN, tid);
         }
     };
-    auto commit = [&](int buf) {
+    auto commit = [&](int buf, const Stage& S) {
         unsigned char* base = smem + buf * BUFB;
-        store_plane(base, ra_h, tid);
-        store_plane(base + PLANEB, rb_h, tid);
+        store_plane(base, S.ah, tid);
+        store_plane(base + PLANEB, S.bh, tid);
         if constexpr (PREC == 3) {
-            store_plane(base + 2 * PLANEB, ra_l, tid);
-            store_plane(base + 3 * PLANEB, rb_l, tid);
+            store_plane(base + 2 * PLANEB, S.al, tid);
+            store_plane(base + 3 * PLANEB, S.bl, tid);
         }
     };
 
-    fetch(0);
-    commit(0);
-    __syncthreads();
-    for (int b = 0; b < nb; ++b) {
-        if (b + 1 < nb) fetch(b + 1);
+    // Operand pipeline, ONE register set: block b+1 is written to LDS right AFTER the barrier that opens iteration b and
+    // block b+2 is requested at once, so a block's loads have a whole iteration (products + barrier) to land instead of
+    // the products alone.  (History, N = 65 536 SDF launch, parity mode: written before the barrier 706 us; this order
+    // 648 us; with a second register set, i.e. two blocks in flight, 732 us -- it spills 50 registers -- and 265 vs 279 us
+    // in bf16 mode where it does not; stream alone 476 us, products alone 391 us: tools/experiments/README.md.)
+    auto step = [&](int b, Stage& S) {
+        __syncthreads();             // buffer b&1 is complete; every wave is done with the products of block b-1
+#ifndef FNEUS_DBG_GEMM_NO_LOAD      // timing experiments only (tools/experiments): the compute loop without its operand stream
+        if (b + 1 < nb) {
+#ifndef FNEUS_DBG_GEMM_NO_COMMIT
+            commit((b + 1) & 1, S);
+#endif
+#ifndef FNEUS_DBG_GEMM_NO_FETCH
+            if (b + 2 < nb) fetch(b + 2, S);
+#endif
+        }
+#endif
         const unsigned char* sA_hi = smem + (b & 1) * BUFB;
         const unsigned char* sB_hi = sA_hi + PLANEB;
         const unsigned char* sA_lo = sA_hi + 2 * PLANEB;
         const unsigned char* sB_lo = sA_hi + 3 * PLANEB;
+#ifdef FNEUS_DBG_GEMM_NO_BIAS
+        if (false) {
+#else
         if (do_bias && b < nb1) {
+#endif
             float s = 0.0f;
             for (int row = 0; row < KB; ++row) {
                 s += (float)*reinterpret_cast<const __bf16*>(sA_hi + row * ROWB + tid * 2);
@@ -170,32 +189,45 @@ __global__ void __launch_bounds__(NTHREADS) dw_gemm_kernel(const GemmJob* __rest
             }
             bias_acc += s;
         }
+#ifndef FNEUS_DBG_GEMM_NO_MFMA      // timing experiments only: the operand stream (global -> registers -> LDS) without the products
 #pragma unroll
         for (int kk = 0; kk < KB / 16; ++kk) {
-            bf16x8 fb_h[2], fb_l[2];
+            // fragment reads run one A tile ahead of the products (hipcc otherwise batches "all reads, wait, all MFMAs",
+            // and with both waves of a SIMD released by the same barrier their read phases coincide); the scheduling
+            // barriers keep that order.  HAZARD as in mlp_engine.h dense_ldsb(): an LDS read must not land in the
+            // registers of an MFMA still queued -- the prefetch targets the OTHER fragment set, last used one stage ago.
+            bf16x8 fb_h[2], fb_l[2], fa_h[2], fa_l[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 fb_h[j] = frag_from_lds(sB_hi, wc * 64 + j * 32, kk, lane);
                 if constexpr (PREC == 3) fb_l[j] = frag_from_lds(sB_lo, wc * 64 + j * 32, kk, lane);
             }
+            fa_h[0] = frag_from_lds(sA_hi, wr * 128, kk, lane);
+            if constexpr (PREC == 3) fa_l[0] = frag_from_lds(sA_lo, wr * 128, kk, lane);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const bf16x8 fa_h = frag_from_lds(sA_hi, wr * 128 + i * 32, kk, lane);
-                bf16x8 fa_l;
-                if constexpr (PREC == 3) fa_l = frag_from_lds(sA_lo, wr * 128 + i * 32, kk, lane);
+                if (i + 1 < 4) {
+                    fa_h[(i + 1) & 1] = frag_from_lds(sA_hi, wr * 128 + (i + 1) * 32, kk, lane);
+                    if constexpr (PREC == 3) fa_l[(i + 1) & 1] = frag_from_lds(sA_lo, wr * 128 + (i + 1) * 32, kk, lane);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     if constexpr (PREC == 3) {
-                        acc[i][j] = mfma32(fa_l, fb_h[j], acc[i][j]);
-                        acc[i][j] = mfma32(fa_h, fb_l[j], acc[i][j]);
+                        acc[i][j] = mfma32(fa_l[i & 1], fb_h[j], acc[i][j]);
+                        acc[i][j] = mfma32(fa_h[i & 1], fb_l[j], acc[i][j]);
                     }
-                    acc[i][j] = mfma32(fa_h, fb_h[j], acc[i][j]);
+                    acc[i][j] = mfma32(fa_h[i & 1], fb_h[j], acc[i][j]);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (b + 1 < nb) commit((b + 1) & 1);
-        __syncthreads();
-    }
+#endif
+    };
+    fetch(0, S0);
+    commit(0, S0);
+    if (nb > 1) fetch(1, S0);
+    for (int b = 0; b < nb; ++b) step(b, S0);
     // epilogue: fp32 atomics (two 128-byte row segments per wave instruction)
     const int hh = lane >> 5, cc = lane & 31;
 #pragma unroll
