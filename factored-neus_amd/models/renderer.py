@@ -124,6 +124,13 @@ class NeuSRenderer:
             color = color + background_rgb * (1.0 - weights.sum(dim=-1, keepdim=True))
         return {"color": color, "sampled_color": rgb, "alpha": alpha, "weights": weights}
 
+    def _ones_b3(self, B, device):
+        key = (B, str(device))
+        cache = self.__dict__.setdefault("_ones_cache", {})
+        if key not in cache:
+            cache[key] = torch.ones(B, 3, device=device)
+        return cache[key]
+
     # ---- render_core (renderer.py:208-389) ------------------------------------------------------------------------
     def render_core(self, rays_o, rays_d, z_vals, sample_dist, sdf_network, deviation_network, color_network,
                     refColor_network, background_alpha=None, background_sampled_color=None, background_rgb=None,
@@ -139,12 +146,13 @@ class NeuSRenderer:
             sdf, normal, rgb, deviation_network.variance, rays_o, rays_d, mid_z, dists,
             cos_anneal_ratio if torch.is_tensor(cos_anneal_ratio) else float(cos_anneal_ratio),
             background_alpha, background_sampled_color)
-        sdf_mask = sdf_mask_u8.bool()
+        sdf_mask = sdf_mask_u8.view(torch.bool)          # the kernel writes exactly 0 / 1: reinterpret, no cast kernel
         if background_rgb is not None:
             color = color + background_rgb * (1.0 - wsum[:, None])
 
         # surface branch at fixed shape (renderer.py:284-343): the two samples bracketing the first sign change
-        ones = torch.ones(B, 3, device=z_vals.device)
+        # constant, never written on the RefColor paths (they produce fresh tensors): allocated once per batch size
+        ones = self._ones_b3(B, z_vals.device) if refColor_network is not None else torch.ones(B, 3, device=z_vals.device)
         specular_color = diffuse_color = surface_color = ones
         losses = None
         if refColor_network is not None:
