@@ -101,3 +101,16 @@ def test_nerf_no_grad_matches_training_forward_and_accumulates():
     (a2.sum() + rgb2.sum()).backward()                               # gradients ACCUMULATE like autograd's
     for p, g in zip(net.parameters(), g1):
         assert torch.allclose(p.grad, 2 * g, rtol=1e-4, atol=1e-6)
+
+
+def test_nerf_matches_the_reference_outputs_in_the_golden_fixture(golden_dir):
+    """tests/golden/units.npz holds NeRF.forward outputs of the REFERENCE itself (tests/golden/gen_golden.py imports it)"""
+    import os
+    from fneus import synth
+    g = np.load(os.path.join(golden_dir, "units.npz"))
+    net, _ = _module(int(g["seed_nerf"]), 3)
+    a, rgb = net(T(g["nerf_in"]).to(DEV), T(g["dirs"][:40]).to(DEV))
+    e_a = np.abs(a.detach().cpu().numpy() - g["nerf_alpha"]).max()
+    e_rgb = np.abs(rgb.detach().cpu().numpy() - g["nerf_rgb"]).max()
+    print(f"  K7 vs the reference's NeRF.forward: density {e_a:.2e}, rgb {e_rgb:.2e}")
+    assert e_a <= 1e-4 and e_rgb <= 1e-4
