@@ -269,6 +269,28 @@ class NeuSRenderer:
             "_z_vals": z_vals, "_sdf": ret["sdf"], "_mid_z_vals": ret["mid_z_vals"],
         }
 
+    def lvis_mateIllu_render_util(self, rays_o, rays_d, near, far):
+        """renderer.py:503-564, the entry of the stage-2 / stage-3 renderers (lvis_render, mateIllu_render): unperturbed
+        hierarchical sampling, SDF at the section mid-points and the per-ray inside-sphere mask.  Geometry is frozen in
+        those stages (lvis.py:78-92 optimises the visibility / indirect-light networks only), so the SDF comes from the
+        no-grad K1 kernel: fneus_ray_setup + 4 x (fneus_upsample, fneus_sdf_fwd, fneus_merge) + fneus_sections + fneus_sdf_fwd."""
+        B = rays_o.shape[0]
+        sample_dist = 2.0 / self.n_samples
+        rays_o, rays_d = rays_o.detach().float().contiguous(), rays_d.detach().float().contiguous()
+        self.sdf_network.refresh()
+        with torch.no_grad():
+            cf = lambda t: None if t is None else t.detach().float().reshape(B, 1).contiguous()
+            z_vals = ops.ray_setup(rays_o, rays_d, self.n_samples, near=cf(near), far=cf(far))
+            n = self.n_samples
+            if self.n_importance > 0:
+                z_vals = self._hierarchical_z(rays_o, rays_d, z_vals.contiguous())
+                n = self.n_samples + self.n_importance
+            dists, mid_z = ops.sections(z_vals.contiguous(), sample_dist)
+            sdf = self.sdf_network.sdf_samples(RaySamples(rays_o, rays_d, mid_z.reshape(-1), n))
+            pts = rays_o[:, None, :] + rays_d[:, None, :] * mid_z[..., None]
+            inside_sphere = torch.linalg.norm(pts, ord=2, dim=-1) < 1.0
+        return {"n_samples": n, "mid_z_vals": mid_z, "sdf": sdf[:, None], "inside_sphere_mask": inside_sphere.any(dim=-1)}
+
     def extract_geometry(self, bound_min, bound_max, resolution, threshold=0.0):
         """renderer.py:729-734: iso-surface of -sdf at `threshold`; the grid goes through K1 (fneus_sdf_fwd), the surface
         is extracted on the device by models/mesh.py (marching tetrahedra; PyMCubes is not a dependency).
