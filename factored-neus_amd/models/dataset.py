@@ -198,3 +198,32 @@ class SyntheticDataset(_RayMixin):
         self.scale_mats_np = [np.eye(4, dtype=np.float32)] * n_images
         self.object_bbox_min = np.array([-1.01, -1.01, -1.01], dtype=np.float32)
         self.object_bbox_max = np.array([1.01, 1.01, 1.01], dtype=np.float32)
+
+
+def export_dtu_scene(ds: "SyntheticDataset", out_dir: str, scale: float = 1.0, offset=(0.0, 0.0, 0.0)) -> str:
+    """Write a SyntheticDataset as a DTU-format case (what `Dataset` and the reference's loader read, dataset.py:41-113):
+    image/%03d.png, mask/%03d.png and cameras_sphere.npz with world_mat_i = K [R | t] (world coordinates = scale * unit
+    sphere coordinates + offset) and scale_mat_i = the unit-sphere normalisation.  Channels are written so that a cv2-style
+    read (BGR) returns ds.images."""
+    from PIL import Image
+    os.makedirs(os.path.join(out_dir, "image"), exist_ok=True)
+    os.makedirs(os.path.join(out_dir, "mask"), exist_ok=True)
+    cams = {}
+    S = np.eye(4, dtype=np.float64)
+    S[:3, :3] *= scale
+    S[:3, 3] = np.asarray(offset, dtype=np.float64)
+    for i in range(ds.n_images):
+        img = (ds.images[i].cpu().numpy() * 256.0).clip(0, 255).astype(np.uint8)      # stored values are BGR / 256
+        msk = (ds.masks[i].cpu().numpy() * 255.0).clip(0, 255).astype(np.uint8)
+        Image.fromarray(img[..., ::-1].copy()).save(os.path.join(out_dir, "image", "%03d.png" % i))
+        Image.fromarray(msk).save(os.path.join(out_dir, "mask", "%03d.png" % i))
+        K = ds.intrinsics_all[i].cpu().numpy().astype(np.float64)
+        pose = ds.pose_all[i].cpu().numpy().astype(np.float64)                        # camera-to-(unit sphere) world
+        pose_w = S @ pose                                                              # camera-to-world, world = S * sphere
+        pose_w[:3, :3] /= scale
+        w2c = np.linalg.inv(pose_w)
+        cams["world_mat_%d" % i] = K @ w2c
+        cams["scale_mat_%d" % i] = S
+    path = os.path.join(out_dir, "cameras_sphere.npz")
+    np.savez(path, **cams)
+    return out_dir

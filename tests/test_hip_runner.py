@@ -60,3 +60,32 @@ def test_runner_train_checkpoint_resume_validate(tmp_path):
     with torch.no_grad():
         sdf_v = r2.trainer.sdf_network.sdf(torch.from_numpy(v).float().to(dev))
     assert sdf_v.abs().max().item() < 5e-3
+
+
+@pytest.mark.parametrize("conf_name", ["wmask.conf", "womask.conf"])
+def test_runner_on_a_dtu_format_case(tmp_path, conf_name):
+    """--type dtu: the file loader (image/*.png, mask/*.png, cameras_sphere.npz) feeds the same step; womask.conf adds the
+    background NeRF++ (K7), the white background and a ramping cos_anneal_ratio -- still one graph"""
+    sys.path.insert(0, os.path.join(ROOT, "factored-neus_amd"))
+    import exp_runner
+    from models.dataset import SyntheticDataset, export_dtu_scene
+    dev = torch.device("cuda:0")
+    data_root = os.path.join(str(tmp_path), "data")
+    export_dtu_scene(SyntheticDataset(n_images=4, H=48, W=64, device=torch.device("cpu"), seed=2),
+                     os.path.join(data_root, "toy"), scale=20.0, offset=(1.0, 2.0, 3.0))
+    src = open(os.path.join(ROOT, "factored-neus_amd", "confs", conf_name)).read()
+    src = src.replace("./exp/CASE_NAME/", str(tmp_path) + "/exp/CASE_NAME/")
+    import re
+    src = re.sub(r"data_dir\s*=\s*\S+", "data_dir = " + data_root + "/CASE_NAME/", src)
+    path = os.path.join(str(tmp_path), conf_name)
+    open(path, "w").write(src)
+    r = exp_runner.Runner(path, mode="train", case="toy", type="dtu", device=dev)
+    assert r.dataset.n_images == 4 and (r.dataset.H, r.dataset.W) == (48, 64)
+    r.batch_size = 128
+    r.save_freq = r.report_freq = r.val_freq = r.val_mesh_freq = 10 ** 9
+    r.train(max_steps=6)
+    assert r.iter_step == 6 and len(r.trainer._graphs) == 1
+    for p in r.trainer.params:
+        assert torch.isfinite(p).all()
+    img = r.validate_image(idx=1, resolution_level=4)
+    assert os.path.exists(img)

@@ -177,3 +177,34 @@ def test_data_parallel_bucket_gloo_world2():
     for a, b, m0, m1 in zip(s0, s1, l0, l1):
         assert np.array_equal(a, b) and np.allclose(a, m0 + m1, atol=1e-6)       # allreduce_sum
     assert np.array_equal(n0, n1) and np.array_equal(n0, np.array([7.0, 3.0, 30.0, 12.0], dtype=np.float32))
+
+
+def test_dtu_format_dataset_reads_files_like_the_reference_loader(tmp_path):
+    """Dataset (reference models/dataset.py:41-113): image/*.png + mask/*.png + cameras_sphere.npz (world_mat_i, scale_mat_i)
+    -> BGR/256 images, intrinsics and poses via the projection-matrix decomposition, rays on the device.  The case is
+    written from the analytic synthetic scene with a non-trivial scale matrix; loading it must give back its cameras."""
+    from models.dataset import Dataset, SyntheticDataset, export_dtu_scene
+
+    class Conf(dict):
+        def get_string(self, k):
+            return self[k]
+
+    cpu = torch.device("cpu")
+    src = SyntheticDataset(n_images=3, H=24, W=32, device=cpu, seed=4)
+    case = export_dtu_scene(src, str(tmp_path / "case"), scale=37.5, offset=(10.0, -4.0, 2.5))
+    ds = Dataset(Conf(data_dir=case, render_cameras_name="cameras_sphere.npz"), device=cpu)
+    assert ds.n_images == 3 and (ds.H, ds.W) == (24, 32)
+    # pixels: 8-bit quantisation of the source, same channel order (the loader mimics cv2.imread: BGR / 256)
+    assert (ds.images - src.images).abs().max().item() <= 1.0 / 256 + 1e-6
+    assert torch.equal(ds.masks > 0.5, src.masks > 0.5)
+    # cameras: world_mat @ scale_mat decomposes back into the unit-sphere intrinsics / poses
+    assert torch.allclose(ds.intrinsics_all[:, :3, :3], src.intrinsics_all[:, :3, :3], atol=2e-3)
+    assert torch.allclose(ds.pose_all, src.pose_all, atol=2e-4)
+    torch.manual_seed(0)
+    a = ds.gen_random_rays_at(1, 32)
+    torch.manual_seed(0)
+    b = src.gen_random_rays_at(1, 32)
+    assert torch.allclose(a[:, :6], b[:, :6], atol=3e-4)                       # same rays
+    assert (a[:, 6:9] - b[:, 6:9]).abs().max().item() <= 1.0 / 256 + 1e-6 and torch.equal(a[:, 9] > 0.5, b[:, 9] > 0.5)
+    o, d = ds.gen_rays_at(2, resolution_level=4)
+    assert o.shape == (6, 8, 3) and torch.allclose(d.norm(dim=-1), torch.ones(6, 8), atol=1e-5)
