@@ -217,14 +217,15 @@ def build_color_jobs(COL_IN=COL_IN, COL_OUT=COL_OUT, N_SIDE=N_SIDE, weight_norm=
             kmap = np.where(feat < 256, feat + N_SIDE, np.where(feat - 256 < N_SIDE, feat - 256, -1))
         else:
             kmap = _lim(feat, n_in)
-        b.frag(fwd_hi, fwd_lo, offV[l], n_in, ksf, ntf, 0, rowmap, kmap, 1.0, rbase[l])
+        rs = rbase[l] if weight_norm else -1          # plain Linear layers: no row scale to apply
+        b.frag(fwd_hi, fwd_lo, offV[l], n_in, ksf, ntf, 0, rowmap, kmap, 1.0, rs)
         kmap_r = _lim(slot_features(ksr), n_out)
         rin = np.arange(ntr * 32)
         if l == 0:
             rowmap_r = np.where(rin < 256, rin + N_SIDE, np.where(rin - 256 < N_SIDE, rin - 256, -1))
         else:
             rowmap_r = _lim(rin, n_in)
-        b.frag(rev_hi, rev_lo, offV[l], n_in, ksr, ntr, 1, rowmap_r, kmap_r, 1.0, rbase[l])
+        b.frag(rev_hi, rev_lo, offV[l], n_in, ksr, ntr, 1, rowmap_r, kmap_r, 1.0, rs)
         b.accvec(bias, offB[l], 1, ntf, rowmap)
     jobs, maps, units = b.finish()
     segs = np.array([(offb[l], offB[l], COL_OUT[l], 0) for l in range(5)], dtype=np.int32)

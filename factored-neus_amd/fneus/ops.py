@@ -189,8 +189,9 @@ class PackedNet:
 
     def pack(self):
         """fold weight-norm + pack the current raw parameters (once per optimiser step)"""
-        _launch("fneus_rowscale", lib.fneus_rowscale, _ptr(self.rows), self.n_rows, _ptr(self.raw), _ptr(self.rowscale),
-                _ptr(self.invnorm), _stream())
+        if self.desc.get("weight_norm", True):        # plain Linear networks have nothing to fold
+            _launch("fneus_rowscale", lib.fneus_rowscale, _ptr(self.rows), self.n_rows, _ptr(self.raw), _ptr(self.rowscale),
+                    _ptr(self.invnorm), _stream())
         _launch("fneus_pack", lib.fneus_pack, _ptr(self.jobs), self.n_jobs, self.units, _ptr(self.maps), _ptr(self.raw),
                 _ptr(self.rowscale), _ptr(self.blob), _stream())
         return self.blob
