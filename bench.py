@@ -57,7 +57,7 @@ KERNEL_BYTES_PARITY = {
 CPU_RAYS = 128          # bounded CPU sample: a quarter batch of the same workload (same samples per ray, same nets)
 
 
-def cpu_baseline(budget_s: float = 20.0, device=None):
+def cpu_baseline(budget_s: float = 12.0, device=None):
     """The oracle (CPU port of the reference algorithm) timed on the host cores: same workload, bounded sample.
     With `device` = the GPU the same port runs through stock PyTorch-ROCm ops on the full batch: the "unfused GPU" figure
     the reference itself would get on this box; reported inside the cpu_baseline object."""
@@ -96,7 +96,8 @@ def cpu_baseline(budget_s: float = 20.0, device=None):
         if step > 0 or budget_s <= 0:
             times.append(dt)
         step += 1
-        if (time.time() - t_start > budget_s and len(times) >= 1) or step >= (8 if on_gpu else 5) or (step >= 1 and dt > budget_s):
+        # bounded sample: about budget_s seconds of CPU work (at most 40 steps); 8 steps of the GPU run of the same code
+        if (time.time() - t_start > budget_s and len(times) >= 1) or step >= (8 if on_gpu else 40) or (step >= 1 and dt > budget_s):
             break
     if not times:
         times = [dt]
@@ -112,7 +113,7 @@ def cpu_baseline(budget_s: float = 20.0, device=None):
         pass
     return {"value": CPU_RAYS * (N_SAMPLES + N_IMPORTANCE) / t, "unit": "ray-samples/s", "cores": threads, "kind": "port",
             "cpu_model": cpu_model,
-            "sample": f"{len(times)} train steps of {CPU_RAYS} rays x {N_SAMPLES + N_IMPORTANCE} samples (1/4 batch of the "
+            "sample": f"{len(times)} train steps (~{sum(times):.0f} s) of {CPU_RAYS} rays x {N_SAMPLES + N_IMPORTANCE} samples (1/4 batch of the "
                       f"same workload) after 1 warm-up, oracle/ref_torch.py fp32, {threads} torch threads of "
                       f"{os.cpu_count()} host cores, median {t:.2f} s/step"}
 
