@@ -13,7 +13,9 @@
 // weight-prefetch depth of this file's kernels (stages; see dense() in mlp_engine.h): measured best at 4 / 8
 #define FNEUS_PREFETCH_X3 4
 #define FNEUS_PREFETCH_X1 8
+#include <stdlib.h>
 #include "mlp_engine.h"
+#include "tp_engine.h"
 #include "fneus_kernels.h"
 
 namespace fneus {
@@ -222,6 +224,76 @@ __global__ void __launch_bounds__(64, 1) refcolor_fwd_both_kernel(HeadArgs cd, H
         color_fwd_body<PREC, TRAIN, VAR_REF_SPECULAR>(scr, vd.blob, src, N, dirs, normal, feat, vd.st, vd.out);
 }
 
+// gradient of the 33 side inputs (2 accumulator tiles) -> d normal of the sample, for the three input layouts
+template <int VAR>
+FN_DEV void side_grad_to_dnormal(const f32x16 (&s2)[2], long n, long nc, bool valid, int lane, int h,
+                                 float* __restrict__ d_normal, const float* __restrict__ normal,
+                                 const float* __restrict__ dirs, const float* __restrict__ rays_d, int m) {
+    if constexpr (VAR == VAR_COLOR) {
+        const float g0 = acc_extract<2, 30>(s2, h), g1 = acc_extract<2, 31>(s2, h), g2 = acc_extract<2, 32>(s2, h);
+        if (valid && lane < 32) {
+            d_normal[n * 3 + 0] = g0;
+            d_normal[n * 3 + 1] = g1;
+            d_normal[n * 3 + 2] = g2;
+        }
+    } else {
+        float nrm[3], d[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) nrm[c] = normal[nc * 3 + c];
+        if (dirs) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) d[c] = dirs[nc * 3 + c];
+        } else {
+            const long ray = nc / m;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) d[c] = rays_d[ray * 3 + c];
+        }
+        float pe[27], jc[27], dn[3];
+        if constexpr (VAR == VAR_REF_DIFFUSE) {    // side = pts | PE4(n):  d n = J_PE(n)^T g[3..29]
+            posenc<4, true>(nrm, pe, jc);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float coef[33];
+#pragma unroll
+                for (int f = 0; f < 33; ++f) coef[f] = (f >= 3 && f < 30 && ((f - 3) % 3) == c) ? jc[f - 3] : 0.0f;
+                const float part = acc_dot_partial<2, 33>(s2, coef, h);
+                dn[c] = part + xor32(part);
+            }
+        } else {                                   // side = n | pts | PE4(ref),  ref = 2 (n^ . -d) n^ + d
+            float nh[3], ref[3], inv_len, sdot, dref[3], gdir[3];
+            reflect_dir(d, nrm, nh, ref, inv_len, sdot);
+            posenc<4, true>(ref, pe, jc);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float coef[33], one[33];
+#pragma unroll
+                for (int f = 0; f < 33; ++f) {
+                    coef[f] = (f >= 6 && ((f - 6) % 3) == c) ? jc[f - 6] : 0.0f;
+                    one[f] = (f == c) ? 1.0f : 0.0f;
+                }
+                const float p1 = acc_dot_partial<2, 33>(s2, coef, h);
+                const float p2 = acc_dot_partial<2, 33>(s2, one, h);
+                dref[c] = p1 + xor32(p1);
+                gdir[c] = p2 + xor32(p2);
+            }
+            // d n^_j = 2 s dref_j - 2 d_j (dref . n^);  n^ = n / |n|  ->  d n = (d n^ - n^ (n^ . d n^)) / |n|
+            const float dr_n = dref[0] * nh[0] + dref[1] * nh[1] + dref[2] * nh[2];
+            float dnh[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dnh[c] = 2.0f * sdot * dref[c] - 2.0f * d[c] * dr_n;
+            const float proj = dnh[0] * nh[0] + dnh[1] * nh[1] + dnh[2] * nh[2];
+            const float eps = 1.1920928955078125e-07f;
+            const bool clamped = (nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]) < eps;   // torch.clamp: zero slope
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dn[c] = gdir[c] + (clamped ? dnh[c] : dnh[c] - nh[c] * proj) * inv_len;
+        }
+        if (valid && lane < 32) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) d_normal[n * 3 + c] = dn[c];
+        }
+    }
+}
+
 template <int PREC, int VAR>
 FN_DEV void color_bwd_body(unsigned char* scr, const unsigned char* blob, long N,
                            const float* __restrict__ d_rgb,   // [N][3]
@@ -284,69 +356,7 @@ FN_DEV void color_bwd_body(unsigned char* scr, const unsigned char* blob, long N
         dense<PREC, 16, 10, 0, 10>(blob, LY.L[0].rev_hi, LY.L[0].rev_lo, bf, acc, lane);
         store_f32<8>(a8, d_feat, 256, nc, h, valid);
         f32x16(&s2)[2] = reinterpret_cast<f32x16(&)[2]>(acc[8]);      // gradient of the 33 side inputs
-        if constexpr (VAR == VAR_COLOR) {
-            const float g0 = acc_extract<2, 30>(s2, h), g1 = acc_extract<2, 31>(s2, h), g2 = acc_extract<2, 32>(s2, h);
-            if (valid && lane < 32) {
-                d_normal[n * 3 + 0] = g0;
-                d_normal[n * 3 + 1] = g1;
-                d_normal[n * 3 + 2] = g2;
-            }
-        } else {
-            float nrm[3], d[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) nrm[c] = normal[nc * 3 + c];
-            if (dirs) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) d[c] = dirs[nc * 3 + c];
-            } else {
-                const long ray = nc / m;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) d[c] = rays_d[ray * 3 + c];
-            }
-            float pe[27], jc[27], dn[3];
-            if constexpr (VAR == VAR_REF_DIFFUSE) {    // side = pts | PE4(n):  d n = J_PE(n)^T g[3..29]
-                posenc<4, true>(nrm, pe, jc);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    float coef[33];
-#pragma unroll
-                    for (int f = 0; f < 33; ++f) coef[f] = (f >= 3 && f < 30 && ((f - 3) % 3) == c) ? jc[f - 3] : 0.0f;
-                    const float part = acc_dot_partial<2, 33>(s2, coef, h);
-                    dn[c] = part + xor32(part);
-                }
-            } else {                                   // side = n | pts | PE4(ref),  ref = 2 (n^ . -d) n^ + d
-                float nh[3], ref[3], inv_len, sdot, dref[3], gdir[3];
-                reflect_dir(d, nrm, nh, ref, inv_len, sdot);
-                posenc<4, true>(ref, pe, jc);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    float coef[33], one[33];
-#pragma unroll
-                    for (int f = 0; f < 33; ++f) {
-                        coef[f] = (f >= 6 && ((f - 6) % 3) == c) ? jc[f - 6] : 0.0f;
-                        one[f] = (f == c) ? 1.0f : 0.0f;
-                    }
-                    const float p1 = acc_dot_partial<2, 33>(s2, coef, h);
-                    const float p2 = acc_dot_partial<2, 33>(s2, one, h);
-                    dref[c] = p1 + xor32(p1);
-                    gdir[c] = p2 + xor32(p2);
-                }
-                // d n^_j = 2 s dref_j - 2 d_j (dref . n^);  n^ = n / |n|  ->  d n = (d n^ - n^ (n^ . d n^)) / |n|
-                const float dr_n = dref[0] * nh[0] + dref[1] * nh[1] + dref[2] * nh[2];
-                float dnh[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) dnh[c] = 2.0f * sdot * dref[c] - 2.0f * d[c] * dr_n;
-                const float proj = dnh[0] * nh[0] + dnh[1] * nh[1] + dnh[2] * nh[2];
-                const float eps = 1.1920928955078125e-07f;
-                const bool clamped = (nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]) < eps;   // torch.clamp: zero slope
-#pragma unroll
-                for (int c = 0; c < 3; ++c) dn[c] = gdir[c] + (clamped ? dnh[c] : dnh[c] - nh[c] * proj) * inv_len;
-            }
-            if (valid && lane < 32) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) d_normal[n * 3 + c] = dn[c];
-            }
-        }
+        side_grad_to_dnormal<VAR>(s2, n, nc, valid, lane, h, d_normal, normal, dirs, rays_d, m);
     }
 }
 
@@ -372,9 +382,269 @@ __global__ void __launch_bounds__(64, 1) refcolor_bwd_both_kernel(HeadArgs cd, H
         color_bwd_body<PREC, VAR_REF_SPECULAR>(scr, vd.blob, N, vd.d_out, vd.fwd_out, vd.st, vd.out, vd.d_normal, normal, dirs, rays_d, m);
 }
 
+
+// ---- tensor-parallel form (see tp_engine.h): 4 waves share a 32-sample tile, wave w owns output tiles 2w, 2w+1 ----------
+// Same maths, stash layouts and results as the one-wave bodies above.  A wave needs < 256 registers, so two workgroups
+// share a CU and one's barrier / store phases overlap the other's MFMAs; the 32-tile launches of the RefColor heads
+// (latency-bound: a launch lasts as long as one tile's chain) get a chain that is four times shorter.
+constexpr int kColTpFrag = 19 * 2 * kFragBytes;          // layer 0 has 19 k-steps (hi, lo)
+constexpr int kColTpLds = kColTpFrag + kWaveScr;         // + the shared row image: 72 192 bytes, two workgroups per CU
+
+FN_DEV void tp_barrier_pair() {      // what a wave without a tile to publish does while the others run tp_exchange
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int PREC, int KS>
+FN_DEV void tp_write_frags(unsigned char* frag, int lane, int ks0, const BFrag<PREC> (&b)[kMaxKS], int src0) {
+    constexpr int NPL = PREC == 3 ? 2 : 1;
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+        *reinterpret_cast<bf16x8*>(frag + ((ks0 + i) * NPL) * kFragBytes + lane * 16) = b[src0 + i].hi;
+        if constexpr (PREC == 3) *reinterpret_cast<bf16x8*>(frag + ((ks0 + i) * NPL + 1) * kFragBytes + lane * 16) = b[src0 + i].lo;
+    }
+}
+
+// ReLU in place on this wave's 2 tiles; returns the 32 sign bits (word `wave` of the tile's 128-bit mask)
+FN_DEV uint32_t relu_mask2(f32x16 (&acc)[2]) {
+    uint32_t m = 0u;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool pos = acc[t][r] > 0.0f;
+            acc[t][r] = pos ? acc[t][r] : 0.0f;
+            m |= (pos ? 1u : 0u) << (t * 16 + r);
+        }
+    return m;
+}
+
+template <int PREC, bool TRAIN, int VAR>
+FN_DEV void color_fwd_tp_body(unsigned char* lds, const unsigned char* blob, const PointSrc& src, long N,
+                              const float* __restrict__ dirs, const float* __restrict__ normal,
+                              const float* __restrict__ feat, const ColStash& st, float* __restrict__ rgb_out) {
+    unsigned char* frag = lds;
+    unsigned char* img = lds + kColTpFrag;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int t0 = 2 * wave;
+    constexpr auto& LY = kColLayout;
+    for (long tile = blockIdx.x; tile * 32 < N; tile += gridDim.x) {
+        asm volatile("" : "+s"(blob));
+        const long n = tile * 32 + r;
+        const bool valid = n < N;
+        const long nc = valid ? n : N - 1;
+        const long n0 = tile * 32;
+        BFrag<PREC> bf[kMaxKS];
+        if (wave == 0) {        // the 33 side inputs: k-steps 16..18 of layer 0, published by wave 0
+            float side[33];
+            float x[3], d[3], nrm[3];
+            load_point(src, nc, x);
+            if (dirs) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) d[c] = dirs[nc * 3 + c];
+            } else {
+                const long ray = nc / src.m;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) d[c] = src.rays_d[ray * 3 + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) nrm[c] = normal[nc * 3 + c];
+            make_side<VAR>(x, d, nrm, side);
+            vec_to_bfrag<PREC, 33, 3, 16>(side, bf, h);
+            tp_write_frags<PREC, 3>(frag, lane, 16, bf, 16);
+            if constexpr (TRAIN) {
+                if (valid) {
+#pragma unroll
+                    for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+                        for (int g = 0; g < 2; ++g) {
+                            const int col = 16 * ks + 8 * g + 4 * h;
+                            bf16x4 vh, vl;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                vh[e] = bf[16 + ks].hi[4 * g + e];
+                                if constexpr (PREC == 3) vl[e] = bf[16 + ks].lo[4 * g + e];
+                            }
+                            *reinterpret_cast<bf16x4*>(st.side_hi + nc * 48 + col) = vh;
+                            if constexpr (PREC == 3) *reinterpret_cast<bf16x4*>(st.side_lo + nc * 48 + col) = vl;
+                        }
+                }
+            }
+        }
+        f32x16 acc[2];
+        // the 256 features: every wave brings its two tiles (k-steps 4w .. 4w+3 of layer 0)
+        load_f32<2>(acc, feat + 32 * t0, 256, nc, h);
+        constexpr bool FEAT_PLANE = TRAIN && VAR != VAR_COLOR;     // the surface head keeps its own copy of the features
+        tp_exchange<PREC, 2, true, FEAT_PLANE>(frag, img, lane, t0, acc);
+        tp_operands<PREC, 19>(frag, lane, bf);
+        if constexpr (FEAT_PLANE) tp_store_rows<PREC, 256>(img, lane, wave, st.feat_hi, st.feat_lo, n0, N);
+        // layer 0 (19 k-steps), layers 1..3
+#pragma unroll 1
+        for (int l = 0; l <= 3; ++l) {
+            asm volatile("" : "+s"(blob));
+            load_accvec<8, 0, 2>(blob, LY.L[l].bias, acc, lane, t0);
+            if (l == 0)
+                tp_dense<PREC, 19, 8, 0, 2>(blob, LY.L[0].fwd_hi, LY.L[0].fwd_lo, frag, bf, acc, lane, t0);
+            else
+                tp_dense<PREC, 16, 8, 0, 2>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, frag, bf, acc, lane, t0);
+            const uint32_t m = relu_mask2(acc);
+            if constexpr (TRAIN) reinterpret_cast<uint32_t*>(st.mask + ((size_t)tile * 4 + l) * 64 + lane)[wave] = m;
+            tp_exchange<PREC, 2, true, TRAIN>(frag, img, lane, t0, acc);
+            tp_operands<PREC, 16>(frag, lane, bf);
+            if constexpr (TRAIN)
+                tp_store_rows<PREC, 256>(img, lane, wave, st.u_hi + (size_t)l * N * 256, st.u_lo + (size_t)l * N * 256, n0, N);
+        }
+        if (wave == 0) {        // output layer: one tile, rows 0..2
+            f32x16 o[1];
+            load_accvec<1, 0, 1>(blob, LY.L[4].bias, o, lane);
+            tp_dense<PREC, 16, 1, 0, 1>(blob, LY.L[4].fwd_hi, LY.L[4].fwd_lo, frag, bf, o, lane);
+            if (valid && lane < 32) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) rgb_out[n * 3 + c] = 1.0f / (1.0f + expf(-o[0][c]));   // fields.py:173-174
+            }
+        }
+    }
+}
+
+template <int PREC, int VAR>
+FN_DEV void color_bwd_tp_body(unsigned char* lds, const unsigned char* blob, long N, const float* __restrict__ d_rgb,
+                              const float* __restrict__ rgb, const ColStash& st, float* __restrict__ d_feat,
+                              float* __restrict__ d_normal, const float* __restrict__ normal,
+                              const float* __restrict__ dirs, const float* __restrict__ rays_d, int m) {
+    unsigned char* frag = lds;
+    unsigned char* img = lds + kColTpFrag;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int t0 = 2 * wave;
+    constexpr auto& LY = kColLayout;
+    for (long tile = blockIdx.x; tile * 32 < N; tile += gridDim.x) {
+        asm volatile("" : "+s"(blob));
+        const long n = tile * 32 + r;
+        const bool valid = n < N;
+        const long nc = valid ? n : N - 1;
+        const long n0 = tile * 32;
+        BFrag<PREC> bf[kMaxKS];
+        // every wave is done with the previous tile's row image before wave 0 reuses it as its scratch
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // zbar_4 = d rgb * sigmoid' (3 rows of one tile): wave 0 writes its stash rows through the image (the others wait
+        // at the first barrier of the exchange below) and publishes k-steps 0, 1
+        if (wave == 0) {
+            f32x16 z[1];
+            zero_acc(z);
+            if (h == 0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float y = rgb[nc * 3 + c];
+                    z[0][c] = valid ? d_rgb[nc * 3 + c] * y * (1.0f - y) : 0.0f;
+                }
+            }
+            store_stash<PREC, 1>(img, lane, z, st.zbar_hi + (size_t)4 * N * 256, st.zbar_lo + (size_t)4 * N * 256, 32, n0, N, 32);
+            tp_exchange<PREC, 1, true, false>(frag, img, lane, 0, z);
+        } else {
+            tp_barrier_pair();
+        }
+        tp_operands<PREC, 2>(frag, lane, bf);
+        f32x16 acc[2];
+        zero_acc(acc);
+        tp_dense<PREC, 2, 8, 0, 2>(blob, LY.L[4].rev_hi, LY.L[4].rev_lo, frag, bf, acc, lane, t0);
+#pragma unroll 1
+        for (int l = 3; l >= 0; --l) {
+            asm volatile("" : "+s"(blob));
+            const uint32_t msk = reinterpret_cast<const uint32_t*>(st.mask + ((size_t)tile * 4 + l) * 64 + lane)[wave];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) {
+                    const bool pos = (msk >> (t * 16 + rr)) & 1u;
+                    acc[t][rr] = (pos && valid) ? acc[t][rr] : 0.0f;
+                }
+            tp_exchange<PREC, 2, true, true>(frag, img, lane, t0, acc);
+            tp_operands<PREC, 16>(frag, lane, bf);
+            tp_store_rows<PREC, 256>(img, lane, wave, st.zbar_hi + (size_t)l * N * 256, st.zbar_lo + (size_t)l * N * 256, n0, N);
+            if (l > 0) {
+                zero_acc(acc);
+                tp_dense<PREC, 16, 8, 0, 2>(blob, LY.L[l].rev_hi, LY.L[l].rev_lo, frag, bf, acc, lane, t0);
+            }
+        }
+        // layer 0 reverse: 10 row tiles -- the 8 feature tiles (two per wave) and the 2 side tiles (wave 0)
+        zero_acc(acc);
+        tp_dense<PREC, 16, 10, 0, 2>(blob, LY.L[0].rev_hi, LY.L[0].rev_lo, frag, bf, acc, lane, t0);
+        store_f32<2>(acc, d_feat + 32 * t0, 256, nc, h, valid);
+        if (wave == 0) {
+            f32x16 s2[2];
+            zero_acc(s2);
+            tp_dense<PREC, 16, 10, 8, 2>(blob, LY.L[0].rev_hi, LY.L[0].rev_lo, frag, bf, s2, lane);
+            side_grad_to_dnormal<VAR>(s2, n, nc, valid, lane, h, d_normal, normal, dirs, rays_d, m);
+        }
+    }
+}
+
+template <int PREC, bool TRAIN, int VAR>
+__global__ void __launch_bounds__(256, 2) color_fwd_tp_kernel(const unsigned char* blob, PointSrc src, long N,
+                                                              const float* __restrict__ dirs, const float* __restrict__ normal,
+                                                              const float* __restrict__ feat, ColStash st,
+                                                              float* __restrict__ rgb_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
+    color_fwd_tp_body<PREC, TRAIN, VAR>(lds_, blob, src, N, dirs, normal, feat, st, rgb_out);
+}
+
+template <int PREC, bool TRAIN>
+__global__ void __launch_bounds__(256, 2) refcolor_fwd_both_tp_kernel(HeadArgs cd, HeadArgs vd, PointSrc src, long N,
+                                                                      const float* __restrict__ dirs,
+                                                                      const float* __restrict__ normal,
+                                                                      const float* __restrict__ feat) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
+    if (blockIdx.y == 0)
+        color_fwd_tp_body<PREC, TRAIN, VAR_REF_DIFFUSE>(lds_, cd.blob, src, N, dirs, normal, feat, cd.st, cd.out);
+    else
+        color_fwd_tp_body<PREC, TRAIN, VAR_REF_SPECULAR>(lds_, vd.blob, src, N, dirs, normal, feat, vd.st, vd.out);
+}
+
+template <int PREC, int VAR>
+__global__ void __launch_bounds__(256, 2) color_bwd_tp_kernel(const unsigned char* blob, long N, const float* __restrict__ d_rgb,
+                                                              const float* __restrict__ rgb, ColStash st,
+                                                              float* __restrict__ d_feat, float* __restrict__ d_normal,
+                                                              const float* __restrict__ normal, const float* __restrict__ dirs,
+                                                              const float* __restrict__ rays_d, int m) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
+    color_bwd_tp_body<PREC, VAR>(lds_, blob, N, d_rgb, rgb, st, d_feat, d_normal, normal, dirs, rays_d, m);
+}
+
+template <int PREC>
+__global__ void __launch_bounds__(256, 2) refcolor_bwd_both_tp_kernel(HeadArgs cd, HeadArgs vd, long N,
+                                                                      const float* __restrict__ normal,
+                                                                      const float* __restrict__ dirs,
+                                                                      const float* __restrict__ rays_d, int m) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
+    if (blockIdx.y == 0)
+        color_bwd_tp_body<PREC, VAR_REF_DIFFUSE>(lds_, cd.blob, N, cd.d_out, cd.fwd_out, cd.st, cd.out, cd.d_normal, normal, dirs, rays_d, m);
+    else
+        color_bwd_tp_body<PREC, VAR_REF_SPECULAR>(lds_, vd.blob, N, vd.d_out, vd.fwd_out, vd.st, vd.out, vd.d_normal, normal, dirs, rays_d, m);
+}
+
 }  // namespace fneus
 
 using namespace fneus;
+
+// tensor-parallel workgroups by default (FNEUS_COL_TP=0: one wave per tile, kept for comparison)
+static inline bool col_tp() {
+    static const int mode = getenv("FNEUS_COL_TP") ? atoi(getenv("FNEUS_COL_TP")) : 1;
+    return mode != 0;
+}
+static inline unsigned tp_grid(long n_tiles) {
+    const long cap = 256 * 2 * 4;
+    return (unsigned)(n_tiles < 1 ? 1 : (n_tiles < cap ? n_tiles : cap));
+}
+#define FNEUS_TP_LAUNCH(KERNEL, GRID, ...)                                                                            \
+    do {                                                                                                              \
+        static bool attr_done = false;                                                                                \
+        if (!attr_done) {                                                                                             \
+            fneus::allow_big_lds(KERNEL);                                                                             \
+            attr_done = true;                                                                                         \
+        }                                                                                                             \
+        hipLaunchKernelGGL((KERNEL), GRID, dim3(256), fneus::kColTpLds, stream, __VA_ARGS__);                         \
+    } while (0)
 
 static inline int grid_for(long n_tiles) {
     long g = n_tiles;
@@ -398,6 +668,15 @@ static int launch_fwd(const void* blob, const float* pts, const float* rays_o, c
     const unsigned char* b = reinterpret_cast<const unsigned char*>(blob);
     ColStash st = stash ? ColStash(*stash) : ColStash();
     if (train && VAR != VAR_COLOR && !st.feat_hi) return -2;
+    if (col_tp()) {
+        dim3 g2(tp_grid((n_pts + 31) / 32));
+        if (prec == 3 && train) FNEUS_TP_LAUNCH((color_fwd_tp_kernel<3, true, VAR>), g2, b, src, n_pts, dirs, normal, feat, st, out);
+        else if (prec == 3) FNEUS_TP_LAUNCH((color_fwd_tp_kernel<3, false, VAR>), g2, b, src, n_pts, dirs, normal, feat, st, out);
+        else if (prec == 1 && train) FNEUS_TP_LAUNCH((color_fwd_tp_kernel<1, true, VAR>), g2, b, src, n_pts, dirs, normal, feat, st, out);
+        else if (prec == 1) FNEUS_TP_LAUNCH((color_fwd_tp_kernel<1, false, VAR>), g2, b, src, n_pts, dirs, normal, feat, st, out);
+        else return -2;
+        return fneus::launch_status();
+    }
     dim3 grid(grid_for((n_pts + 31) / 32)), blk(64);
     if (prec == 3 && train)
         hipLaunchKernelGGL((color_fwd_kernel<3, true, VAR>), grid, blk, 0, stream, b, src, n_pts, dirs, normal, feat, st, out);
@@ -423,6 +702,14 @@ static int launch_bwd(const void* blob, long n_pts, const float* d_out, const fl
     if (VAR != VAR_COLOR && (!normal || (!dirs && !rays_d))) return -2;
     const unsigned char* b = reinterpret_cast<const unsigned char*>(blob);
     ColStash st(*stash);
+    if (col_tp()) {
+        dim3 g2(tp_grid((n_pts + 31) / 32));
+        const int mm = m > 0 ? m : 1;
+        if (prec == 3) FNEUS_TP_LAUNCH((color_bwd_tp_kernel<3, VAR>), g2, b, n_pts, d_out, out, st, d_feat, d_normal, normal, dirs, rays_d, mm);
+        else if (prec == 1) FNEUS_TP_LAUNCH((color_bwd_tp_kernel<1, VAR>), g2, b, n_pts, d_out, out, st, d_feat, d_normal, normal, dirs, rays_d, mm);
+        else return -2;
+        return fneus::launch_status();
+    }
     dim3 grid(grid_for((n_pts + 31) / 32)), blk(64);
     if (prec == 3)
         hipLaunchKernelGGL((color_bwd_kernel<3, VAR>), grid, blk, 0, stream, b, n_pts, d_out, out, st, d_feat, d_normal,
@@ -486,6 +773,15 @@ extern "C" int fneus_refcolor_fwd_both(const void* blob_cd, const void* blob_vd,
     HeadArgs vd{reinterpret_cast<const unsigned char*>(blob_vd), stash_vd ? ColStash(*stash_vd) : ColStash(), spec_out,
                 nullptr, nullptr, nullptr};
     if (train && (!cd.st.feat_hi || !vd.st.feat_hi)) return -2;
+    if (col_tp()) {
+        dim3 g2(tp_grid((n_pts + 31) / 32), 2);
+        if (prec == 3 && train) FNEUS_TP_LAUNCH((refcolor_fwd_both_tp_kernel<3, true>), g2, cd, vd, src, n_pts, dirs, normal, feat);
+        else if (prec == 3) FNEUS_TP_LAUNCH((refcolor_fwd_both_tp_kernel<3, false>), g2, cd, vd, src, n_pts, dirs, normal, feat);
+        else if (prec == 1 && train) FNEUS_TP_LAUNCH((refcolor_fwd_both_tp_kernel<1, true>), g2, cd, vd, src, n_pts, dirs, normal, feat);
+        else if (prec == 1) FNEUS_TP_LAUNCH((refcolor_fwd_both_tp_kernel<1, false>), g2, cd, vd, src, n_pts, dirs, normal, feat);
+        else return -2;
+        return fneus::launch_status();
+    }
     dim3 grid(grid_for((n_pts + 31) / 32), 2), blk(64);
     if (prec == 3 && train)
         hipLaunchKernelGGL((refcolor_fwd_both_kernel<3, true>), grid, blk, 0, stream, cd, vd, src, n_pts, dirs, normal, feat);
@@ -512,6 +808,14 @@ extern "C" int fneus_refcolor_bwd_both(const void* blob_cd, const void* blob_vd,
     HeadArgs cd{reinterpret_cast<const unsigned char*>(blob_cd), ColStash(*stash_cd), d_feat2, d_diffuse, diffuse, d_normal2};
     HeadArgs vd{reinterpret_cast<const unsigned char*>(blob_vd), ColStash(*stash_vd), d_feat2 + n_pts * 256, d_spec, spec,
                 d_normal2 + n_pts * 3};
+    if (col_tp()) {
+        dim3 g2(tp_grid((n_pts + 31) / 32), 2);
+        const int mm = m > 0 ? m : 1;
+        if (prec == 3) FNEUS_TP_LAUNCH((refcolor_bwd_both_tp_kernel<3>), g2, cd, vd, n_pts, normal, dirs, rays_d, mm);
+        else if (prec == 1) FNEUS_TP_LAUNCH((refcolor_bwd_both_tp_kernel<1>), g2, cd, vd, n_pts, normal, dirs, rays_d, mm);
+        else return -2;
+        return fneus::launch_status();
+    }
     dim3 grid(grid_for((n_pts + 31) / 32), 2), blk(64);
     if (prec == 3)
         hipLaunchKernelGGL(refcolor_bwd_both_kernel<3>, grid, blk, 0, stream, cd, vd, n_pts, normal, dirs, rays_d, m > 0 ? m : 1);

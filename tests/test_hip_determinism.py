@@ -50,3 +50,31 @@ def test_sdf_fwd_grad_and_bwd_are_reproducible():
     for _ in range(12):
         for a, b, name in zip(run(), ref, ("sdf", "feat", "normal", "h", "a", "adj", "zbar")):
             assert torch.equal(a, b), name
+
+
+@pytest.mark.parametrize("prec", [3, 1])
+def test_color_forward_backward_are_reproducible(prec):
+    """K4 in its tensor-parallel form reads its B operands from LDS like K2: same guard"""
+    from fneus import ops, synth
+    dev = torch.device("cuda:0")
+    n = 65536
+    cnet = ops.PackedNet("color", dev).load_state_dict({k: torch.from_numpy(v) for k, v in synth.color_state_dict(21).items()})
+    cnet.pack()
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = (torch.rand(n, 3, device=dev, generator=g) * 2 - 1).contiguous()
+    d = torch.nn.functional.normalize(torch.randn(n, 3, device=dev, generator=g), dim=-1).contiguous()
+    nrm = torch.randn(n, 3, device=dev, generator=g)
+    feat = (torch.randn(n, 256, device=dev, generator=g) * 0.3).contiguous()
+    c = torch.randn(n, 3, device=dev, generator=g)
+    st = ops.ColStash(n, dev, prec)
+
+    def run():
+        rgb = ops.color_fwd(cnet.blob, n, prec, nrm, feat, st, True, pts=x, dirs=d)
+        d_feat, d_normal = ops.color_bwd(cnet.blob, n, prec, c, rgb, st)
+        torch.cuda.synchronize()
+        return [t.clone() for t in (rgb, d_feat, d_normal, st.u.view(torch.int16), st.zbar.view(torch.int16), st.mask)]
+
+    ref = run()
+    for _ in range(25):
+        for a, b, name in zip(run(), ref, ("rgb", "d_feat", "d_normal", "u", "zbar", "mask")):
+            assert torch.equal(a, b), name
