@@ -8,6 +8,7 @@
 //
 // One workgroup = 512 threads = 2x4 waves, output tile 256x256 (wave: 128x64 = 4x2 MFMA 32x32x16 tiles), 32-sample
 // LDS blocks double buffered (147 KiB in parity mode).
+#include <stdlib.h>
 #include "fneus_common.h"
 #include "fneus_kernels.h"
 
@@ -258,6 +259,11 @@ extern "C" int fneus_dw_gemm(const void* jobs_dev, int n_jobs, int n_tiles, long
     if (n_tiles <= 0 || n_samples <= 0) return 0;
     // split-K so that the grid holds ~256 workgroups (one 147 KiB workgroup per CU in parity mode)
     int split = 256 / n_tiles;
+    // ... but a workgroup should own at least FNEUS_GEMM_MIN_BLOCKS blocks: its epilogue is 65 536 atomics whatever it summed
+    // (the RefColor launch has 1024 samples; default measured in tools/experiments/README.md)
+    static const int min_blocks = getenv("FNEUS_GEMM_MIN_BLOCKS") ? atoi(getenv("FNEUS_GEMM_MIN_BLOCKS")) : 4;   // RefColor launch: 50 us at 1 / 2, 38 us at 4, 41 us at 8, 60 us at 16
+    const long max_split = n_samples / ((long)KB * min_blocks);
+    if (split > max_split) split = (int)max_split;
     if (split < 1) split = 1;
     long kchunk = (n_samples + split - 1) / split;
     kchunk = ((kchunk + KB - 1) / KB) * KB;
