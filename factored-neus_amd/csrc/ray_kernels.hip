@@ -577,6 +577,31 @@ extern "C" int fneus_composite_bwd(const float* rays_o, const float* rays_d, con
     return fneus::launch_status();
 }
 
+// [B][10] batch rows (rays_o 3, rays_d 3, rgb 3, mask 1: dataset.py:133-151) -> four contiguous arrays, one launch
+__global__ void __launch_bounds__(256) split_batch_kernel(const float* __restrict__ data, int n_rays, float* __restrict__ rays_o,
+                                                          float* __restrict__ rays_d, float* __restrict__ rgb,
+                                                          float* __restrict__ mask) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_rays * 10) return;
+    const int ray = i / 10, c = i - ray * 10;
+    const float v = data[i];
+    if (c < 3) rays_o[ray * 3 + c] = v;
+    else if (c < 6) rays_d[ray * 3 + c - 3] = v;
+    else if (c < 9) rgb[ray * 3 + c - 6] = v;
+    else mask[ray] = v;
+}
+
+extern "C" int fneus_split_batch(const float* data, int n_rays, float* rays_o, float* rays_d, float* rgb, float* mask,
+                                 fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (n_rays <= 0) return 0;
+    if (!data || !rays_o || !rays_d || !rgb || !mask) return -2;
+    hipLaunchKernelGGL(split_batch_kernel, dim3((unsigned)((n_rays * 10 + 255) / 256)), dim3(256), 0, stream, data, n_rays,
+                       rays_o, rays_d, rgb, mask);
+    return fneus::launch_status();
+}
+
 extern "C" int fneus_ray_setup(const float* rays_o, const float* rays_d, const float* near, const float* far,
                                const float* t_rand, int n_rays, int n_samples, float* z_vals, fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;

@@ -234,6 +234,7 @@ class SurfaceGatherFn(torch.autograd.Function):
         ctx.sdf_ws = sdf_ws
         ctx.save_for_backward(sel)
         ctx.mark_non_differentiable(t_sel, sel)
+        ctx.set_materialize_grads(False)         # no zero-filled cotangents for the two index outputs
         return feat_sel, normal_sel, t_sel, sel
 
     @staticmethod
@@ -262,9 +263,12 @@ class Stage1LossFn(torch.autograd.Function):
         ctx.save_for_backward(o["d_color"], o["d_wsum"], o["d_eiknum"], o["d_wpair"], o["d_diffuse"], o["d_spec"])
         aux = (o["losses"], o["surface_color"], o["specular_color"], o["diffuse_color"])
         ctx.mark_non_differentiable(*aux)
+        ctx.set_materialize_grads(False)         # no zero-filled cotangents for the four report-only outputs
         return (o["losses"][0].clone(),) + aux
 
     @staticmethod
     def backward(ctx, g, *unused):
+        if g is None:
+            return (None,) * 14
         grads = torch._foreach_mul(list(ctx.saved_tensors), g)
         return tuple(grads) + (None,) * 8

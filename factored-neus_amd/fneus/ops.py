@@ -588,6 +588,16 @@ def merge(z_old, s_old, z_new, s_new):
     return z_out, s_out
 
 
+def split_batch(data: torch.Tensor):
+    """[B,10] batch -> contiguous rays_o [B,3], rays_d [B,3], rgb [B,3], mask [B,1] in one launch"""
+    _chk_f32(data, "data")
+    B = data.shape[0]
+    f32 = dict(dtype=torch.float32, device=data.device)
+    o, d, rgb, mask = torch.empty(B, 3, **f32), torch.empty(B, 3, **f32), torch.empty(B, 3, **f32), torch.empty(B, 1, **f32)
+    _launch("fneus_split_batch", lib.fneus_split_batch, _ptr(data), B, _ptr(o), _ptr(d), _ptr(rgb), _ptr(mask), _stream())
+    return o, d, rgb, mask
+
+
 def ray_setup(rays_o, rays_d, n_samples: int, near=None, far=None, t_rand=None):
     """coarse depths z_vals [B, n_samples]; near / far None -> unit-sphere bounds computed from the rays"""
     B = rays_o.shape[0]

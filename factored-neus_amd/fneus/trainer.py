@@ -213,7 +213,10 @@ class Stage1Trainer:
         return losses
 
     def _step_body(self, data, cos_anneal_ratio, background_rgb, with_optimizer: bool):
-        rays_o, rays_d, true_rgb, mask = data[:, :3], data[:, 3:6], data[:, 6:9], data[:, 9:10]
+        if data.is_cuda and data.dtype == torch.float32 and data.is_contiguous() and data.shape[1] == 10:
+            rays_o, rays_d, true_rgb, mask = ops.split_batch(data)          # one launch instead of four strided copies
+        else:
+            rays_o, rays_d, true_rgb, mask = data[:, :3], data[:, 3:6], data[:, 6:9], data[:, 9:10]
         ops.overlap_begin(self.device)       # window for side-stream work (fneus/ops.py); joined below, before Adam
         # near / far = None: near_far_from_sphere (dataset.py:186-192) is evaluated inside render's ray set-up launch
         # the losses of exp_runner.py:141-177 are evaluated inside render (fused with the surface shading and their own

@@ -218,6 +218,11 @@ int fneus_upsample(const float* rays_o, const float* rays_d, const float* z, con
 /* cat_z_vals (renderer.py:191-205): stable sort-merge of (z_old | z_new); s_old/s_new/s_out may be NULL (last step) */
 int fneus_merge(const float* z_old, const float* s_old, int m, const float* z_new, const float* s_new, int k, int n_rays,
                 float* z_out, float* s_out, fneus_stream_t stream);
+/* One training batch [B][10] = rays_o, rays_d, rgb, mask per row (what Dataset.gen_random_rays_at returns, dataset.py:133-151)
+ * -> the four contiguous arrays the kernels take (exp_runner.py:134-139 slices the same columns). */
+int fneus_split_batch(const float* data /*[B][10]*/, int n_rays, float* rays_o /*[B][3]*/, float* rays_d /*[B][3]*/,
+                      float* rgb /*[B][3]*/, float* mask /*[B]*/, fneus_stream_t stream);
+
 /* Coarse depths: z_vals [B][n_samples] = near + (far - near) * linspace(0, 1, n_samples) (renderer.py:393-395), plus the
  * per-ray jitter (t_rand[b] - 0.5) * 2 / n_samples when t_rand [B] (uniform in [0,1)) is given (renderer.py:405-409).
  * near / far [B] as passed to NeuSRenderer.render, or both NULL: the unit-sphere bounds of dataset.py:186-192
