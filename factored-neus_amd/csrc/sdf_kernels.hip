@@ -185,10 +185,13 @@ constexpr int kTpLds = 17 * 2 * kFragBytes;      // up to 17 k-steps x (hi, lo) 
 #define FNEUS_TP_MAX_TILES 256
 #endif
 
-template <int PREC>
-__global__ void __launch_bounds__(256, FNEUS_TP_WAVES) sdf_fwd_tp_kernel(const unsigned char* blob, PointSrc src, long N,
-                                                            float* __restrict__ sdf_out) {
+// WAVES = 4: wave w owns output tiles 2w, 2w+1;  WAVES = 8: wave w owns tile w (half the MFMAs and the activation work
+// per wave again, the same two barriers per layer)
+template <int PREC, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES, 1) sdf_fwd_tp_kernel(const unsigned char* blob, PointSrc src, long N,
+                                                                    float* __restrict__ sdf_out) {
     __shared__ __attribute__((aligned(16))) unsigned char frag[kTpLds];
+    constexpr int TN = 8 / WAVES;                    // output tiles per wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     constexpr auto& LY = kSdfLayout;
@@ -204,48 +207,51 @@ __global__ void __launch_bounds__(256, FNEUS_TP_WAVES) sdf_fwd_tp_kernel(const u
         vec_to_bfrag<PREC, 39, 3, 0>(pe, bf, h);       // every wave encodes the (same) 32 points itself
 #pragma unroll
         for (int i = 0; i < 3; ++i) pef[i] = bf[i];
-        f32x16 acc[2];
+        f32x16 acc[TN];
         f32x16(&a1)[1] = reinterpret_cast<f32x16(&)[1]>(acc);
-        const int t0 = 2 * wave;
+        const int t0 = TN * wave;
         // layer 0
-        load_accvec<8, 0, 2>(blob, LY.L[0].bias, acc, lane, t0);
-        dense<PREC, 3, 8, 0, 2>(blob, LY.L[0].fwd_hi, LY.L[0].fwd_lo, bf, acc, lane, t0);
+        load_accvec<8, 0, TN>(blob, LY.L[0].bias, acc, lane, t0);
+        dense<PREC, 3, 8, 0, TN>(blob, LY.L[0].fwd_hi, LY.L[0].fwd_lo, bf, acc, lane, t0);
         softplus_inplace(acc);
-        tp_publish<PREC, 2>(frag, lane, t0, acc);
+        tp_publish<PREC, TN>(frag, lane, t0, acc);
         tp_gather<PREC, 16>(frag, lane, bf);
         for (int l = 1; l <= 2; ++l) {
-            load_accvec<8, 0, 2>(blob, LY.L[l].bias, acc, lane, t0);
-            dense<PREC, 16, 8, 0, 2>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, bf, acc, lane, t0);
+            load_accvec<8, 0, TN>(blob, LY.L[l].bias, acc, lane, t0);
+            dense<PREC, 16, 8, 0, TN>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, bf, acc, lane, t0);
             softplus_inplace(acc);
-            tp_publish<PREC, 2>(frag, lane, t0, acc);
+            tp_publish<PREC, TN>(frag, lane, t0, acc);
             tp_gather<PREC, 16>(frag, lane, bf);
         }
-        // layer 3: 7 output tiles (217 features): wave 3 owns only tile 6
-        if (wave < 3) {
-            load_accvec<7, 0, 2>(blob, LY.L[3].bias, acc, lane, t0);
-            dense<PREC, 16, 7, 0, 2>(blob, LY.L[3].fwd_hi, LY.L[3].fwd_lo, bf, acc, lane, t0);
+        // layer 3: 7 output tiles (217 features): the last tile slot is empty
+        if (t0 + TN <= 7) {
+            load_accvec<7, 0, TN>(blob, LY.L[3].bias, acc, lane, t0);
+            dense<PREC, 16, 7, 0, TN>(blob, LY.L[3].fwd_hi, LY.L[3].fwd_lo, bf, acc, lane, t0);
             softplus_inplace(acc);
-            tp_publish<PREC, 2>(frag, lane, t0, acc);
-        } else {
+            tp_publish<PREC, TN>(frag, lane, t0, acc);
+        } else if (t0 < 7) {          // (WAVES = 4, wave 3: tile 6 only)
             load_accvec<7, 0, 1>(blob, LY.L[3].bias, a1, lane, t0);
             dense<PREC, 16, 7, 0, 1>(blob, LY.L[3].fwd_hi, LY.L[3].fwd_lo, bf, a1, lane, t0);
             softplus_inplace(a1);
             tp_publish<PREC, 1>(frag, lane, t0, a1);
+        } else {                      // (WAVES = 8, wave 7: nothing to publish, keep the barrier count)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         tp_gather<PREC, 14>(frag, lane, bf);
 #pragma unroll
         for (int i = 0; i < 3; ++i) bf[14 + i] = pef[i];      // skip connection (fields.py:83-84)
         // layer 4 (17 k-steps)
-        load_accvec<8, 0, 2>(blob, LY.L[4].bias, acc, lane, t0);
-        dense<PREC, 17, 8, 0, 2>(blob, LY.L[4].fwd_hi, LY.L[4].fwd_lo, bf, acc, lane, t0);
+        load_accvec<8, 0, TN>(blob, LY.L[4].bias, acc, lane, t0);
+        dense<PREC, 17, 8, 0, TN>(blob, LY.L[4].fwd_hi, LY.L[4].fwd_lo, bf, acc, lane, t0);
         softplus_inplace(acc);
-        tp_publish<PREC, 2>(frag, lane, t0, acc);
+        tp_publish<PREC, TN>(frag, lane, t0, acc);
         tp_gather<PREC, 16>(frag, lane, bf);
         for (int l = 5; l <= 7; ++l) {
-            load_accvec<8, 0, 2>(blob, LY.L[l].bias, acc, lane, t0);
-            dense<PREC, 16, 8, 0, 2>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, bf, acc, lane, t0);
+            load_accvec<8, 0, TN>(blob, LY.L[l].bias, acc, lane, t0);
+            dense<PREC, 16, 8, 0, TN>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, bf, acc, lane, t0);
             softplus_inplace(acc);
-            tp_publish<PREC, 2>(frag, lane, t0, acc);
+            tp_publish<PREC, TN>(frag, lane, t0, acc);
             tp_gather<PREC, 16>(frag, lane, bf);
         }
         // layer 8: only the sdf row (tile 8 of 9) is needed; wave 0 computes it
@@ -791,10 +797,13 @@ extern "C" int fneus_sdf_fwd(const void* blob, const float* pts, const float* ra
     // up to one workgroup per CU: 4 waves share a tile (latency-bound launches); beyond that one wave per tile
     static const bool no_tp = getenv("FNEUS_K1_NO_TP") != nullptr;
     const bool tp = tiles <= FNEUS_TP_MAX_TILES && !no_tp;
+    static const bool tp8 = getenv("FNEUS_K1_TP_WAVES") ? atoi(getenv("FNEUS_K1_TP_WAVES")) == 8 : false;
     if (prec == 3 && tp)
-        hipLaunchKernelGGL(sdf_fwd_tp_kernel<3>, dim3((unsigned)(tiles < 512 ? tiles : 512)), dim3(256), 0, stream, b, src, n_pts, sdf_out);
+        if (tp8) hipLaunchKernelGGL((sdf_fwd_tp_kernel<3, 8>), dim3((unsigned)(tiles < 512 ? tiles : 512)), dim3(512), 0, stream, b, src, n_pts, sdf_out);
+        else hipLaunchKernelGGL((sdf_fwd_tp_kernel<3, 4>), dim3((unsigned)(tiles < 512 ? tiles : 512)), dim3(256), 0, stream, b, src, n_pts, sdf_out);
     else if (prec == 1 && tp)
-        hipLaunchKernelGGL(sdf_fwd_tp_kernel<1>, dim3((unsigned)(tiles < 512 ? tiles : 512)), dim3(256), 0, stream, b, src, n_pts, sdf_out);
+        if (tp8) hipLaunchKernelGGL((sdf_fwd_tp_kernel<1, 8>), dim3((unsigned)(tiles < 512 ? tiles : 512)), dim3(512), 0, stream, b, src, n_pts, sdf_out);
+        else hipLaunchKernelGGL((sdf_fwd_tp_kernel<1, 4>), dim3((unsigned)(tiles < 512 ? tiles : 512)), dim3(256), 0, stream, b, src, n_pts, sdf_out);
     else if (prec == 3)
         hipLaunchKernelGGL(sdf_fwd_kernel<3>, dim3(grid_for(tiles)), dim3(64), 0, stream, b, src, n_pts, sdf_out);
     else if (prec == 1)
