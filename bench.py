@@ -119,7 +119,7 @@ def cpu_baseline(budget_s: float = 12.0, device=None):
 
 
 # newest first: the PMC passes are re-collected whenever a kernel's memory behaviour changes (tools/collect_profiles.sh)
-TRAFFIC_FILES = ("r01_f_traffic.json", "r01_e_traffic.json", "r01_d_traffic.json", "r01_c_traffic.json")
+TRAFFIC_FILES = ("r01_g_traffic.json", "r01_f_traffic.json", "r01_e_traffic.json", "r01_d_traffic.json", "r01_c_traffic.json")
 
 
 def main():
