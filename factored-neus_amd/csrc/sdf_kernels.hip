@@ -829,7 +829,10 @@ extern "C" int fneus_sdf_fwd_grad(const void* blob, const float* pts, const floa
     // interleave with their neighbours' traffic), inference 620 vs 650 us; bf16 mode 405 vs 565 us.
     static const int tp_mode = getenv("FNEUS_K2_TP") ? atoi(getenv("FNEUS_K2_TP")) : 1;
     if (tp_mode) {
-        const long cap = 256 * 2 * 4;
+#ifndef FNEUS_K2_GRID_CAP
+#define FNEUS_K2_GRID_CAP (256 * 2 * 4)
+#endif
+        const long cap = FNEUS_K2_GRID_CAP;
         dim3 g2((unsigned)(tiles < cap ? tiles : cap)), b2(256);
 #define FNEUS_K2TP(P, T)                                                                                              \
     do {                                                                                                              \
