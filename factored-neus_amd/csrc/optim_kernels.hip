@@ -9,7 +9,7 @@
 namespace fneus {
 
 constexpr int kAdamMaxSegs = 32;         // per launch (kernel-argument space); longer tables take several launches
-constexpr int kAdamChunk = 1024 * 4;      // values per workgroup iteration
+constexpr int kAdamChunk = 1024;          // values per workgroup iteration: 4 per thread, their loads issued together
 
 struct AdamSegs {
     float* p[kAdamMaxSegs];
@@ -29,10 +29,15 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamSegs s, const float* __re
     // hyper-parameters are doubles on the host side of torch.optim.Adam: 1 - beta is rounded once, from the double
     const float beta1 = (float)beta1d, beta2 = (float)beta2d;
     const float omb1 = (float)(1.0 - beta1d), omb2 = (float)(1.0 - beta2d);
-    const double t = (double)*step_ptr;
+    __shared__ float bc[2];
+    if (threadIdx.x == 0) {          // the two double-precision pow() once per workgroup, not per thread
+        const double t = (double)*step_ptr;
+        bc[0] = (float)(1.0 - pow(beta1d, t));
+        bc[1] = (float)(1.0 - pow(beta2d, t));
+    }
+    __syncthreads();
     const float lr = *lr_ptr;
-    const float bc1 = (float)(1.0 - pow(beta1d, t)), bc2 = (float)(1.0 - pow(beta2d, t));
-    const float step_size = lr / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
+    const float step_size = lr / bc[0], inv_sqrt_bc2 = 1.0f / sqrtf(bc[1]);
     const long n_chunks = s.first_chunk[s.n];
     for (long chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         int seg = 0;
@@ -44,14 +49,28 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamSegs s, const float* __re
         float* __restrict__ v = s.v[seg] + base;
         const long left = s.count[seg] - base;
         const int cnt = left < kAdamChunk ? (int)left : kAdamChunk;
-        for (int i = threadIdx.x; i < cnt; i += 256) {
-            const float gi = g[i];
-            const float mi = beta1 * m[i] + omb1 * gi;
-            const float vi = beta2 * v[i] + omb2 * gi * gi;
-            m[i] = mi;
-            v[i] = vi;
-            p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
-            if (zero_grad) g[i] = 0.0f;
+        // (the 16 loads of a thread are independent: one memory latency per chunk instead of four)
+        float gi[4], mi[4], vi[4], pi[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            const bool ok = i < cnt;
+            gi[k] = ok ? g[i] : 0.0f;
+            mi[k] = ok ? m[i] : 0.0f;
+            vi[k] = ok ? v[i] : 0.0f;
+            pi[k] = ok ? p[i] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            if (i < cnt) {
+                const float mn = beta1 * mi[k] + omb1 * gi[k];
+                const float vn = beta2 * vi[k] + omb2 * gi[k] * gi[k];
+                m[i] = mn;
+                v[i] = vn;
+                p[i] = pi[k] - step_size * mn / (sqrtf(vn) * inv_sqrt_bc2 + eps);
+                if (zero_grad) g[i] = 0.0f;
+            }
         }
     }
 }
@@ -82,7 +101,7 @@ extern "C" int fneus_adam(const FneusAdamSegment* segs /*host array*/, int n_seg
         }
         s.first_chunk[s.n] = chunks;
         if (chunks == 0) continue;
-        const long grid = chunks < 2048 ? chunks : 2048;
+        const long grid = chunks < 4096 ? chunks : 4096;
         hipLaunchKernelGGL(adam_kernel, dim3((unsigned)grid), dim3(256), 0, stream, s, lr, step, beta1, beta2, (float)eps, zero_grad);
     }
     return fneus::launch_status();
