@@ -132,7 +132,9 @@ class Runner:
 
     # ---- validation ----
     def validate_image(self, idx=-1, resolution_level=-1):
-        """render one camera in batch_size chunks (exp_runner.py:374-486) -> PNG via PIL (BGR like the reference)"""
+        """render one camera chunk by chunk (exp_runner.py:374-486) -> PNG via PIL (BGR like the reference).  The chunks are
+        4096 rays (or batch_size if larger) and stay on the device until the image is complete: rays are independent, so
+        the chunk size changes nothing but the number of launches and host synchronisations."""
         from PIL import Image
         if idx < 0:
             idx = np.random.randint(self.dataset.n_images)
@@ -140,11 +142,12 @@ class Runner:
         rays_o, rays_d = self.dataset.gen_rays_at(idx, resolution_level=l)
         H, W, _ = rays_o.shape
         out_rgb = []
-        for o, d in zip(rays_o.reshape(-1, 3).split(self.batch_size), rays_d.reshape(-1, 3).split(self.batch_size)):
+        chunk = max(int(self.batch_size), 4096)
+        for o, d in zip(rays_o.reshape(-1, 3).split(chunk), rays_d.reshape(-1, 3).split(chunk)):
             data = torch.cat([o, d, torch.zeros(len(o), 4, device=o.device)], -1)
             out = self.trainer.render_only(data, cos_anneal_ratio=self.get_cos_anneal_ratio())
-            out_rgb.append(out["color_fine"].cpu().numpy())
-        img = (np.concatenate(out_rgb, 0).reshape(H, W, 3) * 256).clip(0, 255).astype(np.uint8)
+            out_rgb.append(out["color_fine"])
+        img = (torch.cat(out_rgb, 0).reshape(H, W, 3) * 256).clip(0, 255).to(torch.uint8).cpu().numpy()
         os.makedirs(os.path.join(self.base_exp_dir, "validations_fine"), exist_ok=True)
         path = os.path.join(self.base_exp_dir, "validations_fine", "{:0>8d}_{}.png".format(self.iter_step, idx))
         Image.fromarray(img[..., ::-1]).save(path)
