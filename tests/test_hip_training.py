@@ -51,3 +51,49 @@ def test_loss_trajectory_matches_oracle_training():
             assert d <= (2e-3 if i == 0 else 3e-2), (i, k, a[k], r[k])
     print(f"  {steps} training steps: worst relative loss-term deviation from the oracle run {worst:.2e}; "
           f"loss {ref[0]['loss']:.4f} -> {ref[-1]['loss']:.4f} (oracle), {hip[0]['loss']:.4f} -> {hip[-1]['loss']:.4f} (HIP)")
+
+
+def test_womask_loss_trajectory_matches_oracle_training():
+    """the womask configuration: + background NeRF++ (K7 and its weight gradients in the optimiser loop), white background,
+    cos_anneal_ratio ramping -- replayed as one graph -- against the oracle's run of the same steps"""
+    from fneus import ops, synth
+    from fneus.trainer import Stage1Trainer, WMASK_MODEL
+    from oracle import ref_torch as R
+    dev = torch.device("cuda:0")
+    conf = copy.deepcopy(WMASK_MODEL)
+    conf["neus_renderer"] = dict(n_samples=16, n_importance=16, n_outside=8, up_sample_steps=4, perturb=0.0)
+    steps, B, seed, lr = 10, 48, 50, 5e-4
+    batches = [torch.from_numpy(synth.ray_batch(B, seed=700 + i, n_miss=3)) for i in range(steps)]
+    ratios = [min(1.0, 0.1 * i) for i in range(steps)]
+    bg = torch.ones(1, 3)
+    tr = Stage1Trainer(dev, model_conf=conf, prec=ops.PREC_PARITY, seed=seed, lr=lr, use_graph=True)
+    hip = []
+    for b, r in zip(batches, ratios):
+        out = tr.train_step(b.to(dev), cos_anneal_ratio=r, background_rgb=bg.to(dev))
+        hip.append({k: float(v.detach()) for k, v in out.items()})
+    assert len(tr._graphs) == 1
+    T = lambda sd: {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in sd.items()}
+    sd_sdf, sd_col, sd_ref, sd_nerf = (T(synth.sdf_state_dict(seed)), T(synth.color_state_dict(seed + 1)),
+                                       T(synth.refcolor_state_dict(seed + 2)), T(synth.nerf_state_dict(seed + 3)))
+    variance = torch.tensor(0.3, requires_grad=True)
+    leaves = [variance] + [p for sd in (sd_sdf, sd_col, sd_ref, sd_nerf) for p in sd.values()]
+    opt = torch.optim.Adam(leaves, lr=lr)
+    ref = []
+    for b, r in zip(batches, ratios):
+        near, far = R.near_far_from_sphere(b[:, :3], b[:, 3:6])
+        out = R.render(b[:, :3], b[:, 3:6], near, far, R.sdf_params_from_state_dict(sd_sdf), R.inv_s_from_variance(variance),
+                       R.color_params_from_state_dict(sd_col), sd_ref, sd_nerf, n_samples=16, n_importance=16, n_outside=8,
+                       t_rand=None, t_rand_out=None, background_rgb=bg, cos_anneal_ratio=r)
+        losses = R.stage1_loss(out, b[:, 6:9], b[:, 9:10], 0.1, 0.1, 0.1)
+        opt.zero_grad()
+        losses["loss"].backward()
+        opt.step()
+        ref.append({k: float(v.detach()) for k, v in losses.items()})
+    worst = 0.0
+    for i, (a, r) in enumerate(zip(hip, ref)):
+        for k in ("loss", "color_loss", "eikonal_loss", "mask_loss", "surface_loss"):
+            d = abs(a[k] - r[k]) / max(abs(r[k]), 1e-2)
+            worst = max(worst, d)
+            assert d <= (2e-3 if i == 0 else 3e-2), (i, k, a[k], r[k])
+    print(f"  womask, {steps} steps: worst relative loss-term deviation from the oracle run {worst:.2e}; "
+          f"loss {ref[0]['loss']:.4f} -> {ref[-1]['loss']:.4f} (oracle), {hip[0]['loss']:.4f} -> {hip[-1]['loss']:.4f} (HIP)")
