@@ -18,6 +18,7 @@ import torch
 import torch.nn.functional as F
 
 from fneus import ops
+from models.mesh import extract_fields, extract_geometry      # noqa: F401  module-level API of renderer.py:14-40
 from fneus.autograd import CompositeFn, RaySamples, SurfaceGatherFn, Stage1LossFn
 
 
