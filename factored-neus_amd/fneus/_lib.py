@@ -53,6 +53,15 @@ class FneusGemmJob(C.Structure):
                 ("scale", C.c_float), ("tile_base", C.c_int), ("b_w", C.c_int)]
 
 
+class FneusGemmPPJob(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("a_hi", "a_lo", "b_hi", "b_lo", "a2_hi", "a2_lo", "b2_hi", "b2_lo")] + \
+               [(n, C.c_uint32) for n in ("a_blk", "b_blk", "a2_blk", "b2_blk")] + \
+               [(n, C.c_uint16) for n in ("a_f0", "b_f0", "a2_f0", "b2_f0")] + \
+               [("mt", C.c_int32), ("nt", C.c_int32), ("c", C.c_void_p), ("bias", C.c_void_p),
+                ("ldc", C.c_int32), ("m", C.c_int32), ("n", C.c_int32), ("scale", C.c_float),
+                ("wg_base", C.c_int32), ("splits", C.c_int32)]
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -82,6 +91,7 @@ def _load():
         "fneus_refcolor_bwd_both": (C.c_int, [vp, vp, l, vp, ip, vp, vp, vp, vp, vp, vp, C.POINTER(FneusColStash),
                                               C.POINTER(FneusColStash), vp, vp, ip, vp]),
         "fneus_dw_gemm": (C.c_int, [vp, ip, ip, l, ip, vp]),
+        "fneus_dw_gemm_pp": (C.c_int, [vp, ip, ip, l, ip, vp]),
         "fneus_nerf_bg_fwd": (C.c_int, [vp, vp, vp, l, C.POINTER(FneusNerfStash), vp, vp, ip, ip, vp]),
         "fneus_nerf_bg_bwd": (C.c_int, [vp, l, vp, vp, C.POINTER(FneusNerfStash), ip, vp]),
         "fneus_adam": (C.c_int, [C.POINTER(FneusAdamSegment), ip, vp, vp, C.c_double, C.c_double, C.c_double, ip, vp]),

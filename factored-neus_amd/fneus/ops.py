@@ -408,6 +408,65 @@ class GemmJobs:
         _launch("fneus_dw_gemm:" + self.tag, lib.fneus_dw_gemm, _ptr(self.dev_table), len(self.jobs), self.tiles, n_samples, prec, _stream())
 
 
+class PPOperand:
+    """One operand of a fragment-plane product: planes [P, tiles, F, 64, 8] bf16 (P = 1: hi, 2: hi + lo), the first
+    fragment `f0` of the operand inside a block and its tile count; const = the same block for every sample tile."""
+
+    def __init__(self, planes: torch.Tensor, f0: int, tiles: int, const: bool = False):
+        assert planes.dtype == torch.bfloat16 and planes.dim() == 5 and planes.shape[3:] == (64, 8), planes.shape
+        assert planes.is_contiguous() or planes[0].is_contiguous()
+        self.planes, self.f0, self.tiles, self.const = planes, f0, tiles, const
+        self.blk = 0 if const else planes.shape[2] * 1024
+        assert f0 + 2 * tiles <= planes.shape[2], (f0, tiles, planes.shape)
+
+    def ptr(self, p: int):
+        if p >= self.planes.shape[0]:
+            return None
+        assert self.planes[p].is_contiguous()
+        return self.planes[p].data_ptr()
+
+
+class GemmPPJobs:
+    """Device job table for fneus_dw_gemm_pp (include/fneus.h FneusGemmPPJob); pointers refer to live plane tensors."""
+
+    def __init__(self, device, tag="", target_wgs: int = 256):
+        self.device, self.tag, self.target = device, tag, target_wgs
+        self.jobs, self.bytes = [], []
+        self.dev_table, self.n_wgs = None, 0
+
+    def add(self, A: PPOperand, B: PPOperand, c_ptr, ldc, m, n, A2: Optional[PPOperand] = None, B2: Optional[PPOperand] = None,
+            bias_ptr=None, scale=1.0):
+        assert A.tiles <= 8 and B.tiles <= 8 and m <= 32 * A.tiles and n <= 32 * B.tiles
+        j = _lib.FneusGemmPPJob()
+        j.a_hi, j.a_lo, j.b_hi, j.b_lo = A.ptr(0), A.ptr(1), B.ptr(0), B.ptr(1)
+        j.a_blk, j.b_blk, j.a_f0, j.b_f0 = A.blk, B.blk, A.f0, B.f0
+        if A2 is not None:
+            assert A2.tiles == A.tiles and B2.tiles == B.tiles
+            j.a2_hi, j.a2_lo, j.b2_hi, j.b2_lo = A2.ptr(0), A2.ptr(1), B2.ptr(0), B2.ptr(1)
+            j.a2_blk, j.b2_blk, j.a2_f0, j.b2_f0 = A2.blk, B2.blk, A2.f0, B2.f0
+        j.mt, j.nt, j.c, j.bias, j.ldc, j.m, j.n, j.scale = A.tiles, B.tiles, c_ptr, bias_ptr, ldc, m, n, scale
+        self.jobs.append(j)
+        self.bytes.append((A.tiles + B.tiles) * 2048 * (2 if A2 is not None else 1))
+        return self
+
+    def finalize(self, n_sample_tiles: int):
+        """distribute ~target workgroups over the jobs in proportion to the bytes each streams"""
+        tot = float(sum(self.bytes))
+        base = 0
+        for j, b in zip(self.jobs, self.bytes):
+            s = max(1, min(n_sample_tiles, int(round(self.target * b / tot))))
+            j.wg_base, j.splits = base, s
+            base += s
+        self.n_wgs, self.n_sample_tiles = base, n_sample_tiles
+        arr = (_lib.FneusGemmPPJob * len(self.jobs))(*self.jobs)
+        self.dev_table = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(self.device)
+        return self
+
+    def run(self, gprec: int):
+        _launch("fneus_dw_gemm_pp:" + self.tag, lib.fneus_dw_gemm_pp, _ptr(self.dev_table), len(self.jobs), self.n_wgs,
+                self.n_sample_tiles, gprec, _stream())
+
+
 def sdf_dw_jobs(net: PackedNet, stash: SdfStash, bufs: SdfBwdBufs, grad_flat: torch.Tensor, n: int) -> GemmJobs:
     """dW_l = zbar_l^T u_l + a_l^T adj_l for the 9 SDF layers, into the flat fp32 grad buffer."""
     import math

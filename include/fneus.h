@@ -88,6 +88,23 @@ typedef struct FneusGemmJob {
     int32_t b_w;       /* readable row width of B / B2                                                           */
 } FneusGemmJob;
 
+/* One product of fneus_dw_gemm_pp over FRAGMENT PLANES (csrc/fneus_pp.h): a plane holds, per 32-sample tile, the MFMA B
+ * fragments of a layer's activations as the chain kernels produce them (1 KiB each = 16 features x 32 samples).
+ * C[o][i] += scale * sum_tiles (A^T B + A2^T B2); bias[o] += sum_samples A[s][o].  *_lo planes (same layout) carry the
+ * bf16 remainder of every value and are read in the exact-gradient mode (gprec 3) only. */
+typedef struct FneusGemmPPJob {
+    const void *a_hi, *a_lo, *b_hi, *b_lo;      /* plane bases (sample tile 0)                                     */
+    const void *a2_hi, *a2_lo, *b2_hi, *b2_lo;  /* second term or NULL                                             */
+    uint32_t a_blk, b_blk, a2_blk, b2_blk;      /* bytes between consecutive sample tiles; 0 = one constant block  */
+    uint16_t a_f0, b_f0, a2_f0, b2_f0;          /* first 1 KiB fragment of the operand inside a block              */
+    int32_t mt, nt;                             /* 32-row / 32-column tiles of the product, <= 8 each              */
+    float* c;                                   /* fp32 [m][ldc], accumulated with atomics                         */
+    float* bias;                                /* fp32 [m] or NULL                                                */
+    int32_t ldc, m, n;
+    float scale;
+    int32_t wg_base, splits;                    /* first workgroup of the job, number of sample-range splits       */
+} FneusGemmPPJob;
+
 /* one contiguous run of parameters for fneus_adam (all device pointers) */
 typedef struct FneusAdamSegment {
     float* param;
@@ -144,6 +161,12 @@ int fneus_sdf_bwd(const void* sdf_blob, const float* pts, const float* rays_o, c
 /* ---- weight-gradient GEMM (split-K over samples, fp32 atomics into zero-initialised C / bias) ------------------ */
 int fneus_dw_gemm(const void* jobs_dev /*FneusGemmJob[n_jobs] on the device*/, int n_jobs, int n_tiles, long n_samples,
                   int prec, fneus_stream_t stream);
+
+/* The same products over fragment planes (FneusGemmPPJob): what the SDF network's backward uses.  n_wgs = sum of the jobs'
+ * `splits`; gprec 1 = hi planes only (bf16 operands, fp32 accumulation), 3 = hi + lo planes (hi*hi + hi*lo + lo*hi).
+ * Replaces torch autograd's addmm backward for fields.py:86 incl. the double-backward term of fields.py:104-110.       */
+int fneus_dw_gemm_pp(const void* jobs_dev /*FneusGemmPPJob[n_jobs] on the device*/, int n_jobs, int n_wgs,
+                     long n_sample_tiles, int gprec, fneus_stream_t stream);
 
 /* ---- K4: RenderingNetwork.forward, mode 'idr'  (fields.py:150-175 via renderer.py:278) ---------------------- */
 /* view directions: `dirs` [n][3], or NULL -> rays_d[n/m].  train != 0 writes the stash planes for the backward.   */
