@@ -14,31 +14,32 @@ struct PointSrc {
     int m;
 };
 
+// device-side views of FneusSdfStash / FneusSdfBwdBufs (include/fneus.h): fragment planes as byte pointers
 struct SdfStash {
-    __bf16* pe_hi;   __bf16* pe_lo;
-    __bf16* h_hi;    __bf16* h_lo;
-    __bf16* a_hi;    __bf16* a_lo;
-    __bf16* feat_hi; __bf16* feat_lo;
-    unsigned char* ps;   // lane-private sigma'(z_l):  [tiles][8][32][64] x 4 values (fp32 in parity mode, bf16 in fast mode)
-    unsigned char* pa;   // lane-private a_l, same layout (training only)
+    unsigned char *pe_hi, *pe_lo;     // [tiles][4 KiB]
+    unsigned char *h_hi, *h_lo;       // [8][tiles][16 KiB]
+    unsigned char *a_hi, *a_lo;       // [8][tiles][16 KiB]
+    __bf16 *feat_hi, *feat_lo;        // [N][256] row-major
+    unsigned char* ps;                // sigma'(z_l), u16 fixed point: [tiles][8][16 KiB]
     SdfStash() = default;
     SdfStash(const FneusSdfStash& s)
-        : pe_hi((__bf16*)s.pe_hi), pe_lo((__bf16*)s.pe_lo), h_hi((__bf16*)s.h_hi), h_lo((__bf16*)s.h_lo),
-          a_hi((__bf16*)s.a_hi), a_lo((__bf16*)s.a_lo), feat_hi((__bf16*)s.feat_hi), feat_lo((__bf16*)s.feat_lo),
-          ps((unsigned char*)s.ps), pa((unsigned char*)s.pa) {}
+        : pe_hi((unsigned char*)s.pe_hi), pe_lo((unsigned char*)s.pe_lo), h_hi((unsigned char*)s.h_hi),
+          h_lo((unsigned char*)s.h_lo), a_hi((unsigned char*)s.a_hi), a_lo((unsigned char*)s.a_lo),
+          feat_hi((__bf16*)s.feat_hi), feat_lo((__bf16*)s.feat_lo), ps((unsigned char*)s.ps) {}
 };
 
 struct SdfBwdBufs {
-    __bf16* qbar_hi; __bf16* qbar_lo;   // [N][48]      adj_0 = J nbar
-    __bf16* adj_hi;  __bf16* adj_lo;    // [8][N][256]  slot l = adj_{l+1}  (slot 3: 224 valid columns)
-    __bf16* zbar_hi; __bf16* zbar_lo;   // [9][N][256]  slot l = zbar_l     (slot 8: feature rows of the last layer)
-    __bf16* zsdf_hi; __bf16* zsdf_lo;   // [N][32]      column 0 = dL/dsdf  (sdf row of the last layer)
-    f32x4* cscratch;                    // [tiles][8][32][64] fp32x4 coupling terms (lane-private layout)
+    unsigned char *qbar_hi, *qbar_lo;   // [tiles][4 KiB]      adj_0 = J nbar
+    unsigned char *adj_hi, *adj_lo;     // [8][tiles][16 KiB]  slot l = adj_{l+1}
+    unsigned char *zbar_hi, *zbar_lo;   // [9][tiles][16 KiB]  slot l = zbar_l (slot 8: feature rows of the last layer)
+    unsigned char *zsdf_hi, *zsdf_lo;   // [tiles][2 KiB]      feature 0 = dL/dsdf
+    unsigned char *c_hi, *c_lo;         // [tiles][8][16 KiB]  coupling terms, lane-private
     SdfBwdBufs() = default;
     SdfBwdBufs(const FneusSdfBwdBufs& s)
-        : qbar_hi((__bf16*)s.qbar_hi), qbar_lo((__bf16*)s.qbar_lo), adj_hi((__bf16*)s.adj_hi), adj_lo((__bf16*)s.adj_lo),
-          zbar_hi((__bf16*)s.zbar_hi), zbar_lo((__bf16*)s.zbar_lo), zsdf_hi((__bf16*)s.zsdf_hi),
-          zsdf_lo((__bf16*)s.zsdf_lo), cscratch((f32x4*)s.cscratch) {}
+        : qbar_hi((unsigned char*)s.qbar_hi), qbar_lo((unsigned char*)s.qbar_lo), adj_hi((unsigned char*)s.adj_hi),
+          adj_lo((unsigned char*)s.adj_lo), zbar_hi((unsigned char*)s.zbar_hi), zbar_lo((unsigned char*)s.zbar_lo),
+          zsdf_hi((unsigned char*)s.zsdf_hi), zsdf_lo((unsigned char*)s.zsdf_lo), c_hi((unsigned char*)s.c_hi),
+          c_lo((unsigned char*)s.c_lo) {}
 };
 
 struct ColStash {

@@ -20,12 +20,12 @@ LIB_PATH = os.environ.get("FNEUS_LIB") or os.path.join(_HERE, "libfneus_hip.so")
 
 class FneusSdfStash(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
-                ("pe_hi", "pe_lo", "h_hi", "h_lo", "a_hi", "a_lo", "feat_hi", "feat_lo", "ps", "pa")]
+                ("pe_hi", "pe_lo", "h_hi", "h_lo", "a_hi", "a_lo", "feat_hi", "feat_lo", "ps")]
 
 
 class FneusSdfBwdBufs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
-                ("qbar_hi", "qbar_lo", "adj_hi", "adj_lo", "zbar_hi", "zbar_lo", "zsdf_hi", "zsdf_lo", "cscratch")]
+                ("qbar_hi", "qbar_lo", "adj_hi", "adj_lo", "zbar_hi", "zbar_lo", "zsdf_hi", "zsdf_lo", "c_hi", "c_lo")]
 
 
 class FneusColStash(C.Structure):

@@ -69,7 +69,7 @@ class SdfValueGradFn(torch.autograd.Function):
         # zeroed once: fneus_wn_backward clears what it reads, so the buffer is zero again after every step
         grad = ws.get(("sdf_grad", n), lambda: torch.zeros(net.n_params, dtype=torch.float32, device=dev))
         jobs = ws.get(("sdf_jobs", n, prec), lambda: ops.sdf_dw_jobs(net, ctx.stash, bufs, grad, n))
-        jobs.run(n, prec)
+        jobs.run()
         net.wn_backward(grad)
         return None, None, None, None, None, None
 

@@ -203,39 +203,58 @@ class PackedNet:
                 _ptr(self.raw_grad), _stream())
 
 
+# "gradient precision" of the backward stash: 1 = bf16 hi planes only (the weight-gradient GEMM multiplies bf16 operands,
+# fp32 accumulation), 3 = hi + lo planes (fp32-accurate weight gradients, twice the stash traffic).  The forward outputs
+# (sdf, feature, normal, colours) do not depend on it.  FNEUS_GPREC overrides the default.
+DEFAULT_GPREC = int(_os.environ.get("FNEUS_GPREC", "1"))
+
+
+def _gprec(prec: int, gprec: Optional[int]) -> int:
+    g = DEFAULT_GPREC if gprec is None else gprec
+    return 1 if prec == 1 else g
+
+
 class SdfStash:
-    """bf16 activation planes written by sdf_fwd_grad (see include/fneus.h FneusSdfStash)."""
+    """Activation stash written by sdf_fwd_grad (include/fneus.h FneusSdfStash): fragment planes (fneus/pp.py) for
+    h_l, a_l and the positional encoding, the lane-private sigma' plane, row-major feature planes."""
 
-    def __init__(self, n: int, device, prec: int, train: bool):
-        self.n, self.prec = n, prec
+    def __init__(self, n: int, device, prec: int, train: bool, gprec: Optional[int] = None):
+        self.n, self.prec, self.gprec = n, prec, _gprec(prec, gprec)
         bf = torch.bfloat16
-        planes = 2 if prec == 3 else 1
-
-        def alloc(*shape):
-            return torch.empty((planes,) + shape, dtype=bf, device=device)
-
-        self.pe = alloc(n, 48)
-        self.h = alloc(8, n, 256)
-        self.a = alloc(8, n, 256) if train else None
-        self.feat = alloc(n, 256) if train else None
-        # lane-private planes: [tiles][8 layers][32 groups][64 lanes] x 4 values (fp32 in parity mode, bf16 in fast mode)
-        tiles = ((n + 31) // 32 + 3) // 4 * 4          # workgroups hold 4 wave tiles
-        pdt = torch.float32 if prec == 3 else bf
-        self.ps = torch.empty(tiles * 8 * 32 * 64 * 4, dtype=torch.int16, device=device)    # sigma' as u16 fixed point
-        self.pa = torch.empty(tiles * 8 * 32 * 64 * 4, dtype=pdt, device=device) if train else None
+        P = 2 if self.gprec == 3 else 1
+        T = self.tiles = (n + 31) // 32
+        self.pe = torch.zeros((P, T, 4, 64, 8), dtype=bf, device=device) if train else None      # fragment 3 stays zero
+        self.h = torch.empty((P, 8, T, 16, 64, 8), dtype=bf, device=device) if train else None
+        self.a = torch.empty((P, 8, T, 16, 64, 8), dtype=bf, device=device) if train else None
+        # row-major hi / lo planes of the feature vector: the colour network's weight-gradient operand
+        self.feat = torch.empty((2 if prec == 3 else 1, n, 256), dtype=bf, device=device) if train else None
+        self.ps = torch.empty((T, 8, 16, 64, 8), dtype=torch.int16, device=device)      # sigma' as u16 fixed point
         s = _lib.FneusSdfStash()
         s.ps = self.ps.data_ptr()
-        s.pa = self.pa.data_ptr() if train else None
         for name, t in (("pe", self.pe), ("h", self.h), ("a", self.a), ("feat", self.feat)):
             if t is None:
                 continue
             setattr(s, name + "_hi", t[0].data_ptr())
-            setattr(s, name + "_lo", t[1].data_ptr() if planes == 2 else None)
+            setattr(s, name + "_lo", t[1].data_ptr() if t.shape[0] == 2 else None)
         self.c = s
 
-    def plane(self, t):
-        """fp32 value of a stash tensor (hi + lo)"""
-        return t.float().sum(0)
+    def plane(self, t, slot=None):
+        """fp32 value [n, 16 F] of a fragment-plane tensor (hi + lo), optionally of one layer slot"""
+        from . import pp
+        return pp.value(t if slot is None else t[:, slot], self.n)
+
+    def sigma(self, slot):
+        """sigma'(z_slot) [n, 256] decoded from the fixed-point plane (lane-linear fragments)"""
+        u = self.ps[:, slot].to(torch.int32) & 0xFFFF                       # [T, 16, 64, 8]
+        T = u.shape[0]
+        lane = torch.arange(64, device=u.device)
+        r, h = lane & 31, lane >> 5
+        out = torch.empty(T, 32, 256, dtype=torch.float32, device=u.device)
+        for ks in range(16):
+            for j in range(8):
+                f = 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3)
+                out[:, r, f] = u[:, ks, :, j].float() / 65535.0
+        return out.reshape(T * 32, 256)[:self.n]
 
 
 def sdf_fwd(blob, n_pts: int, prec: int, pts=None, rays_o=None, rays_d=None, t=None, m: int = 1, out=None):
@@ -262,19 +281,27 @@ def sdf_fwd_grad(blob, n_pts: int, prec: int, stash: SdfStash, train: bool, pts=
 # backward-side buffers and the weight-gradient GEMM
 # ------------------------------------------------------------------------------------------------------------
 class SdfBwdBufs:
-    def __init__(self, n: int, device, prec: int):
+    """work buffers of sdf_bwd (include/fneus.h FneusSdfBwdBufs): fragment planes + the coupling scratch"""
+
+    def __init__(self, n: int, device, prec: int, gprec: Optional[int] = None):
         bf = torch.bfloat16
-        planes = 2 if prec == 3 else 1
-        self.qbar = torch.zeros((planes, n, 48), dtype=bf, device=device)
-        self.adj = torch.empty((planes, 8, n, 256), dtype=bf, device=device)
-        self.zbar = torch.empty((planes, 9, n, 256), dtype=bf, device=device)
-        self.zsdf = torch.zeros((planes, n, 32), dtype=bf, device=device)
-        self.cscratch = torch.empty((((n + 31) // 32 + 3) // 4 * 4) * 8 * 32 * 64 * 4, dtype=torch.float32, device=device)
+        self.n, self.gprec = n, _gprec(prec, gprec)
+        P = 2 if self.gprec == 3 else 1
+        T = self.tiles = (n + 31) // 32
+        self.qbar = torch.zeros((P, T, 4, 64, 8), dtype=bf, device=device)          # fragment 3 stays zero
+        self.adj = torch.zeros((P, 8, T, 16, 64, 8), dtype=bf, device=device)
+        self.zbar = torch.zeros((P, 9, T, 16, 64, 8), dtype=bf, device=device)
+        self.zsdf = torch.zeros((P, T, 2, 64, 8), dtype=bf, device=device)
+        self.cs = torch.empty((P, T, 8, 16, 64, 8), dtype=bf, device=device)
+        # the implicit "ones" row of the sdf output (a_8 = e_0): one constant block, feature 0 = 1 for every sample
+        from . import pp
+        ones = torch.zeros(32, 32, device=device)
+        ones[:, 0] = 1.0
+        self.ones = pp.pack(ones, 2, P)                                                # [P, 1, 2, 64, 8]
         s = _lib.FneusSdfBwdBufs()
-        for name, t in (("qbar", self.qbar), ("adj", self.adj), ("zbar", self.zbar), ("zsdf", self.zsdf)):
+        for name, t in (("qbar", self.qbar), ("adj", self.adj), ("zbar", self.zbar), ("zsdf", self.zsdf), ("c", self.cs)):
             setattr(s, name + "_hi", t[0].data_ptr())
-            setattr(s, name + "_lo", t[1].data_ptr() if planes == 2 else None)
-        s.cscratch = self.cscratch.data_ptr()
+            setattr(s, name + "_lo", t[1].data_ptr() if P == 2 else None)
         self.c = s
 
 
@@ -462,40 +489,41 @@ class GemmPPJobs:
         self.dev_table = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(self.device)
         return self
 
-    def run(self, gprec: int):
+    def run(self, *_ignored, gprec: Optional[int] = None):
+        """(positional arguments of the row-major GemmJobs.run(n, prec) are accepted and ignored)"""
+        gprec = getattr(self, "gprec", 1) if gprec is None else gprec
         _launch("fneus_dw_gemm_pp:" + self.tag, lib.fneus_dw_gemm_pp, _ptr(self.dev_table), len(self.jobs), self.n_wgs,
                 self.n_sample_tiles, gprec, _stream())
 
 
-def sdf_dw_jobs(net: PackedNet, stash: SdfStash, bufs: SdfBwdBufs, grad_flat: torch.Tensor, n: int) -> GemmJobs:
-    """dW_l = zbar_l^T u_l + a_l^T adj_l for the 9 SDF layers, into the flat fp32 grad buffer."""
+def sdf_dw_jobs(net: PackedNet, stash: SdfStash, bufs: SdfBwdBufs, grad_flat: torch.Tensor, n: int) -> GemmPPJobs:
+    """dW_l = zbar_l^T u_l + a_l^T adj_l for the 9 SDF layers (SURVEY.md Appendix A), into the flat fp32 grad buffer;
+    operands are the fragment planes written by K2 / K3."""
     import math
-    g = GemmJobs(grad_flat.device, "sdf")
+    g = GemmPPJobs(grad_flat.device, "sdf")
+    O = PPOperand
     offW, offb = net.desc["offW"], net.desc["offb"]
     base = grad_flat.data_ptr()
     isq2 = 1.0 / math.sqrt(2.0)
-
-    def L(t, slot):            # layer slot view of a [planes, L, n, 256] tensor -> [planes, n, 256]
-        return t[:, slot]
-
+    zb, h, a, adj = (lambda l: bufs.zbar[:, l]), (lambda l: stash.h[:, l]), (lambda l: stash.a[:, l]), (lambda l: bufs.adj[:, l])
     for l in (1, 2, 3, 5, 6, 7):
-        m = 217 if l == 3 else 256
-        g.add(L(bufs.zbar, l), L(stash.h, l - 1), base + 4 * offW[l], 256, m, 256, 256, 256, 256, 256,
-              A2=L(stash.a, l), B2=L(bufs.adj, l - 1), lda2=256, ldb2=256, bias_ptr=base + 4 * offb[l])
+        mt = 7 if l == 3 else 8
+        g.add(O(zb(l), 0, mt), O(h(l - 1), 0, 8), base + 4 * offW[l], 256, 217 if l == 3 else 256, 256,
+              A2=O(a(l), 0, mt), B2=O(adj(l - 1), 0, 8), bias_ptr=base + 4 * offb[l])
     # layer 0: inputs = PE
-    g.add(L(bufs.zbar, 0), stash.pe, base + 4 * offW[0], 39, 256, 39, 256, 48, 256, 48,
-          A2=L(stash.a, 0), B2=bufs.qbar, lda2=256, ldb2=48, bias_ptr=base + 4 * offb[0])
+    g.add(O(zb(0), 0, 8), O(stash.pe, 0, 2), base + 4 * offW[0], 39, 256, 39,
+          A2=O(a(0), 0, 8), B2=O(bufs.qbar, 0, 2), bias_ptr=base + 4 * offb[0])
     # layer 4: [h_4 (217) ; PE (39)] / sqrt(2)
-    g.add(L(bufs.zbar, 4), L(stash.h, 3), base + 4 * offW[4], 256, 256, 217, 256, 256, 256, 256,
-          A2=L(stash.a, 4), B2=L(bufs.adj, 3), lda2=256, ldb2=256, bias_ptr=base + 4 * offb[4], scale=isq2)
-    g.add(L(bufs.zbar, 4), stash.pe, base + 4 * (offW[4] + 217), 256, 256, 39, 256, 48, 256, 48,
-          A2=L(stash.a, 4), B2=bufs.qbar, lda2=256, ldb2=48, scale=isq2)
-    # layer 8: rows 1..256 (feature), row 0 (sdf; its ascending term is sum_n adj_8[n])
-    g.add(L(bufs.zbar, 8), L(stash.h, 7), base + 4 * (offW[8] + 256), 256, 256, 256, 256, 256, 256, 256,
-          bias_ptr=base + 4 * (offb[8] + 1))
-    g.add(bufs.zsdf, L(stash.h, 7), base + 4 * offW[8], 256, 1, 256, 32, 256, 32, 256,
-          A2=bufs.zsdf, B2=L(bufs.adj, 7), lda2=32, ldb2=256, a2_mode=1, bias_ptr=base + 4 * offb[8])
-    return g.finalize()
+    g.add(O(zb(4), 0, 8), O(h(3), 0, 7), base + 4 * offW[4], 256, 256, 217,
+          A2=O(a(4), 0, 8), B2=O(adj(3), 0, 7), bias_ptr=base + 4 * offb[4], scale=isq2)
+    g.add(O(zb(4), 0, 8), O(stash.pe, 0, 2), base + 4 * (offW[4] + 217), 256, 256, 39,
+          A2=O(a(4), 0, 8), B2=O(bufs.qbar, 0, 2), scale=isq2)
+    # layer 8: rows 1..256 (feature), row 0 (sdf; its ascending term is sum_n adj_8[n]: a_8 = e_0, a constant block)
+    g.add(O(zb(8), 0, 8), O(h(7), 0, 8), base + 4 * (offW[8] + 256), 256, 256, 256, bias_ptr=base + 4 * (offb[8] + 1))
+    g.add(O(bufs.zsdf, 0, 1), O(h(7), 0, 8), base + 4 * offW[8], 256, 1, 256,
+          A2=O(bufs.ones, 0, 1, const=True), B2=O(adj(7), 0, 8), bias_ptr=base + 4 * offb[8])
+    g.gprec = stash.gprec
+    return g.finalize(stash.tiles)
 
 
 def color_dw_jobs(net: PackedNet, feat_planes: torch.Tensor, stash: ColStash, grad_flat: torch.Tensor, n: int,

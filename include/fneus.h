@@ -28,15 +28,17 @@ extern "C" {
 
 typedef void* fneus_stream_t; /* hipStream_t */
 
-/* bf16 planes of the activation stash written by fneus_sdf_fwd_grad and consumed by the backward kernels.
- * All matrices are row-major, one row per sample.  *_lo planes are only touched when prec == 3. */
+/* Activation stash of the SDF network, written by fneus_sdf_fwd_grad and consumed by fneus_sdf_bwd / fneus_dw_gemm_pp.
+ * h, a, pe are FRAGMENT PLANES (csrc/fneus_pp.h): per 32-sample tile the MFMA B fragments of a layer (1 KiB each = 16
+ * features x 32 samples), bf16; tiles = ceil(N / 32).  The *_lo planes carry the bf16 remainder of every value: they are
+ * optional (NULL = not written / not read; "gradient precision" 1) -- with them the weight gradients are fp32-accurate
+ * (gradient precision 3).  feat is still a row-major hi / lo pair: the colour network's weight-gradient operand. */
 typedef struct FneusSdfStash {
-    uint16_t* pe_hi;   uint16_t* pe_lo;   /* [N][48]      positional encoding (cols >= 39 zero)            */
-    uint16_t* h_hi;    uint16_t* h_lo;    /* [8][N][256]  slot l = softplus output of layer l (= input of l+1) */
-    uint16_t* a_hi;    uint16_t* a_lo;    /* [8][N][256]  slot l = a_l = sigma'(z_l) * d sdf/d h_{l+1}      */
-    uint16_t* feat_hi; uint16_t* feat_lo; /* [N][256]     feature vector (colour-network input)             */
-    void* ps; /* lane-private sigma'(z_l): [ceil(N/32)][8][32][64] x 4 values, fp32 (prec 3) or bf16 (prec 1)  */
-    void* pa; /* lane-private a_l, same layout; written when train != 0                                        */
+    uint16_t* pe_hi;   uint16_t* pe_lo;   /* [tiles][4][512]      positional encoding (39 of 64 features; fragment 3 stays zero) */
+    uint16_t* h_hi;    uint16_t* h_lo;    /* [8][tiles][16][512]  slot l = softplus output of layer l (= input of l+1)       */
+    uint16_t* a_hi;    uint16_t* a_lo;    /* [8][tiles][16][512]  slot l = a_l = sigma'(z_l) * d sdf/d h_{l+1}  (train != 0)  */
+    uint16_t* feat_hi; uint16_t* feat_lo; /* [N][256] row-major   feature vector (colour-network input; train != 0)          */
+    void* ps; /* sigma'(z_l) as 16-bit fixed point, lane-private: [tiles][8][16][64] x 16 bytes                              */
 } FneusSdfStash;
 
 /* bf16 planes of the colour network (written by fneus_color_fwd with train != 0 / fneus_color_bwd). */
@@ -49,13 +51,14 @@ typedef struct FneusColStash {
                                                           the colour network (its features are FneusSdfStash.feat)    */
 } FneusColStash;
 
-/* work buffers of fneus_sdf_bwd (operands of the weight-gradient GEMM + private scratch). */
+/* work buffers of fneus_sdf_bwd: the operands of the weight-gradient GEMM (fragment planes like FneusSdfStash, *_lo
+ * optional in the same way) + private scratch. */
 typedef struct FneusSdfBwdBufs {
-    uint16_t* qbar_hi; uint16_t* qbar_lo; /* [N][48]     adj_0 = J^T-transposed normal adjoint                 */
-    uint16_t* adj_hi;  uint16_t* adj_lo;  /* [8][N][256] slot l = adj_{l+1}                                    */
-    uint16_t* zbar_hi; uint16_t* zbar_lo; /* [9][N][256] slot l = dL/dz_l (slot 8: feature rows of layer 8)    */
-    uint16_t* zsdf_hi; uint16_t* zsdf_lo; /* [N][32]     column 0 = dL/dsdf                                    */
-    float* cscratch;                      /* [ceil(N/32)][8][32][64][4] fp32                                   */
+    uint16_t* qbar_hi; uint16_t* qbar_lo; /* [tiles][4][512]      adj_0 = J nbar (as pe)                                   */
+    uint16_t* adj_hi;  uint16_t* adj_lo;  /* [8][tiles][16][512]  slot l = adj_{l+1}                                       */
+    uint16_t* zbar_hi; uint16_t* zbar_lo; /* [9][tiles][16][512]  slot l = dL/dz_l (slot 8: the 256 feature rows of layer 8) */
+    uint16_t* zsdf_hi; uint16_t* zsdf_lo; /* [tiles][2][512]      feature 0 = dL/dsdf (the sdf row of layer 8)             */
+    uint16_t* c_hi;    uint16_t* c_lo;    /* coupling terms between the two chains, lane-private: [tiles][8][16][64] x 16 bytes */
 } FneusSdfBwdBufs;
 
 /* Activation planes of the background NeRF++ (fneus_nerf_bg_fwd / _bwd); bf16 hi / lo planes, row-major, one row per

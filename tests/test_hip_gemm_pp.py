@@ -33,7 +33,7 @@ def test_gemm_pp_two_terms(gprec, n):
              A2=ops.PPOperand(ap, 0, 8), B2=ops.PPOperand(zp, 0, 8), bias_ptr=base + 4 * 65536)
     off1 = 65536 + 256
     jobs.add(ops.PPOperand(ap, 0, 7), ops.PPOperand(dp, 0, 2), base + 4 * off1, 39, 217, 39, scale=0.5)
-    jobs.finalize(T).run(gprec)
+    jobs.finalize(T).run(gprec=gprec)
     torch.cuda.synchronize()
     A256 = torch.zeros(n, 256, dtype=torch.float64, device=dev)
     A256[:, :224] = Av[:, :224]
@@ -72,7 +72,7 @@ def test_gemm_pp_constant_block_and_offsets():
              A2=ops.PPOperand(onesp, 0, 1, const=True), B2=ops.PPOperand(adjp, 0, 8), bias_ptr=grad.data_ptr() + 4 * 257 * 256)
     # columns 64..191 of H against columns 32..95 of ADJ (fragment offsets 4 and 2)
     jobs.add(ops.PPOperand(hp, 4, 4), ops.PPOperand(adjp, 2, 2), grad.data_ptr() + 4 * 256, 256, 128, 64)
-    jobs.finalize(T).run(1)
+    jobs.finalize(T).run(gprec=1)
     torch.cuda.synchronize()
     Hv, ADJv, Zv = pp.value(hp, n).double(), pp.value(adjp, n).double(), pp.value(zsp, n).double()
     ref_row = Zv[:, 0] @ Hv + ADJv.sum(0)          # NOTE: the ragged tile's padding rows are zero in ADJ, so the ones block adds nothing

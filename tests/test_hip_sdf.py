@@ -54,31 +54,50 @@ def test_sdf_fwd_ray_mode(env):
     assert (out.cpu() - ref).abs().max().item() <= 1e-4
 
 
-@pytest.mark.parametrize("prec,tol", [(3, 1e-4), (1, 1e-1)])
-def test_sdf_fwd_grad(env, prec, tol):
+@pytest.mark.parametrize("prec,gprec,tol", [(3, 3, 1e-4), (3, 1, 1e-4), (1, 1, 1e-1)])
+def test_sdf_fwd_grad(env, prec, gprec, tol):
     ops, R = env["ops"], env["R"]
     x = env["x"]
     p64 = {"W": [w.double() for w in env["p"]["W"]], "b": [b.double() for b in env["p"]["b"]], "scale": 1.0}
     sdf_r, feat_r, nrm_r, aux = R.sdf_value_feature_normal(x.double(), p64)
     n = x.shape[0]
-    stash = ops.SdfStash(n, env["dev"], prec, train=True)
+    stash = ops.SdfStash(n, env["dev"], prec, train=True, gprec=gprec)
+    for t in (stash.h, stash.a, stash.pe):
+        t.fill_(float("nan"))          # every fragment the GEMM reads must be written (or stay zero: pe fragment 3)
+    stash.pe[:, :, 3].zero_()
     sdf, feat, nrm = ops.sdf_fwd_grad(env["net"].blob, n, prec, stash, True, pts=x.to(env["dev"]).contiguous())
     e_sdf = (sdf.cpu().double() - sdf_r[:, 0]).abs().max().item()
     e_feat = (feat.cpu().double() - feat_r).abs().max().item()
     e_nrm = (nrm.cpu().double() - nrm_r).abs().max().item()
     print(f"sdf_fwd_grad prec={prec}: sdf {e_sdf:.3e} feat {e_feat:.3e} normal {e_nrm:.3e}")
     assert e_sdf <= tol and e_feat <= tol and e_nrm <= tol
-    # stash planes are the operands of the weight-gradient GEMM: check them against the oracle's intermediates
-    stol = 2e-5 if prec == 3 else 2e-2
-    h = stash.plane(stash.h).cpu().double()
-    a = stash.plane(stash.a).cpu().double()
+    # the stash planes are the operands of the weight-gradient GEMM: check them against the oracle's intermediates.
+    # hi + lo planes carry 16-17 bits, the hi plane alone 8 (relative tolerance 2^-8)
+    exact = prec == 3 and gprec == 3
+    stol = 2e-4 if exact else (2e-2 if prec == 1 else 2e-5)
+    rtol = 0.0 if exact else 2.0 ** -8
+
+    def close(got, ref, name):
+        err = (got - ref).abs()
+        bound = stol + rtol * ref.abs()
+        assert bool((err <= bound + 1e-30).all()), (name, err.max().item())
+
     for l in range(8):
         width = 217 if l == 3 else 256
+        h = stash.plane(stash.h, l).cpu().double()
+        a = stash.plane(stash.a, l).cpu().double()
         h_ref = torch.nn.functional.softplus(aux["z"][l], beta=100)
-        assert (h[l][:, :width] - h_ref[:, :width]).abs().max().item() <= stol * 10, f"h{l}"
-        assert (a[l][:, :width] - aux["a"][l][:, :width]).abs().max().item() <= stol * 10, f"a{l}"
+        close(h[:, :width], h_ref[:, :width], f"h{l}")
+        close(a[:, :width], aux["a"][l][:, :width], f"a{l}")
+        # sigma'(z_l): 16-bit fixed point
+        sg = stash.sigma(l).cpu().double()
+        assert (sg[:, :width] - torch.sigmoid(100.0 * aux["z"][l][:, :width])).abs().max().item() <= (5e-4 if prec == 3 else 2e-1)     # d sigma(100 z)/dz <= 25: z to 4e-6
     pe = stash.plane(stash.pe).cpu().double()
-    assert (pe[:, :39] - aux["h0"]).abs().max().item() <= stol
+    close(pe[:, :39], aux["h0"], "pe")
     assert pe[:, 39:].abs().max().item() == 0.0
-    f = stash.plane(stash.feat).cpu().double()
-    assert (f - feat_r).abs().max().item() <= stol * 10
+    # padding samples of the ragged last tile are stored as zeros (the GEMM sums whole tiles)
+    from fneus import pp
+    full = pp.unpack(stash.h[0, 7]).float()
+    assert full.shape[0] == 32 * stash.tiles and full[n:].abs().max().item() == 0.0
+    f = stash.feat.float().sum(0).cpu().double()
+    assert (f - feat_r).abs().max().item() <= (2e-4 if prec == 3 else 2e-1)

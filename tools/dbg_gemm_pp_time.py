@@ -27,13 +27,13 @@ for target in (int(x) for x in os.environ.get("WGS", "256,192,128,512").split(",
     jobs.finalize(T)
     byts = sum(b for b in jobs.bytes) * T * P
     for _ in range(3):
-        jobs.run(gprec)
+        jobs.run(gprec=gprec)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 20
     e0.record()
     for _ in range(reps):
-        jobs.run(gprec)
+        jobs.run(gprec=gprec)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
