@@ -14,7 +14,10 @@ constexpr int kMaxKS = 19;   // widest layer input on the path: colour layer 0 (
 // DEPTH = prefetch distance in stages (0: the default of the precision mode).  The chain-only kernel K1 is best at 2
 // (parity) / 4 (bf16); the kernels that interleave stash traffic with the chain (K2, K3) gain 8-12 % from 4 / 8 even
 // though the deeper register ring costs them a few more spills (measured, tools/experiments/README.md).
-template <int PREC, int KS, int NT_TOTAL, int T0, int TN, int KS0 = 0, int DEPTH = 0>
+// WLO = false (parity mode only): the lo halves of the WEIGHTS are neither streamed nor multiplied -- two MFMAs per
+// product, w_hi * (x_hi + x_lo): a 2^-9 relative perturbation of every weight.  Used by the backward chains when the
+// weight gradients are taken from bf16 planes anyway (gradient precision 1); never on a forward output.
+template <int PREC, int KS, int NT_TOTAL, int T0, int TN, int KS0 = 0, int DEPTH = 0, bool WLO = true>
 FN_DEV void dense(const unsigned char* __restrict__ blob, uint32_t off_hi, uint32_t off_lo,
                   const BFrag<PREC> (&b)[kMaxKS], f32x16 (&acc)[TN], int lane, int t0_rt = 0) {
     constexpr int GT = TN < 4 ? TN : 4;                 // tiles per stage
@@ -43,7 +46,7 @@ FN_DEV void dense(const unsigned char* __restrict__ blob, uint32_t off_hi, uint3
                 if (t < TN) {
                     const int f = ((s / NG) * NT_TOTAL + T0 + t) * 64;
                     ah[s % (D + 1)][i] = whi(f);
-                    if constexpr (PREC == 3) al[s % (D + 1)][i] = wlo(f);
+                    if constexpr (PREC == 3 && WLO) al[s % (D + 1)][i] = wlo(f);
                 }
             }
         }
@@ -57,7 +60,7 @@ FN_DEV void dense(const unsigned char* __restrict__ blob, uint32_t off_hi, uint3
                 if (t < TN) {
                     const int f = (((s + D) / NG) * NT_TOTAL + T0 + t) * 64;
                     ah[(s + D) % (D + 1)][i] = whi(f);
-                    if constexpr (PREC == 3) al[(s + D) % (D + 1)][i] = wlo(f);
+                    if constexpr (PREC == 3 && WLO) al[(s + D) % (D + 1)][i] = wlo(f);
                 }
             }
         }
@@ -67,7 +70,7 @@ FN_DEV void dense(const unsigned char* __restrict__ blob, uint32_t off_hi, uint3
             const int t = (s % NG) * GT + i;
             if (t < TN) {
                 if constexpr (PREC == 3) {
-                    acc[t] = mfma32(al[s % (D + 1)][i], b[KS0 + ks].hi, acc[t]);
+                    if constexpr (WLO) acc[t] = mfma32(al[s % (D + 1)][i], b[KS0 + ks].hi, acc[t]);
                     acc[t] = mfma32(ah[s % (D + 1)][i], b[KS0 + ks].lo, acc[t]);
                 }
                 acc[t] = mfma32(ah[s % (D + 1)][i], b[KS0 + ks].hi, acc[t]);
@@ -86,7 +89,7 @@ FN_DEV void dense(const unsigned char* __restrict__ blob, uint32_t off_hi, uint3
 // waves of the workgroup) stay in LDS -- frag + (ks * NPL + plane) * 1 KiB + lane * 16 -- and are fetched one k-step
 // ahead of their MFMAs instead of being held in 8 registers per k-step (136 registers for a 17-k-step layer: with them
 // a parity-mode wave does not fit the 256 registers that two workgroups per CU leave it).
-template <int PREC, int KS, int NT_TOTAL, int T0, int TN, int DEPTH = 0>
+template <int PREC, int KS, int NT_TOTAL, int T0, int TN, int DEPTH = 0, bool WLO = true>
 FN_DEV void dense_ldsb(const unsigned char* __restrict__ blob, uint32_t off_hi, uint32_t off_lo,
                        const unsigned char* frag /*LDS, written by other helpers: no restrict*/, f32x16 (&acc)[TN], int lane,
                        int t0_rt = 0) {
@@ -114,7 +117,7 @@ FN_DEV void dense_ldsb(const unsigned char* __restrict__ blob, uint32_t off_hi, 
             for (int i = 0; i < TN; ++i) {
                 const int f = (s * NT_TOTAL + T0 + i) * 64;
                 ah[s % (D + 1)][i] = whi(f);
-                if constexpr (PREC == 3) al[s % (D + 1)][i] = wlo(f);
+                if constexpr (PREC == 3 && WLO) al[s % (D + 1)][i] = wlo(f);
             }
         }
     bh[0] = *reinterpret_cast<const bf16x8*>(fl);
@@ -126,7 +129,7 @@ FN_DEV void dense_ldsb(const unsigned char* __restrict__ blob, uint32_t off_hi, 
             for (int i = 0; i < TN; ++i) {
                 const int f = ((s + D) * NT_TOTAL + T0 + i) * 64;
                 ah[(s + D) % (D + 1)][i] = whi(f);
-                if constexpr (PREC == 3) al[(s + D) % (D + 1)][i] = wlo(f);
+                if constexpr (PREC == 3 && WLO) al[(s + D) % (D + 1)][i] = wlo(f);
             }
         }
         if (s + 1 < KS) {
@@ -139,7 +142,7 @@ FN_DEV void dense_ldsb(const unsigned char* __restrict__ blob, uint32_t off_hi, 
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
             if constexpr (PREC == 3) {
-                acc[i] = mfma32(al[s % (D + 1)][i], bh[s % 3], acc[i]);
+                if constexpr (WLO) acc[i] = mfma32(al[s % (D + 1)][i], bh[s % 3], acc[i]);
                 acc[i] = mfma32(ah[s % (D + 1)][i], bl[s % 3], acc[i]);
             }
             acc[i] = mfma32(ah[s % (D + 1)][i], bh[s % 3], acc[i]);

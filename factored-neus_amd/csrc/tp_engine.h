@@ -107,14 +107,14 @@ template <int PREC> constexpr bool kTpLdsB = PREC == 3 || FNEUS_TP_LDSB_BF16;
 
 // B operand of a tensor-parallel layer: parity mode reads the fragments from LDS k-step by k-step (dense_ldsb), bf16
 // mode has the registers to hold them all (tp_gather + dense)
-template <int PREC, int KS, int NT_TOTAL, int T0, int TN>
+template <int PREC, int KS, int NT_TOTAL, int T0, int TN, bool WLO = true>
 FN_DEV void tp_dense(const unsigned char* __restrict__ blob, uint32_t off_hi, uint32_t off_lo,
                      const unsigned char* frag, const BFrag<PREC> (&bf)[kMaxKS], f32x16 (&acc)[TN], int lane,
                      int t0_rt = 0) {
     if constexpr (kTpLdsB<PREC>)
-        dense_ldsb<PREC, KS, NT_TOTAL, T0, TN, FNEUS_TP_DEPTH>(blob, off_hi, off_lo, frag, acc, lane, t0_rt);
+        dense_ldsb<PREC, KS, NT_TOTAL, T0, TN, FNEUS_TP_DEPTH, WLO>(blob, off_hi, off_lo, frag, acc, lane, t0_rt);
     else
-        dense<PREC, KS, NT_TOTAL, T0, TN, 0, FNEUS_TP_DEPTH>(blob, off_hi, off_lo, bf, acc, lane, t0_rt);
+        dense<PREC, KS, NT_TOTAL, T0, TN, 0, FNEUS_TP_DEPTH, WLO>(blob, off_hi, off_lo, bf, acc, lane, t0_rt);
 }
 template <int PREC, int KS>
 FN_DEV void tp_operands(const unsigned char* frag, int lane, BFrag<PREC> (&bf)[kMaxKS]) {

@@ -28,6 +28,7 @@ class _Workspace:
 
     def __init__(self):
         self.cache = {}
+        self.gprec = None          # gradient precision of the backward stash (ops.DEFAULT_GPREC when None)
 
     def get(self, key, factory):
         if key not in self.cache:
@@ -43,7 +44,7 @@ class SdfValueGradFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, net, samples: RaySamples, prec: int, ws: _Workspace, train: bool):
         n = samples.n
-        stash = ws.get(("sdf_stash", n, prec, train), lambda: ops.SdfStash(n, anchor.device, prec, train))
+        stash = ws.get(("sdf_stash", n, prec, train), lambda: ops.SdfStash(n, anchor.device, prec, train, gprec=ws.gprec))
         sdf, feat, normal = ops.sdf_fwd_grad(net.blob, n, prec, stash, train, **samples.kw())
         ctx.net, ctx.samples, ctx.prec, ctx.ws, ctx.stash, ctx.n = net, samples, prec, ws, stash, n
         return sdf, feat, normal
@@ -64,7 +65,7 @@ class SdfValueGradFn(torch.autograd.Function):
                 d_feat.index_add_(0, sel, dfs)
             if dns is not None:
                 d_normal.index_add_(0, sel, dns)
-        bufs = ws.get(("sdf_bwd", n, prec), lambda: ops.SdfBwdBufs(n, dev, prec))
+        bufs = ws.get(("sdf_bwd", n, prec), lambda: ops.SdfBwdBufs(n, dev, prec, gprec=ctx.stash.gprec))
         ops.sdf_bwd(net.blob, n, prec, ctx.stash, bufs, d_sdf, d_feat, d_normal, **ctx.samples.kw())
         # zeroed once: fneus_wn_backward clears what it reads, so the buffer is zero again after every step
         grad = ws.get(("sdf_grad", n), lambda: torch.zeros(net.n_params, dtype=torch.float32, device=dev))

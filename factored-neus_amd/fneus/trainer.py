@@ -32,7 +32,7 @@ WMASK_MODEL = {   # confs/wmask.conf:49-97
 class Stage1Trainer:
     def __init__(self, device, model_conf: Optional[dict] = None, prec: int = ops.PREC_PARITY, lr: float = 5e-4,
                  igr_weight: float = 0.1, mask_weight: float = 0.1, surface_weight: float = 0.1, seed: int = 0,
-                 synthetic_init: bool = True, distributed: bool = False, use_graph: bool = False):
+                 synthetic_init: bool = True, distributed: bool = False, use_graph: bool = False, gprec=None):
         from models.fields import SDFNetwork, RenderingNetwork, SingleVarianceNetwork, RefColor, NeRF
         from models.renderer import NeuSRenderer
         conf = model_conf or WMASK_MODEL
@@ -58,6 +58,7 @@ class Stage1Trainer:
         for m in self.modules:
             m.to(device)
         self.sdf_network.set_precision(prec)
+        self.sdf_network.set_gradient_precision(gprec)     # None: ops.DEFAULT_GPREC (bf16 planes)
         self.color_network.set_precision(prec)
         self.refColor_network.set_precision(prec)
         if self.nerf_outside is not None:

@@ -76,6 +76,15 @@ class _HipMLP(nn.Module):
         assert prec in (ops.PREC_FAST, ops.PREC_PARITY)
         self.prec = prec
 
+    def set_gradient_precision(self, gprec):
+        """1: the backward stash holds bf16 planes (default: the weight-gradient products carry 2^-9 rounding each), 3: hi +
+        lo planes (fp32-accurate weight gradients, twice the stash traffic); None: ops.DEFAULT_GPREC.  Forward outputs
+        do not depend on it."""
+        assert gprec in (None, 1, 3)
+        self._ws.gprec = gprec
+        for k in [k for k in self._ws.cache if k[0] in ("sdf_stash", "sdf_bwd", "sdf_jobs")]:
+            del self._ws.cache[k]
+
     def _lins(self):
         return [getattr(self, f"lin{l}") for l in range(self.num_layers - 1)]
 
