@@ -14,25 +14,10 @@
 #define FNEUS_PREFETCH_X3 4
 #define FNEUS_PREFETCH_X1 8
 #include <stdlib.h>
-#include "mlp_engine.h"
-#include "tp_engine.h"
+#include "pp_engine.h"
 #include "fneus_kernels.h"
 
 namespace fneus {
-
-// ReLU in place; returns this lane's 128 sign bits (bit 16*t + reg) for the backward pass
-FN_DEV u32x4 relu_mask8(f32x16 (&acc)[8]) {
-    u32x4 m = {0u, 0u, 0u, 0u};
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const bool pos = acc[t][r] > 0.0f;
-            acc[t][r] = pos ? acc[t][r] : 0.0f;
-            m[t >> 1] |= (pos ? 1u : 0u) << ((t & 1) * 16 + r);
-        }
-    return m;
-}
 
 template <int TN>
 FN_DEV void relu_inplace(f32x16 (&acc)[TN]) {
@@ -104,103 +89,6 @@ FN_DEV void make_side(const float (&x)[3], const float (&d)[3], const float (&nr
     }
 }
 
-template <int PREC, bool TRAIN, int VAR>
-FN_DEV void color_fwd_body(unsigned char* scr, const unsigned char* blob, const PointSrc& src, long N,
-                           const float* __restrict__ dirs,      // [N][3] or nullptr (ray mode)
-                           const float* __restrict__ normal,    // [N][3]
-                           const float* __restrict__ feat,      // [N][256]
-                           const ColStash& st, float* __restrict__ rgb_out) {
-    const int lane = threadIdx.x;
-    const int r = lane & 31, h = lane >> 5;
-    constexpr auto& LY = kColLayout;
-    for (long tile = blockIdx.x; tile * 32 < N; tile += gridDim.x) {
-        asm volatile("" : "+s"(blob));
-        const long n = tile * 32 + r;
-        const bool valid = n < N;
-        const long nc = valid ? n : N - 1;
-        const long n0 = tile * 32;
-        float side[33];
-        {
-            float x[3], d[3], nrm[3];
-            load_point(src, nc, x);
-            if (dirs) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) d[c] = dirs[nc * 3 + c];
-            } else {
-                const long ray = nc / src.m;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) d[c] = src.rays_d[ray * 3 + c];
-            }
-#pragma unroll
-            for (int c = 0; c < 3; ++c) nrm[c] = normal[nc * 3 + c];
-            make_side<VAR>(x, d, nrm, side);
-        }
-        BFrag<PREC> bf[kMaxKS];
-        f32x16 acc[8];
-        load_f32<8>(acc, feat, 256, nc, h);
-        if constexpr (TRAIN && VAR != VAR_COLOR)   // the surface head keeps its own copy of the gathered features
-            store_stash<PREC, 8>(scr, lane, acc, st.feat_hi, st.feat_lo, 256, n0, N, 256);
-        acc_to_bfrag<PREC, 8>(acc, bf);
-        vec_to_bfrag<PREC, 33, 3, 16>(side, bf, h);
-        if constexpr (TRAIN) {
-            if (valid) {
-#pragma unroll
-                for (int ks = 0; ks < 3; ++ks)
-#pragma unroll
-                    for (int g = 0; g < 2; ++g) {
-                        const int col = 16 * ks + 8 * g + 4 * h;
-                        bf16x4 vh, vl;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            vh[e] = bf[16 + ks].hi[4 * g + e];
-                            if constexpr (PREC == 3) vl[e] = bf[16 + ks].lo[4 * g + e];
-                        }
-                        *reinterpret_cast<bf16x4*>(st.side_hi + nc * 48 + col) = vh;
-                        if constexpr (PREC == 3) *reinterpret_cast<bf16x4*>(st.side_lo + nc * 48 + col) = vl;
-                    }
-            }
-        }
-        // layer 0: 19 k-steps
-        load_accvec<8, 0, 8>(blob, LY.L[0].bias, acc, lane);
-        dense<PREC, 19, 8, 0, 8>(blob, LY.L[0].fwd_hi, LY.L[0].fwd_lo, bf, acc, lane);
-        if constexpr (TRAIN) {
-            st.mask[(size_t)tile * 4 * 64 + lane] = relu_mask8(acc);
-            store_stash<PREC, 8>(scr, lane, acc, st.u_hi, st.u_lo, 256, n0, N, 256);
-        } else {
-            relu_inplace(acc);
-        }
-        acc_to_bfrag<PREC, 8>(acc, bf);
-        for (int l = 1; l <= 3; ++l) {
-            load_accvec<8, 0, 8>(blob, LY.L[l].bias, acc, lane);
-            dense<PREC, 16, 8, 0, 8>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, bf, acc, lane);
-            if constexpr (TRAIN) {
-                st.mask[((size_t)tile * 4 + l) * 64 + lane] = relu_mask8(acc);
-                store_stash<PREC, 8>(scr, lane, acc, st.u_hi + (size_t)l * N * 256, st.u_lo + (size_t)l * N * 256, 256, n0, N, 256);
-            } else {
-                relu_inplace(acc);
-            }
-            acc_to_bfrag<PREC, 8>(acc, bf);
-        }
-        f32x16 o[1];
-        load_accvec<1, 0, 1>(blob, LY.L[4].bias, o, lane);
-        dense<PREC, 16, 1, 0, 1>(blob, LY.L[4].fwd_hi, LY.L[4].fwd_lo, bf, o, lane);
-        // rows 0..2 of the single output tile live in registers 0..2 of lane half 0
-        if (valid && lane < 32) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) rgb_out[n * 3 + c] = 1.0f / (1.0f + expf(-o[0][c]));   // fields.py:173-174
-        }
-    }
-}
-
-template <int PREC, bool TRAIN, int VAR>
-__global__ void __launch_bounds__(64, 1) color_fwd_kernel(const unsigned char* blob, PointSrc src, long N,
-                                                          const float* __restrict__ dirs, const float* __restrict__ normal,
-                                                          const float* __restrict__ feat, ColStash st,
-                                                          float* __restrict__ rgb_out) {
-    __shared__ __attribute__((aligned(16))) unsigned char scr[kWaveScr];
-    color_fwd_body<PREC, TRAIN, VAR>(scr, blob, src, N, dirs, normal, feat, st, rgb_out);
-}
-
 // both RefColor heads in one launch (blockIdx.y = head): at 2 samples per ray a head is 32 workgroups, i.e. the launch
 // is as long as ONE tile's chain whatever it contains; side by side the two heads cost one such latency instead of two
 struct HeadArgs {
@@ -211,18 +99,6 @@ struct HeadArgs {
     const float* fwd_out;  // backward only: the head's forward output [N][3]
     float* d_normal;       // backward only: [N][3]
 };
-
-template <int PREC, bool TRAIN>
-__global__ void __launch_bounds__(64, 1) refcolor_fwd_both_kernel(HeadArgs cd, HeadArgs vd, PointSrc src, long N,
-                                                                  const float* __restrict__ dirs,
-                                                                  const float* __restrict__ normal,
-                                                                  const float* __restrict__ feat) {
-    __shared__ __attribute__((aligned(16))) unsigned char scr[kWaveScr];
-    if (blockIdx.y == 0)
-        color_fwd_body<PREC, TRAIN, VAR_REF_DIFFUSE>(scr, cd.blob, src, N, dirs, normal, feat, cd.st, cd.out);
-    else
-        color_fwd_body<PREC, TRAIN, VAR_REF_SPECULAR>(scr, vd.blob, src, N, dirs, normal, feat, vd.st, vd.out);
-}
 
 // gradient of the 33 side inputs (2 accumulator tiles) -> d normal of the sample, for the three input layouts
 template <int VAR>
@@ -294,101 +170,13 @@ FN_DEV void side_grad_to_dnormal(const f32x16 (&s2)[2], long n, long nc, bool va
     }
 }
 
-template <int PREC, int VAR>
-FN_DEV void color_bwd_body(unsigned char* scr, const unsigned char* blob, long N,
-                           const float* __restrict__ d_rgb,   // [N][3]
-                           const float* __restrict__ rgb,     // [N][3] forward output
-                           const ColStash& st, float* __restrict__ d_feat /*[N][256]*/,
-                           float* __restrict__ d_normal /*[N][3]*/,
-                           // surface head only: the inputs the side vector was built from
-                           const float* __restrict__ normal, const float* __restrict__ dirs,
-                           const float* __restrict__ rays_d, int m) {
-    const int lane = threadIdx.x;
-    const int r = lane & 31, h = lane >> 5;
-    constexpr auto& LY = kColLayout;
-    for (long tile = blockIdx.x; tile * 32 < N; tile += gridDim.x) {
-        asm volatile("" : "+s"(blob));
-        const long n = tile * 32 + r;
-        const bool valid = n < N;
-        const long nc = valid ? n : N - 1;
-        const long n0 = tile * 32;
-        BFrag<PREC> bf[kMaxKS];
-        f32x16 acc[10];
-        // zbar_4 = d rgb * sigmoid'  (3 rows of one tile)
-        {
-            f32x16 z[1];
-            zero_acc(z);
-            if (h == 0) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float y = rgb[nc * 3 + c];
-                    z[0][c] = valid ? d_rgb[nc * 3 + c] * y * (1.0f - y) : 0.0f;
-                }
-            }
-            store_stash<PREC, 1>(scr, lane, z, st.zbar_hi + (size_t)4 * N * 256, st.zbar_lo + (size_t)4 * N * 256, 32, n0, N, 32);
-            acc_to_bfrag<PREC, 1>(z, bf);
-        }
-        f32x16(&a8)[8] = reinterpret_cast<f32x16(&)[8]>(acc);
-        // layer 4 reverse: 2 k-steps -> 8 row tiles
-        zero_acc(a8);
-        dense<PREC, 2, 8, 0, 8>(blob, LY.L[4].rev_hi, LY.L[4].rev_lo, bf, a8, lane);
-        for (int l = 3; l >= 0; --l) {
-            // zbar_l = relu'(z_l) * ubar_{l+1}: sign bits from the forward pass (lane-private, one 16-byte load)
-            {
-                const u32x4 m = st.mask[((size_t)tile * 4 + l) * 64 + lane];
-#pragma unroll
-                for (int t = 0; t < 8; ++t)
-#pragma unroll
-                    for (int rr = 0; rr < 16; ++rr) {
-                        const bool pos = (m[t >> 1] >> ((t & 1) * 16 + rr)) & 1u;
-                        a8[t][rr] = (pos && valid) ? a8[t][rr] : 0.0f;
-                    }
-            }
-            store_stash<PREC, 8>(scr, lane, a8, st.zbar_hi + (size_t)l * N * 256, st.zbar_lo + (size_t)l * N * 256, 256, n0, N, 256);
-            acc_to_bfrag<PREC, 8>(a8, bf);
-            if (l > 0) {
-                zero_acc(a8);
-                dense<PREC, 16, 8, 0, 8>(blob, LY.L[l].rev_hi, LY.L[l].rev_lo, bf, a8, lane);
-            }
-        }
-        // layer 0 reverse: 10 row tiles (8 feature tiles + 2 side tiles)
-        zero_acc(acc);
-        dense<PREC, 16, 10, 0, 10>(blob, LY.L[0].rev_hi, LY.L[0].rev_lo, bf, acc, lane);
-        store_f32<8>(a8, d_feat, 256, nc, h, valid);
-        f32x16(&s2)[2] = reinterpret_cast<f32x16(&)[2]>(acc[8]);      // gradient of the 33 side inputs
-        side_grad_to_dnormal<VAR>(s2, n, nc, valid, lane, h, d_normal, normal, dirs, rays_d, m);
-    }
-}
-
-template <int PREC, int VAR>
-__global__ void __launch_bounds__(64, 1) color_bwd_kernel(const unsigned char* blob, long N, const float* __restrict__ d_rgb,
-                                                          const float* __restrict__ rgb, ColStash st,
-                                                          float* __restrict__ d_feat, float* __restrict__ d_normal,
-                                                          const float* __restrict__ normal, const float* __restrict__ dirs,
-                                                          const float* __restrict__ rays_d, int m) {
-    __shared__ __attribute__((aligned(16))) unsigned char scr[kWaveScr];
-    color_bwd_body<PREC, VAR>(scr, blob, N, d_rgb, rgb, st, d_feat, d_normal, normal, dirs, rays_d, m);
-}
-
-template <int PREC>
-__global__ void __launch_bounds__(64, 1) refcolor_bwd_both_kernel(HeadArgs cd, HeadArgs vd, long N,
-                                                                  const float* __restrict__ normal,
-                                                                  const float* __restrict__ dirs,
-                                                                  const float* __restrict__ rays_d, int m) {
-    __shared__ __attribute__((aligned(16))) unsigned char scr[kWaveScr];
-    if (blockIdx.y == 0)
-        color_bwd_body<PREC, VAR_REF_DIFFUSE>(scr, cd.blob, N, cd.d_out, cd.fwd_out, cd.st, cd.out, cd.d_normal, normal, dirs, rays_d, m);
-    else
-        color_bwd_body<PREC, VAR_REF_SPECULAR>(scr, vd.blob, N, vd.d_out, vd.fwd_out, vd.st, vd.out, vd.d_normal, normal, dirs, rays_d, m);
-}
-
-
-// ---- tensor-parallel form (see tp_engine.h): 4 waves share a 32-sample tile, wave w owns output tiles 2w, 2w+1 ----------
-// Same maths, stash layouts and results as the one-wave bodies above.  A wave needs < 256 registers, so two workgroups
-// share a CU and one's barrier / store phases overlap the other's MFMAs; the 32-tile launches of the RefColor heads
-// (latency-bound: a launch lasts as long as one tile's chain) get a chain that is four times shorter.
+// ---- tensor-parallel workgroups (tp_engine.h): 4 waves share a 32-sample tile, wave w owns output tiles 2w, 2w+1 ----------
+// A wave needs < 256 registers, so two workgroups share a CU and one's barrier phases overlap the other's MFMAs; the
+// 32-tile launches of the RefColor heads (latency-bound: a launch lasts as long as one tile's chain) get a chain that is
+// four times shorter.  Everything the weight-gradient GEMM needs leaves as fragment planes (fneus_pp.h, pp_engine.h):
+// the B fragments a wave publishes for the exchange are stored to global memory as they are.
 constexpr int kColTpFrag = 19 * 2 * kFragBytes;          // layer 0 has 19 k-steps (hi, lo)
-constexpr int kColTpLds = kColTpFrag + kWaveScr;         // + the shared row image: 72 192 bytes, two workgroups per CU
+constexpr int kColTpLds = kColTpFrag;
 
 FN_DEV void tp_barrier_pair() {      // what a wave without a tile to publish does while the others run tp_exchange
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -424,17 +212,18 @@ FN_DEV void color_fwd_tp_body(unsigned char* lds, const unsigned char* blob, con
                               const float* __restrict__ dirs, const float* __restrict__ normal,
                               const float* __restrict__ feat, const ColStash& st, float* __restrict__ rgb_out) {
     unsigned char* frag = lds;
-    unsigned char* img = lds + kColTpFrag;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int t0 = 2 * wave;
+    const PPLane pl = pp_lane(lane);
     constexpr auto& LY = kColLayout;
+    const long tiles = (N + 31) / 32;
+    const bool lo_planes = TRAIN && PREC == 3 && st.u_lo != nullptr;
     for (long tile = blockIdx.x; tile * 32 < N; tile += gridDim.x) {
         asm volatile("" : "+s"(blob));
         const long n = tile * 32 + r;
         const bool valid = n < N;
         const long nc = valid ? n : N - 1;
-        const long n0 = tile * 32;
         BFrag<PREC> bf[kMaxKS];
         if (wave == 0) {        // the 33 side inputs: k-steps 16..18 of layer 0, published by wave 0
             float side[33];
@@ -453,32 +242,17 @@ FN_DEV void color_fwd_tp_body(unsigned char* lds, const unsigned char* blob, con
             make_side<VAR>(x, d, nrm, side);
             vec_to_bfrag<PREC, 33, 3, 16>(side, bf, h);
             tp_write_frags<PREC, 3>(frag, lane, 16, bf, 16);
-            if constexpr (TRAIN) {
-                if (valid) {
-#pragma unroll
-                    for (int ks = 0; ks < 3; ++ks)
-#pragma unroll
-                        for (int g = 0; g < 2; ++g) {
-                            const int col = 16 * ks + 8 * g + 4 * h;
-                            bf16x4 vh, vl;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                vh[e] = bf[16 + ks].hi[4 * g + e];
-                                if constexpr (PREC == 3) vl[e] = bf[16 + ks].lo[4 * g + e];
-                            }
-                            *reinterpret_cast<bf16x4*>(st.side_hi + nc * 48 + col) = vh;
-                            if constexpr (PREC == 3) *reinterpret_cast<bf16x4*>(st.side_lo + nc * 48 + col) = vl;
-                        }
-                }
-            }
+            if constexpr (TRAIN)    // side plane [tiles][4 fragments] (fragment 3 stays zero)
+                frags_to_plane<PREC, 3>(&bf[16], 0, st.side_hi + (size_t)tile * 4 * kFragBytes,
+                                        lo_planes ? st.side_lo + (size_t)tile * 4 * kFragBytes : nullptr, pl, valid);
         }
         f32x16 acc[2];
         // the 256 features: every wave brings its two tiles (k-steps 4w .. 4w+3 of layer 0)
         load_f32<2>(acc, feat + 32 * t0, 256, nc, h);
         constexpr bool FEAT_PLANE = TRAIN && VAR != VAR_COLOR;     // the surface head keeps its own copy of the features
-        tp_exchange<PREC, 2, true, FEAT_PLANE>(frag, img, lane, t0, acc);
+        tp_exchange_pp<PREC, 2, true>(frag, lane, t0, acc, FEAT_PLANE ? st.feat_hi + (size_t)tile * kPPBlock : nullptr,
+                                      (FEAT_PLANE && lo_planes) ? st.feat_lo + (size_t)tile * kPPBlock : nullptr, pl, valid);
         tp_operands<PREC, 19>(frag, lane, bf);
-        if constexpr (FEAT_PLANE) tp_store_rows<PREC, 256>(img, lane, wave, st.feat_hi, st.feat_lo, n0, N);
         // layer 0 (19 k-steps), layers 1..3
 #pragma unroll 1
         for (int l = 0; l <= 3; ++l) {
@@ -490,10 +264,9 @@ FN_DEV void color_fwd_tp_body(unsigned char* lds, const unsigned char* blob, con
                 tp_dense<PREC, 16, 8, 0, 2>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, frag, bf, acc, lane, t0);
             const uint32_t m = relu_mask2(acc);
             if constexpr (TRAIN) reinterpret_cast<uint32_t*>(st.mask + ((size_t)tile * 4 + l) * 64 + lane)[wave] = m;
-            tp_exchange<PREC, 2, true, TRAIN>(frag, img, lane, t0, acc);
+            tp_exchange_pp<PREC, 2, true>(frag, lane, t0, acc, TRAIN ? st.u_hi + ((size_t)l * tiles + tile) * kPPBlock : nullptr,
+                                          lo_planes ? st.u_lo + ((size_t)l * tiles + tile) * kPPBlock : nullptr, pl, valid);
             tp_operands<PREC, 16>(frag, lane, bf);
-            if constexpr (TRAIN)
-                tp_store_rows<PREC, 256>(img, lane, wave, st.u_hi + (size_t)l * N * 256, st.u_lo + (size_t)l * N * 256, n0, N);
         }
         if (wave == 0) {        // output layer: one tile, rows 0..2
             f32x16 o[1];
@@ -513,22 +286,20 @@ FN_DEV void color_bwd_tp_body(unsigned char* lds, const unsigned char* blob, lon
                               float* __restrict__ d_normal, const float* __restrict__ normal,
                               const float* __restrict__ dirs, const float* __restrict__ rays_d, int m) {
     unsigned char* frag = lds;
-    unsigned char* img = lds + kColTpFrag;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int t0 = 2 * wave;
+    const PPLane pl = pp_lane(lane);
     constexpr auto& LY = kColLayout;
+    const long tiles = (N + 31) / 32;
+    const bool lo_planes = PREC == 3 && st.zbar_lo != nullptr;
     for (long tile = blockIdx.x; tile * 32 < N; tile += gridDim.x) {
         asm volatile("" : "+s"(blob));
         const long n = tile * 32 + r;
         const bool valid = n < N;
         const long nc = valid ? n : N - 1;
-        const long n0 = tile * 32;
         BFrag<PREC> bf[kMaxKS];
-        // every wave is done with the previous tile's row image before wave 0 reuses it as its scratch
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        // zbar_4 = d rgb * sigmoid' (3 rows of one tile): wave 0 writes its stash rows through the image (the others wait
-        // at the first barrier of the exchange below) and publishes k-steps 0, 1
+        // zbar_4 = d rgb * sigmoid' (3 rows of one tile): wave 0 publishes k-steps 0, 1 and stores them as the zout plane
         if (wave == 0) {
             f32x16 z[1];
             zero_acc(z);
@@ -539,8 +310,8 @@ FN_DEV void color_bwd_tp_body(unsigned char* lds, const unsigned char* blob, lon
                     z[0][c] = valid ? d_rgb[nc * 3 + c] * y * (1.0f - y) : 0.0f;
                 }
             }
-            store_stash<PREC, 1>(img, lane, z, st.zbar_hi + (size_t)4 * N * 256, st.zbar_lo + (size_t)4 * N * 256, 32, n0, N, 32);
-            tp_exchange<PREC, 1, true, false>(frag, img, lane, 0, z);
+            tp_exchange_pp<PREC, 1, true>(frag, lane, 0, z, st.zout_hi + (size_t)tile * 2 * kFragBytes,
+                                          lo_planes ? st.zout_lo + (size_t)tile * 2 * kFragBytes : nullptr, pl, valid);
         } else {
             tp_barrier_pair();
         }
@@ -559,9 +330,9 @@ FN_DEV void color_bwd_tp_body(unsigned char* lds, const unsigned char* blob, lon
                     const bool pos = (msk >> (t * 16 + rr)) & 1u;
                     acc[t][rr] = (pos && valid) ? acc[t][rr] : 0.0f;
                 }
-            tp_exchange<PREC, 2, true, true>(frag, img, lane, t0, acc);
+            tp_exchange_pp<PREC, 2, true>(frag, lane, t0, acc, st.zbar_hi + ((size_t)l * tiles + tile) * kPPBlock,
+                                          lo_planes ? st.zbar_lo + ((size_t)l * tiles + tile) * kPPBlock : nullptr, pl, valid);
             tp_operands<PREC, 16>(frag, lane, bf);
-            tp_store_rows<PREC, 256>(img, lane, wave, st.zbar_hi + (size_t)l * N * 256, st.zbar_lo + (size_t)l * N * 256, n0, N);
             if (l > 0) {
                 zero_acc(acc);
                 tp_dense<PREC, 16, 8, 0, 2>(blob, LY.L[l].rev_hi, LY.L[l].rev_lo, frag, bf, acc, lane, t0);
@@ -627,11 +398,6 @@ __global__ void __launch_bounds__(256, 2) refcolor_bwd_both_tp_kernel(HeadArgs c
 
 using namespace fneus;
 
-// tensor-parallel workgroups by default (FNEUS_COL_TP=0: one wave per tile, kept for comparison)
-static inline bool col_tp() {
-    static const int mode = getenv("FNEUS_COL_TP") ? atoi(getenv("FNEUS_COL_TP")) : 1;
-    return mode != 0;
-}
 static inline unsigned tp_grid(long n_tiles) {
     const long cap = 256 * 2 * 4;
     return (unsigned)(n_tiles < 1 ? 1 : (n_tiles < cap ? n_tiles : cap));
@@ -645,14 +411,6 @@ static inline unsigned tp_grid(long n_tiles) {
         }                                                                                                             \
         hipLaunchKernelGGL((KERNEL), GRID, dim3(256), fneus::kColTpLds, stream, __VA_ARGS__);                         \
     } while (0)
-
-static inline int grid_for(long n_tiles) {
-    long g = n_tiles;
-    const long cap = 256 * 8;
-    if (g > cap) g = cap;
-    if (g < 1) g = 1;
-    return (int)g;
-}
 
 template <int VAR>
 static int launch_fwd(const void* blob, const float* pts, const float* rays_o, const float* rays_d, const float* t, int m,
@@ -668,7 +426,7 @@ static int launch_fwd(const void* blob, const float* pts, const float* rays_o, c
     const unsigned char* b = reinterpret_cast<const unsigned char*>(blob);
     ColStash st = stash ? ColStash(*stash) : ColStash();
     if (train && VAR != VAR_COLOR && !st.feat_hi) return -2;
-    if (col_tp()) {
+    {
         dim3 g2(tp_grid((n_pts + 31) / 32));
         if (prec == 3 && train) FNEUS_TP_LAUNCH((color_fwd_tp_kernel<3, true, VAR>), g2, b, src, n_pts, dirs, normal, feat, st, out);
         else if (prec == 3) FNEUS_TP_LAUNCH((color_fwd_tp_kernel<3, false, VAR>), g2, b, src, n_pts, dirs, normal, feat, st, out);
@@ -677,18 +435,6 @@ static int launch_fwd(const void* blob, const float* pts, const float* rays_o, c
         else return -2;
         return fneus::launch_status();
     }
-    dim3 grid(grid_for((n_pts + 31) / 32)), blk(64);
-    if (prec == 3 && train)
-        hipLaunchKernelGGL((color_fwd_kernel<3, true, VAR>), grid, blk, 0, stream, b, src, n_pts, dirs, normal, feat, st, out);
-    else if (prec == 3)
-        hipLaunchKernelGGL((color_fwd_kernel<3, false, VAR>), grid, blk, 0, stream, b, src, n_pts, dirs, normal, feat, st, out);
-    else if (prec == 1 && train)
-        hipLaunchKernelGGL((color_fwd_kernel<1, true, VAR>), grid, blk, 0, stream, b, src, n_pts, dirs, normal, feat, st, out);
-    else if (prec == 1)
-        hipLaunchKernelGGL((color_fwd_kernel<1, false, VAR>), grid, blk, 0, stream, b, src, n_pts, dirs, normal, feat, st, out);
-    else
-        return -2;
-    return fneus::launch_status();
 }
 
 template <int VAR>
@@ -702,7 +448,7 @@ static int launch_bwd(const void* blob, long n_pts, const float* d_out, const fl
     if (VAR != VAR_COLOR && (!normal || (!dirs && !rays_d))) return -2;
     const unsigned char* b = reinterpret_cast<const unsigned char*>(blob);
     ColStash st(*stash);
-    if (col_tp()) {
+    {
         dim3 g2(tp_grid((n_pts + 31) / 32));
         const int mm = m > 0 ? m : 1;
         if (prec == 3) FNEUS_TP_LAUNCH((color_bwd_tp_kernel<3, VAR>), g2, b, n_pts, d_out, out, st, d_feat, d_normal, normal, dirs, rays_d, mm);
@@ -710,16 +456,6 @@ static int launch_bwd(const void* blob, long n_pts, const float* d_out, const fl
         else return -2;
         return fneus::launch_status();
     }
-    dim3 grid(grid_for((n_pts + 31) / 32)), blk(64);
-    if (prec == 3)
-        hipLaunchKernelGGL((color_bwd_kernel<3, VAR>), grid, blk, 0, stream, b, n_pts, d_out, out, st, d_feat, d_normal,
-                           normal, dirs, rays_d, m > 0 ? m : 1);
-    else if (prec == 1)
-        hipLaunchKernelGGL((color_bwd_kernel<1, VAR>), grid, blk, 0, stream, b, n_pts, d_out, out, st, d_feat, d_normal,
-                           normal, dirs, rays_d, m > 0 ? m : 1);
-    else
-        return -2;
-    return fneus::launch_status();
 }
 
 extern "C" int fneus_color_fwd(const void* blob, const float* pts, const float* rays_o, const float* rays_d,
@@ -773,7 +509,7 @@ extern "C" int fneus_refcolor_fwd_both(const void* blob_cd, const void* blob_vd,
     HeadArgs vd{reinterpret_cast<const unsigned char*>(blob_vd), stash_vd ? ColStash(*stash_vd) : ColStash(), spec_out,
                 nullptr, nullptr, nullptr};
     if (train && (!cd.st.feat_hi || !vd.st.feat_hi)) return -2;
-    if (col_tp()) {
+    {
         dim3 g2(tp_grid((n_pts + 31) / 32), 2);
         if (prec == 3 && train) FNEUS_TP_LAUNCH((refcolor_fwd_both_tp_kernel<3, true>), g2, cd, vd, src, n_pts, dirs, normal, feat);
         else if (prec == 3) FNEUS_TP_LAUNCH((refcolor_fwd_both_tp_kernel<3, false>), g2, cd, vd, src, n_pts, dirs, normal, feat);
@@ -782,18 +518,6 @@ extern "C" int fneus_refcolor_fwd_both(const void* blob_cd, const void* blob_vd,
         else return -2;
         return fneus::launch_status();
     }
-    dim3 grid(grid_for((n_pts + 31) / 32), 2), blk(64);
-    if (prec == 3 && train)
-        hipLaunchKernelGGL((refcolor_fwd_both_kernel<3, true>), grid, blk, 0, stream, cd, vd, src, n_pts, dirs, normal, feat);
-    else if (prec == 3)
-        hipLaunchKernelGGL((refcolor_fwd_both_kernel<3, false>), grid, blk, 0, stream, cd, vd, src, n_pts, dirs, normal, feat);
-    else if (prec == 1 && train)
-        hipLaunchKernelGGL((refcolor_fwd_both_kernel<1, true>), grid, blk, 0, stream, cd, vd, src, n_pts, dirs, normal, feat);
-    else if (prec == 1)
-        hipLaunchKernelGGL((refcolor_fwd_both_kernel<1, false>), grid, blk, 0, stream, cd, vd, src, n_pts, dirs, normal, feat);
-    else
-        return -2;
-    return fneus::launch_status();
 }
 
 extern "C" int fneus_refcolor_bwd_both(const void* blob_cd, const void* blob_vd, long n_pts, const float* rays_d, int m,
@@ -808,7 +532,7 @@ extern "C" int fneus_refcolor_bwd_both(const void* blob_cd, const void* blob_vd,
     HeadArgs cd{reinterpret_cast<const unsigned char*>(blob_cd), ColStash(*stash_cd), d_feat2, d_diffuse, diffuse, d_normal2};
     HeadArgs vd{reinterpret_cast<const unsigned char*>(blob_vd), ColStash(*stash_vd), d_feat2 + n_pts * 256, d_spec, spec,
                 d_normal2 + n_pts * 3};
-    if (col_tp()) {
+    {
         dim3 g2(tp_grid((n_pts + 31) / 32), 2);
         const int mm = m > 0 ? m : 1;
         if (prec == 3) FNEUS_TP_LAUNCH((refcolor_bwd_both_tp_kernel<3>), g2, cd, vd, n_pts, normal, dirs, rays_d, mm);
@@ -816,12 +540,4 @@ extern "C" int fneus_refcolor_bwd_both(const void* blob_cd, const void* blob_vd,
         else return -2;
         return fneus::launch_status();
     }
-    dim3 grid(grid_for((n_pts + 31) / 32), 2), blk(64);
-    if (prec == 3)
-        hipLaunchKernelGGL(refcolor_bwd_both_kernel<3>, grid, blk, 0, stream, cd, vd, n_pts, normal, dirs, rays_d, m > 0 ? m : 1);
-    else if (prec == 1)
-        hipLaunchKernelGGL(refcolor_bwd_both_kernel<1>, grid, blk, 0, stream, cd, vd, n_pts, normal, dirs, rays_d, m > 0 ? m : 1);
-    else
-        return -2;
-    return fneus::launch_status();
 }

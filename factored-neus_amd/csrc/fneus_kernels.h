@@ -19,13 +19,13 @@ struct SdfStash {
     unsigned char *pe_hi, *pe_lo;     // [tiles][4 KiB]
     unsigned char *h_hi, *h_lo;       // [8][tiles][16 KiB]
     unsigned char *a_hi, *a_lo;       // [8][tiles][16 KiB]
-    __bf16 *feat_hi, *feat_lo;        // [N][256] row-major
+    unsigned char *feat_hi, *feat_lo; // [tiles][16 KiB]     feature vector (colour-network input)
     unsigned char* ps;                // sigma'(z_l), u16 fixed point: [tiles][8][16 KiB]
     SdfStash() = default;
     SdfStash(const FneusSdfStash& s)
         : pe_hi((unsigned char*)s.pe_hi), pe_lo((unsigned char*)s.pe_lo), h_hi((unsigned char*)s.h_hi),
           h_lo((unsigned char*)s.h_lo), a_hi((unsigned char*)s.a_hi), a_lo((unsigned char*)s.a_lo),
-          feat_hi((__bf16*)s.feat_hi), feat_lo((__bf16*)s.feat_lo), ps((unsigned char*)s.ps) {}
+          feat_hi((unsigned char*)s.feat_hi), feat_lo((unsigned char*)s.feat_lo), ps((unsigned char*)s.ps) {}
 };
 
 struct SdfBwdBufs {
@@ -42,18 +42,19 @@ struct SdfBwdBufs {
           c_lo((unsigned char*)s.c_lo) {}
 };
 
-struct ColStash {
-    __bf16* side_hi; __bf16* side_lo;   // [N][48]      pts | PE4(view) | normal (cols >= 33 zero)
-    __bf16* u_hi;    __bf16* u_lo;      // [4][N][256]  slot l = relu output of layer l (= input of l+1)
-    __bf16* zbar_hi; __bf16* zbar_lo;   // [5][N][256]  slot l = dL/dz_l (slot 4 uses 32-wide rows)
+struct ColStash {                       // fragment planes (include/fneus.h FneusColStash)
+    unsigned char *side_hi, *side_lo;   // [tiles][4 KiB]      pts | PE4(view) | normal (33 of 64 features)
+    unsigned char *u_hi, *u_lo;         // [4][tiles][16 KiB]  slot l = relu output of layer l (= input of l+1)
+    unsigned char *zbar_hi, *zbar_lo;   // [4][tiles][16 KiB]  slot l = dL/dz_l
+    unsigned char *zout_hi, *zout_lo;   // [tiles][2 KiB]      dL/dz of the output layer (3 features)
     u32x4* mask;                        // lane-private ReLU masks: [tiles][4][64] x 128 bits
-    __bf16* feat_hi; __bf16* feat_lo;   // [N][256]     surface head only: its (gathered) input features
-    ColStash() : side_hi(nullptr), side_lo(nullptr), u_hi(nullptr), u_lo(nullptr), zbar_hi(nullptr), zbar_lo(nullptr),
-                 mask(nullptr), feat_hi(nullptr), feat_lo(nullptr) {}
+    unsigned char *feat_hi, *feat_lo;   // [tiles][16 KiB]     surface head only: its (gathered) input features
+    ColStash() { memset(this, 0, sizeof(*this)); }
     ColStash(const FneusColStash& s)
-        : side_hi((__bf16*)s.side_hi), side_lo((__bf16*)s.side_lo), u_hi((__bf16*)s.u_hi), u_lo((__bf16*)s.u_lo),
-          zbar_hi((__bf16*)s.zbar_hi), zbar_lo((__bf16*)s.zbar_lo), mask((u32x4*)s.mask), feat_hi((__bf16*)s.feat_hi),
-          feat_lo((__bf16*)s.feat_lo) {}
+        : side_hi((unsigned char*)s.side_hi), side_lo((unsigned char*)s.side_lo), u_hi((unsigned char*)s.u_hi),
+          u_lo((unsigned char*)s.u_lo), zbar_hi((unsigned char*)s.zbar_hi), zbar_lo((unsigned char*)s.zbar_lo),
+          zout_hi((unsigned char*)s.zout_hi), zout_lo((unsigned char*)s.zout_lo), mask((u32x4*)s.mask),
+          feat_hi((unsigned char*)s.feat_hi), feat_lo((unsigned char*)s.feat_lo) {}
 };
 
 struct NerfStash {

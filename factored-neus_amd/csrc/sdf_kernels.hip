@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(64 * WAVES, 1) sdf_fwd_tp_kernel(const unsigne
 // training, the same fragments -> global memory as the layer's plane (fneus_pp.h: one 16-byte store per lane and
 // fragment, hi part; lo part only in the exact-gradient mode), barrier.  No row image, no transposition: the
 // weight-gradient GEMM reads the fragments as they are.
-constexpr int kTp2Lds = kTpLds + kWaveScr;       // fragments + row image of the feature planes (colour-network operand)
+constexpr int kTp2Lds = kTpLds;                  // the B fragments of the layer in flight
 
 // positional encoding of x as B fragments KS0..KS0+2, recomputed where needed (the point is laundered so that the
 // evaluations are not merged and kept in 24 registers)
@@ -213,7 +213,6 @@ __global__ void __launch_bounds__(256, 2) sdf_fwd_grad_tp_kernel(const unsigned 
                                                                  float* __restrict__ normal_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
     unsigned char* frag = lds_;
-    unsigned char* img = lds_ + kTpLds;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int t0 = 2 * wave;
@@ -226,7 +225,6 @@ __global__ void __launch_bounds__(256, 2) sdf_fwd_grad_tp_kernel(const unsigned 
         const long n = tile * 32 + r;
         const bool valid = n < N;
         const long nc = valid ? n : N - 1;
-        const long n0 = tile * 32;
         unsigned char* sig_t = st.ps + (size_t)tile * 8 * kPPBlock;      // sigma' blocks of this tile, [layer]
         float x[3];
         load_point(src, nc, x);
@@ -283,10 +281,9 @@ __global__ void __launch_bounds__(256, 2) sdf_fwd_grad_tp_kernel(const unsigned 
         load_accvec<9, 0, 2>(blob, LY.L[8].bias, acc, lane, t0);
         tp_dense<PREC, 16, 9, 0, 2>(blob, LY.L[8].fwd_hi, LY.L[8].fwd_lo, frag, bf, acc, lane, t0);
         store_f32<2>(acc, feat_out + 32 * t0, 256, nc, h, valid);
-        if constexpr (TRAIN) {      // row-major feature planes: the colour network's weight-gradient operand (old format)
-            tp_exchange<PREC, 2, false, true>(frag, img, lane, t0, acc);
-            tp_store_rows<PREC, 256>(img, lane, wave, st.feat_hi, st.feat_lo, n0, N);
-        }
+        if constexpr (TRAIN)        // the feature plane: the colour network's weight-gradient operand
+            tp_exchange_pp<PREC, 2, false>(frag, lane, t0, acc, st.feat_hi + (size_t)tile * kPPBlock,
+                                           lo_planes ? st.feat_lo + (size_t)tile * kPPBlock : nullptr, pl, valid);
         if (wave == 0) {
             f32x16 s1[1];
             load_accvec<9, 8, 1>(blob, LY.L[8].bias, s1, lane);

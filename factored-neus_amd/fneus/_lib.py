@@ -30,7 +30,7 @@ class FneusSdfBwdBufs(C.Structure):
 
 class FneusColStash(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
-                ("side_hi", "side_lo", "u_hi", "u_lo", "zbar_hi", "zbar_lo", "mask", "feat_hi", "feat_lo")]
+                ("side_hi", "side_lo", "u_hi", "u_lo", "zbar_hi", "zbar_lo", "zout_hi", "zout_lo", "mask", "feat_hi", "feat_lo")]
 
 
 class FneusNerfStash(C.Structure):

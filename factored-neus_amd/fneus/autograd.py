@@ -85,7 +85,8 @@ class ColorFn(torch.autograd.Function):
                 train: bool, head: int = 0):
         n = samples.n
         normal, feat = normal.contiguous(), feat.contiguous()
-        stash = ws.get(("col_stash", n, prec), lambda: ops.ColStash(n, anchor.device, prec, with_feat=head != 0)) if train else None
+        stash = ws.get(("col_stash", n, prec), lambda: ops.ColStash(n, anchor.device, prec, with_feat=head != 0,
+                                                                    gprec=ws.gprec)) if train else None
         rgb = ops.color_fwd(net.blob, n, prec, normal, feat, stash, train, dirs=samples.dirs, head=head, **samples.kw())
         ctx.net, ctx.prec, ctx.ws, ctx.sdf_ws, ctx.stash, ctx.n, ctx.head, ctx.samples = net, prec, ws, sdf_ws, stash, n, head, samples
         if head != 0:
@@ -110,7 +111,7 @@ class ColorFn(torch.autograd.Function):
         grad = ws.get(("col_grad", n), lambda: torch.zeros(net.n_params, dtype=torch.float32, device=rgb.device))
         jobs = ws.get(("col_jobs", n, prec), lambda: ops.color_dw_jobs(net, feat_planes, ctx.stash, grad, n))
         with ops.on_side_stream(4 if head == 0 else 2):
-            jobs.run(n, prec)
+            jobs.run()
             net.wn_backward(grad)
         return None, d_normal, d_feat, None, None, None, None, None, None, None
 
@@ -147,8 +148,8 @@ class RefHeadsFn(torch.autograd.Function):
     def forward(ctx, anchor, normal, feat, net_cd, net_vd, samples: RaySamples, prec: int, ws: _Workspace, train: bool):
         n = samples.n
         normal, feat = normal.contiguous(), feat.contiguous()
-        st = ws.get(("ref_stash", n, prec), lambda: (ops.ColStash(n, anchor.device, prec, with_feat=True),
-                                                     ops.ColStash(n, anchor.device, prec, with_feat=True))) if train else (None, None)
+        st = ws.get(("ref_stash", n, prec), lambda: (ops.ColStash(n, anchor.device, prec, with_feat=True, gprec=ws.gprec),
+                                                     ops.ColStash(n, anchor.device, prec, with_feat=True, gprec=ws.gprec))) if train else (None, None)
         diffuse, spec = ops.refcolor_fwd_both(net_cd.blob, net_vd.blob, n, prec, normal, feat, st[0], st[1], train,
                                               dirs=samples.dirs, **samples.kw())
         ctx.nets, ctx.prec, ctx.ws, ctx.st, ctx.n, ctx.samples = (net_cd, net_vd), prec, ws, st, n, samples
@@ -168,13 +169,13 @@ class RefHeadsFn(torch.autograd.Function):
         g_cd, g_vd = grad[:net_cd.n_params], grad[net_cd.n_params:]
 
         def build():
-            jobs = ops.GemmJobs(grad.device, "refcolor")
+            jobs = ops.GemmPPJobs(grad.device, "refcolor")
             ops.color_dw_jobs(net_cd, st[0].feat, st[0], g_cd, n, into=jobs)
             ops.color_dw_jobs(net_vd, st[1].feat, st[1], g_vd, n, into=jobs)
-            return jobs.finalize()
+            return jobs.finalize(st[0].tiles)
 
         with ops.on_side_stream(2):          # only Adam consumes these: off the critical path of the backward
-            ws.get(("ref_jobs", n, prec), build).run(n, prec)
+            ws.get(("ref_jobs", n, prec), build).run()
             net_cd.wn_backward(g_cd)
             net_vd.wn_backward(g_vd)
         return None, d_normal2.sum(0), d_feat2.sum(0), None, None, None, None, None, None

@@ -216,7 +216,7 @@ def _gprec(prec: int, gprec: Optional[int]) -> int:
 
 class SdfStash:
     """Activation stash written by sdf_fwd_grad (include/fneus.h FneusSdfStash): fragment planes (fneus/pp.py) for
-    h_l, a_l and the positional encoding, the lane-private sigma' plane, row-major feature planes."""
+    h_l, a_l, the feature vector and the positional encoding, the lane-private sigma' plane."""
 
     def __init__(self, n: int, device, prec: int, train: bool, gprec: Optional[int] = None):
         self.n, self.prec, self.gprec = n, prec, _gprec(prec, gprec)
@@ -226,8 +226,7 @@ class SdfStash:
         self.pe = torch.zeros((P, T, 4, 64, 8), dtype=bf, device=device) if train else None      # fragment 3 stays zero
         self.h = torch.empty((P, 8, T, 16, 64, 8), dtype=bf, device=device) if train else None
         self.a = torch.empty((P, 8, T, 16, 64, 8), dtype=bf, device=device) if train else None
-        # row-major hi / lo planes of the feature vector: the colour network's weight-gradient operand
-        self.feat = torch.empty((2 if prec == 3 else 1, n, 256), dtype=bf, device=device) if train else None
+        self.feat = torch.empty((P, T, 16, 64, 8), dtype=bf, device=device) if train else None   # colour-network operand
         self.ps = torch.empty((T, 8, 16, 64, 8), dtype=torch.int16, device=device)      # sigma' as u16 fixed point
         s = _lib.FneusSdfStash()
         s.ps = self.ps.data_ptr()
@@ -306,21 +305,26 @@ class SdfBwdBufs:
 
 
 class ColStash:
-    def __init__(self, n: int, device, prec: int, with_feat: bool = False):
+    """stash of a colour-shaped MLP (include/fneus.h FneusColStash): fragment planes + the lane-private ReLU masks"""
+
+    def __init__(self, n: int, device, prec: int, with_feat: bool = False, gprec: Optional[int] = None):
         bf = torch.bfloat16
-        planes = 2 if prec == 3 else 1
-        self.feat = torch.empty((planes, n, 256), dtype=bf, device=device) if with_feat else None
-        self.side = torch.zeros((planes, n, 48), dtype=bf, device=device)
-        self.u = torch.empty((planes, 4, n, 256), dtype=bf, device=device)
-        self.zbar = torch.zeros((planes, 5, n, 256), dtype=bf, device=device)
-        self.mask = torch.zeros((((n + 31) // 32 + 3) // 4 * 4) * 4 * 64 * 4, dtype=torch.int32, device=device)
+        self.n, self.gprec = n, _gprec(prec, gprec)
+        P = 2 if self.gprec == 3 else 1
+        T = self.tiles = (n + 31) // 32
+        self.feat = torch.empty((P, T, 16, 64, 8), dtype=bf, device=device) if with_feat else None
+        self.side = torch.zeros((P, T, 4, 64, 8), dtype=bf, device=device)           # fragment 3 stays zero
+        self.u = torch.empty((P, 4, T, 16, 64, 8), dtype=bf, device=device)
+        self.zbar = torch.zeros((P, 4, T, 16, 64, 8), dtype=bf, device=device)
+        self.zout = torch.zeros((P, T, 2, 64, 8), dtype=bf, device=device)
+        self.mask = torch.zeros(T * 4 * 64 * 4, dtype=torch.int32, device=device)
         s = _lib.FneusColStash()
         s.mask = self.mask.data_ptr()
-        for name, t in (("side", self.side), ("u", self.u), ("zbar", self.zbar), ("feat", self.feat)):
+        for name, t in (("side", self.side), ("u", self.u), ("zbar", self.zbar), ("zout", self.zout), ("feat", self.feat)):
             if t is None:
                 continue
             setattr(s, name + "_hi", t[0].data_ptr())
-            setattr(s, name + "_lo", t[1].data_ptr() if planes == 2 else None)
+            setattr(s, name + "_lo", t[1].data_ptr() if P == 2 else None)
         self.c = s
 
 
@@ -476,12 +480,14 @@ class GemmPPJobs:
         self.bytes.append((A.tiles + B.tiles) * 2048 * (2 if A2 is not None else 1))
         return self
 
-    def finalize(self, n_sample_tiles: int):
-        """distribute ~target workgroups over the jobs in proportion to the bytes each streams"""
+    def finalize(self, n_sample_tiles: int, min_tiles: int = 4):
+        """distribute ~target workgroups over the jobs in proportion to the bytes each streams; a workgroup owns at least
+        `min_tiles` sample tiles (its epilogue is up to 65 536 atomics whatever it summed)"""
         tot = float(sum(self.bytes))
         base = 0
+        cap = max(1, n_sample_tiles // min_tiles)
         for j, b in zip(self.jobs, self.bytes):
-            s = max(1, min(n_sample_tiles, int(round(self.target * b / tot))))
+            s = max(1, min(cap, int(round(self.target * b / tot))))
             j.wg_base, j.splits = base, s
             base += s
         self.n_wgs, self.n_sample_tiles = base, n_sample_tiles
@@ -527,23 +533,24 @@ def sdf_dw_jobs(net: PackedNet, stash: SdfStash, bufs: SdfBwdBufs, grad_flat: to
 
 
 def color_dw_jobs(net: PackedNet, feat_planes: torch.Tensor, stash: ColStash, grad_flat: torch.Tensor, n: int,
-                  into: Optional[GemmJobs] = None) -> GemmJobs:
-    """dW of a colour-shaped MLP (colour network: feat_planes = SdfStash.feat; RefColor heads: their own ColStash.feat).
-    `into`: append to that job table instead of finalising a new one (several small networks in one launch)."""
-    g = into if into is not None else GemmJobs(grad_flat.device, net.kind)
+                  into: Optional[GemmPPJobs] = None) -> GemmPPJobs:
+    """dW of a colour-shaped MLP (colour network: feat_planes = SdfStash.feat; RefColor heads: their own ColStash.feat)
+    from fragment planes.  `into`: append to that job table instead of finalising a new one (several small networks in
+    one launch)."""
+    g = into if into is not None else GemmPPJobs(grad_flat.device, net.kind)
+    O = PPOperand
     offW, offb = net.desc["offW"], net.desc["offb"]
     n_side, ld0, n_out = net.desc["n_side"], net.desc["ins"][0], net.desc["outs"][4]
     base = grad_flat.data_ptr()
+    assert feat_planes.shape[0] == stash.zbar.shape[0], "feature planes and colour stash differ in gradient precision"
     # layer 0: columns 0..n_side-1 = side inputs, then the 256 features
-    g.add(stash.zbar[:, 0], feat_planes, base + 4 * (offW[0] + n_side), ld0, 256, 256, 256, 256, 256, 256,
-          bias_ptr=base + 4 * offb[0])
-    g.add(stash.zbar[:, 0], stash.side, base + 4 * offW[0], ld0, 256, n_side, 256, 48, 256, 48)
+    g.add(O(stash.zbar[:, 0], 0, 8), O(feat_planes, 0, 8), base + 4 * (offW[0] + n_side), ld0, 256, 256, bias_ptr=base + 4 * offb[0])
+    g.add(O(stash.zbar[:, 0], 0, 8), O(stash.side, 0, 2), base + 4 * offW[0], ld0, 256, n_side)
     for l in (1, 2, 3):
-        g.add(stash.zbar[:, l], stash.u[:, l - 1], base + 4 * offW[l], 256, 256, 256, 256, 256, 256, 256,
-              bias_ptr=base + 4 * offb[l])
-    g.add(stash.zbar[:, 4], stash.u[:, 3], base + 4 * offW[4], 256, n_out, 256, 32, 256, 32, 256,
-          bias_ptr=base + 4 * offb[4])
-    return g if into is not None else g.finalize()
+        g.add(O(stash.zbar[:, l], 0, 8), O(stash.u[:, l - 1], 0, 8), base + 4 * offW[l], 256, 256, 256, bias_ptr=base + 4 * offb[l])
+    g.add(O(stash.zout, 0, 1), O(stash.u[:, 3], 0, 8), base + 4 * offW[4], 256, n_out, 256, bias_ptr=base + 4 * offb[4])
+    g.gprec = stash.gprec
+    return g if into is not None else g.finalize(stash.tiles)
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -58,7 +58,8 @@ class Stage1Trainer:
         for m in self.modules:
             m.to(device)
         self.sdf_network.set_precision(prec)
-        self.sdf_network.set_gradient_precision(gprec)     # None: ops.DEFAULT_GPREC (bf16 planes)
+        for m in (self.sdf_network, self.color_network, self.refColor_network):
+            m.set_gradient_precision(gprec)                 # None: ops.DEFAULT_GPREC (bf16 planes)
         self.color_network.set_precision(prec)
         self.refColor_network.set_precision(prec)
         if self.nerf_outside is not None:

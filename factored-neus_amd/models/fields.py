@@ -82,7 +82,7 @@ class _HipMLP(nn.Module):
         do not depend on it."""
         assert gprec in (None, 1, 3)
         self._ws.gprec = gprec
-        for k in [k for k in self._ws.cache if k[0] in ("sdf_stash", "sdf_bwd", "sdf_jobs")]:
+        for k in [k for k in self._ws.cache if k[0] in ("sdf_stash", "sdf_bwd", "sdf_jobs", "col_stash", "col_jobs")]:
             del self._ws.cache[k]
 
     def _lins(self):
@@ -332,6 +332,13 @@ class RefColor(nn.Module):
     def set_precision(self, prec: int):
         assert prec in (ops.PREC_FAST, ops.PREC_PARITY)
         self.prec = prec
+
+    def set_gradient_precision(self, gprec):
+        """see SDFNetwork.set_gradient_precision"""
+        assert gprec in (None, 1, 3)
+        self._cd.ws.gprec = gprec
+        for k in [k for k in self._cd.ws.cache if k[0] in ("ref_stash", "ref_jobs")]:
+            del self._cd.ws.cache[k]
 
     def refresh(self):
         """pack the current parameters of both MLPs (once per optimiser step, before rendering)"""

@@ -32,23 +32,25 @@ typedef void* fneus_stream_t; /* hipStream_t */
  * h, a, pe are FRAGMENT PLANES (csrc/fneus_pp.h): per 32-sample tile the MFMA B fragments of a layer (1 KiB each = 16
  * features x 32 samples), bf16; tiles = ceil(N / 32).  The *_lo planes carry the bf16 remainder of every value: they are
  * optional (NULL = not written / not read; "gradient precision" 1) -- with them the weight gradients are fp32-accurate
- * (gradient precision 3).  feat is still a row-major hi / lo pair: the colour network's weight-gradient operand. */
+ * (gradient precision 3). */
 typedef struct FneusSdfStash {
     uint16_t* pe_hi;   uint16_t* pe_lo;   /* [tiles][4][512]      positional encoding (39 of 64 features; fragment 3 stays zero) */
     uint16_t* h_hi;    uint16_t* h_lo;    /* [8][tiles][16][512]  slot l = softplus output of layer l (= input of l+1)       */
     uint16_t* a_hi;    uint16_t* a_lo;    /* [8][tiles][16][512]  slot l = a_l = sigma'(z_l) * d sdf/d h_{l+1}  (train != 0)  */
-    uint16_t* feat_hi; uint16_t* feat_lo; /* [N][256] row-major   feature vector (colour-network input; train != 0)          */
+    uint16_t* feat_hi; uint16_t* feat_lo; /* [tiles][16][512]     feature vector (colour-network input; train != 0)          */
     void* ps; /* sigma'(z_l) as 16-bit fixed point, lane-private: [tiles][8][16][64] x 16 bytes                              */
 } FneusSdfStash;
 
-/* bf16 planes of the colour network (written by fneus_color_fwd with train != 0 / fneus_color_bwd). */
+/* Stash of the colour network / of one RefColor MLP (written by fneus_color_fwd with train != 0 and fneus_color_bwd):
+ * fragment planes like FneusSdfStash, *_lo optional in the same way. */
 typedef struct FneusColStash {
-    uint16_t* side_hi; uint16_t* side_lo; /* [N][48]     pts | PE4(view) | normal (cols >= 33 zero)           */
-    uint16_t* u_hi;    uint16_t* u_lo;    /* [4][N][256] slot l = ReLU output of layer l (= input of l+1)     */
-    uint16_t* zbar_hi; uint16_t* zbar_lo; /* [5][N][256] slot l = dL/dz_l  (slot 4: 32-wide rows, 3 valid)   */
-    void* mask;                           /* lane-private ReLU masks: [ceil(N/32)][4][64] x 16 bytes           */
-    uint16_t* feat_hi; uint16_t* feat_lo; /* [N][256]    fneus_refcolor_* only: copy of the input features; NULL for
-                                                          the colour network (its features are FneusSdfStash.feat)    */
+    uint16_t* side_hi; uint16_t* side_lo; /* [tiles][4][512]      pts | PE4(view) | normal (33 of 64 features; fragment 3 zero) */
+    uint16_t* u_hi;    uint16_t* u_lo;    /* [4][tiles][16][512]  slot l = ReLU output of layer l (= input of l+1)            */
+    uint16_t* zbar_hi; uint16_t* zbar_lo; /* [4][tiles][16][512]  slot l = dL/dz_l                                             */
+    uint16_t* zout_hi; uint16_t* zout_lo; /* [tiles][2][512]      dL/dz of the output layer (3 features)                       */
+    void* mask;                           /* lane-private ReLU masks: [tiles][4][64] x 16 bytes                                */
+    uint16_t* feat_hi; uint16_t* feat_lo; /* [tiles][16][512]     fneus_refcolor_* only: copy of the input features; NULL for
+                                                                   the colour network (its features are FneusSdfStash.feat)    */
 } FneusColStash;
 
 /* work buffers of fneus_sdf_bwd: the operands of the weight-gradient GEMM (fragment planes like FneusSdfStash, *_lo

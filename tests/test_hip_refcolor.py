@@ -54,14 +54,17 @@ def test_refcolor_forward_matches_oracle(prec, tol):
         assert err <= tol, k
 
 
-@pytest.mark.parametrize("prec,tol,gtol", [(3, 1e-4, 5e-4), (1, 3e-2, 1e-1)])
-def test_refcolor_gradients_match_oracle(prec, tol, gtol):
+# gprec 3: hi + lo planes (fp32-accurate weight gradients); gprec 1 (training default): bf16 planes, every product of the
+# weight-gradient GEMM carries 2^-9 rounding (random cotangents: no cancellation); input gradients do not depend on it
+@pytest.mark.parametrize("prec,gprec,tol,gtol,wtol", [(3, 3, 1e-4, 5e-4, 5e-4), (3, 1, 1e-4, 5e-4, 6e-3), (1, 1, 3e-2, 1e-1, 1e-1)])
+def test_refcolor_gradients_match_oracle(prec, gprec, tol, gtol, wtol):
     from oracle import ref_torch as R
     dev = torch.device("cuda:0")
     m = 1024
     pts, feat, d, n = _inputs(m, 4)
     rs = np.random.RandomState(9)
     mod, sd = _module(32, prec)
+    mod.set_gradient_precision(gprec)
     # ---- oracle, fp64 autograd; the loss goes through the heads before the (piecewise) sRGB transfer and clipping
     sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
     n64, f64 = n.double().requires_grad_(True), feat.double().requires_grad_(True)
@@ -96,9 +99,9 @@ def test_refcolor_gradients_match_oracle(prec, tol, gtol):
     worst = 0.0
     for name, p in mod.named_parameters():
         e = rel_err(p.grad, sd64[name].grad)
-        print(f"  refcolor prec={prec} d {name}: rel {e:.3e}")
+        print(f"  refcolor prec={prec} gprec={gprec} d {name}: rel {e:.3e}")
         worst = max(worst, e)
-    assert worst <= gtol
+    assert worst <= wtol
 
 
 def test_refcolor_state_dict_roundtrip_through_flat_buffers():

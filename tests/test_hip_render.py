@@ -21,7 +21,7 @@ def load(golden_dir, name):
     return dict(np.load(os.path.join(golden_dir, name + ".npz")))
 
 
-def build(g, prec):
+def build(g, prec, gprec=None):
     from fneus import synth
     from models.fields import SDFNetwork, RenderingNetwork, SingleVarianceNetwork, RefColor, NeRF
     from models.renderer import NeuSRenderer
@@ -38,6 +38,8 @@ def build(g, prec):
         m.to(DEV)
     sdf.set_precision(prec)
     col.set_precision(prec)
+    for m in (sdf, col, ref):
+        m.set_gradient_precision(gprec)
     nerf = None
     if int(g["n_outside"]) > 0:
         nerf = NeRF(D=8, d_in=4, d_in_view=3, W=256, multires=10, multires_view=4, output_ch=4, skips=[4], use_viewdirs=True)
@@ -48,9 +50,9 @@ def build(g, prec):
     return rnd, dict(sdf=sdf, color=col, var=var, refcolor=ref, nerf=nerf)
 
 
-def run(g, prec, teacher_z, fused_loss=False):
+def run(g, prec, teacher_z, fused_loss=False, gprec=None):
     from oracle import ref_torch as R
-    rnd, nets = build(g, prec)
+    rnd, nets = build(g, prec, gprec)
     data = T(g["data"]).to(DEV)
     rays_o, rays_d, rgb, mask = data[:, :3], data[:, 3:6], data[:, 6:9], data[:, 9:10]
     near, far = R.near_far_from_sphere(rays_o, rays_d)
@@ -99,14 +101,18 @@ def test_render_end_to_end(golden_dir, name):
     assert maxerr(out["_z_vals"], g["trace/z_3"]) <= 3e-3
 
 
+@pytest.mark.parametrize("gprec", [3, 1], ids=["grad_hi_lo", "grad_bf16"])
 @pytest.mark.parametrize("fused", [False, True], ids=["torch_loss", "fused_loss"])
 @pytest.mark.parametrize("name", WMASK[:2] + WOMASK)
-def test_loss_and_gradients(golden_dir, name, fused):
+def test_loss_and_gradients(golden_dir, name, fused, gprec):
     """fused: shading + blend + losses + their gradients from fneus_stage1_loss (what the training step uses);
-    otherwise the same terms written with torch ops on the render dict"""
+    otherwise the same terms written with torch ops on the render dict.
+    gprec 3: the backward stash holds hi + lo planes (fp32-accurate weight gradients); gprec 1 (the training default):
+    bf16 planes -- every product of the weight-gradient GEMMs carries 2^-9 rounding, which shows where a sum cancels
+    (bias gradients of 3 outputs over 512 samples)."""
     from fneus.losses import stage1_loss
     g = load(golden_dir, name)
-    out, nets, (rgb, mask) = run(g, 3, teacher_z=True, fused_loss=fused)
+    out, nets, (rgb, mask) = run(g, 3, teacher_z=True, fused_loss=fused, gprec=gprec)
     if fused:
         losses = out["losses"]
         assert maxerr(out["surface_color"], g["out/surface_color"]) <= 1e-4
@@ -136,13 +142,13 @@ def test_loss_and_gradients(golden_dir, name, fused):
         worst = max(worst, e_sub, e_norm)
         # RefColor is a ReLU MLP evaluated on only 2 samples per masked ray: a single unit whose pre-activation sits
         # within rounding of zero shows up in an individual weight-gradient entry
-        lim_sub = 3e-2 if net in ("refcolor", "nerf") else 5e-3
+        lim_sub = 3e-2 if net in ("refcolor", "nerf") else (5e-3 if gprec == 3 else 8e-3)
         # background NeRF (K7): 9 ReLU layers on only 16 x 24 samples -- one unit at a ReLU boundary is 0.5 % of a norm
         # (tests/test_hip_nerf.py masks such samples and sees 1e-5)
-        lim_norm = 1e-2 if net == "nerf" else 2e-3
+        lim_norm = 1e-2 if net == "nerf" else (2e-3 if gprec == 3 else 5e-3)
         assert e_sub <= lim_sub and e_norm <= lim_norm, (pname, e_sub, e_norm)
         checked += 1
-    print(f"{name}: {checked} parameter tensors, worst relative gradient error {worst:.2e}")
+    print(f"{name} gprec={gprec}: {checked} parameter tensors, worst relative gradient error {worst:.2e}")
     assert checked >= 40
 
 

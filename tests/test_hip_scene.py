@@ -9,7 +9,9 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-STEPS, RAYS, LR, SEED, RES = 400, 512, 5e-4, 40, 96
+STEPS, RAYS, LR, SEED, RES = 1000, 512, 5e-4, 40, 96
+# observed over 3 x 3 HIP runs (MI355X): last-300-step means within 23 % of the oracle run's for every loss term
+LEVEL_TOL = 0.35
 
 
 def _mesh_from_grid(u):
@@ -31,10 +33,11 @@ def test_reconstruction_matches_oracle_training_on_the_synthetic_scene():
     batches = [ds.gen_random_rays_at(i % ds.n_images, RAYS) for i in range(STEPS)]
     conf = copy.deepcopy(WMASK_MODEL)
     conf["neus_renderer"]["perturb"] = 0.0            # same depths on both sides (the jitter streams differ)
-    # ---- HIP path (hipGraph replay), twice: the second run measures the path's own run-to-run spread (fp32 atomics in
-    # the weight-gradient GEMM are its only non-determinism; Adam then amplifies it like any other rounding difference)
-    def run_hip():
-        tr = Stage1Trainer(dev, model_conf=conf, prec=ops.PREC_PARITY, seed=SEED, lr=LR, use_graph=True)
+    # ---- HIP path (hipGraph replay), three runs: two with fp32-accurate weight gradients (gprec 3; the second measures the
+    # path's own run-to-run spread: fp32 atomics in the weight-gradient GEMM are its only non-determinism, Adam then
+    # amplifies it like any other rounding difference) and one in the training default (gprec 1: bf16 gradient planes)
+    def run_hip(gprec):
+        tr = Stage1Trainer(dev, model_conf=conf, prec=ops.PREC_PARITY, seed=SEED, lr=LR, use_graph=True, gprec=gprec)
         u0 = tr.renderer.extract_sdf_grid([-1.01] * 3, [1.01] * 3, RES).clone()
         rows = []
         for b in batches:
@@ -42,8 +45,9 @@ def test_reconstruction_matches_oracle_training_on_the_synthetic_scene():
             rows.append(torch.stack([out[k].detach().reshape(()) for k in ("loss", "color_loss", "eikonal_loss", "mask_loss")]).clone())
         return torch.stack(rows).cpu().numpy(), tr.renderer.extract_sdf_grid([-1.01] * 3, [1.01] * 3, RES).clone(), u0
 
-    hip, u_hip, u_init = run_hip()
-    hip2, u_hip2, _ = run_hip()
+    hip, u_hip, u_init = run_hip(3)
+    hip2, u_hip2, _ = run_hip(3)
+    hipd, u_hipd, _ = run_hip(1)
     # ---- oracle: same weights, same batches, torch.optim.Adam, eager PyTorch-ROCm ops
     T = lambda sd: {k: torch.from_numpy(v).clone().to(dev).requires_grad_(True) for k, v in sd.items()}
     sd_sdf, sd_col, sd_ref = T(synth.sdf_state_dict(SEED)), T(synth.color_state_dict(SEED + 1)), T(synth.refcolor_state_dict(SEED + 2))
@@ -65,30 +69,47 @@ def test_reconstruction_matches_oracle_training_on_the_synthetic_scene():
         p_sdf = R.sdf_params_from_state_dict(sd_sdf)
         u_ref = extract_fields([-1.01] * 3, [1.01] * 3, RES, lambda pts: -R.sdf_only(pts, p_sdf).reshape(-1), device=dev,
                                as_numpy=False)
-    # ---- loss curves: the first steps coincide, the first 150 steps overlay, later the two trajectories decorrelate the
-    # way two runs of ONE implementation do (printed side by side) while staying statistically equal
-    first = np.abs(hip[:10, 0] - ref[:10, 0]) / np.maximum(np.abs(ref[:10, 0]), 1e-2)
-    print(f"  first 10 steps: worst relative loss deviation {first.max():.2e} (step 0: {first[0]:.1e})")
-    assert first[0] < 1e-4 and first.max() < 6e-2
+    # ---- loss curves: the first steps coincide, the first 150 steps overlay, later the trajectories decorrelate the way
+    # two runs of ONE implementation do (printed side by side) while staying statistically equal.  Bounds sit ~1.5x above
+    # what was observed (MI355X): first 10 steps 4e-2; first three 50-step windows 2-8 % (exact gradients) / 2-9 % (bf16
+    # planes); later windows up to 23 % -- two exact-gradient runs differ from each other by 12-21 % there.
+    for tag, run in (("exact", hip), ("bf16-planes", hipd)):
+        first = np.abs(run[:10, 0] - ref[:10, 0]) / np.maximum(np.abs(ref[:10, 0]), 1e-2)
+        print(f"  [{tag}] first 10 steps: worst relative loss deviation {first.max():.2e} (step 0: {first[0]:.1e})")
+        assert first[0] < 1e-4 and first.max() < 6e-2
     win = 50
     for k, name in enumerate(("loss", "color_loss", "eikonal_loss", "mask_loss")):
-        a, a2 = hip[:, k].reshape(-1, win).mean(1), hip2[:, k].reshape(-1, win).mean(1)
+        a, a2, ad = (x[:, k].reshape(-1, win).mean(1) for x in (hip, hip2, hipd))
         r = ref[:, k].reshape(-1, win).mean(1)
         dev_k = np.abs(a - r) / np.maximum(np.abs(r), 1e-3)
+        dev_d = np.abs(ad - r) / np.maximum(np.abs(r), 1e-3)
         self_k = np.abs(a - a2) / np.maximum(np.abs(a2), 1e-3)
-        print(f"  {name:13s} windows of {win} steps\n     oracle {np.round(r, 4)}\n     HIP    {np.round(a, 4)}\n     HIP #2 {np.round(a2, 4)}"
-              f"\n     HIP vs oracle: first 3 windows {dev_k[:3].max():.1e}, all {dev_k.max():.1e};  HIP vs HIP #2: all {self_k.max():.1e}")
-        assert dev_k[:3].max() < 0.08, name
-        assert dev_k.max() < 1.0, name          # decorrelated trajectories (two HIP runs differ by 20-25 % here as well)
-    assert ref[-win:, 0].mean() < 0.5 * ref[:win, 0].mean() and hip[-win:, 0].mean() < 0.5 * hip[:win, 0].mean()
-    # ---- surfaces at equal steps: Chamfer-L1 to the analytic scene (before training, HIP, HIP #2, oracle), mesh to mesh
+        print(f"  {name:13s} windows of {win} steps\n     oracle      {np.round(r, 4)}\n     HIP exact   {np.round(a, 4)}\n     HIP exact#2 {np.round(a2, 4)}"
+              f"\n     HIP bf16 pl {np.round(ad, 4)}"
+              f"\n     exact vs oracle: first 3 windows {dev_k[:3].max():.1e}, all {dev_k.max():.1e};  bf16 planes vs oracle: first 3 "
+              f"{dev_d[:3].max():.1e}, all {dev_d.max():.1e};  exact vs exact #2: all {self_k.max():.1e}")
+        assert dev_k[:3].max() < 0.08 and dev_d[:3].max() < 0.13, name
+        # later the trajectories decorrelate (two exact runs differ by up to 47 % in single 50-step windows: every step
+        # draws another image); what stays comparable is the level over many windows
+        tail = STEPS * 3 // 10
+        lv = [x[-tail:, k].mean() for x in (hip, hip2, hipd, ref)]
+        print(f"     mean over the last {tail} steps: exact {lv[0]:.4f} / {lv[1]:.4f}, bf16 planes {lv[2]:.4f}, oracle {lv[3]:.4f}")
+        for v in lv[:3]:
+            assert abs(v - lv[3]) < LEVEL_TOL * abs(lv[3]), name
+    for run in (hip, hipd, ref):
+        assert run[-win:, 0].mean() < 0.5 * run[:win, 0].mean()
+    # ---- surfaces at equal steps: Chamfer-L1 to the analytic scene (before training, the three HIP runs, oracle), mesh to
+    # mesh.  Observed: initial sphere 0.124; after 400 steps 0.031-0.041 (HIP runs), 0.035 (oracle).
     gt = scene_surface_points(40000, seed=0)
     ch = lambda u: evaluate_mesh(*_mesh_from_grid(u), gt, thresh=0.01, max_dist=1.0)[2]
-    c_init, c_hip, c_hip2, c_ref = ch(u_init), ch(u_hip), ch(u_hip2), ch(u_ref)
-    (v_h, f_h), (v_r, _) = _mesh_from_grid(u_hip), _mesh_from_grid(u_ref)
+    c_init, c_hip, c_hip2, c_hipd, c_ref = ch(u_init), ch(u_hip), ch(u_hip2), ch(u_hipd), ch(u_ref)
+    (v_h, f_h), (v_r, _) = _mesh_from_grid(u_hipd), _mesh_from_grid(u_ref)
     rs = np.random.RandomState(0)
     c_mm = evaluate_mesh(v_h, f_h, v_r[rs.permutation(len(v_r))[:40000]], thresh=0.01, max_dist=1.0)[2]
-    print(f"  Chamfer-L1 to the analytic surface: initial sphere {c_init:.4f}; after {STEPS} steps HIP {c_hip:.4f}, HIP #2 {c_hip2:.4f}, "
-          f"oracle {c_ref:.4f}; HIP mesh vs oracle mesh {c_mm:.4f}")
-    assert c_hip < 0.75 * c_init and c_ref < 0.75 * c_init                 # both runs moved towards the scene ...
-    assert abs(c_hip - c_ref) < 0.5 * c_init                               # ... and ended in the same neighbourhood
+    print(f"  Chamfer-L1 to the analytic surface: initial sphere {c_init:.4f}; after {STEPS} steps HIP exact {c_hip:.4f} / {c_hip2:.4f}, "
+          f"HIP bf16 planes {c_hipd:.4f}, oracle {c_ref:.4f}; HIP (bf16 planes) mesh vs oracle mesh {c_mm:.4f}")
+    # Observed over 3 x 3 HIP runs: 0.019 .. 0.033 with one 0.059 (exact gradients: the spread is the path's own -- atomics
+    # order -> Adam -- not the gradient precision); oracle 0.021; the grid resolves 0.021.  A wrong backward neither gets
+    # here from 0.124 nor keeps the loss levels above within 35 % of the oracle's.
+    for c in (c_hip, c_hip2, c_hipd, c_ref):
+        assert c < 0.6 * c_init and abs(c - c_ref) < 0.4 * c_init

@@ -53,8 +53,8 @@ def test_loss_trajectory_matches_oracle_training(gprec, later_tol):
             worst = max(worst, d)
             # step 0 is a pure forward comparison; later steps also carry 16+16-sample sampler sensitivity and Adam's
             # normalised updates (a noise-level gradient can step either way), so the curves overlay, not coincide
-            assert d <= (2e-3 if i == 0 else 3e-2), (i, k, a[k], r[k])
-    print(f"  {steps} training steps: worst relative loss-term deviation from the oracle run {worst:.2e}; "
+            assert d <= (2e-3 if i == 0 else later_tol), (i, k, a[k], r[k])
+    print(f"  {steps} training steps (gprec {gprec}): worst relative loss-term deviation from the oracle run {worst:.2e}; "
           f"loss {ref[0]['loss']:.4f} -> {ref[-1]['loss']:.4f} (oracle), {hip[0]['loss']:.4f} -> {hip[-1]['loss']:.4f} (HIP)")
 
 
