@@ -21,22 +21,48 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-sys.path.insert(0, os.path.join(ROOT, "factored-neus_amd"))
 REF = "/root/reference"
 
 GRAD_STRIDE = 997
 
 
-def import_reference():
-    for name in ("mcubes", "icecream", "imageio", "cv2"):
+def _load_by_path(name, path):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+# fneus.synth (numpy streams only) is loaded BY PATH: the repo's package directory must never be on sys.path here -- it
+# holds a regular package called `models`, which would shadow the reference's namespace package of the same name.
+synth = _load_by_path("fneus_synth_for_goldens", os.path.join(ROOT, "factored-neus_amd", "fneus", "synth.py"))
+
+
+def import_reference(with_dataset=False, with_stage23=False):
+    for p in list(sys.path):
+        if os.path.abspath(p or ".").startswith(os.path.join(ROOT, "factored-neus_amd")):
+            sys.path.remove(p)
+    assert "models" not in sys.modules or sys.modules["models"].__path__._path[0].startswith(REF), "repo package imported first"
+    for name in ("mcubes", "icecream", "imageio", "cv2", "tifffile", "trimesh"):
         if name not in sys.modules:
-            m = types.ModuleType(name)
-            sys.modules[name] = m
+            sys.modules[name] = types.ModuleType(name)
     sys.modules["icecream"].ic = lambda *a, **k: None
     np.math = math                         # math_utils.py:27,44,52 use np.math.factorial (numpy<2)
     sys.path.insert(0, REF)
     from models import embedder, fields, renderer     # noqa
-    return embedder, fields, renderer
+    for m in (embedder, fields, renderer):
+        assert m.__file__.startswith(REF + "/"), f"{m.__name__} was not loaded from the reference: {m.__file__}"
+    out = [embedder, fields, renderer]
+    if with_dataset:
+        # models/dataset.py imports models.rend_util (imageio freeimage plugin download at import, rend_util.py:4): not on
+        # the path of the ray generator -- an empty module stands in for it
+        if "models.rend_util" not in sys.modules:
+            sys.modules["models.rend_util"] = types.ModuleType("models.rend_util")
+        from models import dataset
+        assert dataset.__file__.startswith(REF + "/")
+        out.append(dataset)
+    return out
 
 
 def to_t(sd):
@@ -44,7 +70,6 @@ def to_t(sd):
 
 
 def build_nets(fields, seeds):
-    from fneus import synth
     torch.manual_seed(0)
     sdf = fields.SDFNetwork(d_out=257, d_in=3, d_hidden=256, n_layers=8, skip_in=[4], multires=6, bias=0.5,
                             scale=1.0, geometric_init=True, weight_norm=True)
@@ -68,7 +93,6 @@ def subsample(t):
 
 
 def gen_units(embedder, fields, renderer, out_dir):
-    from fneus import synth
     seeds = {"sdf": 10, "color": 11, "refcolor": 12, "nerf": 13}
     sdf, col, var, nerf, ref = build_nets(fields, seeds)
     rs = np.random.RandomState(100)
@@ -136,8 +160,10 @@ def gen_units(embedder, fields, renderer, out_dir):
 
 
 def gen_render(fields, renderer, out_dir, name, B, n_samples, n_importance, n_outside, cos_anneal_ratio,
-               ray_seed, n_miss, inside_rays, mask_weight, seeds, white_bkgd=False, adam_steps=3):
-    from fneus import synth
+               ray_seed, n_miss, inside_rays, mask_weight, seeds, white_bkgd=False, adam_steps=3, ray_stride=1,
+               sampler_trace=True):
+    """ray_stride > 1 (large batches): per-SAMPLE arrays ([B, n] and [B*n, ...]) are stored for rays 0, stride, 2 stride, ...
+    only; per-ray arrays, losses and gradients always cover the whole batch."""
     sdf, col, var, nerf, ref = build_nets(fields, seeds)
     data = torch.from_numpy(synth.ray_batch(B, seed=ray_seed, n_miss=n_miss))
     if inside_rays:
@@ -154,10 +180,18 @@ def gen_render(fields, renderer, out_dir, name, B, n_samples, n_importance, n_ou
 
     def cat_hook(ro, rd, z, new_z, s, last=False):
         zz, ss = orig_cat(ro, rd, z, new_z, s, last=last)
-        trace.append((new_z.clone(), zz.clone(), ss.clone()))
+        trace.append((new_z.clone(), zz.clone(), ss.clone(), z.clone(), s.clone()))
         return zz, ss
 
     rnd.cat_z_vals = cat_hook
+    # the inverse-CDF lookups of sample_pdf (renderer.py:64-66): record cdf, u and the index torch.searchsorted returned
+    lookups = []
+    orig_ss = torch.searchsorted
+
+    def ss_hook(cdf, u, right=False, **kw):
+        r = orig_ss(cdf, u, right=right, **kw)
+        lookups.append((cdf.clone(), r.clone()))
+        return r
     core = {}
     orig_core = rnd.render_core
 
@@ -177,10 +211,27 @@ def gen_render(fields, renderer, out_dir, name, B, n_samples, n_importance, n_ou
            **{"seed_" + k: v for k, v in seeds.items()}}
     igr_weight, surface_weight = 0.1, 0.1
     import torch.nn.functional as F
+    sel = slice(None, None, ray_stride)
+    res["ray_stride"] = ray_stride
+
+    def per_sample(t, n_cols=None):
+        """[B, n, ...] or [B*n, ...] array restricted to the stored rays"""
+        a = t.detach().numpy()
+        if ray_stride == 1:
+            return a
+        if a.shape[0] == B:
+            return a[sel]
+        return a.reshape((B, -1) + a.shape[1:])[sel].reshape((-1,) + a.shape[1:])
+
     for step in range(adam_steps):
         trace.clear()
-        out = rnd.render(rays_o, rays_d, near, far, perturb_overwrite=0, background_rgb=bg,
-                         cos_anneal_ratio=cos_anneal_ratio)
+        lookups.clear()
+        torch.searchsorted = ss_hook
+        try:
+            out = rnd.render(rays_o, rays_d, near, far, perturb_overwrite=0, background_rgb=bg,
+                             cos_anneal_ratio=cos_anneal_ratio)
+        finally:
+            torch.searchsorted = orig_ss
         # exp_runner.py:141-177
         mask = (mask_in > 0.5).float() if mask_weight > 0.0 else torch.ones_like(mask_in)
         mask_sum = mask.sum() + 1e-5
@@ -197,11 +248,20 @@ def gen_render(fields, renderer, out_dir, name, B, n_samples, n_importance, n_ou
         loss.backward()
         if step == 0:
             for k, v in out.items():
-                res["out/" + k] = v.detach().numpy()
+                big = v.dim() >= 2 and v.shape[0] == B and v.shape[1] not in (1, 3)
+                res["out/" + k] = per_sample(v) if big else v.detach().numpy()
             for k in ("sdf", "dists", "mid_z_vals", "cdf", "s_val"):
-                res["core/" + k] = core[k].detach().numpy()
-            for i, (nz, zz, ss) in enumerate(trace):
-                res[f"trace/new_z_{i}"], res[f"trace/z_{i}"], res[f"trace/sdf_{i}"] = nz.numpy(), zz.numpy(), ss.numpy()
+                res["core/" + k] = per_sample(core[k])
+            for i, (nz, zz, ss, z_in, s_in) in enumerate(trace):
+                res[f"trace/new_z_{i}"], res[f"trace/z_{i}"], res[f"trace/sdf_{i}"] = per_sample(nz), per_sample(zz), per_sample(ss)
+                if sampler_trace:     # inputs of up_sample step i, its cdf and the bin each new depth was drawn from
+                    cdf, inds = lookups[i]
+                    res[f"trace/z_in_{i}"], res[f"trace/sdf_in_{i}"] = per_sample(z_in), per_sample(s_in)
+                    res[f"trace/cdf_{i}"] = per_sample(cdf)
+                    res[f"trace/bin_{i}"] = per_sample(torch.clamp(inds - 1, min=0)).astype(np.int16)
+            assert not sampler_trace or len(lookups) == len(trace)
+            if ray_stride > 1:       # the final depths of EVERY ray: teacher-forced runs of the whole batch need them
+                res["trace/z_final"] = trace[-1][1].numpy()
             res["loss/loss"] = np.float64(loss.item())
             res["loss/color"] = np.float64(color_fine_loss.item())
             res["loss/surface"] = np.float64(surface_color_loss.item())
@@ -223,21 +283,154 @@ def gen_render(fields, renderer, out_dir, name, B, n_samples, n_importance, n_ou
     print(name + ".npz written; loss", res["loss/loss"], "n_sdf_mask", int(res["out/sdf_mask"].sum()))
 
 
+def gen_lvis_util(fields, renderer, out_dir, name, B, n_samples, n_importance, ray_seed, seeds):
+    """NeuSRenderer.lvis_mateIllu_render_util (renderer.py:503-564): the stage-2/3 entry -- unperturbed hierarchical
+    sampling, SDF at the section mid-points, per-ray inside-sphere mask"""
+    sdf, col, var, nerf, ref = build_nets(fields, seeds)
+    data = torch.from_numpy(synth.ray_batch(B, seed=ray_seed, n_miss=2))
+    data[:2, :3] = data[:2, :3] * 0.2                   # two ray origins inside the unit sphere
+    rays_o, rays_d = data[:, :3], data[:, 3:6]
+    a = (rays_d ** 2).sum(-1, keepdim=True)
+    b = 2.0 * (rays_o * rays_d).sum(-1, keepdim=True)
+    mid = 0.5 * (-b) / a
+    near, far = mid - 1.0, mid + 1.0
+    rnd = renderer.NeuSRenderer(n_samples, n_importance, 0, 4, 1.0, nerf=nerf, sdf_network=sdf, deviation_network=var,
+                                color_network=col, refColor_network=ref)
+    with torch.no_grad():
+        out = rnd.lvis_mateIllu_render_util(rays_o, rays_d, near, far)
+    res = {"data": data.numpy(), "B": B, "n_samples": n_samples, "n_importance": n_importance, "ray_seed": ray_seed,
+           **{"seed_" + k: v for k, v in seeds.items()},
+           "out/n_samples": np.int64(out["n_samples"]), "out/mid_z_vals": out["mid_z_vals"].numpy(),
+           "out/sdf": out["sdf"].numpy(), "out/inside_sphere_mask": out["inside_sphere_mask"].numpy()}
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), **res)
+    print(name + ".npz written; inside_sphere_mask", int(res["out/inside_sphere_mask"].sum()), "of", B)
+
+
+def gen_raygen(dataset, out_dir, name="raygen_dtu"):
+    """Dataset.gen_rays_at / gen_random_rays_at / near_far_from_sphere (dataset.py:115-151, 186-192) called unbound on a
+    stub object that carries exactly the attributes they read: a synthetic DTU-like camera set (K^-1, pose), BGR/256
+    images and masks.  The random pixel draws are recorded (torch.randint is wrapped), so the fixture pins pixels -> rays."""
+    rs = np.random.RandomState(77)
+    n_img, H, W = 3, 48, 64
+    Ks, poses = [], []
+    for i in range(n_img):
+        f = 60.0 + 5.0 * i
+        K = np.array([[f, 0.3 * i, W / 2 - 0.5 + i], [0, f * 1.02, H / 2 - 0.5 - i], [0, 0, 1]], dtype=np.float64)
+        c = rs.standard_normal(3)
+        c = 2.8 * c / np.linalg.norm(c)
+        zc = -c / np.linalg.norm(c)
+        up = np.array([0.1, 1.0, 0.2])
+        xc = np.cross(up, zc)
+        xc /= np.linalg.norm(xc)
+        yc = np.cross(zc, xc)
+        pose = np.eye(4)
+        pose[:3, :3] = np.stack([xc, yc, zc], 1)          # camera-to-world rotation (columns = camera axes)
+        pose[:3, 3] = c
+        K4 = np.eye(4)
+        K4[:3, :3] = K
+        Ks.append(K4)
+        poses.append(pose)
+    stub = types.SimpleNamespace()
+    stub.H, stub.W = H, W
+    stub.intrinsics_all_inv = torch.from_numpy(np.linalg.inv(np.stack(Ks)).astype(np.float32))
+    stub.pose_all = torch.from_numpy(np.stack(poses).astype(np.float32))
+    stub.images = torch.from_numpy((rs.randint(0, 256, size=(n_img, H, W, 3)) / 256.0).astype(np.float32))
+    stub.masks = torch.from_numpy((rs.uniform(size=(n_img, H, W, 3)) > 0.4).astype(np.float32))
+    res = {"H": H, "W": W, "intrinsics_all_inv": stub.intrinsics_all_inv.numpy(), "pose_all": stub.pose_all.numpy(),
+           "images": stub.images.numpy(), "masks": stub.masks.numpy()}
+    D = dataset.Dataset
+    orig_cuda, orig_randint, orig_avail = torch.Tensor.cuda, torch.randint, torch.cuda.is_available
+    draws = []
+
+    def randint_hook(*a, **k):
+        r = orig_randint(*a, **k)
+        draws.append(r.clone())
+        return r
+
+    torch.Tensor.cuda = lambda self, *a, **k: self          # dataset.py:139 hard-codes .cuda()
+    torch.randint = randint_hook
+    torch.cuda.is_available = lambda: False
+    try:
+        for lvl in (1, 4):
+            ro, rv = D.gen_rays_at(stub, 1, resolution_level=lvl)
+            res[f"rays_at_l{lvl}/rays_o"], res[f"rays_at_l{lvl}/rays_v"] = ro.numpy().copy(), rv.numpy().copy()
+        torch.manual_seed(123)
+        for i, (img, bs) in enumerate(((0, 64), (2, 33))):
+            draws.clear()
+            out = D.gen_random_rays_at(stub, torch.tensor(img), bs)
+            res[f"random_{i}/img_idx"], res[f"random_{i}/pixels_x"], res[f"random_{i}/pixels_y"] = img, draws[0].numpy(), draws[1].numpy()
+            res[f"random_{i}/out"] = out.numpy().copy()
+            near, far = D.near_far_from_sphere(stub, out[:, :3], out[:, 3:6])
+            res[f"random_{i}/near"], res[f"random_{i}/far"] = near.numpy(), far.numpy()
+    finally:
+        torch.Tensor.cuda, torch.randint, torch.cuda.is_available = orig_cuda, orig_randint, orig_avail
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), **res)
+    print(name + ".npz written")
+
+
+FIXTURES_V1 = ("units", "render_wmask_b16_n16", "render_wmask_b8_n64", "render_womask_b16_n16_o8", "render_wmask_b16_n16_c0")
+
+
+def check_against(old_dir, new_dir, names):
+    """every key of a committed fixture must be reproduced bit for bit (new keys may be added)"""
+    ok = True
+    for name in names:
+        old_p, new_p = os.path.join(old_dir, name + ".npz"), os.path.join(new_dir, name + ".npz")
+        if not os.path.exists(old_p):
+            continue
+        old, new = np.load(old_p), np.load(new_p)
+        bad = [k for k in old.files if k not in new.files or not np.array_equal(old[k], new[k])]
+        print(f"{name}: {len(old.files)} committed keys, {len(new.files)} regenerated, {len(bad)} differ {bad[:5]}")
+        ok = ok and not bad
+    return ok
+
+
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=HERE, help="directory to write the fixtures to")
+    ap.add_argument("--only", default="", help="comma-separated fixture names (default: all)")
+    ap.add_argument("--check", action="store_true", help="compare the regenerated fixtures in --out with the committed ones")
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    only = set(filter(None, args.only.split(",")))
+    want = lambda n: not only or n in only
     torch.set_num_threads(8)
-    embedder, fields, renderer = import_reference()
+    embedder, fields, renderer, dataset = import_reference(with_dataset=True)
     seeds = {"sdf": 20, "color": 21, "refcolor": 22, "nerf": 23}
-    gen_units(embedder, fields, renderer, HERE)
-    gen_render(fields, renderer, HERE, "render_wmask_b16_n16", B=16, n_samples=16, n_importance=16, n_outside=0,
-               cos_anneal_ratio=1.0, ray_seed=31, n_miss=2, inside_rays=2, mask_weight=0.1, seeds=seeds)
-    gen_render(fields, renderer, HERE, "render_wmask_b8_n64", B=8, n_samples=64, n_importance=64, n_outside=0,
-               cos_anneal_ratio=1.0, ray_seed=32, n_miss=1, inside_rays=0, mask_weight=0.1, seeds=seeds)
-    gen_render(fields, renderer, HERE, "render_womask_b16_n16_o8", B=16, n_samples=16, n_importance=16, n_outside=8,
-               cos_anneal_ratio=0.3, ray_seed=33, n_miss=2, inside_rays=1, mask_weight=0.0, seeds=seeds,
-               white_bkgd=True)
-    gen_render(fields, renderer, HERE, "render_wmask_b16_n16_c0", B=16, n_samples=16, n_importance=16, n_outside=0,
-               cos_anneal_ratio=0.0, ray_seed=34, n_miss=0, inside_rays=0, mask_weight=0.1, seeds=seeds,
-               adam_steps=1)
+    if want("units"):
+        gen_units(embedder, fields, renderer, args.out)
+    if want("render_wmask_b16_n16"):
+        gen_render(fields, renderer, args.out, "render_wmask_b16_n16", B=16, n_samples=16, n_importance=16, n_outside=0,
+                   cos_anneal_ratio=1.0, ray_seed=31, n_miss=2, inside_rays=2, mask_weight=0.1, seeds=seeds)
+    if want("render_wmask_b8_n64"):
+        gen_render(fields, renderer, args.out, "render_wmask_b8_n64", B=8, n_samples=64, n_importance=64, n_outside=0,
+                   cos_anneal_ratio=1.0, ray_seed=32, n_miss=1, inside_rays=0, mask_weight=0.1, seeds=seeds)
+    if want("render_womask_b16_n16_o8"):
+        gen_render(fields, renderer, args.out, "render_womask_b16_n16_o8", B=16, n_samples=16, n_importance=16, n_outside=8,
+                   cos_anneal_ratio=0.3, ray_seed=33, n_miss=2, inside_rays=1, mask_weight=0.0, seeds=seeds,
+                   white_bkgd=True)
+    if want("render_wmask_b16_n16_c0"):
+        gen_render(fields, renderer, args.out, "render_wmask_b16_n16_c0", B=16, n_samples=16, n_importance=16, n_outside=0,
+                   cos_anneal_ratio=0.0, ray_seed=34, n_miss=0, inside_rays=0, mask_weight=0.1, seeds=seeds,
+                   adam_steps=1)
+    # ---- round 2 -----------------------------------------------------------------------------------------------
+    # BASELINE config 1: 256 rays x (32 + 32) samples, 8 new depths per up-sampling step (per-sample arrays: every 16th ray)
+    if want("render_wmask_b256_n32"):
+        gen_render(fields, renderer, args.out, "render_wmask_b256_n32", B=256, n_samples=32, n_importance=32, n_outside=0,
+                   cos_anneal_ratio=1.0, ray_seed=35, n_miss=12, inside_rays=4, mask_weight=0.1, seeds=seeds, ray_stride=16)
+    # the reference configuration's depth (64 + 64) on 64 rays (per-sample arrays: every 4th ray)
+    if want("render_wmask_b64_n64"):
+        gen_render(fields, renderer, args.out, "render_wmask_b64_n64", B=64, n_samples=64, n_importance=64, n_outside=0,
+                   cos_anneal_ratio=1.0, ray_seed=36, n_miss=4, inside_rays=2, mask_weight=0.1, seeds=seeds, ray_stride=4)
+    if want("lvis_util_b24_n32"):
+        gen_lvis_util(fields, renderer, args.out, "lvis_util_b24_n32", B=24, n_samples=32, n_importance=32, ray_seed=37, seeds=seeds)
+    if want("raygen_dtu"):
+        gen_raygen(dataset, args.out)
+    if args.check:
+        ok = check_against(HERE, args.out, FIXTURES_V1)
+        print("committed fixtures reproduced bit for bit" if ok else "MISMATCH against the committed fixtures")
+        sys.exit(0 if ok else 1)
 
 
 if __name__ == "__main__":

@@ -24,5 +24,10 @@ kt=$(find /tmp/prof_t -name '*kernel_trace.csv' | head -1)
 python3 "$root/tools/step_timeline.py" "$kt" > "$out/${tag}_step_timeline.txt" 2>&1
 rocprofv3 --pmc FETCH_SIZE -d /tmp/pmc_f -o f --output-format csv -- python3 "$root/tools/pmc_run.py" parity 2 > /dev/null 2> "$out/${tag}_pmc_f.err"
 rocprofv3 --pmc WRITE_SIZE -d /tmp/pmc_w -o w --output-format csv -- python3 "$root/tools/pmc_run.py" parity 2 > /dev/null 2> "$out/${tag}_pmc_w.err"
-python3 "$root/tools/pmc_summary.py" --json "$out/${tag}_traffic.json" /tmp/pmc_f /tmp/pmc_w > "$out/${tag}_pmc_fetch_write.txt"
-grep -A2 -E "^(sdf_bwd|sdf_fwd_grad|dw_gemm)" "$out/${tag}_pmc_fetch_write.txt"
+python3 "$root/tools/pmc_summary.py" --steps 2 --json "$out/${tag}_traffic.json" /tmp/pmc_f /tmp/pmc_w > "$out/${tag}_pmc_fetch_write.txt"
+grep -A2 -E "^(sdf_bwd|sdf_fwd_grad|dw_gemm)|whole step" "$out/${tag}_pmc_fetch_write.txt"
+# matrix-pipe utilisation per kernel: SQ counters in their own pass (8 SQ slots)
+rm -rf /tmp/pmc_s
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAVES -d /tmp/pmc_s -o s --output-format csv -- python3 "$root/tools/pmc_run.py" parity 2 > /dev/null 2> "$out/${tag}_pmc_s.err"
+python3 "$root/tools/pmc_summary.py" /tmp/pmc_s > "$out/${tag}_sq.txt"
+head -40 "$out/${tag}_sq.txt"

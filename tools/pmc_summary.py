@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Average rocprofv3 --pmc counter_collection.csv values per kernel (fneus kernels only)."""
 import csv, sys, collections, glob, json
-json_out = None
+json_out, n_steps = None, None
+if "--steps" in sys.argv:           # number of identical training steps the profiled run made: per-step totals
+    i = sys.argv.index("--steps")
+    n_steps = int(sys.argv[i + 1])
+    del sys.argv[i:i + 2]
 if "--json" in sys.argv:
     i = sys.argv.index("--json")
     json_out = sys.argv[i + 1]
@@ -23,7 +27,8 @@ for k in sorted(acc):
 if json_out:
     # HBM bytes per launch: FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE under-counts wide coalesced reads 2x on gfx950
     # (MI355X_MICROARCH.md, HBM section).  Keys are the C-ABI entry points bench.py reports its kernels under.
-    entry = {"sdf_bwd_kernel": "fneus_sdf_bwd", "sdf_fwd_grad": "fneus_sdf_fwd_grad", "dw_gemm_kernel": "fneus_dw_gemm",
+    entry = {"sdf_bwd": "fneus_sdf_bwd", "sdf_fwd_grad": "fneus_sdf_fwd_grad", "dw_gemm_pp": "fneus_dw_gemm_pp",
+             "dw_gemm_kernel": "fneus_dw_gemm",
              "color_fwd": "fneus_color_fwd", "color_bwd": "fneus_color_bwd", "sdf_fwd": "fneus_sdf_fwd",
              "refcolor_fwd": "fneus_refcolor_fwd", "refcolor_bwd": "fneus_refcolor_bwd"}
     ks = {}
@@ -36,7 +41,16 @@ if json_out:
                 w = sum(acc[k]["WRITE_SIZE"]) / len(acc[k]["WRITE_SIZE"])
                 ks[name] = {"kernel": k, "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "hbm_bytes_per_launch": (2 * f + w) * 1024}
             break           # first entry wins: sdf_fwd_grad_* must not also file under sdf_fwd
-    json.dump({"_note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/collect_profiles.sh, "
+    step = None
+    if n_steps:
+        tot_f = sum(sum(acc[k]["FETCH_SIZE"]) for k in acc if "FETCH_SIZE" in acc[k])
+        tot_w = sum(sum(acc[k]["WRITE_SIZE"]) for k in acc if "WRITE_SIZE" in acc[k])
+        per_k = {k: (2 * sum(acc[k].get("FETCH_SIZE", [0])) + sum(acc[k].get("WRITE_SIZE", [0]))) * 1024 / n_steps for k in acc}
+        step = {"steps": n_steps, "hbm_bytes_per_step": (2 * tot_f + tot_w) * 1024 / n_steps,
+                "bytes_per_ray_sample": (2 * tot_f + tot_w) * 1024 / n_steps / 65536,
+                "by_kernel_bytes_per_step": dict(sorted(per_k.items(), key=lambda kv: -kv[1]))}
+        print(f"# whole step: {step['hbm_bytes_per_step'] / 1e9:.3f} GB = {step['bytes_per_ray_sample'] / 1024:.1f} KiB per ray sample")
+    json.dump({"step_total": step, "_note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/collect_profiles.sh, "
                         "tools/pmc_run.py parity 2, N = 65536 samples per launch); hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: "
                         "FETCH_SIZE under-counts wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md, HBM section). "
                         "A kernel with several launch shapes per step (dw_gemm, sdf_fwd) is the average over them.",
