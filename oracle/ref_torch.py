@@ -285,8 +285,9 @@ def refcolor_forward(pts, feat, dirs, n, sd: Dict[str, torch.Tensor]):
 # --------------------------------------------------------------------------------------
 # renderer.py:43-77  sample_pdf
 # --------------------------------------------------------------------------------------
-def sample_pdf_det(bins: torch.Tensor, weights: torch.Tensor, n_new: int) -> torch.Tensor:
-    """Deterministic inverse-CDF sampling at u=(k+.5)/n_new  (renderer.py:43-77, det=True)."""
+def sample_pdf_det(bins: torch.Tensor, weights: torch.Tensor, n_new: int, return_bins: bool = False):
+    """Deterministic inverse-CDF sampling at u=(k+.5)/n_new  (renderer.py:43-77, det=True).
+    return_bins: also the bin index each sample was drawn from (`below`) and the cdf."""
     w = weights + 1e-5
     pdf = w / w.sum(-1, keepdim=True)
     cdf = torch.cumsum(pdf, -1)
@@ -301,7 +302,8 @@ def sample_pdf_det(bins: torch.Tensor, weights: torch.Tensor, n_new: int) -> tor
     denom = cdf_a - cdf_b
     denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
     t = (u - cdf_b) / denom
-    return bin_b + t * (bin_a - bin_b)
+    out = bin_b + t * (bin_a - bin_b)
+    return (out, below, cdf) if return_bins else out
 
 
 def exclusive_transmittance(alpha: torch.Tensor) -> torch.Tensor:
@@ -313,7 +315,7 @@ def exclusive_transmittance(alpha: torch.Tensor) -> torch.Tensor:
 # --------------------------------------------------------------------------------------
 # renderer.py:152-205  up_sample / cat_z_vals
 # --------------------------------------------------------------------------------------
-def up_sample(rays_o, rays_d, z_vals, sdf, n_new: int, inv_s: float) -> torch.Tensor:
+def up_sample(rays_o, rays_d, z_vals, sdf, n_new: int, inv_s: float, return_bins: bool = False):
     B, m = z_vals.shape
     pts = rays_o[:, None, :] + rays_d[:, None, :] * z_vals[..., None]
     radius = torch.linalg.norm(pts, dim=-1)
@@ -332,7 +334,7 @@ def up_sample(rays_o, rays_d, z_vals, sdf, n_new: int, inv_s: float) -> torch.Te
     next_cdf = torch.sigmoid(next_est * inv_s)
     alpha = (prev_cdf - next_cdf + 1e-5) / (prev_cdf + 1e-5)
     weights = alpha * exclusive_transmittance(alpha)
-    return sample_pdf_det(z_vals, weights, n_new)
+    return sample_pdf_det(z_vals, weights, n_new, return_bins=return_bins)
 
 
 def cat_z_vals(rays_o, rays_d, z_vals, new_z, sdf, sdf_fn, last: bool):
@@ -582,6 +584,56 @@ def near_far_from_sphere(rays_o, rays_d):
     b = 2.0 * (rays_o * rays_d).sum(-1, keepdim=True)
     mid = 0.5 * (-b) / a
     return mid - 1.0, mid + 1.0
+
+
+# --------------------------------------------------------------------------------------
+# renderer.py:503-564  NeuSRenderer.lvis_mateIllu_render_util: the entry of the stage-2 / stage-3 renderers
+# --------------------------------------------------------------------------------------
+def lvis_mateIllu_render_util(rays_o, rays_d, near, far, sdf_p, n_samples: int, n_importance: int, up_sample_steps: int = 4):
+    """unperturbed hierarchical sampling, SDF at the section mid-points, per-ray inside-sphere mask"""
+    sample_dist = 2.0 / n_samples
+    z = near + (far - near) * torch.linspace(0.0, 1.0, n_samples, dtype=near.dtype)[None, :]
+    sdf_fn = lambda q: sdf_only(q, sdf_p)
+    n = n_samples
+    if n_importance > 0:
+        with torch.no_grad():
+            z = hierarchical_z(rays_o, rays_d, z, sdf_fn, n_importance, up_sample_steps)
+        n = n_samples + n_importance
+    dists = torch.cat([z[:, 1:] - z[:, :-1], torch.full_like(z[:, :1], sample_dist)], -1)
+    mid_z = z + dists * 0.5
+    pts = (rays_o[:, None, :] + rays_d[:, None, :] * mid_z[..., None]).reshape(-1, 3)
+    sdf = sdf_only(pts, sdf_p)
+    inside = (torch.linalg.norm(pts, dim=-1).reshape(-1, n) < 1.0).to(z.dtype)
+    return {"n_samples": n, "mid_z_vals": mid_z, "sdf": sdf, "inside_sphere_mask": inside.sum(-1) > 0.0}
+
+
+# --------------------------------------------------------------------------------------
+# dataset.py:115-151  Dataset.gen_rays_at / gen_random_rays_at (the pixel -> ray part)
+# --------------------------------------------------------------------------------------
+def rays_from_pixels(intrinsics_inv, pose, px, py):
+    """pixel (x, y) -> K^-1 [x, y, 1] -> normalise -> R v; origin = pose[:3, 3]   (dataset.py:140-146).
+    intrinsics_inv, pose: [4,4] of one image; px, py: [...] pixel coordinates (float)."""
+    p = torch.stack([px, py, torch.ones_like(px)], -1)
+    p = torch.matmul(intrinsics_inv[:3, :3], p[..., None])[..., 0]
+    v = p / torch.linalg.norm(p, dim=-1, keepdim=True)
+    v = torch.matmul(pose[:3, :3], v[..., None])[..., 0]
+    return pose[:3, 3].expand(v.shape), v
+
+
+def gen_rays_at(intrinsics_inv, pose, H: int, W: int, resolution_level: int = 1):
+    """dataset.py:115-131: the full image grid at 1 / resolution_level -> rays_o, rays_v [H/l, W/l, 3]"""
+    l = resolution_level
+    tx = torch.linspace(0, W - 1, W // l)
+    ty = torch.linspace(0, H - 1, H // l)
+    px, py = torch.meshgrid(tx, ty, indexing="ij")
+    o, v = rays_from_pixels(intrinsics_inv, pose, px, py)
+    return o.transpose(0, 1), v.transpose(0, 1)
+
+
+def gen_random_rays_at(intrinsics_inv, pose, image, mask, px, py):
+    """dataset.py:133-151 with the pixel draws given: -> [B, 10] = rays_o, rays_v, colour, mask[:, :1]"""
+    o, v = rays_from_pixels(intrinsics_inv, pose, px.float(), py.float())
+    return torch.cat([o, v, image[(py, px)], mask[(py, px)][:, :1]], -1)
 
 
 # --------------------------------------------------------------------------------------

@@ -368,7 +368,8 @@ def gen_raygen(dataset, out_dir, name="raygen_dtu"):
     print(name + ".npz written")
 
 
-FIXTURES_V1 = ("units", "render_wmask_b16_n16", "render_wmask_b8_n64", "render_womask_b16_n16_o8", "render_wmask_b16_n16_c0")
+FIXTURES = ("units", "render_wmask_b16_n16", "render_wmask_b8_n64", "render_womask_b16_n16_o8", "render_wmask_b16_n16_c0",
+            "render_wmask_b256_n32", "render_wmask_b64_n64", "lvis_util_b24_n32", "raygen_dtu")
 
 
 def check_against(old_dir, new_dir, names):
@@ -376,7 +377,7 @@ def check_against(old_dir, new_dir, names):
     ok = True
     for name in names:
         old_p, new_p = os.path.join(old_dir, name + ".npz"), os.path.join(new_dir, name + ".npz")
-        if not os.path.exists(old_p):
+        if not os.path.exists(old_p) or not os.path.exists(new_p):
             continue
         old, new = np.load(old_p), np.load(new_p)
         bad = [k for k in old.files if k not in new.files or not np.array_equal(old[k], new[k])]
@@ -428,7 +429,7 @@ def main():
     if want("raygen_dtu"):
         gen_raygen(dataset, args.out)
     if args.check:
-        ok = check_against(HERE, args.out, FIXTURES_V1)
+        ok = check_against(HERE, args.out, FIXTURES)
         print("committed fixtures reproduced bit for bit" if ok else "MISMATCH against the committed fixtures")
         sys.exit(0 if ok else 1)
 

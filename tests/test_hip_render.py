@@ -21,6 +21,22 @@ def load(golden_dir, name):
     return dict(np.load(os.path.join(golden_dir, name + ".npz")))
 
 
+def stored(x, g):
+    """restrict a per-sample array ([B, n, ...] or [B*n, ...]) of a full-batch run to the rays a strided fixture stores"""
+    s = int(g["ray_stride"]) if "ray_stride" in g else 1
+    if s == 1:
+        return x
+    B = int(g["B"])
+    x = x.detach()
+    if x.shape[0] == B:
+        return x[::s]
+    return x.reshape((B, -1) + tuple(x.shape[1:]))[::s].reshape((-1,) + tuple(x.shape[1:]))
+
+
+def final_z(g):
+    return T(g["trace/z_final"] if "trace/z_final" in g else g["trace/z_3"])
+
+
 def build(g, prec, gprec=None):
     from fneus import synth
     from models.fields import SDFNetwork, RenderingNetwork, SingleVarianceNetwork, RefColor, NeRF
@@ -58,7 +74,7 @@ def run(g, prec, teacher_z, fused_loss=False, gprec=None):
     near, far = R.near_far_from_sphere(rays_o, rays_d)
     bg = torch.ones(1, 3, device=DEV) if int(g["white_bkgd"]) else None
     out = rnd.render(rays_o, rays_d, near, far, perturb_overwrite=0, cos_anneal_ratio=float(g["cos_anneal_ratio"]),
-                     background_rgb=bg, z_vals_override=T(g["trace/z_3"]).to(DEV) if teacher_z else None,
+                     background_rgb=bg, z_vals_override=final_z(g).to(DEV) if teacher_z else None,
                      loss_args=(rgb, mask, 0.1, float(g["mask_weight"]), 0.1) if fused_loss else None)
     return out, nets, (rgb, mask)
 
@@ -69,21 +85,25 @@ def maxerr(a, b):
 
 WMASK = ["render_wmask_b16_n16", "render_wmask_b8_n64", "render_wmask_b16_n16_c0"]
 WOMASK = ["render_womask_b16_n16_o8"]       # n_outside = 8, white background, cos_anneal 0.3
+# round 2: BASELINE config 1 (256 rays x (32+32), 8 new depths per step) and 64 rays at the reference depth (64+64)
+BIG = ["render_wmask_b256_n32", "render_wmask_b64_n64"]
 
 
-@pytest.mark.parametrize("name", WMASK + WOMASK)
+@pytest.mark.parametrize("name", WMASK + WOMASK + BIG)
 def test_render_core_teacher_forced(golden_dir, name):
     g = load(golden_dir, name)
     out, _, _ = run(g, 3, teacher_z=True)
     assert np.array_equal(out["sdf_mask"].cpu().numpy(), g["out/sdf_mask"])
     for k in RAY_KEYS + SAMPLE_KEYS:
-        e = maxerr(out[k], g["out/" + k])
+        x = out[k]
+        x = stored(x, g) if (x.dim() >= 2 and x.shape[1] not in (1, 3)) else x      # per-sample arrays: stored rays only
+        e = maxerr(x, g["out/" + k])
         assert e <= 1e-4, (k, e)
-    assert maxerr(out["_sdf"], g["core/sdf"]) <= 1e-4
-    assert maxerr(out["_mid_z_vals"], g["core/mid_z_vals"]) <= 1e-6
+    assert maxerr(stored(out["_sdf"], g), g["core/sdf"]) <= 1e-4
+    assert maxerr(stored(out["_mid_z_vals"], g), g["core/mid_z_vals"]) <= 1e-6
 
 
-@pytest.mark.parametrize("name", WMASK)
+@pytest.mark.parametrize("name", WMASK + BIG)
 def test_render_end_to_end(golden_dir, name):
     """own sampler: ray-integrated outputs within 1e-4 (per-sample outputs sit at slightly different z: the inverse
     CDF is ill-conditioned where the pdf is flat, see tests/test_oracle_golden.py)"""
@@ -95,15 +115,18 @@ def test_render_end_to_end(golden_dir, name):
     # restatement (tests/test_oracle_golden.py::test_render_end_to_end uses the same split).
     tol = 1e-4 if int(g["n_samples"]) >= 64 else 5e-4
     errs = {k: maxerr(out[k], g["out/" + k]) for k in RAY_KEYS}
-    print(name, {k: f"{v:.1e}" for k, v in errs.items()}, "z", f"{maxerr(out['_z_vals'], g['trace/z_3']):.1e}")
+    print(name, {k: f"{v:.1e}" for k, v in errs.items()}, "z", f"{maxerr(out['_z_vals'], final_z(g)):.1e}")
     for k, e in errs.items():
         assert e <= tol, (k, e)
-    assert maxerr(out["_z_vals"], g["trace/z_3"]) <= 3e-3
+    # depths: the inverse cdf is ill conditioned where the pdf is flat (tests/test_hip_rays.py separates that from bin
+    # choices on the reference's own sampler trace): a handful of depths in flat bins move by 1e-3..1e-2
+    dz = (out["_z_vals"].detach().cpu() - final_z(g)).abs()
+    assert dz.max().item() <= (3e-3 if int(g["B"]) <= 16 else 2e-2) and (dz <= 1e-4).float().mean().item() >= 0.9      # (sorted arrays: one moved depth shifts its neighbours' slots)
 
 
 @pytest.mark.parametrize("gprec", [3, 1], ids=["grad_hi_lo", "grad_bf16"])
 @pytest.mark.parametrize("fused", [False, True], ids=["torch_loss", "fused_loss"])
-@pytest.mark.parametrize("name", WMASK[:2] + WOMASK)
+@pytest.mark.parametrize("name", WMASK[:2] + WOMASK + BIG)
 def test_loss_and_gradients(golden_dir, name, fused, gprec):
     """fused: shading + blend + losses + their gradients from fneus_stage1_loss (what the training step uses);
     otherwise the same terms written with torch ops on the render dict.
@@ -159,3 +182,52 @@ def test_fast_mode_reports_error(golden_dir):
     errs = {k: maxerr(out[k], g["out/" + k]) for k in ("color_fine", "weights", "gradients", "weight_sum")}
     print("bf16 fast mode max abs errors:", {k: f"{v:.2e}" for k, v in errs.items()})
     assert errs["color_fine"] <= 5e-2 and errs["weight_sum"] <= 5e-2
+
+
+@pytest.mark.parametrize("name", ["render_wmask_b16_n16", "render_wmask_b64_n64", "render_wmask_b256_n32"])
+def test_adam_steps_match_reference(golden_dir, name):
+    """Parameters after 1 and 3 optimiser steps of the reference loop (exp_runner.py:179-181: zero_grad, backward, Adam.step
+    on the fixture batch) -- adam1_sub / adam3_sub of the fixtures -- against the training step of this repo: own sampler,
+    fused loss, weight gradients, fneus_adam.  Adam's first update is lr * g / (|g| + eps): +-lr wherever the gradient is
+    not noise, so the comparison is per element against lr, not against the parameter's size."""
+    from fneus import ops
+    from fneus.trainer import Stage1Trainer, WMASK_MODEL
+    import copy
+    g = load(golden_dir, name)
+    conf = copy.deepcopy(WMASK_MODEL)
+    conf["neus_renderer"] = dict(n_samples=int(g["n_samples"]), n_importance=int(g["n_importance"]), n_outside=0,
+                                 up_sample_steps=4, perturb=0.0)
+    lr = 5e-4
+    tr = Stage1Trainer(torch.device(DEV), model_conf=conf, prec=ops.PREC_PARITY, seed=int(g["seed_sdf"]), lr=lr,
+                       mask_weight=float(g["mask_weight"]), use_graph=False, gprec=3)
+    assert int(g["seed_color"]) == int(g["seed_sdf"]) + 1 and int(g["seed_refcolor"]) == int(g["seed_sdf"]) + 2
+    data = T(g["data"]).to(DEV)
+    nets = dict(sdf=tr.sdf_network, color=tr.color_network, var=tr.deviation_network)
+    p0 = {f"{n}.{k}": v.detach().clone() for n, m in nets.items() for k, v in m.named_parameters()}
+    for step in (1, 2, 3):
+        losses = tr.train_step(data, cos_anneal_ratio=float(g["cos_anneal_ratio"]))
+        if step == 1:
+            assert abs(losses["loss"].item() - float(g["adam1_loss"])) <= 2e-4
+        if step not in (1, 3):
+            continue
+        worst_frac, checked = 0.0, 0
+        for key in g:
+            if not key.startswith(f"adam{step}_sub/"):
+                continue
+            pname = key.split("/", 1)[1]
+            net, rest = pname.split(".", 1)
+            prm = dict(nets[net].named_parameters())[rest]
+            got = prm.detach().cpu().reshape(-1)[::997].numpy()
+            ref, start = g[key], p0[pname].cpu().reshape(-1)[::997].numpy()
+            moved = np.abs(ref - start)
+            if step == 1:
+                assert moved.max() <= lr * 1.001 + 1e-7, pname              # the reference itself moved by <= lr
+            off = np.abs(got - ref) > 0.25 * lr                             # an element whose update went elsewhere
+            worst_frac = max(worst_frac, off.mean())
+            # elements off by more than lr/4: gradient at rounding level (either sign is "right"); a few per thousand
+            assert off.mean() <= (0.02 if step == 1 else 0.06), (pname, step, off.mean())
+            if got.size >= 20:
+                assert np.median(np.abs(got - ref)) <= 0.02 * lr, (pname, step)
+            checked += 1
+        assert checked >= 40
+        print(f"  {name}: after {step} Adam step(s) {checked} tensors; worst fraction of elements off by > lr/4: {worst_frac:.4f}")
