@@ -60,8 +60,8 @@ class Runner:
                                      igr_weight=self.igr_weight, mask_weight=self.mask_weight,
                                      surface_weight=surface_weight, synthetic_init=False, distributed=distributed,
                                      use_graph=use_graph)   # cos_anneal_ratio is a device scalar: a ramp replays too
-        # the reference also constructs and checkpoints the background NeRF when n_outside == 0 (it is never evaluated then)
-        self.nerf_outside = self.trainer.nerf_outside or NeRF(**dict(self.conf["model.nerf"])).to(self.device)
+        # constructed and checkpointed also when n_outside == 0 (never evaluated then), as in the reference
+        self.nerf_outside = self.trainer.nerf_outside
         self.iter_step = 0
         if is_continue:
             names = sorted(n for n in os.listdir(os.path.join(self.base_exp_dir, "checkpoints"))
@@ -126,7 +126,7 @@ class Runner:
         t.refColor_network.load_state_dict(ckpt["refColor_network"])
         try:
             t.optimizer.load_state_dict(ckpt["optimizer"])
-        except (ValueError, KeyError):
+        except (ValueError, KeyError, RuntimeError):
             logging.warning("optimizer state of the checkpoint does not match this parameter list; starting Adam fresh")
         self.iter_step = ckpt["iter_step"]
 

@@ -35,6 +35,21 @@ class _Workspace:
             self.cache[key] = factory()
         return self.cache[key]
 
+    # The stash / work buffers are shared per (n, prec): ONE differentiable call per network and size may be in flight.
+    # A second forward of the same size before the first one's backward would overwrite its stash and the first backward
+    # would silently use the wrong activations, so every forward stamps its stash and the backward checks the stamp.
+    def stamp(self, stash):
+        self.generation = getattr(self, "generation", 0) + 1
+        stash.generation = self.generation
+        return self.generation
+
+    @staticmethod
+    def check(stash, generation, what):
+        if getattr(stash, "generation", None) != generation:
+            raise RuntimeError(f"{what}: the activation stash of this call was overwritten by a later forward of the same size "
+                               "before its backward ran (the fused networks keep one stash per batch size: call backward "
+                               "before the next differentiable forward, or use different batch sizes)")
+
 
 class SdfValueGradFn(torch.autograd.Function):
     """K2 forward; backward = K3 + weight-gradient GEMM + weight-norm backward.  The parameters are not autograd
@@ -47,11 +62,13 @@ class SdfValueGradFn(torch.autograd.Function):
         stash = ws.get(("sdf_stash", n, prec, train), lambda: ops.SdfStash(n, anchor.device, prec, train, gprec=ws.gprec))
         sdf, feat, normal = ops.sdf_fwd_grad(net.blob, n, prec, stash, train, **samples.kw())
         ctx.net, ctx.samples, ctx.prec, ctx.ws, ctx.stash, ctx.n = net, samples, prec, ws, stash, n
+        ctx.generation = ws.stamp(stash)
         return sdf, feat, normal
 
     @staticmethod
     def backward(ctx, d_sdf, d_feat, d_normal):
         n, prec, net, ws = ctx.n, ctx.prec, ctx.net, ctx.ws
+        ws.check(ctx.stash, ctx.generation, "SDFNetwork backward")
         dev = d_feat.device if d_feat is not None else (d_sdf.device if d_sdf is not None else d_normal.device)
         d_sdf = torch.zeros(n, device=dev) if d_sdf is None else d_sdf.contiguous()
         d_feat = torch.zeros(n, 256, device=dev) if d_feat is None else d_feat.contiguous()
@@ -89,6 +106,7 @@ class ColorFn(torch.autograd.Function):
                                                                     gprec=ws.gprec)) if train else None
         rgb = ops.color_fwd(net.blob, n, prec, normal, feat, stash, train, dirs=samples.dirs, head=head, **samples.kw())
         ctx.net, ctx.prec, ctx.ws, ctx.sdf_ws, ctx.stash, ctx.n, ctx.head, ctx.samples = net, prec, ws, sdf_ws, stash, n, head, samples
+        ctx.generation = ws.stamp(stash) if stash is not None else None
         if head != 0:
             ctx.save_for_backward(rgb, normal)
         else:
@@ -98,6 +116,7 @@ class ColorFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_rgb):
         n, prec, net, ws, head = ctx.n, ctx.prec, ctx.net, ctx.ws, ctx.head
+        ws.check(ctx.stash, ctx.generation, "colour network backward")
         if head != 0:
             rgb, normal = ctx.saved_tensors
             sm = ctx.samples
@@ -126,11 +145,13 @@ class NerfFn(torch.autograd.Function):
         stash = ws.get(("nerf_stash", n, prec), lambda: ops.NerfStash(n, anchor.device, prec)) if train else None
         density, rgb = ops.nerf_fwd(net.blob, n, prec, pts4, dirs, stash, train)
         ctx.net, ctx.prec, ctx.ws, ctx.stash, ctx.n = net, prec, ws, stash, n
+        ctx.generation = ws.stamp(stash) if stash is not None else None
         return density, rgb
 
     @staticmethod
     def backward(ctx, d_density, d_rgb):
         n, prec, net, ws = ctx.n, ctx.prec, ctx.net, ctx.ws
+        ws.check(ctx.stash, ctx.generation, "background NeRF backward")
         dev = net.blob.device
         d_density = torch.zeros(n, device=dev) if d_density is None else d_density.contiguous()
         d_rgb = torch.zeros(n, 3, device=dev) if d_rgb is None else d_rgb.contiguous()
@@ -153,6 +174,7 @@ class RefHeadsFn(torch.autograd.Function):
         diffuse, spec = ops.refcolor_fwd_both(net_cd.blob, net_vd.blob, n, prec, normal, feat, st[0], st[1], train,
                                               dirs=samples.dirs, **samples.kw())
         ctx.nets, ctx.prec, ctx.ws, ctx.st, ctx.n, ctx.samples = (net_cd, net_vd), prec, ws, st, n, samples
+        ctx.generation = ws.stamp(st[0]) if st[0] is not None else None
         ctx.save_for_backward(diffuse, spec, normal)
         return diffuse, spec
 
@@ -160,6 +182,7 @@ class RefHeadsFn(torch.autograd.Function):
     def backward(ctx, d_diffuse, d_spec):
         diffuse, spec, normal = ctx.saved_tensors
         (net_cd, net_vd), n, prec, ws, st, sm = ctx.nets, ctx.n, ctx.prec, ctx.ws, ctx.st, ctx.samples
+        ws.check(st[0], ctx.generation, "RefColor backward")
         z = lambda g: torch.zeros(n, 3, device=normal.device) if g is None else g.contiguous()
         d_feat2, d_normal2 = ops.refcolor_bwd_both(net_cd.blob, net_vd.blob, n, prec, z(d_diffuse), z(d_spec), diffuse, spec,
                                                    st[0], st[1], normal, dirs=sm.dirs, rays_d=sm.rays_d, m=sm.m)

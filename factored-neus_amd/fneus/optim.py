@@ -6,7 +6,9 @@ state_dict()/load_state_dict() format as the reference's optimiser (exp_runner.p
   a whole network is a single contiguous segment for the kernel);
 * `step` is one device scalar shared by every parameter, `lr` a device scalar: the step is hipGraph-capturable;
 * the kernel clears each gradient after using it (zero_grad() becomes a no-op for the owner of this optimiser).
-Every parameter must have a persistent `.grad` buffer when step() is first called (the trainer guarantees it).
+Every parameter that takes part must have a persistent `.grad` buffer when step() is first called (the trainer guarantees
+it); a parameter whose `.grad` is None is skipped like torch.optim.Adam skips it (no state, no update): the reference hands
+the never-evaluated background NeRF of the wmask configuration to Adam in exactly that way (exp_runner.py:89, 96).
 """
 from __future__ import annotations
 
@@ -40,13 +42,16 @@ class FlatAdam(torch.optim.Adam):
             self._lr_host = float(lr)
 
     def _params(self) -> List[torch.nn.Parameter]:
-        return [p for p in self.param_groups[0]["params"] if p.requires_grad]
+        """the parameters this step updates: those with a gradient (torch.optim.Adam's rule)"""
+        return [p for p in self.param_groups[0]["params"] if p.requires_grad and p.grad is not None]
 
     def _build(self):
         ps = self._params()
+        if not ps:
+            raise RuntimeError("FlatAdam.step(): no parameter has a gradient")
         dev = ps[0].device
         for p in ps:
-            if p.grad is None or p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
+            if p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
                 raise RuntimeError("FlatAdam needs contiguous fp32 parameters with persistent .grad buffers")
         # the shared step counter: continue from a loaded state if there is one
         steps = [float(self.state[p]["step"]) for p in ps if p in self.state and "step" in self.state[p]]
@@ -111,9 +116,30 @@ class FlatAdam(torch.optim.Adam):
                              C.c_void_p(self._step_dev.data_ptr()), float(b1), float(b2), float(self.param_groups[0]["eps"]),
                              int(self.clear_grads), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "fneus_adam")
 
+    def state_dict(self):
+        """torch.optim.Adam's format, with an independent `step` tensor per parameter (inside this optimiser all
+        parameters share one device scalar; a consumer such as torch.optim.Adam increments each entry separately)"""
+        sd = super().state_dict()
+        for st in sd["state"].values():
+            if torch.is_tensor(st.get("step")):
+                st["step"] = st["step"].detach().clone().cpu()
+        return sd
+
     def load_state_dict(self, state_dict):
         """torch shares tensors of the right dtype / device with the dict it is given; the moments move into this
         optimiser's arenas at the next step(), so take private copies now (the source may keep training)"""
+        # torch maps the saved state onto the parameters BY POSITION and checks only the count: a state_dict of another
+        # parameter order would put, say, the background NeRF's moments on the SDF network.  Check the shapes first.
+        saved = state_dict["state"]
+        ids = [i for g in state_dict["param_groups"] for i in g["params"]]
+        ps = [p for g in self.param_groups for p in g["params"]]
+        if len(ids) != len(ps):
+            raise ValueError(f"optimizer state_dict holds {len(ids)} parameters, this optimiser {len(ps)}")
+        for i, p in zip(ids, ps):
+            st = saved.get(i)
+            if st is not None and torch.is_tensor(st.get("exp_avg")) and tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError(f"optimizer state of parameter {i} has shape {tuple(st['exp_avg'].shape)}, the parameter "
+                                 f"{tuple(p.shape)}: the parameter lists differ in order")
         super().load_state_dict(state_dict)
         for st in self.state.values():
             for k in ("step", "exp_avg", "exp_avg_sq"):

@@ -46,15 +46,17 @@ class Stage1Trainer:
             self.sdf_network.load_state_dict(T(synth.sdf_state_dict(seed)))
             self.color_network.load_state_dict(T(synth.color_state_dict(seed + 1)))
             self.refColor_network.load_state_dict(T(synth.refcolor_state_dict(seed + 2)))
-        self.nerf_outside = None
-        if conf["neus_renderer"].get("n_outside", 0) > 0:          # womask: background NeRF++ (renderer.py:452-458)
-            self.nerf_outside = NeRF(**conf.get("nerf", dict(D=8, d_in=4, d_in_view=3, W=256, multires=10,
-                                                             multires_view=4, output_ch=4, skips=[4], use_viewdirs=True)))
-            if synthetic_init:
-                self.nerf_outside.load_state_dict({k: torch.from_numpy(v) for k, v in synth.nerf_state_dict(seed + 3).items()})
-        self.modules = [self.sdf_network, self.deviation_network, self.color_network, self.refColor_network]
-        if self.nerf_outside is not None:
-            self.modules.append(self.nerf_outside)
+        # The background NeRF++ is constructed, checkpointed and handed to Adam whether or not it is evaluated, exactly as
+        # the reference does (exp_runner.py:82, 89, 96): with n_outside == 0 its 24 parameters never receive a gradient
+        # and Adam skips them, but they hold positions 0..23 of the optimiser's parameter list -- which is what makes
+        # optimiser state_dicts interchangeable with the reference's.
+        self.use_nerf = conf["neus_renderer"].get("n_outside", 0) > 0      # womask: renderer.py:452-458
+        self.nerf_outside = NeRF(**conf.get("nerf", dict(D=8, d_in=4, d_in_view=3, W=256, multires=10,
+                                                         multires_view=4, output_ch=4, skips=[4], use_viewdirs=True)))
+        if synthetic_init:
+            self.nerf_outside.load_state_dict({k: torch.from_numpy(v) for k, v in synth.nerf_state_dict(seed + 3).items()})
+        # reference order (exp_runner.py:89-94): nerf_outside, sdf_network, deviation_network, color_network, refColor_network
+        self.modules = [self.nerf_outside, self.sdf_network, self.deviation_network, self.color_network, self.refColor_network]
         for m in self.modules:
             m.to(device)
         self.sdf_network.set_precision(prec)
@@ -62,8 +64,7 @@ class Stage1Trainer:
             m.set_gradient_precision(gprec)                 # None: ops.DEFAULT_GPREC (bf16 planes)
         self.color_network.set_precision(prec)
         self.refColor_network.set_precision(prec)
-        if self.nerf_outside is not None:
-            self.nerf_outside.set_precision(prec)
+        self.nerf_outside.set_precision(prec)
         self.params = [p for m in self.modules for p in m.parameters()]
         # data parallel: two collectives sit inside the step (the 4-float all-reduce of the loss normalisers before the
         # loss, the gradient arena after the backward), so the step is captured as THREE hipGraphs with the collectives
@@ -77,14 +78,15 @@ class Stage1Trainer:
         # every gradient of the model lives in ONE arena: the fused MLPs accumulate into slices of it, the small torch
         # modules get persistent .grad views (autograd accumulates into them in place).  FlatAdam addresses parameters
         # and gradients by pointer and clears the gradients itself; data parallel = one in-place all-reduce of the arena.
-        fused = [self.sdf_network, self.color_network] + ([self.nerf_outside] if self.nerf_outside is not None else [])
+        fused = [self.sdf_network, self.color_network] + ([self.nerf_outside] if self.use_nerf else [])
         self.grads = GradArena(device, fused, self.refColor_network, [self.deviation_network])
         self.optimizer = FlatAdam(self.params, lr=lr)
         self._graphs = {}            # (batch shape, background shape) -> (graph(s), static input, static background, losses)
         self._cos = torch.ones(1, dtype=torch.float32, device=device)    # cos_anneal_ratio of the replayed step
         self._eager_steps = 0
         self.graph_warmup_steps = 2  # eager steps before the first capture (workspaces, job tables, LDS attributes)
-        self.renderer = NeuSRenderer(**conf["neus_renderer"], nerf=self.nerf_outside, sdf_network=self.sdf_network,
+        self.renderer = NeuSRenderer(**conf["neus_renderer"], nerf=self.nerf_outside if self.use_nerf else None,
+                                     sdf_network=self.sdf_network,
                                      deviation_network=self.deviation_network, color_network=self.color_network,
                                      refColor_network=self.refColor_network)
         self.igr_weight, self.mask_weight, self.surface_weight = igr_weight, mask_weight, surface_weight
@@ -140,20 +142,24 @@ class Stage1Trainer:
         st["open"] = None
         st["norms"] = norms
         reduce_loss_norms(norms)             # eager: nothing recorded has run yet, the values are meaningless, but every
-        st["g2"].capture_begin(pool=st["pool"], capture_error_mode="thread_local")   # rank issues the same collectives
+        st["n_coll"] += 1                    # rank issues the same collectives
+        st["g2"].capture_begin(pool=st["pool"], capture_error_mode="thread_local")
         st["open"] = st["g2"]
         return norms
 
     def _capture_dp(self, data: torch.Tensor, background_rgb):
         """data parallel: three graphs per step with the two collectives between them.  Returns None when the capture
-        fails for any reason (the caller then stays on eager launches)."""
+        fails ON ANY RANK (every rank then stays on eager launches).  The outcome is collective: whatever happens, every
+        rank issues exactly the same three collectives here -- the 4-float normaliser exchange, the arena all-reduce (both
+        on meaningless values: nothing recorded has run) and a MIN all-reduce of its success flag -- so a rank whose
+        capture throws cannot pair its first real collectives with its peers' dummy ones."""
         import gc
         static_data = data.clone()
         static_bg = None if background_rgb is None else background_rgb.clone()
         gc.collect()
         torch.cuda.synchronize()
         g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        st = {"g1": g1, "g2": g2, "pool": torch.cuda.graph_pool_handle(), "open": None, "norms": None}
+        st = {"g1": g1, "g2": g2, "pool": torch.cuda.graph_pool_handle(), "open": None, "norms": None, "n_coll": 0}
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         ok, losses = False, None
@@ -170,6 +176,7 @@ class Stage1Trainer:
                 g2.capture_end()
                 st["open"] = None
                 self.bucket.allreduce_sum()          # eager, like the exchange above
+                st["n_coll"] += 1
                 g3.capture_begin(pool=st["pool"], capture_error_mode="thread_local")
                 st["open"] = g3
                 self.optimizer.step()
@@ -181,16 +188,30 @@ class Stage1Trainer:
             print(f"[fneus] data-parallel graph capture failed ({e!r}); continuing with eager launches", file=sys.stderr)
         finally:
             self._capturing = None
-            if st["open"] is not None:
-                try:
-                    st["open"].capture_end()
+            if st["open"] is not None:       # a capture is still open: end it ON THE STREAM THAT IS CAPTURING, or that stream
+                try:                         # stays in capture mode and the next synchronisation fails
+                    with torch.cuda.stream(side):
+                        st["open"].capture_end()
                 except Exception:   # noqa: BLE001
                     pass
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-        if not ok:
+        # make up for the collectives a failed capture did not reach, then agree on the outcome
+        import torch.distributed as dist
+        if st["n_coll"] < 1:
+            reduce_loss_norms(torch.zeros(4, dtype=torch.float32, device=self.device))
+        if st["n_coll"] < 2:
+            self.bucket.allreduce_sum()
+        flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float32, device=self.device)
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        torch.cuda.synchronize()
+        if flag.item() < 0.5:                # some rank failed: ALL ranks run eagerly from here on
+            if ok:
+                import sys
+                print("[fneus] data-parallel graph capture failed on another rank; continuing with eager launches", file=sys.stderr)
             self.use_graph = False
-            self.grads.flat.zero_()
+            self.grads.flat.zero_()          # (the dummy exchanges may have summed a failing rank's partial gradients)
             return None
         return (g1, g2, g3, st["norms"]), static_data, static_bg, losses
 

@@ -116,6 +116,7 @@ class _HipMLP(nn.Module):
         """put the flat gradient buffer into `buf` (a slice of a model-wide arena); call before the first refresh()"""
         self._ext_grad = buf
         self._net = None
+        self._ws.cache.clear()         # job tables cache gradient-buffer addresses
 
     def _attached(self):
         return (self._net is not None and self.lin0.bias.device == self._net.device
@@ -354,6 +355,7 @@ class RefColor(nn.Module):
     def use_grad_buffers(self, buf_cd: torch.Tensor, buf_vd: torch.Tensor):
         self._cd.ext_grad, self._vd.ext_grad = buf_cd, buf_vd
         self._cd.net = self._vd.net = None
+        self._cd.ws.cache.clear()      # job tables cache gradient-buffer addresses
 
     def heads(self, samples: RaySamples, x, n, train: bool):
         """-> diffuse [M,3], specular [M,3] with the value in column 0 (both after their sigmoid), differentiable w.r.t.
@@ -421,6 +423,7 @@ class NeRF(nn.Module):
     def use_grad_buffer(self, buf: torch.Tensor):
         self._be.ext_grad = buf
         self._be.net = None
+        self._be.ws.cache.clear()      # the weight-gradient job table caches raw_grad.data_ptr()
 
     def refresh(self):
         """pack the current parameters (once per optimiser step, before rendering)"""

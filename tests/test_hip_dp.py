@@ -19,12 +19,13 @@ def _trainer():
 
 
 def _grads(tr):
-    return [p.grad.detach().clone() for p in tr.params]
+    return [p.grad.detach().clone() for p in tr.params if p.grad is not None]
 
 
 def _clear(tr):
     for p in tr.params:
-        p.grad.zero_()
+        if p.grad is not None:          # (the never-evaluated background NeRF of the wmask configuration has none)
+            p.grad.zero_()
 
 
 def test_two_half_batches_with_global_normalisers_equal_the_full_batch():
@@ -56,14 +57,14 @@ def test_two_half_batches_with_global_normalisers_equal_the_full_batch():
         s = sum(float(p[k].detach()) for p in parts)
         assert abs(s - ref_losses[k]) <= 2e-6 * max(1.0, abs(ref_losses[k])), (k, s, ref_losses[k])
     worst = 0.0
-    for g, r, p in zip(got, ref, tr.params):
+    for g, r in zip(got, ref):
         scale = r.abs().max().item() + 1e-12
         worst = max(worst, (g - r).abs().max().item() / scale)
     print(f"  two half batches vs full batch: worst relative gradient difference {worst:.2e}")
     assert worst <= 2e-3        # fp32 atomics / summation order only (the K2-K3 chains are evaluated per sample)
 
 
-def _two_ranks(graph: bool):
+def _two_ranks(graph: bool, fail_rank: int = -1):
     import os
     import subprocess
     import sys
@@ -71,8 +72,8 @@ def _two_ranks(graph: bool):
     port = 29600 + (os.getpid() + 151 * int(graph)) % 300
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "tools", "dp_check.py")]
-    env = dict(os.environ, DP_CHECK_GRAPH="1" if graph else "0")
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    env = dict(os.environ, DP_CHECK_GRAPH="1" if graph else "0", DP_CHECK_FAIL_RANK=str(fail_rank))
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
     line = [l for l in r.stdout.splitlines() if l.startswith("DP_CHECK")]
     assert r.returncode == 0 and line and line[0].endswith("OK"), (r.stdout[-2000:], r.stderr[-2000:])
     print(" ", line[0])
@@ -93,3 +94,13 @@ def test_two_ranks_sharing_the_gpu_stay_identical():
     # closely, the later ones must stay on the same curve
     for i, (a, b) in enumerate(zip(eager, graphed)):
         assert abs(a - b) <= (1e-3 if i < 3 else 3e-2) * max(abs(a), 1e-2), (i, a, b)
+
+
+def test_capture_failure_on_one_rank_moves_every_rank_to_eager_launches():
+    """the graph capture of rank 1 throws after the first exchange: the outcome must be collective (every rank issues the
+    same three collectives during capture and all fall back to eager launches), the replicas stay bit-identical and the
+    run finishes -- instead of rank 1's first real collectives pairing with rank 0's dummy ones"""
+    trace = _two_ranks(graph=True, fail_rank=1)
+    eager = _two_ranks(graph=False)
+    assert len(trace) == 7
+    assert abs(trace[0] - eager[0]) <= 1e-5 * max(1.0, abs(eager[0]))

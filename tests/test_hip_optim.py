@@ -87,3 +87,53 @@ def test_flat_adam_state_dict_roundtrip_continues_identically():
     for p, q in zip(a_ps, b_ps):
         assert torch.equal(p.detach(), q.detach())
     assert float(b.state[b_ps[0]]["step"]) == 8.0
+
+
+@pytest.mark.parametrize("n_outside", [0, 8], ids=["wmask", "womask"])
+def test_optimizer_state_is_interchangeable_with_the_reference_parameter_list(n_outside):
+    """The reference hands Adam nerf_outside (24), sdf_network, deviation_network, color_network, refColor_network, in that
+    order, whether or not the background NeRF is evaluated (exp_runner.py:89-96); torch maps optimiser state onto
+    parameters by POSITION.  So (a) a torch.optim.Adam over tensors of the reference's list must load this trainer's
+    optimizer.state_dict() with every moment on the right shape, and (b) FlatAdam must load that Adam's state_dict back and
+    keep stepping; (c) a state_dict of another order (round 1's: sdf first) must be refused, not silently mis-assigned."""
+    import copy
+    from fneus import ops, synth
+    from fneus.trainer import Stage1Trainer, WMASK_MODEL
+    conf = copy.deepcopy(WMASK_MODEL)
+    conf["neus_renderer"] = dict(n_samples=16, n_importance=16, n_outside=n_outside, up_sample_steps=4, perturb=0.0)
+    tr = Stage1Trainer(DEV, model_conf=conf, prec=ops.PREC_PARITY, seed=3, use_graph=False)
+    names = [f"{tag}.{k}" for tag, m in zip(("nerf", "sdf", "var", "color", "ref"), tr.modules) for k, _ in m.named_parameters()]
+    assert len(names) == len(tr.params) == 24 + 27 + 1 + 15 + 20 and names[0].startswith("nerf.") and names[24].startswith("sdf.")
+    data = torch.from_numpy(synth.ray_batch(32, seed=2, n_miss=2)).to(DEV)
+    bg = torch.ones(1, 3, device=DEV) if n_outside else None
+    for _ in range(2):
+        tr.train_step(data, cos_anneal_ratio=0.5, background_rgb=bg)
+    sd = tr.optimizer.state_dict()
+    assert sd["param_groups"][0]["params"] == list(range(len(tr.params)))
+    with_state = set(sd["state"].keys())
+    assert with_state == (set(range(len(tr.params))) if n_outside else set(range(24, len(tr.params))))   # Adam skipped the unused NeRF
+    # (a) a plain torch Adam over the reference's parameter list
+    plain = [torch.nn.Parameter(p.detach().clone()) for p in tr.params]
+    adam = torch.optim.Adam(plain, lr=5e-4)
+    adam.load_state_dict(copy.deepcopy(sd))
+    for i, p in enumerate(plain):
+        if i in with_state:
+            assert adam.state[p]["exp_avg"].shape == p.shape and float(adam.state[p]["step"]) == 2.0
+            p.grad = torch.randn_like(p) * 1e-3
+    adam.step()
+    sd2 = adam.state_dict()
+    # (b) back into a fresh trainer's FlatAdam
+    tr2 = Stage1Trainer(DEV, model_conf=conf, prec=ops.PREC_PARITY, seed=3, use_graph=False)
+    tr2.optimizer.load_state_dict(sd2)
+    tr2.train_step(data, cos_anneal_ratio=0.5, background_rgb=bg)
+    torch.cuda.synchronize()
+    k = 24                                                    # sdf.lin0.bias
+    st = tr2.optimizer.state[tr2.params[k]]
+    assert float(st["step"]) == 4.0 and st["exp_avg"].shape == tr2.params[k].shape
+    assert torch.isfinite(st["exp_avg"]).all() and st["exp_avg"].abs().max() > 0
+    # (c) round 1's order (sdf, deviation, color, refColor[, nerf]) is refused
+    order = list(range(24, len(tr.params))) + list(range(24))
+    bad = {"state": {j: sd2["state"][i] for j, i in enumerate(order) if i in sd2["state"]},
+           "param_groups": copy.deepcopy(sd2["param_groups"])}
+    with pytest.raises(ValueError):
+        tr2.optimizer.load_state_dict(bad)

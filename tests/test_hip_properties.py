@@ -150,3 +150,18 @@ def test_stage2_entry_util_matches_the_oracle_composition():
     assert (out["sdf"].cpu() - sdf_ref).abs().max().item() <= 1e-4
     inside_ref = (torch.linalg.norm(pts, dim=-1) < 1.0).any(dim=-1)
     assert torch.equal(out["inside_sphere_mask"].cpu(), inside_ref)
+
+
+def test_overwritten_stash_is_detected():
+    """two differentiable SDF calls of the same size before the first backward share one stash: the first backward must
+    refuse to run on the second call's activations instead of silently returning wrong gradients"""
+    from models.fields import SDFNetwork
+    net = SDFNetwork(d_out=257, d_in=3, d_hidden=256, n_layers=8, skip_in=[4], multires=6, bias=0.5, scale=1.0,
+                     geometric_init=True, weight_norm=True).to(DEV)
+    a = torch.rand(64, 3, device=DEV) - 0.5
+    b = torch.rand(64, 3, device=DEV) - 0.5
+    ga = net.gradient(a)
+    gb = net.gradient(b)
+    gb.sum().backward()                      # the latest call: fine
+    with pytest.raises(RuntimeError, match="overwritten"):
+        ga.sum().backward()

@@ -37,7 +37,7 @@ def test_runner_train_checkpoint_resume_validate(tmp_path):
                               "optimizer", "iter_step"}                         # exp_runner.py:266-278
     assert "lin0.weight_g" in ck["sdf_network_fine"] and "net_cd.0.weight" in ck["refColor_network"]
     before = {k: v.clone() for k, v in r.trainer.sdf_network.state_dict().items()}
-    step_before = float(r.trainer.optimizer.state[r.trainer.params[0]]["step"])
+    step_before = float(r.trainer.optimizer.state[r.trainer.sdf_network.lin0.bias]["step"])
     # resume in a fresh runner: weights, optimiser moments and the step counter come back
     r2 = exp_runner.Runner(conf, mode="train", case="synth", is_continue=True, type="synthetic", device=dev)
     assert r2.iter_step == 5
@@ -46,7 +46,7 @@ def test_runner_train_checkpoint_resume_validate(tmp_path):
     r2.batch_size = 128
     r2.train(max_steps=2)
     assert r2.iter_step == 7
-    assert float(r2.trainer.optimizer.state[r2.trainer.params[0]]["step"]) == step_before + 2
+    assert float(r2.trainer.optimizer.state[r2.trainer.sdf_network.lin0.bias]["step"]) == step_before + 2
     moved = max((a.cpu() - before[k].cpu()).abs().max().item() for k, a in r2.trainer.sdf_network.state_dict().items())
     assert 0.0 < moved < 1e-2
     img = r2.validate_image(idx=0, resolution_level=8)

@@ -23,6 +23,18 @@ conf = copy.deepcopy(WMASK_MODEL)
 conf["neus_renderer"]["perturb"] = 0.0                         # no depth jitter: eager and replayed runs draw it differently
 tr = Stage1Trainer(dev, model_conf=conf, seed=rank, distributed=True, use_graph=use_graph)   # different initial weights per rank on purpose ...
 broadcast_parameters(tr.modules)                               # ... rank 0's must win
+# DP_CHECK_FAIL_RANK=r: the graph capture of rank r throws half way (after the first exchange): every rank must fall back to
+# eager launches together and the replicas must stay identical
+fail_rank = int(os.environ.get("DP_CHECK_FAIL_RANK", "-1"))
+if use_graph and rank == fail_rank:
+    real_step = tr.optimizer.step
+
+    def failing_step(*a, **k):
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("injected capture failure")
+        return real_step(*a, **k)
+
+    tr.optimizer.step = failing_step
 losses = None
 trace = []
 for b in synthetic_batches(7, 128, dev, rank=rank):
@@ -32,7 +44,13 @@ flat = torch.cat([p.detach().reshape(-1) for p in tr.params])
 gathered = [torch.empty_like(flat) for _ in range(world)]
 dist.all_gather(gathered, flat)
 worst = max((g - gathered[0]).abs().max().item() for g in gathered)
-ok = worst == 0.0 and bool(torch.isfinite(losses["loss"])) and (not use_graph or (tr.use_graph and len(tr._graphs) == 1))
+if fail_rank >= 0:
+    graphs_ok = not tr.use_graph                      # the injected failure must have switched EVERY rank to eager launches
+else:
+    graphs_ok = not use_graph or (tr.use_graph and len(tr._graphs) == 1)
+flags = [None] * world
+dist.all_gather_object(flags, bool(graphs_ok))
+ok = worst == 0.0 and bool(torch.isfinite(losses["loss"])) and all(flags)
 if rank == 0:
     print("DP_TRACE " + " ".join(f"{v:.6f}" for v in trace))
     print(f"DP_CHECK world={world} graphs={int(use_graph)} max replica difference {worst:.3e} global loss {float(losses['loss']):.6f} "
