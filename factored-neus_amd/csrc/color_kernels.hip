@@ -217,7 +217,7 @@ FN_DEV void color_fwd_tp_body(unsigned char* lds, const unsigned char* blob, con
     const int t0 = 2 * wave;
     const PPLane pl = pp_lane(lane);
     constexpr auto& LY = kColLayout;
-    const long tiles = (N + 31) / 32;
+    const long tiles = pp_tiles(N);
     const bool lo_planes = TRAIN && PREC == 3 && st.u_lo != nullptr;
     for (long tile = blockIdx.x; tile * 32 < N; tile += gridDim.x) {
         asm volatile("" : "+s"(blob));
@@ -291,7 +291,7 @@ FN_DEV void color_bwd_tp_body(unsigned char* lds, const unsigned char* blob, lon
     const int t0 = 2 * wave;
     const PPLane pl = pp_lane(lane);
     constexpr auto& LY = kColLayout;
-    const long tiles = (N + 31) / 32;
+    const long tiles = pp_tiles(N);
     const bool lo_planes = PREC == 3 && st.zbar_lo != nullptr;
     for (long tile = blockIdx.x; tile * 32 < N; tile += gridDim.x) {
         asm volatile("" : "+s"(blob));

@@ -22,6 +22,11 @@
 
 namespace fneus {
 
+// sample tiles a plane is allocated for: ceil(N / 32) rounded up to an even count (workgroups of two tiles may store a
+// whole padding tile of zeros behind a ragged end)
+FN_DEV long pp_tiles(long n) { return 2 * ((n + 63) / 64); }
+// (host side: fneus/pp.py alloc_tiles)
+
 // byte offset of this lane's 16 bytes inside fragment ks of a block
 FN_DEV unsigned pp_slot_bytes(int lane, int ks) { return (unsigned)(((2 * (lane & 31) + (lane >> 5)) ^ (8 * (ks & 1))) * 16); }
 
@@ -35,6 +40,9 @@ FN_DEV PPLane pp_lane(int lane) {
 }
 
 FN_DEV void pp_store(unsigned char* __restrict__ block, int ks, const PPLane& pl, bf16x8 v) {
+#ifdef FNEUS_DBG_NO_PLANESTORE          // timing experiments only
+    if (pl.even != 0xFFFFFFFFu) return;
+#endif
     __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(block + (size_t)ks * kFragBytes + ((ks & 1) ? pl.odd : pl.even)));
 }
 FN_DEV bf16x8 pp_load(const unsigned char* __restrict__ block, int ks, const PPLane& pl) {

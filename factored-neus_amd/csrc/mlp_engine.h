@@ -153,6 +153,83 @@ FN_DEV void dense_ldsb(const unsigned char* __restrict__ blob, uint32_t off_hi, 
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 }
 
+// dense_ldsb() for HB sample halves that share ONE pass over the weight fragments (HB = 2: a 64-sample workgroup; half
+// the weight stream, half the barriers and twice the MFMA work per k-step and wave).  The B fragments of half hb live at
+// frag + hb * HALF_BYTES in the same [k-step][plane] order.  Accumulators are [tile][half]: the first row is a valid
+// one-tile view (a wave that owns a single tile of a short layer).
+template <int PREC, int KS, int NT_TOTAL, int T0, int TN, int DEPTH, bool WLO, int HB, int HALF_BYTES>
+FN_DEV void dense_ldsb_h(const unsigned char* __restrict__ blob, uint32_t off_hi, uint32_t off_lo,
+                         const unsigned char* frag /*LDS*/, f32x16 (&acc)[TN][HB], int lane, int t0_rt = 0) {
+    static_assert(TN <= 4, "one stage per k-step");
+    constexpr int NPL = PREC == 3 ? 2 : 1;
+    constexpr int D = DEPTH > 0 ? DEPTH : (PREC == 3 ? FNEUS_PREFETCH_X3 : FNEUS_PREFETCH_X1);
+    const unsigned voff = (unsigned)(lane + t0_rt * 64) * 16u;
+    const gblob_t bhi = (gblob_t)blob + off_hi, blo = (gblob_t)blob + off_lo;
+    auto whi = [&](int f) { return *reinterpret_cast<const bf16x8 FN_GLOBAL*>(bhi + (size_t)f * 16 + voff); };
+    auto wlo = [&](int f) { return *reinterpret_cast<const bf16x8 FN_GLOBAL*>(blo + (size_t)f * 16 + voff); };
+#ifdef FNEUS_DBG_NO_WEIGHTS             // timing experiments only: no weight stream from L2
+    bf16x8 wconst;
+    for (int e = 0; e < 8; ++e) wconst[e] = (__bf16)(float)(lane + e);
+    auto whi2 = [&](int f) { bf16x8 t = wconst; asm volatile("" : "+v"(t)); return t; };
+#define whi whi2
+#define wlo whi2
+#endif
+    const unsigned char* fl = frag + lane * 16;
+    bf16x8 ah[D + 1][TN], al[D + 1][TN];
+    bf16x8 bh[3][HB], bl[3][HB];          // see the hazard note in dense_ldsb(): the prefetch is pinned in front of the MFMAs
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+        if (s < KS) {
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int f = (s * NT_TOTAL + T0 + i) * 64;
+                ah[s % (D + 1)][i] = whi(f);
+                if constexpr (PREC == 3 && WLO) al[s % (D + 1)][i] = wlo(f);
+            }
+        }
+#pragma unroll
+    for (int hb = 0; hb < HB; ++hb) {
+        bh[0][hb] = *reinterpret_cast<const bf16x8*>(fl + hb * HALF_BYTES);
+        if constexpr (PREC == 3) bl[0][hb] = *reinterpret_cast<const bf16x8*>(fl + hb * HALF_BYTES + kFragBytes);
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        if (s + D < KS) {
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int f = ((s + D) * NT_TOTAL + T0 + i) * 64;
+                ah[(s + D) % (D + 1)][i] = whi(f);
+                if constexpr (PREC == 3 && WLO) al[(s + D) % (D + 1)][i] = wlo(f);
+            }
+        }
+        if (s + 1 < KS) {
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+                bh[(s + 1) % 3][hb] = *reinterpret_cast<const bf16x8*>(fl + hb * HALF_BYTES + ((s + 1) * NPL) * kFragBytes);
+                if constexpr (PREC == 3)
+                    bl[(s + 1) % 3][hb] = *reinterpret_cast<const bf16x8*>(fl + hb * HALF_BYTES + ((s + 1) * NPL + 1) * kFragBytes);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+                if constexpr (PREC == 3) {
+                    if constexpr (WLO) acc[i][hb] = mfma32(al[s % (D + 1)][i], bh[s % 3][hb], acc[i][hb]);
+                    acc[i][hb] = mfma32(ah[s % (D + 1)][i], bl[s % 3][hb], acc[i][hb]);
+                }
+                acc[i][hb] = mfma32(ah[s % (D + 1)][i], bh[s % 3][hb], acc[i][hb]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#ifdef FNEUS_DBG_NO_WEIGHTS
+#undef whi
+#undef wlo
+#endif
+}
+
 // accumulators <- packed fp32 vector in accumulator layout ([t][h][16])
 template <int NT_TOTAL, int T0, int TN>
 FN_DEV void load_accvec(const unsigned char* __restrict__ blob, uint32_t off, f32x16 (&acc)[TN], int lane, int t0_rt = 0) {

@@ -23,6 +23,13 @@ FN_DEV void sig_put8(unsigned char* __restrict__ blk, int ks, int lane, const fl
 template <bool STREAM>
 FN_DEV void sig_get8(const unsigned char* __restrict__ blk, int ks, int lane, float (&v)[8]) {
     const u16x8* p = reinterpret_cast<const u16x8*>(blk + (size_t)ks * kFragBytes + lane * 16);
+#ifdef FNEUS_DBG_NO_POSTLOAD            // timing experiments only
+    if (STREAM) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.5f;
+        return;
+    }
+#endif
     const u16x8 o = STREAM ? __builtin_nontemporal_load(p) : *p;
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (float)o[e] * (1.0f / 65535.0f);
@@ -113,6 +120,77 @@ FN_DEV void tp_exchange_pp(unsigned char* frag, int lane, int t0, const f32x16 (
             }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // all fragments of the layer are in LDS
+}
+
+// ---- workgroups of HB sample halves (HB = 2: 64 samples share one pass over the weights; dense_ldsb_h) -----------------
+// LDS: half hb keeps its B fragments at frag + hb * HALF_BYTES.  Everything else as tp_exchange_pp, per half.
+template <int PREC, int TN, bool FRAGS, int HB, int HALF_BYTES>
+FN_DEV void tph_exchange(unsigned char* frag, int lane, int t0, const f32x16 (&acc)[TN][HB], unsigned char* const (&blk_hi)[HB],
+                         unsigned char* const (&blk_lo)[HB], const PPLane& pl, const bool (&valid)[HB],
+                         const BFrag<PREC>* extra = nullptr /* [HB][3] */, int extra_slot = 14, int extra_n = 3) {
+    constexpr int NPL = PREC == 3 ? 2 : 1;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // previous fragments are consumed
+#pragma unroll
+    for (int hb = 0; hb < HB; ++hb) {
+        unsigned char* fh = frag + hb * HALF_BYTES;
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int sh = 0; sh < 2; ++sh) {
+                bf16x8 hi, lo;
+                split_half<PREC>(acc[i][hb], sh, hi, lo);
+                const int ks = 2 * (t0 + i) + sh;
+                if constexpr (FRAGS) {
+                    *reinterpret_cast<bf16x8*>(fh + (ks * NPL) * kFragBytes + lane * 16) = hi;
+                    if constexpr (PREC == 3) *reinterpret_cast<bf16x8*>(fh + (ks * NPL + 1) * kFragBytes + lane * 16) = lo;
+                }
+                if (blk_hi[hb] != nullptr) pp_store(blk_hi[hb], ks, pl, valid[hb] ? hi : zero_bf16x8());
+                if constexpr (PREC == 3) {
+                    if (blk_lo[hb] != nullptr) pp_store(blk_lo[hb], ks, pl, valid[hb] ? lo : zero_bf16x8());
+                }
+            }
+        if (extra) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (i < extra_n) {
+                    *reinterpret_cast<bf16x8*>(fh + ((extra_slot + i) * NPL) * kFragBytes + lane * 16) = extra[hb * 3 + i].hi;
+                    if constexpr (PREC == 3)
+                        *reinterpret_cast<bf16x8*>(fh + ((extra_slot + i) * NPL + 1) * kFragBytes + lane * 16) = extra[hb * 3 + i].lo;
+                }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // all fragments of the layer are in LDS
+}
+
+// B fragments (already split) -> k-steps ks0 .. of the LDS region of one half (no barriers: the caller orders them)
+template <int PREC, int NK>
+FN_DEV void frags_to_lds(unsigned char* fh, int lane, int ks0, const BFrag<PREC>* bf) {
+    constexpr int NPL = PREC == 3 ? 2 : 1;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        *reinterpret_cast<bf16x8*>(fh + ((ks0 + k) * NPL) * kFragBytes + lane * 16) = bf[k].hi;
+        if constexpr (PREC == 3) *reinterpret_cast<bf16x8*>(fh + ((ks0 + k) * NPL + 1) * kFragBytes + lane * 16) = bf[k].lo;
+    }
+}
+
+template <int PREC, int NK>
+FN_DEV void lds_to_frags(const unsigned char* fh, int lane, int ks0, BFrag<PREC>* bf) {
+    constexpr int NPL = PREC == 3 ? 2 : 1;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        bf[k].hi = *reinterpret_cast<const bf16x8*>(fh + ((ks0 + k) * NPL) * kFragBytes + lane * 16);
+        if constexpr (PREC == 3) bf[k].lo = *reinterpret_cast<const bf16x8*>(fh + ((ks0 + k) * NPL + 1) * kFragBytes + lane * 16);
+    }
+}
+
+template <int PREC, int KS, int NT_TOTAL, int T0, int TN, bool WLO, int HB, int HALF_BYTES>
+FN_DEV void tph_dense(const unsigned char* __restrict__ blob, uint32_t off_hi, uint32_t off_lo, const unsigned char* frag,
+                      f32x16 (&acc)[TN][HB], int lane, int t0_rt = 0) {
+    // a stage of HB = 2 carries twice the MFMA time of a 32-sample stage: half the prefetch distance covers the same latency
+#ifndef FNEUS_TPH_DEPTH
+#define FNEUS_TPH_DEPTH ((FNEUS_TP_DEPTH + 1) / 2)
+#endif
+    dense_ldsb_h<PREC, KS, NT_TOTAL, T0, TN, (HB >= 2 ? FNEUS_TPH_DEPTH : FNEUS_TP_DEPTH), WLO, HB, HALF_BYTES>(blob, off_hi, off_lo, frag, acc, lane, t0_rt);
 }
 
 // one-wave kernels: B fragments ks0 .. ks0+NK-1 (already split) -> plane block

@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(256, 2) sdf_fwd_grad_tp_kernel(const unsigned 
     const int t0 = 2 * wave;
     const PPLane pl = pp_lane(lane);
     constexpr auto& LY = kSdfLayout;
-    const long tiles = (N + 31) / 32;
+    const long tiles = pp_tiles(N);
     const bool lo_planes = PREC == 3 && st.h_lo != nullptr;
     for (long tile = blockIdx.x; tile * 32 < N; tile += gridDim.x) {
         asm volatile("" : "+s"(blob));
@@ -391,11 +391,16 @@ FN_DEV void asc_post8(f32x16 (&acc)[TN], int T0, const unsigned char* __restrict
             const int ks = 2 * (T0 + t) + s;
             float sv[8];
             sig_get8<true>(sblk, ks, lane, sv);
+#ifdef FNEUS_DBG_NO_POSTLOAD
+            bf16x8 ah = zero_bf16x8(), al = zero_bf16x8();
+            ah[0] = (__bf16)(float)ks;
+#else
             const bf16x8 ah = pp_load(ablk_hi, ks, pl);
             bf16x8 al = zero_bf16x8();
             if constexpr (PREC == 3) {
                 if (ablk_lo != nullptr) al = pp_load(ablk_lo, ks, pl);
             }
+#endif
             bf16x8 chi, clo;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -430,12 +435,17 @@ FN_DEV void desc_post8(f32x16 (&acc)[TN], int T0, const unsigned char* __restric
             const int ks = 2 * (T0 + t) + s;
             float sv[8];
             sig_get8<true>(sblk, ks, lane, sv);
+#ifdef FNEUS_DBG_NO_POSTLOAD
+            bf16x8 chi = zero_bf16x8(), clo = zero_bf16x8();
+            chi[0] = (__bf16)(float)ks;
+#else
             const bf16x8 chi = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(cblk_hi + (size_t)ks * kFragBytes + lane * 16));
             bf16x8 clo = zero_bf16x8();
             if constexpr (PREC == 3) {
                 if (cblk_lo != nullptr)
                     clo = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(cblk_lo + (size_t)ks * kFragBytes + lane * 16));
             }
+#endif
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[t][8 * s + e] = sv[e] * acc[t][8 * s + e] + ((float)chi[e] + (float)clo[e]);
         }
@@ -450,7 +460,7 @@ __global__ void __launch_bounds__(64, 1) sdf_bwd_kernel(const unsigned char* blo
     const int r = lane & 31, h = lane >> 5;
     const PPLane pl = pp_lane(lane);
     constexpr auto& LY = kSdfLayout;
-    const long tiles = (N + 31) / 32;
+    const long tiles = pp_tiles(N);
     const bool lo_planes = PREC == 3 && bb.adj_lo != nullptr;
     for (long tile = blockIdx.x; tile * 32 < N; tile += gridDim.x) {
         asm volatile("" : "+s"(blob));
@@ -595,7 +605,10 @@ FN_DEV void qbar_frags_tp(const float (&x)[3], const float (&nb)[3], BFrag<PREC>
 
 // WLO: see dense() -- false = the weights enter the two chains as their bf16 hi part (FNEUS_BWD_WHI experiment)
 template <int PREC, bool WLO>
-__global__ void __launch_bounds__(256, 2) sdf_bwd_tp_kernel(const unsigned char* blob, PointSrc src, long N, SdfStash st,
+#ifndef FNEUS_K3_OCC
+#define FNEUS_K3_OCC 2
+#endif
+__global__ void __launch_bounds__(256, FNEUS_K3_OCC) sdf_bwd_tp_kernel(const unsigned char* blob, PointSrc src, long N, SdfStash st,
                                                             SdfBwdBufs bb, const float* __restrict__ d_sdf,
                                                             const float* __restrict__ d_feat,
                                                             const float* __restrict__ d_normal) {
@@ -606,7 +619,7 @@ __global__ void __launch_bounds__(256, 2) sdf_bwd_tp_kernel(const unsigned char*
     const int t0 = 2 * wave;
     const PPLane pl = pp_lane(lane);
     constexpr auto& LY = kSdfLayout;
-    const long tiles = (N + 31) / 32;
+    const long tiles = pp_tiles(N);
     const bool lo_planes = PREC == 3 && bb.adj_lo != nullptr;
     const bool a_has_lo = PREC == 3 && st.a_lo != nullptr, c_has_lo = PREC == 3 && bb.c_lo != nullptr;
     for (long tile = blockIdx.x; tile * 32 < N; tile += gridDim.x) {
@@ -752,6 +765,339 @@ __global__ void __launch_bounds__(256, 2) sdf_bwd_tp_kernel(const unsigned char*
     }
 }
 
+// ---- K3 on workgroups of HB sample halves -------------------------------------------------------------------------
+// sdf_bwd_tp_kernel generalised: a 4-wave workgroup carries HB 32-sample tiles through every layer on ONE pass over the
+// weight fragments (dense_ldsb_h).  HB = 2 halves the weight stream per sample (in parity mode the stream from L2, not
+// the matrix pipe, is the nearer bound of a 32-sample workgroup: 85 B/clk/CU wanted, 64 available) and the barriers per
+// sample, and gives a wave 12 MFMAs per k-step between two weight requests instead of 6.  Wave w owns output tiles 2w,
+// 2w+1 of both halves; the one-off jobs of a tile (q_bar fragments, the sdf tile of the seed) are done by wave 0.
+// ---- post-phase operands fetched ONE LAYER AHEAD ----------------------------------------------------------------------
+// The activation work behind a layer's MFMAs needs sigma'(z_l) and a second lane-private operand (a_l for the ascending
+// chain, the coupling c_l for the descending one) from HBM.  Loaded where they are used, their latency (~2 us under load)
+// is exposed 17 times per tile -- 29 % of K3 (measured with the loads compiled out).  A wave's vector-memory operations
+// retire in order, so an HBM load issued just ahead of a dense phase would stall that phase's first weight fragment
+// instead; the loads are therefore issued right behind the PREVIOUS layer's MFMAs and have that layer's activation work,
+// exchange and barriers to land.  LO: the second operand has a lo plane (gradient precision 3).
+template <int HB, int TN, bool LO>
+struct PostData {
+    u16x8 sg[HB][TN][2];
+    bf16x8 hi[HB][TN][2];
+    bf16x8 lo[HB][TN][LO ? 2 : 1];
+};
+
+// PLANE: the second operand is a fragment plane (slot-permuted: a_l) or lane-linear scratch (c_l)
+template <int HB, int TN, bool LO, bool PLANE>
+FN_DEV void post_fetch(PostData<HB, TN, LO>& d, int T0, const unsigned char* const (&sblk)[HB], const unsigned char* const (&hi)[HB],
+                       const unsigned char* const (&lo)[HB], int lane, const PPLane& pl) {
+#pragma unroll
+    for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int ks = 2 * (T0 + t) + s;
+                d.sg[hb][t][s] = __builtin_nontemporal_load(reinterpret_cast<const u16x8*>(sblk[hb] + (size_t)ks * kFragBytes + lane * 16));
+                const size_t off = (size_t)ks * kFragBytes + (PLANE ? ((ks & 1) ? pl.odd : pl.even) : (unsigned)lane * 16u);
+                d.hi[hb][t][s] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(hi[hb] + off));
+                if constexpr (LO) d.lo[hb][t][s] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(lo[hb] + off));
+            }
+}
+
+// ascending chain: adj_{l+1} = s_l * abar_l in place, coupling c_l = beta (1 - s_l) a_l abar_l to the scratch
+template <int PREC, int HB, int TN, bool LO>
+FN_DEV void asc_apply(f32x16 (&acc)[TN][HB], const PostData<HB, TN, LO>& d, int T0, unsigned char* const (&cb_hi)[HB],
+                      unsigned char* const (&cb_lo)[HB], int lane) {
+#pragma unroll
+    for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int ks = 2 * (T0 + t) + s;
+                bf16x8 chi, clo;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float sv = (float)d.sg[hb][t][s][e] * (1.0f / 65535.0f);
+                    float av = (float)d.hi[hb][t][s][e];
+                    if constexpr (LO) av += (float)d.lo[hb][t][s][e];
+                    const float abar = acc[t][hb][8 * s + e];
+                    const float c = kBeta * (1.0f - sv) * av * abar;      // softplus'' * g_hat * abar  (a = s * g_hat)
+                    acc[t][hb][8 * s + e] = sv * abar;
+                    if constexpr (PREC == 3) {
+                        __bf16 x, y;
+                        split_bf16(c, x, y);
+                        chi[e] = x;
+                        clo[e] = y;
+                    } else {
+                        chi[e] = (__bf16)c;
+                    }
+                }
+                __builtin_nontemporal_store(chi, reinterpret_cast<bf16x8*>(cb_hi[hb] + (size_t)ks * kFragBytes + lane * 16));
+                if constexpr (PREC == 3 && LO)
+                    __builtin_nontemporal_store(clo, reinterpret_cast<bf16x8*>(cb_lo[hb] + (size_t)ks * kFragBytes + lane * 16));
+            }
+}
+
+// descending chain: zbar_l = s_l * hbar_{l+1} + c_l
+template <int HB, int TN, bool LO>
+FN_DEV void desc_apply(f32x16 (&acc)[TN][HB], const PostData<HB, TN, LO>& d) {
+#pragma unroll
+    for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float sv = (float)d.sg[hb][t][s][e] * (1.0f / 65535.0f);
+                    float c = (float)d.hi[hb][t][s][e];
+                    if constexpr (LO) c += (float)d.lo[hb][t][s][e];
+                    acc[t][hb][8 * s + e] = sv * acc[t][hb][8 * s + e] + c;
+                }
+}
+
+// asc_post8 / desc_post8 on half `hb` of [tile][half] accumulators
+template <int PREC, int TN, int HB>
+FN_DEV void asc_post_h(f32x16 (&acc)[TN][HB], int hb, int T0, const unsigned char* __restrict__ sblk,
+                       const unsigned char* __restrict__ ablk_hi, const unsigned char* __restrict__ ablk_lo,
+                       unsigned char* __restrict__ cblk_hi, unsigned char* __restrict__ cblk_lo, int lane, const PPLane& pl) {
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        f32x16(&one)[1] = reinterpret_cast<f32x16(&)[1]>(acc[t][hb]);
+        asc_post8<PREC, 1>(one, T0 + t, sblk, ablk_hi, ablk_lo, cblk_hi, cblk_lo, lane, pl);
+#ifdef FNEUS_POST_FENCE
+        __builtin_amdgcn_sched_barrier(0);      // one tile's loads in flight at a time (register pressure)
+#endif
+    }
+}
+template <int PREC, int TN, int HB>
+FN_DEV void desc_post_h(f32x16 (&acc)[TN][HB], int hb, int T0, const unsigned char* __restrict__ sblk,
+                        const unsigned char* __restrict__ cblk_hi, const unsigned char* __restrict__ cblk_lo, int lane) {
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        f32x16(&one)[1] = reinterpret_cast<f32x16(&)[1]>(acc[t][hb]);
+        desc_post8<PREC, 1>(one, T0 + t, sblk, cblk_hi, cblk_lo, lane);
+#ifdef FNEUS_POST_FENCE
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+}
+
+constexpr int kK3Half = 19 * 2 * kFragBytes;      // B fragments of one half: up to 18 k-steps x (hi, lo) + 1 (parking, see below)
+
+#ifndef FNEUS_K3_FETCH
+#define FNEUS_K3_FETCH 0          // 0: post-phase operands fetched in ONE batch where they are used; 1: one layer ahead (measured: no gain)
+#endif
+template <int PREC, bool WLO, int HB, int GP>
+__global__ void __launch_bounds__(256, 2) sdf_bwd_tph_kernel(const unsigned char* blob, PointSrc src, long N, SdfStash st,
+                                                             SdfBwdBufs bb, const float* __restrict__ d_sdf,
+                                                             const float* __restrict__ d_feat,
+                                                             const float* __restrict__ d_normal) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
+    unsigned char* frag = lds_;
+    constexpr int HALF = kK3Half;
+    constexpr bool LO = PREC == 3 && GP == 3;          // lo planes exist (exact-gradient mode)
+    constexpr bool AHEAD = FNEUS_K3_FETCH != 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int t0 = 2 * wave;
+    const PPLane pl = pp_lane(lane);
+    constexpr auto& LY = kSdfLayout;
+    const long tiles = pp_tiles(N);
+    const long groups = (N + 32 * HB - 1) / (32 * HB);
+    for (long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        asm volatile("" : "+s"(blob));
+        long tile[HB], nc[HB];
+        bool valid[HB];
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb) {
+            tile[hb] = grp * HB + hb;
+            const long n = tile[hb] * 32 + r;
+            valid[hb] = n < N;
+            nc[hb] = valid[hb] ? n : N - 1;
+        }
+        auto blk = [&](unsigned char* base, int slot, int hb) { return base + ((size_t)slot * tiles + tile[hb]) * kPPBlock; };
+        auto priv = [&](unsigned char* base, int l, int hb) { return base + ((size_t)tile[hb] * 8 + l) * kPPBlock; };
+        PostData<HB, 2, LO> pd;
+        auto fetch_asc = [&](int l) {
+            const unsigned char *sb[HB], *ah[HB], *al[HB];
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+                sb[hb] = priv(st.ps, l, hb);
+                ah[hb] = blk(st.a_hi, l, hb);
+                al[hb] = LO ? blk(st.a_lo, l, hb) : nullptr;
+            }
+            post_fetch<HB, 2, LO, true>(pd, t0, sb, ah, al, lane, pl);
+        };
+        auto fetch_desc = [&](int l) {
+            const unsigned char *sb[HB], *ch[HB], *cl[HB];
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+                sb[hb] = priv(st.ps, l, hb);
+                ch[hb] = priv(bb.c_hi, l, hb);
+                cl[hb] = LO ? priv(bb.c_lo, l, hb) : nullptr;
+            }
+            post_fetch<HB, 2, LO, false>(pd, t0, sb, ch, cl, lane, pl);
+        };
+        if constexpr (AHEAD) fetch_asc(0);
+        // ---- qbar = J nbar (wave 0): k-steps 0..2 of the first layer, the qbar plane, and a second copy parked in k-steps
+        // 16..18 of the region: layer 4 takes it as its k-steps 14..16 (tangent of the skip input) -- re-encoding the point
+        // there, with the accumulators live, costs ~120 registers
+        if (wave == 0) {
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+                float x[3], nb[3];
+                load_point(src, nc[hb], x);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) nb[c] = valid[hb] ? d_normal[nc[hb] * 3 + c] : 0.0f;
+                BFrag<PREC> qf[kMaxKS];
+                qbar_frags_tp<PREC, 0>(x, nb, qf, h);
+                frags_to_lds<PREC, 3>(frag + hb * HALF, lane, 0, qf);
+                frags_to_lds<PREC, 3>(frag + hb * HALF, lane, 16, qf);
+                frags_to_plane<PREC, 3>(qf, 0, bb.qbar_hi + (size_t)tile[hb] * 4 * kFragBytes,
+                                        LO ? bb.qbar_lo + (size_t)tile[hb] * 4 * kFragBytes : nullptr, pl, valid[hb]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        f32x16 acc[2][HB];
+        // ---- ascending chain: adj_{l+1} = s_l * (W_l adj_l), coupling c_l to the scratch ----
+#pragma unroll 1
+        for (int l = 0; l <= 7; ++l) {
+            asm volatile("" : "+s"(blob));
+            unsigned char *cb_hi[HB], *cb_lo[HB], *o_hi[HB], *o_lo[HB];
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+                cb_hi[hb] = priv(bb.c_hi, l, hb);
+                cb_lo[hb] = LO ? priv(bb.c_lo, l, hb) : nullptr;
+                o_hi[hb] = blk(bb.adj_hi, l, hb);
+                o_lo[hb] = LO ? blk(bb.adj_lo, l, hb) : nullptr;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) zero_acc(acc[i]);
+            // layer 3 has 7 output tiles: wave 3 computes tile 6 and a padding tile whose weights are zero fragments (the
+            // pack pads every layer to whole tiles), so all waves run the same code
+            if (l == 0)
+                tph_dense<PREC, 3, 8, 0, 2, WLO, HB, HALF>(blob, LY.L[0].fwd_hi, LY.L[0].fwd_lo, frag, acc, lane, t0);
+            else if (l == 3) {
+                if (wave < 3) {
+                    tph_dense<PREC, 16, 7, 0, 2, WLO, HB, HALF>(blob, LY.L[3].fwd_hi, LY.L[3].fwd_lo, frag, acc, lane, t0);
+                } else {
+                    f32x16(&a1)[1][HB] = reinterpret_cast<f32x16(&)[1][HB]>(acc);
+                    tph_dense<PREC, 16, 7, 0, 1, WLO, HB, HALF>(blob, LY.L[3].fwd_hi, LY.L[3].fwd_lo, frag, a1, lane, t0);
+                }
+            } else if (l == 4)
+                tph_dense<PREC, 17, 8, 0, 2, WLO, HB, HALF>(blob, LY.L[4].fwd_hi, LY.L[4].fwd_lo, frag, acc, lane, t0);
+            else
+                tph_dense<PREC, 16, 8, 0, 2, WLO, HB, HALF>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, frag, acc, lane, t0);
+            if constexpr (!AHEAD) fetch_asc(l);
+            asc_apply<PREC, HB, 2, LO>(acc, pd, t0, cb_hi, cb_lo, lane);       // (wave 3, layer 3: its second tile is padding)
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (AHEAD) {       // the next post phase's operands: in flight during this exchange and the next MFMAs
+                if (l < 7) fetch_asc(l + 1);
+                else fetch_desc(7);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (l == 3) {
+                if (wave < 3) {
+                    tph_exchange<PREC, 2, true, HB, HALF>(frag, lane, t0, acc, o_hi, o_lo, pl, valid);
+                } else {
+                    f32x16(&a1)[1][HB] = reinterpret_cast<f32x16(&)[1][HB]>(acc);
+                    BFrag<PREC> ex[HB * 3];     // tangent of the skip input: k-steps 14..16 of layer 4 = the parked copy of qbar
+#pragma unroll
+                    for (int hb = 0; hb < HB; ++hb) lds_to_frags<PREC, 3>(frag + hb * HALF, lane, 16, &ex[hb * 3]);
+                    tph_exchange<PREC, 1, true, HB, HALF>(frag, lane, t0, a1, o_hi, o_lo, pl, valid, ex, 14, 3);
+                }
+            } else if (l < 7) {
+                tph_exchange<PREC, 2, true, HB, HALF>(frag, lane, t0, acc, o_hi, o_lo, pl, valid);
+            } else {
+                tph_exchange<PREC, 2, false, HB, HALF>(frag, lane, t0, acc, o_hi, o_lo, pl, valid);     // adj_8: plane only
+            }
+        }
+        // ---- descending chain: zbar_8 = [fbar ; sbar], ubar_l = W_l^T zbar_l, zbar_{l-1} = s_{l-1} * ubar_l + c_{l-1} ----
+        {
+            unsigned char *o_hi[HB], *o_lo[HB];
+            BFrag<PREC> sf[HB * 3];     // tile 8 of zbar_8: row 0 (register 0 of lane half 0) = d sdf, everything else zero
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+                {
+                    f32x16 t2[2];
+                    load_f32<2>(t2, d_feat + 32 * t0, 256, nc[hb], h);
+                    if (!valid[hb]) zero_acc(t2);
+                    acc[0][hb] = t2[0];
+                    acc[1][hb] = t2[1];
+                }
+                o_hi[hb] = blk(bb.zbar_hi, 8, hb);
+                o_lo[hb] = LO ? blk(bb.zbar_lo, 8, hb) : nullptr;
+                if (wave == 0) {
+                    const float sv = (h == 0 && valid[hb]) ? d_sdf[nc[hb]] : 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        sf[hb * 3 + i].hi = zero_bf16x8();
+                        if constexpr (PREC == 3) sf[hb * 3 + i].lo = zero_bf16x8();
+                    }
+                    if constexpr (PREC == 3) {
+                        __bf16 shi, slo;
+                        split_bf16(sv, shi, slo);
+                        sf[hb * 3].hi[0] = shi;
+                        sf[hb * 3].lo[0] = slo;
+                    } else {
+                        sf[hb * 3].hi[0] = (__bf16)sv;
+                    }
+                    frags_to_plane<PREC, 2>(&sf[hb * 3], 0, bb.zsdf_hi + (size_t)tile[hb] * 2 * kFragBytes,
+                                            LO ? bb.zsdf_lo + (size_t)tile[hb] * 2 * kFragBytes : nullptr, pl, valid[hb]);
+                }
+            }
+            // k-steps 0..15: the feature tiles, 16, 17: the sdf tile
+            tph_exchange<PREC, 2, true, HB, HALF>(frag, lane, t0, acc, o_hi, o_lo, pl, valid, wave == 0 ? sf : nullptr, 16, 2);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) zero_acc(acc[i]);
+        tph_dense<PREC, 18, 8, 0, 2, WLO, HB, HALF>(blob, LY.L[8].rev_hi, LY.L[8].rev_lo, frag, acc, lane, t0);
+#pragma unroll 1
+        for (int l = 7; l >= 0; --l) {
+            asm volatile("" : "+s"(blob));
+            unsigned char *o_hi[HB], *o_lo[HB];
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+                o_hi[hb] = blk(bb.zbar_hi, l, hb);
+                o_lo[hb] = LO ? blk(bb.zbar_lo, l, hb) : nullptr;
+            }
+            // here acc = ubar_{l+1} = hbar_{l+1};  zbar_l = s_l * hbar_{l+1} + c_l
+            if constexpr (!AHEAD) fetch_desc(l);
+            desc_apply<HB, 2, LO>(acc, pd);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (AHEAD) {
+                if (l > 0) fetch_desc(l - 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (l == 0) {
+                tph_exchange<PREC, 2, false, HB, HALF>(frag, lane, t0, acc, o_hi, o_lo, pl, valid);
+                break;
+            }
+            if (l == 3 && wave == 3) {   // zbar_3 has 7 tiles: wave 3 owns tile 6 only
+                f32x16(&a1)[1][HB] = reinterpret_cast<f32x16(&)[1][HB]>(acc);
+                tph_exchange<PREC, 1, true, HB, HALF>(frag, lane, t0, a1, o_hi, o_lo, pl, valid);
+            } else {
+                tph_exchange<PREC, 2, true, HB, HALF>(frag, lane, t0, acc, o_hi, o_lo, pl, valid);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) zero_acc(acc[i]);
+            if (l == 4) {   // ubar_4 restricted to the h_4 rows: tiles 0..6 of the 9-tile reverse pack
+                if (wave < 3) {
+                    tph_dense<PREC, 16, 9, 0, 2, WLO, HB, HALF>(blob, LY.L[4].rev_hi, LY.L[4].rev_lo, frag, acc, lane, t0);
+                } else {
+                    f32x16(&a1)[1][HB] = reinterpret_cast<f32x16(&)[1][HB]>(acc);
+                    tph_dense<PREC, 16, 9, 0, 1, WLO, HB, HALF>(blob, LY.L[4].rev_hi, LY.L[4].rev_lo, frag, a1, lane, t0);
+                }
+            } else if (l == 3) {
+                tph_dense<PREC, 14, 8, 0, 2, WLO, HB, HALF>(blob, LY.L[3].rev_hi, LY.L[3].rev_lo, frag, acc, lane, t0);
+            } else {
+                tph_dense<PREC, 16, 8, 0, 2, WLO, HB, HALF>(blob, LY.L[l].rev_hi, LY.L[l].rev_lo, frag, acc, lane, t0);
+            }
+        }
+    }
+}
+
 }  // namespace fneus
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -848,6 +1194,34 @@ extern "C" int fneus_sdf_bwd(const void* blob, const float* pts, const float* ra
     SdfBwdBufs bb = *bufs;
     // tensor-parallel workgroups (two per CU) by default; FNEUS_K3_TP=0 selects one wave per tile (kept for comparison)
     static const int tp_mode = getenv("FNEUS_K3_TP") ? atoi(getenv("FNEUS_K3_TP")) : 1;
+    // 64-sample workgroups (two tiles per pass over the weights) once the launch fills the chip that way; FNEUS_K3_HB=1 / 2 forces
+    static const int hb_env = getenv("FNEUS_K3_HB") ? atoi(getenv("FNEUS_K3_HB")) : 0;
+    const long n_tiles32 = (n_pts + 31) / 32;
+    const int hbs = hb_env ? hb_env : (n_tiles32 >= 1024 ? 2 : 1);
+    if (tp_mode && (hbs == 2 || hbs == 1) && !(getenv("FNEUS_K3_OLD") != nullptr)) {
+        const long groups = (n_pts + 32 * hbs - 1) / (32 * hbs), cap = 256 * 2 * 4;
+        dim3 g2((unsigned)(groups < cap ? groups : cap)), b2(256);
+        static const bool whi2 = getenv("FNEUS_BWD_WHI") != nullptr && atoi(getenv("FNEUS_BWD_WHI")) != 0;
+        const bool exact = bb.adj_lo != nullptr;            // gradient precision 3: lo planes everywhere
+        if (exact && (!st.a_lo || !bb.c_lo || !bb.zbar_lo || !bb.qbar_lo || !bb.zsdf_lo)) return -2;
+#define FNEUS_K3H(P, W, H, G)                                                                                                \
+    do {                                                                                                                     \
+        static bool attr_done = false;                                                                                       \
+        if (!attr_done) {                                                                                                    \
+            allow_big_lds(sdf_bwd_tph_kernel<P, W, H, G>);                                                                   \
+            attr_done = true;                                                                                                \
+        }                                                                                                                    \
+        hipLaunchKernelGGL((sdf_bwd_tph_kernel<P, W, H, G>), g2, b2, H * kK3Half, stream, b, src, n_pts, st, bb, d_sdf, d_feat, \
+                           d_normal);                                                                                        \
+    } while (0)
+        if (prec == 3 && exact) { if (hbs == 2) FNEUS_K3H(3, true, 2, 3); else FNEUS_K3H(3, true, 1, 3); }
+        else if (prec == 3 && !whi2) { if (hbs == 2) FNEUS_K3H(3, true, 2, 1); else FNEUS_K3H(3, true, 1, 1); }
+        else if (prec == 3) { if (hbs == 2) FNEUS_K3H(3, false, 2, 1); else FNEUS_K3H(3, false, 1, 1); }
+        else if (prec == 1) { if (hbs == 2) FNEUS_K3H(1, true, 2, 1); else FNEUS_K3H(1, true, 1, 1); }
+        else return -2;
+#undef FNEUS_K3H
+        return fneus::launch_status();
+    }
     if (tp_mode) {
         const long tiles = (n_pts + 31) / 32, cap = 256 * 2 * 4;
         dim3 g2((unsigned)(tiles < cap ? tiles : cap)), b2(256);

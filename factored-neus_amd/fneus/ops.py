@@ -222,7 +222,8 @@ class SdfStash:
         self.n, self.prec, self.gprec = n, prec, _gprec(prec, gprec)
         bf = torch.bfloat16
         P = 2 if self.gprec == 3 else 1
-        T = self.tiles = (n + 31) // 32
+        self.tiles = (n + 31) // 32                  # tiles that hold samples (what the GEMM sums over)
+        T = 2 * ((n + 63) // 64)                     # tiles allocated (csrc/fneus_pp.h pp_tiles)
         self.pe = torch.zeros((P, T, 4, 64, 8), dtype=bf, device=device) if train else None      # fragment 3 stays zero
         self.h = torch.empty((P, 8, T, 16, 64, 8), dtype=bf, device=device) if train else None
         self.a = torch.empty((P, 8, T, 16, 64, 8), dtype=bf, device=device) if train else None
@@ -286,7 +287,8 @@ class SdfBwdBufs:
         bf = torch.bfloat16
         self.n, self.gprec = n, _gprec(prec, gprec)
         P = 2 if self.gprec == 3 else 1
-        T = self.tiles = (n + 31) // 32
+        self.tiles = (n + 31) // 32
+        T = 2 * ((n + 63) // 64)
         self.qbar = torch.zeros((P, T, 4, 64, 8), dtype=bf, device=device)          # fragment 3 stays zero
         self.adj = torch.zeros((P, 8, T, 16, 64, 8), dtype=bf, device=device)
         self.zbar = torch.zeros((P, 9, T, 16, 64, 8), dtype=bf, device=device)
@@ -311,7 +313,8 @@ class ColStash:
         bf = torch.bfloat16
         self.n, self.gprec = n, _gprec(prec, gprec)
         P = 2 if self.gprec == 3 else 1
-        T = self.tiles = (n + 31) // 32
+        self.tiles = (n + 31) // 32
+        T = 2 * ((n + 63) // 64)
         self.feat = torch.empty((P, T, 16, 64, 8), dtype=bf, device=device) if with_feat else None
         self.side = torch.zeros((P, T, 4, 64, 8), dtype=bf, device=device)           # fragment 3 stays zero
         self.u = torch.empty((P, 4, T, 16, 64, 8), dtype=bf, device=device)

@@ -24,13 +24,20 @@ def _index(F: int):
 
 
 def n_tiles(n: int) -> int:
+    """sample tiles that hold data"""
     return (n + 31) // 32
+
+
+def alloc_tiles(n: int) -> int:
+    """sample tiles a plane is allocated for (csrc/fneus_pp.h pp_tiles): an even count, because workgroups that carry two
+    tiles store a whole padding tile of zeros behind a ragged end"""
+    return 2 * ((n + 63) // 64)
 
 
 def pack(x: torch.Tensor, F: int, planes: int = 1):
     """x [N, W <= 16 F] float -> bf16 planes [planes, tiles, F, 64, 8] (hi, then lo = bf16(x - hi)); padding is zero"""
     N, W = x.shape
-    T = n_tiles(N)
+    T = alloc_tiles(N)
     full = torch.zeros(T * 32, 16 * F, dtype=torch.float32, device=x.device)
     full[:N, :W] = x.float()
     idx = _index(F).to(x.device)
