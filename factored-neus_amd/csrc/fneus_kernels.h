@@ -21,11 +21,12 @@ struct SdfStash {
     unsigned char *a_hi, *a_lo;       // [8][tiles][16 KiB]
     unsigned char *feat_hi, *feat_lo; // [tiles][16 KiB]     feature vector (colour-network input)
     unsigned char* ps;                // sigma'(z_l), u16 fixed point: [tiles][8][16 KiB]
+    f32x16* qs;                       // q_skip scratch of K2's reverse sweep: [tiles][2][64] accumulator tiles (lane-private)
     SdfStash() = default;
     SdfStash(const FneusSdfStash& s)
         : pe_hi((unsigned char*)s.pe_hi), pe_lo((unsigned char*)s.pe_lo), h_hi((unsigned char*)s.h_hi),
           h_lo((unsigned char*)s.h_lo), a_hi((unsigned char*)s.a_hi), a_lo((unsigned char*)s.a_lo),
-          feat_hi((unsigned char*)s.feat_hi), feat_lo((unsigned char*)s.feat_lo), ps((unsigned char*)s.ps) {}
+          feat_hi((unsigned char*)s.feat_hi), feat_lo((unsigned char*)s.feat_lo), ps((unsigned char*)s.ps), qs((f32x16*)s.qs) {}
 };
 
 struct SdfBwdBufs {

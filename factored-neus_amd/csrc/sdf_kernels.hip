@@ -371,6 +371,242 @@ __global__ void __launch_bounds__(256, 2) sdf_fwd_grad_tp_kernel(const unsigned 
     }
 }
 
+// ---- K2 on workgroups of HB sample halves ----------------------------------------------------------------------------
+// sdf_fwd_grad_tp_kernel generalised like K3 (sdf_bwd_tph_kernel): HB 32-sample tiles share one pass over the weight
+// fragments.  The one-off jobs of a tile are spread over the waves: wave 0 encodes the points (k-steps 0..2 of layer 0, the
+// PE plane, and a copy parked in k-steps 16..18 that layer 4 takes as its skip input), wave hb computes the sdf row, the
+// q_skip tiles and the normal of half hb.  q_skip waits for the end of the reverse sweep in a global scratch line per lane
+// (st.qs: written and read back by the same lane; L2 resident).
+constexpr int kK2Half = 19 * 2 * kFragBytes;
+
+template <int TN, int HB>
+FN_DEV void bias_h(const unsigned char* __restrict__ blob, uint32_t off, f32x16 (&acc)[TN][HB], int lane, int t0_rt) {
+    const f32x16 FN_GLOBAL* __restrict__ p = reinterpret_cast<const f32x16 FN_GLOBAL*>((gblob_t)blob + off);
+    const int h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        const f32x16 v = p[(t0_rt + i) * 2 + h];
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb) acc[i][hb] = v;
+    }
+}
+
+template <int PREC, bool TRAIN, int HB, int GP>
+__global__ void __launch_bounds__(256, 2) sdf_fwd_grad_tph_kernel(const unsigned char* blob, PointSrc src, long N, SdfStash st,
+                                                                  float* __restrict__ sdf_out, float* __restrict__ feat_out,
+                                                                  float* __restrict__ normal_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
+    unsigned char* frag = lds_;
+    constexpr int HALF = kK2Half;
+    constexpr bool LO = TRAIN && PREC == 3 && GP == 3;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int t0 = 2 * wave;
+    const PPLane pl = pp_lane(lane);
+    constexpr auto& LY = kSdfLayout;
+    const long tiles = pp_tiles(N);
+    const long groups = (N + 32 * HB - 1) / (32 * HB);
+    for (long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        asm volatile("" : "+s"(blob));
+        long tile[HB], n[HB], nc[HB];
+        bool valid[HB];
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb) {
+            tile[hb] = grp * HB + hb;
+            n[hb] = tile[hb] * 32 + r;
+            valid[hb] = n[hb] < N;
+            nc[hb] = valid[hb] ? n[hb] : N - 1;
+        }
+        auto blk = [&](unsigned char* base, int slot, int hb) { return base + ((size_t)slot * tiles + tile[hb]) * kPPBlock; };
+        auto sig = [&](int l, int hb) { return st.ps + ((size_t)tile[hb] * 8 + l) * kPPBlock; };
+        // ---- positional encoding (wave 0) ----
+        if (wave == 0) {
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+                float x[3], pe[39], jc[39];
+                load_point(src, nc[hb], x);
+                posenc<6, false>(x, pe, jc);
+                BFrag<PREC> pf[kMaxKS];
+                vec_to_bfrag<PREC, 39, 3, 0>(pe, pf, h);
+                frags_to_lds<PREC, 3>(frag + hb * HALF, lane, 0, pf);
+                frags_to_lds<PREC, 3>(frag + hb * HALF, lane, 16, pf);
+                if constexpr (TRAIN)       // PE plane [tiles][4 fragments] (fragment 3 stays zero)
+                    frags_to_plane<PREC, 3>(pf, 0, st.pe_hi + (size_t)tile[hb] * 4 * kFragBytes,
+                                            LO ? st.pe_lo + (size_t)tile[hb] * 4 * kFragBytes : nullptr, pl, valid[hb]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        f32x16 acc[2][HB];
+        // ---------------- forward chain ----------------
+#pragma unroll 1
+        for (int l = 0; l <= 7; ++l) {
+            asm volatile("" : "+s"(blob));
+            unsigned char *hb_hi[HB], *hb_lo[HB];
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+                hb_hi[hb] = TRAIN ? blk(st.h_hi, l, hb) : nullptr;
+                hb_lo[hb] = LO ? blk(st.h_lo, l, hb) : nullptr;
+            }
+            if (l == 3) {               // 7 output tiles (217 features): wave 3 owns tile 6 only
+                if (wave < 3) {
+                    bias_h<2, HB>(blob, LY.L[3].bias, acc, lane, t0);
+                    tph_dense<PREC, 16, 7, 0, 2, true, HB, HALF>(blob, LY.L[3].fwd_hi, LY.L[3].fwd_lo, frag, acc, lane, t0);
+                } else {
+                    f32x16(&a1)[1][HB] = reinterpret_cast<f32x16(&)[1][HB]>(acc);
+                    bias_h<1, HB>(blob, LY.L[3].bias, a1, lane, t0);
+                    tph_dense<PREC, 16, 7, 0, 1, true, HB, HALF>(blob, LY.L[3].fwd_hi, LY.L[3].fwd_lo, frag, a1, lane, t0);
+                }
+            } else {
+                bias_h<2, HB>(blob, LY.L[l].bias, acc, lane, t0);
+                if (l == 0)
+                    tph_dense<PREC, 3, 8, 0, 2, true, HB, HALF>(blob, LY.L[0].fwd_hi, LY.L[0].fwd_lo, frag, acc, lane, t0);
+                else if (l == 4)
+                    tph_dense<PREC, 17, 8, 0, 2, true, HB, HALF>(blob, LY.L[4].fwd_hi, LY.L[4].fwd_lo, frag, acc, lane, t0);
+                else
+                    tph_dense<PREC, 16, 8, 0, 2, true, HB, HALF>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, frag, acc, lane, t0);
+            }
+            const int tn_l = (l == 3 && wave == 3) ? 1 : 2;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                if (i < tn_l) {
+#pragma unroll
+                    for (int hb = 0; hb < HB; ++hb) {
+                        f32x16(&one)[1] = reinterpret_cast<f32x16(&)[1]>(acc[i][hb]);
+                        softplus_sig8<1>(one, sig(l, hb), t0 + i, lane);
+                    }
+                }
+            if (l == 3 && wave == 3) {
+                f32x16(&a1)[1][HB] = reinterpret_cast<f32x16(&)[1][HB]>(acc);
+                BFrag<PREC> ex[HB * 3];        // skip connection (fields.py:83-84): k-steps 14..16 of layer 4 = the parked encoding
+#pragma unroll
+                for (int hb = 0; hb < HB; ++hb) lds_to_frags<PREC, 3>(frag + hb * HALF, lane, 16, &ex[hb * 3]);
+                tph_exchange<PREC, 1, true, HB, HALF>(frag, lane, t0, a1, hb_hi, hb_lo, pl, valid, ex, 14, 3);
+            } else {
+                tph_exchange<PREC, 2, true, HB, HALF>(frag, lane, t0, acc, hb_hi, hb_lo, pl, valid);
+            }
+        }
+        // layer 8 (linear): feature tiles 0..7 (two per wave) and the sdf row (tile 8: wave hb for half hb)
+        bias_h<2, HB>(blob, LY.L[8].bias, acc, lane, t0);
+        tph_dense<PREC, 16, 9, 0, 2, true, HB, HALF>(blob, LY.L[8].fwd_hi, LY.L[8].fwd_lo, frag, acc, lane, t0);
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                f32x16(&one)[1] = reinterpret_cast<f32x16(&)[1]>(acc[i][hb]);
+                store_f32<1>(one, feat_out + 32 * (t0 + i), 256, nc[hb], h, valid[hb]);
+            }
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb)
+            if (wave == hb) {
+                f32x16 s1[1][1];
+                bias_h<1, 1>(blob, LY.L[8].bias, s1, lane, 8);
+                tph_dense<PREC, 16, 9, 8, 1, true, 1, HALF>(blob, LY.L[8].fwd_hi, LY.L[8].fwd_lo, frag + hb * HALF, s1, lane);
+                if (valid[hb] && lane < 32) sdf_out[n[hb]] = s1[0][0][0];
+            }
+        if constexpr (TRAIN) {      // the feature plane: the colour network's weight-gradient operand
+            unsigned char *f_hi[HB], *f_lo[HB];
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+                f_hi[hb] = st.feat_hi + (size_t)tile[hb] * kPPBlock;
+                f_lo[hb] = LO ? st.feat_lo + (size_t)tile[hb] * kPPBlock : nullptr;
+            }
+            tph_exchange<PREC, 2, false, HB, HALF>(frag, lane, t0, acc, f_hi, f_lo, pl, valid);
+        }
+        // ---------------- reverse sweep: g = d sdf / d u_l   ----------------
+        bias_h<2, HB>(blob, LY.extra, acc, lane, t0);                  // g_hat(h_8) = row 0 of W_8
+#pragma unroll 1
+        for (int l = 7; l >= 0; --l) {
+            asm volatile("" : "+s"(blob));
+            unsigned char *a_hi[HB], *a_lo[HB];
+            u16x8 sg[2][HB][2];          // sigma'(z_l) of this wave's tiles: one batch of loads
+            const int tn_l = (l == 3 && wave == 3) ? 1 : 2;
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+                a_hi[hb] = TRAIN ? blk(st.a_hi, l, hb) : nullptr;
+                a_lo[hb] = LO ? blk(st.a_lo, l, hb) : nullptr;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int sh = 0; sh < 2; ++sh)
+                        sg[i][hb][sh] = *reinterpret_cast<const u16x8*>(sig(l, hb) + (size_t)(2 * (t0 + i) + sh) * kFragBytes + lane * 16);
+            }
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int sh = 0; sh < 2; ++sh)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[i][hb][8 * sh + e] *= (float)sg[i][hb][sh][e] * (1.0f / 65535.0f);   // a_l
+            if (tn_l == 1) {
+                f32x16(&a1)[1][HB] = reinterpret_cast<f32x16(&)[1][HB]>(acc);
+                tph_exchange<PREC, 1, true, HB, HALF>(frag, lane, t0, a1, a_hi, a_lo, pl, valid);
+            } else {
+                tph_exchange<PREC, 2, true, HB, HALF>(frag, lane, t0, acc, a_hi, a_lo, pl, valid);
+            }
+            if (l == 0) break;
+            if (l == 4) {   // 9 row tiles: 0..6 -> g_hat(h_4), 7..8 -> q_skip (PE part of the skip input; wave hb for half hb)
+#pragma unroll
+                for (int hb = 0; hb < HB; ++hb)
+                    if (wave == hb) {
+                        f32x16 qs[2][1];
+                        zero_acc(qs[0]);
+                        zero_acc(qs[1]);
+                        tph_dense<PREC, 16, 9, 7, 2, true, 1, HALF>(blob, LY.L[4].rev_hi, LY.L[4].rev_lo, frag + hb * HALF, qs, lane);
+                        f32x16* q = st.qs + ((size_t)tile[hb] * 2) * 64 + lane;
+                        q[0] = qs[0][0];
+                        q[64] = qs[1][0];
+                    }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) zero_acc(acc[i]);
+                if (wave < 3) {
+                    tph_dense<PREC, 16, 9, 0, 2, true, HB, HALF>(blob, LY.L[4].rev_hi, LY.L[4].rev_lo, frag, acc, lane, t0);
+                } else {
+                    f32x16(&a1)[1][HB] = reinterpret_cast<f32x16(&)[1][HB]>(acc);
+                    tph_dense<PREC, 16, 9, 0, 1, true, HB, HALF>(blob, LY.L[4].rev_hi, LY.L[4].rev_lo, frag, a1, lane, t0);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) zero_acc(acc[i]);
+                if (l == 3)
+                    tph_dense<PREC, 14, 8, 0, 2, true, HB, HALF>(blob, LY.L[3].rev_hi, LY.L[3].rev_lo, frag, acc, lane, t0);
+                else
+                    tph_dense<PREC, 16, 8, 0, 2, true, HB, HALF>(blob, LY.L[l].rev_hi, LY.L[l].rev_lo, frag, acc, lane, t0);
+            }
+        }
+        // the 2 row tiles of the 39 PE inputs and normal = J^T q: wave hb for half hb
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb)
+            if (wave == hb) {
+                f32x16 qq[2][1];
+                zero_acc(qq[0]);
+                zero_acc(qq[1]);
+                tph_dense<PREC, 16, 2, 0, 2, true, 1, HALF>(blob, LY.L[0].rev_hi, LY.L[0].rev_lo, frag + hb * HALF, qq, lane);
+                const f32x16* qsk = st.qs + ((size_t)tile[hb] * 2) * 64 + lane;
+                f32x16 q[2];
+                q[0] = qq[0][0] + qsk[0];
+                q[1] = qq[1][0] + qsk[64];
+                float x[3], pe[39], jc[39];       // Jacobian coefficients of the encoding, recomputed
+                load_point(src, nc[hb], x);
+                posenc<6, true>(x, pe, jc);
+                float nrm[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float coef[39];
+#pragma unroll
+                    for (int f = 0; f < 39; ++f) coef[f] = ((f % 3) == c) ? jc[f] : 0.0f;
+                    const float part = acc_dot_partial<2, 39>(q, coef, h);
+                    nrm[c] = part + xor32(part);
+                }
+                if (valid[hb] && lane < 32) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) normal_out[n[hb] * 3 + c] = nrm[c];
+                }
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // all four waves finish the group together
+    }
+}
+
 // ---- K3 ----------------------------------------------------------------------------------------------------
 // Backward of (sdf, feature, normal) w.r.t. the SDF-network weights: the two chains of SURVEY.md Appendix A.
 //   ascending  (tangent of the reverse sweep): adj_0 = J nbar;  abar_l = W_l adj_l;  adj_{l+1} = s_l * abar_l;
@@ -379,213 +615,6 @@ __global__ void __launch_bounds__(256, 2) sdf_fwd_grad_tp_kernel(const unsigned 
 //               zbar_{l-1} = s_{l-1} * ubar_l + c_{l-1}
 // The operands of dW_l = zbar_l^T u_l + a_l^T adj_l leave as fragment planes (fneus_pp.h) for dw_gemm_pp.hip: the B
 // fragments every layer converts its accumulators into anyway, stored straight from registers.
-// tiles [T0, T0+TN) of the layer;  cblk_*: coupling scratch (lane-private, lane-linear)
-template <int PREC, int TN>
-FN_DEV void asc_post8(f32x16 (&acc)[TN], int T0, const unsigned char* __restrict__ sblk, const unsigned char* __restrict__ ablk_hi,
-                      const unsigned char* __restrict__ ablk_lo, unsigned char* __restrict__ cblk_hi,
-                      unsigned char* __restrict__ cblk_lo, int lane, const PPLane& pl) {
-#pragma unroll
-    for (int t = 0; t < TN; ++t)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int ks = 2 * (T0 + t) + s;
-            float sv[8];
-            sig_get8<true>(sblk, ks, lane, sv);
-#ifdef FNEUS_DBG_NO_POSTLOAD
-            bf16x8 ah = zero_bf16x8(), al = zero_bf16x8();
-            ah[0] = (__bf16)(float)ks;
-#else
-            const bf16x8 ah = pp_load(ablk_hi, ks, pl);
-            bf16x8 al = zero_bf16x8();
-            if constexpr (PREC == 3) {
-                if (ablk_lo != nullptr) al = pp_load(ablk_lo, ks, pl);
-            }
-#endif
-            bf16x8 chi, clo;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float abar = acc[t][8 * s + e];
-                const float av = (float)ah[e] + (float)al[e];
-                const float c = kBeta * (1.0f - sv[e]) * av * abar;      // softplus'' * g_hat * abar  (a = s * g_hat)
-                acc[t][8 * s + e] = sv[e] * abar;
-                if constexpr (PREC == 3) {
-                    __bf16 x, y;
-                    split_bf16(c, x, y);
-                    chi[e] = x;
-                    clo[e] = y;
-                } else {
-                    chi[e] = (__bf16)c;
-                }
-            }
-            __builtin_nontemporal_store(chi, reinterpret_cast<bf16x8*>(cblk_hi + (size_t)ks * kFragBytes + lane * 16));
-            if constexpr (PREC == 3) {
-                if (cblk_lo != nullptr)
-                    __builtin_nontemporal_store(clo, reinterpret_cast<bf16x8*>(cblk_lo + (size_t)ks * kFragBytes + lane * 16));
-            }
-        }
-}
-
-template <int PREC, int TN>
-FN_DEV void desc_post8(f32x16 (&acc)[TN], int T0, const unsigned char* __restrict__ sblk, const unsigned char* __restrict__ cblk_hi,
-                       const unsigned char* __restrict__ cblk_lo, int lane) {
-#pragma unroll
-    for (int t = 0; t < TN; ++t)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int ks = 2 * (T0 + t) + s;
-            float sv[8];
-            sig_get8<true>(sblk, ks, lane, sv);
-#ifdef FNEUS_DBG_NO_POSTLOAD
-            bf16x8 chi = zero_bf16x8(), clo = zero_bf16x8();
-            chi[0] = (__bf16)(float)ks;
-#else
-            const bf16x8 chi = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(cblk_hi + (size_t)ks * kFragBytes + lane * 16));
-            bf16x8 clo = zero_bf16x8();
-            if constexpr (PREC == 3) {
-                if (cblk_lo != nullptr)
-                    clo = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(cblk_lo + (size_t)ks * kFragBytes + lane * 16));
-            }
-#endif
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[t][8 * s + e] = sv[e] * acc[t][8 * s + e] + ((float)chi[e] + (float)clo[e]);
-        }
-}
-
-template <int PREC>
-__global__ void __launch_bounds__(64, 1) sdf_bwd_kernel(const unsigned char* blob, PointSrc src, long N, SdfStash st,
-                                                        SdfBwdBufs bb, const float* __restrict__ d_sdf,
-                                                        const float* __restrict__ d_feat,
-                                                        const float* __restrict__ d_normal) {
-    const int lane = threadIdx.x;
-    const int r = lane & 31, h = lane >> 5;
-    const PPLane pl = pp_lane(lane);
-    constexpr auto& LY = kSdfLayout;
-    const long tiles = pp_tiles(N);
-    const bool lo_planes = PREC == 3 && bb.adj_lo != nullptr;
-    for (long tile = blockIdx.x; tile * 32 < N; tile += gridDim.x) {
-        asm volatile("" : "+s"(blob));
-        const long n = tile * 32 + r;
-        const bool valid = n < N;
-        const long nc = valid ? n : N - 1;
-        const unsigned char* sig_t = st.ps + (size_t)tile * 8 * kPPBlock;
-        unsigned char* c_hi = bb.c_hi + (size_t)tile * 8 * kPPBlock;
-        unsigned char* c_lo = (PREC == 3 && bb.c_lo != nullptr) ? bb.c_lo + (size_t)tile * 8 * kPPBlock : nullptr;
-        auto plane = [&](unsigned char* base, int slot) { return base + ((size_t)slot * tiles + tile) * kPPBlock; };
-        auto plane_lo = [&](unsigned char* base, int slot) { return lo_planes ? base + ((size_t)slot * tiles + tile) * kPPBlock : nullptr; };
-        BFrag<PREC> bf[kMaxKS];
-        BFrag<PREC> qf[3];
-        f32x16 acc[9];
-        f32x16(&a8)[8] = reinterpret_cast<f32x16(&)[8]>(acc);
-        f32x16(&a7)[7] = reinterpret_cast<f32x16(&)[7]>(acc);
-        // ---- qbar = J nbar ----
-        {
-            float x[3], pe[39], jc[39], qb[39];
-            load_point(src, nc, x);
-            posenc<6, true>(x, pe, jc);
-            float nb[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) nb[c] = valid ? d_normal[nc * 3 + c] : 0.0f;
-#pragma unroll
-            for (int f = 0; f < 39; ++f) qb[f] = jc[f] * nb[f % 3];
-            vec_to_bfrag<PREC, 39, 3, 0>(qb, bf, h);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) qf[i] = bf[i];
-            frags_to_plane<PREC, 3>(bf, 0, bb.qbar_hi + (size_t)tile * 4 * kFragBytes,
-                                    lo_planes ? bb.qbar_lo + (size_t)tile * 4 * kFragBytes : nullptr, pl, valid);
-        }
-        // a_l blocks of this tile (lo plane optional)
-        auto a_hi = [&](int l) { return st.a_hi + ((size_t)l * tiles + tile) * kPPBlock; };
-        auto a_lo = [&](int l) { return (PREC == 3 && st.a_lo != nullptr) ? st.a_lo + ((size_t)l * tiles + tile) * kPPBlock : nullptr; };
-        // ---- ascending chain ----
-        zero_acc(a8);
-        dense<PREC, 3, 8, 0, 8, 0, kDeep<PREC>>(blob, LY.L[0].fwd_hi, LY.L[0].fwd_lo, bf, a8, lane);
-        asc_post8<PREC, 8>(a8, 0, sig_t, a_hi(0), a_lo(0), c_hi, c_lo, lane, pl);
-        acc_to_bfrag<PREC, 8>(a8, bf);
-        frags_to_plane<PREC, 16>(bf, 0, plane(bb.adj_hi, 0), plane_lo(bb.adj_lo, 0), pl, valid);
-        for (int l = 1; l <= 2; ++l) {
-            zero_acc(a8);
-            dense<PREC, 16, 8, 0, 8, 0, kDeep<PREC>>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, bf, a8, lane);
-            asc_post8<PREC, 8>(a8, 0, sig_t + (size_t)l * kPPBlock, a_hi(l), a_lo(l), c_hi + (size_t)l * kPPBlock,
-                               c_lo ? c_lo + (size_t)l * kPPBlock : nullptr, lane, pl);
-            acc_to_bfrag<PREC, 8>(a8, bf);
-            frags_to_plane<PREC, 16>(bf, 0, plane(bb.adj_hi, l), plane_lo(bb.adj_lo, l), pl, valid);
-        }
-        {
-            zero_acc(a7);
-            dense<PREC, 16, 7, 0, 7, 0, kDeep<PREC>>(blob, LY.L[3].fwd_hi, LY.L[3].fwd_lo, bf, a7, lane);
-            asc_post8<PREC, 7>(a7, 0, sig_t + (size_t)3 * kPPBlock, a_hi(3), a_lo(3), c_hi + (size_t)3 * kPPBlock,
-                               c_lo ? c_lo + (size_t)3 * kPPBlock : nullptr, lane, pl);
-            acc_to_bfrag<PREC, 7>(a7, bf);
-            frags_to_plane<PREC, 14>(bf, 0, plane(bb.adj_hi, 3), plane_lo(bb.adj_lo, 3), pl, valid);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) bf[14 + i] = qf[i];
-        }
-        {
-            zero_acc(a8);
-            dense<PREC, 17, 8, 0, 8, 0, kDeep<PREC>>(blob, LY.L[4].fwd_hi, LY.L[4].fwd_lo, bf, a8, lane);
-            asc_post8<PREC, 8>(a8, 0, sig_t + (size_t)4 * kPPBlock, a_hi(4), a_lo(4), c_hi + (size_t)4 * kPPBlock,
-                               c_lo ? c_lo + (size_t)4 * kPPBlock : nullptr, lane, pl);
-            acc_to_bfrag<PREC, 8>(a8, bf);
-            frags_to_plane<PREC, 16>(bf, 0, plane(bb.adj_hi, 4), plane_lo(bb.adj_lo, 4), pl, valid);
-        }
-        for (int l = 5; l <= 7; ++l) {
-            zero_acc(a8);
-            dense<PREC, 16, 8, 0, 8, 0, kDeep<PREC>>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, bf, a8, lane);
-            asc_post8<PREC, 8>(a8, 0, sig_t + (size_t)l * kPPBlock, a_hi(l), a_lo(l), c_hi + (size_t)l * kPPBlock,
-                               c_lo ? c_lo + (size_t)l * kPPBlock : nullptr, lane, pl);
-            acc_to_bfrag<PREC, 8>(a8, bf);
-            frags_to_plane<PREC, 16>(bf, 0, plane(bb.adj_hi, l), plane_lo(bb.adj_lo, l), pl, valid);
-        }
-        // ---- descending chain ----
-        load_f32<8>(a8, d_feat, 256, nc, h);
-        if (!valid) zero_acc(a8);
-        zero_acc(reinterpret_cast<f32x16(&)[1]>(acc[8]));
-        if (h == 0 && valid) acc[8][0] = d_sdf[nc];
-        acc_to_bfrag<PREC, 9>(acc, bf);
-        frags_to_plane<PREC, 16>(bf, 0, plane(bb.zbar_hi, 8), plane_lo(bb.zbar_lo, 8), pl, valid);
-        frags_to_plane<PREC, 2>(&bf[16], 0, bb.zsdf_hi + (size_t)tile * 2 * kFragBytes,
-                                lo_planes ? bb.zsdf_lo + (size_t)tile * 2 * kFragBytes : nullptr, pl, valid);
-        zero_acc(a8);
-        dense<PREC, 18, 8, 0, 8, 0, kDeep<PREC>>(blob, LY.L[8].rev_hi, LY.L[8].rev_lo, bf, a8, lane);
-        for (int l = 7; l >= 5; --l) {
-            // here a8 = ubar_{l+1} = hbar_{l+1};  zbar_l = s_l * hbar_{l+1} + c_l
-            desc_post8<PREC, 8>(a8, 0, sig_t + (size_t)l * kPPBlock, c_hi + (size_t)l * kPPBlock,
-                                c_lo ? c_lo + (size_t)l * kPPBlock : nullptr, lane);
-            acc_to_bfrag<PREC, 8>(a8, bf);
-            frags_to_plane<PREC, 16>(bf, 0, plane(bb.zbar_hi, l), plane_lo(bb.zbar_lo, l), pl, valid);
-            zero_acc(a8);
-            dense<PREC, 16, 8, 0, 8, 0, kDeep<PREC>>(blob, LY.L[l].rev_hi, LY.L[l].rev_lo, bf, a8, lane);
-        }
-        {   // zbar_4, then ubar_4 restricted to the h_4 rows (7 tiles of the 9-tile reverse pack)
-            desc_post8<PREC, 8>(a8, 0, sig_t + (size_t)4 * kPPBlock, c_hi + (size_t)4 * kPPBlock,
-                                c_lo ? c_lo + (size_t)4 * kPPBlock : nullptr, lane);
-            acc_to_bfrag<PREC, 8>(a8, bf);
-            frags_to_plane<PREC, 16>(bf, 0, plane(bb.zbar_hi, 4), plane_lo(bb.zbar_lo, 4), pl, valid);
-            zero_acc(a7);
-            dense<PREC, 16, 9, 0, 7, 0, kDeep<PREC>>(blob, LY.L[4].rev_hi, LY.L[4].rev_lo, bf, a7, lane);
-        }
-        {   // zbar_3 (7 tiles), ubar_3
-            desc_post8<PREC, 7>(a7, 0, sig_t + (size_t)3 * kPPBlock, c_hi + (size_t)3 * kPPBlock,
-                                c_lo ? c_lo + (size_t)3 * kPPBlock : nullptr, lane);
-            acc_to_bfrag<PREC, 7>(a7, bf);
-            frags_to_plane<PREC, 14>(bf, 0, plane(bb.zbar_hi, 3), plane_lo(bb.zbar_lo, 3), pl, valid);
-            zero_acc(a8);
-            dense<PREC, 14, 8, 0, 8, 0, kDeep<PREC>>(blob, LY.L[3].rev_hi, LY.L[3].rev_lo, bf, a8, lane);
-        }
-        for (int l = 2; l >= 1; --l) {
-            desc_post8<PREC, 8>(a8, 0, sig_t + (size_t)l * kPPBlock, c_hi + (size_t)l * kPPBlock,
-                                c_lo ? c_lo + (size_t)l * kPPBlock : nullptr, lane);
-            acc_to_bfrag<PREC, 8>(a8, bf);
-            frags_to_plane<PREC, 16>(bf, 0, plane(bb.zbar_hi, l), plane_lo(bb.zbar_lo, l), pl, valid);
-            zero_acc(a8);
-            dense<PREC, 16, 8, 0, 8, 0, kDeep<PREC>>(blob, LY.L[l].rev_hi, LY.L[l].rev_lo, bf, a8, lane);
-        }
-        desc_post8<PREC, 8>(a8, 0, sig_t, c_hi, c_lo, lane);
-        acc_to_bfrag<PREC, 8>(a8, bf);
-        frags_to_plane<PREC, 16>(bf, 0, plane(bb.zbar_hi, 0), plane_lo(bb.zbar_lo, 0), pl, valid);
-    }
-}
-
 // ---- K3, tensor-parallel workgroups --------------------------------------------------------------------------------
 // Same maths, buffers and results as sdf_bwd_kernel, organised like sdf_fwd_grad_tp_kernel: wave w owns tiles 2w, 2w+1 of
 // every layer, two workgroups per CU.  With the fragment planes the kernel has no store phase of its own any more (each
@@ -603,174 +632,6 @@ FN_DEV void qbar_frags_tp(const float (&x)[3], const float (&nb)[3], BFrag<PREC>
     vec_to_bfrag<PREC, 39, 3, KS0>(qb, bf, h);
 }
 
-// WLO: see dense() -- false = the weights enter the two chains as their bf16 hi part (FNEUS_BWD_WHI experiment)
-template <int PREC, bool WLO>
-#ifndef FNEUS_K3_OCC
-#define FNEUS_K3_OCC 2
-#endif
-__global__ void __launch_bounds__(256, FNEUS_K3_OCC) sdf_bwd_tp_kernel(const unsigned char* blob, PointSrc src, long N, SdfStash st,
-                                                            SdfBwdBufs bb, const float* __restrict__ d_sdf,
-                                                            const float* __restrict__ d_feat,
-                                                            const float* __restrict__ d_normal) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
-    unsigned char* frag = lds_;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int t0 = 2 * wave;
-    const PPLane pl = pp_lane(lane);
-    constexpr auto& LY = kSdfLayout;
-    const long tiles = pp_tiles(N);
-    const bool lo_planes = PREC == 3 && bb.adj_lo != nullptr;
-    const bool a_has_lo = PREC == 3 && st.a_lo != nullptr, c_has_lo = PREC == 3 && bb.c_lo != nullptr;
-    for (long tile = blockIdx.x; tile * 32 < N; tile += gridDim.x) {
-        asm volatile("" : "+s"(blob));
-        const long n = tile * 32 + r;
-        const bool valid = n < N;
-        const long nc = valid ? n : N - 1;
-        const unsigned char* sig_t = st.ps + (size_t)tile * 8 * kPPBlock;
-        unsigned char* c_hi = bb.c_hi + (size_t)tile * 8 * kPPBlock;
-        unsigned char* c_lo = c_has_lo ? bb.c_lo + (size_t)tile * 8 * kPPBlock : nullptr;
-        BFrag<PREC> bf[kMaxKS];
-        f32x16 acc[2];
-        f32x16(&a1)[1] = reinterpret_cast<f32x16(&)[1]>(acc);
-        // ---- qbar = J nbar ----
-        float x[3], nb[3];
-        load_point(src, nc, x);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) nb[c] = valid ? d_normal[nc * 3 + c] : 0.0f;
-        qbar_frags_tp<PREC, 0>(x, nb, bf, h);
-        if (wave == 0)
-            frags_to_plane<PREC, 3>(bf, 0, bb.qbar_hi + (size_t)tile * 4 * kFragBytes,
-                                    lo_planes ? bb.qbar_lo + (size_t)tile * 4 * kFragBytes : nullptr, pl, valid);
-        // ---- ascending chain: adj_{l+1} = s_l * (W_l adj_l), coupling c_l to the scratch ----
-#pragma unroll 1
-        for (int l = 0; l <= 7; ++l) {
-            asm volatile("" : "+s"(blob));
-            const unsigned char* sblk = sig_t + (size_t)l * kPPBlock;
-            const unsigned char* ab_hi = st.a_hi + ((size_t)l * tiles + tile) * kPPBlock;
-            const unsigned char* ab_lo = a_has_lo ? st.a_lo + ((size_t)l * tiles + tile) * kPPBlock : nullptr;
-            unsigned char* cb_hi = c_hi + (size_t)l * kPPBlock;
-            unsigned char* cb_lo = c_has_lo ? c_lo + (size_t)l * kPPBlock : nullptr;
-            unsigned char* o_hi = bb.adj_hi + ((size_t)l * tiles + tile) * kPPBlock;
-            unsigned char* o_lo = lo_planes ? bb.adj_lo + ((size_t)l * tiles + tile) * kPPBlock : nullptr;
-            if (l == 3) {
-                if (wave < 3) {
-                    zero_acc(acc);
-                    tp_dense<PREC, 16, 7, 0, 2, WLO>(blob, LY.L[3].fwd_hi, LY.L[3].fwd_lo, frag, bf, acc, lane, t0);
-                    asc_post8<PREC, 2>(acc, t0, sblk, ab_hi, ab_lo, cb_hi, cb_lo, lane, pl);
-                    tp_exchange_pp<PREC, 2, true>(frag, lane, t0, acc, o_hi, o_lo, pl, valid);
-                } else {
-                    zero_acc(a1);
-                    tp_dense<PREC, 16, 7, 0, 1, WLO>(blob, LY.L[3].fwd_hi, LY.L[3].fwd_lo, frag, bf, a1, lane, t0);
-                    asc_post8<PREC, 1>(a1, t0, sblk, ab_hi, ab_lo, cb_hi, cb_lo, lane, pl);
-                    BFrag<PREC>* skip = nullptr;
-                    if constexpr (kTpLdsB<PREC>) {      // tangent of the skip input: k-steps 14..16 of layer 4
-                        qbar_frags_tp<PREC, 14>(x, nb, bf, h);
-                        skip = &bf[14];
-                    }
-                    tp_exchange_pp<PREC, 1, true>(frag, lane, t0, a1, o_hi, o_lo, pl, valid, skip);
-                }
-                tp_operands<PREC, 14>(frag, lane, bf);
-                if constexpr (!kTpLdsB<PREC>) qbar_frags_tp<PREC, 14>(x, nb, bf, h);
-            } else {
-                zero_acc(acc);
-                if (l == 0)
-                    dense<PREC, 3, 8, 0, 2, 0, 0, WLO>(blob, LY.L[0].fwd_hi, LY.L[0].fwd_lo, bf, acc, lane, t0);
-                else if (l == 4)
-                    tp_dense<PREC, 17, 8, 0, 2, WLO>(blob, LY.L[4].fwd_hi, LY.L[4].fwd_lo, frag, bf, acc, lane, t0);
-                else
-                    tp_dense<PREC, 16, 8, 0, 2, WLO>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, frag, bf, acc, lane, t0);
-                asc_post8<PREC, 2>(acc, t0, sblk, ab_hi, ab_lo, cb_hi, cb_lo, lane, pl);
-                if (l < 7) {
-                    tp_exchange_pp<PREC, 2, true>(frag, lane, t0, acc, o_hi, o_lo, pl, valid);
-                    tp_operands<PREC, 16>(frag, lane, bf);
-                } else {
-                    tp_exchange_pp<PREC, 2, false>(frag, lane, t0, acc, o_hi, o_lo, pl, valid);     // adj_8: plane only
-                }
-            }
-        }
-        // ---- descending chain: zbar_8 = [fbar ; sbar], ubar_l = W_l^T zbar_l, zbar_{l-1} = s_{l-1} * ubar_l + c_{l-1} ----
-        load_f32<2>(acc, d_feat + 32 * t0, 256, nc, h);
-        if (!valid) zero_acc(acc);
-        {
-            BFrag<PREC> sf[2];          // tile 8 of zbar_8: row 0 (register 0 of lane half 0) = d sdf, everything else zero
-            BFrag<PREC>* extra = nullptr;
-            if (wave == 0) {
-                const float sv = (h == 0 && valid) ? d_sdf[nc] : 0.0f;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    sf[i].hi = zero_bf16x8();
-                    if constexpr (PREC == 3) sf[i].lo = zero_bf16x8();
-                }
-                if constexpr (PREC == 3) {
-                    __bf16 shi, slo;
-                    split_bf16(sv, shi, slo);
-                    sf[0].hi[0] = shi;
-                    sf[0].lo[0] = slo;
-                } else {
-                    sf[0].hi[0] = (__bf16)sv;
-                }
-                frags_to_plane<PREC, 2>(sf, 0, bb.zsdf_hi + (size_t)tile * 2 * kFragBytes,
-                                        lo_planes ? bb.zsdf_lo + (size_t)tile * 2 * kFragBytes : nullptr, pl, valid);
-                extra = sf;
-            }
-            // k-steps 0..15: the feature tiles, 16, 17: the sdf tile
-            tp_exchange_pp<PREC, 2, true>(frag, lane, t0, acc, bb.zbar_hi + ((size_t)8 * tiles + tile) * kPPBlock,
-                                          lo_planes ? bb.zbar_lo + ((size_t)8 * tiles + tile) * kPPBlock : nullptr, pl, valid,
-                                          extra, 16, 2);
-        }
-        tp_operands<PREC, 18>(frag, lane, bf);
-        zero_acc(acc);
-        tp_dense<PREC, 18, 8, 0, 2, WLO>(blob, LY.L[8].rev_hi, LY.L[8].rev_lo, frag, bf, acc, lane, t0);
-#pragma unroll 1
-        for (int l = 7; l >= 1; --l) {
-            asm volatile("" : "+s"(blob));
-            const unsigned char* sblk = sig_t + (size_t)l * kPPBlock;
-            const unsigned char* cb_hi = c_hi + (size_t)l * kPPBlock;
-            const unsigned char* cb_lo = c_has_lo ? c_lo + (size_t)l * kPPBlock : nullptr;
-            unsigned char* o_hi = bb.zbar_hi + ((size_t)l * tiles + tile) * kPPBlock;
-            unsigned char* o_lo = lo_planes ? bb.zbar_lo + ((size_t)l * tiles + tile) * kPPBlock : nullptr;
-            if (l == 3) {   // zbar_3 has 7 tiles
-                if (wave < 3) {
-                    desc_post8<PREC, 2>(acc, t0, sblk, cb_hi, cb_lo, lane);
-                    tp_exchange_pp<PREC, 2, true>(frag, lane, t0, acc, o_hi, o_lo, pl, valid);
-                } else {
-                    desc_post8<PREC, 1>(a1, t0, sblk, cb_hi, cb_lo, lane);
-                    tp_exchange_pp<PREC, 1, true>(frag, lane, t0, a1, o_hi, o_lo, pl, valid);
-                }
-                tp_operands<PREC, 14>(frag, lane, bf);
-                zero_acc(acc);
-                tp_dense<PREC, 14, 8, 0, 2, WLO>(blob, LY.L[3].rev_hi, LY.L[3].rev_lo, frag, bf, acc, lane, t0);
-            } else {
-                desc_post8<PREC, 2>(acc, t0, sblk, cb_hi, cb_lo, lane);
-                tp_exchange_pp<PREC, 2, true>(frag, lane, t0, acc, o_hi, o_lo, pl, valid);
-                tp_operands<PREC, 16>(frag, lane, bf);
-                if (l == 4) {   // ubar_4 restricted to the h_4 rows: tiles 0..6 of the 9-tile reverse pack
-                    if (wave < 3) {
-                        zero_acc(acc);
-                        tp_dense<PREC, 16, 9, 0, 2, WLO>(blob, LY.L[4].rev_hi, LY.L[4].rev_lo, frag, bf, acc, lane, t0);
-                    } else {
-                        zero_acc(a1);
-                        tp_dense<PREC, 16, 9, 0, 1, WLO>(blob, LY.L[4].rev_hi, LY.L[4].rev_lo, frag, bf, a1, lane, t0);
-                    }
-                } else {
-                    zero_acc(acc);
-                    tp_dense<PREC, 16, 8, 0, 2, WLO>(blob, LY.L[l].rev_hi, LY.L[l].rev_lo, frag, bf, acc, lane, t0);
-                }
-            }
-        }
-        desc_post8<PREC, 2>(acc, t0, sig_t, c_hi, c_lo, lane);
-        tp_exchange_pp<PREC, 2, false>(frag, lane, t0, acc, bb.zbar_hi + (size_t)tile * kPPBlock,
-                                       lo_planes ? bb.zbar_lo + (size_t)tile * kPPBlock : nullptr, pl, valid);
-    }
-}
-
-// ---- K3 on workgroups of HB sample halves -------------------------------------------------------------------------
-// sdf_bwd_tp_kernel generalised: a 4-wave workgroup carries HB 32-sample tiles through every layer on ONE pass over the
-// weight fragments (dense_ldsb_h).  HB = 2 halves the weight stream per sample (in parity mode the stream from L2, not
-// the matrix pipe, is the nearer bound of a 32-sample workgroup: 85 B/clk/CU wanted, 64 available) and the barriers per
-// sample, and gives a wave 12 MFMAs per k-step between two weight requests instead of 6.  Wave w owns output tiles 2w,
-// 2w+1 of both halves; the one-off jobs of a tile (q_bar fragments, the sdf tile of the seed) are done by wave 0.
 // ---- post-phase operands fetched ONE LAYER AHEAD ----------------------------------------------------------------------
 // The activation work behind a layer's MFMAs needs sigma'(z_l) and a second lane-private operand (a_l for the ascending
 // chain, the coupling c_l for the descending one) from HBM.  Loaded where they are used, their latency (~2 us under load)
@@ -854,33 +715,6 @@ FN_DEV void desc_apply(f32x16 (&acc)[TN][HB], const PostData<HB, TN, LO>& d) {
                     if constexpr (LO) c += (float)d.lo[hb][t][s][e];
                     acc[t][hb][8 * s + e] = sv * acc[t][hb][8 * s + e] + c;
                 }
-}
-
-// asc_post8 / desc_post8 on half `hb` of [tile][half] accumulators
-template <int PREC, int TN, int HB>
-FN_DEV void asc_post_h(f32x16 (&acc)[TN][HB], int hb, int T0, const unsigned char* __restrict__ sblk,
-                       const unsigned char* __restrict__ ablk_hi, const unsigned char* __restrict__ ablk_lo,
-                       unsigned char* __restrict__ cblk_hi, unsigned char* __restrict__ cblk_lo, int lane, const PPLane& pl) {
-#pragma unroll
-    for (int t = 0; t < TN; ++t) {
-        f32x16(&one)[1] = reinterpret_cast<f32x16(&)[1]>(acc[t][hb]);
-        asc_post8<PREC, 1>(one, T0 + t, sblk, ablk_hi, ablk_lo, cblk_hi, cblk_lo, lane, pl);
-#ifdef FNEUS_POST_FENCE
-        __builtin_amdgcn_sched_barrier(0);      // one tile's loads in flight at a time (register pressure)
-#endif
-    }
-}
-template <int PREC, int TN, int HB>
-FN_DEV void desc_post_h(f32x16 (&acc)[TN][HB], int hb, int T0, const unsigned char* __restrict__ sblk,
-                        const unsigned char* __restrict__ cblk_hi, const unsigned char* __restrict__ cblk_lo, int lane) {
-#pragma unroll
-    for (int t = 0; t < TN; ++t) {
-        f32x16(&one)[1] = reinterpret_cast<f32x16(&)[1]>(acc[t][hb]);
-        desc_post8<PREC, 1>(one, T0 + t, sblk, cblk_hi, cblk_lo, lane);
-#ifdef FNEUS_POST_FENCE
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-    }
 }
 
 constexpr int kK3Half = 19 * 2 * kFragBytes;      // B fragments of one half: up to 18 k-steps x (hi, lo) + 1 (parking, see below)
@@ -1152,8 +986,43 @@ extern "C" int fneus_sdf_fwd_grad(const void* blob, const float* pts, const floa
     const long tiles = (n_pts + 31) / 32;
     const unsigned char* b = reinterpret_cast<const unsigned char*>(blob);
     SdfStash st = *stash;
-    // one 4-wave workgroup per 32-sample tile, two workgroups per CU (the one-wave-per-tile K2 of round 1 is gone: it
-    // needed a per-wave LDS row image for its stash and lost to this form inside the step)
+    // FNEUS_K2_TPH=1 / 2 (experiment, off; read at every call so that tests can switch it): the HB-generic kernel with 1 / 2
+    // tiles per workgroup.  Measured at N = 65 536, parity mode: standalone 686 / 644 us against 691 us for the 32-sample
+    // kernel below, but 0.55 ms against 0.50 ms inside the training step -- unlike K3, K2 has hardly any loads to batch (its
+    // reverse sweep reads sigma' only), and the serial point encoding of wave 0 lengthens every group's start.
+    const char* tph_env = getenv("FNEUS_K2_TPH");
+    const int hbs = tph_env ? atoi(tph_env) : 0;
+    if (hbs == 1 || hbs == 2) {
+        if (!st.qs) return -2;
+        const long groups = (n_pts + 32 * hbs - 1) / (32 * hbs), cap = 256 * 2 * 4;
+        dim3 g2((unsigned)(groups < cap ? groups : cap)), b2(256);
+        const int gp = (train && st.h_lo != nullptr) ? 3 : 1;
+#define FNEUS_K2H(P, T, H, G)                                                                                                \
+    do {                                                                                                                     \
+        static bool attr_done = false;                                                                                       \
+        if (!attr_done) {                                                                                                    \
+            allow_big_lds(sdf_fwd_grad_tph_kernel<P, T, H, G>);                                                              \
+            attr_done = true;                                                                                                \
+        }                                                                                                                    \
+        hipLaunchKernelGGL((sdf_fwd_grad_tph_kernel<P, T, H, G>), g2, b2, H * kK2Half, stream, b, src, n_pts, st, sdf_out,  \
+                           feat_out, normal_out);                                                                            \
+    } while (0)
+#define FNEUS_K2H_HB(P, T, G)                                                                                                \
+    do {                                                                                                                     \
+        if (hbs == 2) FNEUS_K2H(P, T, 2, G);                                                                                 \
+        else FNEUS_K2H(P, T, 1, G);                                                                                          \
+    } while (0)
+        if (prec == 3 && train && gp == 3) FNEUS_K2H_HB(3, true, 3);
+        else if (prec == 3 && train) FNEUS_K2H_HB(3, true, 1);
+        else if (prec == 3) FNEUS_K2H_HB(3, false, 1);
+        else if (prec == 1 && train) FNEUS_K2H_HB(1, true, 1);
+        else if (prec == 1) FNEUS_K2H_HB(1, false, 1);
+        else return -2;
+#undef FNEUS_K2H_HB
+#undef FNEUS_K2H
+        return fneus::launch_status();
+    }
+    // one 4-wave workgroup per 32-sample tile, two workgroups per CU
     {
 #ifndef FNEUS_K2_GRID_CAP
 #define FNEUS_K2_GRID_CAP (256 * 2 * 4)
@@ -1192,18 +1061,21 @@ extern "C" int fneus_sdf_bwd(const void* blob, const float* pts, const float* ra
     const unsigned char* b = reinterpret_cast<const unsigned char*>(blob);
     SdfStash st = *stash;
     SdfBwdBufs bb = *bufs;
-    // tensor-parallel workgroups (two per CU) by default; FNEUS_K3_TP=0 selects one wave per tile (kept for comparison)
-    static const int tp_mode = getenv("FNEUS_K3_TP") ? atoi(getenv("FNEUS_K3_TP")) : 1;
-    // 64-sample workgroups (two tiles per pass over the weights) once the launch fills the chip that way; FNEUS_K3_HB=1 / 2 forces
-    static const int hb_env = getenv("FNEUS_K3_HB") ? atoi(getenv("FNEUS_K3_HB")) : 0;
+    // 4-wave workgroups, two per CU, carrying HB sample tiles through every layer on one pass over the weights: 64 samples
+    // (HB = 2) once the launch fills the chip that way, 32 for small launches; FNEUS_K3_HB=1 / 2 forces (read at every call)
+    const char* hb_s = getenv("FNEUS_K3_HB");
+    const int hb_env = hb_s ? atoi(hb_s) : 0;
     const long n_tiles32 = (n_pts + 31) / 32;
-    const int hbs = hb_env ? hb_env : (n_tiles32 >= 1024 ? 2 : 1);
-    if (tp_mode && (hbs == 2 || hbs == 1) && !(getenv("FNEUS_K3_OLD") != nullptr)) {
-        const long groups = (n_pts + 32 * hbs - 1) / (32 * hbs), cap = 256 * 2 * 4;
-        dim3 g2((unsigned)(groups < cap ? groups : cap)), b2(256);
-        static const bool whi2 = getenv("FNEUS_BWD_WHI") != nullptr && atoi(getenv("FNEUS_BWD_WHI")) != 0;
-        const bool exact = bb.adj_lo != nullptr;            // gradient precision 3: lo planes everywhere
-        if (exact && (!st.a_lo || !bb.c_lo || !bb.zbar_lo || !bb.qbar_lo || !bb.zsdf_lo)) return -2;
+    const int hbs = (hb_env == 1 || hb_env == 2) ? hb_env : (n_tiles32 >= 1024 ? 2 : 1);
+    const long groups = (n_pts + 32 * hbs - 1) / (32 * hbs), cap = 256 * 2 * 4;
+    dim3 g2((unsigned)(groups < cap ? groups : cap)), b2(256);
+    // FNEUS_BWD_WHI=1 (experiment, off): with bf16 gradient planes the two chains take the weights as their bf16 hi part (2
+    // MFMAs per product, half the weight stream): K3 0.65 -> 0.50 ms in its 32-sample form, but the weight gradients move
+    // from 3.5e-3 to 5.5e-3 of their norm (tests/test_hip_backward.py) and miss the 5e-3 bound of the golden gradient test
+    const char* whi_s = getenv("FNEUS_BWD_WHI");
+    const bool whi = whi_s != nullptr && atoi(whi_s) != 0;
+    const bool exact = bb.adj_lo != nullptr;            // gradient precision 3: lo planes everywhere
+    if (exact && (!st.a_lo || !bb.c_lo || !bb.zbar_lo || !bb.qbar_lo || !bb.zsdf_lo)) return -2;
 #define FNEUS_K3H(P, W, H, G)                                                                                                \
     do {                                                                                                                     \
         static bool attr_done = false;                                                                                       \
@@ -1214,37 +1086,11 @@ extern "C" int fneus_sdf_bwd(const void* blob, const float* pts, const float* ra
         hipLaunchKernelGGL((sdf_bwd_tph_kernel<P, W, H, G>), g2, b2, H * kK3Half, stream, b, src, n_pts, st, bb, d_sdf, d_feat, \
                            d_normal);                                                                                        \
     } while (0)
-        if (prec == 3 && exact) { if (hbs == 2) FNEUS_K3H(3, true, 2, 3); else FNEUS_K3H(3, true, 1, 3); }
-        else if (prec == 3 && !whi2) { if (hbs == 2) FNEUS_K3H(3, true, 2, 1); else FNEUS_K3H(3, true, 1, 1); }
-        else if (prec == 3) { if (hbs == 2) FNEUS_K3H(3, false, 2, 1); else FNEUS_K3H(3, false, 1, 1); }
-        else if (prec == 1) { if (hbs == 2) FNEUS_K3H(1, true, 2, 1); else FNEUS_K3H(1, true, 1, 1); }
-        else return -2;
+    if (prec == 3 && exact) { if (hbs == 2) FNEUS_K3H(3, true, 2, 3); else FNEUS_K3H(3, true, 1, 3); }
+    else if (prec == 3 && !whi) { if (hbs == 2) FNEUS_K3H(3, true, 2, 1); else FNEUS_K3H(3, true, 1, 1); }
+    else if (prec == 3) { if (hbs == 2) FNEUS_K3H(3, false, 2, 1); else FNEUS_K3H(3, false, 1, 1); }
+    else if (prec == 1) { if (hbs == 2) FNEUS_K3H(1, true, 2, 1); else FNEUS_K3H(1, true, 1, 1); }
+    else return -2;
 #undef FNEUS_K3H
-        return fneus::launch_status();
-    }
-    if (tp_mode) {
-        const long tiles = (n_pts + 31) / 32, cap = 256 * 2 * 4;
-        dim3 g2((unsigned)(tiles < cap ? tiles : cap)), b2(256);
-        // FNEUS_BWD_WHI=1 (experiment, off): with bf16 gradient planes the two chains take the weights as their bf16 hi part
-        // (2 MFMAs per product, half the weight stream): K3 0.65 -> 0.50 ms, but the weight gradients move from 3.5e-3
-        // to 5.5e-3 of their norm (tests/test_hip_backward.py) and miss the 5e-3 bound of the golden gradient test
-        static const bool whi = getenv("FNEUS_BWD_WHI") != nullptr && atoi(getenv("FNEUS_BWD_WHI")) != 0;
-        if (prec == 3 && (bb.adj_lo != nullptr || !whi))             // three MFMAs per product
-            hipLaunchKernelGGL((sdf_bwd_tp_kernel<3, true>), g2, b2, kTpLds, stream, b, src, n_pts, st, bb, d_sdf, d_feat, d_normal);
-        else if (prec == 3)
-            hipLaunchKernelGGL((sdf_bwd_tp_kernel<3, false>), g2, b2, kTpLds, stream, b, src, n_pts, st, bb, d_sdf, d_feat, d_normal);
-        else if (prec == 1)
-            hipLaunchKernelGGL((sdf_bwd_tp_kernel<1, true>), g2, b2, kTpLds, stream, b, src, n_pts, st, bb, d_sdf, d_feat, d_normal);
-        else
-            return -2;
-        return fneus::launch_status();
-    }
-    dim3 grid(grid_for((n_pts + 31) / 32)), blk(64);
-    if (prec == 3)
-        hipLaunchKernelGGL(sdf_bwd_kernel<3>, grid, blk, 0, stream, b, src, n_pts, st, bb, d_sdf, d_feat, d_normal);
-    else if (prec == 1)
-        hipLaunchKernelGGL(sdf_bwd_kernel<1>, grid, blk, 0, stream, b, src, n_pts, st, bb, d_sdf, d_feat, d_normal);
-    else
-        return -2;
     return fneus::launch_status();
 }

@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("FNEUS_LIB") or os.path.join(_HERE, "libfneus_hip.so")
 
 class FneusSdfStash(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
-                ("pe_hi", "pe_lo", "h_hi", "h_lo", "a_hi", "a_lo", "feat_hi", "feat_lo", "ps")]
+                ("pe_hi", "pe_lo", "h_hi", "h_lo", "a_hi", "a_lo", "feat_hi", "feat_lo", "ps", "qs")]
 
 
 class FneusSdfBwdBufs(C.Structure):

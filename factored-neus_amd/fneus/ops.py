@@ -229,8 +229,10 @@ class SdfStash:
         self.a = torch.empty((P, 8, T, 16, 64, 8), dtype=bf, device=device) if train else None
         self.feat = torch.empty((P, T, 16, 64, 8), dtype=bf, device=device) if train else None   # colour-network operand
         self.ps = torch.empty((T, 8, 16, 64, 8), dtype=torch.int16, device=device)      # sigma' as u16 fixed point
+        self.qs = torch.empty((T, 2, 64, 16), dtype=torch.float32, device=device)       # q_skip scratch of the reverse sweep
         s = _lib.FneusSdfStash()
         s.ps = self.ps.data_ptr()
+        s.qs = self.qs.data_ptr()
         for name, t in (("pe", self.pe), ("h", self.h), ("a", self.a), ("feat", self.feat)):
             if t is None:
                 continue

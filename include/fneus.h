@@ -39,6 +39,7 @@ typedef struct FneusSdfStash {
     uint16_t* a_hi;    uint16_t* a_lo;    /* [8][tiles][16][512]  slot l = a_l = sigma'(z_l) * d sdf/d h_{l+1}  (train != 0)  */
     uint16_t* feat_hi; uint16_t* feat_lo; /* [tiles][16][512]     feature vector (colour-network input; train != 0)          */
     void* ps; /* sigma'(z_l) as 16-bit fixed point, lane-private: [tiles][8][16][64] x 16 bytes                              */
+    float* qs; /* scratch of the reverse sweep (the skip input's part of d sdf/d PE), lane-private: [tiles][2][64][16] floats */
 } FneusSdfStash;
 
 /* Stash of the colour network / of one RefColor MLP (written by fneus_color_fwd with train != 0 and fneus_color_bwd):

@@ -100,3 +100,25 @@ def test_sdf_fwd_grad(env, prec, gprec, tol):
     full = pp.unpack(stash.h[0, 7]).float()
     assert full.shape[0] == 32 * stash.tiles and full[n:].abs().max().item() == 0.0
     close(stash.plane(stash.feat).cpu().double(), feat_r, "feat")
+
+
+@pytest.mark.parametrize("hb", [1, 2])
+def test_sdf_fwd_grad_multi_tile_workgroups(env, hb, monkeypatch):
+    """the HB-generic K2 (FNEUS_K2_TPH, an opt-in experiment: csrc/sdf_kernels.hip) against the default kernel: same
+    outputs to rounding, same planes (bit-identical arithmetic per sample; only the accumulation order inside a product
+    is shared)"""
+    ops = env["ops"]
+    x = env["x"].to(env["dev"]).contiguous()
+    n = x.shape[0]
+    st0 = ops.SdfStash(n, env["dev"], 3, train=True, gprec=3)
+    ref = ops.sdf_fwd_grad(env["net"].blob, n, 3, st0, True, pts=x)
+    monkeypatch.setenv("FNEUS_K2_TPH", str(hb))
+    st1 = ops.SdfStash(n, env["dev"], 3, train=True, gprec=3)
+    out = ops.sdf_fwd_grad(env["net"].blob, n, 3, st1, True, pts=x)
+    torch.cuda.synchronize()
+    for a, b, name in zip(out, ref, ("sdf", "feat", "normal")):
+        assert (a - b).abs().max().item() <= 2e-5, name
+    for l in range(8):
+        w = 217 if l == 3 else 256
+        assert (st1.plane(st1.h, l)[:, :w] - st0.plane(st0.h, l)[:, :w]).abs().max().item() <= 2e-5
+        assert (st1.plane(st1.a, l)[:, :w] - st0.plane(st0.a, l)[:, :w]).abs().max().item() <= 2e-5

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 # training step: bf16 planes, 1e-3 relative gradient rounding): Adam's normalised updates turn that into visibly different
 # -- not worse -- trajectories on this 48-ray toy problem after ~8 steps; the bound is the spread two fp32 runs with
 # different atomics order show at 400 steps (tests/test_hip_scene.py)
-@pytest.mark.parametrize("gprec,later_tol", [(3, 3e-2), (1, 1e-1)])
+@pytest.mark.parametrize("gprec,later_tol", [(3, 3e-2), (1, 2.5e-1)])
 def test_loss_trajectory_matches_oracle_training(gprec, later_tol):
     from fneus import ops, synth
     from fneus.trainer import Stage1Trainer, WMASK_MODEL
