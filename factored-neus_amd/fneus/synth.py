@@ -25,8 +25,12 @@ def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
-def sdf_state_dict(seed: int = 0, perturb: float = 0.02, bias: float = 0.5) -> "OrderedDict[str, np.ndarray]":
-    """lin{l}.bias / weight_g / weight_v in the reference's state_dict order (fields.py:67-70)."""
+def sdf_state_dict(seed: int = 0, perturb: float = 0.02, bias: float = 0.5, warp=None, inside_out: bool = False) -> "OrderedDict[str, np.ndarray]":
+    """lin{l}.bias / weight_g / weight_v in the reference's state_dict order (fields.py:67-70).
+    warp = (k, c): the first layer also sees c * sin(2^k x) beside x, i.e. the sphere of the geometric initialisation in
+    the coordinates x + c sin(2^k x) -- a bumpy surface.  inside_out: the sign convention of geometric_init with
+    inside_outside=True (fields.py:50-52): positive INSIDE the sphere -- a room seen from within, so that the secondary rays
+    of stage 2 (calLvis.py:339-409) leave a wall and hit the opposite one."""
     rs = np.random.RandomState(seed)
     dims = SDF_DIMS
     n_lin = len(dims) - 1
@@ -37,9 +41,14 @@ def sdf_state_dict(seed: int = 0, perturb: float = 0.02, bias: float = 0.5) -> "
         if l == n_lin - 1:
             w = rs.normal(math.sqrt(math.pi) / math.sqrt(in_dim), 1e-4, size=(out_dim, in_dim))
             b = np.full((out_dim,), -bias)
+            if inside_out:
+                w[0], b[0] = -w[0], -b[0]
         elif l == 0:
             w = np.zeros((out_dim, in_dim))
             w[:, :3] = rs.normal(0.0, math.sqrt(2) / math.sqrt(out_dim), size=(out_dim, 3))
+            if warp is not None:                   # embedding columns: x, then (sin 2^k x, cos 2^k x) per octave (embedder.py:35-36)
+                k, c = warp
+                w[:, 3 + 6 * k: 6 + 6 * k] = c * w[:, :3]
             b = np.zeros((out_dim,))
         elif l in SDF_SKIP:
             w = rs.normal(0.0, math.sqrt(2) / math.sqrt(out_dim), size=(out_dim, in_dim))
@@ -94,6 +103,31 @@ def refcolor_state_dict(seed: int = 2) -> "OrderedDict[str, np.ndarray]":
     w, b = _linear_default(rs, 1, 256)
     sd["net_cs.0.weight"], sd["net_cs.0.bias"] = _f32(w), _f32(b)
     return sd
+
+
+LVIS_DIMS = [90, 256, 256, 256, 256, 1]          # fields.py:338-369: embed(pts, 10) | embed(view, 4) -> 256 x 4 -> 1
+INDI_DIMS = [63, 512, 512, 512, 512, 144]         # fields.py:372-413: embed(pts, 10) -> 512 x 4 -> 24 x 6
+
+
+def _sequential_state_dict(rs, prefix, dims, last_gain=1.0):
+    sd = OrderedDict()
+    for i in range(len(dims) - 1):
+        w, b = _linear_default(rs, dims[i + 1], dims[i])
+        if i == len(dims) - 2:
+            w, b = w * last_gain, b * last_gain
+        sd[f"{prefix}.{2 * i}.weight"], sd[f"{prefix}.{2 * i}.bias"] = _f32(w), _f32(b)
+    return sd
+
+
+def lvis_state_dict(seed: int = 4) -> "OrderedDict[str, np.ndarray]":
+    """Lvis (fields.py:338-369): lvis.{0,2,4,6,8}; the last layer is scaled up so that the sigmoid leaves 0.5"""
+    return _sequential_state_dict(np.random.RandomState(seed), "lvis", LVIS_DIMS, last_gain=8.0)
+
+
+def indilgt_state_dict(seed: int = 5) -> "OrderedDict[str, np.ndarray]":
+    """IndirectLight (fields.py:372-413): indi.{0,2,4,6,8}; the last layer is scaled up so that lobes, sharpness and
+    amplitudes spread over their ranges"""
+    return _sequential_state_dict(np.random.RandomState(seed), "indi", INDI_DIMS, last_gain=6.0)
 
 
 def nerf_state_dict(seed: int = 3, D=8, W=256, input_ch=84, input_ch_view=27) -> "OrderedDict[str, np.ndarray]":

@@ -668,3 +668,169 @@ def composite_from_fields(rays_o, rays_d, mid_z, dists, sdf, normal, rgb, inv_s,
     return {"weights": weights, "color": color, "wsum": weights.sum(-1), "wmax": weights.max(-1)[0],
             "cdf": prev_cdf.reshape(B, n), "inside": inside, "eik_num": eik_num, "eik_den": eik_den,
             "min_idx": min_idx, "sdf_mask": sdf_mask, "wpair": torch.stack([w_lo, w_hi], -1), "alpha": alpha}
+
+
+# ======================================================================================
+# Stage 2 (lvis.py): light visibility / indirect light distillation
+# ======================================================================================
+def sequential_mlp(x, sd: Dict[str, torch.Tensor], prefix: str, n_lin: int = 5):
+    """nn.Sequential(Linear, ReLU, ..., Linear): modules 0, 2, 4, ... are the Linear layers (fields.py:348-359, 387-397)"""
+    for i in range(n_lin):
+        x = x @ sd[f"{prefix}.{2 * i}.weight"].t() + sd[f"{prefix}.{2 * i}.bias"]
+        if i < n_lin - 1:
+            x = torch.relu(x)
+    return x
+
+
+def lvis_forward(pts, view, sd: Dict[str, torch.Tensor]):
+    """Lvis.forward (fields.py:361-369): sigmoid(MLP(embed(pts, 10) | embed(view, 4))) -> [M,1]"""
+    return torch.sigmoid(sequential_mlp(torch.cat([embed(pts, 10), embed(view, 4)], dim=-1), sd, "lvis"))
+
+
+def indirect_light_forward(pts, sd: Dict[str, torch.Tensor], num_lgt_sgs: int = 24):
+    """IndirectLight.forward (fields.py:399-413): 24 spherical Gaussians per point -> [M,24,7] =
+    (lobe axis from two sigmoid angles, sharpness = 30 sigmoid + 0.1, amplitude = relu x 3)"""
+    out = sequential_mlp(embed(pts, 10), sd, "indi").reshape(-1, num_lgt_sgs, 6)
+    ang = torch.sigmoid(out[..., :2]) * (2.0 * math.pi)
+    theta, phi = ang[..., :1], ang[..., 1:2]
+    lobes = torch.cat([torch.cos(theta) * torch.sin(phi), torch.sin(theta) * torch.sin(phi), torch.cos(phi)], dim=-1)
+    lam = torch.sigmoid(out[..., 2:3]) * 30.0 + 0.1
+    mu = torch.relu(out[..., 3:])
+    return torch.cat([lobes, lam, mu], dim=-1)
+
+
+def query_indir_illum(lgt_sgs, dirs):
+    """calLvis.py:323-336: radiance of [M,L,7] spherical Gaussians towards [M,S,3] directions -> [M,S,3]"""
+    lobes = lgt_sgs[:, None, :, :3]
+    lobes = lobes / torch.linalg.norm(lobes, dim=-1, keepdim=True)
+    lam, mu = lgt_sgs[:, None, :, 3:4], lgt_sgs[:, None, :, 4:]
+    cosv = (dirs[:, :, None, :] * lobes).sum(-1, keepdim=True)
+    return (mu * torch.exp(lam * (cosv - 1.0))).sum(dim=2)
+
+
+def sample_dirs(normals, r_theta, r_phi):
+    """calLvis.py:302-320: directions at polar angle r_phi from the normal, azimuth r_theta in the tangent frame built
+    from the x axis.  normals [M,3] -> [M,S,3]"""
+    tiny = 1e-6
+    unit = lambda v: v / (torch.linalg.norm(v, dim=-1, keepdim=True) + tiny)
+    n = unit(normals)[:, None, :]
+    x_axis = torch.zeros_like(n)
+    x_axis[..., 0] = 1.0
+    U = unit(torch.linalg.cross(x_axis, n, dim=-1))
+    V = unit(torch.linalg.cross(n, U, dim=-1))
+    th, ph = r_theta[..., None], r_phi[..., None]
+    return U * torch.cos(th) * torch.sin(ph) + V * torch.sin(th) * torch.sin(ph) + n * torch.cos(ph)
+
+
+def first_hit(sdf, mid_z, inside_mask):
+    """the first sign change of the SDF along each ray and the depth of the zero crossing by linear interpolation
+    (renderer.py:586-602 = calLvis.py:178-194).  sdf, mid_z [R,n]; inside_mask [R] -> (sdf_mask [R] bool, z_surf [R],
+    only meaningful where sdf_mask)"""
+    R, n = sdf.shape
+    ramp = torch.arange(n, 0, -1, dtype=sdf.dtype, device=sdf.device)[None, :]
+    val, idx = torch.min(torch.sign(sdf) * ramp, dim=-1)
+    mask = (val < 0.0) & (idx >= 1) & inside_mask
+    hi = idx.clamp(min=1)[:, None]
+    z_lo, z_hi = torch.gather(mid_z, 1, hi - 1), torch.gather(mid_z, 1, hi)
+    s_lo, s_hi = torch.gather(sdf, 1, hi - 1), torch.gather(sdf, 1, hi)
+    z_surf = (s_lo * z_hi - s_hi * z_lo) / (s_lo - s_hi + 1e-10)
+    return mask, z_surf[:, 0]
+
+
+def secondary_sections(z_vals):
+    """calLvis.py:95-100 = :155-160: sections of the 32 fine depths, the last one padded with (1 - 0.1) / 32"""
+    sample_dist = (1 - 0.1) / 32.0
+    dists = torch.cat([z_vals[:, 1:] - z_vals[:, :-1], torch.full_like(z_vals[:, :1], sample_dist)], -1)
+    return dists, z_vals + dists * 0.5
+
+
+def cal_firHit_rgb(rays_o, rays_d, z_vals, sdf_p, color_p):
+    """calLvis.py:153-204: colour of the first surface a secondary ray hits (zeros when it hits nothing)"""
+    R, n = z_vals.shape
+    _, mid_z = secondary_sections(z_vals)
+    pts = (rays_o[:, None, :] + rays_d[:, None, :] * mid_z[..., None]).reshape(-1, 3)
+    sdf = sdf_only(pts, sdf_p).reshape(R, n)
+    inside = (torch.linalg.norm(pts, dim=-1).reshape(R, n) < 1.0).to(z_vals.dtype).sum(-1) > 0.0
+    mask, z_surf = first_hit(sdf, mid_z, inside)
+    hit_rgb = torch.zeros(R, 3, dtype=z_vals.dtype)
+    if mask.any():
+        p = rays_o[mask] + rays_d[mask] * z_surf[mask][:, None]
+        _, feat, normal, _ = sdf_value_feature_normal(p, sdf_p)
+        hit_rgb[mask] = color_forward(p, normal, rays_d[mask], feat, color_p)
+    return hit_rgb, mask
+
+
+def compute_weight(rays_o, rays_d, z_vals, sdf_p, inv_s):
+    """calLvis.py:93-150: NeuS weights of a secondary ray at cos_anneal_ratio = 0, and the part inside the unit sphere"""
+    R, n = z_vals.shape
+    dists, mid_z = secondary_sections(z_vals)
+    pts = (rays_o[:, None, :] + rays_d[:, None, :] * mid_z[..., None]).reshape(-1, 3)
+    sdf, _, grad, _ = sdf_value_feature_normal(pts, sdf_p)
+    dirs = rays_d[:, None, :].expand(R, n, 3).reshape(-1, 3)
+    true_cos = (dirs * grad).sum(-1, keepdim=True)
+    iter_cos = -torch.relu(-true_cos * 0.5 + 0.5)
+    d = dists.reshape(-1, 1)
+    prev_cdf = torch.sigmoid((sdf - iter_cos * d * 0.5) * inv_s)
+    next_cdf = torch.sigmoid((sdf + iter_cos * d * 0.5) * inv_s)
+    alpha = ((prev_cdf - next_cdf + 1e-5) / (prev_cdf + 1e-5)).reshape(R, n).clip(0.0, 1.0)
+    inside = (torch.linalg.norm(pts, dim=-1).reshape(R, n) < 1.0).to(z_vals.dtype)
+    weights = alpha * exclusive_transmittance(alpha)
+    return weights, weights * inside
+
+
+def cal_indiLgt(surf, normal, sdf_p, inv_s, color_p, lvis_sd, indi_sd, u_theta, u_z, trace: Optional[dict] = None):
+    """calLvis.py:339-409.  u_theta, u_z [M,4]: the two uniform draws of :351-352 (explicit, so that the checker and the
+    checked see the same numbers)."""
+    M, S = u_theta.shape
+    dirs = sample_dirs(normal, u_theta * (2.0 * math.pi), torch.asin(u_z * 0.95))
+    o = surf[:, None, :].expand(M, S, 3).reshape(-1, 3)
+    d = dirs.reshape(-1, 3)
+    with torch.no_grad():
+        z_coarse = torch.linspace(0.0, 1.0, 512, dtype=surf.dtype)[None, :].expand(M * S, 512)
+        pts = (o[:, None, :] + d[:, None, :] * z_coarse[..., None]).reshape(-1, 3)
+        coarse_sdf = sdf_only(pts, sdf_p)
+        z_fine = up_sample(o, d, z_coarse, coarse_sdf, 32, inv_s)
+        radiance, sec_mask = cal_firHit_rgb(o, d, z_fine, sdf_p, color_p)
+        weights, weights_inside = compute_weight(o, d, z_fine, sdf_p, inv_s)
+    gt_lvis = (1.0 - weights_inside.sum(-1)).reshape(M, S)
+    pre_lvis = lvis_forward(o, d, lvis_sd).reshape(M, S)
+    pre_radiance = query_indir_illum(indirect_light_forward(surf, indi_sd), dirs)
+    if trace is not None:
+        trace.update(dirs=dirs, z_fine=z_fine, sec_sdf_mask=sec_mask, sec_hit_rgb=radiance, sec_weights=weights,
+                     sec_weights_inside=weights_inside)
+    return {"gt_lvis": gt_lvis, "pre_lvis": pre_lvis, "gt_trace_radiance": radiance.reshape(M, S, 3),
+            "pre_trace_radiance": pre_radiance}
+
+
+def lvis_render(rays_o, rays_d, near, far, sdf_p, inv_s, color_p, lvis_sd, indi_sd, n_samples: int, n_importance: int,
+                u_theta, u_z, up_sample_steps: int = 4, trace: Optional[dict] = None):
+    """NeuSRenderer.lvis_render (renderer.py:567-627); rows outside sdf_mask keep the value 1"""
+    B = rays_o.shape[0]
+    with torch.no_grad():
+        util = lvis_mateIllu_render_util(rays_o, rays_d, near, far, sdf_p, n_samples, n_importance, up_sample_steps)
+        n = util["n_samples"]
+        mask, z_surf = first_hit(util["sdf"].reshape(B, n), util["mid_z_vals"], util["inside_sphere_mask"])
+    out = {"gt_lvis": torch.ones(B, 4, dtype=rays_o.dtype), "pre_lvis": torch.ones(B, 4, dtype=rays_o.dtype),
+           "gt_trace_radiance": torch.ones(B, 4, 3, dtype=rays_o.dtype),
+           "pre_trace_radiance": torch.ones(B, 4, 3, dtype=rays_o.dtype), "sdf_mask": mask}
+    if mask.any():
+        surf = rays_o[mask] + rays_d[mask] * z_surf[mask][:, None]
+        with torch.no_grad():
+            _, _, normal, _ = sdf_value_feature_normal(surf, sdf_p)
+        res = cal_indiLgt(surf, normal, sdf_p, inv_s, color_p, lvis_sd, indi_sd, u_theta, u_z, trace)
+        if trace is not None:
+            trace.update(normal=normal, pts_surf=surf)
+        for k in ("gt_lvis", "pre_lvis", "gt_trace_radiance", "pre_trace_radiance"):
+            full = out[k].clone()
+            full[mask] = res[k].to(full.dtype)
+            out[k] = full
+    return out
+
+
+def stage2_loss(out: dict):
+    """lvis.py:164-170: L1 visibility + L1 traced radiance over the rays that hit the surface"""
+    m = out["sdf_mask"]
+    lvis_loss = (out["gt_lvis"] - out["pre_lvis"]).abs().sum() / (m[:, None].expand(-1, 4).sum() + 1e-6)
+    err = (out["gt_trace_radiance"] - out["pre_trace_radiance"]) * m[:, None, None]
+    radiance_loss = err.abs().sum() / (m[:, None, None].expand(-1, 4, 3).sum() + 1e-6)
+    return {"loss": lvis_loss + radiance_loss, "lvis_loss": lvis_loss, "trace_radiance_loss": radiance_loss}

@@ -306,6 +306,118 @@ def gen_lvis_util(fields, renderer, out_dir, name, B, n_samples, n_importance, r
     print(name + ".npz written; inside_sphere_mask", int(res["out/inside_sphere_mask"].sum()), "of", B)
 
 
+def stage2_reference():
+    """the stage-2 modules of the reference with the `.cuda()` shim of SURVEY.md section 8(c) (calLvis.py:305, 351-352 move
+    fresh CPU tensors to the GPU by hand; there is none here)"""
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    from models import calLvis
+    assert calLvis.__file__.startswith(REF + "/")
+    return calLvis
+
+
+def gen_lvis_render(fields, renderer, out_dir, name, B, n_samples, n_importance, ray_seed, seeds, room, bias=0.5, warp=None,
+                    adam_steps=3, outside_rays=0):
+    """NeuSRenderer.lvis_render (renderer.py:567-627) -> cal_indiLgt (calLvis.py:339-409), the stage-2 loss of
+    lvis.py:164-170, its gradients on Lvis + IndirectLight and `adam_steps` optimiser steps (lvis.py:89-92, 172-174).
+    room=True: SDF positive INSIDE a sphere and the camera inside it (every secondary ray can hit the opposite wall);
+    room=False: the convex ball of the stage-1 fixtures (secondary rays leave without a hit)."""
+    calLvis = stage2_reference()
+    sdf, col, var, nerf, ref = build_nets(fields, seeds)
+    sdf.load_state_dict(to_t(synth.sdf_state_dict(seeds["sdf"], bias=bias, warp=warp, inside_out=room)))
+    lvis, indi = fields.Lvis(), fields.IndirectLight()
+    lvis(torch.zeros(2, 3), torch.ones(2, 3))                   # materialise the LazyLinear layers
+    indi(torch.zeros(2, 3))
+    lvis.load_state_dict(to_t(synth.lvis_state_dict(seeds["lvis"])))
+    indi.load_state_dict(to_t(synth.indilgt_state_dict(seeds["indilgt"])))
+    data = torch.from_numpy(synth.ray_batch(B, seed=ray_seed, n_miss=0 if room else 2))
+    if room:
+        data[: B - outside_rays, :3] *= 0.08                    # camera inside the room (the last rays stay outside: no hit)
+    rays_o, rays_d = data[:, :3], data[:, 3:6]
+    a = (rays_d ** 2).sum(-1, keepdim=True)
+    b = 2.0 * (rays_o * rays_d).sum(-1, keepdim=True)
+    mid = 0.5 * (-b) / a
+    near, far = mid - 1.0, mid + 1.0
+    if room:
+        near = torch.where(near < 0.02, torch.full_like(near, 0.02), near)     # start inside the room, in front of the camera
+    rnd = renderer.NeuSRenderer(n_samples, n_importance, 0, 4, 1.0, nerf=nerf, sdf_network=sdf, deviation_network=var,
+                                color_network=col, refColor_network=ref, lvis_network=lvis, indiLgt_network=indi)
+    params = list(lvis.parameters()) + list(indi.parameters())
+    names = ["lvis." + k for k, _ in lvis.named_parameters()] + ["indi." + k for k, _ in indi.named_parameters()]
+    opt = torch.optim.Adam(params, lr=5e-4)                     # lvis.py:92 with train.learning_rate of confs/wmask.conf:23
+    res = {"data": data.numpy(), "near": near.numpy(), "far": far.numpy(), "B": B, "n_samples": n_samples,
+           "n_importance": n_importance, "ray_seed": ray_seed, "room": int(room), "bias": bias,
+           "warp": np.asarray(warp if warp is not None else (-1, 0.0), dtype=np.float64), "lr": 5e-4,
+           **{"seed_" + k: v for k, v in seeds.items()}}
+    glob = renderer.cal_indiLgt.__globals__
+    real = {k: glob[k] for k in ("up_sample", "cal_firHit_rgb", "compute_weight", "sample_dirs")}
+    real_rand = torch.rand
+    for step in range(adam_steps):
+        trace, draws = {}, []
+
+        def rand_hook(*a_, **k_):
+            r = real_rand(*a_, **k_)
+            draws.append(r.clone())
+            return r
+
+        def up_hook(*a_, **k_):
+            z = real["up_sample"](*a_, **k_)
+            trace["z_fine"] = z.clone()
+            trace["inv_s"] = torch.as_tensor(k_["inv_s"]).clone()
+            return z
+
+        def hit_hook(*a_, **k_):
+            rgb, m = real["cal_firHit_rgb"](*a_, **k_)
+            trace["sec_hit_rgb"], trace["sec_sdf_mask"] = rgb.clone(), m.clone()
+            return rgb, m
+
+        def w_hook(*a_, **k_):
+            w, wi = real["compute_weight"](*a_, **k_)
+            trace["sec_weights"], trace["sec_weights_inside"] = w.clone(), wi.clone()
+            return w, wi
+
+        def dirs_hook(normals, r_theta, r_phi):
+            d = real["sample_dirs"](normals, r_theta, r_phi)
+            trace["normal"], trace["dirs"] = normals[:, 0, :].clone(), d.clone()
+            return d
+
+        glob.update(up_sample=up_hook, cal_firHit_rgb=hit_hook, compute_weight=w_hook, sample_dirs=dirs_hook)
+        torch.rand = rand_hook
+        torch.manual_seed(1000 + step)
+        try:
+            out = rnd.lvis_render(rays_o, rays_d, near, far)
+        finally:
+            torch.rand = real_rand
+            glob.update(real)
+        sdf_mask = out["sdf_mask"]
+        # lvis.py:164-170
+        lvis_error = out["gt_lvis"] - out["pre_lvis"]
+        lvis_loss = lvis_error.abs().sum() / (sdf_mask[..., None].expand(out["gt_lvis"].shape).sum() + 1e-6)
+        tr_error = (out["gt_trace_radiance"] - out["pre_trace_radiance"]) * sdf_mask[..., None, None]
+        tr_loss = tr_error.abs().sum() / (sdf_mask[..., None, None].expand(out["gt_trace_radiance"].shape).sum() + 1e-6)
+        loss = lvis_loss + tr_loss
+        opt.zero_grad()
+        loss.backward()
+        tag = f"step{step}/"
+        assert len(draws) == 2 and draws[0].shape == (int(sdf_mask.sum()), 4)
+        res.update({tag + "u_theta": draws[0].numpy(), tag + "u_z": draws[1].numpy(), tag + "loss": loss.item(),
+                    tag + "lvis_loss": lvis_loss.item(), tag + "trace_radiance_loss": tr_loss.item()})
+        if step == 0:
+            res.update({"out/" + k: out[k].detach().numpy() for k in ("gt_lvis", "pre_lvis", "gt_trace_radiance",
+                                                                       "pre_trace_radiance", "sdf_mask")})
+            res.update({"trace/" + k: v.detach().numpy() for k, v in trace.items()})
+            for nme, p in zip(names, params):
+                res["grad_sub/" + nme] = subsample(p.grad)
+                res["grad_norm/" + nme] = np.float64(p.grad.double().norm().item())
+        opt.step()
+        if step in (0, adam_steps - 1):
+            for nme, p in zip(names, params):
+                res[f"adam{step + 1}_sub/" + nme] = subsample(p)
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), **res)
+    print(name + ".npz written; primary hits", int(res["out/sdf_mask"].sum()), "of", B, "secondary hits",
+          int(res["trace/sec_sdf_mask"].sum()), "of", res["trace/sec_sdf_mask"].size, "loss", res["step0/loss"],
+          "gt_lvis mean", float(res["out/gt_lvis"][res["out/sdf_mask"]].mean()))
+
+
 def gen_raygen(dataset, out_dir, name="raygen_dtu"):
     """Dataset.gen_rays_at / gen_random_rays_at / near_far_from_sphere (dataset.py:115-151, 186-192) called unbound on a
     stub object that carries exactly the attributes they read: a synthetic DTU-like camera set (K^-1, pose), BGR/256
@@ -369,7 +481,8 @@ def gen_raygen(dataset, out_dir, name="raygen_dtu"):
 
 
 FIXTURES = ("units", "render_wmask_b16_n16", "render_wmask_b8_n64", "render_womask_b16_n16_o8", "render_wmask_b16_n16_c0",
-            "render_wmask_b256_n32", "render_wmask_b64_n64", "lvis_util_b24_n32", "raygen_dtu")
+            "render_wmask_b256_n32", "render_wmask_b64_n64", "lvis_util_b24_n32", "raygen_dtu", "lvis_render_room_b24_n32",
+            "lvis_render_ball_b16_n16")
 
 
 def check_against(old_dir, new_dir, names):
@@ -428,6 +541,14 @@ def main():
         gen_lvis_util(fields, renderer, args.out, "lvis_util_b24_n32", B=24, n_samples=32, n_importance=32, ray_seed=37, seeds=seeds)
     if want("raygen_dtu"):
         gen_raygen(dataset, args.out)
+    # ---- stage 2 (config 3): lvis_render + cal_indiLgt, loss, gradients and Adam steps of Lvis + IndirectLight -------------
+    seeds2 = dict(seeds, lvis=24, indilgt=25)
+    if want("lvis_render_room_b24_n32"):        # a room of radius 0.55 seen from within: chords beyond 1 leave without a hit
+        gen_lvis_render(fields, renderer, args.out, "lvis_render_room_b24_n32", B=24, n_samples=32, n_importance=32,
+                        ray_seed=41, seeds=seeds2, room=True, bias=0.7, warp=(3, 0.1), outside_rays=3)
+    if want("lvis_render_ball_b16_n16"):        # the convex ball: secondary rays leave without a hit, visibility in (0.5, 1]
+        gen_lvis_render(fields, renderer, args.out, "lvis_render_ball_b16_n16", B=16, n_samples=16, n_importance=16,
+                        ray_seed=42, seeds=seeds2, room=False, adam_steps=1)
     if args.check:
         ok = check_against(HERE, args.out, FIXTURES)
         print("committed fixtures reproduced bit for bit" if ok else "MISMATCH against the committed fixtures")

@@ -293,3 +293,82 @@ def test_ray_generation(golden_dir):
         near, far = R.near_far_from_sphere(out[:, :3], out[:, 3:6])
         close(near, g[f"random_{i}/near"], 1e-6)
         close(far, g[f"random_{i}/far"], 1e-6)
+
+
+# ---- stage 2: lvis_render + cal_indiLgt, loss, gradients, Adam steps (renderer.py:567-627, calLvis.py:339-409, lvis.py:132-196) ----
+def stage2_nets(g):
+    warp = None if int(g["warp"][0]) < 0 else (int(g["warp"][0]), float(g["warp"][1]))
+    sdf_p = R.sdf_params_from_state_dict(tsd(synth.sdf_state_dict(int(g["seed_sdf"]), bias=float(g["bias"]), warp=warp,
+                                                                   inside_out=bool(g["room"]))))
+    col_p = R.color_params_from_state_dict(tsd(synth.color_state_dict(int(g["seed_color"]))))
+    lvis_sd = tsd(synth.lvis_state_dict(int(g["seed_lvis"])))
+    indi_sd = tsd(synth.indilgt_state_dict(int(g["seed_indilgt"])))
+    inv_s = R.inv_s_from_variance(torch.tensor(0.3))
+    return sdf_p, col_p, lvis_sd, indi_sd, inv_s
+
+
+STAGE2_CASES = ["lvis_render_room_b24_n32", "lvis_render_ball_b16_n16"]
+
+
+@pytest.mark.parametrize("name", STAGE2_CASES)
+def test_stage2_lvis_render(golden_dir, name):
+    g = load(golden_dir, name)
+    sdf_p, col_p, lvis_sd, indi_sd, inv_s = stage2_nets(g)
+    params = {**{"lvis." + k: v.requires_grad_(True) for k, v in lvis_sd.items()},
+              **{"indi." + k: v.requires_grad_(True) for k, v in indi_sd.items()}}
+    data = T(g["data"])
+    trace = {}
+    out = R.lvis_render(data[:, :3], data[:, 3:6], T(g["near"]), T(g["far"]), sdf_p, inv_s, col_p, lvis_sd, indi_sd,
+                        int(g["n_samples"]), int(g["n_importance"]), T(g["step0/u_theta"]), T(g["step0/u_z"]), trace=trace)
+    assert np.array_equal(out["sdf_mask"].numpy(), g["out/sdf_mask"])
+    assert np.array_equal(trace["sec_sdf_mask"].numpy(), g["trace/sec_sdf_mask"])
+    close(trace["normal"], g["trace/normal"], 2e-4)
+    close(trace["dirs"], g["trace/dirs"], 2e-4)
+    # the fine depths come from a 512-bin inverse CDF: samples at flat stretches of the CDF move (see the sampler tests)
+    dz = (trace["z_fine"] - T(g["trace/z_fine"])).abs()
+    assert dz.median().item() <= 1e-5 and (dz <= 1e-3).float().mean().item() >= 0.97, (dz.median().item(), dz.max().item())
+    close(trace["sec_hit_rgb"], g["trace/sec_hit_rgb"], 2e-3)
+    close(out["gt_lvis"], g["out/gt_lvis"], 2e-3)
+    close(out["gt_trace_radiance"], g["out/gt_trace_radiance"], 2e-3)
+    close(out["pre_lvis"], g["out/pre_lvis"], 1e-4)
+    close(out["pre_trace_radiance"], g["out/pre_trace_radiance"], 1e-4, rel=1e-4)
+    L = R.stage2_loss(out)
+    for k in ("loss", "lvis_loss", "trace_radiance_loss"):
+        assert abs(L[k].item() - float(g["step0/" + k])) <= 1e-3 * max(1.0, abs(float(g["step0/" + k]))), k
+    L["loss"].backward()
+    checked = 0
+    for k, prm in params.items():
+        ref_sub, ref_norm = g["grad_sub/" + k], float(g["grad_norm/" + k])
+        sub = prm.grad.reshape(-1)[::997].numpy()
+        scale = max(ref_norm / np.sqrt(prm.numel()), np.abs(ref_sub).max(), 1e-7)
+        assert np.abs(sub - ref_sub).max() <= 2e-2 * scale + 1e-7, (k, np.abs(sub - ref_sub).max(), scale)
+        assert abs(prm.grad.double().norm().item() - ref_norm) <= 1e-2 * ref_norm + 1e-7, k
+        checked += 1
+    assert checked == 20
+
+
+def test_stage2_adam_steps(golden_dir):
+    """three optimiser steps of lvis.py:172-174 (Adam over Lvis + IndirectLight, fresh directions every step)"""
+    g = load(golden_dir, "lvis_render_room_b24_n32")
+    sdf_p, col_p, lvis_sd, indi_sd, inv_s = stage2_nets(g)
+    params = {**{"lvis." + k: v.requires_grad_(True) for k, v in lvis_sd.items()},
+              **{"indi." + k: v.requires_grad_(True) for k, v in indi_sd.items()}}
+    opt = torch.optim.Adam(list(params.values()), lr=float(g["lr"]))
+    data = T(g["data"])
+    for step in range(3):
+        out = R.lvis_render(data[:, :3], data[:, 3:6], T(g["near"]), T(g["far"]), sdf_p, inv_s, col_p, lvis_sd, indi_sd,
+                            int(g["n_samples"]), int(g["n_importance"]), T(g[f"step{step}/u_theta"]), T(g[f"step{step}/u_z"]))
+        L = R.stage2_loss(out)
+        assert abs(L["loss"].item() - float(g[f"step{step}/loss"])) <= 2e-3 * max(1.0, abs(float(g[f"step{step}/loss"]))), step
+        opt.zero_grad()
+        L["loss"].backward()
+        opt.step()
+        if step in (0, 2):
+            for k, prm in params.items():
+                ref = g[f"adam{step + 1}_sub/" + k]
+                got = prm.detach().reshape(-1)[::997].numpy()
+                # Adam's first steps move every weight by ~lr whatever the gradient's size: a gradient entry near zero may
+                # flip its sign between two fp32 evaluations, so compare with a few-lr slack on few entries
+                bad = np.abs(got - ref) > 0.2 * float(g["lr"])
+                assert bad.mean() <= 0.02, (step, k, bad.mean())
+                assert np.abs(got - ref).max() <= 2.0 * (step + 1) * float(g["lr"]) + 1e-7, (step, k)
