@@ -61,6 +61,7 @@ FN_DEV float pt_norm(const float* o, const float* d, float z) {
 }
 
 // exclusive cumulative product over the ray: vals[j] for this lane's chunk [lane*PER, lane*PER+PER) -> T[j]
+template <int PER>
 FN_DEV void excl_cumprod(const float (&f)[PER], float (&T)[PER], int lane) {
     float loc = 1.0f;
 #pragma unroll
@@ -78,9 +79,13 @@ FN_DEV void excl_cumprod(const float (&f)[PER], float (&T)[PER], int lane) {
 // ---------------------------------------------------------------------------------------------------------------
 // K6a: new z by inverse-CDF sampling of the NeuS weights at a fixed inv_s
 // ---------------------------------------------------------------------------------------------------------------
+// PER samples per lane: 4 for the primary rays (m <= 256), 8 for the 512 coarse samples of a stage-2 secondary ray
+// (calLvis.py:55-90 is the same algorithm as renderer.py:152-189 and returns the new depths only)
+template <int PER>
 __global__ void __launch_bounds__(64) upsample_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                       const float* __restrict__ z_in, const float* __restrict__ sdf_in,
                                                       int m, int k, float inv_s, float* __restrict__ z_new) {
+    constexpr int MAXN = 64 * PER;
     __shared__ float zs[MAXN], ss[MAXN], cdf[MAXN + 1];
     const int ray = blockIdx.x, lane = threadIdx.x;
     float o[3], d[3];
@@ -504,6 +509,120 @@ __global__ void __launch_bounds__(256) ray_setup_kernel(const float* __restrict_
     z_vals[idx] = z;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Stage 2 (lvis.py): first surface hit of a ray and the occlusion of a secondary ray
+// ---------------------------------------------------------------------------------------------------------------
+// One wavefront per ray, n <= 256 samples.
+//   first hit   renderer.py:586-604 = calLvis.py:178-196: idx = first sample with sign(sdf) = -1;
+//               mask = (idx exists) & (idx >= 1) & (some sample lies inside the unit sphere);
+//               z_surf = (s_lo z_hi - s_hi z_lo) / (s_lo - s_hi + 1e-10) between samples idx-1 and idx; p = o + d z_surf.
+//               Rays without a hit get z_surf = 0 (p = o): the callers evaluate the networks at fixed shape.
+//   occlusion   calLvis.py:93-150 (compute_weight, cos_anneal_ratio = 0): sum of the NeuS weights of the samples inside
+//               the unit sphere; only when normal / dists are given.
+__global__ void __launch_bounds__(64) ray_hit_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                     const float* __restrict__ mid_z, const float* __restrict__ sdf,
+                                                     const float* __restrict__ dists, const float* __restrict__ normal,
+                                                     const unsigned char* __restrict__ inside_mask, int n, float inv_s,
+                                                     unsigned char* __restrict__ mask_out, float* __restrict__ z_surf,
+                                                     float* __restrict__ pts_surf, float* __restrict__ occlusion,
+                                                     float* __restrict__ weights) {
+    const int ray = blockIdx.x, lane = threadIdx.x;
+    float o[3], d[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        o[c] = rays_o[ray * 3 + c];
+        d[c] = rays_d[ray * 3 + c];
+    }
+    const size_t base = (size_t)ray * n;
+    const bool occ = normal != nullptr;
+    float fac[PER], T[PER], al[PER], ins[PER];
+    float insum = 0.0f;
+    int firstneg = 1 << 30;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = lane * PER + j;
+        fac[j] = 1.0f; al[j] = 0.0f; ins[j] = 0.0f;
+        if (i < n) {
+            const float s = sdf[base + i], mz = mid_z[base + i];
+            if (occ) {
+                const float g[3] = {normal[(base + i) * 3], normal[(base + i) * 3 + 1], normal[(base + i) * 3 + 2]};
+                const SecVals v = section_values(o, d, mz, dists[base + i], s, g, inv_s, 0.0f);
+                al[j] = v.alpha;
+                ins[j] = v.inside;
+                fac[j] = 1.0f - v.alpha + 1e-7f;
+            } else {
+                ins[j] = pt_norm(o, d, mz) < 1.0f ? 1.0f : 0.0f;
+            }
+            insum += ins[j];
+            if (s < 0.0f) firstneg = min(firstneg, i);
+        }
+    }
+    const int idx = wave_min_i(firstneg);
+    const float in_total = wave_sum(insum);
+    const bool inside_any = inside_mask ? inside_mask[ray] != 0 : in_total > 0.0f;
+    const bool mask = (idx < n) && (idx >= 1) && inside_any;
+    if (occ) {
+        excl_cumprod(fac, T, lane);
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int i = lane * PER + j;
+            if (i < n) {
+                const float w = al[j] * T[j];
+                acc += w * ins[j];
+                if (weights) weights[base + i] = w;
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) occlusion[ray] = acc;
+    }
+    if (lane == 0) {
+        float z = 0.0f;
+        if (mask) {
+            const float z_lo = mid_z[base + idx - 1], z_hi = mid_z[base + idx];
+            const float s_lo = sdf[base + idx - 1], s_hi = sdf[base + idx];
+            z = (s_lo * z_hi - s_hi * z_lo) / (s_lo - s_hi + 1e-10f);
+        }
+        mask_out[ray] = mask ? 1 : 0;
+        z_surf[ray] = z;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pts_surf[ray * 3 + c] = o[c] + d[c] * z;
+    }
+}
+
+// calLvis.py:302-320 (sample_dirs) with the draws of :351-355: S directions per surface point at polar angle
+// phi = asin(0.95 u_z) from the normal and azimuth theta = 2 pi u_theta in the tangent frame built from the x axis;
+// also writes the origin of every secondary ray (the surface point, repeated S times: calLvis.py:357).
+__global__ void __launch_bounds__(256) sample_dirs_kernel(const float* __restrict__ surf, const float* __restrict__ normal,
+                                                          const float* __restrict__ u_theta, const float* __restrict__ u_z,
+                                                          long total, int S, float* __restrict__ origins,
+                                                          float* __restrict__ dirs) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const long pt = idx / S;
+    const float tiny = 1e-6f;
+    float n[3] = {normal[pt * 3], normal[pt * 3 + 1], normal[pt * 3 + 2]};
+    const float nn = sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]) + tiny;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) n[c] = n[c] / nn;
+    // U = unit(x_axis x n), V = unit(n x U)
+    float U[3] = {0.0f, -n[2], n[1]};
+    const float un = sqrtf(U[1] * U[1] + U[2] * U[2]) + tiny;
+    U[1] = U[1] / un;
+    U[2] = U[2] / un;
+    float V[3] = {n[1] * U[2] - n[2] * U[1], n[2] * U[0] - n[0] * U[2], n[0] * U[1] - n[1] * U[0]};
+    const float vn = sqrtf(V[0] * V[0] + V[1] * V[1] + V[2] * V[2]) + tiny;
+    const float theta = u_theta[idx] * 2.0f * 3.14159265358979323846f;
+    const float phi = asinf(u_z[idx] * 0.95f);
+    const float ct = cosf(theta), st = sinf(theta), cp = cosf(phi), sp = sinf(phi);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        dirs[idx * 3 + c] = U[c] * ct * sp + (V[c] / vn) * st * sp + n[c] * cp;
+        origins[idx * 3 + c] = surf[pt * 3 + c];
+    }
+}
+
 }  // namespace fneus
 
 using namespace fneus;
@@ -515,8 +634,11 @@ extern "C" int fneus_upsample(const float* rays_o, const float* rays_d, const fl
     hipStream_t stream = (hipStream_t)stream_;
     fneus::clear_status();
     if (n_rays <= 0) return 0;
-    FN_CHECK_N(m);
-    hipLaunchKernelGGL(upsample_kernel, dim3(n_rays), dim3(64), 0, stream, rays_o, rays_d, z, sdf, m, k, inv_s, z_new);
+    if (m > 512 || m < 2) { set_last_error("fneus_upsample: samples per ray must be in [2, 512]"); return -2; }
+    if (m <= 256)
+        hipLaunchKernelGGL(upsample_kernel<4>, dim3(n_rays), dim3(64), 0, stream, rays_o, rays_d, z, sdf, m, k, inv_s, z_new);
+    else
+        hipLaunchKernelGGL(upsample_kernel<8>, dim3(n_rays), dim3(64), 0, stream, rays_o, rays_d, z, sdf, m, k, inv_s, z_new);
     return fneus::launch_status();
 }
 
@@ -611,5 +733,33 @@ extern "C" int fneus_ray_setup(const float* rays_o, const float* rays_d, const f
     if (n_samples < 2 || (near == nullptr) != (far == nullptr) || (!near && (!rays_o || !rays_d))) return -2;
     hipLaunchKernelGGL(ray_setup_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, rays_o, rays_d, near, far,
                        t_rand, n_rays, n_samples, z_vals);
+    return fneus::launch_status();
+}
+
+extern "C" int fneus_ray_hit(const float* rays_o, const float* rays_d, const float* mid_z, const float* sdf, const float* dists,
+                             const float* normal, const unsigned char* inside_mask, int n_rays, int n, float inv_s,
+                             unsigned char* sdf_mask, float* z_surf, float* pts_surf, float* occlusion, float* weights,
+                             fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (n_rays <= 0) return 0;
+    FN_CHECK_N(n);
+    if ((normal != nullptr) != (dists != nullptr) || (normal != nullptr && occlusion == nullptr)) {
+        set_last_error("fneus_ray_hit: normal, dists and occlusion go together");
+        return -2;
+    }
+    hipLaunchKernelGGL(ray_hit_kernel, dim3(n_rays), dim3(64), 0, stream, rays_o, rays_d, mid_z, sdf, dists, normal, inside_mask, n,
+                       inv_s, sdf_mask, z_surf, pts_surf, occlusion, weights);
+    return fneus::launch_status();
+}
+
+extern "C" int fneus_sample_dirs(const float* surf, const float* normal, const float* u_theta, const float* u_z, int n_pts,
+                                 int n_dirs, float* origins, float* dirs, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    const long total = (long)n_pts * n_dirs;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(sample_dirs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, surf, normal, u_theta, u_z,
+                       total, n_dirs, origins, dirs);
     return fneus::launch_status();
 }

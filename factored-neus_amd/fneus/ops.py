@@ -677,6 +677,35 @@ def upsample(rays_o, rays_d, z, sdf, k: int, inv_s: float):
     return out
 
 
+def ray_hit(rays_o, rays_d, mid_z, sdf, inside_mask=None, dists=None, normal=None, inv_s: float = 1.0, want_weights=False):
+    """first surface hit per ray (+ the occlusion of compute_weight when normal / dists are given), fneus_ray_hit.
+    -> dict(sdf_mask u8 [B], z_surf [B], pts_surf [B,3][, occlusion [B]][, weights [B,n]])"""
+    B, n = mid_z.shape
+    dev = mid_z.device
+    out = {"sdf_mask": torch.empty(B, dtype=torch.uint8, device=dev), "z_surf": torch.empty(B, dtype=torch.float32, device=dev),
+           "pts_surf": torch.empty(B, 3, dtype=torch.float32, device=dev)}
+    if normal is not None:
+        out["occlusion"] = torch.empty(B, dtype=torch.float32, device=dev)
+        if want_weights:
+            out["weights"] = torch.empty(B, n, dtype=torch.float32, device=dev)
+    if inside_mask is not None:
+        inside_mask = inside_mask.to(torch.uint8).contiguous()
+    _launch("fneus_ray_hit", lib.fneus_ray_hit, _ptr(rays_o), _ptr(rays_d), _ptr(mid_z), _ptr(sdf), _ptr(dists), _ptr(normal),
+            _ptr(inside_mask), B, n, float(inv_s), _ptr(out["sdf_mask"]), _ptr(out["z_surf"]), _ptr(out["pts_surf"]),
+            _ptr(out.get("occlusion")), _ptr(out.get("weights")), _stream())
+    return out
+
+
+def sample_dirs(surf, normal, u_theta, u_z):
+    """calLvis.py:302-320 + :351-357 -> origins [M*S,3], dirs [M*S,3]"""
+    M, S = u_theta.shape
+    origins = torch.empty(M * S, 3, dtype=torch.float32, device=surf.device)
+    dirs = torch.empty(M * S, 3, dtype=torch.float32, device=surf.device)
+    _launch("fneus_sample_dirs", lib.fneus_sample_dirs, _ptr(surf), _ptr(normal), _ptr(u_theta), _ptr(u_z), M, S, _ptr(origins),
+            _ptr(dirs), _stream())
+    return origins, dirs
+
+
 def merge(z_old, s_old, z_new, s_new):
     B, m = z_old.shape
     k = z_new.shape[1]

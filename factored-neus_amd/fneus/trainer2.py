@@ -1,0 +1,85 @@
+"""Stage-2 training step (lvis.py:132-196) on the HIP backend: distil light visibility and indirect light.
+
+The geometry and appearance networks of stage 1 are frozen (lvis.py:78-92 hands only Lvis + IndirectLight to Adam); the
+step is   lvis_render (renderer.py:567-627)  ->  L1 visibility + L1 traced radiance (lvis.py:164-170)  ->  backward  ->  Adam.
+Its cost is the ground truth: 4 secondary rays per visible surface point x 512 SDF samples on the K1 kernel (1.05 M points
+for a 512-ray batch), K6 up-sampling, K2 on 65 k mid points, K2 + K4 at the hit points; the two distilled MLPs see at most
+2048 / 512 rows.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from fneus import ops, synth
+from fneus.trainer import WMASK_MODEL
+
+LVIS_RENDERER = dict(n_samples=64, n_importance=64, n_outside=0, up_sample_steps=4, perturb=1.0)     # confs/wmask.conf:99-105
+
+
+def stage2_loss(out: dict):
+    """lvis.py:164-170"""
+    m = out["sdf_mask"]
+    lvis_loss = (out["gt_lvis"] - out["pre_lvis"]).abs().sum() / (m.sum() * 4 + 1e-6)
+    err = (out["gt_trace_radiance"] - out["pre_trace_radiance"]) * m[:, None, None]
+    radiance_loss = err.abs().sum() / (m.sum() * 12 + 1e-6)
+    return {"loss": lvis_loss + radiance_loss, "lvis_loss": lvis_loss, "trace_radiance_loss": radiance_loss}
+
+
+class Stage2Trainer:
+    def __init__(self, device, model_conf: Optional[dict] = None, prec: int = ops.PREC_PARITY, lr: float = 5e-4, seed: int = 0,
+                 synthetic_init: bool = True, sdf_kwargs: Optional[dict] = None):
+        from models.fields import SDFNetwork, RenderingNetwork, SingleVarianceNetwork, RefColor, Lvis, IndirectLight
+        from models.renderer import NeuSRenderer
+        conf = model_conf or dict(WMASK_MODEL, lvis_renderer=LVIS_RENDERER)
+        self.device = device
+        self.sdf_network = SDFNetwork(**conf["sdf_network"])
+        self.color_network = RenderingNetwork(**conf["rendering_network"])
+        self.deviation_network = SingleVarianceNetwork(**conf["variance_network"])
+        self.refColor_network = RefColor()
+        self.lvis_network, self.indiLgt_network = Lvis(), IndirectLight()
+        if synthetic_init:
+            T = lambda sd: {k: torch.from_numpy(v) for k, v in sd.items()}
+            self.sdf_network.load_state_dict(T(synth.sdf_state_dict(seed, **(sdf_kwargs or {}))))
+            self.color_network.load_state_dict(T(synth.color_state_dict(seed + 1)))
+            self.refColor_network.load_state_dict(T(synth.refcolor_state_dict(seed + 2)))
+            self.lvis_network.load_state_dict(T(synth.lvis_state_dict(seed + 4)))
+            self.indiLgt_network.load_state_dict(T(synth.indilgt_state_dict(seed + 5)))
+        self.frozen = [self.sdf_network, self.deviation_network, self.color_network, self.refColor_network]
+        for m in self.frozen + [self.lvis_network, self.indiLgt_network]:
+            m.to(device)
+        for m in self.frozen:
+            for p in m.parameters():
+                p.requires_grad_(False)
+        self.sdf_network.set_precision(prec)
+        self.color_network.set_precision(prec)
+        # lvis.py:89-92
+        self.params = list(self.lvis_network.parameters()) + list(self.indiLgt_network.parameters())
+        self.optimizer = torch.optim.Adam(self.params, lr=lr)
+        self.renderer = NeuSRenderer(**conf.get("lvis_renderer", LVIS_RENDERER), sdf_network=self.sdf_network,
+                                     deviation_network=self.deviation_network, color_network=self.color_network,
+                                     lvis_network=self.lvis_network, indiLgt_network=self.indiLgt_network)
+        self.iter_step = 0
+
+    def set_lr(self, lr: float):
+        for g in self.optimizer.param_groups:
+            g["lr"] = lr
+
+    def get_lr(self) -> float:
+        return float(self.optimizer.param_groups[0]["lr"])
+
+    def train_step(self, data: torch.Tensor, near=None, far=None, u_theta=None, u_z=None):
+        """data [B,10] (dataset.py:133-151); near / far None: unit-sphere bounds.  -> loss dict, or None when no ray of
+        the batch hits the surface (the reference skips such a batch, lvis.py:160-161)"""
+        rays_o, rays_d, _rgb, _mask = ops.split_batch(data.contiguous())
+        out = self.renderer.lvis_render(rays_o, rays_d, near, far, u_theta=u_theta, u_z=u_z)
+        if not bool(out["sdf_mask"].any()):
+            return None
+        losses = stage2_loss(out)
+        self.optimizer.zero_grad(set_to_none=True)
+        losses["loss"].backward()
+        self.optimizer.step()
+        self.iter_step += 1
+        losses["n_hit"] = out["sdf_mask"].sum()
+        return losses

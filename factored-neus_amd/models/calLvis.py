@@ -1,0 +1,121 @@
+"""Stage-2 ground truth with the reference's function names (models/calLvis.py), on the HIP kernels.
+
+cal_indiLgt (calLvis.py:339-409): from every visible surface point, 4 random directions on the hemisphere of the normal;
+each secondary ray is marched through the frozen SDF (512 uniform samples on t in [0, 1] -> K1, 1.05 M points for a
+512-ray batch), re-sampled to 32 depths (K6), and gives the colour of the first surface it hits (K2 + K4 without stash) and
+its occlusion (NeuS weights at cos_anneal_ratio 0); Lvis / IndirectLight predict both quantities.
+
+Launch plan per step (R = 4 x hit points secondary rays):
+  fneus_sample_dirs                      directions + ray origins                         calLvis.py:351-358, 302-320
+  fneus_sdf_fwd       (K1, R x 512)      coarse SDF along the secondary rays              :363-368
+  fneus_upsample      (K6, 512 -> 32)    fine depths                                      :374-379, 55-90
+  fneus_sections                         section lengths / mid points                     :95-100 = :155-160
+  fneus_sdf_fwd_grad  (K2, R x 32)       SDF + gradient at the mid points (one pass serves :171 and :111-117)
+  fneus_ray_hit                          first hit + occlusion                            :178-196, 119-150
+  fneus_sdf_fwd_grad + fneus_color_fwd   (R points) colour at the hit points              :197-203
+The secondary level runs at FIXED shape (all R rays, misses masked afterwards): no host synchronisation inside.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from fneus import ops
+from fneus.autograd import RaySamples
+
+N_COARSE = 512          # calLvis.py:365
+N_FINE = 32             # calLvis.py:378
+SAMPLE_DIST = (1 - 0.1) / 32.0      # calLvis.py:95, 155
+
+
+def gen_light_z(near, far, n_samples, n, device=None):
+    """calLvis.py:9-13"""
+    z = near + (far - near) * torch.linspace(0.0, 1.0, n_samples, device=device)
+    return torch.broadcast_to(z, (n, n_samples))
+
+
+def near_far_from_sphere(rays_o, rays_d):
+    """calLvis.py:16-23"""
+    a = torch.sum(rays_d ** 2, dim=-1, keepdim=True)
+    b = 2.0 * torch.sum(rays_o * rays_d, dim=-1, keepdim=True)
+    mid = 0.5 * (-b) / a
+    return mid - 1.0, mid + 1.0
+
+
+def up_sample(rays_o, rays_d, z_vals, sdf, n_importance, inv_s=64):
+    """calLvis.py:55-90: the new depths only (fneus_upsample, up to 512 samples per ray)"""
+    R, m = z_vals.shape
+    return ops.upsample(rays_o.contiguous(), rays_d.contiguous(), z_vals.contiguous(), sdf.reshape(R, m).contiguous(),
+                        n_importance, float(inv_s))
+
+
+def sample_dirs(normals, r_theta, r_phi):
+    """calLvis.py:302-320 with the reference's arguments (normals [n,1,3], angles [n,S]); the training path uses the fused
+    ops.sample_dirs on the raw uniform draws instead"""
+    tiny = 1e-6
+    unit = lambda v: v / (torch.norm(v, dim=-1, keepdim=True) + tiny)
+    x_axis = torch.zeros_like(normals)
+    x_axis[:, :, 0] = 1
+    n = unit(normals)
+    U = unit(torch.linalg.cross(x_axis, n, dim=-1))
+    V = unit(torch.linalg.cross(n, U, dim=-1))
+    th, ph = r_theta.unsqueeze(-1), r_phi.unsqueeze(-1)
+    return U * torch.cos(th) * torch.sin(ph) + V * torch.sin(th) * torch.sin(ph) + n * torch.cos(ph)
+
+
+def query_indir_illum(lgtSGs, sample_dirs):
+    """calLvis.py:323-336: [n,L,7] spherical Gaussians, [n,S,3] directions -> radiance [n,S,3]"""
+    lobes = lgtSGs[:, None, :, :3]
+    lobes = lobes / torch.norm(lobes, dim=-1, keepdim=True)
+    lam, mu = lgtSGs[:, None, :, 3:4], lgtSGs[:, None, :, 4:]
+    cosv = torch.sum(sample_dirs[:, :, None, :] * lobes, dim=-1, keepdim=True)
+    return torch.sum(mu * torch.exp(lam * (cosv - 1.0)), dim=2)
+
+
+def _secondary_march(origins, dirs, sdf_network, color_network, inv_s, trace=None):
+    """everything of cal_indiLgt that sees the frozen geometry: -> occlusion [R], hit colour [R,3], hit mask [R] (u8)"""
+    R = origins.shape[0]
+    dev = origins.device
+    z_coarse = gen_light_z(0.0, 1.0, N_COARSE, R, device=dev).contiguous()
+    coarse_sdf = sdf_network.sdf_samples(RaySamples(origins, dirs, z_coarse.reshape(-1), N_COARSE)).reshape(R, N_COARSE)
+    z_fine = ops.upsample(origins, dirs, z_coarse, coarse_sdf, N_FINE, inv_s)
+    dists, mid_z = ops.sections(z_fine, SAMPLE_DIST)
+    samples = RaySamples(origins, dirs, mid_z.reshape(-1), N_FINE)
+    sdf, _, grad = sdf_network.value_feature_normal(samples, False)
+    hit = ops.ray_hit(origins, dirs, mid_z, sdf.reshape(R, N_FINE), dists=dists, normal=grad, inv_s=inv_s,
+                      want_weights=trace is not None)
+    at_hit = RaySamples(origins, dirs, hit["z_surf"], 1)
+    _, feat_h, normal_h = sdf_network.value_feature_normal(at_hit, False)
+    rgb = color_network.color_samples(at_hit, normal_h, feat_h, sdf_network, False)
+    mask = hit["sdf_mask"]
+    hit_rgb = rgb * mask[:, None].to(rgb.dtype)                      # calLvis.py:173, 202: zeros where nothing is hit
+    if trace is not None:
+        trace.update(z_fine=z_fine, sec_sdf_mask=mask.bool(), sec_hit_rgb=hit_rgb, sec_weights=hit["weights"],
+                     coarse_sdf=coarse_sdf)
+    return hit["occlusion"], hit_rgb, mask
+
+
+def cal_indiLgt(surf, normal, sdf_network, deviation_network, color_network, lvis_network, indiLgt_network, u_theta=None,
+                u_z=None, trace=None):
+    """calLvis.py:339-409.  surf, normal [n,3]; u_theta, u_z [n,4]: the uniform draws of :351-352 (drawn here when None)"""
+    nsamp = 4
+    n = surf.shape[0]
+    dev = surf.device
+    if u_theta is None:
+        u_theta = torch.rand(n, nsamp, device=dev)
+    if u_z is None:
+        u_z = torch.rand(n, nsamp, device=dev)
+    with torch.no_grad():
+        surf = surf.detach().float().contiguous()
+        origins, dirs = ops.sample_dirs(surf, normal.detach().float().contiguous(), u_theta.float().contiguous(),
+                                        u_z.float().contiguous())
+        inv_s = float(deviation_network.inv_s())          # geometry is frozen in stage 2: a constant
+        occu, hit_rgb, _ = _secondary_march(origins, dirs, sdf_network, color_network, inv_s, trace)
+        gt_lvis = (1.0 - occu).reshape(n, nsamp)
+        gt_trace_radiance = hit_rgb.reshape(n, nsamp, 3)
+    pre_lvis = lvis_network(origins, dirs).reshape(n, nsamp)
+    pre_trace_radiance = query_indir_illum(indiLgt_network(surf), dirs.reshape(n, nsamp, 3))
+    if trace is not None:
+        trace.update(dirs=dirs.reshape(n, nsamp, 3))
+    return {"gt_lvis": gt_lvis, "pre_lvis": pre_lvis, "gt_trace_radiance": gt_trace_radiance,
+            "pre_trace_radiance": pre_trace_radiance}

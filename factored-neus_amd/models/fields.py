@@ -439,3 +439,43 @@ class NeRF(nn.Module):
                                     input_views.detach().float().contiguous(), self.prec, self._be.ws,
                                     torch.is_grad_enabled())
         return density.reshape(-1, 1), rgb
+
+
+class Lvis(nn.Module):
+    """Stage-2 distilled light visibility (fields.py:338-369): sigmoid(MLP(embed(pts, 10) | embed(view, 4))), 90 -> 256 x 4 -> 1.
+    Same state_dict keys as the reference (`lvis.{0,2,4,6,8}.weight / bias`); the first layer is an explicit Linear(90, 256)
+    where the reference uses LazyLinear.  A plain library MLP: the GEMMs go to rocBLAS through torch (<= 2048 rows per step,
+    < 2 % of the stage-2 step, which is the 1 M-point SDF march on the K1 kernel)."""
+
+    def __init__(self):
+        super().__init__()
+        self.embedview_fn_view, ch_view = get_embedder(4)
+        self.embedview_fn_pts, ch_pts = get_embedder(10)
+        self.lvis = nn.Sequential(nn.Linear(ch_pts + ch_view, 256), nn.ReLU(), nn.Linear(256, 256), nn.ReLU(),
+                                  nn.Linear(256, 256), nn.ReLU(), nn.Linear(256, 256), nn.ReLU(), nn.Linear(256, 1),
+                                  nn.Sigmoid())
+
+    def forward(self, pts, view):
+        return self.lvis(torch.cat([self.embedview_fn_pts(pts), self.embedview_fn_view(view)], dim=-1))
+
+
+class IndirectLight(nn.Module):
+    """Stage-2 indirect light as 24 spherical Gaussians per point (fields.py:372-413): 63 -> 512 x 4 -> 144 -> [n, 24, 7] =
+    (lobe axis from two sigmoid angles, sharpness 30 sigmoid + 0.1, relu amplitude x 3).  state_dict keys `indi.{0,..,8}`."""
+
+    def __init__(self, num_lgt_sgs=24):
+        super().__init__()
+        self.num_lgt_sgs = num_lgt_sgs
+        self.embedview_fn_view, _ = get_embedder(4)
+        self.embedview_fn_pts, ch_pts = get_embedder(10)
+        self.indi = nn.Sequential(nn.Linear(ch_pts, 512), nn.ReLU(), nn.Linear(512, 512), nn.ReLU(), nn.Linear(512, 512),
+                                  nn.ReLU(), nn.Linear(512, 512), nn.ReLU(), nn.Linear(512, num_lgt_sgs * 6))
+
+    def forward(self, pts):
+        out = self.indi(self.embedview_fn_pts(pts)).reshape(-1, self.num_lgt_sgs, 6)
+        ang = torch.sigmoid(out[..., :2]) * (2 * np.pi)
+        theta, phi = ang[..., :1], ang[..., 1:2]
+        lobes = torch.cat([torch.cos(theta) * torch.sin(phi), torch.sin(theta) * torch.sin(phi), torch.cos(phi)], dim=-1)
+        lam = torch.sigmoid(out[..., 2:3]) * 30 + 0.1
+        mu = torch.relu(out[..., 3:])
+        return torch.cat([lobes, lam, mu], dim=-1)

@@ -292,6 +292,38 @@ class NeuSRenderer:
             inside_sphere = torch.linalg.norm(pts, ord=2, dim=-1) < 1.0
         return {"n_samples": n, "mid_z_vals": mid_z, "sdf": sdf[:, None], "inside_sphere_mask": inside_sphere.any(dim=-1)}
 
+    def lvis_render(self, rays_o, rays_d, near, far, u_theta=None, u_z=None, trace=None):
+        """renderer.py:567-627: visibility / traced radiance of 4 secondary rays per visible surface point, and the
+        predictions of the Lvis / IndirectLight networks.  Rows of rays without a surface hit hold 1.
+        fneus_ray_hit finds the hit points; they are compacted (one host read of the hit count per step, as the reference's
+        `if n_sdf_mask > 0`) and handed to cal_indiLgt.  u_theta, u_z [hits, 4]: the uniform draws (tests)."""
+        from models.calLvis import cal_indiLgt
+        B = len(rays_o)
+        dev = rays_o.device
+        M = 4
+        util = self.lvis_mateIllu_render_util(rays_o, rays_d, near, far)
+        n = util["n_samples"]
+        rays_o, rays_d = rays_o.detach().float().contiguous(), rays_d.detach().float().contiguous()
+        with torch.no_grad():
+            hit = ops.ray_hit(rays_o, rays_d, util["mid_z_vals"], util["sdf"].reshape(B, n).contiguous(),
+                              inside_mask=util["inside_sphere_mask"])
+            sdf_mask = hit["sdf_mask"].view(torch.bool)
+            idx = sdf_mask.nonzero(as_tuple=True)[0]
+        out = {"gt_lvis": torch.ones(B, M, device=dev), "pre_lvis": torch.ones(B, M, device=dev),
+               "gt_trace_radiance": torch.ones(B, M, 3, device=dev), "pre_trace_radiance": torch.ones(B, M, 3, device=dev),
+               "sdf_mask": sdf_mask}
+        if idx.numel() > 0:
+            with torch.no_grad():
+                pts_surf = hit["pts_surf"][idx].contiguous()
+                _, _, n_surf = self.sdf_network.value_feature_normal(RaySamples(pts=pts_surf), False)
+            res = cal_indiLgt(pts_surf, n_surf, self.sdf_network, self.deviation_network, self.color_network,
+                              self.lvis_network, self.indiLgt_network, u_theta=u_theta, u_z=u_z, trace=trace)
+            if trace is not None:
+                trace.update(pts_surf=pts_surf, normal=n_surf)
+            for k in ("gt_lvis", "pre_lvis", "gt_trace_radiance", "pre_trace_radiance"):
+                out[k] = out[k].index_copy(0, idx, res[k].to(out[k].dtype))
+        return out
+
     def extract_geometry(self, bound_min, bound_max, resolution, threshold=0.0):
         """renderer.py:729-734: iso-surface of -sdf at `threshold`; the grid goes through K1 (fneus_sdf_fwd), the surface
         is extracted on the device by models/mesh.py (marching tetrahedra; PyMCubes is not a dependency).

@@ -240,10 +240,11 @@ int fneus_stage1_loss(const float* color /*[B][3]*/, const float* true_rgb /*[B]
 int fneus_stage1_norms(const float* mask_in, const unsigned char* sdf_mask, const float* eik_den, int n_rays,
                        float mask_weight, float* norms, fneus_stream_t stream);
 
-/* ---- K6: hierarchical sampler pieces (one wavefront per ray, 2 <= samples per ray <= 256) ---------------------- */
+/* ---- K6: hierarchical sampler pieces (one wavefront per ray, 2 <= samples per ray <= 256; fneus_upsample: <= 512) -- */
 /* NeuSRenderer.up_sample + sample_pdf(det=True)  (renderer.py:152-189, 43-77): z [B][m], sdf [B][m] -> z_new [B][k]  */
 int fneus_upsample(const float* rays_o, const float* rays_d, const float* z, const float* sdf, int n_rays, int m, int k,
                    float inv_s, float* z_new, fneus_stream_t stream);
+/* (m <= 512 since round 2: the stage-2 secondary rays up-sample 512 coarse samples, calLvis.py:55-90, same algorithm) */
 /* cat_z_vals (renderer.py:191-205): stable sort-merge of (z_old | z_new); s_old/s_new/s_out may be NULL (last step) */
 int fneus_merge(const float* z_old, const float* s_old, int m, const float* z_new, const float* s_new, int k, int n_rays,
                 float* z_out, float* s_out, fneus_stream_t stream);
@@ -261,6 +262,23 @@ int fneus_ray_setup(const float* rays_o, const float* rays_d, const float* near,
 
 /* section lengths and mid points of render_core (renderer.py:223-226) */
 int fneus_sections(const float* z, int n_rays, int n, float sample_dist, float* dists, float* mid_z, fneus_stream_t stream);
+
+/* ---- Stage 2 (lvis.py): NeuSRenderer.lvis_render (renderer.py:567-627) and cal_indiLgt (calLvis.py:339-409) -------------- */
+/* First surface hit of every ray: idx = first sample with sign(sdf) = -1; sdf_mask = idx exists & idx >= 1 & the ray has a
+ * sample inside the unit sphere (inside_mask [B] if given, else computed from the points); z_surf = zero crossing of the SDF
+ * between samples idx-1 and idx by linear interpolation; pts_surf = o + d z_surf   (renderer.py:586-604 = calLvis.py:178-196;
+ * rays without a hit get z_surf = 0).  With normal [B][n][3] and dists [B][n] also compute_weight (calLvis.py:93-150, NeuS
+ * alpha at cos_anneal_ratio 0): occlusion [B] = sum of the weights of the samples inside the unit sphere, weights [B][n]
+ * (may be NULL).  2 <= n <= 256.                                                                                          */
+int fneus_ray_hit(const float* rays_o, const float* rays_d, const float* mid_z, const float* sdf, const float* dists /*may be NULL*/,
+                  const float* normal /*may be NULL*/, const unsigned char* inside_mask /*may be NULL*/, int n_rays, int n,
+                  float inv_s, unsigned char* sdf_mask, float* z_surf, float* pts_surf, float* occlusion /*NULL without normal*/,
+                  float* weights /*may be NULL*/, fneus_stream_t stream);
+/* sample_dirs (calLvis.py:302-320) on the draws of calLvis.py:351-355: n_dirs directions per surface point,
+ * theta = 2 pi u_theta, phi = asin(0.95 u_z); origins [n_pts*n_dirs][3] = the surface point of each direction (:357).      */
+int fneus_sample_dirs(const float* surf /*[n_pts][3]*/, const float* normal /*[n_pts][3]*/, const float* u_theta /*[n_pts][n_dirs]*/,
+                      const float* u_z /*[n_pts][n_dirs]*/, int n_pts, int n_dirs, float* origins, float* dirs,
+                      fneus_stream_t stream);
 
 /* ---- K7: background NeRF++ of the womask configurations  (fields.py:233-259 NeRF.forward via renderer.py:112-149) ---- */
 /* pts4 [n][4] = (p/|p|, 1/|p|) of the background samples, dirs [n][3]; outputs are RAW: density [n] (alpha_linear) and
