@@ -37,37 +37,47 @@ FLOP_TRAIN_PER_SAMPLE = (0.875 + 2 + 4) * F_SDF + 3 * F_COL      # = 8.84 MFLOP
 KERNEL_FLOPS = {
     "fneus_sdf_fwd_grad": 2 * F_SDF * SAMPLES_PER_STEP,           # value+feature forward and the reverse sweep
     "fneus_sdf_bwd": 2 * F_SDF * SAMPLES_PER_STEP,                # ascending + descending chains
-    "fneus_dw_gemm:sdf": 2 * F_SDF * SAMPLES_PER_STEP,            # dW = zbar^T u + a^T adj for the 9 SDF layers
-    "fneus_dw_gemm:color": F_COL * SAMPLES_PER_STEP,
+    "fneus_dw_gemm_pp:sdf": 2 * F_SDF * SAMPLES_PER_STEP,         # dW = zbar^T u + a^T adj for the 9 SDF layers
+    "fneus_dw_gemm_pp:color": F_COL * SAMPLES_PER_STEP,
     "fneus_color_fwd": F_COL * SAMPLES_PER_STEP,
     "fneus_color_bwd": F_COL * SAMPLES_PER_STEP,
 }
 PEAK_BF16_MFMA_TFLOPS = 2500.0       # MI355X dense bf16 (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0                # HBM3E (MI355X_MICROARCH.md)
-# Algorithmic HBM bytes per sample of the stash design in parity mode: what a launch must move
-# even with perfect caching.  K3: reads sigma' twice 2 x 4096 + a_l 8192 + coupling 8192 + d_feat 1024, writes coupling
-# 8192 + adj planes 8192 + zbar planes 9216 + qbar 192.
+# Algorithmic HBM bytes per sample of the fragment-plane design in parity mode with bf16 gradient planes (DESIGN.md
+# section 4): what a launch must move even with perfect caching.  One 256-wide bf16 plane = 512 B / sample, the sigma'
+# plane (u16 fixed point) 512 B per layer.
+#   K2 writes  h hi 8 x 512, a hi + lo 2 x 8 x 512, sigma' 8 x 512, feature plane 512, PE plane 128, fp32 feature 1024,
+#              sdf + normal 16; reads 12 B of ray data
+#   K3 reads   sigma' 8 x 512, a hi + lo 2 x 8 x 512, d_feat fp32 1024, cotangents 16, the coupling planes it wrote
+#              (hi + lo 2 x 8 x 512); writes the coupling planes 2 x 8 x 512, adj hi 8 x 512, zbar hi 9 x 512, qbar 128
 KERNEL_BYTES_PARITY = {
-    "fneus_sdf_bwd": (2 * 4096 + 8192 + 8192 + 1024 + 8192 + 8192 + 9216 + 192) * SAMPLES_PER_STEP,
-    "fneus_sdf_fwd_grad": (8192 + 8192 + 2048 + 1024 + 4096 + 8192 + 4096 + 192) * SAMPLES_PER_STEP,   # h, a, feat planes, feat fp32,
-                                                                          # sigma' written + read back, a_l private, PE rows
+    "fneus_sdf_fwd_grad": (8 * 512 + 2 * 8 * 512 + 8 * 512 + 512 + 128 + 1024 + 16 + 12) * SAMPLES_PER_STEP,
+    "fneus_sdf_bwd": (8 * 512 + 2 * 8 * 512 + 1024 + 16 + 2 * 8 * 512 + 2 * 8 * 512 + 8 * 512 + 9 * 512 + 128) * SAMPLES_PER_STEP,
 }
 
 
-CPU_RAYS = 128          # bounded CPU sample: a quarter batch of the same workload (same samples per ray, same nets)
+CPU_CONFIGS = {       # BASELINE.json configs[0] and configs[1]
+    "cfg1": dict(rays=256, n_samples=32, n_importance=32),
+    "cfg2": dict(rays=RAYS, n_samples=N_SAMPLES, n_importance=N_IMPORTANCE),
+}
 
 
-def cpu_baseline(budget_s: float = 12.0, device=None):
-    """The oracle (CPU port of the reference algorithm) timed on the host cores: same workload, bounded sample.
-    With `device` = the GPU the same port runs through stock PyTorch-ROCm ops on the full batch: the "unfused GPU" figure
-    the reference itself would get on this box; reported inside the cpu_baseline object."""
+def _cpu_model():
+    try:
+        return next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except Exception:
+        return ""
+
+
+def oracle_train_steps(cfg: dict, min_steps: int, budget_s: float, device=None):
+    """`min_steps` (or more while the budget lasts) FULL-SIZE train steps of the CPU port of the reference algorithm
+    (oracle/ref_torch.py: render -> 4-term loss -> autograd backward -> Adam) after one warm-up step -> per-step seconds"""
     from oracle import ref_torch as R
     from fneus import synth
-    threads = min(32, os.cpu_count() or 1)     # eager torch on small ops gets slower, not faster, beyond ~32 threads
-    torch.set_num_threads(threads)
     on_gpu = device is not None
-    n_rays = RAYS if on_gpu else CPU_RAYS
     dev = device if on_gpu else torch.device("cpu")
+    n_rays, n_s, n_i = cfg["rays"], cfg["n_samples"], cfg["n_importance"]
     T = lambda sd: {k: torch.from_numpy(v).clone().to(dev).requires_grad_(True) for k, v in sd.items()}
     sd_sdf, sd_col, sd_ref = T(synth.sdf_state_dict(0)), T(synth.color_state_dict(1)), T(synth.refcolor_state_dict(2))
     variance = torch.tensor(0.3, device=dev, requires_grad=True)
@@ -84,49 +94,60 @@ def cpu_baseline(budget_s: float = 12.0, device=None):
         t0 = time.time()
         near, far = R.near_far_from_sphere(rays_o, rays_d)
         out = R.render(rays_o, rays_d, near, far, R.sdf_params_from_state_dict(sd_sdf), R.inv_s_from_variance(variance),
-                       R.color_params_from_state_dict(sd_col), sd_ref, None, n_samples=N_SAMPLES,
-                       n_importance=N_IMPORTANCE, t_rand=torch.rand(n_rays, 1, device=dev), cos_anneal_ratio=1.0)
+                       R.color_params_from_state_dict(sd_col), sd_ref, None, n_samples=n_s, n_importance=n_i,
+                       t_rand=torch.rand(n_rays, 1, device=dev), cos_anneal_ratio=1.0)
         losses = R.stage1_loss(out, rgb, mask, 0.1, 0.1, 0.1)
         opt.zero_grad()
         losses["loss"].backward()
         opt.step()
         if on_gpu:
             torch.cuda.synchronize()
-        dt = time.time() - t0
-        if step > 0 or budget_s <= 0:
-            times.append(dt)
+        if step > 0:
+            times.append(time.time() - t0)
         step += 1
-        # bounded sample: about budget_s seconds of CPU work (at most 40 steps); 8 steps of the GPU run of the same code
-        if (time.time() - t_start > budget_s and len(times) >= 1) or step >= (8 if on_gpu else 40) or (step >= 1 and dt > budget_s):
+        if len(times) >= min_steps and (time.time() - t_start > budget_s or len(times) >= 8):
             break
-    if not times:
-        times = [dt]
-    t = float(np.median(times))
-    if on_gpu:
-        return {"value": n_rays * (N_SAMPLES + N_IMPORTANCE) / t, "unit": "ray-samples/s", "ms_per_step": t * 1e3,
-                "sample": f"{len(times)} full {n_rays}-ray train steps of oracle/ref_torch.py (fp32, eager stock PyTorch-ROCm "
+    return times
+
+
+def cpu_baseline(device=None):
+    """The oracle (CPU port of the reference algorithm) timed on the host cores at FULL size: configs[1] (512 rays x
+    (64+64), the headline workload; `value`) and configs[0] (256 x (32+32), the reference's own CPU-runnable case), at
+    least 3 timed steps each after one warm-up, median.  With `device` = the GPU the same port runs through stock
+    PyTorch-ROCm ops: the "unfused GPU" figure the reference itself would get on this box."""
+    if device is not None:
+        times = oracle_train_steps(CPU_CONFIGS["cfg2"], 7, 0.0, device)
+        t = float(np.median(times))
+        return {"value": SAMPLES_PER_STEP / t, "unit": "ray-samples/s", "ms_per_step": t * 1e3,
+                "sample": f"{len(times)} full {RAYS}-ray train steps of oracle/ref_torch.py (fp32, eager stock PyTorch-ROCm "
                           f"ops, autograd double backward) on the same GPU after 1 warm-up"}
-    cpu_model = ""
-    try:
-        cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
-    except Exception:
-        pass
-    return {"value": CPU_RAYS * (N_SAMPLES + N_IMPORTANCE) / t, "unit": "ray-samples/s", "cores": threads, "kind": "port",
-            "cpu_model": cpu_model,
-            "sample": f"{len(times)} train steps (~{sum(times):.0f} s) of {CPU_RAYS} rays x {N_SAMPLES + N_IMPORTANCE} samples (1/4 batch of the "
-                      f"same workload) after 1 warm-up, oracle/ref_torch.py fp32, {threads} torch threads of "
-                      f"{os.cpu_count()} host cores, median {t:.2f} s/step"}
+    threads = min(32, os.cpu_count() or 1)     # eager torch on small ops gets slower, not faster, beyond ~32 threads
+    torch.set_num_threads(threads)
+    legs = {}
+    for name, min_steps, budget in (("cfg2", 3, 20.0), ("cfg1", 3, 6.0)):
+        cfg = CPU_CONFIGS[name]
+        times = oracle_train_steps(cfg, min_steps, budget)
+        t = float(np.median(times))
+        n = cfg["rays"] * (cfg["n_samples"] + cfg["n_importance"])
+        legs[name] = {"value": n / t, "unit": "ray-samples/s", "s_per_step": t, "steps": len(times), "cores": threads,
+                      "workload": f"{cfg['rays']} rays x ({cfg['n_samples']}+{cfg['n_importance']}) samples, full train step"}
+    c2 = legs["cfg2"]
+    return {"value": c2["value"], "unit": "ray-samples/s", "cores": threads, "kind": "port", "cpu_model": _cpu_model(),
+            "sample": f"{c2['steps']} full-size train steps (median {c2['s_per_step']:.2f} s/step) of {RAYS} rays x "
+                      f"{N_SAMPLES + N_IMPORTANCE} samples (BASELINE configs[1], the headline workload) after 1 warm-up, "
+                      f"oracle/ref_torch.py fp32, {threads} torch threads of {os.cpu_count()} host cores",
+            "cfg1": legs["cfg1"], "cfg2": legs["cfg2"]}
 
 
 # newest first: the PMC passes are re-collected whenever a kernel's memory behaviour changes (tools/collect_profiles.sh)
-TRAFFIC_FILES = ("r01_g_traffic.json", "r01_f_traffic.json", "r01_e_traffic.json", "r01_d_traffic.json", "r01_c_traffic.json")
+TRAFFIC_FILES = ("r02_c_traffic.json", "r02_b_traffic.json", "r02_a_traffic.json")
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)      # SURVEY.md section 8(d): >= 50 timed steps after >= 10 warm-ups
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--prec", choices=["parity", "fast"], default="parity")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -147,6 +168,14 @@ def main():
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    if world > 1:       # one line per rank: a SCALE record can show that N ranks on N devices took part
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            ver = "?"
+        print(f"[bench rank {rank}/{world}] device cuda:{local} {torch.cuda.get_device_name(local)} backend "
+              f"{dist.get_backend()} RCCL {ver} MASTER {os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}",
+              file=sys.stderr, flush=True)
 
     def run(prec, steps, warmup, profile):
         tr = Stage1Trainer(device, prec=prec, distributed=(world > 1), use_graph=not args.no_graph)
@@ -161,14 +190,18 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         t0 = time.perf_counter()
+        marks[0].record()
         for i in range(steps):
             tr.train_step(batches[warmup + i])
+            marks[i + 1].record()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        run.step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
         if world > 1:
             t = torch.tensor([dt], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -194,6 +227,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
+        "ms_per_step_median": float(np.median(run.step_ms)),      # per-step HIP events on the launch stream (this rank)
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -216,12 +250,14 @@ def main():
         dom = max((k for k in per if k in KERNEL_FLOPS), key=lambda k: per[k]["ms_per_step"])
         flops_per_launch = KERNEL_FLOPS[dom] / max(round(per[dom]["launches_per_step"]), 1)
         achieved = flops_per_launch / (per[dom]["avg_ms"] * 1e-3) / 1e12
-        traffic = None      # HBM bytes per launch from the committed PMC passes (profiles/*_traffic.json), parity mode only
+        traffic = traffic_src = None      # HBM bytes per launch from the committed PMC passes (profiles/*_traffic.json), parity mode only
         if prec == ops.PREC_PARITY:
             for tag in TRAFFIC_FILES:
                 try:
-                    tj = json.load(open(os.path.join(ROOT, "profiles", tag)))["kernels"]
-                    traffic = tj[dom.split(":")[0]]["hbm_bytes_per_launch"]
+                    tj = json.load(open(os.path.join(ROOT, "profiles", tag)))
+                    traffic = tj["kernels"][dom.split(":")[0]]["hbm_bytes_per_launch"]
+                    traffic_src = {"file": "profiles/" + tag, "kernel": tj["kernels"][dom.split(":")[0]].get("kernel"),
+                                   "step_bytes_per_ray_sample": tj.get("step_total", {}).get("bytes_per_ray_sample")}
                     break
                 except Exception:
                     continue
@@ -229,11 +265,12 @@ def main():
             # the same launch seen against the HBM roofline: these kernels move their whole activation stash
             gbs = KERNEL_BYTES_PARITY[dom] / max(round(per[dom]["launches_per_step"]), 1) / (per[dom]["avg_ms"] * 1e-3) / 1e9
             result["roofline_hbm"] = {"kernel": dom, "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                      "frac": gbs / PEAK_HBM_GBS, "traffic": traffic,
+                                      "frac": gbs / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": traffic_src,
                                       "note": "algorithmic stash bytes per launch (DESIGN.md 4.1) / launch duration; "
                                               "streaming torch kernels reach 4.0 (read) - 6.8 (write) TB/s on this part"}
         result["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS,
                               "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_MFMA_TFLOPS, "traffic": traffic,
+                              "traffic_source": traffic_src,
                               "avg_launch_ms": per[dom]["avg_ms"],
                               "note": "algorithmic (fp32-equivalent) FLOPs per launch / HIP-event launch duration; "
                                       "parity mode issues 3 bf16 MFMAs per algorithmic product"}
@@ -284,6 +321,30 @@ def main():
                                  "note": "512 rays x (64+64 inside + 32 outside) samples, background NeRF++ on the fused K7 "
                                          "kernels, ramping cos_anneal_ratio, same precision mode and launch mode as the headline number"}
         del trw
+
+    if rank == 0 and world == 1 and not args.no_fast_extra:
+        # stage 2 (BASELINE configs[2], lvis.py:132-196): 512 primary rays x (64+64), 4 secondary rays per hit point x 512
+        # coarse SDF samples on K1, Lvis + IndirectLight trained with Adam.  Eager launches (the hit count is read per step).
+        from fneus.trainer2 import Stage2Trainer
+        tr2 = Stage2Trainer(device, prec=prec)
+        sb = synthetic_batches(14, RAYS, device, rank=rank)
+        hits = []
+        for b in sb[:4]:
+            tr2.train_step(b)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for b in sb[4:]:
+            o2 = tr2.train_step(b)
+            if o2 is not None:
+                hits.append(o2["n_hit"])
+        torch.cuda.synchronize()
+        dt_2 = (time.perf_counter() - t0) / 10
+        n_hit = float(torch.stack(hits).float().mean()) if hits else 0.0
+        result["stage2_step"] = {"value": 4 * n_hit * 512 / dt_2, "unit": "secondary-ray SDF samples/s", "ms_per_step": dt_2 * 1e3,
+                                 "primary_rays": RAYS, "mean_hit_points": n_hit, "secondary_rays": 4 * n_hit,
+                                 "note": "lvis_render + L1 losses + backward + Adam (lvis.py:132-196): 4 secondary rays per hit "
+                                         "point x 512 coarse samples through K1, 32 fine samples through K2, same precision mode"}
+        del tr2
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

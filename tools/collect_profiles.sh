@@ -10,7 +10,7 @@ out=$root/gpurun_out
 mkdir -p "$out"
 export TMPDIR=/tmp
 cd /tmp
-python3 "$root/bench.py" --steps 30 --warmup 5 > "$out/${tag}_bench.json" 2> "$out/${tag}_bench.err"
+python3 "$root/bench.py" > "$out/${tag}_bench.json" 2> "$out/${tag}_bench.err"
 tail -1 "$out/${tag}_bench.json"
 rm -rf /tmp/prof_k /tmp/prof_t /tmp/pmc_f /tmp/pmc_w
 rocprofv3 --kernel-trace --stats -d /tmp/prof_k -o k --output-format csv -- python3 "$root/bench.py" --steps 16 --warmup 3 --no-cpu-baseline --no-fast-extra \
