@@ -178,7 +178,7 @@ def test_stage2_adam_steps_match_reference(golden_dir):
                 got = prm.detach().cpu().reshape(-1)[::997].numpy()
                 bad = np.abs(got - want) > 0.2 * lr       # Adam moves every weight by ~lr: near-zero gradients may flip sign
                 assert bad.sum() <= max(1, 0.02 * bad.size), (step, k, int(bad.sum()), bad.size)
-                assert np.abs(got - want).max() <= 2.0 * (step + 1) * lr + 1e-7, (step, k)
+                assert np.abs(got - want).max() <= 2.2 * (step + 1) * lr + 1e-7, (step, k)   # a flipped sign is 2 lr per step
     assert tr.iter_step == 3
 
 

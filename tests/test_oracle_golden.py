@@ -371,4 +371,4 @@ def test_stage2_adam_steps(golden_dir):
                 # flip its sign between two fp32 evaluations, so compare with a few-lr slack on few entries
                 bad = np.abs(got - ref) > 0.2 * float(g["lr"])
                 assert bad.sum() <= max(1, 0.02 * bad.size), (step, k, int(bad.sum()), bad.size)
-                assert np.abs(got - ref).max() <= 2.0 * (step + 1) * float(g["lr"]) + 1e-7, (step, k)
+                assert np.abs(got - ref).max() <= 2.2 * (step + 1) * float(g["lr"]) + 1e-7, (step, k)

@@ -24,6 +24,21 @@ for k in sorted(acc):
         v = acc[k][c]
         print(f"   {c:32s} {sum(v) / len(v):16.0f}  (n={len(v)})")
 
+# matrix-pipe utilisation where the SQ counters were collected: SQ_BUSY_CYCLES counts per shader engine (32 on this part),
+# SQ_VALU_MFMA_BUSY_CYCLES per SIMD (256 CUs x 4): busy fraction = MFMA_BUSY / (BUSY / 32 x 1024)
+rows = []
+for k in sorted(acc):
+    c = {n: sum(v) / len(v) for n, v in acc[k].items()}
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and c.get("SQ_BUSY_CYCLES", 0) > 0:
+        simd_cycles = c["SQ_BUSY_CYCLES"] / 32.0 * 1024.0
+        rows.append((c["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles, k, c))
+if rows:
+    print("# matrix-pipe utilisation per kernel (average launch): MFMA busy cycles / SIMD cycles; waves waiting on an instruction")
+    print("# %-44s %10s %14s %12s" % ("kernel", "MFMA busy", "wait_inst/wave", "waves"))
+    for u, k, c in sorted(rows, reverse=True):
+        wi = c.get("SQ_WAIT_INST_ANY", 0.0) / max(c.get("SQ_WAVE_CYCLES", 1.0), 1.0)
+        print("# %-44s %9.1f%% %13.1f%% %12.0f" % (k[:44], 100 * u, 100 * wi, c.get("SQ_WAVES", 0)))
+
 if json_out:
     # HBM bytes per launch: FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE under-counts wide coalesced reads 2x on gfx950
     # (MI355X_MICROARCH.md, HBM section).  Keys are the C-ABI entry points bench.py reports its kernels under.
