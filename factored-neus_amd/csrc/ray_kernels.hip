@@ -623,6 +623,65 @@ __global__ void __launch_bounds__(256) sample_dirs_kernel(const float* __restric
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Ray generation (models/dataset.py:115-151): pixel (x, y) -> p = K^-1[:3,:3] (x, y, 1) -> v = p / |p| -> d = R v,
+// o = pose[:3, 3].  Images, masks and cameras are device resident: a training batch costs one launch and no host copy.
+// ---------------------------------------------------------------------------------------------------------------
+FN_DEV void pixel_ray(const float* __restrict__ Kinv /*[4][4]*/, const float* __restrict__ pose /*[4][4]*/, float x, float y,
+                      float* o, float* d) {
+    float p[3], v[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)     // torch.matmul of a [3,3] with a [3,1] column: products added left to right
+        p[r] = __fadd_rn(__fadd_rn(__fmul_rn(Kinv[r * 4 + 0], x), __fmul_rn(Kinv[r * 4 + 1], y)), Kinv[r * 4 + 2]);
+    const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(p[0], p[0]), __fmul_rn(p[1], p[1])), __fmul_rn(p[2], p[2])));
+#pragma unroll
+    for (int r = 0; r < 3; ++r) v[r] = __fdiv_rn(p[r], nrm);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        d[r] = __fadd_rn(__fadd_rn(__fmul_rn(pose[r * 4 + 0], v[0]), __fmul_rn(pose[r * 4 + 1], v[1])), __fmul_rn(pose[r * 4 + 2], v[2]));
+        o[r] = pose[r * 4 + 3];
+    }
+}
+
+// gen_random_rays_at (dataset.py:133-151): out [n][10] = rays_o, rays_d, rgb, mask[..., :1] of the given integer pixels
+__global__ void __launch_bounds__(256) gen_random_rays_kernel(const float* __restrict__ Kinv, const float* __restrict__ pose,
+                                                              const float* __restrict__ image, const float* __restrict__ mask,
+                                                              int H, int W, const long long* __restrict__ px,
+                                                              const long long* __restrict__ py, int n, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long x = px[i], y = py[i];
+    float o[3], d[3];
+    pixel_ray(Kinv, pose, (float)x, (float)y, o, d);
+    float* row = out + (size_t)i * 10;
+    const size_t pix = ((size_t)y * W + (size_t)x) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        row[c] = o[c];
+        row[3 + c] = d[c];
+        row[6 + c] = image[pix + c];
+    }
+    row[9] = mask[pix];
+}
+
+// gen_rays_at (dataset.py:115-131): all rays of one camera at the pixel positions tx [nx] x ty [ny] (torch.linspace of the
+// caller) -> rays_o, rays_v [ny][nx][3] (the reference's transposed layout: image row major)
+__global__ void __launch_bounds__(256) gen_rays_grid_kernel(const float* __restrict__ Kinv, const float* __restrict__ pose,
+                                                            const float* __restrict__ tx, const float* __restrict__ ty, int nx,
+                                                            int ny, float* __restrict__ rays_o, float* __restrict__ rays_v) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)nx * ny) return;
+    const int iy = (int)(i / nx), ix = (int)(i - (long)iy * nx);
+    float o[3], d[3];
+    pixel_ray(Kinv, pose, tx[ix], ty[iy], o, d);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        rays_o[i * 3 + c] = o[c];
+        rays_v[i * 3 + c] = d[c];
+    }
+}
+
 }  // namespace fneus
 
 using namespace fneus;
@@ -761,5 +820,31 @@ extern "C" int fneus_sample_dirs(const float* surf, const float* normal, const f
     if (total <= 0) return 0;
     hipLaunchKernelGGL(sample_dirs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, surf, normal, u_theta, u_z,
                        total, n_dirs, origins, dirs);
+    return fneus::launch_status();
+}
+
+extern "C" int fneus_gen_random_rays(const float* intrinsics_inv, const float* pose, const float* image, const float* mask, int H,
+                                     int W, const long long* pixels_x, const long long* pixels_y, int n_rays, float* out,
+                                     fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (n_rays <= 0) return 0;
+    if (!intrinsics_inv || !pose || !image || !mask || !pixels_x || !pixels_y || !out || H <= 0 || W <= 0) {
+        set_last_error("fneus_gen_random_rays: null argument");
+        return -2;
+    }
+    hipLaunchKernelGGL(gen_random_rays_kernel, dim3((n_rays + 255) / 256), dim3(256), 0, stream, intrinsics_inv, pose, image, mask, H,
+                       W, pixels_x, pixels_y, n_rays, out);
+    return fneus::launch_status();
+}
+
+extern "C" int fneus_gen_rays_grid(const float* intrinsics_inv, const float* pose, const float* tx, const float* ty, int nx, int ny,
+                                   float* rays_o, float* rays_v, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    const long total = (long)nx * ny;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(gen_rays_grid_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, intrinsics_inv, pose, tx, ty,
+                       nx, ny, rays_o, rays_v);
     return fneus::launch_status();
 }

@@ -677,6 +677,32 @@ def upsample(rays_o, rays_d, z, sdf, k: int, inv_s: float):
     return out
 
 
+def gen_random_rays(intrinsics_inv, pose, image, mask, px, py):
+    """Dataset.gen_random_rays_at (dataset.py:133-151) for integer pixels px, py (int64 [n]) of one image -> [n,10]"""
+    n = int(px.numel())
+    H, W = int(image.shape[0]), int(image.shape[1])
+    for t, name in ((intrinsics_inv, "intrinsics_inv"), (pose, "pose"), (image, "image"), (mask, "mask")):
+        _chk_f32(t, name)
+    if px.dtype != torch.int64 or py.dtype != torch.int64 or not px.is_cuda or not py.is_cuda:
+        raise ValueError("pixel coordinates must be int64 CUDA tensors")
+    out = torch.empty(n, 10, dtype=torch.float32, device=image.device)
+    _launch("fneus_gen_random_rays", lib.fneus_gen_random_rays, _ptr(intrinsics_inv), _ptr(pose), _ptr(image), _ptr(mask), H, W,
+            _ptr(px.contiguous()), _ptr(py.contiguous()), n, _ptr(out), _stream())
+    return out
+
+
+def gen_rays_grid(intrinsics_inv, pose, tx, ty):
+    """Dataset.gen_rays_at (dataset.py:115-131) at pixel positions tx [nx] x ty [ny] -> rays_o, rays_v [ny, nx, 3]"""
+    nx, ny = int(tx.numel()), int(ty.numel())
+    for t, name in ((intrinsics_inv, "intrinsics_inv"), (pose, "pose"), (tx, "tx"), (ty, "ty")):
+        _chk_f32(t, name)
+    o = torch.empty(ny, nx, 3, dtype=torch.float32, device=tx.device)
+    v = torch.empty(ny, nx, 3, dtype=torch.float32, device=tx.device)
+    _launch("fneus_gen_rays_grid", lib.fneus_gen_rays_grid, _ptr(intrinsics_inv), _ptr(pose), _ptr(tx), _ptr(ty), nx, ny, _ptr(o),
+            _ptr(v), _stream())
+    return o, v
+
+
 def ray_hit(rays_o, rays_d, mid_z, sdf, inside_mask=None, dists=None, normal=None, inv_s: float = 1.0, want_weights=False):
     """first surface hit per ray (+ the occlusion of compute_weight when normal / dists are given), fneus_ray_hit.
     -> dict(sdf_mask u8 [B], z_surf [B], pts_surf [B,3][, occlusion [B]][, weights [B,n]])"""

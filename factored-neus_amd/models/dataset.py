@@ -37,32 +37,35 @@ def load_K_Rt_from_P(P):
 
 
 class _RayMixin:
+    """Ray generation on the HIP kernels (fneus_gen_rays_grid / fneus_gen_random_rays): images, masks and cameras are device
+    resident, a training batch is one launch.  There is no host implementation: the loaders need a GPU device."""
+
+    def _need_gpu(self):
+        if self.device.type != "cuda":
+            raise RuntimeError("ray generation runs on the HIP kernels: construct the dataset on a cuda device")
+
     def gen_rays_at(self, img_idx, resolution_level=1):
         """all rays of one camera, [H/l, W/l, 3] each (dataset.py:115-131)"""
+        from fneus import ops
+        self._need_gpu()
         l = resolution_level
         tx = torch.linspace(0, self.W - 1, self.W // l, device=self.device)
         ty = torch.linspace(0, self.H - 1, self.H // l, device=self.device)
-        px, py = torch.meshgrid(tx, ty, indexing="ij")
-        p = torch.stack([px, py, torch.ones_like(py)], dim=-1)
-        p = torch.matmul(self.intrinsics_all_inv[img_idx, None, None, :3, :3], p[:, :, :, None]).squeeze(-1)
-        v = p / torch.linalg.norm(p, ord=2, dim=-1, keepdim=True)
-        v = torch.matmul(self.pose_all[img_idx, None, None, :3, :3], v[:, :, :, None]).squeeze(-1)
-        o = self.pose_all[img_idx, None, None, :3, 3].expand(v.shape)
-        return o.transpose(0, 1), v.transpose(0, 1)
+        return ops.gen_rays_grid(self.intrinsics_all_inv[int(img_idx)].contiguous(), self.pose_all[int(img_idx)].contiguous(), tx, ty)
 
-    def gen_random_rays_at(self, img_idx, batch_size):
-        """[B,10] = rays_o, rays_d, rgb, mask of random pixels of one camera (dataset.py:133-151), all on the device"""
+    def gen_random_rays_at(self, img_idx, batch_size, pixels=None):
+        """[B,10] = rays_o, rays_d, rgb, mask of random pixels of one camera (dataset.py:133-151), all on the device.
+        pixels = (px, py) int64 tensors: use these instead of drawing (tests)"""
+        from fneus import ops
+        self._need_gpu()
         img_idx = int(img_idx)
-        px = torch.randint(low=0, high=self.W, size=[batch_size], device=self.device)
-        py = torch.randint(low=0, high=self.H, size=[batch_size], device=self.device)
-        color = self.images[img_idx][(py, px)]
-        mask = self.masks[img_idx][(py, px)]
-        p = torch.stack([px, py, torch.ones_like(py)], dim=-1).float()
-        p = torch.matmul(self.intrinsics_all_inv[img_idx, None, :3, :3], p[:, :, None]).squeeze(-1)
-        v = p / torch.linalg.norm(p, ord=2, dim=-1, keepdim=True)
-        v = torch.matmul(self.pose_all[img_idx, None, :3, :3], v[:, :, None]).squeeze(-1)
-        o = self.pose_all[img_idx, None, :3, 3].expand(v.shape)
-        return torch.cat([o, v, color, mask[:, :1]], dim=-1)
+        if pixels is None:
+            px = torch.randint(low=0, high=self.W, size=[batch_size], device=self.device)
+            py = torch.randint(low=0, high=self.H, size=[batch_size], device=self.device)
+        else:
+            px, py = pixels
+        return ops.gen_random_rays(self.intrinsics_all_inv[img_idx].contiguous(), self.pose_all[img_idx].contiguous(),
+                                   self.images[img_idx], self.masks[img_idx], px, py)
 
     @staticmethod
     def near_far_from_sphere(rays_o, rays_d):

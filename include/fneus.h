@@ -263,6 +263,19 @@ int fneus_ray_setup(const float* rays_o, const float* rays_d, const float* near,
 /* section lengths and mid points of render_core (renderer.py:223-226) */
 int fneus_sections(const float* z, int n_rays, int n, float sample_dist, float* dists, float* mid_z, fneus_stream_t stream);
 
+/* ---- Ray generation (models/dataset.py:115-151): pixel -> K^-1 (x, y, 1) -> normalise -> R v; o = pose[:3, 3] ------------- */
+/* Dataset.gen_random_rays_at (dataset.py:133-151): the rays, colours and mask values of n integer pixels of ONE image.
+ * intrinsics_inv, pose: that image's [4][4] matrices (row major); image, mask: its float [H][W][3] planes (BGR / 256 as the
+ * reference's cv2 loader gives them, dataset.py:61-67); pixels_x / pixels_y: int64 [n] (torch.randint);
+ * out [n][10] = rays_o, rays_d, rgb, mask[..., :1].  Everything is device resident: no host copy per training step.   */
+int fneus_gen_random_rays(const float* intrinsics_inv, const float* pose, const float* image, const float* mask, int H, int W,
+                          const long long* pixels_x, const long long* pixels_y, int n_rays, float* out, fneus_stream_t stream);
+/* Dataset.gen_rays_at (dataset.py:115-131): all rays of one camera at pixel positions tx [nx] x ty [ny] (the caller's
+ * torch.linspace(0, W-1, W // l), linspace(0, H-1, H // l)) -> rays_o, rays_v [ny][nx][3] (image-row major, as returned
+ * by the reference after its transpose).                                                                              */
+int fneus_gen_rays_grid(const float* intrinsics_inv, const float* pose, const float* tx, const float* ty, int nx, int ny,
+                        float* rays_o, float* rays_v, fneus_stream_t stream);
+
 /* ---- Stage 2 (lvis.py): NeuSRenderer.lvis_render (renderer.py:567-627) and cal_indiLgt (calLvis.py:339-409) -------------- */
 /* First surface hit of every ray: idx = first sample with sign(sdf) = -1; sdf_mask = idx exists & idx >= 1 & the ray has a
  * sample inside the unit sphere (inside_mask [B] if given, else computed from the points); z_surf = zero crossing of the SDF

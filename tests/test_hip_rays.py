@@ -241,3 +241,33 @@ def test_upsample_bins_and_depths_vs_reference_trace(golden_dir, name):
     print(f"  {name}: {tot} new depths, {flips} drawn from a neighbouring bin (u on the bin edge), "
           f"{100.0 * within / tot:.2f} % within 1e-4 of the reference")
     assert within / tot >= 0.97
+
+
+def test_ray_generation_vs_reference(golden_dir):
+    """fneus_gen_rays_grid / fneus_gen_random_rays against Dataset.gen_rays_at / gen_random_rays_at /
+    near_far_from_sphere of the reference itself (dataset.py:115-151, 186-192; tests/golden/raygen_dtu.npz), through the
+    dataset class the runners use"""
+    import os
+    from models.dataset import SyntheticDataset
+    g = dict(np.load(os.path.join(golden_dir, "raygen_dtu.npz")))
+    dev = torch.device("cuda:0")
+    ds = SyntheticDataset(n_images=3, H=int(g["H"]), W=int(g["W"]), device=dev)
+    to = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
+    ds.intrinsics_all_inv, ds.pose_all = to(g["intrinsics_all_inv"]), to(g["pose_all"])      # the fixture's cameras and images
+    ds.images, ds.masks = to(g["images"]), to(g["masks"])
+    for lvl in (1, 4):
+        o, v = ds.gen_rays_at(1, resolution_level=lvl)
+        assert torch.equal(o.cpu(), torch.from_numpy(g[f"rays_at_l{lvl}/rays_o"]))
+        assert (v.cpu() - torch.from_numpy(g[f"rays_at_l{lvl}/rays_v"])).abs().max().item() <= 2e-7
+    for i in range(2):
+        px, py = to(g[f"random_{i}/pixels_x"]), to(g[f"random_{i}/pixels_y"])
+        out = ds.gen_random_rays_at(int(g[f"random_{i}/img_idx"]), len(px), pixels=(px, py))
+        ref = torch.from_numpy(g[f"random_{i}/out"])
+        assert torch.equal(out.cpu()[:, :3], ref[:, :3]) and torch.equal(out.cpu()[:, 6:], ref[:, 6:])     # origin, rgb, mask: copies
+        assert (out.cpu()[:, 3:6] - ref[:, 3:6]).abs().max().item() <= 2e-7
+        near, far = ds.near_far_from_sphere(out[:, :3], out[:, 3:6])
+        assert (near.cpu() - torch.from_numpy(g[f"random_{i}/near"])).abs().max().item() <= 2e-6
+        assert (far.cpu() - torch.from_numpy(g[f"random_{i}/far"])).abs().max().item() <= 2e-6
+    # drawing its own pixels: in range, unit directions
+    data = ds.gen_random_rays_at(0, 512)
+    assert data.shape == (512, 10) and torch.allclose(data[:, 3:6].norm(dim=-1), torch.ones(512, device=dev), atol=1e-5)

@@ -86,19 +86,24 @@ def test_load_K_Rt_from_P_roundtrip():
         assert np.allclose(pose[:3, :3], Rm.T, atol=1e-5) and np.allclose(pose[:3, 3], c, atol=1e-4)
 
 
-def test_synthetic_dataset_rays_cpu():
+def test_synthetic_dataset_cameras_cpu():
+    """the loaders hold images and cameras; rays come from the HIP kernels (tests/test_hip_rays.py).  Here: the camera
+    matrices of the synthetic scene through the oracle's ray generator, and the loud failure without a GPU device."""
     from models.dataset import SyntheticDataset
     from oracle import ref_torch as R
     ds = SyntheticDataset(n_images=3, H=24, W=32, device=torch.device("cpu"))
-    data = ds.gen_random_rays_at(1, 64)
+    px, py = torch.randint(0, 32, (64,)), torch.randint(0, 24, (64,))
+    data = R.gen_random_rays_at(ds.intrinsics_all_inv[1], ds.pose_all[1], ds.images[1], ds.masks[1], px, py)
     assert data.shape == (64, 10)
     assert torch.allclose(data[:, 3:6].norm(dim=-1), torch.ones(64), atol=1e-5)
     assert torch.allclose(data[:, :3].norm(dim=-1), torch.full((64,), 2.8), atol=1e-4)
     near, far = ds.near_far_from_sphere(data[:, :3], data[:, 3:6])
     n2, f2 = R.near_far_from_sphere(data[:, :3], data[:, 3:6])
     assert torch.equal(near, n2) and torch.equal(far, f2)
-    o, d = ds.gen_rays_at(0, resolution_level=4)
-    assert o.shape == (6, 8, 3) and d.shape == (6, 8, 3)
+    with pytest.raises(RuntimeError):
+        ds.gen_random_rays_at(1, 64)
+    with pytest.raises(RuntimeError):
+        ds.gen_rays_at(0, resolution_level=4)
 
 
 def test_stage1_loss_matches_oracle():
@@ -200,11 +205,11 @@ def test_dtu_format_dataset_reads_files_like_the_reference_loader(tmp_path):
     # cameras: world_mat @ scale_mat decomposes back into the unit-sphere intrinsics / poses
     assert torch.allclose(ds.intrinsics_all[:, :3, :3], src.intrinsics_all[:, :3, :3], atol=2e-3)
     assert torch.allclose(ds.pose_all, src.pose_all, atol=2e-4)
-    torch.manual_seed(0)
-    a = ds.gen_random_rays_at(1, 32)
-    torch.manual_seed(0)
-    b = src.gen_random_rays_at(1, 32)
+    from oracle import ref_torch as R
+    px, py = torch.randint(0, 32, (32,)), torch.randint(0, 24, (32,))
+    a = R.gen_random_rays_at(ds.intrinsics_all_inv[1], ds.pose_all[1], ds.images[1], ds.masks[1], px, py)
+    b = R.gen_random_rays_at(src.intrinsics_all_inv[1], src.pose_all[1], src.images[1], src.masks[1], px, py)
     assert torch.allclose(a[:, :6], b[:, :6], atol=3e-4)                       # same rays
     assert (a[:, 6:9] - b[:, 6:9]).abs().max().item() <= 1.0 / 256 + 1e-6 and torch.equal(a[:, 9] > 0.5, b[:, 9] > 0.5)
-    o, d = ds.gen_rays_at(2, resolution_level=4)
+    o, d = R.gen_rays_at(ds.intrinsics_all_inv[2], ds.pose_all[2], ds.H, ds.W, 4)
     assert o.shape == (6, 8, 3) and torch.allclose(d.norm(dim=-1), torch.ones(6, 8), atol=1e-5)
