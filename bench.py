@@ -237,7 +237,8 @@ def main():
                                "1xMI355X per rank", "rays_per_gpu": RAYS, "samples_per_ray": N_SAMPLES + N_IMPORTANCE,
                    "parallelism": f"dp{world} (ray-sharded replicas, one in-place all-reduce of the gradient arena)",
                    "launch": ("eager kernel launches" if not (tr.use_graph and tr._graphs) else
-                              "three hipGraph replays per step around the two collectives" if world > 1 else
+                              "four hipGraph replays per step around the three collectives (loss normalisers; early part of the gradient "
+                              "arena beside the SDF backward; late part)" if world > 1 else
                               "one hipGraph replay per step")},
         "mfma_roofline_frac_step": value / world * FLOP_TRAIN_PER_SAMPLE / (PEAK_BF16_MFMA_TFLOPS * 1e12),
     }

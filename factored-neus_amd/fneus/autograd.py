@@ -69,6 +69,11 @@ class SdfValueGradFn(torch.autograd.Function):
     def backward(ctx, d_sdf, d_feat, d_normal):
         n, prec, net, ws = ctx.n, ctx.prec, ctx.net, ctx.ws
         ws.check(ctx.stash, ctx.generation, "SDFNetwork backward")
+        # every consumer of sdf / feature / normal has run its backward by now: the gradients of the colour network, the
+        # RefColor heads and the variance are final.  The data-parallel trainer starts their exchange here, beside K3.
+        hook = getattr(ws, "pre_backward", None)
+        if hook is not None:
+            hook()
         dev = d_feat.device if d_feat is not None else (d_sdf.device if d_sdf is not None else d_normal.device)
         d_sdf = torch.zeros(n, device=dev) if d_sdf is None else d_sdf.contiguous()
         d_feat = torch.zeros(n, 256, device=dev) if d_feat is None else d_feat.contiguous()

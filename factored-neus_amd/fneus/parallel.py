@@ -76,7 +76,11 @@ class GradArena:
     gradient buffers into slices of it, the small torch modules get persistent `.grad` views: the data-parallel exchange
     is a single in-place all-reduce of `flat` with no gather / scatter copies, and the optimiser sees adjacent segments."""
 
-    def __init__(self, device, fused_modules, ref_color, small_modules):
+    def __init__(self, device, fused_modules, ref_color, small_modules, n_late: int = 0):
+        """n_late: the first n_late fused modules form the LATE part of the arena (their gradients are complete only at
+        the very end of the backward: the SDF network, the background NeRF); everything behind them -- colour network,
+        RefColor heads, small modules -- is final when the SDF backward starts and can be exchanged beside it
+        (allreduce_early / allreduce_late)."""
         sizes = [m.n_raw() for m in fused_modules] + (ref_color.n_raw() if ref_color is not None else [])
         small = [p for m in small_modules if m is not None for p in m.parameters()]
         total = sum(sizes) + sum(p.numel() for p in small)
@@ -95,6 +99,8 @@ class GradArena:
             off += p.numel()
         self.small = small
         self._small_views = [p.grad for p in small]
+        split = sum(sizes[:n_late])
+        self.late, self.early = self.flat[:split], self.flat[split:]
 
     def restore_small_grads(self):
         """something set a small parameter's .grad to None (or replaced it): point it back at its arena view"""
@@ -107,6 +113,34 @@ class GradArena:
     def allreduce_sum(self, group=None):
         if dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+
+    # ---- the exchange in two parts: `early` while the SDF backward still runs, `late` after it ----
+    def allreduce_early(self, side_stream, group=None):
+        """start the all-reduce of the early part on `side_stream`, ordered after everything issued so far on the current
+        stream; the current stream does NOT wait.  -> a handle for wait_early()."""
+        if not (dist.is_initialized() and dist.get_world_size(group) > 1) or self.early.numel() == 0:
+            return None
+        if not self.flat.is_cuda or side_stream is None:      # host tensors (gloo tests): nothing to overlap with
+            dist.all_reduce(self.early, op=dist.ReduceOp.SUM, group=group)
+            return None
+        side_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side_stream):      # RCCL's stream waits for the stream that is current at the call
+            work = dist.all_reduce(self.early, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        return work, side_stream
+
+    def allreduce_late(self, group=None):
+        if dist.is_initialized() and dist.get_world_size(group) > 1 and self.late.numel() > 0:
+            dist.all_reduce(self.late, op=dist.ReduceOp.SUM, group=group)
+
+    @staticmethod
+    def wait_early(handle):
+        """make the current stream wait for the early part's all-reduce"""
+        if handle is None:
+            return
+        work, side_stream = handle
+        with torch.cuda.stream(side_stream):
+            work.wait()
+        torch.cuda.current_stream().wait_stream(side_stream)
 
 
 def reduce_loss_norms(norms: torch.Tensor, group=None) -> torch.Tensor:

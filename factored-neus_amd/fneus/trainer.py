@@ -74,12 +74,21 @@ class Stage1Trainer:
         self.use_graph = bool(use_graph) and device.type == "cuda" and (
             not distributed or os.environ.get("FNEUS_DP_GRAPH", "1") != "0")
         self._capturing = None
+        self._in_dp_step = False
         self.reduce_norms = self._reduce_norms_hook if distributed else None
         # every gradient of the model lives in ONE arena: the fused MLPs accumulate into slices of it, the small torch
         # modules get persistent .grad views (autograd accumulates into them in place).  FlatAdam addresses parameters
         # and gradients by pointer and clears the gradients itself; data parallel = one in-place all-reduce of the arena.
-        fused = [self.sdf_network, self.color_network] + ([self.nerf_outside] if self.use_nerf else [])
-        self.grads = GradArena(device, fused, self.refColor_network, [self.deviation_network])
+        # arena order: [SDF | background NeRF] = the LATE part (final only when the backward ends), then colour network,
+        # RefColor heads, variance = the EARLY part (final when the SDF backward starts; exchanged beside it)
+        late = [self.sdf_network] + ([self.nerf_outside] if self.use_nerf else [])
+        self.grads = GradArena(device, late + [self.color_network], self.refColor_network, [self.deviation_network],
+                               n_late=len(late))
+        self.split_exchange = self.distributed and os.environ.get("FNEUS_DP_EARLY", "1") != "0"
+        self._xstream = torch.cuda.Stream(device=device) if (self.split_exchange and device.type == "cuda") else None
+        self._early = None           # handle of the early part's all-reduce of the step in flight
+        if self.split_exchange:
+            self.sdf_network._ws.pre_backward = self._early_exchange
         self.optimizer = FlatAdam(self.params, lr=lr)
         self._graphs = {}            # (batch shape, background shape) -> (graph(s), static input, static background, losses)
         self._cos = torch.ones(1, dtype=torch.float32, device=device)    # cos_anneal_ratio of the replayed step
@@ -121,11 +130,17 @@ class Stage1Trainer:
         if static_bg is not None:
             static_bg.copy_(background_rgb)
         if self.distributed:
-            g1, g2, g3, norms = graph
+            g1, g2, g2b, g3, norms = graph
             g1.replay()                      # packs, sampler, K2, colour, compositing, surface gather, RefColor, batch sums
             reduce_loss_norms(norms)         # in place on the static buffer that the loss kernel of g2 reads
-            g2.replay()                      # losses + the whole backward
-            self.bucket.allreduce_sum()
+            g2.replay()                      # losses + the backward (with the split exchange: up to the SDF backward)
+            if g2b is not None:
+                early = self.grads.allreduce_early(self._xstream)     # colour / RefColor / variance gradients: beside ...
+                g2b.replay()                 # ... the SDF backward (K3, its weight-gradient GEMM, weight-norm backward)
+                self.grads.allreduce_late()
+                self.grads.wait_early(early)
+            else:
+                self.bucket.allreduce_sum()
             g3.replay()                      # Adam
         else:
             graph.replay()
@@ -147,6 +162,23 @@ class Stage1Trainer:
         st["open"] = st["g2"]
         return norms
 
+    def _early_exchange(self):
+        """called when the SDF backward starts (fneus/autograd.py SdfValueGradFn.backward): the gradients of every other
+        network are final.  Eager step: start their all-reduce on the exchange stream.  While _capture_dp records a step:
+        the second graph ends here and the third (the SDF backward) begins."""
+        st = self._capturing
+        if st is None:
+            if self._in_dp_step:
+                self._early = self.grads.allreduce_early(self._xstream)
+            return
+        st["g2"].capture_end()
+        st["open"] = None
+        h = self.grads.allreduce_early(self._xstream)      # eager, on meaningless values (see _capture_dp)
+        self.grads.wait_early(h)
+        st["n_coll"] += 1
+        st["g2b"].capture_begin(pool=st["pool"], capture_error_mode="thread_local")
+        st["open"] = st["g2b"]
+
     def _capture_dp(self, data: torch.Tensor, background_rgb):
         """data parallel: three graphs per step with the two collectives between them.  Returns None when the capture
         fails ON ANY RANK (every rank then stays on eager launches).  The outcome is collective: whatever happens, every
@@ -159,7 +191,10 @@ class Stage1Trainer:
         gc.collect()
         torch.cuda.synchronize()
         g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        st = {"g1": g1, "g2": g2, "pool": torch.cuda.graph_pool_handle(), "open": None, "norms": None, "n_coll": 0}
+        g2b = torch.cuda.CUDAGraph() if self.split_exchange else None
+        st = {"g1": g1, "g2": g2, "g2b": g2b, "pool": torch.cuda.graph_pool_handle(), "open": None, "norms": None, "n_coll": 0}
+        last = g2b if self.split_exchange else g2      # the graph that must be open when the backward has been recorded
+        n_expected = 3 if self.split_exchange else 2
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         ok, losses = False, None
@@ -171,11 +206,15 @@ class Stage1Trainer:
                 self._capturing = st
                 losses = self._step_body(static_data, self._cos, static_bg, with_optimizer=False)
                 self._capturing = None
-                if st["open"] is not g2:
-                    raise RuntimeError("the step did not reach the loss-normaliser exchange")
-                g2.capture_end()
+                if st["open"] is not last:
+                    raise RuntimeError("the step did not reach the loss-normaliser exchange" if st["open"] is g1 else
+                                       "the step did not reach the SDF backward")
+                last.capture_end()
                 st["open"] = None
-                self.bucket.allreduce_sum()          # eager, like the exchange above
+                if self.split_exchange:              # eager, like the exchanges above
+                    self.grads.allreduce_late()
+                else:
+                    self.bucket.allreduce_sum()
                 st["n_coll"] += 1
                 g3.capture_begin(pool=st["pool"], capture_error_mode="thread_local")
                 st["open"] = g3
@@ -200,7 +239,12 @@ class Stage1Trainer:
         import torch.distributed as dist
         if st["n_coll"] < 1:
             reduce_loss_norms(torch.zeros(4, dtype=torch.float32, device=self.device))
-        if st["n_coll"] < 2:
+        if self.split_exchange:
+            if st["n_coll"] < 2:
+                self.grads.wait_early(self.grads.allreduce_early(self._xstream))
+            if st["n_coll"] < 3:
+                self.grads.allreduce_late()
+        elif st["n_coll"] < 2:
             self.bucket.allreduce_sum()
         flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float32, device=self.device)
         if dist.is_initialized() and dist.get_world_size() > 1:
@@ -213,7 +257,7 @@ class Stage1Trainer:
             self.use_graph = False
             self.grads.flat.zero_()          # (the dummy exchanges may have summed a failing rank's partial gradients)
             return None
-        return (g1, g2, g3, st["norms"]), static_data, static_bg, losses
+        return (g1, g2, g2b, g3, st["norms"]), static_data, static_bg, losses
 
     def _capture(self, data: torch.Tensor, background_rgb):
         import gc
@@ -227,8 +271,14 @@ class Stage1Trainer:
         return graph, static_data, static_bg, losses
 
     def _eager_step(self, data, cos_anneal_ratio, background_rgb):
+        self._in_dp_step, self._early = self.split_exchange, None
         losses = self._step_body(data, cos_anneal_ratio, background_rgb, with_optimizer=False)
-        if self.bucket is not None:
+        self._in_dp_step = False
+        if self.split_exchange:              # the early part has been on its way since the SDF backward started
+            self.grads.allreduce_late()
+            self.grads.wait_early(self._early)
+            self._early = None
+        elif self.bucket is not None:
             self.bucket.allreduce_sum()      # losses are normalised by the GLOBAL batch: the rank gradients just add up
         self.optimizer.step()
         self.iter_step += 1

@@ -153,6 +153,29 @@ def _dp_worker(rank, world, port, q):
     arena.allreduce_sum()
     for p2, p in zip(net2.parameters(), net.parameters()):
         assert torch.allclose(p2.grad, p.grad, atol=1e-6)
+    # the exchange in two parts (early part beside the SDF backward, late part after it) sums the same arena
+
+    class _Fused(torch.nn.Module):       # stands in for a fused MLP: its gradient buffer is a slice of the arena
+        def __init__(self, n):
+            super().__init__()
+            self.n = n
+
+        def n_raw(self):
+            return self.n
+
+        def use_grad_buffer(self, buf):
+            self.buf = buf
+
+    late_m, early_m = _Fused(11), _Fused(5)
+    arena2 = GradArena(torch.device("cpu"), [late_m, early_m], None, [net2], n_late=1)
+    assert arena2.late.numel() == 11 and arena2.early.numel() == arena2.flat.numel() - 11
+    arena2.flat.copy_(torch.arange(arena2.flat.numel(), dtype=torch.float32) * (rank + 1))
+    want = torch.arange(arena2.flat.numel(), dtype=torch.float32) * 3.0          # ranks 0 and 1: x1 + x2
+    h = arena2.allreduce_early(None)
+    assert torch.equal(arena2.early, want[11:]) and not torch.equal(arena2.late, want[:11])
+    arena2.allreduce_late()
+    arena2.wait_early(h)
+    assert torch.equal(arena2.flat, want)
     # by value (numpy), not shared-memory tensor handles: the worker may exit before the parent reads the queue
     q.put((rank, [p.detach().numpy().copy() for p in net.parameters()], [g.numpy().copy() for g in local], mean,
            [p.grad.numpy().copy() for p in net.parameters()], norms.numpy().copy()))

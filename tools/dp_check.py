@@ -17,7 +17,7 @@ from fneus.trainer import Stage1Trainer, synthetic_batches, WMASK_MODEL
 rank, world, _ = init_from_env("gloo")
 dev = torch.device("cuda:0")
 torch.cuda.set_device(0)
-use_graph = os.environ.get("DP_CHECK_GRAPH", "0") == "1"      # three hipGraphs per step around the two collectives
+use_graph = os.environ.get("DP_CHECK_GRAPH", "0") == "1"      # four hipGraphs per step around the three collectives
 import copy
 conf = copy.deepcopy(WMASK_MODEL)
 conf["neus_renderer"]["perturb"] = 0.0                         # no depth jitter: eager and replayed runs draw it differently
