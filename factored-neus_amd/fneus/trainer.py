@@ -158,7 +158,9 @@ class Stage1Trainer:
         st["norms"] = norms
         reduce_loss_norms(norms)             # eager: nothing recorded has run yet, the values are meaningless, but every
         st["n_coll"] += 1                    # rank issues the same collectives
-        st["g2"].capture_begin(pool=st["pool"], capture_error_mode="thread_local")
+        # with the split exchange this graph is ended by _early_exchange ON THE AUTOGRAD ENGINE'S THREAD (the hook runs
+        # inside the backward): only a relaxed-mode capture may be ended from another thread
+        st["g2"].capture_begin(pool=st["pool"], capture_error_mode="relaxed" if self.split_exchange else "thread_local")
         st["open"] = st["g2"]
         return norms
 
@@ -176,7 +178,7 @@ class Stage1Trainer:
         h = self.grads.allreduce_early(self._xstream)      # eager, on meaningless values (see _capture_dp)
         self.grads.wait_early(h)
         st["n_coll"] += 1
-        st["g2b"].capture_begin(pool=st["pool"], capture_error_mode="thread_local")
+        st["g2b"].capture_begin(pool=st["pool"], capture_error_mode="relaxed")    # begun on the autograd thread, ended on the caller's
         st["open"] = st["g2b"]
 
     def _capture_dp(self, data: torch.Tensor, background_rgb):
