@@ -44,16 +44,16 @@ KERNEL_FLOPS = {
 }
 PEAK_BF16_MFMA_TFLOPS = 2500.0       # MI355X dense bf16 (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0                # HBM3E (MI355X_MICROARCH.md)
-# Algorithmic HBM bytes per sample of the fragment-plane design in parity mode with bf16 gradient planes (DESIGN.md
-# section 4): what a launch must move even with perfect caching.  One 256-wide bf16 plane = 512 B / sample, the sigma'
-# plane (u16 fixed point) 512 B per layer.
-#   K2 writes  h hi 8 x 512, a hi + lo 2 x 8 x 512, sigma' 8 x 512, feature plane 512, PE plane 128, fp32 feature 1024,
-#              sdf + normal 16; reads 12 B of ray data
-#   K3 reads   sigma' 8 x 512, a hi + lo 2 x 8 x 512, d_feat fp32 1024, cotangents 16, the coupling planes it wrote
-#              (hi + lo 2 x 8 x 512); writes the coupling planes 2 x 8 x 512, adj hi 8 x 512, zbar hi 9 x 512, qbar 128
+# Algorithmic HBM bytes per sample of the fragment-plane design in parity mode with bf16 gradient planes (the default,
+# gprec 1): what a launch must move even with perfect caching.  One 256-wide bf16 plane = 512 B per
+# sample and layer, the sigma' plane (u16 fixed point) likewise.
+#   K2 writes  h 8 x 512, a 8 x 512, sigma' 8 x 512, feature plane 512, PE plane 128, fp32 feature 1024, sdf + normal 16;
+#      reads   sigma' back once for its reverse sweep 8 x 512, 12 B of ray data
+#   K3 reads   sigma' twice (ascending + descending chain) 2 x 8 x 512, a 8 x 512, the coupling planes it wrote 8 x 512,
+#              d_feat fp32 1024, cotangents 16;  writes the coupling planes 8 x 512, adj 8 x 512, zbar 9 x 512, qbar 128
 KERNEL_BYTES_PARITY = {
-    "fneus_sdf_fwd_grad": (8 * 512 + 2 * 8 * 512 + 8 * 512 + 512 + 128 + 1024 + 16 + 12) * SAMPLES_PER_STEP,
-    "fneus_sdf_bwd": (8 * 512 + 2 * 8 * 512 + 1024 + 16 + 2 * 8 * 512 + 2 * 8 * 512 + 8 * 512 + 9 * 512 + 128) * SAMPLES_PER_STEP,
+    "fneus_sdf_fwd_grad": (3 * 8 * 512 + 512 + 128 + 1024 + 16 + 8 * 512 + 12) * SAMPLES_PER_STEP,
+    "fneus_sdf_bwd": (2 * 8 * 512 + 8 * 512 + 8 * 512 + 1024 + 16 + 8 * 512 + 8 * 512 + 9 * 512 + 128) * SAMPLES_PER_STEP,
 }
 
 
