@@ -130,6 +130,38 @@ def indilgt_state_dict(seed: int = 5) -> "OrderedDict[str, np.ndarray]":
     return _sequential_state_dict(np.random.RandomState(seed), "indi", INDI_DIMS, last_gain=6.0)
 
 
+def fibonacci_sphere(samples: int) -> np.ndarray:
+    """inverRender.py:69-82: golden-angle spiral, y from 1 to -1"""
+    i = np.arange(samples, dtype=np.float64)
+    y = 1.0 - (i / float(samples - 1)) * 2.0
+    radius = np.sqrt(1.0 - y * y)
+    theta = np.pi * (3.0 - np.sqrt(5.0)) * i
+    return np.stack([np.cos(theta) * radius, y, np.sin(theta) * radius], axis=1)
+
+
+def mateillu_state_dict(seed: int = 6, num_lgt_sgs: int = 128) -> "OrderedDict[str, np.ndarray]":
+    """EnvmapMaterialNetwork (inverRender.py:451-528): lgtSGs [128,7] following the reference's initialisation recipe
+    (grey amplitudes, sharpness 10 + 20 |N|, envmap energy normalised to 0.8 * 2 pi, lobes on two Fibonacci spheres), then
+    brdf_encoder_layer.{0,..,8} (63 -> 512 x 4 -> 32), brdf_decoder_layer.{0,2,4} (32 -> 128 x 2 -> 4), net_cs.{0,..,8}
+    (90 -> 256 x 4 -> 1) in the module's state_dict order."""
+    rs = np.random.RandomState(seed)
+    sg = rs.standard_normal((num_lgt_sgs, 7))
+    sg[:, -2:] = sg[:, -3:-2]
+    sg[:, 3:4] = 10.0 + np.abs(sg[:, 3:4] * 20.0)
+    lam, mu = np.abs(sg[:, 3:4]), np.abs(sg[:, 4:])
+    energy = mu * 2.0 * np.pi / lam * (1.0 - np.exp(-2.0 * lam))
+    sg[:, 4:] = np.abs(sg[:, 4:]) / energy.sum(axis=0, keepdims=True) * 2.0 * np.pi * 0.8
+    lobes = fibonacci_sphere(num_lgt_sgs // 2)
+    sg[: num_lgt_sgs // 2, :3] = lobes
+    sg[num_lgt_sgs // 2:, :3] = lobes
+    sd = OrderedDict()
+    sd["lgtSGs"] = _f32(sg)
+    sd.update(_sequential_state_dict(rs, "brdf_encoder_layer", [63, 512, 512, 512, 512, 32], last_gain=3.0))
+    sd.update(_sequential_state_dict(rs, "brdf_decoder_layer", [32, 128, 128, 4], last_gain=6.0))
+    sd.update(_sequential_state_dict(rs, "net_cs", [90, 256, 256, 256, 256, 1], last_gain=6.0))
+    return sd
+
+
 def nerf_state_dict(seed: int = 3, D=8, W=256, input_ch=84, input_ch_view=27) -> "OrderedDict[str, np.ndarray]":
     """NeRF (fields.py:178-231) with use_viewdirs=True, skips=[4]."""
     rs = np.random.RandomState(seed)

@@ -834,3 +834,219 @@ def stage2_loss(out: dict):
     err = (out["gt_trace_radiance"] - out["pre_trace_radiance"]) * m[:, None, None]
     radiance_loss = err.abs().sum() / (m[:, None, None].expand(-1, 4, 3).sum() + 1e-6)
     return {"loss": lvis_loss + radiance_loss, "lvis_loss": lvis_loss, "trace_radiance_loss": radiance_loss}
+
+
+# ======================================================================================
+# Stage 3 (mateIllu.py): material / illumination estimation with spherical Gaussians (models/inverRender.py)
+# ======================================================================================
+SG_TINY = 1e-6                      # inverRender.py:12
+
+
+def srgb_to_linear(srgb):
+    """math_utils.py:147-152"""
+    eps = torch.finfo(torch.float32).eps
+    low = 25.0 / 323.0 * srgb
+    high = torch.clamp((200.0 * srgb + 11.0) / 211.0, min=eps) ** (12.0 / 5.0)
+    return torch.where(srgb <= 0.04045, low, high)
+
+
+def _unit_tiny(v):
+    """inverRender.py:57-58 norm_axis"""
+    return v / (torch.linalg.norm(v, dim=-1, keepdim=True) + SG_TINY)
+
+
+def leaky_mlp(x, sd: Dict[str, torch.Tensor], prefix: str, n_lin: int, slope: float = 0.2):
+    """nn.Sequential(Linear, LeakyReLU(0.2), ..., Linear) (inverRender.py:473-507)"""
+    for i in range(n_lin):
+        x = x @ sd[f"{prefix}.{2 * i}.weight"].t() + sd[f"{prefix}.{2 * i}.bias"]
+        if i < n_lin - 1:
+            x = F.leaky_relu(x, slope)
+    return x
+
+
+def sg_lambda_trick(lobe1, lam1, mu1, lobe2, lam2, mu2):
+    """product of two spherical Gaussians, assuming lam1 << lam2 (inverRender.py:83-103)"""
+    ratio = lam1 / (lam2 + SG_TINY)
+    lobe1, lobe2 = _unit_tiny(lobe1), _unit_tiny(lobe2)
+    dot = (lobe1 * lobe2).sum(-1, keepdim=True)
+    t = torch.sqrt(ratio * ratio + 1.0 + 2.0 * ratio * dot + SG_TINY)
+    t = torch.minimum(t, ratio + 1.0)
+    lam3 = lam2 * t
+    lobes = (ratio / (t + SG_TINY)) * lobe1 + (1.0 / (t + SG_TINY)) * lobe2
+    mus = mu1 * mu2 * torch.exp(lam2 * (t - ratio - 1.0))
+    return lobes, lam3, mus
+
+
+def sg_hemisphere_int(lam, cos_beta):
+    """integral of a spherical Gaussian over the hemisphere around the normal (inverRender.py:106-125)"""
+    lam = torch.clamp(lam, min=SG_TINY)
+    inv = 1.0 / (lam + SG_TINY)
+    t = torch.sqrt(lam + SG_TINY) * (1.6988 + 10.8438 * inv) / (1.0 + 6.2201 * inv + 10.2415 * inv * inv + SG_TINY)
+    inv_a = torch.exp(-t)
+    up = (cos_beta >= 0).to(lam.dtype)
+    inv_b = torch.exp(-t * torch.clamp(cos_beta, min=0.0))
+    s1 = (1.0 - inv_a * inv_b) / (1.0 - inv_a + inv_b - inv_a * inv_b + SG_TINY)
+    b = torch.exp(t * torch.clamp(cos_beta, max=0.0))
+    s2 = (b - inv_a) / ((1.0 - inv_a) * (b + 1.0) + SG_TINY)
+    s = up * s1 + (1.0 - up) * s2
+    a_b = 2.0 * math.pi / lam * (torch.exp(-lam) - torch.exp(-2.0 * lam))
+    a_u = 2.0 * math.pi / lam * (1.0 - torch.exp(-lam))
+    return a_b * (1.0 - s) + a_u * s
+
+
+def sg_integrate_rgb(normal, lobes, lams, mus):
+    """sum over the lobes of the hemispherical integral of SG x clamped cosine (inverRender.py:264-283)"""
+    mu_cos, lam_cos, alpha_cos = 32.7080, 0.0315, 31.7003
+    lobe_p, lam_p, mu_p = sg_lambda_trick(normal, lam_cos, mu_cos, lobes, lams, mus)
+    dot1 = torch.clamp((lobe_p * normal).sum(-1, keepdim=True), min=0.0)
+    dot2 = torch.clamp((lobes * normal).sum(-1, keepdim=True), min=0.0)
+    rgb = mu_p * sg_hemisphere_int(lam_p, dot1) - mus * alpha_cos * sg_hemisphere_int(lams, dot2)
+    return torch.clamp(rgb.sum(dim=-2), min=0.0, max=1.0)
+
+
+def diffuse_visibility(points, normals, lvis_sd, lobes, lams, u_theta, u_phi):
+    """per-lobe light visibility from the distilled Lvis network (inverRender.py:128-192).  lobes [M,3], lams [M,1] of the
+    direct-light SGs; u_theta, u_phi [M,S]: the uniform draws of :152-153.  -> [M, n]"""
+    M, S = u_theta.shape
+    n = points.shape[0]
+    axis = _unit_tiny(lobes.detach()[:, None, :])                         # [M,1,3]
+    z = torch.zeros_like(axis)
+    z[..., 2] = 1.0
+    U = _unit_tiny(torch.linalg.cross(z, axis, dim=-1))
+    V = _unit_tiny(torch.linalg.cross(axis, U, dim=-1))
+    sharp = lams.detach()[:, None, :][:, :, 0]                            # [M,1]
+    phi_range = torch.arccos((-1.95 * sharp.min()) / sharp + 1.0)
+    th = (u_theta * 2 * math.pi)[..., None]
+    ph = (u_phi * phi_range)[..., None]
+    dirs = U * torch.cos(th) * torch.sin(ph) + V * torch.sin(th) * torch.sin(ph) + axis * torch.cos(ph)      # [M,S,3]
+    flat = dirs.reshape(-1, 3)
+    d_all = flat[None, :, :].expand(n, -1, 3)
+    p_all = points[:, None, :].expand(-1, M * S, 3)
+    front = (normals[:, None, :] * d_all).sum(-1) > SG_TINY
+    vis = torch.zeros(n, M * S, dtype=points.dtype)
+    with torch.no_grad():
+        vis[front] = lvis_forward(p_all[front], d_all[front], lvis_sd).reshape(-1)
+    vis = vis.reshape(n, M, S).permute(1, 2, 0)                           # [M,S,n]
+    w = torch.exp(lams.detach()[:, None, :] * ((dirs * axis).sum(-1, keepdim=True) - 1.0))       # [M,S,1]
+    return ((vis * w).sum(dim=1) / (w.sum(dim=1) + SG_TINY)).detach()
+
+
+def render_with_sg(points, normal, viewdirs, lgtSGs, specular_reflectance, specular_albedo, roughness, diffuse_albedo,
+                   light_vis=None):
+    """inverRender.py:314-449.  lgtSGs [n,M,7]; light_vis [M,n] or None (comp_vis=False)
+    -> linear env_rgb, tone-mapped diffuse / specular, mean visibility"""
+    n, M = lgtSGs.shape[0], lgtSGs.shape[1]
+    lobes = lgtSGs[..., :3] / (torch.linalg.norm(lgtSGs[..., :3], dim=-1, keepdim=True) + SG_TINY)
+    lams = torch.abs(lgtSGs[..., 3:4])
+    mus0 = torch.abs(lgtSGs[..., -3:])
+    nrm = normal[:, None, :].expand(n, M, 3)
+    view = viewdirs[:, None, :].expand(n, M, 3).detach()
+    # normal-distribution function as an SG around the normal, warped to the reflected direction
+    inv_r4 = 2.0 / (roughness * roughness * roughness * roughness)        # [n,1]
+    brdf_lam = inv_r4[:, None, :].expand(n, M, 1)
+    brdf_mu = (inv_r4 / math.pi).expand(n, 3)[:, None, :].expand(n, M, 3)
+    v_dot_lobe = torch.clamp((nrm * view).sum(-1, keepdim=True), min=0.0)
+    warp_lobes = 2 * v_dot_lobe * nrm - view
+    warp_lobes = warp_lobes / (torch.linalg.norm(warp_lobes, dim=-1, keepdim=True) + SG_TINY)
+    warp_lams = brdf_lam / (4 * v_dot_lobe + SG_TINY)
+    half = warp_lobes + view
+    half = half / (torch.linalg.norm(half, dim=-1, keepdim=True) + SG_TINY)
+    v_dot_h = torch.clamp((view * half).sum(-1, keepdim=True), min=0.0)
+    f0 = specular_reflectance[:, None, :].expand(n, M, 3)
+    fresnel = f0 + (1.0 - f0) * torch.pow(2.0, -(5.55473 * v_dot_h + 6.8316) * v_dot_h)
+    dot1 = torch.clamp((warp_lobes * nrm).sum(-1, keepdim=True), min=0.0)
+    dot2 = torch.clamp((view * nrm).sum(-1, keepdim=True), min=0.0)
+    k = ((roughness + 1.0) * (roughness + 1.0) / 8.0)[:, None, :].expand(n, M, 1)
+    g1 = dot1 / (dot1 * (1 - k) + k + SG_TINY)
+    g2 = dot2 / (dot2 * (1 - k) + k + SG_TINY)
+    moi = fresnel * (g1 * g2) / (4 * dot1 * dot2 + SG_TINY)
+    warp_mus = specular_albedo[:, None, :] * brdf_mu * moi
+    shadow = torch.zeros(n, 3, dtype=points.dtype)
+    if light_vis is not None:
+        vis = light_vis.permute(1, 0)[..., None].expand(n, M, 3)
+        mus = mus0 * vis
+        shadow = vis.mean(dim=1)
+    else:
+        mus = mus0
+    # specular: (light SG x BRDF SG) x cosine
+    fl, fla, fmu = sg_lambda_trick(lobes, lams, mus, warp_lobes, warp_lams, warp_mus)
+    specular = sg_integrate_rgb(nrm, fl, fla, fmu)
+    # diffuse: light SG x albedo / pi x cosine
+    diffuse = sg_integrate_rgb(nrm, lobes, lams, mus * (diffuse_albedo / math.pi)[:, None, :].expand(n, M, 3))
+    return {"env_rgb": torch.clamp(specular + diffuse, 0.0, 1.0),
+            "diffuse_rgb": torch.clip(linear_to_srgb(diffuse), 0.0, 1.0),
+            "specular_rgb": torch.clip(linear_to_srgb(specular), 0.0, 1.0), "lvis_mean": shadow}
+
+
+def envmap_material_forward(points, ray_dirs, n, indi_lgt, lvis_sd, mat_sd, u_theta, u_phi, specular_reflectance: float = 0.02):
+    """EnvmapMaterialNetwork.forward (inverRender.py:530-598) + render_with_all_sg (:286-311)"""
+    n = n / (torch.linalg.norm(n, dim=-1, keepdim=True) + SG_TINY)
+    ray_dirs = ray_dirs / (torch.linalg.norm(ray_dirs, dim=-1, keepdim=True) + SG_TINY)
+    view = -ray_dirs
+    pts_enc = embed(points, 10)
+    latent_pre = leaky_mlp(pts_enc, mat_sd, "brdf_encoder_layer", 5)
+    brdf = torch.sigmoid(leaky_mlp(torch.sigmoid(latent_pre), mat_sd, "brdf_decoder_layer", 3))
+    roughness = brdf[..., 3:] * 0.9 + 0.09
+    diffuse_albedo = brdf[..., :3]
+    # sparsity of the latent code: KL(0.05 || mean sigmoid)  (inverRender.py:553-559, 609-612)
+    rho, rho_hat = 0.05, torch.sigmoid(latent_pre).mean(0)
+    kl = (rho * torch.log(rho / rho_hat) + (1 - rho) * torch.log((1 - rho) / (1 - rho_hat))).mean()
+    spec_in = torch.cat([pts_enc, embed(reflect(view, n), 4)], dim=-1)
+    specular_albedo = torch.sigmoid(leaky_mlp(spec_in, mat_sd, "net_cs", 5)).repeat(1, 3)
+    lgt = mat_sd["lgtSGs"]
+    f0 = torch.full((1, 1), specular_reflectance, dtype=points.dtype)
+    direct_sgs = lgt[None].expand(points.shape[0], -1, -1)
+    lobes0 = direct_sgs[0, :, :3] / (torch.linalg.norm(direct_sgs[0, :, :3], dim=-1, keepdim=True) + SG_TINY)
+    vis = diffuse_visibility(points, n, lvis_sd, lobes0, torch.abs(direct_sgs[0, :, 3:4]), u_theta, u_phi)
+    ret = render_with_sg(points, n, view, direct_sgs, f0, specular_albedo, roughness, diffuse_albedo, light_vis=vis)
+    indir = render_with_sg(points, n, view, indi_lgt, f0, specular_albedo, roughness, diffuse_albedo)["env_rgb"]
+    env = ret["env_rgb"]
+    ret.update(rgb=torch.clip(linear_to_srgb(env + indir), 0.0, 1.0), indir_rgb=torch.clip(linear_to_srgb(indir), 0.0, 1.0),
+               env_rgb=torch.clip(linear_to_srgb(env), 0.0, 1.0), roughness=roughness,
+               diffuse_albedo=torch.clip(linear_to_srgb(diffuse_albedo), 0.0, 1.0),
+               specular_albedo=torch.clip(linear_to_srgb(specular_albedo), 0.0, 1.0), encoder_loss=0.01 * kl, light_vis=vis)
+    return ret
+
+
+def mateIllu_render(rays_o, rays_d, near, far, sdf_p, refcolor_sd, lvis_sd, indi_sd, mat_sd, n_samples: int, n_importance: int,
+                    u_theta, u_phi, up_sample_steps: int = 4):
+    """NeuSRenderer.mateIllu_render (renderer.py:630-726); rows outside sdf_mask keep the value 1"""
+    B = rays_o.shape[0]
+    with torch.no_grad():
+        util = lvis_mateIllu_render_util(rays_o, rays_d, near, far, sdf_p, n_samples, n_importance, up_sample_steps)
+        n = util["n_samples"]
+        mask, z_surf = first_hit(util["sdf"].reshape(B, n), util["mid_z_vals"], util["inside_sphere_mask"])
+    one3 = lambda: torch.ones(B, 3, dtype=rays_o.dtype)
+    out = {k: one3() for k in ("rgb", "env_rgb", "indir_rgb", "diffuse_albedo", "specular_albedo", "diffuse_rgb", "specular_rgb",
+                               "lvis_mean", "n_out", "gt_specular_linear", "gt_diffuse_srgb")}
+    out["roughness"] = torch.ones(B, 1, dtype=rays_o.dtype)
+    out.update(sdf_mask=mask, encoder_loss=torch.zeros(()), diffuse_loss=0, specular_loss=0, smooth_loss=0)
+    if mask.any():
+        pts = rays_o[mask] + rays_d[mask] * z_surf[mask][:, None]
+        with torch.no_grad():
+            _, feat, n_surf, _ = sdf_value_feature_normal(pts, sdf_p)
+            rc = refcolor_forward(pts, feat, rays_d[mask], n_surf, refcolor_sd)
+            spec_lin = srgb_to_linear(rc["specular_rgb"])
+            indi = indirect_light_forward(pts, indi_sd)
+        m = envmap_material_forward(pts, rays_d[mask], n_surf, indi, lvis_sd, mat_sd, u_theta, u_phi)
+        for k in ("rgb", "env_rgb", "indir_rgb", "diffuse_albedo", "specular_albedo", "diffuse_rgb", "specular_rgb", "roughness",
+                  "lvis_mean"):
+            full = out[k].clone()
+            full[mask] = m[k].to(full.dtype)
+            out[k] = full
+        for k, v in (("gt_specular_linear", spec_lin), ("gt_diffuse_srgb", rc["diffuse_rgb"]), ("n_out", n_surf)):
+            full = out[k].clone()
+            full[mask] = v
+            out[k] = full
+        out["encoder_loss"] = m["encoder_loss"]
+        out["_light_vis"] = m["light_vis"]
+    return out
+
+
+def stage3_loss(out: dict, true_rgb, mask):
+    """mateIllu.py:152-172: masked L1 colour over the rays that hit + the latent sparsity term"""
+    m = out["sdf_mask"]
+    denom = mask[m].sum() + 1e-5
+    rgb_loss = ((out["rgb"][m] - true_rgb[m]) * mask[m]).abs().sum() / denom
+    psnr = 20.0 * torch.log10(1.0 / (((out["rgb"][m] - true_rgb[m]) ** 2 * mask[m]).sum() / (denom * 3.0)).sqrt())
+    return {"loss": rgb_loss + out["encoder_loss"], "rgb_loss": rgb_loss, "encoder_loss": out["encoder_loss"], "psnr": psnr}

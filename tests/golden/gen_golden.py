@@ -418,6 +418,90 @@ def gen_lvis_render(fields, renderer, out_dir, name, B, n_samples, n_importance,
           "gt_lvis mean", float(res["out/gt_lvis"][res["out/sdf_mask"]].mean()))
 
 
+def gen_mateillu_render(fields, renderer, out_dir, name, B, n_samples, n_importance, ray_seed, seeds, adam_steps=3):
+    """NeuSRenderer.mateIllu_render (renderer.py:630-726) -> EnvmapMaterialNetwork.forward (inverRender.py:530-598), the
+    stage-3 loss of mateIllu.py:152-172, its gradients on the material / illumination network and `adam_steps` optimiser
+    steps (mateIllu.py:91-95, 174-176).  The visibility sampler's two uniform draws (inverRender.py:152-153) are recorded."""
+    stage2_reference()                                          # the .cuda() shim
+    from models import inverRender
+    assert inverRender.__file__.startswith(REF + "/")
+    sdf, col, var, nerf, ref = build_nets(fields, seeds)
+    lvis, indi = fields.Lvis(), fields.IndirectLight()
+    lvis(torch.zeros(2, 3), torch.ones(2, 3))
+    indi(torch.zeros(2, 3))
+    lvis.load_state_dict(to_t(synth.lvis_state_dict(seeds["lvis"])))
+    indi.load_state_dict(to_t(synth.indilgt_state_dict(seeds["indilgt"])))
+    mat = inverRender.EnvmapMaterialNetwork()
+    mat.net_cs(torch.zeros(2, 90))                              # materialise the LazyLinear
+    mat.load_state_dict(to_t(synth.mateillu_state_dict(seeds["mateillu"])))
+    data = torch.from_numpy(synth.ray_batch(B, seed=ray_seed, n_miss=3))
+    rays_o, rays_d, true_rgb, mask_in = data[:, :3], data[:, 3:6], data[:, 6:9], data[:, 9:10]
+    a = (rays_d ** 2).sum(-1, keepdim=True)
+    b = 2.0 * (rays_o * rays_d).sum(-1, keepdim=True)
+    mid = 0.5 * (-b) / a
+    near, far = mid - 1.0, mid + 1.0
+    rnd = renderer.NeuSRenderer(n_samples, n_importance, 0, 4, 1.0, nerf=nerf, sdf_network=sdf, deviation_network=var,
+                                color_network=col, refColor_network=ref, lvis_network=lvis, indiLgt_network=indi,
+                                mateIllu_network=mat)
+    params = list(mat.parameters())
+    names = [k for k, _ in mat.named_parameters()]
+    opt = torch.optim.Adam(params, lr=5e-4)
+    res = {"data": data.numpy(), "B": B, "n_samples": n_samples, "n_importance": n_importance, "ray_seed": ray_seed,
+           "lr": 5e-4, "mask_weight": 0.1, **{"seed_" + k: v for k, v in seeds.items()}}
+    mask = (mask_in > 0.5).float()                              # mateIllu.py:143-146 with train.mask_weight = 0.1
+    real_rand = torch.rand
+    glob = inverRender.render_with_sg.__globals__
+    real_vis = glob["get_diffuse_visibility"]
+    for step in range(adam_steps):
+        draws, trace = [], {}
+
+        def rand_hook(*a_, **k_):
+            r = real_rand(*a_, **k_)
+            draws.append(r.clone())
+            return r
+
+        def vis_hook(*a_, **k_):
+            v = real_vis(*a_, **k_)
+            trace["light_vis"] = v.clone()
+            return v
+
+        glob["get_diffuse_visibility"] = vis_hook
+        torch.rand = rand_hook
+        torch.manual_seed(2000 + step)
+        try:
+            out = rnd.mateIllu_render(rays_o, rays_d, near, far)
+        finally:
+            torch.rand = real_rand
+            glob["get_diffuse_visibility"] = real_vis
+        sdf_mask = out["sdf_mask"]
+        # mateIllu.py:152-172
+        sdf_mask_sum = mask[sdf_mask].sum() + 1e-5
+        rgb_error = (out["rgb"][sdf_mask] - true_rgb[sdf_mask]) * mask[sdf_mask]
+        rgb_loss = rgb_error.abs().sum() / sdf_mask_sum
+        psnr = 20.0 * torch.log10(1.0 / (((out["rgb"][sdf_mask] - true_rgb[sdf_mask]) ** 2 * mask[sdf_mask]).sum() / (sdf_mask_sum * 3.0)).sqrt())
+        loss = rgb_loss + out["encoder_loss"]
+        opt.zero_grad()
+        loss.backward()
+        tag = f"step{step}/"
+        assert len(draws) == 2 and draws[0].shape == (128, 32)
+        res.update({tag + "u_theta": draws[0].numpy(), tag + "u_phi": draws[1].numpy(), tag + "loss": loss.item(),
+                    tag + "rgb_loss": rgb_loss.item(), tag + "encoder_loss": float(out["encoder_loss"]), tag + "psnr": psnr.item()})
+        if step == 0:
+            for k, v in out.items():
+                res["out/" + k] = v.detach().numpy() if torch.is_tensor(v) else np.float64(v)
+            res["trace/light_vis"] = trace["light_vis"].numpy()
+            for nme, p in zip(names, params):
+                res["grad_sub/" + nme] = subsample(p.grad)
+                res["grad_norm/" + nme] = np.float64(p.grad.double().norm().item())
+        opt.step()
+        if step in (0, adam_steps - 1):
+            for nme, p in zip(names, params):
+                res[f"adam{step + 1}_sub/" + nme] = subsample(p)
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), **res)
+    print(name + ".npz written; hits", int(res["out/sdf_mask"].sum()), "of", B, "loss", res["step0/loss"], "rgb mean",
+          float(res["out/rgb"][res["out/sdf_mask"]].mean()), "lvis_mean", float(res["out/lvis_mean"][res["out/sdf_mask"]].mean()))
+
+
 def gen_raygen(dataset, out_dir, name="raygen_dtu"):
     """Dataset.gen_rays_at / gen_random_rays_at / near_far_from_sphere (dataset.py:115-151, 186-192) called unbound on a
     stub object that carries exactly the attributes they read: a synthetic DTU-like camera set (K^-1, pose), BGR/256
@@ -482,7 +566,7 @@ def gen_raygen(dataset, out_dir, name="raygen_dtu"):
 
 FIXTURES = ("units", "render_wmask_b16_n16", "render_wmask_b8_n64", "render_womask_b16_n16_o8", "render_wmask_b16_n16_c0",
             "render_wmask_b256_n32", "render_wmask_b64_n64", "lvis_util_b24_n32", "raygen_dtu", "lvis_render_room_b24_n32",
-            "lvis_render_ball_b16_n16")
+            "lvis_render_ball_b16_n16", "mateillu_render_b24_n32")
 
 
 def check_against(old_dir, new_dir, names):
@@ -549,6 +633,10 @@ def main():
     if want("lvis_render_ball_b16_n16"):        # the convex ball: secondary rays leave without a hit, visibility in (0.5, 1]
         gen_lvis_render(fields, renderer, args.out, "lvis_render_ball_b16_n16", B=16, n_samples=16, n_importance=16,
                         ray_seed=42, seeds=seeds2, room=False, adam_steps=1)
+    # ---- stage 3 (configs 4/5): mateIllu_render + EnvmapMaterialNetwork, loss, gradients, Adam steps -----------------------
+    if want("mateillu_render_b24_n32"):
+        gen_mateillu_render(fields, renderer, args.out, "mateillu_render_b24_n32", B=24, n_samples=32, n_importance=32,
+                            ray_seed=43, seeds=dict(seeds2, mateillu=26))
     if args.check:
         ok = check_against(HERE, args.out, FIXTURES)
         print("committed fixtures reproduced bit for bit" if ok else "MISMATCH against the committed fixtures")

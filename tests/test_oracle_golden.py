@@ -372,3 +372,63 @@ def test_stage2_adam_steps(golden_dir):
                 bad = np.abs(got - ref) > 0.2 * float(g["lr"])
                 assert bad.sum() <= max(1, 0.02 * bad.size), (step, k, int(bad.sum()), bad.size)
                 assert np.abs(got - ref).max() <= 2.2 * (step + 1) * float(g["lr"]) + 1e-7, (step, k)
+
+
+# ---- stage 3: mateIllu_render + EnvmapMaterialNetwork (renderer.py:630-726, inverRender.py:83-598, mateIllu.py:135-203) ----
+def stage3_setup(g):
+    sdf_p = R.sdf_params_from_state_dict(tsd(synth.sdf_state_dict(int(g["seed_sdf"]))))
+    ref_sd = tsd(synth.refcolor_state_dict(int(g["seed_refcolor"])))
+    lvis_sd = tsd(synth.lvis_state_dict(int(g["seed_lvis"])))
+    indi_sd = tsd(synth.indilgt_state_dict(int(g["seed_indilgt"])))
+    mat_sd = {k: v.requires_grad_(True) for k, v in tsd(synth.mateillu_state_dict(int(g["seed_mateillu"]))).items()}
+    return sdf_p, ref_sd, lvis_sd, indi_sd, mat_sd
+
+
+def stage3_run(g, nets, step):
+    sdf_p, ref_sd, lvis_sd, indi_sd, mat_sd = nets
+    data = T(g["data"])
+    near, far = R.near_far_from_sphere(data[:, :3], data[:, 3:6])
+    out = R.mateIllu_render(data[:, :3], data[:, 3:6], near, far, sdf_p, ref_sd, lvis_sd, indi_sd, mat_sd, int(g["n_samples"]),
+                            int(g["n_importance"]), T(g[f"step{step}/u_theta"]), T(g[f"step{step}/u_phi"]))
+    return out, R.stage3_loss(out, data[:, 6:9], (data[:, 9:10] > 0.5).float())
+
+
+def test_stage3_mateillu_render(golden_dir):
+    g = load(golden_dir, "mateillu_render_b24_n32")
+    nets = stage3_setup(g)
+    out, L = stage3_run(g, nets, 0)
+    assert np.array_equal(out["sdf_mask"].numpy(), g["out/sdf_mask"])
+    close(out["_light_vis"], g["trace/light_vis"], 2e-4)
+    for k in ("n_out", "gt_specular_linear", "gt_diffuse_srgb"):
+        close(out[k], g["out/" + k], 2e-4)
+    for k in ("rgb", "env_rgb", "indir_rgb", "diffuse_albedo", "specular_albedo", "diffuse_rgb", "specular_rgb", "roughness",
+              "lvis_mean"):
+        close(out[k], g["out/" + k], 3e-4)
+    for k in ("loss", "rgb_loss", "encoder_loss", "psnr"):
+        assert abs(float(L[k]) - float(g["step0/" + k])) <= 1e-3 * max(1.0, abs(float(g["step0/" + k]))), k
+    L["loss"].backward()
+    for k, prm in nets[4].items():
+        ref_sub, ref_norm = g["grad_sub/" + k], float(g["grad_norm/" + k])
+        sub = prm.grad.reshape(-1)[::997].numpy()
+        scale = max(ref_norm / np.sqrt(prm.numel()), np.abs(ref_sub).max(), 1e-7)
+        assert np.abs(sub - ref_sub).max() <= 2e-2 * scale + 1e-7, (k, np.abs(sub - ref_sub).max(), scale)
+        assert abs(prm.grad.double().norm().item() - ref_norm) <= 1e-2 * ref_norm + 1e-7, k
+
+
+def test_stage3_adam_steps(golden_dir):
+    g = load(golden_dir, "mateillu_render_b24_n32")
+    nets = stage3_setup(g)
+    opt = torch.optim.Adam(list(nets[4].values()), lr=float(g["lr"]))
+    for step in range(3):
+        out, L = stage3_run(g, nets, step)
+        assert abs(float(L["loss"]) - float(g[f"step{step}/loss"])) <= 2e-3 * max(1.0, abs(float(g[f"step{step}/loss"]))), step
+        opt.zero_grad()
+        L["loss"].backward()
+        opt.step()
+        if step in (0, 2):
+            for k, prm in nets[4].items():
+                ref = g[f"adam{step + 1}_sub/" + k]
+                got = prm.detach().reshape(-1)[::997].numpy()
+                bad = np.abs(got - ref) > 0.2 * float(g["lr"])
+                assert bad.sum() <= max(1, (0.02 if step == 0 else 0.10) * bad.size), (step, k, int(bad.sum()), bad.size)
+                assert np.abs(got - ref).max() <= 2.2 * (step + 1) * float(g["lr"]) + 1e-7, (step, k)
