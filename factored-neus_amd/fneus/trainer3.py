@@ -1,0 +1,88 @@
+"""Stage-3 training step (mateIllu.py:135-203) on the HIP backend: material / illumination estimation.
+
+Frozen inputs: the SDF, the RefColor head, Lvis and IndirectLight (mateIllu.py:83-89); trained: EnvmapMaterialNetwork
+(128 light SGs, the BRDF auto-encoder, net_cs; mateIllu.py:91-95).  The step is
+  mateIllu_render (renderer.py:630-726) -> masked L1 colour over the rays that hit + latent sparsity (mateIllu.py:152-172)
+  -> backward -> Adam.
+Cost: the primary sampler (K1 / K6) and the per-lobe light visibility, 128 lobes x 32 directions = 4096 Lvis evaluations per
+hit point (<= 2.1 M per step).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from fneus import ops, synth
+from fneus.trainer import WMASK_MODEL
+
+
+def stage3_loss(out: dict, true_rgb, mask):
+    """mateIllu.py:152-172 (mask = (mask > 0.5) when train.mask_weight > 0, else ones: the caller's business)"""
+    m = out["sdf_mask"]
+    denom = mask[m].sum() + 1e-5
+    diff = out["rgb"][m] - true_rgb[m]
+    rgb_loss = (diff * mask[m]).abs().sum() / denom
+    psnr = 20.0 * torch.log10(1.0 / ((diff ** 2 * mask[m]).sum() / (denom * 3.0)).sqrt())
+    return {"loss": rgb_loss + out["encoder_loss"], "rgb_loss": rgb_loss, "encoder_loss": out["encoder_loss"], "psnr": psnr}
+
+
+class Stage3Trainer:
+    def __init__(self, device, model_conf: Optional[dict] = None, prec: int = ops.PREC_PARITY, lr: float = 5e-4, seed: int = 0,
+                 synthetic_init: bool = True, mask_weight: float = 0.1):
+        from models.fields import SDFNetwork, SingleVarianceNetwork, RefColor, Lvis, IndirectLight
+        from models.inverRender import EnvmapMaterialNetwork
+        from models.renderer import NeuSRenderer
+        conf = model_conf or WMASK_MODEL
+        self.device = device
+        self.sdf_network = SDFNetwork(**conf["sdf_network"])
+        self.deviation_network = SingleVarianceNetwork(**conf["variance_network"])
+        self.refColor_network = RefColor()
+        self.lvis_network, self.indiLgt_network = Lvis(), IndirectLight()
+        torch.manual_seed(seed)
+        self.mateIllu_network = EnvmapMaterialNetwork()
+        if synthetic_init:
+            T = lambda sd: {k: torch.from_numpy(v) for k, v in sd.items()}
+            self.sdf_network.load_state_dict(T(synth.sdf_state_dict(seed)))
+            self.refColor_network.load_state_dict(T(synth.refcolor_state_dict(seed + 2)))
+            self.lvis_network.load_state_dict(T(synth.lvis_state_dict(seed + 4)))
+            self.indiLgt_network.load_state_dict(T(synth.indilgt_state_dict(seed + 5)))
+            self.mateIllu_network.load_state_dict(T(synth.mateillu_state_dict(seed + 6)))
+        self.frozen = [self.sdf_network, self.deviation_network, self.refColor_network, self.lvis_network, self.indiLgt_network]
+        for m in self.frozen + [self.mateIllu_network]:
+            m.to(device)
+        for m in self.frozen:
+            for p in m.parameters():
+                p.requires_grad_(False)
+        self.sdf_network.set_precision(prec)
+        self.refColor_network.set_precision(prec)
+        self.params = list(self.mateIllu_network.parameters())          # mateIllu.py:91-95
+        self.optimizer = torch.optim.Adam(self.params, lr=lr)
+        self.renderer = NeuSRenderer(**conf["neus_renderer"], sdf_network=self.sdf_network,
+                                     deviation_network=self.deviation_network, refColor_network=self.refColor_network,
+                                     lvis_network=self.lvis_network, indiLgt_network=self.indiLgt_network,
+                                     mateIllu_network=self.mateIllu_network)
+        self.mask_weight = mask_weight
+        self.iter_step = 0
+
+    def set_lr(self, lr: float):
+        for g in self.optimizer.param_groups:
+            g["lr"] = lr
+
+    def get_lr(self) -> float:
+        return float(self.optimizer.param_groups[0]["lr"])
+
+    def train_step(self, data: torch.Tensor, near=None, far=None, u_theta=None, u_phi=None):
+        """data [B,10] (dataset.py:133-151).  -> loss dict, or None when no ray hits the surface (mateIllu.py:156)"""
+        rays_o, rays_d, true_rgb, mask = ops.split_batch(data.contiguous())
+        mask = (mask > 0.5).float() if self.mask_weight > 0.0 else torch.ones_like(mask)
+        out = self.renderer.mateIllu_render(rays_o, rays_d, near, far, u_theta=u_theta, u_phi=u_phi)
+        if not bool(out["sdf_mask"].any()):
+            return None
+        losses = stage3_loss(out, true_rgb, mask)
+        self.optimizer.zero_grad(set_to_none=True)
+        losses["loss"].backward()
+        self.optimizer.step()
+        self.iter_step += 1
+        losses["n_hit"] = out["sdf_mask"].sum()
+        return losses

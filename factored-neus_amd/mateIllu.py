@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""Stage-3 runner with the reference's command line (mateIllu.py:1121-1163, mode train) on the MI355X HIP backend.
+
+    python mateIllu.py --mode train --conf ./confs/wmask.conf --case dtu_scan97 --type dtu [--is_continue] [--gpu 0]
+
+Loads the newest stage-2 checkpoint of general.base_exp_dir_lvis (mateIllu.py:97-105, 238-245), trains the
+EnvmapMaterialNetwork (train.metaIllu.*: 40 000 iterations x 512 rays, warm-up then cosine) and writes checkpoints with the
+reference's keys (mateIllu.py:269-284) under general.base_exp_dir_mateIllu.  The validation / relighting / video / PSNR
+modes (mateIllu.py:286-1119) are presentation and not provided.
+"""
+from __future__ import annotations
+
+import argparse
+import logging
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
+
+from fneus import hocon, ops                      # noqa: E402
+from fneus.trainer3 import Stage3Trainer          # noqa: E402
+from models.dataset import Dataset, SyntheticDataset            # noqa: E402
+
+
+def _latest(ckpt_dir, end_iter):
+    names = sorted(n for n in os.listdir(ckpt_dir) if n.endswith("pth") and int(n[5:-4]) <= end_iter)
+    return names[-1] if names else None
+
+
+class Runner:
+    def __init__(self, conf_path, mode="train", case="CASE_NAME", is_continue=False, type="dtu", device=None,
+                 prec=ops.PREC_PARITY):
+        self.device = device or torch.device("cuda")
+        self.conf = hocon.parse_file(conf_path, case)
+        self.base_exp_dir_mateIllu = self.conf["general.base_exp_dir_mateIllu"]
+        self.base_exp_dir_lvis = self.conf["general.base_exp_dir_lvis"]
+        os.makedirs(self.base_exp_dir_mateIllu, exist_ok=True)
+        if type == "dtu":
+            self.dataset = Dataset(self.conf["dataset"], device=self.device)
+        elif type == "synthetic":
+            self.dataset = SyntheticDataset(device=self.device)
+        else:
+            raise NotImplementedError(f"--type {type}: only 'dtu' and 'synthetic' feed the HIP hot path")
+        tc = self.conf["train"]
+        self.end_iter = tc.get_int("metaIllu.end_iter")
+        self.batch_size = tc.get_int("metaIllu.batch_size")
+        self.save_freq, self.report_freq = tc.get_int("save_freq"), tc.get_int("report_freq")
+        self.learning_rate, self.learning_rate_alpha = tc.get_float("learning_rate"), tc.get_float("learning_rate_alpha")
+        self.warm_up_end = tc.get_float("warm_up_end", 0.0)
+        self.mask_weight = tc.get_float("mask_weight")
+        model_conf = {k: dict(self.conf["model"][k]) for k in ("sdf_network", "variance_network", "neus_renderer")}
+        self.trainer = Stage3Trainer(self.device, model_conf=model_conf, prec=prec, lr=self.learning_rate, synthetic_init=False,
+                                     mask_weight=self.mask_weight)
+        self.iter_step = 0
+        prev = _latest(os.path.join(self.base_exp_dir_lvis, "checkpoints"), tc.get_int("lvis.end_iter"))
+        if prev is None:
+            raise FileNotFoundError(f"no stage-2 checkpoint under {self.base_exp_dir_lvis}/checkpoints")
+        logging.info("Find lvis checkpoint: %s", prev)
+        self.load_checkpoint_lvis(prev)
+        if is_continue:
+            name = _latest(os.path.join(self.base_exp_dir_mateIllu, "checkpoints"), self.end_iter)
+            if name is not None:
+                logging.info("Find checkpoint: %s", name)
+                self.load_checkpoint(name)
+
+    def update_learning_rate(self):      # mateIllu.py:214-224
+        if self.iter_step < self.warm_up_end:
+            factor = self.iter_step / self.warm_up_end
+        else:
+            alpha = self.learning_rate_alpha
+            progress = (self.iter_step - self.warm_up_end) / (self.end_iter - self.warm_up_end)
+            factor = (np.cos(np.pi * progress) + 1.0) * 0.5 * (1 - alpha) + alpha
+        self.trainer.set_lr(self.learning_rate * factor)
+
+    def train(self, max_steps=None):
+        self.update_learning_rate()
+        perm = torch.randperm(self.dataset.n_images)
+        steps = self.end_iter - self.iter_step if max_steps is None else max_steps
+        losses = None
+        for _ in range(steps):
+            data = self.dataset.gen_random_rays_at(perm[self.iter_step % len(perm)], self.batch_size)
+            out = self.trainer.train_step(data)
+            if out is None:              # no hit: skipped without counting, as mateIllu.py:156
+                continue
+            losses = out
+            self.iter_step += 1
+            if self.iter_step % self.report_freq == 0:
+                print(self.base_exp_dir_mateIllu)
+                print("iter:{:8>d} loss = {} lr={}".format(self.iter_step, losses["rgb_loss"].item(), self.trainer.get_lr()))
+            if self.iter_step % self.save_freq == 0:
+                self.save_checkpoint()
+            self.update_learning_rate()
+            if self.iter_step % len(perm) == 0:
+                perm = torch.randperm(self.dataset.n_images)
+        return losses
+
+    # ---- checkpoints: the reference's keys and file names (mateIllu.py:238-284) ----
+    def _load_frozen(self, ckpt):
+        t = self.trainer
+        t.sdf_network.load_state_dict(ckpt["sdf_network_fine"])
+        t.deviation_network.load_state_dict(ckpt["variance_network_fine"])
+        t.refColor_network.load_state_dict(ckpt["refColor_network"])
+        t.lvis_network.load_state_dict(ckpt["lvis_network"])
+        t.indiLgt_network.load_state_dict(ckpt["indiLgt_network"])
+
+    def load_checkpoint_lvis(self, name):
+        self._load_frozen(torch.load(os.path.join(self.base_exp_dir_lvis, "checkpoints", name), map_location=self.device))
+
+    def load_checkpoint(self, name):
+        ckpt = torch.load(os.path.join(self.base_exp_dir_mateIllu, "checkpoints", name), map_location=self.device)
+        self._load_frozen(ckpt)
+        self.trainer.mateIllu_network.load_state_dict(ckpt["mateIllu_network"])
+        self.trainer.optimizer.load_state_dict(ckpt["optimizer"])
+        self.iter_step = self.trainer.iter_step = ckpt["iter_step"]
+
+    def save_checkpoint(self):
+        t = self.trainer
+        ckpt = {"sdf_network_fine": t.sdf_network.state_dict(), "variance_network_fine": t.deviation_network.state_dict(),
+                "refColor_network": t.refColor_network.state_dict(), "lvis_network": t.lvis_network.state_dict(),
+                "indiLgt_network": t.indiLgt_network.state_dict(), "mateIllu_network": t.mateIllu_network.state_dict(),
+                "optimizer": t.optimizer.state_dict(), "iter_step": self.iter_step}
+        os.makedirs(os.path.join(self.base_exp_dir_mateIllu, "checkpoints"), exist_ok=True)
+        torch.save(ckpt, os.path.join(self.base_exp_dir_mateIllu, "checkpoints", "ckpt_{:0>6d}.pth".format(self.iter_step)))
+
+
+def main():
+    logging.basicConfig(level=logging.INFO, format="[%(filename)s:%(lineno)d] %(message)s")
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--conf", type=str, default="./confs/wmask.conf")
+    ap.add_argument("--mode", type=str, default="train")
+    ap.add_argument("--is_continue", default=False, action="store_true")
+    ap.add_argument("--gpu", type=int, default=0)
+    ap.add_argument("--case", type=str, default="")
+    ap.add_argument("--type", type=str, default="dtu")
+    ap.add_argument("--prec", choices=["parity", "fast"], default="parity")
+    ap.add_argument("--max_steps", type=int, default=None)
+    args = ap.parse_args()
+    torch.cuda.set_device(args.gpu)
+    runner = Runner(args.conf, args.mode, args.case, args.is_continue, args.type, device=torch.device("cuda", args.gpu),
+                    prec=ops.PREC_PARITY if args.prec == "parity" else ops.PREC_FAST)
+    if args.mode == "train":
+        runner.train(max_steps=args.max_steps)
+    else:
+        raise NotImplementedError(f"--mode {args.mode}: the validation / relighting / video modes of stage 3 are presentation")
+
+
+if __name__ == "__main__":
+    main()

@@ -458,6 +458,29 @@ class Lvis(nn.Module):
     def forward(self, pts, view):
         return self.lvis(torch.cat([self.embedview_fn_pts(pts), self.embedview_fn_view(view)], dim=-1))
 
+    def visibility(self, points, normals, dirs, weights):
+        """get_diffuse_visibility's network part (inverRender.py:163-190), no gradient: for every surface point the network
+        at the S directions of each of the M light lobes, zero where the direction faces away from the normal, averaged per
+        lobe with the given weights.  points, normals [n,3]; dirs [M,S,3]; weights [M,S] -> [M,n]"""
+        return self._visibility_library(points, normals, dirs, weights)
+
+    @torch.no_grad()
+    def _visibility_library(self, points, normals, dirs, weights, chunk: int = 32):
+        """the same through the library GEMMs (rocBLAS), `chunk` points x M*S directions per pass"""
+        M, S = weights.shape
+        flat = dirs.reshape(M * S, 3)
+        d_enc = self.embedview_fn_view(flat)                                  # [MS,27]: the same for every point
+        wsum = weights.sum(dim=1) + 1e-6
+        out = torch.empty(M, points.shape[0], device=points.device)
+        for i in range(0, points.shape[0], chunk):
+            p, nrm = points[i:i + chunk], normals[i:i + chunk]
+            c = p.shape[0]
+            front = (nrm @ flat.t()) > 1e-6                                   # [c, MS]
+            x = torch.cat([self.embedview_fn_pts(p)[:, None, :].expand(c, M * S, -1), d_enc[None].expand(c, -1, -1)], dim=-1)
+            vis = self.lvis(x.reshape(c * M * S, -1)).reshape(c, M, S) * front.reshape(c, M, S)
+            out[:, i:i + c] = ((vis * weights[None]).sum(dim=2) / wsum[None]).t()
+        return out
+
 
 class IndirectLight(nn.Module):
     """Stage-2 indirect light as 24 spherical Gaussians per point (fields.py:372-413): 63 -> 512 x 4 -> 144 -> [n, 24, 7] =

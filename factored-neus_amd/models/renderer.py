@@ -324,6 +324,50 @@ class NeuSRenderer:
                 out[k] = out[k].index_copy(0, idx, res[k].to(out[k].dtype))
         return out
 
+    def mateIllu_render(self, rays_o, rays_d, near, far, u_theta=None, u_phi=None):
+        """renderer.py:630-726: stage 3.  Geometry (SDF), the RefColor head, Lvis and IndirectLight are frozen inputs
+        (mateIllu.py:83-95 trains the EnvmapMaterialNetwork only): hit points by fneus_ray_hit, normal + feature by K2, the
+        diffuse / specular split by the fused RefColor heads, all without stash.  Rows of rays without a hit hold 1.
+        u_theta, u_phi [128, 32]: the uniform draws of the visibility sampler (inverRender.py:152-153; tests)."""
+        from models.inverRender import srgb_to_linear
+        B = len(rays_o)
+        dev = rays_o.device
+        util = self.lvis_mateIllu_render_util(rays_o, rays_d, near, far)
+        n = util["n_samples"]
+        rays_o, rays_d = rays_o.detach().float().contiguous(), rays_d.detach().float().contiguous()
+        with torch.no_grad():
+            hit = ops.ray_hit(rays_o, rays_d, util["mid_z_vals"], util["sdf"].reshape(B, n).contiguous(),
+                              inside_mask=util["inside_sphere_mask"])
+            sdf_mask = hit["sdf_mask"].view(torch.bool)
+            idx = sdf_mask.nonzero(as_tuple=True)[0]
+        one3 = lambda: torch.ones(B, 3, device=dev)
+        out = {k: one3() for k in ("rgb", "env_rgb", "indir_rgb", "diffuse_albedo", "specular_albedo", "diffuse_rgb",
+                                   "specular_rgb", "lvis_mean", "gt_specular_linear", "gt_diffuse_srgb", "n_out")}
+        out["roughness"] = torch.ones(B, 1, device=dev)
+        out.update(sdf_mask=sdf_mask, diffuse_loss=0, specular_loss=0, encoder_loss=0, smooth_loss=0)
+        if idx.numel() > 0:
+            with torch.no_grad():
+                pts_surf = hit["pts_surf"][idx].contiguous()
+                rays_surf = rays_d[idx].contiguous()
+                surf = RaySamples(pts=pts_surf, dirs=rays_surf)
+                _, f_surf, n_surf = self.sdf_network.value_feature_normal(surf, False)
+                self.refColor_network.refresh()
+                diffuse, spec = self.refColor_network.heads(surf, f_surf, n_surf, False)
+                ref = self.refColor_network.shade(diffuse, spec)
+                specular_linear = srgb_to_linear(ref["specular_rgb"])
+                indiLgt = self.indiLgt_network(pts_surf)
+            m = self.mateIllu_network(pts_surf, rays_surf, n_surf, f_surf, specular_linear, indiLgt, self.lvis_network,
+                                      u_theta=u_theta, u_phi=u_phi)
+            for k in ("rgb", "env_rgb", "indir_rgb", "diffuse_albedo", "specular_albedo", "diffuse_rgb", "specular_rgb",
+                      "roughness", "lvis_mean"):
+                out[k] = out[k].index_copy(0, idx, m[k].to(out[k].dtype))
+            out["gt_specular_linear"] = out["gt_specular_linear"].index_copy(0, idx, specular_linear)
+            out["gt_diffuse_srgb"] = out["gt_diffuse_srgb"].index_copy(0, idx, ref["diffuse_rgb"])
+            out["n_out"] = out["n_out"].index_copy(0, idx, n_surf)
+            for k in ("diffuse_loss", "specular_loss", "encoder_loss", "smooth_loss"):
+                out[k] = m[k]
+        return out
+
     def extract_geometry(self, bound_min, bound_max, resolution, threshold=0.0):
         """renderer.py:729-734: iso-surface of -sdf at `threshold`; the grid goes through K1 (fneus_sdf_fwd), the surface
         is extracted on the device by models/mesh.py (marching tetrahedra; PyMCubes is not a dependency).

@@ -1,0 +1,137 @@
+"""GPU parity of stage 3 (NeuSRenderer.mateIllu_render -> EnvmapMaterialNetwork.forward, renderer.py:630-726,
+inverRender.py:83-598; training step of mateIllu.py:135-203) against a fixture produced by the reference itself
+(tests/golden/mateillu_render_b24_n32.npz).  Tolerance 1e-4 absolute on smooth quantities; the primary hit point sits behind
+the hierarchical sampler and a zero-crossing search, so per-ray outputs get 3e-4 (what the CPU oracle shows vs the reference)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+RAY_KEYS = ("rgb", "env_rgb", "indir_rgb", "diffuse_albedo", "specular_albedo", "diffuse_rgb", "specular_rgb", "roughness",
+            "lvis_mean")
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def build(g):
+    from fneus import ops, synth
+    from fneus.trainer import WMASK_MODEL
+    from fneus.trainer3 import Stage3Trainer
+    conf = dict(WMASK_MODEL, neus_renderer=dict(n_samples=int(g["n_samples"]), n_importance=int(g["n_importance"]), n_outside=0,
+                                                up_sample_steps=4, perturb=1.0))
+    tr = Stage3Trainer(torch.device(DEV), model_conf=conf, prec=ops.PREC_PARITY, lr=float(g["lr"]), synthetic_init=False,
+                       mask_weight=float(g["mask_weight"]))
+    sd = lambda d: {k: T(v).to(DEV) for k, v in d.items()}
+    tr.sdf_network.load_state_dict(sd(synth.sdf_state_dict(int(g["seed_sdf"]))))
+    tr.refColor_network.load_state_dict(sd(synth.refcolor_state_dict(int(g["seed_refcolor"]))))
+    tr.lvis_network.load_state_dict(sd(synth.lvis_state_dict(int(g["seed_lvis"]))))
+    tr.indiLgt_network.load_state_dict(sd(synth.indilgt_state_dict(int(g["seed_indilgt"]))))
+    tr.mateIllu_network.load_state_dict(sd(synth.mateillu_state_dict(int(g["seed_mateillu"]))))
+    return tr
+
+
+def rays(g):
+    from oracle import ref_torch as R
+    data = T(g["data"]).to(DEV)
+    near, far = R.near_far_from_sphere(data[:, :3], data[:, 3:6])
+    return data, near, far
+
+
+def test_mateillu_render_vs_reference(golden_dir):
+    from fneus.trainer3 import stage3_loss
+    g = dict(np.load(os.path.join(golden_dir, "mateillu_render_b24_n32.npz")))
+    tr = build(g)
+    data, near, far = rays(g)
+    out = tr.renderer.mateIllu_render(data[:, :3].contiguous(), data[:, 3:6].contiguous(), near, far,
+                                      u_theta=T(g["step0/u_theta"]).to(DEV), u_phi=T(g["step0/u_phi"]).to(DEV))
+    c = lambda t: t.detach().cpu()
+    assert np.array_equal(c(out["sdf_mask"]).numpy(), g["out/sdf_mask"])
+    for k in ("n_out", "gt_specular_linear", "gt_diffuse_srgb"):
+        assert (c(out[k]) - T(g["out/" + k])).abs().max().item() <= 3e-4, k
+    worst = {}
+    for k in RAY_KEYS:
+        worst[k] = (c(out[k]) - T(g["out/" + k])).abs().max().item()
+        assert worst[k] <= 3e-4, (k, worst[k])
+    print("  worst abs differences:", {k: f"{v:.1e}" for k, v in worst.items()})
+    miss = ~T(g["out/sdf_mask"])
+    assert bool((c(out["rgb"])[miss] == 1.0).all())
+    mask = (data[:, 9:10] > 0.5).float()
+    L = stage3_loss(out, data[:, 6:9], mask)
+    for k in ("loss", "rgb_loss", "encoder_loss", "psnr"):
+        assert abs(float(L[k].detach()) - float(g["step0/" + k])) <= 1e-3 * max(1.0, abs(float(g["step0/" + k]))), k
+    L["loss"].backward()
+    for k, prm in tr.mateIllu_network.named_parameters():
+        ref_sub, ref_norm = g["grad_sub/" + k], float(g["grad_norm/" + k])
+        sub = prm.grad.detach().cpu().reshape(-1)[::997].numpy()
+        scale = max(ref_norm / np.sqrt(prm.numel()), np.abs(ref_sub).max(), 1e-7)
+        assert np.abs(sub - ref_sub).max() <= 2e-2 * scale + 1e-7, (k, np.abs(sub - ref_sub).max(), scale)
+        assert abs(prm.grad.double().norm().item() - ref_norm) <= 1e-2 * ref_norm + 1e-7, k
+
+
+def test_light_visibility_vs_reference_trace(golden_dir):
+    """get_diffuse_visibility (inverRender.py:128-192): 128 lobes x 32 directions x every hit point through Lvis"""
+    from models.inverRender import get_diffuse_visibility
+    from oracle import ref_torch as R
+    g = dict(np.load(os.path.join(golden_dir, "mateillu_render_b24_n32.npz")))
+    tr = build(g)
+    m = T(g["out/sdf_mask"])
+    n = torch.nn.functional.normalize(T(g["out/n_out"])[m], dim=-1).to(DEV)      # forward() normalises the normal first
+    # the hit points are not stored: re-derive them with the oracle (CPU) from the same rays
+    from fneus import synth
+    sdf_p = R.sdf_params_from_state_dict({k: T(v) for k, v in synth.sdf_state_dict(int(g["seed_sdf"])).items()})
+    data = T(g["data"])
+    near, far = R.near_far_from_sphere(data[:, :3], data[:, 3:6])
+    util = R.lvis_mateIllu_render_util(data[:, :3], data[:, 3:6], near, far, sdf_p, int(g["n_samples"]), int(g["n_importance"]))
+    mask, z = R.first_hit(util["sdf"].reshape(len(data), -1), util["mid_z_vals"], util["inside_sphere_mask"])
+    assert torch.equal(mask, m)
+    pts = (data[mask, :3] + data[mask, 3:6] * z[mask][:, None]).to(DEV)
+    sg = tr.mateIllu_network.lgtSGs.detach()
+    lobes = sg[:, :3] / (sg[:, :3].norm(dim=-1, keepdim=True) + 1e-6)
+    vis = get_diffuse_visibility(pts, n, tr.lvis_network, lobes, sg[:, 3:4].abs(), nsamp=32,
+                                 u_theta=T(g["step0/u_theta"]).to(DEV), u_phi=T(g["step0/u_phi"]).to(DEV))
+    d = (vis.cpu() - T(g["trace/light_vis"])).abs()
+    print(f"  light visibility vs the reference: worst {d.max().item():.2e}, mean {d.mean().item():.2e}")
+    assert d.max().item() <= 3e-4
+
+
+def test_stage3_adam_steps_match_reference(golden_dir):
+    g = dict(np.load(os.path.join(golden_dir, "mateillu_render_b24_n32.npz")))
+    tr = build(g)
+    data, near, far = rays(g)
+    lr = float(g["lr"])
+    for step in range(3):
+        L = tr.train_step(data, near=near, far=far, u_theta=T(g[f"step{step}/u_theta"]).to(DEV),
+                          u_phi=T(g[f"step{step}/u_phi"]).to(DEV))
+        ref = float(g[f"step{step}/loss"])
+        assert abs(float(L["loss"]) - ref) <= 2e-3 * max(1.0, abs(ref)), (step, float(L["loss"]), ref)
+        if step in (0, 2):
+            for k, prm in tr.mateIllu_network.named_parameters():
+                want = g[f"adam{step + 1}_sub/" + k]
+                got = prm.detach().cpu().reshape(-1)[::997].numpy()
+                bad = np.abs(got - want) > 0.2 * lr
+                assert bad.sum() <= max(1, (0.02 if step == 0 else 0.10) * bad.size), (step, k, int(bad.sum()), bad.size)
+                assert np.abs(got - want).max() <= 2.2 * (step + 1) * lr + 1e-7, (step, k)
+
+
+def test_stage3_step_at_full_size_properties():
+    """config 4 shape: 512 rays x (64 + 64), 4096 Lvis evaluations per hit point.  The step is finite, lowers the loss on a
+    fixed batch, keeps colours in [0, 1] and rows without a hit at exactly 1."""
+    from fneus.trainer import synthetic_batches
+    from fneus.trainer3 import Stage3Trainer
+    tr = Stage3Trainer(torch.device(DEV), seed=3)
+    batch = synthetic_batches(1, 512, torch.device(DEV), seed0=12)[0]
+    first = last = None
+    for i in range(10):
+        out = tr.train_step(batch)
+        assert out is not None and bool(torch.isfinite(out["loss"]))
+        first = float(out["loss"]) if first is None else first
+        last = float(out["loss"])
+    assert int(out["n_hit"]) > 100 and last < first, (first, last)
+    res = tr.renderer.mateIllu_render(batch[:, :3].contiguous(), batch[:, 3:6].contiguous(), None, None)
+    assert float(res["rgb"].min()) >= 0.0 and float(res["rgb"].max()) <= 1.0
+    assert bool((res["rgb"][~res["sdf_mask"]] == 1.0).all())
