@@ -346,6 +346,27 @@ def main():
                                  "note": "lvis_render + L1 losses + backward + Adam (lvis.py:132-196): 4 secondary rays per hit "
                                          "point x 512 coarse samples through K1, 32 fine samples through K2, same precision mode"}
         del tr2
+        # stage 3 (BASELINE configs[3], mateIllu.py:135-203): 512 primary rays, 128 light SGs x 32 directions = 4096 Lvis
+        # evaluations per hit point, closed-form SG rendering, Adam over the EnvmapMaterialNetwork
+        from fneus.trainer3 import Stage3Trainer
+        tr3 = Stage3Trainer(device, prec=prec)
+        hits = []
+        for b in sb[:4]:
+            tr3.train_step(b)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for b in sb[4:]:
+            o3 = tr3.train_step(b)
+            if o3 is not None:
+                hits.append(o3["n_hit"])
+        torch.cuda.synchronize()
+        dt_3 = (time.perf_counter() - t0) / 10
+        n_hit3 = float(torch.stack(hits).float().mean()) if hits else 0.0
+        result["stage3_step"] = {"value": 4096 * n_hit3 / dt_3, "unit": "Lvis visibility evaluations/s", "ms_per_step": dt_3 * 1e3,
+                                 "primary_rays": RAYS, "mean_hit_points": n_hit3,
+                                 "note": "mateIllu_render + masked L1 + latent sparsity + backward + Adam (mateIllu.py:135-203): "
+                                         "128 light lobes x 32 directions through Lvis per hit point, SG rendering of 128 + 24 lobes"}
+        del tr3
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

@@ -61,6 +61,18 @@ constexpr LayerGeom kNerfGeom[kNerfLayers] = {
     {8, 1, 2, 4},     // 11: rgb_linear 128 -> 3 (one tile)
 };
 
+// Lvis, the stage-2 distilled light-visibility network (reference models/fields.py:338-369), inference only (stage 3 evaluates
+// it 4096 times per surface point, inverRender.py:163-180): [PE10(point) 63 -> 64 slots | PE4(direction) 27 -> 32 slots] -> 4 x 256
+// ReLU -> 1.  No reverse packs.
+constexpr int kLvisLayers = 5;
+constexpr LayerGeom kLvisGeom[kLvisLayers] = {
+    {6, 8, 0, 0},
+    {16, 8, 0, 0},
+    {16, 8, 0, 0},
+    {16, 8, 0, 0},
+    {16, 1, 0, 0},    // 256 -> 1 (one tile, row 0)
+};
+
 struct LayerOff {
     uint32_t fwd_hi, fwd_lo, rev_hi, rev_lo, bias;
 };
@@ -91,6 +103,7 @@ constexpr NetLayout<NL> make_layout(const LayerGeom (&g)[NL], int extra_bytes) {
 constexpr NetLayout<kSdfLayers> kSdfLayout = make_layout<kSdfLayers>(kSdfGeom, 8 * 2 * 16 * 4);
 constexpr NetLayout<kColLayers> kColLayout = make_layout<kColLayers>(kColGeom, 0);
 constexpr NetLayout<kNerfLayers> kNerfLayout = make_layout<kNerfLayers>(kNerfGeom, 0);
+constexpr NetLayout<kLvisLayers> kLvisLayout = make_layout<kLvisLayers>(kLvisGeom, 0);
 
 // flat fp32 parameter layouts (natural order): for each layer W[out][in] row-major, then b[out]
 constexpr int kSdfIn[kSdfLayers]  = {39, 256, 256, 256, 256, 256, 256, 256, 256};

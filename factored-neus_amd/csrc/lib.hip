@@ -31,5 +31,6 @@ extern "C" int fneus_layout(int which, int32_t* out, int cap) {
     if (which == 0) return fneus::write_layout(fneus::kSdfLayout, fneus::kSdfGeom, out, cap);
     if (which == 1) return fneus::write_layout(fneus::kColLayout, fneus::kColGeom, out, cap);
     if (which == 2) return fneus::write_layout(fneus::kNerfLayout, fneus::kNerfGeom, out, cap);
+    if (which == 3) return fneus::write_layout(fneus::kLvisLayout, fneus::kLvisGeom, out, cap);
     return -2;
 }

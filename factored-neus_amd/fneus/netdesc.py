@@ -314,3 +314,34 @@ def build_nerf_jobs():
             "ins": NERF_IN, "outs": NERF_OUT, "n_raw": total_raw, "offB": offB, "offG": [None] * 12, "offV": offV,
             "rows": np.zeros(0, dtype=ROW_DTYPE), "bias_segs": np.zeros((0, 4), dtype=np.int32), "weight_norm": False,
             "names": NERF_NAMES}
+
+
+# ---- Lvis (reference models/fields.py:338-369), plain nn.Linear layers, inference packs only -----------------------------
+LVIS_IN = [90, 256, 256, 256, 256]
+LVIS_OUT = [256, 256, 256, 256, 1]
+LVIS_PTS_PE, LVIS_VIEW_PE = 63, 27
+
+
+def build_lvis_jobs():
+    """Pack tables of the stage-2 visibility network for fneus_lvis_visibility (csrc/lvis_kernels.hip, layout 3): forward packs
+    and biases only.  Layer 0's k-slots: 64 slots for PE10(point) (reference columns 0..62), 32 slots for PE4(direction)
+    (columns 63..89)."""
+    ly = query_layout(3)
+    offB, _offG, offV, total_raw = raw_offsets(LVIS_IN, LVIS_OUT, weight_norm=False)
+    b = _Builder()
+    for l in range(5):
+        ksf, ntf, _ksr, _ntr = [int(v) for v in ly.geom[l]]
+        fwd_hi, fwd_lo, _rh, _rl, bias = [int(v) for v in ly.off[l]]
+        n_in, n_out = LVIS_IN[l], LVIS_OUT[l]
+        rowmap = _lim(np.arange(ntf * 32), n_out)
+        feat = slot_features(ksf)
+        if l == 0:
+            kmap = np.where(feat < LVIS_PTS_PE, feat, np.where((feat >= 64) & (feat - 64 < LVIS_VIEW_PE), LVIS_PTS_PE + feat - 64, -1))
+        else:
+            kmap = _lim(feat, n_in)
+        b.frag(fwd_hi, fwd_lo, offV[l], n_in, ksf, ntf, 0, rowmap, kmap, 1.0, -1)
+        b.accvec(bias, offB[l], 1, ntf, rowmap)
+    jobs, maps, units = b.finish()
+    return {"layout": ly, "jobs": jobs, "maps": maps, "units": units, "n_params": 0, "offW": offV, "offb": offB,
+            "ins": LVIS_IN, "outs": LVIS_OUT, "n_raw": total_raw, "offB": offB, "offG": [None] * 5, "offV": offV,
+            "rows": np.zeros(0, dtype=ROW_DTYPE), "bias_segs": np.zeros((0, 4), dtype=np.int32), "weight_norm": False}

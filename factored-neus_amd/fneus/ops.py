@@ -126,7 +126,7 @@ class PackedNet:
     def __init__(self, kind: str, device, raw_grad: Optional[torch.Tensor] = None):
         builders = {"sdf": netdesc.build_sdf_jobs, "color": netdesc.build_color_jobs,
                     "refcd": netdesc.build_refcd_jobs, "refvd": netdesc.build_refvd_jobs,
-                    "nerf": netdesc.build_nerf_jobs}
+                    "nerf": netdesc.build_nerf_jobs, "lvis": netdesc.build_lvis_jobs}
         desc = builders[kind]()
         self.kind, self.desc, self.device = kind, desc, device
         self.layout = desc["layout"]
@@ -675,6 +675,17 @@ def upsample(rays_o, rays_d, z, sdf, k: int, inv_s: float):
     _launch("fneus_upsample", lib.fneus_upsample, _ptr(rays_o), _ptr(rays_d), _ptr(z), _ptr(sdf), B, m, k, float(inv_s), _ptr(out),
                              _stream())
     return out
+
+
+def lvis_visibility(blob, points, normals, dirs, weights, prec: int):
+    """get_diffuse_visibility's network part (inverRender.py:163-190) -> vis [M, n]; dirs [M, 32, 3], weights [M, 32]"""
+    n, M, S = points.shape[0], dirs.shape[0], dirs.shape[1]
+    for t, name in ((points, "points"), (normals, "normals"), (dirs, "dirs"), (weights, "weights")):
+        _chk_f32(t, name)
+    vis = torch.empty(M, n, dtype=torch.float32, device=points.device)
+    _launch("fneus_lvis_visibility", lib.fneus_lvis_visibility, _ptr(blob), _ptr(points), _ptr(normals), _ptr(dirs), _ptr(weights),
+            n, M, S, _ptr(vis), prec, _stream())
+    return vis
 
 
 def gen_random_rays(intrinsics_inv, pose, image, mask, px, py):

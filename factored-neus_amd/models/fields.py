@@ -462,7 +462,36 @@ class Lvis(nn.Module):
         """get_diffuse_visibility's network part (inverRender.py:163-190), no gradient: for every surface point the network
         at the S directions of each of the M light lobes, zero where the direction faces away from the normal, averaged per
         lobe with the given weights.  points, normals [n,3]; dirs [M,S,3]; weights [M,S] -> [M,n]"""
-        return self._visibility_library(points, normals, dirs, weights)
+        if dirs.shape[1] != 32:          # the fused kernel maps one (point, lobe) pair onto one 32-sample MFMA tile
+            return self._visibility_library(points, normals, dirs, weights)
+        net = self._packed()
+        return ops.lvis_visibility(net.blob, points, normals, dirs.contiguous(), weights.contiguous(), self.prec)
+
+    prec = ops.PREC_PARITY
+
+    def set_precision(self, prec: int):
+        assert prec in (ops.PREC_FAST, ops.PREC_PARITY)
+        self.prec = prec
+
+    def _packed(self):
+        """the weights as MFMA fragments (fneus_pack, layout 3); re-packed when a parameter has changed (stage 3 keeps this
+        network frozen, so that is once)"""
+        layers = [self.lvis[i] for i in (0, 2, 4, 6, 8)]
+        dev = layers[0].weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("the fneus HIP backend needs the module on a GPU (there is no CPU fallback)")
+        key = tuple((p.data_ptr(), p._version) for lin in layers for p in (lin.weight, lin.bias))
+        if getattr(self, "_pack_key", None) != key:
+            net = getattr(self, "_net", None)
+            if net is None or net.device != dev:
+                net = ops.PackedNet("lvis", dev)
+            with torch.no_grad():
+                for lin, view in zip(layers, net.raw_views(net.raw)):
+                    view["weight"].copy_(lin.weight)
+                    view["bias"].copy_(lin.bias)
+            net.pack()
+            self._net, self._pack_key = net, key
+        return self._net
 
     @torch.no_grad()
     def _visibility_library(self, points, normals, dirs, weights, chunk: int = 32):

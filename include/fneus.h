@@ -128,7 +128,7 @@ const char* fneus_last_error(void);      /* host pointer, static storage */
  * RefColor MLPs), 2 = background NeRF++ (one entry per pack, csrc/fneus_layout.h).
  * out[0] = n_layers, out[1] = total blob bytes, out[2] = extra offset, then per layer 9 ints:
  * fwd_hi, fwd_lo, rev_hi, rev_lo, bias (byte offsets), ksf, ntf, ksr, ntr.  Returns number of ints written. */
-int fneus_layout(int which, int32_t* out, int cap);
+int fneus_layout(int which /*0 SDF, 1 colour-shaped, 2 background NeRF, 3 Lvis*/, int32_t* out, int cap);
 
 /* ---- weight packing (every optimiser step) --------------------------------------------------------------- */
 /* jobs: device array of PackJob (csrc/fneus_pack.h), maps: device int32 index maps, params: flat fp32 parameters
@@ -292,6 +292,14 @@ int fneus_ray_hit(const float* rays_o, const float* rays_d, const float* mid_z, 
 int fneus_sample_dirs(const float* surf /*[n_pts][3]*/, const float* normal /*[n_pts][3]*/, const float* u_theta /*[n_pts][n_dirs]*/,
                       const float* u_z /*[n_pts][n_dirs]*/, int n_pts, int n_dirs, float* origins, float* dirs,
                       fneus_stream_t stream);
+
+/* ---- Stage 3 (mateIllu.py): per-lobe light visibility, get_diffuse_visibility (inverRender.py:128-192) ------------------------ */
+/* lvis_blob: fneus_pack output for layout 3 (the Lvis network, fields.py:338-369, plain Linear layers).  points, normals
+ * [n_pts][3] (unit normals); dirs [n_lobes][32][3]: the sampled directions around every light lobe (inverRender.py:158-161);
+ * weights [n_lobes][32] = exp(lambda (d . axis - 1)) (:186).  vis [n_lobes][n_pts] = sum_s [n . d_s > 1e-6] Lvis(p, d_s) w_s /
+ * (sum_s w_s + 1e-6)  (:169-188).  One 32-sample MFMA tile per (point, lobe) pair: n_dirs must be 32.                      */
+int fneus_lvis_visibility(const void* lvis_blob, const float* points, const float* normals, const float* dirs,
+                          const float* weights, int n_pts, int n_lobes, int n_dirs, float* vis, int prec, fneus_stream_t stream);
 
 /* ---- K7: background NeRF++ of the womask configurations  (fields.py:233-259 NeRF.forward via renderer.py:112-149) ---- */
 /* pts4 [n][4] = (p/|p|, 1/|p|) of the background samples, dirs [n][3]; outputs are RAW: density [n] (alpha_linear) and

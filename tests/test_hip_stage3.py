@@ -1,7 +1,6 @@
 """GPU parity of stage 3 (NeuSRenderer.mateIllu_render -> EnvmapMaterialNetwork.forward, renderer.py:630-726,
 inverRender.py:83-598; training step of mateIllu.py:135-203) against a fixture produced by the reference itself
-(tests/golden/mateillu_render_b24_n32.npz).  Tolerance 1e-4 absolute on smooth quantities; the primary hit point sits behind
-the hierarchical sampler and a zero-crossing search, so per-ray outputs get 3e-4 (what the CPU oracle shows vs the reference)."""
+(tests/golden/mateillu_render_b24_n32.npz).  Tolerance 1e-4 absolute (BASELINE.json north_star) on every output; observed <= 1.2e-5."""
 import os
 
 import numpy as np
@@ -52,11 +51,11 @@ def test_mateillu_render_vs_reference(golden_dir):
     c = lambda t: t.detach().cpu()
     assert np.array_equal(c(out["sdf_mask"]).numpy(), g["out/sdf_mask"])
     for k in ("n_out", "gt_specular_linear", "gt_diffuse_srgb"):
-        assert (c(out[k]) - T(g["out/" + k])).abs().max().item() <= 3e-4, k
+        assert (c(out[k]) - T(g["out/" + k])).abs().max().item() <= 1e-4, k
     worst = {}
     for k in RAY_KEYS:
         worst[k] = (c(out[k]) - T(g["out/" + k])).abs().max().item()
-        assert worst[k] <= 3e-4, (k, worst[k])
+        assert worst[k] <= 1e-4, (k, worst[k])      # observed <= 1.2e-5
     print("  worst abs differences:", {k: f"{v:.1e}" for k, v in worst.items()})
     miss = ~T(g["out/sdf_mask"])
     assert bool((c(out["rgb"])[miss] == 1.0).all())
@@ -96,7 +95,7 @@ def test_light_visibility_vs_reference_trace(golden_dir):
                                  u_theta=T(g["step0/u_theta"]).to(DEV), u_phi=T(g["step0/u_phi"]).to(DEV))
     d = (vis.cpu() - T(g["trace/light_vis"])).abs()
     print(f"  light visibility vs the reference: worst {d.max().item():.2e}, mean {d.mean().item():.2e}")
-    assert d.max().item() <= 3e-4
+    assert d.max().item() <= 1e-4                # observed 2e-6
 
 
 def test_stage3_adam_steps_match_reference(golden_dir):
@@ -135,3 +134,40 @@ def test_stage3_step_at_full_size_properties():
     res = tr.renderer.mateIllu_render(batch[:, :3].contiguous(), batch[:, 3:6].contiguous(), None, None)
     assert float(res["rgb"].min()) >= 0.0 and float(res["rgb"].max()) <= 1.0
     assert bool((res["rgb"][~res["sdf_mask"]] == 1.0).all())
+
+
+def test_fused_lvis_visibility_vs_library_path():
+    """fneus_lvis_visibility (one MFMA tile per (point, lobe) pair, back-facing lobes skipped, weighted average in the
+    epilogue) against the same network through the library GEMMs, at the full stage-3 shape"""
+    from fneus import ops, synth
+    from models.fields import Lvis
+    from models.inverRender import visibility_sample_dirs
+    dev = torch.device(DEV)
+    net = Lvis()
+    net.load_state_dict({k: T(v) for k, v in synth.lvis_state_dict(31).items()})
+    net.to(dev)
+    g = torch.Generator().manual_seed(9)
+    n = 301
+    pts = (torch.randn(n, 3, generator=g) * 0.35).to(dev)
+    nrm = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(dev)
+    sg = T(synth.mateillu_state_dict(32)["lgtSGs"]).to(dev)
+    lobes = sg[:, :3] / (sg[:, :3].norm(dim=-1, keepdim=True) + 1e-6)
+    dirs, w = visibility_sample_dirs(lobes, sg[:, 3:4].abs(), 32, torch.rand(128, 32, generator=g).to(dev),
+                                     torch.rand(128, 32, generator=g).to(dev))
+    ref = net._visibility_library(pts, nrm, dirs.contiguous(), w.contiguous())
+    got = net.visibility(pts, nrm, dirs.contiguous(), w.contiguous())
+    assert got.shape == ref.shape == (128, n)
+    d = (got - ref).abs()
+    print(f"  fused visibility vs library GEMMs: worst {d.max().item():.2e}; {(ref == 0).float().mean().item() * 100:.0f} % of the lobes face away")
+    assert d.max().item() <= 1e-4
+    assert torch.equal(got == 0, ref == 0)
+    net.set_precision(ops.PREC_FAST)
+    fast = net.visibility(pts, nrm, dirs.contiguous(), w.contiguous())
+    assert (fast - ref).abs().max().item() <= 3e-2
+    # a changed weight is re-packed
+    net.set_precision(ops.PREC_PARITY)
+    with torch.no_grad():
+        net.lvis[8].bias.add_(0.5)
+    again = net.visibility(pts, nrm, dirs.contiguous(), w.contiguous())
+    assert (again - net._visibility_library(pts, nrm, dirs.contiguous(), w.contiguous())).abs().max().item() <= 1e-4
+    assert (again - got).abs().max().item() > 1e-3

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-kernel HIP-event times of one training step (eager launches): python tools/step_profile.py [wmask|womask|stage2] [parity|fast]"""
+"""Per-kernel HIP-event times of one training step (eager launches): python tools/step_profile.py [wmask|womask|stage2|stage3] [parity|fast]"""
 import copy
 import os
 import sys
@@ -19,6 +19,10 @@ batches = synthetic_batches(8, 512, dev)
 if which == "stage2":
     from fneus.trainer2 import Stage2Trainer
     tr = Stage2Trainer(dev, prec=prec)
+    step = lambda b: tr.train_step(b)
+elif which == "stage3":
+    from fneus.trainer3 import Stage3Trainer
+    tr = Stage3Trainer(dev, prec=prec)
     step = lambda b: tr.train_step(b)
 else:
     conf = copy.deepcopy(WMASK_MODEL)
