@@ -58,24 +58,25 @@ struct ColStash {                       // fragment planes (include/fneus.h Fneu
           feat_hi((unsigned char*)s.feat_hi), feat_lo((unsigned char*)s.feat_lo) {}
 };
 
-struct NerfStash {
-    __bf16* pe_hi;   __bf16* pe_lo;     // [N][96]     PE10 of the 4-D background point (84 columns used)
-    __bf16* h_hi;    __bf16* h_lo;      // [8][N][256] slot l = relu output of pts_linears.l
-    __bf16* feat_hi; __bf16* feat_lo;   // [N][256]    feature_linear output
-    __bf16* dpe_hi;  __bf16* dpe_lo;    // [N][32]     PE4 of the view direction (27 columns used)
-    __bf16* hv_hi;   __bf16* hv_lo;     // [N][128]    relu output of views_linears.0
+struct NerfStash {      // fragment planes (fneus_pp.h): [tiles][F fragments][64 slots][8 bf16]; *_lo NULL unless gradient precision 3
+    unsigned char *pe_hi, *pe_lo;       // F = 6   PE10 of the 4-D background point (84 features used)
+    unsigned char *h_hi, *h_lo;         // [8][tiles][16] slot l = relu output of pts_linears.l
+    unsigned char *feat_hi, *feat_lo;   // F = 16  feature_linear output
+    unsigned char *dpe_hi, *dpe_lo;     // F = 2   PE4 of the view direction (27 features used)
+    unsigned char *hv_hi, *hv_lo;       // F = 8   relu output of views_linears.0
     u32x4* mask;                        // lane-private ReLU masks: [tiles][9][64] x 128 bits (slot 8: views layer)
-    __bf16* zbar_hi; __bf16* zbar_lo;   // [8][N][256] slot l = dL/dz of pts_linears.l          (written by the backward)
-    __bf16* zfeat_hi; __bf16* zfeat_lo; // [N][256]    dL/d feature
-    __bf16* zhv_hi;  __bf16* zhv_lo;    // [N][128]    dL/dz of views_linears.0
-    __bf16* zout_hi; __bf16* zout_lo;   // [N][64]     columns 0..2 = dL/d rgb, column 32 = dL/d density
+    unsigned char *zbar_hi, *zbar_lo;   // [8][tiles][16] slot l = dL/dz of pts_linears.l     (written by the backward)
+    unsigned char *zfeat_hi, *zfeat_lo; // F = 16  dL/d feature
+    unsigned char *zhv_hi, *zhv_lo;     // F = 8   dL/dz of views_linears.0
+    unsigned char *zout_hi, *zout_lo;   // F = 4   fragments 0, 1: rows 0..2 = dL/d rgb; fragments 2, 3: row 0 = dL/d density
     NerfStash() { memset(this, 0, sizeof(*this)); }
     NerfStash(const FneusNerfStash& s)
-        : pe_hi((__bf16*)s.pe_hi), pe_lo((__bf16*)s.pe_lo), h_hi((__bf16*)s.h_hi), h_lo((__bf16*)s.h_lo),
-          feat_hi((__bf16*)s.feat_hi), feat_lo((__bf16*)s.feat_lo), dpe_hi((__bf16*)s.dpe_hi), dpe_lo((__bf16*)s.dpe_lo),
-          hv_hi((__bf16*)s.hv_hi), hv_lo((__bf16*)s.hv_lo), mask((u32x4*)s.mask), zbar_hi((__bf16*)s.zbar_hi),
-          zbar_lo((__bf16*)s.zbar_lo), zfeat_hi((__bf16*)s.zfeat_hi), zfeat_lo((__bf16*)s.zfeat_lo),
-          zhv_hi((__bf16*)s.zhv_hi), zhv_lo((__bf16*)s.zhv_lo), zout_hi((__bf16*)s.zout_hi), zout_lo((__bf16*)s.zout_lo) {}
+        : pe_hi((unsigned char*)s.pe_hi), pe_lo((unsigned char*)s.pe_lo), h_hi((unsigned char*)s.h_hi), h_lo((unsigned char*)s.h_lo),
+          feat_hi((unsigned char*)s.feat_hi), feat_lo((unsigned char*)s.feat_lo), dpe_hi((unsigned char*)s.dpe_hi),
+          dpe_lo((unsigned char*)s.dpe_lo), hv_hi((unsigned char*)s.hv_hi), hv_lo((unsigned char*)s.hv_lo), mask((u32x4*)s.mask),
+          zbar_hi((unsigned char*)s.zbar_hi), zbar_lo((unsigned char*)s.zbar_lo), zfeat_hi((unsigned char*)s.zfeat_hi),
+          zfeat_lo((unsigned char*)s.zfeat_lo), zhv_hi((unsigned char*)s.zhv_hi), zhv_lo((unsigned char*)s.zhv_lo),
+          zout_hi((unsigned char*)s.zout_hi), zout_lo((unsigned char*)s.zout_lo) {}
 };
 
 FN_DEV void load_point(const PointSrc& s, long n, float (&x)[3]) {

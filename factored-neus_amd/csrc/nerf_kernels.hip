@@ -5,11 +5,14 @@
 //            -> alpha_linear 1 (raw density) | feature_linear 256 -> [feature | PE4(view) 27] -> Linear 128 + ReLU -> rgb 3
 //   output : raw density [N] and raw rgb [N][3]  (softplus / sigmoid / compositing stay with the caller)
 // Inputs carry no gradient (every z is produced under no_grad, renderer.py:425-449), so the backward is the descending
-// chain only; it writes the dL/dz planes, the weight gradients are one fneus_dw_gemm launch over the stash planes.
+// chain only; it writes the dL/dz planes, the weight gradients are one fneus_dw_gemm_pp launch over the stash planes.
+// Everything the weight-gradient GEMM reads leaves as FRAGMENT PLANES (fneus_pp.h): the B fragments a layer's activations
+// are converted into anyway, stored straight from registers (one 16-byte store per lane and fragment; hi plane, lo plane
+// only in the exact-gradient mode).
 // Same wave-local MFMA engine as the SDF / colour kernels: one wavefront carries a 32-sample tile through the whole net.
 #define FNEUS_PREFETCH_X3 4
 #define FNEUS_PREFETCH_X1 8
-#include "mlp_engine.h"
+#include "pp_engine.h"
 #include "fneus_kernels.h"
 
 namespace fneus {
@@ -58,40 +61,20 @@ FN_DEV void apply_mask(f32x16 (&acc)[TN], const u32x4 m, bool valid) {
         }
 }
 
-// B fragments KS0.. -> columns of a narrow row-major plane [N][ld] (direct 8-byte stores; the planes are small)
-template <int PREC, int KS>
-FN_DEV void store_frag_plane(const BFrag<PREC> (&b)[kMaxKS], int ks0, __bf16* __restrict__ hi, __bf16* __restrict__ lo, int ld,
-                             long n, int h) {
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const int col = 16 * ks + 8 * g + 4 * h;
-            bf16x4 vh, vl;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                vh[e] = b[ks0 + ks].hi[4 * g + e];
-                if constexpr (PREC == 3) vl[e] = b[ks0 + ks].lo[4 * g + e];
-            }
-            *reinterpret_cast<bf16x4*>(hi + n * ld + col) = vh;
-            if constexpr (PREC == 3) *reinterpret_cast<bf16x4*>(lo + n * ld + col) = vl;
-        }
-}
-
 template <int PREC, bool TRAIN>
 __global__ void __launch_bounds__(64, 1) nerf_fwd_kernel(const unsigned char* blob, const float* __restrict__ pts4,
                                                          const float* __restrict__ dirs, long N, NerfStash st,
                                                          float* __restrict__ density, float* __restrict__ rgb) {
-    __shared__ __attribute__((aligned(16))) unsigned char scr[kWaveScr];
     const int lane = threadIdx.x;
     const int r = lane & 31, h = lane >> 5;
+    const PPLane pl = pp_lane(lane);
+    const long tiles = pp_tiles(N);
     constexpr auto& LY = kNerfLayout;
     for (long tile = blockIdx.x; tile * 32 < N; tile += gridDim.x) {
         asm volatile("" : "+s"(blob));
         const long n = tile * 32 + r;
         const bool valid = n < N;
         const long nc = valid ? n : N - 1;
-        const long n0 = tile * 32;
         BFrag<PREC> bpe[kMaxKS];      // the encoding's 6 k-steps: layer 0 and again layer 5
         BFrag<PREC> bf[kMaxKS];
         {
@@ -102,7 +85,8 @@ __global__ void __launch_bounds__(64, 1) nerf_fwd_kernel(const unsigned char* bl
             vec_to_bfrag<PREC, kNerfPE, 6, 0>(pe, bpe, h);
         }
         if constexpr (TRAIN)
-            if (valid) store_frag_plane<PREC, 6>(bpe, 0, st.pe_hi, st.pe_lo, 96, nc, h);
+            frags_to_plane<PREC, 6>(bpe, 0, st.pe_hi + (size_t)tile * 6 * kFragBytes,
+                                    st.pe_lo ? st.pe_lo + (size_t)tile * 6 * kFragBytes : nullptr, pl, valid);
         f32x16 acc[9];
         f32x16(&a8)[8] = reinterpret_cast<f32x16(&)[8]>(acc);
         size_t mslot = (size_t)tile * 9 * 64 + lane;
@@ -111,12 +95,12 @@ __global__ void __launch_bounds__(64, 1) nerf_fwd_kernel(const unsigned char* bl
         dense<PREC, 6, 8, 0, 8>(blob, LY.L[0].fwd_hi, LY.L[0].fwd_lo, bpe, a8, lane);
         {
             const u32x4 m = relu_mask_tiles8(a8);
-            if constexpr (TRAIN) {
-                st.mask[mslot] = m;
-                store_stash<PREC, 8>(scr, lane, a8, st.h_hi, st.h_lo, 256, n0, N, 256);
-            }
+            if constexpr (TRAIN) st.mask[mslot] = m;
         }
         acc_to_bfrag<PREC, 8>(a8, bf);
+        if constexpr (TRAIN)
+            frags_to_plane<PREC, 16>(bf, 0, st.h_hi + (size_t)tile * kPPBlock, st.h_lo ? st.h_lo + (size_t)tile * kPPBlock : nullptr,
+                                     pl, valid);
         // pts_linears.1 .. 7 (pack entries 1..5, 7, 8; entry 6 = the encoding's columns of pts_linears.5)
         for (int l = 1; l <= 7; ++l) {
             asm volatile("" : "+s"(blob));
@@ -125,18 +109,21 @@ __global__ void __launch_bounds__(64, 1) nerf_fwd_kernel(const unsigned char* bl
             dense<PREC, 16, 8, 0, 8>(blob, LY.L[e].fwd_hi, LY.L[e].fwd_lo, bf, a8, lane);
             if (l == 5) dense<PREC, 6, 8, 0, 8>(blob, LY.L[6].fwd_hi, LY.L[6].fwd_lo, bpe, a8, lane);
             const u32x4 m = relu_mask_tiles8(a8);
-            if constexpr (TRAIN) {
-                st.mask[mslot + (size_t)l * 64] = m;
-                store_stash<PREC, 8>(scr, lane, a8, st.h_hi + (size_t)l * N * 256, st.h_lo + (size_t)l * N * 256, 256, n0, N, 256);
-            }
+            if constexpr (TRAIN) st.mask[mslot + (size_t)l * 64] = m;
             acc_to_bfrag<PREC, 8>(a8, bf);
+            if constexpr (TRAIN) {
+                const size_t off = ((size_t)l * tiles + tile) * kPPBlock;
+                frags_to_plane<PREC, 16>(bf, 0, st.h_hi + off, st.h_lo ? st.h_lo + off : nullptr, pl, valid);
+            }
         }
         // feature_linear (tiles 0..7) and alpha_linear (tile 8, row 0): no activation (fields.py:248-249)
         load_accvec<9, 0, 9>(blob, LY.L[9].bias, acc, lane);
         dense<PREC, 16, 9, 0, 9>(blob, LY.L[9].fwd_hi, LY.L[9].fwd_lo, bf, acc, lane);
         if (valid && lane < 32) density[n] = acc[8][0];
-        if constexpr (TRAIN) store_stash<PREC, 8>(scr, lane, a8, st.feat_hi, st.feat_lo, 256, n0, N, 256);
         acc_to_bfrag<PREC, 8>(a8, bf);
+        if constexpr (TRAIN)
+            frags_to_plane<PREC, 16>(bf, 0, st.feat_hi + (size_t)tile * kPPBlock,
+                                     st.feat_lo ? st.feat_lo + (size_t)tile * kPPBlock : nullptr, pl, valid);
         {
             float d[3], pe[kViewPE], jc[kViewPE];
 #pragma unroll
@@ -145,7 +132,8 @@ __global__ void __launch_bounds__(64, 1) nerf_fwd_kernel(const unsigned char* bl
             vec_to_bfrag<PREC, kViewPE, 2, 16>(pe, bf, h);
         }
         if constexpr (TRAIN)
-            if (valid) store_frag_plane<PREC, 2>(bf, 16, st.dpe_hi, st.dpe_lo, 32, nc, h);
+            frags_to_plane<PREC, 2>(&bf[16], 0, st.dpe_hi + (size_t)tile * 2 * kFragBytes,
+                                    st.dpe_lo ? st.dpe_lo + (size_t)tile * 2 * kFragBytes : nullptr, pl, valid);
         // views_linears.0: [feature | PE4(view)] -> 128, ReLU
         f32x16 v[4];
         load_accvec<4, 0, 4>(blob, LY.L[10].bias, v, lane);
@@ -160,12 +148,12 @@ __global__ void __launch_bounds__(64, 1) nerf_fwd_kernel(const unsigned char* bl
                     v[t][rr] = pos ? v[t][rr] : 0.0f;
                     m[t >> 1] |= (pos ? 1u : 0u) << ((t & 1) * 16 + rr);
                 }
-            if constexpr (TRAIN) {
-                st.mask[mslot + (size_t)8 * 64] = m;
-                store_stash<PREC, 4>(scr, lane, v, st.hv_hi, st.hv_lo, 128, n0, N, 128);
-            }
+            if constexpr (TRAIN) st.mask[mslot + (size_t)8 * 64] = m;
         }
         acc_to_bfrag<PREC, 4>(v, bf);
+        if constexpr (TRAIN)
+            frags_to_plane<PREC, 8>(bf, 0, st.hv_hi + (size_t)tile * 8 * kFragBytes,
+                                    st.hv_lo ? st.hv_lo + (size_t)tile * 8 * kFragBytes : nullptr, pl, valid);
         f32x16 o[1];
         load_accvec<1, 0, 1>(blob, LY.L[11].bias, o, lane);
         dense<PREC, 8, 1, 0, 1>(blob, LY.L[11].fwd_hi, LY.L[11].fwd_lo, bf, o, lane);
@@ -179,16 +167,16 @@ __global__ void __launch_bounds__(64, 1) nerf_fwd_kernel(const unsigned char* bl
 template <int PREC>
 __global__ void __launch_bounds__(64, 1) nerf_bwd_kernel(const unsigned char* blob, long N, const float* __restrict__ d_density,
                                                          const float* __restrict__ d_rgb, NerfStash st) {
-    __shared__ __attribute__((aligned(16))) unsigned char scr[kWaveScr];
     const int lane = threadIdx.x;
     const int r = lane & 31, h = lane >> 5;
+    const PPLane pl = pp_lane(lane);
+    const long tiles = pp_tiles(N);
     constexpr auto& LY = kNerfLayout;
     for (long tile = blockIdx.x; tile * 32 < N; tile += gridDim.x) {
         asm volatile("" : "+s"(blob));
         const long n = tile * 32 + r;
         const bool valid = n < N;
         const long nc = valid ? n : N - 1;
-        const long n0 = tile * 32;
         const size_t mslot = (size_t)tile * 9 * 64 + lane;
         BFrag<PREC> bf[kMaxKS];
         // the two narrow cotangent tiles: rows 0..2 of tile 0 = d rgb, row 0 of tile 1 = d density
@@ -199,31 +187,39 @@ __global__ void __launch_bounds__(64, 1) nerf_bwd_kernel(const unsigned char* bl
             for (int c = 0; c < 3; ++c) zo[0][c] = d_rgb[nc * 3 + c];
             zo[1][0] = d_density[nc];
         }
-        store_stash<PREC, 2>(scr, lane, zo, st.zout_hi, st.zout_lo, 64, n0, N, 64);
+        unsigned char* zo_hi = st.zout_hi + (size_t)tile * 4 * kFragBytes;      // zout block: fragments 0, 1 = the rgb tile,
+        unsigned char* zo_lo = st.zout_lo ? st.zout_lo + (size_t)tile * 4 * kFragBytes : nullptr;    // 2, 3 = the density tile
         acc_to_bfrag<PREC, 1>(reinterpret_cast<f32x16(&)[1]>(zo[0]), bf);
+        frags_to_plane<PREC, 2>(bf, 0, zo_hi, zo_lo, pl, valid);
         // rgb_linear reverse: 2 k-steps -> 4 row tiles (the 128 view-branch features), then ReLU' of views_linears.0
         f32x16 v[4];
         zero_acc(v);
         dense<PREC, 2, 4, 0, 4>(blob, LY.L[11].rev_hi, LY.L[11].rev_lo, bf, v, lane);
         apply_mask<4>(v, st.mask[mslot + (size_t)8 * 64], valid);
-        store_stash<PREC, 4>(scr, lane, v, st.zhv_hi, st.zhv_lo, 128, n0, N, 128);
         acc_to_bfrag<PREC, 4>(v, bf);
+        frags_to_plane<PREC, 8>(bf, 0, st.zhv_hi + (size_t)tile * 8 * kFragBytes,
+                                st.zhv_lo ? st.zhv_lo + (size_t)tile * 8 * kFragBytes : nullptr, pl, valid);
         // views_linears.0 reverse onto its 256 feature inputs = dL/d feature (feature_linear has no activation)
         f32x16 a8[8];
         zero_acc(a8);
         dense<PREC, 8, 8, 0, 8>(blob, LY.L[10].rev_hi, LY.L[10].rev_lo, bf, a8, lane);
-        store_stash<PREC, 8>(scr, lane, a8, st.zfeat_hi, st.zfeat_lo, 256, n0, N, 256);
         acc_to_bfrag<PREC, 8>(a8, bf);
+        frags_to_plane<PREC, 16>(bf, 0, st.zfeat_hi + (size_t)tile * kPPBlock,
+                                 st.zfeat_lo ? st.zfeat_lo + (size_t)tile * kPPBlock : nullptr, pl, valid);
         acc_to_bfrag<PREC, 1, 16>(reinterpret_cast<f32x16(&)[1]>(zo[1]), bf);      // k-steps 16, 17: the density row
+        frags_to_plane<PREC, 2>(&bf[16], 2, zo_hi, zo_lo, pl, valid);
         // feature_linear^T dfeature + alpha_linear^T ddensity -> dL/d h_7
         zero_acc(a8);
         dense<PREC, 18, 8, 0, 8>(blob, LY.L[9].rev_hi, LY.L[9].rev_lo, bf, a8, lane);
         for (int l = 7; l >= 0; --l) {
             asm volatile("" : "+s"(blob));
             apply_mask<8>(a8, st.mask[mslot + (size_t)l * 64], valid);
-            store_stash<PREC, 8>(scr, lane, a8, st.zbar_hi + (size_t)l * N * 256, st.zbar_lo + (size_t)l * N * 256, 256, n0, N, 256);
+            acc_to_bfrag<PREC, 8>(a8, bf);
+            {
+                const size_t off = ((size_t)l * tiles + tile) * kPPBlock;
+                frags_to_plane<PREC, 16>(bf, 0, st.zbar_hi + off, st.zbar_lo ? st.zbar_lo + off : nullptr, pl, valid);
+            }
             if (l > 0) {
-                acc_to_bfrag<PREC, 8>(a8, bf);
                 const int e = l < 6 ? l : l + 1;       // pack entry of pts_linears.l (its h columns for l = 5)
                 zero_acc(a8);
                 dense<PREC, 16, 8, 0, 8>(blob, LY.L[e].rev_hi, LY.L[e].rev_lo, bf, a8, lane);
@@ -255,7 +251,6 @@ extern "C" int fneus_nerf_bg_fwd(const void* blob, const float* pts4, const floa
     const unsigned char* b = reinterpret_cast<const unsigned char*>(blob);
     NerfStash st = stash ? NerfStash(*stash) : NerfStash();
     if (train && (!st.pe_hi || !st.h_hi || !st.feat_hi || !st.dpe_hi || !st.hv_hi || !st.mask)) return -2;
-    if (train && prec == 3 && (!st.pe_lo || !st.h_lo || !st.feat_lo || !st.dpe_lo || !st.hv_lo)) return -2;
     dim3 grid(nerf_grid((n_pts + 31) / 32)), blk(64);
     if (prec == 3 && train)
         hipLaunchKernelGGL((nerf_fwd_kernel<3, true>), grid, blk, 0, stream, b, pts4, dirs, n_pts, st, density, rgb);
@@ -278,7 +273,6 @@ extern "C" int fneus_nerf_bg_bwd(const void* blob, long n_pts, const float* d_de
     if (!blob || !d_density || !d_rgb || !stash) return -2;
     NerfStash st(*stash);
     if (!st.mask || !st.zbar_hi || !st.zfeat_hi || !st.zhv_hi || !st.zout_hi) return -2;
-    if (prec == 3 && (!st.zbar_lo || !st.zfeat_lo || !st.zhv_lo || !st.zout_lo)) return -2;
     const unsigned char* b = reinterpret_cast<const unsigned char*>(blob);
     dim3 grid(nerf_grid((n_pts + 31) / 32)), blk(64);
     if (prec == 3)

@@ -147,7 +147,7 @@ class NerfFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, net, pts4, dirs, prec: int, ws: _Workspace, train: bool):
         n = int(pts4.shape[0])
-        stash = ws.get(("nerf_stash", n, prec), lambda: ops.NerfStash(n, anchor.device, prec)) if train else None
+        stash = ws.get(("nerf_stash", n, prec), lambda: ops.NerfStash(n, anchor.device, prec, gprec=ws.gprec)) if train else None
         density, rgb = ops.nerf_fwd(net.blob, n, prec, pts4, dirs, stash, train)
         ctx.net, ctx.prec, ctx.ws, ctx.stash, ctx.n = net, prec, ws, stash, n
         ctx.generation = ws.stamp(stash) if stash is not None else None
@@ -162,7 +162,7 @@ class NerfFn(torch.autograd.Function):
         d_rgb = torch.zeros(n, 3, device=dev) if d_rgb is None else d_rgb.contiguous()
         ops.nerf_bwd(net.blob, n, prec, d_density, d_rgb, ctx.stash)
         jobs = ws.get(("nerf_jobs", n, prec), lambda: ops.nerf_dw_jobs(net, ctx.stash, n))
-        jobs.run(n, prec)
+        jobs.run()
         return None, None, None, None, None, None, None
 
 

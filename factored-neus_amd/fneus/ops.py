@@ -562,14 +562,19 @@ def color_dw_jobs(net: PackedNet, feat_planes: torch.Tensor, stash: ColStash, gr
 # K7: background NeRF++ (womask)
 # ------------------------------------------------------------------------------------------------------------
 class NerfStash:
-    """bf16 activation planes of fneus_nerf_bg_fwd / _bwd (include/fneus.h FneusNerfStash)."""
+    """fragment planes of fneus_nerf_bg_fwd / _bwd (include/fneus.h FneusNerfStash): [P, (layer,) tiles, F, 64, 8] bf16,
+    P = 1 (hi; gradient precision 1) or 2 (hi + lo)"""
 
-    def __init__(self, n: int, device, prec: int):
+    def __init__(self, n: int, device, prec: int, gprec: Optional[int] = None):
+        from . import pp
         bf = torch.bfloat16
-        planes = 2 if prec == 3 else 1
-        z = lambda *shape: torch.zeros((planes,) + shape, dtype=bf, device=device)
-        self.pe, self.h, self.feat, self.dpe, self.hv = z(n, 96), z(8, n, 256), z(n, 256), z(n, 32), z(n, 128)
-        self.zbar, self.zfeat, self.zhv, self.zout = z(8, n, 256), z(n, 256), z(n, 128), z(n, 64)
+        self.gprec = _gprec(prec, gprec)
+        planes = 2 if self.gprec == 3 else 1
+        T = pp.alloc_tiles(n)
+        self.tiles = pp.n_tiles(n)
+        z = lambda *shape: torch.zeros((planes,) + shape + (64, 8), dtype=bf, device=device)
+        self.pe, self.h, self.feat, self.dpe, self.hv = z(T, 6), z(8, T, 16), z(T, 16), z(T, 2), z(T, 8)
+        self.zbar, self.zfeat, self.zhv, self.zout = z(8, T, 16), z(T, 16), z(T, 8), z(T, 4)
         self.mask = torch.zeros(((n + 31) // 32) * 9 * 64 * 4, dtype=torch.int32, device=device)
         s = _lib.FneusNerfStash()
         s.mask = self.mask.data_ptr()
@@ -598,10 +603,11 @@ def nerf_bwd(blob, n_pts, prec, d_density, d_rgb, stash: NerfStash):
             _stream())
 
 
-def nerf_dw_jobs(net: PackedNet, st: NerfStash, n: int) -> GemmJobs:
-    """weight / bias gradients of the 12 Linear layers, accumulated straight into net.raw_grad (plain layers: the raw
-    layout IS the effective one)"""
-    g = GemmJobs(net.raw_grad.device, "nerf")
+def nerf_dw_jobs(net: PackedNet, st: NerfStash, n: int) -> GemmPPJobs:
+    """weight / bias gradients of the 12 Linear layers from the fragment planes, accumulated straight into net.raw_grad
+    (plain layers: the raw layout IS the effective one)"""
+    g = GemmPPJobs(net.raw_grad.device, "nerf")
+    O = PPOperand
     d = net.desc
     P = {name: i for i, name in enumerate(d["names"])}
     base = net.raw_grad.data_ptr()
@@ -609,19 +615,20 @@ def nerf_dw_jobs(net: PackedNet, st: NerfStash, n: int) -> GemmJobs:
     Bv = lambda name: base + 4 * d["offB"][P[name]]
     zb = lambda l: st.zbar[:, l]
     hh = lambda l: st.h[:, l]
-    g.add(zb(0), st.pe, W("pts_linears.0"), 84, 256, 84, 256, 96, 256, 96, bias_ptr=Bv("pts_linears.0"))
+    g.add(O(zb(0), 0, 8), O(st.pe, 0, 3), W("pts_linears.0"), 84, 256, 84, bias_ptr=Bv("pts_linears.0"))
     for l in (1, 2, 3, 4, 6, 7):
-        g.add(zb(l), hh(l - 1), W(f"pts_linears.{l}"), 256, 256, 256, 256, 256, 256, 256, bias_ptr=Bv(f"pts_linears.{l}"))
+        g.add(O(zb(l), 0, 8), O(hh(l - 1), 0, 8), W(f"pts_linears.{l}"), 256, 256, 256, bias_ptr=Bv(f"pts_linears.{l}"))
     # pts_linears.5: columns [PE 84 | h 256] (fields.py:245)
-    g.add(zb(5), st.pe, W("pts_linears.5"), 340, 256, 84, 256, 96, 256, 96, bias_ptr=Bv("pts_linears.5"))
-    g.add(zb(5), hh(4), W("pts_linears.5", 84), 340, 256, 256, 256, 256, 256, 256)
-    g.add(st.zfeat, hh(7), W("feature_linear"), 256, 256, 256, 256, 256, 256, 256, bias_ptr=Bv("feature_linear"))
-    g.add(st.zout, hh(7), W("alpha_linear"), 256, 1, 256, 64, 256, 32, 256, bias_ptr=Bv("alpha_linear"), a_off=32)
+    g.add(O(zb(5), 0, 8), O(st.pe, 0, 3), W("pts_linears.5"), 340, 256, 84, bias_ptr=Bv("pts_linears.5"))
+    g.add(O(zb(5), 0, 8), O(hh(4), 0, 8), W("pts_linears.5", 84), 340, 256, 256)
+    g.add(O(st.zfeat, 0, 8), O(hh(7), 0, 8), W("feature_linear"), 256, 256, 256, bias_ptr=Bv("feature_linear"))
+    g.add(O(st.zout, 2, 1), O(hh(7), 0, 8), W("alpha_linear"), 256, 1, 256, bias_ptr=Bv("alpha_linear"))
     # views_linears.0: columns [feature 256 | PE4(view) 27]
-    g.add(st.zhv, st.feat, W("views_linears.0"), 283, 128, 256, 128, 256, 128, 256, bias_ptr=Bv("views_linears.0"))
-    g.add(st.zhv, st.dpe, W("views_linears.0", 256), 283, 128, 27, 128, 32, 128, 32)
-    g.add(st.zout, st.hv, W("rgb_linear"), 128, 3, 128, 64, 128, 32, 128, bias_ptr=Bv("rgb_linear"))
-    return g.finalize()
+    g.add(O(st.zhv, 0, 4), O(st.feat, 0, 8), W("views_linears.0"), 283, 128, 256, bias_ptr=Bv("views_linears.0"))
+    g.add(O(st.zhv, 0, 4), O(st.dpe, 0, 1), W("views_linears.0", 256), 283, 128, 27)
+    g.add(O(st.zout, 0, 1), O(st.hv, 0, 4), W("rgb_linear"), 128, 3, 128, bias_ptr=Bv("rgb_linear"))
+    g.gprec = st.gprec
+    return g.finalize(st.tiles)
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -60,7 +60,7 @@ class Stage1Trainer:
         for m in self.modules:
             m.to(device)
         self.sdf_network.set_precision(prec)
-        for m in (self.sdf_network, self.color_network, self.refColor_network):
+        for m in (self.sdf_network, self.color_network, self.refColor_network, self.nerf_outside):
             m.set_gradient_precision(gprec)                 # None: ops.DEFAULT_GPREC (bf16 planes)
         self.color_network.set_precision(prec)
         self.refColor_network.set_precision(prec)

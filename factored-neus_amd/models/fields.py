@@ -417,6 +417,12 @@ class NeRF(nn.Module):
         assert prec in (ops.PREC_FAST, ops.PREC_PARITY)
         self.prec = prec
 
+    def set_gradient_precision(self, gprec):
+        """1: bf16 stash planes for the weight-gradient GEMM (default), 3: hi + lo planes (fp32-accurate gradients)"""
+        if self._be is not None:
+            self._be.ws.gprec = gprec
+            self._be.ws.cache.clear()
+
     def n_raw(self) -> int:
         return sum(p.numel() for p in self.parameters())
 

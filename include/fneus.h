@@ -64,19 +64,20 @@ typedef struct FneusSdfBwdBufs {
     uint16_t* c_hi;    uint16_t* c_lo;    /* coupling terms between the two chains, lane-private: [tiles][8][16][64] x 16 bytes */
 } FneusSdfBwdBufs;
 
-/* Activation planes of the background NeRF++ (fneus_nerf_bg_fwd / _bwd); bf16 hi / lo planes, row-major, one row per
- * sample (the operands of the weight-gradient GEMM).  The *_lo pointers are NULL in bf16 mode. */
+/* Activation planes of the background NeRF++ (fneus_nerf_bg_fwd / _bwd): FRAGMENT PLANES like every other stash since
+ * round 2 (csrc/fneus_pp.h: [tiles][F fragments][64 slots][8 bf16], tiles = 2 ceil(n / 64), zero initialised), the operands
+ * of the weight-gradient GEMM fneus_dw_gemm_pp.  The *_lo pointers are NULL unless the gradient precision is 3. */
 typedef struct FneusNerfStash {
-    uint16_t *pe_hi, *pe_lo;       /* [n][96]     PE10 of the 4-D point, 84 columns used                           */
-    uint16_t *h_hi, *h_lo;         /* [8][n][256] slot l = relu output of pts_linears.l                           */
-    uint16_t *feat_hi, *feat_lo;   /* [n][256]    feature_linear output                                           */
-    uint16_t *dpe_hi, *dpe_lo;     /* [n][32]     PE4 of the view direction, 27 columns used                      */
-    uint16_t *hv_hi, *hv_lo;       /* [n][128]    relu output of views_linears.0                                  */
-    uint32_t* mask;                /* [tiles][9][64] x 4 words: ReLU sign bits, lane-private                      */
-    uint16_t *zbar_hi, *zbar_lo;   /* [8][n][256] dL/dz of pts_linears.l                 (written by the backward) */
-    uint16_t *zfeat_hi, *zfeat_lo; /* [n][256]    dL/d feature                                                    */
-    uint16_t *zhv_hi, *zhv_lo;     /* [n][128]    dL/dz of views_linears.0                                        */
-    uint16_t *zout_hi, *zout_lo;   /* [n][64]     columns 0..2 = dL/d rgb, column 32 = dL/d density               */
+    void *pe_hi, *pe_lo;       /* F = 6   PE10 of the 4-D point, 84 features used                              */
+    void *h_hi, *h_lo;         /* [8][tiles][16] slot l = relu output of pts_linears.l                         */
+    void *feat_hi, *feat_lo;   /* F = 16  feature_linear output                                                */
+    void *dpe_hi, *dpe_lo;     /* F = 2   PE4 of the view direction, 27 features used                          */
+    void *hv_hi, *hv_lo;       /* F = 8   relu output of views_linears.0                                       */
+    uint32_t* mask;            /* [tiles][9][64] x 4 words: ReLU sign bits, lane-private                       */
+    void *zbar_hi, *zbar_lo;   /* [8][tiles][16] dL/dz of pts_linears.l              (written by the backward) */
+    void *zfeat_hi, *zfeat_lo; /* F = 16  dL/d feature                                                         */
+    void *zhv_hi, *zhv_lo;     /* F = 8   dL/dz of views_linears.0                                             */
+    void *zout_hi, *zout_lo;   /* F = 4   fragments 0, 1: rows 0..2 = dL/d rgb; fragments 2, 3: row 0 = dL/d density */
 } FneusNerfStash;
 
 /* One product of fneus_dw_gemm: C[m][n] += scale * sum_s (A[s][:m]^T B[s][:n] + A2^T B2); bias[m] += sum_s A[s][:m]. */
@@ -310,7 +311,7 @@ int fneus_nerf_bg_fwd(const void* nerf_blob, const float* pts4, const float* dir
                       float* rgb /*[n][3]*/, int prec, int train, fneus_stream_t stream);
 
 /* autograd of the above w.r.t. the parameters (the inputs are constants: every z is sampled under no_grad): writes the
- * dL/dz planes of the stash; the weight / bias gradients are then ONE fneus_dw_gemm launch over stash planes.          */
+ * dL/dz planes of the stash; the weight / bias gradients are then ONE fneus_dw_gemm_pp launch over stash planes.          */
 int fneus_nerf_bg_bwd(const void* nerf_blob, long n_pts, const float* d_density /*[n]*/, const float* d_rgb /*[n][3]*/,
                       const FneusNerfStash* stash, int prec, fneus_stream_t stream);
 

@@ -61,6 +61,7 @@ def build(g, prec, gprec=None):
         nerf = NeRF(D=8, d_in=4, d_in_view=3, W=256, multires=10, multires_view=4, output_ch=4, skips=[4], use_viewdirs=True)
         nerf.load_state_dict({k: T(v) for k, v in synth.nerf_state_dict(int(g["seed_nerf"])).items()})
         nerf.to(DEV)
+        nerf.set_gradient_precision(gprec)
     rnd = NeuSRenderer(int(g["n_samples"]), int(g["n_importance"]), int(g["n_outside"]), 4, 1.0, nerf=nerf,
                        sdf_network=sdf, deviation_network=var, color_network=col, refColor_network=ref)
     return rnd, dict(sdf=sdf, color=col, var=var, refcolor=ref, nerf=nerf)
