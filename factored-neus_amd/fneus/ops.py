@@ -462,11 +462,15 @@ class PPOperand:
         return self.planes[p].data_ptr()
 
 
+GEMM_COST_FLOOR = int(_os.environ.get("FNEUS_GEMM_FLOOR", "16"))     # in 32-row tiles of A + B (a full product: 16)
+
+
 class GemmPPJobs:
     """Device job table for fneus_dw_gemm_pp (include/fneus.h FneusGemmPPJob); pointers refer to live plane tensors."""
 
-    def __init__(self, device, tag="", target_wgs: int = 256):
+    def __init__(self, device, tag="", target_wgs: int = 256, cost_floor: Optional[int] = None):
         self.device, self.tag, self.target = device, tag, target_wgs
+        self.cost_floor = GEMM_COST_FLOOR if cost_floor is None else cost_floor
         self.jobs, self.bytes = [], []
         self.dev_table, self.n_wgs = None, 0
 
@@ -482,17 +486,26 @@ class GemmPPJobs:
             j.a2_blk, j.b2_blk, j.a2_f0, j.b2_f0 = A2.blk, B2.blk, A2.f0, B2.f0
         j.mt, j.nt, j.c, j.bias, j.ldc, j.m, j.n, j.scale = A.tiles, B.tiles, c_ptr, bias_ptr, ldc, m, n, scale
         self.jobs.append(j)
-        self.bytes.append((A.tiles + B.tiles) * 2048 * (2 if A2 is not None else 1))
+        # cost of one sample tile of this job, for the workgroup distribution.  The kernel's work per stage does not shrink
+        # with a narrow operand (a stage always DMAs and multiplies full 16-fragment parts; there are no branches in its
+        # loop), so every product costs the same: floor = 16 tiles.  Measured (A/B on one box, floors 0 / 8 / 12 / 16): SDF
+        # 0.31 / 0.30 / 0.25 / 0.25 ms, background NeRF (jobs as narrow as 1 + 4 tiles) 0.43 / 0.27 / 0.22 / 0.21 ms.
+        self.bytes.append(max(A.tiles + B.tiles, self.cost_floor) * 2048 * (2 if A2 is not None else 1))
         return self
 
     def finalize(self, n_sample_tiles: int, min_tiles: int = 4):
         """distribute ~target workgroups over the jobs in proportion to the bytes each streams; a workgroup owns at least
         `min_tiles` sample tiles (its epilogue is up to 65 536 atomics whatever it summed)"""
         tot = float(sum(self.bytes))
-        base = 0
         cap = max(1, n_sample_tiles // min_tiles)
-        for j, b in zip(self.jobs, self.bytes):
-            s = max(1, min(cap, int(round(self.target * b / tot))))
+        splits = [max(1, min(cap, int(round(self.target * b / tot)))) for b in self.bytes]
+        # the kernel keeps ONE workgroup per CU (128 KB of LDS): a launch of more than `target` workgroups needs a second
+        # round for the few extra ones and takes nearly twice as long (measured: 258 workgroups 0.39 ms, 238 0.29 ms).
+        # Rounding must therefore never push the total over the target: trim the jobs with the most splits.
+        while sum(splits) > self.target and max(splits) > 1:
+            splits[max(range(len(splits)), key=lambda i: splits[i])] -= 1
+        base = 0
+        for j, s in zip(self.jobs, splits):
             j.wg_base, j.splits = base, s
             base += s
         self.n_wgs, self.n_sample_tiles = base, n_sample_tiles
