@@ -682,6 +682,64 @@ __global__ void __launch_bounds__(256) gen_rays_grid_kernel(const float* __restr
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// womask background branch, render_core_outside (renderer.py:112-149): the element-wise work around the NeRF++ kernels (K7)
+// ---------------------------------------------------------------------------------------------------------------
+// sections of the merged depths, inverted-sphere points (p / |p|, 1 / |p|) with |p| clipped to [1, 1e10], view directions
+__global__ void __launch_bounds__(256) outside_points_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                             const float* __restrict__ z, int n_rays, int nt, float sample_dist,
+                                                             float* __restrict__ pts4, float* __restrict__ dirs,
+                                                             float* __restrict__ dists) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)n_rays * nt) return;
+    const int ray = (int)(idx / nt), i = (int)(idx - (long)ray * nt);
+    const float z0 = z[idx];
+    const float dist = i + 1 < nt ? __fadd_rn(z[idx + 1], -z0) : sample_dist;          // :121-122
+    const float mid = __fadd_rn(z0, __fmul_rn(dist, 0.5f));                              // :123
+    float p[3], s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        p[c] = __fadd_rn(rays_o[ray * 3 + c], __fmul_rn(rays_d[ray * 3 + c], mid));      // :126
+        s = __fadd_rn(s, __fmul_rn(p[c], p[c]));
+        dirs[idx * 3 + c] = rays_d[ray * 3 + c];
+    }
+    const float dis = fminf(fmaxf(sqrtf(s), 1.0f), 1e10f);                               // :128
+#pragma unroll
+    for (int c = 0; c < 3; ++c) pts4[idx * 4 + c] = __fdiv_rn(p[c], dis);                // :129
+    pts4[idx * 4 + 3] = __fdiv_rn(1.0f, dis);
+    dists[idx] = dist;
+}
+
+FN_DEV float softplus1(float x) { return x > 20.0f ? x : log1pf(expf(x)); }              // F.softplus defaults (beta 1, threshold 20)
+
+// alpha = 1 - exp(-softplus(density) * dist), colour = sigmoid(raw)                      (renderer.py:137-138)
+__global__ void __launch_bounds__(256) outside_alpha_fwd_kernel(const float* __restrict__ density, const float* __restrict__ raw,
+                                                                const float* __restrict__ dists, long n, float* __restrict__ alpha,
+                                                                float* __restrict__ rgb) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    alpha[idx] = 1.0f - expf(-softplus1(density[idx]) * dists[idx]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rgb[idx * 3 + c] = 1.0f / (1.0f + expf(-raw[idx * 3 + c]));
+}
+
+__global__ void __launch_bounds__(256) outside_alpha_bwd_kernel(const float* __restrict__ density, const float* __restrict__ rgb,
+                                                                const float* __restrict__ dists, const float* __restrict__ d_alpha,
+                                                                const float* __restrict__ d_rgb, long n,
+                                                                float* __restrict__ d_density, float* __restrict__ d_raw) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const float x = density[idx], dist = dists[idx];
+    const float dsp = x > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-x));                       // softplus'
+    d_density[idx] = d_alpha ? d_alpha[idx] * dist * expf(-softplus1(x) * dist) * dsp : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float y = rgb[idx * 3 + c];
+        d_raw[idx * 3 + c] = d_rgb ? d_rgb[idx * 3 + c] * y * (1.0f - y) : 0.0f;
+    }
+}
+
 }  // namespace fneus
 
 using namespace fneus;
@@ -846,5 +904,36 @@ extern "C" int fneus_gen_rays_grid(const float* intrinsics_inv, const float* pos
     if (total <= 0) return 0;
     hipLaunchKernelGGL(gen_rays_grid_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, intrinsics_inv, pose, tx, ty,
                        nx, ny, rays_o, rays_v);
+    return fneus::launch_status();
+}
+
+extern "C" int fneus_outside_points(const float* rays_o, const float* rays_d, const float* z, int n_rays, int nt, float sample_dist,
+                                    float* pts4, float* dirs, float* dists, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    const long total = (long)n_rays * nt;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(outside_points_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, rays_o, rays_d, z, n_rays, nt,
+                       sample_dist, pts4, dirs, dists);
+    return fneus::launch_status();
+}
+
+extern "C" int fneus_outside_alpha_fwd(const float* density, const float* rgb_raw, const float* dists, long n, float* alpha,
+                                       float* rgb, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(outside_alpha_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, density, rgb_raw, dists, n,
+                       alpha, rgb);
+    return fneus::launch_status();
+}
+
+extern "C" int fneus_outside_alpha_bwd(const float* density, const float* rgb, const float* dists, const float* d_alpha,
+                                       const float* d_rgb, long n, float* d_density, float* d_rgb_raw, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(outside_alpha_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, density, rgb, dists, d_alpha,
+                       d_rgb, n, d_density, d_rgb_raw);
     return fneus::launch_status();
 }

@@ -105,6 +105,9 @@ def _load():
         "fneus_split_batch": (C.c_int, [vp, ip, vp, vp, vp, vp, vp]),
         "fneus_gen_random_rays": (C.c_int, [vp, vp, vp, vp, ip, ip, vp, vp, ip, vp, vp]),
         "fneus_gen_rays_grid": (C.c_int, [vp, vp, vp, vp, ip, ip, vp, vp, vp]),
+        "fneus_outside_points": (C.c_int, [vp, vp, vp, ip, ip, f, vp, vp, vp, vp]),
+        "fneus_outside_alpha_fwd": (C.c_int, [vp, vp, vp, l, vp, vp, vp]),
+        "fneus_outside_alpha_bwd": (C.c_int, [vp, vp, vp, vp, vp, l, vp, vp, vp]),
         "fneus_lvis_visibility": (C.c_int, [vp, vp, vp, vp, vp, ip, ip, ip, vp, ip, vp]),
         "fneus_ray_hit": (C.c_int, [vp] * 7 + [ip, ip, f] + [vp] * 5 + [vp]),
         "fneus_sample_dirs": (C.c_int, [vp] * 4 + [ip, ip, vp, vp, vp]),

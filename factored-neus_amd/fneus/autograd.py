@@ -166,6 +166,26 @@ class NerfFn(torch.autograd.Function):
         return None, None, None, None, None, None, None
 
 
+class OutsideAlphaFn(torch.autograd.Function):
+    """alpha = 1 - exp(-softplus(density) dist), colour = sigmoid(raw) of the background samples (renderer.py:137-138): one
+    launch forward, one backward, instead of ~20 element-wise kernels on [B, n + n_outside] tensors"""
+
+    @staticmethod
+    def forward(ctx, density, rgb_raw, dists):
+        density, rgb_raw, dists = density.contiguous(), rgb_raw.contiguous(), dists.contiguous()
+        alpha, rgb = ops.outside_alpha_fwd(density, rgb_raw, dists)
+        ctx.save_for_backward(density, rgb, dists)
+        ctx.set_materialize_grads(False)
+        return alpha, rgb
+
+    @staticmethod
+    def backward(ctx, d_alpha, d_rgb):
+        density, rgb, dists = ctx.saved_tensors
+        d_density, d_raw = ops.outside_alpha_bwd(density, rgb, dists, None if d_alpha is None else d_alpha.contiguous(),
+                                                 None if d_rgb is None else d_rgb.contiguous())
+        return d_density, d_raw, None
+
+
 class RefHeadsFn(torch.autograd.Function):
     """Both MLPs of RefColor (fields.py:303-330) on the gathered surface samples: one forward launch, one backward
     launch, one weight-gradient GEMM launch for the two networks.  Differentiable inputs: normal, feature."""

@@ -697,6 +697,36 @@ def upsample(rays_o, rays_d, z, sdf, k: int, inv_s: float):
     return out
 
 
+def outside_points(rays_o, rays_d, z_feed, sample_dist: float):
+    """render_core_outside's geometry (renderer.py:121-131) -> pts4 [B*nt,4], dirs [B*nt,3], dists [B,nt]"""
+    B, nt = z_feed.shape
+    dev = z_feed.device
+    pts4 = torch.empty(B * nt, 4, dtype=torch.float32, device=dev)
+    dirs = torch.empty(B * nt, 3, dtype=torch.float32, device=dev)
+    dists = torch.empty(B, nt, dtype=torch.float32, device=dev)
+    _launch("fneus_outside_points", lib.fneus_outside_points, _ptr(rays_o), _ptr(rays_d), _ptr(z_feed), B, nt, float(sample_dist),
+            _ptr(pts4), _ptr(dirs), _ptr(dists), _stream())
+    return pts4, dirs, dists
+
+
+def outside_alpha_fwd(density, rgb_raw, dists):
+    n = int(density.numel())
+    alpha = torch.empty(n, dtype=torch.float32, device=density.device)
+    rgb = torch.empty(n, 3, dtype=torch.float32, device=density.device)
+    _launch("fneus_outside_alpha_fwd", lib.fneus_outside_alpha_fwd, _ptr(density), _ptr(rgb_raw), _ptr(dists), n, _ptr(alpha),
+            _ptr(rgb), _stream())
+    return alpha, rgb
+
+
+def outside_alpha_bwd(density, rgb, dists, d_alpha, d_rgb):
+    n = int(density.numel())
+    d_density = torch.empty(n, dtype=torch.float32, device=density.device)
+    d_raw = torch.empty(n, 3, dtype=torch.float32, device=density.device)
+    _launch("fneus_outside_alpha_bwd", lib.fneus_outside_alpha_bwd, _ptr(density), _ptr(rgb), _ptr(dists), _ptr(d_alpha), _ptr(d_rgb),
+            n, _ptr(d_density), _ptr(d_raw), _stream())
+    return d_density, d_raw
+
+
 def lvis_visibility(blob, points, normals, dirs, weights, prec: int):
     """get_diffuse_visibility's network part (inverRender.py:163-190) -> vis [M, n]; dirs [M, 32, 3], weights [M, 32]"""
     n, M, S = points.shape[0], dirs.shape[0], dirs.shape[1]

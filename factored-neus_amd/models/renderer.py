@@ -19,7 +19,7 @@ import torch.nn.functional as F
 
 from fneus import ops
 from models.mesh import extract_fields, extract_geometry      # noqa: F401  module-level API of renderer.py:14-40
-from fneus.autograd import CompositeFn, RaySamples, SurfaceGatherFn, Stage1LossFn
+from fneus.autograd import CompositeFn, OutsideAlphaFn, RaySamples, SurfaceGatherFn, Stage1LossFn
 
 
 def sample_pdf(bins, weights, n_samples, det=False):
@@ -104,20 +104,19 @@ class NeuSRenderer:
         return z_vals
 
     # ---- render_core_outside (renderer.py:112-149): inverted-sphere background NeRF++, womask configs only --------
-    def render_core_outside(self, rays_o, rays_d, z_vals, sample_dist, nerf, background_rgb=None):
+    def render_core_outside(self, rays_o, rays_d, z_vals, sample_dist, nerf, background_rgb=None, full=True):
         """The background network runs on the fused K7 kernels (models/fields.py NeRF -> fneus_nerf_bg_fwd / _bwd); the
-        inverted-sphere points, softplus / sigmoid and this branch's own weights are element-wise torch ops on
-        [B, n] tensors; the blend with the foreground is inside the HIP compositing kernels."""
+        inverted-sphere points (fneus_outside_points) and softplus / sigmoid / alpha (fneus_outside_alpha_fwd / _bwd) are one
+        launch each; the blend with the foreground is inside the HIP compositing kernels.  full=False (what render() asks
+        for): only `sampled_color` and `alpha`, the two entries the reference's render() consumes (renderer.py:455-458) --
+        this branch's own weights and colour are dead code on that path."""
         B, n = z_vals.shape
-        dists = torch.cat([z_vals[:, 1:] - z_vals[:, :-1], torch.full_like(z_vals[:, :1], sample_dist)], -1)
-        mid_z = z_vals + dists * 0.5
-        pts = rays_o[:, None, :] + rays_d[:, None, :] * mid_z[..., None]
-        dis = torch.linalg.norm(pts, ord=2, dim=-1, keepdim=True).clip(1.0, 1e10)
-        pts4 = torch.cat([pts / dis, 1.0 / dis], dim=-1).reshape(-1, 4)
-        dirs = rays_d[:, None, :].expand(B, n, 3).reshape(-1, 3)
-        density, rgb = nerf(pts4, dirs)
-        rgb = torch.sigmoid(rgb).reshape(B, n, 3)
-        alpha = 1.0 - torch.exp(-F.softplus(density.reshape(B, n)) * dists)
+        pts4, dirs, dists = ops.outside_points(rays_o.contiguous(), rays_d.contiguous(), z_vals.contiguous(), sample_dist)
+        density, rgb_raw = nerf(pts4, dirs)
+        alpha, rgb = OutsideAlphaFn.apply(density.reshape(-1), rgb_raw, dists.reshape(-1))
+        alpha, rgb = alpha.reshape(B, n), rgb.reshape(B, n, 3)
+        if not full:
+            return {"sampled_color": rgb, "alpha": alpha}
         one = torch.ones([B, 1], device=z_vals.device)
         weights = alpha * torch.cumprod(torch.cat([one, 1.0 - alpha + 1e-7], -1), -1)[:, :-1]
         color = (weights[:, :, None] * rgb).sum(dim=1)
@@ -243,8 +242,9 @@ class NeuSRenderer:
         ops.overlap_join()                   # the packs issued beside the sampler are needed from here on
         background_alpha = background_sampled_color = None
         if self.n_outside > 0:                                                    # renderer.py:452-458
-            z_vals_feed, _ = torch.sort(torch.cat([z_vals, z_vals_outside.expand(B, -1)], dim=-1), dim=-1)
-            ret_outside = self.render_core_outside(rays_o, rays_d, z_vals_feed, sample_dist, self.nerf)
+            # sort(cat(z_vals, z_vals_outside)) of two sorted rows = one stable rank merge (fneus_merge)
+            z_vals_feed, _ = ops.merge(z_vals.contiguous(), None, z_vals_outside.expand(B, -1).contiguous(), None)
+            ret_outside = self.render_core_outside(rays_o, rays_d, z_vals_feed, sample_dist, self.nerf, full=False)
             background_sampled_color, background_alpha = ret_outside["sampled_color"], ret_outside["alpha"]
         ret = self.render_core(rays_o, rays_d, z_vals, sample_dist, self.sdf_network, self.deviation_network,
                                self.color_network, self.refColor_network, background_rgb=background_rgb,

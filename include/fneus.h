@@ -315,6 +315,18 @@ int fneus_nerf_bg_fwd(const void* nerf_blob, const float* pts4, const float* dir
 int fneus_nerf_bg_bwd(const void* nerf_blob, long n_pts, const float* d_density /*[n]*/, const float* d_rgb /*[n][3]*/,
                       const FneusNerfStash* stash, int prec, fneus_stream_t stream);
 
+/* ---- the element-wise work of render_core_outside around K7 (renderer.py:112-149) ------------------------------------ */
+/* z [B][nt]: the merged inside + outside depths (renderer.py:453).  -> dists [B][nt] (last section = sample_dist), pts4
+ * [B*nt][4] = (p / |p|, 1 / |p|) at the section mid points with |p| clipped to [1, 1e10], dirs [B*nt][3] = the ray direction. */
+int fneus_outside_points(const float* rays_o, const float* rays_d, const float* z, int n_rays, int nt, float sample_dist,
+                         float* pts4, float* dirs, float* dists, fneus_stream_t stream);
+/* alpha = 1 - exp(-softplus(density) dist), rgb = sigmoid(rgb_raw) (renderer.py:137-138) and the adjoint (d_alpha / d_rgb may
+ * be NULL = zero) */
+int fneus_outside_alpha_fwd(const float* density, const float* rgb_raw, const float* dists, long n, float* alpha, float* rgb,
+                            fneus_stream_t stream);
+int fneus_outside_alpha_bwd(const float* density, const float* rgb, const float* dists, const float* d_alpha, const float* d_rgb,
+                            long n, float* d_density, float* d_rgb_raw, fneus_stream_t stream);
+
 /* ---- K5: NeuS SDF->alpha, front-to-back compositing, eikonal sums, first sign change
  *      (renderer.py:245-274, 290-293, 328-332, 360-372).  Per-ray outputs: color [B][3], wsum/wmax [B],
  *      eik [2][B] = (sum relax*(|g|-1)^2 ; sum relax), min_idx [B], sdf_mask [B] (u8), wpair [B][2] = inside-sphere
