@@ -270,7 +270,7 @@ FN_DEV void acc_to_bfrag(const f32x16 (&acc)[TN], BFrag<PREC> (&b)[kMaxKS]) {
 
 // ---------------------------------------------------------------------------------------------------------
 // Row-major [N][LD] bf16 "stash" matrices (hi plane / lo plane): the operands of the weight-gradient GEMM
-// (dw_gemm.hip).  In accumulator layout a lane holds 4 consecutive features of ONE sample per register group, i.e.
+// (the round-1 GEMM).  In accumulator layout a lane holds 4 consecutive features of ONE sample per register group, i.e.
 // 8-byte pieces scattered over 32 rows; written directly that costs one memory-pipeline pass per 64-byte line
 // (measured: the stash traffic, not the MFMA chain, dominates K2/K3).  Stores therefore go through a per-wave LDS
 // image [32 samples][256 features] (+8 bytes row padding: conflict-free both ways) and leave as whole 512-byte rows.

@@ -2,7 +2,7 @@
 //   K1 sdf_fwd        : PE -> 9 dense layers (Softplus beta=100) -> sdf                      (no-grad sampler path)
 //   K2 sdf_fwd_grad   : sdf, feature[256], normal = d sdf/dx (analytic reverse sweep) + bf16 stash for backward
 //   K3 sdf_bwd_chain  : double-backward chains (ascending + descending); writes the
-//                       operand matrices of the weight-gradient GEMM (dw_gemm.hip)
+//                       operand planes of the weight-gradient GEMM (dw_gemm_pp.hip)
 // One wavefront = 32 samples, whole chain register resident; weights come pre-packed from pack.hip (L2 resident).
 #include <stdlib.h>
 #include "pp_engine.h"

@@ -44,15 +44,6 @@ class FneusAdamSegment(C.Structure):
                 ("count", C.c_long)]
 
 
-class FneusGemmJob(C.Structure):
-    _fields_ = [("a_hi", C.c_void_p), ("a_lo", C.c_void_p), ("b_hi", C.c_void_p), ("b_lo", C.c_void_p),
-                ("a2_hi", C.c_void_p), ("a2_lo", C.c_void_p), ("b2_hi", C.c_void_p), ("b2_lo", C.c_void_p),
-                ("c", C.c_void_p), ("bias", C.c_void_p),
-                ("lda", C.c_int), ("ldb", C.c_int), ("lda2", C.c_int), ("ldb2", C.c_int), ("ldc", C.c_int),
-                ("m", C.c_int), ("n", C.c_int), ("a_w", C.c_int), ("a2_mode", C.c_int),
-                ("scale", C.c_float), ("tile_base", C.c_int), ("b_w", C.c_int)]
-
-
 class FneusGemmPPJob(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("a_hi", "a_lo", "b_hi", "b_lo", "a2_hi", "a2_lo", "b2_hi", "b2_lo")] + \
                [(n, C.c_uint32) for n in ("a_blk", "b_blk", "a2_blk", "b2_blk")] + \
@@ -90,7 +81,6 @@ def _load():
                                               C.POINTER(FneusColStash), vp, vp, ip, ip, vp]),
         "fneus_refcolor_bwd_both": (C.c_int, [vp, vp, l, vp, ip, vp, vp, vp, vp, vp, vp, C.POINTER(FneusColStash),
                                               C.POINTER(FneusColStash), vp, vp, ip, vp]),
-        "fneus_dw_gemm": (C.c_int, [vp, ip, ip, l, ip, vp]),
         "fneus_dw_gemm_pp": (C.c_int, [vp, ip, ip, l, ip, vp]),
         "fneus_nerf_bg_fwd": (C.c_int, [vp, vp, vp, l, C.POINTER(FneusNerfStash), vp, vp, ip, ip, vp]),
         "fneus_nerf_bg_bwd": (C.c_int, [vp, l, vp, vp, C.POINTER(FneusNerfStash), ip, vp]),

@@ -401,49 +401,6 @@ def refcolor_bwd_both(blob_cd, blob_vd, n_pts, prec, d_diffuse, d_spec, diffuse,
     return d_feat2, d_normal2
 
 
-class GemmJobs:
-    """Device job table for fneus_dw_gemm.  Built once per (buffers, N); pointers refer to live stash tensors."""
-
-    def __init__(self, device, tag=""):
-        self.tag = tag
-        self.jobs = []
-        self.tiles = 0
-        self.device = device
-        self.dev_table = None
-
-    @staticmethod
-    def _pl(t, plane, off=0):
-        """address of plane `plane` of a [planes, ...] bf16 tensor view + element offset"""
-        if t is None:
-            return None
-        if plane >= t.shape[0]:
-            return None
-        return t[plane].data_ptr() + 2 * off
-
-    def add(self, A, B, c_ptr, ldc, m, n, lda, ldb, a_w, b_w, A2=None, B2=None, lda2=0, ldb2=0, a2_mode=0,
-            bias_ptr=None, scale=1.0, a_off=0, b_off=0, a2_off=0, b2_off=0):
-        j = _lib.FneusGemmJob()
-        j.a_hi, j.a_lo = self._pl(A, 0, a_off), self._pl(A, 1, a_off)
-        j.b_hi, j.b_lo = self._pl(B, 0, b_off), self._pl(B, 1, b_off)
-        j.a2_hi, j.a2_lo = self._pl(A2, 0, a2_off), self._pl(A2, 1, a2_off)
-        j.b2_hi, j.b2_lo = self._pl(B2, 0, b2_off), self._pl(B2, 1, b2_off)
-        j.c, j.bias = c_ptr, bias_ptr
-        j.lda, j.ldb, j.lda2, j.ldb2, j.ldc = lda, ldb, lda2, ldb2, ldc
-        j.m, j.n, j.a_w, j.b_w, j.a2_mode, j.scale = m, n, a_w, b_w, a2_mode, scale
-        j.tile_base = self.tiles
-        self.tiles += ((m + 255) // 256) * ((n + 255) // 256)
-        self.jobs.append(j)
-
-    def finalize(self):
-        arr = (_lib.FneusGemmJob * len(self.jobs))(*self.jobs)
-        raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
-        self.dev_table = torch.from_numpy(raw).to(self.device)
-        return self
-
-    def run(self, n_samples: int, prec: int):
-        _launch("fneus_dw_gemm:" + self.tag, lib.fneus_dw_gemm, _ptr(self.dev_table), len(self.jobs), self.tiles, n_samples, prec, _stream())
-
-
 class PPOperand:
     """One operand of a fragment-plane product: planes [P, tiles, F, 64, 8] bf16 (P = 1: hi, 2: hi + lo), the first
     fragment `f0` of the operand inside a block and its tile count; const = the same block for every sample tile."""
@@ -514,7 +471,7 @@ class GemmPPJobs:
         return self
 
     def run(self, *_ignored, gprec: Optional[int] = None):
-        """(positional arguments of the row-major GemmJobs.run(n, prec) are accepted and ignored)"""
+        """(positional arguments are accepted and ignored: older callers passed n and prec)"""
         gprec = getattr(self, "gprec", 1) if gprec is None else gprec
         _launch("fneus_dw_gemm_pp:" + self.tag, lib.fneus_dw_gemm_pp, _ptr(self.dev_table), len(self.jobs), self.n_wgs,
                 self.n_sample_tiles, gprec, _stream())

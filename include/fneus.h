@@ -80,21 +80,6 @@ typedef struct FneusNerfStash {
     void *zout_hi, *zout_lo;   /* F = 4   fragments 0, 1: rows 0..2 = dL/d rgb; fragments 2, 3: row 0 = dL/d density */
 } FneusNerfStash;
 
-/* One product of fneus_dw_gemm: C[m][n] += scale * sum_s (A[s][:m]^T B[s][:n] + A2^T B2); bias[m] += sum_s A[s][:m]. */
-typedef struct FneusGemmJob {
-    const uint16_t *a_hi, *a_lo, *b_hi, *b_lo;     /* segment 1 (bf16 planes, row-major, one row per sample)   */
-    const uint16_t *a2_hi, *a2_lo, *b2_hi, *b2_lo; /* segment 2 or NULL                                        */
-    float* c;                                      /* fp32 [m][ldc], accumulated with atomics                  */
-    float* bias;                                   /* fp32 [m] or NULL                                         */
-    int32_t lda, ldb, lda2, ldb2, ldc;
-    int32_t m, n;
-    int32_t a_w;       /* readable row width (elements, multiple of 8) of A / A2 from the given pointer         */
-    int32_t a2_mode;   /* 1: A2 is implicit (column 0 == 1)                                                      */
-    float scale;
-    int32_t tile_base; /* index of this job's first 128x128 tile in the launch                                  */
-    int32_t b_w;       /* readable row width of B / B2                                                           */
-} FneusGemmJob;
-
 /* One product of fneus_dw_gemm_pp over FRAGMENT PLANES (csrc/fneus_pp.h): a plane holds, per 32-sample tile, the MFMA B
  * fragments of a layer's activations as the chain kernels produce them (1 KiB each = 16 features x 32 samples).
  * C[o][i] += scale * sum_tiles (A^T B + A2^T B2); bias[o] += sum_samples A[s][o].  *_lo planes (same layout) carry the
@@ -142,7 +127,7 @@ int fneus_rowscale(const void* rows, int n_rows, const float* raw, float* rowsca
                    fneus_stream_t stream);
 /* backward of the fold: effective-parameter gradients d_eff (W then b per layer) -> ACCUMULATED into the raw
  * parameter gradients d_raw (weight_v, weight_g, bias); bias_segs: device int4 (src_off, dst_off, count, 0).
- * d_eff is consumed: it is all zeros afterwards (ready for the atomics of the next fneus_dw_gemm). */
+ * d_eff is consumed: it is all zeros afterwards (ready for the atomics of the next fneus_dw_gemm_pp). */
 int fneus_wn_backward(const void* rows, int n_rows, const void* bias_segs, int n_segs, const float* raw,
                       const float* rowscale, const float* invnorm, float* d_eff, float* d_raw,
                       fneus_stream_t stream);
@@ -160,17 +145,14 @@ int fneus_sdf_fwd_grad(const void* sdf_blob, const float* pts, const float* rays
 
 /* ---- K3: autograd of K2 w.r.t. the SDF weights, incl. the double backward through SDFNetwork.gradient
  *      (create_graph=True, fields.py:104-110).  Consumes the K2 stash, writes the planes in `bufs`; the weight
- *      gradients themselves are produced by fneus_dw_gemm from those planes. */
+ *      gradients themselves are produced by fneus_dw_gemm_pp from those planes. */
 int fneus_sdf_bwd(const void* sdf_blob, const float* pts, const float* rays_o, const float* rays_d, const float* t,
                   int m, long n_pts, const FneusSdfStash* stash, const FneusSdfBwdBufs* bufs, const float* d_sdf /*[n]*/,
                   const float* d_feat /*[n][256]*/, const float* d_normal /*[n][3]*/, int prec, fneus_stream_t stream);
 
 /* ---- weight-gradient GEMM (split-K over samples, fp32 atomics into zero-initialised C / bias) ------------------ */
-int fneus_dw_gemm(const void* jobs_dev /*FneusGemmJob[n_jobs] on the device*/, int n_jobs, int n_tiles, long n_samples,
-                  int prec, fneus_stream_t stream);
-
-/* The same products over fragment planes (FneusGemmPPJob): what the SDF network's backward uses.  n_wgs = sum of the jobs'
- * `splits`; gprec 1 = hi planes only (bf16 operands, fp32 accumulation), 3 = hi + lo planes (hi*hi + hi*lo + lo*hi).
+/* Products over fragment planes (FneusGemmPPJob): every weight gradient of the five MLPs.  n_wgs = sum of the jobs'
+ * `splits` (at most the CU count: one workgroup per CU); gprec 1 = hi planes only (bf16 operands, fp32 accumulation), 3 = hi + lo planes (hi*hi + hi*lo + lo*hi).
  * Replaces torch autograd's addmm backward for fields.py:86 incl. the double-backward term of fields.py:104-110.       */
 int fneus_dw_gemm_pp(const void* jobs_dev /*FneusGemmPPJob[n_jobs] on the device*/, int n_jobs, int n_wgs,
                      long n_sample_tiles, int gprec, fneus_stream_t stream);
