@@ -325,9 +325,10 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_fast_extra:
         # stage 2 (BASELINE configs[2], lvis.py:132-196): 512 primary rays x (64+64), 4 secondary rays per hit point x 512
-        # coarse SDF samples on K1, Lvis + IndirectLight trained with Adam.  Eager launches (the hit count is read per step).
+        # coarse SDF samples on K1, Lvis + IndirectLight trained with Adam.  Fixed-shape step (every ray treated as a hit point,
+        # masked afterwards) replayed as one hipGraph, like the headline step.
         from fneus.trainer2 import Stage2Trainer
-        tr2 = Stage2Trainer(device, prec=prec)
+        tr2 = Stage2Trainer(device, prec=prec, use_graph=not args.no_graph)
         sb = synthetic_batches(14, RAYS, device, rank=rank)
         hits = []
         for b in sb[:4]:
@@ -343,13 +344,15 @@ def main():
         n_hit = float(torch.stack(hits).float().mean()) if hits else 0.0
         result["stage2_step"] = {"value": 4 * n_hit * 512 / dt_2, "unit": "secondary-ray SDF samples/s", "ms_per_step": dt_2 * 1e3,
                                  "primary_rays": RAYS, "mean_hit_points": n_hit, "secondary_rays": 4 * n_hit,
+                                 "launch": "one hipGraph replay per step (fixed shape: 4 x 512 secondary rays marched, misses masked)"
+                                           if tr2.use_graph else "eager launches, hit points compacted",
                                  "note": "lvis_render + L1 losses + backward + Adam (lvis.py:132-196): 4 secondary rays per hit "
                                          "point x 512 coarse samples through K1, 32 fine samples through K2, same precision mode"}
         del tr2
         # stage 3 (BASELINE configs[3], mateIllu.py:135-203): 512 primary rays, 128 light SGs x 32 directions = 4096 Lvis
         # evaluations per hit point, closed-form SG rendering, Adam over the EnvmapMaterialNetwork
         from fneus.trainer3 import Stage3Trainer
-        tr3 = Stage3Trainer(device, prec=prec)
+        tr3 = Stage3Trainer(device, prec=prec, use_graph=not args.no_graph)
         hits = []
         for b in sb[:4]:
             tr3.train_step(b)
@@ -364,6 +367,8 @@ def main():
         n_hit3 = float(torch.stack(hits).float().mean()) if hits else 0.0
         result["stage3_step"] = {"value": 4096 * n_hit3 / dt_3, "unit": "Lvis visibility evaluations/s", "ms_per_step": dt_3 * 1e3,
                                  "primary_rays": RAYS, "mean_hit_points": n_hit3,
+                                 "launch": "one hipGraph replay per step (fixed shape: all 512 rays evaluated, misses masked)"
+                                           if tr3.use_graph else "eager launches, hit points compacted",
                                  "note": "mateIllu_render + masked L1 + latent sparsity + backward + Adam (mateIllu.py:135-203): "
                                          "128 light lobes x 32 directions through Lvis per hit point, SG rendering of 128 + 24 lobes"}
         del tr3

@@ -268,201 +268,13 @@ FN_DEV void acc_to_bfrag(const f32x16 (&acc)[TN], BFrag<PREC> (&b)[kMaxKS]) {
             }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Row-major [N][LD] bf16 "stash" matrices (hi plane / lo plane): the operands of the weight-gradient GEMM
-// (the round-1 GEMM).  In accumulator layout a lane holds 4 consecutive features of ONE sample per register group, i.e.
-// 8-byte pieces scattered over 32 rows; written directly that costs one memory-pipeline pass per 64-byte line
-// (measured: the stash traffic, not the MFMA chain, dominates K2/K3).  Stores therefore go through a per-wave LDS
-// image [32 samples][256 features] (+8 bytes row padding: conflict-free both ways) and leave as whole 512-byte rows.
-// ---------------------------------------------------------------------------------------------------------
-// Stash stores stream out of the chip (nothing re-reads them within the kernel, except through their own lane-private
-// path much later): FNEUS_NT_STORES marks them non-temporal so that they do not displace the packed weights in L2.
-#ifndef FNEUS_NT_STORES
-#define FNEUS_NT_STORES 13     // measured (N = 65 536, parity mode): K2 961 -> 801 us, K3 1077 -> 931 us; with bit 1 as well K2 +4 %
-#endif
-// bit 0: row-major planes and the lane-private a_l (read by later kernels only), bit 1: sigma' (re-read by the reverse
-// sweep of the same kernel), bit 2: K3's coupling scratch (re-read by its descending chain)
+// fp32 rows that leave for (or arrive from) another kernel stream past the caches: non-temporal accesses keep them from
+// displacing the packed weights in L2
 template <int KIND, class T>
-FN_DEV T stream_load(const T* p) {      // bit 3: the lane-private planes are read once per pass and never hit a cache
-    if constexpr ((FNEUS_NT_STORES >> KIND) & 1)
-        return __builtin_nontemporal_load(p);
-    else
-        return *p;
-}
+FN_DEV T stream_load(const T* p) { return __builtin_nontemporal_load(p); }
 template <int KIND, class T>
-FN_DEV void stream_store(T* p, T v) {
-    if constexpr ((FNEUS_NT_STORES >> KIND) & 1)
-        __builtin_nontemporal_store(v, p);
-    else
-        *p = v;
-}
+FN_DEV void stream_store(T* p, T v) { __builtin_nontemporal_store(v, p); }
 
-constexpr int kScrStride = 520;
-constexpr int kScrPlane = 32 * kScrStride;               // 16 640
-constexpr int kWaveScr = 2 * kScrPlane;                  // 33 280 bytes of LDS per wavefront (hi and lo image)
-
-// order this wave's LDS accesses (compiler + hardware) without draining global memory traffic
-FN_DEV void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-
-#ifndef FNEUS_STASH_VIA_LDS
-#define FNEUS_STASH_VIA_LDS 1
-#endif
-template <int PREC, int TN>
-FN_DEV void store_stash(unsigned char* __restrict__ wscr, int lane, const f32x16 (&acc)[TN], __bf16* __restrict__ hi,
-                        __bf16* __restrict__ lo, int ld, long n0, long N, int ncols) {
-    const int r = lane & 31, h = lane >> 5;
-    constexpr int NPL = PREC == 3 ? 2 : 1;
-#if FNEUS_STASH_VIA_LDS
-    lds_fence();     // earlier readers of the scratch are done
-#pragma unroll
-    for (int t = 0; t < TN; ++t)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            bf16x4 vh, vl;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float v = acc[t][4 * g + e];
-                if constexpr (PREC == 3) {
-                    __bf16 a, b2;
-                    split_bf16(v, a, b2);
-                    vh[e] = a;
-                    vl[e] = b2;
-                } else {
-                    vh[e] = (__bf16)v;
-                }
-            }
-            unsigned char* dst = wscr + r * kScrStride + (32 * t + 8 * g + 4 * h) * 2;
-            *reinterpret_cast<bf16x4*>(dst) = vh;
-            if constexpr (PREC == 3) *reinterpret_cast<bf16x4*>(dst + kScrPlane) = vl;
-        }
-    lds_fence();
-    const int P = ncols >> 2;            // 8-byte pieces per row
-    const int total = 32 * P;
-#pragma unroll
-    for (int pl = 0; pl < NPL; ++pl) {
-        __bf16* __restrict__ plane = pl ? lo : hi;
-        for (int idx = lane; idx < total; idx += 64) {
-            const int row = idx / P, pc = idx - row * P;
-#ifdef FNEUS_DBG_NO_ROWSTORE   // timing experiments only (tools/experiments): keep the LDS traffic, drop the global stores
-            if (n0 + row < N && pc < 0)
-#else
-            if (n0 + row < N)
-#endif
-                stream_store<0>(reinterpret_cast<u32x2*>(plane + (n0 + row) * ld + pc * 4),
-                             *reinterpret_cast<const u32x2*>(wscr + pl * kScrPlane + row * kScrStride + pc * 8));
-        }
-    }
-#else
-    (void)wscr; (void)NPL;
-    const long n = n0 + r;
-    if (n >= N) return;
-#pragma unroll
-    for (int t = 0; t < TN; ++t)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int col = 32 * t + 8 * g + 4 * h;
-            if (col >= ncols) continue;
-            bf16x4 vh, vl;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float v = acc[t][4 * g + e];
-                if constexpr (PREC == 3) {
-                    __bf16 a, b2;
-                    split_bf16(v, a, b2);
-                    vh[e] = a;
-                    vl[e] = b2;
-                } else {
-                    vh[e] = (__bf16)v;
-                }
-            }
-            *reinterpret_cast<bf16x4*>(hi + n * ld + col) = vh;
-            if constexpr (PREC == 3) *reinterpret_cast<bf16x4*>(lo + n * ld + col) = vl;
-        }
-#endif
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Lane-private stash: values that only the SAME lane of the SAME tile reads back later (sigma'(z_l) for the reverse
-// sweep and the backward chains, a_l for the coupling term) live in a lane-linear layout
-//   [tile][layer][t*4+g][lane] x 4 values  ->  every access is one fully coalesced wave instruction.
-// Parity mode keeps them in fp32 (exact), fast mode in bf16.
-// ---------------------------------------------------------------------------------------------------------
-template <int PREC> struct PrivT { typedef f32x4 v4; };
-template <> struct PrivT<1> { typedef bf16x4 v4; };
-
-template <int PREC>
-FN_DEV void priv_put(void* __restrict__ base, int slot, int lane, const float (&v)[4]) {
-    typename PrivT<PREC>::v4 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        if constexpr (PREC == 3) o[e] = v[e];
-        else o[e] = (__bf16)v[e];
-    }
-#ifdef FNEUS_DBG_NO_PRIV
-    if (lane < 0)
-#endif
-    stream_store<0>(reinterpret_cast<typename PrivT<PREC>::v4*>(base) + slot * 64 + lane, o);
-}
-
-template <int PREC>
-FN_DEV void priv_get(const void* __restrict__ base, int slot, int lane, float (&v)[4]) {
-    const typename PrivT<PREC>::v4 o = stream_load<3>(reinterpret_cast<const typename PrivT<PREC>::v4*>(base) + slot * 64 + lane);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = (float)o[e];
-}
-
-// sigma'(z) in [0,1] as 16-bit fixed point (abs. error 7.6e-6): halves the hottest private plane, which is written once
-// and read three times (reverse sweep, ascending and descending backward chains)
-typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
-FN_DEV void sig_put(void* __restrict__ base, int slot, int lane, const float (&v)[4]) {
-    u16x4 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = (unsigned short)__float2uint_rn(fminf(fmaxf(v[e], 0.0f), 1.0f) * 65535.0f);
-#ifdef FNEUS_DBG_NO_PRIV
-    if (lane < 0)
-#endif
-    stream_store<1>(reinterpret_cast<u16x4*>(base) + slot * 64 + lane, o);
-}
-// STREAM: non-temporal load, for data written by an EARLIER kernel (K2 re-reads the sigma' it wrote itself: plain load)
-template <bool STREAM = false>
-FN_DEV void sig_get(const void* __restrict__ base, int slot, int lane, float (&v)[4]) {
-    const u16x4* p = reinterpret_cast<const u16x4*>(base) + slot * 64 + lane;
-    const u16x4 o = STREAM ? stream_load<3>(p) : *p;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = (float)o[e] * (1.0f / 65535.0f);
-}
-constexpr size_t kSigBlockBytes = 32 * 64 * sizeof(u16x4);   // one (tile, layer) block of the sigma' plane
-
-// bytes of one (tile, layer) block of a private stash
-template <int PREC>
-FN_DEV constexpr size_t priv_block_bytes() { return 32 * 64 * sizeof(typename PrivT<PREC>::v4); }
-
-template <int PREC, int TN>
-FN_DEV void load_stash(f32x16 (&acc)[TN], const __bf16* __restrict__ hi, const __bf16* __restrict__ lo, int ld, long n,
-                       int h, int col_limit) {
-#pragma unroll
-    for (int t = 0; t < TN; ++t)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int col = 32 * t + 8 * g + 4 * h;
-            if (col >= col_limit) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[t][4 * g + e] = 0.0f;
-                continue;
-            }
-            const bf16x4 vh = *reinterpret_cast<const bf16x4*>(hi + n * ld + col);
-            if constexpr (PREC == 3) {
-                const bf16x4 vl = *reinterpret_cast<const bf16x4*>(lo + n * ld + col);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[t][4 * g + e] = (float)vh[e] + (float)vl[e];
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[t][4 * g + e] = (float)vh[e];
-            }
-        }
-}
-
-// row-major fp32 [N][LD] store / load of accumulator tiles (4 consecutive floats per access)
 template <int TN>
 FN_DEV void store_f32(const f32x16 (&acc)[TN], float* __restrict__ dst, int ld, long n, int h, bool valid) {
     if (!valid) return;

@@ -1,7 +1,7 @@
 // Tensor-parallel workgroup helpers shared by the SDF and colour kernels: the 4 wavefronts of a workgroup share one
 // 32-sample tile, wave w owns output tiles 2w, 2w+1 of every layer; activated tiles are exchanged through LDS as ready-made
-// B fragments (k-step 2t+s of the next layer = half s of tile t) and, where a stash plane is due, assembled in a shared
-// [32][256] row image that the waves store cooperatively.  See sdf_kernels.hip (K1 / K2) for the design notes.
+// B fragments (k-step 2t+s of the next layer = half s of tile t); where a stash plane is due the same fragments are stored
+// to global memory as they are (pp_engine.h).  See sdf_kernels.hip (K1 / K2) for the design notes.
 #pragma once
 #include "mlp_engine.h"
 
@@ -44,59 +44,6 @@ FN_DEV void tp_gather(const unsigned char* frag, int lane, BFrag<PREC> (&bf)[kMa
     }
 }
 
-template <int PREC, int TN, bool FRAGS, bool IMG>
-FN_DEV void tp_exchange(unsigned char* frag, unsigned char* img, int lane, int t0,
-                        const f32x16 (&acc)[TN], const BFrag<PREC>* skip_frags = nullptr) {
-    constexpr int NPL = PREC == 3 ? 2 : 1;
-    const int r = lane & 31, h = lane >> 5;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // previous fragments / image rows are consumed
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int sh = 0; sh < 2; ++sh) {
-            bf16x8 hi, lo;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if constexpr (PREC == 3) {
-                    __bf16 a, b2;
-                    split_bf16(acc[i][8 * sh + j], a, b2);
-                    hi[j] = a;
-                    lo[j] = b2;
-                } else {
-                    hi[j] = (__bf16)acc[i][8 * sh + j];
-                }
-            }
-            if constexpr (FRAGS) {
-                const int ks = 2 * (t0 + i) + sh;
-                *reinterpret_cast<bf16x8*>(frag + (ks * NPL) * kFragBytes + lane * 16) = hi;
-                if constexpr (PREC == 3) *reinterpret_cast<bf16x8*>(frag + (ks * NPL + 1) * kFragBytes + lane * 16) = lo;
-            }
-            if constexpr (IMG) {   // registers 8sh + 4gg + e hold features 32t + 8(2sh + gg) + 4h + e of sample r
-#pragma unroll
-                for (int gg = 0; gg < 2; ++gg) {
-                    unsigned char* dst = img + r * kScrStride + (32 * (t0 + i) + 8 * (2 * sh + gg) + 4 * h) * 2;
-                    bf16x4 vh, vl;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        vh[e] = hi[4 * gg + e];
-                        if constexpr (PREC == 3) vl[e] = lo[4 * gg + e];
-                    }
-                    *reinterpret_cast<bf16x4*>(dst) = vh;
-                    if constexpr (PREC == 3) *reinterpret_cast<bf16x4*>(dst + kScrPlane) = vl;
-                }
-            }
-        }
-    if (skip_frags) {      // k-steps 14..16 of the next layer: the positional encoding (skip connection, fields.py:83-84)
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            *reinterpret_cast<bf16x8*>(frag + ((14 + i) * NPL) * kFragBytes + lane * 16) = skip_frags[i].hi;
-            if constexpr (PREC == 3)
-                *reinterpret_cast<bf16x8*>(frag + ((14 + i) * NPL + 1) * kFragBytes + lane * 16) = skip_frags[i].lo;
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // fragments and image are complete
-}
-
 #ifndef FNEUS_TP_DEPTH
 #define FNEUS_TP_DEPTH 4        // weight-prefetch depth of the tensor-parallel K2 (stages of 2 tiles); measured 2 / 3 / 4
 #endif
@@ -119,22 +66,6 @@ FN_DEV void tp_dense(const unsigned char* __restrict__ blob, uint32_t off_hi, ui
 template <int PREC, int KS>
 FN_DEV void tp_operands(const unsigned char* frag, int lane, BFrag<PREC> (&bf)[kMaxKS]) {
     if constexpr (!kTpLdsB<PREC>) tp_gather<PREC, KS>(frag, lane, bf);
-}
-
-// image rows -> row-major global planes; every wave takes a quarter of the 512-byte row units
-template <int PREC, int NCOLS>
-FN_DEV void tp_store_rows(const unsigned char* img, int lane, int wave, __bf16* __restrict__ hi,
-                          __bf16* __restrict__ lo, long n0, long N) {
-    constexpr int NPL = PREC == 3 ? 2 : 1;
-    constexpr int P = NCOLS / 4, UPP = 32 * P / 64;
-    for (int u = wave; u < UPP * NPL; u += 4) {
-        const int pl = u / UPP, idx = (u - pl * UPP) * 64 + lane;
-        const int row = idx / P, pc = idx - row * P;
-        __bf16* __restrict__ plane = pl ? lo : hi;
-        if (n0 + row < N)
-            stream_store<0>(reinterpret_cast<u32x2*>(plane + (n0 + row) * 256 + pc * 4),
-                         *reinterpret_cast<const u32x2*>(img + pl * kScrPlane + row * kScrStride + pc * 8));
-    }
 }
 
 }  // namespace fneus

@@ -29,7 +29,7 @@ def stage2_loss(out: dict):
 
 class Stage2Trainer:
     def __init__(self, device, model_conf: Optional[dict] = None, prec: int = ops.PREC_PARITY, lr: float = 5e-4, seed: int = 0,
-                 synthetic_init: bool = True, sdf_kwargs: Optional[dict] = None):
+                 synthetic_init: bool = True, sdf_kwargs: Optional[dict] = None, use_graph: bool = False):
         from models.fields import SDFNetwork, RenderingNetwork, SingleVarianceNetwork, RefColor, Lvis, IndirectLight
         from models.renderer import NeuSRenderer
         conf = model_conf or dict(WMASK_MODEL, lvis_renderer=LVIS_RENDERER)
@@ -56,22 +56,76 @@ class Stage2Trainer:
         self.color_network.set_precision(prec)
         # lvis.py:89-92
         self.params = list(self.lvis_network.parameters()) + list(self.indiLgt_network.parameters())
-        self.optimizer = torch.optim.Adam(self.params, lr=lr)
+        self._init_step_mode(use_graph, lr)
         self.renderer = NeuSRenderer(**conf.get("lvis_renderer", LVIS_RENDERER), sdf_network=self.sdf_network,
                                      deviation_network=self.deviation_network, color_network=self.color_network,
                                      lvis_network=self.lvis_network, indiLgt_network=self.indiLgt_network)
         self.iter_step = 0
 
+    # ---- launch mode (shared with fneus/trainer3.py) -----------------------------------------------------------------------
+    # use_graph: the step runs at FIXED SHAPE (every ray is treated as a hit point and masked afterwards: no host read of the
+    # hit count, no data-dependent shape) and is replayed as ONE hipGraph after two eager warm-up steps -- the ~600
+    # launch-bound element-wise kernels of the torch-side networks and losses then cost their GPU time only.  Differences a
+    # user can observe: a batch without any hit is not skipped (its loss and gradients are zero; Adam's moments still
+    # decay), the direction draws consume the generator per ray instead of per hit point.
+    def _init_step_mode(self, use_graph: bool, lr: float):
+        self.use_graph = bool(use_graph) and self.device.type == "cuda"
+        if self.use_graph:        # a device-scalar learning rate: schedule updates reach the replayed optimiser step
+            self.optimizer = torch.optim.Adam(self.params, lr=torch.tensor(float(lr), device=self.device), capturable=True)
+        else:
+            self.optimizer = torch.optim.Adam(self.params, lr=lr)
+        self._graph, self._eager_steps, self.graph_warmup_steps = None, 0, 2
+
     def set_lr(self, lr: float):
         for g in self.optimizer.param_groups:
-            g["lr"] = lr
+            if torch.is_tensor(g["lr"]):
+                g["lr"].fill_(float(lr))
+            else:
+                g["lr"] = lr
 
     def get_lr(self) -> float:
         return float(self.optimizer.param_groups[0]["lr"])
 
+    def _graph_step(self, data: torch.Tensor):
+        """fixed-shape step: eagerly while warming up, then captured once per batch shape and replayed"""
+        if self._graph is not None and self._graph[1].shape != data.shape:
+            self._graph = None
+        if self._graph is None:
+            if self._eager_steps < self.graph_warmup_steps:
+                self._eager_steps += 1
+                self.iter_step += 1
+                return self._fixed_shape_step(data)
+            import gc
+            static = data.clone()
+            gc.collect()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                losses = self._fixed_shape_step(static)
+            self._graph = (graph, static, losses)
+            graph.replay()           # the capture pass only records: run the step for this batch now
+            self.iter_step += 1
+            return losses
+        graph, static, losses = self._graph
+        static.copy_(data)
+        graph.replay()
+        self.iter_step += 1
+        return losses
+
+    def _fixed_shape_step(self, data: torch.Tensor):
+        rays_o, rays_d, _rgb, _mask = ops.split_batch(data.contiguous())
+        out = self.renderer.lvis_render(rays_o, rays_d, None, None, fixed_shape=True)
+        losses = stage2_loss(out)
+        self.optimizer.zero_grad(set_to_none=True)
+        losses["loss"].backward()
+        self.optimizer.step()
+        return {"n_hit": out["sdf_mask"].sum(), **{k: v.detach() for k, v in losses.items()}}
+
     def train_step(self, data: torch.Tensor, near=None, far=None, u_theta=None, u_z=None):
         """data [B,10] (dataset.py:133-151); near / far None: unit-sphere bounds.  -> loss dict, or None when no ray of
         the batch hits the surface (the reference skips such a batch, lvis.py:160-161)"""
+        if self.use_graph and near is None and u_theta is None:
+            return self._graph_step(data)
         rays_o, rays_d, _rgb, _mask = ops.split_batch(data.contiguous())
         out = self.renderer.lvis_render(rays_o, rays_d, near, far, u_theta=u_theta, u_z=u_z)
         if not bool(out["sdf_mask"].any()):

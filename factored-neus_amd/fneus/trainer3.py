@@ -19,17 +19,17 @@ from fneus.trainer import WMASK_MODEL
 
 def stage3_loss(out: dict, true_rgb, mask):
     """mateIllu.py:152-172 (mask = (mask > 0.5) when train.mask_weight > 0, else ones: the caller's business)"""
-    m = out["sdf_mask"]
-    denom = mask[m].sum() + 1e-5
-    diff = out["rgb"][m] - true_rgb[m]
-    rgb_loss = (diff * mask[m]).abs().sum() / denom
-    psnr = 20.0 * torch.log10(1.0 / ((diff ** 2 * mask[m]).sum() / (denom * 3.0)).sqrt())
+    w = mask * out["sdf_mask"][:, None].to(mask.dtype)          # rays that hit AND lie inside the image mask (no boolean
+    denom = w.sum() + 1e-5                                       # indexing: nothing here may synchronise with the host)
+    diff = out["rgb"] - true_rgb
+    rgb_loss = (diff * w).abs().sum() / denom
+    psnr = 20.0 * torch.log10(1.0 / ((diff ** 2 * w).sum() / (denom * 3.0)).sqrt())
     return {"loss": rgb_loss + out["encoder_loss"], "rgb_loss": rgb_loss, "encoder_loss": out["encoder_loss"], "psnr": psnr}
 
 
 class Stage3Trainer:
     def __init__(self, device, model_conf: Optional[dict] = None, prec: int = ops.PREC_PARITY, lr: float = 5e-4, seed: int = 0,
-                 synthetic_init: bool = True, mask_weight: float = 0.1):
+                 synthetic_init: bool = True, mask_weight: float = 0.1, use_graph: bool = False):
         from models.fields import SDFNetwork, SingleVarianceNetwork, RefColor, Lvis, IndirectLight
         from models.inverRender import EnvmapMaterialNetwork
         from models.renderer import NeuSRenderer
@@ -57,7 +57,7 @@ class Stage3Trainer:
         self.sdf_network.set_precision(prec)
         self.refColor_network.set_precision(prec)
         self.params = list(self.mateIllu_network.parameters())          # mateIllu.py:91-95
-        self.optimizer = torch.optim.Adam(self.params, lr=lr)
+        self._init_step_mode(use_graph, lr)
         self.renderer = NeuSRenderer(**conf["neus_renderer"], sdf_network=self.sdf_network,
                                      deviation_network=self.deviation_network, refColor_network=self.refColor_network,
                                      lvis_network=self.lvis_network, indiLgt_network=self.indiLgt_network,
@@ -65,15 +65,25 @@ class Stage3Trainer:
         self.mask_weight = mask_weight
         self.iter_step = 0
 
-    def set_lr(self, lr: float):
-        for g in self.optimizer.param_groups:
-            g["lr"] = lr
+    # launch mode: see fneus/trainer2.py (fixed-shape step under one hipGraph)
+    from fneus.trainer2 import Stage2Trainer as _S2
+    _init_step_mode, set_lr, get_lr, _graph_step = _S2._init_step_mode, _S2.set_lr, _S2.get_lr, _S2._graph_step
+    del _S2
 
-    def get_lr(self) -> float:
-        return float(self.optimizer.param_groups[0]["lr"])
+    def _fixed_shape_step(self, data: torch.Tensor):
+        rays_o, rays_d, true_rgb, mask = ops.split_batch(data.contiguous())
+        mask = (mask > 0.5).float() if self.mask_weight > 0.0 else torch.ones_like(mask)
+        out = self.renderer.mateIllu_render(rays_o, rays_d, None, None, fixed_shape=True)
+        losses = stage3_loss(out, true_rgb, mask)
+        self.optimizer.zero_grad(set_to_none=True)
+        losses["loss"].backward()
+        self.optimizer.step()
+        return {"n_hit": out["sdf_mask"].sum(), **{k: v.detach() for k, v in losses.items()}}
 
     def train_step(self, data: torch.Tensor, near=None, far=None, u_theta=None, u_phi=None):
         """data [B,10] (dataset.py:133-151).  -> loss dict, or None when no ray hits the surface (mateIllu.py:156)"""
+        if self.use_graph and near is None and u_theta is None:
+            return self._graph_step(data)
         rays_o, rays_d, true_rgb, mask = ops.split_batch(data.contiguous())
         mask = (mask > 0.5).float() if self.mask_weight > 0.0 else torch.ones_like(mask)
         out = self.renderer.mateIllu_render(rays_o, rays_d, near, far, u_theta=u_theta, u_phi=u_phi)

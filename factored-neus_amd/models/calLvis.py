@@ -72,6 +72,18 @@ def query_indir_illum(lgtSGs, sample_dirs):
     return torch.sum(mu * torch.exp(lam * (cosv - 1.0)), dim=2)
 
 
+def frozen_inv_s(deviation_network) -> float:
+    """inv_s = clip(exp(10 variance)) as a host float for fneus_upsample / fneus_ray_hit, read from the device once per
+    value of the parameter (the stage-2 step must not synchronise: it is replayed as a hipGraph)"""
+    v = deviation_network.variance
+    key = (v.data_ptr(), v._version)
+    cached = getattr(deviation_network, "_inv_s_host", None)
+    if cached is None or cached[0] != key:
+        cached = (key, float(deviation_network.inv_s()))
+        deviation_network._inv_s_host = cached
+    return cached[1]
+
+
 def _secondary_march(origins, dirs, sdf_network, color_network, inv_s, trace=None):
     """everything of cal_indiLgt that sees the frozen geometry: -> occlusion [R], hit colour [R,3], hit mask [R] (u8)"""
     R = origins.shape[0]
@@ -109,7 +121,7 @@ def cal_indiLgt(surf, normal, sdf_network, deviation_network, color_network, lvi
         surf = surf.detach().float().contiguous()
         origins, dirs = ops.sample_dirs(surf, normal.detach().float().contiguous(), u_theta.float().contiguous(),
                                         u_z.float().contiguous())
-        inv_s = float(deviation_network.inv_s())          # geometry is frozen in stage 2: a constant
+        inv_s = frozen_inv_s(deviation_network)           # geometry is frozen in stage 2: a constant
         occu, hit_rgb, _ = _secondary_march(origins, dirs, sdf_network, color_network, inv_s, trace)
         gt_lvis = (1.0 - occu).reshape(n, nsamp)
         gt_trace_radiance = hit_rgb.reshape(n, nsamp, 3)

@@ -240,12 +240,22 @@ class EnvmapMaterialNetwork(nn.Module):
         self.lgtSGs = nn.Parameter(sg, requires_grad=True)
         self.envmap = None
 
-    def kl_divergence(self, rho, rho_hat):
-        """inverRender.py:609-612"""
-        rho_hat = torch.mean(torch.sigmoid(rho_hat), 0)
-        return torch.mean(rho * torch.log(rho / rho_hat) + (1 - rho) * torch.log((1 - rho) / (1 - rho_hat)))
+    def kl_divergence(self, rho, rho_hat, point_mask=None):
+        """inverRender.py:609-612.  point_mask [n] bool: the mean runs over the marked points only (the fixed-shape stage-3
+        step evaluates every ray and marks the ones that hit); without a marked point the term is 0"""
+        act = torch.sigmoid(rho_hat)
+        if point_mask is None:
+            rho_hat = torch.mean(act, 0)
+            return torch.mean(rho * torch.log(rho / rho_hat) + (1 - rho) * torch.log((1 - rho) / (1 - rho_hat)))
+        w = point_mask.to(act.dtype)[:, None]
+        cnt = w.sum()
+        some = cnt > 0
+        rho_hat = torch.where(some, (act * w).sum(0) / cnt.clamp(min=1.0), torch.full_like(act[0], rho))
+        kl = torch.mean(rho * torch.log(rho / rho_hat) + (1 - rho) * torch.log((1 - rho) / (1 - rho_hat)))
+        return torch.where(some, kl, torch.zeros_like(kl))
 
-    def forward(self, points, ray_dirs, n, f, gt_specular_linear, indiLgt, lvis_network, u_theta=None, u_phi=None):
+    def forward(self, points, ray_dirs, n, f, gt_specular_linear, indiLgt, lvis_network, u_theta=None, u_phi=None,
+                point_mask=None):
         n = n / (torch.norm(n, dim=-1, keepdim=True) + TINY_NUMBER)
         ray_dirs = ray_dirs / (torch.norm(ray_dirs, dim=-1, keepdim=True) + TINY_NUMBER)
         view_dirs = -ray_dirs
@@ -255,7 +265,7 @@ class EnvmapMaterialNetwork(nn.Module):
         brdf = torch.sigmoid(self.brdf_decoder_layer(torch.sigmoid(latent)))
         roughness = brdf[..., 3:] * 0.9 + 0.09
         diffuse_albedo = brdf[..., :3]
-        loss = 0.01 * self.kl_divergence(0.05, latent)
+        loss = 0.01 * self.kl_divergence(0.05, latent, point_mask)
         specular_albedo = self.net_cs(torch.cat([pts_enc, self.embed_view_fn(ref_dirs)], dim=-1)).repeat(1, 3)
         ret = render_with_all_sg(points, n, view_dirs, self.lgtSGs, self.specular_reflectance, specular_albedo, roughness,
                                  diffuse_albedo, gt_specular_linear, lvis_network=lvis_network, indir_lgtSGs=indiLgt,

@@ -292,11 +292,14 @@ class NeuSRenderer:
             inside_sphere = torch.linalg.norm(pts, ord=2, dim=-1) < 1.0
         return {"n_samples": n, "mid_z_vals": mid_z, "sdf": sdf[:, None], "inside_sphere_mask": inside_sphere.any(dim=-1)}
 
-    def lvis_render(self, rays_o, rays_d, near, far, u_theta=None, u_z=None, trace=None):
+    def lvis_render(self, rays_o, rays_d, near, far, u_theta=None, u_z=None, trace=None, fixed_shape=False):
         """renderer.py:567-627: visibility / traced radiance of 4 secondary rays per visible surface point, and the
         predictions of the Lvis / IndirectLight networks.  Rows of rays without a surface hit hold 1.
-        fneus_ray_hit finds the hit points; they are compacted (one host read of the hit count per step, as the reference's
-        `if n_sdf_mask > 0`) and handed to cal_indiLgt.  u_theta, u_z [hits, 4]: the uniform draws (tests)."""
+        fneus_ray_hit finds the hit points.  Default: they are compacted (one host read of the hit count per step, as the
+        reference's `if n_sdf_mask > 0`) and handed to cal_indiLgt.  fixed_shape=True: every ray is treated as a hit point
+        (rays without one start their secondary rays at the ray origin) and masked afterwards -- a few per cent more work,
+        no host synchronisation and no data-dependent shape: the step can be captured in a hipGraph (fneus/trainer2.py).
+        u_theta, u_z [hits, 4] (or [B, 4] at fixed shape): the uniform draws (tests)."""
         from models.calLvis import cal_indiLgt
         B = len(rays_o)
         dev = rays_o.device
@@ -308,6 +311,20 @@ class NeuSRenderer:
             hit = ops.ray_hit(rays_o, rays_d, util["mid_z_vals"], util["sdf"].reshape(B, n).contiguous(),
                               inside_mask=util["inside_sphere_mask"])
             sdf_mask = hit["sdf_mask"].view(torch.bool)
+        if fixed_shape:
+            with torch.no_grad():
+                pts_surf = hit["pts_surf"]
+                _, _, n_surf = self.sdf_network.value_feature_normal(RaySamples(pts=pts_surf), False)
+            res = cal_indiLgt(pts_surf, n_surf, self.sdf_network, self.deviation_network, self.color_network,
+                              self.lvis_network, self.indiLgt_network, u_theta=u_theta, u_z=u_z, trace=trace)
+            one = torch.ones((), device=dev)
+            out = {"sdf_mask": sdf_mask}
+            for k in ("gt_lvis", "pre_lvis"):
+                out[k] = torch.where(sdf_mask[:, None], res[k], one)
+            for k in ("gt_trace_radiance", "pre_trace_radiance"):
+                out[k] = torch.where(sdf_mask[:, None, None], res[k], one)
+            return out
+        with torch.no_grad():
             idx = sdf_mask.nonzero(as_tuple=True)[0]
         out = {"gt_lvis": torch.ones(B, M, device=dev), "pre_lvis": torch.ones(B, M, device=dev),
                "gt_trace_radiance": torch.ones(B, M, 3, device=dev), "pre_trace_radiance": torch.ones(B, M, 3, device=dev),
@@ -324,10 +341,13 @@ class NeuSRenderer:
                 out[k] = out[k].index_copy(0, idx, res[k].to(out[k].dtype))
         return out
 
-    def mateIllu_render(self, rays_o, rays_d, near, far, u_theta=None, u_phi=None):
+    def mateIllu_render(self, rays_o, rays_d, near, far, u_theta=None, u_phi=None, fixed_shape=False):
         """renderer.py:630-726: stage 3.  Geometry (SDF), the RefColor head, Lvis and IndirectLight are frozen inputs
         (mateIllu.py:83-95 trains the EnvmapMaterialNetwork only): hit points by fneus_ray_hit, normal + feature by K2, the
         diffuse / specular split by the fused RefColor heads, all without stash.  Rows of rays without a hit hold 1.
+        fixed_shape=True: every ray is evaluated (rays without a hit at their origin) and masked afterwards, the latent
+        sparsity term averages over the hit points only: same values and gradients, no host synchronisation, capturable
+        in a hipGraph (fneus/trainer3.py).
         u_theta, u_phi [128, 32]: the uniform draws of the visibility sampler (inverRender.py:152-153; tests)."""
         from models.inverRender import srgb_to_linear
         B = len(rays_o)
@@ -339,16 +359,17 @@ class NeuSRenderer:
             hit = ops.ray_hit(rays_o, rays_d, util["mid_z_vals"], util["sdf"].reshape(B, n).contiguous(),
                               inside_mask=util["inside_sphere_mask"])
             sdf_mask = hit["sdf_mask"].view(torch.bool)
-            idx = sdf_mask.nonzero(as_tuple=True)[0]
+            idx = None if fixed_shape else sdf_mask.nonzero(as_tuple=True)[0]
+        ray_keys = ("rgb", "env_rgb", "indir_rgb", "diffuse_albedo", "specular_albedo", "diffuse_rgb", "specular_rgb", "roughness",
+                    "lvis_mean")
         one3 = lambda: torch.ones(B, 3, device=dev)
-        out = {k: one3() for k in ("rgb", "env_rgb", "indir_rgb", "diffuse_albedo", "specular_albedo", "diffuse_rgb",
-                                   "specular_rgb", "lvis_mean", "gt_specular_linear", "gt_diffuse_srgb", "n_out")}
+        out = {k: one3() for k in ray_keys + ("gt_specular_linear", "gt_diffuse_srgb", "n_out")}
         out["roughness"] = torch.ones(B, 1, device=dev)
         out.update(sdf_mask=sdf_mask, diffuse_loss=0, specular_loss=0, encoder_loss=0, smooth_loss=0)
-        if idx.numel() > 0:
+        if fixed_shape or idx.numel() > 0:
             with torch.no_grad():
-                pts_surf = hit["pts_surf"][idx].contiguous()
-                rays_surf = rays_d[idx].contiguous()
+                pts_surf = hit["pts_surf"] if fixed_shape else hit["pts_surf"][idx].contiguous()
+                rays_surf = rays_d if fixed_shape else rays_d[idx].contiguous()
                 surf = RaySamples(pts=pts_surf, dirs=rays_surf)
                 _, f_surf, n_surf = self.sdf_network.value_feature_normal(surf, False)
                 self.refColor_network.refresh()
@@ -357,13 +378,19 @@ class NeuSRenderer:
                 specular_linear = srgb_to_linear(ref["specular_rgb"])
                 indiLgt = self.indiLgt_network(pts_surf)
             m = self.mateIllu_network(pts_surf, rays_surf, n_surf, f_surf, specular_linear, indiLgt, self.lvis_network,
-                                      u_theta=u_theta, u_phi=u_phi)
-            for k in ("rgb", "env_rgb", "indir_rgb", "diffuse_albedo", "specular_albedo", "diffuse_rgb", "specular_rgb",
-                      "roughness", "lvis_mean"):
-                out[k] = out[k].index_copy(0, idx, m[k].to(out[k].dtype))
-            out["gt_specular_linear"] = out["gt_specular_linear"].index_copy(0, idx, specular_linear)
-            out["gt_diffuse_srgb"] = out["gt_diffuse_srgb"].index_copy(0, idx, ref["diffuse_rgb"])
-            out["n_out"] = out["n_out"].index_copy(0, idx, n_surf)
+                                      u_theta=u_theta, u_phi=u_phi, point_mask=sdf_mask if fixed_shape else None)
+            extra = (("gt_specular_linear", specular_linear), ("gt_diffuse_srgb", ref["diffuse_rgb"]), ("n_out", n_surf))
+            if fixed_shape:
+                sel = sdf_mask[:, None]
+                for k in ray_keys:
+                    out[k] = torch.where(sel, m[k], out[k])
+                for k, v in extra:
+                    out[k] = torch.where(sel, v, out[k])
+            else:
+                for k in ray_keys:
+                    out[k] = out[k].index_copy(0, idx, m[k].to(out[k].dtype))
+                for k, v in extra:
+                    out[k] = out[k].index_copy(0, idx, v)
             for k in ("diffuse_loss", "specular_loss", "encoder_loss", "smooth_loss"):
                 out[k] = m[k]
         return out

@@ -207,3 +207,38 @@ def test_stage2_step_at_full_size_properties():
     miss = ~res["sdf_mask"]
     for k in ("gt_lvis", "pre_lvis", "gt_trace_radiance", "pre_trace_radiance"):
         assert bool((res[k][miss] == 1.0).all()), k
+
+
+def test_fixed_shape_render_matches_the_reference_and_the_graph_step_trains(golden_dir):
+    """lvis_render(fixed_shape=True) -- every ray treated as a hit point, masked afterwards -- gives the reference's outputs
+    when the reference's draws are put on the rows of its hit points; the trainer's hipGraph mode replays that step"""
+    from fneus.trainer import synthetic_batches
+    from fneus.trainer2 import Stage2Trainer, stage2_loss
+    g = load(golden_dir, "lvis_render_room_b24_n32")
+    tr = build(g)
+    data = T(g["data"]).to(DEV)
+    m = T(g["out/sdf_mask"])
+    B = len(m)
+    ut, uz = torch.full((B, 4), 0.5), torch.full((B, 4), 0.5)
+    ut[m], uz[m] = T(g["step0/u_theta"]), T(g["step0/u_z"])
+    out = tr.renderer.lvis_render(data[:, :3].contiguous(), data[:, 3:6].contiguous(), T(g["near"]).to(DEV), T(g["far"]).to(DEV),
+                                  u_theta=ut.to(DEV), u_z=uz.to(DEV), fixed_shape=True)
+    c = lambda t: t.detach().cpu()
+    assert np.array_equal(c(out["sdf_mask"]).numpy(), g["out/sdf_mask"])
+    assert (c(out["pre_lvis"]) - T(g["out/pre_lvis"])).abs().max().item() <= 1e-4
+    assert (c(out["pre_trace_radiance"]) - T(g["out/pre_trace_radiance"])).abs().max().item() <= 1e-4 * max(1.0, float(np.abs(g["out/pre_trace_radiance"]).max()))
+    for key in ("gt_lvis", "gt_trace_radiance"):
+        a, b = c(out[key]), T(g["out/" + key])
+        assert frac_within(a, b, 1e-4) >= 0.9 and (a - b).abs().max().item() <= 2e-3, key
+    L = stage2_loss(out)
+    assert abs(float(L["loss"].detach()) - float(g["step0/loss"])) <= 1e-3 * max(1.0, abs(float(g["step0/loss"])))
+    trg = Stage2Trainer(torch.device(DEV), seed=3, use_graph=True)
+    batch = synthetic_batches(1, 512, torch.device(DEV), seed0=11)[0]
+    losses = [float(trg.train_step(batch)["loss"]) for _ in range(12)]
+    assert trg._graph is not None and trg.iter_step == 12
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    away = batch.clone()
+    away[:, 3:6] = -away[:, 3:6]
+    o = trg.train_step(away)
+    assert int(o["n_hit"]) == 0 and float(o["loss"]) == 0.0
+    assert all(bool(torch.isfinite(p).all()) for p in trg.params)

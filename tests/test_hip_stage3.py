@@ -171,3 +171,41 @@ def test_fused_lvis_visibility_vs_library_path():
     again = net.visibility(pts, nrm, dirs.contiguous(), w.contiguous())
     assert (again - net._visibility_library(pts, nrm, dirs.contiguous(), w.contiguous())).abs().max().item() <= 1e-4
     assert (again - got).abs().max().item() > 1e-3
+
+
+def test_fixed_shape_render_matches_the_reference_and_the_graph_step_trains(golden_dir):
+    """mateIllu_render(fixed_shape=True) -- every ray evaluated, masked afterwards, latent sparsity averaged over the hit points
+    -- gives the reference's outputs and loss; the trainer's hipGraph mode replays that step"""
+    from fneus.trainer3 import Stage3Trainer, stage3_loss
+    from fneus.trainer import synthetic_batches
+    g = dict(np.load(os.path.join(golden_dir, "mateillu_render_b24_n32.npz")))
+    tr = build(g)
+    data, near, far = rays(g)
+    out = tr.renderer.mateIllu_render(data[:, :3].contiguous(), data[:, 3:6].contiguous(), near, far,
+                                      u_theta=T(g["step0/u_theta"]).to(DEV), u_phi=T(g["step0/u_phi"]).to(DEV), fixed_shape=True)
+    for k in RAY_KEYS + ("n_out", "gt_specular_linear", "gt_diffuse_srgb"):
+        assert (out[k].detach().cpu() - T(g["out/" + k])).abs().max().item() <= 1e-4, k
+    L = stage3_loss(out, data[:, 6:9], (data[:, 9:10] > 0.5).float())
+    for k in ("loss", "rgb_loss", "encoder_loss", "psnr"):
+        assert abs(float(L[k].detach()) - float(g["step0/" + k])) <= 1e-3 * max(1.0, abs(float(g["step0/" + k]))), k
+    L["loss"].backward()
+    for k, prm in tr.mateIllu_network.named_parameters():
+        ref_norm = float(g["grad_norm/" + k])
+        assert abs(prm.grad.double().norm().item() - ref_norm) <= 1e-2 * ref_norm + 1e-7, k
+    # the replayed step
+    trg = Stage3Trainer(torch.device(DEV), seed=3, use_graph=True)
+    batch = synthetic_batches(1, 512, torch.device(DEV), seed0=12)[0]
+    losses = []
+    for i in range(12):
+        o = trg.train_step(batch)
+        losses.append(float(o["loss"]))
+    assert trg._graph is not None and trg.iter_step == 12
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    trg.set_lr(1e-4)
+    assert abs(trg.get_lr() - 1e-4) < 1e-12
+    # a batch without a single hit: zero colour loss, finite step
+    away = batch.clone()
+    away[:, 3:6] = -away[:, 3:6]
+    o = trg.train_step(away)
+    assert int(o["n_hit"]) == 0 and bool(torch.isfinite(o["loss"])) and float(o["rgb_loss"]) == 0.0
+    assert all(bool(torch.isfinite(p).all()) for p in trg.mateIllu_network.parameters())
