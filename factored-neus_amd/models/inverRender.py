@@ -162,7 +162,7 @@ def render_with_sg(points, normal, viewdirs, lgtSGs, specular_reflectance, specu
     half = warp_lobes + view
     half = half / (torch.norm(half, dim=-1, keepdim=True) + TINY_NUMBER)
     v_dot_h = torch.clamp(torch.sum(view * half, dim=-1, keepdim=True), min=0.0)
-    f0 = specular_reflectance.to(points.device)[:, None, :].expand(n, M, 3)
+    f0 = specular_reflectance[:, None, :].expand(n, M, 3)
     fresnel = f0 + (1.0 - f0) * torch.pow(2.0, -(5.55473 * v_dot_h + 6.8316) * v_dot_h)
     dot1 = torch.clamp(torch.sum(warp_lobes * nrm, dim=-1, keepdim=True), min=0.0)
     dot2 = torch.clamp(torch.sum(view * nrm, dim=-1, keepdim=True), min=0.0)
@@ -228,7 +228,8 @@ class EnvmapMaterialNetwork(nn.Module):
         self.brdf_encoder_layer = nn.Sequential(*_mlp([brdf_in, 512, 512, 512, 512, self.latent_dim], self.actv_fn))
         self.brdf_decoder_layer = nn.Sequential(*_mlp([self.latent_dim, 128, 128, 4], self.actv_fn))
         self.net_cs = nn.Sequential(*_mlp([ch_pts + ch_view, 256, 256, 256, 256, 1], nn.LeakyReLU(0.2)), nn.Sigmoid())
-        self.specular_reflectance = torch.full([1, 1], float(specular_albedo))
+        # (a plain tensor attribute in the reference: not part of its state_dict -- a non-persistent buffer moves with .to())
+        self.register_buffer("specular_reflectance", torch.full([1, 1], float(specular_albedo)), persistent=False)
         # light SGs: grey amplitudes, sharpness 10 + 20 |N|, energy normalised, lobes on two Fibonacci spheres (:509-525)
         sg = torch.randn(num_lgt_sgs, 7)
         sg[:, -2:] = sg[:, -3:-2].expand(-1, 2)

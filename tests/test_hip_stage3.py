@@ -202,10 +202,10 @@ def test_fixed_shape_render_matches_the_reference_and_the_graph_step_trains(gold
     assert trg._graph is not None and trg.iter_step == 12
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
     trg.set_lr(1e-4)
-    assert abs(trg.get_lr() - 1e-4) < 1e-12
+    assert abs(trg.get_lr() - 1e-4) < 1e-9           # a device fp32 scalar
     # a batch without a single hit: zero colour loss, finite step
-    away = batch.clone()
-    away[:, 3:6] = -away[:, 3:6]
+    from fneus import synth
+    away = torch.from_numpy(synth.ray_batch(512, seed=5, n_miss=512)).to(DEV)        # every ray misses the unit sphere
     o = trg.train_step(away)
     assert int(o["n_hit"]) == 0 and bool(torch.isfinite(o["loss"])) and float(o["rgb_loss"]) == 0.0
     assert all(bool(torch.isfinite(p).all()) for p in trg.mateIllu_network.parameters())
