@@ -26,7 +26,7 @@ if HERE not in sys.path:
 from fneus import hocon, ops                      # noqa: E402
 from fneus.parallel import init_from_env, broadcast_parameters     # noqa: E402
 from fneus.trainer import Stage1Trainer           # noqa: E402
-from models.dataset import Dataset, SyntheticDataset            # noqa: E402
+from models.dataset import Dataset, DatasetShiny, SyntheticDataset            # noqa: E402
 from models.fields import NeRF                    # noqa: E402
 
 
@@ -43,8 +43,10 @@ class Runner:
             self.dataset = Dataset(self.conf["dataset"], device=self.device)
         elif type == "synthetic":
             self.dataset = SyntheticDataset(device=self.device)
+        elif type in ("shiny", "indisg_shiny"):          # reference exp_runner.py:50-51 / lvis.py:48-49
+            self.dataset = DatasetShiny(self.conf["dataset"], device=self.device)
         else:
-            raise NotImplementedError(f"--type {type}: only 'dtu' and 'synthetic' feed the HIP hot path")
+            raise NotImplementedError(f"--type {type}: 'dtu', 'shiny' and 'synthetic' feed the HIP hot path")
         tc = self.conf["train"]
         self.end_iter, self.save_freq, self.report_freq = tc.get_int("end_iter"), tc.get_int("save_freq"), tc.get_int("report_freq")
         self.val_freq, self.val_mesh_freq = tc.get_int("val_freq"), tc.get_int("val_mesh_freq")

@@ -24,7 +24,7 @@ if HERE not in sys.path:
 
 from fneus import hocon, ops                      # noqa: E402
 from fneus.trainer3 import Stage3Trainer          # noqa: E402
-from models.dataset import Dataset, SyntheticDataset            # noqa: E402
+from models.dataset import Dataset, DatasetShiny, SyntheticDataset            # noqa: E402
 
 
 def _latest(ckpt_dir, end_iter):
@@ -44,8 +44,10 @@ class Runner:
             self.dataset = Dataset(self.conf["dataset"], device=self.device)
         elif type == "synthetic":
             self.dataset = SyntheticDataset(device=self.device)
+        elif type in ("shiny", "indisg_shiny"):          # reference exp_runner.py:50-51 / lvis.py:48-49
+            self.dataset = DatasetShiny(self.conf["dataset"], device=self.device)
         else:
-            raise NotImplementedError(f"--type {type}: only 'dtu' and 'synthetic' feed the HIP hot path")
+            raise NotImplementedError(f"--type {type}: 'dtu', 'shiny' and 'synthetic' feed the HIP hot path")
         tc = self.conf["train"]
         self.end_iter = tc.get_int("metaIllu.end_iter")
         self.batch_size = tc.get_int("metaIllu.batch_size")

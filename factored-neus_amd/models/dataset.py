@@ -6,7 +6,10 @@ Dataset           : DTU-format scenes (reference models/dataset.py:41-196): imag
                     uploads every step, dataset.py:133-151).  Colours are BGR/256 like the reference (cv2 order).
 SyntheticDataset  : DTU-shaped synthetic scene (two analytic spheres traced per pixel, cameras on a sphere) for smoke runs
                     and the end-to-end reconstruction test.
-The other reference loaders (Sk3d / Shiny / Glossy*) are data-format variety outside the hot path and are not provided.
+DatasetShiny      : Blender-format scenes of the womask configuration (reference models/dataset.py:522-662, Shiny Blender):
+                    transforms_{split}.json, <frame>.png (sRGB -> linear by the 2.2 power), masks from <frame>_disp.tiff
+                    (or <frame>_alpha.png for the "ball" scene), camera centres halved, OpenGL -> OpenCV axes.
+The other reference loaders (Sk3d / Glossy*) are data-format variety outside the hot path and are not provided.
 """
 from __future__ import annotations
 
@@ -111,6 +114,102 @@ class Dataset(_RayMixin):
         img = (self.images[idx] * 256.0).clip(0, 255)
         l = resolution_level
         return img[::l, ::l].cpu().numpy()
+
+
+class DatasetShiny(_RayMixin):
+    """reference models/dataset.py:522-662.  File formats through PIL (imageio / tifffile / cv2 are not dependencies): PNG
+    colours / 255 then ** 2.2 (rend_util.py:10-17), disparity TIFFs thresholded at 1e-6, `_alpha.png` masks / 256 thresholded
+    at 0.5 and averaged over the channels.  Images, masks and cameras end up on the device; rays come from the HIP kernels."""
+
+    def __init__(self, conf, frame_skip=1, split="train", device=None):
+        import json
+        from PIL import Image
+        self.device = device or torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.conf, self.split = conf, split
+        self.data_dir = conf.get_string("data_dir")
+        with open(os.path.join(self.data_dir, "transforms_{}.json".format(split)), "r") as fp:
+            meta = json.load(fp)
+        ball = "ball" in self.data_dir
+        image_paths, mask_paths, poses = [], [], []
+        for frame in meta["frames"]:
+            poses.append(np.array(frame["transform_matrix"], dtype=np.float64))
+            image_paths.append(os.path.join(self.data_dir, frame["file_path"] + ".png"))
+            mask_paths.append(os.path.join(self.data_dir, frame["file_path"] + ("_alpha.png" if ball else "_disp.tiff")))
+
+        def load_rgb(path):                                   # rend_util.py:10-17
+            img = np.asarray(Image.open(path), dtype=np.float32)[:, :, :3]
+            return np.power(img / 255.0, 2.2).astype(np.float32)
+
+        def load_mask(path):                                  # dataset.py:581-589
+            if ball:
+                m = np.asarray(Image.open(path).convert("RGB"), dtype=np.float32) / 256.0
+                m[m > 0.5] = 1.0
+                return np.mean(m, axis=-1).astype(np.float32)
+            m = np.array(Image.open(path), dtype=np.float32)
+            if m.ndim == 3:
+                m = m[..., 0]
+            m[m > 1e-6] = 1.0
+            return m
+
+        img_h, img_w = load_rgb(image_paths[0]).shape[:2]
+        focal = 0.5 * img_w / np.tan(0.5 * float(meta["camera_angle_x"]))
+        poses = np.array(poses)
+        poses[..., 3] /= 2.0                                  # dataset.py:556-557: the whole last column, as the reference does
+        image_paths, poses = image_paths[::frame_skip], poses[::frame_skip, ...]
+        self.image_paths = self.images_lis = image_paths
+        K = np.array([[focal, 0, img_w / 2], [0, focal, img_h / 2], [0, 0, 1]], dtype=np.float32)
+        self.n_images = len(image_paths)
+        self.images = torch.from_numpy(np.stack([load_rgb(p) for p in image_paths])).to(self.device)
+        masks = np.stack([load_mask(p) for p in mask_paths])          # (all frames, like the reference: frame_skip skips images only)
+        self.masks = torch.from_numpy(masks[: self.n_images]).reshape(self.n_images, img_h, img_w, 1).repeat(1, 1, 1, 3).to(self.device)
+        # 4 x 4 intrinsics (the kernels take the DTU loader's layout); the reference keeps 3 x 3
+        K4 = np.eye(4, dtype=np.float32)
+        K4[:3, :3] = K
+        self.intrinsics_all = torch.from_numpy(np.stack([K4] * self.n_images)).to(self.device)
+        self.intrinsics_all_inv = torch.inverse(self.intrinsics_all)
+        self.focal = focal
+        convert = torch.diag(torch.tensor([1.0, -1.0, -1.0, 1.0]))     # OpenGL camera axes -> OpenCV (dataset.py:592-597, 607)
+        self.pose_all = (torch.from_numpy(poses).float() @ convert).contiguous().to(self.device)
+        self.H, self.W = img_h, img_w
+        self.images_pixels = self.image_pixels = self.H * self.W
+        self.scale_mats_np = [np.eye(4, dtype=np.float32)] * self.n_images
+        self.object_bbox_min = np.array([-1.01, -1.01, -1.01], dtype=np.float32)
+        self.object_bbox_max = np.array([1.01, 1.01, 1.01], dtype=np.float32)
+
+    def image_at(self, idx, resolution_level):
+        """dataset.py:660-662: back to display gamma, nearest-neighbour down-sampling"""
+        img = np.power(self.images[idx].cpu().numpy(), 1.0 / 2.2) * 255
+        l = resolution_level
+        return img[::l, ::l].clip(0, 255)
+
+
+def export_shiny_scene(ds: "SyntheticDataset", out_dir: str, split: str = "train", ball: bool = False) -> str:
+    """Write a SyntheticDataset in the Shiny-Blender layout DatasetShiny reads: transforms_{split}.json with OpenGL camera
+    matrices whose centres are twice the unit-sphere ones, r_%d.png (sRGB-encoded so that the loader's 2.2 power returns
+    ds.images) and the masks as r_%d_disp.tiff (float disparity) or r_%d_alpha.png."""
+    import json
+    from PIL import Image
+    os.makedirs(out_dir, exist_ok=True)
+    K = ds.intrinsics_all[0].cpu().numpy()
+    frames = []
+    flip = np.diag([1.0, -1.0, -1.0, 1.0])
+    for i in range(ds.n_images):
+        img = ds.images[i].cpu().numpy().astype(np.float64)
+        png = np.clip(np.round(np.power(np.clip(img, 0.0, 1.0), 1.0 / 2.2) * 255.0), 0, 255).astype(np.uint8)
+        Image.fromarray(png).save(os.path.join(out_dir, "r_%d.png" % i))
+        m = ds.masks[i].cpu().numpy()[..., 0].astype(np.float32)
+        if ball:
+            Image.fromarray((m * 255).astype(np.uint8)).convert("RGB").save(os.path.join(out_dir, "r_%d_alpha.png" % i))
+        else:
+            Image.fromarray(m * 0.37, mode="F").save(os.path.join(out_dir, "r_%d_disp.tiff" % i))
+        pose = ds.pose_all[i].cpu().numpy().astype(np.float64) @ flip       # OpenCV -> OpenGL axes
+        pose[:3, 3] *= 2.0
+        pose[3, 3] = 2.0            # the loader halves the whole last column (dataset.py:556-557): keep w = 1 after it
+        frames.append({"file_path": "r_%d" % i, "transform_matrix": pose.tolist()})
+    meta = {"camera_angle_x": float(2.0 * np.arctan(0.5 * ds.W / K[0, 0])), "frames": frames}
+    with open(os.path.join(out_dir, "transforms_%s.json" % split), "w") as fp:
+        json.dump(meta, fp)
+    return out_dir
 
 
 # analytic test scene inside the unit sphere: the union of two diffuse spheres (centre, radius, albedo in the image's

@@ -236,3 +236,32 @@ def test_dtu_format_dataset_reads_files_like_the_reference_loader(tmp_path):
     assert (a[:, 6:9] - b[:, 6:9]).abs().max().item() <= 1.0 / 256 + 1e-6 and torch.equal(a[:, 9] > 0.5, b[:, 9] > 0.5)
     o, d = R.gen_rays_at(ds.intrinsics_all_inv[2], ds.pose_all[2], ds.H, ds.W, 4)
     assert o.shape == (6, 8, 3) and torch.allclose(d.norm(dim=-1), torch.ones(6, 8), atol=1e-5)
+
+
+@pytest.mark.parametrize("ball", [False, True])
+def test_shiny_blender_dataset_reads_files_like_the_reference_loader(tmp_path, ball):
+    """DatasetShiny (reference models/dataset.py:522-662): transforms_train.json + PNG colours (sRGB -> linear) + disparity
+    TIFF / alpha PNG masks; camera centres halved and OpenGL axes flipped.  The case is written from the analytic synthetic
+    scene; loading it must give back its images, masks and cameras."""
+    from models.dataset import DatasetShiny, SyntheticDataset, export_shiny_scene
+
+    class Conf(dict):
+        def get_string(self, k):
+            return self[k]
+
+    cpu = torch.device("cpu")
+    src = SyntheticDataset(n_images=3, H=24, W=32, device=cpu, seed=6)
+    case = export_shiny_scene(src, str(tmp_path / ("ball_case" if ball else "case")), ball=ball)
+    ds = DatasetShiny(Conf(data_dir=case), device=cpu)
+    assert ds.n_images == 3 and (ds.H, ds.W) == (24, 32)
+    # colours: 8-bit sRGB quantisation of the linear source (d lin / d srgb <= 2.2 at white)
+    assert (ds.images - src.images).abs().max().item() <= 2.2 / 255 * 0.5 + 2e-3
+    assert torch.equal(ds.masks > 0.5, src.masks > 0.5) and ds.masks.shape == (3, 24, 32, 3)
+    assert torch.allclose(ds.intrinsics_all[:, :3, :3], src.intrinsics_all[:, :3, :3], atol=1e-3)
+    assert torch.allclose(ds.pose_all, src.pose_all, atol=1e-5)
+    from oracle import ref_torch as R
+    px, py = torch.randint(0, 32, (32,)), torch.randint(0, 24, (32,))
+    a = R.gen_random_rays_at(ds.intrinsics_all_inv[1], ds.pose_all[1], ds.images[1], ds.masks[1], px, py)
+    b = R.gen_random_rays_at(src.intrinsics_all_inv[1], src.pose_all[1], src.images[1], src.masks[1], px, py)
+    assert torch.allclose(a[:, :6], b[:, :6], atol=1e-4)
+    assert ds.image_at(0, 2).shape == (12, 16, 3)
