@@ -76,6 +76,25 @@ class Stage2Trainer:
             self.optimizer = torch.optim.Adam(self.params, lr=lr)
         self._graph, self._eager_steps, self.graph_warmup_steps = None, 0, 2
 
+    def optimizer_state_dict(self):
+        """torch.optim.Adam's format with host scalars (what the reference's checkpoints hold): the graph mode keeps `lr` and
+        the step counters on the device"""
+        sd = self.optimizer.state_dict()
+        for g in sd["param_groups"]:
+            if torch.is_tensor(g["lr"]):
+                g["lr"] = float(g["lr"])
+        for st in sd["state"].values():
+            if torch.is_tensor(st.get("step")):
+                st["step"] = st["step"].detach().clone().cpu()
+        return sd
+
+    def load_optimizer_state_dict(self, sd):
+        self.optimizer.load_state_dict(sd)
+        if self.use_graph:               # back to device scalars; a captured graph holds the old tensors: capture again
+            for g in self.optimizer.param_groups:
+                g["lr"] = torch.tensor(float(g["lr"]), device=self.device)
+            self._graph, self._eager_steps = None, 0
+
     def set_lr(self, lr: float):
         for g in self.optimizer.param_groups:
             if torch.is_tensor(g["lr"]):

@@ -34,7 +34,7 @@ def _latest(ckpt_dir, end_iter):
 
 class Runner:
     def __init__(self, conf_path, mode="train", case="CASE_NAME", is_continue=False, type="dtu", device=None,
-                 prec=ops.PREC_PARITY):
+                 prec=ops.PREC_PARITY, use_graph=True):
         self.device = device or torch.device("cuda")
         self.conf = hocon.parse_file(conf_path, case)
         self.base_exp_dir_lvis = self.conf["general.base_exp_dir_lvis"]
@@ -56,7 +56,8 @@ class Runner:
         self.learning_rate, self.learning_rate_alpha = tc.get_float("learning_rate"), tc.get_float("learning_rate_alpha")
         model_conf = {k: dict(self.conf["model"][k]) for k in ("sdf_network", "variance_network", "rendering_network",
                                                                 "lvis_renderer")}
-        self.trainer = Stage2Trainer(self.device, model_conf=model_conf, prec=prec, lr=self.learning_rate, synthetic_init=False)
+        self.trainer = Stage2Trainer(self.device, model_conf=model_conf, prec=prec, lr=self.learning_rate, synthetic_init=False,
+                                     use_graph=use_graph)
         self.iter_step = 0
         geo = _latest(os.path.join(self.base_exp_dir_geometry, "checkpoints"), tc.get_int("end_iter"))
         if geo is None:
@@ -116,7 +117,7 @@ class Runner:
         self._load_geometry(ckpt)
         self.trainer.lvis_network.load_state_dict(ckpt["lvis_network"])
         self.trainer.indiLgt_network.load_state_dict(ckpt["indiLgt_network"])
-        self.trainer.optimizer.load_state_dict(ckpt["optimizer"])
+        self.trainer.load_optimizer_state_dict(ckpt["optimizer"])
         self.iter_step = self.trainer.iter_step = ckpt["iter_step"]
 
     def save_checkpoint(self):
@@ -124,7 +125,7 @@ class Runner:
         ckpt = {"sdf_network_fine": t.sdf_network.state_dict(), "variance_network_fine": t.deviation_network.state_dict(),
                 "color_network_fine": t.color_network.state_dict(), "refColor_network": t.refColor_network.state_dict(),
                 "lvis_network": t.lvis_network.state_dict(), "indiLgt_network": t.indiLgt_network.state_dict(),
-                "optimizer": t.optimizer.state_dict(), "iter_step": self.iter_step}
+                "optimizer": t.optimizer_state_dict(), "iter_step": self.iter_step}
         os.makedirs(os.path.join(self.base_exp_dir_lvis, "checkpoints"), exist_ok=True)
         torch.save(ckpt, os.path.join(self.base_exp_dir_lvis, "checkpoints", "ckpt_{:0>6d}.pth".format(self.iter_step)))
 
@@ -140,10 +141,12 @@ def main():
     ap.add_argument("--type", type=str, default="dtu")
     ap.add_argument("--prec", choices=["parity", "fast"], default="parity")
     ap.add_argument("--max_steps", type=int, default=None)
+    ap.add_argument("--no_graph", action="store_true", help="compact the hit points and launch eagerly instead of replaying the "
+                                                             "fixed-shape step as a hipGraph")
     args = ap.parse_args()
     torch.cuda.set_device(args.gpu)
     runner = Runner(args.conf, args.mode, args.case, args.is_continue, args.type, device=torch.device("cuda", args.gpu),
-                    prec=ops.PREC_PARITY if args.prec == "parity" else ops.PREC_FAST)
+                    prec=ops.PREC_PARITY if args.prec == "parity" else ops.PREC_FAST, use_graph=not args.no_graph)
     if args.mode == "train":
         runner.train(max_steps=args.max_steps)
     else:
