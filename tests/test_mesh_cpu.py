@@ -85,3 +85,48 @@ def test_chamfer_of_extracted_sphere_against_analytic_points():
     a, _, _ = chamfer_l1(far, ref, max_dist=1.0)
     b, _, _ = chamfer_l1(pts, ref, max_dist=1.0)
     assert abs(a - b) < 1e-12
+
+
+def test_clean_mesh_by_masks_and_largest_component():
+    """clean_mesh_pose.py:22-71: vertices outside any camera's dilated mask go, faces with them, then small components"""
+    import os
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(ROOT, "factored-neus_amd"))
+    import clean_mesh_pose as C
+    fp = C.ellipse_footprint(25)
+    assert fp.shape == (25, 25) and fp[12].all() and fp[0].sum() == 1 and fp[:, 12].all() and fp.sum() == fp[::-1].sum()
+    # two cameras looking down the z and x axes at a unit cube of vertices; masks = discs of radius 20 px around the centre
+    K = np.array([[100.0, 0, 50], [0, 100.0, 50], [0, 0, 1]])
+
+    def world_mat(R, t):
+        P = np.eye(4)
+        P[:3, :4] = K @ np.concatenate([R, t[:, None]], 1)
+        return P
+
+    Rz, Rx = np.eye(3), np.array([[0.0, 0, -1], [0, 1, 0], [1, 0, 0]])
+    mats = [world_mat(Rz, np.array([0.0, 0, 5])), world_mat(Rx, np.array([0.0, 0, 5]))]
+    yy, xx = np.mgrid[0:100, 0:100]
+    disc = (((xx - 50) ** 2 + (yy - 50) ** 2) <= 20 ** 2).astype(np.uint8) * 255
+    masks = [disc, disc]
+    # a strip of triangles along x from -3 to 3 (projects from 50-60 to 50+60 px in camera 0: the ends fall outside the
+    # dilated disc of radius 20 + 12), plus one far-away stray triangle inside both masks' padding... and one small island
+    xs = np.linspace(-3, 3, 61)
+    v = np.stack([np.stack([xs, -0.05 * np.ones_like(xs), np.zeros_like(xs)], 1),
+                  np.stack([xs, 0.05 * np.ones_like(xs), np.zeros_like(xs)], 1)], 1).reshape(-1, 3)
+    f = []
+    for i in range(60):
+        a, b, c, d = 2 * i, 2 * i + 1, 2 * i + 2, 2 * i + 3
+        f += [[a, b, c], [b, d, c]]
+    island = np.array([[0.0, 1.0, 0.0], [0.1, 1.0, 0.0], [0.0, 1.1, 0.0]])      # inside both masks, not connected to the strip
+    v = np.concatenate([v, island], 0)
+    f = np.array(f + [[len(v) - 3, len(v) - 2, len(v) - 1]])
+    keep = C.clean_points_by_mask(v, mats, masks)
+    # camera 0 sees x as u = 50 + 100 x / 5: inside the dilated disc (radius 32) for |x| <= 1.6; vertices that project
+    # outside the image (u < -0.5 or u > 99.5) are not judged by that camera (the reference pads the mask with ones)
+    expect = (np.abs(xs) <= 1.6 + 1e-9) | (xs <= -2.6 + 1e-9) | (xs >= 2.5 - 1e-9)
+    assert keep[: len(xs) * 2].reshape(-1, 2)[:, 0].tolist() == expect.tolist()
+    assert keep[-3:].all()
+    v2, f2 = C.clean_mesh(v, f, mats, masks)
+    assert np.abs(v2[:, 0]).max() <= 1.6 + 1e-9 and np.abs(v2[:, 1]).max() < 0.5        # the strip's middle, without the island
+    assert len(f2) == 2 * (int((np.abs(xs) <= 1.6 + 1e-9).sum()) - 1) and f2.max() == len(v2) - 1
