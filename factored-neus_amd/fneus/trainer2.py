@@ -18,18 +18,25 @@ from fneus.trainer import WMASK_MODEL
 LVIS_RENDERER = dict(n_samples=64, n_importance=64, n_outside=0, up_sample_steps=4, perturb=1.0)     # confs/wmask.conf:99-105
 
 
-def stage2_loss(out: dict):
-    """lvis.py:164-170"""
+def stage2_loss(out: dict, reduce=None):
+    """lvis.py:164-170.  reduce(t) -> t summed over the data-parallel ranks (in place): the loss terms are then this rank's
+    SHARE of the global batch's (the hit count that normalises them is global), so that R ranks x B rays give the loss and the
+    gradient of one R*B-ray batch when the shares / the rank gradients are summed"""
     m = out["sdf_mask"]
-    lvis_loss = (out["gt_lvis"] - out["pre_lvis"]).abs().sum() / (m.sum() * 4 + 1e-6)
+    n_hit = m.sum().float().reshape(1)
+    if reduce is not None:
+        n_hit = reduce(n_hit)
+    n_hit = n_hit[0]
+    lvis_loss = (out["gt_lvis"] - out["pre_lvis"]).abs().sum() / (n_hit * 4 + 1e-6)
     err = (out["gt_trace_radiance"] - out["pre_trace_radiance"]) * m[:, None, None]
-    radiance_loss = err.abs().sum() / (m.sum() * 12 + 1e-6)
+    radiance_loss = err.abs().sum() / (n_hit * 12 + 1e-6)
     return {"loss": lvis_loss + radiance_loss, "lvis_loss": lvis_loss, "trace_radiance_loss": radiance_loss}
 
 
 class Stage2Trainer:
     def __init__(self, device, model_conf: Optional[dict] = None, prec: int = ops.PREC_PARITY, lr: float = 5e-4, seed: int = 0,
-                 synthetic_init: bool = True, sdf_kwargs: Optional[dict] = None, use_graph: bool = False):
+                 synthetic_init: bool = True, sdf_kwargs: Optional[dict] = None, use_graph: bool = False,
+                 distributed: bool = False):
         from models.fields import SDFNetwork, RenderingNetwork, SingleVarianceNetwork, RefColor, Lvis, IndirectLight
         from models.renderer import NeuSRenderer
         conf = model_conf or dict(WMASK_MODEL, lvis_renderer=LVIS_RENDERER)
@@ -56,7 +63,7 @@ class Stage2Trainer:
         self.color_network.set_precision(prec)
         # lvis.py:89-92
         self.params = list(self.lvis_network.parameters()) + list(self.indiLgt_network.parameters())
-        self._init_step_mode(use_graph, lr)
+        self._init_step_mode(use_graph, lr, distributed)
         self.renderer = NeuSRenderer(**conf.get("lvis_renderer", LVIS_RENDERER), sdf_network=self.sdf_network,
                                      deviation_network=self.deviation_network, color_network=self.color_network,
                                      lvis_network=self.lvis_network, indiLgt_network=self.indiLgt_network)
@@ -68,7 +75,22 @@ class Stage2Trainer:
     # launch-bound element-wise kernels of the torch-side networks and losses then cost their GPU time only.  Differences a
     # user can observe: a batch without any hit is not skipped (its loss and gradients are zero; Adam's moments still
     # decay), the direction draws consume the generator per ray instead of per hit point.
-    def _init_step_mode(self, use_graph: bool, lr: float):
+    #
+    # distributed (one process per GPU, rays sharded by rank): the fixed-shape step launched eagerly
+    # with two exchanges -- the loss normalisers (hit count; stage 3: mask sum and the latent-sparsity statistics) summed over
+    # the ranks BEFORE the loss, so that R ranks x B rays equal one R*B-ray batch, and ONE in-place all-reduce of the flat
+    # gradient buffer all trained parameters' .grad are views of.  Every rank runs both every step (no data-dependent skip).
+    def _init_step_mode(self, use_graph: bool, lr: float, distributed: bool = False):
+        self.distributed = bool(distributed)
+        self.reduce = None
+        self.grads = None
+        if self.distributed:
+            from fneus.parallel import GradArena, reduce_loss_norms
+            use_graph = False
+            self.reduce = reduce_loss_norms                       # in-place all-reduce(SUM); identity for one rank
+            holder = torch.nn.Module()
+            holder.ps = torch.nn.ParameterList(self.params)
+            self.grads = GradArena(self.device, [], None, [holder])
         self.use_graph = bool(use_graph) and self.device.type == "cuda"
         if self.use_graph:        # a device-scalar learning rate: schedule updates reach the replayed optimiser step
             self.optimizer = torch.optim.Adam(self.params, lr=torch.tensor(float(lr), device=self.device), capturable=True)
@@ -131,13 +153,22 @@ class Stage2Trainer:
         self.iter_step += 1
         return losses
 
+    def _backward_and_step(self, loss):
+        if self.grads is not None:           # data parallel: gradients accumulate into the arena views, summed in place
+            self.grads.restore_small_grads()
+            self.grads.flat.zero_()
+            loss.backward()
+            self.grads.allreduce_sum()
+        else:
+            self.optimizer.zero_grad(set_to_none=True)
+            loss.backward()
+        self.optimizer.step()
+
     def _fixed_shape_step(self, data: torch.Tensor):
         rays_o, rays_d, _rgb, _mask = ops.split_batch(data.contiguous())
         out = self.renderer.lvis_render(rays_o, rays_d, None, None, fixed_shape=True)
-        losses = stage2_loss(out)
-        self.optimizer.zero_grad(set_to_none=True)
-        losses["loss"].backward()
-        self.optimizer.step()
+        losses = stage2_loss(out, self.reduce)
+        self._backward_and_step(losses["loss"])
         return {"n_hit": out["sdf_mask"].sum(), **{k: v.detach() for k, v in losses.items()}}
 
     def train_step(self, data: torch.Tensor, near=None, far=None, u_theta=None, u_z=None):
@@ -145,6 +176,9 @@ class Stage2Trainer:
         the batch hits the surface (the reference skips such a batch, lvis.py:160-161)"""
         if self.use_graph and near is None and u_theta is None:
             return self._graph_step(data)
+        if self.distributed:
+            self.iter_step += 1
+            return self._fixed_shape_step(data)
         rays_o, rays_d, _rgb, _mask = ops.split_batch(data.contiguous())
         out = self.renderer.lvis_render(rays_o, rays_d, near, far, u_theta=u_theta, u_z=u_z)
         if not bool(out["sdf_mask"].any()):

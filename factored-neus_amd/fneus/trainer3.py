@@ -17,10 +17,14 @@ from fneus import ops, synth
 from fneus.trainer import WMASK_MODEL
 
 
-def stage3_loss(out: dict, true_rgb, mask):
-    """mateIllu.py:152-172 (mask = (mask > 0.5) when train.mask_weight > 0, else ones: the caller's business)"""
+def stage3_loss(out: dict, true_rgb, mask, reduce=None):
+    """mateIllu.py:152-172 (mask = (mask > 0.5) when train.mask_weight > 0, else ones: the caller's business).
+    reduce(t) -> t summed over the data-parallel ranks: rgb_loss is then this rank's share of the global batch's"""
     w = mask * out["sdf_mask"][:, None].to(mask.dtype)          # rays that hit AND lie inside the image mask (no boolean
-    denom = w.sum() + 1e-5                                       # indexing: nothing here may synchronise with the host)
+    wsum = w.sum().reshape(1)                                    # indexing: nothing here may synchronise with the host)
+    if reduce is not None:
+        wsum = reduce(wsum)
+    denom = wsum[0] + 1e-5
     diff = out["rgb"] - true_rgb
     rgb_loss = (diff * w).abs().sum() / denom
     psnr = 20.0 * torch.log10(1.0 / ((diff ** 2 * w).sum() / (denom * 3.0)).sqrt())
@@ -29,7 +33,7 @@ def stage3_loss(out: dict, true_rgb, mask):
 
 class Stage3Trainer:
     def __init__(self, device, model_conf: Optional[dict] = None, prec: int = ops.PREC_PARITY, lr: float = 5e-4, seed: int = 0,
-                 synthetic_init: bool = True, mask_weight: float = 0.1, use_graph: bool = False):
+                 synthetic_init: bool = True, mask_weight: float = 0.1, use_graph: bool = False, distributed: bool = False):
         from models.fields import SDFNetwork, SingleVarianceNetwork, RefColor, Lvis, IndirectLight
         from models.inverRender import EnvmapMaterialNetwork
         from models.renderer import NeuSRenderer
@@ -57,7 +61,8 @@ class Stage3Trainer:
         self.sdf_network.set_precision(prec)
         self.refColor_network.set_precision(prec)
         self.params = list(self.mateIllu_network.parameters())          # mateIllu.py:91-95
-        self._init_step_mode(use_graph, lr)
+        self._init_step_mode(use_graph, lr, distributed)
+        self.mateIllu_network.stat_reduce = self.reduce          # global latent-sparsity statistics (data parallel)
         self.renderer = NeuSRenderer(**conf["neus_renderer"], sdf_network=self.sdf_network,
                                      deviation_network=self.deviation_network, refColor_network=self.refColor_network,
                                      lvis_network=self.lvis_network, indiLgt_network=self.indiLgt_network,
@@ -69,22 +74,24 @@ class Stage3Trainer:
     from fneus.trainer2 import Stage2Trainer as _S2
     _init_step_mode, set_lr, get_lr, _graph_step = _S2._init_step_mode, _S2.set_lr, _S2.get_lr, _S2._graph_step
     optimizer_state_dict, load_optimizer_state_dict = _S2.optimizer_state_dict, _S2.load_optimizer_state_dict
+    _backward_and_step = _S2._backward_and_step
     del _S2
 
     def _fixed_shape_step(self, data: torch.Tensor):
         rays_o, rays_d, true_rgb, mask = ops.split_batch(data.contiguous())
         mask = (mask > 0.5).float() if self.mask_weight > 0.0 else torch.ones_like(mask)
         out = self.renderer.mateIllu_render(rays_o, rays_d, None, None, fixed_shape=True)
-        losses = stage3_loss(out, true_rgb, mask)
-        self.optimizer.zero_grad(set_to_none=True)
-        losses["loss"].backward()
-        self.optimizer.step()
+        losses = stage3_loss(out, true_rgb, mask, self.reduce)
+        self._backward_and_step(losses["loss"])
         return {"n_hit": out["sdf_mask"].sum(), **{k: v.detach() for k, v in losses.items()}}
 
     def train_step(self, data: torch.Tensor, near=None, far=None, u_theta=None, u_phi=None):
         """data [B,10] (dataset.py:133-151).  -> loss dict, or None when no ray hits the surface (mateIllu.py:156)"""
         if self.use_graph and near is None and u_theta is None:
             return self._graph_step(data)
+        if self.distributed:
+            self.iter_step += 1
+            return self._fixed_shape_step(data)
         rays_o, rays_d, true_rgb, mask = ops.split_batch(data.contiguous())
         mask = (mask > 0.5).float() if self.mask_weight > 0.0 else torch.ones_like(mask)
         out = self.renderer.mateIllu_render(rays_o, rays_d, near, far, u_theta=u_theta, u_phi=u_phi)

@@ -240,6 +240,7 @@ class EnvmapMaterialNetwork(nn.Module):
         sg[num_lgt_sgs // 2:, :3] = lobes
         self.lgtSGs = nn.Parameter(sg, requires_grad=True)
         self.envmap = None
+        self.stat_reduce = None      # set by the data-parallel trainer: sums the latent-sparsity statistics over the ranks
 
     def kl_divergence(self, rho, rho_hat, point_mask=None):
         """inverRender.py:609-612.  point_mask [n] bool: the mean runs over the marked points only (the fixed-shape stage-3
@@ -250,8 +251,13 @@ class EnvmapMaterialNetwork(nn.Module):
             return torch.mean(rho * torch.log(rho / rho_hat) + (1 - rho) * torch.log((1 - rho) / (1 - rho_hat)))
         w = point_mask.to(act.dtype)[:, None]
         cnt = w.sum()
+        total = (act * w).sum(0)
+        red = getattr(self, "stat_reduce", None)
+        if red is not None:         # data parallel: the mean runs over the hit points of ALL ranks; the other ranks' part is a
+            stats = red(torch.cat([total.detach(), cnt.reshape(1)]))        # constant here (their gradients are theirs)
+            total, cnt = total + (stats[:-1] - total.detach()), stats[-1]
         some = cnt > 0
-        rho_hat = torch.where(some, (act * w).sum(0) / cnt.clamp(min=1.0), torch.full_like(act[0], rho))
+        rho_hat = torch.where(some, total / cnt.clamp(min=1.0), torch.full_like(act[0], rho))
         kl = torch.mean(rho * torch.log(rho / rho_hat) + (1 - rho) * torch.log((1 - rho) / (1 - rho_hat)))
         return torch.where(some, kl, torch.zeros_like(kl))
 

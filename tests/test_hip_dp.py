@@ -104,3 +104,120 @@ def test_capture_failure_on_one_rank_moves_every_rank_to_eager_launches():
     eager = _two_ranks(graph=False)
     assert len(trace) == 7
     assert abs(trace[0] - eager[0]) <= 1e-5 * max(1.0, abs(eager[0]))
+
+
+class _FakeReduce:
+    """stands in for the all-reduce(SUM) of the data-parallel trainers on one process: pass 1 records what every "rank"
+    contributes (per call site, in call order), pass 2 hands back the sums"""
+
+    def __init__(self):
+        self.rec, self.tot, self.i, self.apply = [], None, 0, False
+
+    def begin_rank(self):
+        self.i = 0
+
+    def __call__(self, t):
+        if not self.apply:
+            if self.i == len(self.rec):
+                self.rec.append(t.detach().clone())
+            else:
+                self.rec[self.i] += t.detach()
+            self.i += 1
+            return t
+        out = self.rec[self.i].clone()
+        self.i += 1
+        return out
+
+
+def _param_grads(params):
+    return [p.grad.detach().clone() for p in params]
+
+
+def test_stage2_two_half_batches_with_global_hit_count_equal_the_full_batch():
+    """stage 2 data parallel (fneus/trainer2.py): R ranks x B rays == one R*B-ray batch"""
+    from fneus.trainer import synthetic_batches
+    from fneus.trainer2 import Stage2Trainer, stage2_loss
+    dev = torch.device("cuda:0")
+    tr = Stage2Trainer(dev, seed=4)
+    full = synthetic_batches(1, 128, dev, seed0=321)[0]
+    g = torch.Generator().manual_seed(1)
+    ut, uz = torch.rand(128, 4, generator=g).to(dev), torch.rand(128, 4, generator=g).to(dev)
+
+    def run(rows, reduce):
+        d = full[rows].contiguous()
+        out = tr.renderer.lvis_render(d[:, :3].contiguous(), d[:, 3:6].contiguous(), None, None, u_theta=ut[rows].contiguous(),
+                                      u_z=uz[rows].contiguous(), fixed_shape=True)
+        return stage2_loss(out, reduce)
+
+    for p in tr.params:
+        p.grad = None
+    L = run(slice(0, 128), None)
+    L["loss"].backward()
+    ref, ref_loss = _param_grads(tr.params), float(L["loss"])
+    fake = _FakeReduce()
+    for rows in (slice(0, 64), slice(64, 128)):
+        fake.begin_rank()
+        run(rows, fake)
+    fake.apply = True
+    for p in tr.params:
+        p.grad = None
+    total = 0.0
+    for rows in (slice(0, 64), slice(64, 128)):
+        fake.begin_rank()
+        L = run(rows, fake)
+        L["loss"].backward()                      # .grad accumulates like the arena all-reduce(SUM)
+        total += float(L["loss"])
+    assert abs(total - ref_loss) <= 2e-6 * max(1.0, abs(ref_loss)), (total, ref_loss)
+    worst = max(((a - b).abs().max() / (b.abs().max() + 1e-12)).item() for a, b in zip(_param_grads(tr.params), ref))
+    print(f"  stage 2: two half batches vs full batch: worst relative gradient difference {worst:.2e}")
+    assert worst <= 1e-4
+    # the trainer's own data-parallel step (one rank: the collectives are identities) runs and keeps .grad in its arena
+    trd = Stage2Trainer(dev, seed=4, distributed=True)
+    o = trd.train_step(full)
+    assert bool(torch.isfinite(o["loss"])) and trd.iter_step == 1
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(trd.grads.small, trd.grads._small_views))
+
+
+def test_stage3_two_half_batches_with_global_statistics_equal_the_full_batch():
+    """stage 3 data parallel (fneus/trainer3.py): mask sum and the latent-sparsity statistics are global"""
+    from fneus.trainer import synthetic_batches
+    from fneus.trainer3 import Stage3Trainer, stage3_loss
+    dev = torch.device("cuda:0")
+    tr = Stage3Trainer(dev, seed=4)
+    full = synthetic_batches(1, 128, dev, seed0=322)[0]
+    g = torch.Generator().manual_seed(2)
+    ut, up = torch.rand(128, 32, generator=g).to(dev), torch.rand(128, 32, generator=g).to(dev)
+
+    def run(rows, reduce):
+        d = full[rows].contiguous()
+        tr.mateIllu_network.stat_reduce = reduce
+        out = tr.renderer.mateIllu_render(d[:, :3].contiguous(), d[:, 3:6].contiguous(), None, None, u_theta=ut, u_phi=up,
+                                          fixed_shape=True)
+        return stage3_loss(out, d[:, 6:9].contiguous(), (d[:, 9:10] > 0.5).float(), reduce)
+
+    for p in tr.params:
+        p.grad = None
+    L = run(slice(0, 128), None)
+    L["loss"].backward()
+    ref, ref_rgb, ref_kl = _param_grads(tr.params), float(L["rgb_loss"]), float(L["encoder_loss"])
+    fake = _FakeReduce()
+    for rows in (slice(0, 64), slice(64, 128)):
+        fake.begin_rank()
+        run(rows, fake)
+    fake.apply = True
+    for p in tr.params:
+        p.grad = None
+    rgb = 0.0
+    for rows in (slice(0, 64), slice(64, 128)):
+        fake.begin_rank()
+        L = run(rows, fake)
+        L["loss"].backward()
+        rgb += float(L["rgb_loss"])
+        assert abs(float(L["encoder_loss"]) - ref_kl) <= 1e-6 * max(1.0, abs(ref_kl))       # the same global value on every rank
+    assert abs(rgb - ref_rgb) <= 2e-6 * max(1.0, abs(ref_rgb))
+    worst = max(((a - b).abs().max() / (b.abs().max() + 1e-12)).item() for a, b in zip(_param_grads(tr.params), ref))
+    print(f"  stage 3: two half batches vs full batch: worst relative gradient difference {worst:.2e}")
+    assert worst <= 1e-4
+    trd = Stage3Trainer(dev, seed=4, distributed=True)
+    o = trd.train_step(full)
+    assert bool(torch.isfinite(o["loss"])) and trd.iter_step == 1
