@@ -2,6 +2,7 @@
 """Stage-3 runner with the reference's command line (mateIllu.py:1121-1163, mode train) on the MI355X HIP backend.
 
     python mateIllu.py --mode train --conf ./confs/wmask.conf --case dtu_scan97 --type dtu [--is_continue] [--gpu 0]
+    torchrun --nproc-per-node 8 mateIllu.py --mode train ...             # ray-sharded data parallel (RCCL)
 
 Loads the newest stage-2 checkpoint of general.base_exp_dir_lvis (mateIllu.py:97-105, 238-245), trains the
 EnvmapMaterialNetwork (train.metaIllu.*: 40 000 iterations x 512 rays, warm-up then cosine) and writes checkpoints with the
@@ -34,7 +35,7 @@ def _latest(ckpt_dir, end_iter):
 
 class Runner:
     def __init__(self, conf_path, mode="train", case="CASE_NAME", is_continue=False, type="dtu", device=None,
-                 prec=ops.PREC_PARITY, use_graph=True):
+                 prec=ops.PREC_PARITY, use_graph=True, distributed=False, rank=0):
         self.device = device or torch.device("cuda")
         self.conf = hocon.parse_file(conf_path, case)
         self.base_exp_dir_mateIllu = self.conf["general.base_exp_dir_mateIllu"]
@@ -57,7 +58,8 @@ class Runner:
         self.mask_weight = tc.get_float("mask_weight")
         model_conf = {k: dict(self.conf["model"][k]) for k in ("sdf_network", "variance_network", "neus_renderer")}
         self.trainer = Stage3Trainer(self.device, model_conf=model_conf, prec=prec, lr=self.learning_rate, synthetic_init=False,
-                                     mask_weight=self.mask_weight, use_graph=use_graph)
+                                     mask_weight=self.mask_weight, use_graph=use_graph, distributed=distributed)
+        self.rank = rank
         self.iter_step = 0
         prev = _latest(os.path.join(self.base_exp_dir_lvis, "checkpoints"), tc.get_int("lvis.end_iter"))
         if prev is None:
@@ -70,6 +72,12 @@ class Runner:
                 logging.info("Find checkpoint: %s", name)
                 self.load_checkpoint(name)
 
+    def _broadcast(self):
+        """data parallel: every replica starts from rank 0's trainable parameters"""
+        from fneus.parallel import broadcast_parameters
+        t = self.trainer
+        broadcast_parameters([t.mateIllu_network])
+
     def update_learning_rate(self):      # mateIllu.py:214-224
         if self.iter_step < self.warm_up_end:
             factor = self.iter_step / self.warm_up_end
@@ -80,6 +88,7 @@ class Runner:
         self.trainer.set_lr(self.learning_rate * factor)
 
     def train(self, max_steps=None):
+        self._broadcast()
         self.update_learning_rate()
         perm = torch.randperm(self.dataset.n_images)
         steps = self.end_iter - self.iter_step if max_steps is None else max_steps
@@ -91,10 +100,10 @@ class Runner:
                 continue
             losses = out
             self.iter_step += 1
-            if self.iter_step % self.report_freq == 0:
+            if self.rank == 0 and self.iter_step % self.report_freq == 0:
                 print(self.base_exp_dir_mateIllu)
                 print("iter:{:8>d} loss = {} lr={}".format(self.iter_step, losses["rgb_loss"].item(), self.trainer.get_lr()))
-            if self.iter_step % self.save_freq == 0:
+            if self.rank == 0 and self.iter_step % self.save_freq == 0:
                 self.save_checkpoint()
             self.update_learning_rate()
             if self.iter_step % len(perm) == 0:
@@ -144,9 +153,15 @@ def main():
     ap.add_argument("--no_graph", action="store_true", help="compact the hit points and launch eagerly instead of replaying the "
                                                              "fixed-shape step as a hipGraph")
     args = ap.parse_args()
-    torch.cuda.set_device(args.gpu)
-    runner = Runner(args.conf, args.mode, args.case, args.is_continue, args.type, device=torch.device("cuda", args.gpu),
-                    prec=ops.PREC_PARITY if args.prec == "parity" else ops.PREC_FAST, use_graph=not args.no_graph)
+    from fneus.parallel import init_from_env
+    rank, world, local = init_from_env("nccl")       # torchrun --nproc-per-node N: rays sharded by rank over RCCL
+    gpu = local if world > 1 else args.gpu
+    torch.cuda.set_device(gpu)
+    if world > 1:
+        torch.manual_seed(1234 + rank)               # every rank draws its own pixels and directions
+    runner = Runner(args.conf, args.mode, args.case, args.is_continue, args.type, device=torch.device("cuda", gpu),
+                    prec=ops.PREC_PARITY if args.prec == "parity" else ops.PREC_FAST, use_graph=not args.no_graph,
+                    distributed=world > 1, rank=rank)
     if args.mode == "train":
         runner.train(max_steps=args.max_steps)
     else:
