@@ -12,6 +12,7 @@
 // Same wave-local MFMA engine as the SDF / colour kernels: one wavefront carries a 32-sample tile through the whole net.
 #define FNEUS_PREFETCH_X3 4
 #define FNEUS_PREFETCH_X1 8
+#include <stdlib.h>
 #include "pp_engine.h"
 #include "fneus_kernels.h"
 
@@ -228,9 +229,283 @@ __global__ void __launch_bounds__(64, 1) nerf_bwd_kernel(const unsigned char* bl
     }
 }
 
+
+// ---- tensor-parallel workgroups (tp_engine.h / pp_engine.h) --------------------------------------------------------------
+// The 4 wavefronts of a workgroup share one 32-sample tile, wave w owns output tiles 2w, 2w+1 of every 256-wide layer (tile w
+// of the 128-wide view layer); two workgroups per CU.  At the womask shape (2560 tiles) the one-wave kernels above run
+// 2.5 rounds of 1024 resident waves -- three rounds of a ~130 us chain --, the tensor-parallel form five even rounds of a
+// chain four times shorter.  LDS: 16 k-steps of fragments (hi, lo) + 6 parked k-steps for the point's encoding, which
+// layer 0 and layer 5 read (k-steps 16..21; the view layer's 2 encoding k-steps reuse 16, 17 once layer 5 is done).
+constexpr int kNerfTpLds = 22 * 2 * kFragBytes;
+constexpr int kNerfPark = 16;                      // first parked k-step
+
+template <int PREC>
+FN_DEV unsigned char* frag_at(unsigned char* frag, int ks) {
+    return frag + (size_t)ks * (PREC == 3 ? 2 : 1) * kFragBytes;
+}
+
+template <int PREC, int KS>
+FN_DEV void nerf_write_frags(unsigned char* frag, int lane, int ks0, const BFrag<PREC>* b) {
+    constexpr int NPL = PREC == 3 ? 2 : 1;
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+        *reinterpret_cast<bf16x8*>(frag + ((ks0 + i) * NPL) * kFragBytes + lane * 16) = b[i].hi;
+        if constexpr (PREC == 3) *reinterpret_cast<bf16x8*>(frag + ((ks0 + i) * NPL + 1) * kFragBytes + lane * 16) = b[i].lo;
+    }
+}
+
+// The 16 features of k-step `ks` of the point's encoding as one B fragment, each lane computing only the 8 features of its
+// own slots (feature phi(ks, h, j) = 16 ks + 8 (j >> 2) + 4 h + (j & 3); embedder.py:23-36 with input_dims = 4: feature f < 4 is
+// x_f, then octave k = (f - 4) >> 3 holds sin(2^k x_c) for c = 0..3 and cos(2^k x_c) for c = 0..3).  Spreads the 80 sincos of a
+// tile's encoding over the 4 waves of the workgroup (k-steps w and w + 4) instead of leaving them to one wave.
+template <int PREC>
+FN_DEV void posenc4_frag(const float (&x)[4], int ks, int h, BFrag<PREC>& out) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int f = 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3);
+        float val = 0.0f;
+        if (f < kNerfPE) {
+            const int g = f - 4, c = f < 4 ? f : (g & 3);
+            const float xc = c == 0 ? x[0] : (c == 1 ? x[1] : (c == 2 ? x[2] : x[3]));
+            if (f < 4) {
+                val = xc;
+            } else {
+                float sn, cs;
+                sincosf(xc * (float)(1 << (g >> 3)), &sn, &cs);
+                val = (g & 4) ? cs : sn;
+            }
+        }
+        if constexpr (PREC == 3) {
+            __bf16 a, b;
+            split_bf16(val, a, b);
+            out.hi[j] = a;
+            out.lo[j] = b;
+        } else {
+            out.hi[j] = (__bf16)val;
+        }
+    }
+}
+
+FN_DEV void nerf_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int TN>
+FN_DEV uint32_t relu_bits(f32x16 (&acc)[TN]) {      // ReLU in place; bit t * 16 + r = sign of register r of tile t
+    uint32_t m = 0u;
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool pos = acc[t][r] > 0.0f;
+            acc[t][r] = pos ? acc[t][r] : 0.0f;
+            m |= (pos ? 1u : 0u) << (t * 16 + r);
+        }
+    return m;
+}
+
+template <int TN>
+FN_DEV void apply_bits(f32x16 (&acc)[TN], uint32_t m, bool valid) {
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = (((m >> (t * 16 + r)) & 1u) && valid) ? acc[t][r] : 0.0f;
+}
+
+template <int PREC, bool TRAIN>
+__global__ void __launch_bounds__(256, 2) nerf_fwd_tp_kernel(const unsigned char* blob, const float* __restrict__ pts4,
+                                                             const float* __restrict__ dirs, long N, NerfStash st,
+                                                             float* __restrict__ density, float* __restrict__ rgb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
+    unsigned char* frag = lds_;
+    unsigned char* park = frag_at<PREC>(frag, kNerfPark);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = lane & 31, h = lane >> 5;
+    const int t0 = 2 * wave;
+    const PPLane pl = pp_lane(lane);
+    const long tiles = pp_tiles(N);
+    const bool lo_planes = TRAIN && PREC == 3 && st.h_lo != nullptr;
+    constexpr auto& LY = kNerfLayout;
+    for (long tile = blockIdx.x; tile * 32 < N; tile += gridDim.x) {
+        asm volatile("" : "+s"(blob));
+        const long n = tile * 32 + r;
+        const bool valid = n < N;
+        const long nc = valid ? n : N - 1;
+        BFrag<PREC> bf[kMaxKS], bx[kMaxKS];
+        uint32_t* mrow = reinterpret_cast<uint32_t*>(st.mask + (size_t)tile * 9 * 64 + lane);       // [9 slots][64 lanes] x 4 words
+        nerf_barrier();                                   // the previous tile's fragments are consumed
+        {                                                 // the point's encoding: 6 k-steps, parked for layers 0 and 5;
+            float x[4];                                   // wave w builds k-steps w and w + 4
+#pragma unroll
+            for (int c = 0; c < 4; ++c) x[c] = pts4[nc * 4 + c];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ks = wave + 4 * i;
+                if (ks < 6) {
+                    BFrag<PREC> one[1];
+                    posenc4_frag<PREC>(x, ks, h, one[0]);
+                    nerf_write_frags<PREC, 1>(frag, lane, kNerfPark + ks, one);
+                    if constexpr (TRAIN)
+                        frags_to_plane<PREC, 1>(one, ks, st.pe_hi + (size_t)tile * 6 * kFragBytes,
+                                                lo_planes ? st.pe_lo + (size_t)tile * 6 * kFragBytes : nullptr, pl, valid);
+                }
+            }
+        }
+        nerf_barrier();
+        f32x16 acc[2];
+        // pts_linears.0
+        tp_operands<PREC, 6>(park, lane, bx);
+        load_accvec<8, 0, 2>(blob, LY.L[0].bias, acc, lane, t0);
+        tp_dense<PREC, 6, 8, 0, 2>(blob, LY.L[0].fwd_hi, LY.L[0].fwd_lo, park, bx, acc, lane, t0);
+#pragma unroll 1
+        for (int l = 0; l <= 7; ++l) {
+            if (l > 0) {
+                const int e = l < 6 ? l : l + 1;          // pack entry of pts_linears.l (its h columns for l = 5)
+                load_accvec<8, 0, 2>(blob, LY.L[e].bias, acc, lane, t0);
+                tp_dense<PREC, 16, 8, 0, 2>(blob, LY.L[e].fwd_hi, LY.L[e].fwd_lo, frag, bf, acc, lane, t0);
+                if (l == 5) tp_dense<PREC, 6, 8, 0, 2>(blob, LY.L[6].fwd_hi, LY.L[6].fwd_lo, park, bx, acc, lane, t0);
+            }
+            const uint32_t m = relu_bits<2>(acc);
+            if constexpr (TRAIN) mrow[(size_t)l * 64 * 4 + wave] = m;
+            const size_t off = ((size_t)l * tiles + tile) * kPPBlock;
+            tp_exchange_pp<PREC, 2, true>(frag, lane, t0, acc, TRAIN ? st.h_hi + off : nullptr, lo_planes ? st.h_lo + off : nullptr,
+                                          pl, valid);
+            tp_operands<PREC, 16>(frag, lane, bf);
+        }
+        // feature_linear (tiles 0..7, two per wave) and alpha_linear (tile 8, row 0: wave 0); no activation (fields.py:248-249)
+        load_accvec<9, 0, 2>(blob, LY.L[9].bias, acc, lane, t0);
+        tp_dense<PREC, 16, 9, 0, 2>(blob, LY.L[9].fwd_hi, LY.L[9].fwd_lo, frag, bf, acc, lane, t0);
+        if (wave == 0) {
+            f32x16 a1[1];
+            load_accvec<9, 8, 1>(blob, LY.L[9].bias, a1, lane);
+            tp_dense<PREC, 16, 9, 8, 1>(blob, LY.L[9].fwd_hi, LY.L[9].fwd_lo, frag, bf, a1, lane);
+            if (valid && lane < 32) density[n] = a1[0][0];
+        }
+        BFrag<PREC> bd[2];
+        if (wave == 1) {                                  // PE4 of the view direction: k-steps 16, 17 of the view layer
+            float d[3], pe[kViewPE], jc[kViewPE];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) d[c] = dirs[nc * 3 + c];
+            posenc<4, false>(d, pe, jc);
+            BFrag<PREC> tmp[kMaxKS];
+            vec_to_bfrag<PREC, kViewPE, 2, 0>(pe, tmp, h);
+            bd[0] = tmp[0];
+            bd[1] = tmp[1];
+            if constexpr (TRAIN)
+                frags_to_plane<PREC, 2>(bd, 0, st.dpe_hi + (size_t)tile * 2 * kFragBytes,
+                                        lo_planes ? st.dpe_lo + (size_t)tile * 2 * kFragBytes : nullptr, pl, valid);
+        }
+        tp_exchange_pp<PREC, 2, true>(frag, lane, t0, acc, TRAIN ? st.feat_hi + (size_t)tile * kPPBlock : nullptr,
+                                      lo_planes ? st.feat_lo + (size_t)tile * kPPBlock : nullptr, pl, valid,
+                                      wave == 1 ? bd : nullptr, kNerfPark, 2);
+        tp_operands<PREC, 18>(frag, lane, bf);
+        // views_linears.0: [feature | PE4(view)] -> 128 + ReLU; wave w owns tile w
+        f32x16 v[1];
+        load_accvec<4, 0, 1>(blob, LY.L[10].bias, v, lane, wave);
+        tp_dense<PREC, 18, 4, 0, 1>(blob, LY.L[10].fwd_hi, LY.L[10].fwd_lo, frag, bf, v, lane, wave);
+        {
+            const uint32_t m = relu_bits<1>(v);
+            if constexpr (TRAIN) reinterpret_cast<uint16_t*>(mrow + (size_t)8 * 64 * 4)[wave] = (uint16_t)m;
+        }
+        tp_exchange_pp<PREC, 1, true>(frag, lane, wave, v, TRAIN ? st.hv_hi + (size_t)tile * 8 * kFragBytes : nullptr,
+                                      lo_planes ? st.hv_lo + (size_t)tile * 8 * kFragBytes : nullptr, pl, valid);
+        tp_operands<PREC, 8>(frag, lane, bf);
+        if (wave == 0) {
+            f32x16 o[1];
+            load_accvec<1, 0, 1>(blob, LY.L[11].bias, o, lane);
+            tp_dense<PREC, 8, 1, 0, 1>(blob, LY.L[11].fwd_hi, LY.L[11].fwd_lo, frag, bf, o, lane);
+            if (valid && lane < 32) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) rgb[n * 3 + c] = o[0][c];
+            }
+        }
+    }
+}
+
+template <int PREC>
+__global__ void __launch_bounds__(256, 2) nerf_bwd_tp_kernel(const unsigned char* blob, long N, const float* __restrict__ d_density,
+                                                             const float* __restrict__ d_rgb, NerfStash st) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
+    unsigned char* frag = lds_;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = lane & 31, h = lane >> 5;
+    const int t0 = 2 * wave;
+    const PPLane pl = pp_lane(lane);
+    const long tiles = pp_tiles(N);
+    const bool lo_planes = PREC == 3 && st.zbar_lo != nullptr;
+    constexpr auto& LY = kNerfLayout;
+    for (long tile = blockIdx.x; tile * 32 < N; tile += gridDim.x) {
+        asm volatile("" : "+s"(blob));
+        const long n = tile * 32 + r;
+        const bool valid = n < N;
+        const long nc = valid ? n : N - 1;
+        const uint32_t* mrow = reinterpret_cast<const uint32_t*>(st.mask + (size_t)tile * 9 * 64 + lane);
+        BFrag<PREC> bf[kMaxKS];
+        unsigned char* zo_hi = st.zout_hi + (size_t)tile * 4 * kFragBytes;      // zout block: fragments 0, 1 = the rgb tile,
+        unsigned char* zo_lo = lo_planes ? st.zout_lo + (size_t)tile * 4 * kFragBytes : nullptr;       // 2, 3 = the density tile
+        BFrag<PREC> bden[2];                              // the density tile's fragments (wave 0), published with dL/d feature
+        if (wave == 0) {
+            f32x16 zo[2];
+            zero_acc(zo);
+            if (h == 0 && valid) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) zo[0][c] = d_rgb[nc * 3 + c];
+                zo[1][0] = d_density[nc];
+            }
+            BFrag<PREC> tmp[kMaxKS];
+            acc_to_bfrag<PREC, 1>(reinterpret_cast<f32x16(&)[1]>(zo[1]), tmp);
+            bden[0] = tmp[0];
+            bden[1] = tmp[1];
+            frags_to_plane<PREC, 2>(bden, 2, zo_hi, zo_lo, pl, valid);
+            tp_exchange_pp<PREC, 1, true>(frag, lane, 0, reinterpret_cast<f32x16(&)[1]>(zo[0]), zo_hi, zo_lo, pl, valid);
+        } else {
+            nerf_barrier();
+            nerf_barrier();
+        }
+        tp_operands<PREC, 2>(frag, lane, bf);
+        // rgb_linear reverse: 2 k-steps -> the 128 view-branch features (wave w: tile w), then ReLU' of views_linears.0
+        f32x16 v[1];
+        zero_acc(v);
+        tp_dense<PREC, 2, 4, 0, 1>(blob, LY.L[11].rev_hi, LY.L[11].rev_lo, frag, bf, v, lane, wave);
+        apply_bits<1>(v, reinterpret_cast<const uint16_t*>(mrow + (size_t)8 * 64 * 4)[wave], valid);
+        tp_exchange_pp<PREC, 1, true>(frag, lane, wave, v, st.zhv_hi + (size_t)tile * 8 * kFragBytes,
+                                      lo_planes ? st.zhv_lo + (size_t)tile * 8 * kFragBytes : nullptr, pl, valid);
+        tp_operands<PREC, 8>(frag, lane, bf);
+        // views_linears.0 reverse onto its 256 feature inputs = dL/d feature (feature_linear has no activation)
+        f32x16 acc[2];
+        zero_acc(acc);
+        tp_dense<PREC, 8, 8, 0, 2>(blob, LY.L[10].rev_hi, LY.L[10].rev_lo, frag, bf, acc, lane, t0);
+        tp_exchange_pp<PREC, 2, true>(frag, lane, t0, acc, st.zfeat_hi + (size_t)tile * kPPBlock,
+                                      lo_planes ? st.zfeat_lo + (size_t)tile * kPPBlock : nullptr, pl, valid,
+                                      wave == 0 ? bden : nullptr, 16, 2);          // k-steps 16, 17: the density row
+        tp_operands<PREC, 18>(frag, lane, bf);
+        // feature_linear^T dfeature + alpha_linear^T ddensity -> dL/d h_7
+        zero_acc(acc);
+        tp_dense<PREC, 18, 8, 0, 2>(blob, LY.L[9].rev_hi, LY.L[9].rev_lo, frag, bf, acc, lane, t0);
+#pragma unroll 1
+        for (int l = 7; l >= 0; --l) {
+            apply_bits<2>(acc, mrow[(size_t)l * 64 * 4 + wave], valid);
+            const size_t off = ((size_t)l * tiles + tile) * kPPBlock;
+            tp_exchange_pp<PREC, 2, true>(frag, lane, t0, acc, st.zbar_hi + off, lo_planes ? st.zbar_lo + off : nullptr, pl, valid);
+            if (l > 0) {
+                tp_operands<PREC, 16>(frag, lane, bf);
+                const int e = l < 6 ? l : l + 1;
+                zero_acc(acc);
+                tp_dense<PREC, 16, 8, 0, 2>(blob, LY.L[e].rev_hi, LY.L[e].rev_lo, frag, bf, acc, lane, t0);
+            }
+        }
+    }
+}
+
 }  // namespace fneus
 
 using namespace fneus;
+
+// FNEUS_K7_TP=0 selects the one-wave-per-tile kernels (comparison runs); read at every call
+static inline bool nerf_use_tp() {
+    const char* e = getenv("FNEUS_K7_TP");
+    return !(e && e[0] == '0');
+}
 
 static inline int nerf_grid(long n_tiles) {
     long g = n_tiles;
@@ -251,6 +526,22 @@ extern "C" int fneus_nerf_bg_fwd(const void* blob, const float* pts4, const floa
     const unsigned char* b = reinterpret_cast<const unsigned char*>(blob);
     NerfStash st = stash ? NerfStash(*stash) : NerfStash();
     if (train && (!st.pe_hi || !st.h_hi || !st.feat_hi || !st.dpe_hi || !st.hv_hi || !st.mask)) return -2;
+    if (nerf_use_tp()) {
+        const long nt = (n_pts + 31) / 32;
+        dim3 g2((unsigned)(nt < 2048 ? nt : 2048)), b2(256);
+#define FNEUS_NERF_TP(KERNEL, ...)                                                                       \
+        do {                                                                                             \
+            static bool done = false;                                                                    \
+            if (!done) { fneus::allow_big_lds(KERNEL); done = true; }                                    \
+            hipLaunchKernelGGL((KERNEL), g2, b2, fneus::kNerfTpLds, stream, __VA_ARGS__);                 \
+        } while (0)
+        if (prec == 3 && train) FNEUS_NERF_TP((nerf_fwd_tp_kernel<3, true>), b, pts4, dirs, n_pts, st, density, rgb);
+        else if (prec == 3) FNEUS_NERF_TP((nerf_fwd_tp_kernel<3, false>), b, pts4, dirs, n_pts, st, density, rgb);
+        else if (prec == 1 && train) FNEUS_NERF_TP((nerf_fwd_tp_kernel<1, true>), b, pts4, dirs, n_pts, st, density, rgb);
+        else if (prec == 1) FNEUS_NERF_TP((nerf_fwd_tp_kernel<1, false>), b, pts4, dirs, n_pts, st, density, rgb);
+        else return -2;
+        return fneus::launch_status();
+    }
     dim3 grid(nerf_grid((n_pts + 31) / 32)), blk(64);
     if (prec == 3 && train)
         hipLaunchKernelGGL((nerf_fwd_kernel<3, true>), grid, blk, 0, stream, b, pts4, dirs, n_pts, st, density, rgb);
@@ -274,6 +565,14 @@ extern "C" int fneus_nerf_bg_bwd(const void* blob, long n_pts, const float* d_de
     NerfStash st(*stash);
     if (!st.mask || !st.zbar_hi || !st.zfeat_hi || !st.zhv_hi || !st.zout_hi) return -2;
     const unsigned char* b = reinterpret_cast<const unsigned char*>(blob);
+    if (nerf_use_tp()) {
+        const long nt = (n_pts + 31) / 32;
+        dim3 g2((unsigned)(nt < 2048 ? nt : 2048)), b2(256);
+        if (prec == 3) FNEUS_NERF_TP(nerf_bwd_tp_kernel<3>, b, n_pts, d_density, d_rgb, st);
+        else if (prec == 1) FNEUS_NERF_TP(nerf_bwd_tp_kernel<1>, b, n_pts, d_density, d_rgb, st);
+        else return -2;
+        return fneus::launch_status();
+    }
     dim3 grid(nerf_grid((n_pts + 31) / 32)), blk(64);
     if (prec == 3)
         hipLaunchKernelGGL(nerf_bwd_kernel<3>, grid, blk, 0, stream, b, n_pts, d_density, d_rgb, st);
