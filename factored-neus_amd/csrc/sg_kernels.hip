@@ -1,0 +1,354 @@
+// Stage-3 spherical-Gaussian rendering (reference models/inverRender.py:314-449 render_with_sg with :83-125, :264-283
+// lambda_trick / hemisphere_int / integrate_rgb) as ONE forward and ONE backward launch.
+//
+// Per surface point and light lobe the reference evaluates a chain of ~80 element-wise tensor ops on [points, lobes, 3]
+// tensors (twice: 128 direct lobes with visibility, 24 indirect lobes without), ~600 launches forward and ~1500 with
+// autograd's backward.  Here a wavefront owns a point, its lanes stride over the lobes, and the whole chain runs in
+// registers.  The backward pass recomputes the chain with forward-mode dual numbers (7 tangent directions at a time: first the
+// point's material parameters -- roughness, diffuse albedo, specular albedo --, then the lobe's own 7 SG parameters) and
+// contracts the partials with the incoming cotangents: no hand-derived adjoint to keep in sync with the forward code, the
+// same templated function serves both.  Work per step is tiny (512 x 152 lobe evaluations x ~5000 flops with duals).
+//
+// Outputs are the lobe SUMS before integrate_rgb's clamp (inverRender.py:277): [n][4][3] = direct specular, direct diffuse,
+// indirect specular, indirect diffuse; the clamps, the tone mapping and the losses stay with the caller.
+#include <math.h>
+#include "fneus_common.h"
+#include "fneus_kernels.h"
+
+namespace fneus {
+
+constexpr float kTiny = 1e-6f;      // inverRender.py:12 TINY_NUMBER
+constexpr float kPi = 3.14159265358979323846f;
+
+// ---- forward-mode dual numbers; N = 0 degenerates to plain floats -----------------------------------------------------------
+template <int N>
+struct Dual {
+    float v;
+    float d[N > 0 ? N : 1];
+};
+template <int N> FN_DEV Dual<N> mk(float v) {
+    Dual<N> r;
+    r.v = v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = 0.0f;
+    return r;
+}
+template <int N> FN_DEV Dual<N> var(float v, int idx) {      // an independent variable: d/d(idx) = 1
+    Dual<N> r = mk<N>(v);
+    if (idx >= 0 && idx < N) r.d[idx] = 1.0f;
+    return r;
+}
+#define FN_DUAL_UNARY(NAME, VAL, DER)                                      \
+    template <int N> FN_DEV Dual<N> NAME(const Dual<N>& a) {               \
+        Dual<N> r;                                                         \
+        const float val = (VAL), der = (DER);                              \
+        r.v = val;                                                         \
+        _Pragma("unroll") for (int i = 0; i < N; ++i) r.d[i] = der * a.d[i]; \
+        return r;                                                          \
+    }
+template <int N> FN_DEV Dual<N> operator+(const Dual<N>& a, const Dual<N>& b) {
+    Dual<N> r;
+    r.v = a.v + b.v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = a.d[i] + b.d[i];
+    return r;
+}
+template <int N> FN_DEV Dual<N> operator-(const Dual<N>& a, const Dual<N>& b) {
+    Dual<N> r;
+    r.v = a.v - b.v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = a.d[i] - b.d[i];
+    return r;
+}
+template <int N> FN_DEV Dual<N> operator*(const Dual<N>& a, const Dual<N>& b) {
+    Dual<N> r;
+    r.v = a.v * b.v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i];
+    return r;
+}
+template <int N> FN_DEV Dual<N> operator/(const Dual<N>& a, const Dual<N>& b) {
+    Dual<N> r;
+    const float inv = 1.0f / b.v;
+    r.v = a.v * inv;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * inv;
+    return r;
+}
+template <int N> FN_DEV Dual<N> operator+(const Dual<N>& a, float b) { Dual<N> r = a; r.v += b; return r; }
+template <int N> FN_DEV Dual<N> operator-(const Dual<N>& a, float b) { Dual<N> r = a; r.v -= b; return r; }
+template <int N> FN_DEV Dual<N> operator*(const Dual<N>& a, float b) {
+    Dual<N> r;
+    r.v = a.v * b;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b;
+    return r;
+}
+template <int N> FN_DEV Dual<N> operator/(const Dual<N>& a, float b) { return a * (1.0f / b); }
+template <int N> FN_DEV Dual<N> operator+(float a, const Dual<N>& b) { return b + a; }
+template <int N> FN_DEV Dual<N> operator*(float a, const Dual<N>& b) { return b * a; }
+template <int N> FN_DEV Dual<N> operator-(float a, const Dual<N>& b) { return mk<N>(a) - b; }
+template <int N> FN_DEV Dual<N> operator/(float a, const Dual<N>& b) { return mk<N>(a) / b; }
+FN_DUAL_UNARY(dsqrt, sqrtf(a.v), 0.5f / sqrtf(a.v))
+FN_DUAL_UNARY(dexp, expf(a.v), expf(a.v))
+FN_DUAL_UNARY(dabs, fabsf(a.v), (a.v > 0.0f ? 1.0f : (a.v < 0.0f ? -1.0f : 0.0f)))
+// torch.clamp: the gradient passes where the value lies inside the closed range
+FN_DUAL_UNARY(dclamp_min0, fmaxf(a.v, 0.0f), (a.v >= 0.0f ? 1.0f : 0.0f))
+FN_DUAL_UNARY(dclamp_max0, fminf(a.v, 0.0f), (a.v <= 0.0f ? 1.0f : 0.0f))
+FN_DUAL_UNARY(dclamp_min_tiny, fmaxf(a.v, kTiny), (a.v >= kTiny ? 1.0f : 0.0f))
+template <int N> FN_DEV Dual<N> dmin(const Dual<N>& a, const Dual<N>& b) {      // torch.min(a, b): ties share the gradient
+    if (a.v < b.v) return a;
+    if (b.v < a.v) return b;
+    return (a + b) * 0.5f;
+}
+
+template <int N> struct Vec3 { Dual<N> x, y, z; };
+template <int N> FN_DEV Dual<N> dot3(const Vec3<N>& a, const Vec3<N>& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <int N> FN_DEV Vec3<N> unit_tiny(const Vec3<N>& a) {       // norm_axis: x / (|x| + TINY)
+    const Dual<N> inv = 1.0f / (dsqrt(dot3(a, a)) + kTiny);
+    return Vec3<N>{a.x * inv, a.y * inv, a.z * inv};
+}
+template <int N> FN_DEV Vec3<N> cvec(const float (&v)[3]) { return Vec3<N>{mk<N>(v[0]), mk<N>(v[1]), mk<N>(v[2])}; }
+
+// inverRender.py:83-103 (mus handled by the caller: final_mu = mu1 * mu2 * exp(diff))
+template <int N>
+FN_DEV void lambda_trick(const Vec3<N>& lobe1, const Dual<N>& lam1, const Vec3<N>& lobe2, const Dual<N>& lam2, Vec3<N>& lobes,
+                         Dual<N>& lam3, Dual<N>& expdiff) {
+    const Dual<N> ratio = lam1 / (lam2 + kTiny);
+    const Vec3<N> l1 = unit_tiny(lobe1), l2 = unit_tiny(lobe2);
+    const Dual<N> d = dot3(l1, l2);
+    const Dual<N> tmp = dmin(dsqrt(ratio * ratio + 1.0f + 2.0f * ratio * d + kTiny), ratio + 1.0f);
+    lam3 = lam2 * tmp;
+    const Dual<N> c1 = ratio / (tmp + kTiny), c2 = 1.0f / (tmp + kTiny);
+    lobes = Vec3<N>{c1 * l1.x + c2 * l2.x, c1 * l1.y + c2 * l2.y, c1 * l1.z + c2 * l2.z};
+    expdiff = dexp(lam2 * (tmp - ratio - 1.0f));
+}
+
+// inverRender.py:106-125
+template <int N>
+FN_DEV Dual<N> hemisphere_int(const Dual<N>& lambda_val, const Dual<N>& cos_beta) {
+    const Dual<N> lam = dclamp_min_tiny(lambda_val);
+    const Dual<N> inv = 1.0f / (lam + kTiny);
+    const Dual<N> t = dsqrt(lam + kTiny) * (1.6988f + 10.8438f * inv) / (1.0f + 6.2201f * inv + 10.2415f * inv * inv + kTiny);
+    const Dual<N> inv_a = dexp(mk<N>(0.0f) - t);
+    const Dual<N> inv_b = dexp(mk<N>(0.0f) - t * dclamp_min0(cos_beta));
+    const Dual<N> s1 = (1.0f - inv_a * inv_b) / (1.0f - inv_a + inv_b - inv_a * inv_b + kTiny);
+    const Dual<N> b = dexp(t * dclamp_max0(cos_beta));
+    const Dual<N> s2 = (b - inv_a) / ((1.0f - inv_a) * (b + 1.0f) + kTiny);
+    const Dual<N> s = cos_beta.v >= 0.0f ? s1 : s2;
+    const Dual<N> two_pi_over = (2.0f * kPi) / lam;
+    const Dual<N> e1 = dexp(mk<N>(0.0f) - lam), e2 = dexp(mk<N>(0.0f) - 2.0f * lam);
+    const Dual<N> a_b = two_pi_over * (e1 - e2), a_u = two_pi_over * (1.0f - e1);
+    return a_b * (1.0f - s) + a_u * s;
+}
+
+// the per-channel-independent factor of integrate_rgb (inverRender.py:264-275): rgb_c = mu_c * W
+template <int N>
+FN_DEV Dual<N> integrate_weight(const float (&nrm)[3], const Vec3<N>& lobes, const Dual<N>& lams) {
+    const float mu_cos = 32.7080f, lambda_cos = 0.0315f, alpha_cos = 31.7003f;
+    const Vec3<N> n = cvec<N>(nrm);
+    Vec3<N> lobe_p;
+    Dual<N> lam_p, ed;
+    lambda_trick(n, mk<N>(lambda_cos), lobes, lams, lobe_p, lam_p, ed);
+    const Dual<N> dot1 = dclamp_min0(dot3(lobe_p, n));
+    const Dual<N> dot2 = dclamp_min0(dot3(lobes, n));
+    return mu_cos * ed * hemisphere_int(lam_p, dot1) - alpha_cos * hemisphere_int(lams, dot2);
+}
+
+struct PointConst {          // per point, parameter independent
+    float n[3], v[3], warp[3], v_dot_lobe, fresnel, dot1, dot2;
+};
+FN_DEV PointConst point_consts(const float* __restrict__ normal, const float* __restrict__ view, float f0) {
+    PointConst p;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        p.n[c] = normal[c];
+        p.v[c] = view[c];
+    }
+    p.v_dot_lobe = fmaxf(p.n[0] * p.v[0] + p.n[1] * p.v[1] + p.n[2] * p.v[2], 0.0f);          // :353-355
+    float w[3], nw = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        w[c] = 2.0f * p.v_dot_lobe * p.n[c] - p.v[c];
+        nw += w[c] * w[c];
+    }
+    nw = sqrtf(nw) + kTiny;
+    float hv[3], nh = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        p.warp[c] = w[c] / nw;                                                               // :356-357
+        hv[c] = p.warp[c] + p.v[c];
+        nh += hv[c] * hv[c];
+    }
+    nh = sqrtf(nh) + kTiny;
+    float vdh = 0.0f, d1 = 0.0f, d2 = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        vdh += p.v[c] * (hv[c] / nh);
+        d1 += p.warp[c] * p.n[c];
+        d2 += p.v[c] * p.n[c];
+    }
+    vdh = fmaxf(vdh, 0.0f);                                                                  // :363-365
+    p.fresnel = f0 + (1.0f - f0) * exp2f(-(5.55473f * vdh + 6.8316f) * vdh);                 // :368
+    p.dot1 = fmaxf(d1, 0.0f);                                                                // :370-375
+    p.dot2 = fmaxf(d2, 0.0f);
+    return p;
+}
+
+// one (point, lobe) pair: spec[c], diff[c] contributions.  mat = (roughness, diffuse albedo[3], specular albedo[3]); sg = the
+// lobe's 7 parameters; vis = the lobe's visibility at the point (1 for the indirect lobes).
+template <int N>
+FN_DEV void lobe_terms(const PointConst& pc, const Dual<N> (&mat)[7], const Dual<N> (&sg)[7], float vis, Dual<N> (&spec)[3],
+                       Dual<N> (&diff)[3]) {
+    const Vec3<N> raw{sg[0], sg[1], sg[2]};
+    const Dual<N> inv_len = 1.0f / (dsqrt(dot3(raw, raw)) + kTiny);                          // :334
+    const Vec3<N> lobe{raw.x * inv_len, raw.y * inv_len, raw.z * inv_len};
+    const Dual<N> lam = dabs(sg[3]);                                                         // :335
+    const Dual<N>& r = mat[0];
+    const Dual<N> inv_r4 = 2.0f / (r * r * r * r);                                           // :347
+    const Dual<N> warp_lam = inv_r4 / (4.0f * pc.v_dot_lobe + kTiny);                        // :358
+    const Dual<N> k = (r + 1.0f) * (r + 1.0f) / 8.0f;                                        // :376
+    const Dual<N> g1 = pc.dot1 / (pc.dot1 * (1.0f - k) + k + kTiny);
+    const Dual<N> g2 = pc.dot2 / (pc.dot2 * (1.0f - k) + k + kTiny);
+    const Dual<N> moi = pc.fresnel * (g1 * g2) / (4.0f * pc.dot1 * pc.dot2 + kTiny);         // :382
+    const Dual<N> brdf_mu = inv_r4 / kPi;                                                    // :349
+    const Vec3<N> warp = cvec<N>(pc.warp);
+    Vec3<N> fl;
+    Dual<N> fla, ed;
+    lambda_trick(lobe, lam, warp, warp_lam, fl, fla, ed);                                    // :411-412
+    const Dual<N> w_spec = integrate_weight(pc.n, fl, fla);                                  // :415
+    const Dual<N> w_diff = integrate_weight(pc.n, lobe, lam);                                // :433
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const Dual<N> mu = dabs(sg[4 + c]) * vis;                                            // :336, :402 / :407
+        spec[c] = mu * (mat[4 + c] * brdf_mu * moi) * ed * w_spec;                           // :383, :100, :275
+        diff[c] = mu * (mat[1 + c] / kPi) * w_diff;                                          // :428-431
+    }
+}
+
+// ---- kernels: one wavefront per point, lanes stride over the direct (M) and indirect (L) lobes ------------------------------
+__global__ void __launch_bounds__(64) sg_render_fwd_kernel(const float* __restrict__ lgt /*[M][7]*/, const float* __restrict__ ind /*[n][L][7]*/,
+                                                           const float* __restrict__ vis /*[M][n]*/, const float* __restrict__ normal,
+                                                           const float* __restrict__ view, const float* __restrict__ mat /*[n][7]*/, int n,
+                                                           int M, int L, float f0, float* __restrict__ out /*[n][4][3]*/) {
+    const int pt = blockIdx.x, lane = threadIdx.x;
+    const PointConst pc = point_consts(normal + pt * 3, view + pt * 3, f0);
+    Dual<0> m[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) m[i] = mk<0>(mat[pt * 7 + i]);
+    float acc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = 0.0f;
+    for (int j = lane; j < M + L; j += 64) {
+        const bool direct = j < M;
+        const float* src = direct ? lgt + j * 7 : ind + ((size_t)pt * L + (j - M)) * 7;
+        Dual<0> sg[7], spec[3], diff[3];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) sg[i] = mk<0>(src[i]);
+        lobe_terms<0>(pc, m, sg, direct ? vis[(size_t)j * n + pt] : 1.0f, spec, diff);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            acc[(direct ? 0 : 6) + c] += spec[c].v;
+            acc[(direct ? 3 : 9) + c] += diff[c].v;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        float v = acc[i];
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
+        if (lane == 0) out[pt * 12 + i] = v;
+    }
+}
+
+__global__ void __launch_bounds__(64) sg_render_bwd_kernel(const float* __restrict__ lgt, const float* __restrict__ ind,
+                                                           const float* __restrict__ vis, const float* __restrict__ normal,
+                                                           const float* __restrict__ view, const float* __restrict__ mat, int n, int M,
+                                                           int L, float f0, const float* __restrict__ d_out /*[n][4][3]*/,
+                                                           float* __restrict__ d_mat /*[n][7]*/, float* __restrict__ d_lgt /*[M][7], atomics*/) {
+    const int pt = blockIdx.x, lane = threadIdx.x;
+    const PointConst pc = point_consts(normal + pt * 3, view + pt * 3, f0);
+    float co[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) co[i] = d_out[pt * 12 + i];
+    float gm[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) gm[i] = 0.0f;
+    for (int j = lane; j < M + L; j += 64) {
+        const bool direct = j < M;
+        const float* src = direct ? lgt + j * 7 : ind + ((size_t)pt * L + (j - M)) * 7;
+        const float vj = direct ? vis[(size_t)j * n + pt] : 1.0f;
+        const float* cs = co + (direct ? 0 : 6);          // cotangents of this lobe set: spec[3], diff[3]
+        {   // tangents: the point's material parameters
+            Dual<7> m[7], sg[7], spec[3], diff[3];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                m[i] = var<7>(mat[pt * 7 + i], i);
+                sg[i] = mk<7>(src[i]);
+            }
+            lobe_terms<7>(pc, m, sg, vj, spec, diff);
+#pragma unroll
+            for (int i = 0; i < 7; ++i)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) gm[i] += cs[c] * spec[c].d[i] + cs[3 + c] * diff[c].d[i];
+        }
+        if (direct) {   // tangents: the lobe's own SG parameters (the indirect lobes are constants: IndirectLight is frozen)
+            Dual<7> m[7], sg[7], spec[3], diff[3];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                m[i] = mk<7>(mat[pt * 7 + i]);
+                sg[i] = var<7>(src[i], i);
+            }
+            lobe_terms<7>(pc, m, sg, vj, spec, diff);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                float g = 0.0f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) g += cs[c] * spec[c].d[i] + cs[3 + c] * diff[c].d[i];
+                atomicAdd(d_lgt + j * 7 + i, g);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        float v = gm[i];
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
+        if (lane == 0) d_mat[pt * 7 + i] = v;
+    }
+}
+
+}  // namespace fneus
+
+using namespace fneus;
+
+extern "C" int fneus_sg_render_fwd(const float* lgt_sgs, const float* indir_sgs, const float* vis, const float* normal,
+                                   const float* view, const float* material, int n_pts, int n_direct, int n_indirect,
+                                   float specular_reflectance, float* out, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (n_pts <= 0) return 0;
+    if (!lgt_sgs || !vis || !normal || !view || !material || !out || (n_indirect > 0 && !indir_sgs)) {
+        set_last_error("fneus_sg_render_fwd: null argument");
+        return -2;
+    }
+    hipLaunchKernelGGL(sg_render_fwd_kernel, dim3(n_pts), dim3(64), 0, stream, lgt_sgs, indir_sgs, vis, normal, view, material, n_pts,
+                       n_direct, n_indirect, specular_reflectance, out);
+    return fneus::launch_status();
+}
+
+extern "C" int fneus_sg_render_bwd(const float* lgt_sgs, const float* indir_sgs, const float* vis, const float* normal,
+                                   const float* view, const float* material, int n_pts, int n_direct, int n_indirect,
+                                   float specular_reflectance, const float* d_out, float* d_material, float* d_lgt_sgs,
+                                   fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (n_pts <= 0) return 0;
+    if (!lgt_sgs || !vis || !normal || !view || !material || !d_out || !d_material || !d_lgt_sgs || (n_indirect > 0 && !indir_sgs)) {
+        set_last_error("fneus_sg_render_bwd: null argument");
+        return -2;
+    }
+    hipLaunchKernelGGL(sg_render_bwd_kernel, dim3(n_pts), dim3(64), 0, stream, lgt_sgs, indir_sgs, vis, normal, view, material, n_pts,
+                       n_direct, n_indirect, specular_reflectance, d_out, d_material, d_lgt_sgs);
+    return fneus::launch_status();
+}

@@ -186,6 +186,30 @@ class OutsideAlphaFn(torch.autograd.Function):
         return d_density, d_raw, None
 
 
+class SgRenderFn(torch.autograd.Function):
+    """fneus_sg_render_fwd / _bwd: the spherical-Gaussian rendering of stage 3 (inverRender.py:314-449) for the direct and the
+    indirect lobes in one launch each way.  Differentiable inputs: the light SGs [M,7] and the material [n,7] (roughness,
+    diffuse albedo, specular albedo); normals, view directions, visibilities and the indirect SGs are constants."""
+
+    @staticmethod
+    def forward(ctx, lgt, mat, normal, view, vis, ind, f0: float):
+        t = lambda x: None if x is None else x.detach().float().contiguous()
+        lgt_c, mat_c, normal, view, vis, ind = t(lgt), t(mat), t(normal), t(view), t(vis), t(ind)
+        out = ops.sg_render_fwd(lgt_c, ind, vis, normal, view, mat_c, f0)
+        ctx.f0 = f0
+        ctx.has_ind = ind is not None
+        ctx.save_for_backward(*([lgt_c, mat_c, normal, view, vis] + ([ind] if ind is not None else [])))
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        sv = ctx.saved_tensors
+        lgt, mat, normal, view, vis = sv[:5]
+        ind = sv[5] if ctx.has_ind else None
+        d_mat, d_lgt = ops.sg_render_bwd(lgt, ind, vis, normal, view, mat, ctx.f0, d_out.contiguous())
+        return d_lgt, d_mat, None, None, None, None, None
+
+
 class RefHeadsFn(torch.autograd.Function):
     """Both MLPs of RefColor (fields.py:303-330) on the gathered surface samples: one forward launch, one backward
     launch, one weight-gradient GEMM launch for the two networks.  Differentiable inputs: normal, feature."""

@@ -684,6 +684,26 @@ def outside_alpha_bwd(density, rgb, dists, d_alpha, d_rgb):
     return d_density, d_raw
 
 
+def sg_render_fwd(lgt, ind, vis, normal, view, mat, f0: float):
+    """render_with_sg's lobe sums (inverRender.py:314-449) -> [n, 4, 3]: direct specular / diffuse, indirect specular / diffuse"""
+    n, M = mat.shape[0], lgt.shape[0]
+    L = 0 if ind is None else ind.shape[1]
+    out = torch.empty(n, 4, 3, dtype=torch.float32, device=mat.device)
+    _launch("fneus_sg_render_fwd", lib.fneus_sg_render_fwd, _ptr(lgt), _ptr(ind), _ptr(vis), _ptr(normal), _ptr(view), _ptr(mat), n, M, L,
+            float(f0), _ptr(out), _stream())
+    return out
+
+
+def sg_render_bwd(lgt, ind, vis, normal, view, mat, f0: float, d_out):
+    n, M = mat.shape[0], lgt.shape[0]
+    L = 0 if ind is None else ind.shape[1]
+    d_mat = torch.empty(n, 7, dtype=torch.float32, device=mat.device)
+    d_lgt = torch.zeros(M, 7, dtype=torch.float32, device=mat.device)
+    _launch("fneus_sg_render_bwd", lib.fneus_sg_render_bwd, _ptr(lgt), _ptr(ind), _ptr(vis), _ptr(normal), _ptr(view), _ptr(mat), n, M, L,
+            float(f0), _ptr(d_out), _ptr(d_mat), _ptr(d_lgt), _stream())
+    return d_mat, d_lgt
+
+
 def lvis_visibility(blob, points, normals, dirs, weights, prec: int):
     """get_diffuse_visibility's network part (inverRender.py:163-190) -> vis [M, n]; dirs [M, 32, 3], weights [M, 32]"""
     n, M, S = points.shape[0], dirs.shape[0], dirs.shape[1]

@@ -188,9 +188,38 @@ def render_with_sg(points, normal, viewdirs, lgtSGs, specular_reflectance, specu
             "specular_rgb": torch.clip(tonemap_img(specular_linear), 0.0, 1.0), "lvis_mean": vis_shadow}
 
 
+FUSED_SG = True      # stage 3 on fneus_sg_render_fwd / _bwd (one launch each way); False: the element-wise torch formulation below
+
+
+def _render_with_all_sg_fused(points, normal, viewdirs, lgtSGs, f0: float, specular_albedo, roughness, diffuse_albedo,
+                              lvis_network, indir_lgtSGs, u_theta, u_phi):
+    """render_with_all_sg on the fused kernels: visibility (fneus_lvis_visibility), then every (point, lobe) pair of the 128
+    direct and the 24 indirect SGs in one launch; the clamps of integrate_rgb (:277), of render_with_sg (:440) and the tone
+    mapping (:306-309) are element-wise ops on [n, 3] tensors"""
+    from fneus.autograd import SgRenderFn
+    lobes = lgtSGs[:, :3] / (torch.norm(lgtSGs[:, :3], dim=-1, keepdim=True) + TINY_NUMBER)
+    vis = get_diffuse_visibility(points, normal, lvis_network, lobes, torch.abs(lgtSGs[:, 3:4]), nsamp=32, u_theta=u_theta,
+                                 u_phi=u_phi)                                     # [M, n], detached
+    mat = torch.cat([roughness, diffuse_albedo, specular_albedo], dim=-1)         # [n, 7]
+    sums = SgRenderFn.apply(lgtSGs, mat, normal, viewdirs, vis, indir_lgtSGs, f0)
+    spec_d, diff_d, spec_i, diff_i = (torch.clamp(sums[:, k], 0.0, 1.0) for k in range(4))
+    env = torch.clamp(spec_d + diff_d, 0.0, 1.0)
+    indir = torch.clamp(spec_i + diff_i, 0.0, 1.0) if indir_lgtSGs is not None else torch.zeros_like(points)
+    return {"specular_loss": 0, "diffuse_loss": 0,
+            "diffuse_rgb": torch.clip(tonemap_img(diff_d), 0.0, 1.0), "specular_rgb": torch.clip(tonemap_img(spec_d), 0.0, 1.0),
+            "lvis_mean": vis.mean(dim=0)[:, None].expand(-1, 3),
+            "rgb": torch.clip(tonemap_img(env + indir), 0.0, 1.0), "indir_rgb": torch.clip(tonemap_img(indir), 0.0, 1.0),
+            "env_rgb": torch.clip(tonemap_img(env), 0.0, 1.0)}
+
+
 def render_with_all_sg(points, normal, viewdirs, lgtSGs, specular_reflectance, specular_albedo, roughness, diffuse_albedo,
-                       gt_specular_linear=None, lvis_network=None, indir_lgtSGs=None, u_theta=None, u_phi=None):
+                       gt_specular_linear=None, lvis_network=None, indir_lgtSGs=None, u_theta=None, u_phi=None,
+                       specular_reflectance_value=None):
     """inverRender.py:286-311: direct light (with visibility) + indirect light, tone mapped"""
+    if (FUSED_SG and points.is_cuda and lvis_network is not None and specular_reflectance_value is not None
+            and (indir_lgtSGs is None or not indir_lgtSGs.requires_grad)):
+        return _render_with_all_sg_fused(points, normal, viewdirs, lgtSGs, float(specular_reflectance_value), specular_albedo,
+                                         roughness, diffuse_albedo, lvis_network, indir_lgtSGs, u_theta, u_phi)
     n = normal.shape[0]
     ret = render_with_sg(points, normal, viewdirs, lgtSGs[None].expand(n, -1, -1), specular_reflectance, specular_albedo,
                          roughness, diffuse_albedo, gt_specular_linear, lvis_network=lvis_network, u_theta=u_theta, u_phi=u_phi)
@@ -230,6 +259,7 @@ class EnvmapMaterialNetwork(nn.Module):
         self.net_cs = nn.Sequential(*_mlp([ch_pts + ch_view, 256, 256, 256, 256, 1], nn.LeakyReLU(0.2)), nn.Sigmoid())
         # (a plain tensor attribute in the reference: not part of its state_dict -- a non-persistent buffer moves with .to())
         self.register_buffer("specular_reflectance", torch.full([1, 1], float(specular_albedo)), persistent=False)
+        self.specular_reflectance_value = float(specular_albedo)      # the same as a host float for the fused kernels
         # light SGs: grey amplitudes, sharpness 10 + 20 |N|, energy normalised, lobes on two Fibonacci spheres (:509-525)
         sg = torch.randn(num_lgt_sgs, 7)
         sg[:, -2:] = sg[:, -3:-2].expand(-1, 2)
@@ -276,7 +306,7 @@ class EnvmapMaterialNetwork(nn.Module):
         specular_albedo = self.net_cs(torch.cat([pts_enc, self.embed_view_fn(ref_dirs)], dim=-1)).repeat(1, 3)
         ret = render_with_all_sg(points, n, view_dirs, self.lgtSGs, self.specular_reflectance, specular_albedo, roughness,
                                  diffuse_albedo, gt_specular_linear, lvis_network=lvis_network, indir_lgtSGs=indiLgt,
-                                 u_theta=u_theta, u_phi=u_phi)
+                                 u_theta=u_theta, u_phi=u_phi, specular_reflectance_value=self.specular_reflectance_value)
         ret.update({"roughness": roughness, "diffuse_albedo": torch.clip(tonemap_img(diffuse_albedo), 0.0, 1.0),
                     "specular_albedo": torch.clip(tonemap_img(specular_albedo), 0.0, 1.0), "encoder_loss": loss,
                     "smooth_loss": 0.0})

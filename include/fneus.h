@@ -284,6 +284,20 @@ int fneus_sample_dirs(const float* surf /*[n_pts][3]*/, const float* normal /*[n
 int fneus_lvis_visibility(const void* lvis_blob, const float* points, const float* normals, const float* dirs,
                           const float* weights, int n_pts, int n_lobes, int n_dirs, float* vis, int prec, fneus_stream_t stream);
 
+/* Spherical-Gaussian rendering of stage 3: render_with_sg (inverRender.py:314-449) with lambda_trick (:83-103), hemisphere_int
+ * (:106-125) and integrate_rgb (:264-283) for the n_direct light SGs lgt_sgs [n_direct][7] (with per-lobe visibility vis
+ * [n_direct][n_pts]) and the n_indirect SGs indir_sgs [n_pts][n_indirect][7] of every point (no visibility).  normal, view
+ * [n_pts][3] unit vectors; material [n_pts][7] = roughness, diffuse albedo[3], specular albedo[3].
+ * out [n_pts][4][3] = the lobe sums BEFORE integrate_rgb's clamp: direct specular, direct diffuse, indirect specular, indirect
+ * diffuse.  The backward returns d_material [n_pts][7] and ACCUMULATES (atomics) into d_lgt_sgs [n_direct][7]; the indirect
+ * SGs, normals, view directions and visibilities are constants (frozen networks, mateIllu.py:83-95).                        */
+int fneus_sg_render_fwd(const float* lgt_sgs, const float* indir_sgs, const float* vis, const float* normal, const float* view,
+                        const float* material, int n_pts, int n_direct, int n_indirect, float specular_reflectance, float* out,
+                        fneus_stream_t stream);
+int fneus_sg_render_bwd(const float* lgt_sgs, const float* indir_sgs, const float* vis, const float* normal, const float* view,
+                        const float* material, int n_pts, int n_direct, int n_indirect, float specular_reflectance,
+                        const float* d_out, float* d_material, float* d_lgt_sgs, fneus_stream_t stream);
+
 /* ---- K7: background NeRF++ of the womask configurations  (fields.py:233-259 NeRF.forward via renderer.py:112-149) ---- */
 /* pts4 [n][4] = (p/|p|, 1/|p|) of the background samples, dirs [n][3]; outputs are RAW: density [n] (alpha_linear) and
  * rgb [n][3] (rgb_linear) -- softplus, sigmoid and the compositing of renderer.py:139-149 stay with the caller.

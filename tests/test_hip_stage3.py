@@ -209,3 +209,50 @@ def test_fixed_shape_render_matches_the_reference_and_the_graph_step_trains(gold
     o = trg.train_step(away)
     assert int(o["n_hit"]) == 0 and bool(torch.isfinite(o["loss"])) and float(o["rgb_loss"]) == 0.0
     assert all(bool(torch.isfinite(p).all()) for p in trg.mateIllu_network.parameters())
+
+
+def test_fused_sg_rendering_vs_the_element_wise_formulation():
+    """fneus_sg_render_fwd / _bwd (dual-number backward) against render_with_sg written as torch ops with autograd: values,
+    and the gradients with respect to the light SGs, roughness and both albedos"""
+    import models.inverRender as IR
+    from fneus import synth
+    from models.fields import Lvis, IndirectLight
+    dev = torch.device(DEV)
+    g = torch.Generator().manual_seed(11)
+    n = 150
+    pts = (torch.randn(n, 3, generator=g) * 0.3).to(dev)
+    nrm = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(dev)
+    view = torch.nn.functional.normalize(nrm.cpu() + 0.8 * torch.randn(n, 3, generator=g), dim=-1).to(dev)
+    view[:10] = -view[:10]                                   # some views from behind the surface (n . v < 0: clamped terms)
+    lv, il = Lvis().to(dev), IndirectLight().to(dev)
+    lv.load_state_dict({k: T(v) for k, v in synth.lvis_state_dict(31).items()})
+    il.load_state_dict({k: T(v) for k, v in synth.indilgt_state_dict(33).items()})
+    with torch.no_grad():
+        indi = il(pts)
+    ut, up = torch.rand(128, 32, generator=g).to(dev), torch.rand(128, 32, generator=g).to(dev)
+    cot = torch.randn(n, 3, generator=g).to(dev)
+
+    def run(fused):
+        IR.FUSED_SG = fused
+        sg = T(synth.mateillu_state_dict(32)["lgtSGs"]).to(dev).requires_grad_(True)
+        rough = (torch.rand(n, 1, generator=torch.Generator().manual_seed(5)) * 0.9 + 0.09).to(dev).requires_grad_(True)
+        dalb = torch.rand(n, 3, generator=torch.Generator().manual_seed(6)).to(dev).requires_grad_(True)
+        salb = torch.rand(n, 1, generator=torch.Generator().manual_seed(7)).to(dev).requires_grad_(True)
+        f0 = torch.full([1, 1], 0.02, device=dev)
+        ret = IR.render_with_all_sg(pts, nrm, view, sg, f0, salb.repeat(1, 3), rough, dalb, lvis_network=lv, indir_lgtSGs=indi,
+                                    u_theta=ut, u_phi=up, specular_reflectance_value=0.02)
+        ((ret["rgb"] + 0.5 * ret["env_rgb"] + 0.25 * ret["indir_rgb"] + 0.1 * ret["diffuse_rgb"] + 0.1 * ret["specular_rgb"]) * cot).sum().backward()
+        return ret, [sg.grad, rough.grad, dalb.grad, salb.grad]
+
+    try:
+        ref, gref = run(False)
+        got, ggot = run(True)
+    finally:
+        IR.FUSED_SG = True
+    for k in ("rgb", "env_rgb", "indir_rgb", "diffuse_rgb", "specular_rgb", "lvis_mean"):
+        d = (got[k] - ref[k]).abs().max().item()
+        assert d <= 2e-5, (k, d)
+    for name, a, b in zip(("lgtSGs", "roughness", "diffuse_albedo", "specular_albedo"), ggot, gref):
+        rel = ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+        print(f"  fused SG backward, d {name}: worst relative difference {rel:.2e}")
+        assert rel <= 2e-3, (name, rel)
