@@ -740,6 +740,25 @@ __global__ void __launch_bounds__(256) outside_alpha_bwd_kernel(const float* __r
     }
 }
 
+
+// Embedder.embed (embedder.py:23-36): [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)] per row, d <= 4 columns
+__global__ void __launch_bounds__(256) embed_kernel(const float* __restrict__ x, long n, int d, int n_freqs, float* __restrict__ out) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * d) return;
+    const long row = idx / d;
+    const int c = (int)(idx - row * d);
+    const int w = d * (1 + 2 * n_freqs);
+    const float v = x[idx];
+    float* o = out + row * w;
+    o[c] = v;
+    for (int k = 0; k < n_freqs; ++k) {
+        float s, co;
+        sincosf(__fmul_rn(v, (float)(1 << k)), &s, &co);
+        o[d * (1 + 2 * k) + c] = s;
+        o[d * (2 + 2 * k) + c] = co;
+    }
+}
+
 }  // namespace fneus
 
 using namespace fneus;
@@ -935,5 +954,18 @@ extern "C" int fneus_outside_alpha_bwd(const float* density, const float* rgb, c
     if (n <= 0) return 0;
     hipLaunchKernelGGL(outside_alpha_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, density, rgb, dists, d_alpha,
                        d_rgb, n, d_density, d_rgb_raw);
+    return fneus::launch_status();
+}
+
+extern "C" int fneus_embed(const float* x, long n_rows, int d, int n_freqs, float* out, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (n_rows <= 0) return 0;
+    if (!x || !out || d < 1 || n_freqs < 0 || n_freqs > 24) {
+        set_last_error("fneus_embed: bad argument");
+        return -2;
+    }
+    const long total = n_rows * d;
+    hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, n_rows, d, n_freqs, out);
     return fneus::launch_status();
 }

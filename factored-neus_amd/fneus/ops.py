@@ -704,6 +704,14 @@ def sg_render_bwd(lgt, ind, vis, normal, view, mat, f0: float, d_out):
     return d_mat, d_lgt
 
 
+def embed(x, n_freqs: int):
+    """Embedder.embed (embedder.py:23-36) of a constant [n, d] input in one launch"""
+    n, d = x.shape
+    out = torch.empty(n, d * (1 + 2 * n_freqs), dtype=torch.float32, device=x.device)
+    _launch("fneus_embed", lib.fneus_embed, _ptr(x), n, d, int(n_freqs), _ptr(out), _stream())
+    return out
+
+
 def lvis_visibility(blob, points, normals, dirs, weights, prec: int):
     """get_diffuse_visibility's network part (inverRender.py:163-190) -> vis [M, n]; dirs [M, 32, 3], weights [M, 32]"""
     n, M, S = points.shape[0], dirs.shape[0], dirs.shape[1]

@@ -17,10 +17,19 @@ class Embedder:
         else:
             self.freq_bands = torch.linspace(2.0 ** 0.0, 2.0 ** max_freq, n_freqs)
         self.include_input = kwargs.get("include_input", True)
+        # the kernel's frequencies are the octaves 2^0 .. 2^(L-1) (log sampling with max_freq_log2 = L - 1) and sin / cos
+        self._log_octaves = (kwargs.get("log_sampling", True) and max_freq == n_freqs - 1
+                             and list(kwargs.get("periodic_fns", [torch.sin, torch.cos])) == [torch.sin, torch.cos])
         self.periodic_fns = kwargs.get("periodic_fns", [torch.sin, torch.cos])
         self.out_dim = (d if self.include_input else 0) + d * n_freqs * len(self.periodic_fns)
 
     def embed(self, inputs):
+        # constant 2-D float32 inputs on the GPU (the points and directions the torch-side networks of stages 2 / 3 encode):
+        # one launch of fneus_embed instead of 2 L + 2 element-wise kernels
+        if (inputs.is_cuda and inputs.dim() == 2 and inputs.dtype == torch.float32 and not inputs.requires_grad
+                and self.include_input and self._log_octaves):
+            from fneus import ops
+            return ops.embed(inputs.contiguous(), len(self.freq_bands))
         outs = [inputs] if self.include_input else []
         for freq in self.freq_bands.tolist():
             for fn in self.periodic_fns:

@@ -246,6 +246,11 @@ int fneus_ray_setup(const float* rays_o, const float* rays_d, const float* near,
 /* section lengths and mid points of render_core (renderer.py:223-226) */
 int fneus_sections(const float* z, int n_rays, int n, float sample_dist, float* dists, float* mid_z, fneus_stream_t stream);
 
+/* Embedder.embed (embedder.py:23-36) of constant inputs (points, directions): x [n][d] -> out [n][d (1 + 2 n_freqs)] =
+ * [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)]; one launch instead of 2 L + 2 element-wise kernels.
+ * (The fused MLP kernels encode their inputs themselves; this serves the torch-side networks of stages 2 and 3.)           */
+int fneus_embed(const float* x, long n_rows, int d, int n_freqs, float* out, fneus_stream_t stream);
+
 /* ---- Ray generation (models/dataset.py:115-151): pixel -> K^-1 (x, y, 1) -> normalise -> R v; o = pose[:3, 3] ------------- */
 /* Dataset.gen_random_rays_at (dataset.py:133-151): the rays, colours and mask values of n integer pixels of ONE image.
  * intrinsics_inv, pose: that image's [4][4] matrices (row major); image, mask: its float [H][W][3] planes (BGR / 256 as the

@@ -271,3 +271,20 @@ def test_ray_generation_vs_reference(golden_dir):
     # drawing its own pixels: in range, unit directions
     data = ds.gen_random_rays_at(0, 512)
     assert data.shape == (512, 10) and torch.allclose(data[:, 3:6].norm(dim=-1), torch.ones(512, device=dev), atol=1e-5)
+
+
+def test_embed_kernel_vs_the_torch_embedder():
+    from models.embedder import Embedder, get_embedder
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    for d, L in ((3, 10), (3, 4), (4, 10), (1, 4)):
+        fn, width = get_embedder(L, input_dims=d)
+        x = (torch.randn(1001, d, generator=g) * 2.0).to(dev)
+        got = fn(x)                                  # fneus_embed
+        eo = Embedder(include_input=True, input_dims=d, max_freq_log2=L - 1, num_freqs=L, log_sampling=True,
+                      periodic_fns=[torch.sin, torch.cos])
+        ref = eo.embed(x.cpu().double()).float()     # the torch formulation (CPU, fp64)
+        assert got.shape == (1001, width) == ref.shape
+        assert (got.cpu() - ref).abs().max().item() <= 2e-6 * max(1.0, 2.0 ** (L - 1) * 1e-3 + 1.0)
+        xg = x.clone().requires_grad_(True)          # inputs that need a gradient stay on the torch formulation
+        assert fn(xg).requires_grad
