@@ -33,7 +33,8 @@ template <int PREC>
 __global__ void __launch_bounds__(256, 2) lvis_visibility_tp_kernel(const unsigned char* blob, const float* __restrict__ points,
                                                                     const float* __restrict__ normals,
                                                                     const float* __restrict__ dirs /*[M][32][3]*/,
-                                                                    const float* __restrict__ weights /*[M][32]*/, int n_pts,
+                                                                    const float* __restrict__ weights /*[M][32]*/,
+                                                                    const unsigned char* __restrict__ point_mask, int n_pts,
                                                                     int n_lobes, float* __restrict__ vis /*[M][n_pts]*/) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
     unsigned char* frag = lds_;
@@ -44,6 +45,10 @@ __global__ void __launch_bounds__(256, 2) lvis_visibility_tp_kernel(const unsign
     const PPLane pl = pp_lane(lane);
     constexpr auto& LY = kLvisLayout;
     for (int pt = blockIdx.x; pt < n_pts; pt += gridDim.x) {
+        if (point_mask && point_mask[pt] == 0) {          // a ray without a surface hit (fixed-shape step): nothing to evaluate
+            for (int lobe = threadIdx.x; lobe < n_lobes; lobe += blockDim.x) vis[(size_t)lobe * n_pts + pt] = 0.0f;
+            continue;
+        }
         float x[3], nrm[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -123,8 +128,8 @@ __global__ void __launch_bounds__(256, 2) lvis_visibility_tp_kernel(const unsign
 using namespace fneus;
 
 extern "C" int fneus_lvis_visibility(const void* lvis_blob, const float* points, const float* normals, const float* dirs,
-                                     const float* weights, int n_pts, int n_lobes, int n_dirs, float* vis, int prec,
-                                     fneus_stream_t stream_) {
+                                     const float* weights, const unsigned char* point_mask, int n_pts, int n_lobes, int n_dirs,
+                                     float* vis, int prec, fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     fneus::clear_status();
     if (n_pts <= 0 || n_lobes <= 0) return 0;
@@ -142,12 +147,12 @@ extern "C" int fneus_lvis_visibility(const void* lvis_blob, const float* points,
         static bool done = false;
         if (!done) { fneus::allow_big_lds(lvis_visibility_tp_kernel<3>); done = true; }
         hipLaunchKernelGGL(lvis_visibility_tp_kernel<3>, dim3(grid), dim3(256), fneus::kLvisLds, stream, b, points, normals, dirs,
-                           weights, n_pts, n_lobes, vis);
+                           weights, point_mask, n_pts, n_lobes, vis);
     } else if (prec == 1) {
         static bool done = false;
         if (!done) { fneus::allow_big_lds(lvis_visibility_tp_kernel<1>); done = true; }
         hipLaunchKernelGGL(lvis_visibility_tp_kernel<1>, dim3(grid), dim3(256), fneus::kLvisLds, stream, b, points, normals, dirs,
-                           weights, n_pts, n_lobes, vis);
+                           weights, point_mask, n_pts, n_lobes, vis);
     } else {
         return -2;
     }

@@ -712,14 +712,17 @@ def embed(x, n_freqs: int):
     return out
 
 
-def lvis_visibility(blob, points, normals, dirs, weights, prec: int):
-    """get_diffuse_visibility's network part (inverRender.py:163-190) -> vis [M, n]; dirs [M, 32, 3], weights [M, 32]"""
+def lvis_visibility(blob, points, normals, dirs, weights, prec: int, point_mask=None):
+    """get_diffuse_visibility's network part (inverRender.py:163-190) -> vis [M, n]; dirs [M, 32, 3], weights [M, 32];
+    point_mask [n] bool / uint8: points marked 0 are skipped (their visibility is 0)"""
     n, M, S = points.shape[0], dirs.shape[0], dirs.shape[1]
     for t, name in ((points, "points"), (normals, "normals"), (dirs, "dirs"), (weights, "weights")):
         _chk_f32(t, name)
     vis = torch.empty(M, n, dtype=torch.float32, device=points.device)
+    if point_mask is not None:
+        point_mask = (point_mask.view(torch.uint8) if point_mask.dtype == torch.bool else point_mask.to(torch.uint8)).contiguous()
     _launch("fneus_lvis_visibility", lib.fneus_lvis_visibility, _ptr(blob), _ptr(points), _ptr(normals), _ptr(dirs), _ptr(weights),
-            n, M, S, _ptr(vis), prec, _stream())
+            _ptr(point_mask), n, M, S, _ptr(vis), prec, _stream())
     return vis
 
 

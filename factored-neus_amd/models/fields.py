@@ -464,14 +464,16 @@ class Lvis(nn.Module):
     def forward(self, pts, view):
         return self.lvis(torch.cat([self.embedview_fn_pts(pts), self.embedview_fn_view(view)], dim=-1))
 
-    def visibility(self, points, normals, dirs, weights):
+    def visibility(self, points, normals, dirs, weights, point_mask=None):
         """get_diffuse_visibility's network part (inverRender.py:163-190), no gradient: for every surface point the network
         at the S directions of each of the M light lobes, zero where the direction faces away from the normal, averaged per
-        lobe with the given weights.  points, normals [n,3]; dirs [M,S,3]; weights [M,S] -> [M,n]"""
+        lobe with the given weights.  points, normals [n,3]; dirs [M,S,3]; weights [M,S] -> [M,n].  point_mask [n] bool: the
+        points marked False are not evaluated (visibility 0): the fixed-shape stage-3 step marks the rays that hit"""
         if dirs.shape[1] != 32:          # the fused kernel maps one (point, lobe) pair onto one 32-sample MFMA tile
-            return self._visibility_library(points, normals, dirs, weights)
+            vis = self._visibility_library(points, normals, dirs, weights)
+            return vis if point_mask is None else vis * point_mask[None, :].to(vis.dtype)
         net = self._packed()
-        return ops.lvis_visibility(net.blob, points, normals, dirs.contiguous(), weights.contiguous(), self.prec)
+        return ops.lvis_visibility(net.blob, points, normals, dirs.contiguous(), weights.contiguous(), self.prec, point_mask)
 
     prec = ops.PREC_PARITY
 

@@ -134,13 +134,14 @@ def visibility_sample_dirs(lgtSGLobes, lgtSGLambdas, nsamp, u_theta=None, u_phi=
     return dirs, w
 
 
-def get_diffuse_visibility(points, normals, VisModel, lgtSGLobes, lgtSGLambdas, nsamp=8, u_theta=None, u_phi=None):
+def get_diffuse_visibility(points, normals, VisModel, lgtSGLobes, lgtSGLambdas, nsamp=8, u_theta=None, u_phi=None,
+                           point_mask=None):
     """inverRender.py:128-192 -> [n_lobe, n_points], detached.  VisModel: models.fields.Lvis"""
     from fneus import ops
     with torch.no_grad():
         dirs, w = visibility_sample_dirs(lgtSGLobes, lgtSGLambdas, nsamp, u_theta, u_phi)
         return VisModel.visibility(points.detach().float().contiguous(), normals.detach().float().contiguous(),
-                                   dirs.contiguous(), w.contiguous())
+                                   dirs.contiguous(), w.contiguous(), point_mask)
 
 
 def render_with_sg(points, normal, viewdirs, lgtSGs, specular_reflectance, specular_albedo, roughness, diffuse_albedo,
@@ -192,14 +193,14 @@ FUSED_SG = True      # stage 3 on fneus_sg_render_fwd / _bwd (one launch each wa
 
 
 def _render_with_all_sg_fused(points, normal, viewdirs, lgtSGs, f0: float, specular_albedo, roughness, diffuse_albedo,
-                              lvis_network, indir_lgtSGs, u_theta, u_phi):
+                              lvis_network, indir_lgtSGs, u_theta, u_phi, point_mask=None):
     """render_with_all_sg on the fused kernels: visibility (fneus_lvis_visibility), then every (point, lobe) pair of the 128
     direct and the 24 indirect SGs in one launch; the clamps of integrate_rgb (:277), of render_with_sg (:440) and the tone
     mapping (:306-309) are element-wise ops on [n, 3] tensors"""
     from fneus.autograd import SgRenderFn
     lobes = lgtSGs[:, :3] / (torch.norm(lgtSGs[:, :3], dim=-1, keepdim=True) + TINY_NUMBER)
     vis = get_diffuse_visibility(points, normal, lvis_network, lobes, torch.abs(lgtSGs[:, 3:4]), nsamp=32, u_theta=u_theta,
-                                 u_phi=u_phi)                                     # [M, n], detached
+                                 u_phi=u_phi, point_mask=point_mask)              # [M, n], detached
     mat = torch.cat([roughness, diffuse_albedo, specular_albedo], dim=-1)         # [n, 7]
     sums = SgRenderFn.apply(lgtSGs, mat, normal, viewdirs, vis, indir_lgtSGs, f0)
     spec_d, diff_d, spec_i, diff_i = (torch.clamp(sums[:, k], 0.0, 1.0) for k in range(4))
@@ -214,12 +215,13 @@ def _render_with_all_sg_fused(points, normal, viewdirs, lgtSGs, f0: float, specu
 
 def render_with_all_sg(points, normal, viewdirs, lgtSGs, specular_reflectance, specular_albedo, roughness, diffuse_albedo,
                        gt_specular_linear=None, lvis_network=None, indir_lgtSGs=None, u_theta=None, u_phi=None,
-                       specular_reflectance_value=None):
-    """inverRender.py:286-311: direct light (with visibility) + indirect light, tone mapped"""
+                       specular_reflectance_value=None, point_mask=None):
+    """inverRender.py:286-311: direct light (with visibility) + indirect light, tone mapped.  point_mask [n] bool (fixed-shape
+    step): rows marked False are placeholders whose results the caller discards -- their visibility is not evaluated"""
     if (FUSED_SG and points.is_cuda and lvis_network is not None and specular_reflectance_value is not None
             and (indir_lgtSGs is None or not indir_lgtSGs.requires_grad)):
         return _render_with_all_sg_fused(points, normal, viewdirs, lgtSGs, float(specular_reflectance_value), specular_albedo,
-                                         roughness, diffuse_albedo, lvis_network, indir_lgtSGs, u_theta, u_phi)
+                                         roughness, diffuse_albedo, lvis_network, indir_lgtSGs, u_theta, u_phi, point_mask)
     n = normal.shape[0]
     ret = render_with_sg(points, normal, viewdirs, lgtSGs[None].expand(n, -1, -1), specular_reflectance, specular_albedo,
                          roughness, diffuse_albedo, gt_specular_linear, lvis_network=lvis_network, u_theta=u_theta, u_phi=u_phi)
@@ -306,7 +308,8 @@ class EnvmapMaterialNetwork(nn.Module):
         specular_albedo = self.net_cs(torch.cat([pts_enc, self.embed_view_fn(ref_dirs)], dim=-1)).repeat(1, 3)
         ret = render_with_all_sg(points, n, view_dirs, self.lgtSGs, self.specular_reflectance, specular_albedo, roughness,
                                  diffuse_albedo, gt_specular_linear, lvis_network=lvis_network, indir_lgtSGs=indiLgt,
-                                 u_theta=u_theta, u_phi=u_phi, specular_reflectance_value=self.specular_reflectance_value)
+                                 u_theta=u_theta, u_phi=u_phi, specular_reflectance_value=self.specular_reflectance_value,
+                                 point_mask=point_mask)
         ret.update({"roughness": roughness, "diffuse_albedo": torch.clip(tonemap_img(diffuse_albedo), 0.0, 1.0),
                     "specular_albedo": torch.clip(tonemap_img(specular_albedo), 0.0, 1.0), "encoder_loss": loss,
                     "smooth_loss": 0.0})

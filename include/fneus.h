@@ -287,7 +287,8 @@ int fneus_sample_dirs(const float* surf /*[n_pts][3]*/, const float* normal /*[n
  * weights [n_lobes][32] = exp(lambda (d . axis - 1)) (:186).  vis [n_lobes][n_pts] = sum_s [n . d_s > 1e-6] Lvis(p, d_s) w_s /
  * (sum_s w_s + 1e-6)  (:169-188).  One 32-sample MFMA tile per (point, lobe) pair: n_dirs must be 32.                      */
 int fneus_lvis_visibility(const void* lvis_blob, const float* points, const float* normals, const float* dirs,
-                          const float* weights, int n_pts, int n_lobes, int n_dirs, float* vis, int prec, fneus_stream_t stream);
+                          const float* weights, const unsigned char* point_mask /*[n_pts] or NULL: 0 = skip the point (vis = 0)*/,
+                          int n_pts, int n_lobes, int n_dirs, float* vis, int prec, fneus_stream_t stream);
 
 /* Spherical-Gaussian rendering of stage 3: render_with_sg (inverRender.py:314-449) with lambda_trick (:83-103), hemisphere_int
  * (:106-125) and integrate_rgb (:264-283) for the n_direct light SGs lgt_sgs [n_direct][7] (with per-lobe visibility vis
