@@ -5,7 +5,8 @@
 // 4096 evaluations per point, up to 2.1 M per training step, the hot op of stage 3 -- zeroes the directions that face away
 // from the normal and averages each lobe's samples with the weights exp(lambda (d . axis - 1)).  Here one 32-sample tile
 // IS one (point, lobe) pair: sample r of the tile is direction r of the lobe.  That makes
-//   * the encoding of the point (60 sincos) a per-workgroup constant: computed once per point, kept in registers by wave 0;
+//   * the encoding of the point (60 sincos) a per-workgroup constant: computed once per (point, chunk of 32 lobes), its four
+//     k-steps by the four waves, and parked in LDS;
 //   * the back-face test a per-tile decision: a lobe whose 32 directions all face away costs nothing (about half of them);
 //   * the weighted average a reduction over the 32 lanes of the output tile: the kernel writes vis[lobe][point] directly --
 //     the 4096 network outputs per point never reach memory.
@@ -17,15 +18,50 @@
 
 namespace fneus {
 
-constexpr int kLvisLds = 16 * 2 * kFragBytes;      // B fragments of a 256-wide layer (hi, lo)
+constexpr int kLvisLds = 22 * 2 * kFragBytes;      // 16 k-steps of a 256-wide layer (hi, lo) + the 6 input k-steps, parked
+constexpr int kLvisPark = 16;                      // k-steps 16..19: PE10 of the point (once per workgroup), 20, 21: PE4(direction)
+constexpr int kLvisChunk = 32;                     // lobes per workgroup: the launch is (points x lobe chunks) workgroups, so that
+                                                   // skipped lobes / points shorten the launch instead of idling a resident slot
 
 template <int PREC, int KS>
-FN_DEV void lvis_write_frags(unsigned char* frag, int lane, int ks0, const BFrag<PREC> (&b)[kMaxKS], int src0) {
+FN_DEV void lvis_write_frags(unsigned char* frag, int lane, int ks0, const BFrag<PREC>* b) {
     constexpr int NPL = PREC == 3 ? 2 : 1;
 #pragma unroll
     for (int i = 0; i < KS; ++i) {
-        *reinterpret_cast<bf16x8*>(frag + ((ks0 + i) * NPL) * kFragBytes + lane * 16) = b[src0 + i].hi;
-        if constexpr (PREC == 3) *reinterpret_cast<bf16x8*>(frag + ((ks0 + i) * NPL + 1) * kFragBytes + lane * 16) = b[src0 + i].lo;
+        *reinterpret_cast<bf16x8*>(frag + ((ks0 + i) * NPL) * kFragBytes + lane * 16) = b[i].hi;
+        if constexpr (PREC == 3) *reinterpret_cast<bf16x8*>(frag + ((ks0 + i) * NPL + 1) * kFragBytes + lane * 16) = b[i].lo;
+    }
+}
+
+// the 16 features of k-step ks of PE10(point) (63 features, embedder.py:23-36 with input_dims = 3) as one B fragment; each
+// lane computes only the 8 features of its own slots (feature phi(ks, h, j)), so the 60 sincos of a point are spread over
+// the four waves of the workgroup
+template <int PREC>
+FN_DEV void posenc3_frag(const float (&x)[3], int ks, int h, BFrag<PREC>& out) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int f = 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3);
+        float val = 0.0f;
+        if (f < 63) {
+            const int g = f - 3;
+            const int c = f < 3 ? f : (g % 3);
+            const float xc = c == 0 ? x[0] : (c == 1 ? x[1] : x[2]);
+            if (f < 3) {
+                val = xc;
+            } else {
+                float sn, cs;
+                sincosf(xc * (float)(1 << (g / 6)), &sn, &cs);
+                val = ((g % 6) >= 3) ? cs : sn;
+            }
+        }
+        if constexpr (PREC == 3) {
+            __bf16 a, b;
+            split_bf16(val, a, b);
+            out.hi[j] = a;
+            out.lo[j] = b;
+        } else {
+            out.hi[j] = (__bf16)val;
+        }
     }
 }
 
@@ -38,15 +74,19 @@ __global__ void __launch_bounds__(256, 2) lvis_visibility_tp_kernel(const unsign
                                                                     int n_lobes, float* __restrict__ vis /*[M][n_pts]*/) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
     unsigned char* frag = lds_;
+    unsigned char* park = frag + (size_t)kLvisPark * (PREC == 3 ? 2 : 1) * kFragBytes;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // wave-uniform for the compiler too
     const int r = lane & 31, h = lane >> 5;
     const int t0 = 2 * wave;
     const PPLane pl = pp_lane(lane);
     constexpr auto& LY = kLvisLayout;
-    for (int pt = blockIdx.x; pt < n_pts; pt += gridDim.x) {
+    const int n_chunks = (n_lobes + kLvisChunk - 1) / kLvisChunk;
+    for (long item = blockIdx.x; item < (long)n_pts * n_chunks; item += gridDim.x) {
+        const int pt = (int)(item / n_chunks), lobe0 = (int)(item - (long)pt * n_chunks) * kLvisChunk;
+        const int lobe1 = lobe0 + kLvisChunk < n_lobes ? lobe0 + kLvisChunk : n_lobes;
         if (point_mask && point_mask[pt] == 0) {          // a ray without a surface hit (fixed-shape step): nothing to evaluate
-            for (int lobe = threadIdx.x; lobe < n_lobes; lobe += blockDim.x) vis[(size_t)lobe * n_pts + pt] = 0.0f;
+            for (int lobe = lobe0 + (int)threadIdx.x; lobe < lobe1; lobe += blockDim.x) vis[(size_t)lobe * n_pts + pt] = 0.0f;
             continue;
         }
         float x[3], nrm[3];
@@ -55,13 +95,13 @@ __global__ void __launch_bounds__(256, 2) lvis_visibility_tp_kernel(const unsign
             x[c] = points[pt * 3 + c];
             nrm[c] = normals[pt * 3 + c];
         }
-        BFrag<PREC> bpe[kMaxKS];          // k-steps 0..3: PE10 of the point (wave 0), 4..5: PE4 of the direction (wave 1)
-        if (wave == 0) {
-            float pe[63], jc[63];
-            posenc<10, false>(x, pe, jc);
-            vec_to_bfrag<PREC, 63, 4, 0>(pe, bpe, h);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");         // the previous item's parked fragments are consumed
+        {
+            BFrag<PREC> one[1];
+            posenc3_frag<PREC>(x, wave, h, one[0]);       // k-step `wave` of the point's encoding
+            lvis_write_frags<PREC, 1>(frag, lane, kLvisPark + wave, one);
         }
-        for (int lobe = 0; lobe < n_lobes; ++lobe) {
+        for (int lobe = lobe0; lobe < lobe1; ++lobe) {
             asm volatile("" : "+s"(blob));
             float d[3];
 #pragma unroll
@@ -74,19 +114,19 @@ __global__ void __launch_bounds__(256, 2) lvis_visibility_tp_kernel(const unsign
                 continue;
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the previous tile's fragments are consumed
-            if (wave == 0) lvis_write_frags<PREC, 4>(frag, lane, 0, bpe, 0);
             if (wave == 1) {
                 float pe[27], jc[27];
                 posenc<4, false>(d, pe, jc);
-                vec_to_bfrag<PREC, 27, 2, 4>(pe, bpe, h);
-                lvis_write_frags<PREC, 2>(frag, lane, 4, bpe, 4);
+                BFrag<PREC> tmp[kMaxKS];
+                vec_to_bfrag<PREC, 27, 2, 0>(pe, tmp, h);
+                lvis_write_frags<PREC, 2>(frag, lane, kLvisPark + 4, tmp);
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the 6 input k-steps are in LDS
             BFrag<PREC> bf[kMaxKS];
-            tp_operands<PREC, 6>(frag, lane, bf);
+            tp_operands<PREC, 6>(park, lane, bf);
             f32x16 acc[2];
             load_accvec<8, 0, 2>(blob, LY.L[0].bias, acc, lane, t0);
-            tp_dense<PREC, 6, 8, 0, 2>(blob, LY.L[0].fwd_hi, LY.L[0].fwd_lo, frag, bf, acc, lane, t0);
+            tp_dense<PREC, 6, 8, 0, 2>(blob, LY.L[0].fwd_hi, LY.L[0].fwd_lo, park, bf, acc, lane, t0);
 #pragma unroll 1
             for (int l = 1; l <= 3; ++l) {      // (no per-layer laundering of `blob` here: together with the skip path above it
                                                 // makes the backend place the pointer in a VGPR and fail)
@@ -142,7 +182,8 @@ extern "C" int fneus_lvis_visibility(const void* lvis_blob, const float* points,
         return -2;
     }
     const unsigned char* b = reinterpret_cast<const unsigned char*>(lvis_blob);
-    const unsigned grid = (unsigned)(n_pts < 2048 ? n_pts : 2048);
+    const long items = (long)n_pts * ((n_lobes + fneus::kLvisChunk - 1) / fneus::kLvisChunk);
+    const unsigned grid = (unsigned)(items < 8192 ? items : 8192);
     if (prec == 3) {
         static bool done = false;
         if (!done) { fneus::allow_big_lds(lvis_visibility_tp_kernel<3>); done = true; }
