@@ -17,6 +17,10 @@
 #include "pp_engine.h"
 #include "fneus_kernels.h"
 
+#ifndef FNEUS_COL_OCC
+#define FNEUS_COL_OCC 2      // workgroups per CU the tensor-parallel kernels of this file are compiled for (experiments: 3)
+#endif
+
 namespace fneus {
 
 template <int TN>
@@ -352,7 +356,7 @@ FN_DEV void color_bwd_tp_body(unsigned char* lds, const unsigned char* blob, lon
 }
 
 template <int PREC, bool TRAIN, int VAR>
-__global__ void __launch_bounds__(256, 2) color_fwd_tp_kernel(const unsigned char* blob, PointSrc src, long N,
+__global__ void __launch_bounds__(256, FNEUS_COL_OCC) color_fwd_tp_kernel(const unsigned char* blob, PointSrc src, long N,
                                                               const float* __restrict__ dirs, const float* __restrict__ normal,
                                                               const float* __restrict__ feat, ColStash st,
                                                               float* __restrict__ rgb_out) {
@@ -361,7 +365,7 @@ __global__ void __launch_bounds__(256, 2) color_fwd_tp_kernel(const unsigned cha
 }
 
 template <int PREC, bool TRAIN>
-__global__ void __launch_bounds__(256, 2) refcolor_fwd_both_tp_kernel(HeadArgs cd, HeadArgs vd, PointSrc src, long N,
+__global__ void __launch_bounds__(256, FNEUS_COL_OCC) refcolor_fwd_both_tp_kernel(HeadArgs cd, HeadArgs vd, PointSrc src, long N,
                                                                       const float* __restrict__ dirs,
                                                                       const float* __restrict__ normal,
                                                                       const float* __restrict__ feat) {
@@ -373,7 +377,7 @@ __global__ void __launch_bounds__(256, 2) refcolor_fwd_both_tp_kernel(HeadArgs c
 }
 
 template <int PREC, int VAR>
-__global__ void __launch_bounds__(256, 2) color_bwd_tp_kernel(const unsigned char* blob, long N, const float* __restrict__ d_rgb,
+__global__ void __launch_bounds__(256, FNEUS_COL_OCC) color_bwd_tp_kernel(const unsigned char* blob, long N, const float* __restrict__ d_rgb,
                                                               const float* __restrict__ rgb, ColStash st,
                                                               float* __restrict__ d_feat, float* __restrict__ d_normal,
                                                               const float* __restrict__ normal, const float* __restrict__ dirs,
@@ -383,7 +387,7 @@ __global__ void __launch_bounds__(256, 2) color_bwd_tp_kernel(const unsigned cha
 }
 
 template <int PREC>
-__global__ void __launch_bounds__(256, 2) refcolor_bwd_both_tp_kernel(HeadArgs cd, HeadArgs vd, long N,
+__global__ void __launch_bounds__(256, FNEUS_COL_OCC) refcolor_bwd_both_tp_kernel(HeadArgs cd, HeadArgs vd, long N,
                                                                       const float* __restrict__ normal,
                                                                       const float* __restrict__ dirs,
                                                                       const float* __restrict__ rays_d, int m) {

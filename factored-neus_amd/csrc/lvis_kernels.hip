@@ -13,8 +13,13 @@
 // Tensor-parallel workgroup of 4 waves per tile (tp_engine.h), two workgroups per CU, weights streamed from L2 (0.6 MB).
 #define FNEUS_PREFETCH_X3 4
 #define FNEUS_PREFETCH_X1 8
+#include <stdlib.h>
 #include "pp_engine.h"
 #include "fneus_kernels.h"
+
+#ifndef FNEUS_LVIS_OCC
+#define FNEUS_LVIS_OCC 2      // workgroups per CU the tensor-parallel kernels of this file are compiled for (experiments: 3)
+#endif
 
 namespace fneus {
 
@@ -66,7 +71,7 @@ FN_DEV void posenc3_frag(const float (&x)[3], int ks, int h, BFrag<PREC>& out) {
 }
 
 template <int PREC>
-__global__ void __launch_bounds__(256, 2) lvis_visibility_tp_kernel(const unsigned char* blob, const float* __restrict__ points,
+__global__ void __launch_bounds__(256, FNEUS_LVIS_OCC) lvis_visibility_tp_kernel(const unsigned char* blob, const float* __restrict__ points,
                                                                     const float* __restrict__ normals,
                                                                     const float* __restrict__ dirs /*[M][32][3]*/,
                                                                     const float* __restrict__ weights /*[M][32]*/,
@@ -163,6 +168,133 @@ __global__ void __launch_bounds__(256, 2) lvis_visibility_tp_kernel(const unsign
     }
 }
 
+
+// ---- two lobes per pass (HB = 2) -------------------------------------------------------------------------------------------
+// The tensor-parallel kernels stream every weight fragment from L2 once per 32-sample tile: at the full MFMA rate that is
+// ~85 B / clk / CU, 52 TB/s chip-wide against the ~18 TB/s the L2s deliver -- which is where the 34-37 % MFMA-busy plateau of
+// all of them comes from.  Here a workgroup carries TWO (point, lobe) tiles through the network at once (dense_ldsb_h: one
+// pass over the weight fragments feeds both halves), halving the weight stream per evaluation.  No stash, so the register
+// budget allows it: accumulators [2 tiles][2 halves].
+constexpr int kLvisHalf = 16 * 2 * kFragBytes;     // B fragments of one half (the 6 input k-steps use the first 6)
+constexpr int kLvisLds2 = 2 * kLvisHalf;
+
+template <int PREC>
+__global__ void __launch_bounds__(256, 2) lvis_visibility_tph_kernel(const unsigned char* blob, const float* __restrict__ points,
+                                                                     const float* __restrict__ normals,
+                                                                     const float* __restrict__ dirs /*[M][32][3]*/,
+                                                                     const float* __restrict__ weights /*[M][32]*/,
+                                                                     const unsigned char* __restrict__ point_mask, int n_pts,
+                                                                     int n_lobes, float* __restrict__ vis /*[M][n_pts]*/) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
+    unsigned char* frag = lds_;
+    constexpr int HB = 2, HALF = kLvisHalf;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = lane & 31, h = lane >> 5;
+    const int t0 = 2 * wave;
+    const PPLane pl = pp_lane(lane);
+    constexpr auto& LY = kLvisLayout;
+    const int n_chunks = (n_lobes + kLvisChunk - 1) / kLvisChunk;
+    unsigned char* const none[HB] = {nullptr, nullptr};
+    const bool both[HB] = {true, true};
+    for (long item = blockIdx.x; item < (long)n_pts * n_chunks; item += gridDim.x) {
+        const int pt = (int)(item / n_chunks), lobe0 = (int)(item - (long)pt * n_chunks) * kLvisChunk;
+        const int lobe1 = lobe0 + kLvisChunk < n_lobes ? lobe0 + kLvisChunk : n_lobes;
+        if (point_mask && point_mask[pt] == 0) {
+            for (int lobe = lobe0 + (int)threadIdx.x; lobe < lobe1; lobe += blockDim.x) vis[(size_t)lobe * n_pts + pt] = 0.0f;
+            continue;
+        }
+        float x[3], nrm[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            x[c] = points[pt * 3 + c];
+            nrm[c] = normals[pt * 3 + c];
+        }
+        BFrag<PREC> pe_one[1];                            // k-step `wave` of the point's encoding, kept in registers
+        posenc3_frag<PREC>(x, wave, h, pe_one[0]);
+        for (int la = lobe0; la < lobe1; la += HB) {
+            asm volatile("" : "+s"(blob));
+            float d[HB][3];
+            bool front[HB];
+            int any_front[HB];
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+                const int lobe = la + hb < lobe1 ? la + hb : la;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) d[hb][c] = dirs[((size_t)lobe * 32 + r) * 3 + c];
+                front[hb] = (la + hb < lobe1) && (nrm[0] * d[hb][0] + nrm[1] * d[hb][1] + nrm[2] * d[hb][2]) > 1e-6f;
+                any_front[hb] = __builtin_amdgcn_readfirstlane((int)(__ballot(front[hb]) != 0ull));
+            }
+            if (!any_front[0] && !any_front[1]) {
+                if (threadIdx.x < HB && la + (int)threadIdx.x < lobe1) vis[(size_t)(la + threadIdx.x) * n_pts + pt] = 0.0f;
+                continue;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the previous pair's fragments are consumed
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) lvis_write_frags<PREC, 1>(frag + hb * HALF, lane, wave, pe_one);
+            if (wave >= 2) {                              // waves 2, 3: PE4 of the directions of half 0, 1 (k-steps 4, 5)
+                const int hb = wave - 2;
+                float pe[27], jc[27], dd[3] = {hb ? d[1][0] : d[0][0], hb ? d[1][1] : d[0][1], hb ? d[1][2] : d[0][2]};
+                posenc<4, false>(dd, pe, jc);
+                BFrag<PREC> tmp[kMaxKS];
+                vec_to_bfrag<PREC, 27, 2, 0>(pe, tmp, h);
+                lvis_write_frags<PREC, 2>(frag + hb * HALF, lane, 4, tmp);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            f32x16 acc[2][HB];
+            {
+                f32x16 b2[2];
+                load_accvec<8, 0, 2>(blob, LY.L[0].bias, b2, lane, t0);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int hb = 0; hb < HB; ++hb) acc[t][hb] = b2[t];
+            }
+            tph_dense<PREC, 6, 8, 0, 2, true, HB, HALF>(blob, LY.L[0].fwd_hi, LY.L[0].fwd_lo, frag, acc, lane, t0);
+#pragma unroll 1
+            for (int l = 1; l <= 4; ++l) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[t][hb][e] = fmaxf(acc[t][hb][e], 0.0f);
+                tph_exchange<PREC, 2, true, HB, HALF>(frag, lane, t0, acc, none, none, pl, both);
+                if (l <= 3) {
+                    f32x16 b2[2];
+                    load_accvec<8, 0, 2>(blob, LY.L[l].bias, b2, lane, t0);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int hb = 0; hb < HB; ++hb) acc[t][hb] = b2[t];
+                    tph_dense<PREC, 16, 8, 0, 2, true, HB, HALF>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, frag, acc, lane, t0);
+                }
+            }
+            if (wave == 0) {              // output layer: one tile per half, row 0 = register 0 of lane half 0
+                f32x16 o[1][HB], b1[1];
+                load_accvec<1, 0, 1>(blob, LY.L[4].bias, b1, lane);
+#pragma unroll
+                for (int hb = 0; hb < HB; ++hb) o[0][hb] = b1[0];
+                tph_dense<PREC, 16, 1, 0, 1, true, HB, HALF>(blob, LY.L[4].fwd_hi, LY.L[4].fwd_lo, frag, o, lane);
+#pragma unroll
+                for (int hb = 0; hb < HB; ++hb) {
+                    if (la + hb < lobe1) {
+                        const float w = weights[(size_t)(la + hb) * 32 + r];
+                        float num = (h == 0 && front[hb]) ? w / (1.0f + expf(-o[0][hb][0])) : 0.0f;
+                        float den = h == 0 ? w : 0.0f;
+#pragma unroll
+                        for (int s = 16; s >= 1; s >>= 1) {
+                            num += __shfl_xor(num, s, 64);
+                            den += __shfl_xor(den, s, 64);
+                        }
+                        if (lane == 0) vis[(size_t)(la + hb) * n_pts + pt] = num / (den + 1e-6f);
+                    }
+                }
+            }
+        }
+    }
+}
+
 }  // namespace fneus
 
 using namespace fneus;
@@ -184,6 +316,23 @@ extern "C" int fneus_lvis_visibility(const void* lvis_blob, const float* points,
     const unsigned char* b = reinterpret_cast<const unsigned char*>(lvis_blob);
     const long items = (long)n_pts * ((n_lobes + fneus::kLvisChunk - 1) / fneus::kLvisChunk);
     const unsigned grid = (unsigned)(items < 8192 ? items : 8192);
+    const char* env = getenv("FNEUS_LVIS_HB");            // 2 (default): two lobes share a pass over the weights; 1: one lobe per pass
+    if (!(env && env[0] == '1')) {
+        if (prec == 3) {
+            static bool done = false;
+            if (!done) { fneus::allow_big_lds(lvis_visibility_tph_kernel<3>); done = true; }
+            hipLaunchKernelGGL(lvis_visibility_tph_kernel<3>, dim3(grid), dim3(256), fneus::kLvisLds2, stream, b, points, normals, dirs,
+                               weights, point_mask, n_pts, n_lobes, vis);
+        } else if (prec == 1) {
+            static bool done = false;
+            if (!done) { fneus::allow_big_lds(lvis_visibility_tph_kernel<1>); done = true; }
+            hipLaunchKernelGGL(lvis_visibility_tph_kernel<1>, dim3(grid), dim3(256), fneus::kLvisLds2, stream, b, points, normals, dirs,
+                               weights, point_mask, n_pts, n_lobes, vis);
+        } else {
+            return -2;
+        }
+        return fneus::launch_status();
+    }
     if (prec == 3) {
         static bool done = false;
         if (!done) { fneus::allow_big_lds(lvis_visibility_tp_kernel<3>); done = true; }

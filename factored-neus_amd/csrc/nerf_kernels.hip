@@ -16,6 +16,10 @@
 #include "pp_engine.h"
 #include "fneus_kernels.h"
 
+#ifndef FNEUS_NERF_OCC
+#define FNEUS_NERF_OCC 2      // workgroups per CU the tensor-parallel kernels of this file are compiled for (experiments: 3)
+#endif
+
 namespace fneus {
 
 constexpr int kNerfPE = 84;     // 4 + 2 * 10 * 4
@@ -311,7 +315,7 @@ FN_DEV void apply_bits(f32x16 (&acc)[TN], uint32_t m, bool valid) {
 }
 
 template <int PREC, bool TRAIN>
-__global__ void __launch_bounds__(256, 2) nerf_fwd_tp_kernel(const unsigned char* blob, const float* __restrict__ pts4,
+__global__ void __launch_bounds__(256, FNEUS_NERF_OCC) nerf_fwd_tp_kernel(const unsigned char* blob, const float* __restrict__ pts4,
                                                              const float* __restrict__ dirs, long N, NerfStash st,
                                                              float* __restrict__ density, float* __restrict__ rgb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
@@ -422,7 +426,7 @@ __global__ void __launch_bounds__(256, 2) nerf_fwd_tp_kernel(const unsigned char
 }
 
 template <int PREC>
-__global__ void __launch_bounds__(256, 2) nerf_bwd_tp_kernel(const unsigned char* blob, long N, const float* __restrict__ d_density,
+__global__ void __launch_bounds__(256, FNEUS_NERF_OCC) nerf_bwd_tp_kernel(const unsigned char* blob, long N, const float* __restrict__ d_density,
                                                              const float* __restrict__ d_rgb, NerfStash st) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
     unsigned char* frag = lds_;

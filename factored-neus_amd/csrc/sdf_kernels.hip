@@ -8,6 +8,10 @@
 #include "pp_engine.h"
 #include "fneus_kernels.h"
 
+#ifndef FNEUS_K2_OCC
+#define FNEUS_K2_OCC 2      // workgroups per CU the tensor-parallel kernels of this file are compiled for (experiments: 3)
+#endif
+
 namespace fneus {
 
 // prefetch depth of the kernels that carry stash traffic (K3)
@@ -207,7 +211,7 @@ FN_DEV void pe_frags_tp(const float (&x)[3], BFrag<PREC> (&bf)[kMaxKS], int h) {
 constexpr int kTp2LdsTotal = kTp2Lds + 2 * 64 * 64;     // + q_skip of wave 0 (2 tiles x 64 lanes x 16 floats)
 
 template <int PREC, bool TRAIN>
-__global__ void __launch_bounds__(256, 2) sdf_fwd_grad_tp_kernel(const unsigned char* blob, PointSrc src, long N,
+__global__ void __launch_bounds__(256, FNEUS_K2_OCC) sdf_fwd_grad_tp_kernel(const unsigned char* blob, PointSrc src, long N,
                                                                  SdfStash st, float* __restrict__ sdf_out,
                                                                  float* __restrict__ feat_out,
                                                                  float* __restrict__ normal_out) {
