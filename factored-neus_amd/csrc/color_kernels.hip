@@ -355,6 +355,241 @@ FN_DEV void color_bwd_tp_body(unsigned char* lds, const unsigned char* blob, lon
     }
 }
 
+// ---- the colour network on workgroups of HB sample halves (HB = 2: 64 samples share one pass over the weight fragments) ------
+// The tensor-parallel kernels are bound by the L2 weight stream (every 32-sample tile streams the layer's fragments: ~52 TB/s
+// wanted chip-wide at the full MFMA rate, ~18 delivered); dense_ldsb_h feeds two tiles from one pass.  Same maths, planes and
+// masks as color_fwd_tp_body / color_bwd_tp_body<VAR_COLOR>; used for launches of >= 1024 tiles.
+constexpr int kColHalf = kColTpFrag;
+
+template <int PREC, bool TRAIN, int HB>
+__global__ void __launch_bounds__(256, 2) color_fwd_tph_kernel(const unsigned char* blob, PointSrc src, long N,
+                                                               const float* __restrict__ dirs, const float* __restrict__ normal,
+                                                               const float* __restrict__ feat, ColStash st,
+                                                               float* __restrict__ rgb_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
+    unsigned char* frag = lds_;
+    constexpr int HALF = kColHalf;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = lane & 31, h = lane >> 5;
+    const int t0 = 2 * wave;
+    const PPLane pl = pp_lane(lane);
+    constexpr auto& LY = kColLayout;
+    const long tiles = pp_tiles(N);
+    const long groups = (N + 32 * HB - 1) / (32 * HB);
+    const bool lo_planes = TRAIN && PREC == 3 && st.u_lo != nullptr;
+    for (long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        asm volatile("" : "+s"(blob));
+        long tile[HB], n[HB], nc[HB];
+        bool valid[HB];
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb) {
+            tile[hb] = grp * HB + hb;
+            n[hb] = tile[hb] * 32 + r;
+            valid[hb] = n[hb] < N;
+            nc[hb] = valid[hb] ? n[hb] : N - 1;
+        }
+        if (wave < HB) {        // the 33 side inputs of half `wave`: k-steps 16..18 of layer 0 (not read since the previous group's layer 0)
+            const int hb = wave;
+            float side[33], x[3], d[3], nrm[3];
+            load_point(src, nc[hb], x);
+            if (dirs) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) d[c] = dirs[nc[hb] * 3 + c];
+            } else {
+                const long ray = nc[hb] / src.m;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) d[c] = src.rays_d[ray * 3 + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) nrm[c] = normal[nc[hb] * 3 + c];
+            make_side<VAR_COLOR>(x, d, nrm, side);
+            BFrag<PREC> bs[kMaxKS];
+            vec_to_bfrag<PREC, 33, 3, 16>(side, bs, h);
+            tp_write_frags<PREC, 3>(frag + hb * HALF, lane, 16, bs, 16);
+            if constexpr (TRAIN)
+                frags_to_plane<PREC, 3>(&bs[16], 0, st.side_hi + (size_t)tile[hb] * 4 * kFragBytes,
+                                        lo_planes ? st.side_lo + (size_t)tile[hb] * 4 * kFragBytes : nullptr, pl, valid[hb]);
+        }
+        f32x16 acc[2][HB];
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb) {
+            f32x16 a2[2];
+            load_f32<2>(a2, feat + 32 * t0, 256, nc[hb], h);
+            acc[0][hb] = a2[0];
+            acc[1][hb] = a2[1];
+        }
+        unsigned char* none[HB];
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb) none[hb] = nullptr;
+        tph_exchange<PREC, 2, true, HB, HALF>(frag, lane, t0, acc, none, none, pl, valid);
+#pragma unroll 1
+        for (int l = 0; l <= 3; ++l) {
+            asm volatile("" : "+s"(blob));
+            {
+                f32x16 b2[2];
+                load_accvec<8, 0, 2>(blob, LY.L[l].bias, b2, lane, t0);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int hb = 0; hb < HB; ++hb) acc[t][hb] = b2[t];
+            }
+            if (l == 0)
+                tph_dense<PREC, 19, 8, 0, 2, true, HB, HALF>(blob, LY.L[0].fwd_hi, LY.L[0].fwd_lo, frag, acc, lane, t0);
+            else
+                tph_dense<PREC, 16, 8, 0, 2, true, HB, HALF>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, frag, acc, lane, t0);
+            unsigned char *uh[HB], *ul[HB];
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+                uint32_t m = 0u;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const bool pos = acc[t][hb][e] > 0.0f;
+                        acc[t][hb][e] = pos ? acc[t][hb][e] : 0.0f;
+                        m |= (pos ? 1u : 0u) << (t * 16 + e);
+                    }
+                if constexpr (TRAIN) reinterpret_cast<uint32_t*>(st.mask + ((size_t)tile[hb] * 4 + l) * 64 + lane)[wave] = m;
+                const size_t off = ((size_t)l * tiles + tile[hb]) * kPPBlock;
+                uh[hb] = TRAIN ? st.u_hi + off : nullptr;
+                ul[hb] = lo_planes ? st.u_lo + off : nullptr;
+            }
+            tph_exchange<PREC, 2, true, HB, HALF>(frag, lane, t0, acc, uh, ul, pl, valid);
+        }
+        if (wave == 0) {        // output layer: one tile per half, rows 0..2
+            f32x16 o[1][HB], b1[1];
+            load_accvec<1, 0, 1>(blob, LY.L[4].bias, b1, lane);
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) o[0][hb] = b1[0];
+            tph_dense<PREC, 16, 1, 0, 1, true, HB, HALF>(blob, LY.L[4].fwd_hi, LY.L[4].fwd_lo, frag, o, lane);
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb)
+                if (valid[hb] && lane < 32) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) rgb_out[n[hb] * 3 + c] = 1.0f / (1.0f + expf(-o[0][hb][c]));   // fields.py:173-174
+                }
+        }
+    }
+}
+
+template <int PREC, int HB>
+__global__ void __launch_bounds__(256, 2) color_bwd_tph_kernel(const unsigned char* blob, long N, const float* __restrict__ d_rgb,
+                                                               const float* __restrict__ rgb, ColStash st,
+                                                               float* __restrict__ d_feat, float* __restrict__ d_normal) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
+    unsigned char* frag = lds_;
+    constexpr int HALF = kColHalf;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = lane & 31, h = lane >> 5;
+    const int t0 = 2 * wave;
+    const PPLane pl = pp_lane(lane);
+    constexpr auto& LY = kColLayout;
+    const long tiles = pp_tiles(N);
+    const long groups = (N + 32 * HB - 1) / (32 * HB);
+    const bool lo_planes = PREC == 3 && st.zbar_lo != nullptr;
+    for (long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        asm volatile("" : "+s"(blob));
+        long tile[HB], n[HB], nc[HB];
+        bool valid[HB];
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb) {
+            tile[hb] = grp * HB + hb;
+            n[hb] = tile[hb] * 32 + r;
+            valid[hb] = n[hb] < N;
+            nc[hb] = valid[hb] ? n[hb] : N - 1;
+        }
+        // zbar_4 = d rgb * sigmoid' (3 rows of one tile per half): wave 0 publishes k-steps 0, 1 and stores the zout planes
+        {
+            f32x16 z[1][HB];
+            unsigned char *zh[HB], *zl[HB];
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) z[0][hb][e] = 0.0f;
+                if (wave == 0 && h == 0) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float y = rgb[nc[hb] * 3 + c];
+                        z[0][hb][c] = valid[hb] ? d_rgb[nc[hb] * 3 + c] * y * (1.0f - y) : 0.0f;
+                    }
+                }
+                zh[hb] = wave == 0 ? st.zout_hi + (size_t)tile[hb] * 2 * kFragBytes : nullptr;
+                zl[hb] = (wave == 0 && lo_planes) ? st.zout_lo + (size_t)tile[hb] * 2 * kFragBytes : nullptr;
+            }
+            if (wave == 0) {
+                tph_exchange<PREC, 1, true, HB, HALF>(frag, lane, 0, z, zh, zl, pl, valid);
+            } else {
+                tp_barrier_pair();
+            }
+        }
+        f32x16 acc[2][HB];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[t][hb][e] = 0.0f;
+        tph_dense<PREC, 2, 8, 0, 2, true, HB, HALF>(blob, LY.L[4].rev_hi, LY.L[4].rev_lo, frag, acc, lane, t0);
+#pragma unroll 1
+        for (int l = 3; l >= 0; --l) {
+            asm volatile("" : "+s"(blob));
+            unsigned char *zh[HB], *zl[HB];
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+                const uint32_t msk = reinterpret_cast<const uint32_t*>(st.mask + ((size_t)tile[hb] * 4 + l) * 64 + lane)[wave];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        acc[t][hb][e] = (((msk >> (t * 16 + e)) & 1u) && valid[hb]) ? acc[t][hb][e] : 0.0f;
+                const size_t off = ((size_t)l * tiles + tile[hb]) * kPPBlock;
+                zh[hb] = st.zbar_hi + off;
+                zl[hb] = lo_planes ? st.zbar_lo + off : nullptr;
+            }
+            tph_exchange<PREC, 2, true, HB, HALF>(frag, lane, t0, acc, zh, zl, pl, valid);
+            if (l > 0) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[t][hb][e] = 0.0f;
+                tph_dense<PREC, 16, 8, 0, 2, true, HB, HALF>(blob, LY.L[l].rev_hi, LY.L[l].rev_lo, frag, acc, lane, t0);
+            }
+        }
+        // layer 0 reverse: 10 row tiles -- the 8 feature tiles (two per wave) and the 2 side tiles (wave 0)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[t][hb][e] = 0.0f;
+        tph_dense<PREC, 16, 10, 0, 2, true, HB, HALF>(blob, LY.L[0].rev_hi, LY.L[0].rev_lo, frag, acc, lane, t0);
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb) {
+            f32x16 a2[2] = {acc[0][hb], acc[1][hb]};
+            store_f32<2>(a2, d_feat + 32 * t0, 256, nc[hb], h, valid[hb]);
+        }
+        if (wave == 0) {
+            f32x16 s2[2][HB];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) s2[t][hb][e] = 0.0f;
+            tph_dense<PREC, 16, 10, 8, 2, true, HB, HALF>(blob, LY.L[0].rev_hi, LY.L[0].rev_lo, frag, s2, lane);
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+                const f32x16 one[2] = {s2[0][hb], s2[1][hb]};
+                side_grad_to_dnormal<VAR_COLOR>(one, n[hb], nc[hb], valid[hb], lane, h, d_normal, nullptr, nullptr, nullptr, 1);
+            }
+        }
+    }
+}
+
 template <int PREC, bool TRAIN, int VAR>
 __global__ void __launch_bounds__(256, FNEUS_COL_OCC) color_fwd_tp_kernel(const unsigned char* blob, PointSrc src, long N,
                                                               const float* __restrict__ dirs, const float* __restrict__ normal,
@@ -416,6 +651,23 @@ static inline unsigned tp_grid(long n_tiles) {
         hipLaunchKernelGGL((KERNEL), GRID, dim3(256), fneus::kColTpLds, stream, __VA_ARGS__);                         \
     } while (0)
 
+#define FNEUS_TPH_LAUNCH(KERNEL, GRID, ...)                                                                           \
+    do {                                                                                                              \
+        static bool attr_done = false;                                                                                \
+        if (!attr_done) {                                                                                             \
+            fneus::allow_big_lds(KERNEL);                                                                             \
+            attr_done = true;                                                                                         \
+        }                                                                                                             \
+        hipLaunchKernelGGL((KERNEL), GRID, dim3(256), 2 * fneus::kColHalf, stream, __VA_ARGS__);                      \
+    } while (0)
+
+// 64-sample workgroups for launches that fill the chip (>= 1024 tiles); FNEUS_COL_HB=1 keeps the 32-sample kernels
+static inline bool col_use_hb2(long n_tiles) {
+    const char* e = getenv("FNEUS_COL_HB");
+    if (e && e[0] == '1') return false;
+    return n_tiles >= 1024;
+}
+
 template <int VAR>
 static int launch_fwd(const void* blob, const float* pts, const float* rays_o, const float* rays_d, const float* t, int m,
                       long n_pts, const float* dirs, const float* normal, const float* feat, const FneusColStash* stash,
@@ -430,6 +682,15 @@ static int launch_fwd(const void* blob, const float* pts, const float* rays_o, c
     const unsigned char* b = reinterpret_cast<const unsigned char*>(blob);
     ColStash st = stash ? ColStash(*stash) : ColStash();
     if (train && VAR != VAR_COLOR && !st.feat_hi) return -2;
+    if (VAR == VAR_COLOR && col_use_hb2((n_pts + 31) / 32)) {
+        dim3 g2(tp_grid((n_pts + 63) / 64));
+        if (prec == 3 && train) FNEUS_TPH_LAUNCH((color_fwd_tph_kernel<3, true, 2>), g2, b, src, n_pts, dirs, normal, feat, st, out);
+        else if (prec == 3) FNEUS_TPH_LAUNCH((color_fwd_tph_kernel<3, false, 2>), g2, b, src, n_pts, dirs, normal, feat, st, out);
+        else if (prec == 1 && train) FNEUS_TPH_LAUNCH((color_fwd_tph_kernel<1, true, 2>), g2, b, src, n_pts, dirs, normal, feat, st, out);
+        else if (prec == 1) FNEUS_TPH_LAUNCH((color_fwd_tph_kernel<1, false, 2>), g2, b, src, n_pts, dirs, normal, feat, st, out);
+        else return -2;
+        return fneus::launch_status();
+    }
     {
         dim3 g2(tp_grid((n_pts + 31) / 32));
         if (prec == 3 && train) FNEUS_TP_LAUNCH((color_fwd_tp_kernel<3, true, VAR>), g2, b, src, n_pts, dirs, normal, feat, st, out);
@@ -452,6 +713,13 @@ static int launch_bwd(const void* blob, long n_pts, const float* d_out, const fl
     if (VAR != VAR_COLOR && (!normal || (!dirs && !rays_d))) return -2;
     const unsigned char* b = reinterpret_cast<const unsigned char*>(blob);
     ColStash st(*stash);
+    if (VAR == VAR_COLOR && col_use_hb2((n_pts + 31) / 32)) {
+        dim3 g2(tp_grid((n_pts + 63) / 64));
+        if (prec == 3) FNEUS_TPH_LAUNCH((color_bwd_tph_kernel<3, 2>), g2, b, n_pts, d_out, out, st, d_feat, d_normal);
+        else if (prec == 1) FNEUS_TPH_LAUNCH((color_bwd_tph_kernel<1, 2>), g2, b, n_pts, d_out, out, st, d_feat, d_normal);
+        else return -2;
+        return fneus::launch_status();
+    }
     {
         dim3 g2(tp_grid((n_pts + 31) / 32));
         const int mm = m > 0 ? m : 1;
