@@ -395,6 +395,99 @@ FN_DEV void bias_h(const unsigned char* __restrict__ blob, uint32_t off, f32x16 
     }
 }
 
+// ---- K1 on 64-sample workgroups (chip-filling launches: the 32 768 coarse depths of a step, the 1 M-point march of stage 2) ----
+// The chain kernels stream every weight fragment from L2 once per 32-sample tile -- at the full MFMA rate ~52 TB/s chip-wide
+// against the ~18 TB/s the L2s deliver, which is what holds them at 35-40 % MFMA busy.  Two tiles per workgroup share one pass
+// over the fragments (dense_ldsb_h): half the stream per sample.  Tensor-parallel form (wave w owns tiles 2w, 2w+1), B fragments
+// in LDS, two workgroups per CU; the encoding's fragments are built by waves 0, 1 (one half each), used by layer 0 and parked
+// in k-steps 16..18 for the skip input of layer 4.
+template <int PREC>
+__global__ void __launch_bounds__(256, 2) sdf_fwd_tph_kernel(const unsigned char* blob, PointSrc src, long N,
+                                                             float* __restrict__ sdf_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
+    unsigned char* frag = lds_;
+    constexpr int HB = 2, HALF = kK2Half;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = lane & 31, h = lane >> 5;
+    const int t0 = 2 * wave;
+    const PPLane pl = pp_lane(lane);
+    constexpr auto& LY = kSdfLayout;
+    const long groups = (N + 32 * HB - 1) / (32 * HB);
+    unsigned char* none[HB] = {nullptr, nullptr};
+    for (long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        asm volatile("" : "+s"(blob));
+        long n[HB], nc[HB];
+        bool valid[HB];
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb) {
+            n[hb] = (grp * HB + hb) * 32 + r;
+            valid[hb] = n[hb] < N;
+            nc[hb] = valid[hb] ? n[hb] : N - 1;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the previous group's fragments are consumed
+        if (wave < HB) {
+            const int hb = wave;
+            float x[3], pe[39], jc[39];
+            load_point(src, nc[hb], x);
+            posenc<6, false>(x, pe, jc);
+            BFrag<PREC> pf[kMaxKS];
+            vec_to_bfrag<PREC, 39, 3, 0>(pe, pf, h);
+            frags_to_lds<PREC, 3>(frag + hb * HALF, lane, 0, pf);
+            frags_to_lds<PREC, 3>(frag + hb * HALF, lane, 16, pf);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        f32x16 acc[2][HB];
+#pragma unroll 1
+        for (int l = 0; l <= 7; ++l) {
+            asm volatile("" : "+s"(blob));
+            if (l == 3) {               // 7 output tiles (217 features): wave 3 owns tile 6 only
+                if (wave < 3) {
+                    bias_h<2, HB>(blob, LY.L[3].bias, acc, lane, t0);
+                    tph_dense<PREC, 16, 7, 0, 2, true, HB, HALF>(blob, LY.L[3].fwd_hi, LY.L[3].fwd_lo, frag, acc, lane, t0);
+                } else {
+                    f32x16(&a1)[1][HB] = reinterpret_cast<f32x16(&)[1][HB]>(acc);
+                    bias_h<1, HB>(blob, LY.L[3].bias, a1, lane, t0);
+                    tph_dense<PREC, 16, 7, 0, 1, true, HB, HALF>(blob, LY.L[3].fwd_hi, LY.L[3].fwd_lo, frag, a1, lane, t0);
+                }
+            } else {
+                bias_h<2, HB>(blob, LY.L[l].bias, acc, lane, t0);
+                if (l == 0)
+                    tph_dense<PREC, 3, 8, 0, 2, true, HB, HALF>(blob, LY.L[0].fwd_hi, LY.L[0].fwd_lo, frag, acc, lane, t0);
+                else if (l == 4)
+                    tph_dense<PREC, 17, 8, 0, 2, true, HB, HALF>(blob, LY.L[4].fwd_hi, LY.L[4].fwd_lo, frag, acc, lane, t0);
+                else
+                    tph_dense<PREC, 16, 8, 0, 2, true, HB, HALF>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, frag, acc, lane, t0);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int hb = 0; hb < HB; ++hb) {
+                    f32x16(&one)[1] = reinterpret_cast<f32x16(&)[1]>(acc[i][hb]);
+                    softplus_inplace(one);
+                }
+            if (l == 3 && wave == 3) {
+                f32x16(&a1)[1][HB] = reinterpret_cast<f32x16(&)[1][HB]>(acc);
+                BFrag<PREC> ex[HB * 3];        // skip connection (fields.py:83-84): k-steps 14..16 of layer 4 = the parked encoding
+#pragma unroll
+                for (int hb = 0; hb < HB; ++hb) lds_to_frags<PREC, 3>(frag + hb * HALF, lane, 16, &ex[hb * 3]);
+                tph_exchange<PREC, 1, true, HB, HALF>(frag, lane, t0, a1, none, none, pl, valid, ex, 14, 3);
+            } else {
+                tph_exchange<PREC, 2, true, HB, HALF>(frag, lane, t0, acc, none, none, pl, valid);
+            }
+        }
+        // layer 8: only the sdf row (tile 8 of 9) is needed; wave 0 computes it for both halves
+        if (wave == 0) {
+            f32x16 a1[1][HB];
+            bias_h<1, HB>(blob, LY.L[8].bias, a1, lane, 8);
+            tph_dense<PREC, 16, 9, 8, 1, true, HB, HALF>(blob, LY.L[8].fwd_hi, LY.L[8].fwd_lo, frag, a1, lane);
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb)
+                if (valid[hb] && lane < 32) sdf_out[n[hb]] = a1[0][hb][0];
+        }
+    }
+}
+
 template <int PREC, bool TRAIN, int HB, int GP>
 __global__ void __launch_bounds__(256, 2) sdf_fwd_grad_tph_kernel(const unsigned char* blob, PointSrc src, long N, SdfStash st,
                                                                   float* __restrict__ sdf_out, float* __restrict__ feat_out,
@@ -964,6 +1057,22 @@ extern "C" int fneus_sdf_fwd(const void* blob, const float* pts, const float* ra
     static const bool no_tp = getenv("FNEUS_K1_NO_TP") != nullptr;
     const bool tp = tiles <= FNEUS_TP_MAX_TILES && !no_tp;
     static const bool tp8 = getenv("FNEUS_K1_TP_WAVES") ? atoi(getenv("FNEUS_K1_TP_WAVES")) == 8 : false;
+    // chip-filling launches: 64-sample workgroups (FNEUS_K1_HB=1 keeps one wave per tile)
+    static const bool no_hb = getenv("FNEUS_K1_HB") && getenv("FNEUS_K1_HB")[0] == '1';
+    if (tiles >= 1024 && !no_hb && (prec == 3 || prec == 1)) {
+        const long groups = (n_pts + 63) / 64;
+        const dim3 g2((unsigned)(groups < 2048 ? groups : 2048));
+        if (prec == 3) {
+            static bool done = false;
+            if (!done) { fneus::allow_big_lds(sdf_fwd_tph_kernel<3>); done = true; }
+            hipLaunchKernelGGL(sdf_fwd_tph_kernel<3>, g2, dim3(256), 2 * fneus::kK2Half, stream, b, src, n_pts, sdf_out);
+        } else {
+            static bool done = false;
+            if (!done) { fneus::allow_big_lds(sdf_fwd_tph_kernel<1>); done = true; }
+            hipLaunchKernelGGL(sdf_fwd_tph_kernel<1>, g2, dim3(256), 2 * fneus::kK2Half, stream, b, src, n_pts, sdf_out);
+        }
+        return fneus::launch_status();
+    }
     if (prec == 3 && tp)
         if (tp8) hipLaunchKernelGGL((sdf_fwd_tp_kernel<3, 8>), dim3((unsigned)(tiles < 512 ? tiles : 512)), dim3(512), 0, stream, b, src, n_pts, sdf_out);
         else hipLaunchKernelGGL((sdf_fwd_tp_kernel<3, 4>), dim3((unsigned)(tiles < 512 ? tiles : 512)), dim3(256), 0, stream, b, src, n_pts, sdf_out);

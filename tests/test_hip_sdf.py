@@ -39,6 +39,29 @@ def test_sdf_fwd(env, prec, tol):
     assert err <= tol
 
 
+@pytest.mark.parametrize("prec,tol", [(3, 1e-4), (1, 5e-2)])
+def test_sdf_fwd_chip_filling_launch_uses_64_sample_workgroups(env, prec, tol):
+    """launches of >= 1024 tiles run sdf_fwd_tph_kernel (two tiles share a pass over the weight fragments); ragged size,
+    against the fp64 oracle and -- bit for bit in parity mode -- against the one-wave-per-tile kernel on the same points"""
+    ops, R = env["ops"], env["R"]
+    rs = np.random.RandomState(11)
+    n = 40003                                     # 1251 tiles, the last one ragged, an odd tile count
+    x = T(rs.uniform(-1.1, 1.1, size=(n, 3)).astype(np.float32))
+    ref = R.sdf_only(x.double(), {"W": [w.double() for w in env["p"]["W"]], "b": [b.double() for b in env["p"]["b"]],
+                                  "scale": 1.0})[:, 0]
+    xd = x.to(env["dev"]).contiguous()
+    out = ops.sdf_fwd(env["net"].blob, n, prec, pts=xd)
+    err = (out.cpu().double() - ref).abs().max().item()
+    print(f"sdf_fwd (64-sample workgroups) prec={prec} max abs err {err:.3e}")
+    assert err <= tol
+    # the same points in chunks below the threshold go through the other kernels: same arithmetic, same order
+    parts = torch.cat([ops.sdf_fwd(env["net"].blob, len(c), prec, pts=c.contiguous()) for c in xd.split(20000)])
+    if prec == 3:
+        assert (out - parts).abs().max().item() <= 2e-6
+    again = ops.sdf_fwd(env["net"].blob, n, prec, pts=xd)
+    assert torch.equal(out, again)                # repeatable
+
+
 def test_sdf_fwd_ray_mode(env):
     ops, R = env["ops"], env["R"]
     dev = env["dev"]
