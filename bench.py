@@ -140,7 +140,7 @@ def cpu_baseline(device=None):
 
 
 # newest first: the PMC passes are re-collected whenever a kernel's memory behaviour changes (tools/collect_profiles.sh)
-TRAFFIC_FILES = ("r02_c_traffic.json", "r02_b_traffic.json", "r02_a_traffic.json")
+TRAFFIC_FILES = ("r02_d_traffic.json", "r02_c_traffic.json", "r02_b_traffic.json", "r02_a_traffic.json")
 
 
 def main():
@@ -235,7 +235,7 @@ def main():
         "data": "synthetic DTU-shaped rays (one camera per step), random-init weights of the reference distributions",
         "config": {"workload": "dtu_scan97-shaped wmask.conf stage-1 SDF+radiance train step, 512 rays x (64+64) samples, "
                                "1xMI355X per rank", "rays_per_gpu": RAYS, "samples_per_ray": N_SAMPLES + N_IMPORTANCE,
-                   "parallelism": f"dp{world} (ray-sharded replicas, one in-place all-reduce of the gradient arena)",
+                   "parallelism": f"dp{world} (ray-sharded replicas, the gradient arena all-reduced in place in two parts)",
                    "launch": ("eager kernel launches" if not (tr.use_graph and tr._graphs) else
                               "four hipGraph replays per step around the three collectives (loss normalisers; early part of the gradient "
                               "arena beside the SDF backward; late part)" if world > 1 else
