@@ -290,6 +290,18 @@ FN_DEV void posenc4_frag(const float (&x)[4], int ks, int h, BFrag<PREC>& out) {
     }
 }
 
+template <int TN, int HB>
+FN_DEV void bias_nh(const unsigned char* __restrict__ blob, uint32_t off, f32x16 (&acc)[TN][HB], int lane, int t0_rt) {
+    const f32x16 FN_GLOBAL* __restrict__ p = reinterpret_cast<const f32x16 FN_GLOBAL*>((gblob_t)blob + off);
+    const int hh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        const f32x16 v = p[(t0_rt + i) * 2 + hh];
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb) acc[i][hb] = v;
+    }
+}
+
 FN_DEV void nerf_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int TN>
@@ -501,6 +513,289 @@ __global__ void __launch_bounds__(256, FNEUS_NERF_OCC) nerf_bwd_tp_kernel(const 
     }
 }
 
+
+// ---- 64-sample workgroups (HB = 2: two tiles share one pass over the weight fragments, dense_ldsb_h) --------------------------
+// The tensor-parallel kernels are bound by the L2 weight stream; as for K3, K1 and the colour network
+// two tiles per workgroup halve it.  LDS: 18 k-steps per half (the view layer's 16 + 2), two workgroups per CU; the point's
+// encoding lives in REGISTERS of the wave that built it (k-steps w and w + 4 of both halves) and is written into k-steps 0..5
+// for layer 0 and again, behind layer 5's first product, for its second one.
+constexpr int kNerfHalf = 18 * 2 * kFragBytes;
+
+template <int PREC, bool TRAIN>
+__global__ void __launch_bounds__(256, 2) nerf_fwd_tph_kernel(const unsigned char* blob, const float* __restrict__ pts4,
+                                                              const float* __restrict__ dirs, long N, NerfStash st,
+                                                              float* __restrict__ density, float* __restrict__ rgb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
+    unsigned char* frag = lds_;
+    constexpr int HB = 2, HALF = kNerfHalf;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = lane & 31, h = lane >> 5;
+    const int t0 = 2 * wave;
+    const PPLane pl = pp_lane(lane);
+    const long tiles = pp_tiles(N);
+    const long groups = (N + 32 * HB - 1) / (32 * HB);
+    const bool lo_planes = TRAIN && PREC == 3 && st.h_lo != nullptr;
+    constexpr auto& LY = kNerfLayout;
+    for (long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        asm volatile("" : "+s"(blob));
+        long tile[HB], n[HB], nc[HB];
+        bool valid[HB];
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb) {
+            tile[hb] = grp * HB + hb;
+            n[hb] = tile[hb] * 32 + r;
+            valid[hb] = n[hb] < N;
+            nc[hb] = valid[hb] ? n[hb] : N - 1;
+        }
+        uint32_t* mrow[HB];
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb) mrow[hb] = reinterpret_cast<uint32_t*>(st.mask + (size_t)tile[hb] * 9 * 64 + lane);
+        // the points' encodings: wave w builds k-steps w and w + 4 (< 6) of both halves and keeps them
+        BFrag<PREC> pef[HB][2];
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb) {
+            float x[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) x[c] = pts4[nc[hb] * 4 + c];
+            posenc4_frag<PREC>(x, wave, h, pef[hb][0]);
+            if (wave < 2) posenc4_frag<PREC>(x, wave + 4, h, pef[hb][1]);
+            if constexpr (TRAIN) {
+                unsigned char* ph = st.pe_hi + (size_t)tile[hb] * 6 * kFragBytes;
+                unsigned char* plo = lo_planes ? st.pe_lo + (size_t)tile[hb] * 6 * kFragBytes : nullptr;
+                frags_to_plane<PREC, 1>(&pef[hb][0], wave, ph, plo, pl, valid[hb]);
+                if (wave < 2) frags_to_plane<PREC, 1>(&pef[hb][1], wave + 4, ph, plo, pl, valid[hb]);
+            }
+        }
+        auto write_pe = [&]() {
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+                nerf_write_frags<PREC, 1>(frag + hb * HALF, lane, wave, &pef[hb][0]);
+                if (wave < 2) nerf_write_frags<PREC, 1>(frag + hb * HALF, lane, wave + 4, &pef[hb][1]);
+            }
+        };
+        nerf_barrier();                                   // the previous group's fragments are consumed
+        write_pe();
+        nerf_barrier();
+        f32x16 acc[2][HB];
+        bias_nh<2, HB>(blob, LY.L[0].bias, acc, lane, t0);
+        tph_dense<PREC, 6, 8, 0, 2, true, HB, HALF>(blob, LY.L[0].fwd_hi, LY.L[0].fwd_lo, frag, acc, lane, t0);
+#pragma unroll 1
+        for (int l = 0; l <= 7; ++l) {
+            if (l > 0) {
+                const int e = l < 6 ? l : l + 1;
+                bias_nh<2, HB>(blob, LY.L[e].bias, acc, lane, t0);
+                tph_dense<PREC, 16, 8, 0, 2, true, HB, HALF>(blob, LY.L[e].fwd_hi, LY.L[e].fwd_lo, frag, acc, lane, t0);
+                if (l == 5) {                             // the re-concatenated encoding: a second product into the same tiles
+                    nerf_barrier();
+                    write_pe();
+                    nerf_barrier();
+                    tph_dense<PREC, 6, 8, 0, 2, true, HB, HALF>(blob, LY.L[6].fwd_hi, LY.L[6].fwd_lo, frag, acc, lane, t0);
+                }
+            }
+            unsigned char *ph[HB], *plo[HB];
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+                f32x16 two[2] = {acc[0][hb], acc[1][hb]};
+                const uint32_t m = relu_bits<2>(two);
+                acc[0][hb] = two[0];
+                acc[1][hb] = two[1];
+                if constexpr (TRAIN) mrow[hb][(size_t)l * 64 * 4 + wave] = m;
+                const size_t off = ((size_t)l * tiles + tile[hb]) * kPPBlock;
+                ph[hb] = TRAIN ? st.h_hi + off : nullptr;
+                plo[hb] = lo_planes ? st.h_lo + off : nullptr;
+            }
+            tph_exchange<PREC, 2, true, HB, HALF>(frag, lane, t0, acc, ph, plo, pl, valid);
+        }
+        // feature_linear (tiles 0..7) and alpha_linear (tile 8, row 0: wave 0); no activation
+        bias_nh<2, HB>(blob, LY.L[9].bias, acc, lane, t0);
+        tph_dense<PREC, 16, 9, 0, 2, true, HB, HALF>(blob, LY.L[9].fwd_hi, LY.L[9].fwd_lo, frag, acc, lane, t0);
+        if (wave == 0) {
+            f32x16 a1[1][HB];
+            bias_nh<1, HB>(blob, LY.L[9].bias, a1, lane, 8);
+            tph_dense<PREC, 16, 9, 8, 1, true, HB, HALF>(blob, LY.L[9].fwd_hi, LY.L[9].fwd_lo, frag, a1, lane);
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb)
+                if (valid[hb] && lane < 32) density[n[hb]] = a1[0][hb][0];
+        }
+        BFrag<PREC> bd[HB * 3];
+        if (wave == 1) {                                  // PE4 of the view directions: k-steps 16, 17 of the view layer
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+                float d[3], pe[kViewPE], jc[kViewPE];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) d[c] = dirs[nc[hb] * 3 + c];
+                posenc<4, false>(d, pe, jc);
+                BFrag<PREC> tmp[kMaxKS];
+                vec_to_bfrag<PREC, kViewPE, 2, 0>(pe, tmp, h);
+                bd[hb * 3] = tmp[0];
+                bd[hb * 3 + 1] = tmp[1];
+                if constexpr (TRAIN)
+                    frags_to_plane<PREC, 2>(&bd[hb * 3], 0, st.dpe_hi + (size_t)tile[hb] * 2 * kFragBytes,
+                                            lo_planes ? st.dpe_lo + (size_t)tile[hb] * 2 * kFragBytes : nullptr, pl, valid[hb]);
+            }
+        }
+        {
+            unsigned char *ph[HB], *plo[HB];
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+                ph[hb] = TRAIN ? st.feat_hi + (size_t)tile[hb] * kPPBlock : nullptr;
+                plo[hb] = lo_planes ? st.feat_lo + (size_t)tile[hb] * kPPBlock : nullptr;
+            }
+            tph_exchange<PREC, 2, true, HB, HALF>(frag, lane, t0, acc, ph, plo, pl, valid, wave == 1 ? bd : nullptr, 16, 2);
+        }
+        // views_linears.0: [feature | PE4(view)] -> 128 + ReLU; wave w owns tile w
+        f32x16 v[1][HB];
+        bias_nh<1, HB>(blob, LY.L[10].bias, v, lane, wave);
+        tph_dense<PREC, 18, 4, 0, 1, true, HB, HALF>(blob, LY.L[10].fwd_hi, LY.L[10].fwd_lo, frag, v, lane, wave);
+        {
+            unsigned char *ph[HB], *plo[HB];
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+                f32x16 one[1] = {v[0][hb]};
+                const uint32_t m = relu_bits<1>(one);
+                v[0][hb] = one[0];
+                if constexpr (TRAIN) reinterpret_cast<uint16_t*>(mrow[hb] + (size_t)8 * 64 * 4)[wave] = (uint16_t)m;
+                ph[hb] = TRAIN ? st.hv_hi + (size_t)tile[hb] * 8 * kFragBytes : nullptr;
+                plo[hb] = lo_planes ? st.hv_lo + (size_t)tile[hb] * 8 * kFragBytes : nullptr;
+            }
+            tph_exchange<PREC, 1, true, HB, HALF>(frag, lane, wave, v, ph, plo, pl, valid);
+        }
+        if (wave == 0) {
+            f32x16 o[1][HB];
+            bias_nh<1, HB>(blob, LY.L[11].bias, o, lane, 0);
+            tph_dense<PREC, 8, 1, 0, 1, true, HB, HALF>(blob, LY.L[11].fwd_hi, LY.L[11].fwd_lo, frag, o, lane);
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb)
+                if (valid[hb] && lane < 32) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) rgb[n[hb] * 3 + c] = o[0][hb][c];
+                }
+        }
+    }
+}
+
+template <int PREC>
+__global__ void __launch_bounds__(256, 2) nerf_bwd_tph_kernel(const unsigned char* blob, long N, const float* __restrict__ d_density,
+                                                              const float* __restrict__ d_rgb, NerfStash st) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
+    unsigned char* frag = lds_;
+    constexpr int HB = 2, HALF = kNerfHalf;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = lane & 31, h = lane >> 5;
+    const int t0 = 2 * wave;
+    const PPLane pl = pp_lane(lane);
+    const long tiles = pp_tiles(N);
+    const long groups = (N + 32 * HB - 1) / (32 * HB);
+    const bool lo_planes = PREC == 3 && st.zbar_lo != nullptr;
+    constexpr auto& LY = kNerfLayout;
+    for (long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        asm volatile("" : "+s"(blob));
+        long tile[HB], nc[HB];
+        bool valid[HB];
+        const uint32_t* mrow[HB];
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb) {
+            tile[hb] = grp * HB + hb;
+            const long n = tile[hb] * 32 + r;
+            valid[hb] = n < N;
+            nc[hb] = valid[hb] ? n : N - 1;
+            mrow[hb] = reinterpret_cast<const uint32_t*>(st.mask + (size_t)tile[hb] * 9 * 64 + lane);
+        }
+        BFrag<PREC> bden[HB * 3];                         // the density tiles' fragments (wave 0), published with dL/d feature
+        if (wave == 0) {
+            f32x16 z0[1][HB];
+            unsigned char *zh[HB], *zl[HB];
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+                f32x16 zo[2];
+                zero_acc(zo);
+                if (h == 0 && valid[hb]) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) zo[0][c] = d_rgb[nc[hb] * 3 + c];
+                    zo[1][0] = d_density[nc[hb]];
+                }
+                z0[0][hb] = zo[0];
+                zh[hb] = st.zout_hi + (size_t)tile[hb] * 4 * kFragBytes;
+                zl[hb] = lo_planes ? st.zout_lo + (size_t)tile[hb] * 4 * kFragBytes : nullptr;
+                BFrag<PREC> tmp[kMaxKS];
+                acc_to_bfrag<PREC, 1>(reinterpret_cast<f32x16(&)[1]>(zo[1]), tmp);
+                bden[hb * 3] = tmp[0];
+                bden[hb * 3 + 1] = tmp[1];
+                frags_to_plane<PREC, 2>(&bden[hb * 3], 2, zh[hb], zl[hb], pl, valid[hb]);
+            }
+            tph_exchange<PREC, 1, true, HB, HALF>(frag, lane, 0, z0, zh, zl, pl, valid);
+        } else {
+            nerf_barrier();
+            nerf_barrier();
+        }
+        // rgb_linear reverse -> the 128 view-branch features (wave w: tile w), ReLU' of views_linears.0
+        f32x16 v[1][HB];
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[0][hb][e] = 0.0f;
+        tph_dense<PREC, 2, 4, 0, 1, true, HB, HALF>(blob, LY.L[11].rev_hi, LY.L[11].rev_lo, frag, v, lane, wave);
+        {
+            unsigned char *ph[HB], *plo[HB];
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+                f32x16 one[1] = {v[0][hb]};
+                apply_bits<1>(one, reinterpret_cast<const uint16_t*>(mrow[hb] + (size_t)8 * 64 * 4)[wave], valid[hb]);
+                v[0][hb] = one[0];
+                ph[hb] = st.zhv_hi + (size_t)tile[hb] * 8 * kFragBytes;
+                plo[hb] = lo_planes ? st.zhv_lo + (size_t)tile[hb] * 8 * kFragBytes : nullptr;
+            }
+            tph_exchange<PREC, 1, true, HB, HALF>(frag, lane, wave, v, ph, plo, pl, valid);
+        }
+        f32x16 acc[2][HB];
+        auto zero2 = [&]() {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[t][hb][e] = 0.0f;
+        };
+        // views_linears.0 reverse onto its 256 feature inputs = dL/d feature
+        zero2();
+        tph_dense<PREC, 8, 8, 0, 2, true, HB, HALF>(blob, LY.L[10].rev_hi, LY.L[10].rev_lo, frag, acc, lane, t0);
+        {
+            unsigned char *ph[HB], *plo[HB];
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+                ph[hb] = st.zfeat_hi + (size_t)tile[hb] * kPPBlock;
+                plo[hb] = lo_planes ? st.zfeat_lo + (size_t)tile[hb] * kPPBlock : nullptr;
+            }
+            tph_exchange<PREC, 2, true, HB, HALF>(frag, lane, t0, acc, ph, plo, pl, valid, wave == 0 ? bden : nullptr, 16, 2);
+        }
+        // feature_linear^T dfeature + alpha_linear^T ddensity -> dL/d h_7
+        zero2();
+        tph_dense<PREC, 18, 8, 0, 2, true, HB, HALF>(blob, LY.L[9].rev_hi, LY.L[9].rev_lo, frag, acc, lane, t0);
+#pragma unroll 1
+        for (int l = 7; l >= 0; --l) {
+            unsigned char *ph[HB], *plo[HB];
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+                f32x16 two[2] = {acc[0][hb], acc[1][hb]};
+                apply_bits<2>(two, mrow[hb][(size_t)l * 64 * 4 + wave], valid[hb]);
+                acc[0][hb] = two[0];
+                acc[1][hb] = two[1];
+                const size_t off = ((size_t)l * tiles + tile[hb]) * kPPBlock;
+                ph[hb] = st.zbar_hi + off;
+                plo[hb] = lo_planes ? st.zbar_lo + off : nullptr;
+            }
+            tph_exchange<PREC, 2, true, HB, HALF>(frag, lane, t0, acc, ph, plo, pl, valid);
+            if (l > 0) {
+                const int e = l < 6 ? l : l + 1;
+                zero2();
+                tph_dense<PREC, 16, 8, 0, 2, true, HB, HALF>(blob, LY.L[e].rev_hi, LY.L[e].rev_lo, frag, acc, lane, t0);
+            }
+        }
+    }
+}
+
 }  // namespace fneus
 
 using namespace fneus;
@@ -509,6 +804,13 @@ using namespace fneus;
 static inline bool nerf_use_tp() {
     const char* e = getenv("FNEUS_K7_TP");
     return !(e && e[0] == '0');
+}
+
+// 64-sample workgroups for chip-filling launches (>= 1024 tiles); FNEUS_K7_HB=1 keeps 32 samples per workgroup
+static inline bool nerf_use_hb2(long n_tiles) {
+    const char* e = getenv("FNEUS_K7_HB");
+    if (e && e[0] == '1') return false;
+    return nerf_use_tp() && n_tiles >= 1024;
 }
 
 static inline int nerf_grid(long n_tiles) {
@@ -530,6 +832,22 @@ extern "C" int fneus_nerf_bg_fwd(const void* blob, const float* pts4, const floa
     const unsigned char* b = reinterpret_cast<const unsigned char*>(blob);
     NerfStash st = stash ? NerfStash(*stash) : NerfStash();
     if (train && (!st.pe_hi || !st.h_hi || !st.feat_hi || !st.dpe_hi || !st.hv_hi || !st.mask)) return -2;
+    if (nerf_use_hb2((n_pts + 31) / 32)) {
+        const long ng = (n_pts + 63) / 64;
+        dim3 g2((unsigned)(ng < 2048 ? ng : 2048)), b2(256);
+#define FNEUS_NERF_TPH(KERNEL, ...)                                                                      \
+        do {                                                                                             \
+            static bool done = false;                                                                    \
+            if (!done) { fneus::allow_big_lds(KERNEL); done = true; }                                    \
+            hipLaunchKernelGGL((KERNEL), g2, b2, 2 * fneus::kNerfHalf, stream, __VA_ARGS__);              \
+        } while (0)
+        if (prec == 3 && train) FNEUS_NERF_TPH((nerf_fwd_tph_kernel<3, true>), b, pts4, dirs, n_pts, st, density, rgb);
+        else if (prec == 3) FNEUS_NERF_TPH((nerf_fwd_tph_kernel<3, false>), b, pts4, dirs, n_pts, st, density, rgb);
+        else if (prec == 1 && train) FNEUS_NERF_TPH((nerf_fwd_tph_kernel<1, true>), b, pts4, dirs, n_pts, st, density, rgb);
+        else if (prec == 1) FNEUS_NERF_TPH((nerf_fwd_tph_kernel<1, false>), b, pts4, dirs, n_pts, st, density, rgb);
+        else return -2;
+        return fneus::launch_status();
+    }
     if (nerf_use_tp()) {
         const long nt = (n_pts + 31) / 32;
         dim3 g2((unsigned)(nt < 2048 ? nt : 2048)), b2(256);
@@ -569,6 +887,14 @@ extern "C" int fneus_nerf_bg_bwd(const void* blob, long n_pts, const float* d_de
     NerfStash st(*stash);
     if (!st.mask || !st.zbar_hi || !st.zfeat_hi || !st.zhv_hi || !st.zout_hi) return -2;
     const unsigned char* b = reinterpret_cast<const unsigned char*>(blob);
+    if (nerf_use_hb2((n_pts + 31) / 32)) {
+        const long ng = (n_pts + 63) / 64;
+        dim3 g2((unsigned)(ng < 2048 ? ng : 2048)), b2(256);
+        if (prec == 3) FNEUS_NERF_TPH(nerf_bwd_tph_kernel<3>, b, n_pts, d_density, d_rgb, st);
+        else if (prec == 1) FNEUS_NERF_TPH(nerf_bwd_tph_kernel<1>, b, n_pts, d_density, d_rgb, st);
+        else return -2;
+        return fneus::launch_status();
+    }
     if (nerf_use_tp()) {
         const long nt = (n_pts + 31) / 32;
         dim3 g2((unsigned)(nt < 2048 ? nt : 2048)), b2(256);

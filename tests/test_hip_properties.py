@@ -165,3 +165,71 @@ def test_overwritten_stash_is_detected():
     gb.sum().backward()                      # the latest call: fine
     with pytest.raises(RuntimeError, match="overwritten"):
         ga.sum().backward()
+
+
+def _grads_of(mod):
+    return torch.cat([p.grad.detach().reshape(-1).clone() for p in mod.parameters()])
+
+
+def test_64_sample_workgroups_equal_32_sample_workgroups(monkeypatch):
+    """chip-filling launches (>= 1024 tiles) run kernels whose workgroups carry two 32-sample tiles through one pass over the
+    weight fragments (colour network, background NeRF; FNEUS_COL_HB / FNEUS_K7_HB = 1 select the 32-sample kernels, read at
+    every call).  Same arithmetic per sample: outputs and input gradients agree to rounding-order noise, weight gradients to
+    the summation order of the GEMM's atomics.  Ragged size with an odd tile count."""
+    from fneus import ops, synth
+    from fneus.autograd import RaySamples
+    from models.fields import SDFNetwork, RenderingNetwork, NeRF
+    from fneus.trainer import WMASK_MODEL
+    dev = torch.device("cuda:0")
+    n = 40003
+    g = torch.Generator().manual_seed(3)
+    T = lambda sd: {k: torch.from_numpy(v) for k, v in sd.items()}
+    # ---- colour network (K4) ----
+    sdf = SDFNetwork(**WMASK_MODEL["sdf_network"])
+    col = RenderingNetwork(**WMASK_MODEL["rendering_network"])
+    sdf.load_state_dict(T(synth.sdf_state_dict(1)))
+    col.load_state_dict(T(synth.color_state_dict(2)))
+    sdf.to(dev), col.to(dev)
+    pts = (torch.rand(n, 3, generator=g) * 1.6 - 0.8).to(dev)
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(dev)
+    cot = torch.randn(n, 3, generator=g).to(dev)
+
+    def run_color(hb):
+        monkeypatch.setenv("FNEUS_COL_HB", str(hb))
+        for p in list(sdf.parameters()) + list(col.parameters()):
+            p.grad = None
+        s = RaySamples(pts=pts, dirs=dirs)
+        sdf.refresh(), col.refresh()
+        _, feat, normal = sdf.value_feature_normal(s, True)
+        rgb = col.color_samples(s, normal, feat, sdf, True)
+        (rgb * cot).sum().backward()
+        return rgb.detach().clone(), _grads_of(col), _grads_of(sdf)
+
+    rgb2, gc2, gs2 = run_color(2)
+    rgb1, gc1, gs1 = run_color(1)
+    assert (rgb2 - rgb1).abs().max().item() <= 1e-6
+    for a, b, name in ((gc2, gc1, "colour"), (gs2, gs1, "sdf")):
+        rel = ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+        assert rel <= 2e-4, (name, rel)
+    # ---- background NeRF (K7) ----
+    nerf = NeRF(D=8, d_in=4, d_in_view=3, W=256, multires=10, multires_view=4, output_ch=4, skips=[4], use_viewdirs=True)
+    nerf.load_state_dict(T(synth.nerf_state_dict(3)))
+    nerf.to(dev)
+    p4 = torch.cat([torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1), torch.rand(n, 1, generator=g) * 0.98 + 0.02], -1).to(dev)
+    ca, cr = torch.randn(n, 1, generator=g).to(dev), torch.randn(n, 3, generator=g).to(dev)
+
+    def run_nerf(hb):
+        monkeypatch.setenv("FNEUS_K7_HB", str(hb))
+        for p in nerf.parameters():
+            p.grad = None
+        nerf.refresh()
+        a, rgb = nerf(p4, dirs)
+        ((a * ca).sum() + (rgb * cr).sum()).backward()
+        return a.detach().clone(), rgb.detach().clone(), _grads_of(nerf)
+
+    a2, r2, g2 = run_nerf(2)
+    a1, r1, g1 = run_nerf(1)
+    scale = max(a1.abs().max().item(), 1.0)
+    assert (a2 - a1).abs().max().item() <= 2e-6 * scale and (r2 - r1).abs().max().item() <= 2e-6 * max(r1.abs().max().item(), 1.0)
+    rel = ((g2 - g1).abs().max() / (g1.abs().max() + 1e-12)).item()
+    assert rel <= 2e-4, rel
