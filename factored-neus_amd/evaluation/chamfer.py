@@ -60,10 +60,13 @@ def thin(points: np.ndarray, thresh: float, seed: int = 0) -> np.ndarray:
     return pts[keep]
 
 
-def chamfer_l1(data: np.ndarray, reference: np.ndarray, max_dist: float = 20.0, data_for_s2d: Optional[np.ndarray] = None):
-    """-> (mean data->reference, mean reference->data, overall); dtu_eval.py:124-141, 158"""
+def chamfer_l1(data: np.ndarray, reference: np.ndarray, max_dist: float = 20.0, data_for_s2d: Optional[np.ndarray] = None,
+               reference_for_s2d: Optional[np.ndarray] = None):
+    """-> (mean data->reference, mean reference->data, overall); dtu_eval.py:124-141, 158.  The reference measures data ->
+    reference against the WHOLE reference cloud (:121-126) and reference -> data from the part of it above the ground plane
+    (:131-140): `reference_for_s2d`."""
     d2s, _ = cKDTree(reference).query(data, k=1)
-    s2d, _ = cKDTree(data if data_for_s2d is None else data_for_s2d).query(reference, k=1)
+    s2d, _ = cKDTree(data if data_for_s2d is None else data_for_s2d).query(reference if reference_for_s2d is None else reference_for_s2d, k=1)
     mean_d2s = float(d2s[d2s < max_dist].mean())
     mean_s2d = float(s2d[s2d < max_dist].mean())
     return mean_d2s, mean_s2d, 0.5 * (mean_d2s + mean_s2d)
@@ -85,10 +88,11 @@ def evaluate_mesh(vertices, triangles, reference_points, thresh: float = 0.2, ma
         gi = grid[g_in]
         data_obs = data_in[g_in][mask[gi[:, 0], gi[:, 1], gi[:, 2]].astype(bool)]
     ref = np.asarray(reference_points, np.float64)
+    ref_above = None
     if plane is not None:
         hom = np.concatenate([ref, np.ones_like(ref[:, :1])], -1)
-        ref = ref[(np.asarray(plane).reshape(1, 4) * hom).sum(-1) > 0]
-    return chamfer_l1(data_obs, ref, max_dist, data_for_s2d=data_in)
+        ref_above = ref[(np.asarray(plane).reshape(1, 4) * hom).sum(-1) > 0]
+    return chamfer_l1(data_obs, ref, max_dist, data_for_s2d=data_in, reference_for_s2d=ref_above)
 
 
 def main(argv):

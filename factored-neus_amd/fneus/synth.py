@@ -200,3 +200,51 @@ def ray_batch(batch: int, seed: int = 0, radius: float = 2.8, half_extent: float
     mask = (rs.uniform(0, 1, size=(batch, 1)) < mask_prob).astype(np.float64)
     o = np.broadcast_to(c[None, :], (batch, 3))
     return _f32(np.concatenate([o, d, rgb, mask], axis=1))
+
+
+def icosphere(level: int = 3):
+    """unit icosphere: 12 vertices subdivided `level` times -> (vertices [V,3] float64, triangles [T,3] int64); deterministic"""
+    t = (1.0 + math.sqrt(5.0)) / 2.0
+    v = np.array([[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t],
+                  [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]], dtype=np.float64)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    f = np.array([[0, 11, 5], [0, 5, 1], [0, 1, 7], [0, 7, 10], [0, 10, 11], [1, 5, 9], [5, 11, 4], [11, 10, 2], [10, 7, 6],
+                  [7, 1, 8], [3, 9, 4], [3, 4, 2], [3, 2, 6], [3, 6, 8], [3, 8, 9], [4, 9, 5], [2, 4, 11], [6, 2, 10],
+                  [8, 6, 7], [9, 8, 1]], dtype=np.int64)
+    for _ in range(level):
+        verts = list(map(tuple, v))
+        cache, faces = {}, []
+
+        def mid(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in cache:
+                m = (np.asarray(verts[a]) + np.asarray(verts[b])) * 0.5
+                verts.append(tuple(m / np.linalg.norm(m)))
+                cache[key] = len(verts) - 1
+            return cache[key]
+
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            faces += [[a, ab, ca], [b, bc, ab], [c, ca, bc], [ab, bc, ca]]
+        v, f = np.asarray(verts, dtype=np.float64), np.asarray(faces, dtype=np.int64)
+    return v, f
+
+
+def dtu_eval_scene(seed: int = 0):
+    """A DTU-shaped evaluation case in millimetres (evaluation/dtu_eval.py:36-162): a reconstructed mesh (icosphere of
+    radius 12 with a smooth bump), the "scanned" reference cloud (points on the true sphere of radius 11.8, above and below
+    the ground plane), an observability grid with one octant masked out and the ground plane."""
+    rs = np.random.RandomState(seed)
+    v, f = icosphere(3)
+    bump = 1.0 + 0.03 * np.sin(3.0 * v[:, 0]) * np.cos(2.0 * v[:, 1])
+    vertices = v * (12.0 * bump)[:, None] + np.array([5.0, -3.0, 20.0])
+    n = 30000
+    g = rs.standard_normal((n, 3))
+    stl = 11.8 * g / np.linalg.norm(g, axis=1, keepdims=True) + np.array([5.0, -3.0, 20.0])
+    bb = np.array([[-12.0, -20.0, 4.0], [22.0, 14.0, 36.0]])
+    res = 2.0
+    shape = tuple(int(round((bb[1, i] - bb[0, i]) / res)) + 1 for i in range(3))
+    obs = np.ones(shape, dtype=np.uint8)
+    obs[: shape[0] // 2, : shape[1] // 2, : shape[2] // 2] = 0            # one octant of the volume was never observed
+    plane = np.array([0.0, 0.0, 1.0, -12.0])                               # points with z > 12 count for stl -> data
+    return {"vertices": vertices, "triangles": f, "stl": stl, "ObsMask": obs, "BB": bb, "Res": res, "P": plane}

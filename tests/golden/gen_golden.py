@@ -502,6 +502,62 @@ def gen_mateillu_render(fields, renderer, out_dir, name, B, n_samples, n_importa
           float(res["out/rgb"][res["out/sdf_mask"]].mean()), "lvis_mean", float(res["out/lvis_mean"][res["out/sdf_mask"]].mean()))
 
 
+def gen_dtu_eval(out_dir, name="dtu_eval_synth"):
+    """evaluation/dtu_eval.py eval() of the reference on a synthetic DTU-shaped case (fneus.synth.dtu_eval_scene): the
+    Chamfer numbers the product's evaluation/chamfer.py is pinned to.  open3d and trimesh are absent: their FILE I/O
+    (read_triangle_mesh / read_point_cloud / write_point_cloud / PointCloud.export) is served from arrays -- no part of the
+    evaluated algorithm (sampling, thinning, masking, nearest neighbours: numpy / sklearn) goes through them.  The
+    reference shuffles with an unseeded generator (dtu_eval.py:81): it is seeded here, the product is compared with a
+    tolerance that covers the shuffle."""
+    import tempfile
+    from scipy.io import savemat
+    scene = synth.dtu_eval_scene(0)
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "ObsMask"))
+    savemat(os.path.join(tmp, "ObsMask", "ObsMask1_10.mat"), {"ObsMask": scene["ObsMask"], "BB": scene["BB"], "Res": scene["Res"]})
+    savemat(os.path.join(tmp, "ObsMask", "Plane1.mat"), {"P": scene["P"].reshape(4, 1)})
+
+    class _Mesh:
+        vertices, triangles = scene["vertices"], scene["triangles"]
+
+        def remove_unreferenced_vertices(self):
+            return self
+
+    class _Cloud:
+        points = scene["stl"]
+        colors = None
+
+    o3d = types.ModuleType("open3d")
+    o3d.io = types.SimpleNamespace(read_triangle_mesh=lambda p: _Mesh(), read_point_cloud=lambda p: _Cloud(),
+                                   write_point_cloud=lambda *a, **k: None)
+    o3d.geometry = types.SimpleNamespace(PointCloud=_Cloud)
+    o3d.utility = types.SimpleNamespace(Vector3dVector=lambda x: x)
+    tm = types.ModuleType("trimesh")
+    tm.PointCloud = lambda pts: types.SimpleNamespace(export=lambda *a, **k: None)
+    saved = {k: sys.modules.get(k) for k in ("open3d", "trimesh")}
+    sys.modules["open3d"], sys.modules["trimesh"] = o3d, tm
+    real_rng = np.random.default_rng
+    cwd = os.getcwd()
+    try:
+        dtu_eval = _load_by_path("ref_dtu_eval", os.path.join(REF, "evaluation", "dtu_eval.py"))
+        assert dtu_eval.__file__.startswith(REF + "/")
+        sys.modules["ref_dtu_eval"] = dtu_eval          # its multiprocessing pool pickles sample_single_tri by module name
+        np.random.default_rng = lambda *a, **k: real_rng(12345)
+        os.chdir(tmp)
+        dtu_eval.eval("mesh.ply", 1, tmp, tmp)
+        mean_d2s, mean_s2d, over_all = [float(x) for x in open(os.path.join(tmp, "result.txt")).read().split()]
+    finally:
+        os.chdir(cwd)
+        np.random.default_rng = real_rng
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), scene_seed=0, mean_d2s=mean_d2s, mean_s2d=mean_s2d, over_all=over_all)
+    print(name + ".npz written; d2s", mean_d2s, "s2d", mean_s2d, "overall", over_all)
+
+
 def gen_raygen(dataset, out_dir, name="raygen_dtu"):
     """Dataset.gen_rays_at / gen_random_rays_at / near_far_from_sphere (dataset.py:115-151, 186-192) called unbound on a
     stub object that carries exactly the attributes they read: a synthetic DTU-like camera set (K^-1, pose), BGR/256
@@ -566,7 +622,7 @@ def gen_raygen(dataset, out_dir, name="raygen_dtu"):
 
 FIXTURES = ("units", "render_wmask_b16_n16", "render_wmask_b8_n64", "render_womask_b16_n16_o8", "render_wmask_b16_n16_c0",
             "render_wmask_b256_n32", "render_wmask_b64_n64", "lvis_util_b24_n32", "raygen_dtu", "lvis_render_room_b24_n32",
-            "lvis_render_ball_b16_n16", "mateillu_render_b24_n32")
+            "lvis_render_ball_b16_n16", "mateillu_render_b24_n32", "dtu_eval_synth")
 
 
 def check_against(old_dir, new_dir, names):
@@ -637,6 +693,8 @@ def main():
     if want("mateillu_render_b24_n32"):
         gen_mateillu_render(fields, renderer, args.out, "mateillu_render_b24_n32", B=24, n_samples=32, n_importance=32,
                             ray_seed=43, seeds=dict(seeds2, mateillu=26))
+    if want("dtu_eval_synth"):
+        gen_dtu_eval(args.out)
     if args.check:
         ok = check_against(HERE, args.out, FIXTURES)
         print("committed fixtures reproduced bit for bit" if ok else "MISMATCH against the committed fixtures")

@@ -130,3 +130,21 @@ def test_clean_mesh_by_masks_and_largest_component():
     v2, f2 = C.clean_mesh(v, f, mats, masks)
     assert np.abs(v2[:, 0]).max() <= 1.6 + 1e-9 and np.abs(v2[:, 1]).max() < 0.5        # the strip's middle, without the island
     assert len(f2) == 2 * (int((np.abs(xs) <= 1.6 + 1e-9).sum()) - 1) and f2.max() == len(v2) - 1
+
+
+def test_chamfer_pinned_to_the_reference_evaluation(golden_dir):
+    """evaluation/chamfer.py against the numbers of the reference's own evaluation/dtu_eval.py eval() on the synthetic
+    DTU-shaped case of fneus.synth.dtu_eval_scene (mesh sampling, thinning, observability mask, ground plane, both directed
+    means; tests/golden/gen_golden.py gen_dtu_eval).  The thinning depends on a random shuffle (unseeded in the reference):
+    two shuffles move the means by a few 1e-4 here, the bound is 1 %."""
+    import os
+    from evaluation.chamfer import evaluate_mesh
+    from fneus import synth
+    g = np.load(os.path.join(golden_dir, "dtu_eval_synth.npz"))
+    sc = synth.dtu_eval_scene(int(g["scene_seed"]))
+    d2s, s2d, overall = evaluate_mesh(sc["vertices"], sc["triangles"], sc["stl"], thresh=0.2, max_dist=20.0,
+                                      obs_mask=(sc["ObsMask"], sc["BB"], sc["Res"]), plane=sc["P"], patch=60.0)
+    print(f"  Chamfer d2s {d2s:.5f} (reference {float(g['mean_d2s']):.5f})  s2d {s2d:.5f} ({float(g['mean_s2d']):.5f})")
+    assert abs(d2s - float(g["mean_d2s"])) <= 0.01 * float(g["mean_d2s"])
+    assert abs(s2d - float(g["mean_s2d"])) <= 0.01 * float(g["mean_s2d"])
+    assert abs(overall - float(g["over_all"])) <= 0.01 * float(g["over_all"])
