@@ -233,3 +233,31 @@ def test_64_sample_workgroups_equal_32_sample_workgroups(monkeypatch):
     assert (a2 - a1).abs().max().item() <= 2e-6 * scale and (r2 - r1).abs().max().item() <= 2e-6 * max(r1.abs().max().item(), 1.0)
     rel = ((g2 - g1).abs().max() / (g1.abs().max() + 1e-12)).item()
     assert rel <= 2e-4, rel
+
+
+def test_batch_without_any_surface_hit():
+    """when no ray of a batch hits a surface the reference skips the RefColor branch (renderer.py:296:
+    its parameters get grad None and Adam skips them); here the branch runs at fixed shape with zero weights, so the RefColor
+    parameters receive exactly ZERO gradients: on a fresh optimiser they do not move at all (zero moments -> zero update),
+    afterwards their moments decay.  The step stays finite and the other networks train."""
+    from fneus import synth
+    from fneus.trainer import Stage1Trainer
+    dev = torch.device("cuda:0")
+    # (seed 0: with some initialisations EVERY surface colour starts clipped at 1 -- spec + diffuse ~ 0.5 + 0.5 -- and the
+    # RefColor gradient is zero on hitting batches too, for the reference as for us)
+    tr = Stage1Trainer(dev, seed=0, use_graph=False)
+    miss = torch.from_numpy(synth.ray_batch(512, seed=5, n_miss=512)).to(dev)          # every ray passes outside the unit sphere
+    before = {k: v.detach().clone() for k, v in tr.refColor_network.state_dict().items()}
+    sdf_before = tr.sdf_network.lin0.weight_v.detach().clone()
+    losses = tr.train_step(miss)
+    assert all(bool(torch.isfinite(v)) for v in losses.values() if torch.is_tensor(v))
+    out = tr.render_only(miss)
+    assert not bool(out["sdf_mask"].any())
+    for k, v in tr.refColor_network.state_dict().items():
+        assert torch.equal(v, before[k]), k                                             # zero gradient, zero moments: no update
+    assert not torch.equal(tr.sdf_network.lin0.weight_v.detach(), sdf_before)           # eikonal / mask terms still train the SDF
+    # a hitting batch next: everything trains
+    hit = torch.from_numpy(synth.ray_batch(512, seed=6)).to(dev)
+    tr.train_step(hit)
+    moved = max((v - before[k]).abs().max().item() for k, v in tr.refColor_network.state_dict().items())
+    assert moved > 0.0
