@@ -155,6 +155,14 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels eagerly instead of replaying a hipGraph")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner through the C stdio of the process, which is
+    # flushed at exit -- AFTER Python's own buffer when stdout is a pipe or a file (seen on the MI355X box: five banner lines
+    # behind the JSON line).  So: everything written to descriptor 1 during the run goes to stderr, and the JSON line is
+    # written to the real stdout directly.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     from fneus import ops
     from fneus.parallel import init_from_env, broadcast_parameters
     from fneus.trainer import Stage1Trainer, synthetic_batches
@@ -177,8 +185,12 @@ def main():
               f"{dist.get_backend()} RCCL {ver} MASTER {os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}",
               file=sys.stderr, flush=True)
 
+    # FNEUS_DP_SINGLE=1: the data-parallel step (four graph segments around three RCCL collectives) with ONE rank -- what the
+    # structure of the N > 1 step costs before any wire time; a diagnostic, not the N = 1 configuration
+    dp_single = os.environ.get("FNEUS_DP_SINGLE", "0") == "1" and dist.is_initialized()
+
     def run(prec, steps, warmup, profile):
-        tr = Stage1Trainer(device, prec=prec, distributed=(world > 1), use_graph=not args.no_graph)
+        tr = Stage1Trainer(device, prec=prec, distributed=(world > 1 or dp_single), use_graph=not args.no_graph)
         broadcast_parameters(tr.modules)
         batches = synthetic_batches(steps + warmup + (3 if profile else 0), RAYS, device, rank=rank)
         for i in range(warmup):
@@ -238,8 +250,9 @@ def main():
                    "parallelism": f"dp{world} (ray-sharded replicas, the gradient arena all-reduced in place in two parts)",
                    "launch": ("eager kernel launches" if not (tr.use_graph and tr._graphs) else
                               "four hipGraph replays per step around the three collectives (loss normalisers; early part of the gradient "
-                              "arena beside the SDF backward; late part)" if world > 1 else
+                              "arena beside the SDF backward; late part)" if (world > 1 or dp_single) else
                               "one hipGraph replay per step")},
+        **({"diagnostic": "FNEUS_DP_SINGLE=1: data-parallel step structure with one rank"} if dp_single else {}),
         "mfma_roofline_frac_step": value / world * FLOP_TRAIN_PER_SAMPLE / (PEAK_BF16_MFMA_TFLOPS * 1e12),
     }
 
@@ -384,8 +397,9 @@ def main():
             result["cpu_baseline"] = {"value": None, "error": repr(e)}
 
     if rank == 0:
-        print(json.dumps(result))
-    if world > 1:
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(result) + "\n").encode())
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -13,12 +13,28 @@ import torch
 import torch.distributed as dist
 
 
+def _single_rank_collectives() -> bool:
+    """FNEUS_DP_SINGLE=1: issue every collective even in a world of ONE rank.  A one-GPU box can then run the exact RCCL
+    call sequence of the data-parallel step (communicator set-up, the async all-reduce on the side stream, collectives
+    between the hipGraph segments); the results are unchanged (a sum over one rank)."""
+    return os.environ.get("FNEUS_DP_SINGLE", "0") == "1"
+
+
+def collectives_active(group=None) -> bool:
+    """are collectives issued?  (more than one rank, or FNEUS_DP_SINGLE=1)"""
+    return _active(group)
+
+
+def _active(group=None) -> bool:
+    return dist.is_initialized() and (dist.get_world_size(group) > 1 or _single_rank_collectives())
+
+
 def init_from_env(backend: Optional[str] = None):
     """Initialise torch.distributed from torchrun's environment; returns (rank, world, local_rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _single_rank_collectives()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend=backend or ("nccl" if torch.cuda.is_available() else "gloo"),
@@ -55,7 +71,7 @@ class FlatGradBucket:
     def allreduce_sum(self, group=None):
         """plain sum over ranks: with global loss normalisers (reduce_loss_norms) every rank's gradient is already its
         share of the global batch's gradient"""
-        if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        if not _active(group):
             return
         self.gather()
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
@@ -63,7 +79,7 @@ class FlatGradBucket:
 
     def allreduce_mean(self, group=None):
         """sum over ranks, divide by world size (every rank must call this every step: no data-dependent skipping)"""
-        if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        if not _active(group):
             return
         self.gather()
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
@@ -111,14 +127,14 @@ class GradArena:
                 p.grad = v
 
     def allreduce_sum(self, group=None):
-        if dist.is_initialized() and dist.get_world_size(group) > 1:
+        if _active(group):
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
 
     # ---- the exchange in two parts: `early` while the SDF backward still runs, `late` after it ----
     def allreduce_early(self, side_stream, group=None):
         """start the all-reduce of the early part on `side_stream`, ordered after everything issued so far on the current
         stream; the current stream does NOT wait.  -> a handle for wait_early()."""
-        if not (dist.is_initialized() and dist.get_world_size(group) > 1) or self.early.numel() == 0:
+        if not _active(group) or self.early.numel() == 0:
             return None
         if not self.flat.is_cuda or side_stream is None:      # host tensors (gloo tests): nothing to overlap with
             dist.all_reduce(self.early, op=dist.ReduceOp.SUM, group=group)
@@ -129,7 +145,7 @@ class GradArena:
         return work, side_stream
 
     def allreduce_late(self, group=None):
-        if dist.is_initialized() and dist.get_world_size(group) > 1 and self.late.numel() > 0:
+        if _active(group) and self.late.numel() > 0:
             dist.all_reduce(self.late, op=dist.ReduceOp.SUM, group=group)
 
     @staticmethod
@@ -146,13 +162,13 @@ class GradArena:
 def reduce_loss_norms(norms: torch.Tensor, group=None) -> torch.Tensor:
     """[sum mask, sum mask*sdf_mask, sum eik_den, ray count] of this rank -> of the global batch (SURVEY.md section 8(e):
     the small all-reduce BEFORE the loss that makes R ranks x B rays equal to one R*B-ray batch).  In place."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _active(group):
         dist.all_reduce(norms, op=dist.ReduceOp.SUM, group=group)
     return norms
 
 
 def broadcast_parameters(modules, src: int = 0, group=None):
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not _active(group):
         return
     for m in modules:
         for t in list(m.parameters()) + list(m.buffers()):

@@ -17,7 +17,7 @@ import torch
 
 from fneus import ops, synth
 from fneus.optim import FlatAdam
-from fneus.parallel import GradArena, reduce_loss_norms
+from fneus.parallel import GradArena, collectives_active, reduce_loss_norms
 
 WMASK_MODEL = {   # confs/wmask.conf:49-97
     "sdf_network": dict(d_out=257, d_in=3, d_hidden=256, n_layers=8, skip_in=[4], multires=6, bias=0.5, scale=1.0,
@@ -249,7 +249,7 @@ class Stage1Trainer:
         elif st["n_coll"] < 2:
             self.bucket.allreduce_sum()
         flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float32, device=self.device)
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if collectives_active():
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         torch.cuda.synchronize()
         if flag.item() < 0.5:                # some rank failed: ALL ranks run eagerly from here on
@@ -315,7 +315,7 @@ class Stage1Trainer:
         """data parallel: the loss terms of a step are this rank's SHARE of the global batch's; sum them over the ranks
         (one small all-reduce; call it on every rank, e.g. only when logging)"""
         import torch.distributed as dist
-        if self.bucket is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        if self.bucket is None or not collectives_active():
             return losses
         keys = ["loss", "color_loss", "surface_loss", "eikonal_loss", "mask_loss"]
         v = torch.stack([losses[k].detach().reshape(()) for k in keys])

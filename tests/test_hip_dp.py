@@ -221,3 +221,29 @@ def test_stage3_two_half_batches_with_global_statistics_equal_the_full_batch():
     trd = Stage3Trainer(dev, seed=4, distributed=True)
     o = trd.train_step(full)
     assert bool(torch.isfinite(o["loss"])) and trd.iter_step == 1
+
+
+def test_one_rank_over_rccl_runs_the_data_parallel_call_sequence():
+    """RCCL refuses two ranks on one device, so the test box cannot hold a real N > 1 job; FNEUS_DP_SINGLE=1 makes a world of
+    ONE rank issue every collective of the data-parallel step anyway: communicator set-up, the parameter broadcast, the
+    loss-normaliser all-reduce, the async all-reduce of the early arena part on the side stream while the SDF backward
+    runs, the late part -- eagerly and between the four hipGraph segments.  The trajectories must equal each other (a sum
+    over one rank changes nothing) and the graphs must have been captured."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    traces = []
+    for graph in (False, True):
+        port = 29900 + (os.getpid() + 37 * int(graph)) % 90
+        env = dict(os.environ, DP_CHECK_GRAPH="1" if graph else "0", DP_CHECK_BACKEND="nccl", FNEUS_DP_SINGLE="1",
+                   RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "dp_check.py")], capture_output=True, text=True,
+                           timeout=240, env=env)
+        line = [l for l in r.stdout.splitlines() if l.startswith("DP_CHECK")]
+        assert r.returncode == 0 and line and line[0].endswith("OK"), (r.stdout[-2000:], r.stderr[-2000:])
+        print(" ", line[0])
+        traces.append([float(v) for v in [l for l in r.stdout.splitlines() if l.startswith("DP_TRACE")][0].split()[1:]])
+    for i, (a, b) in enumerate(zip(*traces)):
+        assert abs(a - b) <= (1e-3 if i < 3 else 3e-2) * max(abs(a), 1e-2), (i, a, b)

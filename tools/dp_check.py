@@ -14,7 +14,8 @@ import torch.distributed as dist
 from fneus.parallel import broadcast_parameters, init_from_env
 from fneus.trainer import Stage1Trainer, synthetic_batches, WMASK_MODEL
 
-rank, world, _ = init_from_env("gloo")
+# DP_CHECK_BACKEND=nccl with FNEUS_DP_SINGLE=1 and ONE rank: the same call sequence over RCCL (tests/test_hip_dp.py)
+rank, world, _ = init_from_env(os.environ.get("DP_CHECK_BACKEND", "gloo"))
 dev = torch.device("cuda:0")
 torch.cuda.set_device(0)
 use_graph = os.environ.get("DP_CHECK_GRAPH", "0") == "1"      # four hipGraphs per step around the three collectives
