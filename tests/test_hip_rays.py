@@ -191,7 +191,7 @@ def test_ray_setup_matches_torch_formulation(n, perturb):
 
 
 SAMPLER_CASES = ["render_wmask_b16_n16", "render_wmask_b8_n64", "render_womask_b16_n16_o8", "render_wmask_b256_n32",
-                 "render_wmask_b64_n64"]
+                 "render_wmask_b64_n64", "render_wmask_b512_n64"]
 
 
 @pytest.mark.parametrize("name", SAMPLER_CASES)

