@@ -341,12 +341,21 @@ __global__ void __launch_bounds__(64) composite_fwd_kernel(
 
 // exclusive suffix sum over the ray of per-sample values (chunk layout)
 FN_DEV void excl_suffix_sum(const float (&v)[PER], float (&S)[PER], int lane) {
+    // A true scan from the END of the ray: the terms decay with the transmittance, and "total - prefix" would leave every
+    // late sample with the rounding error of the (much larger) early partial sums -- which the division by 1 - alpha of a
+    // nearly opaque sample then amplifies (seen as 1e-8 noise on d alpha of the far background samples, where the true
+    // gradient is 1e-13 ... 1e-21: 2 % of the background density bias' gradient, a sum that cancels 77 : 1).
     float loc = 0.0f;
 #pragma unroll
-    for (int j = 0; j < PER; ++j) loc += v[j];
-    const float inc = wave_incl_sum(loc, lane);
-    const float total = __shfl(inc, 63, 64);
-    float run = total - inc;   // sum of all chunks after this lane
+    for (int j = PER - 1; j >= 0; --j) loc += v[j];
+    float inc = loc;           // -> sum over the chunks of lanes >= lane
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float o = __shfl_down(inc, d, 64);
+        if (lane + d < 64) inc += o;
+    }
+    const float nxt = __shfl_down(inc, 1, 64);
+    float run = lane < 63 ? nxt : 0.0f;   // sum of all chunks after this lane
 #pragma unroll
     for (int j = PER - 1; j >= 0; --j) {
         S[j] = run;

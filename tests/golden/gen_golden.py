@@ -621,7 +621,8 @@ def gen_raygen(dataset, out_dir, name="raygen_dtu"):
 
 
 FIXTURES = ("units", "render_wmask_b16_n16", "render_wmask_b8_n64", "render_womask_b16_n16_o8", "render_wmask_b16_n16_c0",
-            "render_wmask_b256_n32", "render_wmask_b64_n64", "render_wmask_b512_n64", "lvis_util_b24_n32", "raygen_dtu", "lvis_render_room_b24_n32",
+            "render_wmask_b256_n32", "render_wmask_b64_n64", "render_wmask_b512_n64", "render_womask_b64_n64_o32",
+            "lvis_util_b24_n32", "raygen_dtu", "lvis_render_room_b24_n32",
             "lvis_render_ball_b16_n16", "mateillu_render_b24_n32", "dtu_eval_synth")
 
 
@@ -681,6 +682,11 @@ def main():
     if want("render_wmask_b512_n64"):
         gen_render(fields, renderer, args.out, "render_wmask_b512_n64", B=512, n_samples=64, n_importance=64, n_outside=0,
                    cos_anneal_ratio=1.0, ray_seed=38, n_miss=24, inside_rays=6, mask_weight=0.1, seeds=seeds, ray_stride=32)
+    # womask.conf's sample counts (64 + 64 + 32 outside) on 64 rays (per-sample arrays: every 4th ray)
+    if want("render_womask_b64_n64_o32"):
+        gen_render(fields, renderer, args.out, "render_womask_b64_n64_o32", B=64, n_samples=64, n_importance=64, n_outside=32,
+                   cos_anneal_ratio=0.7, ray_seed=39, n_miss=4, inside_rays=2, mask_weight=0.0, seeds=seeds, white_bkgd=False,
+                   ray_stride=4)
     if want("lvis_util_b24_n32"):
         gen_lvis_util(fields, renderer, args.out, "lvis_util_b24_n32", B=24, n_samples=32, n_importance=32, ray_seed=37, seeds=seeds)
     if want("raygen_dtu"):

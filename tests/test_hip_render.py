@@ -85,7 +85,8 @@ def maxerr(a, b):
 
 
 WMASK = ["render_wmask_b16_n16", "render_wmask_b8_n64", "render_wmask_b16_n16_c0"]
-WOMASK = ["render_womask_b16_n16_o8"]       # n_outside = 8, white background, cos_anneal 0.3
+WOMASK = ["render_womask_b16_n16_o8",      # n_outside = 8, white background, cos_anneal 0.3
+          "render_womask_b64_n64_o32"]     # womask.conf's sample counts (64 + 64 + 32), no background colour, cos_anneal 0.7
 # round 2: BASELINE config 1 (256 rays x (32+32), 8 new depths per step) and 64 rays at the reference depth (64+64)
 # ... and BASELINE config 2 at full size (512 rays x (64+64): the shape bench.py measures)
 BIG = ["render_wmask_b256_n32", "render_wmask_b64_n64", "render_wmask_b512_n64"]

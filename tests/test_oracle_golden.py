@@ -96,7 +96,7 @@ RENDER_CASES = ["render_wmask_b16_n16", "render_wmask_b8_n64", "render_womask_b1
 # round 2: BASELINE config 1 (256 rays x (32+32)) and 64 rays at the reference depth (64+64); per-sample arrays of these
 # fixtures cover every `ray_stride`-th ray only, the final depths of all rays are in trace/z_final
 # ... and config 2 at full size (512 x (64+64))
-BIG_CASES = ["render_wmask_b256_n32", "render_wmask_b64_n64", "render_wmask_b512_n64"]
+BIG_CASES = ["render_wmask_b256_n32", "render_wmask_b64_n64", "render_wmask_b512_n64", "render_womask_b64_n64_o32"]
 
 
 def stored(x, g):
