@@ -623,7 +623,8 @@ def gen_raygen(dataset, out_dir, name="raygen_dtu"):
 FIXTURES = ("units", "render_wmask_b16_n16", "render_wmask_b8_n64", "render_womask_b16_n16_o8", "render_wmask_b16_n16_c0",
             "render_wmask_b256_n32", "render_wmask_b64_n64", "render_wmask_b512_n64", "render_womask_b64_n64_o32",
             "lvis_util_b24_n32", "raygen_dtu", "lvis_render_room_b24_n32",
-            "lvis_render_ball_b16_n16", "mateillu_render_b24_n32", "dtu_eval_synth")
+            "lvis_render_ball_b16_n16", "mateillu_render_b24_n32", "dtu_eval_synth", "lvis_render_room_b128_n64",
+            "mateillu_render_b128_n64")
 
 
 def check_against(old_dir, new_dir, names):
@@ -699,10 +700,16 @@ def main():
     if want("lvis_render_ball_b16_n16"):        # the convex ball: secondary rays leave without a hit, visibility in (0.5, 1]
         gen_lvis_render(fields, renderer, args.out, "lvis_render_ball_b16_n16", B=16, n_samples=16, n_importance=16,
                         ray_seed=42, seeds=seeds2, room=False, adam_steps=1)
+    if want("lvis_render_room_b128_n64"):       # the stage's configured depth (64 + 64) on 128 primary rays / ~460 secondary rays
+        gen_lvis_render(fields, renderer, args.out, "lvis_render_room_b128_n64", B=128, n_samples=64, n_importance=64,
+                        ray_seed=44, seeds=seeds2, room=True, bias=0.7, warp=(3, 0.1), outside_rays=12, adam_steps=1)
     # ---- stage 3 (configs 4/5): mateIllu_render + EnvmapMaterialNetwork, loss, gradients, Adam steps -----------------------
     if want("mateillu_render_b24_n32"):
         gen_mateillu_render(fields, renderer, args.out, "mateillu_render_b24_n32", B=24, n_samples=32, n_importance=32,
                             ray_seed=43, seeds=dict(seeds2, mateillu=26))
+    if want("mateillu_render_b128_n64"):
+        gen_mateillu_render(fields, renderer, args.out, "mateillu_render_b128_n64", B=128, n_samples=64, n_importance=64,
+                            ray_seed=45, seeds=dict(seeds2, mateillu=26), adam_steps=1)
     if want("dtu_eval_synth"):
         gen_dtu_eval(args.out)
     if args.check:

@@ -13,7 +13,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-CASES = ["lvis_render_room_b24_n32", "lvis_render_ball_b16_n16"]
+CASES = ["lvis_render_room_b24_n32", "lvis_render_ball_b16_n16", "lvis_render_room_b128_n64"]
 
 
 def T(a):

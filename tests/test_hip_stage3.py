@@ -41,9 +41,10 @@ def rays(g):
     return data, near, far
 
 
-def test_mateillu_render_vs_reference(golden_dir):
+@pytest.mark.parametrize("name", ["mateillu_render_b24_n32", "mateillu_render_b128_n64"])
+def test_mateillu_render_vs_reference(golden_dir, name):
     from fneus.trainer3 import stage3_loss
-    g = dict(np.load(os.path.join(golden_dir, "mateillu_render_b24_n32.npz")))
+    g = dict(np.load(os.path.join(golden_dir, name + ".npz")))
     tr = build(g)
     data, near, far = rays(g)
     out = tr.renderer.mateIllu_render(data[:, :3].contiguous(), data[:, 3:6].contiguous(), near, far,
@@ -72,11 +73,12 @@ def test_mateillu_render_vs_reference(golden_dir):
         assert abs(prm.grad.double().norm().item() - ref_norm) <= 1e-2 * ref_norm + 1e-7, k
 
 
-def test_light_visibility_vs_reference_trace(golden_dir):
+@pytest.mark.parametrize("name", ["mateillu_render_b24_n32", "mateillu_render_b128_n64"])
+def test_light_visibility_vs_reference_trace(golden_dir, name):
     """get_diffuse_visibility (inverRender.py:128-192): 128 lobes x 32 directions x every hit point through Lvis"""
     from models.inverRender import get_diffuse_visibility
     from oracle import ref_torch as R
-    g = dict(np.load(os.path.join(golden_dir, "mateillu_render_b24_n32.npz")))
+    g = dict(np.load(os.path.join(golden_dir, name + ".npz")))
     tr = build(g)
     m = T(g["out/sdf_mask"])
     n = torch.nn.functional.normalize(T(g["out/n_out"])[m], dim=-1).to(DEV)      # forward() normalises the normal first

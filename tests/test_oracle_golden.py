@@ -308,7 +308,8 @@ def stage2_nets(g):
     return sdf_p, col_p, lvis_sd, indi_sd, inv_s
 
 
-STAGE2_CASES = ["lvis_render_room_b24_n32", "lvis_render_ball_b16_n16"]
+# ... and the stage's configured depth (64 + 64) on 128 primary rays
+STAGE2_CASES = ["lvis_render_room_b24_n32", "lvis_render_ball_b16_n16", "lvis_render_room_b128_n64"]
 
 
 @pytest.mark.parametrize("name", STAGE2_CASES)
@@ -394,8 +395,9 @@ def stage3_run(g, nets, step):
     return out, R.stage3_loss(out, data[:, 6:9], (data[:, 9:10] > 0.5).float())
 
 
-def test_stage3_mateillu_render(golden_dir):
-    g = load(golden_dir, "mateillu_render_b24_n32")
+@pytest.mark.parametrize("name", ["mateillu_render_b24_n32", "mateillu_render_b128_n64"])
+def test_stage3_mateillu_render(golden_dir, name):
+    g = load(golden_dir, name)
     nets = stage3_setup(g)
     out, L = stage3_run(g, nets, 0)
     assert np.array_equal(out["sdf_mask"].numpy(), g["out/sdf_mask"])
