@@ -81,24 +81,11 @@ FN_DEV void excl_cumprod(const float (&f)[PER], float (&T)[PER], int lane) {
 // ---------------------------------------------------------------------------------------------------------------
 // PER samples per lane: 4 for the primary rays (m <= 256), 8 for the 512 coarse samples of a stage-2 secondary ray
 // (calLvis.py:55-90 is the same algorithm as renderer.py:152-189 and returns the new depths only)
+// the body of up_sample + sample_pdf for ONE ray held in LDS (zs, ss: m depths and sdf values, visible to the wave; cdf:
+// scratch of m + 1 floats): the k new depths go to z_new (global) and, when given, to z_new_lds
 template <int PER>
-__global__ void __launch_bounds__(64) upsample_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
-                                                      const float* __restrict__ z_in, const float* __restrict__ sdf_in,
-                                                      int m, int k, float inv_s, float* __restrict__ z_new) {
-    constexpr int MAXN = 64 * PER;
-    __shared__ float zs[MAXN], ss[MAXN], cdf[MAXN + 1];
-    const int ray = blockIdx.x, lane = threadIdx.x;
-    float o[3], d[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        o[c] = rays_o[ray * 3 + c];
-        d[c] = rays_d[ray * 3 + c];
-    }
-    for (int i = lane; i < m; i += 64) {
-        zs[i] = z_in[(size_t)ray * m + i];
-        ss[i] = sdf_in[(size_t)ray * m + i];
-    }
-    __syncthreads();
+FN_DEV void upsample_ray(const float (&o)[3], const float (&d)[3], const float* zs, const float* ss, float* cdf, int m, int k,
+                         float inv_s, int lane, float* __restrict__ z_new, float* z_new_lds) {
     const int ns = m - 1;   // sections
     float alpha[PER], fac[PER], T[PER], w[PER];
 #pragma unroll
@@ -164,8 +151,31 @@ __global__ void __launch_bounds__(64) upsample_kernel(const float* __restrict__ 
         float den = ca - cb;
         if (den < 1e-5f) den = 1.0f;
         const float t = (u - cb) / den;
-        z_new[(size_t)ray * k + q] = zs[below] + t * (zs[above] - zs[below]);
+        const float zq = zs[below] + t * (zs[above] - zs[below]);
+        z_new[q] = zq;
+        if (z_new_lds) z_new_lds[q] = zq;
     }
+}
+
+template <int PER>
+__global__ void __launch_bounds__(64) upsample_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                      const float* __restrict__ z_in, const float* __restrict__ sdf_in,
+                                                      int m, int k, float inv_s, float* __restrict__ z_new) {
+    constexpr int MAXN = 64 * PER;
+    __shared__ float zs[MAXN], ss[MAXN], cdf[MAXN + 1];
+    const int ray = blockIdx.x, lane = threadIdx.x;
+    float o[3], d[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        o[c] = rays_o[ray * 3 + c];
+        d[c] = rays_d[ray * 3 + c];
+    }
+    for (int i = lane; i < m; i += 64) {
+        zs[i] = z_in[(size_t)ray * m + i];
+        ss[i] = sdf_in[(size_t)ray * m + i];
+    }
+    __syncthreads();
+    upsample_ray<PER>(o, d, zs, ss, cdf, m, k, inv_s, lane, z_new + (size_t)ray * k, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -188,6 +198,60 @@ __global__ void __launch_bounds__(64) merge_kernel(const float* __restrict__ z_o
         }
         z_out[(size_t)ray * n + rank] = z;
         if (s_out) s_out[(size_t)ray * n + rank] = (i < m) ? s_old[(size_t)ray * m + i] : s_new[(size_t)ray * k + (i - m)];
+    }
+}
+
+// cat_z_vals of one up-sampling step FUSED with the up_sample of the next one (the steps of a ray depend on nothing but the
+// ray: renderer.py:433-446 is a per-ray recurrence with one SDF evaluation in the middle):
+//   (z_old | z_new, s_old | s_new)  -- stable rank merge -->  z_out, s_out [m + k]           (= merge_kernel)
+//   up_sample(z_out, s_out, inv_s)  ----------------------->  z_next [k_next]                 (= upsample_kernel)
+//   last step (z_final != null): z_final [m + k + k_next] = merge(z_out | z_next)             (= merge_kernel without sdf)
+// Same arithmetic as the separate kernels (results are bit-identical, tests/test_hip_rays.py); 4 launches fewer per render.
+__global__ void __launch_bounds__(64) merge_upsample_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                            const float* __restrict__ z_old, const float* __restrict__ s_old, int m,
+                                                            const float* __restrict__ z_new, const float* __restrict__ s_new, int k,
+                                                            float inv_s, int k_next, float* __restrict__ z_out,
+                                                            float* __restrict__ s_out, float* __restrict__ z_next,
+                                                            float* __restrict__ z_final) {
+    __shared__ float zin[MAXN], sin_[MAXN], zs[MAXN], ss[MAXN], cdf[MAXN + 1], znx[MAXN];
+    const int ray = blockIdx.x, lane = threadIdx.x;
+    const int n = m + k;
+    for (int i = lane; i < n; i += 64) {
+        zin[i] = (i < m) ? z_old[(size_t)ray * m + i] : z_new[(size_t)ray * k + (i - m)];
+        sin_[i] = (i < m) ? s_old[(size_t)ray * m + i] : s_new[(size_t)ray * k + (i - m)];
+    }
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) {
+        const float z = zin[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const float zj = zin[j];
+            rank += (zj < z) || (zj == z && j < i);
+        }
+        zs[rank] = z;
+        ss[rank] = sin_[i];
+        z_out[(size_t)ray * n + rank] = z;
+        s_out[(size_t)ray * n + rank] = sin_[i];
+    }
+    __syncthreads();
+    float o[3], d[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        o[c] = rays_o[ray * 3 + c];
+        d[c] = rays_d[ray * 3 + c];
+    }
+    upsample_ray<4>(o, d, zs, ss, cdf, n, k_next, inv_s, lane, z_next + (size_t)ray * k_next, znx);
+    if (z_final == nullptr) return;
+    __syncthreads();
+    const int nf = n + k_next;
+    for (int i = lane; i < nf; i += 64) {
+        const float z = (i < n) ? zs[i] : znx[i - n];
+        int rank = 0;
+        for (int j = 0; j < nf; ++j) {
+            const float zj = (j < n) ? zs[j] : znx[j - n];
+            rank += (zj < z) || (zj == z && j < i);
+        }
+        z_final[(size_t)ray * nf + rank] = z;
     }
 }
 
@@ -794,6 +858,19 @@ extern "C" int fneus_merge(const float* z_old, const float* s_old, int m, const 
     if (n_rays <= 0) return 0;
     FN_CHECK_N(m + k);
     hipLaunchKernelGGL(merge_kernel, dim3(n_rays), dim3(64), 0, stream, z_old, s_old, m, z_new, s_new, k, z_out, s_out);
+    return fneus::launch_status();
+}
+
+extern "C" int fneus_merge_upsample(const float* rays_o, const float* rays_d, const float* z_old, const float* s_old, int m,
+                                    const float* z_new, const float* s_new, int k, int n_rays, float inv_s, int k_next,
+                                    float* z_out, float* s_out, float* z_next, float* z_final, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (n_rays <= 0) return 0;
+    FN_CHECK_N(m + k + (z_final ? k_next : 0));
+    if (k_next < 1 || k_next > MAXN) { set_last_error("fneus_merge_upsample: k_next must be in [1, 256]"); return -2; }
+    hipLaunchKernelGGL(merge_upsample_kernel, dim3(n_rays), dim3(64), 0, stream, rays_o, rays_d, z_old, s_old, m, z_new, s_new, k,
+                       inv_s, k_next, z_out, s_out, z_next, z_final);
     return fneus::launch_status();
 }
 

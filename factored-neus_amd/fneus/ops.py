@@ -791,6 +791,21 @@ def merge(z_old, s_old, z_new, s_new):
     return z_out, s_out
 
 
+def merge_upsample(rays_o, rays_d, z_old, s_old, z_new, s_new, inv_s: float, k_next: int, last: bool):
+    """cat_z_vals of one up-sampling step + up_sample of the next in one launch -> z_out, s_out [B, m + k], z_next [B, k_next],
+    z_final [B, m + k + k_next] (last step only, else None)"""
+    B, m = z_old.shape
+    k = z_new.shape[1]
+    dev = z_old.device
+    z_out = torch.empty(B, m + k, dtype=torch.float32, device=dev)
+    s_out = torch.empty_like(z_out)
+    z_next = torch.empty(B, k_next, dtype=torch.float32, device=dev)
+    z_final = torch.empty(B, m + k + k_next, dtype=torch.float32, device=dev) if last else None
+    _launch("fneus_merge_upsample", lib.fneus_merge_upsample, _ptr(rays_o), _ptr(rays_d), _ptr(z_old), _ptr(s_old), m, _ptr(z_new),
+            _ptr(s_new), k, B, float(inv_s), int(k_next), _ptr(z_out), _ptr(s_out), _ptr(z_next), _ptr(z_final), _stream())
+    return z_out, s_out, z_next, z_final
+
+
 def split_batch(data: torch.Tensor):
     """[B,10] batch -> contiguous rays_o [B,3], rays_d [B,3], rgb [B,3], mask [B,1] in one launch"""
     _chk_f32(data, "data")

@@ -13,7 +13,10 @@ Differences from the reference that a caller can observe:
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
+
 import torch
 import torch.nn.functional as F
 
@@ -60,6 +63,8 @@ class _LazySVal:
             return (1.0 / self.net.inv_s()).expand(self.B, 1)
 
 
+SAMPLER_FUSED = os.environ.get("FNEUS_SAMPLER_FUSED", "1") != "0"
+
 class NeuSRenderer:
     def __init__(self, n_samples, n_importance, n_outside, up_sample_steps, perturb, nerf=None, sdf_network=None,
                  deviation_network=None, color_network=None, refColor_network=None, lvis_network=None,
@@ -94,14 +99,29 @@ class NeuSRenderer:
         return ops.merge(z_vals.contiguous(), sdf.contiguous(), new_z_vals.contiguous(), new_sdf)
 
     def _hierarchical_z(self, rays_o, rays_d, z_vals):
+        """renderer.py:433-446.  Default: the merge of step i and the up_sample of step i + 1 (and the last step's merge) are
+        ONE launch (fneus_merge_upsample; bit-identical to the separate calls, 7 launches instead of 11 per render);
+        FNEUS_SAMPLER_FUSED=0, a single step, or an instance whose up_sample / cat_z_vals were replaced (tests hook them):
+        the reference's call sequence through the two methods."""
         B, n = z_vals.shape
+        steps = self.up_sample_steps
+        k = self.n_importance // steps
+        own = "up_sample" not in self.__dict__ and "cat_z_vals" not in self.__dict__
         with torch.no_grad():
             sdf = self.sdf_network.sdf_samples(RaySamples(rays_o, rays_d, z_vals.reshape(-1).contiguous(), n)).reshape(B, n)
-            k = self.n_importance // self.up_sample_steps
-            for i in range(self.up_sample_steps):
-                new_z = self.up_sample(rays_o, rays_d, z_vals, sdf, k, 64 * 2 ** i)
-                z_vals, sdf = self.cat_z_vals(rays_o, rays_d, z_vals, new_z, sdf, last=(i + 1 == self.up_sample_steps))
-        return z_vals
+            if not (own and steps >= 2 and SAMPLER_FUSED and n + k * steps <= 256):
+                for i in range(steps):
+                    new_z = self.up_sample(rays_o, rays_d, z_vals, sdf, k, 64 * 2 ** i)
+                    z_vals, sdf = self.cat_z_vals(rays_o, rays_d, z_vals, new_z, sdf, last=(i + 1 == steps))
+                return z_vals
+            ro, rd = rays_o.contiguous(), rays_d.contiguous()
+            z_vals, sdf = z_vals.contiguous(), sdf.contiguous()
+            new_z = ops.upsample(ro, rd, z_vals, sdf, k, 64.0)
+            for i in range(1, steps):
+                new_sdf = self.sdf_network.sdf_samples(RaySamples(rays_o, rays_d, new_z.reshape(-1), k)).reshape(B, k)
+                z_vals, sdf, new_z, z_final = ops.merge_upsample(ro, rd, z_vals, sdf, new_z, new_sdf.contiguous(),
+                                                                 float(64 * 2 ** i), k, last=(i + 1 == steps))
+        return z_final
 
     # ---- render_core_outside (renderer.py:112-149): inverted-sphere background NeRF++, womask configs only --------
     def render_core_outside(self, rays_o, rays_d, z_vals, sample_dist, nerf, background_rgb=None, full=True):

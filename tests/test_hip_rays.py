@@ -53,6 +53,55 @@ def test_upsample_random(m, k):
         assert err.max().item() <= 1e-3 and err.median().item() <= 5e-6, (err.max(), err.median())
 
 
+@pytest.mark.parametrize("m,k,last", [(64, 16, False), (80, 16, False), (96, 16, True), (40, 8, True), (33, 7, False)])
+def test_fused_merge_upsample_is_bit_identical_to_the_separate_kernels(m, k, last):
+    """fneus_merge_upsample = fneus_merge -> fneus_upsample (-> fneus_merge without sdf on the last step)"""
+    from fneus import ops, synth
+    B = 97
+    data = T(synth.ray_batch(B, seed=m + k, n_miss=5)).to(DEV)
+    ro, rd = data[:, :3].contiguous(), data[:, 3:6].contiguous()
+    g = torch.Generator().manual_seed(m)
+    z = torch.sort(torch.rand(B, m, generator=g) * 2.0 + 0.5, dim=-1)[0].to(DEV).contiguous()
+    new_z = torch.sort(torch.rand(B, k, generator=g) * 2.0 + 0.5, dim=-1)[0].to(DEV).contiguous()
+    new_z[:, 0] = z[:, 3]                                  # ties keep the old sample first
+    pts = lambda t: ro[:, None, :] + rd[:, None, :] * t[..., None]
+    f = lambda t: (pts(t).norm(dim=-1) - 0.5 + 0.05 * torch.sin(7 * pts(t)[..., 0])).float().contiguous()
+    s, new_s = f(z), f(new_z)
+    inv_s = 128.0
+    z1, s1 = ops.merge(z, s, new_z, new_s)
+    nz = ops.upsample(ro, rd, z1, s1, k, inv_s)
+    zf = ops.merge(z1, None, nz, None)[0] if last else None
+    z2, s2, nz2, zf2 = ops.merge_upsample(ro, rd, z, s, new_z, new_s, inv_s, k, last)
+    assert torch.equal(z1, z2) and torch.equal(s1, s2) and torch.equal(nz, nz2)
+    assert (zf2 is None) == (not last) and (not last or torch.equal(zf, zf2))
+
+
+def test_fused_sampler_in_render_is_bit_identical():
+    """NeuSRenderer._hierarchical_z: 7 launches (fused) against the reference's call sequence of 11"""
+    import models.renderer as MR
+    from fneus import synth
+    from fneus.trainer import Stage1Trainer
+    tr = Stage1Trainer(torch.device(DEV), seed=3, use_graph=False)
+    data = T(synth.ray_batch(300, seed=12, n_miss=20)).to(DEV)
+    ro, rd = data[:, :3].contiguous(), data[:, 3:6].contiguous()
+    z0 = fops().ray_setup(ro, rd, tr.renderer.n_samples)
+    tr.renderer.sdf_network.refresh()
+    old = MR.SAMPLER_FUSED
+    try:
+        MR.SAMPLER_FUSED = True
+        a = tr.renderer._hierarchical_z(ro, rd, z0)
+        MR.SAMPLER_FUSED = False
+        b = tr.renderer._hierarchical_z(ro, rd, z0)
+    finally:
+        MR.SAMPLER_FUSED = old
+    assert a.shape == (300, 128) and torch.equal(a, b)
+
+
+def fops():
+    from fneus import ops
+    return ops
+
+
 def test_sections():
     from fneus import ops
     z = torch.sort(torch.rand(7, 40), dim=-1)[0]
