@@ -8,7 +8,7 @@ from fneus import ops, synth
 dev = torch.device("cuda:0")
 net = ops.PackedNet("sdf", dev).load_state_dict({k: torch.from_numpy(v) for k, v in synth.sdf_state_dict(20).items()}); net.pack()
 for prec in (3, 1):
-    for n in (32768, 65536, 40003):
+    for n in ([int(a) for a in sys.argv[1:]] or (32768, 65536, 40003)):
         x = (torch.rand(n, 3, device=dev) * 2 - 1).contiguous()
         st = ops.SdfStash(n, dev, prec, False)
         ref, _, _ = ops.sdf_fwd_grad(net.blob, n, prec, st, False, pts=x)
