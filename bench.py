@@ -334,6 +334,23 @@ def main():
                                  "ms_per_step": dt_w * 1e3,
                                  "note": "512 rays x (64+64 inside + 32 outside) samples, background NeRF++ on the fused K7 "
                                          "kernels, ramping cos_anneal_ratio, same precision mode and launch mode as the headline number"}
+        # BASELINE configs[4] quotes 2048 rays per batch: the same step on a 2048-ray batch (a new graph for the new shape)
+        try:
+            trw2 = Stage1Trainer(device, model_conf=conf, prec=prec, use_graph=not args.no_graph)
+            wb2 = synthetic_batches(12, 2048, device, rank=rank, seed0=5000)
+            for i, b in enumerate(wb2[:4]):
+                trw2.train_step(b, cos_anneal_ratio=0.01 * i, background_rgb=bg)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i, b in enumerate(wb2[4:]):
+                trw2.train_step(b, cos_anneal_ratio=0.04 + 0.01 * i, background_rgb=bg)
+            torch.cuda.synchronize()
+            dt_w2 = (time.perf_counter() - t0) / 8
+            result["womask_step"]["rays_2048"] = {"value": 2048 * (N_SAMPLES + N_IMPORTANCE + 32) / dt_w2, "unit": "ray-samples/s",
+                                                  "ms_per_step": dt_w2 * 1e3}
+            del trw2
+        except Exception as e:   # an extra must never take the headline number down with it
+            result["womask_step"]["rays_2048"] = {"value": None, "error": repr(e)}
         del trw
 
     if rank == 0 and world == 1 and not args.no_fast_extra:

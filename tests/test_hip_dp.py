@@ -64,6 +64,43 @@ def test_two_half_batches_with_global_normalisers_equal_the_full_batch():
     assert worst <= 2e-3        # fp32 atomics / summation order only (the K2-K3 chains are evaluated per sample)
 
 
+def test_config5_shape_four_shards_of_512_womask_rays_equal_the_2048_ray_batch():
+    """BASELINE config 5's batch (womask.conf: 64 + 64 + 32 outside samples, background NeRF++, no mask loss; 2048 rays) as
+    four ray shards of 512: with the global loss normalisers the shards' losses and gradients -- incl. the background
+    network's -- add up to those of the one 2048-ray batch"""
+    from fneus import ops
+    from fneus.trainer import Stage1Trainer, WMASK_MODEL, synthetic_batches
+    dev = torch.device("cuda:0")
+    conf = copy.deepcopy(WMASK_MODEL)
+    conf["neus_renderer"].update(n_outside=32, perturb=0.0)
+    tr = Stage1Trainer(dev, model_conf=conf, prec=ops.PREC_PARITY, seed=6, use_graph=False, mask_weight=0.0)
+    full = synthetic_batches(1, 2048, dev, seed0=4242)[0]
+    shards = [full[i * 512:(i + 1) * 512].contiguous() for i in range(4)]
+    bg = torch.ones(1, 3, device=dev)
+    tr._step_body(full, 0.5, bg, with_optimizer=False)
+    _clear(tr)
+    ref_losses = {k: float(v.detach()) for k, v in tr._step_body(full, 0.5, bg, with_optimizer=False).items()}
+    ref = _grads(tr)
+    assert len(ref) == len(tr.params)                      # the background network takes part
+    _clear(tr)
+    seen = []
+    tr.reduce_norms = lambda n: (seen.append(n.clone()), n)[1]
+    for h in shards:
+        tr._step_body(h, 0.5, bg, with_optimizer=False)
+    _clear(tr)
+    total = sum(seen[1:], seen[0])
+    assert float(total[3]) == 2048.0
+    tr.reduce_norms = lambda n: total
+    parts = [tr._step_body(h, 0.5, bg, with_optimizer=False) for h in shards]
+    got = _grads(tr)
+    for k in ("loss", "color_loss", "surface_loss", "eikonal_loss"):
+        s = sum(float(p[k].detach()) for p in parts)
+        assert abs(s - ref_losses[k]) <= 4e-6 * max(1.0, abs(ref_losses[k])), (k, s, ref_losses[k])
+    worst = max((g - r).abs().max().item() / (r.abs().max().item() + 1e-12) for g, r in zip(got, ref))
+    print(f"  config-5 shape, four shards vs the 2048-ray batch: worst relative gradient difference {worst:.2e}")
+    assert worst <= 2e-3
+
+
 def _two_ranks(graph: bool, fail_rank: int = -1):
     import os
     import subprocess
