@@ -66,9 +66,10 @@ class Stage1Trainer:
         self.refColor_network.set_precision(prec)
         self.nerf_outside.set_precision(prec)
         self.params = [p for m in self.modules for p in m.parameters()]
-        # data parallel: two collectives sit inside the step (the 4-float all-reduce of the loss normalisers before the
-        # loss, the gradient arena after the backward), so the step is captured as THREE hipGraphs with the collectives
-        # launched eagerly between their replays (_capture_dp).  FNEUS_DP_GRAPH=0 keeps such runs on eager launches.
+        # data parallel: the collectives sit inside the step (the 4-float all-reduce of the loss normalisers before the
+        # loss; the gradient arena in two parts, the early one beside the SDF backward, the late one after it), so the step
+        # is captured as FOUR hipGraphs (three with FNEUS_DP_EARLY=0: one arena exchange) with the collectives launched
+        # eagerly between their replays (_capture_dp).  FNEUS_DP_GRAPH=0 keeps such runs on eager launches.
         import os
         self.distributed = bool(distributed)
         self.use_graph = bool(use_graph) and device.type == "cuda" and (
@@ -182,11 +183,12 @@ class Stage1Trainer:
         st["open"] = st["g2b"]
 
     def _capture_dp(self, data: torch.Tensor, background_rgb):
-        """data parallel: three graphs per step with the two collectives between them.  Returns None when the capture
-        fails ON ANY RANK (every rank then stays on eager launches).  The outcome is collective: whatever happens, every
-        rank issues exactly the same three collectives here -- the 4-float normaliser exchange, the arena all-reduce (both
-        on meaningless values: nothing recorded has run) and a MIN all-reduce of its success flag -- so a rank whose
-        capture throws cannot pair its first real collectives with its peers' dummy ones."""
+        """data parallel: four graphs per step with the three collectives between them (three and two with
+        FNEUS_DP_EARLY=0).  Returns None when the capture fails ON ANY RANK (every rank then stays on eager launches).  The
+        outcome is collective: whatever happens, every rank issues exactly the same collectives here -- the 4-float
+        normaliser exchange, the arena all-reduce(s) (all on meaningless values: nothing recorded has run) and a MIN
+        all-reduce of its success flag -- so a rank whose capture throws cannot pair its first real collectives with its
+        peers' dummy ones."""
         import gc
         static_data = data.clone()
         static_bg = None if background_rgb is None else background_rgb.clone()
