@@ -76,18 +76,24 @@ class Stage2Trainer:
     # user can observe: a batch without any hit is not skipped (its loss and gradients are zero; Adam's moments still
     # decay), the direction draws consume the generator per ray instead of per hit point.
     #
-    # distributed (one process per GPU, rays sharded by rank): the fixed-shape step launched eagerly
-    # with two exchanges -- the loss normalisers (hit count; stage 3: mask sum and the latent-sparsity statistics) summed over
+    # distributed (one process per GPU, rays sharded by rank): the fixed-shape step (eagerly, or as a
+    # chain of hipGraphs cut at the collectives) with two exchanges -- the loss normalisers (hit count; stage 3: mask sum and the latent-sparsity statistics) summed over
     # the ranks BEFORE the loss, so that R ranks x B rays equal one R*B-ray batch, and ONE in-place all-reduce of the flat
     # gradient buffer all trained parameters' .grad are views of.  Every rank runs both every step (no data-dependent skip).
     def _init_step_mode(self, use_graph: bool, lr: float, distributed: bool = False):
+        import os
+        from fneus.seggraph import SegmentedStep
         self.distributed = bool(distributed)
         self.reduce = None
         self.grads = None
+        self._seg = None
         if self.distributed:
-            from fneus.parallel import GradArena, reduce_loss_norms
-            use_graph = False
-            self.reduce = reduce_loss_norms                       # in-place all-reduce(SUM); identity for one rank
+            from fneus.parallel import GradArena
+            # graphs + collectives: the step is recorded as a chain of hipGraphs cut at its collectives (fneus/seggraph.py);
+            # FNEUS_DP_GRAPH=0 keeps data-parallel runs on eager launches
+            use_graph = use_graph and os.environ.get("FNEUS_DP_GRAPH", "1") != "0"
+            self._seg = SegmentedStep(self.device)
+            self.reduce = self._reduce                            # in-place all-reduce(SUM); identity for one rank
             holder = torch.nn.Module()
             holder.ps = torch.nn.ParameterList(self.params)
             self.grads = GradArena(self.device, [], None, [holder])
@@ -97,6 +103,12 @@ class Stage2Trainer:
         else:
             self.optimizer = torch.optim.Adam(self.params, lr=lr)
         self._graph, self._eager_steps, self.graph_warmup_steps = None, 0, 2
+
+    def _reduce(self, t: torch.Tensor) -> torch.Tensor:
+        """loss normalisers summed over the ranks, in place; while a step is being recorded this is a cut of the graph chain"""
+        from fneus.parallel import reduce_loss_norms
+        self._seg.cut(lambda: reduce_loss_norms(t), t)
+        return t
 
     def optimizer_state_dict(self):
         """torch.optim.Adam's format with host scalars (what the reference's checkpoints hold): the graph mode keeps `lr` and
@@ -128,16 +140,30 @@ class Stage2Trainer:
         return float(self.optimizer.param_groups[0]["lr"])
 
     def _graph_step(self, data: torch.Tensor):
-        """fixed-shape step: eagerly while warming up, then captured once per batch shape and replayed"""
+        """fixed-shape step: eagerly while warming up, then captured once per batch shape and replayed.  Data parallel: the
+        recording is a chain of graphs with the collectives between them (fneus/seggraph.py); if it fails on any rank,
+        every rank stays on eager launches."""
         if self._graph is not None and self._graph[1].shape != data.shape:
             self._graph = None
         if self._graph is None:
             if self._eager_steps < self.graph_warmup_steps:
                 self._eager_steps += 1
                 self.iter_step += 1
+                if self._seg is not None:
+                    return self._seg.count_eagerly(lambda: self._fixed_shape_step(data))
                 return self._fixed_shape_step(data)
-            import gc
             static = data.clone()
+            if self._seg is not None:
+                from fneus.parallel import collectives_active
+                if not self._seg.record(lambda: self._fixed_shape_step(static), list(self._seg.shapes), collectives_active()):
+                    self.use_graph = False
+                    self.iter_step += 1
+                    return self._fixed_shape_step(data)
+                self._graph = (self._seg, static, self._seg.result)
+                self._seg.replay()       # the recording pass only records: run the step for this batch now
+                self.iter_step += 1
+                return self._seg.result
+            import gc
             gc.collect()
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
@@ -158,7 +184,7 @@ class Stage2Trainer:
             self.grads.restore_small_grads()
             self.grads.flat.zero_()
             loss.backward()
-            self.grads.allreduce_sum()
+            self._seg.cut(self.grads.allreduce_sum, self.grads.flat)
         else:
             self.optimizer.zero_grad(set_to_none=True)
             loss.backward()

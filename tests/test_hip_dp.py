@@ -101,15 +101,15 @@ def test_config5_shape_four_shards_of_512_womask_rays_equal_the_2048_ray_batch()
     assert worst <= 2e-3
 
 
-def _two_ranks(graph: bool, fail_rank: int = -1):
+def _two_ranks(graph: bool, fail_rank: int = -1, stage: int = 1):
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    port = 29600 + (os.getpid() + 151 * int(graph)) % 300
+    port = 29600 + (os.getpid() + 151 * int(graph) + 53 * stage + 17 * (fail_rank + 1)) % 300
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "tools", "dp_check.py")]
-    env = dict(os.environ, DP_CHECK_GRAPH="1" if graph else "0", DP_CHECK_FAIL_RANK=str(fail_rank))
+    env = dict(os.environ, DP_CHECK_GRAPH="1" if graph else "0", DP_CHECK_FAIL_RANK=str(fail_rank), DP_CHECK_STAGE=str(stage))
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
     line = [l for l in r.stdout.splitlines() if l.startswith("DP_CHECK")]
     assert r.returncode == 0 and line and line[0].endswith("OK"), (r.stdout[-2000:], r.stderr[-2000:])
@@ -260,7 +260,8 @@ def test_stage3_two_half_batches_with_global_statistics_equal_the_full_batch():
     assert bool(torch.isfinite(o["loss"])) and trd.iter_step == 1
 
 
-def test_one_rank_over_rccl_runs_the_data_parallel_call_sequence():
+@pytest.mark.parametrize("stage", [1, 2, 3])
+def test_one_rank_over_rccl_runs_the_data_parallel_call_sequence(stage):
     """RCCL refuses two ranks on one device, so the test box cannot hold a real N > 1 job; FNEUS_DP_SINGLE=1 makes a world of
     ONE rank issue every collective of the data-parallel step anyway: communicator set-up, the parameter broadcast, the
     loss-normaliser all-reduce, the async all-reduce of the early arena part on the side stream while the SDF backward
@@ -272,8 +273,9 @@ def test_one_rank_over_rccl_runs_the_data_parallel_call_sequence():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     traces = []
     for graph in (False, True):
-        port = 29900 + (os.getpid() + 37 * int(graph)) % 90
+        port = 29900 + (os.getpid() + 37 * int(graph) + 11 * stage) % 90
         env = dict(os.environ, DP_CHECK_GRAPH="1" if graph else "0", DP_CHECK_BACKEND="nccl", FNEUS_DP_SINGLE="1",
+                   DP_CHECK_STAGE=str(stage),
                    RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "dp_check.py")], capture_output=True, text=True,
@@ -282,5 +284,18 @@ def test_one_rank_over_rccl_runs_the_data_parallel_call_sequence():
         assert r.returncode == 0 and line and line[0].endswith("OK"), (r.stdout[-2000:], r.stderr[-2000:])
         print(" ", line[0])
         traces.append([float(v) for v in [l for l in r.stdout.splitlines() if l.startswith("DP_TRACE")][0].split()[1:]])
-    for i, (a, b) in enumerate(zip(*traces)):
-        assert abs(a - b) <= (1e-3 if i < 3 else 3e-2) * max(abs(a), 1e-2), (i, a, b)
+    if stage == 1:       # (stages 2 / 3 draw their directions differently in eager and recorded steps)
+        for i, (a, b) in enumerate(zip(*traces)):
+            assert abs(a - b) <= (1e-3 if i < 3 else 3e-2) * max(abs(a), 1e-2), (i, a, b)
+
+
+@pytest.mark.parametrize("stage", [2, 3])
+def test_stages_2_and_3_two_ranks_with_graph_chains_stay_identical(stage):
+    """the stage-2 / stage-3 data-parallel step as a chain of hipGraphs cut at its collectives (fneus/seggraph.py: the loss
+    normalisers -- stage 3 also the latent-sparsity statistics -- and the gradient buffer), two processes sharing the GPU over
+    gloo: the replicas stay bit-identical, 3 / 4 graphs are recorded; then with a recording failure injected on rank 1: every
+    rank falls back to eager launches together and the run finishes with identical replicas"""
+    trace = _two_ranks(graph=True, stage=stage)
+    assert len(trace) == 7 and all(np.isfinite(trace))
+    _two_ranks(graph=True, fail_rank=1, stage=stage)
+    _two_ranks(graph=False, stage=stage)

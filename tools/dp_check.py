@@ -19,6 +19,48 @@ rank, world, _ = init_from_env(os.environ.get("DP_CHECK_BACKEND", "gloo"))
 dev = torch.device("cuda:0")
 torch.cuda.set_device(0)
 use_graph = os.environ.get("DP_CHECK_GRAPH", "0") == "1"      # four hipGraphs per step around the three collectives
+stage = int(os.environ.get("DP_CHECK_STAGE", "1"))
+if stage in (2, 3):
+    # stages 2 / 3 (fneus/trainer2.py, trainer3.py): the fixed-shape step, eagerly or as a chain of graphs cut at the
+    # collectives (fneus/seggraph.py); DP_CHECK_FAIL_RANK: that rank's recording throws in the optimiser step (after every exchange)
+    from fneus.trainer2 import Stage2Trainer
+    from fneus.trainer3 import Stage3Trainer
+    tr = (Stage2Trainer if stage == 2 else Stage3Trainer)(dev, seed=rank, distributed=True, use_graph=use_graph)
+    mods = [tr.lvis_network, tr.indiLgt_network] if stage == 2 else [tr.mateIllu_network]
+    broadcast_parameters(mods)
+    fail_rank = int(os.environ.get("DP_CHECK_FAIL_RANK", "-1"))
+    if use_graph and rank == fail_rank:
+        real = tr.optimizer.step
+
+        def failing(*a, **k):
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("injected capture failure")
+            return real(*a, **k)
+
+        tr.optimizer.step = failing
+    torch.manual_seed(100 + rank)
+    trace = []
+    for b in synthetic_batches(7, 128, dev, rank=rank):
+        out = tr.train_step(b)
+        v = out["loss"].detach().clone().reshape(1)
+        dist.all_reduce(v)
+        trace.append(float(v))
+    flat = torch.cat([p.detach().reshape(-1) for p in tr.params])
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    worst = max((g - gathered[0]).abs().max().item() for g in gathered)
+    n_graphs = len(tr._seg.graphs)
+    want = 0 if (not use_graph or fail_rank >= 0) else (3 if stage == 2 else 4)
+    flags = [None] * world
+    dist.all_gather_object(flags, bool(n_graphs == want and (tr.use_graph == (want > 0))))
+    ok = worst == 0.0 and all(map(lambda x: x == x and abs(x) < 1e6, trace)) and all(flags)
+    if rank == 0:
+        print("DP_TRACE " + " ".join(f"{v:.6f}" for v in trace))
+        print(f"DP_CHECK stage={stage} world={world} graphs={n_graphs} max replica difference {worst:.3e} global loss {trace[-1]:.6f} "
+              f"{'OK' if ok else 'FAILED'}")
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
 import copy
 conf = copy.deepcopy(WMASK_MODEL)
 conf["neus_renderer"]["perturb"] = 0.0                         # no depth jitter: eager and replayed runs draw it differently
