@@ -154,8 +154,9 @@ def main():
                                                              "fixed-shape step as a hipGraph")
     args = ap.parse_args()
     from fneus.parallel import init_from_env
-    rank, world, local = init_from_env("nccl")       # torchrun --nproc-per-node N: rays sharded by rank over RCCL
-    gpu = local if world > 1 else args.gpu
+    # torchrun --nproc-per-node N: rays sharded by rank over RCCL (FNEUS_DIST_BACKEND=gloo: several ranks on ONE GPU, tests)
+    rank, world, local = init_from_env(os.environ.get("FNEUS_DIST_BACKEND", "nccl"))
+    gpu = local % max(torch.cuda.device_count(), 1) if world > 1 else args.gpu
     torch.cuda.set_device(gpu)
     if world > 1:
         torch.manual_seed(1234 + rank)               # every rank draws its own pixels and directions

@@ -156,3 +156,33 @@ def test_runner_on_a_shiny_blender_format_case(tmp_path):
     r.save_freq = r.report_freq = r.val_freq = r.val_mesh_freq = 10 ** 9
     r.train(max_steps=5)
     assert r.iter_step == 5 and all(bool(torch.isfinite(p).all()) for p in r.trainer.params)
+
+
+def test_stage2_and_stage3_runners_under_torchrun_with_two_ranks(tmp_path):
+    """`torchrun --nproc-per-node 2 lvis.py / mateIllu.py`: rays sharded by rank, the step replayed as a chain of graphs cut at
+    the collectives, rank 0 writes the checkpoints (two ranks share the test box's GPU, so gloo instead of RCCL)"""
+    import re
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "factored-neus_amd"))
+    import exp_runner
+    conf = _conf(str(tmp_path))
+    src = open(conf).read()
+    src = re.sub(r"save_freq = \d+", "save_freq = 4", src)
+    src = src.replace("lvis { batch_size = 512", "lvis { batch_size = 128").replace("metaIllu { batch_size = 512", "metaIllu { batch_size = 128")
+    open(conf, "w").write(src)
+    r1 = exp_runner.Runner(conf, mode="train", case="synth", type="synthetic", device=torch.device("cuda:0"))
+    r1.batch_size = 128
+    r1.train(max_steps=4)
+    assert os.path.exists(os.path.join(r1.base_exp_dir, "checkpoints", "ckpt_000004.pth"))
+    env = dict(os.environ, FNEUS_DIST_BACKEND="gloo")
+    for i, (script, sub) in enumerate((("lvis.py", "lvis"), ("mateIllu.py", "mateIllu"))):
+        port = 29400 + (os.getpid() + 61 * i) % 150
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "factored-neus_amd", script), "--conf", conf, "--case", "synth",
+               "--type", "synthetic", "--max_steps", "8"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=env, cwd=str(tmp_path))
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        ck_dir = os.path.join(str(tmp_path), "exp", "synth", "wmask", sub, "checkpoints")
+        assert sorted(os.listdir(ck_dir)) == ["ckpt_000004.pth", "ckpt_000008.pth"], os.listdir(ck_dir)
+        ck = torch.load(os.path.join(ck_dir, "ckpt_000008.pth"), map_location="cpu")
+        assert int(ck["iter_step"]) == 8
