@@ -187,14 +187,17 @@ def main():
     ap.add_argument("--max_steps", type=int, default=None)
     ap.add_argument("--no_graph", action="store_true", help="launch every kernel of the step eagerly (no hipGraph replay)")
     args = ap.parse_args()
-    rank, world, local = init_from_env("nccl")
-    gpu = local if world > 1 else args.gpu
+    # torchrun --nproc-per-node N: rays sharded by rank over RCCL (FNEUS_DIST_BACKEND=gloo: several ranks on ONE GPU, tests)
+    rank, world, local = init_from_env(os.environ.get("FNEUS_DIST_BACKEND", "nccl"))
+    gpu = local % max(torch.cuda.device_count(), 1) if world > 1 else args.gpu
     torch.cuda.set_device(gpu)
     runner = Runner(args.conf, args.mode, args.case, args.is_continue, args.type, args.surface_weight,
                     device=torch.device("cuda", gpu), prec=ops.PREC_PARITY if args.prec == "parity" else ops.PREC_FAST,
                     distributed=world > 1, use_graph=not args.no_graph)
     if args.mode == "train":
-        runner.train(max_steps=args.max_steps, rank=rank)
+        if world > 1:
+            torch.manual_seed(1234 + rank)           # every rank draws its own images, pixels and depth jitter (the networks
+        runner.train(max_steps=args.max_steps, rank=rank)      # were built and broadcast before: same weights everywhere)
     elif args.mode == "validate_mesh":
         print(runner.validate_mesh(world_space=True, resolution=512, threshold=args.mcube_threshold))   # exp_runner.py:668
     elif args.mode == "validate_image":

@@ -186,3 +186,24 @@ def test_stage2_and_stage3_runners_under_torchrun_with_two_ranks(tmp_path):
         assert sorted(os.listdir(ck_dir)) == ["ckpt_000004.pth", "ckpt_000008.pth"], os.listdir(ck_dir)
         ck = torch.load(os.path.join(ck_dir, "ckpt_000008.pth"), map_location="cpu")
         assert int(ck["iter_step"]) == 8
+
+
+def test_stage1_runner_under_torchrun_with_two_ranks(tmp_path):
+    """`torchrun --nproc-per-node 2 exp_runner.py`: every rank draws its own rays (seeded by rank), the gradients are summed,
+    rank 0 writes the checkpoint (gloo: the two ranks share the test box's GPU)"""
+    import re
+    import subprocess
+    conf = _conf(str(tmp_path))
+    src = re.sub(r"save_freq = \d+", "save_freq = 6", open(conf).read()).replace("batch_size = 512\n", "batch_size = 128\n", 1)
+    open(conf, "w").write(src)
+    port = 29250 + os.getpid() % 140
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "factored-neus_amd", "exp_runner.py"), "--conf", conf, "--case", "synth",
+           "--type", "synthetic", "--max_steps", "6"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=dict(os.environ, FNEUS_DIST_BACKEND="gloo"),
+                       cwd=str(tmp_path))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    ck_dir = os.path.join(str(tmp_path), "exp", "synth", "wmask", "geometry", "checkpoints")
+    assert os.listdir(ck_dir) == ["ckpt_000006.pth"]
+    ck = torch.load(os.path.join(ck_dir, "ckpt_000006.pth"), map_location="cpu")
+    assert int(ck["iter_step"]) == 6 and all(torch.isfinite(v).all() for v in ck["sdf_network_fine"].values())
