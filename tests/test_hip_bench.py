@@ -38,3 +38,20 @@ def test_bench_prints_one_json_line_with_rccl_in_the_process():
     d = _run({"FNEUS_DP_SINGLE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"},
              "--no-profile")
     assert "four hipGraph replays" in d["config"]["launch"] and d["value"] > 0
+
+
+def test_bench_under_torchrun_with_two_ranks_prints_one_json_line():
+    """the driver's N > 1 launch (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`), here with two
+    ranks sharing the box's one GPU over gloo: ONE JSON line on the launcher's stdout, whole-job throughput, max-over-ranks time"""
+    port = 29100 + os.getpid() % 100
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "3"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, FNEUS_DIST_BACKEND="gloo"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "dp2" in d["config"]["parallelism"]
+    assert abs(d["value"] - 2 * 512 * 128 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert "four hipGraph replays" in d["config"]["launch"]
+    assert sum("[bench rank" in l for l in r.stderr.splitlines()) == 2          # one line per rank on stderr
