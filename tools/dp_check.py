@@ -64,7 +64,11 @@ if stage in (2, 3):
 import copy
 conf = copy.deepcopy(WMASK_MODEL)
 conf["neus_renderer"]["perturb"] = 0.0                         # no depth jitter: eager and replayed runs draw it differently
-tr = Stage1Trainer(dev, model_conf=conf, seed=rank, distributed=True, use_graph=use_graph)   # different initial weights per rank on purpose ...
+womask = os.environ.get("DP_CHECK_CONF", "wmask") == "womask"  # + 32 outside samples: the background NeRF's gradients join the arena
+if womask:
+    conf["neus_renderer"]["n_outside"] = 32
+tr = Stage1Trainer(dev, model_conf=conf, seed=rank, distributed=True, use_graph=use_graph,
+                   mask_weight=0.0 if womask else 0.1)          # different initial weights per rank on purpose ...
 broadcast_parameters(tr.modules)                               # ... rank 0's must win
 # DP_CHECK_FAIL_RANK=r: the graph capture of rank r throws half way (after the first exchange): every rank must fall back to
 # eager launches together and the replicas must stay identical
