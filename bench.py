@@ -54,6 +54,8 @@ PEAK_HBM_GBS = 8000.0                # HBM3E (MI355X_MICROARCH.md)
 KERNEL_BYTES_PARITY = {
     "fneus_sdf_fwd_grad": (3 * 8 * 512 + 512 + 128 + 1024 + 16 + 8 * 512 + 12) * SAMPLES_PER_STEP,
     "fneus_sdf_bwd": (2 * 8 * 512 + 8 * 512 + 8 * 512 + 1024 + 16 + 8 * 512 + 8 * 512 + 9 * 512 + 128) * SAMPLES_PER_STEP,
+    # four bf16 planes per layer (h, a, zbar, adj) + PE plane, read once
+    "fneus_dw_gemm_pp:sdf": (4 * 8 * 512 + 512 + 128) * SAMPLES_PER_STEP,
 }
 
 
@@ -282,6 +284,29 @@ def main():
                                       "frac": gbs / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": traffic_src,
                                       "note": "algorithmic stash bytes per launch (DESIGN.md 4.1) / launch duration; "
                                               "streaming torch kernels reach 4.0 (read) - 6.8 (write) TB/s on this part"}
+        # both roofs for the three kernels that carry the step (an extra: `roofline` above stays the contract's object)
+        both = {}
+        for k in ("fneus_sdf_fwd_grad", "fneus_sdf_bwd", "fneus_dw_gemm_pp:sdf"):
+            if k not in per or k not in KERNEL_FLOPS:
+                continue
+            n_l = max(round(per[k]["launches_per_step"]), 1)
+            sec = per[k]["avg_ms"] * 1e-3
+            e = {"avg_launch_ms": round(per[k]["avg_ms"], 4),
+                 "mfma_frac": KERNEL_FLOPS[k] / n_l / sec / 1e12 / PEAK_BF16_MFMA_TFLOPS}
+            if prec == ops.PREC_PARITY and k in KERNEL_BYTES_PARITY:
+                e["hbm_frac_algorithmic_bytes"] = KERNEL_BYTES_PARITY[k] / n_l / sec / 1e9 / PEAK_HBM_GBS
+            if prec == ops.PREC_PARITY and ":" not in k:
+                for tag in TRAFFIC_FILES:
+                    try:
+                        tj = json.load(open(os.path.join(ROOT, "profiles", tag)))
+                        e["hbm_frac_pmc_bytes"] = tj["kernels"][k]["hbm_bytes_per_launch"] / sec / 1e9 / PEAK_HBM_GBS
+                        e["pmc_file"] = "profiles/" + tag
+                        break
+                    except Exception:
+                        continue
+            both[k] = e
+        if both:
+            result["rooflines_by_kernel"] = both
         result["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS,
                               "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_MFMA_TFLOPS, "traffic": traffic,
                               "traffic_source": traffic_src,
