@@ -18,7 +18,6 @@ import os
 import numpy as np
 
 import torch
-import torch.nn.functional as F
 
 from fneus import ops
 from models.mesh import extract_fields, extract_geometry      # noqa: F401  module-level API of renderer.py:14-40

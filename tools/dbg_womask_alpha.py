@@ -3,7 +3,7 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "factored-neus_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import numpy as np, torch
+import torch  # noqa: F401
 import test_hip_render as H
 import test_oracle_golden as O
 from oracle import ref_torch as R
