@@ -340,93 +340,96 @@ def main():
     if rank == 0 and world == 1 and not args.no_fast_extra:
         # the womask configuration (cfg 5 shape): + 32 background samples per ray through the
         # NeRF++ kernels (K7); cos_anneal_ratio ramps there (a device scalar of the replayed step)
-        import copy
-        from fneus.trainer import WMASK_MODEL
-        conf = copy.deepcopy(WMASK_MODEL)
-        conf["neus_renderer"]["n_outside"] = 32
-        trw = Stage1Trainer(device, model_conf=conf, prec=prec, use_graph=not args.no_graph)
-        wb = synthetic_batches(14, RAYS, device, rank=rank)
-        bg = torch.ones(1, 3, device=device)
-        for i, b in enumerate(wb[:4]):
-            trw.train_step(b, cos_anneal_ratio=0.01 * i, background_rgb=bg)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i, b in enumerate(wb[4:]):
-            trw.train_step(b, cos_anneal_ratio=0.04 + 0.01 * i, background_rgb=bg)
-        torch.cuda.synchronize()
-        dt_w = (time.perf_counter() - t0) / 10
-        result["womask_step"] = {"value": RAYS * (N_SAMPLES + N_IMPORTANCE + 32) / dt_w, "unit": "ray-samples/s",
-                                 "ms_per_step": dt_w * 1e3,
-                                 "note": "512 rays x (64+64 inside + 32 outside) samples, background NeRF++ on the fused K7 "
-                                         "kernels, ramping cos_anneal_ratio, same precision mode and launch mode as the headline number"}
-        # BASELINE configs[4] quotes 2048 rays per batch: the same step on a 2048-ray batch (a new graph for the new shape)
         try:
-            trw2 = Stage1Trainer(device, model_conf=conf, prec=prec, use_graph=not args.no_graph)
-            wb2 = synthetic_batches(12, 2048, device, rank=rank, seed0=5000)
-            for i, b in enumerate(wb2[:4]):
-                trw2.train_step(b, cos_anneal_ratio=0.01 * i, background_rgb=bg)
+            import copy
+            from fneus.trainer import WMASK_MODEL
+            conf = copy.deepcopy(WMASK_MODEL)
+            conf["neus_renderer"]["n_outside"] = 32
+            trw = Stage1Trainer(device, model_conf=conf, prec=prec, use_graph=not args.no_graph)
+            wb = synthetic_batches(14, RAYS, device, rank=rank)
+            bg = torch.ones(1, 3, device=device)
+            for i, b in enumerate(wb[:4]):
+                trw.train_step(b, cos_anneal_ratio=0.01 * i, background_rgb=bg)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for i, b in enumerate(wb2[4:]):
-                trw2.train_step(b, cos_anneal_ratio=0.04 + 0.01 * i, background_rgb=bg)
+            for i, b in enumerate(wb[4:]):
+                trw.train_step(b, cos_anneal_ratio=0.04 + 0.01 * i, background_rgb=bg)
             torch.cuda.synchronize()
-            dt_w2 = (time.perf_counter() - t0) / 8
-            result["womask_step"]["rays_2048"] = {"value": 2048 * (N_SAMPLES + N_IMPORTANCE + 32) / dt_w2, "unit": "ray-samples/s",
-                                                  "ms_per_step": dt_w2 * 1e3}
-            del trw2
+            dt_w = (time.perf_counter() - t0) / 10
+            result["womask_step"] = {"value": RAYS * (N_SAMPLES + N_IMPORTANCE + 32) / dt_w, "unit": "ray-samples/s",
+                                     "ms_per_step": dt_w * 1e3,
+                                     "note": "512 rays x (64+64 inside + 32 outside) samples, background NeRF++ on the fused K7 "
+                                             "kernels, ramping cos_anneal_ratio, same precision mode and launch mode as the headline number"}
+            # BASELINE configs[4] quotes 2048 rays per batch: the same step on a 2048-ray batch (a new graph for the new shape)
+            try:
+                trw2 = Stage1Trainer(device, model_conf=conf, prec=prec, use_graph=not args.no_graph)
+                wb2 = synthetic_batches(12, 2048, device, rank=rank, seed0=5000)
+                for i, b in enumerate(wb2[:4]):
+                    trw2.train_step(b, cos_anneal_ratio=0.01 * i, background_rgb=bg)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i, b in enumerate(wb2[4:]):
+                    trw2.train_step(b, cos_anneal_ratio=0.04 + 0.01 * i, background_rgb=bg)
+                torch.cuda.synchronize()
+                dt_w2 = (time.perf_counter() - t0) / 8
+                result["womask_step"]["rays_2048"] = {"value": 2048 * (N_SAMPLES + N_IMPORTANCE + 32) / dt_w2, "unit": "ray-samples/s",
+                                                      "ms_per_step": dt_w2 * 1e3}
+                del trw2
+            except Exception as e:   # an extra must never take the headline number down with it
+                result["womask_step"]["rays_2048"] = {"value": None, "error": repr(e)}
+            del trw
         except Exception as e:   # an extra must never take the headline number down with it
-            result["womask_step"]["rays_2048"] = {"value": None, "error": repr(e)}
-        del trw
+            result["womask_step"] = {"value": None, "error": repr(e)}
 
     if rank == 0 and world == 1 and not args.no_fast_extra:
         # stage 2 (BASELINE configs[2], lvis.py:132-196): 512 primary rays x (64+64), 4 secondary rays per hit point x 512
         # coarse SDF samples on K1, Lvis + IndirectLight trained with Adam.  Fixed-shape step (every ray treated as a hit point,
         # masked afterwards) replayed as one hipGraph, like the headline step.
-        from fneus.trainer2 import Stage2Trainer
-        tr2 = Stage2Trainer(device, prec=prec, use_graph=not args.no_graph)
-        sb = synthetic_batches(14, RAYS, device, rank=rank)
-        hits = []
-        for b in sb[:4]:
-            tr2.train_step(b)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for b in sb[4:]:
-            o2 = tr2.train_step(b)
-            if o2 is not None:
-                hits.append(o2["n_hit"])
-        torch.cuda.synchronize()
-        dt_2 = (time.perf_counter() - t0) / 10
-        n_hit = float(torch.stack(hits).float().mean()) if hits else 0.0
-        result["stage2_step"] = {"value": 4 * n_hit * 512 / dt_2, "unit": "secondary-ray SDF samples/s", "ms_per_step": dt_2 * 1e3,
-                                 "primary_rays": RAYS, "mean_hit_points": n_hit, "secondary_rays": 4 * n_hit,
-                                 "launch": "one hipGraph replay per step (fixed shape: 4 x 512 secondary rays marched, misses masked)"
-                                           if tr2.use_graph else "eager launches, hit points compacted",
-                                 "note": "lvis_render + L1 losses + backward + Adam (lvis.py:132-196): 4 secondary rays per hit "
-                                         "point x 512 coarse samples through K1, 32 fine samples through K2, same precision mode"}
-        del tr2
         # stage 3 (BASELINE configs[3], mateIllu.py:135-203): 512 primary rays, 128 light SGs x 32 directions = 4096 Lvis
         # evaluations per hit point, closed-form SG rendering, Adam over the EnvmapMaterialNetwork
-        from fneus.trainer3 import Stage3Trainer
-        tr3 = Stage3Trainer(device, prec=prec, use_graph=not args.no_graph)
-        hits = []
-        for b in sb[:4]:
-            tr3.train_step(b)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for b in sb[4:]:
-            o3 = tr3.train_step(b)
-            if o3 is not None:
-                hits.append(o3["n_hit"])
-        torch.cuda.synchronize()
-        dt_3 = (time.perf_counter() - t0) / 10
-        n_hit3 = float(torch.stack(hits).float().mean()) if hits else 0.0
-        result["stage3_step"] = {"value": 4096 * n_hit3 / dt_3, "unit": "Lvis visibility evaluations/s", "ms_per_step": dt_3 * 1e3,
-                                 "primary_rays": RAYS, "mean_hit_points": n_hit3,
-                                 "launch": "one hipGraph replay per step (fixed shape: all 512 rays evaluated, misses masked)"
-                                           if tr3.use_graph else "eager launches, hit points compacted",
-                                 "note": "mateIllu_render + masked L1 + latent sparsity + backward + Adam (mateIllu.py:135-203): "
-                                         "128 light lobes x 32 directions through Lvis per hit point, SG rendering of 128 + 24 lobes"}
-        del tr3
+        sb = synthetic_batches(14, RAYS, device, rank=rank)
+
+        def timed_stage(make_trainer):
+            """10 timed steps after 4 warm-ups; the hit count is averaged over the timed steps (graph mode returns the same
+            static tensor every replay, so it is accumulated on the device step by step)"""
+            tr = make_trainer()
+            for b in sb[:4]:
+                tr.train_step(b)
+            torch.cuda.synchronize()
+            hit_sum = torch.zeros((), device=device, dtype=torch.float64)
+            n_counted = 0
+            t0 = time.perf_counter()
+            for b in sb[4:]:
+                o = tr.train_step(b)
+                if o is not None:
+                    hit_sum += o["n_hit"].to(torch.float64).reshape(())
+                    n_counted += 1
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 10
+            return dt, (float(hit_sum) / n_counted if n_counted else 0.0), bool(tr.use_graph)
+
+        try:
+            from fneus.trainer2 import Stage2Trainer
+            dt_2, n_hit, graph2 = timed_stage(lambda: Stage2Trainer(device, prec=prec, use_graph=not args.no_graph))
+            result["stage2_step"] = {"value": 4 * n_hit * 512 / dt_2, "unit": "secondary-ray SDF samples/s", "ms_per_step": dt_2 * 1e3,
+                                     "primary_rays": RAYS, "mean_hit_points": n_hit, "secondary_rays": 4 * n_hit,
+                                     "launch": "one hipGraph replay per step (fixed shape: 4 x 512 secondary rays marched, misses masked)"
+                                               if graph2 else "eager launches, hit points compacted",
+                                     "note": "lvis_render + L1 losses + backward + Adam (lvis.py:132-196): 4 secondary rays per hit "
+                                             "point x 512 coarse samples through K1, 32 fine samples through K2, same precision mode"}
+        except Exception as e:   # an extra must never take the headline number down with it
+            result["stage2_step"] = {"value": None, "error": repr(e)}
+        try:
+            from fneus.trainer3 import Stage3Trainer
+            dt_3, n_hit3, graph3 = timed_stage(lambda: Stage3Trainer(device, prec=prec, use_graph=not args.no_graph))
+            result["stage3_step"] = {"value": 4096 * n_hit3 / dt_3, "unit": "Lvis visibility evaluations/s", "ms_per_step": dt_3 * 1e3,
+                                     "primary_rays": RAYS, "mean_hit_points": n_hit3,
+                                     "launch": "one hipGraph replay per step (fixed shape: all 512 rays evaluated, misses masked)"
+                                               if graph3 else "eager launches, hit points compacted",
+                                     "note": "mateIllu_render + masked L1 + latent sparsity + backward + Adam (mateIllu.py:135-203): "
+                                             "128 light lobes x 32 directions through Lvis per hit point, SG rendering of 128 + 24 lobes"}
+        except Exception as e:
+            result["stage3_step"] = {"value": None, "error": repr(e)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

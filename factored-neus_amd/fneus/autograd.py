@@ -133,7 +133,10 @@ class ColorFn(torch.autograd.Function):
             d_feat, d_normal = ops.color_bwd(net.blob, n, prec, d_rgb.contiguous(), rgb, ctx.stash)
             feat_planes = ctx.sdf_ws.cache[("sdf_stash", n, prec, True)].feat
         grad = ws.get(("col_grad", n), lambda: torch.zeros(net.n_params, dtype=torch.float32, device=rgb.device))
-        jobs = ws.get(("col_jobs", n, prec), lambda: ops.color_dw_jobs(net, feat_planes, ctx.stash, grad, n))
+        # the job table holds raw device pointers into the feature planes: keyed by their address, so that a stash re-created
+        # by SDFNetwork.set_gradient_precision / use_grad_buffer cannot leave a table behind that reads freed memory
+        jobs = ws.get(("col_jobs", n, prec, feat_planes.data_ptr(), tuple(feat_planes.shape)),
+                      lambda: ops.color_dw_jobs(net, feat_planes, ctx.stash, grad, n))
         with ops.on_side_stream(4 if head == 0 else 2):
             jobs.run()
             net.wn_backward(grad)

@@ -169,6 +169,10 @@ class Stage1Trainer:
         network are final.  Eager step: start their all-reduce on the exchange stream.  While _capture_dp records a step:
         the second graph ends here and the third (the SDF backward) begins."""
         st = self._capturing
+        # FNEUS_OVERLAP bits 2 | 4 put the colour / RefColor weight-gradient GEMMs and the fold backward on the ops side
+        # stream: they write the early part of the arena, so that stream joins before the exchange reads it (during a
+        # capture the join also closes the fork, without which capture_end fails)
+        ops.overlap_join()
         if st is None:
             if self._in_dp_step:
                 self._early = self.grads.allreduce_early(self._xstream)

@@ -116,6 +116,27 @@ class Dataset(_RayMixin):
         return img[::l, ::l].cpu().numpy()
 
 
+def _resize_bilinear(img: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+    """cv.resize(img, (out_w, out_h)) with INTER_LINEAR on a float image [H, W, C] (no antialiasing, border replicated)"""
+    h, w = img.shape[:2]
+    if (out_h, out_w) == (h, w):
+        return img.copy()
+
+    def axis(n_in, n_out):
+        x = (np.arange(n_out, dtype=np.float64) + 0.5) * (n_in / n_out) - 0.5
+        i0 = np.floor(x).astype(np.int64)
+        f = (x - i0).astype(np.float32)
+        return np.clip(i0, 0, n_in - 1), np.clip(i0 + 1, 0, n_in - 1), f
+
+    y0, y1, fy = axis(h, out_h)
+    x0, x1, fx = axis(w, out_w)
+    fx = fx[None, :, None]
+    top = img[y0][:, x0] * (1.0 - fx) + img[y0][:, x1] * fx
+    bot = img[y1][:, x0] * (1.0 - fx) + img[y1][:, x1] * fx
+    fy = fy[:, None, None]
+    return (top * (1.0 - fy) + bot * fy).astype(img.dtype)
+
+
 class DatasetShiny(_RayMixin):
     """reference models/dataset.py:522-662.  File formats through PIL (imageio / tifffile / cv2 are not dependencies): PNG
     colours / 255 then ** 2.2 (rend_util.py:10-17), disparity TIFFs thresholded at 1e-6, `_alpha.png` masks / 256 thresholded
@@ -155,13 +176,15 @@ class DatasetShiny(_RayMixin):
         focal = 0.5 * img_w / np.tan(0.5 * float(meta["camera_angle_x"]))
         poses = np.array(poses)
         poses[..., 3] /= 2.0                                  # dataset.py:556-557: the whole last column, as the reference does
-        image_paths, poses = image_paths[::frame_skip], poses[::frame_skip, ...]
+        # frame_skip thins images, poses AND masks (the reference thins the first two only and then fails in the reshape of its
+        # mask stack, dataset.py:563-565, 603: with frame_skip > 1 image i must meet mask i * frame_skip)
+        image_paths, poses, mask_paths = image_paths[::frame_skip], poses[::frame_skip, ...], mask_paths[::frame_skip]
         self.image_paths = self.images_lis = image_paths
         K = np.array([[focal, 0, img_w / 2], [0, focal, img_h / 2], [0, 0, 1]], dtype=np.float32)
         self.n_images = len(image_paths)
         self.images = torch.from_numpy(np.stack([load_rgb(p) for p in image_paths])).to(self.device)
-        masks = np.stack([load_mask(p) for p in mask_paths])          # (all frames, like the reference: frame_skip skips images only)
-        self.masks = torch.from_numpy(masks[: self.n_images]).reshape(self.n_images, img_h, img_w, 1).repeat(1, 1, 1, 3).to(self.device)
+        masks = np.stack([load_mask(p) for p in mask_paths])
+        self.masks = torch.from_numpy(masks).reshape(self.n_images, img_h, img_w, 1).repeat(1, 1, 1, 3).to(self.device)
         # 4 x 4 intrinsics (the kernels take the DTU loader's layout); the reference keeps 3 x 3
         K4 = np.eye(4, dtype=np.float32)
         K4[:3, :3] = K
@@ -177,10 +200,10 @@ class DatasetShiny(_RayMixin):
         self.object_bbox_max = np.array([1.01, 1.01, 1.01], dtype=np.float32)
 
     def image_at(self, idx, resolution_level):
-        """dataset.py:660-662: back to display gamma, nearest-neighbour down-sampling"""
+        """dataset.py:660-662: back to display gamma, resized to (H // l, W // l) like cv.resize's default (bilinear, pixel
+        centres aligned: source coordinate (i + 0.5) * scale - 0.5, clamped at the border)"""
         img = np.power(self.images[idx].cpu().numpy(), 1.0 / 2.2) * 255
-        l = resolution_level
-        return img[::l, ::l].clip(0, 255)
+        return _resize_bilinear(img, self.H // resolution_level, self.W // resolution_level).clip(0, 255)
 
 
 def export_shiny_scene(ds: "SyntheticDataset", out_dir: str, split: str = "train", ball: bool = False) -> str:
