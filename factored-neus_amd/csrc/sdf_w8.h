@@ -1,0 +1,13 @@
+// launchers of the 8-wave-workgroup SDF kernels (sdf_w8_kernels.hip), called by the C-ABI entry points in sdf_kernels.hip
+#pragma once
+#include "fneus_kernels.h"
+
+namespace fneus {
+
+// K1 with HB 32-sample tiles per workgroup (1, 2 or 4)
+int sdf_fwd_w8(const unsigned char* blob, const PointSrc& src, long n_pts, float* sdf_out, int prec, int hb, hipStream_t stream);
+
+// K1 on staggered halves: two groups of 4 waves with HB tiles each (1 or 2), one phase apart
+int sdf_fwd_s8(const unsigned char* blob, const PointSrc& src, long n_pts, float* sdf_out, int prec, int hb, hipStream_t stream);
+
+}  // namespace fneus
