@@ -1069,6 +1069,7 @@ extern "C" int fneus_sdf_fwd(const void* blob, const float* pts, const float* ra
         const char* e_small = getenv("FNEUS_K1_W8_SMALL");
         const int w8_big = e_big ? atoi(e_big) : FNEUS_K1_W8_BIG_DEFAULT;
         const int w8_small = e_small ? atoi(e_small) : FNEUS_K1_W8_SMALL_DEFAULT;
+        if (tiles >= 1024 && w8_big == 3) return fneus::sdf_fwd_p2(b, src, n_pts, sdf_out, prec, stream);            // two-pass pipelined
         if (tiles >= 1024 && w8_big == 22) return fneus::sdf_fwd_s8(b, src, n_pts, sdf_out, prec, 2, stream);     // staggered halves
         if (tiles < 1024 && w8_small == 11) return fneus::sdf_fwd_s8(b, src, n_pts, sdf_out, prec, 1, stream);
         if (tiles >= 1024 && (w8_big == 4 || w8_big == 2)) return fneus::sdf_fwd_w8(b, src, n_pts, sdf_out, prec, w8_big, stream);

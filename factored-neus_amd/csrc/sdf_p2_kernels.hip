@@ -1,0 +1,151 @@
+// SDF-network kernels in the two-pass pipelined form (p2_engine.h): the same maths, operands and per-accumulator summation
+// order as sdf_kernels.hip (reference models/fields.py:74-111); the activation of one half of a workgroup's samples runs
+// inside the MFMA stream of the other half.
+//   K1 sdf_fwd_p2_kernel<PREC>: PE -> 8 x (dense + Softplus(beta = 100)) -> sdf row of the linear last layer (fields.py:93-95)
+#include <stdlib.h>
+#include "p2_engine.h"
+#include "fneus_kernels.h"
+#include "sdf_w8.h"
+
+namespace fneus {
+
+// One work unit = 128 samples (4 tiles); workgroup b takes units b, b + gridDim, ...  Pass schedule of a unit (A = set {0, 1},
+// B = set {2, 3}; "|| x" = the vector work inside the pass):
+//   L0.A || tail of the previous unit (act 7 B -> dot)      L0.B || act 0 A
+//   Ll.A || act l-1 B                                       Ll.B || act l A                (l = 1..7; act 7 A -> dot)
+// The encoding of the NEXT unit is written to slots 16..18 behind layer 4 (their last reader in this unit).
+template <int PREC>
+__global__ void __launch_bounds__(256, 1) sdf_fwd_p2_kernel(const unsigned char* blob, PointSrc src, long N,
+                                                            float* __restrict__ sdf_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
+    float* red = reinterpret_cast<float*>(lds_ + kP2LdsTotal);               // [4 tiles][4 waves][32 samples]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int t0 = 2 * wave, r = lane & 31, h = lane >> 5;
+    constexpr auto& LY = kSdfLayout;
+    const long units = (N + 127) / 128;
+    auto encode = [&](long unit) {          // wave w: encoding of tile w of the unit -> slots 16..18
+        const long n = (unit * 4 + wave) * 32 + r;
+        const long nc = n < N ? n : N - 1;
+        float x[3], pe[39], jc[39];
+        load_point(src, nc, x);
+        posenc<6, false>(x, pe, jc);
+        BFrag<PREC> pf[kMaxKS];
+        vec_to_bfrag<PREC, 39, 3, 0>(pe, pf, h);
+        frags_to_lds<PREC, 3>(lds_ + wave * kP2Half, lane, 16, pf);
+    };
+    auto put_dot = [&](float (&dot)[2], int hb0) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float p = dot[k] + xor32(dot[k]);
+            if (lane < 32) red[((hb0 + k) * 4 + wave) * 32 + lane] = p;
+            dot[k] = 0.0f;
+        }
+    };
+    auto finish = [&](long unit, int hb0) {     // waves hb0, hb0 + 1: sdf of tile `wave` = b_8[0] + the four partial dot products
+        if ((wave >> 1) == (hb0 >> 1) && lane < 32) {
+            f32x16 b8[1];
+            load_accvec<9, 8, 1>(blob, LY.L[8].bias, b8, lane);
+            float s = b8[0][0];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s += red[(wave * 4 + k) * 32 + lane];
+            const long n = (unit * 4 + wave) * 32 + r;
+            if (n < N) sdf_out[n] = s;
+        }
+    };
+#ifdef FNEUS_P2_CLOCK                   // timing experiments only: shader cycles and 100 MHz ticks of every wave behind the outputs
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    f32x16 accA[2][2], accB[2][2], cw[2];
+    float dot[2] = {0.0f, 0.0f};
+    auto load_cw = [&]() { load_accvec<8, 0, 2>(blob, LY.extra, cw, lane, t0); };   // row 0 of W_8 in accumulator layout (the sdf
+                                                                                    // row): fetched where it is used (32 registers)
+    const __amdgpu_buffer_rsrc_t rsrc = p2_rsrc(blob);
+    auto next_of = [&](int l) { return P2Next{LY.L[l].fwd_hi, LY.L[l].fwd_lo, LY.L[l].bias, l == 3 ? 7 : 8}; };
+    P2Prime<FNEUS_P2_DEPTH> pr;
+    p2_prime_all<PREC, FNEUS_P2_DEPTH>(pr, blob, rsrc, lane, t0, next_of(0));
+    if ((long)blockIdx.x < units) encode(blockIdx.x);
+    p2_barrier();
+    bool first = true;
+    for (long unit = blockIdx.x; unit < units; unit += gridDim.x) {
+        asm volatile("" : "+s"(blob));
+        // ---- layer 0 (3 k-steps on the encoding)
+        if (!first) load_cw();
+        if (first)
+            p2_pass<PREC, 3, 8, 1, 0>(blob, rsrc, LY.L[0].fwd_hi, LY.L[0].fwd_lo, pr, next_of(0), lds_, lane, t0, accA, 0, accB, 2, 2, cw, dot);
+        else
+            p2_pass<PREC, 3, 8, 1, 2>(blob, rsrc, LY.L[0].fwd_hi, LY.L[0].fwd_lo, pr, next_of(0), lds_, lane, t0, accA, 0, accB, 2, 2, cw, dot);
+        if (!first) put_dot(dot, 2);
+        p2_barrier();
+        if (!first) finish(unit - gridDim.x, 2);
+        first = false;
+        p2_pass<PREC, 3, 8, 1, 1>(blob, rsrc, LY.L[0].fwd_hi, LY.L[0].fwd_lo, pr, next_of(1), lds_, lane, t0, accB, 2, accA, 0, 2, cw, dot);
+        p2_barrier();
+#pragma unroll 1
+        for (int l = 1; l <= 7; ++l) {
+            asm volatile("" : "+s"(blob));
+            const int tn_prev = (l - 1 == 3 && wave == 3) ? 1 : 2;       // layer 3 has 7 tiles: its last wave publishes one
+            const int tn_this = (l == 3 && wave == 3) ? 1 : 2;
+            const P2Next same = next_of(l), following = next_of(l == 7 ? 0 : l + 1);
+            // pass A: MFMAs of set {0, 1} || activation of layer l-1, set {2, 3}
+            if (l == 3)
+                p2_pass<PREC, 16, 7, 0, 1>(blob, rsrc, LY.L[3].fwd_hi, LY.L[3].fwd_lo, pr, same, lds_, lane, t0, accA, 0, accB, 2, tn_prev, cw, dot);
+            else if (l == 4)
+                p2_pass<PREC, 17, 8, 2, 1>(blob, rsrc, LY.L[4].fwd_hi, LY.L[4].fwd_lo, pr, same, lds_, lane, t0, accA, 0, accB, 2, tn_prev, cw, dot);
+            else
+                p2_pass<PREC, 16, 8, 0, 1>(blob, rsrc, LY.L[l].fwd_hi, LY.L[l].fwd_lo, pr, same, lds_, lane, t0, accA, 0, accB, 2, tn_prev, cw, dot);
+            p2_barrier();
+            // pass B: MFMAs of set {2, 3} || activation of layer l, set {0, 1} (layer 7: -> dot product)
+            if (l == 3)
+                p2_pass<PREC, 16, 7, 0, 1>(blob, rsrc, LY.L[3].fwd_hi, LY.L[3].fwd_lo, pr, following, lds_, lane, t0, accB, 2, accA, 0, tn_this, cw, dot);
+            else if (l == 4)
+                p2_pass<PREC, 17, 8, 2, 1>(blob, rsrc, LY.L[4].fwd_hi, LY.L[4].fwd_lo, pr, following, lds_, lane, t0, accB, 2, accA, 0, tn_this, cw, dot);
+            else if (l == 7) {
+                load_cw();
+                p2_pass<PREC, 16, 8, 0, 2>(blob, rsrc, LY.L[7].fwd_hi, LY.L[7].fwd_lo, pr, following, lds_, lane, t0, accB, 2, accA, 0, tn_this, cw, dot);
+            } else
+                p2_pass<PREC, 16, 8, 0, 1>(blob, rsrc, LY.L[l].fwd_hi, LY.L[l].fwd_lo, pr, following, lds_, lane, t0, accB, 2, accA, 0, tn_this, cw, dot);
+            if (l == 7) put_dot(dot, 0);
+            if (l == 5 && unit + gridDim.x < units) encode(unit + gridDim.x);     // slots 16..18 are free behind layer 4
+            p2_barrier();
+        }
+        finish(unit, 0);
+    }
+    if (!first) {       // tail of the last unit: act 7 of set {2, 3} -> dot
+        load_cw();
+        p2_valu_only<PREC, 2>(lds_, lane, t0, accB, 2, 2, cw, dot);
+        put_dot(dot, 2);
+        p2_barrier();
+        long last = blockIdx.x;
+        while (last + gridDim.x < units) last += gridDim.x;
+        finish(last, 2);
+    }
+#ifdef FNEUS_P2_CLOCK
+    if (lane == 0) {
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(sdf_out + ((N + 3) & ~3L)) + (blockIdx.x * 4 + wave) * 2;
+        st[0] = __builtin_amdgcn_s_memtime() - c0;
+        st[1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+#endif
+}
+
+template <int PREC>
+static int launch_k1_p2(const unsigned char* b, const PointSrc& src, long n_pts, float* sdf_out, hipStream_t stream) {
+    static bool done = false;
+    if (!done) {
+        allow_big_lds(sdf_fwd_p2_kernel<PREC>);
+        done = true;
+    }
+    const long units = (n_pts + 127) / 128;
+    hipLaunchKernelGGL((sdf_fwd_p2_kernel<PREC>), dim3((unsigned)(units < 256 ? units : 256)), dim3(256), kP2LdsTotal + 4 * 4 * 32 * 4,
+                       stream, b, src, n_pts, sdf_out);
+    return launch_status();
+}
+
+int sdf_fwd_p2(const unsigned char* b, const PointSrc& src, long n_pts, float* sdf_out, int prec, hipStream_t stream) {
+    if (prec == 3) return launch_k1_p2<3>(b, src, n_pts, sdf_out, stream);
+    if (prec == 1) return launch_k1_p2<1>(b, src, n_pts, sdf_out, stream);
+    return -2;
+}
+
+}  // namespace fneus

@@ -10,4 +10,7 @@ int sdf_fwd_w8(const unsigned char* blob, const PointSrc& src, long n_pts, float
 // K1 on staggered halves: two groups of 4 waves with HB tiles each (1 or 2), one phase apart
 int sdf_fwd_s8(const unsigned char* blob, const PointSrc& src, long n_pts, float* sdf_out, int prec, int hb, hipStream_t stream);
 
+// K1 in the two-pass pipelined form (sdf_p2_kernels.hip): 128 samples per 4-wave workgroup
+int sdf_fwd_p2(const unsigned char* blob, const PointSrc& src, long n_pts, float* sdf_out, int prec, hipStream_t stream);
+
 }  // namespace fneus
