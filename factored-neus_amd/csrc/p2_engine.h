@@ -82,36 +82,36 @@ struct P2Next {                         // where the next pass finds its weights
     uint32_t off_hi, off_lo, off_bias;
     int nt;                             // output tiles of the next pass's layer (fragment order [ks][t])
 };
-template <int D>
+template <int D, int TN = 2>
 struct P2Prime {
-    bf16x8 ah[D][2], al[D][2];
-    f32x16 bias[2];
+    bf16x8 ah[D][TN], al[D][TN];
+    f32x16 bias[TN];
 };
 
-template <int PREC, int D>
-FN_DEV void p2_prime_stage(P2Prime<D>& pr, int s, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, const P2Next& nx,
+template <int PREC, int D, int TN>
+FN_DEV void p2_prime_stage(P2Prime<D, TN>& pr, int s, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, const P2Next& nx,
                            const unsigned char* blob) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TN; ++i) {
         const uint32_t f = (uint32_t)((s * nx.nt + i) * 64) * 16u;
         pr.ah[s][i] = p2_wload(rsrc, voff, nx.off_hi + f, blob);
         if constexpr (PREC == 3) pr.al[s][i] = p2_wload(rsrc, voff, nx.off_lo + f, blob);
     }
 }
-template <int PREC, int D>
-FN_DEV void p2_prime_bias(P2Prime<D>& pr, const unsigned char* __restrict__ blob, int lane, int t0, const P2Next& nx) {
+template <int PREC, int D, int TN>
+FN_DEV void p2_prime_bias(P2Prime<D, TN>& pr, const unsigned char* __restrict__ blob, int lane, int t0, const P2Next& nx) {
     const f32x16 FN_GLOBAL* __restrict__ p = reinterpret_cast<const f32x16 FN_GLOBAL*>((gblob_t)blob + nx.off_bias);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) pr.bias[i] = p[(t0 + i) * 2 + (lane >> 5)];
+    for (int i = 0; i < TN; ++i) pr.bias[i] = p[(t0 + i) * 2 + (lane >> 5)];
 }
 // everything at once (before the first pass of a launch)
-template <int PREC, int D>
-FN_DEV void p2_prime_all(P2Prime<D>& pr, const unsigned char* __restrict__ blob, __amdgpu_buffer_rsrc_t rsrc, int lane, int t0,
+template <int PREC, int D, int TN>
+FN_DEV void p2_prime_all(P2Prime<D, TN>& pr, const unsigned char* __restrict__ blob, __amdgpu_buffer_rsrc_t rsrc, int lane, int t0,
                          const P2Next& nx) {
     const unsigned voff = (unsigned)(lane + t0 * 64) * 16u;
 #pragma unroll
-    for (int s = 0; s < D; ++s) p2_prime_stage<PREC, D>(pr, s, rsrc, voff, nx, blob);
-    p2_prime_bias<PREC, D>(pr, blob, lane, t0, nx);
+    for (int s = 0; s < D; ++s) p2_prime_stage<PREC, D, TN>(pr, s, rsrc, voff, nx, blob);
+    p2_prime_bias<PREC, D, TN>(pr, blob, lane, t0, nx);
 }
 
 // ---- vector work of the forward chain of K1: softplus -> B fragments (ACT 1) or -> dot product with the sdf row (ACT 2) ----
@@ -128,25 +128,25 @@ FN_DEV void p2_prime_all(P2Prime<D>& pr, const unsigned char* __restrict__ blob,
 //   fragments of k-step s + 1.
 // ACT: 0 none; 1 softplus -> B fragments of the next layer (k-steps 2 (t0 + i) + sh of tiles hbV, hbV + 1);
 //      2 softplus -> partial dot product with cw (the sdf row of the linear last layer), added to dot[]
-template <int PREC, int KS, int NT_TOTAL, int LMAP, int ACT>
+template <int PREC, int KS, int NT_TOTAL, int LMAP, int ACT, int TN = 2>
 FN_DEV void p2_pass(const unsigned char* __restrict__ blob, __amdgpu_buffer_rsrc_t rsrc, uint32_t off_hi, uint32_t off_lo,
-                    P2Prime<FNEUS_P2_DEPTH>& pr, const P2Next& nx, unsigned char* lds, int lane, int t0, f32x16 (&accM)[2][2], int hbM,
-                    f32x16 (&accV)[2][2], int hbV, int tnV, const f32x16 (&cw)[2], float (&dot)[2]) {
+                    P2Prime<FNEUS_P2_DEPTH, TN>& pr, const P2Next& nx, unsigned char* lds, int lane, int t0, f32x16 (&accM)[TN][2], int hbM,
+                    f32x16 (&accV)[TN][2], int hbV, int tnV, const f32x16 (&cw)[TN], float (&dot)[2]) {
     constexpr int NPL = PREC == 3 ? 2 : 1;
     constexpr int D = FNEUS_P2_DEPTH;
-    constexpr int NV = 64;                               // values of accV per lane: 2 tiles x 2 sample tiles x 16
+    constexpr int NV = TN * 32;                          // values of accV per lane: TN tiles x 2 sample tiles x 16
     static_assert(KS >= D, "a pass consumes its D primed stages");
     const unsigned voff = (unsigned)(lane + t0 * 64) * 16u;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {                        // bias = initial accumulator
+    for (int i = 0; i < TN; ++i) {                       // bias = initial accumulator
         accM[i][0] = pr.bias[i];
         accM[i][1] = pr.bias[i];
     }
-    bf16x8 ah[D + 1][2], al[D + 1][2];
+    bf16x8 ah[D + 1][TN], al[D + 1][TN];
 #pragma unroll
     for (int s = 0; s < D; ++s)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TN; ++i) {
             ah[s][i] = pr.ah[s][i];
             if constexpr (PREC == 3) al[s][i] = pr.al[s][i];
         }
@@ -166,14 +166,14 @@ FN_DEV void p2_pass(const unsigned char* __restrict__ blob, __amdgpu_buffer_rsrc
         bh[0][hb] = ldb(hb, p2_slot<LMAP>(0), 0);
         if constexpr (PREC == 3) bl[0][hb] = ldb(hb, p2_slot<LMAP>(0), 1);
     }
-    p2_prime_bias<PREC, D>(pr, blob, lane, t0, nx);     // (the registers are free again: next pass's bias)
+    p2_prime_bias<PREC, D, TN>(pr, blob, lane, t0, nx); // (the registers are free again: next pass's bias)
     typedef __attribute__((ext_vector_type(2))) __bf16 p2_bf16x2;
     uint32_t phw[4], plw[4];                             // the fragment half being assembled by the vector work (4 x 2 bf16)
 #ifdef FNEUS_P2_VCOPY
-    f32x16 vv[2][2];
+    f32x16 vv[TN][2];
     if constexpr (ACT != 0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TN; ++i)
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb) {
                 vv[i][hb] = accV[i][hb];
@@ -181,11 +181,11 @@ FN_DEV void p2_pass(const unsigned char* __restrict__ blob, __amdgpu_buffer_rsrc
             }
     }
 #else
-    f32x16 (&vv)[2][2] = accV;
+    f32x16 (&vv)[TN][2] = accV;
 #endif
     static_for<0, KS>([&](auto S_) {
         constexpr int s = decltype(S_)::value;
-        constexpr int NSLOT = PREC == 3 ? 12 : 4;
+        constexpr int NSLOT = (PREC == 3 ? 6 : 2) * TN;
         constexpr int NP = NV / 2;                                  // value PAIRS of accV (a pair = one packed bf16 word)
         constexpr int MAXP = (NP + KS - 1) / KS + 1;
         float ve[2 * MAXP], vm[2 * MAXP], vl[2 * MAXP];
@@ -275,30 +275,32 @@ FN_DEV void p2_pass(const unsigned char* __restrict__ blob, __amdgpu_buffer_rsrc
             constexpr int q = decltype(Q_)::value;
 #ifndef FNEUS_P2_NO_MFMA
             {
-                constexpr int i = (q >> 1) & 1, hb = q & 1;
+                constexpr int NACC = 2 * TN;                       // accumulators (i, hb) = (r >> 1, r & 1), product-major
+                constexpr int r = q % NACC, prod = q / NACC;
+                constexpr int i = r >> 1, hb = r & 1;
                 if constexpr (PREC == 3) {
-                    if constexpr (q < 4) accM[i][hb] = mfma32(al[s % (D + 1)][i], bh[s % 3][hb], accM[i][hb]);
-                    else if constexpr (q < 8) accM[i][hb] = mfma32(ah[s % (D + 1)][i], bl[s % 3][hb], accM[i][hb]);
+                    if constexpr (prod == 0) accM[i][hb] = mfma32(al[s % (D + 1)][i], bh[s % 3][hb], accM[i][hb]);
+                    else if constexpr (prod == 1) accM[i][hb] = mfma32(ah[s % (D + 1)][i], bl[s % 3][hb], accM[i][hb]);
                     else accM[i][hb] = mfma32(ah[s % (D + 1)][i], bh[s % 3][hb], accM[i][hb]);
                 } else {
                     accM[i][hb] = mfma32(ah[s % (D + 1)][i], bh[s % 3][hb], accM[i][hb]);
                 }
             }
 #else
-            asm volatile("" :: "v"(ah[s % (D + 1)][q & 1]), "v"(al[s % (D + 1)][q & 1]), "v"(bh[s % 3][q & 1]), "v"(bl[s % 3][q & 1]));
+            asm volatile("" :: "v"(ah[s % (D + 1)][0]), "v"(al[s % (D + 1)][0]), "v"(bh[s % 3][q & 1]), "v"(bl[s % 3][q & 1]));
 #endif
             // ---- operand requests of this slot
-            constexpr int NREQ = NSLOT >= 12 ? 4 : 2;      // slots per request group
+            constexpr int NREQ = NSLOT >= 12 ? 4 : (NSLOT >= 4 ? 2 : 1);      // slots per request group
 #ifdef FNEUS_P2_W_FIRST
             constexpr int qw = q, qb = q - NREQ;
 #else
             constexpr int qw = q - NREQ, qb = q;           // B fragments first: they are needed at the next k-step, the weights D later
 #endif
             if constexpr (qw >= 0 && qw < NREQ) {          // weight fragments: (tile, plane) = (qw & 1, qw >> 1) (parity mode)
-                constexpr int per = (2 * NPL + NREQ - 1) / NREQ;
+                constexpr int per = (TN * NPL + NREQ - 1) / NREQ;
 #pragma unroll
-                for (int u = qw * per; u < (qw + 1) * per && u < 2 * NPL; ++u) {
-                    const int i = u & 1, plane = u >> 1;
+                for (int u = qw * per; u < (qw + 1) * per && u < TN * NPL; ++u) {
+                    const int i = u % TN, plane = u / TN;
                     if constexpr (s + D < KS) {
                         const uint32_t f = (uint32_t)(((s + D) * NT_TOTAL + i) * 64) * 16u;
                         if (plane == 0) ah[(s + D) % (D + 1)][i] = p2_wload(rsrc, voff, off_hi + f, blob);
@@ -349,13 +351,13 @@ FN_DEV void p2_pass(const unsigned char* __restrict__ blob, __amdgpu_buffer_rsrc
 }
 
 // the vector work of a pass alone (after the last MFMA pass of a launch)
-template <int PREC, int ACT>
-FN_DEV void p2_valu_only(unsigned char* lds, int lane, int t0, f32x16 (&accV)[2][2], int hbV, int tnV, const f32x16 (&cw)[2],
+template <int PREC, int ACT, int TN = 2>
+FN_DEV void p2_valu_only(unsigned char* lds, int lane, int t0, f32x16 (&accV)[TN][2], int hbV, int tnV, const f32x16 (&cw)[TN],
                          float (&dot)[2]) {
     constexpr int NPL = PREC == 3 ? 2 : 1;
     unsigned char* flV = lds + hbV * kP2Half + lane * 16;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
+    for (int g = 0; g < 4 * TN; ++g) {
         const int i = g >> 2, hb = (g >> 1) & 1, sh = g & 1;
         bf16x8 ph, pl;
 #pragma unroll

@@ -10,8 +10,8 @@
 #include "sdf_w8.h"
 
 #ifndef FNEUS_K1_W8_BIG_DEFAULT
-#define FNEUS_K1_W8_BIG_DEFAULT 0
-#define FNEUS_K1_W8_SMALL_DEFAULT 0
+#define FNEUS_K1_W8_BIG_DEFAULT 31        // round 3: two-pass pipelined kernel, 8 waves (sdf_p2_kernels.hip)
+#define FNEUS_K1_W8_SMALL_DEFAULT 2       // round 3: one tile per 8-wave workgroup, whole layers primed in registers
 #endif
 #ifndef FNEUS_K2_OCC
 #define FNEUS_K2_OCC 2      // workgroups per CU the tensor-parallel kernels of this file are compiled for (experiments: 3)
@@ -1069,8 +1069,9 @@ extern "C" int fneus_sdf_fwd(const void* blob, const float* pts, const float* ra
         const char* e_small = getenv("FNEUS_K1_W8_SMALL");
         const int w8_big = e_big ? atoi(e_big) : FNEUS_K1_W8_BIG_DEFAULT;
         const int w8_small = e_small ? atoi(e_small) : FNEUS_K1_W8_SMALL_DEFAULT;
-        if (tiles >= 1024 && w8_big == 3) return fneus::sdf_fwd_p2(b, src, n_pts, sdf_out, prec, stream);            // two-pass pipelined
+        if (tiles >= 1024 && (w8_big == 3 || w8_big == 31)) return fneus::sdf_fwd_p2(b, src, n_pts, sdf_out, prec, w8_big == 31 ? 1 : 2, stream);   // two-pass pipelined
         if (tiles >= 1024 && w8_big == 22) return fneus::sdf_fwd_s8(b, src, n_pts, sdf_out, prec, 2, stream);     // staggered halves
+        if (tiles < 1024 && w8_small == 2) return fneus::sdf_fwd_w8p(b, src, n_pts, sdf_out, prec, stream);               // primed layers
         if (tiles < 1024 && w8_small == 11) return fneus::sdf_fwd_s8(b, src, n_pts, sdf_out, prec, 1, stream);
         if (tiles >= 1024 && (w8_big == 4 || w8_big == 2)) return fneus::sdf_fwd_w8(b, src, n_pts, sdf_out, prec, w8_big, stream);
         if (tiles < 1024 && w8_small == 1) return fneus::sdf_fwd_w8(b, src, n_pts, sdf_out, prec, 1, stream);

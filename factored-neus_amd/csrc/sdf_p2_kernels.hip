@@ -14,17 +14,19 @@ namespace fneus {
 //   L0.A || tail of the previous unit (act 7 B -> dot)      L0.B || act 0 A
 //   Ll.A || act l-1 B                                       Ll.B || act l A                (l = 1..7; act 7 A -> dot)
 // The encoding of the NEXT unit is written to slots 16..18 behind layer 4 (their last reader in this unit).
-template <int PREC>
-__global__ void __launch_bounds__(256, 1) sdf_fwd_p2_kernel(const unsigned char* blob, PointSrc src, long N,
+template <int PREC, int TN>
+__global__ void __launch_bounds__(512 / TN, 2 / TN) sdf_fwd_p2_kernel(const unsigned char* blob, PointSrc src, long N,
                                                             float* __restrict__ sdf_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
-    float* red = reinterpret_cast<float*>(lds_ + kP2LdsTotal);               // [4 tiles][4 waves][32 samples]
+    constexpr int NW = 8 / TN;                                                // waves: wave w owns output tiles TN w .. TN w + TN - 1
+    float* red = reinterpret_cast<float*>(lds_ + kP2LdsTotal);               // [4 tiles][NW waves][32 samples]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int t0 = 2 * wave, r = lane & 31, h = lane >> 5;
+    const int t0 = TN * wave, r = lane & 31, h = lane >> 5;
     constexpr auto& LY = kSdfLayout;
     const long units = (N + 127) / 128;
-    auto encode = [&](long unit) {          // wave w: encoding of tile w of the unit -> slots 16..18
+    auto encode = [&](long unit) {          // wave w < 4: encoding of tile w of the unit -> slots 16..18
+        if (wave >= 4) return;
         const long n = (unit * 4 + wave) * 32 + r;
         const long nc = n < N ? n : N - 1;
         float x[3], pe[39], jc[39];
@@ -38,17 +40,17 @@ __global__ void __launch_bounds__(256, 1) sdf_fwd_p2_kernel(const unsigned char*
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const float p = dot[k] + xor32(dot[k]);
-            if (lane < 32) red[((hb0 + k) * 4 + wave) * 32 + lane] = p;
+            if (lane < 32) red[((hb0 + k) * NW + wave) * 32 + lane] = p;
             dot[k] = 0.0f;
         }
     };
-    auto finish = [&](long unit, int hb0) {     // waves hb0, hb0 + 1: sdf of tile `wave` = b_8[0] + the four partial dot products
-        if ((wave >> 1) == (hb0 >> 1) && lane < 32) {
+    auto finish = [&](long unit, int hb0) {     // waves hb0, hb0 + 1: sdf of tile `wave` = b_8[0] + the waves' partial dot products
+        if (wave < 4 && (wave >> 1) == (hb0 >> 1) && lane < 32) {
             f32x16 b8[1];
             load_accvec<9, 8, 1>(blob, LY.L[8].bias, b8, lane);
             float s = b8[0][0];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) s += red[(wave * 4 + k) * 32 + lane];
+            for (int k = 0; k < NW; ++k) s += red[(wave * NW + k) * 32 + lane];
             const long n = (unit * 4 + wave) * 32 + r;
             if (n < N) sdf_out[n] = s;
         }
@@ -56,14 +58,14 @@ __global__ void __launch_bounds__(256, 1) sdf_fwd_p2_kernel(const unsigned char*
 #ifdef FNEUS_P2_CLOCK                   // timing experiments only: shader cycles and 100 MHz ticks of every wave behind the outputs
     const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    f32x16 accA[2][2], accB[2][2], cw[2];
+    f32x16 accA[TN][2], accB[TN][2], cw[TN];
     float dot[2] = {0.0f, 0.0f};
-    auto load_cw = [&]() { load_accvec<8, 0, 2>(blob, LY.extra, cw, lane, t0); };   // row 0 of W_8 in accumulator layout (the sdf
+    auto load_cw = [&]() { load_accvec<8, 0, TN>(blob, LY.extra, cw, lane, t0); };   // row 0 of W_8 in accumulator layout (the sdf
                                                                                     // row): fetched where it is used (32 registers)
     const __amdgpu_buffer_rsrc_t rsrc = p2_rsrc(blob);
     auto next_of = [&](int l) { return P2Next{LY.L[l].fwd_hi, LY.L[l].fwd_lo, LY.L[l].bias, l == 3 ? 7 : 8}; };
-    P2Prime<FNEUS_P2_DEPTH> pr;
-    p2_prime_all<PREC, FNEUS_P2_DEPTH>(pr, blob, rsrc, lane, t0, next_of(0));
+    P2Prime<FNEUS_P2_DEPTH, TN> pr;
+    p2_prime_all<PREC, FNEUS_P2_DEPTH, TN>(pr, blob, rsrc, lane, t0, next_of(0));
     if ((long)blockIdx.x < units) encode(blockIdx.x);
     p2_barrier();
     bool first = true;
@@ -72,39 +74,40 @@ __global__ void __launch_bounds__(256, 1) sdf_fwd_p2_kernel(const unsigned char*
         // ---- layer 0 (3 k-steps on the encoding)
         if (!first) load_cw();
         if (first)
-            p2_pass<PREC, 3, 8, 1, 0>(blob, rsrc, LY.L[0].fwd_hi, LY.L[0].fwd_lo, pr, next_of(0), lds_, lane, t0, accA, 0, accB, 2, 2, cw, dot);
+            p2_pass<PREC, 3, 8, 1, 0, TN>(blob, rsrc, LY.L[0].fwd_hi, LY.L[0].fwd_lo, pr, next_of(0), lds_, lane, t0, accA, 0, accB, 2, TN, cw, dot);
         else
-            p2_pass<PREC, 3, 8, 1, 2>(blob, rsrc, LY.L[0].fwd_hi, LY.L[0].fwd_lo, pr, next_of(0), lds_, lane, t0, accA, 0, accB, 2, 2, cw, dot);
+            p2_pass<PREC, 3, 8, 1, 2, TN>(blob, rsrc, LY.L[0].fwd_hi, LY.L[0].fwd_lo, pr, next_of(0), lds_, lane, t0, accA, 0, accB, 2, TN, cw, dot);
         if (!first) put_dot(dot, 2);
         p2_barrier();
         if (!first) finish(unit - gridDim.x, 2);
         first = false;
-        p2_pass<PREC, 3, 8, 1, 1>(blob, rsrc, LY.L[0].fwd_hi, LY.L[0].fwd_lo, pr, next_of(1), lds_, lane, t0, accB, 2, accA, 0, 2, cw, dot);
+        p2_pass<PREC, 3, 8, 1, 1, TN>(blob, rsrc, LY.L[0].fwd_hi, LY.L[0].fwd_lo, pr, next_of(1), lds_, lane, t0, accB, 2, accA, 0, TN, cw, dot);
         p2_barrier();
 #pragma unroll 1
         for (int l = 1; l <= 7; ++l) {
             asm volatile("" : "+s"(blob));
-            const int tn_prev = (l - 1 == 3 && wave == 3) ? 1 : 2;       // layer 3 has 7 tiles: its last wave publishes one
-            const int tn_this = (l == 3 && wave == 3) ? 1 : 2;
+            const int tn3 = 7 - t0 < TN ? 7 - t0 : TN;                   // layer 3 has 7 tiles: its last wave publishes one fewer
+            const int tn_prev = l - 1 == 3 ? tn3 : TN;
+            const int tn_this = l == 3 ? tn3 : TN;
             const P2Next same = next_of(l), following = next_of(l == 7 ? 0 : l + 1);
             // pass A: MFMAs of set {0, 1} || activation of layer l-1, set {2, 3}
             if (l == 3)
-                p2_pass<PREC, 16, 7, 0, 1>(blob, rsrc, LY.L[3].fwd_hi, LY.L[3].fwd_lo, pr, same, lds_, lane, t0, accA, 0, accB, 2, tn_prev, cw, dot);
+                p2_pass<PREC, 16, 7, 0, 1, TN>(blob, rsrc, LY.L[3].fwd_hi, LY.L[3].fwd_lo, pr, same, lds_, lane, t0, accA, 0, accB, 2, tn_prev, cw, dot);
             else if (l == 4)
-                p2_pass<PREC, 17, 8, 2, 1>(blob, rsrc, LY.L[4].fwd_hi, LY.L[4].fwd_lo, pr, same, lds_, lane, t0, accA, 0, accB, 2, tn_prev, cw, dot);
+                p2_pass<PREC, 17, 8, 2, 1, TN>(blob, rsrc, LY.L[4].fwd_hi, LY.L[4].fwd_lo, pr, same, lds_, lane, t0, accA, 0, accB, 2, tn_prev, cw, dot);
             else
-                p2_pass<PREC, 16, 8, 0, 1>(blob, rsrc, LY.L[l].fwd_hi, LY.L[l].fwd_lo, pr, same, lds_, lane, t0, accA, 0, accB, 2, tn_prev, cw, dot);
+                p2_pass<PREC, 16, 8, 0, 1, TN>(blob, rsrc, LY.L[l].fwd_hi, LY.L[l].fwd_lo, pr, same, lds_, lane, t0, accA, 0, accB, 2, tn_prev, cw, dot);
             p2_barrier();
             // pass B: MFMAs of set {2, 3} || activation of layer l, set {0, 1} (layer 7: -> dot product)
             if (l == 3)
-                p2_pass<PREC, 16, 7, 0, 1>(blob, rsrc, LY.L[3].fwd_hi, LY.L[3].fwd_lo, pr, following, lds_, lane, t0, accB, 2, accA, 0, tn_this, cw, dot);
+                p2_pass<PREC, 16, 7, 0, 1, TN>(blob, rsrc, LY.L[3].fwd_hi, LY.L[3].fwd_lo, pr, following, lds_, lane, t0, accB, 2, accA, 0, tn_this, cw, dot);
             else if (l == 4)
-                p2_pass<PREC, 17, 8, 2, 1>(blob, rsrc, LY.L[4].fwd_hi, LY.L[4].fwd_lo, pr, following, lds_, lane, t0, accB, 2, accA, 0, tn_this, cw, dot);
+                p2_pass<PREC, 17, 8, 2, 1, TN>(blob, rsrc, LY.L[4].fwd_hi, LY.L[4].fwd_lo, pr, following, lds_, lane, t0, accB, 2, accA, 0, tn_this, cw, dot);
             else if (l == 7) {
                 load_cw();
-                p2_pass<PREC, 16, 8, 0, 2>(blob, rsrc, LY.L[7].fwd_hi, LY.L[7].fwd_lo, pr, following, lds_, lane, t0, accB, 2, accA, 0, tn_this, cw, dot);
+                p2_pass<PREC, 16, 8, 0, 2, TN>(blob, rsrc, LY.L[7].fwd_hi, LY.L[7].fwd_lo, pr, following, lds_, lane, t0, accB, 2, accA, 0, tn_this, cw, dot);
             } else
-                p2_pass<PREC, 16, 8, 0, 1>(blob, rsrc, LY.L[l].fwd_hi, LY.L[l].fwd_lo, pr, following, lds_, lane, t0, accB, 2, accA, 0, tn_this, cw, dot);
+                p2_pass<PREC, 16, 8, 0, 1, TN>(blob, rsrc, LY.L[l].fwd_hi, LY.L[l].fwd_lo, pr, following, lds_, lane, t0, accB, 2, accA, 0, tn_this, cw, dot);
             if (l == 7) put_dot(dot, 0);
             if (l == 5 && unit + gridDim.x < units) encode(unit + gridDim.x);     // slots 16..18 are free behind layer 4
             p2_barrier();
@@ -113,7 +116,7 @@ __global__ void __launch_bounds__(256, 1) sdf_fwd_p2_kernel(const unsigned char*
     }
     if (!first) {       // tail of the last unit: act 7 of set {2, 3} -> dot
         load_cw();
-        p2_valu_only<PREC, 2>(lds_, lane, t0, accB, 2, 2, cw, dot);
+        p2_valu_only<PREC, 2, TN>(lds_, lane, t0, accB, 2, TN, cw, dot);
         put_dot(dot, 2);
         p2_barrier();
         long last = blockIdx.x;
@@ -129,22 +132,24 @@ __global__ void __launch_bounds__(256, 1) sdf_fwd_p2_kernel(const unsigned char*
 #endif
 }
 
-template <int PREC>
+template <int PREC, int TN>
 static int launch_k1_p2(const unsigned char* b, const PointSrc& src, long n_pts, float* sdf_out, hipStream_t stream) {
     static bool done = false;
     if (!done) {
-        allow_big_lds(sdf_fwd_p2_kernel<PREC>);
+        allow_big_lds(sdf_fwd_p2_kernel<PREC, TN>);
         done = true;
     }
     const long units = (n_pts + 127) / 128;
-    hipLaunchKernelGGL((sdf_fwd_p2_kernel<PREC>), dim3((unsigned)(units < 256 ? units : 256)), dim3(256), kP2LdsTotal + 4 * 4 * 32 * 4,
-                       stream, b, src, n_pts, sdf_out);
+    hipLaunchKernelGGL((sdf_fwd_p2_kernel<PREC, TN>), dim3((unsigned)(units < 256 ? units : 256)), dim3(512 / TN),
+                       kP2LdsTotal + 4 * 8 * 32 * 4, stream, b, src, n_pts, sdf_out);
     return launch_status();
 }
 
-int sdf_fwd_p2(const unsigned char* b, const PointSrc& src, long n_pts, float* sdf_out, int prec, hipStream_t stream) {
-    if (prec == 3) return launch_k1_p2<3>(b, src, n_pts, sdf_out, stream);
-    if (prec == 1) return launch_k1_p2<1>(b, src, n_pts, sdf_out, stream);
+// tn = 2: 4 waves (one per SIMD, 512 registers), tn = 1: 8 waves (two per SIMD: one wave's dependent vector instructions wait
+// while the other issues)
+int sdf_fwd_p2(const unsigned char* b, const PointSrc& src, long n_pts, float* sdf_out, int prec, int tn, hipStream_t stream) {
+    if (prec == 3) return tn == 1 ? launch_k1_p2<3, 1>(b, src, n_pts, sdf_out, stream) : launch_k1_p2<3, 2>(b, src, n_pts, sdf_out, stream);
+    if (prec == 1) return tn == 1 ? launch_k1_p2<1, 1>(b, src, n_pts, sdf_out, stream) : launch_k1_p2<1, 2>(b, src, n_pts, sdf_out, stream);
     return -2;
 }
 

@@ -11,6 +11,9 @@ int sdf_fwd_w8(const unsigned char* blob, const PointSrc& src, long n_pts, float
 int sdf_fwd_s8(const unsigned char* blob, const PointSrc& src, long n_pts, float* sdf_out, int prec, int hb, hipStream_t stream);
 
 // K1 in the two-pass pipelined form (sdf_p2_kernels.hip): 128 samples per 4-wave workgroup
-int sdf_fwd_p2(const unsigned char* blob, const PointSrc& src, long n_pts, float* sdf_out, int prec, hipStream_t stream);
+int sdf_fwd_p2(const unsigned char* blob, const PointSrc& src, long n_pts, float* sdf_out, int prec, int tn, hipStream_t stream);
+
+// K1 for latency-bound launches: one tile per 8-wave workgroup, the whole layer's weight fragments primed in registers
+int sdf_fwd_w8p(const unsigned char* blob, const PointSrc& src, long n_pts, float* sdf_out, int prec, hipStream_t stream);
 
 }  // namespace fneus

@@ -5,6 +5,7 @@
 //                                     hierarchical sampler (renderer.py:430: 16 new depths per ray = 256 tiles).
 #include <stdlib.h>
 #include "w8_engine.h"
+#include "p2_engine.h"
 #include "fneus_kernels.h"
 #include "sdf_w8.h"
 
@@ -274,6 +275,146 @@ __global__ void __launch_bounds__(512, 2) sdf_fwd_s8_kernel(const unsigned char*
     if (g == 0) w8_barrier();
 }
 
+// ---- K1 for the latency-bound launches of the hierarchical sampler (renderer.py:430: 16 new depths per ray = 8192 points = one
+// 32-sample tile per CU): what such a launch costs is the serial latency of ONE tile through nine layers, and 60 % of a layer
+// was waiting for its weight fragments (phase stamps, tools/experiments/r03/k1_stamps.py: dense 5570 cycles for 48 MFMAs).
+// Here the whole layer's fragments of the wave's tile are in registers before the layer starts: stage s of the NEXT layer is
+// requested into the register slot that stage s of the running layer has just vacated (16 slots x (hi, lo) = 128 registers).
+typedef __attribute__((ext_vector_type(4))) unsigned int w8_u32x4;
+FN_DEV bf16x8 w8_bload(__amdgpu_buffer_rsrc_t r, unsigned voff, uint32_t soff) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+
+// LMAP as in p2_engine.h: 1 = the encoding alone (slots 16..18), 2 = 14 slots then the encoding; NXKS = k-steps of the next layer
+template <int PREC, int KS, int LMAP, int NXKS>
+FN_DEV void w8p_dense(bf16x8 (&wh)[17], bf16x8 (&wl)[17], const unsigned char* frag, f32x16& acc, int lane, __amdgpu_buffer_rsrc_t rsrc,
+                      unsigned voff, uint32_t nx_hi, uint32_t nx_lo, int nx_nt) {
+    constexpr int nx_ks = NXKS;
+    constexpr int NPL = PREC == 3 ? 2 : 1;
+    auto slot = [](int s) { return LMAP == 1 ? 16 + s : (LMAP == 2 ? (s < 14 ? s : s + 2) : s); };
+    const unsigned char* fl = frag + lane * 16;
+    bf16x8 bh[3], bl[3];
+    bh[0] = *reinterpret_cast<const bf16x8*>(fl + (slot(0) * NPL) * kFragBytes);
+    if constexpr (PREC == 3) bl[0] = *reinterpret_cast<const bf16x8*>(fl + (slot(0) * NPL + 1) * kFragBytes);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        if (s + 1 < KS) {
+            bh[(s + 1) % 3] = *reinterpret_cast<const bf16x8*>(fl + (slot(s + 1) * NPL) * kFragBytes);
+            if constexpr (PREC == 3) bl[(s + 1) % 3] = *reinterpret_cast<const bf16x8*>(fl + (slot(s + 1) * NPL + 1) * kFragBytes);
+        }
+        if (s >= 1) {      // (hazard note of dense_ldsb(): keep the three B buffers three register sets)
+            asm volatile("" ::"v"(bh[(s - 1) % 3]));
+            if constexpr (PREC == 3) asm volatile("" ::"v"(bl[(s - 1) % 3]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PREC == 3) {
+            acc = mfma32(wl[s], bh[s % 3], acc);
+            acc = mfma32(wh[s], bl[s % 3], acc);
+        }
+        acc = mfma32(wh[s], bh[s % 3], acc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s < nx_ks) {       // the slot is free: stage s of the next layer
+            const uint32_t f = (uint32_t)(s * nx_nt * 64) * 16u;
+            wh[s] = w8_bload(rsrc, voff, nx_hi + f);
+            if constexpr (PREC == 3) wl[s] = w8_bload(rsrc, voff, nx_lo + f);
+        }
+    }
+#pragma unroll
+    for (int s = KS; s < 17; ++s)
+        if (s < nx_ks) {
+            const uint32_t f = (uint32_t)(s * nx_nt * 64) * 16u;
+            wh[s] = w8_bload(rsrc, voff, nx_hi + f);
+            if constexpr (PREC == 3) wl[s] = w8_bload(rsrc, voff, nx_lo + f);
+        }
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+}
+
+template <int PREC>
+__global__ void __launch_bounds__(512, 2) sdf_fwd_w8p_kernel(const unsigned char* blob, PointSrc src, long N, float* __restrict__ sdf_out) {
+    __shared__ __attribute__((aligned(16))) unsigned char frag[kW8Half];
+    __shared__ float red[8 * 32];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = lane & 31, h = lane >> 5;
+    constexpr auto& LY = kSdfLayout;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(blob), 0, 0x7fffffff, 0x00020000);
+    const long tiles = (N + 31) / 32;
+    auto tile_of = [&](int l) { return (l == 3 && wave == 7) ? 6 : wave; };      // layer 3 has 7 tiles: wave 7 repeats tile 6 (not published)
+    auto bias_of = [&](int l) {
+        const f32x16 FN_GLOBAL* __restrict__ p = reinterpret_cast<const f32x16 FN_GLOBAL*>((gblob_t)blob + LY.L[l].bias);
+        return p[tile_of(l) * 2 + h];
+    };
+    for (long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        asm volatile("" : "+s"(blob));
+        w8_barrier();                                   // the previous tile's fragments and sums are consumed
+        bf16x8 wh[17], wl[17];                          // (declared per tile: while the point is encoded only layer 0's three stages are live)
+        f32x16 bias;
+        {
+            const unsigned voff0 = (unsigned)(lane + wave * 64) * 16u;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                wh[s] = w8_bload(rsrc, voff0, LY.L[0].fwd_hi + (uint32_t)(s * 8 * 64) * 16u);
+                if constexpr (PREC == 3) wl[s] = w8_bload(rsrc, voff0, LY.L[0].fwd_lo + (uint32_t)(s * 8 * 64) * 16u);
+            }
+            bias = bias_of(0);
+        }
+        if (wave == 0) {                                // the encoding: slots 16..18 (read in place by layers 0 and 4)
+            const long n = tile * 32 + r;
+            const long nc = n < N ? n : N - 1;
+            float x[3], pe[39], jc[39];
+            load_point(src, nc, x);
+            posenc<6, false>(x, pe, jc);
+            BFrag<PREC> pf[kMaxKS];
+            vec_to_bfrag<PREC, 39, 3, 0>(pe, pf, h);
+            frags_to_lds<PREC, 3>(frag, lane, 16, pf);
+        }
+        w8_barrier();
+        f32x16 acc1[1][1];
+        f32x16& acc = acc1[0][0];
+        // the eight layers written out (compile-time layer index: the register slots of the fragments keep their identity)
+        static_for<0, 8>([&](auto L_) {
+            constexpr int l = decltype(L_)::value;
+            constexpr int ln = l == 7 ? 0 : l + 1;                  // the layer whose fragments are requested meanwhile
+            constexpr int KSl = l == 0 ? 3 : (l == 4 ? 17 : 16), LMAPl = l == 0 ? 1 : (l == 4 ? 2 : 0);
+            constexpr int NXKS = l == 7 ? 0 : (ln == 4 ? 17 : 16);
+            const unsigned voff = (unsigned)(lane + tile_of(ln) * 64) * 16u;
+            acc = bias;
+            w8p_dense<PREC, KSl, LMAPl, NXKS>(wh, wl, frag, acc, lane, rsrc, voff, kSdfLayout.L[ln].fwd_hi, kSdfLayout.L[ln].fwd_lo, ln == 3 ? 7 : 8);
+            if constexpr (l < 7) bias = bias_of(ln);
+            w8_softplus<1>(acc1);
+            if constexpr (l < 7) {
+                w8_barrier();                                       // everyone has read the previous layer's fragments
+                if (!(l == 3 && wave == 7)) {
+                    unsigned char* none[1] = {nullptr};
+                    const bool valid[1] = {true};
+                    const PPLane pl = pp_lane(lane);
+                    w8_put_frags<PREC, 1, false>(frag, lane, wave, acc1, none, none, pl, valid);
+                }
+                w8_barrier();                                       // all fragments of the layer are in LDS
+            }
+        });
+        {   // sdf = b_8[0] + W_8[0, :] . h_8
+            f32x16 cw[1];
+            load_accvec<8, 0, 1>(blob, LY.extra, cw, lane, wave);
+            float p = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) p = fmaf(acc[i], cw[0][i], p);
+            p += xor32(p);
+            if (lane < 32) red[wave * 32 + lane] = p;
+            w8_barrier();
+            if (wave == 0 && lane < 32) {
+                f32x16 b8[1];
+                load_accvec<9, 8, 1>(blob, LY.L[8].bias, b8, lane);
+                float s = b8[0][0];
+#pragma unroll
+                for (int w = 0; w < 8; ++w) s += red[w * 32 + lane];
+                const long n = tile * 32 + r;
+                if (n < N) sdf_out[n] = s;
+            }
+        }
+    }
+}
+
 template <int PREC, int HB>
 static int launch_k1(const unsigned char* b, const PointSrc& src, long n_pts, float* sdf_out, hipStream_t stream) {
     static bool done = false;
@@ -314,6 +455,15 @@ int sdf_fwd_s8(const unsigned char* b, const PointSrc& src, long n_pts, float* s
         if (hb == 1) return launch_k1_s8<1, 1>(b, src, n_pts, sdf_out, stream);
     }
     return -2;
+}
+
+int sdf_fwd_w8p(const unsigned char* b, const PointSrc& src, long n_pts, float* sdf_out, int prec, hipStream_t stream) {
+    const long tiles = (n_pts + 31) / 32;
+    const dim3 grid((unsigned)(tiles < 1024 ? tiles : 1024));
+    if (prec == 3) hipLaunchKernelGGL(sdf_fwd_w8p_kernel<3>, grid, dim3(512), 0, stream, b, src, n_pts, sdf_out);
+    else if (prec == 1) hipLaunchKernelGGL(sdf_fwd_w8p_kernel<1>, grid, dim3(512), 0, stream, b, src, n_pts, sdf_out);
+    else return -2;
+    return launch_status();
 }
 
 int sdf_fwd_w8(const unsigned char* b, const PointSrc& src, long n_pts, float* sdf_out, int prec, int hb, hipStream_t stream) {

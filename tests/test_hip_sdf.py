@@ -54,10 +54,11 @@ def test_sdf_fwd_chip_filling_launch_uses_64_sample_workgroups(env, prec, tol):
     err = (out.cpu().double() - ref).abs().max().item()
     print(f"sdf_fwd (64-sample workgroups) prec={prec} max abs err {err:.3e}")
     assert err <= tol
-    # the same points in chunks below the threshold go through the other kernels: same arithmetic, same order
+    # the same points in chunks below the threshold go through the other kernels: same hidden layers, same order; the sdf row of
+    # the linear last layer is an fp32 dot product in the round-3 kernels (3-product MFMA in the round-2 ones): <= 1e-5 apart
     parts = torch.cat([ops.sdf_fwd(env["net"].blob, len(c), prec, pts=c.contiguous()) for c in xd.split(20000)])
     if prec == 3:
-        assert (out - parts).abs().max().item() <= 2e-6
+        assert (out - parts).abs().max().item() <= 1e-5
     again = ops.sdf_fwd(env["net"].blob, n, prec, pts=xd)
     assert torch.equal(out, again)                # repeatable
 
