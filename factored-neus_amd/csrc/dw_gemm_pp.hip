@@ -75,8 +75,14 @@ FN_DEV void wait_vm() {
     else static_assert(N == 0, "add the count");
 }
 
-template <int GP>
-__global__ void __launch_bounds__(256, 1) dw_gemm_pp_kernel(const GemmPPJob* __restrict__ jobs, int n_jobs, int n_tiles) {
+// DET: the workgroup's partial tile (and bias partial) goes to `scratch` [workgroup][256 x 256 + 256] with plain stores instead
+// of fp32 atomics into C; dw_gemm_pp_reduce_kernel then adds the partials of a product in split order: bit-reproducible
+// gradients (FNEUS_DETERMINISTIC=1).  The atomics of the default mode land in arrival order.
+constexpr int kDetTile = 256 * 256 + 256;
+
+template <int GP, bool DET = false>
+__global__ void __launch_bounds__(256, 1) dw_gemm_pp_kernel(const GemmPPJob* __restrict__ jobs, int n_jobs, int n_tiles,
+                                                            float* __restrict__ scratch = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using Cfg = PPCfg<GP>;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -281,6 +287,28 @@ __global__ void __launch_bounds__(256, 1) dw_gemm_pp_kernel(const GemmPPJob* __r
 #ifdef FNEUS_GPP_NO_ATOMIC
     if (n_jobs > 0) return;
 #endif
+    if constexpr (DET) {
+        float* part = scratch + (size_t)blockIdx.x * kDetTile;
+        if (row_active && col_active) {
+            const int cc = lane & 31;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = 32 * (4 * wc + j) + cc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) part[(32 * (4 * wr + i) + acc_row(r, hh)) * 256 + col] = acc[i][j][r];
+                }
+        }
+        if (do_bias && row_active) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float t = bsum[i] + xor32(bsum[i]);
+                if (lane < 32) part[256 * 256 + 32 * (4 * wr + i) + (lane & 31)] = t;
+            }
+        }
+        return;
+    }
     // ---- epilogue: fp32 atomics, two 128-byte row segments per wave instruction
     if (row_active && col_active) {
         const int cc = lane & 31;
@@ -306,9 +334,54 @@ __global__ void __launch_bounds__(256, 1) dw_gemm_pp_kernel(const GemmPPJob* __r
     }
 }
 
+// C[row][col] += scale * (partials of the product's workgroups in split order); bias[row] += the same of the bias partials
+__global__ void __launch_bounds__(256) dw_gemm_pp_reduce_kernel(const GemmPPJob* __restrict__ jobs, int n_tiles,
+                                                                const float* __restrict__ scratch) {
+    const GemmPPJob* __restrict__ jp = jobs + blockIdx.y;
+    const int m = jp->m, n = jp->n, splits = jp->splits, base = jp->wg_base;
+    const int per = (n_tiles + splits - 1) / splits;
+    const int live = (n_tiles + per - 1) / per;          // workgroups of the product that had sample tiles (the others wrote nothing)
+    const int total = m * n + (jp->bias != nullptr ? m : 0);
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const bool is_bias = idx >= m * n;
+        const int row = is_bias ? idx - m * n : idx / n, col = is_bias ? 0 : idx % n;
+        const size_t off = is_bias ? (size_t)256 * 256 + row : (size_t)row * 256 + col;
+        float sum = 0.0f;
+        for (int s = 0; s < live; ++s) sum += scratch[(size_t)(base + s) * kDetTile + off];
+        if (is_bias) atomicAdd(jp->bias + row, sum);
+        else atomicAdd(jp->c + (size_t)row * jp->ldc + col, jp->scale * sum);     // (one addend per element and launch: order-free)
+    }
+}
+
 }  // namespace fneus
 
 using namespace fneus;
+
+extern "C" int fneus_dw_gemm_pp_det(const void* jobs_dev, int n_jobs, int n_wgs, long n_sample_tiles, int gprec, float* scratch,
+                                    long scratch_floats, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (n_jobs <= 0 || n_wgs <= 0 || n_sample_tiles <= 0) return 0;
+    if (scratch == nullptr || scratch_floats < (long)n_wgs * kDetTile) {
+        fneus::set_last_error("fneus_dw_gemm_pp_det: scratch must hold n_wgs x (256 x 256 + 256) floats");
+        return -2;
+    }
+    const GemmPPJob* jobs = reinterpret_cast<const GemmPPJob*>(jobs_dev);
+    static bool attr_set = false;
+    if (!attr_set) {
+        allow_big_lds(dw_gemm_pp_kernel<1, true>);
+        allow_big_lds(dw_gemm_pp_kernel<3, true>);
+        attr_set = true;
+    }
+    if (gprec == 1)
+        hipLaunchKernelGGL((dw_gemm_pp_kernel<1, true>), dim3(n_wgs), dim3(256), PPCfg<1>::kLds, stream, jobs, n_jobs, (int)n_sample_tiles, scratch);
+    else if (gprec == 3)
+        hipLaunchKernelGGL((dw_gemm_pp_kernel<3, true>), dim3(n_wgs), dim3(256), PPCfg<3>::kLds, stream, jobs, n_jobs, (int)n_sample_tiles, scratch);
+    else
+        return -2;
+    hipLaunchKernelGGL(dw_gemm_pp_reduce_kernel, dim3(64, n_jobs), dim3(256), 0, stream, jobs, (int)n_sample_tiles, scratch);
+    return fneus::launch_status();
+}
 
 extern "C" int fneus_dw_gemm_pp(const void* jobs_dev, int n_jobs, int n_wgs, long n_sample_tiles, int gprec,
                                 fneus_stream_t stream_) {
@@ -318,14 +391,14 @@ extern "C" int fneus_dw_gemm_pp(const void* jobs_dev, int n_jobs, int n_wgs, lon
     const GemmPPJob* jobs = reinterpret_cast<const GemmPPJob*>(jobs_dev);
     static bool attr_set = false;
     if (!attr_set) {
-        allow_big_lds(dw_gemm_pp_kernel<1>);
-        allow_big_lds(dw_gemm_pp_kernel<3>);
+        allow_big_lds(dw_gemm_pp_kernel<1, false>);
+        allow_big_lds(dw_gemm_pp_kernel<3, false>);
         attr_set = true;
     }
     if (gprec == 1)
-        hipLaunchKernelGGL(dw_gemm_pp_kernel<1>, dim3(n_wgs), dim3(256), PPCfg<1>::kLds, stream, jobs, n_jobs, (int)n_sample_tiles);
+        hipLaunchKernelGGL((dw_gemm_pp_kernel<1, false>), dim3(n_wgs), dim3(256), PPCfg<1>::kLds, stream, jobs, n_jobs, (int)n_sample_tiles, (float*)nullptr);
     else if (gprec == 3)
-        hipLaunchKernelGGL(dw_gemm_pp_kernel<3>, dim3(n_wgs), dim3(256), PPCfg<3>::kLds, stream, jobs, n_jobs, (int)n_sample_tiles);
+        hipLaunchKernelGGL((dw_gemm_pp_kernel<3, false>), dim3(n_wgs), dim3(256), PPCfg<3>::kLds, stream, jobs, n_jobs, (int)n_sample_tiles, (float*)nullptr);
     else
         return -2;
     return fneus::launch_status();

@@ -82,6 +82,7 @@ def _load():
         "fneus_refcolor_bwd_both": (C.c_int, [vp, vp, l, vp, ip, vp, vp, vp, vp, vp, vp, C.POINTER(FneusColStash),
                                               C.POINTER(FneusColStash), vp, vp, ip, vp]),
         "fneus_dw_gemm_pp": (C.c_int, [vp, ip, ip, l, ip, vp]),
+        "fneus_dw_gemm_pp_det": (C.c_int, [vp, ip, ip, l, ip, vp, l, vp]),
         "fneus_nerf_bg_fwd": (C.c_int, [vp, vp, vp, l, C.POINTER(FneusNerfStash), vp, vp, ip, ip, vp]),
         "fneus_nerf_bg_bwd": (C.c_int, [vp, l, vp, vp, C.POINTER(FneusNerfStash), ip, vp]),
         "fneus_adam": (C.c_int, [C.POINTER(FneusAdamSegment), ip, vp, vp, C.c_double, C.c_double, C.c_double, ip, vp]),

@@ -45,6 +45,7 @@ def profile_end():
 # for the extra dependencies), so the default is OFF; kept as a switch for multi-queue experiments on other shapes.
 # ------------------------------------------------------------------------------------------------------------
 import os as _os
+import os
 OVERLAP_MASK = int(_os.environ.get("FNEUS_OVERLAP", "0"))
 _overlap = {"on": False, "stream": None, "used": False}
 
@@ -422,6 +423,25 @@ class PPOperand:
 GEMM_COST_FLOOR = int(_os.environ.get("FNEUS_GEMM_FLOOR", "16"))     # in 32-row tiles of A + B (a full product: 16)
 
 
+DET_TILE_FLOATS = 256 * 256 + 256          # csrc/dw_gemm_pp.hip kDetTile
+_det_scratch = {}
+_det_override = None
+
+
+def deterministic() -> bool:
+    """FNEUS_DETERMINISTIC=1 (or set_deterministic(True)): the weight-gradient GEMM sums its split-K partials in a fixed order
+    instead of with fp32 atomics; every other kernel of the step is order-fixed already, so two runs are bit-identical.
+    Read at every launch: set it before a step is captured into a hipGraph."""
+    if _det_override is not None:
+        return _det_override
+    return os.environ.get("FNEUS_DETERMINISTIC", "0") not in ("", "0")
+
+
+def set_deterministic(on: Optional[bool]):
+    global _det_override
+    _det_override = on
+
+
 class GemmPPJobs:
     """Device job table for fneus_dw_gemm_pp (include/fneus.h FneusGemmPPJob); pointers refer to live plane tensors."""
 
@@ -473,6 +493,16 @@ class GemmPPJobs:
     def run(self, *_ignored, gprec: Optional[int] = None):
         """(positional arguments are accepted and ignored: older callers passed n and prec)"""
         gprec = getattr(self, "gprec", 1) if gprec is None else gprec
+        if deterministic():
+            # bit-reproducible gradients: partial tiles to a scratch buffer, summed in split order by a second launch (the
+            # buffer is per device and shared by all job tables: launches on a stream do not overlap)
+            need = self.n_wgs * DET_TILE_FLOATS
+            buf = _det_scratch.get(self.device)
+            if buf is None or buf.numel() < need:
+                buf = _det_scratch[self.device] = torch.empty(max(need, 256 * DET_TILE_FLOATS), dtype=torch.float32, device=self.device)
+            _launch("fneus_dw_gemm_pp_det:" + self.tag, lib.fneus_dw_gemm_pp_det, _ptr(self.dev_table), len(self.jobs), self.n_wgs,
+                    self.n_sample_tiles, gprec, _ptr(buf), buf.numel(), _stream())
+            return
         _launch("fneus_dw_gemm_pp:" + self.tag, lib.fneus_dw_gemm_pp, _ptr(self.dev_table), len(self.jobs), self.n_wgs,
                 self.n_sample_tiles, gprec, _stream())
 

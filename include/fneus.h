@@ -156,6 +156,12 @@ int fneus_sdf_bwd(const void* sdf_blob, const float* pts, const float* rays_o, c
  * Replaces torch autograd's addmm backward for fields.py:86 incl. the double-backward term of fields.py:104-110.       */
 int fneus_dw_gemm_pp(const void* jobs_dev /*FneusGemmPPJob[n_jobs] on the device*/, int n_jobs, int n_wgs,
                      long n_sample_tiles, int gprec, fneus_stream_t stream);
+/* The same products with BIT-REPRODUCIBLE results (FNEUS_DETERMINISTIC=1 in the Python layer): every workgroup writes its
+ * partial tile to `scratch` (n_wgs x (256 x 256 + 256) floats, caller-owned), a second launch adds the partials of a product
+ * in split order.  The reference's addmm backward (exp_runner.py:179-181 via autograd) is deterministic on CPU; the default
+ * entry point above sums split-K partials with fp32 atomics in arrival order. */
+int fneus_dw_gemm_pp_det(const void* jobs_dev, int n_jobs, int n_wgs, long n_sample_tiles, int gprec, float* scratch,
+                         long scratch_floats, fneus_stream_t stream);
 
 /* ---- K4: RenderingNetwork.forward, mode 'idr'  (fields.py:150-175 via renderer.py:278) ---------------------- */
 /* view directions: `dirs` [n][3], or NULL -> rays_d[n/m].  train != 0 writes the stash planes for the backward.   */

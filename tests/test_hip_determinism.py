@@ -78,3 +78,64 @@ def test_color_forward_backward_are_reproducible(prec):
     for _ in range(25):
         for a, b, name in zip(run(), ref, ("rgb", "d_feat", "d_normal", "u", "zbar", "mask")):
             assert torch.equal(a, b), name
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_whole_train_step_is_bit_reproducible_in_deterministic_mode(use_graph):
+    """FNEUS_DETERMINISTIC=1 / ops.set_deterministic(True): the weight-gradient GEMM adds its split-K partials in split order
+    (fneus_dw_gemm_pp_det) instead of with fp32 atomics -- the only order-dependent sums of the step.  Two trainers with the
+    same seed on the same batches then hold bit-identical parameters after every step (the reference's CPU loop,
+    exp_runner.py:179-181, is deterministic as well); in the default mode they differ in the last bits."""
+    from fneus import ops
+    from fneus.trainer import Stage1Trainer, synthetic_batches
+    dev = torch.device("cuda:0")
+    batches = synthetic_batches(6, 512, dev, seed0=77)
+
+    def run(det):
+        ops.set_deterministic(det)
+        torch.manual_seed(1234)                       # the depth jitter of render() draws from torch's generator
+        try:
+            tr = Stage1Trainer(dev, prec=ops.PREC_PARITY, seed=31, use_graph=use_graph)
+            out = []
+            for b in batches:
+                tr.train_step(b)
+                torch.cuda.synchronize()
+                out.append(torch.cat([p.detach().reshape(-1) for p in tr.params]).clone())
+            return out
+        finally:
+            ops.set_deterministic(None)
+
+    a, b = run(True), run(True)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert torch.equal(x, y), f"step {i}: {(x != y).sum().item()} of {x.numel()} parameters differ"
+    # the deterministic sums equal the atomic ones to rounding: same trajectory to ~1e-6 relative after the first step
+    c = run(False)
+    d = (a[0] - c[0]).abs().max().item()
+    print(f"deterministic vs atomic mode after one step: max |difference| {d:.2e}")
+    assert d <= 5e-6
+
+
+def test_deterministic_gemm_equals_the_atomic_one():
+    from fneus import ops
+    net, dev = _net()
+    n = 20000
+    x = (torch.rand(n, 3, device=dev) * 2 - 1).contiguous()
+    ds, df, dn = torch.randn(n, device=dev), torch.randn(n, 256, device=dev), torch.randn(n, 3, device=dev)
+    st, bufs = ops.SdfStash(n, dev, 3, True), ops.SdfBwdBufs(n, dev, 3)
+    for t in (st.h, st.a, bufs.adj, bufs.zbar):
+        t.zero_()
+    ops.sdf_fwd_grad(net.blob, n, 3, st, True, pts=x)
+    ops.sdf_bwd(net.blob, n, 3, st, bufs, ds, df, dn, pts=x)
+    grads = []
+    for det in (False, True, True):
+        ops.set_deterministic(det)
+        try:
+            g = torch.zeros(net.n_params, dtype=torch.float32, device=dev)
+            ops.sdf_dw_jobs(net, st, bufs, g, n).run()
+            torch.cuda.synchronize()
+            grads.append(g)
+        finally:
+            ops.set_deterministic(None)
+    assert torch.equal(grads[1], grads[2])
+    scale = grads[0].abs().max().item()
+    assert (grads[0] - grads[1]).abs().max().item() <= 2e-6 * scale
