@@ -620,11 +620,113 @@ def gen_raygen(dataset, out_dir, name="raygen_dtu"):
     print(name + ".npz written")
 
 
+def write_shiny_case(case_dir, png, disp, alpha, meta, ball):
+    """the files of a Shiny-Blender case from the fixture's arrays (PNG and float TIFF are lossless): used by this generator and,
+    with the same arrays, by the tests"""
+    from PIL import Image
+    os.makedirs(case_dir, exist_ok=True)
+    with open(os.path.join(case_dir, "transforms_train.json"), "w") as fp:
+        fp.write(meta)
+    for i in range(png.shape[0]):
+        Image.fromarray(png[i]).save(os.path.join(case_dir, "r_%d.png" % i))
+        if ball:
+            Image.fromarray(alpha[i]).save(os.path.join(case_dir, "r_%d_alpha.png" % i))
+        else:
+            Image.fromarray(disp[i]).save(os.path.join(case_dir, "r_%d_disp.tiff" % i))
+
+
+def gen_raygen_shiny(dataset, out_dir, name="raygen_shiny"):
+    """DatasetShiny of the reference itself (models/dataset.py:522-662) on a small Shiny-Blender-format case written here:
+    transforms_train.json (camera_angle_x, OpenGL camera-to-world matrices at radius 5.6), r_%d.png colours, r_%d_disp.tiff
+    disparities (the `ball` variant: r_%d_alpha.png).  The reference's own rend_util.load_rgb runs (loaded from its file), with
+    imageio.imread / tifffile.imread / cv2.imread served from PIL.  Pins: linear colours, masks, intrinsics, poses (centres
+    halved, axes flipped), gen_rays_at, gen_random_rays_at (pixel draws recorded), near_far_from_sphere.  The fixture holds the
+    file CONTENTS as arrays; the tests write them back to files for the repo's loader."""
+    import json, tempfile
+    from PIL import Image
+    rs = np.random.RandomState(91)
+    n_img, H, W = 3, 24, 32
+    png = rs.randint(0, 256, size=(n_img, H, W, 3)).astype(np.uint8)
+    disp = (rs.uniform(size=(n_img, H, W)) > 0.35).astype(np.float32) * rs.uniform(0.2, 3.0, size=(n_img, H, W)).astype(np.float32)
+    alpha = np.repeat((rs.uniform(size=(n_img, H, W, 1)) > 0.4).astype(np.uint8) * 255, 3, axis=-1)
+    alpha[:, ::5, ::3] = 100                                    # values below the 0.5 threshold that are not zero
+    frames = []
+    for i in range(n_img):
+        c = rs.standard_normal(3)
+        c = 5.6 * c / np.linalg.norm(c)
+        z = c / np.linalg.norm(c)                               # OpenGL camera: looks along -z
+        x = np.cross(np.array([0.1, 0.2, 1.0]), z)
+        x /= np.linalg.norm(x)
+        y = np.cross(z, x)
+        m = np.eye(4)
+        m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3] = x, y, z, c
+        frames.append({"file_path": "r_%d" % i, "transform_matrix": m.tolist()})
+    meta = json.dumps({"camera_angle_x": 0.6911112070083618, "frames": frames})
+    # readers through PIL, the reference's own rend_util on top of them
+    imageio = types.ModuleType("imageio")
+    imageio.imread = lambda path, **kw: np.asarray(Image.open(path))
+    imageio.plugins = types.SimpleNamespace(freeimage=types.SimpleNamespace(download=lambda: None))
+    saved = {k: sys.modules.get(k) for k in ("imageio", "models.rend_util")}
+    sys.modules["imageio"] = imageio
+    rend_util = _load_by_path("ref_rend_util_for_goldens", os.path.join(REF, "models", "rend_util.py"))
+    assert rend_util.__file__.startswith(REF + "/")
+    old = (dataset.rend_util, getattr(dataset.tf, "imread", None), getattr(dataset.cv, "imread", None))
+    dataset.rend_util = rend_util
+    dataset.tf.imread = lambda path: np.array(Image.open(path), dtype=np.float32)
+    dataset.cv.imread = lambda path: np.asarray(Image.open(path).convert("RGB"))[..., ::-1].copy()      # BGR like cv2
+    orig_cuda, orig_randint, orig_avail = torch.Tensor.cuda, torch.randint, torch.cuda.is_available
+    draws = []
+
+    def randint_hook(*a, **k):
+        r = orig_randint(*a, **k)
+        draws.append(r.clone())
+        return r
+
+    class Conf(dict):
+        def get_string(self, k):
+            return self[k]
+
+    res = {"png": png, "disp": disp, "alpha": alpha, "meta": np.array(meta), "H": H, "W": W}
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.randint = randint_hook
+    torch.cuda.is_available = lambda: False
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            for ball in (False, True):
+                tag = "ball" if ball else "disp"
+                case = os.path.join(tmp, "ball_case" if ball else "case")        # ('ball' in data_dir selects the alpha masks)
+                write_shiny_case(case, png, disp, alpha, meta, ball)
+                ds = dataset.DatasetShiny(Conf(data_dir=case))
+                res[f"{tag}/images"], res[f"{tag}/masks"] = ds.images.numpy().copy(), ds.masks.numpy().copy()
+                res[f"{tag}/intrinsics_all"], res[f"{tag}/pose_all"] = ds.intrinsics_all.numpy().copy(), ds.pose_all.numpy().copy()
+                res[f"{tag}/focal"], res[f"{tag}/n_images"] = float(ds.focal), ds.n_images
+                for lvl in (1, 2):
+                    ro, rv = ds.gen_rays_at(1, resolution_level=lvl)
+                    res[f"{tag}/rays_at_l{lvl}/rays_o"], res[f"{tag}/rays_at_l{lvl}/rays_v"] = ro.numpy().copy(), rv.numpy().copy()
+                torch.manual_seed(321)
+                draws.clear()
+                out = ds.gen_random_rays_at(torch.tensor(2), 48)
+                res[f"{tag}/random/pixels_x"], res[f"{tag}/random/pixels_y"] = draws[0].numpy(), draws[1].numpy()
+                res[f"{tag}/random/out"] = out.numpy().copy()
+                near, far = ds.near_far_from_sphere(out[:, :3], out[:, 3:6])
+                res[f"{tag}/random/near"], res[f"{tag}/random/far"] = near.numpy(), far.numpy()
+    finally:
+        torch.Tensor.cuda, torch.randint, torch.cuda.is_available = orig_cuda, orig_randint, orig_avail
+        dataset.rend_util = old[0]
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), **res)
+    print(name + ".npz written")
+
+
 FIXTURES = ("units", "render_wmask_b16_n16", "render_wmask_b8_n64", "render_womask_b16_n16_o8", "render_wmask_b16_n16_c0",
             "render_wmask_b256_n32", "render_wmask_b64_n64", "render_wmask_b512_n64", "render_womask_b64_n64_o32",
             "lvis_util_b24_n32", "raygen_dtu", "lvis_render_room_b24_n32",
             "lvis_render_ball_b16_n16", "mateillu_render_b24_n32", "dtu_eval_synth", "lvis_render_room_b128_n64",
-            "mateillu_render_b128_n64")
+            "mateillu_render_b128_n64", "raygen_shiny")
 
 
 def check_against(old_dir, new_dir, names):
@@ -692,6 +794,8 @@ def main():
         gen_lvis_util(fields, renderer, args.out, "lvis_util_b24_n32", B=24, n_samples=32, n_importance=32, ray_seed=37, seeds=seeds)
     if want("raygen_dtu"):
         gen_raygen(dataset, args.out)
+    if want("raygen_shiny"):
+        gen_raygen_shiny(dataset, args.out)
     # ---- stage 2 (config 3): lvis_render + cal_indiLgt, loss, gradients and Adam steps of Lvis + IndirectLight -------------
     seeds2 = dict(seeds, lvis=24, indilgt=25)
     if want("lvis_render_room_b24_n32"):        # a room of radius 0.55 seen from within: chords beyond 1 leave without a hit

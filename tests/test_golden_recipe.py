@@ -15,7 +15,7 @@ REF = "/root/reference"
 def test_generator_imports_the_reference_and_reproduces_committed_fixtures(tmp_path):
     gen = os.path.join(ROOT, "tests", "golden", "gen_golden.py")
     # two small cases: a render fixture (one Adam step) and the stage-2/3 entry; --check compares every committed key
-    r = subprocess.run([sys.executable, gen, "--out", str(tmp_path), "--only", "render_wmask_b16_n16_c0,lvis_util_b24_n32,raygen_dtu",
+    r = subprocess.run([sys.executable, gen, "--out", str(tmp_path), "--only", "render_wmask_b16_n16_c0,lvis_util_b24_n32,raygen_dtu,raygen_shiny",
                         "--check"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "committed fixtures reproduced bit for bit" in r.stdout

@@ -322,6 +322,39 @@ def test_ray_generation_vs_reference(golden_dir):
     assert data.shape == (512, 10) and torch.allclose(data[:, 3:6].norm(dim=-1), torch.ones(512, device=dev), atol=1e-5)
 
 
+@pytest.mark.parametrize("ball", [False, True])
+def test_shiny_ray_generation_vs_reference(tmp_path, golden_dir, ball):
+    """the Shiny-Blender feeder of config 5 end to end: files -> models/dataset.py DatasetShiny (device resident) ->
+    fneus_gen_rays_grid / fneus_gen_random_rays, against the reference's own DatasetShiny on the same files
+    (tests/golden/raygen_shiny.npz; dataset.py:522-662)"""
+    import os
+    from conftest import write_shiny_case
+    from models.dataset import DatasetShiny
+    g = dict(np.load(os.path.join(golden_dir, "raygen_shiny.npz")))
+    tag = "ball" if ball else "disp"
+    dev = torch.device("cuda:0")
+
+    class Conf(dict):
+        def get_string(self, k):
+            return self[k]
+
+    ds = DatasetShiny(Conf(data_dir=write_shiny_case(str(tmp_path / ("ball_case" if ball else "case")), g, ball)), device=dev)
+    assert torch.equal(ds.masks.cpu(), torch.from_numpy(g[f"{tag}/masks"])) and torch.equal(ds.pose_all.cpu(), torch.from_numpy(g[f"{tag}/pose_all"]))
+    for lvl in (1, 2):
+        o, v = ds.gen_rays_at(1, resolution_level=lvl)
+        assert torch.equal(o.cpu(), torch.from_numpy(g[f"{tag}/rays_at_l{lvl}/rays_o"]))
+        assert (v.cpu() - torch.from_numpy(g[f"{tag}/rays_at_l{lvl}/rays_v"])).abs().max().item() <= 3e-7
+    to = lambda a: torch.from_numpy(np.asarray(a)).to(dev)
+    px, py = to(g[f"{tag}/random/pixels_x"]), to(g[f"{tag}/random/pixels_y"])
+    out = ds.gen_random_rays_at(2, len(px), pixels=(px, py)).cpu()
+    ref = torch.from_numpy(g[f"{tag}/random/out"])
+    assert torch.equal(out[:, :3], ref[:, :3]) and (out[:, 3:6] - ref[:, 3:6]).abs().max().item() <= 3e-7
+    assert (out[:, 6:9] - ref[:, 6:9]).abs().max().item() <= 1.2e-7 and torch.equal(out[:, 9], ref[:, 9])
+    near, far = ds.near_far_from_sphere(out[:, :3].to(dev), out[:, 3:6].to(dev))
+    assert (near.cpu() - torch.from_numpy(g[f"{tag}/random/near"])).abs().max().item() <= 2e-6
+    assert (far.cpu() - torch.from_numpy(g[f"{tag}/random/far"])).abs().max().item() <= 2e-6
+
+
 def test_embed_kernel_vs_the_torch_embedder():
     from models.embedder import Embedder, get_embedder
     dev = torch.device("cuda:0")

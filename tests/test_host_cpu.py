@@ -265,3 +265,58 @@ def test_shiny_blender_dataset_reads_files_like_the_reference_loader(tmp_path, b
     b = R.gen_random_rays_at(src.intrinsics_all_inv[1], src.pose_all[1], src.images[1], src.masks[1], px, py)
     assert torch.allclose(a[:, :6], b[:, :6], atol=1e-4)
     assert ds.image_at(0, 2).shape == (12, 16, 3)
+
+
+@pytest.mark.parametrize("ball", [False, True])
+def test_shiny_blender_loader_vs_the_reference_loader(tmp_path, golden_dir, ball):
+    """models/dataset.py DatasetShiny against the reference's own DatasetShiny (dataset.py:522-662) on the same files
+    (tests/golden/raygen_shiny.npz, made by tests/golden/gen_golden.py gen_raygen_shiny with the reference's rend_util.load_rgb):
+    linear colours, masks, focal length / intrinsics, poses (centres halved, OpenGL -> OpenCV axes), and the rays of
+    gen_rays_at / gen_random_rays_at / near_far_from_sphere through the oracle's formulation on the loaded cameras."""
+    from conftest import write_shiny_case
+    from models.dataset import DatasetShiny
+    from oracle import ref_torch as R
+    g = dict(np.load(os.path.join(golden_dir, "raygen_shiny.npz")))
+    tag = "ball" if ball else "disp"
+
+    class Conf(dict):
+        def get_string(self, k):
+            return self[k]
+
+    case = write_shiny_case(str(tmp_path / ("ball_case" if ball else "case")), g, ball)
+    ds = DatasetShiny(Conf(data_dir=case), device=torch.device("cpu"))
+    assert ds.n_images == int(g[f"{tag}/n_images"]) and (ds.H, ds.W) == (int(g["H"]), int(g["W"]))
+    assert abs(ds.focal - float(g[f"{tag}/focal"])) <= 1e-9 * float(g[f"{tag}/focal"])
+    assert (ds.images - torch.from_numpy(g[f"{tag}/images"])).abs().max().item() <= 1.2e-7          # (img / 255) ** 2.2 in fp32
+    assert torch.equal(ds.masks, torch.from_numpy(g[f"{tag}/masks"]))
+    assert torch.equal(ds.intrinsics_all[:, :3, :3], torch.from_numpy(g[f"{tag}/intrinsics_all"]))
+    assert torch.equal(ds.pose_all, torch.from_numpy(g[f"{tag}/pose_all"]))
+    for lvl in (1, 2):
+        o, v = R.gen_rays_at(ds.intrinsics_all_inv[1], ds.pose_all[1], ds.H, ds.W, lvl)
+        assert torch.equal(o, torch.from_numpy(g[f"{tag}/rays_at_l{lvl}/rays_o"]))
+        assert (v - torch.from_numpy(g[f"{tag}/rays_at_l{lvl}/rays_v"])).abs().max().item() <= 3e-7
+    px, py = torch.from_numpy(g[f"{tag}/random/pixels_x"]), torch.from_numpy(g[f"{tag}/random/pixels_y"])
+    out = R.gen_random_rays_at(ds.intrinsics_all_inv[2], ds.pose_all[2], ds.images[2], ds.masks[2], px, py)
+    ref = torch.from_numpy(g[f"{tag}/random/out"])
+    assert torch.equal(out[:, :3], ref[:, :3]) and (out[:, 3:6] - ref[:, 3:6]).abs().max().item() <= 3e-7
+    assert (out[:, 6:9] - ref[:, 6:9]).abs().max().item() <= 1.2e-7 and torch.equal(out[:, 9], ref[:, 9])
+    near, far = R.near_far_from_sphere(out[:, :3], out[:, 3:6])
+    assert (near - torch.from_numpy(g[f"{tag}/random/near"])).abs().max().item() <= 2e-6
+    assert (far - torch.from_numpy(g[f"{tag}/random/far"])).abs().max().item() <= 2e-6
+
+
+def test_shiny_frame_skip_keeps_images_and_masks_aligned(tmp_path, golden_dir):
+    from conftest import write_shiny_case
+    from models.dataset import DatasetShiny
+    g = dict(np.load(os.path.join(golden_dir, "raygen_shiny.npz")))
+
+    class Conf(dict):
+        def get_string(self, k):
+            return self[k]
+
+    case = write_shiny_case(str(tmp_path / "case"), g, False)
+    ds = DatasetShiny(Conf(data_dir=case), frame_skip=2, device=torch.device("cpu"))
+    assert ds.n_images == 2
+    assert torch.equal(ds.masks, torch.from_numpy(g["disp/masks"])[::2])                          # image i <-> mask i * frame_skip
+    assert (ds.images - torch.from_numpy(g["disp/images"])[::2]).abs().max().item() <= 1.2e-7
+    assert ds.image_at(0, 5).shape == (int(g["H"]) // 5, int(g["W"]) // 5, 3)                     # (H // l, W // l) like cv.resize
