@@ -142,7 +142,7 @@ def cpu_baseline(device=None):
 
 
 # newest first: the PMC passes are re-collected whenever a kernel's memory behaviour changes (tools/collect_profiles.sh)
-TRAFFIC_FILES = ("r02_e_traffic.json", "r02_d_traffic.json", "r02_c_traffic.json", "r02_b_traffic.json", "r02_a_traffic.json")
+TRAFFIC_FILES = ("r03_a_traffic.json", "r02_e_traffic.json", "r02_d_traffic.json", "r02_c_traffic.json", "r02_b_traffic.json", "r02_a_traffic.json")
 
 
 def main():
@@ -155,6 +155,10 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-fast-extra", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels eagerly instead of replaying a hipGraph")
+    ap.add_argument("--rays-global", type=int, default=0,
+                    help="STRONG scaling: this many rays per step over all ranks (config 5 quotes 2048 = 256 per GPU at 8 ranks); "
+                         "default 0 = weak scaling, 512 rays per rank")
+    ap.add_argument("--womask", action="store_true", help="womask.conf shape (+ 32 background samples per ray through the NeRF++ kernels)")
     args = ap.parse_args()
 
     # The contract is ONE JSON line on stdout.  RCCL prints a version banner through the C stdio of the process, which is
@@ -191,10 +195,25 @@ def main():
     # structure of the N > 1 step costs before any wire time; a diagnostic, not the N = 1 configuration
     dp_single = os.environ.get("FNEUS_DP_SINGLE", "0") == "1" and dist.is_initialized()
 
-    def run(prec, steps, warmup, profile):
-        tr = Stage1Trainer(device, prec=prec, distributed=(world > 1 or dp_single), use_graph=not args.no_graph)
+    strong = args.rays_global > 0
+    rays_rank = max(32, args.rays_global // world) if strong else RAYS
+    n_out = 32 if args.womask else 0
+    samples_rank = rays_rank * (N_SAMPLES + N_IMPORTANCE + n_out)
+
+    def run(prec, steps, warmup, profile, gprec=None):
+        kw = {}
+        if args.womask:
+            import copy
+            from fneus.trainer import WMASK_MODEL
+            conf = copy.deepcopy(WMASK_MODEL)
+            conf["neus_renderer"]["n_outside"] = 32
+            kw["model_conf"] = conf
+        tr = Stage1Trainer(device, prec=prec, distributed=(world > 1 or dp_single), use_graph=not args.no_graph, gprec=gprec, **kw)
         broadcast_parameters(tr.modules)
-        batches = synthetic_batches(steps + warmup + (3 if profile else 0), RAYS, device, rank=rank)
+        batches = synthetic_batches(steps + warmup + (3 if profile else 0), rays_rank, device, rank=rank)
+        step_kw = dict(cos_anneal_ratio=0.5, background_rgb=torch.ones(1, 3, device=device)) if args.womask else {}
+        _step = tr.train_step
+        tr.train_step = lambda b: _step(b, **step_kw)
         for i in range(warmup):
             tr.train_step(batches[i])
         if tr.use_graph and not tr._graphs:      # too few warm-up steps to have captured: capture now, untimed
@@ -231,7 +250,8 @@ def main():
     prec = ops.PREC_PARITY if args.prec == "parity" else ops.PREC_FAST
     dt, prof, tr = run(prec, args.steps, args.warmup, profile=not args.no_profile)
     ms_per_step = dt / args.steps * 1e3
-    value = world * SAMPLES_PER_STEP * args.steps / dt
+    value = world * samples_rank * args.steps / dt
+    gprec_run = ops.DEFAULT_GPREC if hasattr(ops, "DEFAULT_GPREC") else 1
 
     result = {
         "metric": "train-step ray-samples/s (stage-1, 512x128)",
@@ -243,12 +263,17 @@ def main():
         "ms_per_step": ms_per_step,
         "ms_per_step_median": float(np.median(run.step_ms)),      # per-step HIP events on the launch stream (this rank)
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
-        "dtype": "bf16x3 split MFMA, fp32 accumulate (1e-4 parity mode)" if prec == 3 else "bf16 MFMA, fp32 accumulate",
+        "dtype": (f"bf16x3 split MFMA (3 products per value, fp32 accumulate) in every forward and backward chain = the 1e-4 parity mode; "
+                  f"weight-gradient GEMM operands: gradient precision {gprec_run} "
+                  f"({'bf16 planes' if gprec_run == 1 else 'bf16 hi + lo planes'})") if prec == 3 else "bf16 MFMA, fp32 accumulate",
         "data": "synthetic DTU-shaped rays (one camera per step), random-init weights of the reference distributions",
-        "config": {"workload": "dtu_scan97-shaped wmask.conf stage-1 SDF+radiance train step, 512 rays x (64+64) samples, "
-                               "1xMI355X per rank", "rays_per_gpu": RAYS, "samples_per_ray": N_SAMPLES + N_IMPORTANCE,
+        "config": {"workload": (f"Shiny-Blender-shaped womask.conf stage-1 train step, {rays_rank * world} rays per step over {world} rank(s) x "
+                                f"(64+64+32) samples (BASELINE configs[4] shape)" if args.womask else
+                                f"dtu_scan97-shaped wmask.conf stage-1 SDF+radiance train step, {rays_rank} rays x (64+64) samples, "
+                                "1xMI355X per rank"), "rays_per_gpu": rays_rank, "samples_per_ray": N_SAMPLES + N_IMPORTANCE + n_out,
+                   **({"rays_global": rays_rank * world} if strong else {}),
                    "parallelism": f"dp{world} (ray-sharded replicas, the gradient arena all-reduced in place in two parts)",
                    "launch": ("eager kernel launches" if not (tr.use_graph and tr._graphs) else
                               "four hipGraph replays per step around the three collectives (loss normalisers; early part of the gradient "
@@ -257,8 +282,9 @@ def main():
         **({"diagnostic": "FNEUS_DP_SINGLE=1: data-parallel step structure with one rank"} if dp_single else {}),
         "mfma_roofline_frac_step": value / world * FLOP_TRAIN_PER_SAMPLE / (PEAK_BF16_MFMA_TFLOPS * 1e12),
     }
+    standard = not strong and not args.womask          # the extras below describe the headline workload only
 
-    if rank == 0 and prof:
+    if rank == 0 and prof and standard:
         per = {}
         for name, (n, ms) in prof.items():
             per[name] = {"launches_per_step": n / 3.0, "ms_per_step": ms / 3.0, "avg_ms": ms / n}
@@ -314,7 +340,7 @@ def main():
                               "note": "algorithmic (fp32-equivalent) FLOPs per launch / HIP-event launch duration; "
                                       "parity mode issues 3 bf16 MFMAs per algorithmic product"}
 
-    if rank == 0 and world == 1 and not args.no_fast_extra:
+    if rank == 0 and world == 1 and not args.no_fast_extra and standard:
         # forward-only render of the same batch (what validate_image runs per ray chunk), SURVEY.md section 8(d)
         fb = synthetic_batches(4, RAYS, device, rank=rank)
         for b in fb[:2]:
@@ -329,7 +355,7 @@ def main():
         result["forward_only_render"] = {"value": SAMPLES_PER_STEP / dt_r, "unit": "ray-samples/s", "ms_per_call": dt_r * 1e3,
                                          "note": "NeuSRenderer.render under no_grad, eager launches, no stash written"}
 
-    if rank == 0 and world == 1 and not args.no_fast_extra and prec == ops.PREC_PARITY:
+    if rank == 0 and world == 1 and not args.no_fast_extra and prec == ops.PREC_PARITY and standard:
         dt_f, _, _ = run(ops.PREC_FAST, max(args.steps // 2, 5), 3, profile=False)
         v = SAMPLES_PER_STEP * max(args.steps // 2, 5) / dt_f
         result["fast_bf16"] = {"value": v, "unit": "ray-samples/s", "ms_per_step": dt_f / max(args.steps // 2, 5) * 1e3,
@@ -337,7 +363,7 @@ def main():
                                "note": "same step with plain bf16 MFMA operands; NOT a 1e-4 parity mode "
                                        "(observed errors: tests/test_hip_render.py::test_fast_mode_reports_error)"}
 
-    if rank == 0 and world == 1 and not args.no_fast_extra:
+    if rank == 0 and world == 1 and not args.no_fast_extra and standard:
         # the womask configuration (cfg 5 shape): + 32 background samples per ray through the
         # NeRF++ kernels (K7); cos_anneal_ratio ramps there (a device scalar of the replayed step)
         try:
@@ -381,7 +407,7 @@ def main():
         except Exception as e:   # an extra must never take the headline number down with it
             result["womask_step"] = {"value": None, "error": repr(e)}
 
-    if rank == 0 and world == 1 and not args.no_fast_extra:
+    if rank == 0 and world == 1 and not args.no_fast_extra and standard:
         # stage 2 (BASELINE configs[2], lvis.py:132-196): 512 primary rays x (64+64), 4 secondary rays per hit point x 512
         # coarse SDF samples on K1, Lvis + IndirectLight trained with Adam.  Fixed-shape step (every ray treated as a hit point,
         # masked afterwards) replayed as one hipGraph, like the headline step.
@@ -430,6 +456,64 @@ def main():
                                              "128 light lobes x 32 directions through Lvis per hit point, SG rendering of 128 + 24 lobes"}
         except Exception as e:
             result["stage3_step"] = {"value": None, "error": repr(e)}
+
+    if rank == 0 and world == 1 and not args.no_fast_extra and standard and prec == ops.PREC_PARITY:
+        try:    # the same step with fp32-accurate weight gradients (hi + lo planes): the other pinned mode (tests/test_hip_render.py)
+            dt_g, _, _ = run(prec, max(args.steps // 2, 5), 3, profile=False, gprec=3)
+            n_g = max(args.steps // 2, 5)
+            result["exact_gradients_gprec3"] = {"value": SAMPLES_PER_STEP * n_g / dt_g, "unit": "ray-samples/s", "ms_per_step": dt_g / n_g * 1e3}
+        except Exception as e:
+            result["exact_gradients_gprec3"] = {"value": None, "error": repr(e)}
+        try:    # config 5's per-GPU share of a 2048-ray batch at 8 ranks: 256 rays (womask shape), the strong-scaling point
+            import copy
+            from fneus.trainer import WMASK_MODEL
+            conf = copy.deepcopy(WMASK_MODEL)
+            conf["neus_renderer"]["n_outside"] = 32
+            trs = Stage1Trainer(device, model_conf=conf, prec=prec, use_graph=not args.no_graph)
+            sb_ = synthetic_batches(16, 256, device, rank=rank, seed0=7000)
+            bg_ = torch.ones(1, 3, device=device)
+            for b in sb_[:5]:
+                trs.train_step(b, cos_anneal_ratio=0.5, background_rgb=bg_)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for b in sb_[5:]:
+                trs.train_step(b, cos_anneal_ratio=0.5, background_rgb=bg_)
+            torch.cuda.synchronize()
+            dt_s = (time.perf_counter() - t0) / 11
+            result["womask_256_rays_step"] = {"value": 256 * 160 / dt_s, "unit": "ray-samples/s", "ms_per_step": dt_s * 1e3,
+                                              "note": "256 rays x (64+64+32): one rank's share of configs[4]'s 2048-ray batch at 8 ranks "
+                                                      "(python bench.py --gpus 8 --rays-global 2048 --womask measures the 8-rank job)"}
+            del trs
+        except Exception as e:
+            result["womask_256_rays_step"] = {"value": None, "error": repr(e)}
+
+    if rank == 0 and world == 1 and standard and prec == ops.PREC_PARITY:
+        # observed parity errors of THIS build on THIS box against the reference's own outputs: the
+        # 512-ray x (64+64) fixture tests/golden/render_wmask_b512_n64.npz through the helpers of tests/test_hip_render.py
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import test_hip_render as thr
+            g = thr.load(os.path.join(ROOT, "tests", "golden"), "render_wmask_b512_n64")
+            out_t, _, _ = thr.run(g, 3, teacher_z=True)
+            par = {k: thr.maxerr(thr.stored(out_t[k], g) if (out_t[k].dim() >= 2 and out_t[k].shape[1] not in (1, 3)) else out_t[k],
+                                 g["out/" + k]) for k in ("color_fine", "weights", "gradients", "weight_sum", "surface_color")}
+            par["sdf"] = thr.maxerr(thr.stored(out_t["_sdf"], g), g["core/sdf"])
+            out_e, _, _ = thr.run(g, 3, teacher_z=False)
+            dz = (out_e["_z_vals"].detach().cpu() - thr.final_z(g)).abs()
+            result["parity"] = {"fixture": "tests/golden/render_wmask_b512_n64.npz (the reference's own render of 512 rays x (64+64))",
+                                "max_abs_error_teacher_forced_z": par,
+                                "z_vals_own_sampler": {"max_abs": float(dz.max()), "frac_within_1e-4": float((dz <= 1e-4).float().mean())},
+                                "color_fine_own_sampler_max_abs": thr.maxerr(out_e["color_fine"], g["out/color_fine"]),
+                                "tolerance": 1e-4}
+        except Exception as e:
+            result["parity"] = {"error": repr(e)}
+        try:
+            cj = json.load(open(os.path.join(ROOT, "profiles", "r03_chamfer.json")))
+            result["chamfer"] = {k: cj[k] for k in ("what", "steps", "seeds", "hip_mean", "hip_sd", "oracle_mean", "oracle_sd",
+                                                    "ratio_of_means", "sem_log_ratio_pct", "within_2_pct") if k in cj}
+            result["chamfer"]["source"] = "profiles/r03_chamfer.json (tools/chamfer_study.py on the builder's box; not measured in this run)"
+        except Exception:
+            pass
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

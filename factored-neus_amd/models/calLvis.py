@@ -84,13 +84,15 @@ def frozen_inv_s(deviation_network) -> float:
     return cached[1]
 
 
-def _secondary_march(origins, dirs, sdf_network, color_network, inv_s, trace=None):
-    """everything of cal_indiLgt that sees the frozen geometry: -> occlusion [R], hit colour [R,3], hit mask [R] (u8)"""
+def _secondary_march(origins, dirs, sdf_network, color_network, inv_s, trace=None, z_fine_override=None):
+    """everything of cal_indiLgt that sees the frozen geometry: -> occlusion [R], hit colour [R,3], hit mask [R] (u8).
+    z_fine_override: fine depths [R, 32] fed in instead of the 512 -> 32 re-sampling ("teacher forcing": the inverse CDF is ill
+    conditioned at flat stretches, so per-sample parity downstream is checked on the reference's own depths, as in stage 1)"""
     R = origins.shape[0]
     dev = origins.device
     z_coarse = gen_light_z(0.0, 1.0, N_COARSE, R, device=dev).contiguous()
     coarse_sdf = sdf_network.sdf_samples(RaySamples(origins, dirs, z_coarse.reshape(-1), N_COARSE)).reshape(R, N_COARSE)
-    z_fine = ops.upsample(origins, dirs, z_coarse, coarse_sdf, N_FINE, inv_s)
+    z_fine = ops.upsample(origins, dirs, z_coarse, coarse_sdf, N_FINE, inv_s) if z_fine_override is None else z_fine_override.contiguous()
     dists, mid_z = ops.sections(z_fine, SAMPLE_DIST)
     samples = RaySamples(origins, dirs, mid_z.reshape(-1), N_FINE)
     sdf, _, grad = sdf_network.value_feature_normal(samples, False)

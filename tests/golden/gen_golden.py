@@ -362,6 +362,7 @@ def gen_lvis_render(fields, renderer, out_dir, name, B, n_samples, n_importance,
         def up_hook(*a_, **k_):
             z = real["up_sample"](*a_, **k_)
             trace["z_fine"] = z.clone()
+            trace["sec_origins"] = (k_["rays_o"] if "rays_o" in k_ else a_[0]).detach().clone()      # (round 3) the secondary rays' origins: teacher-forced stage-2 test
             trace["inv_s"] = torch.as_tensor(k_["inv_s"]).clone()
             return z
 

@@ -159,6 +159,36 @@ def test_lvis_render_vs_reference(golden_dir, name):
         assert abs(prm.grad.double().norm().item() - ref_norm) <= 1e-2 * ref_norm + 1e-7, k
 
 
+@pytest.mark.parametrize("name", CASES)
+def test_secondary_march_teacher_forced(golden_dir, name):
+    """The traced ground truth with the reference's OWN fine depths fed in (trace/z_fine; the secondary rays' origins and
+    directions from the fixture as well): everything behind the 512 -> 32 inverse-CDF re-sampling -- SDF + gradient at the 32
+    mid points (K2), NeuS weights / occlusion and first hit (fneus_ray_hit), colour at the hit point (K2 + K4) -- must meet the
+    1e-4 of BASELINE.json on EVERY secondary ray, as stage 1 does with teacher-forced depths.  (With its own re-sampling the
+    path differs at a few flat-CDF outliers: test_lvis_render_vs_reference.)"""
+    from models.calLvis import _secondary_march, frozen_inv_s
+    g = load(golden_dir, name)
+    tr = build(g)
+    origins = T(g["trace/sec_origins"]).to(DEV).contiguous()
+    dirs = T(g["trace/dirs"]).reshape(-1, 3).to(DEV).contiguous()
+    assert origins.shape == dirs.shape
+    trace = {}
+    with torch.no_grad():
+        inv_s = frozen_inv_s(tr.deviation_network)
+        assert abs(inv_s - float(g["trace/inv_s"])) <= 1e-4 * inv_s
+        occu, hit_rgb, mask = _secondary_march(origins, dirs, tr.sdf_network, tr.color_network, inv_s, trace,
+                                               z_fine_override=T(g["trace/z_fine"]).to(DEV))
+    c = lambda t: t.detach().cpu()
+    assert np.array_equal(c(mask).numpy().astype(bool), g["trace/sec_sdf_mask"])
+    e_w = (c(trace["sec_weights"]) - T(g["trace/sec_weights"])).abs().max().item()
+    e_rgb = (c(hit_rgb) - T(g["trace/sec_hit_rgb"])).abs().max().item()
+    m = T(g["out/sdf_mask"])
+    gt_lvis = T(g["out/gt_lvis"])[m].reshape(-1)
+    e_vis = ((1.0 - c(occu)) - gt_lvis).abs().max().item()
+    print(f"  {name}: teacher-forced secondary march: weights {e_w:.1e}, visibility {e_vis:.1e}, hit colour {e_rgb:.1e}")
+    assert e_w <= 1e-4 and e_vis <= 1e-4 and e_rgb <= 1e-4
+
+
 def test_stage2_adam_steps_match_reference(golden_dir):
     """three training steps of lvis.py:132-196 on the reference's own direction draws"""
     g = load(golden_dir, "lvis_render_room_b24_n32")
