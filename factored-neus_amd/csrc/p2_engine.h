@@ -224,11 +224,12 @@ FN_DEV void p2_pass(const unsigned char* __restrict__ blob, __amdgpu_buffer_rsrc
                 const float y0 = fmaf(vl[2 * pi], kLn2 / kBeta, vm[2 * pi]);
                 const float y1 = fmaf(vl[2 * pi + 1], kLn2 / kBeta, vm[2 * pi + 1]);
                 if constexpr (ACT == 1) {
-                    const __bf16 h0 = (__bf16)y0, h1 = (__bf16)y1;
-                    p2_bf16x2 hv = {h0, h1};
-                    phw[e >> 1] = __builtin_bit_cast(uint32_t, hv);
+                    p2_bf16x2 hv = {(__bf16)y0, (__bf16)y1};
+                    const uint32_t pk = __builtin_bit_cast(uint32_t, hv);       // ONE v_cvt_pk_bf16_f32; the hi parts as floats
+                    phw[e >> 1] = pk;                                           // come back out of the packed word (shift / mask)
                     if constexpr (PREC == 3) {
-                        p2_bf16x2 lv = {(__bf16)(y0 - (float)h0), (__bf16)(y1 - (float)h1)};
+                        const float h0f = __builtin_bit_cast(float, pk << 16), h1f = __builtin_bit_cast(float, pk & 0xffff0000u);
+                        p2_bf16x2 lv = {(__bf16)(y0 - h0f), (__bf16)(y1 - h1f)};
                         plw[e >> 1] = __builtin_bit_cast(uint32_t, lv);
                         asm volatile("" : "+v"(phw[e >> 1]), "+v"(plw[e >> 1]));
                     } else {
