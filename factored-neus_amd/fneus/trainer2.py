@@ -197,7 +197,7 @@ class Stage2Trainer:
         self._backward_and_step(losses["loss"])
         return {"n_hit": out["sdf_mask"].sum(), **{k: v.detach() for k, v in losses.items()}}
 
-    def train_step(self, data: torch.Tensor, near=None, far=None, u_theta=None, u_z=None):
+    def train_step(self, data: torch.Tensor, near=None, far=None, u_theta=None, u_z=None, z_vals_override=None):
         """data [B,10] (dataset.py:133-151); near / far None: unit-sphere bounds.  -> loss dict, or None when no ray of
         the batch hits the surface (the reference skips such a batch, lvis.py:160-161)"""
         if self.use_graph and near is None and u_theta is None:
@@ -206,7 +206,7 @@ class Stage2Trainer:
             self.iter_step += 1
             return self._fixed_shape_step(data)
         rays_o, rays_d, _rgb, _mask = ops.split_batch(data.contiguous())
-        out = self.renderer.lvis_render(rays_o, rays_d, near, far, u_theta=u_theta, u_z=u_z)
+        out = self.renderer.lvis_render(rays_o, rays_d, near, far, u_theta=u_theta, u_z=u_z, z_vals_override=z_vals_override)
         if not bool(out["sdf_mask"].any()):
             return None
         losses = stage2_loss(out)

@@ -85,7 +85,7 @@ class Stage3Trainer:
         self._backward_and_step(losses["loss"])
         return {"n_hit": out["sdf_mask"].sum(), **{k: v.detach() for k, v in losses.items()}}
 
-    def train_step(self, data: torch.Tensor, near=None, far=None, u_theta=None, u_phi=None):
+    def train_step(self, data: torch.Tensor, near=None, far=None, u_theta=None, u_phi=None, z_vals_override=None):
         """data [B,10] (dataset.py:133-151).  -> loss dict, or None when no ray hits the surface (mateIllu.py:156)"""
         if self.use_graph and near is None and u_theta is None:
             return self._graph_step(data)
@@ -94,7 +94,7 @@ class Stage3Trainer:
             return self._fixed_shape_step(data)
         rays_o, rays_d, true_rgb, mask = ops.split_batch(data.contiguous())
         mask = (mask > 0.5).float() if self.mask_weight > 0.0 else torch.ones_like(mask)
-        out = self.renderer.mateIllu_render(rays_o, rays_d, near, far, u_theta=u_theta, u_phi=u_phi)
+        out = self.renderer.mateIllu_render(rays_o, rays_d, near, far, u_theta=u_theta, u_phi=u_phi, z_vals_override=z_vals_override)
         if not bool(out["sdf_mask"].any()):
             return None
         losses = stage3_loss(out, true_rgb, mask)

@@ -289,7 +289,7 @@ class NeuSRenderer:
             "_z_vals": z_vals, "_sdf": ret["sdf"], "_mid_z_vals": ret["mid_z_vals"],
         }
 
-    def lvis_mateIllu_render_util(self, rays_o, rays_d, near, far):
+    def lvis_mateIllu_render_util(self, rays_o, rays_d, near, far, z_vals_override=None):
         """renderer.py:503-564, the entry of the stage-2 / stage-3 renderers (lvis_render, mateIllu_render): unperturbed
         hierarchical sampling, SDF at the section mid-points and the per-ray inside-sphere mask.  Geometry is frozen in
         those stages (lvis.py:78-92 optimises the visibility / indirect-light networks only), so the SDF comes from the
@@ -303,7 +303,11 @@ class NeuSRenderer:
             z_vals = ops.ray_setup(rays_o, rays_d, self.n_samples, near=cf(near), far=cf(far))
             n = self.n_samples
             if self.n_importance > 0:
-                z_vals = self._hierarchical_z(rays_o, rays_d, z_vals.contiguous())
+                # z_vals_override (tests): the reference's own final depths instead of this sampler's ("teacher forcing", as
+                # render() offers it: the inverse CDF is ill conditioned at flat stretches and everything behind the first
+                # zero crossing -- hit point, PE10 of it, ReLU networks -- amplifies a moved depth)
+                z_vals = self._hierarchical_z(rays_o, rays_d, z_vals.contiguous()) if z_vals_override is None \
+                    else z_vals_override.detach().float().contiguous()
                 n = self.n_samples + self.n_importance
             dists, mid_z = ops.sections(z_vals.contiguous(), sample_dist)
             sdf = self.sdf_network.sdf_samples(RaySamples(rays_o, rays_d, mid_z.reshape(-1), n))
@@ -311,7 +315,7 @@ class NeuSRenderer:
             inside_sphere = torch.linalg.norm(pts, ord=2, dim=-1) < 1.0
         return {"n_samples": n, "mid_z_vals": mid_z, "sdf": sdf[:, None], "inside_sphere_mask": inside_sphere.any(dim=-1)}
 
-    def lvis_render(self, rays_o, rays_d, near, far, u_theta=None, u_z=None, trace=None, fixed_shape=False):
+    def lvis_render(self, rays_o, rays_d, near, far, u_theta=None, u_z=None, trace=None, fixed_shape=False, z_vals_override=None):
         """renderer.py:567-627: visibility / traced radiance of 4 secondary rays per visible surface point, and the
         predictions of the Lvis / IndirectLight networks.  Rows of rays without a surface hit hold 1.
         fneus_ray_hit finds the hit points.  Default: they are compacted (one host read of the hit count per step, as the
@@ -323,7 +327,7 @@ class NeuSRenderer:
         B = len(rays_o)
         dev = rays_o.device
         M = 4
-        util = self.lvis_mateIllu_render_util(rays_o, rays_d, near, far)
+        util = self.lvis_mateIllu_render_util(rays_o, rays_d, near, far, z_vals_override=z_vals_override)
         n = util["n_samples"]
         rays_o, rays_d = rays_o.detach().float().contiguous(), rays_d.detach().float().contiguous()
         with torch.no_grad():
@@ -360,7 +364,7 @@ class NeuSRenderer:
                 out[k] = out[k].index_copy(0, idx, res[k].to(out[k].dtype))
         return out
 
-    def mateIllu_render(self, rays_o, rays_d, near, far, u_theta=None, u_phi=None, fixed_shape=False):
+    def mateIllu_render(self, rays_o, rays_d, near, far, u_theta=None, u_phi=None, fixed_shape=False, z_vals_override=None):
         """renderer.py:630-726: stage 3.  Geometry (SDF), the RefColor head, Lvis and IndirectLight are frozen inputs
         (mateIllu.py:83-95 trains the EnvmapMaterialNetwork only): hit points by fneus_ray_hit, normal + feature by K2, the
         diffuse / specular split by the fused RefColor heads, all without stash.  Rows of rays without a hit hold 1.
@@ -371,7 +375,7 @@ class NeuSRenderer:
         from models.inverRender import srgb_to_linear
         B = len(rays_o)
         dev = rays_o.device
-        util = self.lvis_mateIllu_render_util(rays_o, rays_d, near, far)
+        util = self.lvis_mateIllu_render_util(rays_o, rays_d, near, far, z_vals_override=z_vals_override)
         n = util["n_samples"]
         rays_o, rays_d = rays_o.detach().float().contiguous(), rays_d.detach().float().contiguous()
         with torch.no_grad():

@@ -315,6 +315,22 @@ def stage2_reference():
     return calLvis
 
 
+
+def record_primary_z(rnd, trace):
+    """(round 3) wrap NeuSRenderer.cat_z_vals of this renderer object so that the final depths of the primary rays (the call with
+    last=True, renderer.py:543-548) land in trace["prim_z"]: stage-2 / stage-3 tests can feed them in (teacher forcing)"""
+    real_cat = rnd.cat_z_vals
+
+    def cat_hook(ro, rd, z, new_z, s, last=False):
+        z2, s2 = real_cat(ro, rd, z, new_z, s, last=last)
+        if last:
+            trace["prim_z"] = z2.detach().clone()
+        return z2, s2
+
+    rnd.cat_z_vals = cat_hook
+    return real_cat
+
+
 def gen_lvis_render(fields, renderer, out_dir, name, B, n_samples, n_importance, ray_seed, seeds, room, bias=0.5, warp=None,
                     adam_steps=3, outside_rays=0):
     """NeuSRenderer.lvis_render (renderer.py:567-627) -> cal_indiLgt (calLvis.py:339-409), the stage-2 loss of
@@ -384,11 +400,13 @@ def gen_lvis_render(fields, renderer, out_dir, name, B, n_samples, n_importance,
         glob.update(up_sample=up_hook, cal_firHit_rgb=hit_hook, compute_weight=w_hook, sample_dirs=dirs_hook)
         torch.rand = rand_hook
         torch.manual_seed(1000 + step)
+        real_cat = record_primary_z(rnd, trace)
         try:
             out = rnd.lvis_render(rays_o, rays_d, near, far)
         finally:
             torch.rand = real_rand
             glob.update(real)
+            rnd.cat_z_vals = real_cat
         sdf_mask = out["sdf_mask"]
         # lvis.py:164-170
         lvis_error = out["gt_lvis"] - out["pre_lvis"]
@@ -469,11 +487,13 @@ def gen_mateillu_render(fields, renderer, out_dir, name, B, n_samples, n_importa
         glob["get_diffuse_visibility"] = vis_hook
         torch.rand = rand_hook
         torch.manual_seed(2000 + step)
+        real_cat = record_primary_z(rnd, trace)
         try:
             out = rnd.mateIllu_render(rays_o, rays_d, near, far)
         finally:
             torch.rand = real_rand
             glob["get_diffuse_visibility"] = real_vis
+            rnd.cat_z_vals = real_cat
         sdf_mask = out["sdf_mask"]
         # mateIllu.py:152-172
         sdf_mask_sum = mask[sdf_mask].sum() + 1e-5
@@ -491,6 +511,7 @@ def gen_mateillu_render(fields, renderer, out_dir, name, B, n_samples, n_importa
             for k, v in out.items():
                 res["out/" + k] = v.detach().numpy() if torch.is_tensor(v) else np.float64(v)
             res["trace/light_vis"] = trace["light_vis"].numpy()
+            res["trace/prim_z"] = trace["prim_z"].numpy()          # (round 3) final depths of the primary rays
             for nme, p in zip(names, params):
                 res["grad_sub/" + nme] = subsample(p.grad)
                 res["grad_norm/" + nme] = np.float64(p.grad.double().norm().item())
