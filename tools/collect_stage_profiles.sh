@@ -1,0 +1,19 @@
+#!/bin/bash
+# rocprofv3 kernel statistics of the stage-2 / stage-3 / womask steps (replayed hipGraphs) into gpurun_out/<tag>_<stage>_kernel_stats.txt:
+#   tools/collect_stage_profiles.sh r03_a
+set -u
+tag=${1:-r03_x}
+root=$(cd "$(dirname "$0")/.." && pwd)
+out=$root/gpurun_out
+mkdir -p "$out"
+export TMPDIR=/tmp
+cd /tmp
+for st in stage2 stage3 womask; do
+  rm -rf /tmp/prof_$st
+  rocprofv3 --kernel-trace --stats -d /tmp/prof_$st -o k --output-format csv -- python3 "$root/tools/stage_profile_run.py" $st 20 \
+      > "$out/${tag}_${st}_run.txt" 2> "$out/${tag}_${st}_rocprof.err"
+  ks=$(find /tmp/prof_$st -name '*kernel_stats.csv' | head -1)
+  python3 "$root/tools/summarize_prof.py" "$ks" 24 > "$out/${tag}_${st}_kernel_stats.txt"
+  cat "$out/${tag}_${st}_run.txt" | tail -1
+  head -24 "$out/${tag}_${st}_kernel_stats.txt"
+done
