@@ -1161,6 +1161,9 @@ extern "C" int fneus_sdf_fwd_grad(const void* blob, const float* pts, const floa
 #endif
         const long cap = FNEUS_K2_GRID_CAP;
         dim3 g2((unsigned)(tiles < cap ? tiles : cap)), b2(256);
+        // FNEUS_K2_LDS_PAD (experiment): extra dynamic LDS so that fewer workgroups share a CU (90000: one per CU)
+        const char* pad_s = getenv("FNEUS_K2_LDS_PAD");
+        const int lds_pad = pad_s ? atoi(pad_s) : 0;
 #define FNEUS_K2TP(P, T)                                                                                              \
     do {                                                                                                              \
         static bool attr_done = false;                                                                                \
@@ -1168,7 +1171,7 @@ extern "C" int fneus_sdf_fwd_grad(const void* blob, const float* pts, const floa
             allow_big_lds(sdf_fwd_grad_tp_kernel<P, T>);                                                              \
             attr_done = true;                                                                                         \
         }                                                                                                             \
-        hipLaunchKernelGGL((sdf_fwd_grad_tp_kernel<P, T>), g2, b2, kTp2LdsTotal, stream, b, src, n_pts, st, sdf_out,       \
+        hipLaunchKernelGGL((sdf_fwd_grad_tp_kernel<P, T>), g2, b2, kTp2LdsTotal + lds_pad, stream, b, src, n_pts, st, sdf_out, \
                            feat_out, normal_out);                                                                     \
     } while (0)
         if (prec == 3 && train) FNEUS_K2TP(3, true);
@@ -1201,6 +1204,8 @@ extern "C" int fneus_sdf_bwd(const void* blob, const float* pts, const float* ra
     const int hbs = (hb_env == 1 || hb_env == 2) ? hb_env : (n_tiles32 >= 1024 ? 2 : 1);
     const long groups = (n_pts + 32 * hbs - 1) / (32 * hbs), cap = 256 * 2 * 4;
     dim3 g2((unsigned)(groups < cap ? groups : cap)), b2(256);
+    const char* pad3_s = getenv("FNEUS_K3_LDS_PAD");            // (experiment) as FNEUS_K2_LDS_PAD
+    const int lds_pad3 = pad3_s ? atoi(pad3_s) : 0;
     // FNEUS_BWD_WHI=1 (experiment, off): with bf16 gradient planes the two chains take the weights as their bf16 hi part (2
     // MFMAs per product, half the weight stream): K3 0.65 -> 0.50 ms in its 32-sample form, but the weight gradients move
     // from 3.5e-3 to 5.5e-3 of their norm (tests/test_hip_backward.py) and miss the 5e-3 bound of the golden gradient test
@@ -1215,7 +1220,7 @@ extern "C" int fneus_sdf_bwd(const void* blob, const float* pts, const float* ra
             allow_big_lds(sdf_bwd_tph_kernel<P, W, H, G>);                                                                   \
             attr_done = true;                                                                                                \
         }                                                                                                                    \
-        hipLaunchKernelGGL((sdf_bwd_tph_kernel<P, W, H, G>), g2, b2, H * kK3Half, stream, b, src, n_pts, st, bb, d_sdf, d_feat, \
+        hipLaunchKernelGGL((sdf_bwd_tph_kernel<P, W, H, G>), g2, b2, H * kK3Half + lds_pad3, stream, b, src, n_pts, st, bb, d_sdf, d_feat, \
                            d_normal);                                                                                        \
     } while (0)
     if (prec == 3 && exact) { if (hbs == 2) FNEUS_K3H(3, true, 2, 3); else FNEUS_K3H(3, true, 1, 3); }

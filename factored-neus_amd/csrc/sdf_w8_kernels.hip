@@ -344,7 +344,13 @@ __global__ void __launch_bounds__(512, 2) sdf_fwd_w8p_kernel(const unsigned char
         const f32x16 FN_GLOBAL* __restrict__ p = reinterpret_cast<const f32x16 FN_GLOBAL*>((gblob_t)blob + LY.L[l].bias);
         return p[tile_of(l) * 2 + h];
     };
+#ifdef FNEUS_W8_STAMPS
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(sdf_out + ((N + 3) & ~3L));
+#endif
     for (long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+#ifdef FNEUS_W8_STAMPS
+        const bool stamp_on = tile == blockIdx.x && blockIdx.x < 32;
+#endif
         asm volatile("" : "+s"(blob));
         w8_barrier();                                   // the previous tile's fragments and sums are consumed
         bf16x8 wh[17], wl[17];                          // (declared per tile: while the point is encoded only layer 0's three stages are live)
@@ -378,12 +384,19 @@ __global__ void __launch_bounds__(512, 2) sdf_fwd_w8p_kernel(const unsigned char
             constexpr int KSl = l == 0 ? 3 : (l == 4 ? 17 : 16), LMAPl = l == 0 ? 1 : (l == 4 ? 2 : 0);
             constexpr int NXKS = l == 7 ? 0 : (ln == 4 ? 17 : 16);
             const unsigned voff = (unsigned)(lane + tile_of(ln) * 64) * 16u;
+            W8_STAMP(0);
             acc = bias;
             w8p_dense<PREC, KSl, LMAPl, NXKS>(wh, wl, frag, acc, lane, rsrc, voff, kSdfLayout.L[ln].fwd_hi, kSdfLayout.L[ln].fwd_lo, ln == 3 ? 7 : 8);
             if constexpr (l < 7) bias = bias_of(ln);
+            W8_STAMP(1);
             w8_softplus<1>(acc1);
+#ifdef FNEUS_W8_STAMPS
+            asm volatile("" :: "v"(acc1[0][0]));
+#endif
+            W8_STAMP(2);
             if constexpr (l < 7) {
                 w8_barrier();                                       // everyone has read the previous layer's fragments
+                W8_STAMP(3);
                 if (!(l == 3 && wave == 7)) {
                     unsigned char* none[1] = {nullptr};
                     const bool valid[1] = {true};
@@ -391,6 +404,7 @@ __global__ void __launch_bounds__(512, 2) sdf_fwd_w8p_kernel(const unsigned char
                     w8_put_frags<PREC, 1, false>(frag, lane, wave, acc1, none, none, pl, valid);
                 }
                 w8_barrier();                                       // all fragments of the layer are in LDS
+                W8_STAMP(4);
             }
         });
         {   // sdf = b_8[0] + W_8[0, :] . h_8

@@ -9,7 +9,7 @@ from fneus import ops, synth
 dev = torch.device("cuda:0")
 hb, n = int(sys.argv[1]), int(sys.argv[2])
 os.environ["FNEUS_K1_W8_BIG"] = str(hb) if hb > 1 else "0"
-os.environ["FNEUS_K1_W8_SMALL"] = "1" if hb == 1 else "0"
+os.environ["FNEUS_K1_W8_SMALL"] = os.environ.get("W8_SMALL_MODE", "1") if hb == 1 else "0"
 net = ops.PackedNet("sdf", dev).load_state_dict({k: torch.from_numpy(v) for k, v in synth.sdf_state_dict(20).items()}); net.pack()
 x = (torch.rand(n, 3, device=dev) * 2 - 1).contiguous()
 n4 = (n + 3) & ~3
