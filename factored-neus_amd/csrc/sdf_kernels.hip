@@ -13,6 +13,9 @@
 #define FNEUS_K1_W8_BIG_DEFAULT 31        // round 3: two-pass pipelined kernel, 8 waves (sdf_p2_kernels.hip)
 #define FNEUS_K1_W8_SMALL_DEFAULT 2       // round 3: one tile per 8-wave workgroup, whole layers primed in registers
 #endif
+#ifndef FNEUS_K2_P2_DEFAULT
+#define FNEUS_K2_P2_DEFAULT 1
+#endif
 #ifndef FNEUS_K2_OCC
 #define FNEUS_K2_OCC 2      // workgroups per CU the tensor-parallel kernels of this file are compiled for (experiments: 3)
 #endif
@@ -300,6 +303,9 @@ __global__ void __launch_bounds__(256, FNEUS_K2_OCC) sdf_fwd_grad_tp_kernel(cons
             if (valid && lane < 32) sdf_out[n] = s1[0][0];
         }
         // ---------------- reverse sweep: g = d sdf / d u_l   ----------------
+#ifdef FNEUS_DBG_K2_NO_REVERSE      // timing experiments only
+        if (N > 0) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); continue; }
+#endif
         load_accvec<8, 0, 2>(blob, LY.extra, acc, lane, t0);                 // g_hat(h_8) = row 0 of W_8
         f32x16* qskip_lds = reinterpret_cast<f32x16*>(lds_ + kTp2Lds);     // [2][64] accumulator registers of wave 0
 
@@ -493,7 +499,8 @@ __global__ void __launch_bounds__(256, 2) sdf_fwd_tph_kernel(const unsigned char
     }
 }
 
-template <int PREC, bool TRAIN, int HB, int GP>
+// REV: the reverse sweep alone (normal, a_l planes) on the sigma' blocks a forward launch has written (sdf_p2_train_kernels.hip)
+template <int PREC, bool TRAIN, int HB, int GP, bool REV = false>
 __global__ void __launch_bounds__(256, 2) sdf_fwd_grad_tph_kernel(const unsigned char* blob, PointSrc src, long N, SdfStash st,
                                                                   float* __restrict__ sdf_out, float* __restrict__ feat_out,
                                                                   float* __restrict__ normal_out) {
@@ -521,6 +528,8 @@ __global__ void __launch_bounds__(256, 2) sdf_fwd_grad_tph_kernel(const unsigned
         }
         auto blk = [&](unsigned char* base, int slot, int hb) { return base + ((size_t)slot * tiles + tile[hb]) * kPPBlock; };
         auto sig = [&](int l, int hb) { return st.ps + ((size_t)tile[hb] * 8 + l) * kPPBlock; };
+        f32x16 acc[2][HB];
+        if constexpr (!REV) {
         // ---- positional encoding (wave 0) ----
         if (wave == 0) {
 #pragma unroll
@@ -538,7 +547,6 @@ __global__ void __launch_bounds__(256, 2) sdf_fwd_grad_tph_kernel(const unsigned
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        f32x16 acc[2][HB];
         // ---------------- forward chain ----------------
 #pragma unroll 1
         for (int l = 0; l <= 7; ++l) {
@@ -614,6 +622,7 @@ __global__ void __launch_bounds__(256, 2) sdf_fwd_grad_tph_kernel(const unsigned
             }
             tph_exchange<PREC, 2, false, HB, HALF>(frag, lane, t0, acc, f_hi, f_lo, pl, valid);
         }
+        }       // !REV
         // ---------------- reverse sweep: g = d sdf / d u_l   ----------------
         bias_h<2, HB>(blob, LY.extra, acc, lane, t0);                  // g_hat(h_8) = row 0 of W_8
 #pragma unroll 1
@@ -630,7 +639,11 @@ __global__ void __launch_bounds__(256, 2) sdf_fwd_grad_tph_kernel(const unsigned
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int sh = 0; sh < 2; ++sh)
+#ifdef FNEUS_DBG_NO_SIGLOAD             // timing experiments only
+                        for (int e = 0; e < 8; ++e) sg[i][hb][sh][e] = (unsigned short)(lane * 257 + e + l);
+#else
                         sg[i][hb][sh] = *reinterpret_cast<const u16x8*>(sig(l, hb) + (size_t)(2 * (t0 + i) + sh) * kFragBytes + lane * 16);
+#endif
             }
 #pragma unroll
             for (int hb = 0; hb < HB; ++hb)
@@ -1122,6 +1135,36 @@ extern "C" int fneus_sdf_fwd_grad(const void* blob, const float* pts, const floa
     // tiles per workgroup.  Measured at N = 65 536, parity mode: standalone 686 / 644 us against 691 us for the 32-sample
     // kernel below, but 0.55 ms against 0.50 ms inside the training step -- unlike K3, K2 has hardly any loads to batch (its
     // reverse sweep reads sigma' only), and the serial point encoding of wave 0 lengthens every group's start.
+    // Chip-filling launches (the 65 536 samples of a training step): the forward chain in the two-pass pipelined form with
+    // the stash written on the way (sdf_p2_train_kernels.hip), then the reverse sweep as a launch of its own on 64-sample
+    // workgroups.  FNEUS_K2_P2=0 keeps the fused 32-sample kernel below (read at every call so that tests can switch it).
+    const char* p2_env = getenv("FNEUS_K2_P2");
+    const int k2p2 = p2_env ? atoi(p2_env) : FNEUS_K2_P2_DEFAULT;
+    if (k2p2 && tiles >= 1024 && st.qs && (prec == 3 || prec == 1)) {
+        const int gp = (train && st.h_lo != nullptr && prec == 3) ? 3 : 1;
+        // (timing experiments: 2 = the forward launch alone, 3 = the reverse sweep alone)
+        const int rc = k2p2 == 3 ? 0 : fneus::sdf_fwd_stash_p2(b, src, n_pts, st, sdf_out, feat_out, prec, train ? gp : 0, stream);
+        if (rc || k2p2 == 2) return rc;
+        const long groups = (n_pts + 63) / 64, cap = 256 * 2 * 4;
+        dim3 g2((unsigned)(groups < cap ? groups : cap)), b2(256);
+#define FNEUS_K2REV(P, T, G)                                                                                                  \
+    do {                                                                                                                      \
+        static bool attr_done = false;                                                                                        \
+        if (!attr_done) {                                                                                                     \
+            allow_big_lds(sdf_fwd_grad_tph_kernel<P, T, 2, G, true>);                                                         \
+            attr_done = true;                                                                                                 \
+        }                                                                                                                     \
+        hipLaunchKernelGGL((sdf_fwd_grad_tph_kernel<P, T, 2, G, true>), g2, b2, 2 * kK2Half, stream, b, src, n_pts, st,       \
+                           sdf_out, feat_out, normal_out);                                                                    \
+    } while (0)
+        if (prec == 3 && train && gp == 3) FNEUS_K2REV(3, true, 3);
+        else if (prec == 3 && train) FNEUS_K2REV(3, true, 1);
+        else if (prec == 3) FNEUS_K2REV(3, false, 1);
+        else if (train) FNEUS_K2REV(1, true, 1);
+        else FNEUS_K2REV(1, false, 1);
+#undef FNEUS_K2REV
+        return fneus::launch_status();
+    }
     const char* tph_env = getenv("FNEUS_K2_TPH");
     const int hbs = tph_env ? atoi(tph_env) : 0;
     if (hbs == 1 || hbs == 2) {
