@@ -16,6 +16,9 @@
 #ifndef FNEUS_K2_P2_DEFAULT
 #define FNEUS_K2_P2_DEFAULT 1
 #endif
+#ifndef FNEUS_K2_CHUNKS_DEFAULT
+#define FNEUS_K2_CHUNKS_DEFAULT 1
+#endif
 #ifndef FNEUS_K2_OCC
 #define FNEUS_K2_OCC 2      // workgroups per CU the tensor-parallel kernels of this file are compiled for (experiments: 3)
 #endif
@@ -503,7 +506,7 @@ __global__ void __launch_bounds__(256, 2) sdf_fwd_tph_kernel(const unsigned char
 template <int PREC, bool TRAIN, int HB, int GP, bool REV = false>
 __global__ void __launch_bounds__(256, 2) sdf_fwd_grad_tph_kernel(const unsigned char* blob, PointSrc src, long N, SdfStash st,
                                                                   float* __restrict__ sdf_out, float* __restrict__ feat_out,
-                                                                  float* __restrict__ normal_out) {
+                                                                  float* __restrict__ normal_out, long grp_begin = 0, long grp_end = -1) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
     unsigned char* frag = lds_;
     constexpr int HALF = kK2Half;
@@ -514,8 +517,8 @@ __global__ void __launch_bounds__(256, 2) sdf_fwd_grad_tph_kernel(const unsigned
     const PPLane pl = pp_lane(lane);
     constexpr auto& LY = kSdfLayout;
     const long tiles = pp_tiles(N);
-    const long groups = (N + 32 * HB - 1) / (32 * HB);
-    for (long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+    const long groups = grp_end >= 0 ? grp_end : (N + 32 * HB - 1) / (32 * HB);      // this launch: groups grp_begin .. groups - 1
+    for (long grp = grp_begin + blockIdx.x; grp < groups; grp += gridDim.x) {
         asm volatile("" : "+s"(blob));
         long tile[HB], n[HB], nc[HB];
         bool valid[HB];
@@ -1083,6 +1086,7 @@ extern "C" int fneus_sdf_fwd(const void* blob, const float* pts, const float* ra
         const int w8_big = e_big ? atoi(e_big) : FNEUS_K1_W8_BIG_DEFAULT;
         const int w8_small = e_small ? atoi(e_small) : FNEUS_K1_W8_SMALL_DEFAULT;
         if (tiles >= 1024 && (w8_big == 3 || w8_big == 31)) return fneus::sdf_fwd_p2(b, src, n_pts, sdf_out, prec, w8_big == 31 ? 1 : 2, stream);   // two-pass pipelined
+        if (tiles >= 1024 && w8_big == 32) return fneus::sdf_fwd_p2h(b, src, n_pts, sdf_out, prec, stream);             // two-pass, 64-sample workgroups
         if (tiles >= 1024 && w8_big == 22) return fneus::sdf_fwd_s8(b, src, n_pts, sdf_out, prec, 2, stream);     // staggered halves
         if (tiles < 1024 && w8_small == 2) return fneus::sdf_fwd_w8p(b, src, n_pts, sdf_out, prec, stream);               // primed layers
         if (tiles < 1024 && w8_small == 11) return fneus::sdf_fwd_s8(b, src, n_pts, sdf_out, prec, 1, stream);
@@ -1142,11 +1146,14 @@ extern "C" int fneus_sdf_fwd_grad(const void* blob, const float* pts, const floa
     const int k2p2 = p2_env ? atoi(p2_env) : FNEUS_K2_P2_DEFAULT;
     if (k2p2 && tiles >= 1024 && st.qs && (prec == 3 || prec == 1)) {
         const int gp = (train && st.h_lo != nullptr && prec == 3) ? 3 : 1;
-        // (timing experiments: 2 = the forward launch alone, 3 = the reverse sweep alone)
-        const int rc = k2p2 == 3 ? 0 : fneus::sdf_fwd_stash_p2(b, src, n_pts, st, sdf_out, feat_out, prec, train ? gp : 0, stream);
-        if (rc || k2p2 == 2) return rc;
-        const long groups = (n_pts + 63) / 64, cap = 256 * 2 * 4;
-        dim3 g2((unsigned)(groups < cap ? groups : cap)), b2(256);
+        // FNEUS_K2_CHUNKS (experiment): forward and reverse launches alternate over C chunks of the samples, so that a chunk's
+        // sigma' blocks are still in the memory-side cache when its reverse sweep reads them
+        // (timing experiments: FNEUS_K2_P2 = 2: the forward launches alone, 3: the reverse sweeps alone)
+        const char* ch_env = getenv("FNEUS_K2_CHUNKS");
+        const long units = (n_pts + 127) / 128, groups = (n_pts + 63) / 64, cap = 256 * 2 * 4;
+        long chunks = ch_env ? atol(ch_env) : FNEUS_K2_CHUNKS_DEFAULT;
+        chunks = chunks < 1 ? 1 : (chunks > units / 256 ? (units / 256 > 0 ? units / 256 : 1) : chunks);
+        dim3 b2(256);
 #define FNEUS_K2REV(P, T, G)                                                                                                  \
     do {                                                                                                                      \
         static bool attr_done = false;                                                                                        \
@@ -1155,13 +1162,22 @@ extern "C" int fneus_sdf_fwd_grad(const void* blob, const float* pts, const floa
             attr_done = true;                                                                                                 \
         }                                                                                                                     \
         hipLaunchKernelGGL((sdf_fwd_grad_tph_kernel<P, T, 2, G, true>), g2, b2, 2 * kK2Half, stream, b, src, n_pts, st,       \
-                           sdf_out, feat_out, normal_out);                                                                    \
+                           sdf_out, feat_out, normal_out, g_begin, g_end);                                                    \
     } while (0)
-        if (prec == 3 && train && gp == 3) FNEUS_K2REV(3, true, 3);
-        else if (prec == 3 && train) FNEUS_K2REV(3, true, 1);
-        else if (prec == 3) FNEUS_K2REV(3, false, 1);
-        else if (train) FNEUS_K2REV(1, true, 1);
-        else FNEUS_K2REV(1, false, 1);
+        for (long c = 0; c < chunks; ++c) {
+            const long u_begin = units * c / chunks, u_end = units * (c + 1) / chunks;
+            const int rc = k2p2 == 3 ? 0 : fneus::sdf_fwd_stash_p2(b, src, n_pts, st, sdf_out, feat_out, prec, train ? gp : 0, u_begin, u_end, stream);
+            if (rc) return rc;
+            if (k2p2 == 2) continue;
+            const long g_begin = 2 * u_begin, g_end = 2 * u_end < groups ? 2 * u_end : groups;
+            if (g_end <= g_begin) continue;
+            dim3 g2((unsigned)(g_end - g_begin < cap ? g_end - g_begin : cap));
+            if (prec == 3 && train && gp == 3) FNEUS_K2REV(3, true, 3);
+            else if (prec == 3 && train) FNEUS_K2REV(3, true, 1);
+            else if (prec == 3) FNEUS_K2REV(3, false, 1);
+            else if (train) FNEUS_K2REV(1, true, 1);
+            else FNEUS_K2REV(1, false, 1);
+        }
 #undef FNEUS_K2REV
         return fneus::launch_status();
     }

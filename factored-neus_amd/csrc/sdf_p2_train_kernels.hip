@@ -18,7 +18,8 @@ namespace fneus {
 //   L8.A || act 7 B                                          L8.B || linear output A
 template <int PREC, int MODE>
 __global__ void __launch_bounds__(512, 1) sdf_fwd_stash_p2_kernel(const unsigned char* blob, PointSrc src, long N, SdfStash st,
-                                                                   float* __restrict__ sdf_out, float* __restrict__ feat_out) {
+                                                                   float* __restrict__ sdf_out, float* __restrict__ feat_out,
+                                                                   long unit_begin, long unit_end) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
     constexpr int TN = 1, NW = 8;
     constexpr bool TRAIN = MODE != 0;
@@ -28,7 +29,7 @@ __global__ void __launch_bounds__(512, 1) sdf_fwd_stash_p2_kernel(const unsigned
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int t0 = wave, r = lane & 31, h = lane >> 5;
     constexpr auto& LY = kSdfLayout;
-    const long units = (N + 127) / 128;
+    const long units = unit_end;                 // this launch: units unit_begin .. unit_end - 1 of the (N + 127) / 128
     const long tiles = pp_tiles(N);
     const PPLane pl = pp_lane(lane);
     const unsigned voff_row = (unsigned)(r * 256 + 4 * h) * 4u;
@@ -99,13 +100,13 @@ __global__ void __launch_bounds__(512, 1) sdf_fwd_stash_p2_kernel(const unsigned
     auto next_of = [&](int l) { return P2Next{LY.L[l].fwd_hi, LY.L[l].fwd_lo, LY.L[l].bias, l == 3 ? 7 : (l == 8 ? 9 : 8)}; };
     P2Prime<FNEUS_P2_DEPTH, TN> pr;
     p2_prime_all<PREC, FNEUS_P2_DEPTH, TN>(pr, blob, rsrc, lane, t0, next_of(0));
-    if ((long)blockIdx.x < units) encode(blockIdx.x);
+    if (unit_begin + (long)blockIdx.x < units) encode(unit_begin + blockIdx.x);
     p2_barrier();
     bool first = true;
 #define FNEUS_PASS(KS, NT, LMAP, ACT, L_, NX, ACCM, HBM, ACCV, HBV, TNV, SO)                                                   \
     p2_pass_st<PREC, KS, NT, LMAP, ACT, MODE>(blob, rsrc, LY.L[L_].fwd_hi, LY.L[L_].fwd_lo, pr, NX, lds_, lane, t0, ACCM, HBM, \
                                               ACCV, HBV, TNV, cw, dot, SO, pl.even, pl.odd, voff_row)
-    for (long unit = blockIdx.x; unit < units; unit += gridDim.x) {
+    for (long unit = unit_begin + blockIdx.x; unit < units; unit += gridDim.x) {
         asm volatile("" : "+s"(blob));
         // ---- layer 0 (3 k-steps on the encoding)
         if (first) {
@@ -167,7 +168,7 @@ __global__ void __launch_bounds__(512, 1) sdf_fwd_stash_p2_kernel(const unsigned
     }
 #undef FNEUS_PASS
     if (!first) {       // tail of the last unit: the linear output of set {2, 3}
-        long last = blockIdx.x;
+        long last = unit_begin + blockIdx.x;
         while (last + gridDim.x < units) last += gridDim.x;
         const P2St so = outputs(last, 8, 2);
         p2_linear_out_only<PREC, MODE>(lane, t0, accB, so, pl.even, pl.odd, voff_row);
@@ -176,26 +177,27 @@ __global__ void __launch_bounds__(512, 1) sdf_fwd_stash_p2_kernel(const unsigned
 
 template <int PREC, int MODE>
 static int launch_k2f_p2(const unsigned char* b, const PointSrc& src, long n_pts, const SdfStash& st, float* sdf_out,
-                         float* feat_out, hipStream_t stream) {
+                         float* feat_out, long unit_begin, long unit_end, hipStream_t stream) {
     static bool done = false;
     if (!done) {
         allow_big_lds(sdf_fwd_stash_p2_kernel<PREC, MODE>);
         done = true;
     }
-    const long units = (n_pts + 127) / 128;
+    const long units = unit_end - unit_begin;
+    if (units <= 0) return 0;
     hipLaunchKernelGGL((sdf_fwd_stash_p2_kernel<PREC, MODE>), dim3((unsigned)(units < 256 ? units : 256)), dim3(512),
-                       kP2LdsTotal + 4 * 8 * 32 * 4, stream, b, src, n_pts, st, sdf_out, feat_out);
+                       kP2LdsTotal + 4 * 8 * 32 * 4, stream, b, src, n_pts, st, sdf_out, feat_out, unit_begin, unit_end);
     return launch_status();
 }
 
 // mode 0: inference (sigma' blocks + sdf + features), 1 / 3: training with bf16 / hi + lo planes
 int sdf_fwd_stash_p2(const unsigned char* b, const PointSrc& src, long n_pts, const SdfStash& st, float* sdf_out, float* feat_out,
-                     int prec, int mode, hipStream_t stream) {
-    if (prec == 3 && mode == 0) return launch_k2f_p2<3, 0>(b, src, n_pts, st, sdf_out, feat_out, stream);
-    if (prec == 3 && mode == 1) return launch_k2f_p2<3, 1>(b, src, n_pts, st, sdf_out, feat_out, stream);
-    if (prec == 3 && mode == 3) return launch_k2f_p2<3, 3>(b, src, n_pts, st, sdf_out, feat_out, stream);
-    if (prec == 1 && mode == 0) return launch_k2f_p2<1, 0>(b, src, n_pts, st, sdf_out, feat_out, stream);
-    if (prec == 1 && mode == 1) return launch_k2f_p2<1, 1>(b, src, n_pts, st, sdf_out, feat_out, stream);
+                     int prec, int mode, long unit_begin, long unit_end, hipStream_t stream) {
+    if (prec == 3 && mode == 0) return launch_k2f_p2<3, 0>(b, src, n_pts, st, sdf_out, feat_out, unit_begin, unit_end, stream);
+    if (prec == 3 && mode == 1) return launch_k2f_p2<3, 1>(b, src, n_pts, st, sdf_out, feat_out, unit_begin, unit_end, stream);
+    if (prec == 3 && mode == 3) return launch_k2f_p2<3, 3>(b, src, n_pts, st, sdf_out, feat_out, unit_begin, unit_end, stream);
+    if (prec == 1 && mode == 0) return launch_k2f_p2<1, 0>(b, src, n_pts, st, sdf_out, feat_out, unit_begin, unit_end, stream);
+    if (prec == 1 && mode == 1) return launch_k2f_p2<1, 1>(b, src, n_pts, st, sdf_out, feat_out, unit_begin, unit_end, stream);
     return -2;
 }
 

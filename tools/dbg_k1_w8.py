@@ -31,7 +31,7 @@ for prec in (3, 1):
         big = n >= 1024 * 32
         variants = [("r02", dict(FNEUS_K1_W8_BIG=0, FNEUS_K1_W8_SMALL=0))]
         if big:
-            variants += [("w8 hb4", dict(FNEUS_K1_W8_BIG=4)), ("s8 hb2", dict(FNEUS_K1_W8_BIG=22)), ("p2", dict(FNEUS_K1_W8_BIG=3)), ("p2 8w", dict(FNEUS_K1_W8_BIG=31))]
+            variants += [("w8 hb4", dict(FNEUS_K1_W8_BIG=4)), ("s8 hb2", dict(FNEUS_K1_W8_BIG=22)), ("p2", dict(FNEUS_K1_W8_BIG=3)), ("p2 8w", dict(FNEUS_K1_W8_BIG=31)), ("p2h", dict(FNEUS_K1_W8_BIG=32))]
         else:
             variants += [("w8 hb1", dict(FNEUS_K1_W8_SMALL=1)), ("w8p", dict(FNEUS_K1_W8_SMALL=2))]
         line = f"prec {prec} n={n:8d}:"
