@@ -235,6 +235,49 @@ def test_64_sample_workgroups_equal_32_sample_workgroups(monkeypatch):
     assert rel <= 2e-4, rel
 
 
+@pytest.mark.parametrize("train,gprec", [(True, 1), (True, 3), (False, 1)])
+def test_k2_as_two_launches_equals_the_fused_kernel(monkeypatch, train, gprec):
+    """chip-filling launches of K2 (>= 1024 tiles) run the forward chain in the two-pass pipelined form with the stash written
+    on the way, then the reverse sweep as a launch of its own (csrc/sdf_p2_train_kernels.hip; FNEUS_K2_P2=0 keeps the fused
+    32-sample kernel, read at every call).  Same operands and summation order per accumulator: the feature rows and the
+    forward planes are bit-identical, sdf differs by the order of one 256-term sum (the sdf row is a vector dot product
+    there), sigma' by one step of its 16-bit code, and what the reverse sweep derives from sigma' by that step.  Ragged size
+    with an odd tile count; the tiles allocated beyond the samples stay zero."""
+    from fneus import ops, synth
+    n = 40003
+    net = ops.PackedNet("sdf", DEV).load_state_dict({k: T(v) for k, v in synth.sdf_state_dict(20).items()})
+    net.pack()
+    x = (torch.rand(n, 3, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3)) * 2 - 1).contiguous()
+
+    def run(p2):
+        monkeypatch.setenv("FNEUS_K2_P2", str(p2))
+        st = ops.SdfStash(n, DEV, ops.PREC_PARITY, train, gprec)
+        for t in (st.h, st.a, st.feat):
+            if t is not None:
+                t.zero_()
+        st.ps.zero_()
+        out = ops.sdf_fwd_grad(net.blob, n, ops.PREC_PARITY, st, train, pts=x)
+        torch.cuda.synchronize()
+        return out, st
+
+    (sdf0, feat0, nrm0), s0 = run(0)
+    (sdf1, feat1, nrm1), s1 = run(1)
+    assert (sdf1 - sdf0).abs().max().item() <= 1e-5
+    assert torch.equal(feat1, feat0)
+    assert (nrm1 - nrm0).abs().max().item() <= 5e-5
+    for l in range(8):
+        assert (s1.sigma(l) - s0.sigma(l)).abs().max().item() <= 2.1 / 65535.0, l
+    if train:
+        assert torch.equal(s1.pe, s0.pe) and torch.equal(s1.feat, s0.feat)
+        for l in range(8):
+            F = 14 if l == 3 else 16                        # layer 3 has 7 output tiles
+            assert torch.equal(s1.h[:, l, :, :F], s0.h[:, l, :, :F]), l
+            a1, a0 = s1.plane(s1.a[:, :, :, :F], l), s0.plane(s0.a[:, :, :, :F], l)
+            assert (a1 - a0).abs().max().item() <= (8e-3 if gprec == 1 else 1e-4) * max(a0.abs().max().item(), 1e-6), l
+        if s1.h.shape[2] > s1.tiles:                        # an allocated tile without samples
+            assert float(s1.h[:, :, s1.tiles:].float().abs().max()) == 0.0
+
+
 def test_batch_without_any_surface_hit():
     """when no ray of a batch hits a surface the reference skips the RefColor branch (renderer.py:296:
     its parameters get grad None and Adam skips them); here the branch runs at fixed shape with zero weights, so the RefColor
