@@ -55,6 +55,15 @@ if json_out:
                 w = sum(acc[k]["WRITE_SIZE"]) / len(acc[k]["WRITE_SIZE"])
                 ks[name] = {"kernel": k, "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "hbm_bytes_per_launch": (2 * f + w) * 1024}
             break           # first entry wins: sdf_fwd_grad_* must not also file under sdf_fwd
+    # entry points that are several launches: K2 = forward chain with the stash + reverse sweep (round 3)
+    for name, pre in (("fneus_sdf_fwd_grad", "sdf_fwd_stash_p2"),):
+        for k in sorted(acc):
+            if k.startswith(pre) and name in ks and "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k] and k not in ks[name]["kernel"]:
+                f = sum(acc[k]["FETCH_SIZE"]) / len(acc[k]["FETCH_SIZE"])
+                w = sum(acc[k]["WRITE_SIZE"]) / len(acc[k]["WRITE_SIZE"])
+                e = ks[name]
+                ks[name] = {"kernel": e["kernel"] + " + " + k, "FETCH_SIZE_KB": e["FETCH_SIZE_KB"] + f, "WRITE_SIZE_KB": e["WRITE_SIZE_KB"] + w,
+                            "hbm_bytes_per_launch": e["hbm_bytes_per_launch"] + (2 * f + w) * 1024}
     step = None
     if n_steps:
         tot_f = sum(sum(acc[k]["FETCH_SIZE"]) for k in acc if "FETCH_SIZE" in acc[k])
