@@ -16,7 +16,11 @@
 #include <stdlib.h>
 #include "pp_engine.h"
 #include "fneus_kernels.h"
+#include "lvis_p2.h"
 
+#ifndef FNEUS_LVIS_P2_DEFAULT
+#define FNEUS_LVIS_P2_DEFAULT 1
+#endif
 #ifndef FNEUS_LVIS_OCC
 #define FNEUS_LVIS_OCC 2      // workgroups per CU the tensor-parallel kernels of this file are compiled for (experiments: 3)
 #endif
@@ -316,6 +320,10 @@ extern "C" int fneus_lvis_visibility(const void* lvis_blob, const float* points,
     const unsigned char* b = reinterpret_cast<const unsigned char*>(lvis_blob);
     const long items = (long)n_pts * ((n_lobes + fneus::kLvisChunk - 1) / fneus::kLvisChunk);
     const unsigned grid = (unsigned)(items < 8192 ? items : 8192);
+    // two-pass pipelined kernel on 8-wave workgroups (lvis_p2_kernels.hip); FNEUS_LVIS_P2=0: the 4-wave kernels of this file
+    const char* p2_env = getenv("FNEUS_LVIS_P2");
+    if ((p2_env ? atoi(p2_env) : FNEUS_LVIS_P2_DEFAULT) != 0 && (prec == 3 || prec == 1))
+        return fneus::lvis_visibility_p2(b, points, normals, dirs, weights, point_mask, n_pts, n_lobes, vis, prec, stream);
     const char* env = getenv("FNEUS_LVIS_HB");            // 2 (default): two lobes share a pass over the weights; 1: one lobe per pass
     if (!(env && env[0] == '1')) {
         if (prec == 3) {

@@ -1,0 +1,251 @@
+// Per-lobe light visibility of stage 3 (lvis_kernels.hip; reference models/inverRender.py:128-192 on the Lvis network of
+// models/fields.py:338-369) in the two-pass pipelined form of p2_engine.h: the same tiles ((point, lobe) pair = 32 directions),
+// operands and per-accumulator summation order as lvis_visibility_tph_kernel.
+//
+// A work item is a (point, chunk of 32 lobes) pair as there; its lobes that face the point (about half) are listed first, then
+// taken four at a time: a unit = 4 tiles in two sets A = {0, 1}, B = {2, 3}, 8 waves, wave w owns output tile w of every layer.
+//   L0.A || tail of the previous unit (ReLU of layer 3, set B -> dot)      L0.B || ReLU 0 A
+//   Ll.A || ReLU l-1 B                                                      Ll.B || ReLU l A       (l = 1..3; ReLU 3 -> dot)
+// The last layer (256 -> 1) is a vector dot product on the accumulators + a fixed-order sum over the waves through LDS (as the
+// sdf row of K1), followed by the sigmoid and the weighted average over the tile's 32 directions.
+// LDS per tile: slots 0..15 the running layer's input (layer 0: 4 k-steps PE10(point), 2 k-steps PE4(direction)); slot 16 of
+// tile j keeps k-step j of the item's point encoding (copied into every tile of every unit).
+#include <stdlib.h>
+#include "p2_engine.h"
+#include "fneus_kernels.h"
+#include "lvis_p2.h"
+
+namespace fneus {
+
+#ifndef FNEUS_LVIS_P2_CHUNK
+#define FNEUS_LVIS_P2_CHUNK 64
+#endif
+constexpr int kLvisP2Chunk = FNEUS_LVIS_P2_CHUNK;            // lobes per work item (<= 64: one ballot)
+constexpr int kLvisP2Red = kP2LdsTotal;                      // float [4 tiles][8 waves][32]
+constexpr int kLvisP2List = kP2LdsTotal + 4 * 8 * 32 * 4;    // int act[64], int list[64]
+constexpr int kLvisP2LdsTotal = kLvisP2List + 128 * 4;
+static_assert(kLvisP2Chunk % 8 == 0 && kLvisP2Chunk <= 64, "the chunk's lobes are tested by 8 waves and listed by one ballot");
+
+// k-step ks of PE10(point) as one B fragment (lvis_kernels.hip posenc3_frag)
+template <int PREC>
+FN_DEV void lvis_p2_posenc3(const float (&x)[3], int ks, int h, BFrag<PREC>& out) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int f = 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3);
+        float val = 0.0f;
+        if (f < 63) {
+            const int g = f - 3;
+            const int c = f < 3 ? f : (g % 3);
+            const float xc = c == 0 ? x[0] : (c == 1 ? x[1] : x[2]);
+            if (f < 3) {
+                val = xc;
+            } else {
+                float sn, cs;
+                sincosf(xc * (float)(1 << (g / 6)), &sn, &cs);
+                val = ((g % 6) >= 3) ? cs : sn;
+            }
+        }
+        if constexpr (PREC == 3) {
+            __bf16 a, b;
+            split_bf16(val, a, b);
+            out.hi[j] = a;
+            out.lo[j] = b;
+        } else {
+            out.hi[j] = (__bf16)val;
+        }
+    }
+}
+
+template <int PREC>
+__global__ void __launch_bounds__(512, 1) lvis_visibility_p2_kernel(const unsigned char* blob, const float* __restrict__ points,
+                                                                    const float* __restrict__ normals,
+                                                                    const float* __restrict__ dirs /*[M][32][3]*/,
+                                                                    const float* __restrict__ weights /*[M][32]*/,
+                                                                    const unsigned char* __restrict__ point_mask, int n_pts,
+                                                                    int n_lobes, float* __restrict__ vis /*[M][n_pts]*/) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
+    constexpr int TN = 1, NW = 8;
+    constexpr int NPL = PREC == 3 ? 2 : 1;
+    float* red = reinterpret_cast<float*>(lds_ + kLvisP2Red);
+    int* act = reinterpret_cast<int*>(lds_ + kLvisP2List);
+    int* list = act + 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int t0 = wave, r = lane & 31, h = lane >> 5;
+    constexpr auto& LY = kLvisLayout;
+    const int n_chunks = (n_lobes + kLvisP2Chunk - 1) / kLvisP2Chunk;
+    const __amdgpu_buffer_rsrc_t rsrc = p2_rsrc(blob);
+    auto next_of = [&](int l) { return P2Next{LY.L[l].fwd_hi, LY.L[l].fwd_lo, LY.L[l].bias, 8}; };
+    P2Prime<FNEUS_P2_DEPTH, TN> pr;
+    p2_prime_all<PREC, FNEUS_P2_DEPTH, TN>(pr, blob, rsrc, lane, t0, next_of(0));
+    f32x16 accA[TN][2], accB[TN][2], cw[TN];
+    float dot[2] = {0.0f, 0.0f};
+    auto load_cw = [&]() { load_accvec<8, 0, TN>(blob, LY.extra, cw, lane, t0); };   // the row of the last layer in accumulator layout
+    for (long item = blockIdx.x; item < (long)n_pts * n_chunks; item += gridDim.x) {
+        asm volatile("" : "+s"(blob));
+        const int pt = (int)(item / n_chunks), lobe0 = (int)(item - (long)pt * n_chunks) * kLvisP2Chunk;
+        const int lobe1 = lobe0 + kLvisP2Chunk < n_lobes ? lobe0 + kLvisP2Chunk : n_lobes;
+        if (point_mask && point_mask[pt] == 0) {          // a ray without a surface hit (fixed-shape step): nothing to evaluate
+            for (int lobe = lobe0 + (int)threadIdx.x; lobe < lobe1; lobe += blockDim.x) vis[(size_t)lobe * n_pts + pt] = 0.0f;
+            continue;
+        }
+        float x[3], nrm[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            x[c] = points[pt * 3 + c];
+            nrm[c] = normals[pt * 3 + c];
+        }
+        auto faces = [&](int lobe) {                      // direction r of the lobe on the normal's side (inverRender.py:169)
+            const float* d = dirs + ((size_t)lobe * 32 + r) * 3;
+            return (nrm[0] * d[0] + nrm[1] * d[1] + nrm[2] * d[2]) > 1e-6f;
+        };
+        // ---- the lobes of the chunk with at least one direction facing the point, in order
+        constexpr int PER = kLvisP2Chunk / 8;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int lobe = lobe0 + PER * wave + k;
+            const bool any = lobe < lobe1 && __ballot(faces(lobe < lobe1 ? lobe : lobe0)) != 0ull;
+            if (lane == 0) act[PER * wave + k] = any ? 1 : 0;
+        }
+        p2_barrier();
+        const unsigned long long am = __ballot(lane < kLvisP2Chunk && act[lane] != 0);
+        const unsigned alo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)am);
+        const unsigned ahi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(am >> 32));
+        const unsigned long long amask = ((unsigned long long)ahi << 32) | alo;
+        const int n_active = __builtin_popcountll(amask);
+        if (wave == 0 && lane < kLvisP2Chunk) {
+            if ((amask >> lane) & 1ull) list[__builtin_popcountll(amask & ((1ull << lane) - 1ull))] = lobe0 + lane;
+            else if (lobe0 + lane < lobe1) vis[(size_t)(lobe0 + lane) * n_pts + pt] = 0.0f;      // the whole lobe faces away
+        }
+        if (wave < 4) {                                   // k-step `wave` of the point's encoding -> slot 16 of tile `wave`
+            BFrag<PREC> one;
+            lvis_p2_posenc3<PREC>(x, wave, h, one);
+            unsigned char* dst = lds_ + wave * kP2Half + (16 * NPL) * kFragBytes + lane * 16;
+            *reinterpret_cast<bf16x8*>(dst) = one.hi;
+            if constexpr (PREC == 3) *reinterpret_cast<bf16x8*>(dst + kFragBytes) = one.lo;
+        }
+        p2_barrier();
+        if (n_active == 0) continue;
+        const int n_units = (n_active + 3) >> 2;
+        auto lobe_of = [&](int idx) { return __builtin_amdgcn_readfirstlane(list[idx < n_active ? idx : n_active - 1]); };
+        auto encode = [&](int unit, int ta, int tb) {     // waves ta .. tb: the 6 input k-steps of tile `wave` of the unit
+            if (wave < ta || wave > tb) return;
+            unsigned char* tile = lds_ + wave * kP2Half + lane * 16;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned char* src = lds_ + j * kP2Half + (16 * NPL) * kFragBytes + lane * 16;
+                *reinterpret_cast<bf16x8*>(tile + (j * NPL) * kFragBytes) = *reinterpret_cast<const bf16x8*>(src);
+                if constexpr (PREC == 3)
+                    *reinterpret_cast<bf16x8*>(tile + (j * NPL + 1) * kFragBytes) = *reinterpret_cast<const bf16x8*>(src + kFragBytes);
+            }
+            const int lobe = lobe_of(4 * unit + wave);
+            float d[3], pe[27], jc[27];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) d[c] = dirs[((size_t)lobe * 32 + r) * 3 + c];
+            posenc<4, false>(d, pe, jc);
+            BFrag<PREC> tmp[kMaxKS];
+            vec_to_bfrag<PREC, 27, 2, 0>(pe, tmp, h);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                *reinterpret_cast<bf16x8*>(tile + ((4 + j) * NPL) * kFragBytes) = tmp[j].hi;
+                if constexpr (PREC == 3) *reinterpret_cast<bf16x8*>(tile + ((4 + j) * NPL + 1) * kFragBytes) = tmp[j].lo;
+            }
+        };
+        auto put_dot = [&](int hb0) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float p = dot[k] + xor32(dot[k]);
+                if (lane < 32) red[((hb0 + k) * NW + wave) * 32 + lane] = p;
+                dot[k] = 0.0f;
+            }
+        };
+        auto finish = [&](int unit, int hb0) {            // waves hb0, hb0 + 1: output of tile `wave` -> sigmoid -> weighted average
+            if (wave < hb0 || wave > hb0 + 1) return;
+            const int idx = 4 * unit + wave;
+            if (idx >= n_active) return;
+            const int lobe = lobe_of(idx);
+            f32x16 b4[1];
+            load_accvec<1, 0, 1>(blob, LY.L[4].bias, b4, lane);
+            float s = b4[0][0];
+#pragma unroll
+            for (int k = 0; k < NW; ++k) s += red[(wave * NW + k) * 32 + r];
+            const float w = weights[(size_t)lobe * 32 + r];
+            float num = (h == 0 && faces(lobe)) ? w / (1.0f + expf(-s)) : 0.0f;      // fields.py:358 sigmoid; :183 zero when back-facing
+            float den = h == 0 ? w : 0.0f;
+#pragma unroll
+            for (int sft = 16; sft >= 1; sft >>= 1) {
+                num += __shfl_xor(num, sft, 64);
+                den += __shfl_xor(den, sft, 64);
+            }
+            if (lane == 0) vis[(size_t)lobe * n_pts + pt] = num / (den + 1e-6f);    // inverRender.py:188
+        };
+        encode(0, 0, 3);
+        p2_barrier();
+#define LVIS_PASS(KS, ACT, L_, NX, ACCM, HBM, ACCV, HBV)                                                                     \
+    p2_pass<PREC, KS, 8, 0, ACT, TN>(blob, rsrc, LY.L[L_].fwd_hi, LY.L[L_].fwd_lo, pr, NX, lds_, lane, t0, ACCM, HBM, ACCV, HBV, \
+                                     TN, cw, dot)
+#pragma unroll 1
+        for (int unit = 0; unit < n_units; ++unit) {
+            asm volatile("" : "+s"(blob));
+            if (unit > 0) {
+                load_cw();
+                LVIS_PASS(6, 4, 0, next_of(0), accA, 0, accB, 2);
+                put_dot(2);
+            } else {
+                LVIS_PASS(6, 0, 0, next_of(0), accA, 0, accB, 2);
+            }
+            p2_barrier();
+            if (unit > 0) finish(unit - 1, 2);
+            LVIS_PASS(6, 3, 0, next_of(1), accB, 2, accA, 0);
+            p2_barrier();
+#pragma unroll 1
+            for (int l = 1; l <= 3; ++l) {
+                asm volatile("" : "+s"(blob));
+                const P2Next same = next_of(l), following = next_of(l == 3 ? 0 : l + 1);
+                LVIS_PASS(16, 3, l, same, accA, 0, accB, 2);
+                p2_barrier();
+                if (l == 3) {
+                    load_cw();
+                    LVIS_PASS(16, 4, l, following, accB, 2, accA, 0);
+                    put_dot(0);
+                    if (unit + 1 < n_units) encode(unit + 1, 0, 1);      // set A's slots: last read by pass A of this layer
+                } else {
+                    LVIS_PASS(16, 3, l, following, accB, 2, accA, 0);
+                }
+                p2_barrier();
+            }
+            finish(unit, 0);
+            if (unit + 1 < n_units) encode(unit + 1, 2, 3);             // set B's slots: last read by pass B of layer 3
+        }
+#undef LVIS_PASS
+        load_cw();
+        p2_valu_only<PREC, 4, TN>(lds_, lane, t0, accB, 2, TN, cw, dot);
+        put_dot(2);
+        p2_barrier();
+        finish(n_units - 1, 2);
+        p2_barrier();                                     // red / list / the parked encoding are free for the next item
+    }
+}
+
+template <int PREC>
+static int launch_lvis_p2(const unsigned char* b, const float* points, const float* normals, const float* dirs, const float* weights,
+                          const unsigned char* point_mask, int n_pts, int n_lobes, float* vis, hipStream_t stream) {
+    static bool done = false;
+    if (!done) {
+        allow_big_lds(lvis_visibility_p2_kernel<PREC>);
+        done = true;
+    }
+    const long items = (long)n_pts * ((n_lobes + kLvisP2Chunk - 1) / kLvisP2Chunk);
+    hipLaunchKernelGGL((lvis_visibility_p2_kernel<PREC>), dim3((unsigned)(items < 2048 ? items : 2048)), dim3(512), kLvisP2LdsTotal,
+                       stream, b, points, normals, dirs, weights, point_mask, n_pts, n_lobes, vis);
+    return launch_status();
+}
+
+int lvis_visibility_p2(const unsigned char* b, const float* points, const float* normals, const float* dirs, const float* weights,
+                       const unsigned char* point_mask, int n_pts, int n_lobes, float* vis, int prec, hipStream_t stream) {
+    if (prec == 3) return launch_lvis_p2<3>(b, points, normals, dirs, weights, point_mask, n_pts, n_lobes, vis, stream);
+    if (prec == 1) return launch_lvis_p2<1>(b, points, normals, dirs, weights, point_mask, n_pts, n_lobes, vis, stream);
+    return -2;
+}
+
+}  // namespace fneus

@@ -127,7 +127,8 @@ FN_DEV void p2_prime_all(P2Prime<D, TN>& pr, const unsigned char* __restrict__ b
 //   Operand requests: slots 0..3 the weight fragments of k-step s + D (or the next pass's first stages), slots 4..7 the B
 //   fragments of k-step s + 1.
 // ACT: 0 none; 1 softplus -> B fragments of the next layer (k-steps 2 (t0 + i) + sh of tiles hbV, hbV + 1);
-//      2 softplus -> partial dot product with cw (the sdf row of the linear last layer), added to dot[]
+//      2 softplus -> partial dot product with cw (the sdf row of the linear last layer), added to dot[];
+//      3 / 4: the same with ReLU instead of the softplus (the stage-2 visibility network, lvis_kernels.hip)
 template <int PREC, int KS, int NT_TOTAL, int LMAP, int ACT, int TN = 2>
 FN_DEV void p2_pass(const unsigned char* __restrict__ blob, __amdgpu_buffer_rsrc_t rsrc, uint32_t off_hi, uint32_t off_lo,
                     P2Prime<FNEUS_P2_DEPTH, TN>& pr, const P2Next& nx, unsigned char* lds, int lane, int t0, f32x16 (&accM)[TN][2], int hbM,
@@ -135,6 +136,7 @@ FN_DEV void p2_pass(const unsigned char* __restrict__ blob, __amdgpu_buffer_rsrc
     constexpr int NPL = PREC == 3 ? 2 : 1;
     constexpr int D = FNEUS_P2_DEPTH;
     constexpr int NV = TN * 32;                          // values of accV per lane: TN tiles x 2 sample tiles x 16
+    constexpr bool RELU = ACT >= 3, FRAGS = ACT == 1 || ACT == 3;
     static_assert(KS >= D, "a pass consumes its D primed stages");
     const unsigned voff = (unsigned)(lane + t0 * 64) * 16u;
 #pragma unroll
@@ -202,13 +204,17 @@ FN_DEV void p2_pass(const unsigned char* __restrict__ blob, __amdgpu_buffer_rsrc
                 constexpr int i = g >> 2, hb = (g >> 1) & 1, sh = g & 1;
                 if constexpr (phase == 0) {
                     const float z = vv[i][hb][8 * sh + e];
+                    if constexpr (RELU) {
+                        asm volatile("v_max_f32 %0, 0, %1" : "=v"(vm[vi]) : "v"(z));
+                    } else {
 #ifdef FNEUS_DBG_CHEAP_ACT
-                    ve[vi] = 0.0f;
+                        ve[vi] = 0.0f;
 #else
-                    ve[vi] = fast_exp2(-fabsf(z) * (kBeta * kLog2e));
+                        ve[vi] = fast_exp2(-fabsf(z) * (kBeta * kLog2e));
 #endif
-                    asm volatile("v_max_f32 %0, 0, %2" : "=v"(vm[vi]), "+v"(ve[vi]) : "v"(z));   // max(z, 0) in ONE instruction
-                } else {
+                        asm volatile("v_max_f32 %0, 0, %2" : "=v"(vm[vi]), "+v"(ve[vi]) : "v"(z));   // max(z, 0) in ONE instruction
+                    }
+                } else if constexpr (!RELU) {
 #ifdef FNEUS_DBG_CHEAP_ACT
                     vl[vi] = ve[vi];
 #else
@@ -221,9 +227,9 @@ FN_DEV void p2_pass(const unsigned char* __restrict__ blob, __amdgpu_buffer_rsrc
                 constexpr int v = 2 * (p0 + pi);
                 constexpr int g = v >> 3, e = v & 7;
                 constexpr int i = g >> 2, hb = (g >> 1) & 1, sh = g & 1;
-                const float y0 = fmaf(vl[2 * pi], kLn2 / kBeta, vm[2 * pi]);
-                const float y1 = fmaf(vl[2 * pi + 1], kLn2 / kBeta, vm[2 * pi + 1]);
-                if constexpr (ACT == 1) {
+                const float y0 = RELU ? vm[2 * pi] : fmaf(vl[2 * pi], kLn2 / kBeta, vm[2 * pi]);
+                const float y1 = RELU ? vm[2 * pi + 1] : fmaf(vl[2 * pi + 1], kLn2 / kBeta, vm[2 * pi + 1]);
+                if constexpr (FRAGS) {
                     p2_bf16x2 hv = {(__bf16)y0, (__bf16)y1};
                     const uint32_t pk = __builtin_bit_cast(uint32_t, hv);       // ONE v_cvt_pk_bf16_f32; the hi parts as floats
                     phw[e >> 1] = pk;                                           // come back out of the packed word (shift / mask)
@@ -356,6 +362,7 @@ template <int PREC, int ACT, int TN = 2>
 FN_DEV void p2_valu_only(unsigned char* lds, int lane, int t0, f32x16 (&accV)[TN][2], int hbV, int tnV, const f32x16 (&cw)[TN],
                          float (&dot)[2]) {
     constexpr int NPL = PREC == 3 ? 2 : 1;
+    constexpr bool RELU = ACT >= 3, FRAGS = ACT == 1 || ACT == 3;
     unsigned char* flV = lds + hbV * kP2Half + lane * 16;
 #pragma unroll
     for (int g = 0; g < 4 * TN; ++g) {
@@ -363,8 +370,8 @@ FN_DEV void p2_valu_only(unsigned char* lds, int lane, int t0, f32x16 (&accV)[TN
         bf16x8 ph, pl;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float y = softplus100(accV[i][hb][8 * sh + e]);
-            if constexpr (ACT == 1) {
+            const float y = RELU ? fmaxf(accV[i][hb][8 * sh + e], 0.0f) : softplus100(accV[i][hb][8 * sh + e]);
+            if constexpr (FRAGS) {
                 if constexpr (PREC == 3) {
                     __bf16 a, b2;
                     split_bf16(y, a, b2);
@@ -377,7 +384,7 @@ FN_DEV void p2_valu_only(unsigned char* lds, int lane, int t0, f32x16 (&accV)[TN
                 dot[hb] = fmaf(y, cw[i][8 * sh + e], dot[hb]);
             }
         }
-        if constexpr (ACT == 1) {
+        if constexpr (FRAGS) {
             if (i < tnV) {
                 const int ks = 2 * (t0 + i) + sh;
                 *reinterpret_cast<bf16x8*>(flV + hb * kP2Half + (ks * NPL) * kFragBytes) = ph;

@@ -341,6 +341,8 @@ def build_lvis_jobs():
             kmap = _lim(feat, n_in)
         b.frag(fwd_hi, fwd_lo, offV[l], n_in, ksf, ntf, 0, rowmap, kmap, 1.0, -1)
         b.accvec(bias, offB[l], 1, ntf, rowmap)
+    # the single row of the last layer in accumulator layout (the two-pass kernel takes 256 -> 1 as a vector dot product)
+    b.accvec(ly.extra, offV[4], 1, 8, np.arange(256))
     jobs, maps, units = b.finish()
     return {"layout": ly, "jobs": jobs, "maps": maps, "units": units, "n_params": 0, "offW": offV, "offb": offB,
             "ins": LVIS_IN, "outs": LVIS_OUT, "n_raw": total_raw, "offB": offB, "offG": [None] * 5, "offV": offV,

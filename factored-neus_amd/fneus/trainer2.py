@@ -83,6 +83,13 @@ class Stage2Trainer:
     def _init_step_mode(self, use_graph: bool, lr: float, distributed: bool = False):
         import os
         from fneus.seggraph import SegmentedStep
+        # The distilled MLPs of stages 2 / 3 are torch modules on <= 2048 rows.  MEASURED (MI355X, PyTorch 2.10 + ROCm 7):
+        # the default BLAS backend (hipBLASLt) runs their weight-gradient products -- [256, 512] x [512, 256] -- as ONE
+        # 256 x 256 macro tile on one CU: 118 us each, 0.36 ms of a stage-3 step; rocBLAS takes 6.7 us
+        # (tools/experiments/r03/blaslt_test.py).  FNEUS_TORCH_BLAS=keep leaves the process-wide setting alone.
+        blas = os.environ.get("FNEUS_TORCH_BLAS", "cublas")
+        if blas != "keep" and self.device.type == "cuda":
+            torch.backends.cuda.preferred_blas_library(blas)
         self.distributed = bool(distributed)
         self.reduce = None
         self.grads = None
