@@ -175,6 +175,37 @@ def test_fused_lvis_visibility_vs_library_path():
     assert (again - got).abs().max().item() > 1e-3
 
 
+def test_visibility_two_pass_kernel_equals_the_four_wave_kernel(monkeypatch):
+    """fneus_lvis_visibility runs the two-pass pipelined kernel (csrc/lvis_p2_kernels.hip: 8 waves, four (point, lobe) tiles per
+    unit, facing lobes listed first; FNEUS_LVIS_P2=0 selects the 4-wave kernels, read at every call).  Same operands and
+    summation order per accumulator, the last layer as a vector dot product: equal to rounding-order noise.  Ragged lobe
+    count (100: two chunks, the second one short, unit padding), masked points, lobes that face away."""
+    from fneus import synth
+    from models.fields import Lvis
+    dev = torch.device(DEV)
+    net = Lvis()
+    net.load_state_dict({k: T(v) for k, v in synth.lvis_state_dict(31).items()})
+    net.to(dev)
+    g = torch.Generator().manual_seed(5)
+    n, M = 77, 100
+    pts = (torch.randn(n, 3, generator=g) * 0.35).to(dev)
+    nrm = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(dev)
+    axes = torch.nn.functional.normalize(torch.randn(M, 1, 3, generator=g), dim=-1)
+    dirs = torch.nn.functional.normalize(axes + 0.25 * torch.randn(M, 32, 3, generator=g), dim=-1).to(dev).contiguous()
+    w = torch.rand(M, 32, generator=g).to(dev).contiguous()
+    mask = (torch.rand(n, generator=g) > 0.2).to(dev)
+    out = {}
+    for p2 in (0, 1):
+        monkeypatch.setenv("FNEUS_LVIS_P2", str(p2))
+        out[p2] = (net.visibility(pts, nrm, dirs, w), net.visibility(pts, nrm, dirs, w, point_mask=mask))
+    for a, b in zip(out[0], out[1]):
+        assert (a - b).abs().max().item() <= 2e-6
+        assert torch.equal(a == 0, b == 0)
+    away = (out[1][0] == 0).float().mean().item()
+    assert 0.2 < away < 0.8, away                              # both branches of the back-face test are exercised
+    assert bool((out[1][1][:, ~mask] == 0).all())
+
+
 def test_fixed_shape_render_matches_the_reference_and_the_graph_step_trains(golden_dir):
     """mateIllu_render(fixed_shape=True) -- every ray evaluated, masked afterwards, latent sparsity averaged over the hit points
     -- gives the reference's outputs and loss; the trainer's hipGraph mode replays that step"""
