@@ -74,7 +74,7 @@ class Stage3Trainer:
     from fneus.trainer2 import Stage2Trainer as _S2
     _init_step_mode, set_lr, get_lr, _graph_step = _S2._init_step_mode, _S2.set_lr, _S2.get_lr, _S2._graph_step
     optimizer_state_dict, load_optimizer_state_dict = _S2.optimizer_state_dict, _S2.load_optimizer_state_dict
-    _backward_and_step, _reduce = _S2._backward_and_step, _S2._reduce
+    _backward_and_step, _reduce, _clear_grads = _S2._backward_and_step, _S2._reduce, _S2._clear_grads
     del _S2
 
     def _fixed_shape_step(self, data: torch.Tensor):
@@ -98,7 +98,9 @@ class Stage3Trainer:
         if not bool(out["sdf_mask"].any()):
             return None
         losses = stage3_loss(out, true_rgb, mask)
-        self.optimizer.zero_grad(set_to_none=True)
+        self._clear_grads()
+        if self.grads is not None:
+            self.grads.restore_small_grads()
         losses["loss"].backward()
         self.optimizer.step()
         self.iter_step += 1
