@@ -63,6 +63,24 @@ def test_sdf_fwd_chip_filling_launch_uses_64_sample_workgroups(env, prec, tol):
     assert torch.equal(out, again)                # repeatable
 
 
+@pytest.mark.parametrize("big", [31, 3, 32, 4, 22, 0])
+def test_sdf_fwd_every_chip_filling_kernel_form(env, big, monkeypatch):
+    """the forms of K1 for launches of >= 1024 tiles that are in the tree (FNEUS_K1_W8_BIG, read at every call): 31 two-pass
+    pipelined layers on 8 waves (the default), 3 on 4 waves, 32 on 64-sample workgroups, 4 eight waves in lockstep, 22 staggered
+    halves, 0 the round-2 kernel -- all against the fp64 oracle at the 1e-4 bar, repeatable, ragged size"""
+    ops, R = env["ops"], env["R"]
+    monkeypatch.setenv("FNEUS_K1_W8_BIG", str(big))
+    rs = np.random.RandomState(13)
+    n = 40003
+    x = T(rs.uniform(-1.1, 1.1, size=(n, 3)).astype(np.float32))
+    ref = R.sdf_only(x.double(), {"W": [w.double() for w in env["p"]["W"]], "b": [b.double() for b in env["p"]["b"]],
+                                  "scale": 1.0})[:, 0]
+    xd = x.to(env["dev"]).contiguous()
+    out = ops.sdf_fwd(env["net"].blob, n, 3, pts=xd)
+    assert (out.cpu().double() - ref).abs().max().item() <= 1e-4
+    assert torch.equal(out, ops.sdf_fwd(env["net"].blob, n, 3, pts=xd))
+
+
 def test_sdf_fwd_ray_mode(env):
     ops, R = env["ops"], env["R"]
     dev = env["dev"]
