@@ -511,7 +511,7 @@ def main():
             cj = json.load(open(os.path.join(ROOT, "profiles", "r03_chamfer.json")))
             result["chamfer"] = {k: cj[k] for k in ("what", "steps", "seeds", "hip_mean", "hip_sd", "oracle_mean", "oracle_sd",
                                                     "ratio_of_means", "sem_log_ratio_pct", "within_2_pct") if k in cj}
-            result["chamfer"]["source"] = "profiles/r03_chamfer.json (tools/chamfer_study.py on the builder's box; not measured in this run)"
+            result["chamfer"]["source"] = "profiles/r03_chamfer.json (tests/checkers/chamfer_study.py on the builder's box; not measured in this run)"
         except Exception:
             pass
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """womask: dL/d(raw density) of the background NeRF per sample, HIP path vs the CPU restatement (teacher-forced depths)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "factored-neus_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: F401
 import test_hip_render as H

@@ -12,8 +12,8 @@ Usage: python tools/experiments/r03/num_schemes.py
 """
 import math, sys, os
 import numpy as np, torch
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "../../../factored-neus_amd"))
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "../../.."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "../../factored-neus_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "../.."))
 from fneus import synth
 from oracle import ref_torch as R
 

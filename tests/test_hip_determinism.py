@@ -1,5 +1,5 @@
 """Repeated launches of the chain kernels must be bit-identical (no atomics on these paths): a guard against data races
-between the wavefronts of a workgroup (tools/dbg_race.py found one in the opt-in tensor-parallel K2 this way)."""
+between the wavefronts of a workgroup (tests/checkers/dbg_race.py found one in the opt-in tensor-parallel K2 this way)."""
 import numpy as np
 import pytest
 import torch

@@ -123,13 +123,13 @@ def test_reconstruction_matches_oracle_training_on_the_synthetic_scene():
 
 
 def test_chamfer_at_equal_steps_hip_vs_oracle_over_seeds():
-    """BASELINE.json metric, second half (Chamfer-L1 within 2 % of the reference at equal steps): tools/chamfer_study.py over
+    """BASELINE.json metric, second half (Chamfer-L1 within 2 % of the reference at equal steps): tests/checkers/chamfer_study.py over
     3 seeds x 1200 steps here (8 seeds x 2000 steps: profiles/r03_chamfer.json, mean ratio 1.002, standard error 1.7 %).  The
     HIP path runs in deterministic mode, so the numbers are reproducible; per seed the two paths see the same weights, batches
     and learning-rate schedule.  Seed-to-seed s.d. of one path is 3-6 % of its mean, so with 3 seeds the ratio of the means is
     resolved to ~4 %: the bound is 3 standard errors."""
     import importlib.util, os, types
-    spec = importlib.util.spec_from_file_location("chamfer_study", os.path.join(os.path.dirname(__file__), "..", "tools", "chamfer_study.py"))
+    spec = importlib.util.spec_from_file_location("chamfer_study", os.path.join(os.path.dirname(__file__), "checkers", "chamfer_study.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     res = mod.run_study(types.SimpleNamespace(seeds=3, steps=1200, rays=512, res=96, gprec=1, seed0=300))
