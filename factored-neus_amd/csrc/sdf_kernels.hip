@@ -8,6 +8,7 @@
 #include "pp_engine.h"
 #include "fneus_kernels.h"
 #include "sdf_w8.h"
+#include "s_prefetch.h"
 
 #ifndef FNEUS_K1_W8_BIG_DEFAULT
 #define FNEUS_K1_W8_BIG_DEFAULT 31        // round 3: two-pass pipelined kernel, 8 waves (sdf_p2_kernels.hip)
@@ -518,6 +519,7 @@ __global__ void __launch_bounds__(256, 2) sdf_fwd_grad_tph_kernel(const unsigned
     constexpr auto& LY = kSdfLayout;
     const long tiles = pp_tiles(N);
     const long groups = grp_end >= 0 ? grp_end : (N + 32 * HB - 1) / (32 * HB);      // this launch: groups grp_begin .. groups - 1
+    uint32_t spf = 0;                    // scalar prefetch in flight (s_prefetch.h)
     for (long grp = grp_begin + blockIdx.x; grp < groups; grp += gridDim.x) {
         asm volatile("" : "+s"(blob));
         long tile[HB], n[HB], nc[HB];
@@ -662,6 +664,17 @@ __global__ void __launch_bounds__(256, 2) sdf_fwd_grad_tph_kernel(const unsigned
             } else {
                 tph_exchange<PREC, 2, true, HB, HALF>(frag, lane, t0, acc, a_hi, a_lo, pl, valid);
             }
+#ifdef FNEUS_K2_SPF      // experiment (s_prefetch.h): 307-316 us against 284 without -- every LDS wait of the dense phase
+                         // (lgkmcnt(N)) then also waits for the 64 scalar loads, i.e. for HBM, at the phase's start
+            if constexpr (REV && HB == 2) {
+                s_prefetch_done(spf);                     // (the exchange above ended with lgkmcnt(0) + barrier)
+                // sigma' of the NEXT layer of the sweep (or of the next group's first one) -> L2 while this layer's MFMAs run:
+                // wave w takes 8 KiB of the 2 x 16 KiB
+                const int wv = __builtin_amdgcn_readfirstlane(wave);
+                const long nt = l > 0 ? tile[wv >> 1] : tile[wv >> 1] + (long)gridDim.x * HB;
+                if (nt < tiles) spf = s_prefetch_8k(st.ps + ((size_t)nt * 8 + (l > 0 ? l - 1 : 7)) * kPPBlock + (wv & 1) * 8192);
+            }
+#endif
             if (l == 0) break;
             if (l == 4) {   // 9 row tiles: 0..6 -> g_hat(h_4), 7..8 -> q_skip (PE part of the skip input; wave hb for half hb)
 #pragma unroll
