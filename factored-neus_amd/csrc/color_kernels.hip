@@ -21,6 +21,12 @@
 #define FNEUS_COL_OCC 2      // workgroups per CU the tensor-parallel kernels of this file are compiled for (experiments: 3)
 #endif
 
+#include "color_p2.h"
+
+#ifndef FNEUS_COL_P2_DEFAULT
+#define FNEUS_COL_P2_DEFAULT 1
+#endif
+
 namespace fneus {
 
 template <int TN>
@@ -682,6 +688,14 @@ static int launch_fwd(const void* blob, const float* pts, const float* rays_o, c
     const unsigned char* b = reinterpret_cast<const unsigned char*>(blob);
     ColStash st = stash ? ColStash(*stash) : ColStash();
     if (train && VAR != VAR_COLOR && !st.feat_hi) return -2;
+    if (VAR == VAR_COLOR && (n_pts + 31) / 32 >= 1024 && (prec == 3 || prec == 1)) {
+        // chip-filling launches: the two-pass pipelined kernel (color_p2_kernels.hip); FNEUS_COL_P2=0 keeps the 4-wave kernels
+        const char* p2_env = getenv("FNEUS_COL_P2");
+        if ((p2_env ? atoi(p2_env) : FNEUS_COL_P2_DEFAULT) != 0) {
+            const int mode = !train ? 0 : ((st.u_lo != nullptr && prec == 3) ? 3 : 1);
+            return fneus::color_fwd_p2(b, src, n_pts, dirs, normal, feat, st, out, prec, mode, stream);
+        }
+    }
     if (VAR == VAR_COLOR && col_use_hb2((n_pts + 31) / 32)) {
         dim3 g2(tp_grid((n_pts + 63) / 64));
         if (prec == 3 && train) FNEUS_TPH_LAUNCH((color_fwd_tph_kernel<3, true, 2>), g2, b, src, n_pts, dirs, normal, feat, st, out);

@@ -80,7 +80,7 @@ struct LayerOff {
 template <int NL>
 struct NetLayout {
     LayerOff L[NL];
-    uint32_t extra;   // SDF, Lvis: row 0 of the last layer in accumulator layout (8 tiles x 2 x 16 fp32)
+    uint32_t extra;   // SDF, Lvis: row 0 of the last layer in accumulator layout (8 tiles x 2 x 16 fp32); colour: its 3 rows
     uint32_t total;
 };
 
@@ -101,7 +101,7 @@ constexpr NetLayout<NL> make_layout(const LayerGeom (&g)[NL], int extra_bytes) {
 }
 
 constexpr NetLayout<kSdfLayers> kSdfLayout = make_layout<kSdfLayers>(kSdfGeom, 8 * 2 * 16 * 4);
-constexpr NetLayout<kColLayers> kColLayout = make_layout<kColLayers>(kColGeom, 0);
+constexpr NetLayout<kColLayers> kColLayout = make_layout<kColLayers>(kColGeom, 3 * 8 * 2 * 16 * 4);      // extra: the 3 rows of the last layer
 constexpr NetLayout<kNerfLayers> kNerfLayout = make_layout<kNerfLayers>(kNerfGeom, 0);
 constexpr NetLayout<kLvisLayers> kLvisLayout = make_layout<kLvisLayers>(kLvisGeom, 8 * 2 * 16 * 4);     // extra: row 0 of the last layer
 

@@ -227,6 +227,10 @@ def build_color_jobs(COL_IN=COL_IN, COL_OUT=COL_OUT, N_SIDE=N_SIDE, weight_norm=
             rowmap_r = _lim(rin, n_in)
         b.frag(rev_hi, rev_lo, offV[l], n_in, ksr, ntr, 1, rowmap_r, kmap_r, 1.0, rs)
         b.accvec(bias, offB[l], 1, ntf, rowmap)
+    # the (<= 3) rows of the last layer in accumulator layout: the two-pass forward kernel takes 256 -> 3 as vector dot products
+    for r in range(min(COL_OUT[4], 3)):
+        b.accvec(ly.extra + r * 8 * 2 * 16 * 4, offV[4] + r * COL_IN[4], 1, 8, np.arange(256),
+                 rs_base=(rbase[4] + r) if weight_norm else -1, rs_mode=2)
     jobs, maps, units = b.finish()
     segs = np.array([(offb[l], offB[l], COL_OUT[l], 0) for l in range(5)], dtype=np.int32)
     return {"layout": ly, "jobs": jobs, "maps": maps, "units": units, "n_params": total, "offW": offW, "offb": offb,

@@ -194,8 +194,9 @@ def test_64_sample_workgroups_equal_32_sample_workgroups(monkeypatch):
     dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(dev)
     cot = torch.randn(n, 3, generator=g).to(dev)
 
-    def run_color(hb):
+    def run_color(hb, p2=0):
         monkeypatch.setenv("FNEUS_COL_HB", str(hb))
+        monkeypatch.setenv("FNEUS_COL_P2", str(p2))
         for p in list(sdf.parameters()) + list(col.parameters()):
             p.grad = None
         s = RaySamples(pts=pts, dirs=dirs)
@@ -209,6 +210,13 @@ def test_64_sample_workgroups_equal_32_sample_workgroups(monkeypatch):
     rgb1, gc1, gs1 = run_color(1)
     assert (rgb2 - rgb1).abs().max().item() <= 1e-6
     for a, b, name in ((gc2, gc1, "colour"), (gs2, gs1, "sdf")):
+        rel = ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+        assert rel <= 2e-4, (name, rel)
+    # the forward in the two-pass pipelined form (csrc/color_p2_kernels.hip, the default for such launches; FNEUS_COL_P2=0 above):
+    # same hidden layers, the 256 -> 3 output layer as vector dot products; its planes and ReLU masks feed the same backward
+    rgbp, gcp, gsp = run_color(2, p2=1)
+    assert (rgbp - rgb2).abs().max().item() <= 2e-6
+    for a, b, name in ((gcp, gc2, "colour"), (gsp, gs2, "sdf")):
         rel = ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
         assert rel <= 2e-4, (name, rel)
     # ---- background NeRF (K7) ----
