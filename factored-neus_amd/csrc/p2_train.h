@@ -23,6 +23,9 @@ struct P2St {                               // uniform per pass.  The vector wor
 };                                          //   hi, lo: plane blocks (h_l or the feature plane, stride 1 block)
                                             //   vmask: per lane, the sample of tile hb is inside the launch
 
+#ifndef FNEUS_P2_TRAIN_GS
+#define FNEUS_P2_TRAIN_GS 2
+#endif
 // buffer descriptor of an output region (raw buffer: stride 0, num_records = bytes that may be written)
 FN_DEV __amdgpu_buffer_rsrc_t p2_out_rsrc(unsigned char* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)bytes, 0x00020000);
@@ -84,7 +87,7 @@ FN_DEV void p2_pass_st(const unsigned char* __restrict__ blob, __amdgpu_buffer_r
         constexpr int s = decltype(S_)::value;
         constexpr int NSLOT = (PREC == 3 ? 6 : 2) * TN;
         constexpr int NP = NV / 2;
-        constexpr int GS = 2;               // pairs per group: the phases run group by group (a k-step of layer 0 has 5-6 pairs:
+        constexpr int GS = FNEUS_P2_TRAIN_GS;   // pairs per group: the phases run group by group (a k-step of layer 0 has 5-6 pairs:
                                             // phase-major over all of them keeps ~70 temporaries alive)
         float ve[2 * GS], vm[2 * GS], vl[2 * GS], vr[2 * GS], vq[2 * GS];
         constexpr int p0 = (s * NP + KS - 1) / KS;
