@@ -243,8 +243,8 @@ def test_64_sample_workgroups_equal_32_sample_workgroups(monkeypatch):
     assert rel <= 2e-4, rel
 
 
-@pytest.mark.parametrize("train,gprec", [(True, 1), (True, 3), (False, 1)])
-def test_k2_as_two_launches_equals_the_fused_kernel(monkeypatch, train, gprec):
+@pytest.mark.parametrize("train,gprec,prec", [(True, 1, 3), (True, 3, 3), (False, 1, 3), (True, 1, 1)])
+def test_k2_as_two_launches_equals_the_fused_kernel(monkeypatch, train, gprec, prec):
     """chip-filling launches of K2 (>= 1024 tiles) run the forward chain in the two-pass pipelined form with the stash written
     on the way, then the reverse sweep as a launch of its own (csrc/sdf_p2_train_kernels.hip; FNEUS_K2_P2=0 keeps the fused
     32-sample kernel, read at every call).  Same operands and summation order per accumulator: the feature rows and the
@@ -259,20 +259,21 @@ def test_k2_as_two_launches_equals_the_fused_kernel(monkeypatch, train, gprec):
 
     def run(p2):
         monkeypatch.setenv("FNEUS_K2_P2", str(p2))
-        st = ops.SdfStash(n, DEV, ops.PREC_PARITY, train, gprec)
+        st = ops.SdfStash(n, DEV, prec, train, gprec)
         for t in (st.h, st.a, st.feat):
             if t is not None:
                 t.zero_()
         st.ps.zero_()
-        out = ops.sdf_fwd_grad(net.blob, n, ops.PREC_PARITY, st, train, pts=x)
+        out = ops.sdf_fwd_grad(net.blob, n, prec, st, train, pts=x)
         torch.cuda.synchronize()
         return out, st
 
     (sdf0, feat0, nrm0), s0 = run(0)
     (sdf1, feat1, nrm1), s1 = run(1)
-    assert (sdf1 - sdf0).abs().max().item() <= 1e-5
+    fast = prec == 1        # bf16 mode (not a parity mode): the sdf row is an fp32 dot product here, a bf16 MFMA there
+    assert (sdf1 - sdf0).abs().max().item() <= (5e-3 if fast else 1e-5)
     assert torch.equal(feat1, feat0)
-    assert (nrm1 - nrm0).abs().max().item() <= 5e-5
+    assert (nrm1 - nrm0).abs().max().item() <= (1e-2 if fast else 5e-5)
     for l in range(8):
         assert (s1.sigma(l) - s0.sigma(l)).abs().max().item() <= 2.1 / 65535.0, l
     if train:
