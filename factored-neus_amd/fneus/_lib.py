@@ -44,6 +44,16 @@ class FneusAdamSegment(C.Structure):
                 ("count", C.c_long)]
 
 
+class FneusPackTask(C.Structure):
+    _fields_ = [("jobs", C.c_void_p), ("n_jobs", C.c_int), ("n_units", C.c_int), ("maps", C.c_void_p), ("params", C.c_void_p),
+                ("rowscale", C.c_void_p), ("invnorm", C.c_void_p), ("blob", C.c_void_p), ("rows", C.c_void_p), ("n_rows", C.c_int)]
+
+
+class FneusWnTask(C.Structure):
+    _fields_ = [("rows", C.c_void_p), ("n_rows", C.c_int), ("bias_segs", C.c_void_p), ("n_segs", C.c_int), ("raw", C.c_void_p),
+                ("rowscale", C.c_void_p), ("invnorm", C.c_void_p), ("d_eff", C.c_void_p), ("d_raw", C.c_void_p)]
+
+
 class FneusGemmPPJob(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("a_hi", "a_lo", "b_hi", "b_lo", "a2_hi", "a2_lo", "b2_hi", "b2_lo")] + \
                [(n, C.c_uint32) for n in ("a_blk", "b_blk", "a2_blk", "b2_blk")] + \
@@ -66,6 +76,8 @@ def _load():
         "fneus_layout": (C.c_int, [ip, vp, ip]),
         "fneus_pack": (C.c_int, [vp, ip, ip, vp, vp, vp, vp, vp]),
         "fneus_rowscale": (C.c_int, [vp, ip, vp, vp, vp, vp]),
+        "fneus_refresh_multi": (C.c_int, [C.POINTER(FneusPackTask), ip, vp]),
+        "fneus_wn_backward_multi": (C.c_int, [C.POINTER(FneusWnTask), ip, vp]),
         "fneus_wn_backward": (C.c_int, [vp, ip, vp, ip, vp, vp, vp, vp, vp, vp]),
         "fneus_sdf_fwd": (C.c_int, [vp, vp, vp, vp, vp, ip, l, vp, ip, vp]),
         "fneus_sdf_fwd_grad": (C.c_int, [vp, vp, vp, vp, vp, ip, l, C.POINTER(FneusSdfStash), vp, vp, vp, ip, ip, vp]),

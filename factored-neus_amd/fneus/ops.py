@@ -118,6 +118,74 @@ def _chk_f32(t: torch.Tensor, name: str):
         raise ValueError(f"{name} must be a contiguous float32 CUDA tensor")
 
 
+# Networks whose pack() was called inside `with batched_refresh():` are folded and packed by ONE fneus_refresh_multi call at the
+# end of the block (two launches for all of them instead of one or two each: a training step re-packs 4-5 networks at its
+# start).  FNEUS_PACK_BATCH=0 keeps the per-network launches.
+_pack_batch = None
+PACK_BATCH = _os.environ.get("FNEUS_PACK_BATCH", "1") != "0"
+
+
+class batched_refresh:
+    def __enter__(self):
+        global _pack_batch
+        self.outer = _pack_batch
+        if PACK_BATCH and _pack_batch is None and PROFILE is None:
+            _pack_batch = []
+        return self
+
+    def __exit__(self, *exc):
+        global _pack_batch
+        if self.outer is None and _pack_batch is not None:
+            nets, _pack_batch = _pack_batch, None
+            if exc[0] is None and nets:
+                if len(nets) == 1:
+                    nets[0].pack()
+                else:
+                    tasks = (_lib.FneusPackTask * len(nets))()
+                    for t, n in zip(tasks, nets):
+                        wn = n.desc.get("weight_norm", True)
+                        t.jobs, t.n_jobs, t.n_units, t.maps = n.jobs.data_ptr(), n.n_jobs, n.units, n.maps.data_ptr()
+                        t.params, t.blob = n.raw.data_ptr(), n.blob.data_ptr()
+                        t.rowscale = n.rowscale.data_ptr() if n.rowscale.numel() else None
+                        t.invnorm = n.invnorm.data_ptr() if n.invnorm.numel() else None
+                        t.rows, t.n_rows = (n.rows.data_ptr(), n.n_rows) if wn and n.n_rows else (None, 0)
+                    check(lib.fneus_refresh_multi(tasks, len(nets), _stream()), "fneus_refresh_multi")
+        return False
+
+
+# The same for fneus_wn_backward: inside `with batched_wn_backward():` (around loss.backward() of a single-GPU step: only the
+# optimiser reads the raw gradients) the calls are collected and launched once at the end of the block.
+_wn_batch = None
+
+
+class batched_wn_backward:
+    def __enter__(self):
+        global _wn_batch
+        self.outer = _wn_batch
+        if PACK_BATCH and _wn_batch is None and PROFILE is None:
+            _wn_batch = []
+        return self
+
+    def __exit__(self, *exc):
+        global _wn_batch
+        if self.outer is None and _wn_batch is not None:
+            calls, _wn_batch = _wn_batch, None
+            if exc[0] is None and calls:
+                if len(calls) == 1:
+                    calls[0][0].wn_backward(calls[0][1])
+                else:
+                    tasks = (_lib.FneusWnTask * len(calls))()
+                    for t, (n, d_eff) in zip(tasks, calls):
+                        t.rows, t.n_rows = (n.rows.data_ptr() if n.n_rows else None), n.n_rows
+                        t.bias_segs, t.n_segs = (n.bias_segs.data_ptr() if n.bias_segs.numel() else None), int(n.bias_segs.shape[0])
+                        t.raw, t.d_eff, t.d_raw = n.raw.data_ptr(), d_eff.data_ptr(), n.raw_grad.data_ptr()
+                        t.rowscale = n.rowscale.data_ptr() if n.rowscale.numel() else None
+                        t.invnorm = n.invnorm.data_ptr() if n.invnorm.numel() else None
+                    self.keep = calls                 # the gradient buffers stay referenced until the launch is enqueued
+                    check(lib.fneus_wn_backward_multi(tasks, len(calls), _stream()), "fneus_wn_backward_multi")
+        return False
+
+
 class PackedNet:
     """Device-side packed weights of one MLP ('sdf' or 'color'), its pack-job tables and the flat RAW parameter /
     gradient buffers (bias, weight_g, weight_v per layer, state_dict order).  The weight-norm fold runs inside the
@@ -190,6 +258,10 @@ class PackedNet:
 
     def pack(self):
         """fold weight-norm + pack the current raw parameters (once per optimiser step)"""
+        if _pack_batch is not None:                   # inside `with batched_refresh():` -- launched with the others at its end
+            if all(n is not self for n in _pack_batch):
+                _pack_batch.append(self)
+            return self.blob
         if self.desc.get("weight_norm", True):        # plain Linear networks have nothing to fold
             _launch("fneus_rowscale", lib.fneus_rowscale, _ptr(self.rows), self.n_rows, _ptr(self.raw), _ptr(self.rowscale),
                     _ptr(self.invnorm), _stream())
@@ -199,6 +271,9 @@ class PackedNet:
 
     def wn_backward(self, d_eff: torch.Tensor):
         """accumulate raw-parameter gradients from the effective-parameter gradients"""
+        if _wn_batch is not None:                     # inside `with batched_wn_backward():` -- one launch for all at its end
+            _wn_batch.append((self, d_eff))
+            return
         _launch("fneus_wn_backward", lib.fneus_wn_backward, _ptr(self.rows), self.n_rows, _ptr(self.bias_segs),
                 int(self.bias_segs.shape[0]), _ptr(self.raw), _ptr(self.rowscale), _ptr(self.invnorm), _ptr(d_eff),
                 _ptr(self.raw_grad), _stream())

@@ -307,7 +307,11 @@ class Stage1Trainer:
                                               self.reduce_norms))
         losses = out["losses"]
         self.zero_grad()
-        losses["loss"].backward()
+        if self.bucket is None and not ops.OVERLAP_MASK:     # one GPU: the four fold-backward launches as one, behind the backward
+            with ops.batched_wn_backward():
+                losses["loss"].backward()
+        else:                                                # data parallel: the early part of the arena travels beside the SDF backward
+            losses["loss"].backward()
         ops.overlap_end()                    # the weight gradients issued on the side stream are complete from here on
         if with_optimizer:
             self.optimizer.step()

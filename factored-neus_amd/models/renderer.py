@@ -243,14 +243,24 @@ class NeuSRenderer:
             z_vals_outside = lower[None, :] + (upper - lower)[None, :] * torch.rand([B, self.n_outside], device=dev)
         if self.n_outside > 0:                                                    # renderer.py:418-419
             z_vals_outside = far / torch.flip(z_vals_outside, dims=[-1]) + 1.0 / self.n_samples
-        # networks changed since the last call (optimiser step): fold weight-norm and re-pack once
-        self.sdf_network.refresh()
-        with ops.on_side_stream(1):          # the sampler only needs the SDF network: these packs run beside it
-            self.color_network.refresh()
-            if self.refColor_network is not None:
-                self.refColor_network.refresh()
-            if self.n_outside > 0 and self.nerf is not None and hasattr(self.nerf, "refresh"):
-                self.nerf.refresh()
+        # networks changed since the last call (optimiser step): fold weight-norm and re-pack once -- all of them in one
+        # fneus_refresh_multi call (ops.batched_refresh; with FNEUS_OVERLAP bit 1 the sampler's network first, the others beside it)
+        if ops.OVERLAP_MASK & 1:
+            self.sdf_network.refresh()
+            with ops.on_side_stream(1):
+                self.color_network.refresh()
+                if self.refColor_network is not None:
+                    self.refColor_network.refresh()
+                if self.n_outside > 0 and self.nerf is not None and hasattr(self.nerf, "refresh"):
+                    self.nerf.refresh()
+        else:
+            with ops.batched_refresh():
+                self.sdf_network.refresh()
+                self.color_network.refresh()
+                if self.refColor_network is not None:
+                    self.refColor_network.refresh()
+                if self.n_outside > 0 and self.nerf is not None and hasattr(self.nerf, "refresh"):
+                    self.nerf.refresh()
         n = self.n_samples
         if self.n_importance > 0:
             if z_vals_override is not None:

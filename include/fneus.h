@@ -122,6 +122,17 @@ int fneus_layout(int which /*0 SDF, 1 colour-shaped, 2 background NeRF, 3 Lvis*/
  * nn.utils.weight_norm, fields.py:67-68, happens inside the packer), rowscale: per-row g/||v|| or NULL. */
 int fneus_pack(const void* jobs, int n_jobs, int n_units, const int32_t* maps, const float* params,
                const float* rowscale, void* blob, fneus_stream_t stream);
+
+/* Weight-norm fold + packing of SEVERAL networks in one launch each (what a training step does at its start: four or five
+ * networks, each pair of launches a few microseconds of work).  Task i = the arguments of fneus_rowscale (rows, n_rows,
+ * params = raw, rowscale, invnorm; n_rows = 0 for plain Linear networks) and of fneus_pack for one network.  n_tasks <= 8.
+ * Replaces the per-module fold of nn.utils.weight_norm (fields.py:67-68, 139-140) for all networks of the step at once. */
+typedef struct FneusPackTask {
+    const void* jobs; int n_jobs; int n_units; const int* maps; const float* params; float* rowscale; float* invnorm;
+    void* blob; const void* rows; int n_rows;
+} FneusPackTask;
+int fneus_refresh_multi(const FneusPackTask* tasks /*host array*/, int n_tasks, fneus_stream_t stream);
+
 /* rows: device array of RowInfo (csrc/fneus_pack.h), one per weight-normalised output row. */
 int fneus_rowscale(const void* rows, int n_rows, const float* raw, float* rowscale, float* invnorm,
                    fneus_stream_t stream);
@@ -131,6 +142,14 @@ int fneus_rowscale(const void* rows, int n_rows, const float* raw, float* rowsca
 int fneus_wn_backward(const void* rows, int n_rows, const void* bias_segs, int n_segs, const float* raw,
                       const float* rowscale, const float* invnorm, float* d_eff, float* d_raw,
                       fneus_stream_t stream);
+
+/* fneus_wn_backward for SEVERAL networks in one launch (task i = its arguments); n_tasks <= 8.  The results are read by the
+ * optimiser only, so a single-GPU step can run all of them behind the last weight-gradient GEMM. */
+typedef struct FneusWnTask {
+    const void* rows; int n_rows; const void* bias_segs; int n_segs; const float* raw; const float* rowscale;
+    const float* invnorm; float* d_eff; float* d_raw;
+} FneusWnTask;
+int fneus_wn_backward_multi(const FneusWnTask* tasks /*host array*/, int n_tasks, fneus_stream_t stream);
 
 /* ---- K1: SDFNetwork.sdf under no_grad  (fields.py:93-95 via renderer.py:199, 430, 515) -------------------- */
 int fneus_sdf_fwd(const void* sdf_blob, const float* pts, const float* rays_o, const float* rays_d, const float* t,
