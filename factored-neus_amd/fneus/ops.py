@@ -158,6 +158,36 @@ class batched_refresh:
 _wn_batch = None
 
 
+def _launch_wn_calls(calls):
+    global _wn_batch
+    if not calls:
+        return
+    if len(calls) == 1:
+        saved, _wn_batch = _wn_batch, None
+        try:
+            calls[0][0].wn_backward(calls[0][1])
+        finally:
+            _wn_batch = saved
+        return
+    tasks = (_lib.FneusWnTask * len(calls))()
+    for t, (n, d_eff) in zip(tasks, calls):
+        t.rows, t.n_rows = (n.rows.data_ptr() if n.n_rows else None), n.n_rows
+        t.bias_segs, t.n_segs = (n.bias_segs.data_ptr() if n.bias_segs.numel() else None), int(n.bias_segs.shape[0])
+        t.raw, t.d_eff, t.d_raw = n.raw.data_ptr(), d_eff.data_ptr(), n.raw_grad.data_ptr()
+        t.rowscale = n.rowscale.data_ptr() if n.rowscale.numel() else None
+        t.invnorm = n.invnorm.data_ptr() if n.invnorm.numel() else None
+    check(lib.fneus_wn_backward_multi(tasks, len(calls), _stream()), "fneus_wn_backward_multi")
+
+
+def flush_wn_batch():
+    """launch what `batched_wn_backward` has collected so far (data parallel: before the early part of the gradient arena is
+    exchanged); the block goes on collecting"""
+    global _wn_batch
+    if _wn_batch:
+        calls, _wn_batch = _wn_batch, []
+        _launch_wn_calls(calls)
+
+
 class batched_wn_backward:
     def __enter__(self):
         global _wn_batch
@@ -170,19 +200,8 @@ class batched_wn_backward:
         global _wn_batch
         if self.outer is None and _wn_batch is not None:
             calls, _wn_batch = _wn_batch, None
-            if exc[0] is None and calls:
-                if len(calls) == 1:
-                    calls[0][0].wn_backward(calls[0][1])
-                else:
-                    tasks = (_lib.FneusWnTask * len(calls))()
-                    for t, (n, d_eff) in zip(tasks, calls):
-                        t.rows, t.n_rows = (n.rows.data_ptr() if n.n_rows else None), n.n_rows
-                        t.bias_segs, t.n_segs = (n.bias_segs.data_ptr() if n.bias_segs.numel() else None), int(n.bias_segs.shape[0])
-                        t.raw, t.d_eff, t.d_raw = n.raw.data_ptr(), d_eff.data_ptr(), n.raw_grad.data_ptr()
-                        t.rowscale = n.rowscale.data_ptr() if n.rowscale.numel() else None
-                        t.invnorm = n.invnorm.data_ptr() if n.invnorm.numel() else None
-                    self.keep = calls                 # the gradient buffers stay referenced until the launch is enqueued
-                    check(lib.fneus_wn_backward_multi(tasks, len(calls), _stream()), "fneus_wn_backward_multi")
+            if exc[0] is None:
+                _launch_wn_calls(calls)
         return False
 
 

@@ -173,6 +173,7 @@ class Stage1Trainer:
         # stream: they write the early part of the arena, so that stream joins before the exchange reads it (during a
         # capture the join also closes the fork, without which capture_end fails)
         ops.overlap_join()
+        ops.flush_wn_batch()                 # the fold backward of the colour network and the RefColor heads: their gradients are read next
         if st is None:
             if self._in_dp_step:
                 self._early = self.grads.allreduce_early(self._xstream)
@@ -307,10 +308,10 @@ class Stage1Trainer:
                                               self.reduce_norms))
         losses = out["losses"]
         self.zero_grad()
-        if self.bucket is None and not ops.OVERLAP_MASK:     # one GPU: the four fold-backward launches as one, behind the backward
-            with ops.batched_wn_backward():
+        if not ops.OVERLAP_MASK:     # the fold-backward launches of the networks as one (data parallel: one for the early part of
+            with ops.batched_wn_backward():      # the arena, flushed by _early_exchange, and the SDF network's behind the backward)
                 losses["loss"].backward()
-        else:                                                # data parallel: the early part of the arena travels beside the SDF backward
+        else:
             losses["loss"].backward()
         ops.overlap_end()                    # the weight gradients issued on the side stream are complete from here on
         if with_optimizer:
