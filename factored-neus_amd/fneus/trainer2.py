@@ -188,8 +188,16 @@ class Stage2Trainer:
             gc.collect()
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                losses = self._fixed_shape_step(static)
+            try:
+                with torch.cuda.graph(graph):
+                    losses = self._fixed_shape_step(static)
+            except Exception as e:      # noqa: BLE001 -- a failed capture must leave a working (eager) trainer behind
+                import sys
+                print(f"[fneus] stage graph capture failed ({e!r}); continuing with eager launches", file=sys.stderr)
+                torch.cuda.synchronize()
+                self.use_graph = False
+                self.iter_step += 1
+                return self._fixed_shape_step(data)
             self._graph = (graph, static, losses)
             graph.replay()           # the capture pass only records: run the step for this batch now
             self.iter_step += 1
