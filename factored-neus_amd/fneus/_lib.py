@@ -77,6 +77,7 @@ def _load():
         "fneus_pack": (C.c_int, [vp, ip, ip, vp, vp, vp, vp, vp]),
         "fneus_rowscale": (C.c_int, [vp, ip, vp, vp, vp, vp]),
         "fneus_refresh_multi": (C.c_int, [C.POINTER(FneusPackTask), ip, vp]),
+        "fneus_l2_warm_hint": (C.c_int, [ip, C.POINTER(C.c_void_p), C.POINTER(C.c_long), ip]),
         "fneus_wn_backward_multi": (C.c_int, [C.POINTER(FneusWnTask), ip, vp]),
         "fneus_wn_backward": (C.c_int, [vp, ip, vp, ip, vp, vp, vp, vp, vp, vp]),
         "fneus_sdf_fwd": (C.c_int, [vp, vp, vp, vp, vp, ip, l, vp, ip, vp]),

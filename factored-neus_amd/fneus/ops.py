@@ -118,6 +118,32 @@ def _chk_f32(t: torch.Tensor, name: str):
         raise ValueError(f"{name} must be a contiguous float32 CUDA tensor")
 
 
+def set_l2_warm(slot: int, ranges):
+    """fneus_l2_warm_hint: device ranges [(ptr, bytes), ...] that the next surface_gather (slot 0) / stage1_loss (slot 1) launches
+    read into L2 for the launch behind them; [] clears the slot.  FNEUS_L2_WARM=0 disables it."""
+    if _os.environ.get("FNEUS_L2_WARM", "1") == "0":
+        ranges = []
+    n = len(ranges)
+    ptrs = (C.c_void_p * max(n, 1))(*[r[0] for r in ranges])
+    sizes = (C.c_long * max(n, 1))(*[int(r[1]) for r in ranges])
+    check(lib.fneus_l2_warm_hint(int(slot), ptrs, sizes, n), "fneus_l2_warm_hint")
+
+
+def fragment_ranges(net, reverse: bool):
+    """(ptr, bytes) of a packed network's forward (or reverse) weight fragments, hi + lo, layer by layer"""
+    out = []
+    base = net.blob.data_ptr()
+    for l in range(net.layout.n_layers):
+        ksf, ntf, ksr, ntr = [int(v) for v in net.layout.geom[l]]
+        fwd_hi, fwd_lo, rev_hi, rev_lo, _bias = [int(v) for v in net.layout.off[l]]
+        if reverse:
+            if ksr * ntr > 0:
+                out.append((base + rev_hi, 2 * ksr * ntr * 1024))
+        else:
+            out.append((base + fwd_hi, 2 * ksf * ntf * 1024))
+    return out
+
+
 # Networks whose pack() was called inside `with batched_refresh():` are folded and packed by ONE fneus_refresh_multi call at the
 # end of the block (two launches for all of them instead of one or two each: a training step re-packs 4-5 networks at its
 # start).  FNEUS_PACK_BATCH=0 keeps the per-network launches.

@@ -223,6 +223,11 @@ int fneus_refcolor_bwd_both(const void* blob_cd, const void* blob_vd, long n_pts
                             fneus_stream_t stream);
 
 /* ---- per-ray tail of the training step ------------------------------------------------------------------------ */
+/* Optional: device ranges (e.g. the forward / reverse weight fragments of the RefColor MLPs) that extra workgroups of the next
+ * fneus_surface_gather (slot 0) / fneus_stage1_loss (slot 1) launches read into the L2 caches for the launch that follows
+ * them; n = 0 clears the slot.  Host-side state of the library (not captured per call: set it before a step is recorded). */
+int fneus_l2_warm_hint(int slot, const void* const* ptrs /*host array of device pointers*/, const long* bytes /*host*/, int n);
+
 /* The two samples bracketing the first SDF sign change of every ray (renderer.py:290-293, 316-327), packed for the
  * RefColor heads: sel [2B] (row index into the B*n samples), t_sel [2B], feat_sel [2B][256], normal_sel [2B][3].
  * Rays without a sign change (sdf_mask 0) select samples 0 and 1, as the reference's dense formulation does.           */
