@@ -338,7 +338,9 @@ def main():
                               "traffic_source": traffic_src,
                               "avg_launch_ms": per[dom]["avg_ms"],
                               "note": "algorithmic (fp32-equivalent) FLOPs per launch / HIP-event launch duration; "
-                                      "parity mode issues 3 bf16 MFMAs per algorithmic product"}
+                                      "parity mode issues 3 bf16 MFMAs per algorithmic product"
+                                      + ("; fneus_sdf_fwd_grad is two kernels since round 3 (forward chain with the stash, "
+                                         "reverse sweep): FLOPs and duration of the pair" if dom == "fneus_sdf_fwd_grad" else "")}
 
     if rank == 0 and world == 1 and not args.no_fast_extra and standard:
         # forward-only render of the same batch (what validate_image runs per ray chunk), SURVEY.md section 8(d)
