@@ -1012,6 +1012,52 @@ extern "C" int fneus_gen_rays_grid(const float* intrinsics_inv, const float* pos
     return fneus::launch_status();
 }
 
+// z_vals_outside of NeuSRenderer.render (renderer.py:397-400, 411-419) in one launch: the n_out depths of the inverted-sphere
+// parametrisation per ray.  lin_k = torch.linspace(1e-3, 1 - 1/(n_out + 1), n_out)[k] (torch's own evaluation order: from the start
+// for the lower half, from the end for the upper one), jittered inside its cell [lower_k, upper_k] by u[b][k] when u is given,
+// then z[b][k] = far_b / t[n_out - 1 - k] + 1 / n_samples with far from the rays' unit-sphere bounds (dataset.py:186-192) unless
+// an explicit far is passed.
+__global__ void __launch_bounds__(256) outside_z_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                        const float* __restrict__ far_in, const float* __restrict__ u, int n_rays,
+                                                        int n_out, int n_samples, float* __restrict__ z) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)n_rays * n_out) return;
+    const int b = (int)(i / n_out), k = (int)(i - (long)b * n_out);
+    const int src = n_out - 1 - k;                    // torch.flip
+    const float start = 1e-3f, end = 1.0f - 1.0f / ((float)n_out + 1.0f);
+    const float step = (end - start) / (float)(n_out - 1);
+    auto lin = [&](int j) { return j < n_out / 2 ? start + step * (float)j : end - step * (float)(n_out - 1 - j); };
+    float t = lin(src);
+    if (u) {
+        const float lo = src == 0 ? lin(0) : 0.5f * (lin(src) + lin(src - 1));
+        const float hi = src == n_out - 1 ? lin(n_out - 1) : 0.5f * (lin(src + 1) + lin(src));
+        t = lo + (hi - lo) * u[(long)b * n_out + src];
+    }
+    float far;
+    if (far_in) {
+        far = far_in[b];
+    } else {
+        const float ox = rays_o[b * 3], oy = rays_o[b * 3 + 1], oz = rays_o[b * 3 + 2];
+        const float dx = rays_d[b * 3], dy = rays_d[b * 3 + 1], dz = rays_d[b * 3 + 2];
+        const float a = dx * dx + dy * dy + dz * dz;
+        const float bb = 2.0f * (ox * dx + oy * dy + oz * dz);
+        far = 0.5f * (-bb) / a + 1.0f;
+    }
+    z[i] = far / t + 1.0f / (float)n_samples;
+}
+
+extern "C" int fneus_outside_z(const float* rays_o, const float* rays_d, const float* far, const float* u, int n_rays, int n_out,
+                               int n_samples, float* z, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    const long total = (long)n_rays * n_out;
+    if (total <= 0) return 0;
+    if (n_out < 2 || n_samples <= 0 || (!far && (!rays_o || !rays_d))) return -2;
+    hipLaunchKernelGGL(outside_z_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, rays_o, rays_d, far, u, n_rays,
+                       n_out, n_samples, z);
+    return fneus::launch_status();
+}
+
 extern "C" int fneus_outside_points(const float* rays_o, const float* rays_d, const float* z, int n_rays, int nt, float sample_dist,
                                     float* pts4, float* dirs, float* dists, fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;

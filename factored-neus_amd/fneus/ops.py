@@ -804,6 +804,16 @@ def upsample(rays_o, rays_d, z, sdf, k: int, inv_s: float):
     return out
 
 
+def outside_z(rays_o, rays_d, n_outside: int, n_samples: int, far=None, u=None):
+    """z_vals_outside of NeuSRenderer.render (renderer.py:397-400, 411-419) -> [B, n_outside]; far [B] or None (unit-sphere bound
+    of the rays), u [B, n_outside] uniform draws or None (no jitter)"""
+    B = rays_o.shape[0]
+    z = torch.empty(B, n_outside, dtype=torch.float32, device=rays_o.device)
+    _launch("fneus_outside_z", lib.fneus_outside_z, _ptr(rays_o), _ptr(rays_d), _ptr(far), _ptr(u), B, n_outside, n_samples, _ptr(z),
+            _stream())
+    return z
+
+
 def outside_points(rays_o, rays_d, z_feed, sample_dist: float):
     """render_core_outside's geometry (renderer.py:121-131) -> pts4 [B*nt,4], dirs [B*nt,3], dists [B,nt]"""
     B, nt = z_feed.shape

@@ -222,27 +222,21 @@ class NeuSRenderer:
         B = len(rays_o)
         sample_dist = 2.0 / self.n_samples
         z_vals_outside = None
-        if self.n_outside > 0:                                                    # renderer.py:397-400
-            z_vals_outside = torch.linspace(1e-3, 1.0 - 1.0 / (self.n_outside + 1.0), self.n_outside, device=dev)
         perturb = self.perturb if perturb_overwrite < 0 else perturb_overwrite
         t_rand = torch.rand([B, 1], device=dev) if perturb > 0 else None
         # z = near + (far - near) * linspace(0, 1, n) (+ jitter), renderer.py:393-409; near = None: unit-sphere bounds
         # (dataset.py:186-192) computed in the same launch
         if near is None:
             z_vals = ops.ray_setup(rays_o, rays_d, self.n_samples, t_rand=t_rand)
-            if self.n_outside > 0:
-                a = (rays_d ** 2).sum(-1, keepdim=True)
-                far = 0.5 * (-2.0 * (rays_o * rays_d).sum(-1, keepdim=True)) / a + 1.0
         else:
             z_vals = ops.ray_setup(rays_o, rays_d, self.n_samples, near=near.float().reshape(-1).contiguous(),
                                    far=far.float().reshape(-1).contiguous(), t_rand=t_rand)
-        if perturb > 0 and self.n_outside > 0:                                    # renderer.py:411-416
-            mids = 0.5 * (z_vals_outside[1:] + z_vals_outside[:-1])
-            upper = torch.cat([mids, z_vals_outside[-1:]], -1)
-            lower = torch.cat([z_vals_outside[:1], mids], -1)
-            z_vals_outside = lower[None, :] + (upper - lower)[None, :] * torch.rand([B, self.n_outside], device=dev)
-        if self.n_outside > 0:                                                    # renderer.py:418-419
-            z_vals_outside = far / torch.flip(z_vals_outside, dims=[-1]) + 1.0 / self.n_samples
+        if self.n_outside > 0:
+            # renderer.py:397-400, 411-419 in one launch (fneus_outside_z): linspace(1e-3, 1 - 1/(n+1), n), jittered inside its cells,
+            # flipped, far / t + 1 / n_samples (far = None: the unit-sphere bound of the rays, computed there)
+            u_out = torch.rand([B, self.n_outside], device=dev) if perturb > 0 else None
+            z_vals_outside = ops.outside_z(rays_o, rays_d, self.n_outside, self.n_samples,
+                                           far=None if far is None else far.float().reshape(-1).contiguous(), u=u_out)
         # networks changed since the last call (optimiser step): fold weight-norm and re-pack once -- all of them in one
         # fneus_refresh_multi call (ops.batched_refresh; with FNEUS_OVERLAP bit 1 the sampler's network first, the others beside it)
         if ops.OVERLAP_MASK & 1:

@@ -353,6 +353,12 @@ int fneus_nerf_bg_fwd(const void* nerf_blob, const float* pts4, const float* dir
 int fneus_nerf_bg_bwd(const void* nerf_blob, long n_pts, const float* d_density /*[n]*/, const float* d_rgb /*[n][3]*/,
                       const FneusNerfStash* stash, int prec, fneus_stream_t stream);
 
+/* z_vals_outside of NeuSRenderer.render (renderer.py:397-400, 411-419) -> z [B][n_out]: linspace(1e-3, 1 - 1/(n_out+1), n_out),
+ * jittered inside its cells by u [B][n_out] (NULL: no jitter), flipped, far / t + 1 / n_samples; far [B] or NULL = the rays'
+ * unit-sphere bound (dataset.py:186-192). */
+int fneus_outside_z(const float* rays_o, const float* rays_d, const float* far, const float* u, int n_rays, int n_out,
+                    int n_samples, float* z, fneus_stream_t stream);
+
 /* ---- the element-wise work of render_core_outside around K7 (renderer.py:112-149) ------------------------------------ */
 /* z [B][nt]: the merged inside + outside depths (renderer.py:453).  -> dists [B][nt] (last section = sample_dist), pts4
  * [B*nt][4] = (p / |p|, 1 / |p|) at the section mid points with |p| clipped to [1, 1e10], dirs [B*nt][3] = the ray direction. */

@@ -370,3 +370,30 @@ def test_embed_kernel_vs_the_torch_embedder():
         assert (got.cpu() - ref).abs().max().item() <= 2e-6 * max(1.0, 2.0 ** (L - 1) * 1e-3 + 1.0)
         xg = x.clone().requires_grad_(True)          # inputs that need a gradient stay on the torch formulation
         assert fn(xg).requires_grad
+
+
+@pytest.mark.parametrize("jitter,explicit_far", [(True, False), (False, False), (True, True)])
+def test_outside_depths_in_one_launch_vs_the_reference_formula(jitter, explicit_far):
+    """fneus_outside_z against NeuSRenderer.render's z_vals_outside written out with torch ops exactly as the reference does
+    (renderer.py:397-400, 411-419: linspace, cell mid points, jitter, flip, far / t + 1 / n_samples; far from
+    dataset.py:186-192).  Tolerance: a few ulps of a value of O(1..1000) -- the kernel keeps torch's evaluation order."""
+    from fneus import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(3)
+    B, n_out, n_samples = 513, 32, 64
+    rays_o = (torch.randn(B, 3, device=dev, generator=g) * 0.3 + torch.tensor([0.0, 0.0, -2.5], device=dev)).contiguous()
+    rays_d = torch.nn.functional.normalize(torch.randn(B, 3, device=dev, generator=g) * 0.2 + torch.tensor([0.0, 0.0, 1.0], device=dev), dim=-1).contiguous()
+    u = torch.rand(B, n_out, device=dev, generator=g) if jitter else None
+    a = (rays_d ** 2).sum(-1, keepdim=True)
+    far = 0.5 * (-2.0 * (rays_o * rays_d).sum(-1, keepdim=True)) / a + 1.0
+    z = torch.linspace(1e-3, 1.0 - 1.0 / (n_out + 1.0), n_out, device=dev)
+    if jitter:
+        mids = 0.5 * (z[1:] + z[:-1])
+        upper = torch.cat([mids, z[-1:]], -1)
+        lower = torch.cat([z[:1], mids], -1)
+        z = lower[None, :] + (upper - lower)[None, :] * u
+    ref = far / torch.flip(z if jitter else z[None, :].expand(B, n_out), dims=[-1]) + 1.0 / n_samples
+    got = ops.outside_z(rays_o, rays_d, n_out, n_samples, far=far.reshape(-1).contiguous() if explicit_far else None, u=u)
+    assert got.shape == ref.shape
+    rel = ((got - ref).abs() / ref.abs().clamp_min(1e-6)).max().item()
+    assert rel <= 2e-6, rel

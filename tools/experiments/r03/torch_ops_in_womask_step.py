@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Which PyTorch (aten) ops still launch kernels inside one eager train step, in order, with their input shapes."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "factored-neus_amd"))
+import torch
+from torch.profiler import profile, ProfilerActivity
+from fneus.trainer import Stage1Trainer, synthetic_batches
+dev = torch.device("cuda:0")
+import copy
+from fneus.trainer import WMASK_MODEL
+conf = copy.deepcopy(WMASK_MODEL); conf["neus_renderer"]["n_outside"] = 32
+tr = Stage1Trainer(dev, model_conf=conf, use_graph=False)
+kw = dict(cos_anneal_ratio=0.5, background_rgb=torch.ones(1, 3, device=dev))
+bs = synthetic_batches(4, 512, dev)
+for b in bs[:3]:
+    tr.train_step(b, **kw)
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=False) as prof:
+    tr.train_step(bs[3], **kw)
+    torch.cuda.synchronize()
+evs = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CPU and e.name.startswith("aten::")]
+# keep leaf aten ops that launched a kernel
+out = []
+for e in evs:
+    if e.kernels:
+        out.append((e.time_range.start, e.name, [k.name[:60] for k in e.kernels], e.input_shapes))
+out.sort()
+seen = set()
+for t, name, ks, shp in out:
+    print(f"{name:28s} {str(shp)[:70]:72s} {ks[0]}")
+print(len(out), "aten ops with kernels")
