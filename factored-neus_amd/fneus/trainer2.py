@@ -107,6 +107,13 @@ class Stage2Trainer:
             holder = torch.nn.Module()
             holder.ps = torch.nn.ParameterList(self.params)
             self.grads = GradArena(self.device, [], None, [holder])
+        if self.grads is not None and os.environ.get("FNEUS_DIRECT_GRADS", "1") != "0":
+            # persistent, per-step cleared gradient buffers: the distilled MLPs write their weight gradients straight into them
+            # (models/fields.py _DirectLinearFn: two launches fewer per layer than autograd's mm + accumulate)
+            # -- only inside this trainer's own steps (_direct_grads_on / _off around the forward pass): there the buffers are
+            # cleared before every backward; anyone else calling the modules gets autograd's accumulating route
+            self._direct_modules = [m for m in (getattr(self, "lvis_network", None), getattr(self, "indiLgt_network", None))
+                                    if m is not None and any(p.requires_grad for p in m.parameters())]
         self.use_graph = bool(use_graph) and self.device.type == "cuda"
         # FlatAdam (fneus/optim.py): torch.optim.Adam's state and state_dict with ONE fneus_adam launch per step, device-scalar
         # step counter and learning rate (graph-capturable), gradients cleared by the kernel.  MEASURED: torch's own step costs
@@ -208,6 +215,10 @@ class Stage2Trainer:
         self.iter_step += 1
         return losses
 
+    def _direct_grads(self, on: bool):
+        for m in getattr(self, "_direct_modules", ()):
+            m.direct_grads = on
+
     def _clear_grads(self):
         """torch.optim.Adam: drop the gradients; FlatAdam keeps persistent gradient buffers and clears them itself after use"""
         if not self.flat_adam:
@@ -228,7 +239,11 @@ class Stage2Trainer:
 
     def _fixed_shape_step(self, data: torch.Tensor):
         rays_o, rays_d, _rgb, _mask = ops.split_batch(data.contiguous())
-        out = self.renderer.lvis_render(rays_o, rays_d, None, None, fixed_shape=True)
+        self._direct_grads(True)
+        try:
+            out = self.renderer.lvis_render(rays_o, rays_d, None, None, fixed_shape=True)
+        finally:
+            self._direct_grads(False)
         losses = stage2_loss(out, self.reduce)
         self._backward_and_step(losses["loss"])
         return {"n_hit": out["sdf_mask"].sum(), **{k: v.detach() for k, v in losses.items()}}

@@ -454,6 +454,44 @@ class NeRF(nn.Module):
         return density.reshape(-1, 1), rgb
 
 
+class _DirectLinearFn(torch.autograd.Function):
+    """nn.Linear whose backward writes the weight / bias gradients STRAIGHT into the parameters' persistent `.grad` buffers
+    (`torch.mm(..., out=weight.grad)`, `torch.sum(..., out=bias.grad)`) and hands autograd no gradient for them.  With
+    persistent gradient buffers (the stage-2 / 3 trainers' gradient arena) autograd's own route is mm -> temporary ->
+    `grad += temporary` per tensor: two launches more per layer on tensors of a few hundred KB.  Valid when each parameter is
+    used once per backward and its buffer is overwritten, not accumulated into (the trainers clear the arena every step)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x)
+        ctx.weight, ctx.bias = weight, bias
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        w, b = ctx.weight, ctx.bias
+        dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
+        torch.mm(dy2.t(), x2, out=w.grad)
+        torch.sum(dy2, 0, out=b.grad)
+        dx = (dy2 @ w.detach()).reshape(x.shape) if ctx.needs_input_grad[0] else None
+        return dx, None, None
+
+
+def _seq_direct(seq, x, owner):
+    """run an nn.Sequential; its Linear layers through _DirectLinearFn when the owner asks for it (`owner.direct_grads`, set by
+    the trainers that keep persistent gradient buffers) and the buffers exist"""
+    if not getattr(owner, "direct_grads", False) or not torch.is_grad_enabled():
+        return seq(x)
+    for m in seq:
+        if isinstance(m, nn.Linear) and m.weight.requires_grad and m.weight.grad is not None and m.bias is not None \
+                and m.bias.grad is not None and m.weight.grad.is_contiguous():
+            x = _DirectLinearFn.apply(x, m.weight, m.bias)
+        else:
+            x = m(x)
+    return x
+
+
 class Lvis(nn.Module):
     """Stage-2 distilled light visibility (fields.py:338-369): sigmoid(MLP(embed(pts, 10) | embed(view, 4))), 90 -> 256 x 4 -> 1.
     Same state_dict keys as the reference (`lvis.{0,2,4,6,8}.weight / bias`); the first layer is an explicit Linear(90, 256)
@@ -469,7 +507,7 @@ class Lvis(nn.Module):
                                   nn.Sigmoid())
 
     def forward(self, pts, view):
-        return self.lvis(torch.cat([self.embedview_fn_pts(pts), self.embedview_fn_view(view)], dim=-1))
+        return _seq_direct(self.lvis, torch.cat([self.embedview_fn_pts(pts), self.embedview_fn_view(view)], dim=-1), self)
 
     def visibility(self, points, normals, dirs, weights, point_mask=None):
         """get_diffuse_visibility's network part (inverRender.py:163-190), no gradient: for every surface point the network
@@ -539,7 +577,7 @@ class IndirectLight(nn.Module):
                                   nn.ReLU(), nn.Linear(512, 512), nn.ReLU(), nn.Linear(512, num_lgt_sgs * 6))
 
     def forward(self, pts):
-        out = self.indi(self.embedview_fn_pts(pts)).reshape(-1, self.num_lgt_sgs, 6)
+        out = _seq_direct(self.indi, self.embedview_fn_pts(pts), self).reshape(-1, self.num_lgt_sgs, 6)
         ang = torch.sigmoid(out[..., :2]) * (2 * np.pi)
         theta, phi = ang[..., :1], ang[..., 1:2]
         lobes = torch.cat([torch.cos(theta) * torch.sin(phi), torch.sin(theta) * torch.sin(phi), torch.cos(phi)], dim=-1)
