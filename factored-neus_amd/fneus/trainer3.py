@@ -62,6 +62,9 @@ class Stage3Trainer:
         self.refColor_network.set_precision(prec)
         self.params = list(self.mateIllu_network.parameters())          # mateIllu.py:91-95
         self._init_step_mode(use_graph, lr, distributed)
+        import os
+        if self.grads is not None and os.environ.get("FNEUS_DIRECT_GRADS", "1") != "0":
+            self._direct_modules = [self.mateIllu_network]      # its three MLPs: dW / db straight into the gradient arena
         self.mateIllu_network.stat_reduce = self.reduce          # global latent-sparsity statistics (data parallel)
         self.renderer = NeuSRenderer(**conf["neus_renderer"], sdf_network=self.sdf_network,
                                      deviation_network=self.deviation_network, refColor_network=self.refColor_network,
@@ -75,12 +78,17 @@ class Stage3Trainer:
     _init_step_mode, set_lr, get_lr, _graph_step = _S2._init_step_mode, _S2.set_lr, _S2.get_lr, _S2._graph_step
     optimizer_state_dict, load_optimizer_state_dict = _S2.optimizer_state_dict, _S2.load_optimizer_state_dict
     _backward_and_step, _reduce, _clear_grads = _S2._backward_and_step, _S2._reduce, _S2._clear_grads
+    _direct_grads = _S2._direct_grads
     del _S2
 
     def _fixed_shape_step(self, data: torch.Tensor):
         rays_o, rays_d, true_rgb, mask = ops.split_batch(data.contiguous())
         mask = (mask > 0.5).float() if self.mask_weight > 0.0 else torch.ones_like(mask)
-        out = self.renderer.mateIllu_render(rays_o, rays_d, None, None, fixed_shape=True)
+        self._direct_grads(True)
+        try:
+            out = self.renderer.mateIllu_render(rays_o, rays_d, None, None, fixed_shape=True)
+        finally:
+            self._direct_grads(False)
         losses = stage3_loss(out, true_rgb, mask, self.reduce)
         self._backward_and_step(losses["loss"])
         return {"n_hit": out["sdf_mask"].sum(), **{k: v.detach() for k, v in losses.items()}}

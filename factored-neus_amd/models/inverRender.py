@@ -19,6 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from models.embedder import get_embedder
+from models.fields import _seq_direct
 
 TINY_NUMBER = 1e-6
 
@@ -300,12 +301,14 @@ class EnvmapMaterialNetwork(nn.Module):
         view_dirs = -ray_dirs
         ref_dirs = 2.0 * torch.sum(view_dirs * n, dim=-1, keepdim=True) * n - view_dirs
         pts_enc = self.embed_pts_fn(points)
-        latent = self.brdf_encoder_layer(self.brdf_embed_fn(points))
-        brdf = torch.sigmoid(self.brdf_decoder_layer(torch.sigmoid(latent)))
+        # (_seq_direct: inside Stage3Trainer's own steps the Linear layers write dW / db straight into their persistent gradient
+        # buffers, models/fields.py _DirectLinearFn; otherwise these are the plain nn.Sequential calls)
+        latent = _seq_direct(self.brdf_encoder_layer, self.brdf_embed_fn(points), self)
+        brdf = torch.sigmoid(_seq_direct(self.brdf_decoder_layer, torch.sigmoid(latent), self))
         roughness = brdf[..., 3:] * 0.9 + 0.09
         diffuse_albedo = brdf[..., :3]
         loss = 0.01 * self.kl_divergence(0.05, latent, point_mask)
-        specular_albedo = self.net_cs(torch.cat([pts_enc, self.embed_view_fn(ref_dirs)], dim=-1)).repeat(1, 3)
+        specular_albedo = _seq_direct(self.net_cs, torch.cat([pts_enc, self.embed_view_fn(ref_dirs)], dim=-1), self).repeat(1, 3)
         ret = render_with_all_sg(points, n, view_dirs, self.lgtSGs, self.specular_reflectance, specular_albedo, roughness,
                                  diffuse_albedo, gt_specular_linear, lvis_network=lvis_network, indir_lgtSGs=indiLgt,
                                  u_theta=u_theta, u_phi=u_phi, specular_reflectance_value=self.specular_reflectance_value,
