@@ -1,0 +1,132 @@
+// Stage 2: predicted indirect radiance of a surface point along its sampled directions, fused from the raw output of the
+// IndirectLight MLP: the network's output transform (reference models/fields.py:395-413: angles -> lobe axis, sharpness,
+// amplitude) and query_indir_illum (models/calLvis.py:323-336: normalise the axes, sum of spherical Gaussians) were ~25
+// element-wise PyTorch launches forward and ~45 backward on [512, 4, 24, 3] tensors.  One wavefront per point, lane l = lobe l:
+//   theta = 2 pi sigmoid(o0), phi = 2 pi sigmoid(o1), axis = (cos theta sin phi, sin theta sin phi, cos phi) / |.|
+//   lambda = 30 sigmoid(o2) + 0.1, mu_c = relu(o_{3+c})
+//   radiance[s][c] = sum_l mu_c[l] exp(lambda_l (axis_l . d_s - 1))
+// The backward is the hand-derived adjoint (checked against autograd of the element-wise formulation, tests/test_hip_stage2.py).
+#include "fneus_common.h"
+#include "fneus_kernels.h"
+
+namespace fneus {
+
+constexpr int kIndirMaxS = 8;
+constexpr float kTwoPi = 6.283185307179586f;
+
+struct IndirLobe {
+    float sg0, sg1, sg2;            // sigmoids of o0, o1, o2
+    float st, ct, sp, cp;           // sin / cos of theta, phi
+    float ax[3], inv_norm;          // normalised axis, 1 / |raw axis|
+    float lam, mu[3];
+    bool pos[3];
+};
+
+FN_DEV IndirLobe indir_lobe(const float* __restrict__ o) {
+    IndirLobe L;
+    L.sg0 = 1.0f / (1.0f + expf(-o[0]));
+    L.sg1 = 1.0f / (1.0f + expf(-o[1]));
+    L.sg2 = 1.0f / (1.0f + expf(-o[2]));
+    const float theta = L.sg0 * kTwoPi, phi = L.sg1 * kTwoPi;
+    sincosf(theta, &L.st, &L.ct);
+    sincosf(phi, &L.sp, &L.cp);
+    const float a0 = L.ct * L.sp, a1 = L.st * L.sp, a2 = L.cp;
+    L.inv_norm = 1.0f / sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
+    L.ax[0] = a0 * L.inv_norm;
+    L.ax[1] = a1 * L.inv_norm;
+    L.ax[2] = a2 * L.inv_norm;
+    L.lam = L.sg2 * 30.0f + 0.1f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        L.pos[c] = o[3 + c] > 0.0f;
+        L.mu[c] = L.pos[c] ? o[3 + c] : 0.0f;
+    }
+    return L;
+}
+
+__global__ void __launch_bounds__(64) indir_illum_fwd_kernel(const float* __restrict__ raw, const float* __restrict__ dirs, int n, int nl,
+                                                             int ns, float* __restrict__ radiance) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    if (i >= n) return;
+    const bool live = lane < nl;
+    float o[6] = {0, 0, 0, 0, 0, 0};
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o[k] = raw[((size_t)i * nl + lane) * 6 + k];
+    }
+    const IndirLobe L = indir_lobe(o);
+    for (int s = 0; s < ns; ++s) {
+        const float* d = dirs + ((size_t)i * ns + s) * 3;
+        const float cosv = L.ax[0] * d[0] + L.ax[1] * d[1] + L.ax[2] * d[2];
+        const float w = live ? expf(L.lam * (cosv - 1.0f)) : 0.0f;
+        float v[3] = {L.mu[0] * w, L.mu[1] * w, L.mu[2] * w};
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] += __shfl_xor(v[c], sh, 64);
+        }
+        if (lane < 3) radiance[((size_t)i * ns + s) * 3 + lane] = lane == 0 ? v[0] : (lane == 1 ? v[1] : v[2]);
+    }
+}
+
+__global__ void __launch_bounds__(64) indir_illum_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ dirs,
+                                                             const float* __restrict__ d_rad, int n, int nl, int ns,
+                                                             float* __restrict__ d_raw) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    if (i >= n || lane >= nl) return;
+    float o[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o[k] = raw[((size_t)i * nl + lane) * 6 + k];
+    const IndirLobe L = indir_lobe(o);
+    float dmu[3] = {0, 0, 0}, dlam = 0.0f, du[3] = {0, 0, 0};
+    for (int s = 0; s < ns; ++s) {
+        const float* d = dirs + ((size_t)i * ns + s) * 3;
+        const float* g = d_rad + ((size_t)i * ns + s) * 3;
+        const float cosv = L.ax[0] * d[0] + L.ax[1] * d[1] + L.ax[2] * d[2];
+        const float w = expf(L.lam * (cosv - 1.0f));
+        const float a = g[0] * L.mu[0] + g[1] * L.mu[1] + g[2] * L.mu[2];      // dL/dw
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dmu[c] += g[c] * w;
+        dlam += a * w * (cosv - 1.0f);
+        const float dcos = a * w * L.lam;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) du[c] += dcos * d[c];
+    }
+    // through axis = raw / |raw|
+    const float udu = L.ax[0] * du[0] + L.ax[1] * du[1] + L.ax[2] * du[2];
+    float dr[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dr[c] = (du[c] - L.ax[c] * udu) * L.inv_norm;
+    const float dtheta = dr[0] * (-L.st * L.sp) + dr[1] * (L.ct * L.sp);
+    const float dphi = dr[0] * (L.ct * L.cp) + dr[1] * (L.st * L.cp) - dr[2] * L.sp;
+    float* out = d_raw + ((size_t)i * nl + lane) * 6;
+    out[0] = dtheta * kTwoPi * L.sg0 * (1.0f - L.sg0);
+    out[1] = dphi * kTwoPi * L.sg1 * (1.0f - L.sg1);
+    out[2] = dlam * 30.0f * L.sg2 * (1.0f - L.sg2);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[3 + c] = L.pos[c] ? dmu[c] : 0.0f;
+}
+
+}  // namespace fneus
+
+using namespace fneus;
+
+extern "C" int fneus_indir_illum_fwd(const float* raw, const float* dirs, int n, int n_lobes, int n_dirs, float* radiance,
+                                     fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    clear_status();
+    if (n <= 0) return 0;
+    if (!raw || !dirs || !radiance || n_lobes <= 0 || n_lobes > 64 || n_dirs <= 0 || n_dirs > kIndirMaxS) return -2;
+    hipLaunchKernelGGL(indir_illum_fwd_kernel, dim3(n), dim3(64), 0, stream, raw, dirs, n, n_lobes, n_dirs, radiance);
+    return launch_status();
+}
+
+extern "C" int fneus_indir_illum_bwd(const float* raw, const float* dirs, const float* d_radiance, int n, int n_lobes, int n_dirs,
+                                     float* d_raw, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    clear_status();
+    if (n <= 0) return 0;
+    if (!raw || !dirs || !d_radiance || !d_raw || n_lobes <= 0 || n_lobes > 64 || n_dirs <= 0 || n_dirs > kIndirMaxS) return -2;
+    hipLaunchKernelGGL(indir_illum_bwd_kernel, dim3(n), dim3(64), 0, stream, raw, dirs, d_radiance, n, n_lobes, n_dirs, d_raw);
+    return launch_status();
+}

@@ -804,6 +804,21 @@ def upsample(rays_o, rays_d, z, sdf, k: int, inv_s: float):
     return out
 
 
+def indir_illum_fwd(raw, dirs):
+    """raw [n, L, 6] (IndirectLight's MLP output), dirs [n, S, 3] -> radiance [n, S, 3] (fneus_indir_illum_fwd)"""
+    n, L, S = raw.shape[0], raw.shape[1], dirs.shape[1]
+    out = torch.empty(n, S, 3, dtype=torch.float32, device=raw.device)
+    _launch("fneus_indir_illum_fwd", lib.fneus_indir_illum_fwd, _ptr(raw), _ptr(dirs), n, L, S, _ptr(out), _stream())
+    return out
+
+
+def indir_illum_bwd(raw, dirs, d_rad):
+    n, L, S = raw.shape[0], raw.shape[1], dirs.shape[1]
+    d_raw = torch.empty_like(raw)
+    _launch("fneus_indir_illum_bwd", lib.fneus_indir_illum_bwd, _ptr(raw), _ptr(dirs), _ptr(d_rad), n, L, S, _ptr(d_raw), _stream())
+    return d_raw
+
+
 def outside_z(rays_o, rays_d, n_outside: int, n_samples: int, far=None, u=None):
     """z_vals_outside of NeuSRenderer.render (renderer.py:397-400, 411-419) -> [B, n_outside]; far [B] or None (unit-sphere bound
     of the rays), u [B, n_outside] uniform draws or None (no jitter)"""

@@ -128,7 +128,10 @@ def cal_indiLgt(surf, normal, sdf_network, deviation_network, color_network, lvi
         gt_lvis = (1.0 - occu).reshape(n, nsamp)
         gt_trace_radiance = hit_rgb.reshape(n, nsamp, 3)
     pre_lvis = lvis_network(origins, dirs).reshape(n, nsamp)
-    pre_trace_radiance = query_indir_illum(indiLgt_network(surf), dirs.reshape(n, nsamp, 3))
+    if surf.is_cuda and hasattr(indiLgt_network, "radiance") and indiLgt_network.num_lgt_sgs <= 64:
+        pre_trace_radiance = indiLgt_network.radiance(surf, dirs.reshape(n, nsamp, 3))       # the two lines below, fused
+    else:
+        pre_trace_radiance = query_indir_illum(indiLgt_network(surf), dirs.reshape(n, nsamp, 3))
     if trace is not None:
         trace.update(dirs=dirs.reshape(n, nsamp, 3))
     return {"gt_lvis": gt_lvis, "pre_lvis": pre_lvis, "gt_trace_radiance": gt_trace_radiance,

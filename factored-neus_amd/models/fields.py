@@ -454,6 +454,18 @@ class NeRF(nn.Module):
         return density.reshape(-1, 1), rgb
 
 
+class _IndirIllumFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, raw, dirs):
+        ctx.save_for_backward(raw, dirs)
+        return ops.indir_illum_fwd(raw, dirs)
+
+    @staticmethod
+    def backward(ctx, d_rad):
+        raw, dirs = ctx.saved_tensors
+        return ops.indir_illum_bwd(raw, dirs, d_rad.contiguous()), None
+
+
 class _DirectLinearFn(torch.autograd.Function):
     """nn.Linear whose backward writes the weight / bias gradients STRAIGHT into the parameters' persistent `.grad` buffers
     (`torch.mm(..., out=weight.grad)`, `torch.sum(..., out=bias.grad)`) and hands autograd no gradient for them.  With
@@ -575,6 +587,12 @@ class IndirectLight(nn.Module):
         self.embedview_fn_pts, ch_pts = get_embedder(10)
         self.indi = nn.Sequential(nn.Linear(ch_pts, 512), nn.ReLU(), nn.Linear(512, 512), nn.ReLU(), nn.Linear(512, 512),
                                   nn.ReLU(), nn.Linear(512, 512), nn.ReLU(), nn.Linear(512, num_lgt_sgs * 6))
+
+    def radiance(self, pts, sample_dirs):
+        """query_indir_illum(self(pts), sample_dirs) (calLvis.py:323-336) [n, S, 3] without materialising the lobes: the output
+        transform below and the sum of spherical Gaussians in one launch forward, one backward (fneus_indir_illum_fwd / _bwd)"""
+        raw = _seq_direct(self.indi, self.embedview_fn_pts(pts), self).reshape(-1, self.num_lgt_sgs, 6)
+        return _IndirIllumFn.apply(raw.contiguous(), sample_dirs.detach().float().contiguous())
 
     def forward(self, pts):
         out = _seq_direct(self.indi, self.embedview_fn_pts(pts), self).reshape(-1, self.num_lgt_sgs, 6)

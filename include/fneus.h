@@ -318,6 +318,15 @@ int fneus_sample_dirs(const float* surf /*[n_pts][3]*/, const float* normal /*[n
                       fneus_stream_t stream);
 
 /* ---- Stage 3 (mateIllu.py): per-lobe light visibility, get_diffuse_visibility (inverRender.py:128-192) ------------------------ */
+/* ---- stage 2: predicted indirect radiance from the RAW output of the IndirectLight MLP (models/fields.py:395-413 output
+ * transform + models/calLvis.py:323-336 query_indir_illum) and its adjoint ------------------------------------------------- */
+/* raw [n][L][6] (theta, phi, sharpness, amplitude rgb before their sigmoid / relu), dirs [n][S][3] unit directions (no
+ * gradient) -> radiance [n][S][3] = sum_l mu_l exp(lambda_l (axis_l . d_s - 1)).  L <= 64, S <= 8. */
+int fneus_indir_illum_fwd(const float* raw, const float* dirs, int n, int n_lobes, int n_dirs, float* radiance,
+                          fneus_stream_t stream);
+int fneus_indir_illum_bwd(const float* raw, const float* dirs, const float* d_radiance /*[n][S][3]*/, int n, int n_lobes,
+                          int n_dirs, float* d_raw /*[n][L][6]*/, fneus_stream_t stream);
+
 /* lvis_blob: fneus_pack output for layout 3 (the Lvis network, fields.py:338-369, plain Linear layers).  points, normals
  * [n_pts][3] (unit normals); dirs [n_lobes][32][3]: the sampled directions around every light lobe (inverRender.py:158-161);
  * weights [n_lobes][32] = exp(lambda (d . axis - 1)) (:186).  vis [n_lobes][n_pts] = sum_s [n . d_s > 1e-6] Lvis(p, d_s) w_s /

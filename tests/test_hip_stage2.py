@@ -280,3 +280,33 @@ def test_fixed_shape_render_matches_the_reference_and_the_graph_step_trains(gold
     o = trg.train_step(away)
     assert int(o["n_hit"]) == 0 and float(o["loss"]) == 0.0
     assert all(bool(torch.isfinite(p).all()) for p in trg.params)
+
+
+def test_fused_indirect_radiance_vs_the_element_wise_formulation():
+    """IndirectLight.radiance (fneus_indir_illum_fwd / _bwd: the network's output transform + query_indir_illum in one launch each)
+    against query_indir_illum(IndirectLight.forward(.)) through autograd: values and the gradients of every parameter"""
+    from fneus import synth
+    from models.calLvis import query_indir_illum
+    from models.fields import IndirectLight
+    dev = torch.device(DEV)
+    net = IndirectLight()
+    net.load_state_dict({k: T(v) for k, v in synth.indilgt_state_dict(5).items()})
+    net.to(dev)
+    g = torch.Generator().manual_seed(2)
+    n, S = 301, 4
+    pts = (torch.randn(n, 3, generator=g) * 0.4).to(dev)
+    dirs = torch.nn.functional.normalize(torch.randn(n, S, 3, generator=g), dim=-1).to(dev)
+    cot = torch.randn(n, S, 3, generator=g).to(dev)
+
+    def run(fused):
+        for p in net.parameters():
+            p.grad = None
+        rad = net.radiance(pts, dirs) if fused else query_indir_illum(net(pts), dirs)
+        (rad * cot).sum().backward()
+        return rad.detach().clone(), [p.grad.detach().clone() for p in net.parameters()]
+
+    r0, g0 = run(False)
+    r1, g1 = run(True)
+    assert (r1 - r0).abs().max().item() <= 2e-6 * max(1.0, r0.abs().max().item())
+    for a, b in zip(g1, g0):
+        assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-6)
