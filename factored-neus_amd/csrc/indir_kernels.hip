@@ -130,3 +130,76 @@ extern "C" int fneus_indir_illum_bwd(const float* raw, const float* dirs, const 
     hipLaunchKernelGGL(indir_illum_bwd_kernel, dim3(n), dim3(64), 0, stream, raw, dirs, d_radiance, n, n_lobes, n_dirs, d_raw);
     return launch_status();
 }
+
+// ---- sRGB transfer curves as ONE element-wise launch (and one for the adjoint) -------------------------------------------------
+// linear_to_srgb / srgb_to_linear (reference models/math_utils.py:138-152, used by RefColor, fields.py:329-335, and by the stage-3
+// tone mapping, inverRender.py:13-18) are where(x <= t, a x, pow-branch): 7-8 element-wise PyTorch launches each on [512, 3]
+// tensors, as many again in the backward, seven calls per stage-3 step.  mode bit 0: 0 = linear -> sRGB, 1 = sRGB -> linear;
+// bit 1: clip the result to [0, 1] (torch.clip behind the curve: zero gradient outside).
+namespace fneus {
+
+FN_DEV float srgb_curve(float x, int mode, float& slope) {
+    const float eps = 1.1920929e-07f;       // torch.finfo(float32).eps: the clamp in front of the power
+    float y;
+    if ((mode & 1) == 0) {
+        if (x <= 0.0031308f) {
+            y = (323.0f / 25.0f) * x;
+            slope = 323.0f / 25.0f;
+        } else {
+            const float c = fmaxf(x, eps);
+            const float p = powf(c, 5.0f / 12.0f);
+            y = (211.0f * p - 11.0f) / 200.0f;
+            slope = x >= eps ? (211.0f / 200.0f) * (5.0f / 12.0f) * p / c : 0.0f;
+        }
+    } else {
+        if (x <= 0.04045f) {
+            y = (25.0f / 323.0f) * x;
+            slope = 25.0f / 323.0f;
+        } else {
+            const float t = (200.0f * x + 11.0f) / 211.0f;
+            const float c = fmaxf(t, eps);
+            const float p = powf(c, 12.0f / 5.0f);
+            y = p;
+            slope = t >= eps ? (12.0f / 5.0f) * p / c * (200.0f / 211.0f) : 0.0f;
+        }
+    }
+    if (mode & 2) {
+        if (y < 0.0f || y > 1.0f) slope = 0.0f;
+        y = fminf(fmaxf(y, 0.0f), 1.0f);
+    }
+    return y;
+}
+
+__global__ void __launch_bounds__(256) srgb_fwd_kernel(const float* __restrict__ x, long n, int mode, float* __restrict__ y) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s;
+    y[i] = srgb_curve(x[i], mode, s);
+}
+__global__ void __launch_bounds__(256) srgb_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, long n, int mode,
+                                                       float* __restrict__ dx) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s;
+    (void)srgb_curve(x[i], mode, s);
+    dx[i] = dy[i] * s;
+}
+
+}  // namespace fneus
+
+extern "C" int fneus_srgb_fwd(const float* x, long n, int mode, float* y, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (n <= 0) return 0;
+    if (!x || !y || mode < 0 || mode > 3) return -2;
+    hipLaunchKernelGGL(fneus::srgb_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, n, mode, y);
+    return fneus::launch_status();
+}
+extern "C" int fneus_srgb_bwd(const float* x, const float* dy, long n, int mode, float* dx, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (n <= 0) return 0;
+    if (!x || !dy || !dx || mode < 0 || mode > 3) return -2;
+    hipLaunchKernelGGL(fneus::srgb_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, dy, n, mode, dx);
+    return fneus::launch_status();
+}

@@ -804,6 +804,30 @@ def upsample(rays_o, rays_d, z, sdf, k: int, inv_s: float):
     return out
 
 
+class _SrgbFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mode):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        _launch("fneus_srgb_fwd", lib.fneus_srgb_fwd, _ptr(x), x.numel(), mode, _ptr(y), _stream())
+        ctx.save_for_backward(x)
+        ctx.mode = mode
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        _launch("fneus_srgb_bwd", lib.fneus_srgb_bwd, _ptr(x), _ptr(dy), x.numel(), ctx.mode, _ptr(dx), _stream())
+        return dx, None
+
+
+def srgb(x, to_linear: bool = False, clip: bool = False):
+    """linear_to_srgb / srgb_to_linear (math_utils.py:138-152), optionally followed by clip(., 0, 1), as one launch (fneus_srgb_fwd)"""
+    return _SrgbFn.apply(x, (1 if to_linear else 0) | (2 if clip else 0))
+
+
 def indir_illum_fwd(raw, dirs):
     """raw [n, L, 6] (IndirectLight's MLP output), dirs [n, S, 3] -> radiance [n, S, 3] (fneus_indir_illum_fwd)"""
     n, L, S = raw.shape[0], raw.shape[1], dirs.shape[1]

@@ -256,6 +256,8 @@ def _l2_normalize(x):
 
 
 def _linear_to_srgb(linear):
+    if linear.is_cuda and linear.dtype == torch.float32:
+        return ops.srgb(linear)                   # one launch (fneus_srgb_fwd / _bwd)
     eps = torch.finfo(torch.float32).eps
     srgb0 = 323.0 / 25.0 * linear
     srgb1 = (211.0 * torch.clamp(linear, min=eps) ** (5.0 / 12.0) - 11.0) / 200.0
@@ -374,9 +376,11 @@ class RefColor(nn.Module):
     @staticmethod
     def shade(diffuse, spec):
         spec = spec[:, :1].repeat(1, 3)
-        return {"rgb": torch.clip(_linear_to_srgb(spec + diffuse), 0.0, 1.0),
-                "specular_rgb": torch.clip(_linear_to_srgb(spec), 0.0, 1.0),
-                "diffuse_rgb": torch.clip(_linear_to_srgb(diffuse), 0.0, 1.0)}
+        if diffuse.is_cuda and diffuse.dtype == torch.float32:
+            f = lambda x: ops.srgb(x, clip=True)      # clip(linear_to_srgb(.), 0, 1) in one launch
+        else:
+            f = lambda x: torch.clip(_linear_to_srgb(x), 0.0, 1.0)
+        return {"rgb": f(spec + diffuse), "specular_rgb": f(spec), "diffuse_rgb": f(diffuse)}
 
     def forward_samples(self, samples: RaySamples, x, n):
         """hot-path entry: sample positions given as (rays_o, rays_d, t) like the other fused kernels"""

@@ -18,14 +18,21 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from fneus import ops
 from models.embedder import get_embedder
 from models.fields import _seq_direct
 
 TINY_NUMBER = 1e-6
 
 
+def _fused_ok(x):
+    return x.is_cuda and x.dtype == torch.float32
+
+
 def linear_to_srgb(linear):
-    """math_utils.py:138-144"""
+    """math_utils.py:138-144 (one launch on the GPU: fneus_srgb_fwd / _bwd)"""
+    if _fused_ok(linear):
+        return ops.srgb(linear)
     eps = torch.finfo(torch.float32).eps
     return torch.where(linear <= 0.0031308, 323.0 / 25.0 * linear,
                        (211.0 * torch.clamp(linear, min=eps) ** (5.0 / 12.0) - 11.0) / 200.0)
@@ -33,8 +40,17 @@ def linear_to_srgb(linear):
 
 def srgb_to_linear(srgb):
     """math_utils.py:147-152"""
+    if _fused_ok(srgb):
+        return ops.srgb(srgb, to_linear=True)
     eps = torch.finfo(torch.float32).eps
     return torch.where(srgb <= 0.04045, 25.0 / 323.0 * srgb, torch.clamp((200.0 * srgb + 11.0) / 211.0, min=eps) ** (12.0 / 5.0))
+
+
+def tonemap_clip(linear):
+    """torch.clip(tonemap_img(linear), 0, 1) as the reference writes it everywhere (inverRender.py:567-598): one launch"""
+    if _fused_ok(linear):
+        return ops.srgb(linear, clip=True)
+    return torch.clip(linear_to_srgb(linear), 0.0, 1.0)
 
 
 tonemap_img = linear_to_srgb          # inverRender.py:13-18 with mode = 'dtu'
@@ -186,8 +202,8 @@ def render_with_sg(points, normal, viewdirs, lgtSGs, specular_reflectance, specu
     diffuse = (diffuse_albedo / np.pi)[:, None, :].expand(n, M, 3)
     diffuse_linear = integrate_rgb(nrm, lobes, lambdas, mus * diffuse)
     return {"specular_loss": 0, "diffuse_loss": 0, "env_rgb": torch.clamp(specular_linear + diffuse_linear, 0.0, 1.0),
-            "diffuse_rgb": torch.clip(tonemap_img(diffuse_linear), 0.0, 1.0),
-            "specular_rgb": torch.clip(tonemap_img(specular_linear), 0.0, 1.0), "lvis_mean": vis_shadow}
+            "diffuse_rgb": tonemap_clip(diffuse_linear),
+            "specular_rgb": tonemap_clip(specular_linear), "lvis_mean": vis_shadow}
 
 
 FUSED_SG = True      # stage 3 on fneus_sg_render_fwd / _bwd (one launch each way); False: the element-wise torch formulation below
@@ -208,10 +224,10 @@ def _render_with_all_sg_fused(points, normal, viewdirs, lgtSGs, f0: float, specu
     env = torch.clamp(spec_d + diff_d, 0.0, 1.0)
     indir = torch.clamp(spec_i + diff_i, 0.0, 1.0) if indir_lgtSGs is not None else torch.zeros_like(points)
     return {"specular_loss": 0, "diffuse_loss": 0,
-            "diffuse_rgb": torch.clip(tonemap_img(diff_d), 0.0, 1.0), "specular_rgb": torch.clip(tonemap_img(spec_d), 0.0, 1.0),
+            "diffuse_rgb": tonemap_clip(diff_d), "specular_rgb": tonemap_clip(spec_d),
             "lvis_mean": vis.mean(dim=0)[:, None].expand(-1, 3),
-            "rgb": torch.clip(tonemap_img(env + indir), 0.0, 1.0), "indir_rgb": torch.clip(tonemap_img(indir), 0.0, 1.0),
-            "env_rgb": torch.clip(tonemap_img(env), 0.0, 1.0)}
+            "rgb": tonemap_clip(env + indir), "indir_rgb": tonemap_clip(indir),
+            "env_rgb": tonemap_clip(env)}
 
 
 def render_with_all_sg(points, normal, viewdirs, lgtSGs, specular_reflectance, specular_albedo, roughness, diffuse_albedo,
@@ -231,8 +247,8 @@ def render_with_all_sg(points, normal, viewdirs, lgtSGs, specular_reflectance, s
         indir_rgb = render_with_sg(points, normal, viewdirs, indir_lgtSGs, specular_reflectance, specular_albedo, roughness,
                                    diffuse_albedo, gt_specular_linear, comp_vis=False)["env_rgb"]
     env_rgb = ret["env_rgb"]
-    ret.update({"rgb": torch.clip(tonemap_img(env_rgb + indir_rgb), 0.0, 1.0),
-                "indir_rgb": torch.clip(tonemap_img(indir_rgb), 0.0, 1.0), "env_rgb": torch.clip(tonemap_img(env_rgb), 0.0, 1.0)})
+    ret.update({"rgb": tonemap_clip(env_rgb + indir_rgb),
+                "indir_rgb": tonemap_clip(indir_rgb), "env_rgb": tonemap_clip(env_rgb)})
     return ret
 
 
@@ -313,8 +329,8 @@ class EnvmapMaterialNetwork(nn.Module):
                                  diffuse_albedo, gt_specular_linear, lvis_network=lvis_network, indir_lgtSGs=indiLgt,
                                  u_theta=u_theta, u_phi=u_phi, specular_reflectance_value=self.specular_reflectance_value,
                                  point_mask=point_mask)
-        ret.update({"roughness": roughness, "diffuse_albedo": torch.clip(tonemap_img(diffuse_albedo), 0.0, 1.0),
-                    "specular_albedo": torch.clip(tonemap_img(specular_albedo), 0.0, 1.0), "encoder_loss": loss,
+        ret.update({"roughness": roughness, "diffuse_albedo": tonemap_clip(diffuse_albedo),
+                    "specular_albedo": tonemap_clip(specular_albedo), "encoder_loss": loss,
                     "smooth_loss": 0.0})
         return ret
 

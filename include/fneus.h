@@ -318,6 +318,12 @@ int fneus_sample_dirs(const float* surf /*[n_pts][3]*/, const float* normal /*[n
                       fneus_stream_t stream);
 
 /* ---- Stage 3 (mateIllu.py): per-lobe light visibility, get_diffuse_visibility (inverRender.py:128-192) ------------------------ */
+/* ---- sRGB transfer curves (models/math_utils.py:138-152; RefColor, fields.py:329-335; stage-3 tone mapping, inverRender.py:13-18)
+ * as one element-wise launch and one for the adjoint.  mode bit 0: 0 = linear -> sRGB, 1 = sRGB -> linear; bit 1: clip to [0, 1]
+ * behind the curve (zero gradient outside). */
+int fneus_srgb_fwd(const float* x, long n, int mode, float* y, fneus_stream_t stream);
+int fneus_srgb_bwd(const float* x, const float* dy, long n, int mode, float* dx, fneus_stream_t stream);
+
 /* ---- stage 2: predicted indirect radiance from the RAW output of the IndirectLight MLP (models/fields.py:395-413 output
  * transform + models/calLvis.py:323-336 query_indir_illum) and its adjoint ------------------------------------------------- */
 /* raw [n][L][6] (theta, phi, sharpness, amplitude rgb before their sigmoid / relu), dirs [n][S][3] unit directions (no

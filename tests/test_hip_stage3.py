@@ -289,3 +289,33 @@ def test_fused_sg_rendering_vs_the_element_wise_formulation():
         rel = ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
         print(f"  fused SG backward, d {name}: worst relative difference {rel:.2e}")
         assert rel <= 2e-3, (name, rel)
+
+
+@pytest.mark.parametrize("to_linear,clip", [(False, False), (True, False), (False, True)])
+def test_fused_srgb_curves_vs_the_element_wise_formulation(to_linear, clip):
+    """fneus_srgb_fwd / _bwd against math_utils.py:138-152 written with torch ops (+ torch.clip): values and gradient, on inputs
+    that straddle both branch points, zero, negatives and values beyond 1"""
+    from fneus import ops
+    dev = torch.device(DEV)
+    g = torch.Generator().manual_seed(4)
+    x = torch.cat([torch.rand(4000, generator=g) * 1.4 - 0.1, torch.tensor([0.0, 0.0031308, 0.04045, 1.0, 2.0, -0.5, 1e-9])]).to(dev)
+    cot = torch.randn(x.shape, generator=g).to(dev)
+    eps = torch.finfo(torch.float32).eps
+
+    def ref(v):
+        if to_linear:
+            y = torch.where(v <= 0.04045, 25.0 / 323.0 * v, torch.clamp((200.0 * v + 11.0) / 211.0, min=eps) ** (12.0 / 5.0))
+        else:
+            y = torch.where(v <= 0.0031308, 323.0 / 25.0 * v, (211.0 * torch.clamp(v, min=eps) ** (5.0 / 12.0) - 11.0) / 200.0)
+        return torch.clip(y, 0.0, 1.0) if clip else y
+
+    xa = x.clone().requires_grad_(True)
+    ya = ref(xa)
+    (ya * cot).sum().backward()
+    xb = x.clone().requires_grad_(True)
+    yb = ops.srgb(xb, to_linear=to_linear, clip=clip)
+    (yb * cot).sum().backward()
+    assert (yb - ya).abs().max().item() <= 2e-6
+    # (the clip's sub-gradient exactly at 0 / 1 and the branch points are measure-zero conventions: compare away from them)
+    away = ((ya.detach() - 0.0).abs() > 1e-6) & ((ya.detach() - 1.0).abs() > 1e-6)
+    assert ((xb.grad - xa.grad).abs()[away] <= 2e-5 * xa.grad.abs()[away].clamp_min(1.0)).all()

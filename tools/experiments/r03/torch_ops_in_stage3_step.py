@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Which PyTorch (aten) ops still launch kernels inside one eager train step, in order, with their input shapes."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "factored-neus_amd"))
+import torch
+from torch.profiler import profile, ProfilerActivity
+from fneus.trainer import synthetic_batches
+from fneus.trainer3 import Stage3Trainer
+dev = torch.device("cuda:0")
+tr = Stage3Trainer(dev, use_graph=False)
+bs = synthetic_batches(4, 512, dev)
+for b in bs[:3]:
+    tr.train_step(b)
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=False) as prof:
+    tr._fixed_shape_step(bs[3])
+    torch.cuda.synchronize()
+evs = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CPU and e.name.startswith("aten::")]
+# keep leaf aten ops that launched a kernel
+out = []
+for e in evs:
+    if e.kernels:
+        out.append((e.time_range.start, e.name, [k.name[:60] for k in e.kernels], e.input_shapes))
+out.sort()
+seen = set()
+for t, name, ks, shp in out:
+    print(f"{name:28s} {str(shp)[:70]:72s} {ks[0]}")
+print(len(out), "aten ops with kernels")
