@@ -828,6 +828,16 @@ def srgb(x, to_linear: bool = False, clip: bool = False):
     return _SrgbFn.apply(x, (1 if to_linear else 0) | (2 if clip else 0))
 
 
+def vis_sample_dirs(lobes, lambdas, u_theta, u_phi):
+    """fneus_vis_sample_dirs: lobes [M,3], lambdas [M], u_theta / u_phi [M,S] -> dirs [M,S,3], weights [M,S]"""
+    M, S = u_theta.shape
+    dirs = torch.empty(M, S, 3, dtype=torch.float32, device=lobes.device)
+    w = torch.empty(M, S, dtype=torch.float32, device=lobes.device)
+    _launch("fneus_vis_sample_dirs", lib.fneus_vis_sample_dirs, _ptr(lobes), _ptr(lambdas), _ptr(u_theta), _ptr(u_phi), M, S, _ptr(dirs),
+            _ptr(w), _stream())
+    return dirs, w
+
+
 def indir_illum_fwd(raw, dirs):
     """raw [n, L, 6] (IndirectLight's MLP output), dirs [n, S, 3] -> radiance [n, S, 3] (fneus_indir_illum_fwd)"""
     n, L, S = raw.shape[0], raw.shape[1], dirs.shape[1]

@@ -318,6 +318,11 @@ int fneus_sample_dirs(const float* surf /*[n_pts][3]*/, const float* normal /*[n
                       fneus_stream_t stream);
 
 /* ---- Stage 3 (mateIllu.py): per-lobe light visibility, get_diffuse_visibility (inverRender.py:128-192) ------------------------ */
+/* The direction set of get_diffuse_visibility (inverRender.py:133-161): lobes [M][3], lambdas [M] (sharpness), u_theta / u_phi
+ * [M][S] uniform draws -> dirs [M][S][3] inside each lobe's cone, weights [M][S] = exp(lambda (dir . axis - 1)). */
+int fneus_vis_sample_dirs(const float* lobes, const float* lambdas, const float* u_theta, const float* u_phi, int n_lobes, int n_samp,
+                          float* dirs, float* weights, fneus_stream_t stream);
+
 /* ---- sRGB transfer curves (models/math_utils.py:138-152; RefColor, fields.py:329-335; stage-3 tone mapping, inverRender.py:13-18)
  * as one element-wise launch and one for the adjoint.  mode bit 0: 0 = linear -> sRGB, 1 = sRGB -> linear; bit 1: clip to [0, 1]
  * behind the curve (zero gradient outside). */

@@ -319,3 +319,21 @@ def test_fused_srgb_curves_vs_the_element_wise_formulation(to_linear, clip):
     # (the clip's sub-gradient exactly at 0 / 1 and the branch points are measure-zero conventions: compare away from them)
     away = ((ya.detach() - 0.0).abs() > 1e-6) & ((ya.detach() - 1.0).abs() > 1e-6)
     assert ((xb.grad - xa.grad).abs()[away] <= 2e-5 * xa.grad.abs()[away].clamp_min(1.0)).all()
+
+
+def test_fused_visibility_direction_set_vs_the_element_wise_formulation():
+    """fneus_vis_sample_dirs against visibility_sample_dirs' element-wise formulation (inverRender.py:133-161; evaluated on the
+    CPU, where the module keeps it) on the same uniform draws: directions and weights"""
+    from fneus import synth
+    from models.inverRender import visibility_sample_dirs
+    dev = torch.device(DEV)
+    sg = T(synth.mateillu_state_dict(32)["lgtSGs"])
+    lobes = sg[:, :3] / (sg[:, :3].norm(dim=-1, keepdim=True) + 1e-6)
+    lam = sg[:, 3:4].abs()
+    g = torch.Generator().manual_seed(6)
+    ut, up = torch.rand(128, 32, generator=g), torch.rand(128, 32, generator=g)
+    d_ref, w_ref = visibility_sample_dirs(lobes, lam, 32, ut, up)
+    d, w = visibility_sample_dirs(lobes.to(dev), lam.to(dev), 32, ut.to(dev), up.to(dev))
+    assert d.shape == (128, 32, 3) and w.shape == (128, 32)
+    assert (d.cpu() - d_ref).abs().max().item() <= 5e-6
+    assert ((w.cpu() - w_ref).abs() <= 2e-5 * w_ref.abs().clamp_min(1e-3)).all()
