@@ -271,3 +271,33 @@ extern "C" int fneus_vis_sample_dirs(const float* lobes, const float* lambdas, c
                        weights);
     return fneus::launch_status();
 }
+
+// ---- IndirectLight's output transform alone (models/fields.py:395-413), forward only: raw [n][L][6] -> lgtSGs [n][L][7] = (axis,
+// lambda, mu).  Stage 3 evaluates the frozen network once per step: ~15 element-wise launches before. ---------------------------
+namespace fneus {
+__global__ void __launch_bounds__(256) indir_sgs_kernel(const float* __restrict__ raw, long n_lobes_total, float* __restrict__ sgs) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_lobes_total) return;
+    float o[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o[k] = raw[i * 6 + k];
+    const IndirLobe L = indir_lobe(o);
+    float* out = sgs + i * 7;
+    out[0] = L.ct * L.sp;
+    out[1] = L.st * L.sp;
+    out[2] = L.cp;
+    out[3] = L.lam;
+    out[4] = L.mu[0];
+    out[5] = L.mu[1];
+    out[6] = L.mu[2];
+}
+}  // namespace fneus
+
+extern "C" int fneus_indir_sgs(const float* raw, long n_lobes_total, float* sgs, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (n_lobes_total <= 0) return 0;
+    if (!raw || !sgs) return -2;
+    hipLaunchKernelGGL(fneus::indir_sgs_kernel, dim3((unsigned)((n_lobes_total + 255) / 256)), dim3(256), 0, stream, raw, n_lobes_total, sgs);
+    return fneus::launch_status();
+}

@@ -113,6 +113,7 @@ def _load():
         "fneus_outside_points": (C.c_int, [vp, vp, vp, ip, ip, f, vp, vp, vp, vp]),
         "fneus_outside_z": (C.c_int, [vp, vp, vp, vp, ip, ip, ip, vp, vp]),
         "fneus_vis_sample_dirs": (C.c_int, [vp, vp, vp, vp, ip, ip, vp, vp, vp]),
+        "fneus_indir_sgs": (C.c_int, [vp, l, vp, vp]),
         "fneus_srgb_fwd": (C.c_int, [vp, l, ip, vp, vp]),
         "fneus_srgb_bwd": (C.c_int, [vp, vp, l, ip, vp, vp]),
         "fneus_indir_illum_fwd": (C.c_int, [vp, vp, ip, ip, ip, vp, vp]),

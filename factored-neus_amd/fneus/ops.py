@@ -838,6 +838,14 @@ def vis_sample_dirs(lobes, lambdas, u_theta, u_phi):
     return dirs, w
 
 
+def indir_sgs(raw):
+    """fneus_indir_sgs: IndirectLight's output transform without gradient, raw [n, L, 6] -> [n, L, 7]"""
+    raw = raw.contiguous()
+    out = torch.empty(raw.shape[0], raw.shape[1], 7, dtype=torch.float32, device=raw.device)
+    _launch("fneus_indir_sgs", lib.fneus_indir_sgs, _ptr(raw), raw.shape[0] * raw.shape[1], _ptr(out), _stream())
+    return out
+
+
 def indir_illum_fwd(raw, dirs):
     """raw [n, L, 6] (IndirectLight's MLP output), dirs [n, S, 3] -> radiance [n, S, 3] (fneus_indir_illum_fwd)"""
     n, L, S = raw.shape[0], raw.shape[1], dirs.shape[1]

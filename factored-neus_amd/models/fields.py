@@ -600,6 +600,8 @@ class IndirectLight(nn.Module):
 
     def forward(self, pts):
         out = _seq_direct(self.indi, self.embedview_fn_pts(pts), self).reshape(-1, self.num_lgt_sgs, 6)
+        if out.is_cuda and out.dtype == torch.float32 and not (torch.is_grad_enabled() and out.requires_grad):
+            return ops.indir_sgs(out)             # frozen network (stage 3): the lines below in one launch
         ang = torch.sigmoid(out[..., :2]) * (2 * np.pi)
         theta, phi = ang[..., :1], ang[..., 1:2]
         lobes = torch.cat([torch.cos(theta) * torch.sin(phi), torch.sin(theta) * torch.sin(phi), torch.cos(phi)], dim=-1)

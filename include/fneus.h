@@ -318,6 +318,10 @@ int fneus_sample_dirs(const float* surf /*[n_pts][3]*/, const float* normal /*[n
                       fneus_stream_t stream);
 
 /* ---- Stage 3 (mateIllu.py): per-lobe light visibility, get_diffuse_visibility (inverRender.py:128-192) ------------------------ */
+/* IndirectLight's output transform (models/fields.py:395-413), no gradient: raw [N][6] -> lgtSGs [N][7] = (cos th sin ph, sin th sin ph,
+ * cos ph, 30 sigmoid(o2) + 0.1, relu(o3..5)), N = points x lobes. */
+int fneus_indir_sgs(const float* raw, long n_lobes_total, float* sgs, fneus_stream_t stream);
+
 /* The direction set of get_diffuse_visibility (inverRender.py:133-161): lobes [M][3], lambdas [M] (sharpness), u_theta / u_phi
  * [M][S] uniform draws -> dirs [M][S][3] inside each lobe's cone, weights [M][S] = exp(lambda (dir . axis - 1)). */
 int fneus_vis_sample_dirs(const float* lobes, const float* lambdas, const float* u_theta, const float* u_phi, int n_lobes, int n_samp,

@@ -337,3 +337,19 @@ def test_fused_visibility_direction_set_vs_the_element_wise_formulation():
     assert d.shape == (128, 32, 3) and w.shape == (128, 32)
     assert (d.cpu() - d_ref).abs().max().item() <= 5e-6
     assert ((w.cpu() - w_ref).abs() <= 2e-5 * w_ref.abs().clamp_min(1e-3)).all()
+
+
+def test_fused_indirect_light_output_transform():
+    """IndirectLight.forward without gradient (fneus_indir_sgs) against its element-wise formulation (with gradient enabled)"""
+    from fneus import synth
+    from models.fields import IndirectLight
+    dev = torch.device(DEV)
+    net = IndirectLight()
+    net.load_state_dict({k: T(v) for k, v in synth.indilgt_state_dict(5).items()})
+    net.to(dev)
+    pts = (torch.randn(257, 3, generator=torch.Generator().manual_seed(8)) * 0.4).to(dev)
+    ref = net(pts).detach()                      # parameters require grad: the torch formulation
+    with torch.no_grad():
+        got = net(pts)
+    assert got.shape == ref.shape == (257, net.num_lgt_sgs, 7)
+    assert (got - ref).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item())
