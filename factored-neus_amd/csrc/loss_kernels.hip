@@ -17,8 +17,8 @@ namespace fneus {
 // with their 1.1 MB of weight fragments per head in L2 (every XCD has its own).  surface_gather (512 single-wave workgroups)
 // runs right in front of the forward launch and the loss kernel (ONE workgroup) right in front of the backward one: extra
 // workgroups of these launches read the fragments the next launch is about to stream -- workgroup w serves XCD w % 8
-// (round-robin dispatch), the workgroups of an XCD share the lines of every range.  fneus_l2_warm_hint names the ranges.
-constexpr int kWarmRanges = 12;
+// (round-robin dispatch), the workgroups of an XCD share the lines of every range.  The caller names the ranges per launch (FneusWarmRanges).
+constexpr int kWarmRanges = FNEUS_MAX_WARM_RANGES;
 struct WarmList {
     int n;
     const unsigned char* p[kWarmRanges];
@@ -32,7 +32,20 @@ FN_DEV void warm_l2(const WarmList& W, int wb, int n_wb, int tid, int n_threads)
             acc += *reinterpret_cast<const unsigned*>(W.p[r] + (size_t)line * 128);
     asm volatile("" ::"v"(acc));
 }
-static WarmList g_warm[2];                  // host side: slot 0 in front of the RefColor forward, 1 in front of its backward
+// The ranges are an ARGUMENT of the launch that warms them (FneusWarmRanges, passed by the caller that owns the buffers): the
+// library keeps no pointer beyond a call, and a captured graph holds exactly the ranges its own step named.
+static WarmList warm_list(const FneusWarmRanges* w) {
+    WarmList W;
+    W.n = 0;
+    if (w != nullptr && w->n > 0) {
+        W.n = w->n < kWarmRanges ? w->n : kWarmRanges;
+        for (int i = 0; i < W.n; ++i) {
+            W.p[i] = reinterpret_cast<const unsigned char*>(w->ptr[i]);
+            W.lines[i] = (unsigned)(w->bytes[i] / 128);
+        }
+    }
+    return W;
+}
 
 // one wavefront per ray: sel[2b], sel[2b+1] = b*n + hi - 1, b*n + hi  with hi = sdf_mask ? min_idx : 1
 __global__ void __launch_bounds__(64) surface_gather_kernel(const int32_t* __restrict__ min_idx,
@@ -276,12 +289,12 @@ using namespace fneus;
 
 extern "C" int fneus_surface_gather(const int32_t* min_idx, const unsigned char* sdf_mask, const float* mid_z,
                                     const float* feat, const float* normal, int n_rays, int n, int32_t* sel, float* t_sel,
-                                    float* feat_sel, float* normal_sel, fneus_stream_t stream_) {
+                                    float* feat_sel, float* normal_sel, const FneusWarmRanges* warm, fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     fneus::clear_status();
     if (n_rays <= 0) return 0;
     if (n < 2) return -2;
-    const WarmList& W = g_warm[0];
+    const WarmList W = warm_list(warm);
     hipLaunchKernelGGL(surface_gather_kernel, dim3(n_rays + (W.n > 0 ? 1024 : 0)), dim3(64), 0, stream, min_idx, sdf_mask, mid_z, feat,
                        normal, n, sel, t_sel, feat_sel, normal_sel, n_rays, W);
     return fneus::launch_status();
@@ -292,14 +305,14 @@ extern "C" int fneus_stage1_loss(const float* color, const float* true_rgb, cons
                                  const unsigned char* sdf_mask, const float* norms, int n_rays, float igr_weight,
                                  float mask_weight, float surface_weight, float* losses, float* surface_color, float* specular_color,
                                  float* diffuse_color, float* d_color, float* d_wsum, float* d_eiknum, float* d_wpair,
-                                 float* d_diffuse, float* d_spec, fneus_stream_t stream_) {
+                                 float* d_diffuse, float* d_spec, const FneusWarmRanges* warm, fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     fneus::clear_status();
     if (n_rays <= 0) return -2;
     LossArgs a{color, true_rgb, mask_in, wsum, eik_num, eik_den, diffuse, spec, wpair, sdf_mask, norms, n_rays, igr_weight, mask_weight,
                surface_weight, losses, surface_color, specular_color, diffuse_color, d_color, d_wsum, d_eiknum, d_wpair,
                d_diffuse, d_spec};
-    const WarmList& W = g_warm[1];
+    const WarmList W = warm_list(warm);
     hipLaunchKernelGGL(stage1_loss_kernel, dim3(1 + (W.n > 0 ? 16 : 0)), dim3(kLossThreads), 0, stream, a, W);
     return fneus::launch_status();
 }
@@ -312,16 +325,4 @@ extern "C" int fneus_stage1_norms(const float* mask_in, const unsigned char* sdf
     hipLaunchKernelGGL(stage1_norms_kernel, dim3(1), dim3(kLossThreads), 0, stream, mask_in, sdf_mask, eik_den, n_rays,
                        mask_weight, norms);
     return fneus::launch_status();
-}
-
-
-extern "C" int fneus_l2_warm_hint(int slot, const void* const* ptrs, const long* bytes, int n) {
-    if (slot < 0 || slot > 1 || n < 0 || n > kWarmRanges) return -2;
-    WarmList& W = g_warm[slot];
-    W.n = n;
-    for (int i = 0; i < n; ++i) {
-        W.p[i] = reinterpret_cast<const unsigned char*>(ptrs[i]);
-        W.lines[i] = (unsigned)(bytes[i] / 128);
-    }
-    return 0;
 }

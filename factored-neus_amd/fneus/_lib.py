@@ -77,7 +77,6 @@ def _load():
         "fneus_pack": (C.c_int, [vp, ip, ip, vp, vp, vp, vp, vp]),
         "fneus_rowscale": (C.c_int, [vp, ip, vp, vp, vp, vp]),
         "fneus_refresh_multi": (C.c_int, [C.POINTER(FneusPackTask), ip, vp]),
-        "fneus_l2_warm_hint": (C.c_int, [ip, C.POINTER(C.c_void_p), C.POINTER(C.c_long), ip]),
         "fneus_wn_backward_multi": (C.c_int, [C.POINTER(FneusWnTask), ip, vp]),
         "fneus_wn_backward": (C.c_int, [vp, ip, vp, ip, vp, vp, vp, vp, vp, vp]),
         "fneus_sdf_fwd": (C.c_int, [vp, vp, vp, vp, vp, ip, l, vp, ip, vp]),
@@ -99,8 +98,8 @@ def _load():
         "fneus_nerf_bg_fwd": (C.c_int, [vp, vp, vp, l, C.POINTER(FneusNerfStash), vp, vp, ip, ip, vp]),
         "fneus_nerf_bg_bwd": (C.c_int, [vp, l, vp, vp, C.POINTER(FneusNerfStash), ip, vp]),
         "fneus_adam": (C.c_int, [C.POINTER(FneusAdamSegment), ip, vp, vp, C.c_double, C.c_double, C.c_double, ip, vp]),
-        "fneus_surface_gather": (C.c_int, [vp, vp, vp, vp, vp, ip, ip, vp, vp, vp, vp, vp]),
-        "fneus_stage1_loss": (C.c_int, [vp] * 11 + [ip, f, f, f] + [vp] * 10 + [vp]),
+        "fneus_surface_gather": (C.c_int, [vp, vp, vp, vp, vp, ip, ip, vp, vp, vp, vp, vp, vp]),
+        "fneus_stage1_loss": (C.c_int, [vp] * 11 + [ip, f, f, f] + [vp] * 10 + [vp, vp]),
         "fneus_stage1_norms": (C.c_int, [vp, vp, vp, ip, f, vp, vp]),
         "fneus_upsample": (C.c_int, [vp, vp, vp, vp, ip, ip, ip, f, vp, vp]),
         "fneus_merge": (C.c_int, [vp, vp, ip, vp, vp, ip, ip, vp, vp, vp]),

@@ -305,9 +305,9 @@ class SurfaceGatherFn(torch.autograd.Function):
     through the workspace (see SdfValueGradFn.backward) and returns no dense gradient."""
 
     @staticmethod
-    def forward(ctx, feat, normal, mid_z, min_idx, sdf_mask, sdf_ws: _Workspace):
+    def forward(ctx, feat, normal, mid_z, min_idx, sdf_mask, sdf_ws: _Workspace, warm=None):
         sel, t_sel, feat_sel, normal_sel = ops.surface_gather(min_idx, sdf_mask, mid_z.contiguous(), feat.contiguous(),
-                                                              normal.contiguous())
+                                                              normal.contiguous(), warm=warm)
         ctx.sdf_ws = sdf_ws
         ctx.save_for_backward(sel)
         ctx.mark_non_differentiable(t_sel, sel)
@@ -319,7 +319,7 @@ class SurfaceGatherFn(torch.autograd.Function):
         (sel,) = ctx.saved_tensors
         ctx.sdf_ws.cache["surface_grads"] = (sel, None if d_feat_sel is None else d_feat_sel.contiguous(),
                                              None if d_normal_sel is None else d_normal_sel.contiguous())
-        return None, None, None, None, None, None
+        return None, None, None, None, None, None, None
 
 
 class Stage1LossFn(torch.autograd.Function):
@@ -329,14 +329,14 @@ class Stage1LossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, color, wsum, eik_num, wpair, diffuse, spec, eik_den, true_rgb, mask_in, sdf_mask, igr_weight,
-                mask_weight, surface_weight, reduce_norms=None):
+                mask_weight, surface_weight, reduce_norms=None, warm=None):
         mask_flat = mask_in.contiguous().reshape(-1)
         norms = None
         if reduce_norms is not None:       # data parallel: normalisers of the global batch
             norms = reduce_norms(ops.stage1_norms(mask_flat, sdf_mask, eik_den.contiguous(), mask_weight))
         o = ops.stage1_loss(color.contiguous(), true_rgb.contiguous(), mask_flat, wsum.contiguous(),
                             eik_num.contiguous(), eik_den.contiguous(), diffuse.contiguous(), spec.contiguous(),
-                            wpair.contiguous(), sdf_mask, igr_weight, mask_weight, surface_weight, norms=norms)
+                            wpair.contiguous(), sdf_mask, igr_weight, mask_weight, surface_weight, norms=norms, warm=warm)
         ctx.save_for_backward(o["d_color"], o["d_wsum"], o["d_eiknum"], o["d_wpair"], o["d_diffuse"], o["d_spec"])
         aux = (o["losses"], o["surface_color"], o["specular_color"], o["diffuse_color"])
         ctx.mark_non_differentiable(*aux)
@@ -346,6 +346,6 @@ class Stage1LossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, *unused):
         if g is None:
-            return (None,) * 14
+            return (None,) * 15
         grads = torch._foreach_mul(list(ctx.saved_tensors), g)
-        return tuple(grads) + (None,) * 8
+        return tuple(grads) + (None,) * 9

@@ -118,15 +118,32 @@ def _chk_f32(t: torch.Tensor, name: str):
         raise ValueError(f"{name} must be a contiguous float32 CUDA tensor")
 
 
-def set_l2_warm(slot: int, ranges):
-    """fneus_l2_warm_hint: device ranges [(ptr, bytes), ...] that the next surface_gather (slot 0) / stage1_loss (slot 1) launches
-    read into L2 for the launch behind them; [] clears the slot.  FNEUS_L2_WARM=0 disables it."""
-    if _os.environ.get("FNEUS_L2_WARM", "1") == "0":
-        ranges = []
-    n = len(ranges)
-    ptrs = (C.c_void_p * max(n, 1))(*[r[0] for r in ranges])
-    sizes = (C.c_long * max(n, 1))(*[int(r[1]) for r in ranges])
-    check(lib.fneus_l2_warm_hint(int(slot), ptrs, sizes, n), "fneus_l2_warm_hint")
+MAX_WARM_RANGES = 12
+
+
+class WarmRanges(C.Structure):
+    """FneusWarmRanges (include/fneus.h): device ranges that the extra workgroups of ONE surface_gather / stage1_loss launch read
+    into L2 for the launch behind it.  Built by the owner of the buffers (models/fields.py RefColor) and handed to the call:
+    the library keeps nothing of it."""
+    _fields_ = [("n", C.c_int), ("ptr", C.c_void_p * MAX_WARM_RANGES), ("bytes", C.c_long * MAX_WARM_RANGES)]
+
+
+def warm_ranges(ranges):
+    """[(ptr, bytes), ...] -> WarmRanges, or None (no ranges, or FNEUS_L2_WARM=0)"""
+    if not ranges or _os.environ.get("FNEUS_L2_WARM", "1") == "0":
+        return None
+    if len(ranges) > MAX_WARM_RANGES:
+        raise ValueError(f"at most {MAX_WARM_RANGES} warm-up ranges per launch")
+    w = WarmRanges()
+    w.n = len(ranges)
+    for i, (p, b) in enumerate(ranges):
+        w.ptr[i] = int(p)
+        w.bytes[i] = int(b)
+    return w
+
+
+def _warm_arg(w):
+    return None if w is None else C.byref(w)
 
 
 def fragment_ranges(net, reverse: bool):
@@ -754,8 +771,8 @@ def nerf_dw_jobs(net: PackedNet, st: NerfStash, n: int) -> GemmPPJobs:
 # ------------------------------------------------------------------------------------------------------------
 # per-ray kernels
 # ------------------------------------------------------------------------------------------------------------
-def surface_gather(min_idx, sdf_mask, mid_z, feat, normal):
-    """-> sel [2B] int32, t_sel [2B], feat_sel [2B,256], normal_sel [2B,3]"""
+def surface_gather(min_idx, sdf_mask, mid_z, feat, normal, warm=None):
+    """-> sel [2B] int32, t_sel [2B], feat_sel [2B,256], normal_sel [2B,3];  warm: WarmRanges of the launch that follows"""
     B, n = mid_z.shape
     dev = mid_z.device
     sel = torch.empty(2 * B, dtype=torch.int32, device=dev)
@@ -763,7 +780,7 @@ def surface_gather(min_idx, sdf_mask, mid_z, feat, normal):
     feat_sel = torch.empty(2 * B, 256, dtype=torch.float32, device=dev)
     normal_sel = torch.empty(2 * B, 3, dtype=torch.float32, device=dev)
     _launch("fneus_surface_gather", lib.fneus_surface_gather, _ptr(min_idx), _ptr(sdf_mask), _ptr(mid_z), _ptr(feat), _ptr(normal),
-            B, n, _ptr(sel), _ptr(t_sel), _ptr(feat_sel), _ptr(normal_sel), _stream())
+            B, n, _ptr(sel), _ptr(t_sel), _ptr(feat_sel), _ptr(normal_sel), _warm_arg(warm), _stream())
     return sel, t_sel, feat_sel, normal_sel
 
 
@@ -776,7 +793,7 @@ def stage1_norms(mask_in, sdf_mask, eik_den, mask_weight):
 
 
 def stage1_loss(color, true_rgb, mask_in, wsum, eik_num, eik_den, diffuse, spec, wpair, sdf_mask, igr_weight, mask_weight,
-                surface_weight, norms=None):
+                surface_weight, norms=None, warm=None):
     """fused shading + losses + gradients (include/fneus.h fneus_stage1_loss); returns a dict of device tensors"""
     B = color.shape[0]
     dev = color.device
@@ -792,7 +809,7 @@ def stage1_loss(color, true_rgb, mask_in, wsum, eik_num, eik_den, diffuse, spec,
             _ptr(eik_den), _ptr(diffuse), _ptr(spec), _ptr(wpair), _ptr(sdf_mask), _ptr(norms), B, float(igr_weight), float(mask_weight),
             float(surface_weight), _ptr(o["losses"]), _ptr(o["surface_color"]), _ptr(o["specular_color"]),
             _ptr(o["diffuse_color"]), _ptr(o["d_color"]), _ptr(o["d_wsum"]), _ptr(o["d_eiknum"]), _ptr(o["d_wpair"]),
-            _ptr(o["d_diffuse"]), _ptr(o["d_spec"]), _stream())
+            _ptr(o["d_diffuse"]), _ptr(o["d_spec"]), _warm_arg(warm), _stream())
     return o
 
 

@@ -349,11 +349,18 @@ class RefColor(nn.Module):
         self._vd.refresh()
         # the two 32-tile launches of these heads are as long as one tile's chain and stream 1.1 MB of fragments per head:
         # name them to the launches in front of them, whose idle workgroups read them into L2 (csrc/loss_kernels.hip)
+        # The ranges belong to THIS instance and travel as an argument of those launches (warm_ranges()): nothing global.
         key = (self._cd.net.blob.data_ptr(), self._vd.net.blob.data_ptr())
         if getattr(self, "_warm_key", None) != key and self._cd.net.blob.is_cuda:
             self._warm_key = key
-            ops.set_l2_warm(0, ops.fragment_ranges(self._cd.net, False) + ops.fragment_ranges(self._vd.net, False))
-            ops.set_l2_warm(1, ops.fragment_ranges(self._cd.net, True) + ops.fragment_ranges(self._vd.net, True))
+            self._warm = (ops.warm_ranges(ops.fragment_ranges(self._cd.net, False) + ops.fragment_ranges(self._vd.net, False)),
+                          ops.warm_ranges(ops.fragment_ranges(self._cd.net, True) + ops.fragment_ranges(self._vd.net, True)))
+
+    def warm_ranges(self, backward: bool):
+        """ops.WarmRanges of the packed weight fragments the next RefColor launch streams (forward / backward), or None: handed
+        to the surface_gather / stage1_loss launch in front of it (fneus.h FneusWarmRanges)"""
+        w = getattr(self, "_warm", None)
+        return None if w is None else w[1 if backward else 0]
 
     def flat_grads(self):
         return [b.net.raw_grad for b in (self._cd, self._vd) if b.net is not None]

@@ -176,7 +176,7 @@ class NeuSRenderer:
         losses = None
         if refColor_network is not None:
             feat_sel, normal_sel, t_sel, _sel = SurfaceGatherFn.apply(feat, normal, mid_z, min_idx, sdf_mask_u8,
-                                                                      sdf_network._ws)
+                                                                      sdf_network._ws, refColor_network.warm_ranges(False))
             # 2 samples per ray in the (rays_o, rays_d, t) form of the fused kernels (pts = o + d * t, renderer.py:322)
             surf = RaySamples(rays_o, rays_d, t_sel, 2)
             diffuse, spec = refColor_network.heads(surf, feat_sel, normal_sel, train)
@@ -185,7 +185,7 @@ class NeuSRenderer:
                 reduce_norms = loss_args[5] if len(loss_args) > 5 else None
                 loss, lvec, surface_color, specular_color, diffuse_color = Stage1LossFn.apply(
                     color, wsum, eik_num, wpair, diffuse, spec, eik_den, true_rgb, mask_in, sdf_mask_u8, float(igr_w),
-                    float(mask_w), float(surf_w), reduce_norms)
+                    float(mask_w), float(surf_w), reduce_norms, refColor_network.warm_ranges(True))
                 losses = {"loss": loss, "color_loss": lvec[1], "surface_loss": lvec[2], "eikonal_loss": lvec[3],
                           "mask_loss": lvec[4], "psnr": lvec[5]}
             else:

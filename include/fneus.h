@@ -223,17 +223,24 @@ int fneus_refcolor_bwd_both(const void* blob_cd, const void* blob_vd, long n_pts
                             fneus_stream_t stream);
 
 /* ---- per-ray tail of the training step ------------------------------------------------------------------------ */
-/* Optional: device ranges (e.g. the forward / reverse weight fragments of the RefColor MLPs) that extra workgroups of the next
- * fneus_surface_gather (slot 0) / fneus_stage1_loss (slot 1) launches read into the L2 caches for the launch that follows
- * them; n = 0 clears the slot.  Host-side state of the library (not captured per call: set it before a step is recorded). */
-int fneus_l2_warm_hint(int slot, const void* const* ptrs /*host array of device pointers*/, const long* bytes /*host*/, int n);
+/* Optional argument of fneus_surface_gather / fneus_stage1_loss (NULL = none): device ranges (e.g. the forward / reverse weight
+ * fragments of the RefColor MLPs) that extra workgroups of THIS launch read into the L2 caches for the launch that follows it.
+ * A host struct read during the call only: the library keeps no pointer of it, the ranges must be live while the launch (or a
+ * graph that captured it) runs -- the caller that owns the buffers names them per call.                                      */
+#define FNEUS_MAX_WARM_RANGES 12
+typedef struct FneusWarmRanges {
+    int n;                                      /* ranges in use (<= FNEUS_MAX_WARM_RANGES) */
+    const void* ptr[FNEUS_MAX_WARM_RANGES];     /* device pointers */
+    long bytes[FNEUS_MAX_WARM_RANGES];
+} FneusWarmRanges;
 
 /* The two samples bracketing the first SDF sign change of every ray (renderer.py:290-293, 316-327), packed for the
  * RefColor heads: sel [2B] (row index into the B*n samples), t_sel [2B], feat_sel [2B][256], normal_sel [2B][3].
  * Rays without a sign change (sdf_mask 0) select samples 0 and 1, as the reference's dense formulation does.           */
 int fneus_surface_gather(const int32_t* min_idx, const unsigned char* sdf_mask, const float* mid_z /*[B][n]*/,
                          const float* feat /*[B*n][256]*/, const float* normal /*[B*n][3]*/, int n_rays, int n,
-                         int32_t* sel, float* t_sel, float* feat_sel, float* normal_sel, fneus_stream_t stream);
+                         int32_t* sel, float* t_sel, float* feat_sel, float* normal_sel, const FneusWarmRanges* warm /*or NULL*/,
+                         fneus_stream_t stream);
 
 /* RefColor shading (linear->sRGB, clip: fields.py:262-268, 331-335), the two-sample blend (renderer.py:336-343), the
  * training losses (exp_runner.py:141-177: colour L1, surface L1, eikonal, mask BCE) and the gradient of the total loss
@@ -245,7 +252,8 @@ int fneus_stage1_loss(const float* color /*[B][3]*/, const float* true_rgb /*[B]
                       const unsigned char* sdf_mask /*[B]*/, const float* norms /*[4] or NULL*/, int n_rays,
                       float igr_weight, float mask_weight, float surface_weight, float* losses, float* surface_color /*[B][3]*/, float* specular_color,
                       float* diffuse_color, float* d_color, float* d_wsum, float* d_eiknum, float* d_wpair,
-                      float* d_diffuse /*[2B][3]*/, float* d_spec /*[2B][3]*/, fneus_stream_t stream);
+                      float* d_diffuse /*[2B][3]*/, float* d_spec /*[2B][3]*/, const FneusWarmRanges* warm /*or NULL*/,
+                      fneus_stream_t stream);
 
 /* Data parallel: norms[4] = (sum mask, sum mask*sdf_mask, sum eik_den, ray count) of this rank's batch.  Sum them over
  * the ranks (a 4-float all-reduce) and pass the result to fneus_stage1_loss: its loss terms and gradients are then this

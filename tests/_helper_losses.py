@@ -1,5 +1,6 @@
-"""Stage-1 training losses (reference exp_runner.py:141-177), written without boolean indexing so that a training
-step has no host synchronisation: x[sdf_mask].sum() == (x * sdf_mask).sum()."""
+"""TEST HELPER (not product code): the stage-1 training losses (reference exp_runner.py:141-177) as plain torch ops on a render
+result dict, written without boolean indexing: x[sdf_mask].sum() == (x * sdf_mask).sum().  The product computes them in
+fneus_stage1_loss (csrc/loss_kernels.hip); the tests differentiate this formulation through the HIP render to check it."""
 from __future__ import annotations
 
 import torch

@@ -29,7 +29,7 @@ def _case(B, seed, mask_weight):
 
 
 def _torch_formulation(c, igr=0.1, sw=0.1):
-    from fneus.losses import stage1_loss
+    from _helper_losses import stage1_loss
     from models.fields import RefColor
     B = c["color"].shape[0]
     leaves = {k: c[k].clone().requires_grad_(True) for k in ("color", "wsum", "eik_num", "wpair", "diffuse", "spec")}

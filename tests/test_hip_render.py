@@ -147,7 +147,7 @@ def test_loss_and_gradients(golden_dir, name, fused, gprec):
     gprec 3: the backward stash holds hi + lo planes (fp32-accurate weight gradients); gprec 1 (the training default):
     bf16 planes -- every product of the weight-gradient GEMMs carries 2^-9 rounding, which shows where a sum cancels
     (bias gradients of 3 outputs over 512 samples)."""
-    from fneus.losses import stage1_loss
+    from _helper_losses import stage1_loss
     g = load(golden_dir, name)
     out, nets, (rgb, mask) = run(g, 3, teacher_z=True, fused_loss=fused, gprec=gprec)
     if fused:

@@ -107,7 +107,7 @@ def test_synthetic_dataset_cameras_cpu():
 
 
 def test_stage1_loss_matches_oracle():
-    from fneus.losses import stage1_loss
+    from _helper_losses import stage1_loss
     from oracle import ref_torch as R
     rs = np.random.RandomState(3)
     B = 40
@@ -126,7 +126,9 @@ def _dp_worker(rank, world, port, q):
                       LOCAL_RANK=str(rank))
     sys.path.insert(0, os.path.join(ROOT, "factored-neus_amd"))
     import torch.distributed as dist
-    from fneus.parallel import FlatGradBucket, broadcast_parameters, init_from_env
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from fneus.parallel import broadcast_parameters, init_from_env
+    from _helper_bucket import FlatGradBucket
     r, w, _ = init_from_env("gloo")
     torch.manual_seed(100 + rank)
     net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 2))

@@ -21,7 +21,7 @@ head -16 "$out/${tag}_kernel_stats.txt"
 rocprofv3 --kernel-trace -d /tmp/prof_t -o t --output-format csv -- python3 "$root/bench.py" --steps 4 --warmup 2 --no-graph --no-cpu-baseline --no-fast-extra --no-profile \
     > /dev/null 2> "$out/${tag}_rocprof_t.err"
 kt=$(find /tmp/prof_t -name '*kernel_trace.csv' | head -1)
-python3 "$root/tools/step_timeline.py" "$kt" > "$out/${tag}_step_timeline.txt" 2>&1
+python3 "$root/tools/step_timeline.py" "$kt" > "$out/${tag}_step_timeline.txt" 2>&1 || echo "step_timeline FAILED" >&2
 rocprofv3 --pmc FETCH_SIZE -d /tmp/pmc_f -o f --output-format csv -- python3 "$root/tools/pmc_run.py" parity 2 > /dev/null 2> "$out/${tag}_pmc_f.err"
 rocprofv3 --pmc WRITE_SIZE -d /tmp/pmc_w -o w --output-format csv -- python3 "$root/tools/pmc_run.py" parity 2 > /dev/null 2> "$out/${tag}_pmc_w.err"
 python3 "$root/tools/pmc_summary.py" --steps 2 --json "$out/${tag}_traffic.json" /tmp/pmc_f /tmp/pmc_w > "$out/${tag}_pmc_fetch_write.txt"
@@ -31,3 +31,14 @@ rm -rf /tmp/pmc_s
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAVES -d /tmp/pmc_s -o s --output-format csv -- python3 "$root/tools/pmc_run.py" parity 2 > /dev/null 2> "$out/${tag}_pmc_s.err"
 python3 "$root/tools/pmc_summary.py" /tmp/pmc_s > "$out/${tag}_sq.txt"
 head -40 "$out/${tag}_sq.txt"
+
+# gate: an artefact that holds a Python traceback (or an empty summary) is not evidence -- fail the collection
+bad=0
+for f in "$out/${tag}_bench.json" "$out/${tag}_bench_under_rocprof.json" "$out/${tag}_kernel_stats.txt" "$out/${tag}_step_timeline.txt" \
+         "$out/${tag}_pmc_fetch_write.txt" "$out/${tag}_traffic.json" "$out/${tag}_sq.txt"; do
+    if [ ! -s "$f" ] || grep -q -E "^Traceback|^step_timeline:" "$f"; then
+        echo "collect_profiles: BROKEN ARTEFACT $f" >&2
+        bad=1
+    fi
+done
+exit $bad

@@ -17,3 +17,12 @@ for st in stage2 stage3 womask; do
   cat "$out/${tag}_${st}_run.txt" | tail -1
   head -24 "$out/${tag}_${st}_kernel_stats.txt"
 done
+bad=0
+for st in stage2 stage3 womask; do
+    f="$out/${tag}_${st}_kernel_stats.txt"
+    if [ ! -s "$f" ] || grep -q "^Traceback" "$f"; then
+        echo "collect_stage_profiles: BROKEN ARTEFACT $f" >&2
+        bad=1
+    fi
+done
+exit $bad

@@ -18,9 +18,12 @@ def short(n):
 def main(path, top=25):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    idx = [i for i, r in enumerate(rows) if "rowscale_kernel" in r["Kernel_Name"]]
-    # a step starts at the first rowscale launch of a burst (one per packed network)
+    # a step starts at the first weight-norm fold of a burst: one `rowscale_multi_kernel` launch for all networks
+    # (fneus_refresh_multi), or one `rowscale_kernel` per packed network with FNEUS_PACK_BATCH=0
+    idx = [i for i, r in enumerate(rows) if re.search(r"rowscale(_multi)?_kernel", r["Kernel_Name"])]
     starts = [i for k, i in enumerate(idx) if k == 0 or i - idx[k - 1] > 8]
+    if len(starts) < 2:
+        sys.exit(f"step_timeline: found {len(starts)} step starts (rowscale launches) in {path}: need at least two steps")
     a, b = starts[-2], starts[-1]
     seg = rows[a:b]
     print(f"# one step: {len(seg)} kernels, span {(int(seg[-1]['End_Timestamp']) - int(seg[0]['Start_Timestamp'])) / 1e6:.3f} ms")
