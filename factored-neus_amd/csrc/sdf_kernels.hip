@@ -8,6 +8,7 @@
 #include "pp_engine.h"
 #include "fneus_kernels.h"
 #include "sdf_w8.h"
+#include "sdf_r8.h"
 #include "s_prefetch.h"
 
 #ifndef FNEUS_K1_W8_BIG_DEFAULT
@@ -16,6 +17,9 @@
 #endif
 #ifndef FNEUS_K2_P2_DEFAULT
 #define FNEUS_K2_P2_DEFAULT 1
+#endif
+#ifndef FNEUS_K2_REV8_DEFAULT
+#define FNEUS_K2_REV8_DEFAULT 1
 #endif
 #ifndef FNEUS_K2_CHUNKS_DEFAULT
 #define FNEUS_K2_CHUNKS_DEFAULT 1
@@ -1184,6 +1188,14 @@ extern "C" int fneus_sdf_fwd_grad(const void* blob, const float* pts, const floa
             if (k2p2 == 2) continue;
             const long g_begin = 2 * u_begin, g_end = 2 * u_end < groups ? 2 * u_end : groups;
             if (g_end <= g_begin) continue;
+            // reverse sweep: resident-weight 8-wave workgroups (sdf_r8_kernels.hip); FNEUS_K2_REV8=0 keeps the 4-wave kernel
+            // below (read at every call so that tests can switch it)
+            const char* r8_env = getenv("FNEUS_K2_REV8");
+            if (r8_env ? atoi(r8_env) != 0 : FNEUS_K2_REV8_DEFAULT) {
+                const int rc8 = fneus::sdf_grad_rev_r8(b, src, n_pts, st, normal_out, prec, train, gp, g_begin, g_end, stream);
+                if (rc8) return rc8;
+                continue;
+            }
             dim3 g2((unsigned)(g_end - g_begin < cap ? g_end - g_begin : cap));
             if (prec == 3 && train && gp == 3) FNEUS_K2REV(3, true, 3);
             else if (prec == 3 && train) FNEUS_K2REV(3, true, 1);

@@ -313,3 +313,43 @@ def test_batch_without_any_surface_hit():
     tr.train_step(hit)
     moved = max((v - before[k]).abs().max().item() for k, v in tr.refColor_network.state_dict().items())
     assert moved > 0.0
+
+
+@pytest.mark.parametrize("train,gprec,prec,n", [(True, 1, 3, 40003), (True, 3, 3, 40003), (False, 1, 3, 40003), (True, 1, 1, 40003),
+                                                (True, 1, 3, 65536)])
+def test_k2_reverse_sweep_r8_equals_the_4_wave_kernel(monkeypatch, train, gprec, prec, n):
+    """the reverse sweep of K2 on resident-weight 8-wave workgroups (csrc/sdf_r8_kernels.hip, r8_engine.h; FNEUS_K2_REV8=0 keeps
+    the 4-wave kernel of sdf_kernels.hip, read at every call): same sigma' blocks, same operands and the same summation order
+    per accumulator.  What differs is where hipcc contracts the lo part of a hi / lo split (`x - hi`) with the product that
+    formed x -- the rounding of a lo fragment's last bit (2^-17 of the value): the normals agree to 2e-5 (parity mode), the a_l
+    planes to a step of their format, and the kernel is bit-reproducible.  Ragged size with an odd tile count, and the bench's."""
+    from fneus import ops, synth
+    net = ops.PackedNet("sdf", DEV).load_state_dict({k: T(v) for k, v in synth.sdf_state_dict(21).items()})
+    net.pack()
+    x = (torch.rand(n, 3, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5)) * 2 - 1).contiguous()
+
+    def run(r8):
+        monkeypatch.setenv("FNEUS_K2_REV8", str(r8))
+        st = ops.SdfStash(n, DEV, prec, train, gprec)
+        if st.a is not None:
+            st.a.zero_()
+        out = ops.sdf_fwd_grad(net.blob, n, prec, st, train, pts=x)
+        torch.cuda.synchronize()
+        return out, st
+
+    (sdf0, feat0, nrm0), s0 = run(0)
+    (sdf1, feat1, nrm1), s1 = run(1)
+    (sdf2, feat2, nrm2), s2 = run(1)
+    fast = prec == 1
+    assert torch.equal(sdf1, sdf0) and torch.equal(feat1, feat0)
+    assert torch.isfinite(nrm1).all()
+    assert (nrm1 - nrm0).abs().max().item() <= (2e-2 if fast else 2e-5)
+    assert torch.equal(nrm2, nrm1)
+    if train:
+        assert torch.equal(s2.a, s1.a)
+        for l in range(8):
+            F = 14 if l == 3 else 16                        # layer 3 has 7 output tiles
+            a1, a0 = s1.plane(s1.a[:, :, :, :F], l), s0.plane(s0.a[:, :, :, :F], l)
+            assert (a1 - a0).abs().max().item() <= (8e-3 if gprec == 1 else 1e-4) * max(a0.abs().max().item(), 1e-6), l
+        if s1.a.shape[2] > s1.tiles:                        # an allocated tile without samples stays zero
+            assert float(s1.a[:, :, s1.tiles:].float().abs().max()) == 0.0
