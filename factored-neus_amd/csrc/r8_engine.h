@@ -28,7 +28,7 @@ namespace fneus {
 
 constexpr int kR8Half = 19 * 2 * kFragBytes;
 constexpr int kR8Lds = 2 * kR8Half;
-constexpr int kR8MaxKS = 18;
+constexpr int kR8MaxKS = 17;
 
 struct R8W {                                    // this wave's tile of one layer: fragment s = k-step s (hi, lo)
     bf16x8 hi[kR8MaxKS], lo[kR8MaxKS];
@@ -50,43 +50,71 @@ FN_DEV void r8_wload_all(R8W& W, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, con
 }
 
 // acc += sum_{s < KS} W[s] . B[SLOT0 + s] for ONE half (fl = its LDS region + lane * 16).  KSN > 0: stage s of the next layer
-// (nx) is requested into W[s] right behind the MFMAs that read it (stages KS .. KSN-1, if any, at the end).
+// (nx) is requested into W[s] FNEUS_R8_WLAG k-steps behind the MFMAs that read it (the last ones behind the phase).
 // Same operands and per-accumulator summation order (lo.hi, hi.lo, hi.hi per k-step) as dense_ldsb_h.
-template <int PREC, int KS, int KSN, int SLOT0 = 0>
+// LMAP (p2_slot): 0: k-step s is slot s; 2: the skip layer's input -- 14 k-steps of h_4, then the encoding's 3 parked in slots
+// 16..18 (fields.py:83-84).  voff: of the NEXT layer's tile (a wave may own another tile there).
+#ifndef FNEUS_R8_WLAG
+#define FNEUS_R8_WLAG 2             // the next layer's stage s is requested behind the MFMAs of k-step s + WLAG - 1
+#endif
+#ifndef FNEUS_R8_BDIST
+#define FNEUS_R8_BDIST 2            // B fragments are requested this many k-steps ahead of their MFMAs
+#endif
+template <int PREC, int KS, int KSN, int LMAP = 0>
 FN_DEV void r8_dense(R8W& W, const unsigned char* fl, f32x16& acc, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, const R8Layer& nx,
                      const unsigned char* blob) {
     constexpr int NPL = PREC == 3 ? 2 : 1;
-    bf16x8 bh[3], bl[3];               // HAZARD (mlp_engine.h dense_ldsb): the prefetch of k-step s + 1 is pinned in front of the
-    bh[0] = *reinterpret_cast<const bf16x8*>(fl + (SLOT0 * NPL) * kFragBytes);      // MFMAs of k-step s (distinct registers)
-    if constexpr (PREC == 3) bl[0] = *reinterpret_cast<const bf16x8*>(fl + (SLOT0 * NPL + 1) * kFragBytes);
+    // B ring.  A k-step is only 3 MFMAs here (96 cycles of this wave's matrix time), less than an LDS round trip with eight waves
+    // reading: requested one k-step ahead (as the 12-MFMA k-steps of the other engines do) every k-step waited for its fragments
+    // -- 286 cycles per k-step of a SIMD's two waves instead of 192 (FNEUS_R8_STAMPS).  Distance D, ring of D + 2 buffers:
+    // HAZARD (mlp_engine.h dense_ldsb): an LDS load must not land in the operand registers of an MFMA that is still queued; the
+    // buffer written at k-step s last fed the MFMAs of k-step s - 2, and the requests are pinned in front of the MFMAs of k-step s.
+    constexpr int D = FNEUS_R8_BDIST < KS ? FNEUS_R8_BDIST : KS - 1, NB = D + 2;
+    constexpr int LAG = FNEUS_R8_WLAG;
+    bf16x8 bh[NB], bl[NB];
+    static_for<0, D>([&](auto S_) {
+        constexpr int s = decltype(S_)::value;
+        bh[s % NB] = *reinterpret_cast<const bf16x8*>(fl + (p2_slot<LMAP>(s) * NPL) * kFragBytes);
+        if constexpr (PREC == 3) bl[s % NB] = *reinterpret_cast<const bf16x8*>(fl + (p2_slot<LMAP>(s) * NPL + 1) * kFragBytes);
+    });
     static_for<0, KS>([&](auto S_) {
         constexpr int s = decltype(S_)::value;
-        if constexpr (s + 1 < KS) {
-            bh[(s + 1) % 3] = *reinterpret_cast<const bf16x8*>(fl + ((SLOT0 + s + 1) * NPL) * kFragBytes);
-            if constexpr (PREC == 3) bl[(s + 1) % 3] = *reinterpret_cast<const bf16x8*>(fl + ((SLOT0 + s + 1) * NPL + 1) * kFragBytes);
+        if constexpr (s + D < KS) {
+            bh[(s + D) % NB] = *reinterpret_cast<const bf16x8*>(fl + (p2_slot<LMAP>(s + D) * NPL) * kFragBytes);
+            if constexpr (PREC == 3) bl[(s + D) % NB] = *reinterpret_cast<const bf16x8*>(fl + (p2_slot<LMAP>(s + D) * NPL + 1) * kFragBytes);
+        }
+        // The request for stage s' of the next layer goes out LAG k-steps after the MFMAs that read W[s'] were issued: a load
+        // whose destination a queued MFMA still has to read stalls at issue until that MFMA has started (write-after-read), and
+        // with it everything behind it -- requested right behind their last reader the 32 requests of a phase cost ~76 cycles each
+        // (FNEUS_R8_STAMPS: 4355 cycles for the requesting half's dense phase against 1930 for the others).
+        if constexpr (s >= LAG && s - LAG < KSN) {
+            constexpr int q = s - LAG;
+            const uint32_t f = (uint32_t)(q * nx.nt * 64) * 16u;
+            W.hi[q] = p2_wload(rsrc, voff, nx.off_hi + f, blob);
+            if constexpr (PREC == 3) W.lo[q] = p2_wload(rsrc, voff, nx.off_lo + f, blob);
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (PREC == 3) {
-            acc = mfma32(W.lo[s], bh[s % 3], acc);
-            acc = mfma32(W.hi[s], bl[s % 3], acc);
+            acc = mfma32(W.lo[s], bh[s % NB], acc);
+            acc = mfma32(W.hi[s], bl[s % NB], acc);
         }
-        acc = mfma32(W.hi[s], bh[s % 3], acc);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (s < KSN) {
-            const uint32_t f = (uint32_t)(s * nx.nt * 64) * 16u;
-            W.hi[s] = p2_wload(rsrc, voff, nx.off_hi + f, blob);
-            if constexpr (PREC == 3) W.lo[s] = p2_wload(rsrc, voff, nx.off_lo + f, blob);
-        }
+        acc = mfma32(W.hi[s], bh[s % NB], acc);
         __builtin_amdgcn_sched_barrier(0);
     });
-    static_for<KS, KSN>([&](auto S_) {
-        constexpr int s = decltype(S_)::value;
-        const uint32_t f = (uint32_t)(s * nx.nt * 64) * 16u;
-        W.hi[s] = p2_wload(rsrc, voff, nx.off_hi + f, blob);
-        if constexpr (PREC == 3) W.lo[s] = p2_wload(rsrc, voff, nx.off_lo + f, blob);
+    static_for<(KS > LAG ? KS - LAG : 0), KSN>([&](auto S_) {
+        constexpr int q = decltype(S_)::value;
+        const uint32_t f = (uint32_t)(q * nx.nt * 64) * 16u;
+        W.hi[q] = p2_wload(rsrc, voff, nx.off_hi + f, blob);
+        if constexpr (PREC == 3) W.lo[q] = p2_wload(rsrc, voff, nx.off_lo + f, blob);
     });
     // the caller may reuse the B registers at once (LDS loads): let the last MFMAs read them first
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+}
+
+// the next layer's stages alone (a wave without a tile in the running layer)
+template <int PREC, int KSN>
+FN_DEV void r8_request(R8W& W, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, const R8Layer& nx, const unsigned char* blob) {
+    r8_wload_all<PREC, KSN>(W, rsrc, voff, nx, blob);
 }
 
 FN_DEV void r8_zero(f32x16& a) {

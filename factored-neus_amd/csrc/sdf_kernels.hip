@@ -18,6 +18,9 @@
 #ifndef FNEUS_K2_P2_DEFAULT
 #define FNEUS_K2_P2_DEFAULT 1
 #endif
+#ifndef FNEUS_K3_R8_DEFAULT
+#define FNEUS_K3_R8_DEFAULT 1
+#endif
 #ifndef FNEUS_K2_REV8_DEFAULT
 #define FNEUS_K2_REV8_DEFAULT 1
 #endif
@@ -1297,6 +1300,16 @@ extern "C" int fneus_sdf_bwd(const void* blob, const float* pts, const float* ra
     const bool whi = whi_s != nullptr && atoi(whi_s) != 0;
     const bool exact = bb.adj_lo != nullptr;            // gradient precision 3: lo planes everywhere
     if (exact && (!st.a_lo || !bb.c_lo || !bb.zbar_lo || !bb.qbar_lo || !bb.zsdf_lo)) return -2;
+    // Chip-filling launches: resident-weight 8-wave workgroups (sdf_r8_kernels.hip).  FNEUS_K3_R8=0 keeps the 4-wave kernels
+    // below (read at every call so that tests can switch it); they also take launches whose planes exceed the 32-bit buffer
+    // offsets of the r8 kernel (2 GiB per array: 14 563 sample tiles of 9 x 16 KiB).
+    {
+        const char* r8_env = getenv("FNEUS_K3_R8");
+        const bool r8 = r8_env ? atoi(r8_env) != 0 : FNEUS_K3_R8_DEFAULT;
+        const long tiles_pp = 2 * ((n_pts + 63) / 64);
+        if (r8 && !whi && hb_env == 0 && n_tiles32 >= 1024 && tiles_pp * 9 * (long)kPPBlock < (1L << 31) && (prec == 3 || prec == 1))
+            return fneus::sdf_bwd_r8(b, src, n_pts, st, bb, d_sdf, d_feat, d_normal, prec, exact ? 3 : 1, stream);
+    }
 #define FNEUS_K3H(P, W, H, G)                                                                                                \
     do {                                                                                                                     \
         static bool attr_done = false;                                                                                       \

@@ -8,4 +8,8 @@ namespace fneus {
 int sdf_grad_rev_r8(const unsigned char* blob, const PointSrc& src, long n_pts, const SdfStash& st, float* normal_out, int prec, int train,
                     int gp, long g_begin, long g_end, hipStream_t stream);
 
+// K3 (both backward chains; writes the planes of SdfBwdBufs); gp = 3: hi + lo planes
+int sdf_bwd_r8(const unsigned char* blob, const PointSrc& src, long n_pts, const SdfStash& st, const SdfBwdBufs& bb, const float* d_sdf,
+               const float* d_feat, const float* d_normal, int prec, int gp, hipStream_t stream);
+
 }  // namespace fneus

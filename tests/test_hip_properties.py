@@ -315,15 +315,18 @@ def test_batch_without_any_surface_hit():
     assert moved > 0.0
 
 
+@pytest.mark.parametrize("nh", [4, 2])
 @pytest.mark.parametrize("train,gprec,prec,n", [(True, 1, 3, 40003), (True, 3, 3, 40003), (False, 1, 3, 40003), (True, 1, 1, 40003),
-                                                (True, 1, 3, 65536)])
-def test_k2_reverse_sweep_r8_equals_the_4_wave_kernel(monkeypatch, train, gprec, prec, n):
+                                                (True, 1, 3, 65536), (True, 1, 3, 40067)])
+def test_k2_reverse_sweep_r8_equals_the_4_wave_kernel(monkeypatch, train, gprec, prec, n, nh):
     """the reverse sweep of K2 on resident-weight 8-wave workgroups (csrc/sdf_r8_kernels.hip, r8_engine.h; FNEUS_K2_REV8=0 keeps
     the 4-wave kernel of sdf_kernels.hip, read at every call): same sigma' blocks, same operands and the same summation order
     per accumulator.  What differs is where hipcc contracts the lo part of a hi / lo split (`x - hi`) with the product that
     formed x -- the rounding of a lo fragment's last bit (2^-17 of the value): the normals agree to 2e-5 (parity mode), the a_l
-    planes to a step of their format, and the kernel is bit-reproducible.  Ragged size with an odd tile count, and the bench's."""
+    planes to a step of their format, and the kernel is bit-reproducible.  64- and 128-sample workgroups (FNEUS_R8_NH); ragged
+    sizes with an odd tile count (40 003) and with a last 128-sample group of which only two tiles are allocated (40 067)."""
     from fneus import ops, synth
+    monkeypatch.setenv("FNEUS_R8_NH", str(nh))
     net = ops.PackedNet("sdf", DEV).load_state_dict({k: T(v) for k, v in synth.sdf_state_dict(21).items()})
     net.pack()
     x = (torch.rand(n, 3, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5)) * 2 - 1).contiguous()
@@ -353,3 +356,48 @@ def test_k2_reverse_sweep_r8_equals_the_4_wave_kernel(monkeypatch, train, gprec,
             assert (a1 - a0).abs().max().item() <= (8e-3 if gprec == 1 else 1e-4) * max(a0.abs().max().item(), 1e-6), l
         if s1.a.shape[2] > s1.tiles:                        # an allocated tile without samples stays zero
             assert float(s1.a[:, :, s1.tiles:].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("nh", [4, 2])
+@pytest.mark.parametrize("gprec,prec,n", [(1, 3, 40003), (3, 3, 40003), (1, 1, 40003), (1, 3, 65536), (1, 3, 40067)])
+def test_k3_r8_equals_the_4_wave_kernel(monkeypatch, gprec, prec, n, nh):
+    """K3 on resident-weight 8-wave workgroups (csrc/sdf_r8_kernels.hip; FNEUS_K3_R8=0 keeps the 4-wave kernel of sdf_kernels.hip,
+    read at every call): same stash, same operands, same summation order per accumulator (the sdf tile's two k-steps of the seed
+    are added in front of the other sixteen instead of behind them) -- every plane the weight-gradient GEMM reads (qbar, adj_1..8,
+    zbar_0..8, zsdf) agrees to a step of its format, and the kernel is bit-reproducible.  64- and 128-sample workgroups
+    (FNEUS_R8_NH); ragged sizes as in the reverse sweep's test."""
+    from fneus import ops, synth, pp
+    monkeypatch.setenv("FNEUS_R8_NH", str(nh))
+    net = ops.PackedNet("sdf", DEV).load_state_dict({k: T(v) for k, v in synth.sdf_state_dict(22).items()})
+    net.pack()
+    g = torch.Generator(device=DEV).manual_seed(7)
+    x = (torch.rand(n, 3, device=DEV, generator=g) * 2 - 1).contiguous()
+    ds = torch.randn(n, device=DEV, generator=g)
+    df = torch.randn(n, 256, device=DEV, generator=g) * 0.1
+    dn = torch.randn(n, 3, device=DEV, generator=g)
+    st = ops.SdfStash(n, DEV, prec, True, gprec)
+    ops.sdf_fwd_grad(net.blob, n, prec, st, True, pts=x)
+
+    def run(r8):
+        monkeypatch.setenv("FNEUS_K3_R8", str(r8))
+        b = ops.SdfBwdBufs(n, DEV, prec, gprec)
+        ops.sdf_bwd(net.blob, n, prec, st, b, ds, df, dn, pts=x)
+        torch.cuda.synchronize()
+        return b
+
+    b0, b1, b2 = run(0), run(1), run(1)
+    for name in ("qbar", "adj", "zbar", "zsdf"):
+        t0, t1, t2 = getattr(b0, name), getattr(b1, name), getattr(b2, name)
+        assert torch.equal(t1, t2), name
+        assert torch.isfinite(t1.float()).all(), name
+    assert torch.equal(b1.qbar, b0.qbar) and torch.equal(b1.zsdf, b0.zsdf)
+    tol = 8e-3 if gprec == 1 else (2e-4 if prec == 3 else 8e-3)
+    if prec == 1:
+        tol = 3e-2          # bf16 chain (not a parity mode): a flipped rounding propagates through the layers
+    for name, slots in (("adj", 8), ("zbar", 9)):
+        t0, t1 = getattr(b0, name), getattr(b1, name)
+        for l in range(slots):
+            v0, v1 = pp.value(t0[:, l], n), pp.value(t1[:, l], n)
+            assert (v1 - v0).abs().max().item() <= tol * max(v0.abs().max().item(), 1e-9), (name, l)
+        if t1.shape[2] > b1.tiles:                          # an allocated tile without samples stays zero
+            assert float(t1[:, :, b1.tiles:].float().abs().max()) == 0.0
