@@ -59,6 +59,32 @@ KERNEL_BYTES_PARITY = {
 }
 
 
+# The colour network's design bytes per sample (gprec 1): forward writes u 4 x 512 + the side plane 128 + the masks 64 and reads the
+# fp32 feature / normal rows 1024 + 12; backward reads masks + d_rgb and writes zbar 4 x 512 + zout + d_feat fp32 1024 + d_normal 12;
+# its GEMM reads u, zbar (8 x 512), the feature and side planes (512 + 128).
+KERNEL_BYTES_PARITY_EXTRA = {
+    "fneus_color_fwd": (4 * 512 + 128 + 64 + 1024 + 12 + 12) * SAMPLES_PER_STEP,
+    "fneus_color_bwd": (64 + 12 + 4 * 512 + 64 + 1024 + 12) * SAMPLES_PER_STEP,
+    "fneus_dw_gemm_pp:color": (8 * 512 + 512 + 128 + 64) * SAMPLES_PER_STEP,
+    "fneus_sdf_fwd": 0.875 * 16 * SAMPLES_PER_STEP,
+}
+HBM_ACHIEVABLE_GBS = 6300.0          # float4 copy on this part (MI355X_MICROARCH.md: 6.29 TB/s measured, 79 % of the 8 TB/s spec)
+MFMAS_PER_PRODUCT = {"fneus_dw_gemm_pp:sdf": 1, "fneus_dw_gemm_pp:color": 1}      # gprec 1: bf16 planes; the chains issue 3
+KERNEL_FLOPS_EXTRA = {"fneus_sdf_fwd": 0.875 * F_SDF * SAMPLES_PER_STEP}
+
+
+def kernel_floor_ms(name, gprec=1):
+    """floor of one step's launches of a kernel in the shipped design: max(design bytes / achievable HBM rate, MFMAs issued x
+    algorithmic FLOPs / the dense bf16 peak).  The parity arithmetic issues 3 MFMAs per product in the chains, the
+    weight-gradient GEMM 1 (gprec 1) or 3 (gprec 3)."""
+    flops = KERNEL_FLOPS.get(name, KERNEL_FLOPS_EXTRA.get(name, 0.0))
+    byts = KERNEL_BYTES_PARITY.get(name, KERNEL_BYTES_PARITY_EXTRA.get(name, 0.0))
+    k = MFMAS_PER_PRODUCT.get(name, 3) if gprec == 1 else 3
+    t_mfma = k * flops / (PEAK_BF16_MFMA_TFLOPS * 1e12) * 1e3
+    t_hbm = byts / (HBM_ACHIEVABLE_GBS * 1e9) * 1e3
+    return {"floor_ms": max(t_mfma, t_hbm), "mfma_ms": t_mfma, "hbm_ms": t_hbm, "bound": "mfma" if t_mfma >= t_hbm else "hbm"}
+
+
 CPU_CONFIGS = {       # BASELINE.json configs[0] and configs[1]
     "cfg1": dict(rays=256, n_samples=32, n_importance=32),
     "cfg2": dict(rays=RAYS, n_samples=N_SAMPLES, n_importance=N_IMPORTANCE),
@@ -331,6 +357,29 @@ def main():
                     except Exception:
                         continue
             both[k] = e
+        # the design's own floor, kernel by kernel and for the step: how far each kernel is from what its
+        # bytes and its 3-MFMA products allow, whatever the roofline fraction says
+        if prec == ops.PREC_PARITY:
+            floors, floor_sum, measured_sum = {}, 0.0, 0.0
+            for k in list(KERNEL_FLOPS) + list(KERNEL_FLOPS_EXTRA):
+                if k not in per:
+                    continue
+                f = kernel_floor_ms(k, gprec_run)
+                floors[k] = {"ms_per_step": round(per[k]["ms_per_step"], 4), "floor_ms": round(f["floor_ms"], 4), "bound": f["bound"],
+                             "frac_of_floor": round(f["floor_ms"] / per[k]["ms_per_step"], 3)}
+                floor_sum += f["floor_ms"]
+                measured_sum += per[k]["ms_per_step"]
+                if k in both:
+                    both[k]["floor_ms"] = round(f["floor_ms"], 4)
+                    both[k]["frac_of_floor"] = floors[k]["frac_of_floor"]
+            rest = ms_per_step - measured_sum                   # sampler, compositing, RefColor heads, loss, optimiser, PyTorch remainder
+            result["floor"] = {"kernels": floors, "step_floor_ms": round(floor_sum, 4),
+                               "step_floor_plus_unmodelled_rest_ms": round(floor_sum + max(rest, 0.0), 4),
+                               "ms_per_step": round(ms_per_step, 4), "frac_of_floor": round(floor_sum / ms_per_step, 3),
+                               "note": "floor of a kernel = max(design HBM bytes / 6.3 TB/s achievable, MFMAs issued x algorithmic FLOPs / "
+                                       "2.5 PFLOP/s): what THIS design (fragment-plane stash, 3 bf16 MFMAs per product, a separate "
+                                       "weight-gradient GEMM) could reach with every launch at its own roof and no latency-bound tail; "
+                                       "north_star's 2e8 ray-samples/s (0.33 ms per step) lies below this floor in parity mode"}
         if both:
             result["rooflines_by_kernel"] = both
         result["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS,

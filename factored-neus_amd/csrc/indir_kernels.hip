@@ -167,6 +167,12 @@ FN_DEV float srgb_curve(float x, int mode, float& slope) {
         if (y < 0.0f || y > 1.0f) slope = 0.0f;
         y = fminf(fmaxf(y, 0.0f), 1.0f);
     }
+    // NaN in, NaN out (value and slope), as torch.where over torch.clamp(...) ** p does (math_utils.py:138-152): fmaxf / fminf
+    // return the other operand for a NaN, which would turn a diverged run's colour into a finite number and hide the fault
+    if (x != x) {
+        y = x;
+        slope = x;
+    }
     return y;
 }
 

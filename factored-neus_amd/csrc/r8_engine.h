@@ -60,6 +60,16 @@ FN_DEV void r8_wload_all(R8W& W, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, con
 #ifndef FNEUS_R8_BDIST
 #define FNEUS_R8_BDIST 2            // B fragments are requested this many k-steps ahead of their MFMAs
 #endif
+#ifndef FNEUS_R8_WSPLIT
+#define FNEUS_R8_WSPLIT 10          // stages of the next layer requested inside the dense phase; the others behind its barrier
+#endif
+// how many of the next layer's KSN stages the dense phase itself requests: eight waves x 32 requests of 1 KiB are 4096 cycles of
+// the CU's 64 B / clk vector-memory path -- more than the phase's 3400 cycles of MFMAs, and a wave whose request does not get
+// into that path stalls its MFMAs behind it (FNEUS_R8_STAMPS: the requesting half's dense phase took 5860 cycles).  The first
+// FNEUS_R8_WSPLIT stages fit beside the MFMAs; the rest goes out at the start of the post phase (r8_request_rest), when the
+// matrix pipe idles anyway, and is back before the next dense phase reaches those k-steps.
+template <int KSN> constexpr int r8_inside = KSN < FNEUS_R8_WSPLIT ? KSN : FNEUS_R8_WSPLIT;
+
 template <int PREC, int KS, int KSN, int LMAP = 0>
 FN_DEV void r8_dense(R8W& W, const unsigned char* fl, f32x16& acc, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, const R8Layer& nx,
                      const unsigned char* blob) {
@@ -87,7 +97,7 @@ FN_DEV void r8_dense(R8W& W, const unsigned char* fl, f32x16& acc, __amdgpu_buff
         // whose destination a queued MFMA still has to read stalls at issue until that MFMA has started (write-after-read), and
         // with it everything behind it -- requested right behind their last reader the 32 requests of a phase cost ~76 cycles each
         // (FNEUS_R8_STAMPS: 4355 cycles for the requesting half's dense phase against 1930 for the others).
-        if constexpr (s >= LAG && s - LAG < KSN) {
+        if constexpr (s >= LAG && s - LAG < r8_inside<KSN>) {
             constexpr int q = s - LAG;
             const uint32_t f = (uint32_t)(q * nx.nt * 64) * 16u;
             W.hi[q] = p2_wload(rsrc, voff, nx.off_hi + f, blob);
@@ -101,7 +111,7 @@ FN_DEV void r8_dense(R8W& W, const unsigned char* fl, f32x16& acc, __amdgpu_buff
         acc = mfma32(W.hi[s], bh[s % NB], acc);
         __builtin_amdgcn_sched_barrier(0);
     });
-    static_for<(KS > LAG ? KS - LAG : 0), KSN>([&](auto S_) {
+    static_for<(KS > LAG ? KS - LAG : 0), r8_inside<KSN>>([&](auto S_) {
         constexpr int q = decltype(S_)::value;
         const uint32_t f = (uint32_t)(q * nx.nt * 64) * 16u;
         W.hi[q] = p2_wload(rsrc, voff, nx.off_hi + f, blob);
@@ -109,6 +119,17 @@ FN_DEV void r8_dense(R8W& W, const unsigned char* fl, f32x16& acc, __amdgpu_buff
     });
     // the caller may reuse the B registers at once (LDS loads): let the last MFMAs read them first
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+}
+
+// stages r8_inside<KSN> .. KSN-1 of the next layer: behind the barrier of the requesting dense phase
+template <int PREC, int KSN>
+FN_DEV void r8_request_rest(R8W& W, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, const R8Layer& nx, const unsigned char* blob) {
+    static_for<r8_inside<KSN>, KSN>([&](auto S_) {
+        constexpr int q = decltype(S_)::value;
+        const uint32_t f = (uint32_t)(q * nx.nt * 64) * 16u;
+        W.hi[q] = p2_wload(rsrc, voff, nx.off_hi + f, blob);
+        if constexpr (PREC == 3) W.lo[q] = p2_wload(rsrc, voff, nx.off_lo + f, blob);
+    });
 }
 
 // the next layer's stages alone (a wave without a tile in the running layer)

@@ -106,6 +106,8 @@ __global__ void __launch_bounds__(512, 1) sdf_grad_rev_r8_kernel(const unsigned 
     const __amdgpu_buffer_rsrc_t rs_a_lo = r8_array(LO ? st.a_lo : nullptr, (size_t)tiles * 8 * kPPBlock);
     auto rev_of = [&](int l) { return R8Layer{kSdfLayout.L[l].rev_hi, kSdfLayout.L[l].rev_lo, l == 4 ? 9 : 8}; };
     R8W W;
+    u16x8 sg[2][2];                     // two operand sets: phase p (= step * NH + half) uses set p & 1
+    bool first = true;
 #ifdef FNEUS_R8_STAMPS
     unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime(), stamp_d_prev = 0;     // [0]: outside the steps too; [4 + hb]: dense of half hb
     const unsigned long long stamp_t0 = stamp_last;
@@ -116,13 +118,13 @@ __global__ void __launch_bounds__(512, 1) sdf_grad_rev_r8_kernel(const unsigned 
         auto valid_of = [&](int hb) { return (tile0 + hb) * 32 + r < N; };
         // [slot][tile] planes: a tile beyond the allocation would alias tile 0.. of the next slot -- its offset is put beyond every array
         auto blk_off = [&](int slot, int hb) { return tile0 + hb < tiles ? (uint32_t)(((size_t)slot * tiles + tile0 + hb) * kPPBlock) : 0x7ff00000u; };
-        auto priv_off = [&](int l, int hb) { return (uint32_t)(((size_t)(tile0 + hb) * 8 + l) * kPPBlock); };            // [tile][8] lane-private
-        // sigma'(z_l) of this wave's tile: fragments 2 w, 2 w + 1 of the block of (tile, l)
-        auto sig_load = [&](u16x8 (&sg)[2], int l, int hb) {
-            const uint32_t so = priv_off(l, hb) + (uint32_t)(2 * w) * kFragBytes;
-            sg[0] = __builtin_bit_cast(u16x8, r8_ldb(rs_ps, lane16, so));
-            sg[1] = __builtin_bit_cast(u16x8, r8_ldb(rs_ps, lane16, so + kFragBytes));
+        // sigma'(z_l) of this wave's tile: fragments 2 w, 2 w + 1 of the lane-private block of (tile, l), [tile][8] blocks
+        auto sig_load_at = [&](u16x8 (&sgs)[2], int l, long tile) {
+            const uint32_t so = (uint32_t)(((size_t)tile * 8 + l) * kPPBlock) + (uint32_t)(2 * w) * kFragBytes;
+            sgs[0] = __builtin_bit_cast(u16x8, r8_ldb(rs_ps, lane16, so));
+            sgs[1] = __builtin_bit_cast(u16x8, r8_ldb(rs_ps, lane16, so + kFragBytes));
         };
+        auto sig_load = [&](u16x8 (&sgs)[2], int l, int hb) { sig_load_at(sgs, l, tile0 + hb); };
         // a_l = s_l * g_hat(h_{l+1}) -> region hb, plane slot l
         auto post = [&](const f32x16& acc, const u16x8 (&sg)[2], int l, int hb) {
 #pragma unroll
@@ -133,10 +135,12 @@ __global__ void __launch_bounds__(512, 1) sdf_grad_rev_r8_kernel(const unsigned 
                 r8_put_half<PREC, LO>(y, sh, w, lane, lds_ + hb * HALF, true, rs_a_hi, rs_a_lo, blk_off(l, hb), pl, valid_of(hb));
             }
         };
-        u16x8 sg[2][2];                 // two operand sets: phase p (= step * NH + half) uses set p & 1
-        sig_load(sg[0], 7, 0);
-        sig_load(sg[1], 7, 1);
-        r8_wload_all<PREC, 16>(W, rsrc, voff, rev_of(7), blob);
+        if (first) {                    // (later groups: requested at the end of the group before)
+            sig_load(sg[0], 7, 0);
+            sig_load(sg[1], 7, 1);
+            r8_wload_all<PREC, 16>(W, rsrc, voff, rev_of(7), blob);
+            first = false;
+        }
         f32x16 acc;
         {   // a_7 = s_7 * g_hat(h_8), g_hat(h_8) = row 0 of W_8 (the same for every sample)
             f32x16 g8[1];
@@ -154,7 +158,7 @@ __global__ void __launch_bounds__(512, 1) sdf_grad_rev_r8_kernel(const unsigned 
         auto step = [&](auto L_, auto KS_, auto KSN_) {
             constexpr int L = decltype(L_)::value, KS = decltype(KS_)::value, KSN = decltype(KSN_)::value;
             asm volatile("" : "+s"(blob));
-            const R8Layer nx = rev_of(L > 1 ? L - 1 : 1);
+            const R8Layer nx = rev_of(L > 1 ? L - 1 : 7);           // (step 1: the first pack of the next group)
             const bool has_post = !(L == 4 && w == 7);              // a_3 has 7 tiles
             static_for<0, NH>([&](auto HB_) {
                 constexpr int hb = decltype(HB_)::value;
@@ -180,11 +184,13 @@ __global__ void __launch_bounds__(512, 1) sdf_grad_rev_r8_kernel(const unsigned 
 #endif
                 p2_barrier();                                       // every wave has read region hb
                 R8_STAMP(2);
+                if constexpr (hb == NH - 1) r8_request_rest<PREC, KSN>(W, rsrc, voff, nx, blob);
                 if (has_post) post(acc, sg[hb & 1], L - 1, hb);
                 // the freed operand set: sigma' of the phase two further on (wave 7 has no tile in layer 3: blocks allocated, unused)
                 if constexpr (hb + 2 < NH) sig_load(sg[hb & 1], L - 1, hb + 2);
                 else if constexpr (L >= 2) sig_load(sg[hb & 1], L - 2, hb + 2 - NH);
-                R8_PHASE_SYNC();
+                else sig_load_at(sg[hb & 1], 7, (grp + gridDim.x) * NH + hb + 2 - NH);       // the next group's first phases (beyond the
+                R8_PHASE_SYNC();                                                              // last group: zeros, unused)
                 R8_STAMP(3);
             });
         };
@@ -196,7 +202,7 @@ __global__ void __launch_bounds__(512, 1) sdf_grad_rev_r8_kernel(const unsigned 
         step(IC(4), IC(16), IC(14));     // next: L[3], 14 k-steps
         step(IC(3), IC(14), IC(16));
         step(IC(2), IC(16), IC(16));
-        step(IC(1), IC(16), IC(0));
+        step(IC(1), IC(16), IC(16));     // next: L[7] of the following group
 #undef IC
         if (!FNEUS_R8_SYNC) p2_barrier();                           // a_0 of every half is in LDS
         // the 2 row tiles of the 39 PE inputs and normal = J^T q: wave hb for half hb
@@ -327,6 +333,7 @@ __global__ void __launch_bounds__(512, 1) sdf_bwd_r8_kernel(const unsigned char*
     const __amdgpu_buffer_rsrc_t rs_adj_hi = r8_array(bb.adj_hi, sz8), rs_adj_lo = r8_array(LO ? bb.adj_lo : nullptr, sz8);
     const __amdgpu_buffer_rsrc_t rs_zbar_hi = r8_array(bb.zbar_hi, sz9), rs_zbar_lo = r8_array(LO ? bb.zbar_lo : nullptr, sz9);
     R8W W;
+    R8Ops ops[2];                       // phase p (= step * NH + half) uses set p & 1
     bool first = true;
     for (long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         asm volatile("" : "+s"(blob));
@@ -340,6 +347,18 @@ __global__ void __launch_bounds__(512, 1) sdf_bwd_r8_kernel(const unsigned char*
             const uint32_t so = priv_off(l, hb) + (uint32_t)(2 * w) * kFragBytes;
             o.sg[0] = __builtin_bit_cast(u16x8, r8_ldb(rs_ps, lane16, so));
             o.sg[1] = __builtin_bit_cast(u16x8, r8_ldb(rs_ps, lane16, so + kFragBytes));
+        };
+        auto load_asc_at = [&](R8Ops& o, int l, long tile) {      // (any tile: the first operands of the NEXT group too)
+            const uint32_t sp = (uint32_t)(((size_t)tile * 8 + l) * kPPBlock) + (uint32_t)(2 * w) * kFragBytes;
+            o.sg[0] = __builtin_bit_cast(u16x8, r8_ldb(rs_ps, lane16, sp));
+            o.sg[1] = __builtin_bit_cast(u16x8, r8_ldb(rs_ps, lane16, sp + kFragBytes));
+            const uint32_t so = (tile < tiles ? (uint32_t)(((size_t)l * tiles + tile) * kPPBlock) : 0x7ff00000u) + (uint32_t)(2 * w) * kFragBytes;
+            o.hi[0] = __builtin_bit_cast(bf16x8, r8_ldb(rs_a_hi, pl.even, so));
+            o.hi[1] = __builtin_bit_cast(bf16x8, r8_ldb(rs_a_hi, pl.odd, so + kFragBytes));
+            if constexpr (LO) {
+                o.lo[0] = __builtin_bit_cast(bf16x8, r8_ldb(rs_a_lo, pl.even, so));
+                o.lo[1] = __builtin_bit_cast(bf16x8, r8_ldb(rs_a_lo, pl.odd, so + kFragBytes));
+            }
         };
         auto load_asc = [&](R8Ops& o, int l, int hb) {
             load_sig(o, l, hb);
@@ -414,11 +433,12 @@ __global__ void __launch_bounds__(512, 1) sdf_bwd_r8_kernel(const unsigned char*
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        R8Ops ops[2];                   // phase p (= step * NH + half) uses set p & 1
-        load_asc(ops[0], 0, 0);
-        load_asc(ops[1], 0, 1);
-        if (first) r8_wload_all<PREC, 3>(W, rsrc, voff, fwd_of(0), blob);
-        first = false;
+        if (first) {                    // (later groups: requested at the end of the group before)
+            load_asc(ops[0], 0, 0);
+            load_asc(ops[1], 0, 1);
+            r8_wload_all<PREC, 3>(W, rsrc, voff, fwd_of(0), blob);
+            first = false;
+        }
         // ---- qbar = J nbar (wave hb for half hb): k-steps 0..2 of F0, the qbar plane, and a copy parked in slots 16..18 (F4)
         if (w < NH) {
             const int hb = w;
@@ -454,6 +474,7 @@ __global__ void __launch_bounds__(512, 1) sdf_bwd_r8_kernel(const unsigned char*
                 r8_zero(acc);
                 r8_dense<PREC, KS, (hb == NH - 1 ? KSN : 0), LMAP>(W, lds_ + hb * HALF + lane * 16, acc, rsrc, vo_next, nx, blob);
                 p2_barrier();                                       // every wave has read region hb
+                if constexpr (hb == NH - 1) r8_request_rest<PREC, KSN>(W, rsrc, vo_next, nx, blob);
                 constexpr bool keep = KEEP && L == 7;
                 if (active) asc_post(acc, ops[hb & 1], L, hb, keep, L < 7);     // adj_8: plane only
                 // the freed operand set -> the phase two further on (at the turn: s_7, c_7 of the first descending phases)
@@ -532,10 +553,12 @@ __global__ void __launch_bounds__(512, 1) sdf_bwd_r8_kernel(const unsigned char*
                 }
                 r8_dense<PREC, KS, (hb == NH - 1 ? KSN : 0)>(W, lds_ + hb * HALF + lane * 16, acc, rsrc, voff, nx, blob);
                 p2_barrier();
+                if constexpr (hb == NH - 1) r8_request_rest<PREC, KSN>(W, rsrc, voff, nx, blob);
                 if (active) desc_post(acc, ops[hb & 1], L - 1, hb, L > 1);          // zbar_0: plane only
                 if constexpr (hb + 2 < NH) load_desc(ops[hb & 1], L - 1, hb + 2);
                 else if constexpr (L >= 2) load_desc(ops[hb & 1], L - 2, hb + 2 - NH);
-                R8_PHASE_SYNC();
+                else load_asc_at(ops[hb & 1], 0, (grp + gridDim.x) * NH + hb + 2 - NH);      // the next group's first phases (beyond the
+                R8_PHASE_SYNC();                                                             // last group: zeros, unused)
             });
         };
         desc_step(IC(8), IC(16), IC(16));                 // (+ the sdf tile's 2 k-steps, streamed)

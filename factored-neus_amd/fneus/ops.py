@@ -201,9 +201,29 @@ class batched_refresh:
 _wn_batch = None
 
 
+MAX_WN_TASKS = 8         # csrc/pack.hip kMaxWnTasks: task table by value in the kernel arguments
+
+
 def _launch_wn_calls(calls):
     global _wn_batch
     if not calls:
+        return
+    # one task per (network, d_eff): a network collected twice would have two tasks racing on its raw gradient inside the launch
+    seen, uniq = set(), []
+    for n, d_eff in calls:
+        key = (id(n), d_eff.data_ptr())
+        if key not in seen:
+            seen.add(key)
+            uniq.append((n, d_eff))
+    calls = uniq
+    if len({id(n) for n, _ in calls}) != len(calls) or len(calls) > MAX_WN_TASKS:
+        # the same network with two different d_eff buffers, or more tasks than one launch takes: one launch each, in order
+        saved, _wn_batch = _wn_batch, None
+        try:
+            for n, d_eff in calls:
+                n.wn_backward(d_eff)
+        finally:
+            _wn_batch = saved
         return
     if len(calls) == 1:
         saved, _wn_batch = _wn_batch, None
@@ -243,8 +263,10 @@ class batched_wn_backward:
         global _wn_batch
         if self.outer is None and _wn_batch is not None:
             calls, _wn_batch = _wn_batch, None
-            if exc[0] is None:
-                _launch_wn_calls(calls)
+            # ALSO when the block exits on an exception: the weight-gradient GEMMs that ran have accumulated into the d_eff
+            # buffers, which fneus_wn_backward consumes AND clears -- dropping the calls would leave them non-zero and the next
+            # step would silently add stale gradients (the unbatched path clears each buffer right behind its GEMM)
+            _launch_wn_calls(calls)
         return False
 
 

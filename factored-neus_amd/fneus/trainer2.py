@@ -33,6 +33,25 @@ def stage2_loss(out: dict, reduce=None):
     return {"loss": lvis_loss + radiance_loss, "lvis_loss": lvis_loss, "trace_radiance_loss": radiance_loss}
 
 
+class blas_scope:
+    """torch.backends.cuda.preferred_blas_library(name) for the duration of a block; the previous setting comes back behind it
+    (name None: nothing is touched)"""
+
+    def __init__(self, name):
+        self.name, self.prev = name, None
+
+    def __enter__(self):
+        if self.name is not None:
+            self.prev = torch.backends.cuda.preferred_blas_library()
+            torch.backends.cuda.preferred_blas_library(self.name)
+        return self
+
+    def __exit__(self, *exc):
+        if self.name is not None and self.prev is not None:
+            torch.backends.cuda.preferred_blas_library(self.prev)
+        return False
+
+
 class Stage2Trainer:
     def __init__(self, device, model_conf: Optional[dict] = None, prec: int = ops.PREC_PARITY, lr: float = 5e-4, seed: int = 0,
                  synthetic_init: bool = True, sdf_kwargs: Optional[dict] = None, use_graph: bool = False,
@@ -87,9 +106,12 @@ class Stage2Trainer:
         # the default BLAS backend (hipBLASLt) runs their weight-gradient products -- [256, 512] x [512, 256] -- as ONE
         # 256 x 256 macro tile on one CU: 118 us each, 0.36 ms of a stage-3 step; rocBLAS takes 6.7 us
         # (tools/experiments/r03/blaslt_test.py).  FNEUS_TORCH_BLAS=keep leaves the process-wide setting alone.
+        # The preference is set for the duration of THIS trainer's steps only (blas_scope: saved and restored around every
+        # train_step; a replayed hipGraph holds the kernels it was recorded with): the host application's own matmuls, and
+        # oracle / reference comparisons in the same process, keep the backend they had.
         blas = os.environ.get("FNEUS_TORCH_BLAS", "cublas")
-        if blas != "keep" and self.device.type == "cuda":
-            torch.backends.cuda.preferred_blas_library(blas)
+        self._blas = blas if (blas != "keep" and self.device.type == "cuda") else None
+        self.graph_error = None             # why a graph capture fell back to eager launches, if it did
         self.distributed = bool(distributed)
         self.reduce = None
         self.grads = None
@@ -198,8 +220,9 @@ class Stage2Trainer:
             try:
                 with torch.cuda.graph(graph):
                     losses = self._fixed_shape_step(static)
-            except Exception as e:      # noqa: BLE001 -- a failed capture must leave a working (eager) trainer behind
-                import sys
+            except RuntimeError as e:   # a capture the runtime refuses must leave a working (eager) trainer behind; anything
+                import sys              # else (a bug in the step) propagates
+                self.graph_error = repr(e)
                 print(f"[fneus] stage graph capture failed ({e!r}); continuing with eager launches", file=sys.stderr)
                 torch.cuda.synchronize()
                 self.use_graph = False
@@ -251,6 +274,10 @@ class Stage2Trainer:
     def train_step(self, data: torch.Tensor, near=None, far=None, u_theta=None, u_z=None, z_vals_override=None):
         """data [B,10] (dataset.py:133-151); near / far None: unit-sphere bounds.  -> loss dict, or None when no ray of
         the batch hits the surface (the reference skips such a batch, lvis.py:160-161)"""
+        with blas_scope(self._blas):
+            return self._train_step(data, near, far, u_theta, u_z, z_vals_override)
+
+    def _train_step(self, data, near, far, u_theta, u_z, z_vals_override):
         if self.use_graph and near is None and u_theta is None:
             return self._graph_step(data)
         if self.distributed:

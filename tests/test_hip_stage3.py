@@ -319,6 +319,13 @@ def test_fused_srgb_curves_vs_the_element_wise_formulation(to_linear, clip):
     # (the clip's sub-gradient exactly at 0 / 1 and the branch points are measure-zero conventions: compare away from them)
     away = ((ya.detach() - 0.0).abs() > 1e-6) & ((ya.detach() - 1.0).abs() > 1e-6)
     assert ((xb.grad - xa.grad).abs()[away] <= 2e-5 * xa.grad.abs()[away].clamp_min(1.0)).all()
+    # NaN in, NaN out -- value and gradient -- as the reference's torch.where over torch.clamp(...) ** p: a diverged run must not
+    # come out of the tone mapping with a finite colour
+    xn = torch.tensor([float("nan"), 0.5], device=dev, requires_grad=True)
+    yn = ops.srgb(xn, to_linear=to_linear, clip=clip)
+    yn.sum().backward()
+    assert torch.isnan(yn[0]) and torch.isfinite(yn[1]) and torch.isnan(xn.grad[0]) and torch.isfinite(xn.grad[1])
+    assert torch.isnan(ref(torch.tensor([float("nan")], device=dev)))[0]
 
 
 def test_fused_visibility_direction_set_vs_the_element_wise_formulation():
