@@ -238,6 +238,13 @@ def main():
         broadcast_parameters(tr.modules)
         batches = synthetic_batches(steps + warmup + (3 if profile else 0), rays_rank, device, rank=rank)
         step_kw = dict(cos_anneal_ratio=0.5, background_rgb=torch.ones(1, 3, device=device)) if args.womask else {}
+        # more than one rank: the job measures both forms of its gradient exchange on its own steps (untimed, ahead of the W
+        # warm-up steps) and keeps the faster one -- every rank takes the same decision (fneus/trainer.py autotune_exchange)
+        if world > 1 or dp_single:
+            choice = tr.autotune_exchange(batches[:max(4, min(len(batches), 8))], **step_kw)
+            run.exchange = choice
+            print(f"[bench rank {rank}/{world}] gradient exchange: {choice['choice']} (split {choice['ms_split']} ms, single "
+                  f"{choice['ms_single']} ms per step over {choice['steps']} steps; {choice['why']})", file=sys.stderr, flush=True)
         _step = tr.train_step
         tr.train_step = lambda b: _step(b, **step_kw)
         for i in range(warmup):
@@ -300,10 +307,17 @@ def main():
                                 f"dtu_scan97-shaped wmask.conf stage-1 SDF+radiance train step, {rays_rank} rays x (64+64) samples, "
                                 "1xMI355X per rank"), "rays_per_gpu": rays_rank, "samples_per_ray": N_SAMPLES + N_IMPORTANCE + n_out,
                    **({"rays_global": rays_rank * world} if strong else {}),
-                   "parallelism": f"dp{world} (ray-sharded replicas, the gradient arena all-reduced in place in two parts)",
+                   "parallelism": (f"dp{world} (ray-sharded replicas; gradient arena all-reduced in place, "
+                                   + (("in two parts, the early one beside the SDF backward" if tr.split_exchange else
+                                       "in one exchange behind the backward") if (world > 1 or dp_single) else "no exchange with one rank")
+                                   + (f"; chosen at start-up on this job's own steps: split {run.exchange['ms_split']} ms vs single "
+                                      f"{run.exchange['ms_single']} ms per step" if getattr(run, "exchange", None) and run.exchange.get("steps") else "")
+                                   + "; >1 rank over RCCL unmeasured on the builder's 1-GPU boxes)"),
                    "launch": ("eager kernel launches" if not (tr.use_graph and tr._graphs) else
-                              "four hipGraph replays per step around the three collectives (loss normalisers; early part of the gradient "
-                              "arena beside the SDF backward; late part)" if (world > 1 or dp_single) else
+                              ("four hipGraph replays per step around the three collectives (loss normalisers; early part of the gradient "
+                               "arena beside the SDF backward; late part)" if tr.split_exchange else
+                               "three hipGraph replays per step around the two collectives (loss normalisers; gradient arena)")
+                              if (world > 1 or dp_single) else
                               "one hipGraph replay per step")},
         **({"diagnostic": "FNEUS_DP_SINGLE=1: data-parallel step structure with one rank"} if dp_single else {}),
         "mfma_roofline_frac_step": value / world * FLOP_TRAIN_PER_SAMPLE / (PEAK_BF16_MFMA_TFLOPS * 1e12),

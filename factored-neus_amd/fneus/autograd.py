@@ -347,5 +347,7 @@ class Stage1LossFn(torch.autograd.Function):
     def backward(ctx, g, *unused):
         if g is None:
             return (None,) * 15
+        if ops.UNIT_LOSS_GRAD:               # the trainers' `loss.backward()`: the cotangent is the constant 1 (ops.unit_loss_grad)
+            return tuple(ctx.saved_tensors) + (None,) * 9
         grads = torch._foreach_mul(list(ctx.saved_tensors), g)
         return tuple(grads) + (None,) * 9

@@ -105,6 +105,24 @@ def _launch(name, fn, *args):
     PROFILE.append((name, e0, e1))
 
 
+# The fused loss kernel hands out the gradients of the TOTAL loss; autograd multiplies them by the cotangent of the loss -- a launch
+# per step for a factor that is the constant 1 when the trainer calls loss.backward().  Inside `with unit_loss_grad():` the saved
+# gradients are passed on as they are.
+UNIT_LOSS_GRAD = False
+
+
+class unit_loss_grad:
+    def __enter__(self):
+        global UNIT_LOSS_GRAD
+        self.prev, UNIT_LOSS_GRAD = UNIT_LOSS_GRAD, True
+        return self
+
+    def __exit__(self, *exc):
+        global UNIT_LOSS_GRAD
+        UNIT_LOSS_GRAD = self.prev
+        return False
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 

@@ -12,6 +12,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import os
+
 import torch
 
 from fneus import ops, synth
@@ -84,14 +86,18 @@ class Stage1Trainer:
         late = [self.sdf_network] + ([self.nerf_outside] if self.use_nerf else [])
         self.grads = GradArena(device, late + [self.color_network], self.refColor_network, [self.deviation_network],
                                n_late=len(late))
+        # FNEUS_DP_EARLY = 1 / 0 fixes the form (split / single exchange); "auto" (the default of bench.py and the runners with
+        # more than one rank, through autotune_exchange) measures both on the job's own steps and keeps the faster one
         self.split_exchange = self.distributed and os.environ.get("FNEUS_DP_EARLY", "1") != "0"
-        self._xstream = torch.cuda.Stream(device=device) if (self.split_exchange and device.type == "cuda") else None
+        self.exchange_choice = None          # filled by autotune_exchange: {"choice", "ms_split", "ms_single", "steps"}
+        self._xstream = torch.cuda.Stream(device=device) if (self.distributed and device.type == "cuda") else None
         self._early = None           # handle of the early part's all-reduce of the step in flight
-        if self.split_exchange:
+        if self.distributed:         # (the hook looks at split_exchange when it runs: both forms can be recorded by one trainer)
             self.sdf_network._ws.pre_backward = self._early_exchange
         self.optimizer = FlatAdam(self.params, lr=lr)
         self._graphs = {}            # (batch shape, background shape) -> (graph(s), static input, static background, losses)
         self._cos = torch.ones(1, dtype=torch.float32, device=device)    # cos_anneal_ratio of the replayed step
+        self._cos_val = 1.0
         self._eager_steps = 0
         self.graph_warmup_steps = 2  # eager steps before the first capture (workspaces, job tables, LDS attributes)
         self.renderer = NeuSRenderer(**conf["neus_renderer"], nerf=self.nerf_outside if self.use_nerf else None,
@@ -101,6 +107,8 @@ class Stage1Trainer:
         self.igr_weight, self.mask_weight, self.surface_weight = igr_weight, mask_weight, surface_weight
         self.bucket = self.grads if distributed else None
         self.iter_step = 0
+        self._auto = None
+        self._auto_begin()
 
     def set_lr(self, lr: float):
         self.optimizer.set_lr(lr)
@@ -111,14 +119,16 @@ class Stage1Trainer:
     def train_step(self, data: torch.Tensor, cos_anneal_ratio: float = 1.0, background_rgb=None):
         """data [B,10] = rays_o, rays_d, rgb, mask (dataset.py:133-151).  Returns the loss dict (device tensors; with
         use_graph they are static buffers that the next step overwrites)."""
+        if self._auto is not None:
+            self._auto_advance()
         if not self.use_graph or ops.PROFILE is not None:
             return self._eager_step(data, cos_anneal_ratio, background_rgb)
         # one capture per batch shape: cos_anneal_ratio is a device scalar that the compositing kernels read at run time
         # (it ramps every step in the womask configuration), the background colour a static buffer
-        key = (tuple(data.shape), None if background_rgb is None else tuple(background_rgb.shape))
+        key = (tuple(data.shape), None if background_rgb is None else tuple(background_rgb.shape), self.split_exchange)
         entry = self._graphs.get(key)
         if entry is None:
-            if self._eager_steps < self.graph_warmup_steps or len(self._graphs) >= 4:
+            if self._eager_steps < self.graph_warmup_steps or len(self._graphs) >= 6:
                 return self._eager_step(data, cos_anneal_ratio, background_rgb)
             entry = (self._capture_dp if self.distributed else self._capture)(data, background_rgb)
             self._graphs[key] = entry
@@ -126,7 +136,9 @@ class Stage1Trainer:
                 return self._eager_step(data, cos_anneal_ratio, background_rgb)
         graph, static_data, static_bg, losses = entry
         static_data.copy_(data)
-        self._cos.fill_(float(cos_anneal_ratio))
+        if float(cos_anneal_ratio) != self._cos_val:        # (constant in wmask.conf: no launch per step)
+            self._cos_val = float(cos_anneal_ratio)
+            self._cos.fill_(self._cos_val)
         if static_bg is not None:
             static_bg.copy_(background_rgb)
         if self.distributed:
@@ -168,6 +180,8 @@ class Stage1Trainer:
         """called when the SDF backward starts (fneus/autograd.py SdfValueGradFn.backward): the gradients of every other
         network are final.  Eager step: start their all-reduce on the exchange stream.  While _capture_dp records a step:
         the second graph ends here and the third (the SDF backward) begins."""
+        if not self.split_exchange:          # single exchange behind the backward: nothing happens here
+            return
         st = self._capturing
         # FNEUS_OVERLAP bits 2 | 4 put the colour / RefColor weight-gradient GEMMs and the fold backward on the ops side
         # stream: they write the early part of the arena, so that stream joins before the exchange reads it (during a
@@ -267,6 +281,66 @@ class Stage1Trainer:
             return None
         return (g1, g2, g2b, g3, st["norms"]), static_data, static_bg, losses
 
+    # ---- which form of the gradient exchange?  ("overlap or direct reduce-scatter -- measure both") -----------
+    # Data parallel with more than one rank and FNEUS_DP_EARLY unset (or "auto"): the job measures both forms on ITS OWN training
+    # steps -- warm-up / capture steps, then AUTO_STEPS timed steps with the arena exchanged in two parts (four hipGraphs around
+    # three collectives), the same with one exchange behind the backward (three graphs around two) -- takes the MAX over the
+    # ranks of each wall time (one small all-reduce: every rank sees the same two numbers, so every rank takes the same
+    # decision) and keeps the faster form.  The steps are ordinary training steps: nothing is repeated or thrown away.
+    AUTO_STEPS = 20
+
+    def _auto_begin(self):
+        import os
+        forced = os.environ.get("FNEUS_DP_EARLY", "auto")
+        if not self.distributed or not collectives_active() or forced in ("0", "1"):
+            self.exchange_choice = {"choice": "split" if self.split_exchange else "single", "ms_split": None, "ms_single": None,
+                                    "steps": 0, "why": ("FNEUS_DP_EARLY=" + forced) if forced in ("0", "1") else "no collectives"}
+            self._auto = None
+            return
+        self.split_exchange = True
+        self._auto = {"phase": 0, "count": 0, "t0": 0.0, "ms": {}}
+
+    def _auto_advance(self):
+        """called at the start of every train_step while the selection runs"""
+        import time
+        import torch.distributed as dist
+        a = self._auto
+        warm = self.graph_warmup_steps + 3                           # eager warm-up where needed, the capture, first replays
+        if a["phase"] in (0, 2) and a["count"] == warm:              # warm-up of this form done: start its clock
+            torch.cuda.synchronize()
+            dist.barrier()
+            a["t0"], a["count"], a["phase"] = time.perf_counter(), 0, a["phase"] + 1
+        elif a["phase"] in (1, 3) and a["count"] == self.AUTO_STEPS:
+            torch.cuda.synchronize()
+            t = torch.tensor([(time.perf_counter() - a["t0"]) / self.AUTO_STEPS * 1e3], dtype=torch.float32, device=self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            a["ms"]["split" if a["phase"] == 1 else "single"] = float(t.item())
+            if a["phase"] == 1:
+                self.split_exchange, a["phase"], a["count"] = False, 2, 0
+            else:
+                ms = a["ms"]
+                self.split_exchange = ms["split"] <= ms["single"]
+                self.exchange_choice = {"choice": "split" if self.split_exchange else "single", "ms_split": round(ms["split"], 4),
+                                        "ms_single": round(ms["single"], 4), "steps": self.AUTO_STEPS,
+                                        "why": "measured on this job's own steps (max over ranks)"}
+                self._auto = None
+                if int(os.environ.get("RANK", "0")) == 0 or os.environ.get("FNEUS_DP_VERBOSE"):
+                    import sys
+                    c = self.exchange_choice
+                    print(f"[fneus] gradient exchange: {c['choice']} (split {c['ms_split']} ms, single {c['ms_single']} ms per step "
+                          f"over {c['steps']} steps each, max over ranks)", file=sys.stderr, flush=True)
+                return
+        a["count"] += 1
+
+    def autotune_exchange(self, batches, cos_anneal_ratio: float = 1.0, background_rgb=None):
+        """run training steps on `batches` until the selection above has finished (bench.py: ahead of its warm-up, so that no timed
+        step contains a capture); returns the record {"choice", "ms_split", "ms_single", "steps", "why"}"""
+        i = 0
+        while self._auto is not None:
+            self.train_step(batches[i % len(batches)], cos_anneal_ratio, background_rgb)
+            i += 1
+        return self.exchange_choice
+
     def _capture(self, data: torch.Tensor, background_rgb):
         import gc
         static_data = data.clone()
@@ -309,10 +383,11 @@ class Stage1Trainer:
         losses = out["losses"]
         self.zero_grad()
         if not ops.OVERLAP_MASK:     # the fold-backward launches of the networks as one (data parallel: one for the early part of
-            with ops.batched_wn_backward():      # the arena, flushed by _early_exchange, and the SDF network's behind the backward)
-                losses["loss"].backward()
+            with ops.batched_wn_backward(), ops.unit_loss_grad():     # the arena, flushed by _early_exchange, and the SDF
+                losses["loss"].backward()                             # network's behind the backward)
         else:
-            losses["loss"].backward()
+            with ops.unit_loss_grad():
+                losses["loss"].backward()
         ops.overlap_end()                    # the weight gradients issued on the side stream are complete from here on
         if with_optimizer:
             self.optimizer.step()

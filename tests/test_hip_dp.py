@@ -101,7 +101,7 @@ def test_config5_shape_four_shards_of_512_womask_rays_equal_the_2048_ray_batch()
     assert worst <= 2e-3
 
 
-def _two_ranks(graph: bool, fail_rank: int = -1, stage: int = 1, conf: str = "wmask"):
+def _two_ranks(graph: bool, fail_rank: int = -1, stage: int = 1, conf: str = "wmask", steps: int = 7):
     import os
     import subprocess
     import sys
@@ -110,8 +110,8 @@ def _two_ranks(graph: bool, fail_rank: int = -1, stage: int = 1, conf: str = "wm
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "tools", "dp_check.py")]
     env = dict(os.environ, DP_CHECK_GRAPH="1" if graph else "0", DP_CHECK_FAIL_RANK=str(fail_rank), DP_CHECK_STAGE=str(stage),
-               DP_CHECK_CONF=conf)
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
+               DP_CHECK_CONF=conf, DP_CHECK_STEPS=str(steps))
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=360, env=env)
     line = [l for l in r.stdout.splitlines() if l.startswith("DP_CHECK")]
     assert r.returncode == 0 and line and line[0].endswith("OK"), (r.stdout[-2000:], r.stderr[-2000:])
     print(" ", line[0])
@@ -132,6 +132,15 @@ def test_two_ranks_sharing_the_gpu_stay_identical():
     # closely, the later ones must stay on the same curve
     for i, (a, b) in enumerate(zip(eager, graphed)):
         assert abs(a - b) <= (1e-3 if i < 3 else 3e-2) * max(abs(a), 1e-2), (i, a, b)
+
+
+def test_exchange_form_is_measured_and_agreed_at_start_up():
+    """more than one rank, FNEUS_DP_EARLY unset: the job times both forms of its gradient exchange on its own training steps (the
+    arena in two parts beside the SDF backward: four graphs around three collectives; one exchange behind the backward: three
+    around two), every rank sees the same two MAX-over-ranks timings and keeps the same form (tools/dp_check.py checks the
+    agreement, that both timings exist and that the replicas are bit-identical across the switch); 60 steps of two ranks."""
+    trace = _two_ranks(graph=True, steps=60)
+    assert len(trace) == 60 and all(t == t for t in trace)
 
 
 def test_capture_failure_on_one_rank_moves_every_rank_to_eager_launches():

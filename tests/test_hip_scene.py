@@ -124,16 +124,17 @@ def test_reconstruction_matches_oracle_training_on_the_synthetic_scene():
 
 def test_chamfer_at_equal_steps_hip_vs_oracle_over_seeds():
     """BASELINE.json metric, second half (Chamfer-L1 within 2 % of the reference at equal steps): tests/checkers/chamfer_study.py over
-    3 seeds x 1200 steps here (8 seeds x 2000 steps: profiles/r03_chamfer.json, mean ratio 1.002, standard error 1.7 %).  The
-    HIP path runs in deterministic mode, so the numbers are reproducible; per seed the two paths see the same weights, batches
-    and learning-rate schedule.  Seed-to-seed s.d. of one path is 3-6 % of its mean, so with 3 seeds the ratio of the means is
-    resolved to ~4 %: the bound is 3 standard errors."""
+    8 seeds x 1200 steps HERE, in the driver's run (32 seeds x 2000 steps on the builder's box: profiles/r03_chamfer.json, ratio
+    0.9976, standard error 0.74 %).  The HIP path runs in deterministic mode, so the numbers are reproducible; per seed the two
+    paths see the same weights, batches and learning-rate schedule.  The per-seed log ratio scatters by ~4 % (both paths are
+    chaotic in their rounding), so 8 seeds resolve the ratio of the means to ~1.5 %: the bound is 3 standard errors, 5 %
+    -- a backward that is wrong by 5 % does not pass here."""
     import importlib.util, os, types
     spec = importlib.util.spec_from_file_location("chamfer_study", os.path.join(os.path.dirname(__file__), "checkers", "chamfer_study.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    res = mod.run_study(types.SimpleNamespace(seeds=3, steps=1200, rays=512, res=96, gprec=1, seed0=300))
+    res = mod.run_study(types.SimpleNamespace(seeds=8, steps=1200, rays=512, res=96, gprec=1, seed0=300))
     print({k: v for k, v in res.items() if k != "runs"})
     assert res["hip_mean"] < 0.4 * np.mean([r["chamfer_init"] for r in res["runs"]])       # both reconstruct the scene ...
     assert res["oracle_mean"] < 0.4 * np.mean([r["chamfer_init"] for r in res["runs"]])
-    assert abs(res["ratio_of_means"] - 1.0) <= 0.12                                        # ... equally well
+    assert abs(res["ratio_of_means"] - 1.0) <= 0.05, (res["ratio_of_means"], res.get("sem_log_ratio_pct"))      # ... equally well

@@ -84,8 +84,10 @@ if use_graph and rank == fail_rank:
     tr.optimizer.step = failing_step
 losses = None
 trace = []
-for b in synthetic_batches(7, 128, dev, rank=rank):
-    losses = tr.global_losses(tr.train_step(b))
+n_steps = int(os.environ.get("DP_CHECK_STEPS", "7"))          # >= 55: the run crosses the start-up selection of the exchange form
+bs = synthetic_batches(min(n_steps, 8), 128, dev, rank=rank)
+for i in range(n_steps):
+    losses = tr.global_losses(tr.train_step(bs[i % len(bs)]))
     trace.append(float(losses["loss"]))
 flat = torch.cat([p.detach().reshape(-1) for p in tr.params])
 gathered = [torch.empty_like(flat) for _ in range(world)]
@@ -94,7 +96,16 @@ worst = max((g - gathered[0]).abs().max().item() for g in gathered)
 if fail_rank >= 0:
     graphs_ok = not tr.use_graph                      # the injected failure must have switched EVERY rank to eager launches
 else:
-    graphs_ok = not use_graph or (tr.use_graph and len(tr._graphs) == 1)
+    # one captured step per exchange form met so far (FNEUS_DP_EARLY unset: both forms are measured at start-up, fneus/trainer.py)
+    graphs_ok = not use_graph or (tr.use_graph and len(tr._graphs) in (1, 2))
+if n_steps >= 55 and os.environ.get("FNEUS_DP_EARLY", "auto") not in ("0", "1"):
+    # the selection has finished, with timings for both forms, and every rank has taken the same decision
+    c = tr.exchange_choice
+    picks = [None] * world
+    dist.all_gather_object(picks, None if c is None else (c["choice"], c["ms_split"], c["ms_single"]))
+    graphs_ok = graphs_ok and c is not None and c["steps"] > 0 and all(p == picks[0] for p in picks) and tr._auto is None
+    if rank == 0:
+        print(f"DP_EXCHANGE {c}")
 flags = [None] * world
 dist.all_gather_object(flags, bool(graphs_ok))
 ok = worst == 0.0 and bool(torch.isfinite(losses["loss"])) and all(flags)
