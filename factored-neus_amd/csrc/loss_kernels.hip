@@ -283,9 +283,44 @@ __global__ void __launch_bounds__(kLossThreads) stage1_norms_kernel(const float*
     }
 }
 
+// the way back of surface_gather: d_feat[sel[i]] += sum over the heads of d_feat_heads[h][i], the same for the normals.  One
+// wavefront per gathered row; the 2 B selected rows are distinct (two consecutive samples of each ray), so plain read-modify-write.
+__global__ void __launch_bounds__(64) surface_scatter_kernel(const int32_t* __restrict__ sel, const float* __restrict__ dfh,
+                                                             const float* __restrict__ dnh, int n_heads, long n_rows,
+                                                             float* __restrict__ d_feat, float* __restrict__ d_normal) {
+    const long i = blockIdx.x;
+    const int lane = threadIdx.x;
+    const long dst = sel[i];
+    if (dfh != nullptr) {
+        f32x4 s = *reinterpret_cast<const f32x4*>(d_feat + dst * 256 + lane * 4);
+        for (int hd = 0; hd < n_heads; ++hd) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(dfh + ((long)hd * n_rows + i) * 256 + lane * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] += v[e];
+        }
+        *reinterpret_cast<f32x4*>(d_feat + dst * 256 + lane * 4) = s;
+    }
+    if (dnh != nullptr && lane < 3) {
+        float s = d_normal[dst * 3 + lane];
+        for (int hd = 0; hd < n_heads; ++hd) s += dnh[((long)hd * n_rows + i) * 3 + lane];
+        d_normal[dst * 3 + lane] = s;
+    }
+}
+
 }  // namespace fneus
 
 using namespace fneus;
+
+extern "C" int fneus_surface_scatter(const int32_t* sel, const float* d_feat_heads, const float* d_normal_heads, int n_heads, long n_rows,
+                                     float* d_feat, float* d_normal, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (n_rows <= 0 || n_heads <= 0) return 0;
+    if (sel == nullptr || (d_feat_heads != nullptr && d_feat == nullptr) || (d_normal_heads != nullptr && d_normal == nullptr)) return -2;
+    hipLaunchKernelGGL(surface_scatter_kernel, dim3((unsigned)n_rows), dim3(64), 0, stream, sel, d_feat_heads, d_normal_heads, n_heads, n_rows,
+                       d_feat, d_normal);
+    return fneus::launch_status();
+}
 
 extern "C" int fneus_surface_gather(const int32_t* min_idx, const unsigned char* sdf_mask, const float* mid_z,
                                     const float* feat, const float* normal, int n_rays, int n, int32_t* sel, float* t_sel,

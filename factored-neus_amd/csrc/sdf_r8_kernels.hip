@@ -107,7 +107,6 @@ __global__ void __launch_bounds__(512, 1) sdf_grad_rev_r8_kernel(const unsigned 
     auto rev_of = [&](int l) { return R8Layer{kSdfLayout.L[l].rev_hi, kSdfLayout.L[l].rev_lo, l == 4 ? 9 : 8}; };
     R8W W;
     u16x8 sg[2][2];                     // two operand sets: phase p (= step * NH + half) uses set p & 1
-    bool first = true;
 #ifdef FNEUS_R8_STAMPS
     unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime(), stamp_d_prev = 0;     // [0]: outside the steps too; [4 + hb]: dense of half hb
     const unsigned long long stamp_t0 = stamp_last;
@@ -135,12 +134,11 @@ __global__ void __launch_bounds__(512, 1) sdf_grad_rev_r8_kernel(const unsigned 
                 r8_put_half<PREC, LO>(y, sh, w, lane, lds_ + hb * HALF, true, rs_a_hi, rs_a_lo, blk_off(l, hb), pl, valid_of(hb));
             }
         };
-        if (first) {                    // (later groups: requested at the end of the group before)
-            sig_load(sg[0], 7, 0);
-            sig_load(sg[1], 7, 1);
-            r8_wload_all<PREC, 16>(W, rsrc, voff, rev_of(7), blob);
-            first = false;
-        }
+        // (NOT requested behind the last phases of the group before, as K3 does: the streamed passes of this kernel's epilogue --
+        // the PE tiles of L[0] -- would wait for their fragments behind those requests; measured 219 against 210 us)
+        sig_load(sg[0], 7, 0);
+        sig_load(sg[1], 7, 1);
+        r8_wload_all<PREC, 16>(W, rsrc, voff, rev_of(7), blob);
         f32x16 acc;
         {   // a_7 = s_7 * g_hat(h_8), g_hat(h_8) = row 0 of W_8 (the same for every sample)
             f32x16 g8[1];
@@ -158,7 +156,7 @@ __global__ void __launch_bounds__(512, 1) sdf_grad_rev_r8_kernel(const unsigned 
         auto step = [&](auto L_, auto KS_, auto KSN_) {
             constexpr int L = decltype(L_)::value, KS = decltype(KS_)::value, KSN = decltype(KSN_)::value;
             asm volatile("" : "+s"(blob));
-            const R8Layer nx = rev_of(L > 1 ? L - 1 : 7);           // (step 1: the first pack of the next group)
+            const R8Layer nx = rev_of(L > 1 ? L - 1 : 1);
             const bool has_post = !(L == 4 && w == 7);              // a_3 has 7 tiles
             static_for<0, NH>([&](auto HB_) {
                 constexpr int hb = decltype(HB_)::value;
@@ -189,8 +187,7 @@ __global__ void __launch_bounds__(512, 1) sdf_grad_rev_r8_kernel(const unsigned 
                 // the freed operand set: sigma' of the phase two further on (wave 7 has no tile in layer 3: blocks allocated, unused)
                 if constexpr (hb + 2 < NH) sig_load(sg[hb & 1], L - 1, hb + 2);
                 else if constexpr (L >= 2) sig_load(sg[hb & 1], L - 2, hb + 2 - NH);
-                else sig_load_at(sg[hb & 1], 7, (grp + gridDim.x) * NH + hb + 2 - NH);       // the next group's first phases (beyond the
-                R8_PHASE_SYNC();                                                              // last group: zeros, unused)
+                R8_PHASE_SYNC();
                 R8_STAMP(3);
             });
         };
@@ -202,7 +199,7 @@ __global__ void __launch_bounds__(512, 1) sdf_grad_rev_r8_kernel(const unsigned 
         step(IC(4), IC(16), IC(14));     // next: L[3], 14 k-steps
         step(IC(3), IC(14), IC(16));
         step(IC(2), IC(16), IC(16));
-        step(IC(1), IC(16), IC(16));     // next: L[7] of the following group
+        step(IC(1), IC(16), IC(0));
 #undef IC
         if (!FNEUS_R8_SYNC) p2_barrier();                           // a_0 of every half is in LDS
         // the 2 row tiles of the 39 PE inputs and normal = J^T q: wave hb for half hb
@@ -335,6 +332,10 @@ __global__ void __launch_bounds__(512, 1) sdf_bwd_r8_kernel(const unsigned char*
     R8W W;
     R8Ops ops[2];                       // phase p (= step * NH + half) uses set p & 1
     bool first = true;
+#ifdef FNEUS_R8_STAMPS
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();     // [0]: outside the steps; [4..7]: descending
+    const unsigned long long stamp_t0 = stamp_last;
+#endif
     for (long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         asm volatile("" : "+s"(blob));
         const long tile0 = grp * NH;
@@ -471,9 +472,12 @@ __global__ void __launch_bounds__(512, 1) sdf_bwd_r8_kernel(const unsigned char*
             const bool active = !(L == 3 && w == 7);                // F3 has 7 output tiles
             static_for<0, NH>([&](auto HB_) {
                 constexpr int hb = decltype(HB_)::value;
+                R8_STAMP(0);
                 r8_zero(acc);
                 r8_dense<PREC, KS, (hb == NH - 1 ? KSN : 0), LMAP>(W, lds_ + hb * HALF + lane * 16, acc, rsrc, vo_next, nx, blob);
+                R8_STAMP(1);
                 p2_barrier();                                       // every wave has read region hb
+                R8_STAMP(2);
                 if constexpr (hb == NH - 1) r8_request_rest<PREC, KSN>(W, rsrc, vo_next, nx, blob);
                 constexpr bool keep = KEEP && L == 7;
                 if (active) asc_post(acc, ops[hb & 1], L, hb, keep, L < 7);     // adj_8: plane only
@@ -482,6 +486,7 @@ __global__ void __launch_bounds__(512, 1) sdf_bwd_r8_kernel(const unsigned char*
                 else if constexpr (L < 7) load_asc(ops[hb & 1], L + 1, hb + 2 - NH);
                 else if constexpr (!keep) load_desc(ops[hb & 1], 7, hb + 2 - NH);
                 R8_PHASE_SYNC();
+                R8_STAMP(3);
             });
         };
         using std::integral_constant;
@@ -544,6 +549,7 @@ __global__ void __launch_bounds__(512, 1) sdf_bwd_r8_kernel(const unsigned char*
             const bool active = !(L == 4 && w == 7);                // R4: the 7 tiles of h_4 (wave 7: a q_skip tile, unused); zbar_3 has 7
             static_for<0, NH>([&](auto HB_) {
                 constexpr int hb = decltype(HB_)::value;
+                R8_STAMP(0);
                 r8_zero(acc);
                 if constexpr (L == 8) {     // the sdf tile of zbar_8: k-steps 16, 17 of R8, streamed
                     f32x16(&a1)[1][1] = reinterpret_cast<f32x16(&)[1][1]>(acc);
@@ -552,13 +558,16 @@ __global__ void __launch_bounds__(512, 1) sdf_bwd_r8_kernel(const unsigned char*
                                                                      lds_ + hb * HALF + 16 * (PREC == 3 ? 2 : 1) * kFragBytes, a1, lane, w);
                 }
                 r8_dense<PREC, KS, (hb == NH - 1 ? KSN : 0)>(W, lds_ + hb * HALF + lane * 16, acc, rsrc, voff, nx, blob);
+                R8_STAMP(5);
                 p2_barrier();
+                R8_STAMP(6);
                 if constexpr (hb == NH - 1) r8_request_rest<PREC, KSN>(W, rsrc, voff, nx, blob);
                 if (active) desc_post(acc, ops[hb & 1], L - 1, hb, L > 1);          // zbar_0: plane only
                 if constexpr (hb + 2 < NH) load_desc(ops[hb & 1], L - 1, hb + 2);
                 else if constexpr (L >= 2) load_desc(ops[hb & 1], L - 2, hb + 2 - NH);
                 else load_asc_at(ops[hb & 1], 0, (grp + gridDim.x) * NH + hb + 2 - NH);      // the next group's first phases (beyond the
                 R8_PHASE_SYNC();                                                             // last group: zeros, unused)
+                R8_STAMP(7);
             });
         };
         desc_step(IC(8), IC(16), IC(16));                 // (+ the sdf tile's 2 k-steps, streamed)
@@ -572,6 +581,12 @@ __global__ void __launch_bounds__(512, 1) sdf_bwd_r8_kernel(const unsigned char*
 #undef IC
         if (!FNEUS_R8_SYNC) p2_barrier();                           // the group's fragments are consumed
     }
+#ifdef FNEUS_R8_STAMPS
+    if (blockIdx.x == 0 && lane == 0 && (w == 0 || w == 4 || w == 7))
+        printf("bwd_r8 NH %d wave %d: total %llu cycles; ascending: dense %llu, barrier wait %llu, post %llu; descending: dense %llu, barrier wait %llu, "
+               "post %llu; rest (post -> next dense, qbar, seed, group edges) %llu\n", NH, w, __builtin_amdgcn_s_memtime() - stamp_t0, stamp_sum[1],
+               stamp_sum[2], stamp_sum[3], stamp_sum[5], stamp_sum[6], stamp_sum[7], stamp_sum[0]);
+#endif
 }
 
 template <int PREC, int GP, int NH>

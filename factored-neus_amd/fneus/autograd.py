@@ -87,6 +87,9 @@ class SdfValueGradFn(torch.autograd.Function):
                 d_feat.index_add_(0, sel, dfs)
             if dns is not None:
                 d_normal.index_add_(0, sel, dns)
+        heads = ws.cache.pop("surface_head_grads", None)      # (RefHeadsFn.backward: per-head gradients of the gathered rows)
+        if heads is not None:
+            ops.surface_scatter(heads[0], heads[1], heads[2], d_feat, d_normal)       # head sum + scatter-add in one launch
         bufs = ws.get(("sdf_bwd", n, prec), lambda: ops.SdfBwdBufs(n, dev, prec, gprec=ctx.stash.gprec))
         ops.sdf_bwd(net.blob, n, prec, ctx.stash, bufs, d_sdf, d_feat, d_normal, **ctx.samples.kw())
         # zeroed once: fneus_wn_backward clears what it reads, so the buffer is zero again after every step
@@ -226,6 +229,7 @@ class RefHeadsFn(torch.autograd.Function):
         diffuse, spec = ops.refcolor_fwd_both(net_cd.blob, net_vd.blob, n, prec, normal, feat, st[0], st[1], train,
                                               dirs=samples.dirs, **samples.kw())
         ctx.nets, ctx.prec, ctx.ws, ctx.st, ctx.n, ctx.samples = (net_cd, net_vd), prec, ws, st, n, samples
+        ctx.gathered = _GATHERED.get((feat.data_ptr(), normal.data_ptr()))        # inputs straight from SurfaceGatherFn?
         ctx.generation = ws.stamp(st[0]) if st[0] is not None else None
         ctx.save_for_backward(diffuse, spec, normal)
         return diffuse, spec
@@ -253,6 +257,12 @@ class RefHeadsFn(torch.autograd.Function):
             ws.get(("ref_jobs", n, prec), build).run()
             net_cd.wn_backward(g_cd)
             net_vd.wn_backward(g_vd)
+        if ctx.gathered is not None:
+            # the rows came from surface_gather: their per-head gradients go to the SDF backward as they are (one launch adds the
+            # heads and scatters the rows) instead of sum -> SurfaceGatherFn.backward -> index_add_ (four launches)
+            sdf_ws, sel = ctx.gathered
+            sdf_ws.cache["surface_head_grads"] = (sel, d_feat2, d_normal2)
+            return None, None, None, None, None, None, None, None, None
         return None, d_normal2.sum(0), d_feat2.sum(0), None, None, None, None, None, None
 
 
@@ -299,6 +309,9 @@ class CompositeFn(torch.autograd.Function):
         return d_sdf, d_normal, d_rgb, d_var.sum().reshape(ctx.var_shape), None, None, None, None, None, d_bga, d_bgc
 
 
+_GATHERED = {}       # (feat_sel pointer, normal_sel pointer) of the latest surface_gather -> (SDF workspace, sel)
+
+
 class SurfaceGatherFn(torch.autograd.Function):
     """Rows of (feature, normal, depth) at the two samples bracketing the first SDF sign change of every ray
     (renderer.py:290-293, 316-327), one launch.  Its backward hands the 2B gradient rows to the SDF network's backward
@@ -309,6 +322,10 @@ class SurfaceGatherFn(torch.autograd.Function):
         sel, t_sel, feat_sel, normal_sel = ops.surface_gather(min_idx, sdf_mask, mid_z.contiguous(), feat.contiguous(),
                                                               normal.contiguous(), warm=warm)
         ctx.sdf_ws = sdf_ws
+        # a consumer that produces per-head gradients of exactly these rows (RefHeadsFn) may hand them to the SDF backward
+        # directly (fneus_surface_scatter) instead of summing them and going through this function's backward
+        _GATHERED.clear()                    # (one slot: the consumer looks it up right behind this call, in the same step)
+        _GATHERED[(feat_sel.data_ptr(), normal_sel.data_ptr())] = (sdf_ws, sel)
         ctx.save_for_backward(sel)
         ctx.mark_non_differentiable(t_sel, sel)
         ctx.set_materialize_grads(False)         # no zero-filled cotangents for the two index outputs

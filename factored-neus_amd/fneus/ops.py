@@ -824,6 +824,16 @@ def surface_gather(min_idx, sdf_mask, mid_z, feat, normal, warm=None):
     return sel, t_sel, feat_sel, normal_sel
 
 
+def surface_scatter(sel, d_feat_heads, d_normal_heads, d_feat, d_normal):
+    """d_feat[sel] += sum over heads of d_feat_heads [H, R, 256]; d_normal[sel] += sum of d_normal_heads [H, R, 3] (in place)"""
+    H, R = (d_feat_heads if d_feat_heads is not None else d_normal_heads).shape[:2]
+    for x, nm in ((d_feat_heads, "d_feat_heads"), (d_normal_heads, "d_normal_heads"), (d_feat, "d_feat"), (d_normal, "d_normal")):
+        if x is not None:
+            _chk_f32(x, nm)
+    _launch("fneus_surface_scatter", lib.fneus_surface_scatter, _ptr(sel), _ptr(d_feat_heads), _ptr(d_normal_heads), int(H), int(R),
+            _ptr(d_feat), _ptr(d_normal), _stream())
+
+
 def stage1_norms(mask_in, sdf_mask, eik_den, mask_weight):
     """[sum mask, sum mask*sdf_mask, sum eik_den, ray count] of this batch (to be summed over the ranks)"""
     norms = torch.empty(4, dtype=torch.float32, device=mask_in.device)

@@ -242,6 +242,12 @@ int fneus_surface_gather(const int32_t* min_idx, const unsigned char* sdf_mask, 
                          int32_t* sel, float* t_sel, float* feat_sel, float* normal_sel, const FneusWarmRanges* warm /*or NULL*/,
                          fneus_stream_t stream);
 
+/* The way back of fneus_surface_gather: d_feat[sel[i]][:] += sum_h d_feat_heads[h][i][:], d_normal likewise (the gradients of the
+ * RefColor heads with respect to the gathered rows, renderer.py:316-327 through autograd's index backward).  The selected rows are
+ * distinct.  Either heads pointer may be NULL.  Replaces two sums over the heads and two index_add_ launches.                    */
+int fneus_surface_scatter(const int32_t* sel /*[R]*/, const float* d_feat_heads /*[H][R][256]*/, const float* d_normal_heads /*[H][R][3]*/,
+                          int n_heads, long n_rows, float* d_feat /*[N][256]*/, float* d_normal /*[N][3]*/, fneus_stream_t stream);
+
 /* RefColor shading (linear->sRGB, clip: fields.py:262-268, 331-335), the two-sample blend (renderer.py:336-343), the
  * training losses (exp_runner.py:141-177: colour L1, surface L1, eikonal, mask BCE) and the gradient of the total loss
  * with respect to every differentiable input, in one launch.  diffuse / spec are the outputs of fneus_refcolor_fwd

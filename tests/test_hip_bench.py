@@ -57,5 +57,5 @@ def test_bench_under_torchrun_with_two_ranks_prints_one_json_line():
     assert abs(d["value"] - 2 * 512 * 128 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     assert "four hipGraph replays" in d["config"]["launch"] or "three hipGraph replays" in d["config"]["launch"]
     assert "chosen at start-up" in d["config"]["parallelism"]
-    assert sum("[bench rank" in l and "device" in l for l in r.stderr.splitlines()) == 2          # one line per rank on stderr
-    assert sum("gradient exchange:" in l for l in r.stderr.splitlines()) >= 2                   # ... and each rank's decision
+    # one line per rank on stderr, and each rank's decision (counted in the text: two ranks write to one pipe, lines can interleave)
+    assert r.stderr.count("] device cuda:") == 2 and r.stderr.count("gradient exchange:") >= 2, r.stderr[-2000:]

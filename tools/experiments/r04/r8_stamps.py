@@ -17,3 +17,9 @@ os.environ["FNEUS_K2_P2"] = "3"
 for _ in range(3):
     ops.sdf_fwd_grad(net.blob, n, 3, st, True, pts=xx)
     torch.cuda.synchronize()
+# K3 (sdf_bwd_r8_kernel) on the same stash
+bufs = ops.SdfBwdBufs(n, dev, 3, 1)
+ds, df, dn = torch.randn(n, device=dev), torch.randn(n, 256, device=dev), torch.randn(n, 3, device=dev)
+for _ in range(3):
+    ops.sdf_bwd(net.blob, n, 3, st, bufs, ds, df, dn, pts=xx)
+    torch.cuda.synchronize()
