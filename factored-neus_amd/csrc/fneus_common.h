@@ -83,6 +83,35 @@ FN_DEV float sig_from_softplus(float h) { return 1.0f - fast_exp2(-h * (kBeta * 
 
 FN_DEV float sigmoidf_acc(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
+// sin and cos of the positional encodings' arguments (|x| <= a few hundred: 2^9 x 1.5 for PE10): three-constant Cody-Waite
+// reduction by pi / 2 and the single-precision minimax polynomials on [-pi/4, pi/4] -- max abs error 9.2e-8 over |x| <= 800
+// (float32 emulation against fp64, tests/test_host_cpu.py::test_fn_sincos_scheme), ~28 vector instructions.  libm's sincosf is
+// 136 (it carries a large-argument path), 18 calls per encoded point: 2450 instructions in the encode phase of every chain kernel,
+// run by 4 of a workgroup's 8 waves while the others wait -- 5-7 % of K1 / K2.  (Accurate: the encodings feed the 1e-4 outputs.)
+FN_DEV void fn_sincos(float x, float& s, float& c) {
+    const float q = __builtin_rintf(x * 0.63661977236758134308f);
+    float r = fmaf(q, -1.5703125f, x);
+    r = fmaf(q, -4.837512969970703125e-4f, r);
+    r = fmaf(q, -7.54978995489188216e-8f, r);
+    const float z = r * r;
+    float ps = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    ps = fmaf(ps, z, -1.6666654611e-1f);
+    ps = fmaf(ps * z, r, r);
+    float pc = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    pc = fmaf(pc, z, 4.166664568298827e-2f);
+    pc = fmaf(pc * z, z, fmaf(-0.5f, z, 1.0f));
+    const int n = (int)q;
+    const float a = (n & 1) ? pc : ps, b2 = (n & 1) ? ps : pc;          // quadrant: (s, c), (c, -s), (-s, -c), (-c, s)
+    s = (n & 2) ? -a : a;
+    c = ((n + 1) & 2) ? -b2 : b2;
+    // Results anchored call by call.  Without it hipcc SLP-packs the arithmetic of neighbouring calls (v_pk_fma_f32 with scalar
+    // register pairs as constants, op_sel_hi 0): the colour network's two-pass kernel then produced encodings that differed from
+    // run to run in its bf16 build (tools/experiments/r04/col_repro_dbg.py: every launch, ~1000 of 65 536 samples, only in the units
+    // encoded between two passes; the same source with this anchor, or with libm's sincosf, is bit-reproducible).  Cause not pinned
+    // down (the packed form reads a 64-bit scalar operand whose upper half is not the constant); the unpacked form costs nothing here.
+    asm volatile("" : "+v"(s), "+v"(c));
+}
+
 // exchange with the other lane half (lane ^ 32)
 FN_DEV float xor32(float v) { return __shfl_xor(v, 32, 64); }
 

@@ -59,7 +59,7 @@ FN_DEV void posenc3_frag(const float (&x)[3], int ks, int h, BFrag<PREC>& out) {
                 val = xc;
             } else {
                 float sn, cs;
-                sincosf(xc * (float)(1 << (g / 6)), &sn, &cs);
+                fn_sincos(xc * (float)(1 << (g / 6)), sn, cs);
                 val = ((g % 6) >= 3) ? cs : sn;
             }
         }

@@ -41,7 +41,7 @@ FN_DEV void lvis_p2_posenc3(const float (&x)[3], int ks, int h, BFrag<PREC>& out
                 val = xc;
             } else {
                 float sn, cs;
-                sincosf(xc * (float)(1 << (g / 6)), &sn, &cs);
+                fn_sincos(xc * (float)(1 << (g / 6)), sn, cs);
                 val = ((g % 6) >= 3) ? cs : sn;
             }
         }

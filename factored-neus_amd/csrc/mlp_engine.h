@@ -303,7 +303,7 @@ FN_DEV void load_f32(f32x16 (&acc)[TN], const float* __restrict__ src, int ld, l
 
 // ---------------------------------------------------------------------------------------------------------
 // Positional encoding (reference models/embedder.py:23-36): feature order [x, sin(2^0 x), cos(2^0 x), ...]
-// pe[3 + 6k + c] = sin(2^k x_c), pe[3 + 6k + 3 + c] = cos(2^k x_c).  Accurate sincosf (parity <= 1e-6).
+// pe[3 + 6k + c] = sin(2^k x_c), pe[3 + 6k + 3 + c] = cos(2^k x_c).  fn_sincos (fneus_common.h): 9.2e-8 abs (parity <= 1e-6).
 // jc[f] = d pe[f] / d x_{f's coordinate}.
 // ---------------------------------------------------------------------------------------------------------
 template <int L, bool WITH_JAC>
@@ -319,7 +319,7 @@ FN_DEV void posenc(const float (&x)[3], float (&pe)[3 + 6 * L], float (&jc)[3 + 
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float s, co;
-            sincosf(x[c] * f, &s, &co);
+            fn_sincos(x[c] * f, s, co);
             pe[3 + 6 * k + c] = s;
             pe[3 + 6 * k + 3 + c] = co;
             if constexpr (WITH_JAC) {

@@ -35,7 +35,7 @@ FN_DEV void posenc4x10(const float (&x)[4], float (&pe)[kNerfPE]) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             float s, co;
-            sincosf(x[c] * f, &s, &co);
+            fn_sincos(x[c] * f, s, co);
             pe[4 + 8 * k + c] = s;
             pe[4 + 8 * k + 4 + c] = co;
         }
@@ -275,7 +275,7 @@ FN_DEV void posenc4_frag(const float (&x)[4], int ks, int h, BFrag<PREC>& out) {
                 val = xc;
             } else {
                 float sn, cs;
-                sincosf(xc * (float)(1 << (g >> 3)), &sn, &cs);
+                fn_sincos(xc * (float)(1 << (g >> 3)), sn, cs);
                 val = (g & 4) ? cs : sn;
             }
         }

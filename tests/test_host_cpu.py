@@ -322,3 +322,37 @@ def test_shiny_frame_skip_keeps_images_and_masks_aligned(tmp_path, golden_dir):
     assert torch.equal(ds.masks, torch.from_numpy(g["disp/masks"])[::2])                          # image i <-> mask i * frame_skip
     assert (ds.images - torch.from_numpy(g["disp/images"])[::2]).abs().max().item() <= 1.2e-7
     assert ds.image_at(0, 5).shape == (int(g["H"]) // 5, int(g["W"]) // 5, 3)                     # (H // l, W // l) like cv.resize
+
+
+def test_fn_sincos_scheme():
+    """csrc/fneus_common.h fn_sincos -- the sine / cosine of the positional encodings in every chain kernel -- restated in float32
+    numpy (every fmaf as one rounding): three-constant Cody-Waite reduction by pi / 2, single-precision minimax polynomials on
+    [-pi/4, pi/4], quadrant selection.  Max abs error against fp64 over the encodings' argument range (|x| <= 2^9 x 1.5)."""
+    f32 = np.float32
+
+    def fma(a, b, c):
+        return (np.asarray(a, np.float64) * np.asarray(b, np.float64) + np.asarray(c, np.float64)).astype(f32)
+
+    def sincos(x):
+        x = x.astype(f32)
+        q = np.rint(x * f32(0.63661977236758134308)).astype(f32)
+        r = fma(q, f32(-1.5703125), x)
+        r = fma(q, f32(-4.837512969970703125e-4), r)
+        r = fma(q, f32(-7.54978995489188216e-8), r)
+        z = (r * r).astype(f32)
+        ps = fma(f32(-1.9515295891e-4), z, f32(8.3321608736e-3))
+        ps = fma(ps, z, f32(-1.6666654611e-1))
+        ps = fma((ps * z).astype(f32), r, r)
+        pc = fma(f32(2.443315711809948e-5), z, f32(-1.388731625493765e-3))
+        pc = fma(pc, z, f32(4.166664568298827e-2))
+        pc = fma((pc * z).astype(f32), z, fma(f32(-0.5), z, f32(1.0)))
+        n = q.astype(np.int64)
+        a, b = np.where(n & 1, pc, ps), np.where(n & 1, ps, pc)
+        return np.where(n & 2, -a, a), np.where((n + 1) & 2, -b, b)
+
+    rs = np.random.RandomState(0)
+    for scale in (2.0, 50.0, 800.0):
+        x = (rs.rand(400000) * 2 - 1) * scale
+        s, c = sincos(x)
+        x64 = x.astype(f32).astype(np.float64)
+        assert np.abs(s - np.sin(x64)).max() <= 1.2e-7 and np.abs(c - np.cos(x64)).max() <= 1.2e-7, scale
