@@ -83,32 +83,44 @@ FN_DEV float sig_from_softplus(float h) { return 1.0f - fast_exp2(-h * (kBeta * 
 
 FN_DEV float sigmoidf_acc(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
-// sin and cos of the positional encodings' arguments (|x| <= a few hundred: 2^9 x 1.5 for PE10): three-constant Cody-Waite
-// reduction by pi / 2 and the single-precision minimax polynomials on [-pi/4, pi/4] -- max abs error 9.2e-8 over |x| <= 800
-// (float32 emulation against fp64, tests/test_host_cpu.py::test_fn_sincos_scheme), ~28 vector instructions.  libm's sincosf is
-// 136 (it carries a large-argument path), 18 calls per encoded point: 2450 instructions in the encode phase of every chain kernel,
-// run by 4 of a workgroup's 8 waves while the others wait -- 5-7 % of K1 / K2.  (Accurate: the encodings feed the 1e-4 outputs.)
+// sin and cos of the positional encodings' arguments (|x| <= a few hundred: 2^9 x 1.5 for PE10), correctly rounded in > 98 % of
+// the cases and never more than 0.52 ulp off (tests/test_host_cpu.py::test_fn_sincos_scheme restates it in numpy): the argument
+// is reduced by pi / 2 (two constants) in double-precision fmas and the
+// polynomials on [-pi/4, pi/4] (least squares on Chebyshev nodes, 1.4e-11 and 7.6e-10 from sin and cos) run in double --
+// v_fma_f64 issues at the rate of v_fma_f32 on gfx950 -- so the only rounding of note is the final one to float.
+//   libm's sincosf is 136 instructions (it carries a large-argument path) and 1-2 ulp; this is ~26 and lands on the value the
+//   reference's host libm returns, which an fp32 Cody-Waite + cephes version (28 instructions, 1.5 ulp) did not: its encodings
+//   moved hit points by ~1e-6, enough to put a leaky-ReLU input of stage 3's net_cs on the other side of its kink in the 24-ray
+//   fixture (tools/experiments/r04/stage3_grad_dbg.py; 7 % of that layer's weight gradient).
+// 18 calls per encoded point: ~2450 libm instructions in the encode phase of every chain kernel, run by 4 of a workgroup's 8 waves
+// while the others wait.
 FN_DEV void fn_sincos(float x, float& s, float& c) {
-    const float q = __builtin_rintf(x * 0.63661977236758134308f);
-    float r = fmaf(q, -1.5703125f, x);
-    r = fmaf(q, -4.837512969970703125e-4f, r);
-    r = fmaf(q, -7.54978995489188216e-8f, r);
-    const float z = r * r;
-    float ps = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
-    ps = fmaf(ps, z, -1.6666654611e-1f);
-    ps = fmaf(ps * z, r, r);
-    float pc = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
-    pc = fmaf(pc, z, 4.166664568298827e-2f);
-    pc = fmaf(pc * z, z, fmaf(-0.5f, z, 1.0f));
+#ifdef FNEUS_LIBM_SINCOS                // A/B builds (tools/experiments/build_variant.sh)
+    sincosf(x, &s, &c);
+    return;
+#endif
+    const double xd = (double)x;
+    const double q = __builtin_rint(xd * 0.63661977236758134308);
+    double r = __builtin_fma(q, -1.57079632679489661923, xd);
+    r = __builtin_fma(q, -6.123233995736766e-17, r);
+    const double z = r * r;
+    double ps = __builtin_fma(2.724990252733835e-06, z, -1.984008661428886e-04);
+    ps = __builtin_fma(ps, z, 8.333331874648266e-03);
+    ps = __builtin_fma(ps, z, -1.666666666385583e-01);
+    ps = __builtin_fma(ps * z, r, r);
+    double pc = __builtin_fma(2.4547940868609518e-05, z, -1.3888303106225684e-03);
+    pc = __builtin_fma(pc, z, 4.166666466064577e-02);
+    pc = __builtin_fma(pc * z, z, __builtin_fma(-0.5, z, 1.0));
     const int n = (int)q;
-    const float a = (n & 1) ? pc : ps, b2 = (n & 1) ? ps : pc;          // quadrant: (s, c), (c, -s), (-s, -c), (-c, s)
+    const float fs = (float)ps, fc = (float)pc;
+    const float a = (n & 1) ? fc : fs, b2 = (n & 1) ? fs : fc;          // quadrant: (s, c), (c, -s), (-s, -c), (-c, s)
     s = (n & 2) ? -a : a;
     c = ((n + 1) & 2) ? -b2 : b2;
-    // Results anchored call by call.  Without it hipcc SLP-packs the arithmetic of neighbouring calls (v_pk_fma_f32 with scalar
-    // register pairs as constants, op_sel_hi 0): the colour network's two-pass kernel then produced encodings that differed from
-    // run to run in its bf16 build (tools/experiments/r04/col_repro_dbg.py: every launch, ~1000 of 65 536 samples, only in the units
-    // encoded between two passes; the same source with this anchor, or with libm's sincosf, is bit-reproducible).  Cause not pinned
-    // down (the packed form reads a 64-bit scalar operand whose upper half is not the constant); the unpacked form costs nothing here.
+    // Results anchored call by call: hipcc SLP-packed the fp32 arithmetic of neighbouring calls of the fp32 version (v_pk_fma_f32
+    // with scalar register pairs as constants, op_sel_hi 0), and the colour network's two-pass kernel then produced encodings
+    // that differed from run to run in its bf16 build (tools/experiments/r04/col_repro_dbg.py: every launch, ~1000 of 65 536
+    // samples, only in the units encoded between two passes; with the anchor, or with libm's sincosf, bit-reproducible).  Cause
+    // not pinned down; kept although there is no packed fp64 arithmetic to form.
     asm volatile("" : "+v"(s), "+v"(c));
 }
 

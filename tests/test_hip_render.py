@@ -135,10 +135,7 @@ def test_render_end_to_end(golden_dir, name):
     # depths: the inverse cdf is ill conditioned where the pdf is flat (tests/test_hip_rays.py separates that from bin
     # choices on the reference's own sampler trace): a handful of depths in flat bins move by 1e-3..1e-2
     dz = (out["_z_vals"].detach().cpu() - final_z(g)).abs()
-    # (one bound for every fixture: how far a depth moves inside a flat bin does not depend on the number of rays -- the 8-ray
-    # fixture has one depth that moves by 2.6e-3 with libm's sincosf in the encodings and by 4.0e-3 with fn_sincos, 1.2e-7 apart;
-    # sorted arrays: one moved depth shifts its neighbours' slots)
-    assert dz.max().item() <= 2e-2 and (dz <= 1e-4).float().mean().item() >= 0.9
+    assert dz.max().item() <= (3e-3 if int(g["B"]) <= 16 else 2e-2) and (dz <= 1e-4).float().mean().item() >= 0.9      # (sorted arrays: one moved depth shifts its neighbours' slots)
 
 
 @pytest.mark.parametrize("gprec", [3, 1], ids=["grad_hi_lo", "grad_bf16"])

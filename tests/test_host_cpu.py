@@ -325,34 +325,40 @@ def test_shiny_frame_skip_keeps_images_and_masks_aligned(tmp_path, golden_dir):
 
 
 def test_fn_sincos_scheme():
-    """csrc/fneus_common.h fn_sincos -- the sine / cosine of the positional encodings in every chain kernel -- restated in float32
-    numpy (every fmaf as one rounding): three-constant Cody-Waite reduction by pi / 2, single-precision minimax polynomials on
-    [-pi/4, pi/4], quadrant selection.  Max abs error against fp64 over the encodings' argument range (|x| <= 2^9 x 1.5)."""
-    f32 = np.float32
+    """csrc/fneus_common.h fn_sincos -- the sine / cosine of the positional encodings in every chain kernel -- restated in numpy:
+    the argument reduced by pi / 2 (two constants) with double-precision fmas, double-precision polynomials on [-pi/4, pi/4], quadrant
+    selection, one rounding to float.  Over the encodings' argument range (|x| <= 2^9 x 1.5) it is the correctly rounded float in
+    > 98 % of the cases and within 0.52 ulp everywhere (fma restated in long double: 64 mantissa bits, then rounded to double)."""
+    f32, L = np.float32, np.longdouble
 
     def fma(a, b, c):
-        return (np.asarray(a, np.float64) * np.asarray(b, np.float64) + np.asarray(c, np.float64)).astype(f32)
+        return (np.asarray(a, L) * np.asarray(b, L) + np.asarray(c, L)).astype(np.float64)
 
     def sincos(x):
-        x = x.astype(f32)
-        q = np.rint(x * f32(0.63661977236758134308)).astype(f32)
-        r = fma(q, f32(-1.5703125), x)
-        r = fma(q, f32(-4.837512969970703125e-4), r)
-        r = fma(q, f32(-7.54978995489188216e-8), r)
-        z = (r * r).astype(f32)
-        ps = fma(f32(-1.9515295891e-4), z, f32(8.3321608736e-3))
-        ps = fma(ps, z, f32(-1.6666654611e-1))
-        ps = fma((ps * z).astype(f32), r, r)
-        pc = fma(f32(2.443315711809948e-5), z, f32(-1.388731625493765e-3))
-        pc = fma(pc, z, f32(4.166664568298827e-2))
-        pc = fma((pc * z).astype(f32), z, fma(f32(-0.5), z, f32(1.0)))
+        xd = x.astype(f32).astype(np.float64)
+        q = np.rint(xd * 0.63661977236758134308)
+        r = fma(q, -1.57079632679489661923, xd)
+        r = fma(q, -6.123233995736766e-17, r)
+        z = r * r
+        ps = fma(2.724990252733835e-06, z, -1.984008661428886e-04)
+        ps = fma(ps, z, 8.333331874648266e-03)
+        ps = fma(ps, z, -1.666666666385583e-01)
+        ps = fma(ps * z, r, r)
+        pc = fma(2.4547940868609518e-05, z, -1.3888303106225684e-03)
+        pc = fma(pc, z, 4.166666466064577e-02)
+        pc = fma(pc * z, z, fma(-0.5, z, 1.0))
         n = q.astype(np.int64)
-        a, b = np.where(n & 1, pc, ps), np.where(n & 1, ps, pc)
+        fs, fc = ps.astype(f32), pc.astype(f32)
+        a, b = np.where(n & 1, fc, fs), np.where(n & 1, fs, fc)
         return np.where(n & 2, -a, a), np.where((n + 1) & 2, -b, b)
 
     rs = np.random.RandomState(0)
     for scale in (2.0, 50.0, 800.0):
         x = (rs.rand(400000) * 2 - 1) * scale
         s, c = sincos(x)
-        x64 = x.astype(f32).astype(np.float64)
-        assert np.abs(s - np.sin(x64)).max() <= 1.2e-7 and np.abs(c - np.cos(x64)).max() <= 1.2e-7, scale
+        xl = x.astype(f32).astype(L)
+        for got, want in ((s, np.sin(xl)), (c, np.cos(xl))):
+            ulp = np.spacing(np.abs(want).astype(f32)).astype(np.float64)
+            err = np.abs(got.astype(L) - want).astype(np.float64)
+            assert (err / ulp).max() <= 0.52 and err.max() <= 3.1e-8, (scale, (err / ulp).max(), err.max())
+            assert (got == want.astype(f32)).mean() >= 0.98, (scale, (got == want.astype(f32)).mean())
