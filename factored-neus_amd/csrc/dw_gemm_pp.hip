@@ -80,10 +80,21 @@ FN_DEV void wait_vm() {
 // gradients (FNEUS_DETERMINISTIC=1).  The atomics of the default mode land in arrival order.
 constexpr int kDetTile = 256 * 256 + 256;
 
+// sample tiles the products run over: all the planes hold, or -- n_samples_dev given -- those of the first *n_samples_dev
+// samples (the planes of a launch that read its sample count from device memory, fneus_nerf_bg_fwd: tiles beyond it hold
+// whatever an earlier step left there)
+FN_DEV int live_tiles(int n_tiles, const int32_t* __restrict__ n_samples_dev) {
+    if (n_samples_dev == nullptr) return n_tiles;
+    const int t = (__builtin_amdgcn_readfirstlane(*n_samples_dev) + 31) >> 5;
+    return t < n_tiles ? (t > 0 ? t : 0) : n_tiles;
+}
+
 template <int GP, bool DET = false>
 __global__ void __launch_bounds__(256, 1) dw_gemm_pp_kernel(const GemmPPJob* __restrict__ jobs, int n_jobs, int n_tiles,
-                                                            float* __restrict__ scratch = nullptr) {
+                                                            float* __restrict__ scratch = nullptr,
+                                                            const int32_t* __restrict__ n_samples_dev = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    n_tiles = live_tiles(n_tiles, n_samples_dev);
     using Cfg = PPCfg<GP>;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -336,7 +347,10 @@ __global__ void __launch_bounds__(256, 1) dw_gemm_pp_kernel(const GemmPPJob* __r
 
 // C[row][col] += scale * (partials of the product's workgroups in split order); bias[row] += the same of the bias partials
 __global__ void __launch_bounds__(256) dw_gemm_pp_reduce_kernel(const GemmPPJob* __restrict__ jobs, int n_tiles,
-                                                                const float* __restrict__ scratch) {
+                                                                const float* __restrict__ scratch,
+                                                                const int32_t* __restrict__ n_samples_dev) {
+    n_tiles = live_tiles(n_tiles, n_samples_dev);
+    if (n_tiles <= 0) return;
     const GemmPPJob* __restrict__ jp = jobs + blockIdx.y;
     const int m = jp->m, n = jp->n, splits = jp->splits, base = jp->wg_base;
     const int per = (n_tiles + splits - 1) / splits;
@@ -357,8 +371,8 @@ __global__ void __launch_bounds__(256) dw_gemm_pp_reduce_kernel(const GemmPPJob*
 
 using namespace fneus;
 
-extern "C" int fneus_dw_gemm_pp_det(const void* jobs_dev, int n_jobs, int n_wgs, long n_sample_tiles, int gprec, float* scratch,
-                                    long scratch_floats, fneus_stream_t stream_) {
+extern "C" int fneus_dw_gemm_pp_det(const void* jobs_dev, int n_jobs, int n_wgs, long n_sample_tiles, const int32_t* n_samples_dev,
+                                    int gprec, float* scratch, long scratch_floats, fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     fneus::clear_status();
     if (n_jobs <= 0 || n_wgs <= 0 || n_sample_tiles <= 0) return 0;
@@ -374,17 +388,17 @@ extern "C" int fneus_dw_gemm_pp_det(const void* jobs_dev, int n_jobs, int n_wgs,
         attr_set = true;
     }
     if (gprec == 1)
-        hipLaunchKernelGGL((dw_gemm_pp_kernel<1, true>), dim3(n_wgs), dim3(256), PPCfg<1>::kLds, stream, jobs, n_jobs, (int)n_sample_tiles, scratch);
+        hipLaunchKernelGGL((dw_gemm_pp_kernel<1, true>), dim3(n_wgs), dim3(256), PPCfg<1>::kLds, stream, jobs, n_jobs, (int)n_sample_tiles, scratch, n_samples_dev);
     else if (gprec == 3)
-        hipLaunchKernelGGL((dw_gemm_pp_kernel<3, true>), dim3(n_wgs), dim3(256), PPCfg<3>::kLds, stream, jobs, n_jobs, (int)n_sample_tiles, scratch);
+        hipLaunchKernelGGL((dw_gemm_pp_kernel<3, true>), dim3(n_wgs), dim3(256), PPCfg<3>::kLds, stream, jobs, n_jobs, (int)n_sample_tiles, scratch, n_samples_dev);
     else
         return -2;
-    hipLaunchKernelGGL(dw_gemm_pp_reduce_kernel, dim3(64, n_jobs), dim3(256), 0, stream, jobs, (int)n_sample_tiles, scratch);
+    hipLaunchKernelGGL(dw_gemm_pp_reduce_kernel, dim3(64, n_jobs), dim3(256), 0, stream, jobs, (int)n_sample_tiles, scratch, n_samples_dev);
     return fneus::launch_status();
 }
 
-extern "C" int fneus_dw_gemm_pp(const void* jobs_dev, int n_jobs, int n_wgs, long n_sample_tiles, int gprec,
-                                fneus_stream_t stream_) {
+extern "C" int fneus_dw_gemm_pp(const void* jobs_dev, int n_jobs, int n_wgs, long n_sample_tiles, const int32_t* n_samples_dev,
+                                int gprec, fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     fneus::clear_status();
     if (n_jobs <= 0 || n_wgs <= 0 || n_sample_tiles <= 0) return 0;
@@ -396,9 +410,9 @@ extern "C" int fneus_dw_gemm_pp(const void* jobs_dev, int n_jobs, int n_wgs, lon
         attr_set = true;
     }
     if (gprec == 1)
-        hipLaunchKernelGGL((dw_gemm_pp_kernel<1, false>), dim3(n_wgs), dim3(256), PPCfg<1>::kLds, stream, jobs, n_jobs, (int)n_sample_tiles, (float*)nullptr);
+        hipLaunchKernelGGL((dw_gemm_pp_kernel<1, false>), dim3(n_wgs), dim3(256), PPCfg<1>::kLds, stream, jobs, n_jobs, (int)n_sample_tiles, (float*)nullptr, n_samples_dev);
     else if (gprec == 3)
-        hipLaunchKernelGGL((dw_gemm_pp_kernel<3, false>), dim3(n_wgs), dim3(256), PPCfg<3>::kLds, stream, jobs, n_jobs, (int)n_sample_tiles, (float*)nullptr);
+        hipLaunchKernelGGL((dw_gemm_pp_kernel<3, false>), dim3(n_wgs), dim3(256), PPCfg<3>::kLds, stream, jobs, n_jobs, (int)n_sample_tiles, (float*)nullptr, n_samples_dev);
     else
         return -2;
     return fneus::launch_status();

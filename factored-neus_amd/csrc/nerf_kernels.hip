@@ -66,14 +66,24 @@ FN_DEV void apply_mask(f32x16 (&acc)[TN], const u32x4 m, bool valid) {
         }
 }
 
+// how many of the launch's Ncap samples are live: all of them, or the length of the list fneus_outside_select made (device memory,
+// so a step that lists a different number of samples every time keeps its launch shapes).  The planes keep the strides of Ncap.
+FN_DEV long nerf_count(long Ncap, const int32_t* __restrict__ n_dev) {
+    if (n_dev == nullptr) return Ncap;
+    const long v = __builtin_amdgcn_readfirstlane(*n_dev);
+    return v < Ncap ? (v > 0 ? v : 0) : Ncap;
+}
+
 template <int PREC, bool TRAIN>
 __global__ void __launch_bounds__(64, 1) nerf_fwd_kernel(const unsigned char* blob, const float* __restrict__ pts4,
-                                                         const float* __restrict__ dirs, long N, NerfStash st,
-                                                         float* __restrict__ density, float* __restrict__ rgb) {
+                                                         const float* __restrict__ dirs, long Ncap, NerfStash st,
+                                                         float* __restrict__ density, float* __restrict__ rgb,
+        const int32_t* __restrict__ n_dev) {
+    const long N = nerf_count(Ncap, n_dev);
     const int lane = threadIdx.x;
     const int r = lane & 31, h = lane >> 5;
     const PPLane pl = pp_lane(lane);
-    const long tiles = pp_tiles(N);
+    const long tiles = pp_tiles(Ncap);
     constexpr auto& LY = kNerfLayout;
     for (long tile = blockIdx.x; tile * 32 < N; tile += gridDim.x) {
         asm volatile("" : "+s"(blob));
@@ -170,12 +180,14 @@ __global__ void __launch_bounds__(64, 1) nerf_fwd_kernel(const unsigned char* bl
 }
 
 template <int PREC>
-__global__ void __launch_bounds__(64, 1) nerf_bwd_kernel(const unsigned char* blob, long N, const float* __restrict__ d_density,
-                                                         const float* __restrict__ d_rgb, NerfStash st) {
+__global__ void __launch_bounds__(64, 1) nerf_bwd_kernel(const unsigned char* blob, long Ncap, const float* __restrict__ d_density,
+                                                         const float* __restrict__ d_rgb, NerfStash st,
+        const int32_t* __restrict__ n_dev) {
+    const long N = nerf_count(Ncap, n_dev);
     const int lane = threadIdx.x;
     const int r = lane & 31, h = lane >> 5;
     const PPLane pl = pp_lane(lane);
-    const long tiles = pp_tiles(N);
+    const long tiles = pp_tiles(Ncap);
     constexpr auto& LY = kNerfLayout;
     for (long tile = blockIdx.x; tile * 32 < N; tile += gridDim.x) {
         asm volatile("" : "+s"(blob));
@@ -328,8 +340,10 @@ FN_DEV void apply_bits(f32x16 (&acc)[TN], uint32_t m, bool valid) {
 
 template <int PREC, bool TRAIN>
 __global__ void __launch_bounds__(256, FNEUS_NERF_OCC) nerf_fwd_tp_kernel(const unsigned char* blob, const float* __restrict__ pts4,
-                                                             const float* __restrict__ dirs, long N, NerfStash st,
-                                                             float* __restrict__ density, float* __restrict__ rgb) {
+                                                             const float* __restrict__ dirs, long Ncap, NerfStash st,
+                                                             float* __restrict__ density, float* __restrict__ rgb,
+        const int32_t* __restrict__ n_dev) {
+    const long N = nerf_count(Ncap, n_dev);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
     unsigned char* frag = lds_;
     unsigned char* park = frag_at<PREC>(frag, kNerfPark);
@@ -338,7 +352,7 @@ __global__ void __launch_bounds__(256, FNEUS_NERF_OCC) nerf_fwd_tp_kernel(const 
     const int r = lane & 31, h = lane >> 5;
     const int t0 = 2 * wave;
     const PPLane pl = pp_lane(lane);
-    const long tiles = pp_tiles(N);
+    const long tiles = pp_tiles(Ncap);
     const bool lo_planes = TRAIN && PREC == 3 && st.h_lo != nullptr;
     constexpr auto& LY = kNerfLayout;
     for (long tile = blockIdx.x; tile * 32 < N; tile += gridDim.x) {
@@ -438,8 +452,10 @@ __global__ void __launch_bounds__(256, FNEUS_NERF_OCC) nerf_fwd_tp_kernel(const 
 }
 
 template <int PREC>
-__global__ void __launch_bounds__(256, FNEUS_NERF_OCC) nerf_bwd_tp_kernel(const unsigned char* blob, long N, const float* __restrict__ d_density,
-                                                             const float* __restrict__ d_rgb, NerfStash st) {
+__global__ void __launch_bounds__(256, FNEUS_NERF_OCC) nerf_bwd_tp_kernel(const unsigned char* blob, long Ncap, const float* __restrict__ d_density,
+                                                             const float* __restrict__ d_rgb, NerfStash st,
+        const int32_t* __restrict__ n_dev) {
+    const long N = nerf_count(Ncap, n_dev);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
     unsigned char* frag = lds_;
     const int lane = threadIdx.x & 63;
@@ -447,7 +463,7 @@ __global__ void __launch_bounds__(256, FNEUS_NERF_OCC) nerf_bwd_tp_kernel(const 
     const int r = lane & 31, h = lane >> 5;
     const int t0 = 2 * wave;
     const PPLane pl = pp_lane(lane);
-    const long tiles = pp_tiles(N);
+    const long tiles = pp_tiles(Ncap);
     const bool lo_planes = PREC == 3 && st.zbar_lo != nullptr;
     constexpr auto& LY = kNerfLayout;
     for (long tile = blockIdx.x; tile * 32 < N; tile += gridDim.x) {
@@ -523,8 +539,10 @@ constexpr int kNerfHalf = 18 * 2 * kFragBytes;
 
 template <int PREC, bool TRAIN>
 __global__ void __launch_bounds__(256, 2) nerf_fwd_tph_kernel(const unsigned char* blob, const float* __restrict__ pts4,
-                                                              const float* __restrict__ dirs, long N, NerfStash st,
-                                                              float* __restrict__ density, float* __restrict__ rgb) {
+                                                              const float* __restrict__ dirs, long Ncap, NerfStash st,
+                                                              float* __restrict__ density, float* __restrict__ rgb,
+        const int32_t* __restrict__ n_dev) {
+    const long N = nerf_count(Ncap, n_dev);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
     unsigned char* frag = lds_;
     constexpr int HB = 2, HALF = kNerfHalf;
@@ -533,7 +551,7 @@ __global__ void __launch_bounds__(256, 2) nerf_fwd_tph_kernel(const unsigned cha
     const int r = lane & 31, h = lane >> 5;
     const int t0 = 2 * wave;
     const PPLane pl = pp_lane(lane);
-    const long tiles = pp_tiles(N);
+    const long tiles = pp_tiles(Ncap);
     const long groups = (N + 32 * HB - 1) / (32 * HB);
     const bool lo_planes = TRAIN && PREC == 3 && st.h_lo != nullptr;
     constexpr auto& LY = kNerfLayout;
@@ -676,8 +694,10 @@ __global__ void __launch_bounds__(256, 2) nerf_fwd_tph_kernel(const unsigned cha
 }
 
 template <int PREC>
-__global__ void __launch_bounds__(256, 2) nerf_bwd_tph_kernel(const unsigned char* blob, long N, const float* __restrict__ d_density,
-                                                              const float* __restrict__ d_rgb, NerfStash st) {
+__global__ void __launch_bounds__(256, 2) nerf_bwd_tph_kernel(const unsigned char* blob, long Ncap, const float* __restrict__ d_density,
+                                                              const float* __restrict__ d_rgb, NerfStash st,
+        const int32_t* __restrict__ n_dev) {
+    const long N = nerf_count(Ncap, n_dev);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
     unsigned char* frag = lds_;
     constexpr int HB = 2, HALF = kNerfHalf;
@@ -686,7 +706,7 @@ __global__ void __launch_bounds__(256, 2) nerf_bwd_tph_kernel(const unsigned cha
     const int r = lane & 31, h = lane >> 5;
     const int t0 = 2 * wave;
     const PPLane pl = pp_lane(lane);
-    const long tiles = pp_tiles(N);
+    const long tiles = pp_tiles(Ncap);
     const long groups = (N + 32 * HB - 1) / (32 * HB);
     const bool lo_planes = PREC == 3 && st.zbar_lo != nullptr;
     constexpr auto& LY = kNerfLayout;
@@ -823,7 +843,7 @@ static inline int nerf_grid(long n_tiles) {
 
 extern "C" int fneus_nerf_bg_fwd(const void* blob, const float* pts4, const float* dirs, long n_pts,
                                  const FneusNerfStash* stash, float* density, float* rgb, int prec, int train,
-                                 fneus_stream_t stream_) {
+                                 const int32_t* n_dev, fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     fneus::clear_status();
     if (n_pts <= 0) return 0;
@@ -841,10 +861,10 @@ extern "C" int fneus_nerf_bg_fwd(const void* blob, const float* pts4, const floa
             if (!done) { fneus::allow_big_lds(KERNEL); done = true; }                                    \
             hipLaunchKernelGGL((KERNEL), g2, b2, 2 * fneus::kNerfHalf, stream, __VA_ARGS__);              \
         } while (0)
-        if (prec == 3 && train) FNEUS_NERF_TPH((nerf_fwd_tph_kernel<3, true>), b, pts4, dirs, n_pts, st, density, rgb);
-        else if (prec == 3) FNEUS_NERF_TPH((nerf_fwd_tph_kernel<3, false>), b, pts4, dirs, n_pts, st, density, rgb);
-        else if (prec == 1 && train) FNEUS_NERF_TPH((nerf_fwd_tph_kernel<1, true>), b, pts4, dirs, n_pts, st, density, rgb);
-        else if (prec == 1) FNEUS_NERF_TPH((nerf_fwd_tph_kernel<1, false>), b, pts4, dirs, n_pts, st, density, rgb);
+        if (prec == 3 && train) FNEUS_NERF_TPH((nerf_fwd_tph_kernel<3, true>), b, pts4, dirs, n_pts, st, density, rgb, n_dev);
+        else if (prec == 3) FNEUS_NERF_TPH((nerf_fwd_tph_kernel<3, false>), b, pts4, dirs, n_pts, st, density, rgb, n_dev);
+        else if (prec == 1 && train) FNEUS_NERF_TPH((nerf_fwd_tph_kernel<1, true>), b, pts4, dirs, n_pts, st, density, rgb, n_dev);
+        else if (prec == 1) FNEUS_NERF_TPH((nerf_fwd_tph_kernel<1, false>), b, pts4, dirs, n_pts, st, density, rgb, n_dev);
         else return -2;
         return fneus::launch_status();
     }
@@ -857,29 +877,29 @@ extern "C" int fneus_nerf_bg_fwd(const void* blob, const float* pts4, const floa
             if (!done) { fneus::allow_big_lds(KERNEL); done = true; }                                    \
             hipLaunchKernelGGL((KERNEL), g2, b2, fneus::kNerfTpLds, stream, __VA_ARGS__);                 \
         } while (0)
-        if (prec == 3 && train) FNEUS_NERF_TP((nerf_fwd_tp_kernel<3, true>), b, pts4, dirs, n_pts, st, density, rgb);
-        else if (prec == 3) FNEUS_NERF_TP((nerf_fwd_tp_kernel<3, false>), b, pts4, dirs, n_pts, st, density, rgb);
-        else if (prec == 1 && train) FNEUS_NERF_TP((nerf_fwd_tp_kernel<1, true>), b, pts4, dirs, n_pts, st, density, rgb);
-        else if (prec == 1) FNEUS_NERF_TP((nerf_fwd_tp_kernel<1, false>), b, pts4, dirs, n_pts, st, density, rgb);
+        if (prec == 3 && train) FNEUS_NERF_TP((nerf_fwd_tp_kernel<3, true>), b, pts4, dirs, n_pts, st, density, rgb, n_dev);
+        else if (prec == 3) FNEUS_NERF_TP((nerf_fwd_tp_kernel<3, false>), b, pts4, dirs, n_pts, st, density, rgb, n_dev);
+        else if (prec == 1 && train) FNEUS_NERF_TP((nerf_fwd_tp_kernel<1, true>), b, pts4, dirs, n_pts, st, density, rgb, n_dev);
+        else if (prec == 1) FNEUS_NERF_TP((nerf_fwd_tp_kernel<1, false>), b, pts4, dirs, n_pts, st, density, rgb, n_dev);
         else return -2;
         return fneus::launch_status();
     }
     dim3 grid(nerf_grid((n_pts + 31) / 32)), blk(64);
     if (prec == 3 && train)
-        hipLaunchKernelGGL((nerf_fwd_kernel<3, true>), grid, blk, 0, stream, b, pts4, dirs, n_pts, st, density, rgb);
+        hipLaunchKernelGGL((nerf_fwd_kernel<3, true>), grid, blk, 0, stream, b, pts4, dirs, n_pts, st, density, rgb, n_dev);
     else if (prec == 3)
-        hipLaunchKernelGGL((nerf_fwd_kernel<3, false>), grid, blk, 0, stream, b, pts4, dirs, n_pts, st, density, rgb);
+        hipLaunchKernelGGL((nerf_fwd_kernel<3, false>), grid, blk, 0, stream, b, pts4, dirs, n_pts, st, density, rgb, n_dev);
     else if (prec == 1 && train)
-        hipLaunchKernelGGL((nerf_fwd_kernel<1, true>), grid, blk, 0, stream, b, pts4, dirs, n_pts, st, density, rgb);
+        hipLaunchKernelGGL((nerf_fwd_kernel<1, true>), grid, blk, 0, stream, b, pts4, dirs, n_pts, st, density, rgb, n_dev);
     else if (prec == 1)
-        hipLaunchKernelGGL((nerf_fwd_kernel<1, false>), grid, blk, 0, stream, b, pts4, dirs, n_pts, st, density, rgb);
+        hipLaunchKernelGGL((nerf_fwd_kernel<1, false>), grid, blk, 0, stream, b, pts4, dirs, n_pts, st, density, rgb, n_dev);
     else
         return -2;
     return fneus::launch_status();
 }
 
 extern "C" int fneus_nerf_bg_bwd(const void* blob, long n_pts, const float* d_density, const float* d_rgb,
-                                 const FneusNerfStash* stash, int prec, fneus_stream_t stream_) {
+                                 const FneusNerfStash* stash, int prec, const int32_t* n_dev, fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     fneus::clear_status();
     if (n_pts <= 0) return 0;
@@ -890,24 +910,24 @@ extern "C" int fneus_nerf_bg_bwd(const void* blob, long n_pts, const float* d_de
     if (nerf_use_hb2((n_pts + 31) / 32)) {
         const long ng = (n_pts + 63) / 64;
         dim3 g2((unsigned)(ng < 2048 ? ng : 2048)), b2(256);
-        if (prec == 3) FNEUS_NERF_TPH(nerf_bwd_tph_kernel<3>, b, n_pts, d_density, d_rgb, st);
-        else if (prec == 1) FNEUS_NERF_TPH(nerf_bwd_tph_kernel<1>, b, n_pts, d_density, d_rgb, st);
+        if (prec == 3) FNEUS_NERF_TPH(nerf_bwd_tph_kernel<3>, b, n_pts, d_density, d_rgb, st, n_dev);
+        else if (prec == 1) FNEUS_NERF_TPH(nerf_bwd_tph_kernel<1>, b, n_pts, d_density, d_rgb, st, n_dev);
         else return -2;
         return fneus::launch_status();
     }
     if (nerf_use_tp()) {
         const long nt = (n_pts + 31) / 32;
         dim3 g2((unsigned)(nt < 2048 ? nt : 2048)), b2(256);
-        if (prec == 3) FNEUS_NERF_TP(nerf_bwd_tp_kernel<3>, b, n_pts, d_density, d_rgb, st);
-        else if (prec == 1) FNEUS_NERF_TP(nerf_bwd_tp_kernel<1>, b, n_pts, d_density, d_rgb, st);
+        if (prec == 3) FNEUS_NERF_TP(nerf_bwd_tp_kernel<3>, b, n_pts, d_density, d_rgb, st, n_dev);
+        else if (prec == 1) FNEUS_NERF_TP(nerf_bwd_tp_kernel<1>, b, n_pts, d_density, d_rgb, st, n_dev);
         else return -2;
         return fneus::launch_status();
     }
     dim3 grid(nerf_grid((n_pts + 31) / 32)), blk(64);
     if (prec == 3)
-        hipLaunchKernelGGL(nerf_bwd_kernel<3>, grid, blk, 0, stream, b, n_pts, d_density, d_rgb, st);
+        hipLaunchKernelGGL(nerf_bwd_kernel<3>, grid, blk, 0, stream, b, n_pts, d_density, d_rgb, st, n_dev);
     else if (prec == 1)
-        hipLaunchKernelGGL(nerf_bwd_kernel<1>, grid, blk, 0, stream, b, n_pts, d_density, d_rgb, st);
+        hipLaunchKernelGGL(nerf_bwd_kernel<1>, grid, blk, 0, stream, b, n_pts, d_density, d_rgb, st, n_dev);
     else
         return -2;
     return fneus::launch_status();

@@ -760,13 +760,14 @@ __global__ void __launch_bounds__(256) gen_rays_grid_kernel(const float* __restr
 // womask background branch, render_core_outside (renderer.py:112-149): the element-wise work around the NeRF++ kernels (K7)
 // ---------------------------------------------------------------------------------------------------------------
 // sections of the merged depths, inverted-sphere points (p / |p|, 1 / |p|) with |p| clipped to [1, 1e10], view directions
-__global__ void __launch_bounds__(256) outside_points_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
-                                                             const float* __restrict__ z, int n_rays, int nt, float sample_dist,
-                                                             float* __restrict__ pts4, float* __restrict__ dirs,
-                                                             float* __restrict__ dists) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)n_rays * nt) return;
-    const int ray = (int)(idx / nt), i = (int)(idx - (long)ray * nt);
+FN_DEV float softplus1(float x) { return x > 20.0f ? x : log1pf(expf(x)); }              // F.softplus defaults (beta 1, threshold 20)
+
+// sample i of a ray's merged depths z [n_rays][nt] -> its section length, the inverted-sphere point (p / |p|, 1 / |p|) of the
+// section's mid point with |p| clipped to [1, 1e10], and the ray direction
+FN_DEV void outside_point(const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ z, int ray,
+                          int i, int nt, float sample_dist, float* __restrict__ p4, float* __restrict__ dir3,
+                          float* __restrict__ dist_out) {
+    const long idx = (long)ray * nt + i;
     const float z0 = z[idx];
     const float dist = i + 1 < nt ? __fadd_rn(z[idx + 1], -z0) : sample_dist;          // :121-122
     const float mid = __fadd_rn(z0, __fmul_rn(dist, 0.5f));                              // :123
@@ -775,16 +776,136 @@ __global__ void __launch_bounds__(256) outside_points_kernel(const float* __rest
     for (int c = 0; c < 3; ++c) {
         p[c] = __fadd_rn(rays_o[ray * 3 + c], __fmul_rn(rays_d[ray * 3 + c], mid));      // :126
         s = __fadd_rn(s, __fmul_rn(p[c], p[c]));
-        dirs[idx * 3 + c] = rays_d[ray * 3 + c];
+        dir3[c] = rays_d[ray * 3 + c];
     }
     const float dis = fminf(fmaxf(sqrtf(s), 1.0f), 1e10f);                               // :128
 #pragma unroll
-    for (int c = 0; c < 3; ++c) pts4[idx * 4 + c] = __fdiv_rn(p[c], dis);                // :129
-    pts4[idx * 4 + 3] = __fdiv_rn(1.0f, dis);
-    dists[idx] = dist;
+    for (int c = 0; c < 3; ++c) p4[c] = __fdiv_rn(p[c], dis);                            // :129
+    p4[3] = __fdiv_rn(1.0f, dis);
+    *dist_out = dist;
 }
 
-FN_DEV float softplus1(float x) { return x > 20.0f ? x : log1pf(expf(x)); }              // F.softplus defaults (beta 1, threshold 20)
+__global__ void __launch_bounds__(256) outside_points_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                             const float* __restrict__ z, int n_rays, int nt, float sample_dist,
+                                                             float* __restrict__ pts4, float* __restrict__ dirs,
+                                                             float* __restrict__ dists) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)n_rays * nt) return;
+    const int ray = (int)(idx / nt), i = (int)(idx - (long)ray * nt);
+    outside_point(rays_o, rays_d, z, ray, i, nt, sample_dist, pts4 + idx * 4, dirs + idx * 3, dists + idx);
+}
+
+// ---- the background network only where its output is used --------------------------------------------------------------------
+// render() evaluates the NeRF at all n + n_out merged depths of a ray (renderer.py:452-458) and render_core blends sample i < n
+// as alpha_i inside_i + bg_alpha_i (1 - inside_i), colour likewise (renderer.py:350-356): with inside_i = 1 the background value
+// is multiplied by exactly 0, forward and backward.  The depths between near and far lie inside the unit sphere for most of a
+// ray (the importance samples nearly always), so ~3/4 of the evaluations are of that kind.  fneus_outside_select lists the
+// samples whose background value IS used -- i >= n, or |o + d mid_i| >= 1 for the core's own section mid point (the expression
+// of section_values, pt_norm: round-to-nearest operations only, so both kernels see the same number; kSelectMargin keeps a
+// band below 1 in the list all the same) -- in ray-major order, and the NeRF kernels, the alpha kernels and the weight-gradient
+// GEMM run over that list, its length read from device memory (no host synchronisation, fixed launch shapes).
+constexpr float kSelectMargin = 1e-5f;
+
+// pass 1, one workgroup of 256 threads per ray (nt <= 256): rank[ray][i] = position of sample i among the ray's listed samples
+// or -1, cnt[ray] = how many; the unlisted samples' alpha / colour (what the compositing reads for them) are written as zeros
+__global__ void __launch_bounds__(256) outside_flags_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                            const float* __restrict__ z_core, int n, int nt, float sample_dist,
+                                                            int32_t* __restrict__ cnt, int32_t* __restrict__ rank,
+                                                            float* __restrict__ alpha_full, float* __restrict__ rgb_full) {
+    __shared__ int wsum[4];
+    const int ray = blockIdx.x, i = threadIdx.x, lane = i & 63, wave = i >> 6;
+    bool used = false;
+    if (i < nt) {
+        used = true;
+        if (i < n) {
+            const float z0 = z_core[(long)ray * n + i];
+            const float dd = (i + 1 < n) ? z_core[(long)ray * n + i + 1] - z0 : sample_dist;      // sections_kernel
+            used = !(pt_norm(rays_o + ray * 3, rays_d + ray * 3, z0 + dd * 0.5f) < 1.0f - kSelectMargin);
+        }
+    }
+    const unsigned long long m = __ballot(used);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(m);
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    if (i < nt) {
+        const long idx = (long)ray * nt + i;
+        rank[idx] = used ? base + before : -1;
+        if (!used) {
+            alpha_full[idx] = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) rgb_full[idx * 3 + c] = 0.0f;
+        }
+    }
+    if (i == 0) cnt[ray] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// pass 2, one workgroup per ray: the ray's first list position = sum of the counts of the rays before it; the listed samples'
+// inverted-sphere points, directions, section lengths and sample indices go to their list positions
+__global__ void __launch_bounds__(256) outside_compact_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                              const float* __restrict__ z_feed, int n_rays, int nt,
+                                                              float sample_dist, const int32_t* __restrict__ cnt,
+                                                              const int32_t* __restrict__ rank, float* __restrict__ pts4,
+                                                              float* __restrict__ dirs, float* __restrict__ dists,
+                                                              int32_t* __restrict__ sel, int32_t* __restrict__ count) {
+    __shared__ int wsum[4];
+    const int ray = blockIdx.x, i = threadIdx.x, lane = i & 63, wave = i >> 6;
+    int part = 0;
+    for (int b = i; b < ray; b += 256) part += cnt[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    if (lane == 0) wsum[wave] = part;
+    __syncthreads();
+    const int first = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (ray == n_rays - 1 && i == 0) *count = first + cnt[ray];
+    if (i >= nt) return;
+    const long idx = (long)ray * nt + i;
+    const int rk = rank[idx];
+    if (rk < 0) return;
+    const long k = (long)first + rk;
+    sel[k] = (int32_t)idx;
+    outside_point(rays_o, rays_d, z_feed, ray, i, nt, sample_dist, pts4 + k * 4, dirs + k * 3, dists + k);
+}
+
+// fneus_outside_alpha_fwd / _bwd over the list: entry k < *count is sample sel[k] of the [B][nt] arrays
+__global__ void __launch_bounds__(256) outside_alpha_sel_fwd_kernel(const float* __restrict__ density, const float* __restrict__ raw,
+                                                                    const float* __restrict__ dists, const int32_t* __restrict__ sel,
+                                                                    const int32_t* __restrict__ count, float* __restrict__ alpha_full,
+                                                                    float* __restrict__ rgb_full) {
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= *count) return;
+    const long idx = sel[k];
+    alpha_full[idx] = 1.0f - expf(-softplus1(density[k]) * dists[k]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rgb_full[idx * 3 + c] = 1.0f / (1.0f + expf(-raw[k * 3 + c]));
+}
+
+__global__ void __launch_bounds__(256) outside_alpha_sel_bwd_kernel(const float* __restrict__ density, const float* __restrict__ rgb_full,
+                                                                    const float* __restrict__ dists, const int32_t* __restrict__ sel,
+                                                                    const int32_t* __restrict__ count,
+                                                                    const float* __restrict__ d_alpha_full,
+                                                                    const float* __restrict__ d_rgb_full, long cap,
+                                                                    float* __restrict__ d_density, float* __restrict__ d_raw) {
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= cap) return;
+    if (k >= *count) {                                   // (never read by the backward kernels; defined all the same)
+        d_density[k] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) d_raw[k * 3 + c] = 0.0f;
+        return;
+    }
+    const long idx = sel[k];
+    const float x = density[k], dist = dists[k];
+    const float dsp = x > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-x));                       // softplus'
+    d_density[k] = d_alpha_full ? d_alpha_full[idx] * dist * expf(-softplus1(x) * dist) * dsp : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float y = rgb_full[idx * 3 + c];
+        d_raw[k * 3 + c] = d_rgb_full ? d_rgb_full[idx * 3 + c] * y * (1.0f - y) : 0.0f;
+    }
+}
+
 
 // alpha = 1 - exp(-softplus(density) * dist), colour = sigmoid(raw)                      (renderer.py:137-138)
 __global__ void __launch_bounds__(256) outside_alpha_fwd_kernel(const float* __restrict__ density, const float* __restrict__ raw,
@@ -1066,6 +1187,48 @@ extern "C" int fneus_outside_points(const float* rays_o, const float* rays_d, co
     if (total <= 0) return 0;
     hipLaunchKernelGGL(outside_points_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, rays_o, rays_d, z, n_rays, nt,
                        sample_dist, pts4, dirs, dists);
+    return fneus::launch_status();
+}
+
+extern "C" int fneus_outside_select(const float* rays_o, const float* rays_d, const float* z_core, const float* z_feed, int n_rays,
+                                    int n, int nt, float sample_dist, int32_t* work, float* pts4, float* dirs, float* dists,
+                                    int32_t* sel, int32_t* count, float* alpha_full, float* rgb_full, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (n_rays <= 0) return 0;
+    if (nt > 256 || n < 0 || n > nt || !rays_o || !rays_d || !z_core || !z_feed || !work || !pts4 || !dirs || !dists || !sel || !count ||
+        !alpha_full || !rgb_full) {
+        fneus::set_last_error("fneus_outside_select: needs n <= nt <= 256 and every buffer");
+        return -2;
+    }
+    int32_t* cnt = work;
+    int32_t* rank = work + n_rays;
+    hipLaunchKernelGGL(outside_flags_kernel, dim3(n_rays), dim3(256), 0, stream, rays_o, rays_d, z_core, n, nt, sample_dist, cnt, rank,
+                       alpha_full, rgb_full);
+    hipLaunchKernelGGL(outside_compact_kernel, dim3(n_rays), dim3(256), 0, stream, rays_o, rays_d, z_feed, n_rays, nt, sample_dist, cnt,
+                       rank, pts4, dirs, dists, sel, count);
+    return fneus::launch_status();
+}
+
+extern "C" int fneus_outside_alpha_sel_fwd(const float* density, const float* rgb_raw, const float* dists, const int32_t* sel,
+                                           const int32_t* count, long cap, float* alpha_full, float* rgb_full,
+                                           fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (cap <= 0) return 0;
+    hipLaunchKernelGGL(outside_alpha_sel_fwd_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, stream, density, rgb_raw, dists,
+                       sel, count, alpha_full, rgb_full);
+    return fneus::launch_status();
+}
+
+extern "C" int fneus_outside_alpha_sel_bwd(const float* density, const float* rgb_full, const float* dists, const int32_t* sel,
+                                           const int32_t* count, long cap, const float* d_alpha_full, const float* d_rgb_full,
+                                           float* d_density, float* d_rgb_raw, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (cap <= 0) return 0;
+    hipLaunchKernelGGL(outside_alpha_sel_bwd_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, stream, density, rgb_full, dists,
+                       sel, count, d_alpha_full, d_rgb_full, cap, d_density, d_rgb_raw);
     return fneus::launch_status();
 }
 

@@ -93,10 +93,10 @@ def _load():
                                               C.POINTER(FneusColStash), vp, vp, ip, ip, vp]),
         "fneus_refcolor_bwd_both": (C.c_int, [vp, vp, l, vp, ip, vp, vp, vp, vp, vp, vp, C.POINTER(FneusColStash),
                                               C.POINTER(FneusColStash), vp, vp, ip, vp]),
-        "fneus_dw_gemm_pp": (C.c_int, [vp, ip, ip, l, ip, vp]),
-        "fneus_dw_gemm_pp_det": (C.c_int, [vp, ip, ip, l, ip, vp, l, vp]),
-        "fneus_nerf_bg_fwd": (C.c_int, [vp, vp, vp, l, C.POINTER(FneusNerfStash), vp, vp, ip, ip, vp]),
-        "fneus_nerf_bg_bwd": (C.c_int, [vp, l, vp, vp, C.POINTER(FneusNerfStash), ip, vp]),
+        "fneus_dw_gemm_pp": (C.c_int, [vp, ip, ip, l, vp, ip, vp]),
+        "fneus_dw_gemm_pp_det": (C.c_int, [vp, ip, ip, l, vp, ip, vp, l, vp]),
+        "fneus_nerf_bg_fwd": (C.c_int, [vp, vp, vp, l, C.POINTER(FneusNerfStash), vp, vp, ip, ip, vp, vp]),
+        "fneus_nerf_bg_bwd": (C.c_int, [vp, l, vp, vp, C.POINTER(FneusNerfStash), ip, vp, vp]),
         "fneus_adam": (C.c_int, [C.POINTER(FneusAdamSegment), ip, vp, vp, C.c_double, C.c_double, C.c_double, ip, vp]),
         "fneus_surface_gather": (C.c_int, [vp, vp, vp, vp, vp, ip, ip, vp, vp, vp, vp, vp, vp]),
         "fneus_surface_scatter": (C.c_int, [vp, vp, vp, ip, C.c_long, vp, vp, vp]),
@@ -118,6 +118,9 @@ def _load():
         "fneus_srgb_bwd": (C.c_int, [vp, vp, l, ip, vp, vp]),
         "fneus_indir_illum_fwd": (C.c_int, [vp, vp, ip, ip, ip, vp, vp]),
         "fneus_indir_illum_bwd": (C.c_int, [vp, vp, vp, ip, ip, ip, vp, vp]),
+        "fneus_outside_select": (C.c_int, [vp, vp, vp, vp, ip, ip, ip, f, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "fneus_outside_alpha_sel_fwd": (C.c_int, [vp, vp, vp, vp, vp, l, vp, vp, vp]),
+        "fneus_outside_alpha_sel_bwd": (C.c_int, [vp, vp, vp, vp, vp, l, vp, vp, vp, vp, vp]),
         "fneus_outside_alpha_fwd": (C.c_int, [vp, vp, vp, l, vp, vp, vp]),
         "fneus_outside_alpha_bwd": (C.c_int, [vp, vp, vp, vp, vp, l, vp, vp, vp]),
         "fneus_sg_render_fwd": (C.c_int, [vp] * 6 + [ip, ip, ip, f, vp, vp]),

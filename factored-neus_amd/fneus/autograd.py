@@ -151,11 +151,12 @@ class NerfFn(torch.autograd.Function):
     the backward writes the dL/dz planes and accumulates the parameter gradients into the network's flat buffer."""
 
     @staticmethod
-    def forward(ctx, anchor, net, pts4, dirs, prec: int, ws: _Workspace, train: bool):
+    def forward(ctx, anchor, net, pts4, dirs, prec: int, ws: _Workspace, train: bool, n_dev=None):
+        """n_dev: device int32 count (ops.outside_select): rows beyond it are not evaluated"""
         n = int(pts4.shape[0])
         stash = ws.get(("nerf_stash", n, prec), lambda: ops.NerfStash(n, anchor.device, prec, gprec=ws.gprec)) if train else None
-        density, rgb = ops.nerf_fwd(net.blob, n, prec, pts4, dirs, stash, train)
-        ctx.net, ctx.prec, ctx.ws, ctx.stash, ctx.n = net, prec, ws, stash, n
+        density, rgb = ops.nerf_fwd(net.blob, n, prec, pts4, dirs, stash, train, n_dev)
+        ctx.net, ctx.prec, ctx.ws, ctx.stash, ctx.n, ctx.n_dev = net, prec, ws, stash, n, n_dev
         ctx.generation = ws.stamp(stash) if stash is not None else None
         return density, rgb
 
@@ -166,10 +167,10 @@ class NerfFn(torch.autograd.Function):
         dev = net.blob.device
         d_density = torch.zeros(n, device=dev) if d_density is None else d_density.contiguous()
         d_rgb = torch.zeros(n, 3, device=dev) if d_rgb is None else d_rgb.contiguous()
-        ops.nerf_bwd(net.blob, n, prec, d_density, d_rgb, ctx.stash)
+        ops.nerf_bwd(net.blob, n, prec, d_density, d_rgb, ctx.stash, ctx.n_dev)
         jobs = ws.get(("nerf_jobs", n, prec), lambda: ops.nerf_dw_jobs(net, ctx.stash, n))
-        jobs.run()
-        return None, None, None, None, None, None, None
+        jobs.run(n_dev=ctx.n_dev)
+        return None, None, None, None, None, None, None, None
 
 
 class OutsideAlphaFn(torch.autograd.Function):
@@ -189,6 +190,29 @@ class OutsideAlphaFn(torch.autograd.Function):
         density, rgb, dists = ctx.saved_tensors
         d_density, d_raw = ops.outside_alpha_bwd(density, rgb, dists, None if d_alpha is None else d_alpha.contiguous(),
                                                  None if d_rgb is None else d_rgb.contiguous())
+        return d_density, d_raw, None
+
+
+class OutsideAlphaSelFn(torch.autograd.Function):
+    """OutsideAlphaFn over the list of ops.outside_select: density / rgb_raw are rows of the list, the outputs the full [B, nt]
+    arrays render_core reads (zeros at the samples that are not listed: their values are multiplied by 0 there)"""
+
+    @staticmethod
+    def forward(ctx, density, rgb_raw, s):
+        density, rgb_raw = density.contiguous(), rgb_raw.contiguous()
+        alpha, rgb = ops.outside_alpha_sel_fwd(density, rgb_raw, s)
+        ctx.save_for_backward(density, rgb)
+        ctx.lists = (s.dists, s.sel, s.count)
+        ctx.set_materialize_grads(False)
+        return alpha, rgb
+
+    @staticmethod
+    def backward(ctx, d_alpha, d_rgb):
+        density, rgb = ctx.saved_tensors
+        dists, sel, count = ctx.lists
+        d_density, d_raw = ops.outside_alpha_sel_bwd(density, rgb, dists, sel, count,
+                                                     None if d_alpha is None else d_alpha.contiguous(),
+                                                     None if d_rgb is None else d_rgb.contiguous())
         return d_density, d_raw, None
 
 

@@ -667,8 +667,9 @@ class GemmPPJobs:
         self.dev_table = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(self.device)
         return self
 
-    def run(self, *_ignored, gprec: Optional[int] = None):
-        """(positional arguments are accepted and ignored: older callers passed n and prec)"""
+    def run(self, *_ignored, gprec: Optional[int] = None, n_dev: Optional[torch.Tensor] = None):
+        """(positional arguments are accepted and ignored: older callers passed n and prec)
+        n_dev: device int32 sample count (outside_select): only the sample tiles of the first n_dev samples are summed"""
         gprec = getattr(self, "gprec", 1) if gprec is None else gprec
         if deterministic():
             # bit-reproducible gradients: partial tiles to a scratch buffer, summed in split order by a second launch (the
@@ -678,10 +679,10 @@ class GemmPPJobs:
             if buf is None or buf.numel() < need:
                 buf = _det_scratch[self.device] = torch.empty(max(need, 256 * DET_TILE_FLOATS), dtype=torch.float32, device=self.device)
             _launch("fneus_dw_gemm_pp_det:" + self.tag, lib.fneus_dw_gemm_pp_det, _ptr(self.dev_table), len(self.jobs), self.n_wgs,
-                    self.n_sample_tiles, gprec, _ptr(buf), buf.numel(), _stream())
+                    self.n_sample_tiles, _ptr(n_dev), gprec, _ptr(buf), buf.numel(), _stream())
             return
         _launch("fneus_dw_gemm_pp:" + self.tag, lib.fneus_dw_gemm_pp, _ptr(self.dev_table), len(self.jobs), self.n_wgs,
-                self.n_sample_tiles, gprec, _stream())
+                self.n_sample_tiles, _ptr(n_dev), gprec, _stream())
 
 
 def sdf_dw_jobs(net: PackedNet, stash: SdfStash, bufs: SdfBwdBufs, grad_flat: torch.Tensor, n: int) -> GemmPPJobs:
@@ -762,22 +763,23 @@ class NerfStash:
         self.c = s
 
 
-def nerf_fwd(blob, n_pts, prec, pts4, dirs, stash: Optional[NerfStash], train: bool):
-    """NeRF.forward (fields.py:233-259) on the HIP engine -> raw density [n], raw rgb [n,3]"""
+def nerf_fwd(blob, n_pts, prec, pts4, dirs, stash: Optional[NerfStash], train: bool, n_dev: Optional[torch.Tensor] = None):
+    """NeRF.forward (fields.py:233-259) on the HIP engine -> raw density [n], raw rgb [n,3]
+    n_dev: device int32 count (outside_select): only the first n_dev rows are evaluated, the others are left unwritten"""
     _chk_f32(pts4, "pts4")
     _chk_f32(dirs, "dirs")
     density = torch.empty(n_pts, dtype=torch.float32, device=blob.device)
     rgb = torch.empty(n_pts, 3, dtype=torch.float32, device=blob.device)
     _launch("fneus_nerf_bg_fwd", lib.fneus_nerf_bg_fwd, _ptr(blob), _ptr(pts4), _ptr(dirs), n_pts,
-            C.byref(stash.c) if stash is not None else None, _ptr(density), _ptr(rgb), prec, int(train), _stream())
+            C.byref(stash.c) if stash is not None else None, _ptr(density), _ptr(rgb), prec, int(train), _ptr(n_dev), _stream())
     return density, rgb
 
 
-def nerf_bwd(blob, n_pts, prec, d_density, d_rgb, stash: NerfStash):
+def nerf_bwd(blob, n_pts, prec, d_density, d_rgb, stash: NerfStash, n_dev: Optional[torch.Tensor] = None):
     _chk_f32(d_density, "d_density")
     _chk_f32(d_rgb, "d_rgb")
     _launch("fneus_nerf_bg_bwd", lib.fneus_nerf_bg_bwd, _ptr(blob), n_pts, _ptr(d_density), _ptr(d_rgb), C.byref(stash.c), prec,
-            _stream())
+            _ptr(n_dev), _stream())
 
 
 def nerf_dw_jobs(net: PackedNet, st: NerfStash, n: int) -> GemmPPJobs:
@@ -948,6 +950,53 @@ def outside_points(rays_o, rays_d, z_feed, sample_dist: float):
     _launch("fneus_outside_points", lib.fneus_outside_points, _ptr(rays_o), _ptr(rays_d), _ptr(z_feed), B, nt, float(sample_dist),
             _ptr(pts4), _ptr(dirs), _ptr(dists), _stream())
     return pts4, dirs, dists
+
+
+class OutsideSelection:
+    """what fneus_outside_select lists (include/fneus.h): the background samples whose value render_core uses"""
+    __slots__ = ("pts4", "dirs", "dists", "sel", "count", "alpha_full", "rgb_full", "B", "nt", "cap")
+
+
+def bg_select_enabled() -> bool:
+    """FNEUS_BG_SELECT=0: the background network at every merged depth, as the reference evaluates it (comparison runs)"""
+    return os.environ.get("FNEUS_BG_SELECT", "1") != "0"
+
+
+def outside_select(rays_o, rays_d, z_core, z_feed, sample_dist: float) -> OutsideSelection:
+    B, nt = z_feed.shape
+    n = z_core.shape[1]
+    dev = z_feed.device
+    o = OutsideSelection()
+    o.B, o.nt, o.cap = B, nt, B * nt
+    f32, i32 = torch.float32, torch.int32
+    o.pts4 = torch.empty(o.cap, 4, dtype=f32, device=dev)
+    o.dirs = torch.empty(o.cap, 3, dtype=f32, device=dev)
+    o.dists = torch.empty(o.cap, dtype=f32, device=dev)
+    o.sel = torch.empty(o.cap, dtype=i32, device=dev)
+    o.count = torch.empty(1, dtype=i32, device=dev)
+    o.alpha_full = torch.empty(B, nt, dtype=f32, device=dev)
+    o.rgb_full = torch.empty(B, nt, 3, dtype=f32, device=dev)
+    work = torch.empty(B + o.cap, dtype=i32, device=dev)
+    _launch("fneus_outside_select", lib.fneus_outside_select, _ptr(rays_o), _ptr(rays_d), _ptr(z_core), _ptr(z_feed), B, n, nt,
+            float(sample_dist), _ptr(work), _ptr(o.pts4), _ptr(o.dirs), _ptr(o.dists), _ptr(o.sel), _ptr(o.count), _ptr(o.alpha_full),
+            _ptr(o.rgb_full), _stream())
+    return o
+
+
+def outside_alpha_sel_fwd(density, rgb_raw, s: OutsideSelection):
+    """alpha / colour of the listed samples into s.alpha_full / s.rgb_full (zeros elsewhere)"""
+    _launch("fneus_outside_alpha_sel_fwd", lib.fneus_outside_alpha_sel_fwd, _ptr(density), _ptr(rgb_raw), _ptr(s.dists), _ptr(s.sel),
+            _ptr(s.count), s.cap, _ptr(s.alpha_full), _ptr(s.rgb_full), _stream())
+    return s.alpha_full, s.rgb_full
+
+
+def outside_alpha_sel_bwd(density, rgb_full, dists, sel, count, d_alpha_full, d_rgb_full):
+    cap = int(density.numel())
+    d_density = torch.empty(cap, dtype=torch.float32, device=density.device)
+    d_raw = torch.empty(cap, 3, dtype=torch.float32, device=density.device)
+    _launch("fneus_outside_alpha_sel_bwd", lib.fneus_outside_alpha_sel_bwd, _ptr(density), _ptr(rgb_full), _ptr(dists), _ptr(sel),
+            _ptr(count), cap, _ptr(d_alpha_full), _ptr(d_rgb_full), _ptr(d_density), _ptr(d_raw), _stream())
+    return d_density, d_raw
 
 
 def outside_alpha_fwd(density, rgb_raw, dists):

@@ -453,15 +453,16 @@ class NeRF(nn.Module):
         """pack the current parameters (once per optimiser step, before rendering)"""
         self._be.refresh()
 
-    def forward(self, input_pts, input_views):
-        """input_pts [N,4] inverted-sphere points, input_views [N,3] -> raw density [N,1], raw rgb [N,3]"""
+    def forward(self, input_pts, input_views, n_active=None):
+        """input_pts [N,4] inverted-sphere points, input_views [N,3] -> raw density [N,1], raw rgb [N,3]
+        n_active: device int32 count (ops.outside_select): only the first n_active rows are evaluated"""
         if not self._fused:
             raise NotImplementedError("the fused background-NeRF kernels are specialised for confs/womask.conf "
                                       "(D=8, W=256, d_in=4, multires=10, multires_view=4, skips=[4], use_viewdirs)")
         self._be.ensure()
         density, rgb = NerfFn.apply(self._be.anchor, self._be.net, input_pts.detach().float().contiguous(),
                                     input_views.detach().float().contiguous(), self.prec, self._be.ws,
-                                    torch.is_grad_enabled())
+                                    torch.is_grad_enabled(), n_active)
         return density.reshape(-1, 1), rgb
 
 

@@ -21,7 +21,7 @@ import torch
 
 from fneus import ops
 from models.mesh import extract_fields, extract_geometry      # noqa: F401  module-level API of renderer.py:14-40
-from fneus.autograd import CompositeFn, OutsideAlphaFn, RaySamples, SurfaceGatherFn, Stage1LossFn
+from fneus.autograd import CompositeFn, OutsideAlphaFn, OutsideAlphaSelFn, RaySamples, SurfaceGatherFn, Stage1LossFn
 
 
 def sample_pdf(bins, weights, n_samples, det=False):
@@ -123,13 +123,20 @@ class NeuSRenderer:
         return z_final
 
     # ---- render_core_outside (renderer.py:112-149): inverted-sphere background NeRF++, womask configs only --------
-    def render_core_outside(self, rays_o, rays_d, z_vals, sample_dist, nerf, background_rgb=None, full=True):
+    def render_core_outside(self, rays_o, rays_d, z_vals, sample_dist, nerf, background_rgb=None, full=True, z_core=None):
         """The background network runs on the fused K7 kernels (models/fields.py NeRF -> fneus_nerf_bg_fwd / _bwd); the
         inverted-sphere points (fneus_outside_points) and softplus / sigmoid / alpha (fneus_outside_alpha_fwd / _bwd) are one
         launch each; the blend with the foreground is inside the HIP compositing kernels.  full=False (what render() asks
         for): only `sampled_color` and `alpha`, the two entries the reference's render() consumes (renderer.py:455-458) --
         this branch's own weights and colour are dead code on that path."""
         B, n = z_vals.shape
+        if z_core is not None and not full and n <= 256 and ops.bg_select_enabled():
+            # render() hands over the depths render_core works on: the network runs only where render_core uses its value
+            # (ops.outside_select; samples inside the unit sphere take the foreground alone, renderer.py:350-356)
+            s = ops.outside_select(rays_o.contiguous(), rays_d.contiguous(), z_core.contiguous(), z_vals.contiguous(), sample_dist)
+            density, rgb_raw = nerf(s.pts4, s.dirs, n_active=s.count)
+            alpha, rgb = OutsideAlphaSelFn.apply(density.reshape(-1), rgb_raw, s)
+            return {"sampled_color": rgb, "alpha": alpha}
         pts4, dirs, dists = ops.outside_points(rays_o.contiguous(), rays_d.contiguous(), z_vals.contiguous(), sample_dist)
         density, rgb_raw = nerf(pts4, dirs)
         alpha, rgb = OutsideAlphaFn.apply(density.reshape(-1), rgb_raw, dists.reshape(-1))
@@ -267,7 +274,7 @@ class NeuSRenderer:
         if self.n_outside > 0:                                                    # renderer.py:452-458
             # sort(cat(z_vals, z_vals_outside)) of two sorted rows = one stable rank merge (fneus_merge)
             z_vals_feed, _ = ops.merge(z_vals.contiguous(), None, z_vals_outside.expand(B, -1).contiguous(), None)
-            ret_outside = self.render_core_outside(rays_o, rays_d, z_vals_feed, sample_dist, self.nerf, full=False)
+            ret_outside = self.render_core_outside(rays_o, rays_d, z_vals_feed, sample_dist, self.nerf, full=False, z_core=z_vals)
             background_sampled_color, background_alpha = ret_outside["sampled_color"], ret_outside["alpha"]
         ret = self.render_core(rays_o, rays_d, z_vals, sample_dist, self.sdf_network, self.deviation_network,
                                self.color_network, self.refColor_network, background_rgb=background_rgb,

@@ -174,13 +174,15 @@ int fneus_sdf_bwd(const void* sdf_blob, const float* pts, const float* rays_o, c
  * `splits` (at most the CU count: one workgroup per CU); gprec 1 = hi planes only (bf16 operands, fp32 accumulation), 3 = hi + lo planes (hi*hi + hi*lo + lo*hi).
  * Replaces torch autograd's addmm backward for fields.py:86 incl. the double-backward term of fields.py:104-110.       */
 int fneus_dw_gemm_pp(const void* jobs_dev /*FneusGemmPPJob[n_jobs] on the device*/, int n_jobs, int n_wgs,
-                     long n_sample_tiles, int gprec, fneus_stream_t stream);
+                     long n_sample_tiles, const int32_t* n_samples_dev /*NULL, or a DEVICE count: only the sample tiles of the
+                     first *n_samples_dev samples are summed (planes of a launch that took its count from fneus_outside_select)*/,
+                     int gprec, fneus_stream_t stream);
 /* The same products with BIT-REPRODUCIBLE results (FNEUS_DETERMINISTIC=1 in the Python layer): every workgroup writes its
  * partial tile to `scratch` (n_wgs x (256 x 256 + 256) floats, caller-owned), a second launch adds the partials of a product
  * in split order.  The reference's addmm backward (exp_runner.py:179-181 via autograd) is deterministic on CPU; the default
  * entry point above sums split-K partials with fp32 atomics in arrival order. */
-int fneus_dw_gemm_pp_det(const void* jobs_dev, int n_jobs, int n_wgs, long n_sample_tiles, int gprec, float* scratch,
-                         long scratch_floats, fneus_stream_t stream);
+int fneus_dw_gemm_pp_det(const void* jobs_dev, int n_jobs, int n_wgs, long n_sample_tiles, const int32_t* n_samples_dev,
+                         int gprec, float* scratch, long scratch_floats, fneus_stream_t stream);
 
 /* ---- K4: RenderingNetwork.forward, mode 'idr'  (fields.py:150-175 via renderer.py:278) ---------------------- */
 /* view directions: `dirs` [n][3], or NULL -> rays_d[n/m].  train != 0 writes the stash planes for the backward.   */
@@ -384,12 +386,15 @@ int fneus_sg_render_bwd(const float* lgt_sgs, const float* indir_sgs, const floa
  * nerf_blob: fneus_pack output for layout 2.  train != 0 writes the stash planes for the backward.                     */
 int fneus_nerf_bg_fwd(const void* nerf_blob, const float* pts4, const float* dirs, long n_pts,
                       const FneusNerfStash* stash /*host struct, may be NULL when !train*/, float* density /*[n]*/,
-                      float* rgb /*[n][3]*/, int prec, int train, fneus_stream_t stream);
+                      float* rgb /*[n][3]*/, int prec, int train,
+                      const int32_t* n_dev /*NULL, or a DEVICE count <= n_pts: only the first *n_dev rows are evaluated (the list
+                      of fneus_outside_select); buffers and stash planes keep the shape of n_pts*/, fneus_stream_t stream);
 
 /* autograd of the above w.r.t. the parameters (the inputs are constants: every z is sampled under no_grad): writes the
  * dL/dz planes of the stash; the weight / bias gradients are then ONE fneus_dw_gemm_pp launch over stash planes.          */
 int fneus_nerf_bg_bwd(const void* nerf_blob, long n_pts, const float* d_density /*[n]*/, const float* d_rgb /*[n][3]*/,
-                      const FneusNerfStash* stash, int prec, fneus_stream_t stream);
+                      const FneusNerfStash* stash, int prec, const int32_t* n_dev /*as in fneus_nerf_bg_fwd*/,
+                      fneus_stream_t stream);
 
 /* z_vals_outside of NeuSRenderer.render (renderer.py:397-400, 411-419) -> z [B][n_out]: linspace(1e-3, 1 - 1/(n_out+1), n_out),
  * jittered inside its cells by u [B][n_out] (NULL: no jitter), flipped, far / t + 1 / n_samples; far [B] or NULL = the rays'
@@ -402,6 +407,25 @@ int fneus_outside_z(const float* rays_o, const float* rays_d, const float* far, 
  * [B*nt][4] = (p / |p|, 1 / |p|) at the section mid points with |p| clipped to [1, 1e10], dirs [B*nt][3] = the ray direction. */
 int fneus_outside_points(const float* rays_o, const float* rays_d, const float* z, int n_rays, int nt, float sample_dist,
                          float* pts4, float* dirs, float* dists, fneus_stream_t stream);
+/* The background samples whose value render_core USES (renderer.py:350-356 blends sample i < n as x_i inside_i + bg_i (1 - inside_i):
+ * inside the unit sphere the background value is multiplied by exactly 0, forward and backward).  z_core [B][n]: the depths
+ * render_core gets; z_feed [B][nt]: the merged depths the background is evaluated at (renderer.py:453), nt <= 256.  Listed, in
+ * ray-major order: every sample i >= n and every i < n whose section mid point (renderer.py:228-231) is not inside the unit sphere.
+ * -> count (device int32), sel [count] = index into [B][nt], and pts4 / dirs / dists of fneus_outside_points for the listed samples
+ * (buffers of B nt rows); alpha_full [B][nt] / rgb_full [B][nt][3] get zeros at the samples NOT listed (the listed ones are
+ * written by fneus_outside_alpha_sel_fwd).  work: B + B nt int32.  fneus_nerf_bg_fwd / _bwd and fneus_dw_gemm_pp take `count`
+ * as their device-side sample count. */
+int fneus_outside_select(const float* rays_o, const float* rays_d, const float* z_core, const float* z_feed, int n_rays, int n,
+                         int nt, float sample_dist, int32_t* work, float* pts4, float* dirs, float* dists, int32_t* sel,
+                         int32_t* count, float* alpha_full, float* rgb_full, fneus_stream_t stream);
+/* fneus_outside_alpha_fwd / _bwd over that list: row k < *count of density / rgb_raw / dists is sample sel[k] of the full arrays
+ * (cap = rows of the list buffers) */
+int fneus_outside_alpha_sel_fwd(const float* density, const float* rgb_raw, const float* dists, const int32_t* sel,
+                                const int32_t* count, long cap, float* alpha_full, float* rgb_full, fneus_stream_t stream);
+int fneus_outside_alpha_sel_bwd(const float* density, const float* rgb_full, const float* dists, const int32_t* sel,
+                                const int32_t* count, long cap, const float* d_alpha_full /*or NULL*/,
+                                const float* d_rgb_full /*or NULL*/, float* d_density /*[cap]*/, float* d_rgb_raw /*[cap][3]*/,
+                                fneus_stream_t stream);
 /* alpha = 1 - exp(-softplus(density) dist), rgb = sigmoid(rgb_raw) (renderer.py:137-138) and the adjoint (d_alpha / d_rgb may
  * be NULL = zero) */
 int fneus_outside_alpha_fwd(const float* density, const float* rgb_raw, const float* dists, long n, float* alpha, float* rgb,

@@ -273,3 +273,62 @@ def test_lvis_render_util_vs_reference(golden_dir):
     assert dz.max().item() <= 1e-2 and (dz <= 1e-4).float().mean().item() >= 0.9
     same = (dz <= 1e-6).reshape(-1)
     assert ds[same].max().item() <= 1e-4
+
+
+def test_outside_select_lists_the_samples_render_core_uses():
+    """fneus_outside_select: in the list <=> the sample is a background sample (i >= n) or its section mid point is not inside
+    the unit sphere (the `inside_sphere` render_core multiplies the foreground with, renderer.py:270-272, 350-356); the rows of
+    the list are the rows fneus_outside_points makes for those samples, in ray-major order."""
+    from fneus import ops, synth
+    B, n, n_out = 96, 128, 32
+    data = torch.from_numpy(synth.ray_batch(B, seed=5, half_extent=0.9)).to(DEV)        # rays up to the sphere's rim
+    o, d = data[:, :3].contiguous(), data[:, 3:6].contiguous()
+    mid = -(o * d).sum(-1, keepdim=True) / (d * d).sum(-1, keepdim=True)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    z_core = (mid - 1.0 + 2.0 * torch.rand(B, n, generator=g).sort(dim=1).values.to(DEV)).contiguous()
+    z_out = (mid + 1.0 + 0.1 + 3.0 * torch.rand(B, n_out, generator=g).sort(dim=1).values.to(DEV)).contiguous()
+    z_feed = torch.cat([z_core, z_out], dim=1).contiguous()
+    sd = 2.0 / 64
+    s = ops.outside_select(o, d, z_core, z_feed, sd)
+    cnt = int(s.count.item())
+    sel = s.sel[:cnt].long().cpu()
+    assert bool((sel[1:] > sel[:-1]).all())                                                # ray-major, each sample once
+    listed = torch.zeros(B * (n + n_out), dtype=torch.bool)
+    listed[sel] = True
+    listed = listed.reshape(B, n + n_out)
+    assert bool(listed[:, n:].all())
+    _, mid_z = ops.sections(z_core, sd)
+    pn = (o[:, None, :] + d[:, None, :] * mid_z[..., None]).norm(dim=-1).cpu()
+    assert bool(listed[:, :n][pn >= 1.0].all())                                            # every sample render_core takes from it
+    assert not bool(listed[:, :n][pn < 1.0 - 1e-4].any())                                  # and nothing from well inside
+    frac = listed.float().mean().item()
+    assert 0.2 < frac < 0.9, frac
+    pts4, dirs, dists = ops.outside_points(o, d, z_feed, sd)
+    k = sel.to(DEV)
+    assert torch.equal(s.pts4[:cnt], pts4[k]) and torch.equal(s.dirs[:cnt], dirs[k]) and torch.equal(s.dists[:cnt], dists.reshape(-1)[k])
+    assert bool((s.alpha_full.reshape(-1).cpu()[~listed.reshape(-1)] == 0).all())
+    assert bool((s.rgb_full.reshape(-1, 3).cpu()[~listed.reshape(-1)] == 0).all())
+
+
+@pytest.mark.parametrize("name", WOMASK)
+def test_background_only_where_it_is_used_changes_nothing(golden_dir, name, monkeypatch):
+    """womask: the background network evaluated at the listed samples only (the default) against all n + n_out depths per ray
+    as the reference does it (FNEUS_BG_SELECT=0): inside the unit sphere its value is multiplied by exactly 0, so the rendered
+    outputs are the same numbers and the NeRF's weight gradients the same sums in another order."""
+    from _helper_losses import stage1_loss
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FNEUS_BG_SELECT", mode)
+        g = load(golden_dir, name)
+        out, nets, (rgb, mask) = run(g, 3, teacher_z=True, gprec=3)
+        L = stage1_loss(out, rgb, mask, igr_weight=0.1, mask_weight=float(g["mask_weight"]), surface_weight=0.1)
+        L["loss"].backward()
+        res[mode] = (out, {k: p.grad.detach().clone() for k, p in nets["nerf"].named_parameters()},
+                     {k: p.grad.detach().clone() for k, p in nets["sdf"].named_parameters()})
+    a, b = res["1"], res["0"]
+    for k in ("color_fine", "weights", "weight_sum"):
+        assert torch.equal(a[0][k], b[0][k]), k
+    for grads in (1, 2):
+        for k in a[grads]:
+            scale = b[grads][k].abs().max().item() + 1e-12
+            assert (a[grads][k] - b[grads][k]).abs().max().item() <= 2e-5 * scale + 1e-9, (k, scale)
