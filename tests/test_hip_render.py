@@ -200,7 +200,10 @@ def test_fast_mode_reports_error(golden_dir):
 
 # gradient precision 1 (bf16 planes for the weight-gradient GEMM) is what bench.py times; 3 (hi + lo planes) is fp32-accurate.
 # Bounds per mode: (fraction of elements off by > lr/4 after 1 / 3 steps, median |difference| in units of lr)
-ADAM_BOUNDS = {3: (0.02, 0.06, 0.02), 1: (0.02, 0.06, 0.02)}      # observed: <= 0.04 of the elements after 3 steps in either mode
+# Observed (MI355X, four fixtures, the same on two runs; tools/runs/r04_t.sh): after 1 step no element off in either mode, median
+# <= 1e-4 lr; after 3 steps gprec 3: <= 0.0303 of a tensor's sampled elements (one of 33), median <= 0.0174 lr; gprec 1: <= 0.0400,
+# median <= 0.0177 lr.  Bounds = observed + 50 %.
+ADAM_BOUNDS = {3: (0.01, 0.046, 0.026), 1: (0.01, 0.06, 0.027)}
 
 
 @pytest.mark.parametrize("gprec", [3, 1])
@@ -231,7 +234,7 @@ def test_adam_steps_match_reference(golden_dir, name, gprec):
             assert abs(losses["loss"].item() - float(g["adam1_loss"])) <= 2e-4
         if step not in (1, 3):
             continue
-        worst_frac, checked = 0.0, 0
+        worst_frac, worst_med, checked = 0.0, 0.0, 0
         for key in g:
             if not key.startswith(f"adam{step}_sub/"):
                 continue
@@ -248,10 +251,12 @@ def test_adam_steps_match_reference(golden_dir, name, gprec):
             # elements off by more than lr/4: gradient at rounding level (either sign is "right"); a few per thousand
             assert off.mean() <= (b1 if step == 1 else b3), (pname, step, off.mean())
             if got.size >= 20:
+                worst_med = max(worst_med, float(np.median(np.abs(got - ref))) / lr)
                 assert np.median(np.abs(got - ref)) <= bmed * lr, (pname, step)
             checked += 1
         assert checked >= 40
-        print(f"  {name} gprec {gprec}: after {step} Adam step(s) {checked} tensors; worst fraction of elements off by > lr/4: {worst_frac:.4f}")
+        print(f"  {name} gprec {gprec}: after {step} Adam step(s) {checked} tensors; worst fraction of elements off by > lr/4: {worst_frac:.4f}, "
+              f"worst median |difference| {worst_med:.4f} lr")
 
 
 def test_lvis_render_util_vs_reference(golden_dir):

@@ -10,8 +10,11 @@ import torch
 pytestmark = pytest.mark.gpu
 
 STEPS, RAYS, LR, SEED, RES = 1000, 512, 5e-4, 40, 96
-# observed over 3 x 3 HIP runs (MI355X): last-300-step means within 23 % of the oracle run's for every loss term
-LEVEL_TOL = 0.45
+# The HIP runs are deterministic here (FNEUS_DETERMINISTIC=1) and so is the oracle run: the numbers below are functions of the
+# code, the same on every run (tools/runs/r04_t.sh, twice).  Observed: last-300-step means within 15.4 % of the oracle run's for
+# every loss term (exact gradients <= 11.4 %, bf16 planes <= 15.4 %).  The trajectories are chaotic in their rounding -- another
+# summation order anywhere gives other numbers of the same spread (round 3, atomics: up to 23 %) -- so the bound is 2x, not 1.5x.
+LEVEL_TOL = 0.30
 
 
 def _mesh_from_grid(u):
@@ -20,7 +23,8 @@ def _mesh_from_grid(u):
     return v.cpu().numpy().astype(np.float64) / (RES - 1.0) * 2.02 - 1.01, f.cpu().numpy()
 
 
-def test_reconstruction_matches_oracle_training_on_the_synthetic_scene():
+def test_reconstruction_matches_oracle_training_on_the_synthetic_scene(monkeypatch):
+    monkeypatch.setenv("FNEUS_DETERMINISTIC", "1")     # fixed-order weight-gradient sums: a HIP run is one number, not a sample
     from evaluation.chamfer import evaluate_mesh
     from fneus import ops, synth
     from fneus.trainer import Stage1Trainer, WMASK_MODEL
@@ -47,6 +51,7 @@ def test_reconstruction_matches_oracle_training_on_the_synthetic_scene():
 
     hip, u_hip, u_init = run_hip(3)
     hip2, u_hip2, _ = run_hip(3)
+    assert np.array_equal(hip, hip2) and torch.equal(u_hip, u_hip2), "two deterministic runs of 1000 training steps differ"
     hipd, u_hipd, _ = run_hip(1)
     # ---- oracle: same weights, same batches, torch.optim.Adam, eager PyTorch-ROCm ops
     T = lambda sd: {k: torch.from_numpy(v).clone().to(dev).requires_grad_(True) for k, v in sd.items()}
@@ -78,7 +83,7 @@ def test_reconstruction_matches_oracle_training_on_the_synthetic_scene():
     for tag, run in (("exact", hip), ("bf16-planes", hipd)):
         first = np.abs(run[:10, 0] - ref[:10, 0]) / np.maximum(np.abs(ref[:10, 0]), 1e-2)
         print(f"  [{tag}] first 10 steps: worst relative loss deviation {first.max():.2e} (step 0: {first[0]:.1e})")
-        assert first[0] < 1e-4 and first.max() < 8e-2
+        assert first[0] < 1e-4 and first.max() < 2e-2        # observed 2.6e-3 (exact) / 5.6e-3 (bf16 planes)
     win = 50
     for k, name in enumerate(("loss", "color_loss", "eikonal_loss", "mask_loss")):
         a, a2, ad = (x[:, k].reshape(-1, win).mean(1) for x in (hip, hip2, hipd))
@@ -90,7 +95,7 @@ def test_reconstruction_matches_oracle_training_on_the_synthetic_scene():
               f"\n     HIP bf16 pl {np.round(ad, 4)}"
               f"\n     exact vs oracle: first 3 windows {dev_k[:3].max():.1e}, all {dev_k.max():.1e};  bf16 planes vs oracle: first 3 "
               f"{dev_d[:3].max():.1e}, all {dev_d.max():.1e};  exact vs exact #2: all {self_k.max():.1e}")
-        assert dev_k[:3].max() < 0.12 and dev_d[:3].max() < 0.18, name
+        assert dev_k[:3].max() < 0.08 and dev_d[:3].max() < 0.08, name      # observed <= 4.1e-2 / <= 2.0e-2 over the four terms
         # later the trajectories decorrelate (two exact runs differ by up to 47 % in single 50-step windows: every step
         # draws another image); what stays comparable is the level over many windows
         tail = STEPS * 3 // 10
@@ -116,10 +121,11 @@ def test_reconstruction_matches_oracle_training_on_the_synthetic_scene():
     # A single snapshot of a single run can be an outlier (0.092 once in 12 runs, next to 0.018 of its twin run: a stray
     # component of the level set at that step, with loss levels like every other run's): every run must have moved towards
     # the surface, and the MEDIAN of the three HIP runs must be as close to it as the oracle run is.
+    # Deterministic runs (round 4): 0.0270 (exact, both runs), 0.0335 (bf16 planes), oracle 0.0258 of 0.1239 initially.
     for c in (c_hip, c_hip2, c_hipd, c_ref):
-        assert c < 0.85 * c_init, c
+        assert c < 0.5 * c_init, c
     c_med = float(np.median([c_hip, c_hip2, c_hipd]))
-    assert c_ref < 0.5 * c_init and c_med < 0.5 * c_init and abs(c_med - c_ref) < 0.3 * c_init, (c_med, c_ref)
+    assert c_ref < 0.4 * c_init and c_med < 0.4 * c_init and abs(c_med - c_ref) < 0.15 * c_init, (c_med, c_ref)
 
 
 def test_chamfer_at_equal_steps_hip_vs_oracle_over_seeds():
