@@ -42,6 +42,8 @@ KERNEL_FLOPS = {
     "fneus_color_fwd": F_COL * SAMPLES_PER_STEP,
     "fneus_color_bwd": F_COL * SAMPLES_PER_STEP,
 }
+# (single-GPU steps run the colour network's products inside the SDF network's launch: fneus/autograd.py ColorFn.backward)
+KERNEL_FLOPS["fneus_dw_gemm_pp:sdf+color"] = KERNEL_FLOPS["fneus_dw_gemm_pp:sdf"] + KERNEL_FLOPS["fneus_dw_gemm_pp:color"]
 PEAK_BF16_MFMA_TFLOPS = 2500.0       # MI355X dense bf16 (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0                # HBM3E (MI355X_MICROARCH.md)
 # Algorithmic HBM bytes per sample of the fragment-plane design in parity mode with bf16 gradient planes (the default,
@@ -68,8 +70,10 @@ KERNEL_BYTES_PARITY_EXTRA = {
     "fneus_dw_gemm_pp:color": (8 * 512 + 512 + 128 + 64) * SAMPLES_PER_STEP,
     "fneus_sdf_fwd": 0.875 * 16 * SAMPLES_PER_STEP,
 }
+KERNEL_BYTES_PARITY["fneus_dw_gemm_pp:sdf+color"] = (KERNEL_BYTES_PARITY["fneus_dw_gemm_pp:sdf"]
+                                                     + KERNEL_BYTES_PARITY_EXTRA["fneus_dw_gemm_pp:color"])
 HBM_ACHIEVABLE_GBS = 6300.0          # float4 copy on this part (MI355X_MICROARCH.md: 6.29 TB/s measured, 79 % of the 8 TB/s spec)
-MFMAS_PER_PRODUCT = {"fneus_dw_gemm_pp:sdf": 1, "fneus_dw_gemm_pp:color": 1}      # gprec 1: bf16 planes; the chains issue 3
+MFMAS_PER_PRODUCT = {"fneus_dw_gemm_pp:sdf": 1, "fneus_dw_gemm_pp:color": 1, "fneus_dw_gemm_pp:sdf+color": 1}      # gprec 1: bf16 planes; the chains issue 3
 KERNEL_FLOPS_EXTRA = {"fneus_sdf_fwd": 0.875 * F_SDF * SAMPLES_PER_STEP}
 
 
@@ -352,7 +356,7 @@ def main():
                                               "streaming torch kernels reach 4.0 (read) - 6.8 (write) TB/s on this part"}
         # both roofs for the three kernels that carry the step (an extra: `roofline` above stays the contract's object)
         both = {}
-        for k in ("fneus_sdf_fwd_grad", "fneus_sdf_bwd", "fneus_dw_gemm_pp:sdf"):
+        for k in ("fneus_sdf_fwd_grad", "fneus_sdf_bwd", "fneus_dw_gemm_pp:sdf", "fneus_dw_gemm_pp:sdf+color"):
             if k not in per or k not in KERNEL_FLOPS:
                 continue
             n_l = max(round(per[k]["launches_per_step"]), 1)

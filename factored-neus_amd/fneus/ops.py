@@ -685,11 +685,18 @@ class GemmPPJobs:
                 self.n_sample_tiles, _ptr(n_dev), gprec, _stream())
 
 
-def sdf_dw_jobs(net: PackedNet, stash: SdfStash, bufs: SdfBwdBufs, grad_flat: torch.Tensor, n: int) -> GemmPPJobs:
+def gemm_merge_enabled() -> bool:
+    """FNEUS_GEMM_MERGE=0: the colour network's weight-gradient products as a launch of their own behind its backward (comparison
+    runs); default: in the SDF network's launch behind K3 (one launch over the same 65 536 samples instead of two)"""
+    return os.environ.get("FNEUS_GEMM_MERGE", "1") != "0"
+
+
+def sdf_dw_jobs(net: PackedNet, stash: SdfStash, bufs: SdfBwdBufs, grad_flat: torch.Tensor, n: int, also=None) -> GemmPPJobs:
     """dW_l = zbar_l^T u_l + a_l^T adj_l for the 9 SDF layers (SURVEY.md Appendix A), into the flat fp32 grad buffer;
-    operands are the fragment planes written by K2 / K3."""
+    operands are the fragment planes written by K2 / K3.  also(table): products over the same samples to append (the colour
+    network's, color_dw_jobs(..., into=table)) before the workgroups are distributed."""
     import math
-    g = GemmPPJobs(grad_flat.device, "sdf")
+    g = GemmPPJobs(grad_flat.device, "sdf" if also is None else "sdf+color")
     O = PPOperand
     offW, offb = net.desc["offW"], net.desc["offb"]
     base = grad_flat.data_ptr()
@@ -712,6 +719,9 @@ def sdf_dw_jobs(net: PackedNet, stash: SdfStash, bufs: SdfBwdBufs, grad_flat: to
     g.add(O(bufs.zsdf, 0, 1), O(h(7), 0, 8), base + 4 * offW[8], 256, 1, 256,
           A2=O(bufs.ones, 0, 1, const=True), B2=O(adj(7), 0, 8), bias_ptr=base + 4 * offb[8])
     g.gprec = stash.gprec
+    if also is not None:
+        also(g)
+        assert g.gprec == stash.gprec, "merged weight-gradient products differ in gradient precision"
     return g.finalize(stash.tiles)
 
 

@@ -88,12 +88,16 @@ class Stage1Trainer:
                                n_late=len(late))
         # FNEUS_DP_EARLY = 1 / 0 fixes the form (split / single exchange); "auto" (the default of bench.py and the runners with
         # more than one rank, through autotune_exchange) measures both on the job's own steps and keeps the faster one
+        self._warm_keys = set()
         self.split_exchange = self.distributed and os.environ.get("FNEUS_DP_EARLY", "1") != "0"
         self.exchange_choice = None          # filled by autotune_exchange: {"choice", "ms_split", "ms_single", "steps"}
         self._xstream = torch.cuda.Stream(device=device) if (self.distributed and device.type == "cuda") else None
         self._early = None           # handle of the early part's all-reduce of the step in flight
         if self.distributed:         # (the hook looks at split_exchange when it runs: both forms can be recorded by one trainer)
             self.sdf_network._ws.pre_backward = self._early_exchange
+            # (the split exchange ships the colour network's gradients when the SDF backward starts: its weight-gradient
+            # products must not wait for the SDF network's launch then, fneus/autograd.py ColorFn.backward)
+            self.sdf_network._ws.color_grads_early = lambda: self.split_exchange
         self.optimizer = FlatAdam(self.params, lr=lr)
         self._graphs = {}            # (batch shape, background shape) -> (graph(s), static input, static background, losses)
         self._cos = torch.ones(1, dtype=torch.float32, device=device)    # cos_anneal_ratio of the replayed step
@@ -128,7 +132,10 @@ class Stage1Trainer:
         key = (tuple(data.shape), None if background_rgb is None else tuple(background_rgb.shape), self.split_exchange)
         entry = self._graphs.get(key)
         if entry is None:
-            if self._eager_steps < self.graph_warmup_steps or len(self._graphs) >= 6:
+            # (one eager step per form of the step as well: the two forms of the gradient exchange use different job tables of the
+            # weight-gradient GEMM, and a table is built -- host to device -- by the first step that needs it)
+            if self._eager_steps < self.graph_warmup_steps or len(self._graphs) >= 6 or key not in self._warm_keys:
+                self._warm_keys.add(key)
                 return self._eager_step(data, cos_anneal_ratio, background_rgb)
             entry = (self._capture_dp if self.distributed else self._capture)(data, background_rgb)
             self._graphs[key] = entry

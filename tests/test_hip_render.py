@@ -337,3 +337,21 @@ def test_background_only_where_it_is_used_changes_nothing(golden_dir, name, monk
         for k in a[grads]:
             scale = b[grads][k].abs().max().item() + 1e-12
             assert (a[grads][k] - b[grads][k]).abs().max().item() <= 2e-5 * scale + 1e-9, (k, scale)
+
+
+@pytest.mark.parametrize("name", ["render_wmask_b64_n64"])
+def test_colour_products_inside_the_sdf_launch_change_nothing(golden_dir, name, monkeypatch):
+    """the colour network's weight-gradient products in the SDF network's launch behind K3 (default) against a launch of their own
+    behind the colour backward (FNEUS_GEMM_MERGE=0): the same sums over the same planes, split over workgroups differently"""
+    from _helper_losses import stage1_loss
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FNEUS_GEMM_MERGE", mode)
+        g = load(golden_dir, name)
+        out, nets, (rgb, mask) = run(g, 3, teacher_z=True, gprec=1)
+        L = stage1_loss(out, rgb, mask, igr_weight=0.1, mask_weight=float(g["mask_weight"]), surface_weight=0.1)
+        L["loss"].backward()
+        res[mode] = {f"{n}.{k}": p.grad.detach().clone() for n in ("sdf", "color") for k, p in nets[n].named_parameters()}
+    for k in res["1"]:
+        scale = res["0"][k].abs().max().item() + 1e-12
+        assert (res["1"][k] - res["0"][k]).abs().max().item() <= 2e-5 * scale + 1e-9, (k, scale)
