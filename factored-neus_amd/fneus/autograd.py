@@ -95,21 +95,39 @@ class SdfValueGradFn(torch.autograd.Function):
         # zeroed once: fneus_wn_backward clears what it reads, so the buffer is zero again after every step
         grad = ws.get(("sdf_grad", n), lambda: torch.zeros(net.n_params, dtype=torch.float32, device=dev))
         # the colour network's products over the same samples wait here (ColorFn.backward): one launch for both networks
-        col = ws.cache.pop("pending_color_dw", None)
+        col, ref = ws.cache.pop("pending_color_dw", None), ws.cache.pop("pending_ref_dw", None)
         if col is not None and (col["n"] != n or col["stash"].gprec != ctx.stash.gprec):
             _run_color_dw(col)
             col = None
+        if ref is not None and (col is None or ref["st"][0].gprec != ctx.stash.gprec):
+            _run_ref_dw(ref)
+            ref = None
         if col is not None:
-            jobs = ws.get(("sdf_col_jobs", n, prec) + col["key"],
-                          lambda: ops.sdf_dw_jobs(net, ctx.stash, bufs, grad, n, also=lambda g: ops.color_dw_jobs(
-                              col["net"], col["feat_planes"], col["stash"], col["grad"], n, into=g)))
+            def also(g):
+                ops.color_dw_jobs(col["net"], col["feat_planes"], col["stash"], col["grad"], n, into=g)
+                if ref is not None:      # the heads' planes hold the 2 B gathered rows: products with their own tile count
+                    for net_h, st_h, g_h in zip(ref["nets"], ref["st"], ref["grads"]):
+                        ops.color_dw_jobs(net_h, st_h.feat, st_h, g_h, ref["n"], into=g, own_tiles=True)
+
+            jobs = ws.get(("sdf_col_jobs", n, prec) + col["key"] + (ref["key"] if ref is not None else ()),
+                          lambda: ops.sdf_dw_jobs(net, ctx.stash, bufs, grad, n, also=also))
             jobs.run()
             col["net"].wn_backward(col["grad"])
+            if ref is not None:
+                for net_h, g_h in zip(ref["nets"], ref["grads"]):
+                    net_h.wn_backward(g_h)
         else:
             jobs = ws.get(("sdf_jobs", n, prec), lambda: ops.sdf_dw_jobs(net, ctx.stash, bufs, grad, n))
             jobs.run()
         net.wn_backward(grad)
         return None, None, None, None, None, None
+
+
+def _run_ref_dw(ref):
+    """the RefColor heads' weight-gradient products as a launch of their own"""
+    ref["ws"].get(("ref_jobs", ref["n"], ref["prec"]), ref["build"]).run()
+    for net, g in zip(ref["nets"], ref["grads"]):
+        net.wn_backward(g)
 
 
 def _run_color_dw(col):
@@ -313,10 +331,24 @@ class RefHeadsFn(torch.autograd.Function):
             ops.color_dw_jobs(net_vd, st[1].feat, st[1], g_vd, n, into=jobs)
             return jobs.finalize(st[0].tiles)
 
-        with ops.on_side_stream(2):          # only Adam consumes these: off the critical path of the backward
-            ws.get(("ref_jobs", n, prec), build).run()
-            net_cd.wn_backward(g_cd)
-            net_vd.wn_backward(g_vd)
+        ref = dict(ws=ws, n=n, prec=prec, build=build, nets=(net_cd, net_vd), grads=(g_cd, g_vd), st=st,
+                   key=(st[0].zbar.data_ptr(), st[1].zbar.data_ptr(), grad.data_ptr()))
+        early = getattr(ctx.gathered[0], "color_grads_early", None) if ctx.gathered is not None else None
+        if ctx.gathered is not None and ops.gemm_merge_enabled() and not (early is not None and early()):
+            # rows gathered from the SDF network's outputs: its backward follows in this pass, and its weight-gradient launch
+            # takes these products along (ColorFn.backward does the same with the colour network's)
+            sdf_ws = ctx.gathered[0]
+            sdf_ws.cache["pending_ref_dw"] = ref
+
+            def flush():
+                left = sdf_ws.cache.pop("pending_ref_dw", None)
+                if left is not None:
+                    _run_ref_dw(left)
+
+            torch.autograd.Variable._execution_engine.queue_callback(flush)
+        else:
+            with ops.on_side_stream(2):          # only Adam consumes these: off the critical path of the backward
+                _run_ref_dw(ref)
         if ctx.gathered is not None:
             # the rows came from surface_gather: their per-head gradients go to the SDF backward as they are (one launch adds the
             # heads and scatters the rows) instead of sum -> SurfaceGatherFn.backward -> index_add_ (four launches)

@@ -629,7 +629,8 @@ class GemmPPJobs:
         self.dev_table, self.n_wgs = None, 0
 
     def add(self, A: PPOperand, B: PPOperand, c_ptr, ldc, m, n, A2: Optional[PPOperand] = None, B2: Optional[PPOperand] = None,
-            bias_ptr=None, scale=1.0):
+            bias_ptr=None, scale=1.0, n_tiles: int = 0):
+        """n_tiles: sample tiles of this product's planes when they differ from the launch's (finalize)"""
         assert A.tiles <= 8 and B.tiles <= 8 and m <= 32 * A.tiles and n <= 32 * B.tiles
         j = _lib.FneusGemmPPJob()
         j.a_hi, j.a_lo, j.b_hi, j.b_lo = A.ptr(0), A.ptr(1), B.ptr(0), B.ptr(1)
@@ -639,6 +640,7 @@ class GemmPPJobs:
             j.a2_hi, j.a2_lo, j.b2_hi, j.b2_lo = A2.ptr(0), A2.ptr(1), B2.ptr(0), B2.ptr(1)
             j.a2_blk, j.b2_blk, j.a2_f0, j.b2_f0 = A2.blk, B2.blk, A2.f0, B2.f0
         j.mt, j.nt, j.c, j.bias, j.ldc, j.m, j.n, j.scale = A.tiles, B.tiles, c_ptr, bias_ptr, ldc, m, n, scale
+        j.n_tiles = int(n_tiles)
         self.jobs.append(j)
         # cost of one sample tile of this job, for the workgroup distribution.  The kernel's work per stage does not shrink
         # with a narrow operand (a stage always DMAs and multiplies full 16-fragment parts; there are no branches in its
@@ -650,9 +652,10 @@ class GemmPPJobs:
     def finalize(self, n_sample_tiles: int, min_tiles: int = 4):
         """distribute ~target workgroups over the jobs in proportion to the bytes each streams; a workgroup owns at least
         `min_tiles` sample tiles (its epilogue is up to 65 536 atomics whatever it summed)"""
-        tot = float(sum(self.bytes))
-        cap = max(1, n_sample_tiles // min_tiles)
-        splits = [max(1, min(cap, int(round(self.target * b / tot)))) for b in self.bytes]
+        tiles = [j.n_tiles if j.n_tiles > 0 else n_sample_tiles for j in self.jobs]
+        cost = [b * t for b, t in zip(self.bytes, tiles)]
+        tot = float(sum(cost))
+        splits = [max(1, min(max(1, t // min_tiles), int(round(self.target * c / tot)))) for c, t in zip(cost, tiles)]
         # the kernel keeps ONE workgroup per CU (128 KB of LDS): a launch of more than `target` workgroups needs a second
         # round for the few extra ones and takes nearly twice as long (measured: 258 workgroups 0.39 ms, 238 0.29 ms).
         # Rounding must therefore never push the total over the target: trim the jobs with the most splits.
@@ -696,7 +699,7 @@ def sdf_dw_jobs(net: PackedNet, stash: SdfStash, bufs: SdfBwdBufs, grad_flat: to
     operands are the fragment planes written by K2 / K3.  also(table): products over the same samples to append (the colour
     network's, color_dw_jobs(..., into=table)) before the workgroups are distributed."""
     import math
-    g = GemmPPJobs(grad_flat.device, "sdf" if also is None else "sdf+color")
+    g = GemmPPJobs(grad_flat.device, "sdf" if also is None else "sdf+color")       # ("+color": and whatever else waited)
     O = PPOperand
     offW, offb = net.desc["offW"], net.desc["offb"]
     base = grad_flat.data_ptr()
@@ -726,7 +729,7 @@ def sdf_dw_jobs(net: PackedNet, stash: SdfStash, bufs: SdfBwdBufs, grad_flat: to
 
 
 def color_dw_jobs(net: PackedNet, feat_planes: torch.Tensor, stash: ColStash, grad_flat: torch.Tensor, n: int,
-                  into: Optional[GemmPPJobs] = None) -> GemmPPJobs:
+                  into: Optional[GemmPPJobs] = None, own_tiles: bool = False) -> GemmPPJobs:
     """dW of a colour-shaped MLP (colour network: feat_planes = SdfStash.feat; RefColor heads: their own ColStash.feat)
     from fragment planes.  `into`: append to that job table instead of finalising a new one (several small networks in
     one launch)."""
@@ -736,12 +739,15 @@ def color_dw_jobs(net: PackedNet, feat_planes: torch.Tensor, stash: ColStash, gr
     n_side, ld0, n_out = net.desc["n_side"], net.desc["ins"][0], net.desc["outs"][4]
     base = grad_flat.data_ptr()
     assert feat_planes.shape[0] == stash.zbar.shape[0], "feature planes and colour stash differ in gradient precision"
+    nt = stash.tiles if own_tiles else 0         # own_tiles: these planes hold another number of samples than the launch's
     # layer 0: columns 0..n_side-1 = side inputs, then the 256 features
-    g.add(O(stash.zbar[:, 0], 0, 8), O(feat_planes, 0, 8), base + 4 * (offW[0] + n_side), ld0, 256, 256, bias_ptr=base + 4 * offb[0])
-    g.add(O(stash.zbar[:, 0], 0, 8), O(stash.side, 0, 2), base + 4 * offW[0], ld0, 256, n_side)
+    g.add(O(stash.zbar[:, 0], 0, 8), O(feat_planes, 0, 8), base + 4 * (offW[0] + n_side), ld0, 256, 256, bias_ptr=base + 4 * offb[0],
+          n_tiles=nt)
+    g.add(O(stash.zbar[:, 0], 0, 8), O(stash.side, 0, 2), base + 4 * offW[0], ld0, 256, n_side, n_tiles=nt)
     for l in (1, 2, 3):
-        g.add(O(stash.zbar[:, l], 0, 8), O(stash.u[:, l - 1], 0, 8), base + 4 * offW[l], 256, 256, 256, bias_ptr=base + 4 * offb[l])
-    g.add(O(stash.zout, 0, 1), O(stash.u[:, 3], 0, 8), base + 4 * offW[4], 256, n_out, 256, bias_ptr=base + 4 * offb[4])
+        g.add(O(stash.zbar[:, l], 0, 8), O(stash.u[:, l - 1], 0, 8), base + 4 * offW[l], 256, 256, 256, bias_ptr=base + 4 * offb[l],
+              n_tiles=nt)
+    g.add(O(stash.zout, 0, 1), O(stash.u[:, 3], 0, 8), base + 4 * offW[4], 256, n_out, 256, bias_ptr=base + 4 * offb[4], n_tiles=nt)
     g.gprec = stash.gprec
     return g if into is not None else g.finalize(stash.tiles)
 
