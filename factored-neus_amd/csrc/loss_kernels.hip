@@ -135,34 +135,32 @@ FN_DEV void block_sum(float (&v)[NV], float* sm /*[NV][16]*/) {
     __syncthreads();
 }
 
-// shading of one ray: blend of the two bracketing samples; returns surface colour (and optionally the parts)
-struct Shade {
-    float brdf[2][3], y[2][3], w[2], W;
-    float surf[3];
+// shading of one ray: blend of the two bracketing samples.  TWO threads per ray (neighbouring lanes 2 b, 2 b + 1 of a wave), one
+// per bracketing sample: the 14 sRGB curves of a ray (powf each) were the kernel -- one 1024-thread workgroup, half of it idle with
+// 512 rays, every curve evaluated again in the gradient sweep: 25 us per step.  Each thread now evaluates the 7 curves of its
+// sample once (the values stay in registers for the gradient sweep when the batch fits one pass) and the pair exchanges its
+// terms by lane shuffle.
+struct HalfShade {
+    float brdf[3], y[3];          // specular + diffuse of this sample per channel, its sRGB value (unclipped)
+    float ys, yd[3];              // clip(sRGB(specular)), clip(sRGB(diffuse))
+    float w;                      // this sample's blend weight + 1e-5
 };
-FN_DEV void shade_ray(const LossArgs& a, int b, bool sm, Shade& s, float (&spec_c)[3], float (&diff_c)[3]) {
-    s.w[0] = a.wpair[b * 2 + 0] + 1e-5f;
-    s.w[1] = a.wpair[b * 2 + 1] + 1e-5f;
-    s.W = s.w[0] + s.w[1];
-    float ys[2], yd[2][3];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const float sp = a.spec[(2 * b + k) * 3];
-        ys[k] = clip01(srgb(sp));
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float df = a.diffuse[(2 * b + k) * 3 + c];
-            s.brdf[k][c] = sp + df;
-            s.y[k][c] = srgb(s.brdf[k][c]);
-            yd[k][c] = clip01(srgb(df));
-        }
-    }
+FN_DEV void shade_half(const LossArgs& a, int b, int k, HalfShade& h) {
+    h.w = a.wpair[b * 2 + k] + 1e-5f;
+    const float sp = a.spec[(2 * b + k) * 3];
+    h.ys = clip01(srgb(sp));
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        s.surf[c] = sm ? (clip01(s.y[0][c]) * s.w[0] + clip01(s.y[1][c]) * s.w[1]) / s.W : 1.0f;
-        spec_c[c] = sm ? (ys[0] * s.w[0] + ys[1] * s.w[1]) / s.W : 1.0f;
-        diff_c[c] = sm ? (yd[0][c] * s.w[0] + yd[1][c] * s.w[1]) / s.W : 1.0f;
+        const float df = a.diffuse[(2 * b + k) * 3 + c];
+        h.brdf[c] = sp + df;
+        h.y[c] = srgb(h.brdf[c]);
+        h.yd[c] = clip01(srgb(df));
     }
+}
+// both samples' terms of a ray in blend order (sample 0 first: the sums of the one-thread version, bit for bit)
+FN_DEV float pair_blend(float mine, float w_mine, int k, float W) {
+    const float t = mine * w_mine, o = __shfl_xor(t, 1, 64);
+    return ((k == 0 ? t : o) + (k == 0 ? o : t)) / W;
 }
 
 __global__ void __launch_bounds__(kLossThreads) stage1_loss_kernel(LossArgs a, WarmList W) {
@@ -173,27 +171,38 @@ __global__ void __launch_bounds__(kLossThreads) stage1_loss_kernel(LossArgs a, W
         return;
     }
     const bool use_mask = a.mask_weight > 0.0f;
+    const bool single = 2 * a.B <= kLossThreads;          // one pass: the shading of sweep 1 is still in registers in sweep 2
+    HalfShade hs;
     // ---- sweep 1: batch sums ----
     // 0 mask_sum, 1 mask*sdf_mask, 2 |colour error|, 3 |surface error| (unweighted by 1/sum), 4 eik num, 5 eik den,
     // 6 BCE sum, 7 squared colour error
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int b = tid; b < a.B; b += kLossThreads) {
+    for (int p = tid; p < 2 * a.B; p += kLossThreads) {
+        const int b = p >> 1, k = p & 1;
         const float m = use_mask ? (a.mask_in[b] > 0.5f ? 1.0f : 0.0f) : 1.0f;
         const bool sm = a.sdf_mask[b] != 0;
-        Shade s;
-        float spec_c[3], diff_c[3];
-        shade_ray(a, b, sm, s, spec_c, diff_c);
+        shade_half(a, b, k, hs);
+        const float Wsum = hs.w + __shfl_xor(hs.w, 1, 64);
+        float surf[3], spec_c, diff_c[3];
+        spec_c = pair_blend(hs.ys, hs.w, k, Wsum);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            surf[c] = pair_blend(clip01(hs.y[c]), hs.w, k, Wsum);
+            diff_c[c] = pair_blend(hs.yd[c], hs.w, k, Wsum);
+        }
+        if (k != 0) continue;                // the ray's sums and outputs: its first thread
         acc[0] += m;
         acc[1] += sm ? m : 0.0f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
+            const float sc = sm ? surf[c] : 1.0f;
             const float ce = (a.color[b * 3 + c] - a.true_rgb[b * 3 + c]) * m;
             acc[2] += fabsf(ce);
             acc[7] += ce * (a.color[b * 3 + c] - a.true_rgb[b * 3 + c]);
-            if (sm) acc[3] += fabsf(a.surface_weight * (s.surf[c] - a.true_rgb[b * 3 + c]) * m);
-            a.surface_color[b * 3 + c] = s.surf[c];
-            a.specular_color[b * 3 + c] = spec_c[c];
-            a.diffuse_color[b * 3 + c] = diff_c[c];
+            if (sm) acc[3] += fabsf(a.surface_weight * (sc - a.true_rgb[b * 3 + c]) * m);
+            a.surface_color[b * 3 + c] = sc;
+            a.specular_color[b * 3 + c] = sm ? spec_c : 1.0f;
+            a.diffuse_color[b * 3 + c] = sm ? diff_c[c] : 1.0f;
         }
         acc[4] += a.eik_num[b];
         acc[5] += a.eik_den[b];
@@ -221,38 +230,34 @@ __global__ void __launch_bounds__(kLossThreads) stage1_loss_kernel(LossArgs a, W
         a.losses[6] = mask_sum;
         a.losses[7] = mask_sdf_sum;
     }
-    // ---- sweep 2: gradients of the total loss ----
-    for (int b = tid; b < a.B; b += kLossThreads) {
+    // ---- sweep 2: gradients of the total loss (thread (b, k): the gradients of sample k; k = 0 also the ray's) ----
+    for (int p = tid; p < 2 * a.B; p += kLossThreads) {
+        const int b = p >> 1, k = p & 1;
         const float m = use_mask ? (a.mask_in[b] > 0.5f ? 1.0f : 0.0f) : 1.0f;
         const bool sm = a.sdf_mask[b] != 0;
-        Shade s;
-        float spec_c[3], diff_c[3];
-        shade_ray(a, b, sm, s, spec_c, diff_c);
-        float dw[2] = {0.0f, 0.0f}, dsp[2] = {0.0f, 0.0f};
+        if (!single) shade_half(a, b, k, hs);
+        const float Wsum = hs.w + __shfl_xor(hs.w, 1, 64);
+        float dwk = 0.0f, dspk = 0.0f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float t = a.true_rgb[b * 3 + c];
-            a.d_color[b * 3 + c] = sgn((a.color[b * 3 + c] - t) * m) * m / mask_sum;
+            const float surf = sm ? pair_blend(clip01(hs.y[c]), hs.w, k, Wsum) : 1.0f;
+            if (k == 0) a.d_color[b * 3 + c] = sgn((a.color[b * 3 + c] - t) * m) * m / mask_sum;
             // surface term: |surface_weight (surf - t) m| / mask_sdf_sum over rays with a sign change
-            const float dsurf = sm ? sgn(a.surface_weight * (s.surf[c] - t) * m) * a.surface_weight * m / mask_sdf_sum : 0.0f;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const float yk = s.y[k][c];
-                const float inside = (yk >= 0.0f && yk <= 1.0f) ? 1.0f : 0.0f;          // torch.clip passes the gradient on [0, 1]
-                const float dy = dsurf * s.w[k] / s.W * inside;
-                const float dx = dy != 0.0f ? dy * dsrgb(s.brdf[k][c]) : 0.0f;
-                a.d_diffuse[(2 * b + k) * 3 + c] = dx;
-                dsp[k] += dx;
-                dw[k] += dsurf * (clip01(yk) - s.surf[c]) / s.W;
-            }
+            const float dsurf = sm ? sgn(a.surface_weight * (surf - t) * m) * a.surface_weight * m / mask_sdf_sum : 0.0f;
+            const float yk = hs.y[c];
+            const float inside = (yk >= 0.0f && yk <= 1.0f) ? 1.0f : 0.0f;          // torch.clip passes the gradient on [0, 1]
+            const float dy = dsurf * hs.w / Wsum * inside;
+            const float dx = dy != 0.0f ? dy * dsrgb(hs.brdf[c]) : 0.0f;
+            a.d_diffuse[(2 * b + k) * 3 + c] = dx;
+            dspk += dx;
+            dwk += dsurf * (clip01(yk) - surf) / Wsum;
         }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            a.d_wpair[b * 2 + k] = dw[k];
-            a.d_spec[(2 * b + k) * 3 + 0] = dsp[k];
-            a.d_spec[(2 * b + k) * 3 + 1] = 0.0f;
-            a.d_spec[(2 * b + k) * 3 + 2] = 0.0f;
-        }
+        a.d_wpair[b * 2 + k] = dwk;
+        a.d_spec[(2 * b + k) * 3 + 0] = dspk;
+        a.d_spec[(2 * b + k) * 3 + 1] = 0.0f;
+        a.d_spec[(2 * b + k) * 3 + 2] = 0.0f;
+        if (k != 0) continue;
         a.d_eiknum[b] = a.igr_weight / eik_den;
         const float wr = a.wsum[b];
         const bool in = wr >= 1e-3f && wr <= 1.0f - 1e-3f;
