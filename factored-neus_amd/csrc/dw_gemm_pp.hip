@@ -34,6 +34,7 @@ struct GemmPPJob {
     float scale;
     int32_t wg_base, splits;
     int32_t n_tiles, pad_;                      // sample tiles of THIS product's planes; 0: the launch's
+    const int32_t* n_dev;                       // or NULL: device-side count of the samples its planes hold this step
 };
 static_assert(sizeof(GemmPPJob) == sizeof(FneusGemmPPJob), "GemmPPJob must mirror FneusGemmPPJob");
 
@@ -108,7 +109,8 @@ __global__ void __launch_bounds__(256, 1) dw_gemm_pp_kernel(const GemmPPJob* __r
     const GemmPPJob* __restrict__ jp = jobs + ji;
     const int mt = jp->mt, nt = jp->nt;
     const int split = blockIdx.x - jp->wg_base;
-    if (jp->n_tiles > 0) n_tiles = jp->n_tiles;                   // (products over other planes in the same launch: RefColor's 2 B rows)
+    if (jp->n_tiles > 0) n_tiles = jp->n_tiles;                   // (products over other planes in the same launch: RefColor's 2 B rows,
+    n_tiles = live_tiles(n_tiles, jp->n_dev);                     //  the background network's listed samples)
     const int per = (n_tiles + jp->splits - 1) / jp->splits;      // sample tiles [tb, te) of this workgroup
     const int tb = split * per;
     const int te = tb + per < n_tiles ? tb + per : n_tiles;
@@ -355,6 +357,8 @@ __global__ void __launch_bounds__(256) dw_gemm_pp_reduce_kernel(const GemmPPJob*
     if (n_tiles <= 0) return;
     const GemmPPJob* __restrict__ jp = jobs + blockIdx.y;
     if (jp->n_tiles > 0) n_tiles = jp->n_tiles;
+    n_tiles = live_tiles(n_tiles, jp->n_dev);
+    if (n_tiles <= 0) return;
     const int m = jp->m, n = jp->n, splits = jp->splits, base = jp->wg_base;
     const int per = (n_tiles + splits - 1) / splits;
     const int live = (n_tiles + per - 1) / per;          // workgroups of the product that had sample tiles (the others wrote nothing)

@@ -60,7 +60,7 @@ class FneusGemmPPJob(C.Structure):
                [(n, C.c_uint16) for n in ("a_f0", "b_f0", "a2_f0", "b2_f0")] + \
                [("mt", C.c_int32), ("nt", C.c_int32), ("c", C.c_void_p), ("bias", C.c_void_p),
                 ("ldc", C.c_int32), ("m", C.c_int32), ("n", C.c_int32), ("scale", C.c_float),
-                ("wg_base", C.c_int32), ("splits", C.c_int32), ("n_tiles", C.c_int32), ("pad_", C.c_int32)]
+                ("wg_base", C.c_int32), ("splits", C.c_int32), ("n_tiles", C.c_int32), ("pad_", C.c_int32), ("n_dev", C.c_void_p)]
 
 
 def _load():

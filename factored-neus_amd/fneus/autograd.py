@@ -63,6 +63,8 @@ class SdfValueGradFn(torch.autograd.Function):
         sdf, feat, normal = ops.sdf_fwd_grad(net.blob, n, prec, stash, train, **samples.kw())
         ctx.net, ctx.samples, ctx.prec, ctx.ws, ctx.stash, ctx.n = net, samples, prec, ws, stash, n
         ctx.generation = ws.stamp(stash)
+        if train:       # (a flag, not a count: a forward whose backward never runs must not stick)
+            _PENDING_OPEN[anchor.device] = 1
         return sdf, feat, normal
 
     @staticmethod
@@ -95,21 +97,28 @@ class SdfValueGradFn(torch.autograd.Function):
         # zeroed once: fneus_wn_backward clears what it reads, so the buffer is zero again after every step
         grad = ws.get(("sdf_grad", n), lambda: torch.zeros(net.n_params, dtype=torch.float32, device=dev))
         # the colour network's products over the same samples wait here (ColorFn.backward): one launch for both networks
+        _PENDING_OPEN[dev] = 0
         col, ref = ws.cache.pop("pending_color_dw", None), ws.cache.pop("pending_ref_dw", None)
+        bgs = [r for r in _PENDING_NERF.pop(dev, [])]
         if col is not None and (col["n"] != n or col["stash"].gprec != ctx.stash.gprec):
             _run_color_dw(col)
             col = None
         if ref is not None and (col is None or ref["st"][0].gprec != ctx.stash.gprec):
             _run_ref_dw(ref)
             ref = None
+        for r in [r for r in bgs if col is None or r["stash"].gprec != ctx.stash.gprec]:
+            _run_nerf_dw(r)
+            bgs.remove(r)
         if col is not None:
             def also(g):
                 ops.color_dw_jobs(col["net"], col["feat_planes"], col["stash"], col["grad"], n, into=g)
                 if ref is not None:      # the heads' planes hold the 2 B gathered rows: products with their own tile count
                     for net_h, st_h, g_h in zip(ref["nets"], ref["st"], ref["grads"]):
                         ops.color_dw_jobs(net_h, st_h.feat, st_h, g_h, ref["n"], into=g, own_tiles=True)
+                for r in bgs:            # the background network's: their own tile count and device-side sample count
+                    ops.nerf_dw_jobs(r["net"], r["stash"], r["n"], into=g, n_dev=r["n_dev"])
 
-            jobs = ws.get(("sdf_col_jobs", n, prec) + col["key"] + (ref["key"] if ref is not None else ()),
+            jobs = ws.get(("sdf_col_jobs", n, prec) + col["key"] + (ref["key"] if ref is not None else ()) + sum((r["key"] for r in bgs), ()),
                           lambda: ops.sdf_dw_jobs(net, ctx.stash, bufs, grad, n, also=also))
             jobs.run()
             col["net"].wn_backward(col["grad"])
@@ -222,9 +231,31 @@ class NerfFn(torch.autograd.Function):
         d_density = torch.zeros(n, device=dev) if d_density is None else d_density.contiguous()
         d_rgb = torch.zeros(n, 3, device=dev) if d_rgb is None else d_rgb.contiguous()
         ops.nerf_bwd(net.blob, n, prec, d_density, d_rgb, ctx.stash, ctx.n_dev)
-        jobs = ws.get(("nerf_jobs", n, prec), lambda: ops.nerf_dw_jobs(net, ctx.stash, n))
-        jobs.run(n_dev=ctx.n_dev)
+        rec = dict(ws=ws, net=net, n=n, prec=prec, stash=ctx.stash, n_dev=ctx.n_dev,
+                   key=(ctx.stash.zbar.data_ptr(), net.raw_grad.data_ptr(), 0 if ctx.n_dev is None else ctx.n_dev.data_ptr()))
+        if ops.gemm_merge_enabled() and _PENDING_OPEN.get(dev, 0) > 0:
+            # an SDF network's backward is still to come in this pass (SdfValueGradFn.forward ran after this network's forward:
+            # NeuSRenderer.render evaluates the background right in front of the compositing): its launch takes these products
+            _PENDING_NERF.setdefault(dev, []).append(rec)
+
+            def flush():
+                for left in _PENDING_NERF.pop(dev, []):
+                    _run_nerf_dw(left)
+
+            torch.autograd.Variable._execution_engine.queue_callback(flush)
+        else:
+            _run_nerf_dw(rec)
         return None, None, None, None, None, None, None, None
+
+
+_PENDING_NERF = {}      # device -> records of NerfFn.backward waiting for the SDF network's weight-gradient launch
+_PENDING_OPEN = {}      # device -> SdfValueGradFn forwards (with a stash) whose backward has not run
+
+
+def _run_nerf_dw(rec):
+    """the background network's weight-gradient products as a launch of their own"""
+    jobs = rec["ws"].get(("nerf_jobs", rec["n"], rec["prec"]), lambda: ops.nerf_dw_jobs(rec["net"], rec["stash"], rec["n"]))
+    jobs.run(n_dev=rec["n_dev"])
 
 
 class OutsideAlphaFn(torch.autograd.Function):

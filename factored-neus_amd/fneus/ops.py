@@ -625,12 +625,17 @@ class GemmPPJobs:
     def __init__(self, device, tag="", target_wgs: int = 256, cost_floor: Optional[int] = None):
         self.device, self.tag, self.target = device, tag, target_wgs
         self.cost_floor = GEMM_COST_FLOOR if cost_floor is None else cost_floor
-        self.jobs, self.bytes = [], []
+        self.jobs, self.bytes, self.live = [], [], []
+        # share of their tiles that products with a device-side sample count are expected to sum (the host does not know the
+        # count when it hands out the workgroups): the background network's list holds its n_out samples per ray and the few of
+        # the other n that lie outside the unit sphere -- a quarter to a third of n + n_out
+        self.live_fraction = 0.3
         self.dev_table, self.n_wgs = None, 0
 
     def add(self, A: PPOperand, B: PPOperand, c_ptr, ldc, m, n, A2: Optional[PPOperand] = None, B2: Optional[PPOperand] = None,
-            bias_ptr=None, scale=1.0, n_tiles: int = 0):
-        """n_tiles: sample tiles of this product's planes when they differ from the launch's (finalize)"""
+            bias_ptr=None, scale=1.0, n_tiles: int = 0, n_dev: Optional[torch.Tensor] = None):
+        """n_tiles: sample tiles of this product's planes when they differ from the launch's (finalize); n_dev: device int32 count
+        of the samples they hold this step (the tensor must outlive the table)"""
         assert A.tiles <= 8 and B.tiles <= 8 and m <= 32 * A.tiles and n <= 32 * B.tiles
         j = _lib.FneusGemmPPJob()
         j.a_hi, j.a_lo, j.b_hi, j.b_lo = A.ptr(0), A.ptr(1), B.ptr(0), B.ptr(1)
@@ -641,6 +646,8 @@ class GemmPPJobs:
             j.a2_blk, j.b2_blk, j.a2_f0, j.b2_f0 = A2.blk, B2.blk, A2.f0, B2.f0
         j.mt, j.nt, j.c, j.bias, j.ldc, j.m, j.n, j.scale = A.tiles, B.tiles, c_ptr, bias_ptr, ldc, m, n, scale
         j.n_tiles = int(n_tiles)
+        j.n_dev = None if n_dev is None else n_dev.data_ptr()
+        self.live.append(1.0 if n_dev is None else self.live_fraction)
         self.jobs.append(j)
         # cost of one sample tile of this job, for the workgroup distribution.  The kernel's work per stage does not shrink
         # with a narrow operand (a stage always DMAs and multiplies full 16-fragment parts; there are no branches in its
@@ -653,7 +660,7 @@ class GemmPPJobs:
         """distribute ~target workgroups over the jobs in proportion to the bytes each streams; a workgroup owns at least
         `min_tiles` sample tiles (its epilogue is up to 65 536 atomics whatever it summed)"""
         tiles = [j.n_tiles if j.n_tiles > 0 else n_sample_tiles for j in self.jobs]
-        cost = [b * t for b, t in zip(self.bytes, tiles)]
+        cost = [b * t * f for b, t, f in zip(self.bytes, tiles, self.live)]
         tot = float(sum(cost))
         splits = [max(1, min(max(1, t // min_tiles), int(round(self.target * c / tot)))) for c, t in zip(cost, tiles)]
         # the kernel keeps ONE workgroup per CU (128 KB of LDS): a launch of more than `target` workgroups needs a second
@@ -686,6 +693,17 @@ class GemmPPJobs:
             return
         _launch("fneus_dw_gemm_pp:" + self.tag, lib.fneus_dw_gemm_pp, _ptr(self.dev_table), len(self.jobs), self.n_wgs,
                 self.n_sample_tiles, _ptr(n_dev), gprec, _stream())
+
+
+class _OwnPlanes:
+    """GemmPPJobs.add for products over another network's planes in a shared launch: their own sample-tile count and, where the
+    planes hold a different number of samples every step, their device-side count"""
+
+    def __init__(self, jobs: GemmPPJobs, n_tiles: int, n_dev: Optional[torch.Tensor] = None):
+        self.jobs, self.n_tiles, self.n_dev = jobs, n_tiles, n_dev
+
+    def add(self, *a, **k):
+        return self.jobs.add(*a, n_tiles=self.n_tiles, n_dev=self.n_dev, **k)
 
 
 def gemm_merge_enabled() -> bool:
@@ -798,10 +816,12 @@ def nerf_bwd(blob, n_pts, prec, d_density, d_rgb, stash: NerfStash, n_dev: Optio
             _ptr(n_dev), _stream())
 
 
-def nerf_dw_jobs(net: PackedNet, st: NerfStash, n: int) -> GemmPPJobs:
+def nerf_dw_jobs(net: PackedNet, st: NerfStash, n: int, into: Optional[GemmPPJobs] = None,
+                 n_dev: Optional[torch.Tensor] = None) -> GemmPPJobs:
     """weight / bias gradients of the 12 Linear layers from the fragment planes, accumulated straight into net.raw_grad
-    (plain layers: the raw layout IS the effective one)"""
-    g = GemmPPJobs(net.raw_grad.device, "nerf")
+    (plain layers: the raw layout IS the effective one).  into: append to that table (products with their own tile count and,
+    n_dev given, their own device-side sample count) instead of finalising a new one"""
+    g = _OwnPlanes(into, st.tiles, n_dev) if into is not None else GemmPPJobs(net.raw_grad.device, "nerf")
     O = PPOperand
     d = net.desc
     P = {name: i for i, name in enumerate(d["names"])}
@@ -822,6 +842,8 @@ def nerf_dw_jobs(net: PackedNet, st: NerfStash, n: int) -> GemmPPJobs:
     g.add(O(st.zhv, 0, 4), O(st.feat, 0, 8), W("views_linears.0"), 283, 128, 256, bias_ptr=Bv("views_linears.0"))
     g.add(O(st.zhv, 0, 4), O(st.dpe, 0, 1), W("views_linears.0", 256), 283, 128, 27)
     g.add(O(st.zout, 0, 1), O(st.hv, 0, 4), W("rgb_linear"), 128, 3, 128, bias_ptr=Bv("rgb_linear"))
+    if into is not None:
+        return into
     g.gprec = st.gprec
     return g.finalize(st.tiles)
 
@@ -978,7 +1000,9 @@ def bg_select_enabled() -> bool:
     return os.environ.get("FNEUS_BG_SELECT", "1") != "0"
 
 
-def outside_select(rays_o, rays_d, z_core, z_feed, sample_dist: float) -> OutsideSelection:
+def outside_select(rays_o, rays_d, z_core, z_feed, sample_dist: float, count: Optional[torch.Tensor] = None) -> OutsideSelection:
+    """count: int32[1] buffer for the list's length (a persistent one where tables hold its address: the weight-gradient job table
+    of a training step); a fresh one otherwise"""
     B, nt = z_feed.shape
     n = z_core.shape[1]
     dev = z_feed.device
@@ -989,7 +1013,7 @@ def outside_select(rays_o, rays_d, z_core, z_feed, sample_dist: float) -> Outsid
     o.dirs = torch.empty(o.cap, 3, dtype=f32, device=dev)
     o.dists = torch.empty(o.cap, dtype=f32, device=dev)
     o.sel = torch.empty(o.cap, dtype=i32, device=dev)
-    o.count = torch.empty(1, dtype=i32, device=dev)
+    o.count = torch.empty(1, dtype=i32, device=dev) if count is None else count
     o.alpha_full = torch.empty(B, nt, dtype=f32, device=dev)
     o.rgb_full = torch.empty(B, nt, 3, dtype=f32, device=dev)
     work = torch.empty(B + o.cap, dtype=i32, device=dev)

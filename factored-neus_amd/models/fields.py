@@ -453,6 +453,12 @@ class NeRF(nn.Module):
         """pack the current parameters (once per optimiser step, before rendering)"""
         self._be.refresh()
 
+    def select_count(self, cap: int) -> torch.Tensor:
+        """the int32 buffer that holds how many of `cap` rows a selected evaluation uses (ops.outside_select): one per size, like the
+        stash -- kernels and the weight-gradient job table of the step keep its address"""
+        self._be.ensure()
+        return self._be.ws.get(("select_count", cap), lambda: torch.zeros(1, dtype=torch.int32, device=self._be.anchor.device))
+
     def forward(self, input_pts, input_views, n_active=None):
         """input_pts [N,4] inverted-sphere points, input_views [N,3] -> raw density [N,1], raw rgb [N,3]
         n_active: device int32 count (ops.outside_select): only the first n_active rows are evaluated"""

@@ -133,7 +133,8 @@ class NeuSRenderer:
         if z_core is not None and not full and n <= 256 and ops.bg_select_enabled():
             # render() hands over the depths render_core works on: the network runs only where render_core uses its value
             # (ops.outside_select; samples inside the unit sphere take the foreground alone, renderer.py:350-356)
-            s = ops.outside_select(rays_o.contiguous(), rays_d.contiguous(), z_core.contiguous(), z_vals.contiguous(), sample_dist)
+            s = ops.outside_select(rays_o.contiguous(), rays_d.contiguous(), z_core.contiguous(), z_vals.contiguous(), sample_dist,
+                                   count=nerf.select_count(B * n) if hasattr(nerf, "select_count") else None)
             density, rgb_raw = nerf(s.pts4, s.dirs, n_active=s.count)
             alpha, rgb = OutsideAlphaSelFn.apply(density.reshape(-1), rgb_raw, s)
             return {"sampled_color": rgb, "alpha": alpha}
@@ -160,13 +161,18 @@ class NeuSRenderer:
     # ---- render_core (renderer.py:208-389) ------------------------------------------------------------------------
     def render_core(self, rays_o, rays_d, z_vals, sample_dist, sdf_network, deviation_network, color_network,
                     refColor_network, background_alpha=None, background_sampled_color=None, background_rgb=None,
-                    cos_anneal_ratio=0.0, loss_args=None):
+                    cos_anneal_ratio=0.0, loss_args=None, background_fn=None):
+        """background_fn() -> (alpha, sampled_color): the background evaluated HERE, right in front of the compositing, instead of
+        ahead of the call (render() passes it: with the background network's forward behind the SDF network's, autograd runs its
+        backward first and the SDF network's weight-gradient launch can take its products along)"""
         B, n = z_vals.shape
         train = torch.is_grad_enabled()
         dists, mid_z = ops.sections(z_vals.contiguous(), sample_dist)
         samples = RaySamples(rays_o, rays_d, mid_z.reshape(-1), n)
         sdf, feat, normal = sdf_network.value_feature_normal(samples, train)
         rgb = color_network.color_samples(samples, normal, feat, sdf_network, train)
+        if background_fn is not None:
+            background_alpha, background_sampled_color = background_fn()
         # inv_s = clip(exp(10 variance)) (renderer.py:245) is applied inside the compositing kernels
         (color, weights, wsum, wpair, eik_num, wmax, cdf, inside, eik_den, min_idx, sdf_mask_u8) = CompositeFn.apply(
             sdf, normal, rgb, deviation_network.variance, rays_o, rays_d, mid_z, dists,
@@ -270,16 +276,16 @@ class NeuSRenderer:
                 z_vals = self._hierarchical_z(rays_o, rays_d, z_vals.contiguous())
             n = self.n_samples + self.n_importance
         ops.overlap_join()                   # the packs issued beside the sampler are needed from here on
-        background_alpha = background_sampled_color = None
+        background_fn = None
         if self.n_outside > 0:                                                    # renderer.py:452-458
-            # sort(cat(z_vals, z_vals_outside)) of two sorted rows = one stable rank merge (fneus_merge)
-            z_vals_feed, _ = ops.merge(z_vals.contiguous(), None, z_vals_outside.expand(B, -1).contiguous(), None)
-            ret_outside = self.render_core_outside(rays_o, rays_d, z_vals_feed, sample_dist, self.nerf, full=False, z_core=z_vals)
-            background_sampled_color, background_alpha = ret_outside["sampled_color"], ret_outside["alpha"]
+            def background_fn():
+                # sort(cat(z_vals, z_vals_outside)) of two sorted rows = one stable rank merge (fneus_merge)
+                z_vals_feed, _ = ops.merge(z_vals.contiguous(), None, z_vals_outside.expand(B, -1).contiguous(), None)
+                ret_outside = self.render_core_outside(rays_o, rays_d, z_vals_feed, sample_dist, self.nerf, full=False, z_core=z_vals)
+                return ret_outside["alpha"], ret_outside["sampled_color"]
         ret = self.render_core(rays_o, rays_d, z_vals, sample_dist, self.sdf_network, self.deviation_network,
                                self.color_network, self.refColor_network, background_rgb=background_rgb,
-                               background_alpha=background_alpha, background_sampled_color=background_sampled_color,
-                               cos_anneal_ratio=cos_anneal_ratio, loss_args=loss_args)
+                               background_fn=background_fn, cos_anneal_ratio=cos_anneal_ratio, loss_args=loss_args)
         weights = ret["weights"]
         return {
             "color_fine": ret["color"],

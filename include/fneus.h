@@ -97,6 +97,8 @@ typedef struct FneusGemmPPJob {
     int32_t wg_base, splits;                    /* first workgroup of the job, number of sample-range splits       */
     int32_t n_tiles, pad_;                      /* sample tiles of THIS product's planes (products over other planes in
                                                    the same launch); 0 = the launch's n_sample_tiles                  */
+    const int32_t* n_dev;                       /* NULL, or a DEVICE count of the samples this product's planes hold
+                                                   (fneus_outside_select): only their tiles are summed                */
 } FneusGemmPPJob;
 
 /* one contiguous run of parameters for fneus_adam (all device pointers) */
