@@ -86,7 +86,7 @@ class Stage3Trainer:
         mask = (mask > 0.5).float() if self.mask_weight > 0.0 else torch.ones_like(mask)
         self._direct_grads(True)
         try:
-            out = self.renderer.mateIllu_render(rays_o, rays_d, None, None, fixed_shape=True)
+            out = self.renderer.mateIllu_render(rays_o, rays_d, None, None, fixed_shape=True, keys=("rgb",))
         finally:
             self._direct_grads(False)
         losses = stage3_loss(out, true_rgb, mask, self.reduce)

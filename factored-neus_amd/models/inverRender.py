@@ -215,7 +215,7 @@ FUSED_SG = True      # stage 3 on fneus_sg_render_fwd / _bwd (one launch each wa
 
 
 def _render_with_all_sg_fused(points, normal, viewdirs, lgtSGs, f0: float, specular_albedo, roughness, diffuse_albedo,
-                              lvis_network, indir_lgtSGs, u_theta, u_phi, point_mask=None):
+                              lvis_network, indir_lgtSGs, u_theta, u_phi, point_mask=None, want=None):
     """render_with_all_sg on the fused kernels: visibility (fneus_lvis_visibility), then every (point, lobe) pair of the 128
     direct and the 24 indirect SGs in one launch; the clamps of integrate_rgb (:277), of render_with_sg (:440) and the tone
     mapping (:306-309) are element-wise ops on [n, 3] tensors"""
@@ -228,22 +228,25 @@ def _render_with_all_sg_fused(points, normal, viewdirs, lgtSGs, f0: float, specu
     spec_d, diff_d, spec_i, diff_i = (torch.clamp(sums[:, k], 0.0, 1.0) for k in range(4))
     env = torch.clamp(spec_d + diff_d, 0.0, 1.0)
     indir = torch.clamp(spec_i + diff_i, 0.0, 1.0) if indir_lgtSGs is not None else torch.zeros_like(points)
-    return {"specular_loss": 0, "diffuse_loss": 0,
-            "diffuse_rgb": tonemap_clip(diff_d), "specular_rgb": tonemap_clip(spec_d),
-            "lvis_mean": vis.mean(dim=0)[:, None].expand(-1, 3),
-            "rgb": tonemap_clip(env + indir), "indir_rgb": tonemap_clip(indir),
-            "env_rgb": tonemap_clip(env)}
+    ret = {"specular_loss": 0, "diffuse_loss": 0}
+    for k, make in (("diffuse_rgb", lambda: tonemap_clip(diff_d)), ("specular_rgb", lambda: tonemap_clip(spec_d)),
+                    ("lvis_mean", lambda: vis.mean(dim=0)[:, None].expand(-1, 3)), ("rgb", lambda: tonemap_clip(env + indir)),
+                    ("indir_rgb", lambda: tonemap_clip(indir)), ("env_rgb", lambda: tonemap_clip(env))):
+        if want is None or k in want:        # (a training step reads `rgb` alone: each of the others is a launch or two)
+            ret[k] = make()
+    return ret
 
 
 def render_with_all_sg(points, normal, viewdirs, lgtSGs, specular_reflectance, specular_albedo, roughness, diffuse_albedo,
                        gt_specular_linear=None, lvis_network=None, indir_lgtSGs=None, u_theta=None, u_phi=None,
-                       specular_reflectance_value=None, point_mask=None):
+                       specular_reflectance_value=None, point_mask=None, want=None):
     """inverRender.py:286-311: direct light (with visibility) + indirect light, tone mapped.  point_mask [n] bool (fixed-shape
-    step): rows marked False are placeholders whose results the caller discards -- their visibility is not evaluated"""
+    step): rows marked False are placeholders whose results the caller discards -- their visibility is not evaluated.
+    want: set of result keys the caller reads (None = all); the others may be left out"""
     if (FUSED_SG and points.is_cuda and lvis_network is not None and specular_reflectance_value is not None
             and (indir_lgtSGs is None or not indir_lgtSGs.requires_grad)):
         return _render_with_all_sg_fused(points, normal, viewdirs, lgtSGs, float(specular_reflectance_value), specular_albedo,
-                                         roughness, diffuse_albedo, lvis_network, indir_lgtSGs, u_theta, u_phi, point_mask)
+                                         roughness, diffuse_albedo, lvis_network, indir_lgtSGs, u_theta, u_phi, point_mask, want)
     n = normal.shape[0]
     ret = render_with_sg(points, normal, viewdirs, lgtSGs[None].expand(n, -1, -1), specular_reflectance, specular_albedo,
                          roughness, diffuse_albedo, gt_specular_linear, lvis_network=lvis_network, u_theta=u_theta, u_phi=u_phi)
@@ -316,7 +319,8 @@ class EnvmapMaterialNetwork(nn.Module):
         return torch.where(some, kl, torch.zeros_like(kl))
 
     def forward(self, points, ray_dirs, n, f, gt_specular_linear, indiLgt, lvis_network, u_theta=None, u_phi=None,
-                point_mask=None):
+                point_mask=None, want=None):
+        """want: set of result keys the caller reads (None = all, the reference's dict); the losses are always returned"""
         n = n / (torch.norm(n, dim=-1, keepdim=True) + TINY_NUMBER)
         ray_dirs = ray_dirs / (torch.norm(ray_dirs, dim=-1, keepdim=True) + TINY_NUMBER)
         view_dirs = -ray_dirs
@@ -333,10 +337,12 @@ class EnvmapMaterialNetwork(nn.Module):
         ret = render_with_all_sg(points, n, view_dirs, self.lgtSGs, self.specular_reflectance, specular_albedo, roughness,
                                  diffuse_albedo, gt_specular_linear, lvis_network=lvis_network, indir_lgtSGs=indiLgt,
                                  u_theta=u_theta, u_phi=u_phi, specular_reflectance_value=self.specular_reflectance_value,
-                                 point_mask=point_mask)
-        ret.update({"roughness": roughness, "diffuse_albedo": tonemap_clip(diffuse_albedo),
-                    "specular_albedo": tonemap_clip(specular_albedo), "encoder_loss": loss,
-                    "smooth_loss": 0.0})
+                                 point_mask=point_mask, want=want)
+        ret.update({"roughness": roughness, "encoder_loss": loss, "smooth_loss": 0.0})
+        if want is None or "diffuse_albedo" in want:
+            ret["diffuse_albedo"] = tonemap_clip(diffuse_albedo)
+        if want is None or "specular_albedo" in want:
+            ret["specular_albedo"] = tonemap_clip(specular_albedo)
         return ret
 
     def get_light(self):

@@ -381,14 +381,18 @@ class NeuSRenderer:
                 out[k] = out[k].index_copy(0, idx, res[k].to(out[k].dtype))
         return out
 
-    def mateIllu_render(self, rays_o, rays_d, near, far, u_theta=None, u_phi=None, fixed_shape=False, z_vals_override=None):
+    def mateIllu_render(self, rays_o, rays_d, near, far, u_theta=None, u_phi=None, fixed_shape=False, z_vals_override=None,
+                        keys=None):
         """renderer.py:630-726: stage 3.  Geometry (SDF), the RefColor head, Lvis and IndirectLight are frozen inputs
         (mateIllu.py:83-95 trains the EnvmapMaterialNetwork only): hit points by fneus_ray_hit, normal + feature by K2, the
         diffuse / specular split by the fused RefColor heads, all without stash.  Rows of rays without a hit hold 1.
         fixed_shape=True: every ray is evaluated (rays without a hit at their origin) and masked afterwards, the latent
         sparsity term averages over the hit points only: same values and gradients, no host synchronisation, capturable
         in a hipGraph (fneus/trainer3.py).
-        u_theta, u_phi [128, 32]: the uniform draws of the visibility sampler (inverRender.py:152-153; tests)."""
+        u_theta, u_phi [128, 32]: the uniform draws of the visibility sampler (inverRender.py:152-153; tests).
+        keys: the per-ray entries the caller reads (None = the reference's whole dict).  The training step reads `rgb` (plus
+        `sdf_mask` and the loss terms, which are always there): every other entry is tone mapping, a fill and a select on [B, 3]
+        tensors, a launch each -- 35 launches of the fixed-shape step."""
         from models.inverRender import srgb_to_linear
         B = len(rays_o)
         dev = rays_o.device
@@ -402,9 +406,14 @@ class NeuSRenderer:
             idx = None if fixed_shape else sdf_mask.nonzero(as_tuple=True)[0]
         ray_keys = ("rgb", "env_rgb", "indir_rgb", "diffuse_albedo", "specular_albedo", "diffuse_rgb", "specular_rgb", "roughness",
                     "lvis_mean")
+        want = None if keys is None else set(keys)
+        need = lambda k: want is None or k in want
+        extra_keys = ("gt_specular_linear", "gt_diffuse_srgb", "n_out")
+        ray_keys = tuple(k for k in ray_keys if need(k))
         one3 = lambda: torch.ones(B, 3, device=dev)
-        out = {k: one3() for k in ray_keys + ("gt_specular_linear", "gt_diffuse_srgb", "n_out")}
-        out["roughness"] = torch.ones(B, 1, device=dev)
+        out = {k: one3() for k in ray_keys + tuple(k for k in extra_keys if need(k))}
+        if need("roughness"):
+            out["roughness"] = torch.ones(B, 1, device=dev)
         out.update(sdf_mask=sdf_mask, diffuse_loss=0, specular_loss=0, encoder_loss=0, smooth_loss=0)
         if fixed_shape or idx.numel() > 0:
             with torch.no_grad():
@@ -413,13 +422,16 @@ class NeuSRenderer:
                 surf = RaySamples(pts=pts_surf, dirs=rays_surf)
                 _, f_surf, n_surf = self.sdf_network.value_feature_normal(surf, False)
                 self.refColor_network.refresh()
-                diffuse, spec = self.refColor_network.heads(surf, f_surf, n_surf, False)
-                ref = self.refColor_network.shade(diffuse, spec)
-                specular_linear = srgb_to_linear(ref["specular_rgb"])
+                ref, specular_linear = None, None
+                if need("gt_specular_linear") or need("gt_diffuse_srgb"):     # (logged only: the networks below do not read them)
+                    diffuse, spec = self.refColor_network.heads(surf, f_surf, n_surf, False)
+                    ref = self.refColor_network.shade(diffuse, spec)
+                    specular_linear = srgb_to_linear(ref["specular_rgb"])
                 indiLgt = self.indiLgt_network(pts_surf)
             m = self.mateIllu_network(pts_surf, rays_surf, n_surf, f_surf, specular_linear, indiLgt, self.lvis_network,
-                                      u_theta=u_theta, u_phi=u_phi, point_mask=sdf_mask if fixed_shape else None)
-            extra = (("gt_specular_linear", specular_linear), ("gt_diffuse_srgb", ref["diffuse_rgb"]), ("n_out", n_surf))
+                                      u_theta=u_theta, u_phi=u_phi, point_mask=sdf_mask if fixed_shape else None, want=want)
+            extra = tuple((k, v) for k, v in (("gt_specular_linear", specular_linear),
+                                              ("gt_diffuse_srgb", None if ref is None else ref["diffuse_rgb"]), ("n_out", n_surf)) if need(k))
             if fixed_shape:
                 sel = sdf_mask[:, None]
                 for k in ray_keys:
