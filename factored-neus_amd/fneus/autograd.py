@@ -63,8 +63,8 @@ class SdfValueGradFn(torch.autograd.Function):
         sdf, feat, normal = ops.sdf_fwd_grad(net.blob, n, prec, stash, train, **samples.kw())
         ctx.net, ctx.samples, ctx.prec, ctx.ws, ctx.stash, ctx.n = net, samples, prec, ws, stash, n
         ctx.generation = ws.stamp(stash)
-        if train:       # (a flag, not a count: a forward whose backward never runs must not stick)
-            _PENDING_OPEN[anchor.device] = 1
+        if train:       # the forward whose backward is still to come (its stamp, not a count: a forward whose backward never runs
+            _PENDING_OPEN[anchor.device] = (id(ws), ctx.generation)       # is replaced by the next one)
         return sdf, feat, normal
 
     @staticmethod
@@ -97,9 +97,15 @@ class SdfValueGradFn(torch.autograd.Function):
         # zeroed once: fneus_wn_backward clears what it reads, so the buffer is zero again after every step
         grad = ws.get(("sdf_grad", n), lambda: torch.zeros(net.n_params, dtype=torch.float32, device=dev))
         # the colour network's products over the same samples wait here (ColorFn.backward): one launch for both networks
-        _PENDING_OPEN[dev] = 0
+        # products that wait for this launch: only records made for THIS forward (a backward pass that died half way leaves its
+        # records behind: they must not ride in a later step's launch)
+        mine = (id(ws), ctx.generation)
+        if _PENDING_OPEN.get(dev) == mine:
+            _PENDING_OPEN[dev] = None
         col, ref = ws.cache.pop("pending_color_dw", None), ws.cache.pop("pending_ref_dw", None)
-        bgs = [r for r in _PENDING_NERF.pop(dev, [])]
+        col = col if col is not None and col["for"] == mine else None
+        ref = ref if ref is not None and ref["for"] == mine else None
+        bgs = [r for r in _PENDING_NERF.pop(dev, {}).values() if r["for"] == mine]
         if col is not None and (col["n"] != n or col["stash"].gprec != ctx.stash.gprec):
             _run_color_dw(col)
             col = None
@@ -186,6 +192,7 @@ class ColorFn(torch.autograd.Function):
             feat_planes = ctx.sdf_ws.cache[("sdf_stash", n, prec, True)].feat
         grad = ws.get(("col_grad", n), lambda: torch.zeros(net.n_params, dtype=torch.float32, device=rgb.device))
         col = dict(ws=ws, net=net, n=n, prec=prec, stash=ctx.stash, grad=grad, feat_planes=feat_planes,
+                   **{"for": (id(ctx.sdf_ws), getattr(ctx.sdf_ws, "generation", None))},
                    key=(feat_planes.data_ptr(), tuple(feat_planes.shape), ctx.stash.zbar.data_ptr(), grad.data_ptr()))
         # Head 0 reads the SDF network's feature planes, so the SDF network's backward follows in this backward pass whenever the
         # features carry a gradient: its weight-gradient launch takes these products along (same samples, one launch instead of
@@ -198,9 +205,8 @@ class ColorFn(torch.autograd.Function):
             sdf_ws.cache["pending_color_dw"] = col
 
             def flush():
-                left = sdf_ws.cache.pop("pending_color_dw", None)
-                if left is not None:
-                    _run_color_dw(left)
+                if sdf_ws.cache.get("pending_color_dw") is col:
+                    _run_color_dw(sdf_ws.cache.pop("pending_color_dw"))
 
             torch.autograd.Variable._execution_engine.queue_callback(flush)
         else:
@@ -233,13 +239,15 @@ class NerfFn(torch.autograd.Function):
         ops.nerf_bwd(net.blob, n, prec, d_density, d_rgb, ctx.stash, ctx.n_dev)
         rec = dict(ws=ws, net=net, n=n, prec=prec, stash=ctx.stash, n_dev=ctx.n_dev,
                    key=(ctx.stash.zbar.data_ptr(), net.raw_grad.data_ptr(), 0 if ctx.n_dev is None else ctx.n_dev.data_ptr()))
-        if ops.gemm_merge_enabled() and _PENDING_OPEN.get(dev, 0) > 0:
+        if ops.gemm_merge_enabled() and _PENDING_OPEN.get(dev) is not None:
             # an SDF network's backward is still to come in this pass (SdfValueGradFn.forward ran after this network's forward:
             # NeuSRenderer.render evaluates the background right in front of the compositing): its launch takes these products
-            _PENDING_NERF.setdefault(dev, []).append(rec)
+            rec["for"] = _PENDING_OPEN[dev]
+            _PENDING_NERF.setdefault(dev, {})[id(net)] = rec          # (one record per network: a stale one is replaced)
 
             def flush():
-                for left in _PENDING_NERF.pop(dev, []):
+                left = _PENDING_NERF.get(dev, {}).pop(id(net), None)
+                if left is rec:
                     _run_nerf_dw(left)
 
             torch.autograd.Variable._execution_engine.queue_callback(flush)
@@ -248,8 +256,8 @@ class NerfFn(torch.autograd.Function):
         return None, None, None, None, None, None, None, None
 
 
-_PENDING_NERF = {}      # device -> records of NerfFn.backward waiting for the SDF network's weight-gradient launch
-_PENDING_OPEN = {}      # device -> SdfValueGradFn forwards (with a stash) whose backward has not run
+_PENDING_NERF = {}      # device -> {id(network): record of NerfFn.backward waiting for the SDF network's weight-gradient launch}
+_PENDING_OPEN = {}      # device -> (id(workspace), stash stamp) of the latest SdfValueGradFn forward whose backward has not run
 
 
 def _run_nerf_dw(rec):
@@ -363,6 +371,7 @@ class RefHeadsFn(torch.autograd.Function):
             return jobs.finalize(st[0].tiles)
 
         ref = dict(ws=ws, n=n, prec=prec, build=build, nets=(net_cd, net_vd), grads=(g_cd, g_vd), st=st,
+                   **{"for": None if ctx.gathered is None else (id(ctx.gathered[0]), getattr(ctx.gathered[0], "generation", None))},
                    key=(st[0].zbar.data_ptr(), st[1].zbar.data_ptr(), grad.data_ptr()))
         early = getattr(ctx.gathered[0], "color_grads_early", None) if ctx.gathered is not None else None
         if ctx.gathered is not None and ops.gemm_merge_enabled() and not (early is not None and early()):
@@ -372,9 +381,8 @@ class RefHeadsFn(torch.autograd.Function):
             sdf_ws.cache["pending_ref_dw"] = ref
 
             def flush():
-                left = sdf_ws.cache.pop("pending_ref_dw", None)
-                if left is not None:
-                    _run_ref_dw(left)
+                if sdf_ws.cache.get("pending_ref_dw") is ref:
+                    _run_ref_dw(sdf_ws.cache.pop("pending_ref_dw"))
 
             torch.autograd.Variable._execution_engine.queue_callback(flush)
         else:
