@@ -9,6 +9,9 @@
 // The 19 input k-steps of a set are written when the set's last reader of the running unit has finished: the feature rows
 // (fp32 [n][256]) are split into hi / lo fragments by all 8 waves (k-steps 2w, 2w + 1 of both tiles), the side inputs by two.
 #include <stdlib.h>
+#ifndef FNEUS_P2_DEPTH
+#define FNEUS_P2_DEPTH 2            // weight-prefetch distance of this file's passes (p2_engine.h: 3).  30 spilled registers at depth 3, 8 at depth 2: 2 us
+#endif                              // (tools/runs/r04_ab.sh k2d2 / k2d1 / cold2)
 #include "p2_relu.h"
 #include "fneus_kernels.h"
 #include "color_p2.h"

@@ -5,6 +5,9 @@
 // The reverse sweep (normal = d sdf / d x, the a_l planes) is a launch of its own (sdf_kernels.hip, sdf_grad_rev): it needs
 // nothing from this kernel but the sigma' blocks, which went through memory inside the fused kernel as well.
 #include <stdlib.h>
+#ifndef FNEUS_P2_DEPTH
+#define FNEUS_P2_DEPTH 2            // weight-prefetch distance of this file's passes (p2_engine.h: 3).  48 spilled registers at depth 3 (scratch reloads inside the passes), 23 at depth 2: K2's forward launch 10-22 us faster by box
+#endif                              // (tools/runs/r04_ab.sh k2d2 / k2d1 / cold2)
 #include "p2_train.h"
 #include "fneus_kernels.h"
 #include "sdf_w8.h"
