@@ -212,7 +212,8 @@ __global__ void __launch_bounds__(64) merge_upsample_kernel(const float* __restr
                                                             const float* __restrict__ z_new, const float* __restrict__ s_new, int k,
                                                             float inv_s, int k_next, float* __restrict__ z_out,
                                                             float* __restrict__ s_out, float* __restrict__ z_next,
-                                                            float* __restrict__ z_final) {
+                                                            float* __restrict__ z_final, float sample_dist,
+                                                            float* __restrict__ dists, float* __restrict__ mid_z) {
     __shared__ float zin[MAXN], sin_[MAXN], zs[MAXN], ss[MAXN], cdf[MAXN + 1], znx[MAXN];
     const int ray = blockIdx.x, lane = threadIdx.x;
     const int n = m + k;
@@ -252,6 +253,16 @@ __global__ void __launch_bounds__(64) merge_upsample_kernel(const float* __restr
             rank += (zj < z) || (zj == z && j < i);
         }
         z_final[(size_t)ray * nf + rank] = z;
+        if (dists) zin[rank] = z;                    // (zin is free: the first merge has read it)
+    }
+    if (dists == nullptr) return;
+    // the sections of the final depths (sections_kernel's expressions: renderer.py:223-226) -- what render_core asks for next
+    __syncthreads();
+    for (int i = lane; i < nf; i += 64) {
+        const float z0 = zin[i];
+        const float dd = (i + 1 < nf) ? zin[i + 1] - z0 : sample_dist;
+        dists[(size_t)ray * nf + i] = dd;
+        mid_z[(size_t)ray * nf + i] = z0 + dd * 0.5f;
     }
 }
 
@@ -984,14 +995,15 @@ extern "C" int fneus_merge(const float* z_old, const float* s_old, int m, const 
 
 extern "C" int fneus_merge_upsample(const float* rays_o, const float* rays_d, const float* z_old, const float* s_old, int m,
                                     const float* z_new, const float* s_new, int k, int n_rays, float inv_s, int k_next,
-                                    float* z_out, float* s_out, float* z_next, float* z_final, fneus_stream_t stream_) {
+                                    float* z_out, float* s_out, float* z_next, float* z_final, float sample_dist, float* dists,
+                                    float* mid_z, fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     fneus::clear_status();
     if (n_rays <= 0) return 0;
     FN_CHECK_N(m + k + (z_final ? k_next : 0));
     if (k_next < 1 || k_next > MAXN) { set_last_error("fneus_merge_upsample: k_next must be in [1, 256]"); return -2; }
     hipLaunchKernelGGL(merge_upsample_kernel, dim3(n_rays), dim3(64), 0, stream, rays_o, rays_d, z_old, s_old, m, z_new, s_new, k,
-                       inv_s, k_next, z_out, s_out, z_next, z_final);
+                       inv_s, k_next, z_out, s_out, z_next, z_final, sample_dist, (z_final && mid_z) ? dists : nullptr, mid_z);
     return fneus::launch_status();
 }
 

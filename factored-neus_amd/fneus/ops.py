@@ -1164,9 +1164,10 @@ def merge(z_old, s_old, z_new, s_new):
     return z_out, s_out
 
 
-def merge_upsample(rays_o, rays_d, z_old, s_old, z_new, s_new, inv_s: float, k_next: int, last: bool):
+def merge_upsample(rays_o, rays_d, z_old, s_old, z_new, s_new, inv_s: float, k_next: int, last: bool, sample_dist=None):
     """cat_z_vals of one up-sampling step + up_sample of the next in one launch -> z_out, s_out [B, m + k], z_next [B, k_next],
-    z_final [B, m + k + k_next] (last step only, else None)"""
+    z_final [B, m + k + k_next] (last step only, else None).  sample_dist given (with last): also the sections of z_final in
+    the same launch; the result is then (z_out, s_out, z_next, z_final, dists, mid_z)"""
     B, m = z_old.shape
     k = z_new.shape[1]
     dev = z_old.device
@@ -1174,8 +1175,14 @@ def merge_upsample(rays_o, rays_d, z_old, s_old, z_new, s_new, inv_s: float, k_n
     s_out = torch.empty_like(z_out)
     z_next = torch.empty(B, k_next, dtype=torch.float32, device=dev)
     z_final = torch.empty(B, m + k + k_next, dtype=torch.float32, device=dev) if last else None
+    sec = last and sample_dist is not None
+    dists = torch.empty_like(z_final) if sec else None
+    mid_z = torch.empty_like(z_final) if sec else None
     _launch("fneus_merge_upsample", lib.fneus_merge_upsample, _ptr(rays_o), _ptr(rays_d), _ptr(z_old), _ptr(s_old), m, _ptr(z_new),
-            _ptr(s_new), k, B, float(inv_s), int(k_next), _ptr(z_out), _ptr(s_out), _ptr(z_next), _ptr(z_final), _stream())
+            _ptr(s_new), k, B, float(inv_s), int(k_next), _ptr(z_out), _ptr(s_out), _ptr(z_next), _ptr(z_final),
+            float(sample_dist) if sec else 0.0, _ptr(dists), _ptr(mid_z), _stream())
+    if sample_dist is not None:
+        return z_out, s_out, z_next, z_final, dists, mid_z
     return z_out, s_out, z_next, z_final
 
 

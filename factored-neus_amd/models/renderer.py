@@ -118,8 +118,11 @@ class NeuSRenderer:
             new_z = ops.upsample(ro, rd, z_vals, sdf, k, 64.0)
             for i in range(1, steps):
                 new_sdf = self.sdf_network.sdf_samples(RaySamples(rays_o, rays_d, new_z.reshape(-1), k)).reshape(B, k)
-                z_vals, sdf, new_z, z_final = ops.merge_upsample(ro, rd, z_vals, sdf, new_z, new_sdf.contiguous(),
-                                                                 float(64 * 2 ** i), k, last=(i + 1 == steps))
+                # (the last launch also writes the sections of the final depths: render_core asks for them next)
+                z_vals, sdf, new_z, z_final, dists, mid_z = ops.merge_upsample(ro, rd, z_vals, sdf, new_z, new_sdf.contiguous(),
+                                                                               float(64 * 2 ** i), k, last=(i + 1 == steps),
+                                                                               sample_dist=2.0 / self.n_samples)
+        self._final_sections = (z_final, 2.0 / self.n_samples, dists, mid_z)
         return z_final
 
     # ---- render_core_outside (renderer.py:112-149): inverted-sphere background NeRF++, womask configs only --------
@@ -167,7 +170,11 @@ class NeuSRenderer:
         backward first and the SDF network's weight-gradient launch can take its products along)"""
         B, n = z_vals.shape
         train = torch.is_grad_enabled()
-        dists, mid_z = ops.sections(z_vals.contiguous(), sample_dist)
+        fs = self.__dict__.pop("_final_sections", None)          # the sampler's last launch has made them for ITS result
+        if fs is not None and fs[0] is z_vals and fs[1] == sample_dist:
+            dists, mid_z = fs[2], fs[3]
+        else:
+            dists, mid_z = ops.sections(z_vals.contiguous(), sample_dist)
         samples = RaySamples(rays_o, rays_d, mid_z.reshape(-1), n)
         sdf, feat, normal = sdf_network.value_feature_normal(samples, train)
         rgb = color_network.color_samples(samples, normal, feat, sdf_network, train)

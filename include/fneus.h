@@ -283,10 +283,12 @@ int fneus_merge(const float* z_old, const float* s_old, int m, const float* z_ne
                 float* z_out, float* s_out, fneus_stream_t stream);
 /* cat_z_vals of one up-sampling step fused with up_sample of the next (renderer.py:433-446 is a per-ray recurrence):
  * z_out, s_out [B][m + k] = merge; z_next [B][k_next] = up_sample(z_out, s_out, inv_s); z_final (may be NULL; the last
- * step, renderer.py:445 last=True) [B][m + k + k_next] = merge(z_out | z_next).  Bit-identical to the separate calls. */
+ * step, renderer.py:445 last=True) [B][m + k + k_next] = merge(z_out | z_next).  Bit-identical to the separate calls.
+ * dists, mid_z (may be NULL; with z_final): fneus_sections of z_final in the same launch -- what render_core asks for next. */
 int fneus_merge_upsample(const float* rays_o, const float* rays_d, const float* z_old, const float* s_old, int m,
                          const float* z_new, const float* s_new, int k, int n_rays, float inv_s, int k_next, float* z_out,
-                         float* s_out, float* z_next, float* z_final, fneus_stream_t stream);
+                         float* s_out, float* z_next, float* z_final, float sample_dist, float* dists, float* mid_z,
+                         fneus_stream_t stream);
 /* One training batch [B][10] = rays_o, rays_d, rgb, mask per row (what Dataset.gen_random_rays_at returns, dataset.py:133-151)
  * -> the four contiguous arrays the kernels take (exp_runner.py:134-139 slices the same columns). */
 int fneus_split_batch(const float* data /*[B][10]*/, int n_rays, float* rays_o /*[B][3]*/, float* rays_d /*[B][3]*/,
