@@ -74,6 +74,15 @@ def test_fused_merge_upsample_is_bit_identical_to_the_separate_kernels(m, k, las
     z2, s2, nz2, zf2 = ops.merge_upsample(ro, rd, z, s, new_z, new_s, inv_s, k, last)
     assert torch.equal(z1, z2) and torch.equal(s1, s2) and torch.equal(nz, nz2)
     assert (zf2 is None) == (not last) and (not last or torch.equal(zf, zf2))
+    # with a section length given, the last launch also writes fneus_sections of its result
+    sd = 2.0 / 64
+    z3, s3, nz3, zf3, dists3, mid3 = ops.merge_upsample(ro, rd, z, s, new_z, new_s, inv_s, k, last, sample_dist=sd)
+    assert torch.equal(z3, z2) and torch.equal(s3, s2) and torch.equal(nz3, nz2)
+    if last:
+        dists, mid = ops.sections(zf, sd)
+        assert torch.equal(zf3, zf) and torch.equal(dists3, dists) and torch.equal(mid3, mid)
+    else:
+        assert zf3 is None and dists3 is None and mid3 is None
 
 
 def test_fused_sampler_in_render_is_bit_identical():
