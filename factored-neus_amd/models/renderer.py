@@ -161,6 +161,13 @@ class NeuSRenderer:
             cache[key] = torch.ones(B, 3, device=device)
         return cache[key]
 
+    def _sections(self, z_vals, sample_dist):
+        """section lengths and mid points (renderer.py:223-226): the sampler's last launch has written them for ITS result"""
+        fs = self.__dict__.pop("_final_sections", None)
+        if fs is not None and fs[0] is z_vals and fs[1] == sample_dist:
+            return fs[2], fs[3]
+        return ops.sections(z_vals.contiguous(), sample_dist)
+
     # ---- render_core (renderer.py:208-389) ------------------------------------------------------------------------
     def render_core(self, rays_o, rays_d, z_vals, sample_dist, sdf_network, deviation_network, color_network,
                     refColor_network, background_alpha=None, background_sampled_color=None, background_rgb=None,
@@ -170,11 +177,7 @@ class NeuSRenderer:
         backward first and the SDF network's weight-gradient launch can take its products along)"""
         B, n = z_vals.shape
         train = torch.is_grad_enabled()
-        fs = self.__dict__.pop("_final_sections", None)          # the sampler's last launch has made them for ITS result
-        if fs is not None and fs[0] is z_vals and fs[1] == sample_dist:
-            dists, mid_z = fs[2], fs[3]
-        else:
-            dists, mid_z = ops.sections(z_vals.contiguous(), sample_dist)
+        dists, mid_z = self._sections(z_vals, sample_dist)
         samples = RaySamples(rays_o, rays_d, mid_z.reshape(-1), n)
         sdf, feat, normal = sdf_network.value_feature_normal(samples, train)
         rgb = color_network.color_samples(samples, normal, feat, sdf_network, train)
@@ -333,7 +336,7 @@ class NeuSRenderer:
                 z_vals = self._hierarchical_z(rays_o, rays_d, z_vals.contiguous()) if z_vals_override is None \
                     else z_vals_override.detach().float().contiguous()
                 n = self.n_samples + self.n_importance
-            dists, mid_z = ops.sections(z_vals.contiguous(), sample_dist)
+            dists, mid_z = self._sections(z_vals, sample_dist)
             sdf = self.sdf_network.sdf_samples(RaySamples(rays_o, rays_d, mid_z.reshape(-1), n))
             pts = rays_o[:, None, :] + rays_d[:, None, :] * mid_z[..., None]
             inside_sphere = torch.linalg.norm(pts, ord=2, dim=-1) < 1.0
