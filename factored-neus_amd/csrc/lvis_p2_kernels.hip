@@ -2,8 +2,12 @@
 // models/fields.py:338-369) in the two-pass pipelined form of p2_engine.h: the same tiles ((point, lobe) pair = 32 directions),
 // operands and per-accumulator summation order as lvis_visibility_tph_kernel.
 //
-// A work item is a (point, chunk of 32 lobes) pair as there; its lobes that face the point (about half) are listed first, then
-// taken four at a time: a unit = 4 tiles in two sets A = {0, 1}, B = {2, 3}, 8 waves, wave w owns output tile w of every layer.
+// A work item is a (point, chunk of 64 lobes) pair.  Round 4: its (lobe, direction) pairs that face the point are LISTED first
+// (lobe-major; a direction on the far side of the normal is multiplied by zero, inverRender.py:183 -- about half of the 32
+// directions of a lobe near the horizon, all of them beyond it) and the list is taken 32 entries = one tile at a time, so a tile
+// holds directions of several lobes; the weighted sums per lobe are segmented sums over the list.  Before, every lobe with at
+// least one facing direction cost a whole tile: 57 k tiles per step where the facing directions fill 33 k.
+// A unit = 4 tiles in two sets A = {0, 1}, B = {2, 3}, 8 waves, wave w owns output tile w of every layer.
 //   L0.A || tail of the previous unit (ReLU of layer 3, set B -> dot)      L0.B || ReLU 0 A
 //   Ll.A || ReLU l-1 B                                                      Ll.B || ReLU l A       (l = 1..3; ReLU 3 -> dot)
 // The last layer (256 -> 1) is a vector dot product on the accumulators + a fixed-order sum over the waves through LDS (as the
@@ -22,9 +26,12 @@ namespace fneus {
 #endif
 constexpr int kLvisP2Chunk = FNEUS_LVIS_P2_CHUNK;            // lobes per work item (<= 64: one ballot)
 constexpr int kLvisP2Red = kP2LdsTotal;                      // float [4 tiles][8 waves][32]
-constexpr int kLvisP2List = kP2LdsTotal + 4 * 8 * 32 * 4;    // int act[64], int list[64]
+constexpr int kLvisP2List = kP2LdsTotal + 4 * 8 * 32 * 4;    // float den[64], float num[64]: the chunk's lobes
 constexpr int kLvisP2LdsTotal = kLvisP2List + 128 * 4;
-static_assert(kLvisP2Chunk % 8 == 0 && kLvisP2Chunk <= 64, "the chunk's lobes are tested by 8 waves and listed by one ballot");
+// slots 17, 18 of a tile's region are not used by this network (16 input k-steps + the parked encoding in slot 16): 4 KiB each
+constexpr int kLvisP2Pairs = 17 * 2 * kFragBytes;            // tile 0: uint16 [64 x 32] the listed pairs (lobe in chunk << 5 | direction)
+constexpr int kLvisP2Counts = kP2Half + 17 * 2 * kFragBytes; // tile 1: int [8] listed pairs per wave of a listing round
+static_assert(kLvisP2Chunk % 16 == 0 && kLvisP2Chunk <= 64, "512 threads list 16 lobes x 32 directions per round");
 
 // k-step ks of PE10(point) as one B fragment (lvis_kernels.hip posenc3_frag)
 template <int PREC>
@@ -67,8 +74,10 @@ __global__ void __launch_bounds__(512, 1) lvis_visibility_p2_kernel(const unsign
     constexpr int TN = 1, NW = 8;
     constexpr int NPL = PREC == 3 ? 2 : 1;
     float* red = reinterpret_cast<float*>(lds_ + kLvisP2Red);
-    int* act = reinterpret_cast<int*>(lds_ + kLvisP2List);
-    int* list = act + 64;
+    float* den = reinterpret_cast<float*>(lds_ + kLvisP2List);
+    float* num = den + 64;
+    unsigned short* pairs = reinterpret_cast<unsigned short*>(lds_ + kLvisP2Pairs);
+    int* counts = reinterpret_cast<int*>(lds_ + kLvisP2Counts);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int t0 = wave, r = lane & 31, h = lane >> 5;
@@ -95,27 +104,40 @@ __global__ void __launch_bounds__(512, 1) lvis_visibility_p2_kernel(const unsign
             x[c] = points[pt * 3 + c];
             nrm[c] = normals[pt * 3 + c];
         }
-        auto faces = [&](int lobe) {                      // direction r of the lobe on the normal's side (inverRender.py:169)
-            const float* d = dirs + ((size_t)lobe * 32 + r) * 3;
-            return (nrm[0] * d[0] + nrm[1] * d[1] + nrm[2] * d[2]) > 1e-6f;
-        };
-        // ---- the lobes of the chunk with at least one direction facing the point, in order
-        constexpr int PER = kLvisP2Chunk / 8;
+        // ---- the (lobe, direction) pairs of the chunk on the normal's side (inverRender.py:169), lobe-major: 16 lobes per round
+        int n_pairs = 0;
+#pragma unroll 1
+        for (int round = 0; round < kLvisP2Chunk / 16; ++round) {
+            const int lj = 16 * round + (int)(threadIdx.x >> 5), lobe = lobe0 + lj;
+            bool f = false;
+            if (lobe < lobe1) {
+                const float* d = dirs + ((size_t)lobe * 32 + r) * 3;
+                f = (nrm[0] * d[0] + nrm[1] * d[1] + nrm[2] * d[2]) > 1e-6f;
+            }
+            const unsigned long long m = __ballot(f);
+            if (lane == 0) counts[wave] = __builtin_popcountll(m);
+            p2_barrier();
+            int before = n_pairs, total = 0;
 #pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int lobe = lobe0 + PER * wave + k;
-            const bool any = lobe < lobe1 && __ballot(faces(lobe < lobe1 ? lobe : lobe0)) != 0ull;
-            if (lane == 0) act[PER * wave + k] = any ? 1 : 0;
+            for (int k = 0; k < NW; ++k) {
+                const int c = counts[k];
+                before += k < wave ? c : 0;
+                total += c;
+            }
+            if (f) pairs[before + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (unsigned short)((lj << 5) | r);
+            n_pairs += total;
+            p2_barrier();                                 // counts are rewritten by the next round
         }
-        p2_barrier();
-        const unsigned long long am = __ballot(lane < kLvisP2Chunk && act[lane] != 0);
-        const unsigned alo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)am);
-        const unsigned ahi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(am >> 32));
-        const unsigned long long amask = ((unsigned long long)ahi << 32) | alo;
-        const int n_active = __builtin_popcountll(amask);
-        if (wave == 0 && lane < kLvisP2Chunk) {
-            if ((amask >> lane) & 1ull) list[__builtin_popcountll(amask & ((1ull << lane) - 1ull))] = lobe0 + lane;
-            else if (lobe0 + lane < lobe1) vis[(size_t)(lobe0 + lane) * n_pts + pt] = 0.0f;      // the whole lobe faces away
+        n_pairs = __builtin_amdgcn_readfirstlane(n_pairs);
+        // the lobes' weight sums over ALL 32 directions (the denominator of inverRender.py:188) and their running numerators
+        for (int lj = wave; lj < kLvisP2Chunk; lj += NW) {
+            float dsum = (lobe0 + lj < lobe1 && h == 0) ? weights[(size_t)(lobe0 + lj) * 32 + r] : 0.0f;
+#pragma unroll
+            for (int sft = 16; sft >= 1; sft >>= 1) dsum += __shfl_xor(dsum, sft, 64);
+            if (lane == 0) {
+                den[lj] = dsum;
+                num[lj] = 0.0f;
+            }
         }
         if (wave < 4) {                                   // k-step `wave` of the point's encoding -> slot 16 of tile `wave`
             BFrag<PREC> one;
@@ -125,9 +147,14 @@ __global__ void __launch_bounds__(512, 1) lvis_visibility_p2_kernel(const unsign
             if constexpr (PREC == 3) *reinterpret_cast<bf16x8*>(dst + kFragBytes) = one.lo;
         }
         p2_barrier();
-        if (n_active == 0) continue;
-        const int n_units = (n_active + 3) >> 2;
-        auto lobe_of = [&](int idx) { return __builtin_amdgcn_readfirstlane(list[idx < n_active ? idx : n_active - 1]); };
+        const int n_tiles = (n_pairs + 31) >> 5;
+        const int n_units = (n_tiles + 3) >> 2;
+        // slot r of tile t holds pair 32 t + r of the list (the last pair again beyond its end: computed, not counted)
+        auto pair_of = [&](int t, bool& valid) {
+            const int e = 32 * t + r;
+            valid = e < n_pairs;
+            return (int)pairs[valid ? e : (n_pairs > 0 ? n_pairs - 1 : 0)];
+        };
         auto encode = [&](int unit, int ta, int tb) {     // waves ta .. tb: the 6 input k-steps of tile `wave` of the unit
             if (wave < ta || wave > tb) return;
             unsigned char* tile = lds_ + wave * kP2Half + lane * 16;
@@ -138,10 +165,12 @@ __global__ void __launch_bounds__(512, 1) lvis_visibility_p2_kernel(const unsign
                 if constexpr (PREC == 3)
                     *reinterpret_cast<bf16x8*>(tile + (j * NPL + 1) * kFragBytes) = *reinterpret_cast<const bf16x8*>(src + kFragBytes);
             }
-            const int lobe = lobe_of(4 * unit + wave);
+            bool valid;
+            const int pr_ = pair_of(4 * unit + wave, valid);
+            const int lobe = lobe0 + (pr_ >> 5), dir = pr_ & 31;
             float d[3], pe[27], jc[27];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) d[c] = dirs[((size_t)lobe * 32 + r) * 3 + c];
+            for (int c = 0; c < 3; ++c) d[c] = dirs[((size_t)lobe * 32 + dir) * 3 + c];
             posenc<4, false>(d, pe, jc);
             BFrag<PREC> tmp[kMaxKS];
             vec_to_bfrag<PREC, 27, 2, 0>(pe, tmp, h);
@@ -159,26 +188,42 @@ __global__ void __launch_bounds__(512, 1) lvis_visibility_p2_kernel(const unsign
                 dot[k] = 0.0f;
             }
         };
-        auto finish = [&](int unit, int hb0) {            // waves hb0, hb0 + 1: output of tile `wave` -> sigmoid -> weighted average
+        auto finish = [&](int unit, int hb0) {            // waves hb0, hb0 + 1: output of tile `wave` -> sigmoid -> the lobes' numerators
             if (wave < hb0 || wave > hb0 + 1) return;
-            const int idx = 4 * unit + wave;
-            if (idx >= n_active) return;
-            const int lobe = lobe_of(idx);
+            const int t = 4 * unit + wave;
+            if (t >= n_tiles) return;
+            bool valid;
+            const int pr_ = pair_of(t, valid);
+            const int lj = pr_ >> 5, dir = pr_ & 31;
             f32x16 b4[1];
             load_accvec<1, 0, 1>(blob, LY.L[4].bias, b4, lane);
             float s = b4[0][0];
 #pragma unroll
             for (int k = 0; k < NW; ++k) s += red[(wave * NW + k) * 32 + r];
-            const float w = weights[(size_t)lobe * 32 + r];
-            float num = (h == 0 && faces(lobe)) ? w / (1.0f + expf(-s)) : 0.0f;      // fields.py:358 sigmoid; :183 zero when back-facing
-            float den = h == 0 ? w : 0.0f;
+            const float w = weights[(size_t)(lobe0 + lj) * 32 + dir];
+            float v = (h == 0 && valid) ? w / (1.0f + expf(-s)) : 0.0f;             // fields.py:358 sigmoid (every listed pair faces)
+            // segmented inclusive scan over lanes 0..31 (the list is lobe-major: a lobe's pairs are neighbours); the last lane of a
+            // segment adds its sum to the lobe's numerator.  A lobe has at most 32 pairs, so it is split over at most two tiles:
+            // 0 + a + b in either order is the same number, whichever tile comes first.
+            const int key = (h == 0 && valid) ? lj : -1 - lane;
 #pragma unroll
-            for (int sft = 16; sft >= 1; sft >>= 1) {
-                num += __shfl_xor(num, sft, 64);
-                den += __shfl_xor(den, sft, 64);
+            for (int sft = 1; sft < 32; sft <<= 1) {
+                const float ov = __shfl_up(v, sft, 64);
+                const int ok = __shfl_up(key, sft, 64);
+                if ((lane & 31) >= sft && ok == key) v += ov;
             }
-            if (lane == 0) vis[(size_t)lobe * n_pts + pt] = num / (den + 1e-6f);    // inverRender.py:188
+            const int nk = __shfl_down(key, 1, 64);
+            if (h == 0 && valid && (r == 31 || nk != key)) atomicAdd(&num[lj], v);
         };
+        auto write_vis = [&]() {                          // inverRender.py:188: weighted mean over the lobe's 32 directions
+            for (int lj = (int)threadIdx.x; lj < lobe1 - lobe0; lj += (int)blockDim.x)
+                vis[(size_t)(lobe0 + lj) * n_pts + pt] = num[lj] / (den[lj] + 1e-6f);
+        };
+        if (n_pairs == 0) {                               // the whole chunk faces away
+            write_vis();
+            p2_barrier();
+            continue;
+        }
         encode(0, 0, 3);
         p2_barrier();
 #define LVIS_PASS(KS, ACT, L_, NX, ACCM, HBM, ACCV, HBV)                                                                     \
@@ -223,7 +268,9 @@ __global__ void __launch_bounds__(512, 1) lvis_visibility_p2_kernel(const unsign
         put_dot(2);
         p2_barrier();
         finish(n_units - 1, 2);
-        p2_barrier();                                     // red / list / the parked encoding are free for the next item
+        p2_barrier();                                     // every numerator is complete
+        write_vis();
+        p2_barrier();                                     // red / the lists / the parked encoding are free for the next item
     }
 }
 
