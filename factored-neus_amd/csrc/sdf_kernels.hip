@@ -1085,6 +1085,21 @@ static inline int grid_for(long n_tiles) {
     return (int)g;
 }
 
+extern "C" int fneus_sdf_fwd_rays(const void* blob, const float* rays_o, const float* rays_d, const float* t, int m, long n_pts,
+                                  const unsigned char* ray_mask, float fill, int32_t* work, float* sdf_out, int prec,
+                                  fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (n_pts <= 0) return 0;
+    if (!blob || !rays_o || !rays_d || !t || !ray_mask || !work || !sdf_out || m <= 0 || m % 128 != 0 || n_pts % m != 0 ||
+        (n_pts + 31) / 32 < 1024 || (prec != 1 && prec != 3)) {
+        fneus::set_last_error("fneus_sdf_fwd_rays: rays of m = k x 128 samples, >= 32 768 samples in all, every buffer");
+        return -2;
+    }
+    PointSrc src{nullptr, rays_o, rays_d, t, m};
+    return fneus::sdf_fwd_p2_rays(reinterpret_cast<const unsigned char*>(blob), src, n_pts, ray_mask, fill, work, sdf_out, prec, stream);
+}
+
 extern "C" int fneus_sdf_fwd(const void* blob, const float* pts, const float* rays_o, const float* rays_d,
                              const float* t, int m, long n_pts, float* sdf_out, int prec, fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;

@@ -12,6 +12,8 @@ int sdf_fwd_s8(const unsigned char* blob, const PointSrc& src, long n_pts, float
 
 // K1 in the two-pass pipelined form (sdf_p2_kernels.hip): 128 samples per 4-wave workgroup
 int sdf_fwd_p2(const unsigned char* blob, const PointSrc& src, long n_pts, float* sdf_out, int prec, int tn, hipStream_t stream);
+int sdf_fwd_p2_rays(const unsigned char* blob, const PointSrc& src, long n_pts, const unsigned char* ray_mask, float fill, int32_t* work,
+                    float* sdf_out, int prec, hipStream_t stream);
 
 // K1 in the two-pass pipelined form on 64-sample workgroups, two per CU (sdf_p2h_kernels.hip)
 int sdf_fwd_p2h(const unsigned char* blob, const PointSrc& src, long n_pts, float* sdf_out, int prec, hipStream_t stream);

@@ -80,6 +80,7 @@ def _load():
         "fneus_wn_backward_multi": (C.c_int, [C.POINTER(FneusWnTask), ip, vp]),
         "fneus_wn_backward": (C.c_int, [vp, ip, vp, ip, vp, vp, vp, vp, vp, vp]),
         "fneus_sdf_fwd": (C.c_int, [vp, vp, vp, vp, vp, ip, l, vp, ip, vp]),
+        "fneus_sdf_fwd_rays": (C.c_int, [vp, vp, vp, vp, ip, l, vp, f, vp, vp, ip, vp]),
         "fneus_sdf_fwd_grad": (C.c_int, [vp, vp, vp, vp, vp, ip, l, C.POINTER(FneusSdfStash), vp, vp, vp, ip, ip, vp]),
     }
     optional = {

@@ -437,10 +437,19 @@ class SdfStash:
         return out.reshape(T * 32, 256)[:self.n]
 
 
-def sdf_fwd(blob, n_pts: int, prec: int, pts=None, rays_o=None, rays_d=None, t=None, m: int = 1, out=None):
+def sdf_fwd(blob, n_pts: int, prec: int, pts=None, rays_o=None, rays_d=None, t=None, m: int = 1, out=None, ray_mask=None,
+            fill: float = 1.0):
+    """ray_mask [n_pts / m] uint8 / bool (ray form, m a multiple of 128, >= 32 768 samples): only the marked rays are evaluated, the
+    samples of the others get `fill` (fneus_sdf_fwd_rays)"""
     dev = blob.device
     if out is None:
         out = torch.empty(n_pts, dtype=torch.float32, device=dev)
+    if ray_mask is not None and pts is None and m % 128 == 0 and n_pts >= 32768 and os.environ.get("FNEUS_K1_RAY_MASK", "1") != "0":
+        mask = ray_mask.view(torch.uint8) if ray_mask.dtype == torch.bool else ray_mask
+        work = torch.empty(n_pts // 128 + 1, dtype=torch.int32, device=dev)
+        _launch("fneus_sdf_fwd_rays", lib.fneus_sdf_fwd_rays, _ptr(blob), _ptr(rays_o), _ptr(rays_d), _ptr(t), m, n_pts,
+                _ptr(mask.contiguous()), float(fill), _ptr(work), _ptr(out), prec, _stream())
+        return out
     _launch("fneus_sdf_fwd", lib.fneus_sdf_fwd, _ptr(blob), _ptr(pts), _ptr(rays_o), _ptr(rays_d), _ptr(t), m, n_pts, _ptr(out), prec,
                             _stream())
     return out

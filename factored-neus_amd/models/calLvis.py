@@ -84,14 +84,16 @@ def frozen_inv_s(deviation_network) -> float:
     return cached[1]
 
 
-def _secondary_march(origins, dirs, sdf_network, color_network, inv_s, trace=None, z_fine_override=None):
+def _secondary_march(origins, dirs, sdf_network, color_network, inv_s, trace=None, z_fine_override=None, ray_mask=None):
     """everything of cal_indiLgt that sees the frozen geometry: -> occlusion [R], hit colour [R,3], hit mask [R] (u8).
     z_fine_override: fine depths [R, 32] fed in instead of the 512 -> 32 re-sampling ("teacher forcing": the inverse CDF is ill
     conditioned at flat stretches, so per-sample parity downstream is checked on the reference's own depths, as in stage 1)"""
     R = origins.shape[0]
     dev = origins.device
     z_coarse = gen_light_z(0.0, 1.0, N_COARSE, R, device=dev).contiguous()
-    coarse_sdf = sdf_network.sdf_samples(RaySamples(origins, dirs, z_coarse.reshape(-1), N_COARSE)).reshape(R, N_COARSE)
+    # ray_mask [R] (fixed-shape step): the rays of primary rays without a hit are placeholders whose results the caller
+    # discards -- the 512-sample march, nine tenths of this function's time, skips them (their coarse SDF reads 1.0)
+    coarse_sdf = sdf_network.sdf_samples(RaySamples(origins, dirs, z_coarse.reshape(-1), N_COARSE), ray_mask=ray_mask).reshape(R, N_COARSE)
     z_fine = ops.upsample(origins, dirs, z_coarse, coarse_sdf, N_FINE, inv_s) if z_fine_override is None else z_fine_override.contiguous()
     dists, mid_z = ops.sections(z_fine, SAMPLE_DIST)
     samples = RaySamples(origins, dirs, mid_z.reshape(-1), N_FINE)
@@ -110,8 +112,9 @@ def _secondary_march(origins, dirs, sdf_network, color_network, inv_s, trace=Non
 
 
 def cal_indiLgt(surf, normal, sdf_network, deviation_network, color_network, lvis_network, indiLgt_network, u_theta=None,
-                u_z=None, trace=None):
-    """calLvis.py:339-409.  surf, normal [n,3]; u_theta, u_z [n,4]: the uniform draws of :351-352 (drawn here when None)"""
+                u_z=None, trace=None, point_mask=None):
+    """calLvis.py:339-409.  surf, normal [n,3]; u_theta, u_z [n,4]: the uniform draws of :351-352 (drawn here when None).
+    point_mask [n] bool (fixed-shape step): rows marked False are placeholders whose results the caller discards"""
     nsamp = 4
     n = surf.shape[0]
     dev = surf.device
@@ -124,7 +127,8 @@ def cal_indiLgt(surf, normal, sdf_network, deviation_network, color_network, lvi
         origins, dirs = ops.sample_dirs(surf, normal.detach().float().contiguous(), u_theta.float().contiguous(),
                                         u_z.float().contiguous())
         inv_s = frozen_inv_s(deviation_network)           # geometry is frozen in stage 2: a constant
-        occu, hit_rgb, _ = _secondary_march(origins, dirs, sdf_network, color_network, inv_s, trace)
+        ray_mask = None if point_mask is None else point_mask[:, None].expand(n, nsamp).reshape(-1).contiguous()
+        occu, hit_rgb, _ = _secondary_march(origins, dirs, sdf_network, color_network, inv_s, trace, ray_mask=ray_mask)
         gt_lvis = (1.0 - occu).reshape(n, nsamp)
         gt_trace_radiance = hit_rgb.reshape(n, nsamp, 3)
     pre_lvis = lvis_network(origins, dirs).reshape(n, nsamp)

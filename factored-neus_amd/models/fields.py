@@ -177,10 +177,10 @@ class SDFNetwork(_HipMLP):
         self._init_backend()
 
     # ---- hot-path entry points used by NeuSRenderer ----
-    def sdf_samples(self, samples: RaySamples) -> torch.Tensor:
-        """no-grad SDF values [n] (K1)"""
+    def sdf_samples(self, samples: RaySamples, ray_mask=None) -> torch.Tensor:
+        """no-grad SDF values [n] (K1).  ray_mask [rays]: rays whose values the caller reads (the others get 1.0 unevaluated)"""
         self._ensure()
-        return ops.sdf_fwd(self._net.blob, samples.n, self.prec, **samples.kw())
+        return ops.sdf_fwd(self._net.blob, samples.n, self.prec, ray_mask=ray_mask, **samples.kw())
 
     def value_feature_normal(self, samples: RaySamples, train: bool):
         """sdf [n], feature [n,256], normal [n,3] in one fused pass (K2), differentiable w.r.t. the parameters"""

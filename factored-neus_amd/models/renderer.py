@@ -366,7 +366,7 @@ class NeuSRenderer:
                 pts_surf = hit["pts_surf"]
                 _, _, n_surf = self.sdf_network.value_feature_normal(RaySamples(pts=pts_surf), False)
             res = cal_indiLgt(pts_surf, n_surf, self.sdf_network, self.deviation_network, self.color_network,
-                              self.lvis_network, self.indiLgt_network, u_theta=u_theta, u_z=u_z, trace=trace)
+                              self.lvis_network, self.indiLgt_network, u_theta=u_theta, u_z=u_z, trace=trace, point_mask=sdf_mask)
             one = torch.ones((), device=dev)
             out = {"sdf_mask": sdf_mask}
             for k in ("gt_lvis", "pre_lvis"):

@@ -159,6 +159,14 @@ int fneus_wn_backward_multi(const FneusWnTask* tasks /*host array*/, int n_tasks
 int fneus_sdf_fwd(const void* sdf_blob, const float* pts, const float* rays_o, const float* rays_d, const float* t,
                   int m, long n_pts, float* sdf_out /*[n]*/, int prec, fneus_stream_t stream);
 
+/* K1 on the rays marked in ray_mask [n_pts / m] only (rays of m = k x 128 samples, >= 32 768 samples in all): the secondary
+ * rays of stage 2 whose primary ray hit the surface (calLvis.py:339-409 marches the hit points' rays only; the fixed-shape step
+ * marches 4 per primary ray).  The samples of the other rays get `fill`.  work: int32 [n_pts / 128 + 1] device scratch (the
+ * list of 128-sample units to evaluate and its length: no host synchronisation). */
+int fneus_sdf_fwd_rays(const void* sdf_blob, const float* rays_o, const float* rays_d, const float* t, int m, long n_pts,
+                       const unsigned char* ray_mask, float fill, int32_t* work, float* sdf_out /*[n]*/, int prec,
+                       fneus_stream_t stream);
+
 /* ---- K2: SDFNetwork.forward + SDFNetwork.gradient  (fields.py:74-111 via renderer.py:238-242) ------------- */
 /* train != 0 additionally writes the a_l / feature planes needed by fneus_sdf_bwd. */
 int fneus_sdf_fwd_grad(const void* sdf_blob, const float* pts, const float* rays_o, const float* rays_d,

@@ -401,3 +401,24 @@ def test_k3_r8_equals_the_4_wave_kernel(monkeypatch, gprec, prec, n, nh):
             assert (v1 - v0).abs().max().item() <= tol * max(v0.abs().max().item(), 1e-9), (name, l)
         if t1.shape[2] > b1.tiles:                          # an allocated tile without samples stays zero
             assert float(t1[:, :, b1.tiles:].float().abs().max()) == 0.0
+
+
+def test_k1_on_marked_rays_only_equals_k1_there_and_fills_the_rest():
+    """fneus_sdf_fwd_rays (the stage-2 march of the fixed-shape step): marked rays get the values of the plain launch bit for bit,
+    the samples of the others the fill value; nothing marked, everything marked and a ragged mix"""
+    import numpy as np
+    from fneus import ops, synth
+    dev = torch.device("cuda:0")
+    net = ops.PackedNet("sdf", dev).load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.sdf_state_dict(7).items()})
+    net.pack()
+    R, m = 300, 256
+    g = torch.Generator().manual_seed(0)
+    o = (torch.rand(R, 3, generator=g) - 0.5).to(dev).contiguous()
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1).to(dev).contiguous()
+    t = torch.rand(R * m, generator=g).to(dev).contiguous()
+    full = ops.sdf_fwd(net.blob, R * m, 3, rays_o=o, rays_d=d, t=t, m=m)
+    for frac in (0.0, 1.0, 0.37):
+        mask = (torch.rand(R, generator=g) < frac).to(dev)
+        got = ops.sdf_fwd(net.blob, R * m, 3, rays_o=o, rays_d=d, t=t, m=m, ray_mask=mask, fill=2.5)
+        want = torch.where(mask[:, None], full.reshape(R, m), torch.full_like(full.reshape(R, m), 2.5))
+        assert torch.equal(got.reshape(R, m), want), frac
