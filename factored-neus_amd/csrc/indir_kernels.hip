@@ -191,7 +191,68 @@ __global__ void __launch_bounds__(256) srgb_bwd_kernel(const float* __restrict__
     dx[i] = dy[i] * s;
 }
 
+// The tail of render_with_all_sg (inverRender.py:277, 440, 306-309) for the colour a training step reads: the four lobe sums of
+// fneus_sg_render_fwd [n][4][3] (direct specular / diffuse, indirect specular / diffuse) -> clamp each, env = clamp(direct
+// specular + diffuse), indir = clamp(indirect ...), rgb = clip(sRGB(env + indir)).  The same operations in the same order as the
+// element-wise formulation (3 clamps, 3 adds, the curve: 8 launches forward, ~25 in autograd's backward).
+FN_DEV float clamp01_nan(float v) { return v != v ? v : fminf(fmaxf(v, 0.0f), 1.0f); }      // torch.clamp: NaN in, NaN out
+
+__global__ void __launch_bounds__(256) sg_combine_fwd_kernel(const float* __restrict__ sums, long n, int has_indir, float* __restrict__ rgb) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * 3) return;
+    const long p = i / 3;
+    const int c = (int)(i - p * 3);
+    const float* q = sums + p * 12 + c;
+    const float env = clamp01_nan(clamp01_nan(q[0]) + clamp01_nan(q[3]));
+    float ind = 0.0f;
+    if (has_indir) ind = clamp01_nan(clamp01_nan(q[6]) + clamp01_nan(q[9]));
+    float slope;
+    rgb[i] = srgb_curve(env + ind, 2, slope);
+}
+__global__ void __launch_bounds__(256) sg_combine_bwd_kernel(const float* __restrict__ sums, const float* __restrict__ d_rgb, long n,
+                                                             int has_indir, float* __restrict__ d_sums) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * 3) return;
+    const long p = i / 3;
+    const int c = (int)(i - p * 3);
+    const float* q = sums + p * 12 + c;
+    float* dq = d_sums + p * 12 + c;
+    auto in01 = [](float v) { return v >= 0.0f && v <= 1.0f; };        // torch.clamp passes the gradient on [min, max]
+    const float e = clamp01_nan(q[0]) + clamp01_nan(q[3]), env = clamp01_nan(e);
+    float f = 0.0f, ind = 0.0f;
+    if (has_indir) {
+        f = clamp01_nan(q[6]) + clamp01_nan(q[9]);
+        ind = clamp01_nan(f);
+    }
+    float slope;
+    (void)srgb_curve(env + ind, 2, slope);
+    const float g = d_rgb[i] * slope;
+    const float ge = in01(e) ? g : 0.0f, gi = (has_indir && in01(f)) ? g : 0.0f;
+    dq[0] = in01(q[0]) ? ge : 0.0f;
+    dq[3] = in01(q[3]) ? ge : 0.0f;
+    dq[6] = (has_indir && in01(q[6])) ? gi : 0.0f;
+    dq[9] = (has_indir && in01(q[9])) ? gi : 0.0f;
+}
+
 }  // namespace fneus
+
+extern "C" int fneus_sg_combine_fwd(const float* sums, long n, int has_indir, float* rgb, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (n <= 0) return 0;
+    if (!sums || !rgb) return -2;
+    hipLaunchKernelGGL(fneus::sg_combine_fwd_kernel, dim3((unsigned)((n * 3 + 255) / 256)), dim3(256), 0, stream, sums, n, has_indir, rgb);
+    return fneus::launch_status();
+}
+extern "C" int fneus_sg_combine_bwd(const float* sums, const float* d_rgb, long n, int has_indir, float* d_sums, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (n <= 0) return 0;
+    if (!sums || !d_rgb || !d_sums) return -2;
+    hipLaunchKernelGGL(fneus::sg_combine_bwd_kernel, dim3((unsigned)((n * 3 + 255) / 256)), dim3(256), 0, stream, sums, d_rgb, n, has_indir,
+                       d_sums);
+    return fneus::launch_status();
+}
 
 extern "C" int fneus_srgb_fwd(const float* x, long n, int mode, float* y, fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;

@@ -333,6 +333,22 @@ class SgRenderFn(torch.autograd.Function):
         return d_lgt, d_mat, None, None, None, None, None
 
 
+class SgCombineFn(torch.autograd.Function):
+    """fneus_sg_combine_fwd / _bwd: the clamps, sums and tone mapping between the lobe sums and the rendered colour of stage 3"""
+
+    @staticmethod
+    def forward(ctx, sums, has_indir: bool):
+        sums = sums.contiguous()
+        ctx.save_for_backward(sums)
+        ctx.has_indir = has_indir
+        return ops.sg_combine_fwd(sums, has_indir)
+
+    @staticmethod
+    def backward(ctx, d_rgb):
+        (sums,) = ctx.saved_tensors
+        return ops.sg_combine_bwd(sums, d_rgb.contiguous(), ctx.has_indir), None
+
+
 class RefHeadsFn(torch.autograd.Function):
     """Both MLPs of RefColor (fields.py:303-330) on the gathered surface samples: one forward launch, one backward
     launch, one weight-gradient GEMM launch for the two networks.  Differentiable inputs: normal, feature."""

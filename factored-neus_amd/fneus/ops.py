@@ -1066,6 +1066,21 @@ def outside_alpha_bwd(density, rgb, dists, d_alpha, d_rgb):
     return d_density, d_raw
 
 
+def sg_combine_fwd(sums, has_indir: bool):
+    """[n, 4, 3] lobe sums of sg_render_fwd -> tone-mapped colour [n, 3] (include/fneus.h fneus_sg_combine_fwd)"""
+    n = sums.shape[0]
+    rgb = torch.empty(n, 3, dtype=torch.float32, device=sums.device)
+    _launch("fneus_sg_combine_fwd", lib.fneus_sg_combine_fwd, _ptr(sums), n, int(has_indir), _ptr(rgb), _stream())
+    return rgb
+
+
+def sg_combine_bwd(sums, d_rgb, has_indir: bool):
+    d_sums = torch.empty_like(sums)
+    _launch("fneus_sg_combine_bwd", lib.fneus_sg_combine_bwd, _ptr(sums), _ptr(d_rgb), sums.shape[0], int(has_indir), _ptr(d_sums),
+            _stream())
+    return d_sums
+
+
 def sg_render_fwd(lgt, ind, vis, normal, view, mat, f0: float):
     """render_with_sg's lobe sums (inverRender.py:314-449) -> [n, 4, 3]: direct specular / diffuse, indirect specular / diffuse"""
     n, M = mat.shape[0], lgt.shape[0]

@@ -225,7 +225,12 @@ def _render_with_all_sg_fused(points, normal, viewdirs, lgtSGs, f0: float, specu
                                  u_phi=u_phi, point_mask=point_mask)              # [M, n], detached
     mat = torch.cat([roughness, diffuse_albedo, specular_albedo], dim=-1)         # [n, 7]
     sums = SgRenderFn.apply(lgtSGs, mat, normal, viewdirs, vis, indir_lgtSGs, f0)
-    spec_d, diff_d, spec_i, diff_i = (torch.clamp(sums[:, k], 0.0, 1.0) for k in range(4))
+    if want is not None and want <= {"rgb"}:           # the training step: the colour alone, clamps and tone mapping in one launch
+        from fneus.autograd import SgCombineFn
+        return {"specular_loss": 0, "diffuse_loss": 0, "rgb": SgCombineFn.apply(sums, indir_lgtSGs is not None)}
+    # (one clamp and one unbind for the four sums: four slices + clamps are 8 launches forward and ~25 backward -- every slice's
+    # backward is a zero fill, a copy and an add on the [n, 4, 3] gradient)
+    spec_d, diff_d, spec_i, diff_i = torch.clamp(sums, 0.0, 1.0).unbind(1)
     env = torch.clamp(spec_d + diff_d, 0.0, 1.0)
     indir = torch.clamp(spec_i + diff_i, 0.0, 1.0) if indir_lgtSGs is not None else torch.zeros_like(points)
     ret = {"specular_loss": 0, "diffuse_loss": 0}
@@ -330,10 +335,10 @@ class EnvmapMaterialNetwork(nn.Module):
         # buffers, models/fields.py _DirectLinearFn; otherwise these are the plain nn.Sequential calls)
         latent = _seq_direct(self.brdf_encoder_layer, self.brdf_embed_fn(points), self)
         brdf = torch.sigmoid(_seq_direct(self.brdf_decoder_layer, torch.sigmoid(latent), self))
-        roughness = brdf[..., 3:] * 0.9 + 0.09
-        diffuse_albedo = brdf[..., :3]
+        diffuse_albedo, rough_raw = torch.split(brdf, [3, 1], dim=-1)      # (split: its backward is one concatenation)
+        roughness = rough_raw * 0.9 + 0.09
         loss = 0.01 * self.kl_divergence(0.05, latent, point_mask)
-        specular_albedo = _seq_direct(self.net_cs, torch.cat([pts_enc, self.embed_view_fn(ref_dirs)], dim=-1), self).repeat(1, 3)
+        specular_albedo = _seq_direct(self.net_cs, torch.cat([pts_enc, self.embed_view_fn(ref_dirs)], dim=-1), self).expand(-1, 3)
         ret = render_with_all_sg(points, n, view_dirs, self.lgtSGs, self.specular_reflectance, specular_albedo, roughness,
                                  diffuse_albedo, gt_specular_linear, lvis_network=lvis_network, indir_lgtSGs=indiLgt,
                                  u_theta=u_theta, u_phi=u_phi, specular_reflectance_value=self.specular_reflectance_value,

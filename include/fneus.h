@@ -393,6 +393,13 @@ int fneus_sg_render_fwd(const float* lgt_sgs, const float* indir_sgs, const floa
 int fneus_sg_render_bwd(const float* lgt_sgs, const float* indir_sgs, const float* vis, const float* normal, const float* view,
                         const float* material, int n_pts, int n_direct, int n_indirect, float specular_reflectance,
                         const float* d_out, float* d_material, float* d_lgt_sgs, fneus_stream_t stream);
+/* The colour a stage-3 training step reads, from the four lobe sums of fneus_sg_render_fwd [n][4][3]: clamp each to [0, 1],
+ * env = clamp(direct specular + diffuse), indir = clamp(indirect specular + diffuse) (0 when has_indir == 0), rgb =
+ * clip(linear -> sRGB (env + indir)) -- inverRender.py:277, 440, 306-309 -- and the adjoint (torch.clamp / torch.clip pass the
+ * gradient on the closed interval). */
+int fneus_sg_combine_fwd(const float* sums, long n, int has_indir, float* rgb /*[n][3]*/, fneus_stream_t stream);
+int fneus_sg_combine_bwd(const float* sums, const float* d_rgb, long n, int has_indir, float* d_sums /*[n][4][3]*/,
+                         fneus_stream_t stream);
 
 /* ---- K7: background NeRF++ of the womask configurations  (fields.py:233-259 NeRF.forward via renderer.py:112-149) ---- */
 /* pts4 [n][4] = (p/|p|, 1/|p|) of the background samples, dirs [n][3]; outputs are RAW: density [n] (alpha_linear) and

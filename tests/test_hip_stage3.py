@@ -360,3 +360,27 @@ def test_fused_indirect_light_output_transform():
         got = net(pts)
     assert got.shape == ref.shape == (257, net.num_lgt_sgs, 7)
     assert (got - ref).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item())
+
+
+def test_sg_combine_equals_the_elementwise_tail():
+    """fneus_sg_combine_fwd / _bwd against the clamps, sums and tone mapping it replaces (inverRender.py:277, 440, 306-309), values
+    bit for bit, gradients through torch.clamp's closed-interval rule; sums far outside [0, 1], on its ends and a NaN"""
+    from fneus.autograd import SgCombineFn
+    from models.inverRender import tonemap_clip
+    g = torch.Generator().manual_seed(0)
+    sums = (torch.rand(600, 4, 3, generator=g) * 1.6 - 0.3)
+    sums[0, 0, 0], sums[1, 1, 1], sums[2, 2, 2] = 0.0, 1.0, float("nan")
+    for has_indir in (True, False):
+        a = sums.clone().to(DEV).requires_grad_(True)
+        b = sums.clone().to(DEV).requires_grad_(True)
+        rgb_a = SgCombineFn.apply(a, has_indir)
+        sd, dd, si, di = torch.clamp(b, 0.0, 1.0).unbind(1)
+        env = torch.clamp(sd + dd, 0.0, 1.0)
+        ind = torch.clamp(si + di, 0.0, 1.0) if has_indir else torch.zeros_like(env)
+        rgb_b = tonemap_clip(env + ind)
+        assert torch.equal(torch.nan_to_num(rgb_a, nan=-7.0), torch.nan_to_num(rgb_b, nan=-7.0))
+        w = torch.rand(600, 3, generator=g).to(DEV)
+        (rgb_a * w).nansum().backward()
+        (rgb_b * w).nansum().backward()
+        ok = ~torch.isnan(b.grad) & ~torch.isnan(a.grad)
+        assert torch.equal(a.grad[ok], b.grad[ok]) and int(ok.sum()) >= 600 * 12 - 12
