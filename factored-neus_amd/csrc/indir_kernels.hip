@@ -195,6 +195,60 @@ __global__ void __launch_bounds__(256) srgb_bwd_kernel(const float* __restrict__
 // fneus_sg_render_fwd [n][4][3] (direct specular / diffuse, indirect specular / diffuse) -> clamp each, env = clamp(direct
 // specular + diffuse), indir = clamp(indirect ...), rgb = clip(sRGB(env + indir)).  The same operations in the same order as the
 // element-wise formulation (3 clamps, 3 adds, the curve: 8 launches forward, ~25 in autograd's backward).
+// The latent-sparsity term of stage 3 (inverRender.py:609-612; mateIllu.py:163): rho_hat_j = mean over the marked points of
+// sigmoid(latent[i][j]), kl = mean_j (rho log(rho / rho_hat_j) + (1 - rho) log((1 - rho) / (1 - rho_hat_j))); 0 without a marked
+// point.  ~22 element-wise launches on [32]-element tensors forward and ~20 backward, as one launch each: ONE workgroup, the
+// column sums over the points in a fixed order (thread t sums rows t, t + 32, ... of column t & 31; then a tree over the 32 row
+// groups).  stats [34]: rho_hat [32], the number of marked points, kl -- saved for the backward.
+constexpr int kKlDim = 32;
+__global__ void __launch_bounds__(1024) latent_kl_fwd_kernel(const float* __restrict__ latent, const unsigned char* __restrict__ mask,
+                                                             int n, float rho, float* __restrict__ stats) {
+    __shared__ float part[32][kKlDim + 1];
+    __shared__ float cnts[32];
+    const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    float s = 0.0f, c = 0.0f;
+    for (int i = grp; i < n; i += 32) {
+        const float w = mask ? (mask[i] ? 1.0f : 0.0f) : 1.0f;
+        s += w / (1.0f + expf(-latent[(long)i * kKlDim + col]));
+        c += w;
+    }
+    part[grp][col] = s;
+    if (col == 0) cnts[grp] = c;
+    __syncthreads();
+    if (grp == 0) {
+        float tot = 0.0f, cnt = 0.0f;
+        for (int g = 0; g < 32; ++g) {
+            tot += part[g][col];
+            cnt += cnts[g];
+        }
+        const float rh = cnt > 0.0f ? tot / fmaxf(cnt, 1.0f) : rho;
+        float term = rho * logf(rho / rh) + (1.0f - rho) * logf((1.0f - rho) / (1.0f - rh));
+        for (int d = 16; d >= 1; d >>= 1) term += __shfl_xor(term, d, 64);
+        stats[col] = rh;
+        if (col == 0) {
+            stats[32] = cnt;
+            stats[33] = cnt > 0.0f ? term / (float)kKlDim : 0.0f;
+        }
+    }
+}
+// d latent[i][j] = d_kl / 32 * (-rho / rho_hat_j + (1 - rho) / (1 - rho_hat_j)) * w_i / cnt * act (1 - act)
+__global__ void __launch_bounds__(256) latent_kl_bwd_kernel(const float* __restrict__ latent, const unsigned char* __restrict__ mask,
+                                                            int n, float rho, const float* __restrict__ stats,
+                                                            const float* __restrict__ d_kl, float* __restrict__ d_latent) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)n * kKlDim) return;
+    const int col = (int)(idx & (kKlDim - 1));
+    const long i = idx >> 5;
+    const float cnt = stats[32], rh = stats[col];
+    const float w = mask ? (mask[i] ? 1.0f : 0.0f) : 1.0f;
+    float g = 0.0f;
+    if (cnt > 0.0f && w != 0.0f) {
+        const float a = 1.0f / (1.0f + expf(-latent[idx]));
+        g = d_kl[0] * (1.0f / (float)kKlDim) * (-rho / rh + (1.0f - rho) / (1.0f - rh)) / fmaxf(cnt, 1.0f) * a * (1.0f - a);
+    }
+    d_latent[idx] = g;
+}
+
 FN_DEV float clamp01_nan(float v) { return v != v ? v : fminf(fmaxf(v, 0.0f), 1.0f); }      // torch.clamp: NaN in, NaN out
 
 __global__ void __launch_bounds__(256) sg_combine_fwd_kernel(const float* __restrict__ sums, long n, int has_indir, float* __restrict__ rgb) {
@@ -235,6 +289,24 @@ __global__ void __launch_bounds__(256) sg_combine_bwd_kernel(const float* __rest
 }
 
 }  // namespace fneus
+
+extern "C" int fneus_latent_kl_fwd(const float* latent, const unsigned char* point_mask, int n, float rho, float* stats,
+                                   fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (!latent || !stats || n <= 0 || !(rho > 0.0f && rho < 1.0f)) return -2;
+    hipLaunchKernelGGL(fneus::latent_kl_fwd_kernel, dim3(1), dim3(1024), 0, stream, latent, point_mask, n, rho, stats);
+    return fneus::launch_status();
+}
+extern "C" int fneus_latent_kl_bwd(const float* latent, const unsigned char* point_mask, int n, float rho, const float* stats,
+                                   const float* d_kl, float* d_latent, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (!latent || !stats || !d_kl || !d_latent || n <= 0) return -2;
+    hipLaunchKernelGGL(fneus::latent_kl_bwd_kernel, dim3((unsigned)(((long)n * 32 + 255) / 256)), dim3(256), 0, stream, latent, point_mask,
+                       n, rho, stats, d_kl, d_latent);
+    return fneus::launch_status();
+}
 
 extern "C" int fneus_sg_combine_fwd(const float* sums, long n, int has_indir, float* rgb, fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;

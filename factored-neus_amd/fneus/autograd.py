@@ -333,6 +333,24 @@ class SgRenderFn(torch.autograd.Function):
         return d_lgt, d_mat, None, None, None, None, None
 
 
+class LatentKlFn(torch.autograd.Function):
+    """fneus_latent_kl_fwd / _bwd: the latent-sparsity term of stage 3 over the marked points (inverRender.py:609-612)"""
+
+    @staticmethod
+    def forward(ctx, latent, point_mask, rho: float):
+        latent = latent.contiguous()
+        mask = None if point_mask is None else (point_mask.view(torch.uint8) if point_mask.dtype == torch.bool else point_mask).contiguous()
+        stats = ops.latent_kl_fwd(latent, mask, rho)
+        ctx.save_for_backward(latent, stats)
+        ctx.mask, ctx.rho = mask, rho
+        return stats[33]
+
+    @staticmethod
+    def backward(ctx, d_kl):
+        latent, stats = ctx.saved_tensors
+        return ops.latent_kl_bwd(latent, ctx.mask, ctx.rho, stats, d_kl.reshape(1).contiguous()), None, None
+
+
 class SgCombineFn(torch.autograd.Function):
     """fneus_sg_combine_fwd / _bwd: the clamps, sums and tone mapping between the lobe sums and the rendered colour of stage 3"""
 

@@ -1066,6 +1066,21 @@ def outside_alpha_bwd(density, rgb, dists, d_alpha, d_rgb):
     return d_density, d_raw
 
 
+def latent_kl_fwd(latent, point_mask, rho: float):
+    """-> stats [34]: rho_hat [32], the number of marked points, kl (include/fneus.h fneus_latent_kl_fwd)"""
+    stats = torch.empty(34, dtype=torch.float32, device=latent.device)
+    _launch("fneus_latent_kl_fwd", lib.fneus_latent_kl_fwd, _ptr(latent), _ptr(point_mask), latent.shape[0], float(rho), _ptr(stats),
+            _stream())
+    return stats
+
+
+def latent_kl_bwd(latent, point_mask, rho: float, stats, d_kl):
+    d_latent = torch.empty_like(latent)
+    _launch("fneus_latent_kl_bwd", lib.fneus_latent_kl_bwd, _ptr(latent), _ptr(point_mask), latent.shape[0], float(rho), _ptr(stats),
+            _ptr(d_kl), _ptr(d_latent), _stream())
+    return d_latent
+
+
 def sg_combine_fwd(sums, has_indir: bool):
     """[n, 4, 3] lobe sums of sg_render_fwd -> tone-mapped colour [n, 3] (include/fneus.h fneus_sg_combine_fwd)"""
     n = sums.shape[0]

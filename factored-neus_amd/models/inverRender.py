@@ -307,6 +307,11 @@ class EnvmapMaterialNetwork(nn.Module):
     def kl_divergence(self, rho, rho_hat, point_mask=None):
         """inverRender.py:609-612.  point_mask [n] bool: the mean runs over the marked points only (the fixed-shape stage-3
         step evaluates every ray and marks the ones that hit); without a marked point the term is 0"""
+        red = getattr(self, "stat_reduce", None)
+        if rho_hat.is_cuda and rho_hat.dim() == 2 and rho_hat.shape[1] == 32 and rho_hat.dtype == torch.float32 and \
+                (red is None or point_mask is None):
+            from fneus.autograd import LatentKlFn                   # one launch forward, one backward (~40 element-wise ones)
+            return LatentKlFn.apply(rho_hat, point_mask, float(rho))
         act = torch.sigmoid(rho_hat)
         if point_mask is None:
             rho_hat = torch.mean(act, 0)

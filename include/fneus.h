@@ -393,6 +393,12 @@ int fneus_sg_render_fwd(const float* lgt_sgs, const float* indir_sgs, const floa
 int fneus_sg_render_bwd(const float* lgt_sgs, const float* indir_sgs, const float* vis, const float* normal, const float* view,
                         const float* material, int n_pts, int n_direct, int n_indirect, float specular_reflectance,
                         const float* d_out, float* d_material, float* d_lgt_sgs, fneus_stream_t stream);
+/* The latent-sparsity term of stage 3 (inverRender.py:609-612): latent [n][32], point_mask [n] (NULL = every point), rho in
+ * (0, 1) -> stats [34] = rho_hat [32] (mean sigmoid over the marked points), their number, kl (0 without a marked point); and the
+ * adjoint d_latent [n][32] for the cotangent d_kl [1] (device scalar). */
+int fneus_latent_kl_fwd(const float* latent, const unsigned char* point_mask, int n, float rho, float* stats, fneus_stream_t stream);
+int fneus_latent_kl_bwd(const float* latent, const unsigned char* point_mask, int n, float rho, const float* stats, const float* d_kl,
+                        float* d_latent, fneus_stream_t stream);
 /* The colour a stage-3 training step reads, from the four lobe sums of fneus_sg_render_fwd [n][4][3]: clamp each to [0, 1],
  * env = clamp(direct specular + diffuse), indir = clamp(indirect specular + diffuse) (0 when has_indir == 0), rgb =
  * clip(linear -> sRGB (env + indir)) -- inverRender.py:277, 440, 306-309 -- and the adjoint (torch.clamp / torch.clip pass the

@@ -384,3 +384,27 @@ def test_sg_combine_equals_the_elementwise_tail():
         (rgb_b * w).nansum().backward()
         ok = ~torch.isnan(b.grad) & ~torch.isnan(a.grad)
         assert torch.equal(a.grad[ok], b.grad[ok]) and int(ok.sum()) >= 600 * 12 - 12
+
+
+def test_latent_kl_equals_the_elementwise_formulation():
+    """fneus_latent_kl_fwd / _bwd against inverRender.py:609-612 written with torch ops (fp64): all points, a mask, an empty mask"""
+    from fneus.autograd import LatentKlFn
+    g = torch.Generator().manual_seed(1)
+    latent = (torch.randn(512, 32, generator=g) * 2.0).to(DEV)
+    rho = 0.05
+    for mask in (None, (torch.rand(512, generator=g) < 0.8).to(DEV), torch.zeros(512, dtype=torch.bool, device=DEV)):
+        a = latent.clone().requires_grad_(True)
+        kl = LatentKlFn.apply(a, mask, rho)
+        (kl * 3.0).backward()
+        b = latent.double().clone().requires_grad_(True)
+        act = torch.sigmoid(b)
+        w = torch.ones(512, 1, device=DEV, dtype=torch.float64) if mask is None else mask.double()[:, None]
+        cnt = w.sum()
+        if cnt.item() > 0:
+            rh = (act * w).sum(0) / cnt
+            ref = torch.mean(rho * torch.log(rho / rh) + (1 - rho) * torch.log((1 - rho) / (1 - rh)))
+            (ref * 3.0).backward()
+            assert abs(kl.item() - ref.item()) <= 2e-6 * max(1.0, abs(ref.item()))
+            assert (a.grad.double() - b.grad).abs().max().item() <= 2e-6 * b.grad.abs().max().item() + 1e-12
+        else:
+            assert kl.item() == 0.0 and float(a.grad.abs().max()) == 0.0
