@@ -249,6 +249,52 @@ __global__ void __launch_bounds__(256) latent_kl_bwd_kernel(const float* __restr
     d_latent[idx] = g;
 }
 
+// The image terms of the stage-3 step (mateIllu.py:152-172): w = mask x hit, rgb_loss = sum |diff w| / (sum w + 1e-5),
+// psnr = 20 log10(1 / sqrt(sum diff^2 w / ((sum w + 1e-5) 3))), and d rgb_loss / d rgb.  ONE workgroup, fixed summation order
+// (thread t takes rays t, t + 1024, ...; wave tree; waves in order) -- ~22 element-wise launches forward and ~8 backward before.
+__global__ void __launch_bounds__(1024) stage3_loss_kernel(const float* __restrict__ rgb, const float* __restrict__ true_rgb,
+                                                           const float* __restrict__ mask, const unsigned char* __restrict__ hit,
+                                                           int n, float* __restrict__ out /*[3]: rgb_loss, psnr, sum w*/,
+                                                           float* __restrict__ d_rgb) {
+    __shared__ float red[3][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float a[3] = {0.0f, 0.0f, 0.0f};          // sum w, sum |diff w|, sum diff^2 w
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float w = mask[i] * (hit[i] ? 1.0f : 0.0f);
+        a[0] += w;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float d = rgb[i * 3 + c] - true_rgb[i * 3 + c];
+            a[1] += fabsf(d * w);
+            a[2] += d * d * w;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        for (int d = 32; d >= 1; d >>= 1) a[k] += __shfl_xor(a[k], d, 64);
+        if (lane == 0) red[k][wave] = a[k];
+    }
+    __syncthreads();
+    float t[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        for (int w = 0; w < 16; ++w) t[k] += red[k][w];
+    const float denom = t[0] + 1e-5f;
+    if (threadIdx.x == 0) {
+        out[0] = t[1] / denom;
+        out[1] = 20.0f * log10f(1.0f / sqrtf(t[2] / (denom * 3.0f)));
+        out[2] = t[0];
+    }
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float w = mask[i] * (hit[i] ? 1.0f : 0.0f);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float d = (rgb[i * 3 + c] - true_rgb[i * 3 + c]) * w;
+            d_rgb[i * 3 + c] = (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f)) * w / denom;
+        }
+    }
+}
+
 FN_DEV float clamp01_nan(float v) { return v != v ? v : fminf(fmaxf(v, 0.0f), 1.0f); }      // torch.clamp: NaN in, NaN out
 
 __global__ void __launch_bounds__(256) sg_combine_fwd_kernel(const float* __restrict__ sums, long n, int has_indir, float* __restrict__ rgb) {
@@ -289,6 +335,15 @@ __global__ void __launch_bounds__(256) sg_combine_bwd_kernel(const float* __rest
 }
 
 }  // namespace fneus
+
+extern "C" int fneus_stage3_loss(const float* rgb, const float* true_rgb, const float* mask, const unsigned char* hit, int n, float* out,
+                                 float* d_rgb, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (!rgb || !true_rgb || !mask || !hit || !out || !d_rgb || n <= 0) return -2;
+    hipLaunchKernelGGL(fneus::stage3_loss_kernel, dim3(1), dim3(1024), 0, stream, rgb, true_rgb, mask, hit, n, out, d_rgb);
+    return fneus::launch_status();
+}
 
 extern "C" int fneus_latent_kl_fwd(const float* latent, const unsigned char* point_mask, int n, float rho, float* stats,
                                    fneus_stream_t stream_) {

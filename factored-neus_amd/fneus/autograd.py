@@ -333,6 +333,23 @@ class SgRenderFn(torch.autograd.Function):
         return d_lgt, d_mat, None, None, None, None, None
 
 
+class Stage3LossFn(torch.autograd.Function):
+    """fneus_stage3_loss: the masked L1 colour term and the psnr of a stage-3 step, with the gradient of the former"""
+
+    @staticmethod
+    def forward(ctx, rgb, true_rgb, mask, hit):
+        out, d_rgb = ops.stage3_loss(rgb.contiguous(), true_rgb.contiguous(), mask.reshape(-1).contiguous(),
+                                     (hit.view(torch.uint8) if hit.dtype == torch.bool else hit).contiguous())
+        ctx.save_for_backward(d_rgb)
+        ctx.mark_non_differentiable(out)
+        return out[0].clone(), out          # (the loss as its own tensor: `out` carries no gradient)
+
+    @staticmethod
+    def backward(ctx, d_loss, _d_out):
+        (d_rgb,) = ctx.saved_tensors
+        return d_rgb * d_loss, None, None, None
+
+
 class LatentKlFn(torch.autograd.Function):
     """fneus_latent_kl_fwd / _bwd: the latent-sparsity term of stage 3 over the marked points (inverRender.py:609-612)"""
 

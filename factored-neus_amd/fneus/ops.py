@@ -1066,6 +1066,15 @@ def outside_alpha_bwd(density, rgb, dists, d_alpha, d_rgb):
     return d_density, d_raw
 
 
+def stage3_loss(rgb, true_rgb, mask, hit):
+    """-> out [3] = (rgb_loss, psnr, sum of the weights), d_rgb [n, 3] = d rgb_loss / d rgb (include/fneus.h fneus_stage3_loss)"""
+    out = torch.empty(3, dtype=torch.float32, device=rgb.device)
+    d_rgb = torch.empty_like(rgb)
+    _launch("fneus_stage3_loss", lib.fneus_stage3_loss, _ptr(rgb), _ptr(true_rgb), _ptr(mask), _ptr(hit), rgb.shape[0], _ptr(out),
+            _ptr(d_rgb), _stream())
+    return out, d_rgb
+
+
 def latent_kl_fwd(latent, point_mask, rho: float):
     """-> stats [34]: rho_hat [32], the number of marked points, kl (include/fneus.h fneus_latent_kl_fwd)"""
     stats = torch.empty(34, dtype=torch.float32, device=latent.device)

@@ -20,6 +20,10 @@ from fneus.trainer import WMASK_MODEL
 def stage3_loss(out: dict, true_rgb, mask, reduce=None):
     """mateIllu.py:152-172 (mask = (mask > 0.5) when train.mask_weight > 0, else ones: the caller's business).
     reduce(t) -> t summed over the data-parallel ranks: rgb_loss is then this rank's share of the global batch's"""
+    if reduce is None and out["rgb"].is_cuda and out["rgb"].dtype == torch.float32 and mask.dtype == torch.float32:
+        from fneus.autograd import Stage3LossFn                  # the sums below and their gradient in one launch (~30 before)
+        rgb_loss, vals = Stage3LossFn.apply(out["rgb"], true_rgb.float(), mask, out["sdf_mask"])
+        return {"loss": rgb_loss + out["encoder_loss"], "rgb_loss": rgb_loss, "encoder_loss": out["encoder_loss"], "psnr": vals[1]}
     w = mask * out["sdf_mask"][:, None].to(mask.dtype)          # rays that hit AND lie inside the image mask (no boolean
     wsum = w.sum().reshape(1)                                    # indexing: nothing here may synchronise with the host)
     if reduce is not None:

@@ -316,7 +316,7 @@ class NeuSRenderer:
             "_z_vals": z_vals, "_sdf": ret["sdf"], "_mid_z_vals": ret["mid_z_vals"],
         }
 
-    def lvis_mateIllu_render_util(self, rays_o, rays_d, near, far, z_vals_override=None):
+    def lvis_mateIllu_render_util(self, rays_o, rays_d, near, far, z_vals_override=None, need_inside=True):
         """renderer.py:503-564, the entry of the stage-2 / stage-3 renderers (lvis_render, mateIllu_render): unperturbed
         hierarchical sampling, SDF at the section mid-points and the per-ray inside-sphere mask.  Geometry is frozen in
         those stages (lvis.py:78-92 optimises the visibility / indirect-light networks only), so the SDF comes from the
@@ -338,9 +338,11 @@ class NeuSRenderer:
                 n = self.n_samples + self.n_importance
             dists, mid_z = self._sections(z_vals, sample_dist)
             sdf = self.sdf_network.sdf_samples(RaySamples(rays_o, rays_d, mid_z.reshape(-1), n))
-            pts = rays_o[:, None, :] + rays_d[:, None, :] * mid_z[..., None]
-            inside_sphere = torch.linalg.norm(pts, ord=2, dim=-1) < 1.0
-        return {"n_samples": n, "mid_z_vals": mid_z, "sdf": sdf[:, None], "inside_sphere_mask": inside_sphere.any(dim=-1)}
+            inside_any = None
+            if need_inside:     # (fneus_ray_hit tests the same samples itself when it is not handed the mask: the fixed-shape
+                pts = rays_o[:, None, :] + rays_d[:, None, :] * mid_z[..., None]          # steps skip these six launches)
+                inside_any = (torch.linalg.norm(pts, ord=2, dim=-1) < 1.0).any(dim=-1)
+        return {"n_samples": n, "mid_z_vals": mid_z, "sdf": sdf[:, None], "inside_sphere_mask": inside_any}
 
     def lvis_render(self, rays_o, rays_d, near, far, u_theta=None, u_z=None, trace=None, fixed_shape=False, z_vals_override=None):
         """renderer.py:567-627: visibility / traced radiance of 4 secondary rays per visible surface point, and the
@@ -354,7 +356,7 @@ class NeuSRenderer:
         B = len(rays_o)
         dev = rays_o.device
         M = 4
-        util = self.lvis_mateIllu_render_util(rays_o, rays_d, near, far, z_vals_override=z_vals_override)
+        util = self.lvis_mateIllu_render_util(rays_o, rays_d, near, far, z_vals_override=z_vals_override, need_inside=not fixed_shape)
         n = util["n_samples"]
         rays_o, rays_d = rays_o.detach().float().contiguous(), rays_d.detach().float().contiguous()
         with torch.no_grad():
@@ -406,7 +408,7 @@ class NeuSRenderer:
         from models.inverRender import srgb_to_linear
         B = len(rays_o)
         dev = rays_o.device
-        util = self.lvis_mateIllu_render_util(rays_o, rays_d, near, far, z_vals_override=z_vals_override)
+        util = self.lvis_mateIllu_render_util(rays_o, rays_d, near, far, z_vals_override=z_vals_override, need_inside=not fixed_shape)
         n = util["n_samples"]
         rays_o, rays_d = rays_o.detach().float().contiguous(), rays_d.detach().float().contiguous()
         with torch.no_grad():

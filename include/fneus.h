@@ -393,6 +393,10 @@ int fneus_sg_render_fwd(const float* lgt_sgs, const float* indir_sgs, const floa
 int fneus_sg_render_bwd(const float* lgt_sgs, const float* indir_sgs, const float* vis, const float* normal, const float* view,
                         const float* material, int n_pts, int n_direct, int n_indirect, float specular_reflectance,
                         const float* d_out, float* d_material, float* d_lgt_sgs, fneus_stream_t stream);
+/* The image terms of a stage-3 step (mateIllu.py:152-172) over n rays: w = mask x hit; out[0] = sum |(rgb - true_rgb) w| /
+ * (sum w + 1e-5), out[1] = psnr, out[2] = sum w; d_rgb [n][3] = d out[0] / d rgb. */
+int fneus_stage3_loss(const float* rgb, const float* true_rgb, const float* mask /*[n]*/, const unsigned char* hit /*[n]*/, int n,
+                      float* out /*[3]*/, float* d_rgb, fneus_stream_t stream);
 /* The latent-sparsity term of stage 3 (inverRender.py:609-612): latent [n][32], point_mask [n] (NULL = every point), rho in
  * (0, 1) -> stats [34] = rho_hat [32] (mean sigmoid over the marked points), their number, kl (0 without a marked point); and the
  * adjoint d_latent [n][32] for the cotangent d_kl [1] (device scalar). */
