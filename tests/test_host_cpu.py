@@ -362,3 +362,37 @@ def test_fn_sincos_scheme():
             err = np.abs(got.astype(L) - want).astype(np.float64)
             assert (err / ulp).max() <= 0.52 and err.max() <= 3.1e-8, (scale, (err / ulp).max(), err.max())
             assert (got == want.astype(f32)).mean() >= 0.98, (scale, (got == want.astype(f32)).mean())
+
+
+def test_gemm_job_table_hands_out_workgroups_by_the_work_a_product_has():
+    """fneus/ops.py GemmPPJobs.finalize (host logic of fneus_dw_gemm_pp, no launch): at most 256 workgroups, every product at least
+    one, none more than its sample tiles / 4; products over other planes (own tile count) and products whose planes hold a
+    device-side number of samples (expected share 0.3) get workgroups in proportion to what they stream"""
+    import ctypes
+    from fneus import ops, _lib
+    z = lambda tiles, F: torch.zeros(1, tiles, F, 64, 8, dtype=torch.bfloat16)
+    T = 2048
+    big_a, big_b = z(T, 16), z(T, 16)
+    g = ops.GemmPPJobs(torch.device("cpu"), "test")
+    O = ops.PPOperand
+    for _ in range(17):                                   # the SDF network's products: full-width, the launch's 2048 tiles
+        g.add(O(big_a, 0, 8), O(big_b, 0, 8), 0, 256, 256, 256)
+    small_a, small_b = z(32, 16), z(32, 16)
+    own = ops._OwnPlanes(g, 32)
+    for _ in range(12):                                   # the RefColor heads': 32 tiles of their own
+        own.add(O(small_a, 0, 8), O(small_b, 0, 8), 0, 256, 256, 256)
+    cnt = torch.zeros(1, dtype=torch.int32)
+    bg_a, bg_b = z(2560, 16), z(2560, 16)
+    bg = ops._OwnPlanes(g, 2560, cnt)
+    for _ in range(14):                                   # the background network's: 2560 tiles allocated, ~30 % live
+        bg.add(O(bg_a, 0, 8), O(bg_b, 0, 8), 0, 256, 256, 256)
+    g.finalize(T)
+    splits = [j.splits for j in g.jobs]
+    assert g.n_wgs == sum(splits) <= 256 and min(splits) >= 1
+    assert [j.wg_base for j in g.jobs] == [sum(splits[:i]) for i in range(len(splits))]
+    assert all(j.n_tiles == 0 for j in g.jobs[:17]) and all(j.n_tiles == 32 for j in g.jobs[17:29]) and all(j.n_tiles == 2560 for j in g.jobs[29:])
+    assert all(s <= 32 // 4 for s in splits[17:29]) and all(s == 1 for s in splits[17:29])          # 1.5 % of a full product's work
+    sdf, bgs = splits[0], splits[29]
+    assert abs(bgs / sdf - 0.3 * 2560 / 2048) <= 0.15, (sdf, bgs)                                    # 0.375 of a full product each
+    assert all(j.n_dev == cnt.data_ptr() for j in g.jobs[29:]) and all(not j.n_dev for j in g.jobs[:29])
+    assert ctypes.sizeof(_lib.FneusGemmPPJob) == 152          # include/fneus.h FneusGemmPPJob (csrc/dw_gemm_pp.hip asserts its own mirror)
