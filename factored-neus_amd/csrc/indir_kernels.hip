@@ -249,6 +249,50 @@ __global__ void __launch_bounds__(256) latent_kl_bwd_kernel(const float* __restr
     d_latent[idx] = g;
 }
 
+// The two L1 terms of a stage-2 step (lvis.py:164-170) over the primary rays with a hit: lvis_loss = sum |gt - pre| / (4 n_hit +
+// 1e-6) on [B][4], radiance_loss = sum |gt - pre| / (12 n_hit + 1e-6) on [B][4][3], and their gradients with respect to the
+// predictions (rows of rays without a hit: zero).  ONE workgroup, fixed summation order; ~35 element-wise launches before.
+__global__ void __launch_bounds__(1024) stage2_loss_kernel(const float* __restrict__ gt_lvis, const float* __restrict__ pre_lvis,
+                                                           const float* __restrict__ gt_rad, const float* __restrict__ pre_rad,
+                                                           const unsigned char* __restrict__ hit, int n, float* __restrict__ out,
+                                                           float* __restrict__ d_lvis, float* __restrict__ d_rad) {
+    __shared__ float red[3][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float a[3] = {0.0f, 0.0f, 0.0f};          // n_hit, sum |lvis error|, sum |radiance error|
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        if (!hit[i]) continue;
+        a[0] += 1.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[1] += fabsf(gt_lvis[i * 4 + k] - pre_lvis[i * 4 + k]);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) a[2] += fabsf(gt_rad[i * 12 + k] - pre_rad[i * 12 + k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        for (int d = 32; d >= 1; d >>= 1) a[k] += __shfl_xor(a[k], d, 64);
+        if (lane == 0) red[k][wave] = a[k];
+    }
+    __syncthreads();
+    float t[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        for (int w = 0; w < 16; ++w) t[k] += red[k][w];
+    const float dl = t[0] * 4.0f + 1e-6f, dr = t[0] * 12.0f + 1e-6f;
+    if (threadIdx.x == 0) {
+        out[0] = t[1] / dl;
+        out[1] = t[2] / dr;
+        out[2] = t[0];
+    }
+    auto sg = [](float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); };
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const bool h = hit[i] != 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d_lvis[i * 4 + k] = h ? -sg(gt_lvis[i * 4 + k] - pre_lvis[i * 4 + k]) / dl : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) d_rad[i * 12 + k] = h ? -sg(gt_rad[i * 12 + k] - pre_rad[i * 12 + k]) / dr : 0.0f;
+    }
+}
+
 // The image terms of the stage-3 step (mateIllu.py:152-172): w = mask x hit, rgb_loss = sum |diff w| / (sum w + 1e-5),
 // psnr = 20 log10(1 / sqrt(sum diff^2 w / ((sum w + 1e-5) 3))), and d rgb_loss / d rgb.  ONE workgroup, fixed summation order
 // (thread t takes rays t, t + 1024, ...; wave tree; waves in order) -- ~22 element-wise launches forward and ~8 backward before.
@@ -335,6 +379,17 @@ __global__ void __launch_bounds__(256) sg_combine_bwd_kernel(const float* __rest
 }
 
 }  // namespace fneus
+
+extern "C" int fneus_stage2_loss(const float* gt_lvis, const float* pre_lvis, const float* gt_rad, const float* pre_rad,
+                                 const unsigned char* hit, int n, float* out, float* d_pre_lvis, float* d_pre_rad,
+                                 fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (!gt_lvis || !pre_lvis || !gt_rad || !pre_rad || !hit || !out || !d_pre_lvis || !d_pre_rad || n <= 0) return -2;
+    hipLaunchKernelGGL(fneus::stage2_loss_kernel, dim3(1), dim3(1024), 0, stream, gt_lvis, pre_lvis, gt_rad, pre_rad, hit, n, out,
+                       d_pre_lvis, d_pre_rad);
+    return fneus::launch_status();
+}
 
 extern "C" int fneus_stage3_loss(const float* rgb, const float* true_rgb, const float* mask, const unsigned char* hit, int n, float* out,
                                  float* d_rgb, fneus_stream_t stream_) {

@@ -119,6 +119,7 @@ def _load():
         "fneus_srgb_bwd": (C.c_int, [vp, vp, l, ip, vp, vp]),
         "fneus_indir_illum_fwd": (C.c_int, [vp, vp, ip, ip, ip, vp, vp]),
         "fneus_indir_illum_bwd": (C.c_int, [vp, vp, vp, ip, ip, ip, vp, vp]),
+        "fneus_stage2_loss": (C.c_int, [vp, vp, vp, vp, vp, ip, vp, vp, vp, vp]),
         "fneus_stage3_loss": (C.c_int, [vp, vp, vp, vp, ip, vp, vp, vp]),
         "fneus_latent_kl_fwd": (C.c_int, [vp, vp, ip, f, vp, vp]),
         "fneus_latent_kl_bwd": (C.c_int, [vp, vp, ip, f, vp, vp, vp, vp]),

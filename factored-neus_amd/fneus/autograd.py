@@ -333,6 +333,25 @@ class SgRenderFn(torch.autograd.Function):
         return d_lgt, d_mat, None, None, None, None, None
 
 
+class Stage2LossFn(torch.autograd.Function):
+    """fneus_stage2_loss: the two L1 terms of a stage-2 step over the rays with a hit and their gradients (lvis.py:164-170)"""
+
+    @staticmethod
+    def forward(ctx, pre_lvis, pre_rad, gt_lvis, gt_rad, hit):
+        c = lambda t: t.detach().float().contiguous()
+        out, d_l, d_r = ops.stage2_loss(c(gt_lvis), c(pre_lvis), c(gt_rad), c(pre_rad),
+                                        (hit.view(torch.uint8) if hit.dtype == torch.bool else hit).contiguous())
+        ctx.save_for_backward(d_l, d_r)
+        ctx.shapes = (pre_lvis.shape, pre_rad.shape)
+        ctx.mark_non_differentiable(out)
+        return out[0] + out[1], out         # (the sum: a tensor of its own that carries the gradient)
+
+    @staticmethod
+    def backward(ctx, d_loss, _d_out):
+        d_l, d_r = ctx.saved_tensors
+        return (d_l * d_loss).reshape(ctx.shapes[0]), (d_r * d_loss).reshape(ctx.shapes[1]), None, None, None
+
+
 class Stage3LossFn(torch.autograd.Function):
     """fneus_stage3_loss: the masked L1 colour term and the psnr of a stage-3 step, with the gradient of the former"""
 

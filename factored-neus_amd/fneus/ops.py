@@ -1066,6 +1066,15 @@ def outside_alpha_bwd(density, rgb, dists, d_alpha, d_rgb):
     return d_density, d_raw
 
 
+def stage2_loss(gt_lvis, pre_lvis, gt_rad, pre_rad, hit):
+    """-> out [3] = (lvis_loss, radiance_loss, n_hit), d_pre_lvis, d_pre_rad (include/fneus.h fneus_stage2_loss)"""
+    out = torch.empty(3, dtype=torch.float32, device=pre_lvis.device)
+    d_l, d_r = torch.empty_like(pre_lvis), torch.empty_like(pre_rad)
+    _launch("fneus_stage2_loss", lib.fneus_stage2_loss, _ptr(gt_lvis), _ptr(pre_lvis), _ptr(gt_rad), _ptr(pre_rad), _ptr(hit),
+            pre_lvis.shape[0], _ptr(out), _ptr(d_l), _ptr(d_r), _stream())
+    return out, d_l, d_r
+
+
 def stage3_loss(rgb, true_rgb, mask, hit):
     """-> out [3] = (rgb_loss, psnr, sum of the weights), d_rgb [n, 3] = d rgb_loss / d rgb (include/fneus.h fneus_stage3_loss)"""
     out = torch.empty(3, dtype=torch.float32, device=rgb.device)

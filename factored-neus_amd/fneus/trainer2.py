@@ -23,6 +23,13 @@ def stage2_loss(out: dict, reduce=None):
     SHARE of the global batch's (the hit count that normalises them is global), so that R ranks x B rays give the loss and the
     gradient of one R*B-ray batch when the shares / the rank gradients are summed"""
     m = out["sdf_mask"]
+    if reduce is None and out["pre_lvis"].is_cuda and out["pre_lvis"].dtype == torch.float32 and out["pre_lvis"].dim() == 2 \
+            and out["pre_lvis"].shape[1] == 4 and out["pre_lvis"].shape[0] == m.shape[0]:
+        # both terms and their gradients in one launch (~35 element-wise ones).  Rows without a hit hold equal values on both
+        # sides (1, or -- `raw` results of the fixed-shape step -- placeholders): the kernel skips them by the mask
+        from fneus.autograd import Stage2LossFn
+        loss, vals = Stage2LossFn.apply(out["pre_lvis"], out["pre_trace_radiance"], out["gt_lvis"], out["gt_trace_radiance"], m)
+        return {"loss": loss, "lvis_loss": vals[0], "trace_radiance_loss": vals[1]}
     n_hit = m.sum().float().reshape(1)
     if reduce is not None:
         n_hit = reduce(n_hit)
@@ -264,7 +271,7 @@ class Stage2Trainer:
         rays_o, rays_d, _rgb, _mask = ops.split_batch(data.contiguous())
         self._direct_grads(True)
         try:
-            out = self.renderer.lvis_render(rays_o, rays_d, None, None, fixed_shape=True)
+            out = self.renderer.lvis_render(rays_o, rays_d, None, None, fixed_shape=True, raw=self.reduce is None)
         finally:
             self._direct_grads(False)
         losses = stage2_loss(out, self.reduce)

@@ -344,7 +344,8 @@ class NeuSRenderer:
                 inside_any = (torch.linalg.norm(pts, ord=2, dim=-1) < 1.0).any(dim=-1)
         return {"n_samples": n, "mid_z_vals": mid_z, "sdf": sdf[:, None], "inside_sphere_mask": inside_any}
 
-    def lvis_render(self, rays_o, rays_d, near, far, u_theta=None, u_z=None, trace=None, fixed_shape=False, z_vals_override=None):
+    def lvis_render(self, rays_o, rays_d, near, far, u_theta=None, u_z=None, trace=None, fixed_shape=False, z_vals_override=None,
+                    raw=False):
         """renderer.py:567-627: visibility / traced radiance of 4 secondary rays per visible surface point, and the
         predictions of the Lvis / IndirectLight networks.  Rows of rays without a surface hit hold 1.
         fneus_ray_hit finds the hit points.  Default: they are compacted (one host read of the hit count per step, as the
@@ -369,6 +370,8 @@ class NeuSRenderer:
                 _, _, n_surf = self.sdf_network.value_feature_normal(RaySamples(pts=pts_surf), False)
             res = cal_indiLgt(pts_surf, n_surf, self.sdf_network, self.deviation_network, self.color_network,
                               self.lvis_network, self.indiLgt_network, u_theta=u_theta, u_z=u_z, trace=trace, point_mask=sdf_mask)
+            if raw:      # (the caller applies the mask itself -- fneus_stage2_loss: rows of rays without a hit are placeholders)
+                return dict(res, sdf_mask=sdf_mask)
             one = torch.ones((), device=dev)
             out = {"sdf_mask": sdf_mask}
             for k in ("gt_lvis", "pre_lvis"):

@@ -393,6 +393,11 @@ int fneus_sg_render_fwd(const float* lgt_sgs, const float* indir_sgs, const floa
 int fneus_sg_render_bwd(const float* lgt_sgs, const float* indir_sgs, const float* vis, const float* normal, const float* view,
                         const float* material, int n_pts, int n_direct, int n_indirect, float specular_reflectance,
                         const float* d_out, float* d_material, float* d_lgt_sgs, fneus_stream_t stream);
+/* The two L1 terms of a stage-2 step (lvis.py:164-170) over the n primary rays, 4 secondary rays each: out[0] = sum over rays
+ * with a hit of |gt_lvis - pre_lvis| / (4 n_hit + 1e-6), out[1] = the same of the traced radiance [n][4][3] / (12 n_hit + 1e-6),
+ * out[2] = n_hit; d_pre_lvis [n][4], d_pre_rad [n][4][3]: gradients of out[0] / out[1] (zero rows without a hit). */
+int fneus_stage2_loss(const float* gt_lvis, const float* pre_lvis, const float* gt_rad, const float* pre_rad,
+                      const unsigned char* hit, int n, float* out /*[3]*/, float* d_pre_lvis, float* d_pre_rad, fneus_stream_t stream);
 /* The image terms of a stage-3 step (mateIllu.py:152-172) over n rays: w = mask x hit; out[0] = sum |(rgb - true_rgb) w| /
  * (sum w + 1e-5), out[1] = psnr, out[2] = sum w; d_rgb [n][3] = d out[0] / d rgb. */
 int fneus_stage3_loss(const float* rgb, const float* true_rgb, const float* mask /*[n]*/, const unsigned char* hit /*[n]*/, int n,
