@@ -508,7 +508,7 @@ def main():
             dt_2, n_hit, graph2 = timed_stage(lambda: Stage2Trainer(device, prec=prec, use_graph=not args.no_graph))
             result["stage2_step"] = {"value": 4 * n_hit * 512 / dt_2, "unit": "secondary-ray SDF samples/s", "ms_per_step": dt_2 * 1e3,
                                      "primary_rays": RAYS, "mean_hit_points": n_hit, "secondary_rays": 4 * n_hit,
-                                     "launch": "one hipGraph replay per step (fixed shape: 4 x 512 secondary rays marched, misses masked)"
+                                     "launch": "one hipGraph replay per step (fixed shape: the 4 secondary rays of every primary ray with a hit marched)"
                                                if graph2 else "eager launches, hit points compacted",
                                      "note": "lvis_render + L1 losses + backward + Adam (lvis.py:132-196): 4 secondary rays per hit "
                                              "point x 512 coarse samples through K1, 32 fine samples through K2, same precision mode"}
@@ -522,7 +522,9 @@ def main():
                                      "launch": "one hipGraph replay per step (fixed shape: all 512 rays evaluated, misses masked)"
                                                if graph3 else "eager launches, hit points compacted",
                                      "note": "mateIllu_render + masked L1 + latent sparsity + backward + Adam (mateIllu.py:135-203): "
-                                             "128 light lobes x 32 directions through Lvis per hit point, SG rendering of 128 + 24 lobes"}
+                                             "128 light lobes x 32 directions per hit point (the nominal count `value` uses; the network "
+                                             "runs on the directions that face the surface, as in the reference: about half), SG rendering "
+                                             "of 128 + 24 lobes"}
         except Exception as e:
             result["stage3_step"] = {"value": None, "error": repr(e)}
 
