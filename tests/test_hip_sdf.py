@@ -55,10 +55,13 @@ def test_sdf_fwd_chip_filling_launch_uses_64_sample_workgroups(env, prec, tol):
     print(f"sdf_fwd (64-sample workgroups) prec={prec} max abs err {err:.3e}")
     assert err <= tol
     # the same points in chunks below the threshold go through the other kernels: same hidden layers, same order; the sdf row of
-    # the linear last layer is an fp32 dot product in the round-3 kernels (3-product MFMA in the round-2 ones): <= 1e-5 apart
+    # the linear last layer is the same fp32 dot product in both round-3 kernel families: observed 0.0 apart (round 4); the bound of
+    # round 2 (2e-6) stands for a reordered dot product -- 1e-5 was needed only against the round-2 kernels' 3-product MFMA row
     parts = torch.cat([ops.sdf_fwd(env["net"].blob, len(c), prec, pts=c.contiguous()) for c in xd.split(20000)])
     if prec == 3:
-        assert (out - parts).abs().max().item() <= 1e-5
+        apart = (out - parts).abs().max().item()
+        print(f"  two-pass kernel vs the small-launch kernels on the same points: {apart:.2e}")
+        assert apart <= 2e-6
     again = ops.sdf_fwd(env["net"].blob, n, prec, pts=xd)
     assert torch.equal(out, again)                # repeatable
 
