@@ -325,7 +325,8 @@ __global__ void __launch_bounds__(64) composite_fwd_kernel(
     const float* __restrict__ bg_alpha, const float* __restrict__ bg_color, int n_out,
     float* __restrict__ weights, float* __restrict__ color, float* __restrict__ wsum, float* __restrict__ wmax,
     float* __restrict__ cdf_out, float* __restrict__ inside_out, float* __restrict__ eik /*[2][B]*/,
-    int* __restrict__ min_idx_out, unsigned char* __restrict__ mask_out, float* __restrict__ wpair /*[B][2]*/) {
+    int* __restrict__ min_idx_out, unsigned char* __restrict__ mask_out, float* __restrict__ wpair /*[B][2]*/,
+    const float* __restrict__ back_rgb /*[back_rows][3] or NULL*/, int back_rows) {
     const float car = car_dev ? *car_dev : car_host;     // device scalar: the value can change between replays of a captured step
     const int ray = blockIdx.x, lane = threadIdx.x;
     const float inv_s = load_inv_s(inv_s_ptr, inv_s_mode);
@@ -402,7 +403,12 @@ __global__ void __launch_bounds__(64) composite_fwd_kernel(
     for (int c = 0; c < 3; ++c) csum[c] = wave_sum(csum[c]);
     if (lane == 0) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) color[ray * 3 + c] = csum[c];
+        for (int c = 0; c < 3; ++c) {
+            // renderer.py:367-368: color + background_rgb * (1 - weights_sum), the product and the sum rounded separately as the
+            // element-wise formulation does
+            const float back = back_rgb ? __fmul_rn(back_rgb[(back_rows > 1 ? ray : 0) * 3 + c], __fadd_rn(1.0f, -ws)) : 0.0f;
+            color[ray * 3 + c] = back_rgb ? __fadd_rn(csum[c], back) : csum[c];
+        }
         wsum[ray] = ws;
         wmax[ray] = wm;
         eik[ray] = en;                       // planar: both rows are contiguous [B] vectors for the loss kernel
@@ -448,7 +454,8 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(
     const float* __restrict__ d_weights /*[B][nt] or null*/, const float* __restrict__ d_wpair /*[B][2]*/,
     const float* __restrict__ d_eiknum /*[B]*/, float* __restrict__ d_sdf, float* __restrict__ d_normal,
     float* __restrict__ d_rgb, float* __restrict__ d_inv_s /*[B]*/, float* __restrict__ d_bg_alpha /*[B][nt]*/,
-    float* __restrict__ d_bg_color /*[B][nt][3]*/) {
+    float* __restrict__ d_bg_color /*[B][nt][3]*/,
+    const float* __restrict__ back_rgb /*[back_rows][3] or NULL*/, int back_rows) {
     const float car = car_dev ? *car_dev : car_host;     // device scalar: the value can change between replays of a captured step
     const int ray = blockIdx.x, lane = threadIdx.x;
     const float inv_s = load_inv_s(inv_s_ptr, inv_s_mode);
@@ -461,7 +468,11 @@ __global__ void __launch_bounds__(64) composite_bwd_kernel(
         d[c] = rays_d[ray * 3 + c];
         dc[c] = d_color[ray * 3 + c];
     }
-    const float dws = d_wsum[ray];
+    float dws = d_wsum[ray];
+    if (back_rgb) {                          // color = ... + background_rgb (1 - wsum): wsum's cotangent gets -(d_color . background_rgb)
+        const float* bk = back_rgb + (back_rows > 1 ? ray : 0) * 3;
+        dws -= __fadd_rn(__fadd_rn(__fmul_rn(dc[0], bk[0]), __fmul_rn(dc[1], bk[1])), __fmul_rn(dc[2], bk[2]));
+    }
     const float deik = d_eiknum[ray];
     const bool mask = mask_in[ray] != 0;
     const int idx = min_idx[ray];
@@ -1024,14 +1035,15 @@ extern "C" int fneus_composite_fwd(const float* rays_o, const float* rays_d, con
                                    const float* bg_alpha,
                                    const float* bg_color, int n_out, float* weights, float* color, float* wsum,
                                    float* wmax, float* cdf, float* inside, float* eik, int32_t* min_idx,
-                                   unsigned char* sdf_mask, float* wpair, fneus_stream_t stream_) {
+                                   unsigned char* sdf_mask, float* wpair, const float* background_rgb, int background_rows,
+                                   fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     fneus::clear_status();
     if (n_rays <= 0) return 0;
     FN_CHECK_N(n + (bg_alpha ? n_out : 0));
     hipLaunchKernelGGL(composite_fwd_kernel, dim3(n_rays), dim3(64), 0, stream, rays_o, rays_d, mid_z, dists, sdf, normal,
                        rgb, inv_s, inv_s_mode, n, cos_anneal_ratio, cos_anneal_dev, bg_alpha, bg_color, n_out, weights, color, wsum, wmax, cdf, inside,
-                       eik, min_idx, sdf_mask, wpair);
+                       eik, min_idx, sdf_mask, wpair, background_rgb, background_rows);
     return fneus::launch_status();
 }
 
@@ -1043,14 +1055,14 @@ extern "C" int fneus_composite_bwd(const float* rays_o, const float* rays_d, con
                                    const unsigned char* sdf_mask, const float* d_color, const float* d_wsum,
                                    const float* d_weights, const float* d_wpair, const float* d_eiknum, float* d_sdf,
                                    float* d_normal, float* d_rgb, float* d_inv_s, float* d_bg_alpha, float* d_bg_color,
-                                   fneus_stream_t stream_) {
+                                   const float* background_rgb, int background_rows, fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     fneus::clear_status();
     if (n_rays <= 0) return 0;
     FN_CHECK_N(n + (bg_alpha ? n_out : 0));
     hipLaunchKernelGGL(composite_bwd_kernel, dim3(n_rays), dim3(64), 0, stream, rays_o, rays_d, mid_z, dists, sdf, normal,
                        rgb, inv_s, inv_s_mode, n, cos_anneal_ratio, cos_anneal_dev, bg_alpha, bg_color, n_out, min_idx, sdf_mask, d_color, d_wsum,
-                       d_weights, d_wpair, d_eiknum, d_sdf, d_normal, d_rgb, d_inv_s, d_bg_alpha, d_bg_color);
+                       d_weights, d_wpair, d_eiknum, d_sdf, d_normal, d_rgb, d_inv_s, d_bg_alpha, d_bg_color, background_rgb, background_rows);
     return fneus::launch_status();
 }
 

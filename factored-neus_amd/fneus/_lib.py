@@ -136,8 +136,8 @@ def _load():
         "fneus_lvis_visibility": (C.c_int, [vp, vp, vp, vp, vp, vp, ip, ip, ip, vp, ip, vp]),
         "fneus_ray_hit": (C.c_int, [vp] * 7 + [ip, ip, f] + [vp] * 5 + [vp]),
         "fneus_sample_dirs": (C.c_int, [vp] * 4 + [ip, ip, vp, vp, vp]),
-        "fneus_composite_fwd": (C.c_int, [vp] * 8 + [ip, ip, ip, f, vp, vp, vp, ip] + [vp] * 10 + [vp]),
-        "fneus_composite_bwd": (C.c_int, [vp] * 8 + [ip, ip, ip, f, vp, vp, vp, ip] + [vp] * 13 + [vp]),
+        "fneus_composite_fwd": (C.c_int, [vp] * 8 + [ip, ip, ip, f, vp, vp, vp, ip] + [vp] * 10 + [vp, ip, vp]),
+        "fneus_composite_bwd": (C.c_int, [vp] * 8 + [ip, ip, ip, f, vp, vp, vp, ip] + [vp] * 13 + [vp, ip, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)

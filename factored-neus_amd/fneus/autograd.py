@@ -474,13 +474,15 @@ class CompositeFn(torch.autograd.Function):
     Differentiable outputs: color [B,3], weights [B,n(+n_out)], wsum [B], wpair [B,2], eik_num [B]."""
 
     @staticmethod
-    def forward(ctx, sdf, normal, rgb, variance, rays_o, rays_d, mid_z, dists, car: float, bg_alpha=None, bg_color=None):
+    def forward(ctx, sdf, normal, rgb, variance, rays_o, rays_d, mid_z, dists, car: float, bg_alpha=None, bg_color=None,
+                back_rgb=None):
+        """back_rgb [1, 3] / [B, 3] (a constant): color + back_rgb (1 - wsum) of renderer.py:367-368, inside the kernels"""
         bga = None if bg_alpha is None else bg_alpha.contiguous()
         bgc = None if bg_color is None else bg_color.contiguous()
         var1 = variance.detach().reshape(1).contiguous()
         out = ops.composite_fwd(rays_o, rays_d, mid_z, dists, sdf.contiguous(), normal.contiguous(), rgb.contiguous(),
-                                var1, car, bga, bgc, inv_s_mode=1)
-        ctx.car, ctx.has_bg, ctx.var_shape = car, bga is not None, variance.shape
+                                var1, car, bga, bgc, inv_s_mode=1, back_rgb=back_rgb)
+        ctx.car, ctx.has_bg, ctx.var_shape, ctx.back_rgb = car, bga is not None, variance.shape, back_rgb
         ctx.set_materialize_grads(False)        # unused outputs (e.g. `weights`) must not be zero-filled for us
         saved = [sdf, normal, rgb, var1, rays_o, rays_d, mid_z, dists, out["min_idx"], out["sdf_mask"]]
         if ctx.has_bg:
@@ -506,8 +508,8 @@ class CompositeFn(torch.autograd.Function):
         d_weights = None if d_weights is None else d_weights.contiguous()
         d_sdf, d_normal, d_rgb, d_var, d_bga, d_bgc = ops.composite_bwd(
             rays_o, rays_d, mid_z, dists, sdf, normal, rgb, var1, ctx.car, min_idx, sdf_mask, d_color, d_wsum, d_weights,
-            d_wpair, d_eiknum, bga, bgc, inv_s_mode=1)
-        return d_sdf, d_normal, d_rgb, d_var.sum().reshape(ctx.var_shape), None, None, None, None, None, d_bga, d_bgc
+            d_wpair, d_eiknum, bga, bgc, inv_s_mode=1, back_rgb=ctx.back_rgb)
+        return d_sdf, d_normal, d_rgb, d_var.sum().reshape(ctx.var_shape), None, None, None, None, None, d_bga, d_bgc, None
 
 
 _GATHERED = {}       # (feat_sel pointer, normal_sel pointer) of the latest surface_gather -> (SDF workspace, sel)

@@ -1279,13 +1279,23 @@ def _car(car):
     return float(car), None
 
 
+def _back_rows(back_rgb, B):
+    if back_rgb is None:
+        return None, 0
+    back_rgb = back_rgb.detach().float().reshape(-1, 3).contiguous()
+    assert back_rgb.shape[0] in (1, B), "background_rgb: one colour or one per ray"
+    return back_rgb, int(back_rgb.shape[0])
+
+
 def composite_fwd(rays_o, rays_d, mid_z, dists, sdf, normal, rgb, inv_s, car: float, bg_alpha=None, bg_color=None,
-                  inv_s_mode: int = 0):
-    """inv_s_mode 1: `inv_s` is the variance parameter (see include/fneus.h).  out["eik"] is [2, B]."""
+                  inv_s_mode: int = 0, back_rgb=None):
+    """inv_s_mode 1: `inv_s` is the variance parameter (see include/fneus.h).  out["eik"] is [2, B].
+    back_rgb [1, 3] / [B, 3]: the constant background colour of renderer.py:367-368, added inside the kernel"""
     B, n = mid_z.shape
     n_out = 0 if bg_alpha is None else bg_alpha.shape[1] - n
     nt = n + n_out
     dev = mid_z.device
+    back, back_rows = _back_rows(back_rgb, B)
     f32 = dict(dtype=torch.float32, device=dev)
     out = {
         "weights": torch.empty(B, nt, **f32), "color": torch.empty(B, 3, **f32), "wsum": torch.empty(B, **f32),
@@ -1297,13 +1307,14 @@ def composite_fwd(rays_o, rays_d, mid_z, dists, sdf, normal, rgb, inv_s, car: fl
             _ptr(normal), _ptr(rgb), _ptr(inv_s), int(inv_s_mode), B, n, *_car(car), _ptr(bg_alpha), _ptr(bg_color), n_out,
             _ptr(out["weights"]), _ptr(out["color"]), _ptr(out["wsum"]), _ptr(out["wmax"]), _ptr(out["cdf"]),
             _ptr(out["inside"]), _ptr(out["eik"]), _ptr(out["min_idx"]), _ptr(out["sdf_mask"]), _ptr(out["wpair"]),
-            _stream())
+            _ptr(back), back_rows, _stream())
     return out
 
 
 def composite_bwd(rays_o, rays_d, mid_z, dists, sdf, normal, rgb, inv_s, car, min_idx, sdf_mask, d_color, d_wsum,
-                  d_weights, d_wpair, d_eiknum, bg_alpha=None, bg_color=None, inv_s_mode: int = 0):
+                  d_weights, d_wpair, d_eiknum, bg_alpha=None, bg_color=None, inv_s_mode: int = 0, back_rgb=None):
     B, n = mid_z.shape
+    back, back_rows = _back_rows(back_rgb, B)
     n_out = 0 if bg_alpha is None else bg_alpha.shape[1] - n
     dev = mid_z.device
     d_sdf = torch.empty(B * n, dtype=torch.float32, device=dev)
@@ -1315,5 +1326,5 @@ def composite_bwd(rays_o, rays_d, mid_z, dists, sdf, normal, rgb, inv_s, car, mi
     _launch("fneus_composite_bwd", lib.fneus_composite_bwd, _ptr(rays_o), _ptr(rays_d), _ptr(mid_z), _ptr(dists), _ptr(sdf),
             _ptr(normal), _ptr(rgb), _ptr(inv_s), int(inv_s_mode), B, n, *_car(car), _ptr(bg_alpha), _ptr(bg_color), n_out, _ptr(min_idx),
             _ptr(sdf_mask), _ptr(d_color), _ptr(d_wsum), _ptr(d_weights), _ptr(d_wpair), _ptr(d_eiknum), _ptr(d_sdf),
-            _ptr(d_normal), _ptr(d_rgb), _ptr(d_inv_s), _ptr(d_bga), _ptr(d_bgc), _stream())
+            _ptr(d_normal), _ptr(d_rgb), _ptr(d_inv_s), _ptr(d_bga), _ptr(d_bgc), _ptr(back), back_rows, _stream())
     return d_sdf, d_normal, d_rgb, d_inv_s, d_bga, d_bgc

@@ -187,9 +187,11 @@ class NeuSRenderer:
         (color, weights, wsum, wpair, eik_num, wmax, cdf, inside, eik_den, min_idx, sdf_mask_u8) = CompositeFn.apply(
             sdf, normal, rgb, deviation_network.variance, rays_o, rays_d, mid_z, dists,
             cos_anneal_ratio if torch.is_tensor(cos_anneal_ratio) else float(cos_anneal_ratio),
-            background_alpha, background_sampled_color)
+            background_alpha, background_sampled_color,
+            # renderer.py:367-368 `color + background_rgb * (1 - weights_sum)` for a constant background: inside the kernels
+            background_rgb if (background_rgb is not None and not background_rgb.requires_grad) else None)
         sdf_mask = sdf_mask_u8.view(torch.bool)          # the kernel writes exactly 0 / 1: reinterpret, no cast kernel
-        if background_rgb is not None:
+        if background_rgb is not None and background_rgb.requires_grad:
             color = color + background_rgb * (1.0 - wsum[:, None])
 
         # surface branch at fixed shape (renderer.py:284-343): the two samples bracketing the first sign change

@@ -485,7 +485,8 @@ int fneus_composite_fwd(const float* rays_o, const float* rays_d, const float* m
                         const float* bg_color /*[B][n+n_out][3] or NULL*/, int n_out,
                         float* weights /*[B][n (+n_out)]*/, float* color, float* wsum, float* wmax, float* cdf,
                         float* inside, float* eik, int32_t* min_idx, unsigned char* sdf_mask, float* wpair,
-                        fneus_stream_t stream);
+                        const float* background_rgb /*[background_rows][3] (1 row or one per ray) or NULL: color +=
+                        background_rgb (1 - wsum), renderer.py:367-368*/, int background_rows, fneus_stream_t stream);
 /* adjoint of fneus_composite_fwd; d_weights may be NULL; d_inv_s is per ray (caller sums). */
 int fneus_composite_bwd(const float* rays_o, const float* rays_d, const float* mid_z, const float* dists, const float* sdf,
                         const float* normal, const float* rgb, const float* inv_s, int inv_s_mode, int n_rays, int n,
@@ -495,7 +496,7 @@ int fneus_composite_bwd(const float* rays_o, const float* rays_d, const float* m
                         const float* d_color, const float* d_wsum, const float* d_weights, const float* d_wpair,
                         const float* d_eiknum, float* d_sdf, float* d_normal, float* d_rgb, float* d_inv_s,
                         float* d_bg_alpha /*[B][n+n_out] or NULL*/, float* d_bg_color /*or NULL*/,
-                        fneus_stream_t stream);
+                        const float* background_rgb /*as in the forward: a constant*/, int background_rows, fneus_stream_t stream);
 
 /* ---- optimiser: torch.optim.Adam.step() over the whole model in one launch (exp_runner.py:108, 179-181) ---------- */
 /* segs: HOST array of contiguous parameter runs (32 per launch).  lr and step are device scalars (step is incremented first,

@@ -355,3 +355,35 @@ def test_colour_products_inside_the_sdf_launch_change_nothing(golden_dir, name, 
     for k in res["1"]:
         scale = res["0"][k].abs().max().item() + 1e-12
         assert (res["1"][k] - res["0"][k]).abs().max().item() <= 2e-5 * scale + 1e-9, (k, scale)
+
+
+@pytest.mark.parametrize("rows", [1, 40])
+def test_constant_background_colour_inside_the_compositing_kernels(rows):
+    """renderer.py:367-368 `color + background_rgb * (1 - weights_sum)` in fneus_composite_fwd / _bwd (back_rgb) against the two
+    element-wise lines behind the kernel: same colour bit for bit, same gradients of sdf / normal / rgb"""
+    from fneus import synth
+    from fneus.autograd import CompositeFn
+    B, n = 40, 64
+    g = torch.Generator().manual_seed(2)
+    data = torch.from_numpy(synth.ray_batch(B, seed=3)).to(DEV)
+    ro, rd = data[:, :3].contiguous(), data[:, 3:6].contiguous()
+    mid = -(ro * rd).sum(-1, keepdim=True)
+    z = (mid - 1.0 + 2.0 * torch.rand(B, n, generator=g).sort(dim=1).values.to(DEV)).contiguous()
+    dists = torch.full_like(z, 2.0 / n)
+    var = torch.tensor(0.3, device=DEV, requires_grad=True)
+    back = torch.rand(rows, 3, generator=g).to(DEV)
+    res = []
+    for fused in (True, False):
+        sdf = (torch.randn(B * n, generator=torch.Generator().manual_seed(5)) * 0.2).to(DEV).requires_grad_(True)
+        nrm = torch.nn.functional.normalize(torch.randn(B * n, 3, generator=torch.Generator().manual_seed(6)), dim=-1).to(DEV).requires_grad_(True)
+        rgb = torch.rand(B * n, 3, generator=torch.Generator().manual_seed(7)).to(DEV).requires_grad_(True)
+        out = CompositeFn.apply(sdf, nrm, rgb, var, ro, rd, z, dists, 0.5, None, None, back if fused else None)
+        color, wsum = out[0], out[2]
+        if not fused:
+            color = color + back * (1.0 - wsum[:, None])
+        w = torch.rand(B, 3, generator=torch.Generator().manual_seed(8)).to(DEV)
+        ((color * w).sum() + 0.3 * wsum.sum()).backward()
+        res.append((color.detach(), sdf.grad, nrm.grad, rgb.grad))
+    assert torch.equal(res[0][0], res[1][0])
+    for a, b in zip(res[0][1:], res[1][1:]):
+        assert (a - b).abs().max().item() <= 1e-6 * b.abs().max().item() + 1e-12
