@@ -5,6 +5,7 @@ Points are never differentiated (all z values are produced under no_grad in the 
 """
 from __future__ import annotations
 
+import weakref
 from typing import Optional
 
 import torch
@@ -90,7 +91,7 @@ class SdfValueGradFn(torch.autograd.Function):
             if dns is not None:
                 d_normal.index_add_(0, sel, dns)
         heads = ws.cache.pop("surface_head_grads", None)      # (RefHeadsFn.backward: per-head gradients of the gathered rows)
-        if heads is not None:
+        if heads is not None and heads[3] == (id(ws), ctx.generation):    # (a leftover of another forward does not ride along)
             ops.surface_scatter(heads[0], heads[1], heads[2], d_feat, d_normal)       # head sum + scatter-add in one launch
         bufs = ws.get(("sdf_bwd", n, prec), lambda: ops.SdfBwdBufs(n, dev, prec, gprec=ctx.stash.gprec))
         ops.sdf_bwd(net.blob, n, prec, ctx.stash, bufs, d_sdf, d_feat, d_normal, **ctx.samples.kw())
@@ -103,9 +104,22 @@ class SdfValueGradFn(torch.autograd.Function):
         if _PENDING_OPEN.get(dev) == mine:
             _PENDING_OPEN[dev] = None
         col, ref = ws.cache.pop("pending_color_dw", None), ws.cache.pop("pending_ref_dw", None)
-        col = col if col is not None and col["for"] == mine else None
-        ref = ref if ref is not None and ref["for"] == mine else None
-        bgs = [r for r in _PENDING_NERF.pop(dev, {}).values() if r["for"] == mine]
+        # a record made for ANOTHER forward of this workspace (two renders before one backward pass) is not dropped: its
+        # products run as a launch of their own, unless its own stash has been overwritten since (then it is stale)
+        if col is not None and col["for"] != mine:
+            if _record_alive(col["stash"], col["gen"]):
+                _run_color_dw(col)
+            col = None
+        if ref is not None and ref["for"] != mine:
+            if _record_alive(ref["st"][0], ref["gen"]):
+                _run_ref_dw(ref)
+            ref = None
+        bgs = []
+        for r in _PENDING_NERF.pop(dev, {}).values():
+            if r["for"] == mine:
+                bgs.append(r)
+            elif _record_alive(r["stash"], r["gen"]):
+                _run_nerf_dw(r)
         if col is not None and (col["n"] != n or col["stash"].gprec != ctx.stash.gprec):
             _run_color_dw(col)
             col = None
@@ -136,6 +150,11 @@ class SdfValueGradFn(torch.autograd.Function):
             jobs.run()
         net.wn_backward(grad)
         return None, None, None, None, None, None
+
+
+def _record_alive(stash, gen):
+    """a waiting weight-gradient record may still run iff the stash it reads is the one its backward wrote into"""
+    return stash is not None and getattr(stash, "generation", None) == gen
 
 
 def _run_ref_dw(ref):
@@ -170,6 +189,9 @@ class ColorFn(torch.autograd.Function):
         rgb = ops.color_fwd(net.blob, n, prec, normal, feat, stash, train, dirs=samples.dirs, head=head, **samples.kw())
         ctx.net, ctx.prec, ctx.ws, ctx.sdf_ws, ctx.stash, ctx.n, ctx.head, ctx.samples = net, prec, ws, sdf_ws, stash, n, head, samples
         ctx.generation = ws.stamp(stash) if stash is not None else None
+        # the SDF forward whose feature planes this call consumes: the latest one on that workspace NOW (by the time of the
+        # backward a later render may have stamped it again)
+        ctx.sdf_generation = getattr(sdf_ws, "generation", None) if sdf_ws is not None else None
         if head != 0:
             ctx.save_for_backward(rgb, normal)
         else:
@@ -191,8 +213,8 @@ class ColorFn(torch.autograd.Function):
             d_feat, d_normal = ops.color_bwd(net.blob, n, prec, d_rgb.contiguous(), rgb, ctx.stash)
             feat_planes = ctx.sdf_ws.cache[("sdf_stash", n, prec, True)].feat
         grad = ws.get(("col_grad", n), lambda: torch.zeros(net.n_params, dtype=torch.float32, device=rgb.device))
-        col = dict(ws=ws, net=net, n=n, prec=prec, stash=ctx.stash, grad=grad, feat_planes=feat_planes,
-                   **{"for": (id(ctx.sdf_ws), getattr(ctx.sdf_ws, "generation", None))},
+        col = dict(ws=ws, net=net, n=n, prec=prec, stash=ctx.stash, grad=grad, feat_planes=feat_planes, gen=ctx.generation,
+                   **{"for": (id(ctx.sdf_ws), ctx.sdf_generation)},
                    key=(feat_planes.data_ptr(), tuple(feat_planes.shape), ctx.stash.zbar.data_ptr(), grad.data_ptr()))
         # Head 0 reads the SDF network's feature planes, so the SDF network's backward follows in this backward pass whenever the
         # features carry a gradient: its weight-gradient launch takes these products along (same samples, one launch instead of
@@ -237,7 +259,7 @@ class NerfFn(torch.autograd.Function):
         d_density = torch.zeros(n, device=dev) if d_density is None else d_density.contiguous()
         d_rgb = torch.zeros(n, 3, device=dev) if d_rgb is None else d_rgb.contiguous()
         ops.nerf_bwd(net.blob, n, prec, d_density, d_rgb, ctx.stash, ctx.n_dev)
-        rec = dict(ws=ws, net=net, n=n, prec=prec, stash=ctx.stash, n_dev=ctx.n_dev,
+        rec = dict(ws=ws, net=net, n=n, prec=prec, stash=ctx.stash, n_dev=ctx.n_dev, gen=ctx.generation,
                    key=(ctx.stash.zbar.data_ptr(), net.raw_grad.data_ptr(), 0 if ctx.n_dev is None else ctx.n_dev.data_ptr()))
         if ops.gemm_merge_enabled() and _PENDING_OPEN.get(dev) is not None:
             # an SDF network's backward is still to come in this pass (SdfValueGradFn.forward ran after this network's forward:
@@ -416,7 +438,7 @@ class RefHeadsFn(torch.autograd.Function):
         diffuse, spec = ops.refcolor_fwd_both(net_cd.blob, net_vd.blob, n, prec, normal, feat, st[0], st[1], train,
                                               dirs=samples.dirs, **samples.kw())
         ctx.nets, ctx.prec, ctx.ws, ctx.st, ctx.n, ctx.samples = (net_cd, net_vd), prec, ws, st, n, samples
-        ctx.gathered = _GATHERED.get((feat.data_ptr(), normal.data_ptr()))        # inputs straight from SurfaceGatherFn?
+        ctx.gathered = _take_gathered(feat, normal)          # inputs straight from SurfaceGatherFn? -> (SDF workspace, sel, stamp)
         ctx.generation = ws.stamp(st[0]) if st[0] is not None else None
         ctx.save_for_backward(diffuse, spec, normal)
         return diffuse, spec
@@ -440,8 +462,8 @@ class RefHeadsFn(torch.autograd.Function):
             ops.color_dw_jobs(net_vd, st[1].feat, st[1], g_vd, n, into=jobs)
             return jobs.finalize(st[0].tiles)
 
-        ref = dict(ws=ws, n=n, prec=prec, build=build, nets=(net_cd, net_vd), grads=(g_cd, g_vd), st=st,
-                   **{"for": None if ctx.gathered is None else (id(ctx.gathered[0]), getattr(ctx.gathered[0], "generation", None))},
+        ref = dict(ws=ws, n=n, prec=prec, build=build, nets=(net_cd, net_vd), grads=(g_cd, g_vd), st=st, gen=ctx.generation,
+                   **{"for": None if ctx.gathered is None else ctx.gathered[2]},
                    key=(st[0].zbar.data_ptr(), st[1].zbar.data_ptr(), grad.data_ptr()))
         early = getattr(ctx.gathered[0], "color_grads_early", None) if ctx.gathered is not None else None
         if ctx.gathered is not None and ops.gemm_merge_enabled() and not (early is not None and early()):
@@ -461,8 +483,8 @@ class RefHeadsFn(torch.autograd.Function):
         if ctx.gathered is not None:
             # the rows came from surface_gather: their per-head gradients go to the SDF backward as they are (one launch adds the
             # heads and scatters the rows) instead of sum -> SurfaceGatherFn.backward -> index_add_ (four launches)
-            sdf_ws, sel = ctx.gathered
-            sdf_ws.cache["surface_head_grads"] = (sel, d_feat2, d_normal2)
+            sdf_ws, sel, made_for = ctx.gathered
+            sdf_ws.cache["surface_head_grads"] = (sel, d_feat2, d_normal2, made_for)
             return None, None, None, None, None, None, None, None, None
         return None, d_normal2.sum(0), d_feat2.sum(0), None, None, None, None, None, None
 
@@ -512,7 +534,20 @@ class CompositeFn(torch.autograd.Function):
         return d_sdf, d_normal, d_rgb, d_var.sum().reshape(ctx.var_shape), None, None, None, None, None, d_bga, d_bgc, None
 
 
-_GATHERED = {}       # (feat_sel pointer, normal_sel pointer) of the latest surface_gather -> (SDF workspace, sel)
+# The latest surface_gather's outputs, held WEAKLY and recognised by identity (an address can be handed to an unrelated tensor of
+# the same shape by the caching allocator once the rows are freed): (ref(feat_sel), ref(normal_sel), SDF workspace, sel, stamp of
+# the SDF forward the rows came from).  One slot, taken by the first consumer that asks for exactly these tensors.
+_GATHERED = []
+
+
+def _take_gathered(feat, normal):
+    if not _GATHERED:
+        return None
+    rf, rn, sdf_ws, sel, made_for = _GATHERED[0]
+    if rf() is feat and rn() is normal:
+        _GATHERED.clear()
+        return sdf_ws, sel, made_for
+    return None
 
 
 class SurfaceGatherFn(torch.autograd.Function):
@@ -528,7 +563,8 @@ class SurfaceGatherFn(torch.autograd.Function):
         # a consumer that produces per-head gradients of exactly these rows (RefHeadsFn) may hand them to the SDF backward
         # directly (fneus_surface_scatter) instead of summing them and going through this function's backward
         _GATHERED.clear()                    # (one slot: the consumer looks it up right behind this call, in the same step)
-        _GATHERED[(feat_sel.data_ptr(), normal_sel.data_ptr())] = (sdf_ws, sel)
+        _GATHERED.append((weakref.ref(feat_sel), weakref.ref(normal_sel), sdf_ws, sel,
+                          (id(sdf_ws), getattr(sdf_ws, "generation", None))))
         ctx.save_for_backward(sel)
         ctx.mark_non_differentiable(t_sel, sel)
         ctx.set_materialize_grads(False)         # no zero-filled cotangents for the two index outputs
@@ -567,7 +603,8 @@ class Stage1LossFn(torch.autograd.Function):
     def backward(ctx, g, *unused):
         if g is None:
             return (None,) * 15
-        if ops.UNIT_LOSS_GRAD:               # the trainers' `loss.backward()`: the cotangent is the constant 1 (ops.unit_loss_grad)
+        seed = ops.UNIT_LOSS_SEED            # the trainers' `loss.backward(one)`: the cotangent IS their persistent constant 1
+        if seed is not None and (g is seed or (g.data_ptr() == seed.data_ptr() and g.shape == seed.shape)):
             return tuple(ctx.saved_tensors) + (None,) * 9
         grads = torch._foreach_mul(list(ctx.saved_tensors), g)
         return tuple(grads) + (None,) * 9

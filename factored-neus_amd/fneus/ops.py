@@ -106,20 +106,24 @@ def _launch(name, fn, *args):
 
 
 # The fused loss kernel hands out the gradients of the TOTAL loss; autograd multiplies them by the cotangent of the loss -- a launch
-# per step for a factor that is the constant 1 when the trainer calls loss.backward().  Inside `with unit_loss_grad():` the saved
-# gradients are passed on as they are.
-UNIT_LOSS_GRAD = False
+# per step for a factor that is the constant 1 when the trainer calls loss.backward(one).  Inside `with unit_loss_grad(one):` a
+# loss node whose cotangent IS that tensor (identity, not value: a loss-scaling wrapper or a hook that multiplies the loss hands
+# autograd another tensor and gets the multiply) passes the saved gradients on as they are.
+UNIT_LOSS_SEED = None
 
 
 class unit_loss_grad:
+    def __init__(self, seed):
+        self.seed = seed
+
     def __enter__(self):
-        global UNIT_LOSS_GRAD
-        self.prev, UNIT_LOSS_GRAD = UNIT_LOSS_GRAD, True
+        global UNIT_LOSS_SEED
+        self.prev, UNIT_LOSS_SEED = UNIT_LOSS_SEED, self.seed
         return self
 
     def __exit__(self, *exc):
-        global UNIT_LOSS_GRAD
-        UNIT_LOSS_GRAD = self.prev
+        global UNIT_LOSS_SEED
+        UNIT_LOSS_SEED = self.prev
         return False
 
 

@@ -394,10 +394,10 @@ class Stage1Trainer:
         if one is None or one.device != losses["loss"].device or one.shape != losses["loss"].shape:
             one = self._seed_one = torch.ones_like(losses["loss"])
         if not ops.OVERLAP_MASK:     # the fold-backward launches of the networks as one (data parallel: one for the early part of
-            with ops.batched_wn_backward(), ops.unit_loss_grad():     # the arena, flushed by _early_exchange, and the SDF
+            with ops.batched_wn_backward(), ops.unit_loss_grad(one):     # the arena, flushed by _early_exchange, and the SDF
                 losses["loss"].backward(one)                          # network's behind the backward)
         else:
-            with ops.unit_loss_grad():
+            with ops.unit_loss_grad(one):
                 losses["loss"].backward(one)
         ops.overlap_end()                    # the weight gradients issued on the side stream are complete from here on
         if with_optimizer:

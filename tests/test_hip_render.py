@@ -357,6 +357,37 @@ def test_colour_products_inside_the_sdf_launch_change_nothing(golden_dir, name, 
         assert (res["1"][k] - res["0"][k]).abs().max().item() <= 2e-5 * scale + 1e-9, (k, scale)
 
 
+@pytest.mark.parametrize("name", ["render_wmask_b64_n64", "render_womask_b16_n16_o8"])
+def test_two_renders_one_backward_keep_every_weight_gradient(golden_dir, name, monkeypatch):
+    """two differentiable renders of different batch size before ONE backward pass (what the stash-overwrite message recommends):
+    the first render's colour / RefColor / background products wait for a weight-gradient launch that is stamped for the FIRST
+    SDF forward, not for the latest one -- merged launches (default) against launches of their own (FNEUS_GEMM_MERGE=0)"""
+    from oracle import ref_torch as R
+    from _helper_losses import stage1_loss
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FNEUS_GEMM_MERGE", mode)
+        g = load(golden_dir, name)
+        rnd, nets = build(g, 3, 1)
+        data = T(g["data"]).to(DEV)
+        bg = torch.ones(1, 3, device=DEV) if int(g["white_bkgd"]) else None
+        total = 0.0
+        for rows in (data[: data.shape[0] // 2], data):
+            rays_o, rays_d, rgb, mask = rows[:, :3], rows[:, 3:6], rows[:, 6:9], rows[:, 9:10]
+            near, far = R.near_far_from_sphere(rays_o, rays_d)
+            out = rnd.render(rays_o, rays_d, near, far, perturb_overwrite=0, cos_anneal_ratio=float(g["cos_anneal_ratio"]),
+                             background_rgb=bg)
+            total = total + stage1_loss(out, rgb, mask, igr_weight=0.1, mask_weight=float(g["mask_weight"]),
+                                        surface_weight=0.1)["loss"]
+        total.backward()
+        res[mode] = {f"{n}.{k}": p.grad.detach().clone() for n in ("sdf", "color", "refcolor", "nerf") if nets[n] is not None
+                     for k, p in nets[n].named_parameters()}
+    assert any(k.startswith("refcolor.") for k in res["1"]) and any(k.startswith("color.") for k in res["1"])
+    for k in res["1"]:
+        scale = res["0"][k].abs().max().item() + 1e-12
+        assert (res["1"][k] - res["0"][k]).abs().max().item() <= 2e-5 * scale + 1e-9, (k, scale)
+
+
 @pytest.mark.parametrize("rows", [1, 40])
 def test_constant_background_colour_inside_the_compositing_kernels(rows):
     """renderer.py:367-368 `color + background_rgb * (1 - weights_sum)` in fneus_composite_fwd / _bwd (back_rgb) against the two
