@@ -121,7 +121,9 @@ FN_DEV void fn_sincos(float x, float& s, float& c) {
     // that differed from run to run in its bf16 build (tools/experiments/r04/col_repro_dbg.py: every launch, ~1000 of 65 536
     // samples, only in the units encoded between two passes; with the anchor, or with libm's sincosf, bit-reproducible).  Cause
     // not pinned down; kept although there is no packed fp64 arithmetic to form.
+#ifndef FNEUS_SINCOS_NO_ANCHOR           // A/B builds: is the anchor still needed with the double-precision version?
     asm volatile("" : "+v"(s), "+v"(c));
+#endif
 }
 
 // exchange with the other lane half (lane ^ 32)

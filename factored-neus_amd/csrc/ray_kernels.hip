@@ -201,6 +201,29 @@ __global__ void __launch_bounds__(64) merge_kernel(const float* __restrict__ z_o
     }
 }
 
+// Rank of element i of (a[0..m) | b[0..k)) in the STABLE sort of the concatenation (what merge_kernel finds with one scan over all
+// m + k entries per element) when `a` is ascending -- the old depths of a sampler step always are: ray_setup's depths or the
+// output of the previous merge.  `b` (the new depths of sample_pdf: ascending up to rounding) is scanned as it is, so no order is
+// assumed within it.  An old entry has its i predecessors of `a` in front of it plus the entries of b strictly below it; a new
+// entry the entries of b in front of it (stable) plus every entry of `a` that is <= it (upper bound by bisection).
+FN_DEV int merged_rank(const float* a, int m, const float* b, int k, int i) {
+    const bool is_new = i >= m;
+    const int ib = i - m;
+    const float z = is_new ? b[ib] : a[i];
+    int r = 0;
+    for (int j = 0; j < k; ++j) {
+        const float zj = b[j];
+        r += (zj < z) || (is_new && zj == z && j < ib);
+    }
+    if (!is_new) return r + i;
+    int lo = 0, hi = m;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] <= z) lo = mid + 1; else hi = mid;
+    }
+    return r + lo;
+}
+
 // cat_z_vals of one up-sampling step FUSED with the up_sample of the next one (the steps of a ray depend on nothing but the
 // ray: renderer.py:433-446 is a per-ray recurrence with one SDF evaluation in the middle):
 //   (z_old | z_new, s_old | s_new)  -- stable rank merge -->  z_out, s_out [m + k]           (= merge_kernel)
@@ -224,11 +247,7 @@ __global__ void __launch_bounds__(64) merge_upsample_kernel(const float* __restr
     __syncthreads();
     for (int i = lane; i < n; i += 64) {
         const float z = zin[i];
-        int rank = 0;
-        for (int j = 0; j < n; ++j) {
-            const float zj = zin[j];
-            rank += (zj < z) || (zj == z && j < i);
-        }
+        const int rank = merged_rank(zin, m, zin + m, k, i);
         zs[rank] = z;
         ss[rank] = sin_[i];
         z_out[(size_t)ray * n + rank] = z;
@@ -247,11 +266,7 @@ __global__ void __launch_bounds__(64) merge_upsample_kernel(const float* __restr
     const int nf = n + k_next;
     for (int i = lane; i < nf; i += 64) {
         const float z = (i < n) ? zs[i] : znx[i - n];
-        int rank = 0;
-        for (int j = 0; j < nf; ++j) {
-            const float zj = (j < n) ? zs[j] : znx[j - n];
-            rank += (zj < z) || (zj == z && j < i);
-        }
+        const int rank = merged_rank(zs, n, znx, k_next, i);
         z_final[(size_t)ray * nf + rank] = z;
         if (dists) zin[rank] = z;                    // (zin is free: the first merge has read it)
     }

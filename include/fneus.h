@@ -292,6 +292,8 @@ int fneus_merge(const float* z_old, const float* s_old, int m, const float* z_ne
 /* cat_z_vals of one up-sampling step fused with up_sample of the next (renderer.py:433-446 is a per-ray recurrence):
  * z_out, s_out [B][m + k] = merge; z_next [B][k_next] = up_sample(z_out, s_out, inv_s); z_final (may be NULL; the last
  * step, renderer.py:445 last=True) [B][m + k + k_next] = merge(z_out | z_next).  Bit-identical to the separate calls.
+ * z_old must be ASCENDING per ray (it is: fneus_ray_setup's depths or the z_out of the previous step) -- the merge ranks an entry
+ * by its position in its own run plus a search of the other run (round 5); z_new may be in any order.
  * dists, mid_z (may be NULL; with z_final): fneus_sections of z_final in the same launch -- what render_core asks for next. */
 int fneus_merge_upsample(const float* rays_o, const float* rays_d, const float* z_old, const float* s_old, int m,
                          const float* z_new, const float* s_new, int k, int n_rays, float inv_s, int k_next, float* z_out,

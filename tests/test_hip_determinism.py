@@ -72,12 +72,16 @@ def test_color_forward_backward_are_reproducible(prec):
         rgb = ops.color_fwd(cnet.blob, n, prec, nrm, feat, st, True, pts=x, dirs=d)
         d_feat, d_normal = ops.color_bwd(cnet.blob, n, prec, c, rgb, st)
         torch.cuda.synchronize()
-        return [t.clone() for t in (rgb, d_feat, d_normal, st.u.view(torch.int16), st.zbar.view(torch.int16), st.mask)]
+        return [t.clone() for t in (rgb, d_feat, d_normal, st.u.view(torch.int16), st.zbar.view(torch.int16), st.mask,
+                                    st.side.view(torch.int16))]
 
+    # `side` = the encodings of the side inputs as the kernel stored them: round 4 saw them differ from run to run in the units a
+    # workgroup encodes BETWEEN two passes (units >= 256 of this launch) with an SLP-packed fp32 sincos (fneus_common.h fn_sincos;
+    # tools/experiments/r04/col_repro_dbg.py is this loop)
     ref = run()
-    for _ in range(25):
-        for a, b, name in zip(run(), ref, ("rgb", "d_feat", "d_normal", "u", "zbar", "mask")):
-            assert torch.equal(a, b), name
+    for it in range(60):
+        for a, b, name in zip(run(), ref, ("rgb", "d_feat", "d_normal", "u", "zbar", "mask", "side")):
+            assert torch.equal(a, b), (name, it, int((a != b).sum()))
 
 
 @pytest.mark.parametrize("use_graph", [False, True])

@@ -83,6 +83,15 @@ def test_fused_merge_upsample_is_bit_identical_to_the_separate_kernels(m, k, las
         assert torch.equal(zf3, zf) and torch.equal(dists3, dists) and torch.equal(mid3, mid)
     else:
         assert zf3 is None and dists3 is None and mid3 is None
+    # round 5: the fused kernel ranks an entry by its place in its own run + a search of the other run.  Only the OLD run has to
+    # be ascending for that; new depths in any order (and with ties among themselves) still come out as the stable sort
+    perm = torch.randperm(k, generator=g).to(DEV)
+    new_z_p, new_s_p = new_z[:, perm].contiguous(), new_s[:, perm].contiguous()
+    new_z_p[:, 1] = new_z_p[:, 2]
+    new_s_p[:, 1] = 0.125
+    z4, s4 = ops.merge(z, s, new_z_p, new_s_p)
+    z5, s5, _, _ = ops.merge_upsample(ro, rd, z, s, new_z_p, new_s_p, inv_s, k, last)
+    assert torch.equal(z4, z5) and torch.equal(s4, s5)
 
 
 def test_fused_sampler_in_render_is_bit_identical():
