@@ -135,7 +135,13 @@ def test_render_end_to_end(golden_dir, name):
     # depths: the inverse cdf is ill conditioned where the pdf is flat (tests/test_hip_rays.py separates that from bin
     # choices on the reference's own sampler trace): a handful of depths in flat bins move by 1e-3..1e-2
     dz = (out["_z_vals"].detach().cpu() - final_z(g)).abs()
-    assert dz.max().item() <= (3e-3 if int(g["B"]) <= 16 else 2e-2) and (dz <= 1e-4).float().mean().item() >= 0.9      # (sorted arrays: one moved depth shifts its neighbours' slots)
+    frac = (dz <= 1e-4).float().mean().item()
+    print(name, f"depths within 1e-4: {100 * frac:.2f} %, worst {dz.max().item():.1e}")
+    # (sorted arrays: one moved depth shifts its neighbours' slots.)  At the reference's sample counts (64 + 64) >= 97 % of the
+    # depths of a batch agree to 1e-4 (observed: 97.66 % of the 512-ray fixture, 99.06 % of the 64-ray one); a single ray with a moved
+    # depth is 1/8 of the 8-ray fixture (94.6 %), and the toy depths integrate a coarser cdf (97.9 ... 99.6 %)
+    big = int(g["n_samples"]) >= 64 and int(g["B"]) >= 64
+    assert dz.max().item() <= (3e-3 if int(g["B"]) <= 16 else 2e-2) and frac >= (0.97 if big else 0.9)
 
 
 @pytest.mark.parametrize("gprec", [3, 1], ids=["grad_hi_lo", "grad_bf16"])

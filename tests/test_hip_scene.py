@@ -13,8 +13,9 @@ STEPS, RAYS, LR, SEED, RES = 1000, 512, 5e-4, 40, 96
 # The HIP runs are deterministic here (FNEUS_DETERMINISTIC=1) and so is the oracle run: the numbers below are functions of the
 # code, the same on every run (tools/runs/r04_t.sh, twice).  Observed: last-300-step means within 15.4 % of the oracle run's for
 # every loss term (exact gradients <= 11.4 %, bf16 planes <= 15.4 %).  The trajectories are chaotic in their rounding -- another
-# summation order anywhere gives other numbers of the same spread (round 3, atomics: up to 23 %) -- so the bound is 2x, not 1.5x.
-LEVEL_TOL = 0.30
+# summation order anywhere gives other numbers of the same spread (round 3, atomics: up to 23 %) -- so the bound is 1.6x (round 5:
+# 0.30 -> 0.25).
+LEVEL_TOL = 0.25
 
 
 def _mesh_from_grid(u):
@@ -125,22 +126,22 @@ def test_reconstruction_matches_oracle_training_on_the_synthetic_scene(monkeypat
     for c in (c_hip, c_hip2, c_hipd, c_ref):
         assert c < 0.5 * c_init, c
     c_med = float(np.median([c_hip, c_hip2, c_hipd]))
-    assert c_ref < 0.4 * c_init and c_med < 0.4 * c_init and abs(c_med - c_ref) < 0.15 * c_init, (c_med, c_ref)
+    assert c_ref < 0.4 * c_init and c_med < 0.4 * c_init and abs(c_med - c_ref) < 0.08 * c_init, (c_med, c_ref)
 
 
 def test_chamfer_at_equal_steps_hip_vs_oracle_over_seeds():
     """BASELINE.json metric, second half (Chamfer-L1 within 2 % of the reference at equal steps): tests/checkers/chamfer_study.py over
-    8 seeds x 1200 steps HERE, in the driver's run (32 seeds x 2000 steps on the builder's box: profiles/r03_chamfer.json, ratio
-    0.9976, standard error 0.74 %).  The HIP path runs in deterministic mode, so the numbers are reproducible; per seed the two
+    12 seeds x 1200 steps HERE, in the driver's run (32 seeds x 2000 steps on the builder's box: profiles/r05_chamfer.json /
+    profiles/r03_chamfer.json, ratio 0.9976, standard error 0.74 %).  The HIP path runs in deterministic mode, so the numbers are reproducible; per seed the two
     paths see the same weights, batches and learning-rate schedule.  The per-seed log ratio scatters by ~4 % (both paths are
-    chaotic in their rounding), so 8 seeds resolve the ratio of the means to ~1.5 %: the bound is 3 standard errors, 5 %
-    -- a backward that is wrong by 5 % does not pass here."""
+    chaotic in their rounding), so 12 seeds resolve the ratio of the means to ~1.2 %: the bound is 3 standard errors, 4 %
+    (round 5; round 4: 8 seeds at 5 %) -- a backward that is wrong by 4 % does not pass here."""
     import importlib.util, os, types
     spec = importlib.util.spec_from_file_location("chamfer_study", os.path.join(os.path.dirname(__file__), "checkers", "chamfer_study.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    res = mod.run_study(types.SimpleNamespace(seeds=8, steps=1200, rays=512, res=96, gprec=1, seed0=300))
+    res = mod.run_study(types.SimpleNamespace(seeds=12, steps=1200, rays=512, res=96, gprec=1, seed0=300))
     print({k: v for k, v in res.items() if k != "runs"})
     assert res["hip_mean"] < 0.4 * np.mean([r["chamfer_init"] for r in res["runs"]])       # both reconstruct the scene ...
     assert res["oracle_mean"] < 0.4 * np.mean([r["chamfer_init"] for r in res["runs"]])
-    assert abs(res["ratio_of_means"] - 1.0) <= 0.05, (res["ratio_of_means"], res.get("sem_log_ratio_pct"))      # ... equally well
+    assert abs(res["ratio_of_means"] - 1.0) <= 0.04, (res["ratio_of_means"], res.get("sem_log_ratio_pct"))      # ... equally well
