@@ -16,9 +16,8 @@
 // h = lane >> 5 of the next layer -- element jj = 16 i + e (tile i of the pair, accumulator register e), which is k-step
 // 4 b + (jj >> 3), slot jj & 7 of the 16-deep fragments (fneus_common.h phi).  No lane ever needs another lane's values, and the
 // block maximum that fixes the scale is a maximum over registers.
-//   x6  = Q(x):  v_cvt_scalef32_pk32_fp6_f16 on the 16 registers of packed fp16 hi parts: element order jj (linear);
-//   xl6 = Q(xl): v_cvt_scalef32_2xpk16_fp6_f32 on (lo of tile 0, lo of tile 1): element 2 e + i (interleaved) -- the weights
-//                of that term are packed in the same order (h6_pack_kernel), so neither side moves a register.
+//   x6 = Q(x), xl6 = Q(xl): v_cvt_scalef32_2xpk16_fp6_f32 on (values of tile 0, values of tile 1): it emits element 2 e + i
+//   (interleaved); the fp6 weights are packed in the same order (h6_pack_kernel), so neither side moves a register.
 // A wave therefore has to own BOTH tiles of a pair: 4 waves x 2 output tiles, 512 registers, one workgroup per CU.
 #pragma once
 #include <type_traits>
@@ -35,12 +34,14 @@ typedef __attribute__((ext_vector_type(2))) unsigned int h6_u32x2;
 
 // ---- weights: the h6 blob of the SDF network's forward chain (layers 0..7; the sdf row of layer 8 and the biases stay in the
 // bf3 blob).  Per layer: fp16 hi fragments [ks][t] (1 KiB each, the order of fwd_hi), then one record per (block b, tile t):
-constexpr int kH6RecWA = 0;          // Q(W), interleaved order: registers 0..3 [64 lanes][16 B]
-constexpr int kH6RecWB = 1024;       //                          registers 4..5 [64][8 B]
-constexpr int kH6RecLA = 1536;       // Q(Wl), linear order
-constexpr int kH6RecLB = 2560;
-constexpr int kH6RecSc = 3072;       // [64] dwords: byte 0 = scale of Q(W), byte 1 = scale of Q(Wl)
-constexpr int kH6Rec = 3328;
+// An fp6 operand is stored as EIGHT dwords per lane, two planes [64 lanes][16 B] (ONE per-lane offset, lane * 16, addresses
+// everything): dwords 0..5 the 32 codes, dword 6 the scales of the lane's blocks (byte 0: of Q(W) / x6, byte 1: of Q(Wl) / xl6),
+// dword 7 unused.  Two 16-byte loads then land in one 8-register tuple whose first six registers ARE the MFMA operand -- no
+// register is moved (assembling six registers from a 16-byte and an 8-byte piece cost a `s_waitcnt vmcnt(0)` + moves per load).
+constexpr int kH6RecW = 0;           // Q(W)  dwords 0..3 | 1024: dwords 4..7
+constexpr int kH6RecL = 2048;        // Q(Wl) dwords 0..3 | 3072: dwords 4..7
+constexpr int kH6Rec = 4096;
+// (both fp6 operands in the element order of v_cvt_scalef32_2xpk16_fp6_f32: element 2 e + i = register e of tile i of the pair)
 
 // k-steps of block b of a layer's INPUT (-1: no such k-step: zeros).  kind 0: 256 inputs; 1: layer 0 (the encoding, 3 k-steps);
 // 2: layer 4 ([h_3: 14 k-steps | encoding: 3], fields.py:83-84)
@@ -72,14 +73,12 @@ constexpr H6Layout make_h6_layout() {
 }
 constexpr H6Layout kH6Layout = make_h6_layout();
 
-// ---- activations in LDS, per 32-sample tile
+// ---- activations in LDS, per 32-sample tile: every access is lane * 16 + a constant
 constexpr int kH6Hi = 0;                          // fp16 hi fragments: slots 0..15 of the running layer's input, 16..18 the encoding
-constexpr int kH6QA = 19 * kFragBytes;            // x6  registers 0..3: [5 blocks][64][16 B]   (block 4 = the encoding)
-constexpr int kH6QB = kH6QA + 5 * 1024;           // x6  registers 4..5: [5][64][8 B]
-constexpr int kH6LA = kH6QB + 5 * 512;            // xl6
-constexpr int kH6LB = kH6LA + 5 * 1024;
-constexpr int kH6SC = kH6LB + 5 * 512;            // [5][64] dwords: byte 0 = scale of x6, byte 1 = scale of xl6
-constexpr int kH6Tile = kH6SC + 5 * 256;          // 36 096 B
+constexpr int kH6Q = 19 * kFragBytes;             // per block (5: block 4 = the encoding) four planes [64][16 B]:
+constexpr int kH6QX = 0;                          //   x6  dwords 0..3 | 1024: {x6 4, x6 5, scales, -}
+constexpr int kH6QL = 2048;                       //   xl6 dwords 0..3 | 3072: {xl6 4, xl6 5, scales, -}
+constexpr int kH6Tile = kH6Q + 5 * 4096;          // 39 936 B
 constexpr int kH6LdsTotal = 4 * kH6Tile;
 
 // LDS slot of k-step s / LDS block of block b of a layer's input
@@ -92,7 +91,26 @@ template <int OPA, int OPB>
 FN_DEV f32x16 mfma_fp6(const i32x8& a, const i32x8& b, f32x16 c, int sa, int sb) {
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 2, 2, OPA, sa, OPB, sb);
 }
-typedef __attribute__((ext_vector_type(6))) unsigned int u32x6_fwd;
+
+// v_cvt_scalef32_2xpk16_fp6_f32 and its operands.  The instruction converts one element pair per pass and reads its 32 source
+// registers AND the scale pass by pass; neither the hardware nor hipcc (ROCm 7.2) keeps a later instruction from writing a
+// register it has not read yet.  Seen, each one on the GPU (tools/experiments/r05: h6_pack_check.py, h6_dbg.sh, the ISA):
+//   * results in the register of the scale (`... v[66:71], v[2:17], v[18:33], v66`): pair 0 right, the rest divided by garbage;
+//   * results inside a source tuple (`... v[70:75], v[70:85], ...`): a few elements wrong (sdf 1.4e-4 instead of 5e-5);
+//   * `v_accvgpr_read_b32 v38, a178` right behind `... v[188:193], v[38:53], v[54:69], v196`: NaN.
+// So: h6_cvt keeps scale and sources out of the result registers (an empty asm reads them behind the conversion), and whoever
+// calls it keeps them alive until h6_cvt_release -- placed a few dozen issue cycles later -- or uses h6_cvt_slow.
+FN_DEV u32x6 h6_cvt(const f32x16& a, const f32x16& b, float scale) {
+    u32x6 q = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(a, b, scale);
+    asm volatile("" : "+v"(q) : "v"(scale), "v"(a), "v"(b));
+    return q;
+}
+FN_DEV void h6_cvt_release(const f32x16& a, const f32x16& b, float scale) { asm volatile("" ::"v"(scale), "v"(a), "v"(b)); }
+FN_DEV u32x6 h6_cvt_slow(const f32x16& a, const f32x16& b, float scale) {
+    u32x6 q = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(a, b, scale);
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(q) : "v"(scale), "v"(a), "v"(b));
+    return q;
+}
 
 // the 32 values of a lane's block -> fp16 hi parts, x6, xl6 and the scale dword.  v is overwritten by the lo parts.
 // Scales: E = exponent of the block maximum; x6 = Q(x / 2^(E-2)) (block maximum in [4, 8): the top quarter binade saturates at 7.5,
@@ -114,6 +132,7 @@ FN_DEV void h6_quant(f32x16& v0, f32x16& v1, H6Block& o, bool nonneg) {
     for (int e = 0; e < 16; ++e) m = nonneg ? fmaxf(m, fmaxf(v0[e], v1[e])) : fmaxf(m, fmaxf(fabsf(v0[e]), fabsf(v1[e])));
     float sx, sl;
     h6_scales(m, sx, sl, o.sc);
+    o.q = h6_cvt_slow(v0, v1, sx);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const _Float16 a = (_Float16)v0[e], b = (_Float16)v1[e];
@@ -122,86 +141,28 @@ FN_DEV void h6_quant(f32x16& v0, f32x16& v1, H6Block& o, bool nonneg) {
         v0[e] -= (float)a;
         v1[e] -= (float)b;
     }
-    o.q = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(o.hh, sx);
-    o.ql = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(v0, v1, sl);
+    o.ql = h6_cvt_slow(v0, v1, sl);
 }
-// ... to LDS: the block's four hi fragments at slots slot0 .. slot0 + 3 (those with s < ns), the fp6 operands at block blk
-FN_DEV void h6_store(unsigned char* tile, int lane, int slot0, int ns, int blk, const H6Block& o) {
+// ... to LDS (tile16 = tile + lane * 16): the block's hi fragments at slots slot0 .. (those with s < ns), the fp6 operands at blk
+FN_DEV void h6_store(unsigned char* tile16, int slot0, int ns, int blk, const H6Block& o) {
 #pragma unroll
     for (int s = 0; s < 4; ++s)
         if (s < ns) {
             f16x8 f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) f[j] = o.hh[8 * s + j];
-            *reinterpret_cast<f16x8*>(tile + kH6Hi + (slot0 + s) * kFragBytes + lane * 16) = f;
+            *reinterpret_cast<f16x8*>(tile16 + kH6Hi + (slot0 + s) * kFragBytes) = f;
         }
-    *reinterpret_cast<p2_u32x4*>(tile + kH6QA + blk * 1024 + lane * 16) = p2_u32x4{o.q[0], o.q[1], o.q[2], o.q[3]};
-    *reinterpret_cast<h6_u32x2*>(tile + kH6QB + blk * 512 + lane * 8) = h6_u32x2{o.q[4], o.q[5]};
-    *reinterpret_cast<p2_u32x4*>(tile + kH6LA + blk * 1024 + lane * 16) = p2_u32x4{o.ql[0], o.ql[1], o.ql[2], o.ql[3]};
-    *reinterpret_cast<h6_u32x2*>(tile + kH6LB + blk * 512 + lane * 8) = h6_u32x2{o.ql[4], o.ql[5]};
-    *reinterpret_cast<uint32_t*>(tile + kH6SC + blk * 256 + lane * 4) = o.sc;
+    unsigned char* q = tile16 + kH6Q + blk * 4096;
+    *reinterpret_cast<p2_u32x4*>(q + kH6QX) = p2_u32x4{o.q[0], o.q[1], o.q[2], o.q[3]};
+    *reinterpret_cast<p2_u32x4*>(q + kH6QX + 1024) = p2_u32x4{o.q[4], o.q[5], o.sc, 0u};
+    *reinterpret_cast<p2_u32x4*>(q + kH6QL) = p2_u32x4{o.ql[0], o.ql[1], o.ql[2], o.ql[3]};
+    *reinterpret_cast<p2_u32x4*>(q + kH6QL + 1024) = p2_u32x4{o.ql[4], o.ql[5], o.sc, 0u};
 }
 
-// ---- operand sets of one block: weights of the wave's two tiles (from L2), activations of the two sample tiles of a set (LDS)
-struct H6W {
-    f16x8 hi[4][2];          // [k-step of the block][tile]
-    u32x6 w6[2], l6[2];      // Q(W) (interleaved), Q(Wl) (linear)
-    int sc[2];
-};
-struct H6B {
-    f16x8 hi[4][2];          // [k-step][sample tile]
-    u32x6 x6[2], xl6[2];
-    int sc[2];
-};
-FN_DEV i32x8 h6_op(const u32x6& v) { return i32x8{(int)v[0], (int)v[1], (int)v[2], (int)v[3], (int)v[4], (int)v[5], 0, 0}; }
-
-template <int KIND, int NT_TOTAL>
-FN_DEV void h6_wload(H6W& w, __amdgpu_buffer_rsrc_t rsrc, uint32_t off_hi, uint32_t off_rec, int b, int lane, int t0) {
-    const unsigned v16 = (unsigned)(lane + t0 * 64) * 16u;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int ks = h6_ks(KIND, b, s);
-        if (ks >= 0) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                w.hi[s][i] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)v16, (int)(off_hi + (uint32_t)((ks * NT_TOTAL + i) * 64) * 16u), 0));
-        }
-    }
-    const unsigned l16 = (unsigned)lane * 16u, l8 = (unsigned)lane * 8u, l4 = (unsigned)lane * 4u;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const uint32_t rec = off_rec + (uint32_t)((b * NT_TOTAL + i) * kH6Rec) + (uint32_t)t0 * kH6Rec;
-        const p2_u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)l16, (int)(rec + kH6RecWA), 0);
-        const h6_u32x2 a2 = __builtin_bit_cast(h6_u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)l8, (int)(rec + kH6RecWB), 0));
-        const p2_u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)l16, (int)(rec + kH6RecLA), 0);
-        const h6_u32x2 c2 = __builtin_bit_cast(h6_u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)l8, (int)(rec + kH6RecLB), 0));
-        w.w6[i] = u32x6{a[0], a[1], a[2], a[3], a2[0], a2[1]};
-        w.l6[i] = u32x6{c[0], c[1], c[2], c[3], c2[0], c2[1]};
-        w.sc[i] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)l4, (int)(rec + kH6RecSc), 0);
-    }
-}
-
-template <int KIND>
-FN_DEV void h6_bload(H6B& o, const unsigned char* set /* first tile of the set */, int b, int lane) {
-    constexpr int dummy = 0;
-    (void)dummy;
-#pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {
-        const unsigned char* tile = set + hb * kH6Tile;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int ks = h6_ks(KIND, b, s);
-            if (ks >= 0) o.hi[s][hb] = *reinterpret_cast<const f16x8*>(tile + kH6Hi + h6_slot(KIND, ks) * kFragBytes + lane * 16);
-        }
-        const int blk = h6_lds_block(KIND, b);
-        const p2_u32x4 a = *reinterpret_cast<const p2_u32x4*>(tile + kH6QA + blk * 1024 + lane * 16);
-        const h6_u32x2 a2 = *reinterpret_cast<const h6_u32x2*>(tile + kH6QB + blk * 512 + lane * 8);
-        const p2_u32x4 c = *reinterpret_cast<const p2_u32x4*>(tile + kH6LA + blk * 1024 + lane * 16);
-        const h6_u32x2 c2 = *reinterpret_cast<const h6_u32x2*>(tile + kH6LB + blk * 512 + lane * 8);
-        o.x6[hb] = u32x6{a[0], a[1], a[2], a[3], a2[0], a2[1]};
-        o.xl6[hb] = u32x6{c[0], c[1], c[2], c[3], c2[0], c2[1]};
-        o.sc[hb] = *reinterpret_cast<const int*>(tile + kH6SC + blk * 256 + lane * 4);
-    }
+// an operand from its two 16-byte pieces
+FN_DEV i32x8 h6_op8(const p2_u32x4& a, const p2_u32x4& b) {
+    return i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
 }
 
 }  // namespace fneus

@@ -6,6 +6,9 @@
 //   fneus_sdf_fwd_h6   : the kernel
 #include <stdlib.h>
 #include "h6_engine.h"
+#ifndef FNEUS_H6_GS
+#define FNEUS_H6_GS 8
+#endif
 #include "fneus_kernels.h"
 
 namespace fneus {
@@ -38,7 +41,7 @@ __global__ void __launch_bounds__(64) h6_pack_kernel(const unsigned char* __rest
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float w = (float)hi[j] + (float)lo[j];
-            const _Float16 wh = (_Float16)w;
+            const _Float16 wh = (_Float16)w;          // (subnormal fp16 hi parts are multiplied as they are: measured, r05/h6_dbg.sh)
             const float wl = w - (float)wh;
             h16[j] = wh;
             const int jj = 8 * s + j;
@@ -56,73 +59,109 @@ __global__ void __launch_bounds__(64) h6_pack_kernel(const unsigned char* __rest
     }
     // Q(W) in the order of xl6 (element 2 e + i = (tile i, register e) = jj 16 i + e): 2xpk16(a, b) emits a[e], b[e] alternately
     const uint32_t e6 = __builtin_bit_cast(uint32_t, fmaxf(m, 1.0e-30f)) >> 23, el6 = __builtin_bit_cast(uint32_t, fmaxf(ml, 1.0e-30f)) >> 23;
-    const u32x6 q = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(w0, w1, __builtin_bit_cast(float, (e6 - 2u) << 23));
-    // Q(Wl) in linear order: a[e] = jj 2 e, b[e] = jj 2 e + 1
-    f32x16 ea, eb;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        ea[e] = 2 * e < 16 ? wl0[(2 * e) & 15] : wl1[(2 * e) & 15];
-        eb[e] = 2 * e + 1 < 16 ? wl0[(2 * e + 1) & 15] : wl1[(2 * e + 1) & 15];
-    }
-    const u32x6 ql = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(ea, eb, __builtin_bit_cast(float, (el6 - 2u) << 23));
-    unsigned char* rec = hblob + kH6Layout.L[l].rec + (size_t)(b * nt + t) * kH6Rec;
-    *reinterpret_cast<p2_u32x4*>(rec + kH6RecWA + lane * 16) = p2_u32x4{q[0], q[1], q[2], q[3]};
-    *reinterpret_cast<h6_u32x2*>(rec + kH6RecWB + lane * 8) = h6_u32x2{q[4], q[5]};
-    *reinterpret_cast<p2_u32x4*>(rec + kH6RecLA + lane * 16) = p2_u32x4{ql[0], ql[1], ql[2], ql[3]};
-    *reinterpret_cast<h6_u32x2*>(rec + kH6RecLB + lane * 8) = h6_u32x2{ql[4], ql[5]};
-    *reinterpret_cast<uint32_t*>(rec + kH6RecSc + lane * 4) = (e6 - 2u) | ((el6 - 2u) << 8);
+    const u32x6 q = h6_cvt_slow(w0, w1, __builtin_bit_cast(float, (e6 - 2u) << 23));
+    // Q(Wl) in the same order (x6 is converted from the fp32 values of the two tiles like xl6)
+    const u32x6 ql = h6_cvt_slow(wl0, wl1, __builtin_bit_cast(float, (el6 - 2u) << 23));
+    unsigned char* rec = hblob + kH6Layout.L[l].rec + (size_t)(b * nt + t) * kH6Rec + lane * 16;
+    const uint32_t sc = (e6 - 2u) | ((el6 - 2u) << 8);
+    *reinterpret_cast<p2_u32x4*>(rec + kH6RecW) = p2_u32x4{q[0], q[1], q[2], q[3]};
+    *reinterpret_cast<p2_u32x4*>(rec + kH6RecW + 1024) = p2_u32x4{q[4], q[5], sc, 0u};
+    *reinterpret_cast<p2_u32x4*>(rec + kH6RecL) = p2_u32x4{ql[0], ql[1], ql[2], ql[3]};
+    *reinterpret_cast<p2_u32x4*>(rec + kH6RecL + 1024) = p2_u32x4{ql[4], ql[5], sc, 0u};
 }
 
-// what a pass needs before its first MFMA and the previous pass requests: the bias here, the first block's weights in the weight
-// buffer the previous pass's last block did not use (START: which one -- the passes of a unit have 1 1 4 4 4 4 4 4 5 5 4 .. blocks)
-struct H6Prime {
-    f32x16 bias[2];
-};
+// What a pass needs before its first MFMA is requested by the pass before it:
+//   * the bias: loaded straight into accV[.][0] -- the NEXT pass's accumulators of its first sample tile -- once this pass's vector
+//     work is through with them (half way); the next pass copies it to its second sample tile.  No registers of its own;
+//   * the first block's hi fragments in the hi buffer this pass's last block did not use (START: which one -- the passes of a
+//     unit have 1 1 4 4 4 4 4 4 5 5 4 .. blocks), its fp6 weights in the one fp6 buffer, requested behind the last fp6 MFMA.
 struct H6Next {
     uint32_t off_hi, off_rec, off_bias;
 };
+struct H6Whi {
+    f16x8 hi[4][2];          // ring of four k-steps x the wave's two tiles: k-step g of the stream of passes sits in g % 4, requested
+};                           // three k-steps ahead (also across passes: PH = position of a pass's k-step 0)
+struct H6Wq {
+    i32x8 w6[2], l6[2];      // Q(W), Q(Wl) of the two tiles: dwords 0..5 the codes, 6 the scale bytes
+};
+// every weight load: uniform descriptor + the ONE per-lane offset lane * 16 (lane * 4 for the scales) + a scalar offset that
+// carries layer, block, tile and the wave's first tile
+struct H6Lane {
+    unsigned l16, hb64;                      // lane * 16, (lane >> 5) * 64 (the bias rows of the lane half)
+    unsigned t0_frag, t0_rec, t0_bias;       // wave-uniform: t0 * 1024, t0 * kH6Rec, t0 * 128
+};
+template <int NT_TOTAL>
+FN_DEV f16x8 h6_whi_load(__amdgpu_buffer_rsrc_t rsrc, uint32_t off_hi, int ks, int i, const H6Lane& ln) {
+    return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)ln.l16, (int)(off_hi + ln.t0_frag + (uint32_t)((ks * NT_TOTAL + i) * kFragBytes)), 0));
+}
+template <int NT_TOTAL>
+FN_DEV void h6_wq_load(H6Wq& w, __amdgpu_buffer_rsrc_t rsrc, uint32_t off_rec, int b, const H6Lane& ln) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const uint32_t rec = off_rec + ln.t0_rec + (uint32_t)((b * NT_TOTAL + i) * kH6Rec);
+        w.w6[i] = h6_op8(__builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)ln.l16, (int)(rec + kH6RecW), 0),
+                         __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)ln.l16, (int)(rec + kH6RecW + 1024), 0));
+        w.l6[i] = h6_op8(__builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)ln.l16, (int)(rec + kH6RecL), 0),
+                         __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)ln.l16, (int)(rec + kH6RecL + 1024), 0));
+    }
+}
+// the bias of the wave's two tiles in accumulator layout ([t][h][16] fp32) -> acc[.][0]
+FN_DEV void h6_bias_load(__amdgpu_buffer_rsrc_t brsrc, uint32_t off_bias, const H6Lane& ln, f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brsrc, (int)ln.hb64, (int)(off_bias + ln.t0_bias + (uint32_t)(i * 128 + g * 16)), 0));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][0][4 * g + e] = v[e];
+        }
+}
 
-// One pass: MFMAs of layer (KIND, NT_TOTAL) on the sample tiles hbM, hbM + 1 (accM) with, inside their stream, the vector work on
-// accV = the previous pass's accumulators of tiles hbV, hbV + 1:
+// One pass: MFMAs of layer (KIND, NT_TOTAL) on the sample tiles hbM, hbM + 1 (accM; accM[.][0] holds the bias on entry) with,
+// inside their stream, the vector work on accV = the previous pass's accumulators of tiles hbV, hbV + 1:
 //   ACT 1: softplus -> fp16 hi fragments + fp6 blocks of the next layer's input in LDS (block = this wave's tile pair);
+//          MASK7: the values of tiles >= tnV are zeros (layer 3 has 7 tiles);
 //   ACT 2: softplus -> partial dot product with cw (the sdf row of the linear last layer); 0: none.
 // Per block of 64 k: 16 slots hi.hi (4 k-steps x 2 tiles x 2 sample tiles), 8 slots of fp6 cross terms; a slot = one MFMA + its
-// share of the vector work + operand requests, fenced by sched_barrier like p2_pass.  Operands are double buffered by block: the
-// weights of block b + 1 are requested in the first slots of block b, its activations behind slot 12 (an LDS load must not land
-// in registers that a queued MFMA still reads, p2_engine.h: by then the MFMAs that read that buffer have left the pipe).
-template <int KIND, int NT_TOTAL, int NKIND, int NNT, int ACT, int START>
-FN_DEV void h6_pass(const unsigned char* __restrict__ blob, __amdgpu_buffer_rsrc_t rsrc, uint32_t off_hi, uint32_t off_rec, H6Prime& pr,
-                    H6W (&wb)[2], const H6Next& nx, unsigned char* lds, int lane, int t0, f32x16 (&accM)[2][2], int hbM, f32x16 (&accV)[2][2],
-                    int hbV, int tnV, const f32x16 (&cw)[2], float (&dot)[2]) {
+// share of the vector work + operand requests, fenced by sched_barrier like p2_pass.
+template <int KIND, int NT_TOTAL, int NKIND, int NNT, int ACT, int PH, int HBM, bool MASK7 = false>
+FN_DEV void h6_pass(__amdgpu_buffer_rsrc_t brsrc, __amdgpu_buffer_rsrc_t rsrc, uint32_t off_hi, uint32_t off_rec,
+                    H6Whi& wr, H6Wq& wq, const H6Next& nx, unsigned char* const (&tile16)[4], const H6Lane& ln, int wave,
+                    f32x16 (&accM)[2][2], f32x16 (&accV)[2][2], int tnV, const f32x16 (&cw)[2], float (&dot)[2]) {
+    constexpr int HBV = HBM ^ 2;             // tile16[k] = LDS address of sample tile k + lane * 16
+    asm volatile("" : "+s"(off_hi), "+s"(off_rec));      // (offsets formed here, by scalar adds, not hoisted out of the unit loop and spilled)
     constexpr int NB = h6_blocks(KIND);
     constexpr int NSLOT = NB * 24;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        accM[i][0] = pr.bias[i];
-        accM[i][1] = pr.bias[i];
-    }
-    H6B bb[2];
-    const unsigned char* setM = lds + hbM * kH6Tile;
-    unsigned char* setV = lds + hbV * kH6Tile;
-    h6_bload<KIND>(bb[START], setM, 0, lane);
-    {   // the registers are free again: next pass's bias
-        const f32x16 FN_GLOBAL* __restrict__ p = reinterpret_cast<const f32x16 FN_GLOBAL*>((gblob_t)blob + nx.off_bias);
+    for (int i = 0; i < 2; ++i) accM[i][1] = accM[i][0];
+    // activations: hi fragments one k-step ahead through a ring of three (p2_engine.h: an LDS load must not land in registers
+    // that a queued MFMA still reads), the fp6 operands of a block behind its slot 8 (their last readers, the fp6 MFMAs of the
+    // block before, have left the pipe by then)
+    f16x8 bh[3][2];
+    i32x8 bx6[2], bxl6[2];       // (dword 6: the scale bytes)
+    auto ld_bh = [&](int slot, int hb) { return *reinterpret_cast<const f16x8*>(tile16[HBM + hb] + kH6Hi + slot * kFragBytes); };
 #pragma unroll
-        for (int i = 0; i < 2; ++i) pr.bias[i] = p[(t0 + i) * 2 + (lane >> 5)];
-    }
+    for (int hb = 0; hb < 2; ++hb) bh[0][hb] = ld_bh(h6_slot(KIND, h6_ks(KIND, 0, 0)), hb);
+    if constexpr (ACT == 0) h6_bias_load(brsrc, nx.off_bias, ln, accV);       // (no vector work: accV is free from the start)
     // ---- the vector work as a list of micro-steps (constant indices only); per sample tile hb:
     //   groups of 8 values: A exp2 / max, B log2, C y (in place);  M block maximum;  S scales;  H fp16 pairs;  L lo parts (in
-    //   place);  Q the two conversions;  T stores
-    constexpr int OPS_HB = ACT == 1 ? (4 * 24 + 16 + 1 + 16 + 32 + 2 + 9) : (ACT == 2 ? 4 * 24 : 0);
-    constexpr int NM = 2 * OPS_HB;
-    float ve[8], vm[8], vl[8], bm = 0.0f, sx = 1.0f, sl = 1.0f;
+    //   place);  Q the two conversions;  T stores;  behind sample tile 0: the next pass's bias into its registers
+    constexpr int GS = FNEUS_H6_GS, NG = 32 / GS;             // softplus in groups of GS values: 3 GS temporaries
+    constexpr int OPS_HB = ACT == 1 ? (96 + 16 + 1 + 16 + 32 + 2 + 8 + 1) : (ACT == 2 ? 96 : 0);
+    constexpr int NM = ACT == 0 ? 0 : 2 * OPS_HB + 1;
+    float ve[GS], vm[GS], vl[GS], bm = 0.0f, sx = 1.0f, sl = 1.0f;
     H6Block ob;
     auto micro = [&](auto J_) {
-        constexpr int j = decltype(J_)::value;
+        constexpr int j0_ = decltype(J_)::value;
+        if constexpr (j0_ == OPS_HB) {
+            h6_bias_load(brsrc, nx.off_bias, ln, accV);
+        } else {
+        constexpr int j = j0_ < OPS_HB ? j0_ : j0_ - 1;
         constexpr int hb = j / OPS_HB, k = j % OPS_HB;
         if constexpr (k < 96) {
-            constexpr int g = k / 24, ph = (k % 24) / 8, q = k % 8;
-            constexpr int v = 8 * g + q, i = v >> 4, e = v & 15;
+            constexpr int g = k / (3 * GS), ph = (k % (3 * GS)) / GS, q = k % GS;
+            constexpr int v = GS * g + q, i = v >> 4, e = v & 15;
+            static_assert(NG * 3 * GS == 96, "32 values");
             if constexpr (ph == 0) {
                 const float z = accV[i][hb][e];
                 ve[q] = fast_exp2(-fabsf(z) * (kBeta * kLog2e));
@@ -133,7 +172,7 @@ FN_DEV void h6_pass(const unsigned char* __restrict__ blob, __amdgpu_buffer_rsrc
             } else {
                 float y = fmaf(vl[q], kLn2 / kBeta, vm[q]);
                 if constexpr (ACT == 1) {
-                    y = i < tnV ? y : 0.0f;              // (layer 3 has 7 tiles: the eighth contributes nothing, also not to the scale)
+                    if constexpr (MASK7) y = i < tnV ? y : 0.0f;      // (the eighth tile contributes nothing, also not to the scale)
                     accV[i][hb][e] = y;
                     asm volatile("" : "+v"(accV[i][hb][e]));
                 } else {
@@ -144,76 +183,122 @@ FN_DEV void h6_pass(const unsigned char* __restrict__ blob, __amdgpu_buffer_rsrc
         } else if constexpr (ACT == 1) {
             constexpr int k2 = k - 96;
             if constexpr (k2 < 16) {                     // M (softplus >= 0: no absolute values)
-                if constexpr (k2 == 0) bm = 0.0f;
-                bm = fmaxf(bm, fmaxf(accV[0][hb][k2], accV[1][hb][k2]));
-                asm volatile("" : "+v"(bm));
+                if constexpr (k2 == 0) bm = 1.0e-30f;
+                asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(bm) : "v"(accV[0][hb][k2]), "v"(accV[1][hb][k2]));
             } else if constexpr (k2 == 16) {             // S
-                h6_scales(bm, sx, sl, ob.sc);
+                const uint32_t ex = __builtin_bit_cast(uint32_t, bm) >> 23;       // (>= 27: both scale bytes stay positive)
+                sx = __builtin_bit_cast(float, (ex - 2u) << 23);
+                sl = __builtin_bit_cast(float, (ex - 14u) << 23);
+                ob.sc = (ex - 2u) | ((ex - 14u) << 8);
                 asm volatile("" : "+v"(sx), "+v"(sl), "+v"(ob.sc));
-            } else if constexpr (k2 < 33) {              // H: values 2 p, 2 p + 1 -> one packed register
-                constexpr int p = k2 - 17, v = 2 * p, i = v >> 4, e = v & 15;
-                ob.hh[v] = (_Float16)accV[i][hb][e];
-                ob.hh[v + 1] = (_Float16)accV[i][hb][e + 1];
-            } else if constexpr (k2 < 65) {              // L
-                constexpr int v = k2 - 33, i = v >> 4, e = v & 15;
-                accV[i][hb][e] -= (float)ob.hh[v];
-                asm volatile("" : "+v"(accV[i][hb][e]));
-            } else if constexpr (k2 == 65) {
-                ob.q = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(ob.hh, sx);
+            } else if constexpr (k2 == 17) {             // x6 = Q(y) from the fp32 values of the two tiles (element 2 e + i, like xl6)
+                ob.q = h6_cvt(accV[0][hb], accV[1][hb], sx);
+            } else if constexpr (k2 < 34) {              // H: values 2 p, 2 p + 1 -> one packed register (round to nearest even)
+                constexpr int pp = k2 - 18, v = 2 * pp, i = v >> 4, e = v & 15;
+                uint32_t pk;
+                asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk) : "v"(accV[i][hb][e]), "v"(accV[i][hb][e + 1]));
+                const f16x2 h2 = __builtin_bit_cast(f16x2, pk);
+                ob.hh[v] = h2[0];
+                ob.hh[v + 1] = h2[1];
+            } else if constexpr (k2 < 66) {              // L: lo = y - hi in ONE instruction (the fp16 operand widened inside the fma)
+                constexpr int v = k2 - 34, i = v >> 4, e = v & 15;
+                f16x2 h2 = {ob.hh[v & ~1], ob.hh[(v & ~1) + 1]};
+                const uint32_t pk = __builtin_bit_cast(uint32_t, h2);
+                if constexpr ((v & 1) == 0)
+                    asm volatile("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]" : "+v"(accV[i][hb][e]) : "v"(pk));
+                else
+                    asm volatile("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(accV[i][hb][e]) : "v"(pk));
             } else if constexpr (k2 == 66) {
-                ob.ql = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(accV[0][hb], accV[1][hb], sl);
-            } else {                                     // T: 9 stores
+                ob.ql = h6_cvt(accV[0][hb], accV[1][hb], sl);
+            } else {                                     // T: 8 stores, release
                 constexpr int st = k2 - 67;
-                unsigned char* tile = setV + hb * kH6Tile;
-                const int blk = t0 >> 1;
+                unsigned char* tile = tile16[HBV + hb];
+                unsigned char* qb = tile + kH6Q + wave * 4096;          // (block = this wave's tile pair)
                 if constexpr (st < 4) {
                     f16x8 f;
 #pragma unroll
                     for (int jx = 0; jx < 8; ++jx) f[jx] = ob.hh[8 * st + jx];
-                    *reinterpret_cast<f16x8*>(tile + kH6Hi + (2 * t0 + st) * kFragBytes + lane * 16) = f;
+                    *reinterpret_cast<f16x8*>(tile + kH6Hi + (4 * wave + st) * kFragBytes) = f;
                 } else if constexpr (st == 4) {
-                    *reinterpret_cast<p2_u32x4*>(tile + kH6QA + blk * 1024 + lane * 16) = p2_u32x4{ob.q[0], ob.q[1], ob.q[2], ob.q[3]};
+                    *reinterpret_cast<p2_u32x4*>(qb + kH6QX) = p2_u32x4{ob.q[0], ob.q[1], ob.q[2], ob.q[3]};
                 } else if constexpr (st == 5) {
-                    *reinterpret_cast<h6_u32x2*>(tile + kH6QB + blk * 512 + lane * 8) = h6_u32x2{ob.q[4], ob.q[5]};
+                    *reinterpret_cast<p2_u32x4*>(qb + kH6QX + 1024) = p2_u32x4{ob.q[4], ob.q[5], ob.sc, 0u};
                 } else if constexpr (st == 6) {
-                    *reinterpret_cast<p2_u32x4*>(tile + kH6LA + blk * 1024 + lane * 16) = p2_u32x4{ob.ql[0], ob.ql[1], ob.ql[2], ob.ql[3]};
+                    *reinterpret_cast<p2_u32x4*>(qb + kH6QL) = p2_u32x4{ob.ql[0], ob.ql[1], ob.ql[2], ob.ql[3]};
                 } else if constexpr (st == 7) {
-                    *reinterpret_cast<h6_u32x2*>(tile + kH6LB + blk * 512 + lane * 8) = h6_u32x2{ob.ql[4], ob.ql[5]};
-                } else {
-                    *reinterpret_cast<uint32_t*>(tile + kH6SC + blk * 256 + lane * 4) = ob.sc;
+                    *reinterpret_cast<p2_u32x4*>(qb + kH6QL + 1024) = p2_u32x4{ob.ql[4], ob.ql[5], ob.sc, 0u};
+                } else {                                 // (the conversions' sources and scales are free from here on)
+                    h6_cvt_release(accV[0][hb], accV[1][hb], sx);
+                    h6_cvt_release(accV[0][hb], accV[1][hb], sl);
                 }
             }
+        }
         }
     };
     static_for<0, NB>([&](auto B_) {
         constexpr int b = decltype(B_)::value;
-        constexpr int cur = (b + START) & 1, nxt = cur ^ 1;
+        // running index of this block's first k-step among the pass's k-steps (ring position of the hi fragments)
+        constexpr int kk0 = KIND == 2 ? (b < 4 ? 4 * b : 14) : 4 * b;
+        constexpr int ns = KIND == 1 ? 3 : (KIND == 2 ? (b < 3 ? 4 : (b == 3 ? 2 : 3)) : 4);      // k-steps of the block
         __builtin_amdgcn_sched_barrier(0);
         static_for<0, 24>([&](auto Q_) {
             constexpr int q = decltype(Q_)::value;
             constexpr int slot = b * 24 + q;
             if constexpr (q < 16) {
                 constexpr int s = q >> 2, r = q & 3, i = r >> 1, hb = r & 1;
-                if constexpr (h6_ks(KIND, b, s) >= 0) accM[i][hb] = mfma32h(wb[cur].hi[s][i], bb[cur].hi[s][hb], accM[i][hb]);
+                if constexpr (s < ns) {
+                    accM[i][hb] = mfma32h(wr.hi[(PH + kk0 + s) % 4][i], bh[(kk0 + s) % 3][hb], accM[i][hb]);
+                    if constexpr (hb == 1) {             // (the tile's last MFMA of this k-step is out:) its fragment three k-steps on
+                        constexpr int kn = kk0 + s + 3, KS = KIND == 1 ? 3 : (KIND == 2 ? 17 : 16);
+                        if constexpr (kn < KS) wr.hi[(PH + kn) % 4][i] = h6_whi_load<NT_TOTAL>(rsrc, off_hi, kn, i, ln);
+                        else wr.hi[(PH + kn) % 4][i] = h6_whi_load<NNT>(rsrc, nx.off_hi, kn - KS, i, ln);
+                    }
+                    if constexpr (r < 2) {               // hi fragment of the next k-step of the pass (of the next block behind the last)
+                        constexpr bool more = s + 1 < ns || b + 1 < NB;
+                        if constexpr (more) {
+                            constexpr int ks_n = s + 1 < ns ? h6_ks(KIND, b, s + 1) : h6_ks(KIND, b + 1, 0);
+                            bh[(kk0 + s + 1) % 3][r] = ld_bh(h6_slot(KIND, ks_n), r);
+                        }
+                    }
+                }
             } else {
+#ifdef FNEUS_H6_T2_FIRST
+                constexpr int r = (q - 16) & 3, term = 1 - ((q - 16) >> 2), i = r >> 1, hb = r & 1;
+#else
                 constexpr int r = (q - 16) & 3, term = (q - 16) >> 2, i = r >> 1, hb = r & 1;
-                if constexpr (term == 0) accM[i][hb] = mfma_fp6<0, 1>(h6_op(wb[cur].w6[i]), h6_op(bb[cur].xl6[hb]), accM[i][hb], wb[cur].sc[i], bb[cur].sc[hb]);
-                else accM[i][hb] = mfma_fp6<1, 0>(h6_op(wb[cur].l6[i]), h6_op(bb[cur].x6[hb]), accM[i][hb], wb[cur].sc[i], bb[cur].sc[hb]);
+#endif
+#ifndef FNEUS_H6_NO_T1                  // (debugging: the two cross terms one by one)
+                if constexpr (term == 0) accM[i][hb] = mfma_fp6<0, 1>(wq.w6[i], bxl6[hb], accM[i][hb], wq.w6[i][6], bxl6[hb][6]);
+#endif
+#ifndef FNEUS_H6_NO_T2
+#ifndef FNEUS_H6_T2A
+#define FNEUS_H6_T2A 1
+#define FNEUS_H6_T2B 0
+#endif
+                if constexpr (term == 1) accM[i][hb] = mfma_fp6<FNEUS_H6_T2A, FNEUS_H6_T2B>(wq.l6[i], bx6[hb], accM[i][hb], wq.l6[i][6], bx6[hb][6]);
+#endif
             }
-            if constexpr (q == 0) {                      // weights of the next block (or of the next pass's first block)
-                if constexpr (b + 1 < NB) h6_wload<KIND, NT_TOTAL>(wb[nxt], rsrc, off_hi, off_rec, b + 1, lane, t0);
-                else h6_wload<NKIND, NNT>(wb[nxt], rsrc, nx.off_hi, nx.off_rec, 0, lane, t0);
+            if constexpr (q == 8 || q == 9) {            // fp6 operands of this block, sample tile q - 8
+                constexpr int hb = q - 8, blk = h6_lds_block(KIND, b);
+                const unsigned char* qb = tile16[HBM + hb] + kH6Q + blk * 4096;
+                bx6[hb] = h6_op8(*reinterpret_cast<const p2_u32x4*>(qb + kH6QX), *reinterpret_cast<const p2_u32x4*>(qb + kH6QX + 1024));
+                bxl6[hb] = h6_op8(*reinterpret_cast<const p2_u32x4*>(qb + kH6QL), *reinterpret_cast<const p2_u32x4*>(qb + kH6QL + 1024));
             }
-            if constexpr (q == 12 && b + 1 < NB) h6_bload<KIND>(bb[nxt], setM, b + 1, lane);
             if constexpr (NM > 0) {          // micro-steps j with floor(j NSLOT / NM) == slot
                 constexpr int j0 = (slot * NM + NSLOT - 1) / NSLOT, j1 = ((slot + 1) * NM + NSLOT - 1) / NSLOT;
                 static_for<j0, j1>(micro);
             }
             __builtin_amdgcn_sched_barrier(0);
         });
-        // the operands of this block stay live to its end (no prefetch may be given their registers early)
+        // the fp6 operands of this block stay live to its end; then the fp6 weights of the next block (or of the next pass's first
+        // block) go into the one buffer: a load from L2 takes longer than the last fp6 MFMA needs to read its operands
 #pragma unroll
-        for (int hb = 0; hb < 2; ++hb) asm volatile("" ::"v"(bb[cur].x6[hb]), "v"(bb[cur].xl6[hb]), "v"(bb[cur].hi[3][hb]));
+        for (int hb = 0; hb < 2; ++hb) asm volatile("" ::"v"(bx6[hb]), "v"(bxl6[hb]));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(wq.w6[i]), "v"(wq.l6[i]));
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (b + 1 < NB) h6_wq_load<NT_TOTAL>(wq, rsrc, off_rec, b + 1, ln);
+        else h6_wq_load<NNT>(wq, rsrc, nx.off_rec, 0, ln);
     });
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 }
@@ -242,6 +327,10 @@ __global__ void __launch_bounds__(256, 1) sdf_fwd_h6_kernel(const unsigned char*
     constexpr auto& LY = kSdfLayout;
     constexpr auto& HY = kH6Layout;
     const long units = (N + 127) / 128;
+    const H6Lane ln{(unsigned)lane * 16u, (unsigned)h * 64u, (unsigned)t0 * 1024u, (unsigned)t0 * (unsigned)kH6Rec,
+                    (unsigned)t0 * 128u};
+    unsigned char* const tile16[4] = {lds_ + lane * 16, lds_ + kH6Tile + lane * 16, lds_ + 2 * kH6Tile + lane * 16,
+                                      lds_ + 3 * kH6Tile + lane * 16};
     auto encode = [&](long unit) {          // wave w: encoding of tile w of the unit -> hi slots 16..18, fp6 block 4
         const long n = (unit * 4 + wave) * 32 + r;
         const long nc = n < N ? n : N - 1;
@@ -260,7 +349,7 @@ __global__ void __launch_bounds__(256, 1) sdf_fwd_h6_kernel(const unsigned char*
         }
         H6Block ob;
         h6_quant(v0, v1, ob, false);
-        h6_store(lds_ + wave * kH6Tile, lane, 16, 3, 4, ob);
+        h6_store(lds_ + wave * kH6Tile + lane * 16, 16, 3, 4, ob);
     };
     auto put_dot = [&](float (&dot)[2], int hb0) {
 #pragma unroll
@@ -284,62 +373,92 @@ __global__ void __launch_bounds__(256, 1) sdf_fwd_h6_kernel(const unsigned char*
     f32x16 accA[2][2], accB[2][2], cw[2];
     float dot[2] = {0.0f, 0.0f};
     auto load_cw = [&]() { load_accvec<8, 0, 2>(blob, LY.extra, cw, lane, t0); };
-    const __amdgpu_buffer_rsrc_t rsrc = p2_rsrc(hblob);
+    const __amdgpu_buffer_rsrc_t rsrc = p2_rsrc(hblob), brsrc = p2_rsrc(blob);
     auto next_of = [&](int l) { return H6Next{HY.L[l].hi, HY.L[l].rec, LY.L[l].bias}; };
-    H6Prime pr;
-    H6W wb[2];
-    h6_wload<1, 8>(wb[0], rsrc, HY.L[0].hi, HY.L[0].rec, 0, lane, t0);
-    {
-        const f32x16 FN_GLOBAL* __restrict__ p = reinterpret_cast<const f32x16 FN_GLOBAL*>((gblob_t)blob + LY.L[0].bias);
+    H6Whi wr;
+    H6Wq wq;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) pr.bias[i] = p[(t0 + i) * 2 + h];
-    }
+    for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) wr.hi[ks][i] = h6_whi_load<8>(rsrc, HY.L[0].hi, ks, i, ln);
+    h6_wq_load<8>(wq, rsrc, HY.L[0].rec, 0, ln);
+    h6_bias_load(brsrc, LY.L[0].bias, ln, accA);
     if ((long)blockIdx.x < units) encode(blockIdx.x);
     p2_barrier();
     bool first = true;
     long prev_unit = 0;
-#define H6_PASS(KIND, NT, NKIND, NNT, ACT, START, L_, NX, ACCM, HBM, ACCV, HBV, TNV) \
-    h6_pass<KIND, NT, NKIND, NNT, ACT, START>(blob, rsrc, HY.L[L_].hi, HY.L[L_].rec, pr, wb, NX, lds_, lane, t0, ACCM, HBM, ACCV, HBV, TNV, cw, dot)
+#ifdef FNEUS_H6_DUMP                    // debugging (one unit only): hi fragment slot 0 of sample tiles 0 and 2 behind every layer
+    auto dump_layer = [&](int idx) {
+        if (wave < 2) {
+            const uint32_t* srcw = reinterpret_cast<const uint32_t*>(lds_ + (wave * 2) * kH6Tile + kH6Hi);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(sdf_out) + 256 + idx * 512 + wave * 256;
+            for (int k = 0; k < 4; ++k) dst[k * 64 + lane] = srcw[k * 64 + lane];
+        }
+    };
+#define H6_DUMP_LAYER(IDX) dump_layer(IDX);
+#else
+#define H6_DUMP_LAYER(IDX)
+#endif
+    // pass A: MFMAs of sample tiles {0, 1} (accA) || vector work on accB; pass B the other way round
+#define H6_A(KIND, NT, NKIND, NNT, ACT, START, M7, L_, NX, TNV) \
+    h6_pass<KIND, NT, NKIND, NNT, ACT, START, 0, M7>(brsrc, rsrc, HY.L[L_].hi, HY.L[L_].rec, wr, wq, NX, tile16, ln, wave, accA, accB, TNV, cw, dot)
+#define H6_B(KIND, NT, NKIND, NNT, ACT, START, M7, L_, NX, TNV) \
+    h6_pass<KIND, NT, NKIND, NNT, ACT, START, 2, M7>(brsrc, rsrc, HY.L[L_].hi, HY.L[L_].rec, wr, wq, NX, tile16, ln, wave, accB, accA, TNV, cw, dot)
     for (long unit = blockIdx.x; unit < units; unit += gridDim.x) {
         asm volatile("" : "+s"(blob), "+s"(hblob));
         // ---- layer 0 (one block: the encoding)
         if (!first) load_cw();
-        if (first) H6_PASS(1, 8, 1, 8, 0, 0, 0, next_of(0), accA, 0, accB, 2, 2);
-        else H6_PASS(1, 8, 1, 8, 2, 0, 0, next_of(0), accA, 0, accB, 2, 2);
+        if (first) H6_A(1, 8, 1, 8, 0, 0, false, 0, next_of(0), 2);
+        else H6_A(1, 8, 1, 8, 2, 0, false, 0, next_of(0), 2);
         if (!first) put_dot(dot, 2);
         p2_barrier();
         if (!first) finish(prev_unit, 2);
         first = false;
-        H6_PASS(1, 8, 0, 8, 1, 1, 0, next_of(1), accB, 2, accA, 0, 2);
+        H6_B(1, 8, 0, 8, 1, 3, false, 0, next_of(1), 2);
         p2_barrier();
-#pragma unroll 1
-        for (int l = 1; l <= 7; ++l) {
-            asm volatile("" : "+s"(blob), "+s"(hblob));
-            const int tn3 = 7 - t0 < 2 ? 7 - t0 : 2;                    // layer 3 has 7 tiles: its last wave publishes one fewer
-            const int tn_prev = l - 1 == 3 ? tn3 : 2;
-            const int tn_this = l == 3 ? tn3 : 2;
-            const H6Next same = next_of(l), following = next_of(l == 7 ? 0 : l + 1);
-            // pass A: MFMAs of set {0, 1} || activation of layer l-1, set {2, 3}
-            if (l == 3) H6_PASS(0, 7, 0, 7, 1, 0, 3, same, accA, 0, accB, 2, tn_prev);
-            else if (l == 4) H6_PASS(2, 8, 2, 8, 1, 0, 4, same, accA, 0, accB, 2, tn_prev);
-            else H6_PASS(0, 8, 0, 8, 1, 0, l, same, accA, 0, accB, 2, tn_prev);
+        const int tn3 = 7 - t0 < 2 ? 7 - t0 : 2;                        // layer 3 has 7 tiles: its last wave publishes one fewer
+        // layers 1..4: the ring stands at 2 (3 + 3 k-steps of layer 0, 16 per pass behind them); 4.B at 3; 5..7 at 0
+#pragma unroll
+        for (int l = 1; l <= 2; ++l) {
+            const H6Next same = next_of(l), following = next_of(l + 1);
+            H6_A(0, 8, 0, 8, 1, 2, false, l, same, 2);
             p2_barrier();
-            // pass B: MFMAs of set {2, 3} || activation of layer l, set {0, 1} (layer 7: -> dot product)
-            if (l == 2) H6_PASS(0, 8, 0, 7, 1, 0, 2, following, accB, 2, accA, 0, tn_this);
-            else if (l == 3) H6_PASS(0, 7, 2, 8, 1, 0, 3, following, accB, 2, accA, 0, tn_this);
-            else if (l == 4) H6_PASS(2, 8, 0, 8, 1, 1, 4, following, accB, 2, accA, 0, tn_this);
-            else if (l == 7) {
+            if (l == 2) H6_B(0, 8, 0, 7, 1, 2, false, 2, following, 2);
+            else H6_B(0, 8, 0, 8, 1, 2, false, 1, following, 2);
+            p2_barrier();
+            H6_DUMP_LAYER(l)
+        }
+        H6_A(0, 7, 0, 7, 1, 2, false, 3, next_of(3), 2);
+        p2_barrier();
+        H6_B(0, 7, 2, 8, 1, 2, true, 3, next_of(4), tn3);
+        p2_barrier();
+        H6_DUMP_LAYER(3)
+        H6_A(2, 8, 2, 8, 1, 2, true, 4, next_of(4), tn3);
+        p2_barrier();
+        H6_B(2, 8, 0, 8, 1, 3, false, 4, next_of(5), 2);
+        p2_barrier();
+        H6_DUMP_LAYER(4)
+        // (unrolled: with `#pragma unroll 1` the second sample-tile set came out NaN from layer 6 on -- the pass behind the loop's
+        // back edge, fp6 term Q(Wl) Q(x) only -- and fine with the loop unrolled: tools/experiments/r05/h6_dump.py; cause not found)
+#pragma unroll
+        for (int l = 5; l <= 7; ++l) {
+            const H6Next same = next_of(l), following = next_of(l == 7 ? 0 : l + 1);
+            H6_A(0, 8, 0, 8, 1, 0, false, l, same, 2);
+            p2_barrier();
+            if (l == 7) {
                 load_cw();
-                H6_PASS(0, 8, 1, 8, 2, 0, 7, following, accB, 2, accA, 0, tn_this);
-            } else H6_PASS(0, 8, 0, 8, 1, 0, l, following, accB, 2, accA, 0, tn_this);
-            if (l == 7) put_dot(dot, 0);
+                H6_B(0, 8, 1, 8, 2, 0, false, 7, following, 2);
+                put_dot(dot, 0);
+            } else H6_B(0, 8, 0, 8, 1, 0, false, l, following, 2);
             if (l == 5 && unit + gridDim.x < units) encode(unit + gridDim.x);     // the encoding's slots are free behind layer 4
             p2_barrier();
+            H6_DUMP_LAYER(l)
         }
         finish(unit, 0);
         prev_unit = unit;
     }
-#undef H6_PASS
+#undef H6_A
+#undef H6_B
     if (!first) {       // tail of the last unit: act 7 of set {2, 3} -> dot
         load_cw();
         h6_valu_dot(accB, cw, dot);
@@ -357,7 +476,7 @@ extern "C" int fneus_h6_pack(const void* blob, void* hblob, fneus_stream_t strea
     hipStream_t stream = (hipStream_t)stream_;
     fneus::clear_status();
     int units = 0;
-    for (int l = 0; l < 8; ++l) units += fneus::h6_blocks(fneus::h6_kind(l)) * fneus::kSdfGeom[l].ntf;
+    for (int l = 0; l < 8; ++l) units += (l == 0 ? 1 : (l == 4 ? 5 : 4)) * fneus::kSdfGeom[l].ntf;
     hipLaunchKernelGGL(fneus::h6_pack_kernel, dim3(units), dim3(64), 0, stream, reinterpret_cast<const unsigned char*>(blob),
                        reinterpret_cast<unsigned char*>(hblob));
     return fneus::launch_status();

@@ -441,6 +441,41 @@ class SdfStash:
         return out.reshape(T * 32, 256)[:self.n]
 
 
+# Round-5 prototype (plan (ii)): K1's chip-filling launches with "h6" products -- one fp16 MFMA for hi.hi, two
+# block-scaled fp6 MFMAs per 64 k for the cross terms (csrc/h6_engine.h): 1.5 MFMA-times per product instead of 3, sdf still
+# within 1e-4 (tests/test_hip_sdf.py).  FNEUS_K1_H6=1 / set_k1_h6(True) routes parity-mode launches of >= K1_H6_MIN points there.
+K1_H6 = os.environ.get("FNEUS_K1_H6", "0") == "1"
+K1_H6_MIN = int(os.environ.get("FNEUS_K1_H6_MIN", "32768"))
+_H6_BLOBS = {}
+
+
+def set_k1_h6(on: bool):
+    global K1_H6
+    K1_H6 = bool(on)
+
+
+def h6_blob(blob, repack: bool = True):
+    """the h6 form of a packed SDF network's forward chain, derived from the bf16 hi + lo fragments of `blob` (fneus_h6_pack);
+    re-derived on every call by default (the weights change every training step; the kernel is a few microseconds)"""
+    key = (blob.data_ptr(), blob.device)
+    hb = _H6_BLOBS.get(key)
+    fresh = hb is None
+    if fresh:
+        hb = _H6_BLOBS[key] = torch.zeros(int(lib.fneus_h6_blob_bytes()), dtype=torch.uint8, device=blob.device)
+    if repack or fresh:
+        _launch("fneus_h6_pack", lib.fneus_h6_pack, _ptr(blob), _ptr(hb), _stream())
+    return hb
+
+
+def sdf_fwd_h6(blob, n_pts: int, pts=None, rays_o=None, rays_d=None, t=None, m: int = 1, out=None, repack: bool = True):
+    if out is None:
+        out = torch.empty(n_pts, dtype=torch.float32, device=blob.device)
+    hb = h6_blob(blob, repack)
+    _launch("fneus_sdf_fwd_h6", lib.fneus_sdf_fwd_h6, _ptr(blob), _ptr(hb), _ptr(pts), _ptr(rays_o), _ptr(rays_d), _ptr(t), m, n_pts,
+            _ptr(out), _stream())
+    return out
+
+
 def sdf_fwd(blob, n_pts: int, prec: int, pts=None, rays_o=None, rays_d=None, t=None, m: int = 1, out=None, ray_mask=None,
             fill: float = 1.0):
     """ray_mask [n_pts / m] uint8 / bool (ray form, m a multiple of 128, >= 32 768 samples): only the marked rays are evaluated, the
@@ -448,6 +483,8 @@ def sdf_fwd(blob, n_pts: int, prec: int, pts=None, rays_o=None, rays_d=None, t=N
     dev = blob.device
     if out is None:
         out = torch.empty(n_pts, dtype=torch.float32, device=dev)
+    if K1_H6 and prec == PREC_PARITY and n_pts >= K1_H6_MIN and ray_mask is None:
+        return sdf_fwd_h6(blob, n_pts, pts=pts, rays_o=rays_o, rays_d=rays_d, t=t, m=m, out=out)
     if ray_mask is not None and pts is None and m % 128 == 0 and n_pts >= 32768 and os.environ.get("FNEUS_K1_RAY_MASK", "1") != "0":
         mask = ray_mask.view(torch.uint8) if ray_mask.dtype == torch.bool else ray_mask
         work = torch.empty(n_pts // 128 + 1, dtype=torch.int32, device=dev)

@@ -20,6 +20,7 @@
 #ifndef FNEUS_H
 #define FNEUS_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -280,6 +281,15 @@ int fneus_stage1_loss(const float* color /*[B][3]*/, const float* true_rgb /*[B]
  * rank's share of the GLOBAL batch's, and the gradient all-reduce is a plain sum.  norms = NULL: one batch, one rank. */
 int fneus_stage1_norms(const float* mask_in, const unsigned char* sdf_mask, const float* eik_den, int n_rays,
                        float mask_weight, float* norms, fneus_stream_t stream);
+
+/* ---- round 5 prototype: K1 with "h6" products (csrc/h6_engine.h): hi.hi as ONE fp16 MFMA per 16 k, the cross terms hi.lo + lo.hi
+ * as two block-scaled fp6 MFMAs per 64 k (v_mfma_scale_f32_32x32x64_f8f6f4) -- SDFNetwork.sdf, models/fields.py:93-95, at 1.5
+ * MFMA-times per product.  hblob: fneus_h6_blob_bytes() bytes, derived from a packed SDF blob by fneus_h6_pack (again whenever
+ * the blob is re-packed); same points / outputs as fneus_sdf_fwd (parity mode only). */
+size_t fneus_h6_blob_bytes(void);
+int fneus_h6_pack(const void* blob, void* hblob, fneus_stream_t stream);
+int fneus_sdf_fwd_h6(const void* blob, const void* hblob, const float* pts, const float* rays_o, const float* rays_d, const float* t,
+                     int m, long n_pts, float* sdf_out, fneus_stream_t stream);
 
 /* ---- K6: hierarchical sampler pieces (one wavefront per ray, 2 <= samples per ray <= 256; fneus_upsample: <= 512) -- */
 /* NeuSRenderer.up_sample + sample_pdf(det=True)  (renderer.py:152-189, 43-77): z [B][m], sdf [B][m] -> z_new [B][k]  */

@@ -167,3 +167,36 @@ def test_sdf_fwd_grad_multi_tile_workgroups(env, hb, monkeypatch):
         w = 217 if l == 3 else 256
         assert (st1.plane(st1.h, l)[:, :w] - st0.plane(st0.h, l)[:, :w]).abs().max().item() <= 2e-5
         assert (st1.plane(st1.a, l)[:, :w] - st0.plane(st0.a, l)[:, :w]).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("n", [128, 1000, 40003, 65536])
+def test_sdf_fwd_h6_products(env, n):
+    """round-5 prototype (csrc/h6_engine.h, DESIGN.md 4.4 plan (ii)): K1 with ONE fp16 MFMA per 16 k for hi.hi and two block-scaled
+    fp6 MFMAs per 64 k for the cross terms -- 1.5 MFMA-times per product.  Against the fp64 oracle at north_star's 1e-4
+    (tests/checkers/num_schemes.py predicts <= 2.4e-5 on three networks) and beside the shipped three-product kernel"""
+    ops, R = env["ops"], env["R"]
+    rs = np.random.RandomState(13)
+    x = T(rs.uniform(-1.1, 1.1, size=(n, 3)).astype(np.float32))
+    x[0] = 0.0
+    ref = R.sdf_only(x.double(), {"W": [w.double() for w in env["p"]["W"]], "b": [b.double() for b in env["p"]["b"]],
+                                  "scale": 1.0})[:, 0]
+    xd = x.to(env["dev"]).contiguous()
+    out = ops.sdf_fwd_h6(env["net"].blob, n, pts=xd)
+    bf3 = ops.sdf_fwd(env["net"].blob, n, 3, pts=xd)
+    err, err3 = (out.cpu().double() - ref).abs().max().item(), (bf3.cpu().double() - ref).abs().max().item()
+    print(f"sdf_fwd h6 n={n}: max abs err {err:.3e} (three bf16 products: {err3:.3e})")
+    assert err <= 1e-4
+    # ray form (points = o + d t) and repeated launches: bit-identical
+    again = ops.sdf_fwd_h6(env["net"].blob, n, pts=xd, repack=False)
+    assert torch.equal(out, again)
+
+
+def test_sdf_fwd_h6_switch_routes_the_samplers_big_launch(env, monkeypatch):
+    ops = env["ops"]
+    n = 65536
+    xd = (torch.rand(n, 3, device=env["dev"]) * 2 - 1).contiguous()
+    direct = ops.sdf_fwd_h6(env["net"].blob, n, pts=xd)
+    monkeypatch.setattr(ops, "K1_H6", True)
+    assert torch.equal(ops.sdf_fwd(env["net"].blob, n, 3, pts=xd), direct)
+    monkeypatch.setattr(ops, "K1_H6", False)
+    assert not torch.equal(ops.sdf_fwd(env["net"].blob, n, 3, pts=xd), direct)
