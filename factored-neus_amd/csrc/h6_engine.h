@@ -85,11 +85,23 @@ constexpr int kH6LdsTotal = 4 * kH6Tile;
 FN_DEV constexpr int h6_slot(int kind, int ks) { return kind == 1 ? 16 + ks : (kind == 2 ? (ks < 14 ? ks : ks + 2) : ks); }
 FN_DEV constexpr int h6_lds_block(int kind, int b) { return kind == 1 ? 4 : b; }
 
-FN_DEV f32x16 mfma32h(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+FN_DEV f32x16 mfma32h(f16x8 a, f16x8 b, f32x16 c) {
+#ifdef FNEUS_H6_NO_MFMA                  // timing experiments only
+    asm volatile("" : "+v"(c) : "v"(a), "v"(b));
+    return c;
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
+}
 // fp6 x fp6 with the scale bytes OPA of sa / OPB of sb (0 or 1)
 template <int OPA, int OPB>
 FN_DEV f32x16 mfma_fp6(const i32x8& a, const i32x8& b, f32x16 c, int sa, int sb) {
+#ifdef FNEUS_H6_NO_MFMA
+    asm volatile("" : "+v"(c) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+    return c;
+#else
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 2, 2, OPA, sa, OPB, sb);
+#endif
 }
 
 // v_cvt_scalef32_2xpk16_fp6_f32 and its operands.  The instruction converts one element pair per pass and reads its 32 source

@@ -92,6 +92,12 @@ struct H6Lane {
 };
 template <int NT_TOTAL>
 FN_DEV f16x8 h6_whi_load(__amdgpu_buffer_rsrc_t rsrc, uint32_t off_hi, int ks, int i, const H6Lane& ln) {
+#ifdef FNEUS_H6_NO_WEIGHTS               // timing experiments only
+    f16x8 t;
+    for (int e = 0; e < 8; ++e) t[e] = (_Float16)(0.001f * (float)(ln.l16 + e));
+    asm volatile("" : "+v"(t));
+    return t;
+#endif
     return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)ln.l16, (int)(off_hi + ln.t0_frag + (uint32_t)((ks * NT_TOTAL + i) * kFragBytes)), 0));
 }
 template <int NT_TOTAL>
@@ -146,10 +152,16 @@ FN_DEV void h6_pass(__amdgpu_buffer_rsrc_t brsrc, __amdgpu_buffer_rsrc_t rsrc, u
     // ---- the vector work as a list of micro-steps (constant indices only); per sample tile hb:
     //   groups of 8 values: A exp2 / max, B log2, C y (in place);  M block maximum;  S scales;  H fp16 pairs;  L lo parts (in
     //   place);  Q the two conversions;  T stores;  behind sample tile 0: the next pass's bias into its registers
-    constexpr int GS = FNEUS_H6_GS, NG = 32 / GS;             // softplus in groups of GS values: 3 GS temporaries
-    constexpr int OPS_HB = ACT == 1 ? (96 + 16 + 1 + 16 + 32 + 2 + 8 + 1) : (ACT == 2 ? 96 : 0);
+    // One micro-step = ONE vector instruction, and an instruction's result is used GS micro-steps later at the earliest: a wave alone
+    // on its SIMD issues in order and stalls on every dependent instruction (tools/experiments/r05/h6_parts.sh: with the softplus as
+    // three micro-steps of 2-4 dependent instructions the vector work alone took 130 of the launch's 151 us, 13 cycles per
+    // instruction).  Per group of GS values the phases are  R z <- accumulator | N t = -|z| c | E e = exp2 t | X m = max(z, 0) |
+    // A s = 1 + e | G L = log2 s | F y = m + L c'.
+    constexpr int GS = FNEUS_H6_GS, NG = 32 / GS, SP = 7 * 32;   // softplus: 7 phases x 32 values
+    constexpr int OPS_HB = ACT == 1 ? (SP + 16 + 1 + 16 + 32 + 2 + 8 + 1) : (ACT == 2 ? SP + 32 : 0);
     constexpr int NM = ACT == 0 ? 0 : 2 * OPS_HB + 1;
-    float ve[GS], vm[GS], vl[GS], bm = 0.0f, sx = 1.0f, sl = 1.0f;
+    float vz[GS], ve[GS], vm[GS], bm = 0.0f, bm2 = 0.0f, sx = 1.0f, sl = 1.0f;
+    float yd[ACT == 2 ? 32 : 1];         // ACT 2: the values of a sample tile, multiplied with the sdf row behind the softplus
     H6Block ob;
     auto micro = [&](auto J_) {
         constexpr int j0_ = decltype(J_)::value;
@@ -158,35 +170,49 @@ FN_DEV void h6_pass(__amdgpu_buffer_rsrc_t brsrc, __amdgpu_buffer_rsrc_t rsrc, u
         } else {
         constexpr int j = j0_ < OPS_HB ? j0_ : j0_ - 1;
         constexpr int hb = j / OPS_HB, k = j % OPS_HB;
-        if constexpr (k < 96) {
-            constexpr int g = k / (3 * GS), ph = (k % (3 * GS)) / GS, q = k % GS;
+        if constexpr (k < SP) {
+            constexpr int g = k / (7 * GS), ph = (k % (7 * GS)) / GS, q = k % GS;
             constexpr int v = GS * g + q, i = v >> 4, e = v & 15;
-            static_assert(NG * 3 * GS == 96, "32 values");
+            static_assert(NG * 7 * GS == SP, "32 values");
             if constexpr (ph == 0) {
-                const float z = accV[i][hb][e];
-                ve[q] = fast_exp2(-fabsf(z) * (kBeta * kLog2e));
-                asm volatile("v_max_f32 %0, 0, %2" : "=v"(vm[q]), "+v"(ve[q]) : "v"(z));
+                vz[q] = accV[i][hb][e];
+                asm volatile("" : "+v"(vz[q]));
             } else if constexpr (ph == 1) {
-                vl[q] = fast_log2(1.0f + ve[q]);
-                asm volatile("" : "+v"(vl[q]));
+                asm volatile("v_mul_f32 %0, %1, |%2|" : "=v"(ve[q]) : "v"(-kBeta * kLog2e), "v"(vz[q]));
+            } else if constexpr (ph == 2) {
+                ve[q] = fast_exp2(ve[q]);
+                asm volatile("" : "+v"(ve[q]));
+            } else if constexpr (ph == 3) {
+                asm volatile("v_max_f32 %0, 0, %1" : "=v"(vm[q]) : "v"(vz[q]));
+            } else if constexpr (ph == 4) {
+                asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(ve[q]));
+            } else if constexpr (ph == 5) {
+                ve[q] = fast_log2(ve[q]);
+                asm volatile("" : "+v"(ve[q]));
             } else {
-                float y = fmaf(vl[q], kLn2 / kBeta, vm[q]);
                 if constexpr (ACT == 1) {
+                    float y;
+                    asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(y) : "v"(ve[q]), "v"(kLn2 / kBeta), "v"(vm[q]));
                     if constexpr (MASK7) y = i < tnV ? y : 0.0f;      // (the eighth tile contributes nothing, also not to the scale)
                     accV[i][hb][e] = y;
                     asm volatile("" : "+v"(accV[i][hb][e]));
                 } else {
-                    dot[hb] = fmaf(y, cw[i][e], dot[hb]);
-                    asm volatile("" : "+v"(dot[hb]));
+                    asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(yd[v]) : "v"(ve[q]), "v"(kLn2 / kBeta), "v"(vm[q]));
                 }
             }
+        } else if constexpr (ACT == 2) {                 // the dot product with the sdf row: two chains per sample tile would be
+            constexpr int v = k - SP, i = v >> 4, e = v & 15;      // better still; 32 dependent fmas are 32 x 8 cycles per tile
+            dot[hb] = fmaf(yd[v], cw[i][e], dot[hb]);
+            asm volatile("" : "+v"(dot[hb]));
         } else if constexpr (ACT == 1) {
-            constexpr int k2 = k - 96;
+            constexpr int k2 = k - SP;
             if constexpr (k2 < 16) {                     // M (softplus >= 0: no absolute values)
-                if constexpr (k2 == 0) bm = 1.0e-30f;
-                asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(bm) : "v"(accV[0][hb][k2]), "v"(accV[1][hb][k2]));
+                if constexpr (k2 == 0) bm = 1.0e-30f;      // (two chains: a v_max3 waits for the one before it)
+                if constexpr (k2 == 1) bm2 = 1.0e-30f;
+                if constexpr ((k2 & 1) == 0) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(bm) : "v"(accV[0][hb][k2]), "v"(accV[1][hb][k2]));
+                else asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(bm2) : "v"(accV[0][hb][k2]), "v"(accV[1][hb][k2]));
             } else if constexpr (k2 == 16) {             // S
-                const uint32_t ex = __builtin_bit_cast(uint32_t, bm) >> 23;       // (>= 27: both scale bytes stay positive)
+                const uint32_t ex = __builtin_bit_cast(uint32_t, fmaxf(bm, bm2)) >> 23;       // (>= 27: both scale bytes stay positive)
                 sx = __builtin_bit_cast(float, (ex - 2u) << 23);
                 sl = __builtin_bit_cast(float, (ex - 14u) << 23);
                 ob.sc = (ex - 2u) | ((ex - 14u) << 8);
@@ -284,10 +310,12 @@ FN_DEV void h6_pass(__amdgpu_buffer_rsrc_t brsrc, __amdgpu_buffer_rsrc_t rsrc, u
                 bx6[hb] = h6_op8(*reinterpret_cast<const p2_u32x4*>(qb + kH6QX), *reinterpret_cast<const p2_u32x4*>(qb + kH6QX + 1024));
                 bxl6[hb] = h6_op8(*reinterpret_cast<const p2_u32x4*>(qb + kH6QL), *reinterpret_cast<const p2_u32x4*>(qb + kH6QL + 1024));
             }
+#ifndef FNEUS_H6_NO_VALU
             if constexpr (NM > 0) {          // micro-steps j with floor(j NSLOT / NM) == slot
                 constexpr int j0 = (slot * NM + NSLOT - 1) / NSLOT, j1 = ((slot + 1) * NM + NSLOT - 1) / NSLOT;
                 static_for<j0, j1>(micro);
             }
+#endif
             __builtin_amdgcn_sched_barrier(0);
         });
         // the fp6 operands of this block stay live to its end; then the fp6 weights of the next block (or of the next pass's first
@@ -417,17 +445,18 @@ __global__ void __launch_bounds__(256, 1) sdf_fwd_h6_kernel(const unsigned char*
         H6_B(1, 8, 0, 8, 1, 3, false, 0, next_of(1), 2);
         p2_barrier();
         const int tn3 = 7 - t0 < 2 ? 7 - t0 : 2;                        // layer 3 has 7 tiles: its last wave publishes one fewer
-        // layers 1..4: the ring stands at 2 (3 + 3 k-steps of layer 0, 16 per pass behind them); 4.B at 3; 5..7 at 0
-#pragma unroll
-        for (int l = 1; l <= 2; ++l) {
-            const H6Next same = next_of(l), following = next_of(l + 1);
-            H6_A(0, 8, 0, 8, 1, 2, false, l, same, 2);
-            p2_barrier();
-            if (l == 2) H6_B(0, 8, 0, 7, 1, 2, false, 2, following, 2);
-            else H6_B(0, 8, 0, 8, 1, 2, false, 1, following, 2);
-            p2_barrier();
-            H6_DUMP_LAYER(l)
-        }
+        // layers 1..4: the ring stands at 2 (3 + 3 k-steps of layer 0, 16 per pass behind them); 4.B at 3; 5..7 at 0.
+        // Every layer is written out.  (With `#pragma unroll 1` loops over the layers the sample tiles {0, 1} came out NaN from layer 6
+        // on -- the pass behind the loop's back edge, and only through the fp6 term Q(Wl) Q(x) -- while the unrolled code is right:
+        // tools/experiments/r05/h6_dump.py; cause not found, `#pragma unroll` alone is refused by the optimizer in some builds.)
+#define H6_LAYER(L_, PH_, NK_, NN_)                                                     \
+        H6_A(0, 8, 0, 8, 1, PH_, false, L_, next_of(L_), 2);                            \
+        p2_barrier();                                                                   \
+        H6_B(0, 8, NK_, NN_, 1, PH_, false, L_, next_of(L_ + 1), 2);                    \
+        p2_barrier();                                                                   \
+        H6_DUMP_LAYER(L_)
+        H6_LAYER(1, 2, 0, 8)
+        H6_LAYER(2, 2, 0, 7)
         H6_A(0, 7, 0, 7, 1, 2, false, 3, next_of(3), 2);
         p2_barrier();
         H6_B(0, 7, 2, 8, 1, 2, true, 3, next_of(4), tn3);
@@ -438,22 +467,21 @@ __global__ void __launch_bounds__(256, 1) sdf_fwd_h6_kernel(const unsigned char*
         H6_B(2, 8, 0, 8, 1, 3, false, 4, next_of(5), 2);
         p2_barrier();
         H6_DUMP_LAYER(4)
-        // (unrolled: with `#pragma unroll 1` the second sample-tile set came out NaN from layer 6 on -- the pass behind the loop's
-        // back edge, fp6 term Q(Wl) Q(x) only -- and fine with the loop unrolled: tools/experiments/r05/h6_dump.py; cause not found)
-#pragma unroll
-        for (int l = 5; l <= 7; ++l) {
-            const H6Next same = next_of(l), following = next_of(l == 7 ? 0 : l + 1);
-            H6_A(0, 8, 0, 8, 1, 0, false, l, same, 2);
-            p2_barrier();
-            if (l == 7) {
-                load_cw();
-                H6_B(0, 8, 1, 8, 2, 0, false, 7, following, 2);
-                put_dot(dot, 0);
-            } else H6_B(0, 8, 0, 8, 1, 0, false, l, following, 2);
-            if (l == 5 && unit + gridDim.x < units) encode(unit + gridDim.x);     // the encoding's slots are free behind layer 4
-            p2_barrier();
-            H6_DUMP_LAYER(l)
-        }
+        H6_A(0, 8, 0, 8, 1, 0, false, 5, next_of(5), 2);
+        p2_barrier();
+        H6_B(0, 8, 0, 8, 1, 0, false, 5, next_of(6), 2);
+        if (unit + gridDim.x < units) encode(unit + gridDim.x);         // the encoding's slots are free behind layer 4
+        p2_barrier();
+        H6_DUMP_LAYER(5)
+        H6_LAYER(6, 0, 0, 8)
+        H6_A(0, 8, 0, 8, 1, 0, false, 7, next_of(7), 2);
+        p2_barrier();
+        load_cw();
+        H6_B(0, 8, 1, 8, 2, 0, false, 7, next_of(0), 2);
+        put_dot(dot, 0);
+        p2_barrier();
+        H6_DUMP_LAYER(7)
+#undef H6_LAYER
         finish(unit, 0);
         prev_unit = unit;
     }
