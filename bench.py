@@ -586,6 +586,63 @@ def main():
         except Exception:
             pass
 
+    if rank == 0 and world == 1 and standard and prec == ops.PREC_PARITY and not args.no_fast_extra:
+        # DESIGN.md section 4.4, plan (ii), the prototype: K1 with "h6" products -- hi.hi as ONE fp16 MFMA per 16 k, the cross terms
+        # as two block-scaled fp6 MFMAs per 64 k (csrc/h6_engine.h): 1.5 MFMA-times per product instead of 3.  Behind FNEUS_K1_H6 /
+        # ops.set_k1_h6; NOT the headline's arithmetic.  Reported: the launch beside the shipped one on the same points with both
+        # errors against fp64, and the steps whose K1 launches it replaces.
+        try:
+            from oracle import ref_torch as R
+            from fneus import synth
+            sd = {k: torch.from_numpy(v) for k, v in synth.sdf_state_dict(20).items()}
+            pr = R.sdf_params_from_state_dict(sd)
+            net6 = ops.PackedNet("sdf", device)
+            net6.set_raw_from_effective([w.to(device) for w in pr["W"]], [b.to(device) for b in pr["b"]])
+            net6.pack()
+            npt = RAYS * (N_SAMPLES + N_IMPORTANCE)
+            gq = torch.Generator(device=device).manual_seed(1)
+            xq = (torch.rand(npt, 3, device=device, generator=gq) * 2.2 - 1.1).contiguous()
+            ref64 = R.sdf_only(xq[:8192].cpu().double(), {"W": [w.double() for w in pr["W"]], "b": [b.double() for b in pr["b"]], "scale": 1.0})[:, 0]
+
+            def k1_time(fn):
+                for _ in range(5):
+                    fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    o = fn()
+                e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) / 20, float((o[:8192].cpu().double() - ref64).abs().max())
+
+            ops.h6_blob(net6.blob)
+            t3, e3 = k1_time(lambda: ops.sdf_fwd(net6.blob, npt, 3, pts=xq))
+            t6, e6 = k1_time(lambda: ops.sdf_fwd_h6(net6.blob, npt, pts=xq, repack=False))
+            h6 = {"what": "K1 (SDFNetwork.sdf) with fp16 hi.hi + two block-scaled fp6 cross terms: 1.5 MFMA-times per product",
+                  "k1_points": npt, "k1_ms_three_bf16_products": t3, "k1_ms_h6": t6,
+                  "k1_sdf_max_abs_error_vs_fp64": {"three_bf16_products": e3, "h6": e6, "tolerance": 1e-4}}
+            ops.set_k1_h6(True)
+            try:
+                trh = Stage1Trainer(device, prec=prec, use_graph=not args.no_graph)
+                hb_ = synthetic_batches(14, RAYS, device, rank=rank)
+                for b in hb_[:4]:
+                    trh.train_step(b)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for b in hb_[4:]:
+                    trh.train_step(b)
+                torch.cuda.synchronize()
+                h6["stage1_step_ms_sampler_k1_h6"] = (time.perf_counter() - t0) / 10 * 1e3
+                del trh
+                from fneus.trainer2 import Stage2Trainer
+                dt_2h, _, _ = timed_stage(lambda: Stage2Trainer(device, prec=prec, use_graph=not args.no_graph))
+                h6["stage2_step_ms_march_h6"] = dt_2h * 1e3
+            finally:
+                ops.set_k1_h6(False)
+            result["h6_products_prototype"] = h6
+        except Exception as e:
+            result["h6_products_prototype"] = {"value": None, "error": repr(e)}
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             result["cpu_baseline"] = cpu_baseline()

@@ -344,8 +344,16 @@ FN_DEV void h6_valu_dot(f32x16 (&accV)[2][2], const f32x16 (&cw)[2], float (&dot
 // Work unit = 128 samples, pass schedule = sdf_fwd_p2_kernel's (A = sample tiles {0, 1}, B = {2, 3}):
 //   L0.A || tail of the previous unit (act 7 B -> dot)      L0.B || act 0 A
 //   Ll.A || act l-1 B                                       Ll.B || act l A                (l = 1..7; act 7 A -> dot)
+// Units to evaluate: all of them, or -- `sel.list` given -- the listed ones (the 128-sample units of the marked rays, list and length in
+// device memory: sdf_p2_kernels.hip k1_unit_list_kernel); the samples of the others get sel.fill from the workgroups up front.
+struct H6UnitSel {
+    const int32_t* list;
+    const int32_t* n_list;
+    const unsigned char* ray_mask;
+    float fill;
+};
 __global__ void __launch_bounds__(256, 1) sdf_fwd_h6_kernel(const unsigned char* blob, const unsigned char* hblob, PointSrc src, long N,
-                                                            float* __restrict__ sdf_out) {
+                                                            float* __restrict__ sdf_out, H6UnitSel sel) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
     constexpr int NW = 4;
     float* red = reinterpret_cast<float*>(lds_ + kH6LdsTotal);               // [4 tiles][NW waves][32 samples]
@@ -354,7 +362,13 @@ __global__ void __launch_bounds__(256, 1) sdf_fwd_h6_kernel(const unsigned char*
     const int t0 = 2 * wave, r = lane & 31, h = lane >> 5;
     constexpr auto& LY = kSdfLayout;
     constexpr auto& HY = kH6Layout;
-    const long units = (N + 127) / 128;
+    const long all_units = (N + 127) / 128;
+    const long units = sel.list ? (long)__builtin_amdgcn_readfirstlane(*sel.n_list) : all_units;          // positions in the list
+    auto U = [&](long i) { return sel.list ? (long)__builtin_amdgcn_readfirstlane(sel.list[i]) : i; };    // position -> unit
+    if (sel.list) {
+        for (long u = blockIdx.x; u < all_units; u += gridDim.x)
+            if (sel.ray_mask[(u * 128) / src.m] == 0 && threadIdx.x < 128 && u * 128 + threadIdx.x < N) sdf_out[u * 128 + threadIdx.x] = sel.fill;
+    }
     const H6Lane ln{(unsigned)lane * 16u, (unsigned)h * 64u, (unsigned)t0 * 1024u, (unsigned)t0 * (unsigned)kH6Rec,
                     (unsigned)t0 * 128u};
     unsigned char* const tile16[4] = {lds_ + lane * 16, lds_ + kH6Tile + lane * 16, lds_ + 2 * kH6Tile + lane * 16,
@@ -411,7 +425,7 @@ __global__ void __launch_bounds__(256, 1) sdf_fwd_h6_kernel(const unsigned char*
         for (int i = 0; i < 2; ++i) wr.hi[ks][i] = h6_whi_load<8>(rsrc, HY.L[0].hi, ks, i, ln);
     h6_wq_load<8>(wq, rsrc, HY.L[0].rec, 0, ln);
     h6_bias_load(brsrc, LY.L[0].bias, ln, accA);
-    if ((long)blockIdx.x < units) encode(blockIdx.x);
+    if ((long)blockIdx.x < units) encode(U(blockIdx.x));
     p2_barrier();
     bool first = true;
     long prev_unit = 0;
@@ -432,7 +446,8 @@ __global__ void __launch_bounds__(256, 1) sdf_fwd_h6_kernel(const unsigned char*
     h6_pass<KIND, NT, NKIND, NNT, ACT, START, 0, M7>(brsrc, rsrc, HY.L[L_].hi, HY.L[L_].rec, wr, wq, NX, tile16, ln, wave, accA, accB, TNV, cw, dot)
 #define H6_B(KIND, NT, NKIND, NNT, ACT, START, M7, L_, NX, TNV) \
     h6_pass<KIND, NT, NKIND, NNT, ACT, START, 2, M7>(brsrc, rsrc, HY.L[L_].hi, HY.L[L_].rec, wr, wq, NX, tile16, ln, wave, accB, accA, TNV, cw, dot)
-    for (long unit = blockIdx.x; unit < units; unit += gridDim.x) {
+    for (long pos = blockIdx.x; pos < units; pos += gridDim.x) {
+        const long unit = U(pos);
         asm volatile("" : "+s"(blob), "+s"(hblob));
         // ---- layer 0 (one block: the encoding)
         if (!first) load_cw();
@@ -470,7 +485,7 @@ __global__ void __launch_bounds__(256, 1) sdf_fwd_h6_kernel(const unsigned char*
         H6_A(0, 8, 0, 8, 1, 0, false, 5, next_of(5), 2);
         p2_barrier();
         H6_B(0, 8, 0, 8, 1, 0, false, 5, next_of(6), 2);
-        if (unit + gridDim.x < units) encode(unit + gridDim.x);         // the encoding's slots are free behind layer 4
+        if (pos + gridDim.x < units) encode(U(pos + gridDim.x));        // the encoding's slots are free behind layer 4
         p2_barrier();
         H6_DUMP_LAYER(5)
         H6_LAYER(6, 0, 0, 8)
@@ -510,20 +525,36 @@ extern "C" int fneus_h6_pack(const void* blob, void* hblob, fneus_stream_t strea
     return fneus::launch_status();
 }
 
+namespace fneus {
+void k1_unit_list(const unsigned char* ray_mask, int m, long all_units, int32_t* work, hipStream_t stream);      // sdf_p2_kernels.hip
+}
+
+// ray_mask (may be NULL) [n_pts / m] + work [n_pts / 128 + 1] int32: only the samples of the marked rays are evaluated, the others
+// get `fill` (the form of fneus_sdf_fwd_rays: ray mode, m a multiple of 128)
 extern "C" int fneus_sdf_fwd_h6(const void* blob, const void* hblob, const float* pts, const float* rays_o, const float* rays_d,
-                                const float* t, int m, long n_pts, float* sdf_out, fneus_stream_t stream_) {
+                                const float* t, int m, long n_pts, const unsigned char* ray_mask, float fill, int32_t* work,
+                                float* sdf_out, fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     fneus::clear_status();
     if (n_pts <= 0) return 0;
+    if (ray_mask && (pts || !work || m <= 0 || m % 128 != 0)) {
+        fneus::set_last_error("fneus_sdf_fwd_h6: a ray mask needs the ray form with m = k x 128 samples per ray and the work buffer");
+        return -2;
+    }
     static bool done = false;
     if (!done) {
         fneus::allow_big_lds(fneus::sdf_fwd_h6_kernel);
         done = true;
     }
-    const fneus::PointSrc src{pts, rays_o, rays_d, t, m};
+    const fneus::PointSrc src{pts, rays_o, rays_d, t, m > 0 ? m : 1};
     const long units = (n_pts + 127) / 128;
+    fneus::H6UnitSel sel{nullptr, nullptr, nullptr, 0.0f};
+    if (ray_mask) {
+        fneus::k1_unit_list(ray_mask, m, units, work, stream);
+        sel = fneus::H6UnitSel{work + 1, work, ray_mask, fill};
+    }
     hipLaunchKernelGGL(fneus::sdf_fwd_h6_kernel, dim3((unsigned)(units < 256 ? units : 256)), dim3(256),
                        fneus::kH6LdsTotal + 4 * 4 * 32 * 4, stream, reinterpret_cast<const unsigned char*>(blob),
-                       reinterpret_cast<const unsigned char*>(hblob), src, n_pts, sdf_out);
+                       reinterpret_cast<const unsigned char*>(hblob), src, n_pts, sdf_out, sel);
     return fneus::launch_status();
 }

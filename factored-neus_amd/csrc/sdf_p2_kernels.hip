@@ -187,6 +187,10 @@ __global__ void __launch_bounds__(1024) k1_unit_list_kernel(const unsigned char*
     if (threadIdx.x == 0) work[0] = base;
 }
 
+void k1_unit_list(const unsigned char* ray_mask, int m, long all_units, int32_t* work, hipStream_t stream) {
+    hipLaunchKernelGGL(k1_unit_list_kernel, dim3(1), dim3(1024), 0, stream, ray_mask, m, all_units, work);
+}
+
 // K1 on the marked rays only (fneus_sdf_fwd_rays); two-pass kernel on 8 waves
 int sdf_fwd_p2_rays(const unsigned char* b, const PointSrc& src, long n_pts, const unsigned char* ray_mask, float fill, int32_t* work,
                     float* sdf_out, int prec, hipStream_t stream) {

@@ -135,7 +135,7 @@ def _load():
         "fneus_embed": (C.c_int, [vp, l, ip, ip, vp, vp]),
         "fneus_h6_blob_bytes": (C.c_size_t, []),
         "fneus_h6_pack": (C.c_int, [vp, vp, vp]),
-        "fneus_sdf_fwd_h6": (C.c_int, [vp, vp, vp, vp, vp, vp, ip, l, vp, vp]),
+        "fneus_sdf_fwd_h6": (C.c_int, [vp, vp, vp, vp, vp, vp, ip, l, vp, f, vp, vp, vp]),
         "fneus_lvis_visibility": (C.c_int, [vp, vp, vp, vp, vp, vp, ip, ip, ip, vp, ip, vp]),
         "fneus_ray_hit": (C.c_int, [vp] * 7 + [ip, ip, f] + [vp] * 5 + [vp]),
         "fneus_sample_dirs": (C.c_int, [vp] * 4 + [ip, ip, vp, vp, vp]),

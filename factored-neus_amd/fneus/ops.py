@@ -467,12 +467,17 @@ def h6_blob(blob, repack: bool = True):
     return hb
 
 
-def sdf_fwd_h6(blob, n_pts: int, pts=None, rays_o=None, rays_d=None, t=None, m: int = 1, out=None, repack: bool = True):
+def sdf_fwd_h6(blob, n_pts: int, pts=None, rays_o=None, rays_d=None, t=None, m: int = 1, out=None, repack: bool = True,
+               ray_mask=None, fill: float = 1.0):
     if out is None:
         out = torch.empty(n_pts, dtype=torch.float32, device=blob.device)
     hb = h6_blob(blob, repack)
+    mask = work = None
+    if ray_mask is not None:
+        mask = (ray_mask.view(torch.uint8) if ray_mask.dtype == torch.bool else ray_mask).contiguous()
+        work = torch.empty(n_pts // 128 + 1, dtype=torch.int32, device=blob.device)
     _launch("fneus_sdf_fwd_h6", lib.fneus_sdf_fwd_h6, _ptr(blob), _ptr(hb), _ptr(pts), _ptr(rays_o), _ptr(rays_d), _ptr(t), m, n_pts,
-            _ptr(out), _stream())
+            _ptr(mask), float(fill), _ptr(work), _ptr(out), _stream())
     return out
 
 
@@ -483,8 +488,10 @@ def sdf_fwd(blob, n_pts: int, prec: int, pts=None, rays_o=None, rays_d=None, t=N
     dev = blob.device
     if out is None:
         out = torch.empty(n_pts, dtype=torch.float32, device=dev)
-    if K1_H6 and prec == PREC_PARITY and n_pts >= K1_H6_MIN and ray_mask is None:
-        return sdf_fwd_h6(blob, n_pts, pts=pts, rays_o=rays_o, rays_d=rays_d, t=t, m=m, out=out)
+    if K1_H6 and prec == PREC_PARITY and n_pts >= K1_H6_MIN:
+        masked = ray_mask is not None and pts is None and m % 128 == 0 and os.environ.get("FNEUS_K1_RAY_MASK", "1") != "0"
+        return sdf_fwd_h6(blob, n_pts, pts=pts, rays_o=rays_o, rays_d=rays_d, t=t, m=m, out=out,
+                          ray_mask=ray_mask if masked else None, fill=fill)
     if ray_mask is not None and pts is None and m % 128 == 0 and n_pts >= 32768 and os.environ.get("FNEUS_K1_RAY_MASK", "1") != "0":
         mask = ray_mask.view(torch.uint8) if ray_mask.dtype == torch.bool else ray_mask
         work = torch.empty(n_pts // 128 + 1, dtype=torch.int32, device=dev)

@@ -289,7 +289,9 @@ int fneus_stage1_norms(const float* mask_in, const unsigned char* sdf_mask, cons
 size_t fneus_h6_blob_bytes(void);
 int fneus_h6_pack(const void* blob, void* hblob, fneus_stream_t stream);
 int fneus_sdf_fwd_h6(const void* blob, const void* hblob, const float* pts, const float* rays_o, const float* rays_d, const float* t,
-                     int m, long n_pts, float* sdf_out, fneus_stream_t stream);
+                     int m, long n_pts, const unsigned char* ray_mask, float fill, int32_t* work, float* sdf_out,
+                     fneus_stream_t stream);
+/* (ray_mask / fill / work as in fneus_sdf_fwd_rays; ray_mask NULL: every sample) */
 
 /* ---- K6: hierarchical sampler pieces (one wavefront per ray, 2 <= samples per ray <= 256; fneus_upsample: <= 512) -- */
 /* NeuSRenderer.up_sample + sample_pdf(det=True)  (renderer.py:152-189, 43-77): z [B][m], sdf [B][m] -> z_new [B][k]  */

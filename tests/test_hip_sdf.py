@@ -200,3 +200,19 @@ def test_sdf_fwd_h6_switch_routes_the_samplers_big_launch(env, monkeypatch):
     assert torch.equal(ops.sdf_fwd(env["net"].blob, n, 3, pts=xd), direct)
     monkeypatch.setattr(ops, "K1_H6", False)
     assert not torch.equal(ops.sdf_fwd(env["net"].blob, n, 3, pts=xd), direct)
+
+
+def test_sdf_fwd_h6_on_the_marked_rays_only(env):
+    """the ray-mask form of fneus_sdf_fwd_rays on the h6 kernel: unmarked rays get `fill`, marked ones the same values as the
+    unmasked launch (bit for bit)"""
+    ops = env["ops"]
+    B, m = 300, 128
+    g = torch.Generator().manual_seed(4)
+    ro = (torch.rand(B, 3, generator=g) * 0.4 - 0.2).to(env["dev"]).contiguous()
+    rd = torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=-1).to(env["dev"]).contiguous()
+    t = (torch.rand(B * m, generator=g) * 1.5).to(env["dev"]).contiguous()
+    mask = (torch.rand(B, generator=g) < 0.6).to(env["dev"])
+    full = ops.sdf_fwd_h6(env["net"].blob, B * m, rays_o=ro, rays_d=rd, t=t, m=m)
+    part = ops.sdf_fwd_h6(env["net"].blob, B * m, rays_o=ro, rays_d=rd, t=t, m=m, ray_mask=mask, fill=7.0, repack=False)
+    full, part = full.reshape(B, m), part.reshape(B, m)
+    assert torch.equal(part[mask], full[mask]) and bool((part[~mask] == 7.0).all())
