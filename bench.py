@@ -422,7 +422,7 @@ def main():
         torch.cuda.synchronize()
         dt_r = (time.perf_counter() - t0) / n_fwd
         result["forward_only_render"] = {"value": SAMPLES_PER_STEP / dt_r, "unit": "ray-samples/s", "ms_per_call": dt_r * 1e3,
-                                         "note": "NeuSRenderer.render under no_grad, eager launches, no stash written"}
+                                         "note": "NeuSRenderer.render under no_grad, no stash written; one hipGraph replay per chunk shape (round 5; FNEUS_RENDER_GRAPH=0: eager launches)"}
 
     if rank == 0 and world == 1 and not args.no_fast_extra and prec == ops.PREC_PARITY and standard:
         dt_f, _, _ = run(ops.PREC_FAST, max(args.steps // 2, 5), 3, profile=False)

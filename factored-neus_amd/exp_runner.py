@@ -148,7 +148,7 @@ class Runner:
         for o, d in zip(rays_o.reshape(-1, 3).split(chunk), rays_d.reshape(-1, 3).split(chunk)):
             data = torch.cat([o, d, torch.zeros(len(o), 4, device=o.device)], -1)
             out = self.trainer.render_only(data, cos_anneal_ratio=self.get_cos_anneal_ratio())
-            out_rgb.append(out["color_fine"])
+            out_rgb.append(out["color_fine"].clone())       # (a replayed chunk graph hands out static buffers)
         img = (torch.cat(out_rgb, 0).reshape(H, W, 3) * 256).clip(0, 255).to(torch.uint8).cpu().numpy()
         os.makedirs(os.path.join(self.base_exp_dir, "validations_fine"), exist_ok=True)
         path = os.path.join(self.base_exp_dir, "validations_fine", "{:0>8d}_{}.png".format(self.iter_step, idx))

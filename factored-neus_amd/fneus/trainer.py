@@ -427,6 +427,31 @@ class Stage1Trainer:
         self.grads.restore_small_grads()
 
     def render_only(self, data: torch.Tensor, cos_anneal_ratio: float = 1.0):
+        """forward-only render of a ray chunk (exp_runner.py:374-486 validate_image, per chunk).  With use_graph the ~25 launches
+        of a chunk shape are captured once and replayed (FNEUS_RENDER_GRAPH=0: eager): the returned tensors are then static
+        buffers that the next call of the same shape overwrites -- clone what has to outlive it."""
+        import os
+        if self.use_graph and data.is_cuda and ops.PROFILE is None and os.environ.get("FNEUS_RENDER_GRAPH", "1") != "0":
+            cache = self.__dict__.setdefault("_render_graphs", {})
+            key = (tuple(data.shape), data.dtype)
+            ent = cache.get(key)
+            if ent is None:
+                self._render_eager(data, cos_anneal_ratio)          # allocations and lazy set-up outside the capture
+                static = data.clone()
+                cos = torch.full((1,), float(cos_anneal_ratio), dtype=torch.float32, device=data.device)
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    out = self._render_eager(static, cos)
+                ent = cache[key] = (graph, static, cos, out)
+            graph, static, cos, out = ent
+            static.copy_(data)
+            cos.fill_(float(cos_anneal_ratio))
+            graph.replay()
+            return out
+        return self._render_eager(data, cos_anneal_ratio)
+
+    def _render_eager(self, data: torch.Tensor, cos_anneal_ratio):
         rays_o, rays_d = data[:, :3], data[:, 3:6]
         with torch.no_grad():
             return self.renderer.render(rays_o, rays_d, None, None, perturb_overwrite=0, cos_anneal_ratio=cos_anneal_ratio)

@@ -87,3 +87,25 @@ def test_replay_follows_a_ramping_cos_anneal_ratio_and_a_background_colour():
     a = float(tr._step_body(batches[0], 0.0, bg, with_optimizer=False)["loss"])
     b = float(tr._step_body(batches[0], 1.0, bg, with_optimizer=False)["loss"])
     assert abs(a - b) > 1e-4 * abs(a)
+
+
+def test_forward_only_render_replays_one_graph_per_chunk_shape():
+    """Stage1Trainer.render_only (validate_image's chunk render): with use_graph the launches of a chunk shape are captured once
+    and replayed -- bit for bit the eager render, for a new chunk of the same shape and another cos_anneal_ratio too; the
+    returned tensors are static buffers (the next call overwrites them)"""
+    from fneus.trainer import synthetic_batches
+    dev = torch.device("cuda:0")
+    eager, graphed = _trainer(False), _trainer(True)
+    a, b = synthetic_batches(2, 384, dev, seed0=99)
+    small = synthetic_batches(1, 100, dev, seed0=7)[0]
+    keys = ("color_fine", "weights", "weight_sum", "gradients", "surface_color", "_z_vals")
+    for data, cos in ((a, 1.0), (b, 0.35), (small, 1.0), (a, 0.35)):
+        ref = eager.render_only(data, cos_anneal_ratio=cos)
+        out = graphed.render_only(data, cos_anneal_ratio=cos)
+        for k in keys:
+            assert torch.equal(ref[k], out[k]), (k, cos, tuple(data.shape))
+    assert len(graphed._render_graphs) == 2                      # two chunk shapes
+    first = graphed.render_only(a)["color_fine"]
+    kept = first.clone()
+    second = graphed.render_only(b)["color_fine"]
+    assert second.data_ptr() == first.data_ptr() and not torch.equal(kept, second)

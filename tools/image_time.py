@@ -17,7 +17,7 @@ for chunk in (512, 4096, 16384):
         outs = []
         for oo, dd in zip(o.split(chunk), d.split(chunk)):
             data = torch.cat([oo, dd, torch.zeros(len(oo), 4, device=dev)], -1)
-            outs.append(tr.render_only(data)["color_fine"])
+            outs.append(tr.render_only(data)["color_fine"].clone())
         img = torch.cat(outs).cpu()
         dt = time.time() - t0
     print(f"chunk {chunk:6d} rays: {dt:.2f} s per 1600x1200 image ({o.shape[0] * 128 / dt / 1e7:.2f}e7 ray-samples/s)")
