@@ -579,10 +579,10 @@ def main():
         except Exception as e:
             result["parity"] = {"error": repr(e)}
         try:
-            cj = json.load(open(os.path.join(ROOT, "profiles", "r03_chamfer.json")))
+            cj = json.load(open(os.path.join(ROOT, "profiles", "r05_chamfer.json")))
             result["chamfer"] = {k: cj[k] for k in ("what", "steps", "seeds", "hip_mean", "hip_sd", "oracle_mean", "oracle_sd",
                                                     "ratio_of_means", "sem_log_ratio_pct", "within_2_pct") if k in cj}
-            result["chamfer"]["source"] = "profiles/r03_chamfer.json (tests/checkers/chamfer_study.py on the builder's box; not measured in this run)"
+            result["chamfer"]["source"] = "profiles/r05_chamfer.json (tests/checkers/chamfer_study.py on the builder's box, round-5 kernels; not measured in this run)"
         except Exception:
             pass
 

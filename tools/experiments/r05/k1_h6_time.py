@@ -12,7 +12,7 @@ for seed, kw in [(20, {}), (3, dict(perturb=0.1)), (5, dict(perturb=0.05, warp=(
     net = ops.PackedNet("sdf", dev)
     net.set_raw_from_effective([w.to(dev) for w in p["W"]], [b.to(dev) for b in p["b"]])
     net.pack()
-    for n in (65536, 1 << 20):
+    for n in (32768, 65536, 1 << 20):
         g = torch.Generator(device=dev).manual_seed(1)
         x = (torch.rand(n, 3, device=dev, generator=g) * 2.2 - 1.1).contiguous()
         sub = x[:8192].cpu().double()
