@@ -51,6 +51,9 @@ FN_DEV void p2_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: 
 #ifndef FNEUS_P2_DEPTH
 #define FNEUS_P2_DEPTH 3           // weight-prefetch distance in k-steps (a k-step of a pass = 12 MFMAs = 384 cycles)
 #endif
+#ifndef FNEUS_P2_BD
+#define FNEUS_P2_BD 1              // prefetch distance of the B fragments (LDS) in k-steps; the ring holds BD + 2 k-steps
+#endif
 
 typedef __attribute__((ext_vector_type(4))) unsigned int p2_u32x4;
 
@@ -155,7 +158,8 @@ FN_DEV void p2_pass(const unsigned char* __restrict__ blob, __amdgpu_buffer_rsrc
     const unsigned char* flM = lds + hbM * kP2Half + lane * 16;
     unsigned char* flV = lds + hbV * kP2Half + lane * 16;
     unsigned char* dump = lds + kP2Dump + lane * 16;
-    bf16x8 bh[3][2], bl[3][2];
+    constexpr int BD = FNEUS_P2_BD, RB = BD + 2;
+    bf16x8 bh[RB][2], bl[RB][2];
 #ifdef FNEUS_P2_NO_LDSB                 // timing experiments only: no B-fragment reads from LDS
     bf16x8 bconst;
     for (int e = 0; e < 8; ++e) bconst[e] = (__bf16)(0.002f * (float)(lane - e));
@@ -164,10 +168,14 @@ FN_DEV void p2_pass(const unsigned char* __restrict__ blob, __amdgpu_buffer_rsrc
     auto ldb = [&](int hb, int slot, int plane) { return *reinterpret_cast<const bf16x8*>(flM + hb * kP2Half + (slot * NPL + plane) * kFragBytes); };
 #endif
 #pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {
-        bh[0][hb] = ldb(hb, p2_slot<LMAP>(0), 0);
-        if constexpr (PREC == 3) bl[0][hb] = ldb(hb, p2_slot<LMAP>(0), 1);
-    }
+    for (int b0 = 0; b0 < BD; ++b0)
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            if (b0 < KS) {
+                bh[b0][hb] = ldb(hb, p2_slot<LMAP>(b0 < KS ? b0 : 0), 0);
+                if constexpr (PREC == 3) bl[b0][hb] = ldb(hb, p2_slot<LMAP>(b0 < KS ? b0 : 0), 1);
+            }
+        }
     p2_prime_bias<PREC, D, TN>(pr, blob, lane, t0, nx); // (the registers are free again: next pass's bias)
     typedef __attribute__((ext_vector_type(2))) __bf16 p2_bf16x2;
     uint32_t phw[4], plw[4];                             // the fragment half being assembled by the vector work (4 x 2 bf16)
@@ -286,15 +294,15 @@ FN_DEV void p2_pass(const unsigned char* __restrict__ blob, __amdgpu_buffer_rsrc
                 constexpr int r = q % NACC, prod = q / NACC;
                 constexpr int i = r >> 1, hb = r & 1;
                 if constexpr (PREC == 3) {
-                    if constexpr (prod == 0) accM[i][hb] = mfma32(al[s % (D + 1)][i], bh[s % 3][hb], accM[i][hb]);
-                    else if constexpr (prod == 1) accM[i][hb] = mfma32(ah[s % (D + 1)][i], bl[s % 3][hb], accM[i][hb]);
-                    else accM[i][hb] = mfma32(ah[s % (D + 1)][i], bh[s % 3][hb], accM[i][hb]);
+                    if constexpr (prod == 0) accM[i][hb] = mfma32(al[s % (D + 1)][i], bh[s % RB][hb], accM[i][hb]);
+                    else if constexpr (prod == 1) accM[i][hb] = mfma32(ah[s % (D + 1)][i], bl[s % RB][hb], accM[i][hb]);
+                    else accM[i][hb] = mfma32(ah[s % (D + 1)][i], bh[s % RB][hb], accM[i][hb]);
                 } else {
-                    accM[i][hb] = mfma32(ah[s % (D + 1)][i], bh[s % 3][hb], accM[i][hb]);
+                    accM[i][hb] = mfma32(ah[s % (D + 1)][i], bh[s % RB][hb], accM[i][hb]);
                 }
             }
 #else
-            asm volatile("" :: "v"(ah[s % (D + 1)][0]), "v"(al[s % (D + 1)][0]), "v"(bh[s % 3][q & 1]), "v"(bl[s % 3][q & 1]));
+            asm volatile("" :: "v"(ah[s % (D + 1)][0]), "v"(al[s % (D + 1)][0]), "v"(bh[s % RB][q & 1]), "v"(bl[s % RB][q & 1]));
 #endif
             // ---- operand requests of this slot
             constexpr int NREQ = NSLOT >= 12 ? 4 : (NSLOT >= 4 ? 2 : 1);      // slots per request group
@@ -321,13 +329,13 @@ FN_DEV void p2_pass(const unsigned char* __restrict__ blob, __amdgpu_buffer_rsrc
                 }
             }
 #ifndef FNEUS_P2_B_AT_START
-            if constexpr (qb >= 0 && qb < NREQ && s + 1 < KS) {       // B fragments of k-step s + 1
+            if constexpr (qb >= 0 && qb < NREQ && s + BD < KS) {      // B fragments of k-step s + BD
                 constexpr int per = (2 * NPL + NREQ - 1) / NREQ;
 #pragma unroll
                 for (int u = qb * per; u < (qb + 1) * per && u < 2 * NPL; ++u) {
                     const int hb = u & 1, plane = u >> 1;
-                    if (plane == 0) bh[(s + 1) % 3][hb] = ldb(hb, p2_slot<LMAP>(s + 1), 0);
-                    else bl[(s + 1) % 3][hb] = ldb(hb, p2_slot<LMAP>(s + 1), 1);
+                    if (plane == 0) bh[(s + BD) % RB][hb] = ldb(hb, p2_slot<LMAP>(s + BD < KS ? s + BD : 0), 0);
+                    else bl[(s + BD) % RB][hb] = ldb(hb, p2_slot<LMAP>(s + BD < KS ? s + BD : 0), 1);
                 }
             }
 #endif
@@ -347,8 +355,8 @@ FN_DEV void p2_pass(const unsigned char* __restrict__ blob, __amdgpu_buffer_rsrc
         // last MFMA has only just been issued (seen: the lo fragment of slot 7).
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
-            asm volatile("" ::"v"(bh[s % 3][hb]));
-            if constexpr (PREC == 3) asm volatile("" ::"v"(bl[s % 3][hb]));
+            asm volatile("" ::"v"(bh[s % RB][hb]));
+            if constexpr (PREC == 3) asm volatile("" ::"v"(bl[s % RB][hb]));
         }
     });
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
