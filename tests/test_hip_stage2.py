@@ -137,11 +137,12 @@ def test_lvis_render_vs_reference(golden_dir, name):
     pr, pr_ref = c(out["pre_trace_radiance"]), T(g["out/pre_trace_radiance"])
     assert (pr - pr_ref).abs().max().item() <= 1e-4 * max(1.0, pr_ref.abs().max().item())
     # ground truth behind the re-sampling
-    for key, tol_bulk, tol_max in (("gt_lvis", 1e-4, 2e-3), ("gt_trace_radiance", 1e-4, 2e-3)):
+    # (round 5: observed 100 % within 1e-4 on the three fixtures, worst 7.7e-5 / 1.2e-7; the bounds were 90 % and 2e-3)
+    for key, tol_bulk, tol_max in (("gt_lvis", 1e-4, 2e-4), ("gt_trace_radiance", 1e-4, 2e-4)):
         a, b = c(out[key]), T(g["out/" + key])
         f = frac_within(a, b, tol_bulk)
         print(f"  {name}: {key} within {tol_bulk:g}: {100 * f:.2f} %, worst {float((a - b).abs().max()):.2e}")
-        assert f >= 0.9 and (a - b).abs().max().item() <= tol_max, key
+        assert f >= 0.995 and (a - b).abs().max().item() <= tol_max, key
     assert torch.equal(c(out["gt_lvis"])[~m], torch.ones_like(c(out["gt_lvis"])[~m]))
     # loss and gradients of lvis.py:164-170 -- with the reference's own primary depths fed in (trace/prim_z): the trained networks
     # are ReLU MLPs on PE10 of the primary hit point (frequencies up to 2^9), and a zero crossing that moves by 1e-4 where the own
@@ -215,10 +216,13 @@ def test_stage2_adam_steps_match_reference(golden_dir):
                 want = g[f"adam{step + 1}_sub/" + k]
                 got = prm.detach().cpu().reshape(-1)[::997].numpy()
                 bad = np.abs(got - want) > 0.2 * lr       # Adam moves every weight by ~lr: near-zero gradients may flip sign
-                # ... and the traced ground truth differs at a few re-sampling outliers (see above): after three steps up
-                # to one weight in ten has drifted by more than 0.2 lr, none by more than the 2 lr per step of a flipped sign
-                assert bad.sum() <= max(1, (0.02 if step == 0 else 0.10) * bad.size), (step, k, int(bad.sum()), bad.size)
-                assert np.abs(got - want).max() <= 2.2 * (step + 1) * lr + 1e-7, (step, k)   # a flipped sign is 2 lr per step
+                # ... and the traced ground truth differs at a few re-sampling outliers (see above): after three steps a few
+                # weights in a hundred have drifted by more than 0.2 lr, none by more than two flipped signs
+                print(f"  adam step {step + 1} {k}: {int(bad.sum())} of {bad.size} sampled weights off by > 0.2 lr, worst {np.abs(got - want).max() / lr:.2f} lr")
+                # (round 5: observed none after one step -- worst 0.04 lr -- and <= 3.0 % after three, worst 2.67 lr; the bounds
+                # were 2 % / 10 % and 2.2 lr per step)
+                assert bad.sum() <= max(1, (0.005 if step == 0 else 0.05) * bad.size), (step, k, int(bad.sum()), bad.size)
+                assert np.abs(got - want).max() <= (0.2 if step == 0 else 4.0) * lr + 1e-7, (step, k)   # a flipped sign is 2 lr per step
     assert tr.iter_step == 3
 
 
