@@ -21,17 +21,19 @@ struct AdamSegs {
     int n;
 };
 
-__global__ void adam_tick_kernel(float* __restrict__ step) { *step += 1.0f; }
-
+// `step` (float[2]): [0] the number of steps taken so far, [1] an arrival counter (bits of an unsigned, zero between launches).
+// The step count of THIS update is step[0] + 1; the last workgroup to finish writes it back (round 5: the increment was a
+// launch of its own).  TICK = 0: a further launch of the same update (tables of more than 32 segments): the count is current.
+template <int TICK>
 __global__ void __launch_bounds__(256) adam_kernel(AdamSegs s, const float* __restrict__ lr_ptr,
-                                                   const float* __restrict__ step_ptr, double beta1d, double beta2d,
+                                                   float* __restrict__ step_ptr, double beta1d, double beta2d,
                                                    float eps, int zero_grad) {
     // hyper-parameters are doubles on the host side of torch.optim.Adam: 1 - beta is rounded once, from the double
     const float beta1 = (float)beta1d, beta2 = (float)beta2d;
     const float omb1 = (float)(1.0 - beta1d), omb2 = (float)(1.0 - beta2d);
     __shared__ float bc[2];
     if (threadIdx.x == 0) {          // the two double-precision pow() once per workgroup, not per thread
-        const double t = (double)*step_ptr;
+        const double t = (double)*step_ptr + (TICK ? 1.0 : 0.0);
         bc[0] = (float)(1.0 - pow(beta1d, t));
         bc[1] = (float)(1.0 - pow(beta2d, t));
     }
@@ -73,6 +75,16 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamSegs s, const float* __re
             }
         }
     }
+    if constexpr (TICK != 0) {           // every workgroup has read step[0] (above) before it arrives here
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned* cnt = reinterpret_cast<unsigned*>(step_ptr + 1);
+            if (atomicAdd(cnt, 1u) == gridDim.x - 1) {
+                *cnt = 0u;
+                *step_ptr += 1.0f;
+            }
+        }
+    }
 }
 
 }  // namespace fneus
@@ -84,7 +96,7 @@ extern "C" int fneus_adam(const FneusAdamSegment* segs /*host array*/, int n_seg
     hipStream_t stream = (hipStream_t)stream_;
     fneus::clear_status();
     if (n_segs <= 0) return 0;
-    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, stream, step);
+    bool ticked = false;
     for (int first = 0; first < n_segs; first += kAdamMaxSegs) {
         AdamSegs s;
         s.n = n_segs - first < kAdamMaxSegs ? n_segs - first : kAdamMaxSegs;
@@ -102,7 +114,9 @@ extern "C" int fneus_adam(const FneusAdamSegment* segs /*host array*/, int n_seg
         s.first_chunk[s.n] = chunks;
         if (chunks == 0) continue;
         const long grid = chunks < 4096 ? chunks : 4096;
-        hipLaunchKernelGGL(adam_kernel, dim3((unsigned)grid), dim3(256), 0, stream, s, lr, step, beta1, beta2, (float)eps, zero_grad);
+        if (!ticked) hipLaunchKernelGGL(adam_kernel<1>, dim3((unsigned)grid), dim3(256), 0, stream, s, lr, step, beta1, beta2, (float)eps, zero_grad);
+        else hipLaunchKernelGGL(adam_kernel<0>, dim3((unsigned)grid), dim3(256), 0, stream, s, lr, step, beta1, beta2, (float)eps, zero_grad);
+        ticked = true;
     }
     return fneus::launch_status();
 }

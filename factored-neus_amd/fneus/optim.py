@@ -55,7 +55,10 @@ class FlatAdam(torch.optim.Adam):
                 raise RuntimeError("FlatAdam needs contiguous fp32 parameters with persistent .grad buffers")
         # the shared step counter: continue from a loaded state if there is one
         steps = [float(self.state[p]["step"]) for p in ps if p in self.state and "step" in self.state[p]]
-        self._step_dev = torch.full((), max(steps) if steps else 0.0, dtype=torch.float32, device=dev)
+        # (fneus_adam: float[2] = the step count and the launch's arrival counter; the state's `step` is the 0-d view of [0])
+        self._step_buf = torch.zeros(2, dtype=torch.float32, device=dev)
+        self._step_buf[0] = max(steps) if steps else 0.0
+        self._step_dev = self._step_buf[0]
         self._lr_host = float(self.param_groups[0]["lr"])
         self._lr_dev = torch.full((), self._lr_host, dtype=torch.float32, device=dev)
         # merge parameters whose storage AND gradient storage are adjacent

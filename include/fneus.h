@@ -513,8 +513,10 @@ int fneus_composite_bwd(const float* rays_o, const float* rays_d, const float* m
                         const float* background_rgb /*as in the forward: a constant*/, int background_rows, fneus_stream_t stream);
 
 /* ---- optimiser: torch.optim.Adam.step() over the whole model in one launch (exp_runner.py:108, 179-181) ---------- */
-/* segs: HOST array of contiguous parameter runs (32 per launch).  lr and step are device scalars (step is incremented first,
- * then used for the bias corrections); no weight decay, no amsgrad.  zero_grad != 0 clears each gradient after use. */
+/* segs: HOST array of contiguous parameter runs (32 per launch).  lr: device scalar.  step: device float[2] -- [0] the steps
+ * taken so far (this update uses step[0] + 1 for the bias corrections and leaves it there), [1] scratch of the launch, zero
+ * between calls (round 5: the increment was a launch of its own).  No weight decay, no amsgrad.  zero_grad != 0 clears each
+ * gradient after use. */
 int fneus_adam(const FneusAdamSegment* segs, int n_segs, const float* lr, float* step, double beta1, double beta2,
                double eps, int zero_grad, fneus_stream_t stream);
 
