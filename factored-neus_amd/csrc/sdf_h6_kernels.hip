@@ -73,8 +73,9 @@ __global__ void __launch_bounds__(64) h6_pack_kernel(const unsigned char* __rest
 // What a pass needs before its first MFMA is requested by the pass before it:
 //   * the bias: loaded straight into accV[.][0] -- the NEXT pass's accumulators of its first sample tile -- once this pass's vector
 //     work is through with them (half way); the next pass copies it to its second sample tile.  No registers of its own;
-//   * the first block's hi fragments in the hi buffer this pass's last block did not use (START: which one -- the passes of a
-//     unit have 1 1 4 4 4 4 4 4 5 5 4 .. blocks), its fp6 weights in the one fp6 buffer, requested behind the last fp6 MFMA.
+//   * its first three k-steps of fp16 hi fragments: the ring H6Whi runs on across passes (PH = ring position of a pass's k-step 0:
+//     the passes of a unit have 3 3 16 .. 16 17 17 16 .. 16 k-steps = 232 = 0 mod 4, so PH is a compile-time constant per pass);
+//   * the fp6 weights of its first block in the one fp6 buffer, requested behind this pass's last fp6 MFMA.
 struct H6Next {
     uint32_t off_hi, off_rec, off_bias;
 };
@@ -442,10 +443,10 @@ __global__ void __launch_bounds__(256, 1) sdf_fwd_h6_kernel(const unsigned char*
 #define H6_DUMP_LAYER(IDX)
 #endif
     // pass A: MFMAs of sample tiles {0, 1} (accA) || vector work on accB; pass B the other way round
-#define H6_A(KIND, NT, NKIND, NNT, ACT, START, M7, L_, NX, TNV) \
-    h6_pass<KIND, NT, NKIND, NNT, ACT, START, 0, M7>(brsrc, rsrc, HY.L[L_].hi, HY.L[L_].rec, wr, wq, NX, tile16, ln, wave, accA, accB, TNV, cw, dot)
-#define H6_B(KIND, NT, NKIND, NNT, ACT, START, M7, L_, NX, TNV) \
-    h6_pass<KIND, NT, NKIND, NNT, ACT, START, 2, M7>(brsrc, rsrc, HY.L[L_].hi, HY.L[L_].rec, wr, wq, NX, tile16, ln, wave, accB, accA, TNV, cw, dot)
+#define H6_A(KIND, NT, NKIND, NNT, ACT, PH, M7, L_, NX, TNV) \
+    h6_pass<KIND, NT, NKIND, NNT, ACT, PH, 0, M7>(brsrc, rsrc, HY.L[L_].hi, HY.L[L_].rec, wr, wq, NX, tile16, ln, wave, accA, accB, TNV, cw, dot)
+#define H6_B(KIND, NT, NKIND, NNT, ACT, PH, M7, L_, NX, TNV) \
+    h6_pass<KIND, NT, NKIND, NNT, ACT, PH, 2, M7>(brsrc, rsrc, HY.L[L_].hi, HY.L[L_].rec, wr, wq, NX, tile16, ln, wave, accB, accA, TNV, cw, dot)
     for (long pos = blockIdx.x; pos < units; pos += gridDim.x) {
         const long unit = U(pos);
         asm volatile("" : "+s"(blob), "+s"(hblob));
@@ -518,6 +519,10 @@ extern "C" size_t fneus_h6_blob_bytes(void) { return fneus::kH6Layout.total; }
 extern "C" int fneus_h6_pack(const void* blob, void* hblob, fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     fneus::clear_status();
+    if (!blob || !hblob) {
+        fneus::set_last_error("fneus_h6_pack: blob and hblob must be given");
+        return -2;
+    }
     int units = 0;
     for (int l = 0; l < 8; ++l) units += (l == 0 ? 1 : (l == 4 ? 5 : 4)) * fneus::kSdfGeom[l].ntf;
     hipLaunchKernelGGL(fneus::h6_pack_kernel, dim3(units), dim3(64), 0, stream, reinterpret_cast<const unsigned char*>(blob),
@@ -537,6 +542,10 @@ extern "C" int fneus_sdf_fwd_h6(const void* blob, const void* hblob, const float
     hipStream_t stream = (hipStream_t)stream_;
     fneus::clear_status();
     if (n_pts <= 0) return 0;
+    if (!blob || !hblob || !sdf_out || (!pts && (!rays_o || !rays_d || !t))) {
+        fneus::set_last_error("fneus_sdf_fwd_h6: blob, hblob, sdf_out and either pts or (rays_o, rays_d, t) must be given");
+        return -2;
+    }
     if (ray_mask && (pts || !work || m <= 0 || m % 128 != 0)) {
         fneus::set_last_error("fneus_sdf_fwd_h6: a ray mask needs the ray form with m = k x 128 samples per ray and the work buffer");
         return -2;
