@@ -54,6 +54,11 @@ class FneusWnTask(C.Structure):
                 ("rowscale", C.c_void_p), ("invnorm", C.c_void_p), ("d_eff", C.c_void_p), ("d_raw", C.c_void_p)]
 
 
+class FneusMlpJob(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("x", "weight", "bias", "y", "dy", "dx", "d_weight", "d_bias")] + \
+               [(n, C.c_int) for n in ("rows", "n_in", "n_out", "act", "act_in")]
+
+
 class FneusGemmPPJob(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("a_hi", "a_lo", "b_hi", "b_lo", "a2_hi", "a2_lo", "b2_hi", "b2_lo")] + \
                [(n, C.c_uint32) for n in ("a_blk", "b_blk", "a2_blk", "b2_blk")] + \
@@ -133,6 +138,9 @@ def _load():
         "fneus_sg_render_fwd": (C.c_int, [vp] * 6 + [ip, ip, ip, f, vp, vp]),
         "fneus_sg_render_bwd": (C.c_int, [vp] * 6 + [ip, ip, ip, f, vp, vp, vp, vp]),
         "fneus_embed": (C.c_int, [vp, l, ip, ip, vp, vp]),
+        "fneus_mlp_forward": (C.c_int, [C.POINTER(FneusMlpJob), ip, vp]),
+        "fneus_mlp_backward_input": (C.c_int, [C.POINTER(FneusMlpJob), ip, vp]),
+        "fneus_mlp_backward_params": (C.c_int, [C.POINTER(FneusMlpJob), ip, vp]),
         "fneus_h6_blob_bytes": (C.c_size_t, []),
         "fneus_h6_pack": (C.c_int, [vp, vp, vp]),
         "fneus_sdf_fwd_h6": (C.c_int, [vp, vp, vp, vp, vp, vp, ip, l, vp, f, vp, vp, vp]),

@@ -1025,6 +1025,42 @@ def indir_illum_bwd(raw, dirs, d_rad):
     return d_raw
 
 
+# ---- the trained plain MLPs of stages 2 / 3 on a few hundred rows (fneus_mlp_*: csrc/mlp_rows_kernels.hip) -------------------------
+ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_SIGMOID = 0, 1, 2, 3
+MLP_MAX_JOBS = 16
+# FNEUS_MLP_ROWS=0: the stage-2 / 3 modules keep torch's nn.Sequential (rocBLAS GEMMs + element-wise launches), for A/B runs
+MLP_ROWS = os.environ.get("FNEUS_MLP_ROWS", "1") != "0"
+
+
+def _mlp_jobs(jobs):
+    from ._lib import FneusMlpJob
+    arr = (FneusMlpJob * len(jobs))()
+    for a, j in zip(arr, jobs):
+        for k in ("x", "weight", "bias", "y", "dy", "dx", "d_weight", "d_bias"):
+            t = j.get(k)
+            if t is not None:
+                _chk_f32(t, f"fneus_mlp: {k}")
+                setattr(a, k, t.data_ptr())
+        a.rows, a.n_in, a.n_out = int(j["rows"]), int(j["n_in"]), int(j["n_out"])
+        a.act, a.act_in = int(j.get("act", 0)), int(j.get("act_in", 0))
+    return arr
+
+
+def mlp_forward(jobs):
+    """one launch: y = act(x W^T + b) for every job (dicts with the fields of FneusMlpJob, include/fneus.h)"""
+    _launch("fneus_mlp_forward", lib.fneus_mlp_forward, _mlp_jobs(jobs), len(jobs), _stream())
+
+
+def mlp_backward_input(jobs):
+    """one launch: dx = ((dy * act'(y)) W) * act_in'(x) for every job"""
+    _launch("fneus_mlp_backward_input", lib.fneus_mlp_backward_input, _mlp_jobs(jobs), len(jobs), _stream())
+
+
+def mlp_backward_params(jobs):
+    """one launch: d_weight = (dy * act'(y))^T x and d_bias = its column sums for every job (both overwritten)"""
+    _launch("fneus_mlp_backward_params", lib.fneus_mlp_backward_params, _mlp_jobs(jobs), len(jobs), _stream())
+
+
 def outside_z(rays_o, rays_d, n_outside: int, n_samples: int, far=None, u=None):
     """z_vals_outside of NeuSRenderer.render (renderer.py:397-400, 411-419) -> [B, n_outside]; far [B] or None (unit-sphere bound
     of the rays), u [B, n_outside] uniform draws or None (no jitter)"""

@@ -508,14 +508,120 @@ class _DirectLinearFn(torch.autograd.Function):
         return dx, None, None
 
 
+def _mlp_spec(seq):
+    """[(Linear, activation code)] of an nn.Sequential of nn.Linear layers each followed by at most one of ReLU /
+    LeakyReLU(0.2) / Sigmoid (what fneus_mlp_* evaluates), else None"""
+    layers = []
+    for m in seq:
+        if isinstance(m, nn.Linear):
+            layers.append([m, ops.ACT_NONE])
+        elif not layers or layers[-1][1] != ops.ACT_NONE:
+            return None
+        elif isinstance(m, nn.ReLU):
+            layers[-1][1] = ops.ACT_RELU
+        elif isinstance(m, nn.LeakyReLU) and abs(m.negative_slope - 0.2) < 1e-12:
+            layers[-1][1] = ops.ACT_LEAKY02
+        elif isinstance(m, nn.Sigmoid):
+            layers[-1][1] = ops.ACT_SIGMOID
+        else:
+            return None
+    return layers or None
+
+
+class _SeqMlpFn(torch.autograd.Function):
+    """An nn.Sequential of Linear + activation layers on the fneus_mlp_* kernels (csrc/mlp_rows_kernels.hip): one launch per
+    layer forward, one per layer for the input gradients, ONE for every weight and bias gradient of the network -- through torch
+    a GEMM per Linear and direction, an element-wise launch per activation and direction and a reduction per bias gradient.
+    direct: the parameter gradients are written STRAIGHT into the parameters' persistent `.grad` buffers (overwritten) and autograd
+    gets none for them -- the stage-2 / 3 trainers' gradient arena, see _DirectLinearFn; otherwise they are returned to autograd.
+    args: x [..., n_in], acts (tuple of activation codes), direct, then weight, bias per layer (bias may be None)."""
+
+    @staticmethod
+    def forward(ctx, x, acts, direct, *wb):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        rows = x2.shape[0]
+        ys, inp = [], x2
+        for l, act in enumerate(acts):
+            w, b = wb[2 * l], wb[2 * l + 1]
+            y = torch.empty(rows, w.shape[0], dtype=torch.float32, device=x.device)
+            if rows:
+                ops.mlp_forward([dict(x=inp, weight=w.detach(), bias=None if b is None else b.detach(), y=y, rows=rows,
+                                      n_in=w.shape[1], n_out=w.shape[0], act=act)])
+            ys.append(y)
+            inp = y
+        ctx.save_for_backward(x2, *ys)
+        ctx.acts, ctx.direct, ctx.wb, ctx.x_shape = acts, direct, wb, x.shape
+        return ys[-1].reshape(*x.shape[:-1], ys[-1].shape[-1])
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, *ys = ctx.saved_tensors
+        acts, wb, L, rows = ctx.acts, ctx.wb, len(ctx.acts), x2.shape[0]
+        grads = [None] * (2 * L)
+        if rows == 0:
+            for l in range(L):
+                for q, p in enumerate((wb[2 * l], wb[2 * l + 1])):
+                    if p is not None and ctx.needs_input_grad[3 + 2 * l + q]:
+                        if ctx.direct:
+                            p.grad.zero_()
+                        else:
+                            grads[2 * l + q] = torch.zeros_like(p)
+            return (torch.zeros(ctx.x_shape, device=x2.device) if ctx.needs_input_grad[0] else None, None, None, *grads)
+        delta = [None] * L
+        delta[L - 1] = dout.reshape(rows, -1).contiguous()
+        top = lambda l: acts[l] if l == L - 1 else ops.ACT_NONE       # below the top layer dy is the pre-activation's gradient
+        dx0 = None
+        for l in range(L - 1, -1, -1):
+            if l == 0 and not ctx.needs_input_grad[0]:
+                break
+            w = wb[2 * l].detach()
+            dx = torch.empty(rows, w.shape[1], dtype=torch.float32, device=x2.device)
+            ops.mlp_backward_input([dict(dy=delta[l], y=ys[l] if top(l) else None, weight=w, x=ys[l - 1] if l else None, dx=dx,
+                                         rows=rows, n_in=w.shape[1], n_out=w.shape[0], act=top(l), act_in=acts[l - 1] if l else 0)])
+            if l:
+                delta[l - 1] = dx
+            else:
+                dx0 = dx.reshape(ctx.x_shape)
+        jobs = []
+        for l in range(L):
+            w, b = wb[2 * l], wb[2 * l + 1]
+            need_w, need_b = ctx.needs_input_grad[3 + 2 * l], b is not None and ctx.needs_input_grad[4 + 2 * l]
+            if not (need_w or need_b):
+                continue
+            if ctx.direct:
+                dw, db = w.grad, (b.grad if need_b else None)
+            else:
+                dw = torch.empty_like(w, memory_format=torch.contiguous_format)
+                db = torch.empty_like(b) if need_b else None
+                grads[2 * l], grads[2 * l + 1] = (dw if need_w else None), db
+            jobs.append(dict(dy=delta[l], y=ys[l] if top(l) else None, x=ys[l - 1] if l else x2, d_weight=dw, d_bias=db, rows=rows,
+                             n_in=w.shape[1], n_out=w.shape[0], act=top(l)))
+        for i in range(0, len(jobs), ops.MLP_MAX_JOBS):
+            ops.mlp_backward_params(jobs[i:i + ops.MLP_MAX_JOBS])
+        return (dx0, None, None, *grads)
+
+
 def _seq_direct(seq, x, owner):
-    """run an nn.Sequential; its Linear layers through _DirectLinearFn when the owner asks for it (`owner.direct_grads`, set by
-    the trainers that keep persistent gradient buffers) and the buffers exist"""
-    if not getattr(owner, "direct_grads", False) or not torch.is_grad_enabled():
+    """run an nn.Sequential of Linear + activation layers.  On the GPU: the fneus_mlp_* kernels (_SeqMlpFn; FNEUS_MLP_ROWS=0 keeps
+    torch's modules), the parameter gradients written straight into persistent `.grad` buffers when the owner asks for it
+    (`owner.direct_grads`, set by the trainers that keep a gradient arena, for the duration of their own steps) and every
+    buffer exists.  Otherwise the plain modules, Linear layers through _DirectLinearFn under the same condition."""
+    want_direct = getattr(owner, "direct_grads", False) and torch.is_grad_enabled()
+
+    def has_buffers(m):
+        return m.weight.requires_grad and m.weight.grad is not None and m.bias is not None and m.bias.grad is not None \
+            and m.weight.grad.is_contiguous()
+
+    if ops.MLP_ROWS and x.is_cuda and x.dtype == torch.float32:
+        spec = _mlp_spec(seq)
+        if spec is not None and all(m.weight.dtype == torch.float32 and m.weight.is_contiguous() for m, _ in spec):
+            direct = bool(want_direct) and all(has_buffers(m) for m, _ in spec)
+            wb = [p for m, _ in spec for p in (m.weight, m.bias)]
+            return _SeqMlpFn.apply(x, tuple(a for _, a in spec), direct, *wb)
+    if not want_direct:
         return seq(x)
     for m in seq:
-        if isinstance(m, nn.Linear) and m.weight.requires_grad and m.weight.grad is not None and m.bias is not None \
-                and m.bias.grad is not None and m.weight.grad.is_contiguous():
+        if isinstance(m, nn.Linear) and has_buffers(m):
             x = _DirectLinearFn.apply(x, m.weight, m.bias)
         else:
             x = m(x)

@@ -386,6 +386,32 @@ int fneus_indir_illum_fwd(const float* raw, const float* dirs, int n, int n_lobe
 int fneus_indir_illum_bwd(const float* raw, const float* dirs, const float* d_radiance /*[n][S][3]*/, int n, int n_lobes,
                           int n_dirs, float* d_raw /*[n][L][6]*/, fneus_stream_t stream);
 
+/* ---- stages 2 / 3: the TRAINED plain MLPs on a few hundred rows -- Lvis and IndirectLight (models/fields.py:338-413: nn.Linear +
+ * ReLU, Lvis ends in a sigmoid), the BRDF auto-encoder and net_cs of EnvmapMaterialNetwork (models/inverRender.py:451-598:
+ * nn.Linear + LeakyReLU(0.2), net_cs ends in a sigmoid).  Replaces torch's per-Linear GEMM + activation + bias-gradient launches:
+ * one launch per layer and direction, one for ALL weight / bias gradients of the listed layers.  fp32 products and sums
+ * (fp32 MFMA), bit-reproducible.  Every array row-major fp32; the jobs of one call are independent of each other (a call = one
+ * launch of up to 16 jobs: the same layer index of several networks, or all layers of a network for the parameter gradients).
+ * act / act_in: 0 none, 1 ReLU, 2 LeakyReLU(0.2), 3 sigmoid. */
+typedef struct FneusMlpJob {
+    const float* x;        /* [rows][n_in] the layer's input (the previous layer's output) */
+    const float* weight;   /* [n_out][n_in] nn.Linear.weight */
+    const float* bias;     /* [n_out] or NULL */
+    float* y;              /* [rows][n_out] the layer's output act(x W^T + b) */
+    const float* dy;       /* backward: [rows][n_out] gradient of y if act != 0 (act'(y) is applied while it is loaded), of the
+                              pre-activation if act == 0 (what fneus_mlp_backward_input of the layer above has written) */
+    float* dx;             /* backward_input: [rows][n_in] gradient of the PRE-activation of the layer below (act_in' from x
+                              applied); with act_in == 0 the gradient of x itself */
+    float* d_weight;       /* backward_params: [n_out][n_in], OVERWRITTEN */
+    float* d_bias;         /* backward_params: [n_out], OVERWRITTEN; NULL = not wanted */
+    int rows, n_in, n_out;
+    int act;               /* this layer's activation (see dy) */
+    int act_in;            /* the activation that produced x (backward_input) */
+} FneusMlpJob;
+int fneus_mlp_forward(const FneusMlpJob* layers /*host array*/, int n_layers, fneus_stream_t stream);          /* x, weight, bias -> y */
+int fneus_mlp_backward_input(const FneusMlpJob* layers /*host array*/, int n_layers, fneus_stream_t stream);   /* dy (y), weight, x -> dx */
+int fneus_mlp_backward_params(const FneusMlpJob* layers /*host array*/, int n_layers, fneus_stream_t stream);  /* dy (y), x -> d_weight, d_bias */
+
 /* lvis_blob: fneus_pack output for layout 3 (the Lvis network, fields.py:338-369, plain Linear layers).  points, normals
  * [n_pts][3] (unit normals); dirs [n_lobes][32][3]: the sampled directions around every light lobe (inverRender.py:158-161);
  * weights [n_lobes][32] = exp(lambda (d . axis - 1)) (:186).  vis [n_lobes][n_pts] = sum_s [n . d_s > 1e-6] Lvis(p, d_s) w_s /
