@@ -131,10 +131,20 @@ def cal_indiLgt(surf, normal, sdf_network, deviation_network, color_network, lvi
         occu, hit_rgb, _ = _secondary_march(origins, dirs, sdf_network, color_network, inv_s, trace, ray_mask=ray_mask)
         gt_lvis = (1.0 - occu).reshape(n, nsamp)
         gt_trace_radiance = hit_rgb.reshape(n, nsamp, 3)
-    pre_lvis = lvis_network(origins, dirs).reshape(n, nsamp)
-    if surf.is_cuda and hasattr(indiLgt_network, "radiance") and indiLgt_network.num_lgt_sgs <= 64:
+    if surf.is_cuda and hasattr(indiLgt_network, "radiance_from_raw") and indiLgt_network.num_lgt_sgs <= 64 \
+            and hasattr(lvis_network, "mlp_input"):
+        # the two networks layer by layer in the same launches (models/fields.py seq_group), then the lobes' output transform and
+        # query_indir_illum in one launch (IndirectLight.radiance)
+        from models.fields import seq_group
+        pre_lvis, raw = seq_group([(lvis_network.lvis, lvis_network.mlp_input(origins, dirs), lvis_network),
+                                   (indiLgt_network.indi, indiLgt_network.embedview_fn_pts(surf), indiLgt_network)])
+        pre_lvis = pre_lvis.reshape(n, nsamp)
+        pre_trace_radiance = indiLgt_network.radiance_from_raw(raw, dirs.reshape(n, nsamp, 3))
+    elif surf.is_cuda and hasattr(indiLgt_network, "radiance") and indiLgt_network.num_lgt_sgs <= 64:
+        pre_lvis = lvis_network(origins, dirs).reshape(n, nsamp)
         pre_trace_radiance = indiLgt_network.radiance(surf, dirs.reshape(n, nsamp, 3))       # the two lines below, fused
     else:
+        pre_lvis = lvis_network(origins, dirs).reshape(n, nsamp)
         pre_trace_radiance = query_indir_illum(indiLgt_network(surf), dirs.reshape(n, nsamp, 3))
     if trace is not None:
         trace.update(dirs=dirs.reshape(n, nsamp, 3))

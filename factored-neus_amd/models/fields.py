@@ -528,104 +528,142 @@ def _mlp_spec(seq):
     return layers or None
 
 
-class _SeqMlpFn(torch.autograd.Function):
-    """An nn.Sequential of Linear + activation layers on the fneus_mlp_* kernels (csrc/mlp_rows_kernels.hip): one launch per
-    layer forward, one per layer for the input gradients, ONE for every weight and bias gradient of the network -- through torch
-    a GEMM per Linear and direction, an element-wise launch per activation and direction and a reduction per bias gradient.
-    direct: the parameter gradients are written STRAIGHT into the parameters' persistent `.grad` buffers (overwritten) and autograd
-    gets none for them -- the stage-2 / 3 trainers' gradient arena, see _DirectLinearFn; otherwise they are returned to autograd.
-    args: x [..., n_in], acts (tuple of activation codes), direct, then weight, bias per layer (bias may be None)."""
+class _MlpGroupFn(torch.autograd.Function):
+    """Independent nn.Sequential MLPs of Linear + activation layers IN LOCKSTEP on the fneus_mlp_* kernels
+    (csrc/mlp_rows_kernels.hip): layer p of every network is ONE launch forward, one for the input gradients, and every weight and
+    bias gradient of all of them one launch (16 layers per launch) -- through torch a GEMM per Linear and direction, an
+    element-wise launch per activation and direction and a reduction per bias gradient, per network.
+    args: nets = ((activation codes, direct), ...), then per network x [..., n_in] and weight, bias per layer (bias may be None).
+    direct: that network's parameter gradients are written STRAIGHT into the parameters' persistent `.grad` buffers (overwritten) and
+    autograd gets none for them -- the stage-2 / 3 trainers' gradient arena, see _DirectLinearFn.  -> one output per network."""
 
     @staticmethod
-    def forward(ctx, x, acts, direct, *wb):
-        x2 = x.reshape(-1, x.shape[-1]).contiguous()
-        rows = x2.shape[0]
-        ys, inp = [], x2
-        for l, act in enumerate(acts):
-            w, b = wb[2 * l], wb[2 * l + 1]
-            y = torch.empty(rows, w.shape[0], dtype=torch.float32, device=x.device)
-            if rows:
-                ops.mlp_forward([dict(x=inp, weight=w.detach(), bias=None if b is None else b.detach(), y=y, rows=rows,
-                                      n_in=w.shape[1], n_out=w.shape[0], act=act)])
-            ys.append(y)
-            inp = y
-        ctx.save_for_backward(x2, *ys)
-        ctx.acts, ctx.direct, ctx.wb, ctx.x_shape = acts, direct, wb, x.shape
-        return ys[-1].reshape(*x.shape[:-1], ys[-1].shape[-1])
+    def _split(nets, tensors):
+        pos, out = 0, []
+        for acts, _ in nets:
+            out.append((pos, tensors[pos], tensors[pos + 1:pos + 1 + 2 * len(acts)]))
+            pos += 1 + 2 * len(acts)
+        return out
 
     @staticmethod
-    def backward(ctx, dout):
-        x2, *ys = ctx.saved_tensors
-        acts, wb, L, rows = ctx.acts, ctx.wb, len(ctx.acts), x2.shape[0]
-        grads = [None] * (2 * L)
-        if rows == 0:
-            for l in range(L):
-                for q, p in enumerate((wb[2 * l], wb[2 * l + 1])):
-                    if p is not None and ctx.needs_input_grad[3 + 2 * l + q]:
-                        if ctx.direct:
-                            p.grad.zero_()
-                        else:
-                            grads[2 * l + q] = torch.zeros_like(p)
-            return (torch.zeros(ctx.x_shape, device=x2.device) if ctx.needs_input_grad[0] else None, None, None, *grads)
-        delta = [None] * L
-        delta[L - 1] = dout.reshape(rows, -1).contiguous()
-        top = lambda l: acts[l] if l == L - 1 else ops.ACT_NONE       # below the top layer dy is the pre-activation's gradient
-        dx0 = None
-        for l in range(L - 1, -1, -1):
-            if l == 0 and not ctx.needs_input_grad[0]:
-                break
-            w = wb[2 * l].detach()
-            dx = torch.empty(rows, w.shape[1], dtype=torch.float32, device=x2.device)
-            ops.mlp_backward_input([dict(dy=delta[l], y=ys[l] if top(l) else None, weight=w, x=ys[l - 1] if l else None, dx=dx,
-                                         rows=rows, n_in=w.shape[1], n_out=w.shape[0], act=top(l), act_in=acts[l - 1] if l else 0)])
-            if l:
-                delta[l - 1] = dx
-            else:
-                dx0 = dx.reshape(ctx.x_shape)
+    def forward(ctx, nets, *tensors):
+        parts = _MlpGroupFn._split(nets, tensors)
+        x2s = [x.reshape(-1, x.shape[-1]).contiguous() for _, x, _ in parts]
+        ys = [[] for _ in nets]
+        for p in range(max(len(acts) for acts, _ in nets)):
+            jobs = []
+            for n, ((acts, _), (_, x, wb)) in enumerate(zip(nets, parts)):
+                if p >= len(acts):
+                    continue
+                w, b = wb[2 * p], wb[2 * p + 1]
+                rows = x2s[n].shape[0]
+                y = torch.empty(rows, w.shape[0], dtype=torch.float32, device=x.device)
+                if rows:
+                    jobs.append(dict(x=ys[n][-1] if p else x2s[n], weight=w.detach(), bias=None if b is None else b.detach(), y=y,
+                                     rows=rows, n_in=w.shape[1], n_out=w.shape[0], act=acts[p]))
+                ys[n].append(y)
+            for i in range(0, len(jobs), ops.MLP_MAX_JOBS):
+                ops.mlp_forward(jobs[i:i + ops.MLP_MAX_JOBS])
+        ctx.save_for_backward(*x2s, *[y for net in ys for y in net])
+        ctx.nets, ctx.parts, ctx.shapes = nets, [(pos, wb) for pos, _, wb in parts], [x.shape for _, x, _ in parts]
+        return tuple(net[-1].reshape(*x.shape[:-1], net[-1].shape[-1]) for net, (_, x, _) in zip(ys, parts))
+
+    @staticmethod
+    def backward(ctx, *douts):
+        nets, N = ctx.nets, len(ctx.nets)
+        saved = list(ctx.saved_tensors)
+        x2s, flat, ys = saved[:N], saved[N:], []
+        for acts, _ in nets:
+            ys.append(flat[:len(acts)])
+            flat = flat[len(acts):]
+        grads = [None] * (sum(1 + 2 * len(acts) for acts, _ in nets))
+        need = lambda i: ctx.needs_input_grad[1 + i]
+        delta = [[None] * len(acts) for acts, _ in nets]
+        for n, (acts, _) in enumerate(nets):
+            delta[n][-1] = douts[n].reshape(x2s[n].shape[0], ys[n][-1].shape[1]).contiguous()
+        top = lambda n, l: nets[n][0][l] if l == len(nets[n][0]) - 1 else ops.ACT_NONE   # below the top layer dy is the pre-activation's gradient
+        # input gradients, top layers first: step t takes layer L - 1 - t of every network
+        for t in range(max(len(acts) for acts, _ in nets)):
+            jobs, outs = [], []
+            for n, (acts, _) in enumerate(nets):
+                l = len(acts) - 1 - t
+                pos, wb = ctx.parts[n]
+                rows = x2s[n].shape[0]
+                if l < 0 or (l == 0 and not need(pos)):
+                    continue
+                w = wb[2 * l].detach()
+                dx = torch.empty(rows, w.shape[1], dtype=torch.float32, device=w.device)
+                if rows:
+                    jobs.append(dict(dy=delta[n][l], y=ys[n][l] if top(n, l) else None, weight=w, x=ys[n][l - 1] if l else None, dx=dx,
+                                     rows=rows, n_in=w.shape[1], n_out=w.shape[0], act=top(n, l), act_in=acts[l - 1] if l else 0))
+                if l:
+                    delta[n][l - 1] = dx
+                else:
+                    grads[pos] = dx.reshape(ctx.shapes[n])
+            for i in range(0, len(jobs), ops.MLP_MAX_JOBS):
+                ops.mlp_backward_input(jobs[i:i + ops.MLP_MAX_JOBS])
         jobs = []
-        for l in range(L):
-            w, b = wb[2 * l], wb[2 * l + 1]
-            need_w, need_b = ctx.needs_input_grad[3 + 2 * l], b is not None and ctx.needs_input_grad[4 + 2 * l]
-            if not (need_w or need_b):
-                continue
-            if ctx.direct:
-                dw, db = w.grad, (b.grad if need_b else None)
-            else:
-                dw = torch.empty_like(w, memory_format=torch.contiguous_format)
-                db = torch.empty_like(b) if need_b else None
-                grads[2 * l], grads[2 * l + 1] = (dw if need_w else None), db
-            jobs.append(dict(dy=delta[l], y=ys[l] if top(l) else None, x=ys[l - 1] if l else x2, d_weight=dw, d_bias=db, rows=rows,
-                             n_in=w.shape[1], n_out=w.shape[0], act=top(l)))
+        for n, (acts, direct) in enumerate(nets):
+            pos, wb = ctx.parts[n]
+            rows = x2s[n].shape[0]
+            for l in range(len(acts)):
+                w, b = wb[2 * l], wb[2 * l + 1]
+                need_w, need_b = need(pos + 1 + 2 * l), b is not None and need(pos + 2 + 2 * l)
+                if not (need_w or need_b):
+                    continue
+                if direct:
+                    dw, db = w.grad, (b.grad if need_b else None)
+                else:
+                    dw = torch.empty_like(w, memory_format=torch.contiguous_format)
+                    db = torch.empty_like(b) if need_b else None
+                    grads[pos + 1 + 2 * l], grads[pos + 2 + 2 * l] = (dw if need_w else None), db
+                if rows:
+                    jobs.append(dict(dy=delta[n][l], y=ys[n][l] if top(n, l) else None, x=ys[n][l - 1] if l else x2s[n], d_weight=dw,
+                                     d_bias=db, rows=rows, n_in=w.shape[1], n_out=w.shape[0], act=top(n, l)))
+                else:                 # no rows: the sums are empty
+                    dw.zero_()
+                    if db is not None:
+                        db.zero_()
         for i in range(0, len(jobs), ops.MLP_MAX_JOBS):
             ops.mlp_backward_params(jobs[i:i + ops.MLP_MAX_JOBS])
-        return (dx0, None, None, *grads)
+        return (None, *grads)
 
 
-def _seq_direct(seq, x, owner):
-    """run an nn.Sequential of Linear + activation layers.  On the GPU: the fneus_mlp_* kernels (_SeqMlpFn; FNEUS_MLP_ROWS=0 keeps
-    torch's modules), the parameter gradients written straight into persistent `.grad` buffers when the owner asks for it
-    (`owner.direct_grads`, set by the trainers that keep a gradient arena, for the duration of their own steps) and every
-    buffer exists.  Otherwise the plain modules, Linear layers through _DirectLinearFn under the same condition."""
-    want_direct = getattr(owner, "direct_grads", False) and torch.is_grad_enabled()
-
+def seq_group(items):
+    """[(nn.Sequential, x, owner), ...] -> [outputs]: independent MLPs of Linear + activation layers evaluated in lockstep.  On the
+    GPU: the fneus_mlp_* kernels (_MlpGroupFn; FNEUS_MLP_ROWS=0 keeps torch's modules), a network's parameter gradients written
+    straight into persistent `.grad` buffers when its owner asks for it (`owner.direct_grads`, set by the trainers that keep a
+    gradient arena, for the duration of their own steps) and every buffer exists.  Networks the kernels do not take (another
+    activation, another dtype, the CPU) run as the plain modules, Linear layers through _DirectLinearFn under the same condition."""
     def has_buffers(m):
         return m.weight.requires_grad and m.weight.grad is not None and m.bias is not None and m.bias.grad is not None \
             and m.weight.grad.is_contiguous()
 
-    if ops.MLP_ROWS and x.is_cuda and x.dtype == torch.float32:
-        spec = _mlp_spec(seq)
+    results = [None] * len(items)
+    nets, tensors, where = [], [], []
+    for idx, (seq, x, owner) in enumerate(items):
+        want_direct = getattr(owner, "direct_grads", False) and torch.is_grad_enabled()
+        spec = _mlp_spec(seq) if (ops.MLP_ROWS and x.is_cuda and x.dtype == torch.float32) else None
         if spec is not None and all(m.weight.dtype == torch.float32 and m.weight.is_contiguous() for m, _ in spec):
             direct = bool(want_direct) and all(has_buffers(m) for m, _ in spec)
-            wb = [p for m, _ in spec for p in (m.weight, m.bias)]
-            return _SeqMlpFn.apply(x, tuple(a for _, a in spec), direct, *wb)
-    if not want_direct:
-        return seq(x)
-    for m in seq:
-        if isinstance(m, nn.Linear) and has_buffers(m):
-            x = _DirectLinearFn.apply(x, m.weight, m.bias)
+            nets.append((tuple(a for _, a in spec), direct))
+            tensors += [x] + [p for m, _ in spec for p in (m.weight, m.bias)]
+            where.append(idx)
+        elif not want_direct:
+            results[idx] = seq(x)
         else:
-            x = m(x)
-    return x
+            for m in seq:
+                x = _DirectLinearFn.apply(x, m.weight, m.bias) if isinstance(m, nn.Linear) and has_buffers(m) else m(x)
+            results[idx] = x
+    if nets:
+        for idx, y in zip(where, _MlpGroupFn.apply(tuple(nets), *tensors)):
+            results[idx] = y
+    return results
+
+
+def _seq_direct(seq, x, owner):
+    """one nn.Sequential through seq_group"""
+    return seq_group([(seq, x, owner)])[0]
 
 
 class Lvis(nn.Module):
@@ -642,8 +680,11 @@ class Lvis(nn.Module):
                                   nn.Linear(256, 256), nn.ReLU(), nn.Linear(256, 256), nn.ReLU(), nn.Linear(256, 1),
                                   nn.Sigmoid())
 
+    def mlp_input(self, pts, view):
+        return torch.cat([self.embedview_fn_pts(pts), self.embedview_fn_view(view)], dim=-1)
+
     def forward(self, pts, view):
-        return _seq_direct(self.lvis, torch.cat([self.embedview_fn_pts(pts), self.embedview_fn_view(view)], dim=-1), self)
+        return _seq_direct(self.lvis, self.mlp_input(pts, view), self)
 
     def visibility(self, points, normals, dirs, weights, point_mask=None):
         """get_diffuse_visibility's network part (inverRender.py:163-190), no gradient: for every surface point the network
@@ -715,7 +756,11 @@ class IndirectLight(nn.Module):
     def radiance(self, pts, sample_dirs):
         """query_indir_illum(self(pts), sample_dirs) (calLvis.py:323-336) [n, S, 3] without materialising the lobes: the output
         transform below and the sum of spherical Gaussians in one launch forward, one backward (fneus_indir_illum_fwd / _bwd)"""
-        raw = _seq_direct(self.indi, self.embedview_fn_pts(pts), self).reshape(-1, self.num_lgt_sgs, 6)
+        return self.radiance_from_raw(_seq_direct(self.indi, self.embedview_fn_pts(pts), self), sample_dirs)
+
+    def radiance_from_raw(self, raw, sample_dirs):
+        """raw: the MLP's output [n, 6 L] (`self.indi` on `self.embedview_fn_pts(pts)`)"""
+        raw = raw.reshape(-1, self.num_lgt_sgs, 6)
         return _IndirIllumFn.apply(raw.contiguous(), sample_dirs.detach().float().contiguous())
 
     def forward(self, pts):

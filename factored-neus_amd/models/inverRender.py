@@ -20,7 +20,7 @@ import torch.nn.functional as F
 
 from fneus import ops
 from models.embedder import get_embedder
-from models.fields import _seq_direct
+from models.fields import _seq_direct, seq_group
 
 TINY_NUMBER = 1e-6
 
@@ -338,12 +338,14 @@ class EnvmapMaterialNetwork(nn.Module):
         pts_enc = self.embed_pts_fn(points)
         # (_seq_direct: inside Stage3Trainer's own steps the Linear layers write dW / db straight into their persistent gradient
         # buffers, models/fields.py _DirectLinearFn; otherwise these are the plain nn.Sequential calls)
-        latent = _seq_direct(self.brdf_encoder_layer, self.brdf_embed_fn(points), self)
+        # (the encoder and net_cs have their inputs now: layer by layer in the same launches, models/fields.py seq_group)
+        latent, cs = seq_group([(self.brdf_encoder_layer, self.brdf_embed_fn(points), self),
+                                (self.net_cs, torch.cat([pts_enc, self.embed_view_fn(ref_dirs)], dim=-1), self)])
         brdf = torch.sigmoid(_seq_direct(self.brdf_decoder_layer, torch.sigmoid(latent), self))
         diffuse_albedo, rough_raw = torch.split(brdf, [3, 1], dim=-1)      # (split: its backward is one concatenation)
         roughness = rough_raw * 0.9 + 0.09
         loss = 0.01 * self.kl_divergence(0.05, latent, point_mask)
-        specular_albedo = _seq_direct(self.net_cs, torch.cat([pts_enc, self.embed_view_fn(ref_dirs)], dim=-1), self).expand(-1, 3)
+        specular_albedo = cs.expand(-1, 3)
         ret = render_with_all_sg(points, n, view_dirs, self.lgtSGs, self.specular_reflectance, specular_albedo, roughness,
                                  diffuse_albedo, gt_specular_linear, lvis_network=lvis_network, indir_lgtSGs=indiLgt,
                                  u_theta=u_theta, u_phi=u_phi, specular_reflectance_value=self.specular_reflectance_value,

@@ -132,6 +132,33 @@ def test_mlp_rows_reproducible_and_no_rows():
     assert torch.equal(y, a[0])
 
 
+def test_mlp_group_equals_one_by_one():
+    """networks of different depth and row count in lockstep (stage 2: Lvis + IndirectLight; stage 3: BRDF encoder + net_cs):
+    the same launches' arithmetic, bit for bit, as each network on its own"""
+    torch.manual_seed(11)
+    from models import fields
+    owner = _Owner()
+    kinds = [("lvis", 2048), ("indi", 512), ("brdf_dec", 300), ("one", 0)]
+    seqs = [_net(k).cuda() for k, _ in kinds]
+    xs = [torch.randn(r, s[0].in_features, device="cuda") for (_, r), s in zip(kinds, seqs)]
+    xs[2].requires_grad_(True)
+    single = []
+    for s, x in zip(seqs, xs):
+        y = fields._seq_direct(s, x, owner)
+        y.square().sum().backward()
+        single.append((y.detach(), [p.grad.clone() for p in s.parameters()], None if x.grad is None else x.grad.clone()))
+        for p in s.parameters():
+            p.grad = None
+        x.grad = None
+    ys = fields.seq_group([(s, x, owner) for s, x in zip(seqs, xs)])
+    sum(y.square().sum() for y in ys).backward()
+    for (y1, g1, dx1), y, s, x in zip(single, ys, seqs, xs):
+        assert torch.equal(y1, y.detach())
+        for a, p in zip(g1, s.parameters()):
+            assert torch.equal(a, p.grad)
+        assert (dx1 is None) == (x.grad is None) and (dx1 is None or torch.equal(dx1, x.grad))
+
+
 def test_mlp_rows_rejects_missing_arguments():
     from fneus import ops
     w = torch.randn(4, 8, device="cuda")
