@@ -201,15 +201,17 @@ __global__ void __launch_bounds__(256) srgb_bwd_kernel(const float* __restrict__
 // column sums over the points in a fixed order (thread t sums rows t, t + 32, ... of column t & 31; then a tree over the 32 row
 // groups).  stats [34]: rho_hat [32], the number of marked points, kl -- saved for the backward.
 constexpr int kKlDim = 32;
+// activated != 0: `latent` holds sigmoid(latent) already (the encoder's last layer applied it: fneus_mlp_forward, act 3)
 __global__ void __launch_bounds__(1024) latent_kl_fwd_kernel(const float* __restrict__ latent, const unsigned char* __restrict__ mask,
-                                                             int n, float rho, float* __restrict__ stats) {
+                                                             int n, float rho, int activated, float* __restrict__ stats) {
     __shared__ float part[32][kKlDim + 1];
     __shared__ float cnts[32];
     const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
     float s = 0.0f, c = 0.0f;
     for (int i = grp; i < n; i += 32) {
         const float w = mask ? (mask[i] ? 1.0f : 0.0f) : 1.0f;
-        s += w / (1.0f + expf(-latent[(long)i * kKlDim + col]));
+        const float x = latent[(long)i * kKlDim + col];
+        s += activated ? w * x : w / (1.0f + expf(-x));
         c += w;
     }
     part[grp][col] = s;
@@ -233,7 +235,7 @@ __global__ void __launch_bounds__(1024) latent_kl_fwd_kernel(const float* __rest
 }
 // d latent[i][j] = d_kl / 32 * (-rho / rho_hat_j + (1 - rho) / (1 - rho_hat_j)) * w_i / cnt * act (1 - act)
 __global__ void __launch_bounds__(256) latent_kl_bwd_kernel(const float* __restrict__ latent, const unsigned char* __restrict__ mask,
-                                                            int n, float rho, const float* __restrict__ stats,
+                                                            int n, float rho, int activated, const float* __restrict__ stats,
                                                             const float* __restrict__ d_kl, float* __restrict__ d_latent) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)n * kKlDim) return;
@@ -244,7 +246,7 @@ __global__ void __launch_bounds__(256) latent_kl_bwd_kernel(const float* __restr
     float g = 0.0f;
     if (cnt > 0.0f && w != 0.0f) {
         const float a = 1.0f / (1.0f + expf(-latent[idx]));
-        g = d_kl[0] * (1.0f / (float)kKlDim) * (-rho / rh + (1.0f - rho) / (1.0f - rh)) / fmaxf(cnt, 1.0f) * a * (1.0f - a);
+        g = d_kl[0] * (1.0f / (float)kKlDim) * (-rho / rh + (1.0f - rho) / (1.0f - rh)) / fmaxf(cnt, 1.0f) * (activated ? 1.0f : a * (1.0f - a));
     }
     d_latent[idx] = g;
 }
@@ -400,21 +402,21 @@ extern "C" int fneus_stage3_loss(const float* rgb, const float* true_rgb, const 
     return fneus::launch_status();
 }
 
-extern "C" int fneus_latent_kl_fwd(const float* latent, const unsigned char* point_mask, int n, float rho, float* stats,
+extern "C" int fneus_latent_kl_fwd(const float* latent, const unsigned char* point_mask, int n, float rho, int activated, float* stats,
                                    fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     fneus::clear_status();
     if (!latent || !stats || n <= 0 || !(rho > 0.0f && rho < 1.0f)) return -2;
-    hipLaunchKernelGGL(fneus::latent_kl_fwd_kernel, dim3(1), dim3(1024), 0, stream, latent, point_mask, n, rho, stats);
+    hipLaunchKernelGGL(fneus::latent_kl_fwd_kernel, dim3(1), dim3(1024), 0, stream, latent, point_mask, n, rho, activated, stats);
     return fneus::launch_status();
 }
-extern "C" int fneus_latent_kl_bwd(const float* latent, const unsigned char* point_mask, int n, float rho, const float* stats,
+extern "C" int fneus_latent_kl_bwd(const float* latent, const unsigned char* point_mask, int n, float rho, int activated, const float* stats,
                                    const float* d_kl, float* d_latent, fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     fneus::clear_status();
     if (!latent || !stats || !d_kl || !d_latent || n <= 0) return -2;
     hipLaunchKernelGGL(fneus::latent_kl_bwd_kernel, dim3((unsigned)(((long)n * 32 + 255) / 256)), dim3(256), 0, stream, latent, point_mask,
-                       n, rho, stats, d_kl, d_latent);
+                       n, rho, activated, stats, d_kl, d_latent);
     return fneus::launch_status();
 }
 
@@ -461,13 +463,16 @@ extern "C" int fneus_srgb_bwd(const float* x, const float* dy, long n, int mode,
 // ~45 element-wise PyTorch launches on [128, 32, 3] tensors before.  One workgroup: the minimum over the lobes is a block reduction.
 namespace fneus {
 
+// SGS: `lobes` is the light-SG table lgtSGs [M][7] itself and `lambdas` is unused -- the lobe axis sg[0..2] / (|sg[0..2]| + 1e-6) and the
+// sharpness |sg[3]| of render_with_all_sg (inverRender.py:420-421) are taken here instead of four element-wise launches before this one
+template <bool SGS>
 __global__ void __launch_bounds__(256) vis_sample_dirs_kernel(const float* __restrict__ lobes, const float* __restrict__ lambdas,
                                                               const float* __restrict__ u_theta, const float* __restrict__ u_phi, int M,
                                                               int S, float* __restrict__ dirs, float* __restrict__ w) {
     __shared__ float red[256];
     const int tid = threadIdx.x;
     float mn = 3.4e38f;
-    for (int m = tid; m < M; m += 256) mn = fminf(mn, lambdas[m]);
+    for (int m = tid; m < M; m += 256) mn = fminf(mn, SGS ? fabsf(lobes[m * 7 + 3]) : lambdas[m]);
     red[tid] = mn;
     __syncthreads();
     for (int s = 128; s >= 1; s >>= 1) {
@@ -478,7 +483,17 @@ __global__ void __launch_bounds__(256) vis_sample_dirs_kernel(const float* __res
     const float tiny = 1e-6f;
     for (int i = tid; i < M * S; i += 256) {
         const int m = i / S;
-        float ax[3] = {lobes[m * 3], lobes[m * 3 + 1], lobes[m * 3 + 2]};
+        float ax[3];
+        if constexpr (SGS) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) ax[c] = lobes[m * 7 + c];
+            const float n0 = sqrtf(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]) + tiny;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) ax[c] /= n0;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) ax[c] = lobes[m * 3 + c];
+        }
         const float na = sqrtf(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]) + tiny;
 #pragma unroll
         for (int c = 0; c < 3; ++c) ax[c] /= na;
@@ -491,7 +506,7 @@ __global__ void __launch_bounds__(256) vis_sample_dirs_kernel(const float* __res
         const float nv = sqrtf(V[0] * V[0] + V[1] * V[1] + V[2] * V[2]) + tiny;
 #pragma unroll
         for (int c = 0; c < 3; ++c) V[c] /= nv;
-        const float lam = lambdas[m];
+        const float lam = SGS ? fabsf(lobes[m * 7 + 3]) : lambdas[m];
         const float phi_range = acosf((-1.95f * lam_min) / lam + 1.0f);
         const float th = u_theta[i] * 2.0f * 3.14159265358979323846f, ph = u_phi[i] * phi_range;
         float st, ct, sp, cp;
@@ -516,8 +531,93 @@ extern "C" int fneus_vis_sample_dirs(const float* lobes, const float* lambdas, c
     fneus::clear_status();
     if (n_lobes <= 0 || n_samp <= 0) return 0;
     if (!lobes || !lambdas || !u_theta || !u_phi || !dirs || !weights) return -2;
-    hipLaunchKernelGGL(fneus::vis_sample_dirs_kernel, dim3(1), dim3(256), 0, stream, lobes, lambdas, u_theta, u_phi, n_lobes, n_samp, dirs,
-                       weights);
+    hipLaunchKernelGGL(fneus::vis_sample_dirs_kernel<false>, dim3(1), dim3(256), 0, stream, lobes, lambdas, u_theta, u_phi, n_lobes, n_samp,
+                       dirs, weights);
+    return fneus::launch_status();
+}
+extern "C" int fneus_vis_sample_dirs_sgs(const float* lgt_sgs, const float* u_theta, const float* u_phi, int n_lobes, int n_samp, float* dirs,
+                                         float* weights, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (n_lobes <= 0 || n_samp <= 0) return 0;
+    if (!lgt_sgs || !u_theta || !u_phi || !dirs || !weights) return -2;
+    hipLaunchKernelGGL(fneus::vis_sample_dirs_kernel<true>, dim3(1), dim3(256), 0, stream, lgt_sgs, (const float*)nullptr, u_theta, u_phi, n_lobes,
+                       n_samp, dirs, weights);
+    return fneus::launch_status();
+}
+
+// ---- the inputs of EnvmapMaterialNetwork's MLPs (reference models/inverRender.py:530-545) in one launch: unit normal and view direction,
+// the reflected direction, the encodings.  n = normal / (|normal| + 1e-6), v = -ray_dir / (|ray_dir| + 1e-6), r = 2 (v . n) n - v;
+// enc_pts [rows][63] = embed(point, 10) (the BRDF encoder's input), x_cs [rows][90] = [embed(point, 10) | embed(r, 4)] (net_cs's input).
+// Ten element-wise launches, three fneus_embed launches and a concatenation before.  Thread (row, j): j < 3 a point coordinate, j >= 3 a
+// coordinate of the directions.
+namespace fneus {
+__global__ void __launch_bounds__(256) material_inputs_kernel(const float* __restrict__ points, const float* __restrict__ ray_dirs,
+                                                              const float* __restrict__ normals, int n, float* __restrict__ n_unit,
+                                                              float* __restrict__ view_dirs, float* __restrict__ enc_pts,
+                                                              float* __restrict__ x_cs) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * 6) return;
+    const int row = idx / 6, j = idx - row * 6;
+    if (j < 3) {
+        const float v = points[row * 3 + j];
+        float* a = enc_pts + (size_t)row * 63;
+        float* b = x_cs + (size_t)row * 90;
+        a[j] = v;
+        b[j] = v;
+        for (int k = 0; k < 10; ++k) {
+            float s, c;
+            sincosf(__fmul_rn(v, (float)(1 << k)), &s, &c);
+            a[3 * (1 + 2 * k) + j] = s;
+            a[3 * (2 + 2 * k) + j] = c;
+            b[3 * (1 + 2 * k) + j] = s;
+            b[3 * (2 + 2 * k) + j] = c;
+        }
+        return;
+    }
+    const int c = j - 3;
+    const float tiny = 1e-6f;
+    float nr[3], rd[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        nr[q] = normals[row * 3 + q];
+        rd[q] = ray_dirs[row * 3 + q];
+    }
+    const float nn = sqrtf(nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2]) + tiny;
+    const float nd = sqrtf(rd[0] * rd[0] + rd[1] * rd[1] + rd[2] * rd[2]) + tiny;
+    float vd[3], dot = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        nr[q] = nr[q] / nn;
+        vd[q] = -(rd[q] / nd);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) dot += vd[q] * nr[q];
+    const float ref = 2.0f * dot * nr[c] - vd[c];
+    n_unit[row * 3 + c] = nr[c];
+    view_dirs[row * 3 + c] = vd[c];
+    float* b = x_cs + (size_t)row * 90 + 63;
+    b[c] = ref;
+    for (int k = 0; k < 4; ++k) {
+        float s, co;
+        sincosf(__fmul_rn(ref, (float)(1 << k)), &s, &co);
+        b[3 * (1 + 2 * k) + c] = s;
+        b[3 * (2 + 2 * k) + c] = co;
+    }
+}
+}  // namespace fneus
+
+extern "C" int fneus_material_inputs(const float* points, const float* ray_dirs, const float* normals, int n, float* n_unit,
+                                     float* view_dirs, float* enc_pts, float* x_cs, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (n <= 0) return 0;
+    if (!points || !ray_dirs || !normals || !n_unit || !view_dirs || !enc_pts || !x_cs) {
+        fneus::set_last_error("fneus_material_inputs: every array must be given");
+        return -2;
+    }
+    hipLaunchKernelGGL(fneus::material_inputs_kernel, dim3((unsigned)((n * 6 + 255) / 256)), dim3(256), 0, stream, points, ray_dirs, normals, n,
+                       n_unit, view_dirs, enc_pts, x_cs);
     return fneus::launch_status();
 }
 

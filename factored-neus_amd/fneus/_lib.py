@@ -126,8 +126,10 @@ def _load():
         "fneus_indir_illum_bwd": (C.c_int, [vp, vp, vp, ip, ip, ip, vp, vp]),
         "fneus_stage2_loss": (C.c_int, [vp, vp, vp, vp, vp, ip, vp, vp, vp, vp]),
         "fneus_stage3_loss": (C.c_int, [vp, vp, vp, vp, ip, vp, vp, vp]),
-        "fneus_latent_kl_fwd": (C.c_int, [vp, vp, ip, f, vp, vp]),
-        "fneus_latent_kl_bwd": (C.c_int, [vp, vp, ip, f, vp, vp, vp, vp]),
+        "fneus_latent_kl_fwd": (C.c_int, [vp, vp, ip, f, ip, vp, vp]),
+        "fneus_latent_kl_bwd": (C.c_int, [vp, vp, ip, f, ip, vp, vp, vp, vp]),
+        "fneus_vis_sample_dirs_sgs": (C.c_int, [vp, vp, vp, ip, ip, vp, vp, vp]),
+        "fneus_material_inputs": (C.c_int, [vp, vp, vp, ip, vp, vp, vp, vp, vp]),
         "fneus_sg_combine_fwd": (C.c_int, [vp, l, ip, vp, vp]),
         "fneus_sg_combine_bwd": (C.c_int, [vp, vp, l, ip, vp, vp]),
         "fneus_outside_select": (C.c_int, [vp, vp, vp, vp, ip, ip, ip, f, vp, vp, vp, vp, vp, vp, vp, vp, vp]),

@@ -395,18 +395,19 @@ class LatentKlFn(torch.autograd.Function):
     """fneus_latent_kl_fwd / _bwd: the latent-sparsity term of stage 3 over the marked points (inverRender.py:609-612)"""
 
     @staticmethod
-    def forward(ctx, latent, point_mask, rho: float):
+    def forward(ctx, latent, point_mask, rho: float, activated: bool = False):
+        """activated: `latent` is sigmoid(latent) already (the encoder's last layer applied it)"""
         latent = latent.contiguous()
         mask = None if point_mask is None else (point_mask.view(torch.uint8) if point_mask.dtype == torch.bool else point_mask).contiguous()
-        stats = ops.latent_kl_fwd(latent, mask, rho)
+        stats = ops.latent_kl_fwd(latent, mask, rho, activated)
         ctx.save_for_backward(latent, stats)
-        ctx.mask, ctx.rho = mask, rho
+        ctx.mask, ctx.rho, ctx.activated = mask, rho, activated
         return stats[33]
 
     @staticmethod
     def backward(ctx, d_kl):
         latent, stats = ctx.saved_tensors
-        return ops.latent_kl_bwd(latent, ctx.mask, ctx.rho, stats, d_kl.reshape(1).contiguous()), None, None
+        return ops.latent_kl_bwd(latent, ctx.mask, ctx.rho, stats, d_kl.reshape(1).contiguous(), ctx.activated), None, None, None
 
 
 class SgCombineFn(torch.autograd.Function):

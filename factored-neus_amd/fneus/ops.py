@@ -1002,6 +1002,30 @@ def vis_sample_dirs(lobes, lambdas, u_theta, u_phi):
     return dirs, w
 
 
+def vis_sample_dirs_sgs(lgt_sgs, u_theta, u_phi):
+    """fneus_vis_sample_dirs_sgs: the light-SG table lgtSGs [M,7] itself (axis normalisation and |sharpness| inside the launch),
+    u_theta / u_phi [M,S] -> dirs [M,S,3], weights [M,S]"""
+    M, S = u_theta.shape
+    dirs = torch.empty(M, S, 3, dtype=torch.float32, device=lgt_sgs.device)
+    w = torch.empty(M, S, dtype=torch.float32, device=lgt_sgs.device)
+    _launch("fneus_vis_sample_dirs_sgs", lib.fneus_vis_sample_dirs_sgs, _ptr(lgt_sgs), _ptr(u_theta), _ptr(u_phi), M, S, _ptr(dirs), _ptr(w),
+            _stream())
+    return dirs, w
+
+
+def material_inputs(points, ray_dirs, normals):
+    """fneus_material_inputs (inverRender.py:530-545, no gradient): points, ray_dirs, normals [n,3] -> unit normal [n,3], view
+    direction [n,3], embed(points, 10) [n,63], [embed(points, 10) | embed(reflected direction, 4)] [n,90]"""
+    n = points.shape[0]
+    for t, name in ((points, "points"), (ray_dirs, "ray_dirs"), (normals, "normals")):
+        _chk_f32(t, name)
+    mk = lambda w: torch.empty(n, w, dtype=torch.float32, device=points.device)
+    n_unit, view, enc, x_cs = mk(3), mk(3), mk(63), mk(90)
+    _launch("fneus_material_inputs", lib.fneus_material_inputs, _ptr(points), _ptr(ray_dirs), _ptr(normals), n, _ptr(n_unit), _ptr(view),
+            _ptr(enc), _ptr(x_cs), _stream())
+    return n_unit, view, enc, x_cs
+
+
 def indir_sgs(raw):
     """fneus_indir_sgs: IndirectLight's output transform without gradient, raw [n, L, 6] -> [n, L, 7]"""
     raw = raw.contiguous()
@@ -1168,18 +1192,19 @@ def stage3_loss(rgb, true_rgb, mask, hit):
     return out, d_rgb
 
 
-def latent_kl_fwd(latent, point_mask, rho: float):
-    """-> stats [34]: rho_hat [32], the number of marked points, kl (include/fneus.h fneus_latent_kl_fwd)"""
+def latent_kl_fwd(latent, point_mask, rho: float, activated: bool = False):
+    """-> stats [34]: rho_hat [32], the number of marked points, kl (include/fneus.h fneus_latent_kl_fwd); activated: `latent` is
+    sigmoid(latent) already"""
     stats = torch.empty(34, dtype=torch.float32, device=latent.device)
-    _launch("fneus_latent_kl_fwd", lib.fneus_latent_kl_fwd, _ptr(latent), _ptr(point_mask), latent.shape[0], float(rho), _ptr(stats),
-            _stream())
+    _launch("fneus_latent_kl_fwd", lib.fneus_latent_kl_fwd, _ptr(latent), _ptr(point_mask), latent.shape[0], float(rho), int(activated),
+            _ptr(stats), _stream())
     return stats
 
 
-def latent_kl_bwd(latent, point_mask, rho: float, stats, d_kl):
+def latent_kl_bwd(latent, point_mask, rho: float, stats, d_kl, activated: bool = False):
     d_latent = torch.empty_like(latent)
-    _launch("fneus_latent_kl_bwd", lib.fneus_latent_kl_bwd, _ptr(latent), _ptr(point_mask), latent.shape[0], float(rho), _ptr(stats),
-            _ptr(d_kl), _ptr(d_latent), _stream())
+    _launch("fneus_latent_kl_bwd", lib.fneus_latent_kl_bwd, _ptr(latent), _ptr(point_mask), latent.shape[0], float(rho), int(activated),
+            _ptr(stats), _ptr(d_kl), _ptr(d_latent), _stream())
     return d_latent
 
 

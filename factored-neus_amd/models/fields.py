@@ -54,6 +54,16 @@ class WNLinear(nn.Module):
         return self.weight_v * (self.weight_g / self.weight_v.norm(dim=1, keepdim=True))
 
 
+def _frozen_key(params):
+    """(address, version) of every parameter when NONE of them is trained (the frozen networks of stages 2 / 3), else None: a
+    frozen network whose key has not changed since it was packed need not be packed again (a state_dict load or any other in-place
+    write bumps the versions; trained parameters are also written by the optimiser kernel, which does not, so they always pack)"""
+    params = list(params)
+    if any(p.requires_grad for p in params):
+        return None
+    return tuple((p.data_ptr(), p._version) for p in params)
+
+
 class _HipMLP(nn.Module):
     """Shared plumbing of the two fused MLPs.
 
@@ -126,6 +136,11 @@ class _HipMLP(nn.Module):
         """Fold weight-norm and pack the current parameters for the kernels.  Call once per step before rendering."""
         if not self._attached():
             self._attach()
+            self._frozen_packed = None
+        key = _frozen_key(self.parameters())
+        if key is not None and key == getattr(self, "_frozen_packed", None) and self._packed:
+            return
+        self._frozen_packed = key
         for lin, gview in zip(self._lins(), self._net.raw_views(self._net.raw_grad)):
             for name in ("bias", "weight_g", "weight_v"):      # optimizer.zero_grad(set_to_none=True) drops the views
                 prm = getattr(lin, name)
@@ -300,6 +315,11 @@ class _PlainBackend:
     def refresh(self):
         if not self.attached():
             self.attach()
+            self.frozen_packed = None
+        key = _frozen_key(p for lin in self.layers for p in (lin.weight, lin.bias))
+        if key is not None and key == getattr(self, "frozen_packed", None) and self.packed:
+            return
+        self.frozen_packed = key
         for lin, gview in zip(self.layers, self.net.raw_views(self.net.raw_grad)):
             for name in ("bias", "weight"):
                 prm = getattr(lin, name)
@@ -629,8 +649,14 @@ class _MlpGroupFn(torch.autograd.Function):
         return (None, *grads)
 
 
+_TOP_ACTS = {ops.ACT_NONE: lambda x: x, ops.ACT_RELU: torch.relu, ops.ACT_LEAKY02: lambda x: torch.nn.functional.leaky_relu(x, 0.2),
+             ops.ACT_SIGMOID: torch.sigmoid}
+
+
 def seq_group(items):
-    """[(nn.Sequential, x, owner), ...] -> [outputs]: independent MLPs of Linear + activation layers evaluated in lockstep.  On the
+    """[(nn.Sequential, x, owner[, top_act]), ...] -> [outputs]: top_act (an ops.ACT_* code) is an activation the CALLER applies to
+    the output of a network that ends in a Linear layer (torch.sigmoid(decoder(x))): it becomes the last layer's activation.
+    [(nn.Sequential, x, owner), ...] -> [outputs]: independent MLPs of Linear + activation layers evaluated in lockstep.  On the
     GPU: the fneus_mlp_* kernels (_MlpGroupFn; FNEUS_MLP_ROWS=0 keeps torch's modules), a network's parameter gradients written
     straight into persistent `.grad` buffers when its owner asks for it (`owner.direct_grads`, set by the trainers that keep a
     gradient arena, for the duration of their own steps) and every buffer exists.  Networks the kernels do not take (another
@@ -641,20 +667,27 @@ def seq_group(items):
 
     results = [None] * len(items)
     nets, tensors, where = [], [], []
-    for idx, (seq, x, owner) in enumerate(items):
+    for idx, item in enumerate(items):
+        seq, x, owner = item[:3]
+        top_act = item[3] if len(item) > 3 else None
         want_direct = getattr(owner, "direct_grads", False) and torch.is_grad_enabled()
         spec = _mlp_spec(seq) if (ops.MLP_ROWS and x.is_cuda and x.dtype == torch.float32) else None
+        if spec is not None and top_act is not None:
+            if spec[-1][1] != ops.ACT_NONE:
+                raise ValueError("seq_group: top_act given for a network that ends in an activation")
+            spec[-1][1] = top_act
         if spec is not None and all(m.weight.dtype == torch.float32 and m.weight.is_contiguous() for m, _ in spec):
             direct = bool(want_direct) and all(has_buffers(m) for m, _ in spec)
             nets.append((tuple(a for _, a in spec), direct))
             tensors += [x] + [p for m, _ in spec for p in (m.weight, m.bias)]
             where.append(idx)
-        elif not want_direct:
-            results[idx] = seq(x)
         else:
-            for m in seq:
-                x = _DirectLinearFn.apply(x, m.weight, m.bias) if isinstance(m, nn.Linear) and has_buffers(m) else m(x)
-            results[idx] = x
+            if not want_direct:
+                x = seq(x)
+            else:
+                for m in seq:
+                    x = _DirectLinearFn.apply(x, m.weight, m.bias) if isinstance(m, nn.Linear) and has_buffers(m) else m(x)
+            results[idx] = x if top_act is None else _TOP_ACTS[top_act](x)
     if nets:
         for idx, y in zip(where, _MlpGroupFn.apply(tuple(nets), *tensors)):
             results[idx] = y

@@ -128,9 +128,19 @@ def integrate_rgb(normal, final_lobes, final_lambdas, final_mus):
     return torch.clamp(rgb.sum(dim=-2), min=0.0, max=1.0)
 
 
-def visibility_sample_dirs(lgtSGLobes, lgtSGLambdas, nsamp, u_theta=None, u_phi=None):
+def visibility_sample_dirs(lgtSGLobes, lgtSGLambdas, nsamp, u_theta=None, u_phi=None, lgt_sgs=None):
     """the direction set of get_diffuse_visibility (inverRender.py:133-161): nsamp directions around every light lobe inside
-    a cone whose opening follows the lobe's sharpness -> dirs [M, nsamp, 3], weights exp(lambda (d . axis - 1)) [M, nsamp]"""
+    a cone whose opening follows the lobe's sharpness -> dirs [M, nsamp, 3], weights exp(lambda (d . axis - 1)) [M, nsamp].
+    lgt_sgs [M, 7]: the light-SG table the lobes and sharpnesses come from (axis sg[:3] / (|sg[:3]| + 1e-6), sharpness |sg[3]|:
+    render_with_all_sg) -- on the GPU they are then taken inside the launch and lgtSGLobes / lgtSGLambdas may be None"""
+    if lgt_sgs is not None and lgt_sgs.is_cuda and lgt_sgs.dtype == torch.float32 and lgt_sgs.shape[-1] == 7:
+        M, dev = lgt_sgs.shape[0], lgt_sgs.device
+        u_theta = torch.rand(M, nsamp, device=dev) if u_theta is None else u_theta
+        u_phi = torch.rand(M, nsamp, device=dev) if u_phi is None else u_phi
+        return ops.vis_sample_dirs_sgs(lgt_sgs.detach().contiguous(), u_theta.float().contiguous(), u_phi.float().contiguous())
+    if lgtSGLobes is None:
+        lgtSGLobes = lgt_sgs[:, :3] / (torch.norm(lgt_sgs[:, :3], dim=-1, keepdim=True) + TINY_NUMBER)
+        lgtSGLambdas = torch.abs(lgt_sgs[:, 3:4])
     M = lgtSGLobes.shape[0]
     dev = lgtSGLobes.device
     if lgtSGLobes.is_cuda and lgtSGLobes.dtype == torch.float32:       # one launch instead of ~45 element-wise ones
@@ -157,11 +167,12 @@ def visibility_sample_dirs(lgtSGLobes, lgtSGLambdas, nsamp, u_theta=None, u_phi=
 
 
 def get_diffuse_visibility(points, normals, VisModel, lgtSGLobes, lgtSGLambdas, nsamp=8, u_theta=None, u_phi=None,
-                           point_mask=None):
-    """inverRender.py:128-192 -> [n_lobe, n_points], detached.  VisModel: models.fields.Lvis"""
+                           point_mask=None, lgt_sgs=None):
+    """inverRender.py:128-192 -> [n_lobe, n_points], detached.  VisModel: models.fields.Lvis.  lgt_sgs: see
+    visibility_sample_dirs"""
     from fneus import ops
     with torch.no_grad():
-        dirs, w = visibility_sample_dirs(lgtSGLobes, lgtSGLambdas, nsamp, u_theta, u_phi)
+        dirs, w = visibility_sample_dirs(lgtSGLobes, lgtSGLambdas, nsamp, u_theta, u_phi, lgt_sgs=lgt_sgs)
         return VisModel.visibility(points.detach().float().contiguous(), normals.detach().float().contiguous(),
                                    dirs.contiguous(), w.contiguous(), point_mask)
 
@@ -220,9 +231,8 @@ def _render_with_all_sg_fused(points, normal, viewdirs, lgtSGs, f0: float, specu
     direct and the 24 indirect SGs in one launch; the clamps of integrate_rgb (:277), of render_with_sg (:440) and the tone
     mapping (:306-309) are element-wise ops on [n, 3] tensors"""
     from fneus.autograd import SgRenderFn
-    lobes = lgtSGs[:, :3] / (torch.norm(lgtSGs[:, :3], dim=-1, keepdim=True) + TINY_NUMBER)
-    vis = get_diffuse_visibility(points, normal, lvis_network, lobes, torch.abs(lgtSGs[:, 3:4]), nsamp=32, u_theta=u_theta,
-                                 u_phi=u_phi, point_mask=point_mask)              # [M, n], detached
+    vis = get_diffuse_visibility(points, normal, lvis_network, None, None, nsamp=32, u_theta=u_theta, u_phi=u_phi,
+                                 point_mask=point_mask, lgt_sgs=lgtSGs)           # [M, n], detached
     mat = torch.cat([roughness, diffuse_albedo, specular_albedo], dim=-1)         # [n, 7]
     sums = SgRenderFn.apply(lgtSGs, mat, normal, viewdirs, vis, indir_lgtSGs, f0)
     if want is not None and want <= {"rgb"}:           # the training step: the colour alone, clamps and tone mapping in one launch
@@ -304,15 +314,16 @@ class EnvmapMaterialNetwork(nn.Module):
         self.envmap = None
         self.stat_reduce = None      # set by the data-parallel trainer: sums the latent-sparsity statistics over the ranks
 
-    def kl_divergence(self, rho, rho_hat, point_mask=None):
+    def kl_divergence(self, rho, rho_hat, point_mask=None, activated=False):
         """inverRender.py:609-612.  point_mask [n] bool: the mean runs over the marked points only (the fixed-shape stage-3
-        step evaluates every ray and marks the ones that hit); without a marked point the term is 0"""
+        step evaluates every ray and marks the ones that hit); without a marked point the term is 0.  activated: `rho_hat` is
+        sigmoid(latent) already"""
         red = getattr(self, "stat_reduce", None)
         if rho_hat.is_cuda and rho_hat.dim() == 2 and rho_hat.shape[1] == 32 and rho_hat.dtype == torch.float32 and \
                 (red is None or point_mask is None):
             from fneus.autograd import LatentKlFn                   # one launch forward, one backward (~40 element-wise ones)
-            return LatentKlFn.apply(rho_hat, point_mask, float(rho))
-        act = torch.sigmoid(rho_hat)
+            return LatentKlFn.apply(rho_hat, point_mask, float(rho), bool(activated))
+        act = rho_hat if activated else torch.sigmoid(rho_hat)
         if point_mask is None:
             rho_hat = torch.mean(act, 0)
             return torch.mean(rho * torch.log(rho / rho_hat) + (1 - rho) * torch.log((1 - rho) / (1 - rho_hat)))
@@ -331,20 +342,26 @@ class EnvmapMaterialNetwork(nn.Module):
     def forward(self, points, ray_dirs, n, f, gt_specular_linear, indiLgt, lvis_network, u_theta=None, u_phi=None,
                 point_mask=None, want=None):
         """want: set of result keys the caller reads (None = all, the reference's dict); the losses are always returned"""
-        n = n / (torch.norm(n, dim=-1, keepdim=True) + TINY_NUMBER)
-        ray_dirs = ray_dirs / (torch.norm(ray_dirs, dim=-1, keepdim=True) + TINY_NUMBER)
-        view_dirs = -ray_dirs
-        ref_dirs = 2.0 * torch.sum(view_dirs * n, dim=-1, keepdim=True) * n - view_dirs
-        pts_enc = self.embed_pts_fn(points)
-        # (_seq_direct: inside Stage3Trainer's own steps the Linear layers write dW / db straight into their persistent gradient
-        # buffers, models/fields.py _DirectLinearFn; otherwise these are the plain nn.Sequential calls)
-        # (the encoder and net_cs have their inputs now: layer by layer in the same launches, models/fields.py seq_group)
-        latent, cs = seq_group([(self.brdf_encoder_layer, self.brdf_embed_fn(points), self),
-                                (self.net_cs, torch.cat([pts_enc, self.embed_view_fn(ref_dirs)], dim=-1), self)])
-        brdf = torch.sigmoid(_seq_direct(self.brdf_decoder_layer, torch.sigmoid(latent), self))
+        from fneus import ops
+        fused_in = (points.is_cuda and all(t.dtype == torch.float32 and not t.requires_grad for t in (points, ray_dirs, n))
+                    and points.dim() == 2)
+        if fused_in:       # normalisations, reflected direction, the three encodings and the concatenation in one launch
+            n, view_dirs, brdf_in, cs_in = ops.material_inputs(points.contiguous(), ray_dirs.contiguous(), n.contiguous())
+        else:
+            n = n / (torch.norm(n, dim=-1, keepdim=True) + TINY_NUMBER)
+            ray_dirs = ray_dirs / (torch.norm(ray_dirs, dim=-1, keepdim=True) + TINY_NUMBER)
+            view_dirs = -ray_dirs
+            ref_dirs = 2.0 * torch.sum(view_dirs * n, dim=-1, keepdim=True) * n - view_dirs
+            brdf_in = self.brdf_embed_fn(points)
+            cs_in = torch.cat([self.embed_pts_fn(points), self.embed_view_fn(ref_dirs)], dim=-1)
+        # The encoder and net_cs have their inputs now: layer by layer in the same launches (models/fields.py seq_group; inside
+        # Stage3Trainer's own steps the parameter gradients go straight into their persistent buffers).  The two sigmoids of :555-556
+        # are the last activations of the encoder and the decoder there (the latent code is read through its sigmoid only).
+        act_latent, cs = seq_group([(self.brdf_encoder_layer, brdf_in, self, ops.ACT_SIGMOID), (self.net_cs, cs_in, self)])
+        brdf = seq_group([(self.brdf_decoder_layer, act_latent, self, ops.ACT_SIGMOID)])[0]
         diffuse_albedo, rough_raw = torch.split(brdf, [3, 1], dim=-1)      # (split: its backward is one concatenation)
         roughness = rough_raw * 0.9 + 0.09
-        loss = 0.01 * self.kl_divergence(0.05, latent, point_mask)
+        loss = 0.01 * self.kl_divergence(0.05, act_latent, point_mask, activated=True)
         specular_albedo = cs.expand(-1, 3)
         ret = render_with_all_sg(points, n, view_dirs, self.lgtSGs, self.specular_reflectance, specular_albedo, roughness,
                                  diffuse_albedo, gt_specular_linear, lvis_network=lvis_network, indir_lgtSGs=indiLgt,

@@ -370,6 +370,15 @@ int fneus_indir_sgs(const float* raw, long n_lobes_total, float* sgs, fneus_stre
  * [M][S] uniform draws -> dirs [M][S][3] inside each lobe's cone, weights [M][S] = exp(lambda (dir . axis - 1)). */
 int fneus_vis_sample_dirs(const float* lobes, const float* lambdas, const float* u_theta, const float* u_phi, int n_lobes, int n_samp,
                           float* dirs, float* weights, fneus_stream_t stream);
+/* the same from the light-SG table lgtSGs [M][7] of EnvmapMaterialNetwork: lobes = sg[0..2] / (|sg[0..2]| + 1e-6), lambdas = |sg[3]|
+ * (render_with_all_sg, inverRender.py:420-421) taken inside the launch. */
+int fneus_vis_sample_dirs_sgs(const float* lgt_sgs, const float* u_theta, const float* u_phi, int n_lobes, int n_samp, float* dirs,
+                              float* weights, fneus_stream_t stream);
+/* The inputs of EnvmapMaterialNetwork's MLPs (inverRender.py:530-545), no gradient: points, ray_dirs, normals [n][3] ->
+ * n_unit = normal / (|normal| + 1e-6), view_dirs = -ray_dir / (|ray_dir| + 1e-6) [n][3], enc_pts [n][63] = embed(point, 10) (the BRDF
+ * encoder's input; embedder.py:23-36), x_cs [n][90] = [embed(point, 10) | embed(2 (v . n) n - v, 4)] (net_cs's input). */
+int fneus_material_inputs(const float* points, const float* ray_dirs, const float* normals, int n, float* n_unit, float* view_dirs,
+                          float* enc_pts, float* x_cs, fneus_stream_t stream);
 
 /* ---- sRGB transfer curves (models/math_utils.py:138-152; RefColor, fields.py:329-335; stage-3 tone mapping, inverRender.py:13-18)
  * as one element-wise launch and one for the adjoint.  mode bit 0: 0 = linear -> sRGB, 1 = sRGB -> linear; bit 1: clip to [0, 1]
@@ -445,9 +454,12 @@ int fneus_stage3_loss(const float* rgb, const float* true_rgb, const float* mask
 /* The latent-sparsity term of stage 3 (inverRender.py:609-612): latent [n][32], point_mask [n] (NULL = every point), rho in
  * (0, 1) -> stats [34] = rho_hat [32] (mean sigmoid over the marked points), their number, kl (0 without a marked point); and the
  * adjoint d_latent [n][32] for the cotangent d_kl [1] (device scalar). */
-int fneus_latent_kl_fwd(const float* latent, const unsigned char* point_mask, int n, float rho, float* stats, fneus_stream_t stream);
-int fneus_latent_kl_bwd(const float* latent, const unsigned char* point_mask, int n, float rho, const float* stats, const float* d_kl,
-                        float* d_latent, fneus_stream_t stream);
+/* activated != 0: `latent` holds sigmoid(latent) already (fneus_mlp_forward applied it as the encoder's last activation); the adjoint is
+ * then the gradient of that activated tensor. */
+int fneus_latent_kl_fwd(const float* latent, const unsigned char* point_mask, int n, float rho, int activated, float* stats,
+                        fneus_stream_t stream);
+int fneus_latent_kl_bwd(const float* latent, const unsigned char* point_mask, int n, float rho, int activated, const float* stats,
+                        const float* d_kl, float* d_latent, fneus_stream_t stream);
 /* The colour a stage-3 training step reads, from the four lobe sums of fneus_sg_render_fwd [n][4][3]: clamp each to [0, 1],
  * env = clamp(direct specular + diffuse), indir = clamp(indirect specular + diffuse) (0 when has_indir == 0), rgb =
  * clip(linear -> sRGB (env + indir)) -- inverRender.py:277, 440, 306-309 -- and the adjoint (torch.clamp / torch.clip pass the

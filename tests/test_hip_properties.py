@@ -167,6 +167,40 @@ def test_overwritten_stash_is_detected():
         ga.sum().backward()
 
 
+def test_frozen_network_packs_again_only_after_a_parameter_changed(monkeypatch):
+    """stages 2 / 3 refresh their frozen networks every step: the pack launches are skipped while no parameter has been written
+    (address + version of every parameter), and come back with the first in-place write; a trained network always packs"""
+    from fneus import ops
+    from fneus.autograd import RaySamples
+    from models.fields import SDFNetwork
+    net = SDFNetwork(d_out=257, d_in=3, d_hidden=256, n_layers=8, skip_in=[4], multires=6, bias=0.5, scale=1.0,
+                     geometric_init=True, weight_norm=True).to(DEV)
+    calls = []
+    real = ops.PackedNet.pack
+    monkeypatch.setattr(ops.PackedNet, "pack", lambda self: (calls.append(1), real(self))[1])
+    pts = RaySamples(pts=(torch.rand(256, 3, device=DEV) - 0.5).contiguous())
+    net.refresh()
+    net.refresh()
+    assert len(calls) == 2                                  # trained parameters: every refresh packs
+    for p in net.parameters():
+        p.requires_grad_(False)
+    net.refresh()
+    y0 = net.sdf_samples(pts).clone()
+    net.refresh()
+    net.refresh()
+    assert len(calls) == 3                                  # frozen and unchanged: packed once
+    with torch.no_grad():
+        net.lin8.bias.add_(0.25)
+    net.refresh()
+    assert len(calls) == 4
+    y1 = net.sdf_samples(pts)
+    assert (y1 - y0 - 0.25).abs().max().item() <= 1e-5      # lin8's first output row is the sdf
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    net.refresh()
+    assert len(calls) == 5                                  # a state_dict load writes every parameter
+
+
 def _grads_of(mod):
     return torch.cat([p.grad.detach().reshape(-1).clone() for p in mod.parameters()])
 

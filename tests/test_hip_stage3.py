@@ -346,6 +346,48 @@ def test_fused_visibility_direction_set_vs_the_element_wise_formulation():
     assert ((w.cpu() - w_ref).abs() <= 2e-5 * w_ref.abs().clamp_min(1e-3)).all()
 
 
+def test_direction_set_from_the_light_sg_table():
+    """fneus_vis_sample_dirs_sgs (axis normalisation and |sharpness| inside the launch) against fneus_vis_sample_dirs on the lobes
+    and sharpnesses render_with_all_sg takes from the table with torch ops (inverRender.py:420-421)"""
+    from fneus import synth, ops
+    dev = torch.device(DEV)
+    sg = T(synth.mateillu_state_dict(32)["lgtSGs"]).to(dev)
+    sg[5, 3] = -sg[5, 3]                        # (a negative sharpness: the table's absolute value is what counts)
+    g = torch.Generator().manual_seed(6)
+    ut, up = torch.rand(128, 32, generator=g).to(dev), torch.rand(128, 32, generator=g).to(dev)
+    lobes = sg[:, :3] / (sg[:, :3].norm(dim=-1, keepdim=True) + 1e-6)
+    d_ref, w_ref = ops.vis_sample_dirs(lobes.contiguous(), sg[:, 3].abs().contiguous(), ut, up)
+    d, w = ops.vis_sample_dirs_sgs(sg.contiguous(), ut, up)
+    assert (d - d_ref).abs().max().item() <= 2e-6
+    assert ((w - w_ref).abs() <= 1e-5 * w_ref.abs().clamp_min(1e-3)).all()
+
+
+def test_material_inputs_equal_the_elementwise_formulation():
+    """fneus_material_inputs against inverRender.py:530-545 written with torch ops and the Embedder: unit normal, view direction,
+    the BRDF encoder's and net_cs's inputs; a zero normal and a zero ray direction stay finite (the 1e-6 in the norms)"""
+    from fneus import ops
+    from models.embedder import get_embedder
+    dev = torch.device(DEV)
+    g = torch.Generator().manual_seed(3)
+    pts = (torch.randn(517, 3, generator=g) * 0.6).to(dev)
+    rd = torch.randn(517, 3, generator=g).to(dev) * 1.7
+    nrm = torch.randn(517, 3, generator=g).to(dev) * 0.3
+    nrm[7] = 0.0
+    rd[9] = 0.0
+    n_u, view, enc, x_cs = ops.material_inputs(pts, rd, nrm)
+    e10, _ = get_embedder(10)
+    e4, _ = get_embedder(4)
+    n_ref = nrm / (torch.norm(nrm, dim=-1, keepdim=True) + 1e-6)
+    v_ref = -(rd / (torch.norm(rd, dim=-1, keepdim=True) + 1e-6))
+    r_ref = 2.0 * torch.sum(v_ref * n_ref, dim=-1, keepdim=True) * n_ref - v_ref
+    assert (n_u - n_ref).abs().max().item() <= 2e-7 and (view - v_ref).abs().max().item() <= 2e-7
+    assert torch.equal(enc, e10(pts))                                   # the same sincosf of the same products
+    assert torch.equal(x_cs[:, :63], enc)
+    # the reflected direction differs by rounding (<= 4e-7), its top octave multiplies that by 8
+    assert (x_cs[:, 63:] - e4(r_ref)).abs().max().item() <= 5e-6
+    assert torch.isfinite(x_cs).all() and torch.isfinite(n_u).all() and torch.isfinite(view).all()
+
+
 def test_fused_indirect_light_output_transform():
     """IndirectLight.forward without gradient (fneus_indir_sgs) against its element-wise formulation (with gradient enabled)"""
     from fneus import synth
@@ -408,3 +450,12 @@ def test_latent_kl_equals_the_elementwise_formulation():
             assert (a.grad.double() - b.grad).abs().max().item() <= 2e-6 * b.grad.abs().max().item() + 1e-12
         else:
             assert kl.item() == 0.0 and float(a.grad.abs().max()) == 0.0
+        # the encoder's last layer may have applied the sigmoid already (models/inverRender.py forward): the same term, the
+        # gradient with respect to the activated code
+        c = torch.sigmoid(latent).requires_grad_(True)
+        kl_c = LatentKlFn.apply(c, mask, rho, True)
+        (kl_c * 3.0).backward()
+        assert abs(kl_c.item() - kl.item()) <= 1e-6 * max(1.0, abs(kl.item()))
+        s_ = torch.sigmoid(latent)
+        chain = c.grad * s_ * (1.0 - s_)
+        assert (chain - a.grad).abs().max().item() <= 1e-6 * float(a.grad.abs().max()) + 1e-12

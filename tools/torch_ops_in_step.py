@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Which PyTorch (aten) ops still launch kernels inside one eager train step, in order, with their input shapes."""
+"""Which PyTorch (aten) ops still launch kernels inside one eager train step, in order, with their input shapes:
+python tools/torch_ops_in_step.py [stage1 | stage2 | stage3]   (stages 2 / 3: the fixed-shape step the graphs replay)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "factored-neus_amd"))
@@ -7,13 +8,24 @@ import torch
 from torch.profiler import profile, ProfilerActivity
 from fneus.trainer import Stage1Trainer, synthetic_batches
 dev = torch.device("cuda:0")
-tr = Stage1Trainer(dev, use_graph=False)
+which = sys.argv[1] if len(sys.argv) > 1 else "stage1"
+if which == "stage2":
+    from fneus.trainer2 import Stage2Trainer
+    tr = Stage2Trainer(dev, use_graph=False)
+    step = tr._fixed_shape_step
+elif which == "stage3":
+    from fneus.trainer3 import Stage3Trainer
+    tr = Stage3Trainer(dev, use_graph=False)
+    step = tr._fixed_shape_step
+else:
+    tr = Stage1Trainer(dev, use_graph=False)
+    step = tr.train_step
 bs = synthetic_batches(4, 512, dev)
 for b in bs[:3]:
-    tr.train_step(b)
+    step(b)
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=False) as prof:
-    tr.train_step(bs[3])
+    step(bs[3])
     torch.cuda.synchronize()
 evs = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CPU and e.name.startswith("aten::")]
 # keep leaf aten ops that launched a kernel
