@@ -4,10 +4,11 @@
 // Per surface point and light lobe the reference evaluates a chain of ~80 element-wise tensor ops on [points, lobes, 3]
 // tensors (twice: 128 direct lobes with visibility, 24 indirect lobes without), ~600 launches forward and ~1500 with
 // autograd's backward.  Here a wavefront owns a point, its lanes stride over the lobes, and the whole chain runs in
-// registers.  The backward pass recomputes the chain with forward-mode dual numbers (7 tangent directions at a time: first the
-// point's material parameters -- roughness, diffuse albedo, specular albedo --, then the lobe's own 7 SG parameters) and
-// contracts the partials with the incoming cotangents: no hand-derived adjoint to keep in sync with the forward code, the
-// same templated function serves both.  Work per step is tiny (512 x 152 lobe evaluations x ~5000 flops with duals).
+// registers.  The backward pass recomputes the chain with forward-mode dual numbers and contracts the partials with the incoming
+// cotangents: no hand-derived adjoint of the chain to keep in sync with the forward code, the same templated function
+// (lobe_factors) serves both.  Round 5: the colour channels' albedos and amplitudes multiply the chain's result, so their partials
+// are read off its value and only the roughness and the lobe's axis / sharpness carry tangents -- one pass of 5 where there were
+// two of 7 (lobe_adjoint) -- and the light table's gradient leaves as one atomic per workgroup, not per point: 155 -> 27 us per step.
 //
 // Outputs are the lobe SUMS before integrate_rgb's clamp (inverRender.py:277): [n][4][3] = direct specular, direct diffuse,
 // indirect specular, indirect diffuse; the clamps, the tone mapping and the losses stay with the caller.
@@ -195,35 +196,76 @@ FN_DEV PointConst point_consts(const float* __restrict__ normal, const float* __
     return p;
 }
 
-// one (point, lobe) pair: spec[c], diff[c] contributions.  mat = (roughness, diffuse albedo[3], specular albedo[3]); sg = the
-// lobe's 7 parameters; vis = the lobe's visibility at the point (1 for the indirect lobes).
+// one (point, lobe) pair, the factors every colour channel shares: they depend on the roughness r and on the lobe's axis and
+// sharpness sg[0..3] only
 template <int N>
-FN_DEV void lobe_terms(const PointConst& pc, const Dual<N> (&mat)[7], const Dual<N> (&sg)[7], float vis, Dual<N> (&spec)[3],
-                       Dual<N> (&diff)[3]) {
+struct LobeFactors {
+    Dual<N> brdf_mu, moi, ed, w_spec, w_diff;
+};
+template <int N>
+FN_DEV LobeFactors<N> lobe_factors(const PointConst& pc, const Dual<N>& r, const Dual<N> (&sg)[7]) {
+    LobeFactors<N> f;
     const Vec3<N> raw{sg[0], sg[1], sg[2]};
     const Dual<N> inv_len = 1.0f / (dsqrt(dot3(raw, raw)) + kTiny);                          // :334
     const Vec3<N> lobe{raw.x * inv_len, raw.y * inv_len, raw.z * inv_len};
     const Dual<N> lam = dabs(sg[3]);                                                         // :335
-    const Dual<N>& r = mat[0];
     const Dual<N> inv_r4 = 2.0f / (r * r * r * r);                                           // :347
     const Dual<N> warp_lam = inv_r4 / (4.0f * pc.v_dot_lobe + kTiny);                        // :358
     const Dual<N> k = (r + 1.0f) * (r + 1.0f) / 8.0f;                                        // :376
     const Dual<N> g1 = pc.dot1 / (pc.dot1 * (1.0f - k) + k + kTiny);
     const Dual<N> g2 = pc.dot2 / (pc.dot2 * (1.0f - k) + k + kTiny);
-    const Dual<N> moi = pc.fresnel * (g1 * g2) / (4.0f * pc.dot1 * pc.dot2 + kTiny);         // :382
-    const Dual<N> brdf_mu = inv_r4 / kPi;                                                    // :349
+    f.moi = pc.fresnel * (g1 * g2) / (4.0f * pc.dot1 * pc.dot2 + kTiny);                     // :382
+    f.brdf_mu = inv_r4 / kPi;                                                                // :349
     const Vec3<N> warp = cvec<N>(pc.warp);
     Vec3<N> fl;
-    Dual<N> fla, ed;
-    lambda_trick(lobe, lam, warp, warp_lam, fl, fla, ed);                                    // :411-412
-    const Dual<N> w_spec = integrate_weight(pc.n, fl, fla);                                  // :415
-    const Dual<N> w_diff = integrate_weight(pc.n, lobe, lam);                                // :433
+    Dual<N> fla;
+    lambda_trick(lobe, lam, warp, warp_lam, fl, fla, f.ed);                                  // :411-412
+    f.w_spec = integrate_weight(pc.n, fl, fla);                                              // :415
+    f.w_diff = integrate_weight(pc.n, lobe, lam);                                            // :433
+    return f;
+}
+
+// one (point, lobe) pair: spec[c], diff[c] contributions.  mat = (roughness, diffuse albedo[3], specular albedo[3]); sg = the
+// lobe's 7 parameters; vis = the lobe's visibility at the point (1 for the indirect lobes).
+template <int N>
+FN_DEV void lobe_terms(const PointConst& pc, const Dual<N> (&mat)[7], const Dual<N> (&sg)[7], float vis, Dual<N> (&spec)[3],
+                       Dual<N> (&diff)[3]) {
+    const LobeFactors<N> f = lobe_factors<N>(pc, mat[0], sg);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const Dual<N> mu = dabs(sg[4 + c]) * vis;                                            // :336, :402 / :407
-        spec[c] = mu * (mat[4 + c] * brdf_mu * moi) * ed * w_spec;                           // :383, :100, :275
-        diff[c] = mu * (mat[1 + c] / kPi) * w_diff;                                          // :428-431
+        spec[c] = mu * (mat[4 + c] * f.brdf_mu * f.moi) * f.ed * f.w_spec;                   // :383, :100, :275
+        diff[c] = mu * (mat[1 + c] / kPi) * f.w_diff;                                        // :428-431
     }
+}
+
+// The adjoint of one pair for the cotangents cs = (spec[3], diff[3]).  The colour channels enter as products --
+//   spec_c = |sg_{4+c}| vis * mat_{4+c} * S,  diff_c = |sg_{4+c}| vis * mat_{1+c} * D,  S = brdf_mu moi ed w_spec,  D = w_diff / pi --
+// so the six albedos and the three amplitudes need no tangent: their partials are the other factors.  What is left are the
+// roughness and the lobe's axis and sharpness: ONE pass of the shared chain with NT tangents (5 for a direct lobe, 1 for an
+// indirect one, whose parameters are constants) where round 4 ran two passes of 7.
+template <int NT>
+FN_DEV void lobe_adjoint(const PointConst& pc, const float (&m)[7], const float (&s)[7], float vis, const float* cs, float (&gm)[7],
+                         float (&gs)[7]) {
+    Dual<NT> sg[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) sg[i] = var<NT>(s[i], i < 4 ? 1 + i : -1);
+    const LobeFactors<NT> f = lobe_factors<NT>(pc, var<NT>(m[0], 0), sg);
+    const Dual<NT> S = f.brdf_mu * f.moi * f.ed * f.w_spec, D = f.w_diff / kPi;
+    float A = 0.0f, B = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float mu = fabsf(s[4 + c]) * vis;
+        A += cs[c] * mu * m[4 + c];
+        B += cs[3 + c] * mu * m[1 + c];
+        gm[1 + c] += cs[3 + c] * mu * D.v;
+        gm[4 + c] += cs[c] * mu * S.v;
+        const float sgn = s[4 + c] > 0.0f ? 1.0f : (s[4 + c] < 0.0f ? -1.0f : 0.0f);
+        gs[4 + c] = sgn * vis * (cs[c] * m[4 + c] * S.v + cs[3 + c] * m[1 + c] * D.v);
+    }
+    gm[0] += A * S.d[0] + B * D.d[0];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gs[i] = NT > 1 ? A * S.d[NT > 1 ? 1 + i : 0] + B * D.d[NT > 1 ? 1 + i : 0] : 0.0f;
 }
 
 // ---- kernels: one wavefront per point, lanes stride over the direct (M) and indirect (L) lobes ------------------------------
@@ -261,60 +303,101 @@ __global__ void __launch_bounds__(64) sg_render_fwd_kernel(const float* __restri
     }
 }
 
-__global__ void __launch_bounds__(64) sg_render_bwd_kernel(const float* __restrict__ lgt, const float* __restrict__ ind,
-                                                           const float* __restrict__ vis, const float* __restrict__ normal,
-                                                           const float* __restrict__ view, const float* __restrict__ mat, int n, int M,
-                                                           int L, float f0, const float* __restrict__ d_out /*[n][4][3]*/,
-                                                           float* __restrict__ d_mat /*[n][7]*/, float* __restrict__ d_lgt /*[M][7], atomics*/) {
-    const int pt = blockIdx.x, lane = threadIdx.x;
-    const PointConst pc = point_consts(normal + pt * 3, view + pt * 3, f0);
-    float co[12];
+// Backward.  A workgroup of 4 waves owns kSgBwdPts points (a wave takes every fourth of them), a lane the lobes lane, lane + 64, ...
+// The light table's gradient is summed over the workgroup's points in registers, over its waves in LDS (fixed order) and leaves as
+// ONE atomic per (lobe, parameter) and workgroup: with an atomic per (point, lobe, parameter) -- 458 752 of them on 896 addresses
+// for 512 points -- the launch took 155 us, eleven times the forward (the dual-number arithmetic was never the cost: one pass
+// of 5 tangents instead of two of 7 left it at 159).
+#ifndef FNEUS_SG_BWD_PTS
+#define FNEUS_SG_BWD_PTS 4          // MEASURED (512 points, 128 + 24 lobes): 16 points per workgroup 80 us, 8: 44, 4: 27
+#endif
+constexpr int kSgBwdPts = FNEUS_SG_BWD_PTS;
+constexpr int kSgBwdSlots = 4;             // lobes per lane and sweep: 256 direct lobes per sweep (the reference has 128)
+__global__ void __launch_bounds__(256) sg_render_bwd_kernel(const float* __restrict__ lgt, const float* __restrict__ ind,
+                                                            const float* __restrict__ vis, const float* __restrict__ normal,
+                                                            const float* __restrict__ view, const float* __restrict__ mat, int n, int M,
+                                                            int L, float f0, const float* __restrict__ d_out /*[n][4][3]*/,
+                                                            float* __restrict__ d_mat /*[n][7]*/, float* __restrict__ d_lgt /*[M][7], atomics*/) {
+    __shared__ float red[4][kSgBwdSlots * 64 * 7];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pt0 = blockIdx.x * kSgBwdPts;
+    // ---- the material parameters' gradient and the indirect lobes: a point at a time, lanes stride over all lobes
+    for (int q = wave; q < kSgBwdPts; q += 4) {
+        const int pt = pt0 + q;
+        if (pt >= n) break;
+        const PointConst pc = point_consts(normal + pt * 3, view + pt * 3, f0);
+        float co[12], gm[7], m[7];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) co[i] = d_out[pt * 12 + i];
-    float gm[7];
+        for (int i = 0; i < 12; ++i) co[i] = d_out[pt * 12 + i];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) gm[i] = 0.0f;
-    for (int j = lane; j < M + L; j += 64) {
-        const bool direct = j < M;
-        const float* src = direct ? lgt + j * 7 : ind + ((size_t)pt * L + (j - M)) * 7;
-        const float vj = direct ? vis[(size_t)j * n + pt] : 1.0f;
-        const float* cs = co + (direct ? 0 : 6);          // cotangents of this lobe set: spec[3], diff[3]
-        {   // tangents: the point's material parameters
-            Dual<7> m[7], sg[7], spec[3], diff[3];
-#pragma unroll
-            for (int i = 0; i < 7; ++i) {
-                m[i] = var<7>(mat[pt * 7 + i], i);
-                sg[i] = mk<7>(src[i]);
-            }
-            lobe_terms<7>(pc, m, sg, vj, spec, diff);
-#pragma unroll
-            for (int i = 0; i < 7; ++i)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) gm[i] += cs[c] * spec[c].d[i] + cs[3 + c] * diff[c].d[i];
+        for (int i = 0; i < 7; ++i) {
+            gm[i] = 0.0f;
+            m[i] = mat[pt * 7 + i];
         }
-        if (direct) {   // tangents: the lobe's own SG parameters (the indirect lobes are constants: IndirectLight is frozen)
-            Dual<7> m[7], sg[7], spec[3], diff[3];
+        for (int j = lane; j < L; j += 64) {            // constants (IndirectLight is frozen): the material parameters' share only
+            float sg[7], gs[7];
 #pragma unroll
-            for (int i = 0; i < 7; ++i) {
-                m[i] = mk<7>(mat[pt * 7 + i]);
-                sg[i] = var<7>(src[i], i);
-            }
-            lobe_terms<7>(pc, m, sg, vj, spec, diff);
+            for (int i = 0; i < 7; ++i) sg[i] = ind[((size_t)pt * L + j) * 7 + i];
+            lobe_adjoint<1>(pc, m, sg, 1.0f, co + 6, gm, gs);
+        }
 #pragma unroll
-            for (int i = 0; i < 7; ++i) {
-                float g = 0.0f;
+        for (int i = 0; i < 7; ++i) {
+            float v = gm[i];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) g += cs[c] * spec[c].d[i] + cs[3 + c] * diff[c].d[i];
-                atomicAdd(d_lgt + j * 7 + i, g);
-            }
+            for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
+            if (lane == 0) d_mat[pt * 7 + i] = v;
         }
     }
+    // (d_mat of a wave's points holds the indirect share now; the same wave adds the direct lobes' share below)
+    // ---- the direct lobes, kSgBwdSlots x 64 at a time
+    for (int base = 0; base < M; base += kSgBwdSlots * 64) {
+        float acc[kSgBwdSlots][7];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        float v = gm[i];
+        for (int k = 0; k < kSgBwdSlots; ++k)
 #pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
-        if (lane == 0) d_mat[pt * 7 + i] = v;
+            for (int i = 0; i < 7; ++i) acc[k][i] = 0.0f;
+        for (int q = wave; q < kSgBwdPts; q += 4) {
+            const int pt = pt0 + q;
+            if (pt >= n) break;
+            const PointConst pc = point_consts(normal + pt * 3, view + pt * 3, f0);
+            float co[6], gm[7], m[7];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) co[i] = d_out[pt * 12 + i];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                gm[i] = 0.0f;
+                m[i] = mat[pt * 7 + i];
+            }
+#pragma unroll
+            for (int k = 0; k < kSgBwdSlots; ++k) {
+                const int j = base + k * 64 + lane;
+                if (j < M) {
+                    float sg[7], gs[7];
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) sg[i] = lgt[j * 7 + i];
+                    lobe_adjoint<5>(pc, m, sg, vis[(size_t)j * n + pt], co, gm, gs);
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) acc[k][i] += gs[i];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                float v = gm[i];
+#pragma unroll
+                for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
+                if (lane == 0) d_mat[pt * 7 + i] += v;
+            }
+        }
+        __syncthreads();     // (red: the previous sweep's readers are done)
+#pragma unroll
+        for (int k = 0; k < kSgBwdSlots; ++k)
+#pragma unroll
+            for (int i = 0; i < 7; ++i) red[wave][(k * 64 + lane) * 7 + i] = acc[k][i];
+        __syncthreads();
+        for (int e = threadIdx.x; e < kSgBwdSlots * 64 * 7; e += 256) {
+            const int j = base + e / 7;
+            if (j < M) atomicAdd(d_lgt + (size_t)base * 7 + e, red[0][e] + red[1][e] + red[2][e] + red[3][e]);
+        }
     }
 }
 
@@ -348,7 +431,7 @@ extern "C" int fneus_sg_render_bwd(const float* lgt_sgs, const float* indir_sgs,
         set_last_error("fneus_sg_render_bwd: null argument");
         return -2;
     }
-    hipLaunchKernelGGL(sg_render_bwd_kernel, dim3(n_pts), dim3(64), 0, stream, lgt_sgs, indir_sgs, vis, normal, view, material, n_pts,
-                       n_direct, n_indirect, specular_reflectance, d_out, d_material, d_lgt_sgs);
+    hipLaunchKernelGGL(sg_render_bwd_kernel, dim3((n_pts + kSgBwdPts - 1) / kSgBwdPts), dim3(256), 0, stream, lgt_sgs, indir_sgs, vis, normal,
+                       view, material, n_pts, n_direct, n_indirect, specular_reflectance, d_out, d_material, d_lgt_sgs);
     return fneus::launch_status();
 }
