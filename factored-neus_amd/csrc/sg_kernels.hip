@@ -268,16 +268,53 @@ FN_DEV void lobe_adjoint(const PointConst& pc, const float (&m)[7], const float 
     for (int i = 0; i < 4; ++i) gs[i] = NT > 1 ? A * S.d[NT > 1 ? 1 + i : 0] + B * D.d[NT > 1 ? 1 + i : 0] : 0.0f;
 }
 
+// The point's material (roughness, diffuse albedo[3], specular albedo[3]).  HEADS: straight from the outputs of the two MLP heads --
+// `mat` is the BRDF decoder's [n][4] = (diffuse albedo rgb, raw roughness), `cs` net_cs's [n]: roughness = 0.9 raw + 0.09
+// (inverRender.py:557), the specular albedo is cs in all three channels (:560) -- instead of the [n][7] table five element-wise
+// launches assembled (and five took apart again in the backward).
+template <bool HEADS>
+FN_DEV void load_material(const float* __restrict__ mat, const float* __restrict__ cs, int pt, float (&m)[7]) {
+    if constexpr (HEADS) {
+        m[0] = __fadd_rn(__fmul_rn(mat[pt * 4 + 3], 0.9f), 0.09f);        // (two roundings, like the two tensor ops: no fma)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            m[1 + c] = mat[pt * 4 + c];
+            m[4 + c] = cs[pt];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) m[i] = mat[pt * 7 + i];
+    }
+}
+// gradient of the material: gm [7] -> d_mat (+ d_cs); ADD: on top of what is there (written by the same lane before)
+template <bool HEADS, bool ADD>
+FN_DEV void store_material_grad(const float (&gm)[7], int pt, float* __restrict__ d_mat, float* __restrict__ d_cs) {
+    if constexpr (HEADS) {
+        const float g[4] = {gm[1], gm[2], gm[3], 0.9f * gm[0]};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d_mat[pt * 4 + c] = ADD ? d_mat[pt * 4 + c] + g[c] : g[c];
+        const float gc = gm[4] + gm[5] + gm[6];
+        d_cs[pt] = ADD ? d_cs[pt] + gc : gc;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) d_mat[pt * 7 + i] = ADD ? d_mat[pt * 7 + i] + gm[i] : gm[i];
+    }
+}
+
 // ---- kernels: one wavefront per point, lanes stride over the direct (M) and indirect (L) lobes ------------------------------
+template <bool HEADS>
 __global__ void __launch_bounds__(64) sg_render_fwd_kernel(const float* __restrict__ lgt /*[M][7]*/, const float* __restrict__ ind /*[n][L][7]*/,
                                                            const float* __restrict__ vis /*[M][n]*/, const float* __restrict__ normal,
-                                                           const float* __restrict__ view, const float* __restrict__ mat /*[n][7]*/, int n,
-                                                           int M, int L, float f0, float* __restrict__ out /*[n][4][3]*/) {
+                                                           const float* __restrict__ view, const float* __restrict__ mat /*[n][7]*/,
+                                                           const float* __restrict__ cs, int n, int M, int L, float f0,
+                                                           float* __restrict__ out /*[n][4][3]*/) {
     const int pt = blockIdx.x, lane = threadIdx.x;
     const PointConst pc = point_consts(normal + pt * 3, view + pt * 3, f0);
+    float mf[7];
+    load_material<HEADS>(mat, cs, pt, mf);
     Dual<0> m[7];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) m[i] = mk<0>(mat[pt * 7 + i]);
+    for (int i = 0; i < 7; ++i) m[i] = mk<0>(mf[i]);
     float acc[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) acc[i] = 0.0f;
@@ -313,11 +350,13 @@ __global__ void __launch_bounds__(64) sg_render_fwd_kernel(const float* __restri
 #endif
 constexpr int kSgBwdPts = FNEUS_SG_BWD_PTS;
 constexpr int kSgBwdSlots = 4;             // lobes per lane and sweep: 256 direct lobes per sweep (the reference has 128)
+template <bool HEADS>
 __global__ void __launch_bounds__(256) sg_render_bwd_kernel(const float* __restrict__ lgt, const float* __restrict__ ind,
                                                             const float* __restrict__ vis, const float* __restrict__ normal,
-                                                            const float* __restrict__ view, const float* __restrict__ mat, int n, int M,
-                                                            int L, float f0, const float* __restrict__ d_out /*[n][4][3]*/,
-                                                            float* __restrict__ d_mat /*[n][7]*/, float* __restrict__ d_lgt /*[M][7], atomics*/) {
+                                                            const float* __restrict__ view, const float* __restrict__ mat,
+                                                            const float* __restrict__ cs, int n, int M, int L, float f0,
+                                                            const float* __restrict__ d_out /*[n][4][3]*/, float* __restrict__ d_mat /*[n][7]*/,
+                                                            float* __restrict__ d_cs, float* __restrict__ d_lgt /*[M][7], atomics*/) {
     __shared__ float red[4][kSgBwdSlots * 64 * 7];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pt0 = blockIdx.x * kSgBwdPts;
@@ -330,10 +369,8 @@ __global__ void __launch_bounds__(256) sg_render_bwd_kernel(const float* __restr
 #pragma unroll
         for (int i = 0; i < 12; ++i) co[i] = d_out[pt * 12 + i];
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            gm[i] = 0.0f;
-            m[i] = mat[pt * 7 + i];
-        }
+        for (int i = 0; i < 7; ++i) gm[i] = 0.0f;
+        load_material<HEADS>(mat, cs, pt, m);
         for (int j = lane; j < L; j += 64) {            // constants (IndirectLight is frozen): the material parameters' share only
             float sg[7], gs[7];
 #pragma unroll
@@ -341,12 +378,10 @@ __global__ void __launch_bounds__(256) sg_render_bwd_kernel(const float* __restr
             lobe_adjoint<1>(pc, m, sg, 1.0f, co + 6, gm, gs);
         }
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            float v = gm[i];
+        for (int i = 0; i < 7; ++i)
 #pragma unroll
-            for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
-            if (lane == 0) d_mat[pt * 7 + i] = v;
-        }
+            for (int s = 32; s >= 1; s >>= 1) gm[i] += __shfl_xor(gm[i], s, 64);
+        if (lane == 0) store_material_grad<HEADS, false>(gm, pt, d_mat, d_cs);
     }
     // (d_mat of a wave's points holds the indirect share now; the same wave adds the direct lobes' share below)
     // ---- the direct lobes, kSgBwdSlots x 64 at a time
@@ -364,10 +399,8 @@ __global__ void __launch_bounds__(256) sg_render_bwd_kernel(const float* __restr
 #pragma unroll
             for (int i = 0; i < 6; ++i) co[i] = d_out[pt * 12 + i];
 #pragma unroll
-            for (int i = 0; i < 7; ++i) {
-                gm[i] = 0.0f;
-                m[i] = mat[pt * 7 + i];
-            }
+            for (int i = 0; i < 7; ++i) gm[i] = 0.0f;
+            load_material<HEADS>(mat, cs, pt, m);
 #pragma unroll
             for (int k = 0; k < kSgBwdSlots; ++k) {
                 const int j = base + k * 64 + lane;
@@ -381,12 +414,10 @@ __global__ void __launch_bounds__(256) sg_render_bwd_kernel(const float* __restr
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 7; ++i) {
-                float v = gm[i];
+            for (int i = 0; i < 7; ++i)
 #pragma unroll
-                for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
-                if (lane == 0) d_mat[pt * 7 + i] += v;
-            }
+                for (int s = 32; s >= 1; s >>= 1) gm[i] += __shfl_xor(gm[i], s, 64);
+            if (lane == 0) store_material_grad<HEADS, true>(gm, pt, d_mat, d_cs);
         }
         __syncthreads();     // (red: the previous sweep's readers are done)
 #pragma unroll
@@ -405,33 +436,63 @@ __global__ void __launch_bounds__(256) sg_render_bwd_kernel(const float* __restr
 
 using namespace fneus;
 
-extern "C" int fneus_sg_render_fwd(const float* lgt_sgs, const float* indir_sgs, const float* vis, const float* normal,
-                                   const float* view, const float* material, int n_pts, int n_direct, int n_indirect,
-                                   float specular_reflectance, float* out, fneus_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+static int sg_fwd(const float* lgt_sgs, const float* indir_sgs, const float* vis, const float* normal, const float* view,
+                  const float* material, const float* cs, bool heads, int n_pts, int n_direct, int n_indirect, float f0, float* out,
+                  hipStream_t stream) {
     fneus::clear_status();
     if (n_pts <= 0) return 0;
-    if (!lgt_sgs || !vis || !normal || !view || !material || !out || (n_indirect > 0 && !indir_sgs)) {
+    if (!lgt_sgs || !vis || !normal || !view || !material || !out || (n_indirect > 0 && !indir_sgs) || (heads && !cs)) {
         set_last_error("fneus_sg_render_fwd: null argument");
         return -2;
     }
-    hipLaunchKernelGGL(sg_render_fwd_kernel, dim3(n_pts), dim3(64), 0, stream, lgt_sgs, indir_sgs, vis, normal, view, material, n_pts,
-                       n_direct, n_indirect, specular_reflectance, out);
+    if (heads) hipLaunchKernelGGL(sg_render_fwd_kernel<true>, dim3(n_pts), dim3(64), 0, stream, lgt_sgs, indir_sgs, vis, normal, view, material, cs,
+                                  n_pts, n_direct, n_indirect, f0, out);
+    else hipLaunchKernelGGL(sg_render_fwd_kernel<false>, dim3(n_pts), dim3(64), 0, stream, lgt_sgs, indir_sgs, vis, normal, view, material, cs,
+                            n_pts, n_direct, n_indirect, f0, out);
     return fneus::launch_status();
 }
 
-extern "C" int fneus_sg_render_bwd(const float* lgt_sgs, const float* indir_sgs, const float* vis, const float* normal,
-                                   const float* view, const float* material, int n_pts, int n_direct, int n_indirect,
-                                   float specular_reflectance, const float* d_out, float* d_material, float* d_lgt_sgs,
-                                   fneus_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+static int sg_bwd(const float* lgt_sgs, const float* indir_sgs, const float* vis, const float* normal, const float* view,
+                  const float* material, const float* cs, bool heads, int n_pts, int n_direct, int n_indirect, float f0,
+                  const float* d_out, float* d_material, float* d_cs, float* d_lgt_sgs, hipStream_t stream) {
     fneus::clear_status();
     if (n_pts <= 0) return 0;
-    if (!lgt_sgs || !vis || !normal || !view || !material || !d_out || !d_material || !d_lgt_sgs || (n_indirect > 0 && !indir_sgs)) {
+    if (!lgt_sgs || !vis || !normal || !view || !material || !d_out || !d_material || !d_lgt_sgs || (n_indirect > 0 && !indir_sgs) ||
+        (heads && (!cs || !d_cs))) {
         set_last_error("fneus_sg_render_bwd: null argument");
         return -2;
     }
-    hipLaunchKernelGGL(sg_render_bwd_kernel, dim3((n_pts + kSgBwdPts - 1) / kSgBwdPts), dim3(256), 0, stream, lgt_sgs, indir_sgs, vis, normal,
-                       view, material, n_pts, n_direct, n_indirect, specular_reflectance, d_out, d_material, d_lgt_sgs);
+    const dim3 grid((n_pts + kSgBwdPts - 1) / kSgBwdPts);
+    if (heads) hipLaunchKernelGGL(sg_render_bwd_kernel<true>, grid, dim3(256), 0, stream, lgt_sgs, indir_sgs, vis, normal, view, material, cs, n_pts,
+                                  n_direct, n_indirect, f0, d_out, d_material, d_cs, d_lgt_sgs);
+    else hipLaunchKernelGGL(sg_render_bwd_kernel<false>, grid, dim3(256), 0, stream, lgt_sgs, indir_sgs, vis, normal, view, material, cs, n_pts,
+                            n_direct, n_indirect, f0, d_out, d_material, d_cs, d_lgt_sgs);
     return fneus::launch_status();
+}
+
+extern "C" int fneus_sg_render_fwd(const float* lgt_sgs, const float* indir_sgs, const float* vis, const float* normal,
+                                   const float* view, const float* material, int n_pts, int n_direct, int n_indirect,
+                                   float specular_reflectance, float* out, fneus_stream_t stream) {
+    return sg_fwd(lgt_sgs, indir_sgs, vis, normal, view, material, nullptr, false, n_pts, n_direct, n_indirect, specular_reflectance, out,
+                  (hipStream_t)stream);
+}
+extern "C" int fneus_sg_render_bwd(const float* lgt_sgs, const float* indir_sgs, const float* vis, const float* normal,
+                                   const float* view, const float* material, int n_pts, int n_direct, int n_indirect,
+                                   float specular_reflectance, const float* d_out, float* d_material, float* d_lgt_sgs,
+                                   fneus_stream_t stream) {
+    return sg_bwd(lgt_sgs, indir_sgs, vis, normal, view, material, nullptr, false, n_pts, n_direct, n_indirect, specular_reflectance, d_out,
+                  d_material, nullptr, d_lgt_sgs, (hipStream_t)stream);
+}
+extern "C" int fneus_sg_render_heads_fwd(const float* lgt_sgs, const float* indir_sgs, const float* vis, const float* normal,
+                                         const float* view, const float* brdf, const float* cs, int n_pts, int n_direct, int n_indirect,
+                                         float specular_reflectance, float* out, fneus_stream_t stream) {
+    return sg_fwd(lgt_sgs, indir_sgs, vis, normal, view, brdf, cs, true, n_pts, n_direct, n_indirect, specular_reflectance, out,
+                  (hipStream_t)stream);
+}
+extern "C" int fneus_sg_render_heads_bwd(const float* lgt_sgs, const float* indir_sgs, const float* vis, const float* normal,
+                                         const float* view, const float* brdf, const float* cs, int n_pts, int n_direct, int n_indirect,
+                                         float specular_reflectance, const float* d_out, float* d_brdf, float* d_cs, float* d_lgt_sgs,
+                                         fneus_stream_t stream) {
+    return sg_bwd(lgt_sgs, indir_sgs, vis, normal, view, brdf, cs, true, n_pts, n_direct, n_indirect, specular_reflectance, d_out, d_brdf,
+                  d_cs, d_lgt_sgs, (hipStream_t)stream);
 }

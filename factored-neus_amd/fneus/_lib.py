@@ -139,6 +139,8 @@ def _load():
         "fneus_outside_alpha_bwd": (C.c_int, [vp, vp, vp, vp, vp, l, vp, vp, vp]),
         "fneus_sg_render_fwd": (C.c_int, [vp] * 6 + [ip, ip, ip, f, vp, vp]),
         "fneus_sg_render_bwd": (C.c_int, [vp] * 6 + [ip, ip, ip, f, vp, vp, vp, vp]),
+        "fneus_sg_render_heads_fwd": (C.c_int, [vp] * 7 + [ip, ip, ip, f, vp, vp]),
+        "fneus_sg_render_heads_bwd": (C.c_int, [vp] * 7 + [ip, ip, ip, f, vp, vp, vp, vp, vp]),
         "fneus_embed": (C.c_int, [vp, l, ip, ip, vp, vp]),
         "fneus_mlp_forward": (C.c_int, [C.POINTER(FneusMlpJob), ip, vp]),
         "fneus_mlp_backward_input": (C.c_int, [C.POINTER(FneusMlpJob), ip, vp]),

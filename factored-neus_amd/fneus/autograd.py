@@ -355,6 +355,33 @@ class SgRenderFn(torch.autograd.Function):
         return d_lgt, d_mat, None, None, None, None, None
 
 
+class SgRenderHeadsFn(torch.autograd.Function):
+    """SgRenderFn with the material taken straight from the two MLP heads (fneus_sg_render_heads_fwd / _bwd): brdf [n,4] = the
+    BRDF decoder's sigmoid (diffuse albedo, raw roughness), cs [n,1] = net_cs's output -- the five element-wise launches that
+    assembled the [n,7] table (split, 0.9 r + 0.09, expand, cat) and their five in the backward are gone.  direct_lgt: the light
+    table's gradient is accumulated STRAIGHT into `lgt.grad` (the trainers' persistent, per-step cleared buffer: no zero fill,
+    no `grad += temporary`) and autograd gets none for it."""
+
+    @staticmethod
+    def forward(ctx, lgt, brdf, cs, normal, view, vis, ind, f0: float, direct_lgt: bool):
+        t = lambda x: None if x is None else x.detach().float().contiguous()
+        lgt_c, brdf_c, cs_c, normal, view, vis, ind = t(lgt), t(brdf), t(cs), t(normal), t(view), t(vis), t(ind)
+        out = ops.sg_render_heads_fwd(lgt_c, ind, vis, normal, view, brdf_c, cs_c, f0)
+        ctx.f0, ctx.has_ind = f0, ind is not None
+        ctx.lgt_param = lgt if direct_lgt else None
+        ctx.save_for_backward(*([lgt_c, brdf_c, cs_c, normal, view, vis] + ([ind] if ind is not None else [])))
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        sv = ctx.saved_tensors
+        lgt, brdf, cs, normal, view, vis = sv[:6]
+        ind = sv[6] if ctx.has_ind else None
+        into = None if ctx.lgt_param is None else ctx.lgt_param.grad
+        d_brdf, d_cs, d_lgt = ops.sg_render_heads_bwd(lgt, ind, vis, normal, view, brdf, cs, ctx.f0, d_out.contiguous(), into)
+        return (None if into is not None else d_lgt), d_brdf, d_cs, None, None, None, None, None, None
+
+
 class Stage2LossFn(torch.autograd.Function):
     """fneus_stage2_loss: the two L1 terms of a stage-2 step over the rays with a hit and their gradients (lvis.py:164-170)"""
 

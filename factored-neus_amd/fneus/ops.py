@@ -1233,14 +1233,39 @@ def sg_render_fwd(lgt, ind, vis, normal, view, mat, f0: float):
     return out
 
 
-def sg_render_bwd(lgt, ind, vis, normal, view, mat, f0: float, d_out):
+def sg_render_bwd(lgt, ind, vis, normal, view, mat, f0: float, d_out, d_lgt=None):
+    """-> d_mat [n,7], d_lgt [M,7].  d_lgt given: the light table's gradient is ACCUMULATED into it (a persistent, cleared buffer)"""
     n, M = mat.shape[0], lgt.shape[0]
     L = 0 if ind is None else ind.shape[1]
     d_mat = torch.empty(n, 7, dtype=torch.float32, device=mat.device)
-    d_lgt = torch.zeros(M, 7, dtype=torch.float32, device=mat.device)
+    if d_lgt is None:
+        d_lgt = torch.zeros(M, 7, dtype=torch.float32, device=mat.device)
     _launch("fneus_sg_render_bwd", lib.fneus_sg_render_bwd, _ptr(lgt), _ptr(ind), _ptr(vis), _ptr(normal), _ptr(view), _ptr(mat), n, M, L,
             float(f0), _ptr(d_out), _ptr(d_mat), _ptr(d_lgt), _stream())
     return d_mat, d_lgt
+
+
+def sg_render_heads_fwd(lgt, ind, vis, normal, view, brdf, cs, f0: float):
+    """sg_render_fwd with the material taken from the two MLP heads' outputs: brdf [n,4] (diffuse albedo, raw roughness), cs [n,1]"""
+    n, M = brdf.shape[0], lgt.shape[0]
+    L = 0 if ind is None else ind.shape[1]
+    out = torch.empty(n, 4, 3, dtype=torch.float32, device=brdf.device)
+    _launch("fneus_sg_render_heads_fwd", lib.fneus_sg_render_heads_fwd, _ptr(lgt), _ptr(ind), _ptr(vis), _ptr(normal), _ptr(view), _ptr(brdf),
+            _ptr(cs), n, M, L, float(f0), _ptr(out), _stream())
+    return out
+
+
+def sg_render_heads_bwd(lgt, ind, vis, normal, view, brdf, cs, f0: float, d_out, d_lgt=None):
+    """-> d_brdf [n,4], d_cs [n,1], d_lgt [M,7] (accumulated into `d_lgt` when given)"""
+    n, M = brdf.shape[0], lgt.shape[0]
+    L = 0 if ind is None else ind.shape[1]
+    d_brdf = torch.empty(n, 4, dtype=torch.float32, device=brdf.device)
+    d_cs = torch.empty(n, 1, dtype=torch.float32, device=brdf.device)
+    if d_lgt is None:
+        d_lgt = torch.zeros(M, 7, dtype=torch.float32, device=brdf.device)
+    _launch("fneus_sg_render_heads_bwd", lib.fneus_sg_render_heads_bwd, _ptr(lgt), _ptr(ind), _ptr(vis), _ptr(normal), _ptr(view), _ptr(brdf),
+            _ptr(cs), n, M, L, float(f0), _ptr(d_out), _ptr(d_brdf), _ptr(d_cs), _ptr(d_lgt), _stream())
+    return d_brdf, d_cs, d_lgt
 
 
 def embed(x, n_freqs: int):

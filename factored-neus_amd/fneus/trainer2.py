@@ -40,25 +40,6 @@ def stage2_loss(out: dict, reduce=None):
     return {"loss": lvis_loss + radiance_loss, "lvis_loss": lvis_loss, "trace_radiance_loss": radiance_loss}
 
 
-class blas_scope:
-    """torch.backends.cuda.preferred_blas_library(name) for the duration of a block; the previous setting comes back behind it
-    (name None: nothing is touched)"""
-
-    def __init__(self, name):
-        self.name, self.prev = name, None
-
-    def __enter__(self):
-        if self.name is not None:
-            self.prev = torch.backends.cuda.preferred_blas_library()
-            torch.backends.cuda.preferred_blas_library(self.name)
-        return self
-
-    def __exit__(self, *exc):
-        if self.name is not None and self.prev is not None:
-            torch.backends.cuda.preferred_blas_library(self.prev)
-        return False
-
-
 class Stage2Trainer:
     def __init__(self, device, model_conf: Optional[dict] = None, prec: int = ops.PREC_PARITY, lr: float = 5e-4, seed: int = 0,
                  synthetic_init: bool = True, sdf_kwargs: Optional[dict] = None, use_graph: bool = False,
@@ -109,15 +90,8 @@ class Stage2Trainer:
     def _init_step_mode(self, use_graph: bool, lr: float, distributed: bool = False):
         import os
         from fneus.seggraph import SegmentedStep
-        # The distilled MLPs of stages 2 / 3 are torch modules on <= 2048 rows.  MEASURED (MI355X, PyTorch 2.10 + ROCm 7):
-        # the default BLAS backend (hipBLASLt) runs their weight-gradient products -- [256, 512] x [512, 256] -- as ONE
-        # 256 x 256 macro tile on one CU: 118 us each, 0.36 ms of a stage-3 step; rocBLAS takes 6.7 us
-        # (tools/experiments/r03/blaslt_test.py).  FNEUS_TORCH_BLAS=keep leaves the process-wide setting alone.
-        # The preference is set for the duration of THIS trainer's steps only (blas_scope: saved and restored around every
-        # train_step; a replayed hipGraph holds the kernels it was recorded with): the host application's own matmuls, and
-        # oracle / reference comparisons in the same process, keep the backend they had.
-        blas = os.environ.get("FNEUS_TORCH_BLAS", "cublas")
-        self._blas = blas if (blas != "keep" and self.device.type == "cuda") else None
+        # (the distilled MLPs of stages 2 / 3 run on the fneus_mlp_* kernels since round 5 -- models/fields.py seq_group: there is no
+        # library GEMM left in a step, and the BLAS-backend preference rounds 3 / 4 set around every step is gone with it)
         self.graph_error = None             # why a graph capture fell back to eager launches, if it did
         self.distributed = bool(distributed)
         self.reduce = None
@@ -281,10 +255,6 @@ class Stage2Trainer:
     def train_step(self, data: torch.Tensor, near=None, far=None, u_theta=None, u_z=None, z_vals_override=None):
         """data [B,10] (dataset.py:133-151); near / far None: unit-sphere bounds.  -> loss dict, or None when no ray of
         the batch hits the surface (the reference skips such a batch, lvis.py:160-161)"""
-        with blas_scope(self._blas):
-            return self._train_step(data, near, far, u_theta, u_z, z_vals_override)
-
-    def _train_step(self, data, near, far, u_theta, u_z, z_vals_override):
         if self.use_graph and near is None and u_theta is None:
             return self._graph_step(data)
         if self.distributed:

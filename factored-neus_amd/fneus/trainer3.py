@@ -99,11 +99,6 @@ class Stage3Trainer:
 
     def train_step(self, data: torch.Tensor, near=None, far=None, u_theta=None, u_phi=None, z_vals_override=None):
         """data [B,10] (dataset.py:133-151).  -> loss dict, or None when no ray hits the surface (mateIllu.py:156)"""
-        from fneus.trainer2 import blas_scope
-        with blas_scope(self._blas):        # (the BLAS backend of the torch-side MLPs: for the duration of the step only)
-            return self._train_step(data, near, far, u_theta, u_phi, z_vals_override)
-
-    def _train_step(self, data, near, far, u_theta, u_phi, z_vals_override):
         if self.use_graph and near is None and u_theta is None:
             return self._graph_step(data)
         if self.distributed:

@@ -226,15 +226,19 @@ FUSED_SG = True      # stage 3 on fneus_sg_render_fwd / _bwd (one launch each wa
 
 
 def _render_with_all_sg_fused(points, normal, viewdirs, lgtSGs, f0: float, specular_albedo, roughness, diffuse_albedo,
-                              lvis_network, indir_lgtSGs, u_theta, u_phi, point_mask=None, want=None):
+                              lvis_network, indir_lgtSGs, u_theta, u_phi, point_mask=None, want=None, heads=None):
     """render_with_all_sg on the fused kernels: visibility (fneus_lvis_visibility), then every (point, lobe) pair of the 128
     direct and the 24 indirect SGs in one launch; the clamps of integrate_rgb (:277), of render_with_sg (:440) and the tone
-    mapping (:306-309) are element-wise ops on [n, 3] tensors"""
-    from fneus.autograd import SgRenderFn
+    mapping (:306-309) are element-wise ops on [n, 3] tensors.  heads = (brdf [n,4], cs [n,1], direct_lgt): the material as the
+    two MLP heads hand it over (fneus.autograd.SgRenderHeadsFn) -- roughness / albedos are then not read here"""
+    from fneus.autograd import SgRenderFn, SgRenderHeadsFn
     vis = get_diffuse_visibility(points, normal, lvis_network, None, None, nsamp=32, u_theta=u_theta, u_phi=u_phi,
                                  point_mask=point_mask, lgt_sgs=lgtSGs)           # [M, n], detached
-    mat = torch.cat([roughness, diffuse_albedo, specular_albedo], dim=-1)         # [n, 7]
-    sums = SgRenderFn.apply(lgtSGs, mat, normal, viewdirs, vis, indir_lgtSGs, f0)
+    if heads is not None:
+        sums = SgRenderHeadsFn.apply(lgtSGs, heads[0], heads[1], normal, viewdirs, vis, indir_lgtSGs, f0, bool(heads[2]))
+    else:
+        mat = torch.cat([roughness, diffuse_albedo, specular_albedo], dim=-1)     # [n, 7]
+        sums = SgRenderFn.apply(lgtSGs, mat, normal, viewdirs, vis, indir_lgtSGs, f0)
     if want is not None and want <= {"rgb"}:           # the training step: the colour alone, clamps and tone mapping in one launch
         from fneus.autograd import SgCombineFn
         return {"specular_loss": 0, "diffuse_loss": 0, "rgb": SgCombineFn.apply(sums, indir_lgtSGs is not None)}
@@ -252,16 +256,21 @@ def _render_with_all_sg_fused(points, normal, viewdirs, lgtSGs, f0: float, specu
     return ret
 
 
+def _fused_sg_applies(points, lvis_network, specular_reflectance_value, indir_lgtSGs):
+    return (FUSED_SG and points.is_cuda and lvis_network is not None and specular_reflectance_value is not None
+            and (indir_lgtSGs is None or not indir_lgtSGs.requires_grad))
+
+
 def render_with_all_sg(points, normal, viewdirs, lgtSGs, specular_reflectance, specular_albedo, roughness, diffuse_albedo,
                        gt_specular_linear=None, lvis_network=None, indir_lgtSGs=None, u_theta=None, u_phi=None,
-                       specular_reflectance_value=None, point_mask=None, want=None):
+                       specular_reflectance_value=None, point_mask=None, want=None, heads=None):
     """inverRender.py:286-311: direct light (with visibility) + indirect light, tone mapped.  point_mask [n] bool (fixed-shape
     step): rows marked False are placeholders whose results the caller discards -- their visibility is not evaluated.
     want: set of result keys the caller reads (None = all); the others may be left out"""
-    if (FUSED_SG and points.is_cuda and lvis_network is not None and specular_reflectance_value is not None
-            and (indir_lgtSGs is None or not indir_lgtSGs.requires_grad)):
+    if _fused_sg_applies(points, lvis_network, specular_reflectance_value, indir_lgtSGs):
         return _render_with_all_sg_fused(points, normal, viewdirs, lgtSGs, float(specular_reflectance_value), specular_albedo,
-                                         roughness, diffuse_albedo, lvis_network, indir_lgtSGs, u_theta, u_phi, point_mask, want)
+                                         roughness, diffuse_albedo, lvis_network, indir_lgtSGs, u_theta, u_phi, point_mask, want,
+                                         heads=heads)
     n = normal.shape[0]
     ret = render_with_sg(points, normal, viewdirs, lgtSGs[None].expand(n, -1, -1), specular_reflectance, specular_albedo,
                          roughness, diffuse_albedo, gt_specular_linear, lvis_network=lvis_network, u_theta=u_theta, u_phi=u_phi)
@@ -359,19 +368,33 @@ class EnvmapMaterialNetwork(nn.Module):
         # are the last activations of the encoder and the decoder there (the latent code is read through its sigmoid only).
         act_latent, cs = seq_group([(self.brdf_encoder_layer, brdf_in, self, ops.ACT_SIGMOID), (self.net_cs, cs_in, self)])
         brdf = seq_group([(self.brdf_decoder_layer, act_latent, self, ops.ACT_SIGMOID)])[0]
-        diffuse_albedo, rough_raw = torch.split(brdf, [3, 1], dim=-1)      # (split: its backward is one concatenation)
-        roughness = rough_raw * 0.9 + 0.09
         loss = 0.01 * self.kl_divergence(0.05, act_latent, point_mask, activated=True)
-        specular_albedo = cs.expand(-1, 3)
+        # A training step reads the rendered colour alone: the SG kernels then take the two heads' outputs as they are (roughness =
+        # 0.9 raw + 0.09 and the three equal specular channels inside the launch) and write the light table's gradient straight into
+        # its persistent buffer; the [n, 7] material table and `roughness` exist only for callers that ask for them.
+        lean = (want is not None and "roughness" not in want and _fused_sg_applies(points, lvis_network, self.specular_reflectance_value, indiLgt)
+                and brdf.dtype == torch.float32)
+        heads = None
+        if lean:
+            direct_lgt = (getattr(self, "direct_grads", False) and torch.is_grad_enabled() and self.lgtSGs.requires_grad
+                          and self.lgtSGs.grad is not None and self.lgtSGs.grad.is_contiguous())
+            heads = (brdf, cs, direct_lgt)
+            diffuse_albedo = roughness = specular_albedo = None
+        else:
+            diffuse_albedo, rough_raw = torch.split(brdf, [3, 1], dim=-1)      # (split: its backward is one concatenation)
+            roughness = rough_raw * 0.9 + 0.09
+            specular_albedo = cs.expand(-1, 3)
         ret = render_with_all_sg(points, n, view_dirs, self.lgtSGs, self.specular_reflectance, specular_albedo, roughness,
                                  diffuse_albedo, gt_specular_linear, lvis_network=lvis_network, indir_lgtSGs=indiLgt,
                                  u_theta=u_theta, u_phi=u_phi, specular_reflectance_value=self.specular_reflectance_value,
-                                 point_mask=point_mask, want=want)
-        ret.update({"roughness": roughness, "encoder_loss": loss, "smooth_loss": 0.0})
+                                 point_mask=point_mask, want=want, heads=heads)
+        ret.update({"encoder_loss": loss, "smooth_loss": 0.0})
+        if not lean:
+            ret["roughness"] = roughness
         if want is None or "diffuse_albedo" in want:
-            ret["diffuse_albedo"] = tonemap_clip(diffuse_albedo)
+            ret["diffuse_albedo"] = tonemap_clip(brdf[:, :3] if diffuse_albedo is None else diffuse_albedo)
         if want is None or "specular_albedo" in want:
-            ret["specular_albedo"] = tonemap_clip(specular_albedo)
+            ret["specular_albedo"] = tonemap_clip(cs.expand(-1, 3) if specular_albedo is None else specular_albedo)
         return ret
 
     def get_light(self):

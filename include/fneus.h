@@ -442,6 +442,15 @@ int fneus_sg_render_fwd(const float* lgt_sgs, const float* indir_sgs, const floa
 int fneus_sg_render_bwd(const float* lgt_sgs, const float* indir_sgs, const float* vis, const float* normal, const float* view,
                         const float* material, int n_pts, int n_direct, int n_indirect, float specular_reflectance,
                         const float* d_out, float* d_material, float* d_lgt_sgs, fneus_stream_t stream);
+/* The same with the material taken straight from the outputs of EnvmapMaterialNetwork's two heads: brdf [n_pts][4] = (diffuse albedo
+ * rgb, raw roughness) -- the sigmoid of the BRDF decoder -- and cs [n_pts] (net_cs): roughness = 0.9 raw + 0.09 (inverRender.py:557),
+ * specular albedo = cs in all three channels (:560).  The backward returns d_brdf [n_pts][4] and d_cs [n_pts]. */
+int fneus_sg_render_heads_fwd(const float* lgt_sgs, const float* indir_sgs, const float* vis, const float* normal, const float* view,
+                              const float* brdf, const float* cs, int n_pts, int n_direct, int n_indirect, float specular_reflectance,
+                              float* out, fneus_stream_t stream);
+int fneus_sg_render_heads_bwd(const float* lgt_sgs, const float* indir_sgs, const float* vis, const float* normal, const float* view,
+                              const float* brdf, const float* cs, int n_pts, int n_direct, int n_indirect, float specular_reflectance,
+                              const float* d_out, float* d_brdf, float* d_cs, float* d_lgt_sgs, fneus_stream_t stream);
 /* The two L1 terms of a stage-2 step (lvis.py:164-170) over the n primary rays, 4 secondary rays each: out[0] = sum over rays
  * with a hit of |gt_lvis - pre_lvis| / (4 n_hit + 1e-6), out[1] = the same of the traced radiance [n][4][3] / (12 n_hit + 1e-6),
  * out[2] = n_hit; d_pre_lvis [n][4], d_pre_rad [n][4][3]: gradients of out[0] / out[1] (zero rows without a hit). */

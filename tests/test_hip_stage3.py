@@ -404,6 +404,45 @@ def test_fused_indirect_light_output_transform():
     assert (got - ref).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item())
 
 
+def test_sg_render_from_the_heads_equals_the_material_table():
+    """fneus_sg_render_heads_fwd / _bwd (brdf [n,4] and cs [n,1] as the two MLP heads hand them over) against the [n,7] material
+    table assembled with torch ops (inverRender.py:557-560) through fneus_sg_render_fwd / _bwd: the same sums and the same
+    gradients to rounding (0.9 x and the sum of three channels are taken in another order); the light table's gradient accumulated
+    into a persistent buffer equals the returned one"""
+    from fneus import synth
+    from fneus.autograd import SgRenderFn, SgRenderHeadsFn
+    dev = torch.device(DEV)
+    g = torch.Generator().manual_seed(12)
+    n, M, L = 300, 128, 24
+    lgt = T(synth.mateillu_state_dict(32)["lgtSGs"]).to(dev)
+    unit = lambda t: t / t.norm(dim=-1, keepdim=True)
+    normal, view = unit(torch.randn(n, 3, generator=g)).to(dev), unit(torch.randn(n, 3, generator=g)).to(dev)
+    vis = torch.rand(M, n, generator=g).to(dev)
+    ind = torch.rand(n, L, 7, generator=g).to(dev)
+    ind[..., 3] = ind[..., 3] * 20 + 1
+    brdf0, cs0 = torch.rand(n, 4, generator=g).to(dev) * 0.9 + 0.05, torch.rand(n, 1, generator=g).to(dev) * 0.9 + 0.05
+    cot = torch.randn(n, 4, 3, generator=g).to(dev)
+    la, ba, ca = lgt.clone().requires_grad_(True), brdf0.clone().requires_grad_(True), cs0.clone().requires_grad_(True)
+    mat = torch.cat([ba[:, 3:4] * 0.9 + 0.09, ba[:, :3], ca.expand(-1, 3)], dim=-1)
+    sums_a = SgRenderFn.apply(la, mat, normal, view, vis, ind, 0.02)
+    (sums_a * cot).sum().backward()
+    lb, bb, cb = lgt.clone().requires_grad_(True), brdf0.clone().requires_grad_(True), cs0.clone().requires_grad_(True)
+    sums_b = SgRenderHeadsFn.apply(lb, bb, cb, normal, view, vis, ind, 0.02, False)
+    (sums_b * cot).sum().backward()
+    print(f"  heads vs table: sums differ by {(sums_a - sums_b).abs().max().item():.2e} of {sums_a.abs().max().item():.2e}")
+    assert (sums_a - sums_b).abs().max().item() <= 2e-6 * sums_a.abs().max().item()        # observed 4e-7
+    for a, b in ((ba.grad, bb.grad), (ca.grad, cb.grad)):
+        print(f"  heads vs table: gradient differs by {(a - b).abs().max().item():.2e} of {a.abs().max().item():.2e}")
+        assert (a - b).abs().max().item() <= 1e-5 * a.abs().max().item()                       # observed 2.7e-6
+    assert (la.grad - lb.grad).abs().max().item() <= 1e-5 * la.grad.abs().max().item()     # (atomics: the order of arrival)
+    lc = lgt.clone().requires_grad_(True)
+    lc.grad = torch.zeros_like(lc)
+    bc, cc = brdf0.clone().requires_grad_(True), cs0.clone().requires_grad_(True)
+    (SgRenderHeadsFn.apply(lc, bc, cc, normal, view, vis, ind, 0.02, True) * cot).sum().backward()
+    assert (lc.grad - lb.grad).abs().max().item() <= 1e-5 * lb.grad.abs().max().item()
+    assert torch.equal(bc.grad, bb.grad) and torch.equal(cc.grad, cb.grad)
+
+
 def test_sg_combine_equals_the_elementwise_tail():
     """fneus_sg_combine_fwd / _bwd against the clamps, sums and tone mapping it replaces (inverRender.py:277, 440, 306-309), values
     bit for bit, gradients through torch.clamp's closed-interval rule; sums far outside [0, 1], on its ends and a NaN"""

@@ -24,7 +24,7 @@ bs = synthetic_batches(4, 512, dev)
 for b in bs[:3]:
     step(b)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=False) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
     step(bs[3])
     torch.cuda.synchronize()
 evs = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CPU and e.name.startswith("aten::")]
@@ -32,9 +32,11 @@ evs = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CP
 out = []
 for e in evs:
     if e.kernels:
-        out.append((e.time_range.start, e.name, [k.name[:60] for k in e.kernels], e.input_shapes))
+        site = next((f for f in (e.stack or []) if "/factored-neus_amd/" in f or "/bench.py" in f), "")
+        site = site.split("/factored-neus_amd/")[-1][:60]
+        out.append((e.time_range.start, e.name, [k.name[:60] for k in e.kernels], e.input_shapes, site))
 out.sort()
 seen = set()
-for t, name, ks, shp in out:
-    print(f"{name:28s} {str(shp)[:70]:72s} {ks[0]}")
+for t, name, ks, shp, site in out:
+    print(f"{name:26s} {str(shp)[:50]:52s} {site:62s} {ks[0][:40]}")
 print(len(out), "aten ops with kernels")
