@@ -586,7 +586,13 @@ class _MlpGroupFn(torch.autograd.Function):
                 ops.mlp_forward(jobs[i:i + ops.MLP_MAX_JOBS])
         ctx.save_for_backward(*x2s, *[y for net in ys for y in net])
         ctx.nets, ctx.parts, ctx.shapes = nets, [(pos, wb) for pos, _, wb in parts], [x.shape for _, x, _ in parts]
-        return tuple(net[-1].reshape(*x.shape[:-1], net[-1].shape[-1]) for net, (_, x, _) in zip(ys, parts))
+        outs = tuple(net[-1].reshape(*x.shape[:-1], net[-1].shape[-1]) for net, (_, x, _) in zip(ys, parts))
+        # a frozen network on a constant input (stage 3's IndirectLight riding along with the trained ones): nothing to differentiate
+        frozen = [o for o, (_, x, wb) in zip(outs, parts) if not any(t is not None and t.requires_grad for t in (x, *wb))]
+        if frozen:
+            ctx.mark_non_differentiable(*frozen)
+        ctx.set_materialize_grads(False)       # (no zero fill for the cotangent of an output nobody differentiates)
+        return outs
 
     @staticmethod
     def backward(ctx, *douts):
@@ -600,16 +606,26 @@ class _MlpGroupFn(torch.autograd.Function):
         need = lambda i: ctx.needs_input_grad[1 + i]
         delta = [[None] * len(acts) for acts, _ in nets]
         for n, (acts, _) in enumerate(nets):
-            delta[n][-1] = douts[n].reshape(x2s[n].shape[0], ys[n][-1].shape[1]).contiguous()
+            pos, wb = ctx.parts[n]
+            if douts[n] is not None:
+                delta[n][-1] = douts[n].reshape(x2s[n].shape[0], ys[n][-1].shape[1]).contiguous()
+            elif any(need(pos + i) for i in range(1 + len(wb))):       # an unused output of a network that is differentiated
+                delta[n][-1] = torch.zeros_like(ys[n][-1])
         top = lambda n, l: nets[n][0][l] if l == len(nets[n][0]) - 1 else ops.ACT_NONE   # below the top layer dy is the pre-activation's gradient
-        # input gradients, top layers first: step t takes layer L - 1 - t of every network
+        # input gradients, top layers first: step t takes layer L - 1 - t of every network, down to the lowest layer that still
+        # has something to differentiate below it (`low`: 0 = the input itself; L = nothing at all, a frozen network)
+        low = []
+        for n, (acts, _) in enumerate(nets):
+            pos, wb = ctx.parts[n]
+            wanted = [l for l in range(len(acts)) if need(pos + 1 + 2 * l) or (wb[2 * l + 1] is not None and need(pos + 2 + 2 * l))]
+            low.append(-1 if need(pos) else (wanted[0] if wanted else len(acts)))
         for t in range(max(len(acts) for acts, _ in nets)):
             jobs, outs = [], []
             for n, (acts, _) in enumerate(nets):
                 l = len(acts) - 1 - t
                 pos, wb = ctx.parts[n]
                 rows = x2s[n].shape[0]
-                if l < 0 or (l == 0 and not need(pos)):
+                if l < 0 or l <= low[n]:
                     continue
                 w = wb[2 * l].detach()
                 dx = torch.empty(rows, w.shape[1], dtype=torch.float32, device=w.device)
@@ -774,6 +790,17 @@ class Lvis(nn.Module):
         return out
 
 
+class DeferredIndirectLight:
+    """IndirectLight(pts) that has not run yet (IndirectLight.deferred)"""
+
+    def __init__(self, net, pts):
+        self.net, self.pts = net, pts
+
+    def resolve(self):
+        with torch.no_grad():
+            return self.net(self.pts)
+
+
 class IndirectLight(nn.Module):
     """Stage-2 indirect light as 24 spherical Gaussians per point (fields.py:372-413): 63 -> 512 x 4 -> 144 -> [n, 24, 7] =
     (lobe axis from two sigmoid angles, sharpness 30 sigmoid + 0.1, relu amplitude x 3).  state_dict keys `indi.{0,..,8}`."""
@@ -795,6 +822,15 @@ class IndirectLight(nn.Module):
         """raw: the MLP's output [n, 6 L] (`self.indi` on `self.embedview_fn_pts(pts)`)"""
         raw = raw.reshape(-1, self.num_lgt_sgs, 6)
         return _IndirIllumFn.apply(raw.contiguous(), sample_dirs.detach().float().contiguous())
+
+    def deferred(self, pts):
+        """the lobes of `pts`, not evaluated yet: a caller that runs other MLPs on the same points (EnvmapMaterialNetwork.forward)
+        takes this network's layers into the same launches (seq_group) and finishes with sgs_from_raw"""
+        return DeferredIndirectLight(self, pts)
+
+    def sgs_from_raw(self, raw):
+        """the output transform (fields.py:395-413) of the MLP's output [n, 6 L], no gradient -> [n, L, 7]"""
+        return ops.indir_sgs(raw.detach().reshape(-1, self.num_lgt_sgs, 6).contiguous())
 
     def forward(self, pts):
         out = _seq_direct(self.indi, self.embedview_fn_pts(pts), self).reshape(-1, self.num_lgt_sgs, 6)

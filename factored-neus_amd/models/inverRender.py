@@ -20,7 +20,7 @@ import torch.nn.functional as F
 
 from fneus import ops
 from models.embedder import get_embedder
-from models.fields import _seq_direct, seq_group
+from models.fields import _seq_direct, seq_group, DeferredIndirectLight
 
 TINY_NUMBER = 1e-6
 
@@ -321,6 +321,7 @@ class EnvmapMaterialNetwork(nn.Module):
         sg[num_lgt_sgs // 2:, :3] = lobes
         self.lgtSGs = nn.Parameter(sg, requires_grad=True)
         self.envmap = None
+        self.resolves_deferred_indirect = True      # forward() accepts IndirectLight.deferred(points) as `indiLgt`
         self.stat_reduce = None      # set by the data-parallel trainer: sums the latent-sparsity statistics over the ranks
 
     def kl_divergence(self, rho, rho_hat, point_mask=None, activated=False):
@@ -366,7 +367,14 @@ class EnvmapMaterialNetwork(nn.Module):
         # The encoder and net_cs have their inputs now: layer by layer in the same launches (models/fields.py seq_group; inside
         # Stage3Trainer's own steps the parameter gradients go straight into their persistent buffers).  The two sigmoids of :555-556
         # are the last activations of the encoder and the decoder there (the latent code is read through its sigmoid only).
-        act_latent, cs = seq_group([(self.brdf_encoder_layer, brdf_in, self, ops.ACT_SIGMOID), (self.net_cs, cs_in, self)])
+        items = [(self.brdf_encoder_layer, brdf_in, self, ops.ACT_SIGMOID), (self.net_cs, cs_in, self)]
+        if isinstance(indiLgt, DeferredIndirectLight):        # the frozen IndirectLight of the same points: the same launches
+            same = fused_in and indiLgt.pts.data_ptr() == points.data_ptr() and indiLgt.pts.shape == points.shape
+            items.append((indiLgt.net.indi, brdf_in if same else indiLgt.net.embedview_fn_pts(indiLgt.pts), indiLgt.net))
+        outs = seq_group(items)
+        act_latent, cs = outs[0], outs[1]
+        if isinstance(indiLgt, DeferredIndirectLight):
+            indiLgt = indiLgt.net.sgs_from_raw(outs[2])
         brdf = seq_group([(self.brdf_decoder_layer, act_latent, self, ops.ACT_SIGMOID)])[0]
         loss = 0.01 * self.kl_divergence(0.05, act_latent, point_mask, activated=True)
         # A training step reads the rendered colour alone: the SG kernels then take the two heads' outputs as they are (roughness =

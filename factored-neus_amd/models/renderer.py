@@ -444,7 +444,13 @@ class NeuSRenderer:
                     diffuse, spec = self.refColor_network.heads(surf, f_surf, n_surf, False)
                     ref = self.refColor_network.shade(diffuse, spec)
                     specular_linear = srgb_to_linear(ref["specular_rgb"])
-                indiLgt = self.indiLgt_network(pts_surf)
+                # (a frozen MLP on the points the material network encodes anyway: EnvmapMaterialNetwork.forward takes its layers
+                # into the launches of its own two MLPs when it can)
+                if getattr(self.mateIllu_network, "resolves_deferred_indirect", False) and hasattr(self.indiLgt_network, "deferred") \
+                        and pts_surf.is_cuda and not any(p.requires_grad for p in self.indiLgt_network.parameters()):
+                    indiLgt = self.indiLgt_network.deferred(pts_surf)
+                else:
+                    indiLgt = self.indiLgt_network(pts_surf)
             m = self.mateIllu_network(pts_surf, rays_surf, n_surf, f_surf, specular_linear, indiLgt, self.lvis_network,
                                       u_theta=u_theta, u_phi=u_phi, point_mask=sdf_mask if fixed_shape else None, want=want)
             extra = tuple((k, v) for k, v in (("gt_specular_linear", specular_linear),
