@@ -398,6 +398,8 @@ class Stage2LossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_loss, _d_out):
         d_l, d_r = ctx.saved_tensors
+        if d_loss is ops.UNIT_LOSS_SEED:          # loss.backward(one) inside `with ops.unit_loss_grad(one)`: the factor is 1
+            return d_l.reshape(ctx.shapes[0]), d_r.reshape(ctx.shapes[1]), None, None, None
         return (d_l * d_loss).reshape(ctx.shapes[0]), (d_r * d_loss).reshape(ctx.shapes[1]), None, None, None
 
 
@@ -415,6 +417,8 @@ class Stage3LossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_loss, _d_out):
         (d_rgb,) = ctx.saved_tensors
+        if d_loss is ops.UNIT_LOSS_SEED:          # loss.backward(one) inside `with ops.unit_loss_grad(one)`: the factor is 1
+            return d_rgb, None, None, None
         return d_rgb * d_loss, None, None, None
 
 

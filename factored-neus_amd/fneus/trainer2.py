@@ -228,17 +228,26 @@ class Stage2Trainer:
         if not self.flat_adam:
             self.optimizer.zero_grad(set_to_none=True)
 
+    def _backward(self, loss):
+        """loss.backward() with a persistent unit seed: the fused loss nodes recognise it (ops.unit_loss_grad) and hand their saved
+        gradients on without the multiplication by 1, and autograd does not fill a fresh seed every step"""
+        one = getattr(self, "_seed_one", None)
+        if one is None or one.device != loss.device or one.shape != loss.shape:
+            one = self._seed_one = torch.ones_like(loss)
+        with ops.unit_loss_grad(one):
+            loss.backward(one)
+
     def _backward_and_step(self, loss):
         if self.grads is not None:           # gradients accumulate into the arena views (data parallel: summed in place)
             self.grads.restore_small_grads()
             if not self.flat_adam:           # (FlatAdam leaves them cleared)
                 self.grads.flat.zero_()
-            loss.backward()
+            self._backward(loss)
             if self._seg is not None:
                 self._seg.cut(self.grads.allreduce_sum, self.grads.flat)
         else:
             self._clear_grads()
-            loss.backward()
+            self._backward(loss)
         self.optimizer.step()
 
     def _fixed_shape_step(self, data: torch.Tensor):

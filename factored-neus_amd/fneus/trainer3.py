@@ -81,7 +81,7 @@ class Stage3Trainer:
     from fneus.trainer2 import Stage2Trainer as _S2
     _init_step_mode, set_lr, get_lr, _graph_step = _S2._init_step_mode, _S2.set_lr, _S2.get_lr, _S2._graph_step
     optimizer_state_dict, load_optimizer_state_dict = _S2.optimizer_state_dict, _S2.load_optimizer_state_dict
-    _backward_and_step, _reduce, _clear_grads = _S2._backward_and_step, _S2._reduce, _S2._clear_grads
+    _backward_and_step, _backward, _reduce, _clear_grads = _S2._backward_and_step, _S2._backward, _S2._reduce, _S2._clear_grads
     _direct_grads = _S2._direct_grads
     del _S2
 
@@ -90,7 +90,8 @@ class Stage3Trainer:
         mask = (mask > 0.5).float() if self.mask_weight > 0.0 else torch.ones_like(mask)
         self._direct_grads(True)
         try:
-            out = self.renderer.mateIllu_render(rays_o, rays_d, None, None, fixed_shape=True, keys=("rgb",))
+            # (raw: the loss masks the rays without a hit itself -- single GPU: fneus_stage3_loss; data parallel: `w` of stage3_loss)
+            out = self.renderer.mateIllu_render(rays_o, rays_d, None, None, fixed_shape=True, keys=("rgb",), raw=True)
         finally:
             self._direct_grads(False)
         losses = stage3_loss(out, true_rgb, mask, self.reduce)

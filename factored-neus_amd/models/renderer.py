@@ -399,7 +399,7 @@ class NeuSRenderer:
         return out
 
     def mateIllu_render(self, rays_o, rays_d, near, far, u_theta=None, u_phi=None, fixed_shape=False, z_vals_override=None,
-                        keys=None):
+                        keys=None, raw=False):
         """renderer.py:630-726: stage 3.  Geometry (SDF), the RefColor head, Lvis and IndirectLight are frozen inputs
         (mateIllu.py:83-95 trains the EnvmapMaterialNetwork only): hit points by fneus_ray_hit, normal + feature by K2, the
         diffuse / specular split by the fused RefColor heads, all without stash.  Rows of rays without a hit hold 1.
@@ -409,7 +409,10 @@ class NeuSRenderer:
         u_theta, u_phi [128, 32]: the uniform draws of the visibility sampler (inverRender.py:152-153; tests).
         keys: the per-ray entries the caller reads (None = the reference's whole dict).  The training step reads `rgb` (plus
         `sdf_mask` and the loss terms, which are always there): every other entry is tone mapping, a fill and a select on [B, 3]
-        tensors, a launch each -- 35 launches of the fixed-shape step."""
+        tensors, a launch each -- 35 launches of the fixed-shape step.
+        raw (with fixed_shape): the rows of rays without a hit are left as the networks returned them (placeholders) instead of 1 --
+        for a caller that masks with `sdf_mask` itself (fneus_stage3_loss does): a fill and a select per entry, and the select's
+        backward, are not launched."""
         from models.inverRender import srgb_to_linear
         B = len(rays_o)
         dev = rays_o.device
@@ -428,8 +431,9 @@ class NeuSRenderer:
         extra_keys = ("gt_specular_linear", "gt_diffuse_srgb", "n_out")
         ray_keys = tuple(k for k in ray_keys if need(k))
         one3 = lambda: torch.ones(B, 3, device=dev)
-        out = {k: one3() for k in ray_keys + tuple(k for k in extra_keys if need(k))}
-        if need("roughness"):
+        raw = bool(raw and fixed_shape)
+        out = {} if raw else {k: one3() for k in ray_keys + tuple(k for k in extra_keys if need(k))}
+        if need("roughness") and not raw:
             out["roughness"] = torch.ones(B, 1, device=dev)
         out.update(sdf_mask=sdf_mask, diffuse_loss=0, specular_loss=0, encoder_loss=0, smooth_loss=0)
         if fixed_shape or idx.numel() > 0:
@@ -455,7 +459,10 @@ class NeuSRenderer:
                                       u_theta=u_theta, u_phi=u_phi, point_mask=sdf_mask if fixed_shape else None, want=want)
             extra = tuple((k, v) for k, v in (("gt_specular_linear", specular_linear),
                                               ("gt_diffuse_srgb", None if ref is None else ref["diffuse_rgb"]), ("n_out", n_surf)) if need(k))
-            if fixed_shape:
+            if raw:
+                out.update({k: m[k] for k in ray_keys})
+                out.update(dict(extra))
+            elif fixed_shape:
                 sel = sdf_mask[:, None]
                 for k in ray_keys:
                     out[k] = torch.where(sel, m[k], out[k])
