@@ -34,6 +34,22 @@ def gen_light_z(near, far, n_samples, n, device=None):
     return torch.broadcast_to(z, (n, n_samples))
 
 
+_COARSE_Z = {}
+
+
+def _coarse_depths(n_rays, device):
+    """gen_light_z(0, 1, N_COARSE, n_rays) as a contiguous [n_rays, N_COARSE] tensor, built once per ray count and device: the
+    secondary march's coarse depths are the same 512 values for every ray of every step (a linspace, two element-wise launches
+    and a 4 MB copy per step before); read-only for its users"""
+    key = (int(n_rays), str(device))
+    z = _COARSE_Z.get(key)
+    if z is None:
+        if len(_COARSE_Z) >= 4:
+            _COARSE_Z.clear()
+        z = _COARSE_Z[key] = gen_light_z(0.0, 1.0, N_COARSE, n_rays, device=device).contiguous()
+    return z
+
+
 def near_far_from_sphere(rays_o, rays_d):
     """calLvis.py:16-23"""
     a = torch.sum(rays_d ** 2, dim=-1, keepdim=True)
@@ -90,7 +106,7 @@ def _secondary_march(origins, dirs, sdf_network, color_network, inv_s, trace=Non
     conditioned at flat stretches, so per-sample parity downstream is checked on the reference's own depths, as in stage 1)"""
     R = origins.shape[0]
     dev = origins.device
-    z_coarse = gen_light_z(0.0, 1.0, N_COARSE, R, device=dev).contiguous()
+    z_coarse = _coarse_depths(R, dev)
     # ray_mask [R] (fixed-shape step): the rays of primary rays without a hit are placeholders whose results the caller
     # discards -- the 512-sample march, nine tenths of this function's time, skips them (their coarse SDF reads 1.0)
     coarse_sdf = sdf_network.sdf_samples(RaySamples(origins, dirs, z_coarse.reshape(-1), N_COARSE), ray_mask=ray_mask).reshape(R, N_COARSE)
