@@ -535,6 +535,15 @@ def main():
             result["exact_gradients_gprec3"] = {"value": SAMPLES_PER_STEP * n_g / dt_g, "unit": "ray-samples/s", "ms_per_step": dt_g / n_g * 1e3}
         except Exception as e:
             result["exact_gradients_gprec3"] = {"value": None, "error": repr(e)}
+        try:    # gradient precision 2: lo planes for the two operands of the colour network's output layer alone -- the one product
+            # whose bf16 rounding exceeds the exact mode's bounds (tests/test_hip_render.py runs those bounds on this mode)
+            dt_m, _, _ = run(prec, max(args.steps // 2, 5), 3, profile=False, gprec=2)
+            n_m = max(args.steps // 2, 5)
+            result["mixed_gradients_gprec2"] = {"value": SAMPLES_PER_STEP * n_m / dt_m, "unit": "ray-samples/s", "ms_per_step": dt_m / n_m * 1e3,
+                                                "note": "the gradient bounds of gprec 3 (5e-3 of scale per sampled element, 2e-3 of a tensor's norm) hold; "
+                                                        "hi planes everywhere but zout and slot 3 of u (0.6 KB per sample)"}
+        except Exception as e:
+            result["mixed_gradients_gprec2"] = {"value": None, "error": repr(e)}
         try:    # config 5's per-GPU share of a 2048-ray batch at 8 ranks: 256 rays (womask shape), the strong-scaling point
             import copy
             from fneus.trainer import WMASK_MODEL

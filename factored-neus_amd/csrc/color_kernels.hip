@@ -228,6 +228,8 @@ FN_DEV void color_fwd_tp_body(unsigned char* lds, const unsigned char* blob, con
     const PPLane pl = pp_lane(lane);
     constexpr auto& LY = kColLayout;
     const long tiles = pp_tiles(N);
+    // lo planes: all of them (gradient precision 3: side_lo given), or -- gradient precision 2, side_lo NULL -- slot 3 of u alone: the
+    // operand of the output layer's weight gradient, the one product of this network whose bf16 rounding shows (include/fneus.h)
     const bool lo_planes = TRAIN && PREC == 3 && st.u_lo != nullptr;
     for (long tile = blockIdx.x; tile * 32 < N; tile += gridDim.x) {
         asm volatile("" : "+s"(blob));
@@ -254,14 +256,14 @@ FN_DEV void color_fwd_tp_body(unsigned char* lds, const unsigned char* blob, con
             tp_write_frags<PREC, 3>(frag, lane, 16, bf, 16);
             if constexpr (TRAIN)    // side plane [tiles][4 fragments] (fragment 3 stays zero)
                 frags_to_plane<PREC, 3>(&bf[16], 0, st.side_hi + (size_t)tile * 4 * kFragBytes,
-                                        lo_planes ? st.side_lo + (size_t)tile * 4 * kFragBytes : nullptr, pl, valid);
+                                        (lo_planes && st.side_lo) ? st.side_lo + (size_t)tile * 4 * kFragBytes : nullptr, pl, valid);
         }
         f32x16 acc[2];
         // the 256 features: every wave brings its two tiles (k-steps 4w .. 4w+3 of layer 0)
         load_f32<2>(acc, feat + 32 * t0, 256, nc, h);
         constexpr bool FEAT_PLANE = TRAIN && VAR != VAR_COLOR;     // the surface head keeps its own copy of the features
         tp_exchange_pp<PREC, 2, true>(frag, lane, t0, acc, FEAT_PLANE ? st.feat_hi + (size_t)tile * kPPBlock : nullptr,
-                                      (FEAT_PLANE && lo_planes) ? st.feat_lo + (size_t)tile * kPPBlock : nullptr, pl, valid);
+                                      (FEAT_PLANE && lo_planes && st.feat_lo) ? st.feat_lo + (size_t)tile * kPPBlock : nullptr, pl, valid);
         tp_operands<PREC, 19>(frag, lane, bf);
         // layer 0 (19 k-steps), layers 1..3
 #pragma unroll 1
@@ -275,7 +277,7 @@ FN_DEV void color_fwd_tp_body(unsigned char* lds, const unsigned char* blob, con
             const uint32_t m = relu_mask2(acc);
             if constexpr (TRAIN) reinterpret_cast<uint32_t*>(st.mask + ((size_t)tile * 4 + l) * 64 + lane)[wave] = m;
             tp_exchange_pp<PREC, 2, true>(frag, lane, t0, acc, TRAIN ? st.u_hi + ((size_t)l * tiles + tile) * kPPBlock : nullptr,
-                                          lo_planes ? st.u_lo + ((size_t)l * tiles + tile) * kPPBlock : nullptr, pl, valid);
+                                          (lo_planes && (st.side_lo || l == 3)) ? st.u_lo + ((size_t)l * tiles + tile) * kPPBlock : nullptr, pl, valid);
             tp_operands<PREC, 16>(frag, lane, bf);
         }
         if (wave == 0) {        // output layer: one tile, rows 0..2
@@ -321,7 +323,7 @@ FN_DEV void color_bwd_tp_body(unsigned char* lds, const unsigned char* blob, lon
                 }
             }
             tp_exchange_pp<PREC, 1, true>(frag, lane, 0, z, st.zout_hi + (size_t)tile * 2 * kFragBytes,
-                                          lo_planes ? st.zout_lo + (size_t)tile * 2 * kFragBytes : nullptr, pl, valid);
+                                          (PREC == 3 && st.zout_lo) ? st.zout_lo + (size_t)tile * 2 * kFragBytes : nullptr, pl, valid);
         } else {
             tp_barrier_pair();
         }
@@ -415,7 +417,7 @@ __global__ void __launch_bounds__(256, 2) color_fwd_tph_kernel(const unsigned ch
             tp_write_frags<PREC, 3>(frag + hb * HALF, lane, 16, bs, 16);
             if constexpr (TRAIN)
                 frags_to_plane<PREC, 3>(&bs[16], 0, st.side_hi + (size_t)tile[hb] * 4 * kFragBytes,
-                                        lo_planes ? st.side_lo + (size_t)tile[hb] * 4 * kFragBytes : nullptr, pl, valid[hb]);
+                                        (lo_planes && st.side_lo) ? st.side_lo + (size_t)tile[hb] * 4 * kFragBytes : nullptr, pl, valid[hb]);
         }
         f32x16 acc[2][HB];
 #pragma unroll
@@ -459,7 +461,7 @@ __global__ void __launch_bounds__(256, 2) color_fwd_tph_kernel(const unsigned ch
                 if constexpr (TRAIN) reinterpret_cast<uint32_t*>(st.mask + ((size_t)tile[hb] * 4 + l) * 64 + lane)[wave] = m;
                 const size_t off = ((size_t)l * tiles + tile[hb]) * kPPBlock;
                 uh[hb] = TRAIN ? st.u_hi + off : nullptr;
-                ul[hb] = lo_planes ? st.u_lo + off : nullptr;
+                ul[hb] = (lo_planes && (st.side_lo || l == 3)) ? st.u_lo + off : nullptr;
             }
             tph_exchange<PREC, 2, true, HB, HALF>(frag, lane, t0, acc, uh, ul, pl, valid);
         }
@@ -522,7 +524,7 @@ __global__ void __launch_bounds__(256, 2) color_bwd_tph_kernel(const unsigned ch
                     }
                 }
                 zh[hb] = wave == 0 ? st.zout_hi + (size_t)tile[hb] * 2 * kFragBytes : nullptr;
-                zl[hb] = (wave == 0 && lo_planes) ? st.zout_lo + (size_t)tile[hb] * 2 * kFragBytes : nullptr;
+                zl[hb] = (wave == 0 && PREC == 3 && st.zout_lo) ? st.zout_lo + (size_t)tile[hb] * 2 * kFragBytes : nullptr;
             }
             if (wave == 0) {
                 tph_exchange<PREC, 1, true, HB, HALF>(frag, lane, 0, z, zh, zl, pl, valid);

@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(512, 1) color_fwd_p2_kernel(const unsigned cha
             if constexpr (TRAIN) {
                 if (tile < tiles)
                     frags_to_plane<PREC, 3>(&bs[16], 0, st.side_hi + (size_t)tile * 4 * kFragBytes,
-                                            LO ? st.side_lo + (size_t)tile * 4 * kFragBytes : nullptr, pl, n < N);
+                                            (LO && st.side_lo) ? st.side_lo + (size_t)tile * 4 * kFragBytes : nullptr, pl, n < N);
             }
         }
     };
@@ -135,7 +135,9 @@ __global__ void __launch_bounds__(512, 1) color_fwd_p2_kernel(const unsigned cha
         if constexpr (TRAIN) {
             so.sig = p2_out_rsrc(reinterpret_cast<unsigned char*>(st.mask) + ((size_t)tile * 4 + lV) * 1024, ok ? 8192u : 0u);
             so.hi = p2_out_rsrc(st.u_hi + ((size_t)lV * tiles + tile) * kPPBlock, ok ? 2u * (unsigned)kPPBlock : 0u);
-            if constexpr (LO) so.lo = p2_out_rsrc(st.u_lo + ((size_t)lV * tiles + tile) * kPPBlock, ok ? 2u * (unsigned)kPPBlock : 0u);
+            // (gradient precision 2 -- side_lo NULL -- keeps the lo plane of slot 3 alone: the stores of the other slots fall outside an
+            //  empty buffer and are dropped)
+            if constexpr (LO) so.lo = p2_out_rsrc(st.u_lo + ((size_t)lV * tiles + tile) * kPPBlock, (ok && (st.side_lo || lV == 3)) ? 2u * (unsigned)kPPBlock : 0u);
         }
         return so;
     };

@@ -120,13 +120,15 @@ class SdfValueGradFn(torch.autograd.Function):
                 bgs.append(r)
             elif _record_alive(r["stash"], r["gen"]):
                 _run_nerf_dw(r)
-        if col is not None and (col["n"] != n or col["stash"].gprec != ctx.stash.gprec):
+        # (plane precision: gradient precision 2 is hi planes for everything that rides in this launch)
+        planes = lambda st: 1 if st.gprec == 2 else st.gprec
+        if col is not None and (col["n"] != n or planes(col["stash"]) != planes(ctx.stash)):
             _run_color_dw(col)
             col = None
-        if ref is not None and (col is None or ref["st"][0].gprec != ctx.stash.gprec):
+        if ref is not None and (col is None or planes(ref["st"][0]) != planes(ctx.stash)):
             _run_ref_dw(ref)
             ref = None
-        for r in [r for r in bgs if col is None or r["stash"].gprec != ctx.stash.gprec]:
+        for r in [r for r in bgs if col is None or planes(r["stash"]) != planes(ctx.stash)]:
             _run_nerf_dw(r)
             bgs.remove(r)
         if col is not None:
@@ -213,6 +215,9 @@ class ColorFn(torch.autograd.Function):
             d_feat, d_normal = ops.color_bwd(net.blob, n, prec, d_rgb.contiguous(), rgb, ctx.stash)
             feat_planes = ctx.sdf_ws.cache[("sdf_stash", n, prec, True)].feat
         grad = ws.get(("col_grad", n), lambda: torch.zeros(net.n_params, dtype=torch.float32, device=rgb.device))
+        if ctx.stash.gprec == 2:        # the output layer's product on hi + lo planes (both operands are complete: u_3 from the
+            st = ctx.stash              # forward, zout from the launch above); the others follow in the merged launch as usual
+            ws.get(("col_out_jobs", n, prec, st.zout.data_ptr(), grad.data_ptr()), lambda: ops.color_out_dw_jobs(net, st, grad)).run()
         col = dict(ws=ws, net=net, n=n, prec=prec, stash=ctx.stash, grad=grad, feat_planes=feat_planes, gen=ctx.generation,
                    **{"for": (id(ctx.sdf_ws), ctx.sdf_generation)},
                    key=(feat_planes.data_ptr(), tuple(feat_planes.shape), ctx.stash.zbar.data_ptr(), grad.data_ptr()))

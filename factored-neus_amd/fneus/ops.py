@@ -391,9 +391,15 @@ class PackedNet:
 DEFAULT_GPREC = int(_os.environ.get("FNEUS_GPREC", "1"))
 
 
-def _gprec(prec: int, gprec: Optional[int]) -> int:
+def _gprec(prec: int, gprec: Optional[int], mixed: bool = False) -> int:
+    """gradient precision of a stash: 1 = hi planes, 3 = hi + lo planes, 2 (round 5) = hi planes everywhere but for the ONE product
+    whose bf16 rounding exceeds the exact mode's bounds -- the colour network's output layer (3 x 256: zout^T u_3; see
+    tools/experiments/r05/gprec_tensors.py) -- which keeps its two lo planes.  Only the colour network's stash knows mode 2
+    (mixed=True); for every other stash it is mode 1."""
     g = DEFAULT_GPREC if gprec is None else gprec
-    return 1 if prec == 1 else g
+    if prec == 1:
+        return 1
+    return g if (g != 2 or mixed) else 1
 
 
 class SdfStash:
@@ -548,7 +554,7 @@ class ColStash:
 
     def __init__(self, n: int, device, prec: int, with_feat: bool = False, gprec: Optional[int] = None):
         bf = torch.bfloat16
-        self.n, self.gprec = n, _gprec(prec, gprec)
+        self.n, self.gprec = n, _gprec(prec, gprec, mixed=not with_feat)
         P = 2 if self.gprec == 3 else 1
         self.tiles = (n + 31) // 32
         T = 2 * ((n + 63) // 64)
@@ -565,6 +571,15 @@ class ColStash:
                 continue
             setattr(s, name + "_hi", t[0].data_ptr())
             setattr(s, name + "_lo", t[1].data_ptr() if P == 2 else None)
+        self.u3_lo = self.zout_lo = None
+        if self.gprec == 2:
+            # the output layer's two operands keep their lo planes: slot 3 of u and zout.  The kernels address u_lo like u_hi
+            # ([4][tiles] blocks) and, with side_lo NULL, touch slot 3 alone (include/fneus.h): the pointer is slot 3's plane minus
+            # three slots that do not exist
+            self.u3_lo = torch.empty((T, 16, 64, 8), dtype=bf, device=device)
+            self.zout_lo = torch.zeros((T, 2, 64, 8), dtype=bf, device=device)
+            s.u_lo = self.u3_lo.data_ptr() - 3 * T * 16 * 1024
+            s.zout_lo = self.zout_lo.data_ptr()
         self.c = s
 
 
@@ -640,14 +655,18 @@ class PPOperand:
     """One operand of a fragment-plane product: planes [P, tiles, F, 64, 8] bf16 (P = 1: hi, 2: hi + lo), the first
     fragment `f0` of the operand inside a block and its tile count; const = the same block for every sample tile."""
 
-    def __init__(self, planes: torch.Tensor, f0: int, tiles: int, const: bool = False):
+    def __init__(self, planes: torch.Tensor, f0: int, tiles: int, const: bool = False, lo: Optional[torch.Tensor] = None):
+        """lo: the lo plane [tiles, F, 64, 8] as a tensor of its own (planes then holds the hi plane only)"""
         assert planes.dtype == torch.bfloat16 and planes.dim() == 5 and planes.shape[3:] == (64, 8), planes.shape
         assert planes.is_contiguous() or planes[0].is_contiguous()
-        self.planes, self.f0, self.tiles, self.const = planes, f0, tiles, const
+        assert lo is None or (lo.is_contiguous() and lo.shape == planes.shape[1:] and lo.dtype == torch.bfloat16)
+        self.planes, self.f0, self.tiles, self.const, self.lo = planes, f0, tiles, const, lo
         self.blk = 0 if const else planes.shape[2] * 1024
         assert f0 + 2 * tiles <= planes.shape[2], (f0, tiles, planes.shape)
 
     def ptr(self, p: int):
+        if p == 1 and self.lo is not None:
+            return self.lo.data_ptr()
         if p >= self.planes.shape[0]:
             return None
         assert self.planes[p].is_contiguous()
@@ -822,9 +841,23 @@ def color_dw_jobs(net: PackedNet, feat_planes: torch.Tensor, stash: ColStash, gr
     for l in (1, 2, 3):
         g.add(O(stash.zbar[:, l], 0, 8), O(stash.u[:, l - 1], 0, 8), base + 4 * offW[l], 256, 256, 256, bias_ptr=base + 4 * offb[l],
               n_tiles=nt)
-    g.add(O(stash.zout, 0, 1), O(stash.u[:, 3], 0, 8), base + 4 * offW[4], 256, n_out, 256, bias_ptr=base + 4 * offb[4], n_tiles=nt)
-    g.gprec = stash.gprec
+    if stash.gprec != 2:      # (gradient precision 2: the output layer's product runs on hi + lo planes in a launch of its own,
+        g.add(O(stash.zout, 0, 1), O(stash.u[:, 3], 0, 8), base + 4 * offW[4], 256, n_out, 256, bias_ptr=base + 4 * offb[4], n_tiles=nt)
+    g.gprec = 1 if stash.gprec == 2 else stash.gprec                                             # color_out_dw_jobs)
     return g if into is not None else g.finalize(stash.tiles)
+
+
+def color_out_dw_jobs(net: PackedNet, stash: ColStash, grad_flat: torch.Tensor) -> GemmPPJobs:
+    """gradient precision 2: dW and db of the colour network's output layer (3 x 256) from the hi + lo planes of its two operands --
+    a launch of its own at gradient precision 3 (a launch is one precision); 0.6 KB per sample against the 2 KB of all lo planes"""
+    assert stash.gprec == 2
+    g = GemmPPJobs(grad_flat.device, net.kind + ".out")
+    offW, offb, n_out = net.desc["offW"], net.desc["offb"], net.desc["outs"][4]
+    base = grad_flat.data_ptr()
+    g.add(PPOperand(stash.zout, 0, 1, lo=stash.zout_lo), PPOperand(stash.u[:, 3], 0, 8, lo=stash.u3_lo), base + 4 * offW[4], 256, n_out, 256,
+          bias_ptr=base + 4 * offb[4])
+    g.gprec = 3
+    return g.finalize(stash.tiles)
 
 
 # ------------------------------------------------------------------------------------------------------------

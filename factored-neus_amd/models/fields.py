@@ -88,11 +88,12 @@ class _HipMLP(nn.Module):
 
     def set_gradient_precision(self, gprec):
         """1: the backward stash holds bf16 planes (default: the weight-gradient products carry 2^-9 rounding each), 3: hi +
-        lo planes (fp32-accurate weight gradients, twice the stash traffic); None: ops.DEFAULT_GPREC.  Forward outputs
-        do not depend on it."""
-        assert gprec in (None, 1, 3)
+        lo planes (fp32-accurate weight gradients, twice the stash traffic), 2: bf16 planes but for the two operands of the colour
+        network's output layer -- the one product whose rounding exceeds mode 3's bounds (ops._gprec); None: ops.DEFAULT_GPREC.
+        Forward outputs do not depend on it."""
+        assert gprec in (None, 1, 2, 3)
         self._ws.gprec = gprec
-        for k in [k for k in self._ws.cache if k[0] in ("sdf_stash", "sdf_bwd", "sdf_jobs", "col_stash", "col_jobs")]:
+        for k in [k for k in self._ws.cache if k[0] in ("sdf_stash", "sdf_bwd", "sdf_jobs", "col_stash", "col_jobs", "col_out_jobs")]:
             del self._ws.cache[k]
 
     def _lins(self):
@@ -358,7 +359,7 @@ class RefColor(nn.Module):
 
     def set_gradient_precision(self, gprec):
         """see SDFNetwork.set_gradient_precision"""
-        assert gprec in (None, 1, 3)
+        assert gprec in (None, 1, 2, 3)
         self._cd.ws.gprec = gprec
         for k in [k for k in self._cd.ws.cache if k[0] in ("ref_stash", "ref_jobs")]:
             del self._cd.ws.cache[k]

@@ -44,7 +44,10 @@ typedef struct FneusSdfStash {
 } FneusSdfStash;
 
 /* Stash of the colour network / of one RefColor MLP (written by fneus_color_fwd with train != 0 and fneus_color_bwd):
- * fragment planes like FneusSdfStash, *_lo optional in the same way. */
+ * fragment planes like FneusSdfStash, *_lo optional in the same way.  Gradient precision 2 (round 5): side_lo and zbar_lo NULL,
+ * u_lo and zout_lo given -- of u_lo only slot 3 is then written (the other slots' addresses are never touched and need not
+ * exist): the two operands of the output layer's weight gradient, the one product of the colour network whose bf16 rounding
+ * exceeds the bounds of the exact mode. */
 typedef struct FneusColStash {
     uint16_t* side_hi; uint16_t* side_lo; /* [tiles][4][512]      pts | PE4(view) | normal (33 of 64 features; fragment 3 zero) */
     uint16_t* u_hi;    uint16_t* u_lo;    /* [4][tiles][16][512]  slot l = ReLU output of layer l (= input of l+1)            */

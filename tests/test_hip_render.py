@@ -144,7 +144,7 @@ def test_render_end_to_end(golden_dir, name):
     assert dz.max().item() <= (3e-3 if int(g["B"]) <= 16 else 2e-2) and frac >= (0.97 if big else 0.9)
 
 
-@pytest.mark.parametrize("gprec", [3, 1], ids=["grad_hi_lo", "grad_bf16"])
+@pytest.mark.parametrize("gprec", [3, 2, 1], ids=["grad_hi_lo", "grad_mixed", "grad_bf16"])
 @pytest.mark.parametrize("fused", [False, True], ids=["torch_loss", "fused_loss"])
 @pytest.mark.parametrize("name", WMASK[:2] + WOMASK + BIG)
 def test_loss_and_gradients(golden_dir, name, fused, gprec):
@@ -152,7 +152,8 @@ def test_loss_and_gradients(golden_dir, name, fused, gprec):
     otherwise the same terms written with torch ops on the render dict.
     gprec 3: the backward stash holds hi + lo planes (fp32-accurate weight gradients); gprec 1 (the training default):
     bf16 planes -- every product of the weight-gradient GEMMs carries 2^-9 rounding, which shows where a sum cancels
-    (bias gradients of 3 outputs over 512 samples)."""
+    (bias gradients of 3 outputs over 512 samples); gprec 2: bf16 planes but for the colour network's output layer (the tensors
+    that showed it: tools/experiments/r05/gprec_tensors.py) -- held to the bounds of gprec 3."""
     from _helper_losses import stage1_loss
     g = load(golden_dir, name)
     out, nets, (rgb, mask) = run(g, 3, teacher_z=True, fused_loss=fused, gprec=gprec)
@@ -185,10 +186,10 @@ def test_loss_and_gradients(golden_dir, name, fused, gprec):
         worst = max(worst, e_sub, e_norm)
         # RefColor is a ReLU MLP evaluated on only 2 samples per masked ray: a single unit whose pre-activation sits
         # within rounding of zero shows up in an individual weight-gradient entry
-        lim_sub = 3e-2 if net in ("refcolor", "nerf") else (5e-3 if gprec == 3 else 8e-3)
+        lim_sub = 3e-2 if net in ("refcolor", "nerf") else (5e-3 if gprec in (2, 3) else 8e-3)
         # background NeRF (K7): 9 ReLU layers on only 16 x 24 samples -- one unit at a ReLU boundary is 0.5 % of a norm
         # (tests/test_hip_nerf.py masks such samples and sees 1e-5)
-        lim_norm = 1e-2 if net == "nerf" else (2e-3 if gprec == 3 else 5e-3)
+        lim_norm = 1e-2 if net == "nerf" else (2e-3 if gprec in (2, 3) else 5e-3)
         assert e_sub <= lim_sub and e_norm <= lim_norm, (pname, e_sub, e_norm)
         checked += 1
     print(f"{name} gprec={gprec}: {checked} parameter tensors, worst relative gradient error {worst:.2e}")
