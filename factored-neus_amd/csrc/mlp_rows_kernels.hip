@@ -272,6 +272,13 @@ static int rows_launch(const FneusMlpJob* jobs, int n_jobs, int kind, hipStream_
                 J.db = f.d_bias;
                 if (f.act != 0) J.a_aux = f.y, J.a_act = f.act;
             }
+            // (operands are addressed through 32-bit buffer offsets: an array of 2 GiB or more is another caller's problem -- the stage-2 / 3
+            //  networks see a few thousand rows)
+            const long widest = f.n_in > f.n_out ? f.n_in : f.n_out;
+            if ((long)f.rows * widest * 4 >= (1L << 31) || (long)f.n_in * f.n_out * 4 >= (1L << 31)) {
+                set_last_error("fneus_mlp: an operand of 2 GiB or more (rows x width x 4 bytes): split the rows");
+                return -2;
+            }
             J.tiles_n = (J.n + 31) / 32;
             J.first_tile = tiles;
             tiles += ((J.m + 31) / 32) * J.tiles_n;

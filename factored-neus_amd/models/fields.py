@@ -689,6 +689,8 @@ def seq_group(items):
         top_act = item[3] if len(item) > 3 else None
         want_direct = getattr(owner, "direct_grads", False) and torch.is_grad_enabled()
         spec = _mlp_spec(seq) if (ops.MLP_ROWS and x.is_cuda and x.dtype == torch.float32) else None
+        if spec is not None and x.numel() // max(1, x.shape[-1]) * max(max(m.in_features, m.out_features) for m, _ in spec) * 4 >= 2 ** 31:
+            spec = None            # (the kernels address an operand through 32-bit offsets: such a batch goes to torch's modules)
         if spec is not None and top_act is not None:
             if spec[-1][1] != ops.ACT_NONE:
                 raise ValueError("seq_group: top_act given for a network that ends in an activation")

@@ -166,3 +166,6 @@ def test_mlp_rows_rejects_missing_arguments():
         ops.mlp_forward([dict(weight=w, rows=3, n_in=8, n_out=4)])            # no x, no y
     with pytest.raises(RuntimeError, match="fneus_mlp"):
         ops.mlp_backward_params([dict(weight=w, x=torch.randn(3, 8, device="cuda"), rows=3, n_in=8, n_out=4)])
+    x = torch.randn(3, 8, device="cuda")
+    with pytest.raises(RuntimeError, match="2 GiB"):            # 32-bit operand offsets: refused, not wrapped around
+        ops.mlp_forward([dict(x=x, weight=w, y=torch.empty(3, 4, device="cuda"), rows=2 ** 27, n_in=8, n_out=4)])
