@@ -527,6 +527,20 @@ def main():
                                              "of 128 + 24 lobes"}
         except Exception as e:
             result["stage3_step"] = {"value": None, "error": repr(e)}
+        try:    # the lever this step has left, measured and NOT the default: its visibility launch with ONE fp16 product
+            def _s3_h16():
+                tr3 = Stage3Trainer(device, prec=prec, use_graph=not args.no_graph)
+                tr3.lvis_network.set_precision(ops.PREC_H16)
+                return tr3
+            dt_3h, _, _ = timed_stage(_s3_h16)
+            result["stage3_step_lvis_one_fp16_product"] = {
+                "ms_per_step": dt_3h * 1e3,
+                "note": "Lvis.set_precision(ops.PREC_H16) / FNEUS_LVIS_PREC=2: the visibility kernel at a third of its matrix work (1.25 -> 0.57 ms). "
+                        "On the synthetic network every output of the reference fixtures stays within 3.5e-5 (a lobe's visibility within 3.9e-5; "
+                        "three bf16 products: 3e-7), but the error grows with the network's sharpness (fp64 emulation, "
+                        "tools/experiments/r05/lvis_schemes.py: 1.5e-4 with every hidden layer's weights doubled) -- not a parity mode, off by default"}
+        except Exception as e:
+            result["stage3_step_lvis_one_fp16_product"] = {"ms_per_step": None, "error": repr(e)}
 
     if rank == 0 and world == 1 and not args.no_fast_extra and standard and prec == ops.PREC_PARITY:
         try:    # the same step with fp32-accurate weight gradients (hi + lo planes): the other pinned mode (tests/test_hip_render.py)

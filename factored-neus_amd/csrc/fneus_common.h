@@ -59,6 +59,23 @@ FN_DEV f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// PREC 2 (round 5, the stage-3 visibility network only): ONE product per multiplication like PREC 1, on fp16 operands -- 11
+// significant bits instead of 8.  The fragments travel in the same 8 x 16-bit containers (bf16x8): only the conversion into them
+// (to16) and the matrix instruction (mfma32p) know the format.
+typedef _Float16 fn_f16x8 __attribute__((ext_vector_type(8)));
+template <int PREC>
+FN_DEV __bf16 to16(float v) {
+    if constexpr (PREC == 2) return __builtin_bit_cast(__bf16, (_Float16)v);
+    else return (__bf16)v;
+}
+template <int PREC>
+FN_DEV f32x16 mfma32p(bf16x8 a, bf16x8 b, f32x16 c) {
+    if constexpr (PREC == 2)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(fn_f16x8, a), __builtin_bit_cast(fn_f16x8, b), c, 0, 0, 0);
+    else
+        return mfma32(a, b, c);
+}
+
 FN_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 FN_DEV float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
 FN_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }

@@ -322,7 +322,7 @@ extern "C" int fneus_lvis_visibility(const void* lvis_blob, const float* points,
     const unsigned grid = (unsigned)(items < 8192 ? items : 8192);
     // two-pass pipelined kernel on 8-wave workgroups (lvis_p2_kernels.hip); FNEUS_LVIS_P2=0: the 4-wave kernels of this file
     const char* p2_env = getenv("FNEUS_LVIS_P2");
-    if ((p2_env ? atoi(p2_env) : FNEUS_LVIS_P2_DEFAULT) != 0 && (prec == 3 || prec == 1))
+    if (prec == 2 || ((p2_env ? atoi(p2_env) : FNEUS_LVIS_P2_DEFAULT) != 0 && (prec == 3 || prec == 1)))      // (prec 2 exists in this form only)
         return fneus::lvis_visibility_p2(b, points, normals, dirs, weights, point_mask, n_pts, n_lobes, vis, prec, stream);
     const char* env = getenv("FNEUS_LVIS_HB");            // 2 (default): two lobes share a pass over the weights; 1: one lobe per pass
     if (!(env && env[0] == '1')) {
@@ -354,5 +354,42 @@ extern "C" int fneus_lvis_visibility(const void* lvis_blob, const float* points,
     } else {
         return -2;
     }
+    return fneus::launch_status();
+}
+
+// ---- the Lvis blob for prec 2: every forward weight fragment as ONE fp16 value per weight (the sum of its bf16 hi + lo parts,
+// rounded once), in the place of the hi fragment; biases, the last layer's fp32 row and everything else copied.  A one-off per
+// parameter change (stage 3 keeps the network frozen).
+namespace fneus {
+__global__ void __launch_bounds__(256) lvis_h16_pack_kernel(const unsigned char* __restrict__ blob, unsigned char* __restrict__ out) {
+    constexpr auto& LY = kLvisLayout;
+    const uint32_t off = (blockIdx.x * 256u + threadIdx.x) * 16u;
+    if (off >= LY.total) return;
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(blob + off);
+#pragma unroll
+    for (int l = 0; l < kLvisLayers; ++l) {
+        const uint32_t bytes = (uint32_t)(kLvisGeom[l].ksf * kLvisGeom[l].ntf) * kFragBytes;
+        if (off >= LY.L[l].fwd_hi && off < LY.L[l].fwd_hi + bytes) {
+            const bf16x8 lo = *reinterpret_cast<const bf16x8*>(blob + LY.L[l].fwd_lo + (off - LY.L[l].fwd_hi));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = to16<2>((float)v[e] + (float)lo[e]);
+        }
+    }
+    *reinterpret_cast<bf16x8*>(out + off) = v;
+}
+}  // namespace fneus
+
+extern "C" size_t fneus_lvis_blob_bytes(void) { return fneus::kLvisLayout.total; }
+
+extern "C" int fneus_lvis_h16_pack(const void* lvis_blob, void* out, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (!lvis_blob || !out) {
+        fneus::set_last_error("fneus_lvis_h16_pack: blob and out must be given");
+        return -2;
+    }
+    const unsigned n16 = (fneus::kLvisLayout.total + 15) / 16;
+    hipLaunchKernelGGL(fneus::lvis_h16_pack_kernel, dim3((n16 + 255) / 256), dim3(256), 0, stream, reinterpret_cast<const unsigned char*>(lvis_blob),
+                       reinterpret_cast<unsigned char*>(out));
     return fneus::launch_status();
 }

@@ -58,7 +58,7 @@ FN_DEV void lvis_p2_posenc3(const float (&x)[3], int ks, int h, BFrag<PREC>& out
             out.hi[j] = a;
             out.lo[j] = b;
         } else {
-            out.hi[j] = (__bf16)val;
+            out.hi[j] = to16<PREC>(val);
         }
     }
 }
@@ -292,6 +292,7 @@ int lvis_visibility_p2(const unsigned char* b, const float* points, const float*
                        const unsigned char* point_mask, int n_pts, int n_lobes, float* vis, int prec, hipStream_t stream) {
     if (prec == 3) return launch_lvis_p2<3>(b, points, normals, dirs, weights, point_mask, n_pts, n_lobes, vis, stream);
     if (prec == 1) return launch_lvis_p2<1>(b, points, normals, dirs, weights, point_mask, n_pts, n_lobes, vis, stream);
+    if (prec == 2) return launch_lvis_p2<2>(b, points, normals, dirs, weights, point_mask, n_pts, n_lobes, vis, stream);   // blob: fneus_lvis_h16_pack
     return -2;
 }
 

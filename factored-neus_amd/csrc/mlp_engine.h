@@ -349,7 +349,7 @@ FN_DEV void vec_to_bfrag(const float (&v)[NF], BFrag<PREC> (&b)[kMaxKS], int h) 
                 b[KS0 + ks].hi[j] = hi;
                 b[KS0 + ks].lo[j] = lo;
             } else {
-                b[KS0 + ks].hi[j] = (__bf16)val;
+                b[KS0 + ks].hi[j] = to16<PREC>(val);
             }
         }
 }

@@ -238,7 +238,7 @@ FN_DEV void p2_pass(const unsigned char* __restrict__ blob, __amdgpu_buffer_rsrc
                 const float y0 = RELU ? vm[2 * pi] : fmaf(vl[2 * pi], kLn2 / kBeta, vm[2 * pi]);
                 const float y1 = RELU ? vm[2 * pi + 1] : fmaf(vl[2 * pi + 1], kLn2 / kBeta, vm[2 * pi + 1]);
                 if constexpr (FRAGS) {
-                    p2_bf16x2 hv = {(__bf16)y0, (__bf16)y1};
+                    p2_bf16x2 hv = {to16<PREC>(y0), to16<PREC>(y1)};
                     const uint32_t pk = __builtin_bit_cast(uint32_t, hv);       // ONE v_cvt_pk_bf16_f32; the hi parts as floats
                     phw[e >> 1] = pk;                                           // come back out of the packed word (shift / mask)
                     if constexpr (PREC == 3) {
@@ -298,7 +298,7 @@ FN_DEV void p2_pass(const unsigned char* __restrict__ blob, __amdgpu_buffer_rsrc
                     else if constexpr (prod == 1) accM[i][hb] = mfma32(ah[s % (D + 1)][i], bl[s % RB][hb], accM[i][hb]);
                     else accM[i][hb] = mfma32(ah[s % (D + 1)][i], bh[s % RB][hb], accM[i][hb]);
                 } else {
-                    accM[i][hb] = mfma32(ah[s % (D + 1)][i], bh[s % RB][hb], accM[i][hb]);
+                    accM[i][hb] = mfma32p<PREC>(ah[s % (D + 1)][i], bh[s % RB][hb], accM[i][hb]);
                 }
             }
 #else
@@ -386,7 +386,7 @@ FN_DEV void p2_valu_only(unsigned char* lds, int lane, int t0, f32x16 (&accV)[TN
                     ph[e] = a;
                     pl[e] = b2;
                 } else {
-                    ph[e] = (__bf16)y;
+                    ph[e] = to16<PREC>(y);
                 }
             } else {
                 dot[hb] = fmaf(y, cw[i][8 * sh + e], dot[hb]);

@@ -149,6 +149,8 @@ def _load():
         "fneus_h6_pack": (C.c_int, [vp, vp, vp]),
         "fneus_sdf_fwd_h6": (C.c_int, [vp, vp, vp, vp, vp, vp, ip, l, vp, f, vp, vp, vp]),
         "fneus_lvis_visibility": (C.c_int, [vp, vp, vp, vp, vp, vp, ip, ip, ip, vp, ip, vp]),
+        "fneus_lvis_blob_bytes": (C.c_size_t, []),
+        "fneus_lvis_h16_pack": (C.c_int, [vp, vp, vp]),
         "fneus_ray_hit": (C.c_int, [vp] * 7 + [ip, ip, f] + [vp] * 5 + [vp]),
         "fneus_sample_dirs": (C.c_int, [vp] * 4 + [ip, ip, vp, vp, vp]),
         "fneus_composite_fwd": (C.c_int, [vp] * 8 + [ip, ip, ip, f, vp, vp, vp, ip] + [vp] * 10 + [vp, ip, vp]),

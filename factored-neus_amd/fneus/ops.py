@@ -11,6 +11,7 @@ from . import _lib, netdesc
 from ._lib import lib, check
 
 PREC_FAST, PREC_PARITY = 1, 3
+PREC_H16 = 2          # ONE fp16 product per multiplication: the stage-3 visibility network only (fneus_lvis_visibility)
 
 # Optional per-kernel timing with HIP events on the launch stream (used by bench.py for the roofline figures).
 # PROFILE = None disables it (default; the hot path then records nothing and never synchronises).
@@ -1306,6 +1307,14 @@ def embed(x, n_freqs: int):
     n, d = x.shape
     out = torch.empty(n, d * (1 + 2 * n_freqs), dtype=torch.float32, device=x.device)
     _launch("fneus_embed", lib.fneus_embed, _ptr(x), n, d, int(n_freqs), _ptr(out), _stream())
+    return out
+
+
+def lvis_h16_pack(blob):
+    """the Lvis blob with every forward weight as one fp16 value (fneus_lvis_h16_pack): what fneus_lvis_visibility takes at prec 2"""
+    out = torch.empty(int(lib.fneus_lvis_blob_bytes()), dtype=torch.uint8, device=blob.device)
+    assert blob.numel() >= out.numel()
+    _launch("fneus_lvis_h16_pack", lib.fneus_lvis_h16_pack, _ptr(blob), _ptr(out), _stream())
     return out
 
 

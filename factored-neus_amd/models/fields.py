@@ -11,6 +11,7 @@
 from __future__ import annotations
 
 import math
+import os
 
 import numpy as np
 import torch
@@ -747,12 +748,20 @@ class Lvis(nn.Module):
             vis = self._visibility_library(points, normals, dirs, weights)
             return vis if point_mask is None else vis * point_mask[None, :].to(vis.dtype)
         net = self._packed()
-        return ops.lvis_visibility(net.blob, points, normals, dirs.contiguous(), weights.contiguous(), self.prec, point_mask)
+        blob = net.blob
+        if self.prec == ops.PREC_H16:                # the blob with one fp16 value per weight, converted when the packed blob changed
+            if getattr(self, "_h16_key", None) != self._pack_key:
+                self._h16_blob, self._h16_key = ops.lvis_h16_pack(net.blob), self._pack_key
+            blob = self._h16_blob
+        return ops.lvis_visibility(blob, points, normals, dirs.contiguous(), weights.contiguous(), self.prec, point_mask)
 
-    prec = ops.PREC_PARITY
+    # The visibility launch of stage 3 in the 1e-4 mode: ops.PREC_PARITY (three bf16 products; a lobe's visibility within 3e-7 of
+    # float64) or ops.PREC_H16 (ONE fp16 product: within 3e-5 -- a lobe averages up to 32 sigmoid outputs -- at half the time:
+    # 1.27 -> 0.63 ms per stage-3 step).  FNEUS_LVIS_PREC selects the default.
+    prec = int(os.environ.get("FNEUS_LVIS_PREC", str(ops.PREC_PARITY)))
 
     def set_precision(self, prec: int):
-        assert prec in (ops.PREC_FAST, ops.PREC_PARITY)
+        assert prec in (ops.PREC_FAST, ops.PREC_H16, ops.PREC_PARITY)
         self.prec = prec
 
     def _packed(self):

@@ -431,6 +431,11 @@ int fneus_mlp_backward_params(const FneusMlpJob* layers /*host array*/, int n_la
 int fneus_lvis_visibility(const void* lvis_blob, const float* points, const float* normals, const float* dirs,
                           const float* weights, const unsigned char* point_mask /*[n_pts] or NULL: 0 = skip the point (vis = 0)*/,
                           int n_pts, int n_lobes, int n_dirs, float* vis, int prec, fneus_stream_t stream);
+/* prec 2 (round 5; this entry point only): ONE fp16 product per multiplication -- a lobe's visibility averages up to 32 sigmoid
+ * outputs and stays within 3e-5 of the parity mode's at a third of its matrix work; lvis_blob is then the output of
+ * fneus_lvis_h16_pack (the packed blob with every forward weight as one fp16 value; fneus_lvis_blob_bytes() bytes). */
+size_t fneus_lvis_blob_bytes(void);
+int fneus_lvis_h16_pack(const void* lvis_blob, void* out, fneus_stream_t stream);
 
 /* Spherical-Gaussian rendering of stage 3: render_with_sg (inverRender.py:314-449) with lambda_trick (:83-103), hemisphere_int
  * (:106-125) and integrate_rgb (:264-283) for the n_direct light SGs lgt_sgs [n_direct][7] (with per-lobe visibility vis

@@ -157,21 +157,32 @@ def test_fused_lvis_visibility_vs_library_path():
     dirs, w = visibility_sample_dirs(lobes, sg[:, 3:4].abs(), 32, torch.rand(128, 32, generator=g).to(dev),
                                      torch.rand(128, 32, generator=g).to(dev))
     ref = net._visibility_library(pts, nrm, dirs.contiguous(), w.contiguous())
+    net.set_precision(ops.PREC_PARITY)
     got = net.visibility(pts, nrm, dirs.contiguous(), w.contiguous())
     assert got.shape == ref.shape == (128, n)
     d = (got - ref).abs()
     print(f"  fused visibility vs library GEMMs: worst {d.max().item():.2e}; {(ref == 0).float().mean().item() * 100:.0f} % of the lobes face away")
-    assert d.max().item() <= 1e-4
+    assert d.max().item() <= 5e-6                     # observed 6e-7
     assert torch.equal(got == 0, ref == 0)
     net.set_precision(ops.PREC_FAST)
     fast = net.visibility(pts, nrm, dirs.contiguous(), w.contiguous())
-    assert (fast - ref).abs().max().item() <= 3e-2
-    # a changed weight is re-packed
-    net.set_precision(ops.PREC_PARITY)
+    e_fast = (fast - ref).abs().max().item()
+    assert e_fast <= 3e-2
+    # ONE fp16 product (ops.PREC_H16, opt-in: its error grows with the network's sharpness, tools/experiments/r05/lvis_schemes.py):
+    # on this network within 1e-4 of the library path and several times closer than the bf16 fast mode
+    net.set_precision(ops.PREC_H16)
+    h16 = net.visibility(pts, nrm, dirs.contiguous(), w.contiguous())
+    e_h16 = (h16 - ref).abs().max().item()
+    print(f"  one fp16 product: worst {e_h16:.2e} (one bf16 product: {e_fast:.2e})")
+    assert e_h16 <= 1e-4 and e_h16 * 4.0 <= e_fast and torch.equal(h16 == 0, ref == 0)
+    # a changed weight is re-packed, in both blobs
     with torch.no_grad():
         net.lvis[8].bias.add_(0.5)
+    ref2 = net._visibility_library(pts, nrm, dirs.contiguous(), w.contiguous())
+    assert (net.visibility(pts, nrm, dirs.contiguous(), w.contiguous()) - ref2).abs().max().item() <= 1e-4
+    net.set_precision(ops.PREC_PARITY)
     again = net.visibility(pts, nrm, dirs.contiguous(), w.contiguous())
-    assert (again - net._visibility_library(pts, nrm, dirs.contiguous(), w.contiguous())).abs().max().item() <= 1e-4
+    assert (again - ref2).abs().max().item() <= 5e-6
     assert (again - got).abs().max().item() > 1e-3
 
 
