@@ -12,9 +12,12 @@
 //   Ll.A || ReLU l-1 B                                                      Ll.B || ReLU l A       (l = 1..3; ReLU 3 -> dot)
 // The last layer (256 -> 1) is a vector dot product on the accumulators + a fixed-order sum over the waves through LDS (as the
 // sdf row of K1), followed by the sigmoid and the weighted average over the tile's 32 directions.
-// LDS per tile: slots 0..15 the running layer's input (layer 0: 4 k-steps PE10(point), 2 k-steps PE4(direction)); slot 16 of
-// tile j keeps k-step j of the item's point encoding (copied into every tile of every unit).
+// LDS per tile: slots 0..15 the running layer's input (layer 0, round 5: slots 0, 1 the 2 k-steps PE4(direction); the 4 k-steps
+// PE10(point) sit in slots 0..3 of tiles 0, 1 for the one pass per item that multiplies them).
 #include <stdlib.h>
+#ifndef FNEUS_P2_DEPTH
+#define FNEUS_P2_DEPTH 2            // weight-prefetch distance of this file's passes (p2_engine.h: 3): layer 0's direction part is a pass of 2 k-steps
+#endif
 #include "p2_engine.h"
 #include "fneus_kernels.h"
 #include "lvis_p2.h"
@@ -84,9 +87,16 @@ __global__ void __launch_bounds__(512, 1) lvis_visibility_p2_kernel(const unsign
     constexpr auto& LY = kLvisLayout;
     const int n_chunks = (n_lobes + kLvisP2Chunk - 1) / kLvisP2Chunk;
     const __amdgpu_buffer_rsrc_t rsrc = p2_rsrc(blob);
-    auto next_of = [&](int l) { return P2Next{LY.L[l].fwd_hi, LY.L[l].fwd_lo, LY.L[l].bias, 8}; };
+    // Layer 0 in two parts (round 5): its first four k-steps multiply the POINT's encoding -- the same for every direction of an item --
+    // and run once per item (pass P below); a unit's layer-0 passes take the two k-steps of the direction's encoding from there.  Same
+    // operands in the same order per accumulator as the one six-k-step pass: bit-identical, 8 of a unit's 108 k-steps fewer.
+    constexpr uint32_t kDirPart = 4u * 8u * (uint32_t)kFragBytes;            // k-steps 4, 5 of layer 0's fragments ([ks][tile])
+    auto next_of = [&](int l) {
+        return l == 0 ? P2Next{LY.L[0].fwd_hi + kDirPart, LY.L[0].fwd_lo + kDirPart, LY.L[0].bias, 8}
+                      : P2Next{LY.L[l].fwd_hi, LY.L[l].fwd_lo, LY.L[l].bias, 8};
+    };
+    const P2Next point_part{LY.L[0].fwd_hi, LY.L[0].fwd_lo, LY.L[0].bias, 8};
     P2Prime<FNEUS_P2_DEPTH, TN> pr;
-    p2_prime_all<PREC, FNEUS_P2_DEPTH, TN>(pr, blob, rsrc, lane, t0, next_of(0));
     f32x16 accA[TN][2], accB[TN][2], cw[TN];
     float dot[2] = {0.0f, 0.0f};
     auto load_cw = [&]() { load_accvec<8, 0, TN>(blob, LY.extra, cw, lane, t0); };   // the row of the last layer in accumulator layout
@@ -139,12 +149,15 @@ __global__ void __launch_bounds__(512, 1) lvis_visibility_p2_kernel(const unsign
                 num[lj] = 0.0f;
             }
         }
-        if (wave < 4) {                                   // k-step `wave` of the point's encoding -> slot 16 of tile `wave`
+        if (wave < 4) {                                   // k-step `wave` of the point's encoding -> slot `wave` of tiles 0 and 1 (set A)
             BFrag<PREC> one;
             lvis_p2_posenc3<PREC>(x, wave, h, one);
-            unsigned char* dst = lds_ + wave * kP2Half + (16 * NPL) * kFragBytes + lane * 16;
-            *reinterpret_cast<bf16x8*>(dst) = one.hi;
-            if constexpr (PREC == 3) *reinterpret_cast<bf16x8*>(dst + kFragBytes) = one.lo;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                unsigned char* dst = lds_ + t * kP2Half + (wave * NPL) * kFragBytes + lane * 16;
+                *reinterpret_cast<bf16x8*>(dst) = one.hi;
+                if constexpr (PREC == 3) *reinterpret_cast<bf16x8*>(dst + kFragBytes) = one.lo;
+            }
         }
         p2_barrier();
         const int n_tiles = (n_pairs + 31) >> 5;
@@ -155,16 +168,9 @@ __global__ void __launch_bounds__(512, 1) lvis_visibility_p2_kernel(const unsign
             valid = e < n_pairs;
             return (int)pairs[valid ? e : (n_pairs > 0 ? n_pairs - 1 : 0)];
         };
-        auto encode = [&](int unit, int ta, int tb) {     // waves ta .. tb: the 6 input k-steps of tile `wave` of the unit
+        auto encode = [&](int unit, int ta, int tb) {     // waves ta .. tb: the 2 direction k-steps of tile `wave` of the unit (slots 0, 1)
             if (wave < ta || wave > tb) return;
             unsigned char* tile = lds_ + wave * kP2Half + lane * 16;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned char* src = lds_ + j * kP2Half + (16 * NPL) * kFragBytes + lane * 16;
-                *reinterpret_cast<bf16x8*>(tile + (j * NPL) * kFragBytes) = *reinterpret_cast<const bf16x8*>(src);
-                if constexpr (PREC == 3)
-                    *reinterpret_cast<bf16x8*>(tile + (j * NPL + 1) * kFragBytes) = *reinterpret_cast<const bf16x8*>(src + kFragBytes);
-            }
             bool valid;
             const int pr_ = pair_of(4 * unit + wave, valid);
             const int lobe = lobe0 + (pr_ >> 5), dir = pr_ & 31;
@@ -176,8 +182,8 @@ __global__ void __launch_bounds__(512, 1) lvis_visibility_p2_kernel(const unsign
             vec_to_bfrag<PREC, 27, 2, 0>(pe, tmp, h);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                *reinterpret_cast<bf16x8*>(tile + ((4 + j) * NPL) * kFragBytes) = tmp[j].hi;
-                if constexpr (PREC == 3) *reinterpret_cast<bf16x8*>(tile + ((4 + j) * NPL + 1) * kFragBytes) = tmp[j].lo;
+                *reinterpret_cast<bf16x8*>(tile + (j * NPL) * kFragBytes) = tmp[j].hi;
+                if constexpr (PREC == 3) *reinterpret_cast<bf16x8*>(tile + (j * NPL + 1) * kFragBytes) = tmp[j].lo;
             }
         };
         auto put_dot = [&](int hb0) {
@@ -224,24 +230,36 @@ __global__ void __launch_bounds__(512, 1) lvis_visibility_p2_kernel(const unsign
             p2_barrier();
             continue;
         }
+#define LVIS_PASS_AT(KS, ACT, OFF_HI, OFF_LO, NX, ACCM, HBM, ACCV, HBV)                                                       \
+    p2_pass<PREC, KS, 8, 0, ACT, TN>(blob, rsrc, OFF_HI, OFF_LO, pr, NX, lds_, lane, t0, ACCM, HBM, ACCV, HBV, TN, cw, dot)
+#define LVIS_PASS(KS, ACT, L_, NX, ACCM, HBM, ACCV, HBV) LVIS_PASS_AT(KS, ACT, LY.L[L_].fwd_hi, LY.L[L_].fwd_lo, NX, ACCM, HBM, ACCV, HBV)
+// layer 0's direction part: 2 k-steps on top of the point part (the primed bias registers are the pass's initial accumulators)
+#define LVIS_L0(ACT, NX, ACCM, HBM, ACCV, HBV)                                                                                \
+    do {                                                                                                                      \
+        pr.bias[0] = acc0;                                                                                                    \
+        LVIS_PASS_AT(2, ACT, LY.L[0].fwd_hi + kDirPart, LY.L[0].fwd_lo + kDirPart, NX, ACCM, HBM, ACCV, HBV);                  \
+    } while (0)
+        // pass P: bias + the point part of layer 0, once per item (every column of the tile holds the same point: one accumulator
+        // vector serves all directions)
+        p2_prime_all<PREC, FNEUS_P2_DEPTH, TN>(pr, blob, rsrc, lane, t0, point_part);
+        LVIS_PASS_AT(4, 0, point_part.off_hi, point_part.off_lo, next_of(0), accA, 0, accB, 2);
+        const f32x16 acc0 = accA[0][0];
+        p2_barrier();                                     // set A's slots 0..3 have been read: the units' direction k-steps go there
         encode(0, 0, 3);
         p2_barrier();
-#define LVIS_PASS(KS, ACT, L_, NX, ACCM, HBM, ACCV, HBV)                                                                     \
-    p2_pass<PREC, KS, 8, 0, ACT, TN>(blob, rsrc, LY.L[L_].fwd_hi, LY.L[L_].fwd_lo, pr, NX, lds_, lane, t0, ACCM, HBM, ACCV, HBV, \
-                                     TN, cw, dot)
 #pragma unroll 1
         for (int unit = 0; unit < n_units; ++unit) {
             asm volatile("" : "+s"(blob));
             if (unit > 0) {
                 load_cw();
-                LVIS_PASS(6, 4, 0, next_of(0), accA, 0, accB, 2);
+                LVIS_L0(4, next_of(0), accA, 0, accB, 2);
                 put_dot(2);
             } else {
-                LVIS_PASS(6, 0, 0, next_of(0), accA, 0, accB, 2);
+                LVIS_L0(0, next_of(0), accA, 0, accB, 2);
             }
             p2_barrier();
             if (unit > 0) finish(unit - 1, 2);
-            LVIS_PASS(6, 3, 0, next_of(1), accB, 2, accA, 0);
+            LVIS_L0(3, next_of(1), accB, 2, accA, 0);
             p2_barrier();
 #pragma unroll 1
             for (int l = 1; l <= 3; ++l) {
@@ -263,6 +281,8 @@ __global__ void __launch_bounds__(512, 1) lvis_visibility_p2_kernel(const unsign
             if (unit + 1 < n_units) encode(unit + 1, 2, 3);             // set B's slots: last read by pass B of layer 3
         }
 #undef LVIS_PASS
+#undef LVIS_PASS_AT
+#undef LVIS_L0
         load_cw();
         p2_valu_only<PREC, 4, TN>(lds_, lane, t0, accB, 2, TN, cw, dot);
         put_dot(2);
