@@ -396,3 +396,46 @@ def test_gemm_job_table_hands_out_workgroups_by_the_work_a_product_has():
     assert abs(bgs / sdf - 0.3 * 2560 / 2048) <= 0.15, (sdf, bgs)                                    # 0.375 of a full product each
     assert all(j.n_dev == cnt.data_ptr() for j in g.jobs[29:]) and all(not j.n_dev for j in g.jobs[:29])
     assert ctypes.sizeof(_lib.FneusGemmPPJob) == 152          # include/fneus.h FneusGemmPPJob (csrc/dw_gemm_pp.hip asserts its own mirror)
+
+
+def test_mlp_group_host_logic_on_cpu_tensors():
+    """models/fields.py seq_group off the GPU: the Linear + activation stacks of stages 2 / 3 are recognised (`_mlp_spec`: what the
+    fneus_mlp_* kernels take), anything else is refused, CPU tensors run the plain modules (there is no CPU kernel path), the
+    caller's `top_act` is applied behind them, and a frozen network's pack key follows in-place writes"""
+    import torch.nn as nn
+    sys.path.insert(0, os.path.join(ROOT, "factored-neus_amd"))
+    from fneus import ops
+    from models import fields
+    from models.fields import Lvis, IndirectLight
+    from models.inverRender import EnvmapMaterialNetwork
+    lv, ind, mat = Lvis(), IndirectLight(), EnvmapMaterialNetwork()
+    acts = lambda seq: [a for _, a in fields._mlp_spec(seq)]
+    assert acts(lv.lvis) == [ops.ACT_RELU] * 4 + [ops.ACT_SIGMOID]
+    assert acts(ind.indi) == [ops.ACT_RELU] * 4 + [ops.ACT_NONE]
+    assert acts(mat.brdf_encoder_layer) == [ops.ACT_LEAKY02] * 4 + [ops.ACT_NONE]
+    assert acts(mat.brdf_decoder_layer) == [ops.ACT_LEAKY02] * 2 + [ops.ACT_NONE]
+    assert acts(mat.net_cs) == [ops.ACT_LEAKY02] * 4 + [ops.ACT_SIGMOID]
+    assert fields._mlp_spec(nn.Sequential(nn.Linear(4, 4), nn.Tanh())) is None               # an activation the kernels do not have
+    assert fields._mlp_spec(nn.Sequential(nn.Linear(4, 4), nn.LeakyReLU(0.1))) is None         # another slope
+    assert fields._mlp_spec(nn.Sequential(nn.Linear(4, 4), nn.ReLU(), nn.ReLU())) is None      # two activations behind one layer
+    assert fields._mlp_spec(nn.Sequential(nn.ReLU(), nn.Linear(4, 4))) is None
+
+    class Owner:
+        direct_grads = False
+
+    torch.manual_seed(0)
+    x1, x2 = torch.randn(7, 32), torch.randn(5, 90)
+    y1, y2 = fields.seq_group([(mat.brdf_decoder_layer, x1, Owner(), ops.ACT_SIGMOID), (mat.net_cs, x2, Owner())])
+    assert torch.equal(y1, torch.sigmoid(mat.brdf_decoder_layer(x1))) and torch.equal(y2, mat.net_cs(x2))
+    y1.sum().backward()
+    assert mat.brdf_decoder_layer[0].weight.grad is not None
+    # frozen-network pack key: None while a parameter is trained, changes with an in-place write
+    lin = nn.Linear(3, 3)
+    assert fields._frozen_key(lin.parameters()) is None
+    for p in lin.parameters():
+        p.requires_grad_(False)
+    k0 = fields._frozen_key(lin.parameters())
+    assert k0 is not None and k0 == fields._frozen_key(lin.parameters())
+    with torch.no_grad():
+        lin.bias.add_(1.0)
+    assert fields._frozen_key(lin.parameters()) != k0
