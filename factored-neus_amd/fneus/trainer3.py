@@ -90,8 +90,9 @@ class Stage3Trainer:
         mask = (mask > 0.5).float() if self.mask_weight > 0.0 else torch.ones_like(mask)
         self._direct_grads(True)
         try:
-            # (raw: the loss masks the rays without a hit itself -- single GPU: fneus_stage3_loss; data parallel: `w` of stage3_loss)
-            out = self.renderer.mateIllu_render(rays_o, rays_d, None, None, fixed_shape=True, keys=("rgb",), raw=True)
+            # (raw: fneus_stage3_loss skips the rays without a hit by their mask.  The data-parallel step's element-wise loss
+            # MULTIPLIES by the mask: it keeps the placeholder rows filled with 1, a placeholder need not be finite)
+            out = self.renderer.mateIllu_render(rays_o, rays_d, None, None, fixed_shape=True, keys=("rgb",), raw=self.reduce is None)
         finally:
             self._direct_grads(False)
         losses = stage3_loss(out, true_rgb, mask, self.reduce)
