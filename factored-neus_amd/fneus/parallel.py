@@ -127,4 +127,6 @@ def broadcast_parameters(modules, src: int = 0, group=None):
         return
     for m in modules:
         for t in list(m.parameters()) + list(m.buffers()):
-            dist.broadcast(t.data, src=src, group=group)
+            # (detach(), not .data: the write then counts in the parameter's version, which tells a frozen network to pack again --
+            #  models/fields.py _frozen_key)
+            dist.broadcast(t.detach(), src=src, group=group)
