@@ -110,10 +110,15 @@ __global__ void __launch_bounds__(64) wn_backward_multi_kernel(WnTasks T) {
 FN_DEV void pack_unit(const PackJob* __restrict__ jobs, int n_jobs, const int* __restrict__ maps,
                       const float* __restrict__ params, const float* __restrict__ rowscale,
                       unsigned char* __restrict__ blob, int unit, int lane) {
-    // locate the job (n_jobs is a few dozen; unit_base is ascending)
-    int ji = 0;
-    for (int i = 1; i < n_jobs; ++i)
-        if (jobs[i].unit_base <= unit) ji = i;
+    // locate the job: unit_base is ascending -- a bisection (6 dependent scalar loads for the SDF network's 40 jobs instead of one per
+    // job: 14.9 -> 13.1 us per launch; four waves per workgroup instead of one changed nothing: the launch is a chain of dependent
+    // gathers -- job, index maps, parameters, row scales -- not dispatch)
+    int ji = 0, hi_j = n_jobs - 1;
+    while (ji < hi_j) {
+        const int mid = (ji + hi_j + 1) >> 1;
+        if (jobs[mid].unit_base <= unit) ji = mid;
+        else hi_j = mid - 1;
+    }
     const PackJob jb = jobs[ji];
     const int u = unit - jb.unit_base;
     const int r = lane & 31, h = lane >> 5;
