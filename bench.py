@@ -172,7 +172,7 @@ def cpu_baseline(device=None):
 
 
 # newest first: the PMC passes are re-collected whenever a kernel's memory behaviour changes (tools/collect_profiles.sh)
-TRAFFIC_FILES = ("r05_d_traffic.json", "r05_c_traffic.json", "r05_b_traffic.json", "r05_a_traffic.json", "r04_h_traffic.json", "r04_f_traffic.json", "r04_e_traffic.json", "r04_d_traffic.json", "r04_c_traffic.json", "r04_b_traffic.json", "r04_a_traffic.json", "r03_h_traffic.json", "r03_g_traffic.json", "r03_f_traffic.json", "r03_e_traffic.json", "r03_d_traffic.json", "r03_c_traffic.json", "r03_b_traffic.json", "r03_a_traffic.json", "r02_e_traffic.json", "r02_d_traffic.json", "r02_c_traffic.json", "r02_b_traffic.json", "r02_a_traffic.json")
+TRAFFIC_FILES = ("r05_e_traffic.json", "r05_d_traffic.json", "r05_c_traffic.json", "r05_b_traffic.json", "r05_a_traffic.json", "r04_h_traffic.json", "r04_f_traffic.json", "r04_e_traffic.json", "r04_d_traffic.json", "r04_c_traffic.json", "r04_b_traffic.json", "r04_a_traffic.json", "r03_h_traffic.json", "r03_g_traffic.json", "r03_f_traffic.json", "r03_e_traffic.json", "r03_d_traffic.json", "r03_c_traffic.json", "r03_b_traffic.json", "r03_a_traffic.json", "r02_e_traffic.json", "r02_d_traffic.json", "r02_c_traffic.json", "r02_b_traffic.json", "r02_a_traffic.json")
 
 
 def main():
