@@ -215,9 +215,21 @@ class Stage2Trainer:
             return losses
         graph, static, losses = self._graph
         static.copy_(data)
+        self._refresh_frozen()
         graph.replay()
         self.iter_step += 1
         return losses
+
+    def _refresh_frozen(self):
+        """A frozen network is packed when its parameters change (models/fields.py refresh: address + version), and the eager
+        warm-up steps have packed it before the step was captured -- so the captured step holds no pack launch for it.  A
+        load_state_dict (or any other version-bumping write) into a frozen network AFTER the capture is picked up here: its
+        refresh() runs eagerly in front of the replay and packs into the same blob the captured kernels read (a no-op, one tuple
+        comparison per network, while nothing changed)."""
+        for m in getattr(self, "frozen", ()):
+            for sub in m.modules():
+                if hasattr(sub, "refresh") and not any(p.requires_grad for p in sub.parameters()):
+                    sub.refresh()
 
     def _direct_grads(self, on: bool):
         for m in getattr(self, "_direct_modules", ()):

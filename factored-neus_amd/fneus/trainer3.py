@@ -82,7 +82,7 @@ class Stage3Trainer:
     _init_step_mode, set_lr, get_lr, _graph_step = _S2._init_step_mode, _S2.set_lr, _S2.get_lr, _S2._graph_step
     optimizer_state_dict, load_optimizer_state_dict = _S2.optimizer_state_dict, _S2.load_optimizer_state_dict
     _backward_and_step, _backward, _reduce, _clear_grads = _S2._backward_and_step, _S2._backward, _S2._reduce, _S2._clear_grads
-    _direct_grads = _S2._direct_grads
+    _direct_grads, _refresh_frozen = _S2._direct_grads, _S2._refresh_frozen
     del _S2
 
     def _fixed_shape_step(self, data: torch.Tensor):

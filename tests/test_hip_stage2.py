@@ -287,6 +287,31 @@ def test_fixed_shape_render_matches_the_reference_and_the_graph_step_trains(gold
     assert all(bool(torch.isfinite(p).all()) for p in trg.params)
 
 
+def test_frozen_weights_loaded_after_the_capture_reach_the_replayed_step():
+    """The captured step holds no pack launch for a frozen network (it was packed by the eager warm-up); a load_state_dict into the
+    frozen SDF network AFTER the capture must still reach the replays (Stage2Trainer._refresh_frozen packs in front of the replay)."""
+    from fneus import synth
+    from fneus.trainer import synthetic_batches
+    from fneus.trainer2 import Stage2Trainer
+    dev = torch.device(DEV)
+    batch = synthetic_batches(1, 256, dev, seed0=21)[0]
+    trg = Stage2Trainer(dev, seed=3, use_graph=True)
+    for _ in range(4):
+        trg.train_step(batch)
+    assert trg._graph is not None
+    hits_before = int(trg.train_step(batch)["n_hit"])
+    new_sd = {k: torch.from_numpy(v) for k, v in synth.sdf_state_dict(9).items()}
+    trg.sdf_network.load_state_dict(new_sd)                     # a different surface
+    o = trg.train_step(batch)
+    tre = Stage2Trainer(dev, seed=3, use_graph=False)
+    tre.sdf_network.load_state_dict(new_sd)
+    rays_o, rays_d = batch[:, :3].contiguous(), batch[:, 3:6].contiguous()
+    ref = tre.renderer.lvis_render(rays_o, rays_d, None, None, fixed_shape=True)
+    n_new = int(ref["sdf_mask"].sum())
+    assert n_new != hits_before, "the two synthetic surfaces must differ in their hit count for this test to have teeth"
+    assert int(o["n_hit"]) == n_new                             # the replay saw the new surface
+
+
 def test_fused_indirect_radiance_vs_the_element_wise_formulation():
     """IndirectLight.radiance (fneus_indir_illum_fwd / _bwd: the network's output transform + query_indir_illum in one launch each)
     against query_indir_illum(IndirectLight.forward(.)) through autograd: values and the gradients of every parameter"""
