@@ -22,6 +22,7 @@
 #endif
 
 #include "color_p2.h"
+#include "color_r8.h"
 
 #ifndef FNEUS_COL_P2_DEFAULT
 #define FNEUS_COL_P2_DEFAULT 1
@@ -729,6 +730,14 @@ static int launch_bwd(const void* blob, long n_pts, const float* d_out, const fl
     if (VAR != VAR_COLOR && (!normal || (!dirs && !rays_d))) return -2;
     const unsigned char* b = reinterpret_cast<const unsigned char*>(blob);
     ColStash st(*stash);
+    if (VAR == VAR_COLOR && (n_pts + 31) / 32 >= 1024 && (prec == 3 || prec == 1)) {
+        // chip-filling launches: resident-weight 8-wave workgroups (color_r8_kernels.hip, round 6); FNEUS_COL_BWD_R8=0 keeps the
+        // 4-wave kernels below, which also take launches whose planes exceed the r8 kernel's 32-bit buffer offsets
+        const char* r8_env = getenv("FNEUS_COL_BWD_R8");
+        const long tiles_pp = 2 * ((n_pts + 63) / 64);
+        if ((r8_env ? atoi(r8_env) : 1) != 0 && tiles_pp * 4 * (long)kPPBlock < (1L << 31))
+            return fneus::color_bwd_r8(b, n_pts, d_out, out, st, d_feat, d_normal, prec, stream);
+    }
     if (VAR == VAR_COLOR && col_use_hb2((n_pts + 31) / 32)) {
         dim3 g2(tp_grid((n_pts + 63) / 64));
         if (prec == 3) FNEUS_TPH_LAUNCH((color_bwd_tph_kernel<3, 2>), g2, b, n_pts, d_out, out, st, d_feat, d_normal);

@@ -48,6 +48,24 @@ FN_DEV void static_for(F&& f) {
 
 FN_DEV void p2_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// FNEUS_P2_STAMPS (timing experiments only): shader cycles of waves 0 and 4 of block 0, summed per part of a pass --
+// [0] pass entry -> first k-step, [1] the k-steps, [2] behind the k-steps, [3] outside p2_pass (barriers, encode, finish)
+#ifdef FNEUS_P2_STAMPS
+__device__ unsigned long long g_p2_stamp[2][4];
+__device__ unsigned long long g_p2_last[2];
+#define P2_STAMP(k)                                                                                   \
+    do {                                                                                              \
+        if (blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == 256)) {                            \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                               \
+            const int w_ = threadIdx.x >> 8;                                                          \
+            g_p2_stamp[w_][k] += t_ - g_p2_last[w_];                                                  \
+            g_p2_last[w_] = t_;                                                                       \
+        }                                                                                             \
+    } while (0)
+#else
+#define P2_STAMP(k) do { } while (0)
+#endif
+
 #ifndef FNEUS_P2_DEPTH
 #define FNEUS_P2_DEPTH 3           // weight-prefetch distance in k-steps (a k-step of a pass = 12 MFMAs = 384 cycles)
 #endif
@@ -142,6 +160,7 @@ FN_DEV void p2_pass(const unsigned char* __restrict__ blob, __amdgpu_buffer_rsrc
     constexpr bool RELU = ACT >= 3, FRAGS = ACT == 1 || ACT == 3;
     static_assert(KS >= D, "a pass consumes its D primed stages");
     const unsigned voff = (unsigned)(lane + t0 * 64) * 16u;
+    P2_STAMP(3);
 #pragma unroll
     for (int i = 0; i < TN; ++i) {                       // bias = initial accumulator
         accM[i][0] = pr.bias[i];
@@ -193,6 +212,7 @@ FN_DEV void p2_pass(const unsigned char* __restrict__ blob, __amdgpu_buffer_rsrc
 #else
     f32x16 (&vv)[TN][2] = accV;
 #endif
+    P2_STAMP(0);
     static_for<0, KS>([&](auto S_) {
         constexpr int s = decltype(S_)::value;
         constexpr int NSLOT = (PREC == 3 ? 6 : 2) * TN;
@@ -359,7 +379,9 @@ FN_DEV void p2_pass(const unsigned char* __restrict__ blob, __amdgpu_buffer_rsrc
             if constexpr (PREC == 3) asm volatile("" ::"v"(bl[s % RB][hb]));
         }
     });
+    P2_STAMP(1);
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    P2_STAMP(2);
 #ifdef FNEUS_P2_DRAIN
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_sleep 8" ::: "memory");
 #endif

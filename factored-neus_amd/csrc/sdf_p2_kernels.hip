@@ -71,6 +71,9 @@ __global__ void __launch_bounds__(512 / TN, 2 / TN) sdf_fwd_p2_kernel(const unsi
             if (n < N) sdf_out[n] = s;
         }
     };
+#ifdef FNEUS_P2_STAMPS
+    if (blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == 256)) g_p2_last[threadIdx.x >> 8] = __builtin_amdgcn_s_memtime();
+#endif
 #ifdef FNEUS_P2_CLOCK                   // timing experiments only: shader cycles and 100 MHz ticks of every wave behind the outputs
     const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -140,6 +143,15 @@ __global__ void __launch_bounds__(512 / TN, 2 / TN) sdf_fwd_p2_kernel(const unsi
         p2_barrier();
         finish(prev_unit, 2);
     }
+#ifdef FNEUS_P2_STAMPS
+    P2_STAMP(3);
+    if (blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == 256)) {
+        const int w_ = threadIdx.x >> 8;
+        printf("p2 K1 wave %d: entry %llu  k-steps %llu  tail %llu  outside %llu cycles\n", 4 * w_, g_p2_stamp[w_][0], g_p2_stamp[w_][1], g_p2_stamp[w_][2],
+               g_p2_stamp[w_][3]);
+        for (int k = 0; k < 4; ++k) g_p2_stamp[w_][k] = 0;
+    }
+#endif
 #ifdef FNEUS_P2_CLOCK
     if (lane == 0) {
         unsigned long long* st = reinterpret_cast<unsigned long long*>(sdf_out + ((N + 3) & ~3L)) + (blockIdx.x * 4 + wave) * 2;

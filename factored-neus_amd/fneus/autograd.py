@@ -212,12 +212,12 @@ class ColorFn(torch.autograd.Function):
             feat_planes = ctx.stash.feat
         else:
             (rgb,) = ctx.saved_tensors
-            d_feat, d_normal = ops.color_bwd(net.blob, n, prec, d_rgb.contiguous(), rgb, ctx.stash)
+            d_rgb = d_rgb.contiguous()
+            d_feat, d_normal = ops.color_bwd(net.blob, n, prec, d_rgb, rgb, ctx.stash)
             feat_planes = ctx.sdf_ws.cache[("sdf_stash", n, prec, True)].feat
         grad = ws.get(("col_grad", n), lambda: torch.zeros(net.n_params, dtype=torch.float32, device=rgb.device))
-        if ctx.stash.gprec == 2:        # the output layer's product on hi + lo planes (both operands are complete: u_3 from the
-            st = ctx.stash              # forward, zout from the launch above); the others follow in the merged launch as usual
-            ws.get(("col_out_jobs", n, prec, st.zout.data_ptr(), grad.data_ptr()), lambda: ops.color_out_dw_jobs(net, st, grad)).run()
+        if ctx.stash.gprec == 2:        # the output layer's product with exact operands (u_3 hi + lo from the forward, zout in fp32 from
+            ops.color_out_dw(net, ctx.stash, d_rgb, rgb, grad, n, cache=ws)       # d_rgb and rgb); the others follow in the merged launch as usual
         col = dict(ws=ws, net=net, n=n, prec=prec, stash=ctx.stash, grad=grad, feat_planes=feat_planes, gen=ctx.generation,
                    **{"for": (id(ctx.sdf_ws), ctx.sdf_generation)},
                    key=(feat_planes.data_ptr(), tuple(feat_planes.shape), ctx.stash.zbar.data_ptr(), grad.data_ptr()))

@@ -389,7 +389,7 @@ class PackedNet:
 # "gradient precision" of the backward stash: 1 = bf16 hi planes only (the weight-gradient GEMM multiplies bf16 operands,
 # fp32 accumulation), 3 = hi + lo planes (fp32-accurate weight gradients, twice the stash traffic).  The forward outputs
 # (sdf, feature, normal, colours) do not depend on it.  FNEUS_GPREC overrides the default.
-DEFAULT_GPREC = int(_os.environ.get("FNEUS_GPREC", "1"))
+DEFAULT_GPREC = int(_os.environ.get("FNEUS_GPREC", "2"))
 
 
 def _gprec(prec: int, gprec: Optional[int], mixed: bool = False) -> int:
@@ -859,6 +859,25 @@ def color_out_dw_jobs(net: PackedNet, stash: ColStash, grad_flat: torch.Tensor) 
           bias_ptr=base + 4 * offb[4])
     g.gprec = 3
     return g.finalize(stash.tiles)
+
+
+def color_out_dw(net: PackedNet, stash: ColStash, d_rgb: torch.Tensor, rgb: torch.Tensor, grad_flat: torch.Tensor, n: int, cache=None):
+    """gradient precision 2: dW and db of the colour network's output layer from the hi + lo planes of u_3 and zout formed in fp32 from
+    d_rgb and rgb (fneus_color_out_dw: one streaming pass, 1 KiB per sample).  The deterministic mode keeps the fixed-order GEMM on
+    the hi + lo planes of both operands (its job table lives in `cache`, a workspace: a captured step keeps its address)."""
+    assert stash.gprec == 2
+    if deterministic():
+        make = lambda: color_out_dw_jobs(net, stash, grad_flat)
+        jobs = make() if cache is None else cache.get(("col_out_jobs", n, stash.zout.data_ptr(), grad_flat.data_ptr()), make)
+        return jobs.run()
+    offW, offb = net.desc["offW"], net.desc["offb"]
+    _chk_f32(d_rgb, "d_rgb")
+    _chk_f32(rgb, "rgb")
+    if getattr(stash, "out_dw_scratch", None) is None:      # the replicas of the 771 sums: zero once, every call leaves them zero
+        stash.out_dw_scratch = torch.zeros(int(lib.fneus_color_out_dw_scratch_floats()), dtype=torch.float32, device=grad_flat.device)
+    _launch("fneus_color_out_dw", lib.fneus_color_out_dw, _ptr(stash.u[0, 3]), _ptr(stash.u3_lo), _ptr(d_rgb), _ptr(rgb), int(n),
+            C.c_void_p(grad_flat.data_ptr() + 4 * offW[4]), C.c_void_p(grad_flat.data_ptr() + 4 * offb[4]), _ptr(stash.out_dw_scratch),
+            _stream())
 
 
 # ------------------------------------------------------------------------------------------------------------

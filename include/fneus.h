@@ -211,6 +211,17 @@ int fneus_color_fwd(const void* col_blob, const float* pts, const float* rays_o,
 int fneus_color_bwd(const void* col_blob, long n_pts, const float* d_rgb, const float* rgb, const FneusColStash* stash,
                     float* d_feat, float* d_normal, int prec, fneus_stream_t stream);
 
+/* Weight and bias gradient of the colour network's OUTPUT layer (lin4, 256 -> 3: fields.py:170-174 through autograd's addmm backward)
+ * with exact operands -- gradient precision 2, the default of the training step:  dW[c][k] += sum_n zout[n][c] u3[n][k],
+ * db[c] += sum_n zout[n][c],  zout = d_rgb * rgb * (1 - rgb) formed in fp32.  u3_hi / u3_lo: slot 3 of FneusColStash.u (fragment
+ * planes [tiles][16][64][8] bf16; u3_lo may be NULL: hi plane alone).  dW [3][256] and db [3] (or NULL) are ACCUMULATED into
+ * (fp32 atomics).  It is the one product of a step whose bf16 operand rounding exceeds the exact mode's gradient bounds.          */
+/* scratch: fneus_color_out_dw_scratch_floats() floats, ZERO at the first call; the call leaves it zero (replicas of the sums: an
+ * address receives 16 atomic adds, not one per workgroup; a second, one-workgroup launch folds them into dW / db).                */
+int fneus_color_out_dw(const void* u3_hi, const void* u3_lo, const float* d_rgb /*[n][3]*/, const float* rgb /*[n][3]*/, long n_pts,
+                       float* dW, float* db, float* scratch, fneus_stream_t stream);
+int fneus_color_out_dw_scratch_floats(void);
+
 /* ---- K4': RefColor.forward, the surface colour head  (fields.py:271-335 via renderer.py:330-339) ------------- */
 /* Its two MLPs have the colour network's shape and run on the same kernels.  head 1 = net_cd: [pts | PE4(n) | feature]
  * -> diffuse rgb out[n][3];  head 2 = viewdir_mlp + net_cs: [n | pts | PE4(reflect(-d, n/|n|)) | feature] -> specular

@@ -437,6 +437,82 @@ def test_k3_r8_equals_the_4_wave_kernel(monkeypatch, gprec, prec, n, nh):
             assert float(t1[:, :, b1.tiles:].float().abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("nh", [4, 2])
+@pytest.mark.parametrize("gprec,prec,n", [(1, 3, 40003), (2, 3, 40003), (3, 3, 40003), (1, 1, 40003), (2, 3, 65536), (1, 3, 40067)])
+def test_colour_backward_r8_equals_the_4_wave_kernel(monkeypatch, gprec, prec, n, nh):
+    """the colour network's backward on resident-weight 8-wave workgroups (csrc/color_r8_kernels.hip, round 6; FNEUS_COL_BWD_R8=0 keeps
+    the 4-wave kernel of color_kernels.hip, read at every call): same masks, same operands, same summation order per accumulator --
+    d_feat and d_normal agree to the rounding of a lo fragment's last bit, every plane the weight-gradient GEMM reads (zbar_0..3,
+    zout) to a step of its format, and the kernel is bit-reproducible.  64- and 128-sample workgroups (FNEUS_R8_NH); ragged sizes."""
+    from fneus import ops, synth, pp
+    monkeypatch.setenv("FNEUS_R8_NH", str(nh))
+    net = ops.PackedNet("color", DEV).load_state_dict({k: T(v) for k, v in synth.color_state_dict(23).items()})
+    net.pack()
+    g = torch.Generator(device=DEV).manual_seed(9)
+    x = (torch.rand(n, 3, device=DEV, generator=g) * 2 - 1).contiguous()
+    d = torch.randn(n, 3, device=DEV, generator=g)
+    d = (d / d.norm(dim=-1, keepdim=True)).contiguous()
+    nrm = torch.randn(n, 3, device=DEV, generator=g)
+    feat = (torch.randn(n, 256, device=DEV, generator=g) * 0.3).contiguous()
+    c_rgb = torch.randn(n, 3, device=DEV, generator=g)
+    st = ops.ColStash(n, DEV, prec, gprec=gprec)
+    rgb = ops.color_fwd(net.blob, n, prec, nrm, feat, st, True, pts=x, dirs=d)
+
+    def run(r8):
+        monkeypatch.setenv("FNEUS_COL_BWD_R8", str(r8))
+        st.zbar.zero_()
+        st.zout.zero_()
+        if st.zout_lo is not None:
+            st.zout_lo.zero_()
+        df, dn = ops.color_bwd(net.blob, n, prec, c_rgb, rgb, st)
+        torch.cuda.synchronize()
+        return df.clone(), dn.clone(), st.zbar.clone(), st.zout.clone(), None if st.zout_lo is None else st.zout_lo.clone()
+
+    a, b, c = run(0), run(1), run(1)
+    for u, v in zip(b, c):
+        assert (u is None and v is None) or torch.equal(u, v)
+    assert torch.isfinite(b[0]).all() and torch.isfinite(b[1]).all()
+    fast = prec == 1
+    sc_f, sc_n = a[0].abs().max().item(), a[1].abs().max().item()
+    assert (b[0] - a[0]).abs().max().item() <= (3e-2 if fast else 2e-5) * sc_f
+    assert (b[1] - a[1]).abs().max().item() <= (3e-2 if fast else 2e-5) * sc_n
+    assert torch.equal(b[3], a[3])                                      # zout: formed from d_rgb and rgb alone
+    if a[4] is not None:
+        assert torch.equal(b[4], a[4])
+    tol = 3e-2 if fast else (8e-3 if gprec != 3 else 2e-4)
+    for l in range(4):
+        v0, v1 = pp.value(a[2][:, l], n), pp.value(b[2][:, l], n)
+        assert (v1 - v0).abs().max().item() <= tol * max(v0.abs().max().item(), 1e-9), l
+    if b[2].shape[2] > st.tiles:                                        # an allocated tile without samples stays zero
+        assert float(b[2][:, :, st.tiles:].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("n", [40003, 65536, 100])
+def test_colour_output_layer_gradient_with_exact_operands(n):
+    """fneus_color_out_dw (gradient precision 2): dW4 = zout^T u_3 and db4 = sum zout from the hi + lo planes of u_3 and zout formed in
+    fp32 from d_rgb and rgb, against fp64 on the same planes: fp32 accumulation only (<= 1e-5 of the tensor's largest element)"""
+    from fneus import ops, synth, pp
+    net = ops.PackedNet("color", DEV).load_state_dict({k: T(v) for k, v in synth.color_state_dict(24).items()})
+    g = torch.Generator(device=DEV).manual_seed(13)
+    u3 = torch.randn(n, 256, device=DEV, generator=g).clamp_min(0.0)
+    st = ops.ColStash(n, DEV, 3, gprec=2)
+    planes = pp.pack(u3, 16, 2)                                          # [2, tiles, 16, 64, 8]
+    st.u[0, 3].copy_(planes[0])
+    st.u3_lo.copy_(planes[1])
+    rgb = torch.rand(n, 3, device=DEV, generator=g)
+    d_rgb = torch.randn(n, 3, device=DEV, generator=g)
+    grad = torch.zeros(net.n_params, dtype=torch.float32, device=DEV)
+    ops.color_out_dw(net, st, d_rgb, rgb, grad, n)
+    dWs, dbs = net.split_flat(grad)
+    uval = pp.value(planes, n).double()                                  # what the planes hold (17 significant bits)
+    z = (d_rgb * rgb * (1.0 - rgb)).double()
+    ref_W, ref_b = z.t() @ uval, z.sum(0)
+    assert (dWs[4].double() - ref_W).abs().max().item() <= 1e-5 * ref_W.abs().max().item()
+    assert (dbs[4].double() - ref_b).abs().max().item() <= 1e-5 * max(ref_b.abs().max().item(), 1.0)
+    for l in range(4):
+        assert float(dWs[l].abs().max()) == 0.0 and float(dbs[l].abs().max()) == 0.0
+
+
 def test_k1_on_marked_rays_only_equals_k1_there_and_fills_the_rest():
     """fneus_sdf_fwd_rays (the stage-2 march of the fixed-shape step): marked rays get the values of the plain launch bit for bit,
     the samples of the others the fill value; nothing marked, everything marked and a ragged mix"""
