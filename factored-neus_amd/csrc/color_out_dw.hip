@@ -117,7 +117,18 @@ __global__ void __launch_bounds__(256) color_out_dw_kernel(const unsigned char* 
 }
 
 // the replicas -> the gradient (accumulated), and cleared for the next launch
-__global__ void __launch_bounds__(256) color_out_fold_kernel(float* __restrict__ rep, float* __restrict__ dW, float* __restrict__ db) {
+__global__ void __launch_bounds__(256) color_out_fold_kernel(float* __restrict__ rep, float* __restrict__ dW, float* __restrict__ db,
+                                                             const float* __restrict__ fold_src, int fold_n, float* __restrict__ fold_dst) {
+    if (fold_src != nullptr) {          // a rider: sum(fold_src) added to *fold_dst (fixed order: lane-strided, butterfly, waves 0..3)
+        __shared__ float wsum[4];
+        float v = 0.0f;
+        for (int i = threadIdx.x; i < fold_n; i += 256) v += fold_src[i];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) *fold_dst += (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    }
     for (int i = threadIdx.x; i < 771; i += 256) {
         float v[kCodReplicas];
 #pragma unroll
@@ -140,7 +151,7 @@ using namespace fneus;
 extern "C" int fneus_color_out_dw_scratch_floats(void) { return kCodReplicas * kCodStride; }
 
 extern "C" int fneus_color_out_dw(const void* u3_hi, const void* u3_lo, const float* d_rgb, const float* rgb, long n_pts, float* dW, float* db,
-                                  float* scratch, fneus_stream_t stream_) {
+                                  float* scratch, const float* fold_src, int fold_n, float* fold_dst, fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     fneus::clear_status();
     if (n_pts <= 0) return 0;
@@ -149,6 +160,6 @@ extern "C" int fneus_color_out_dw(const void* u3_hi, const void* u3_lo, const fl
     const long pairs = (tiles + 1) / 2;
     hipLaunchKernelGGL(color_out_dw_kernel, dim3((unsigned)(pairs < 512 ? pairs : 512)), dim3(256), 0, stream,
                        static_cast<const unsigned char*>(u3_hi), static_cast<const unsigned char*>(u3_lo), d_rgb, rgb, n_pts, scratch);
-    hipLaunchKernelGGL(color_out_fold_kernel, dim3(1), dim3(256), 0, stream, scratch, dW, db);
+    hipLaunchKernelGGL(color_out_fold_kernel, dim3(1), dim3(256), 0, stream, scratch, dW, db, fold_dst ? fold_src : nullptr, fold_n, fold_dst);
     return fneus::launch_status();
 }

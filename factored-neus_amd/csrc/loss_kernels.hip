@@ -229,6 +229,7 @@ __global__ void __launch_bounds__(kLossThreads) stage1_loss_kernel(LossArgs a, W
         a.losses[5] = 20.0f * log10f(1.0f / sqrtf(acc[7] / ((acc[0] + 1e-5f) * 3.0f)));     // psnr of THIS batch
         a.losses[6] = mask_sum;
         a.losses[7] = mask_sdf_sum;
+        a.losses[8] = a.losses[0];            // the total once more: callers take this slot as the loss tensor of its own (no copy launch)
     }
     // ---- sweep 2: gradients of the total loss (thread (b, k): the gradients of sample k; k = 0 also the ray's) ----
     for (int p = tid; p < 2 * a.B; p += kLossThreads) {

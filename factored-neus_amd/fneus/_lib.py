@@ -93,7 +93,7 @@ def _load():
                                     vp, vp, vp, ip, vp]),
         "fneus_color_fwd": (C.c_int, [vp, vp, vp, vp, vp, ip, l, vp, vp, vp, C.POINTER(FneusColStash), vp, ip, ip, vp]),
         "fneus_color_bwd": (C.c_int, [vp, l, vp, vp, C.POINTER(FneusColStash), vp, vp, ip, vp]),
-        "fneus_color_out_dw": (C.c_int, [vp, vp, vp, vp, l, vp, vp, vp, vp]),
+        "fneus_color_out_dw": (C.c_int, [vp, vp, vp, vp, l, vp, vp, vp, vp, ip, vp, vp]),
         "fneus_color_out_dw_scratch_floats": (C.c_int, []),
         "fneus_refcolor_fwd": (C.c_int, [vp, ip, vp, vp, vp, vp, ip, l, vp, vp, vp, C.POINTER(FneusColStash), vp, ip, ip, vp]),
         "fneus_refcolor_bwd": (C.c_int, [vp, ip, l, vp, ip, vp, vp, vp, vp, C.POINTER(FneusColStash), vp, vp, ip, vp]),

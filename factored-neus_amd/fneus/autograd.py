@@ -74,10 +74,11 @@ class SdfValueGradFn(torch.autograd.Function):
         ws.check(ctx.stash, ctx.generation, "SDFNetwork backward")
         # every consumer of sdf / feature / normal has run its backward by now: the gradients of the colour network, the
         # RefColor heads and the variance are final.  The data-parallel trainer starts their exchange here, beside K3.
+        dev = d_feat.device if d_feat is not None else (d_sdf.device if d_sdf is not None else d_normal.device)
+        ops.flush_fold_rider(dev)          # (a variance-gradient sum no fold launch has taken along: gradient precision 1 / 3)
         hook = getattr(ws, "pre_backward", None)
         if hook is not None:
             hook()
-        dev = d_feat.device if d_feat is not None else (d_sdf.device if d_sdf is not None else d_normal.device)
         d_sdf = torch.zeros(n, device=dev) if d_sdf is None else d_sdf.contiguous()
         d_feat = torch.zeros(n, 256, device=dev) if d_feat is None else d_feat.contiguous()
         d_normal = torch.zeros(n, 3, device=dev) if d_normal is None else d_normal.contiguous()
@@ -542,6 +543,7 @@ class CompositeFn(torch.autograd.Function):
         out = ops.composite_fwd(rays_o, rays_d, mid_z, dists, sdf.contiguous(), normal.contiguous(), rgb.contiguous(),
                                 var1, car, bga, bgc, inv_s_mode=1, back_rgb=back_rgb)
         ctx.car, ctx.has_bg, ctx.var_shape, ctx.back_rgb = car, bga is not None, variance.shape, back_rgb
+        ctx.var_param = variance if (variance.is_leaf and variance.requires_grad) else None
         ctx.set_materialize_grads(False)        # unused outputs (e.g. `weights`) must not be zero-filled for us
         saved = [sdf, normal, rgb, var1, rays_o, rays_d, mid_z, dists, out["min_idx"], out["sdf_mask"]]
         if ctx.has_bg:
@@ -568,7 +570,17 @@ class CompositeFn(torch.autograd.Function):
         d_sdf, d_normal, d_rgb, d_var, d_bga, d_bgc = ops.composite_bwd(
             rays_o, rays_d, mid_z, dists, sdf, normal, rgb, var1, ctx.car, min_idx, sdf_mask, d_color, d_wsum, d_weights,
             d_wpair, d_eiknum, bga, bgc, inv_s_mode=1, back_rgb=ctx.back_rgb)
-        return d_sdf, d_normal, d_rgb, d_var.sum().reshape(ctx.var_shape), None, None, None, None, None, d_bga, d_bgc, None
+        # the variance parameter's gradient = the sum of the per-ray terms.  With a persistent gradient buffer (the trainers' arena) and
+        # the colour network's exact output-layer launch still to come in this backward pass, the sum rides in that launch's fold
+        # stage and is added to variance.grad there: a reduction launch and autograd's accumulation launch less per step
+        var = ctx.var_param
+        if (var is not None and var.grad is not None and var.grad.is_contiguous() and var.grad.dtype == torch.float32 and var.numel() == 1
+                and ops.DEFAULT_FOLD_RIDER and ops.PROFILE is None):
+            ops.offer_fold_rider(d_var, var.grad)
+            d_var_out = None
+        else:
+            d_var_out = d_var.sum().reshape(ctx.var_shape)
+        return d_sdf, d_normal, d_rgb, d_var_out, None, None, None, None, None, d_bga, d_bgc, None
 
 
 # The latest surface_gather's outputs, held WEAKLY and recognised by identity (an address can be handed to an unrelated tensor of
@@ -634,7 +646,7 @@ class Stage1LossFn(torch.autograd.Function):
         aux = (o["losses"], o["surface_color"], o["specular_color"], o["diffuse_color"])
         ctx.mark_non_differentiable(*aux)
         ctx.set_materialize_grads(False)         # no zero-filled cotangents for the four report-only outputs
-        return (o["losses"][0].clone(),) + aux
+        return (o["loss"],) + aux          # (slot 8 of the kernel's losses: the total as a tensor of its own, no copy launch)
 
     @staticmethod
     def backward(ctx, g, *unused):

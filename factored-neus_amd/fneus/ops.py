@@ -877,7 +877,44 @@ def color_out_dw(net: PackedNet, stash: ColStash, d_rgb: torch.Tensor, rgb: torc
         stash.out_dw_scratch = torch.zeros(int(lib.fneus_color_out_dw_scratch_floats()), dtype=torch.float32, device=grad_flat.device)
     _launch("fneus_color_out_dw", lib.fneus_color_out_dw, _ptr(stash.u[0, 3]), _ptr(stash.u3_lo), _ptr(d_rgb), _ptr(rgb), int(n),
             C.c_void_p(grad_flat.data_ptr() + 4 * offW[4]), C.c_void_p(grad_flat.data_ptr() + 4 * offb[4]), _ptr(stash.out_dw_scratch),
-            _stream())
+            *_take_fold_rider(grad_flat.device), _stream())
+
+
+# A small reduction that waits for the next one-workgroup fold launch of the backward pass (fneus_color_out_dw's): CompositeFn.backward
+# leaves the per-ray gradients of inv_s here with the address of the variance parameter's gradient; whatever still waits when the
+# backward pass ends is summed by torch (autograd-engine callback).  One slot per device.
+_FOLD_RIDER = {}
+DEFAULT_FOLD_RIDER = _os.environ.get("FNEUS_FOLD_RIDER", "1") != "0"
+
+
+def offer_fold_rider(src: torch.Tensor, dst: torch.Tensor):
+    """sum(src) is to be ADDED to the one-element tensor dst by the next fold launch on this device"""
+    dev = src.device
+    rec = (src, dst)
+    _FOLD_RIDER[dev] = rec
+
+    def flush():
+        if _FOLD_RIDER.get(dev) is rec:
+            del _FOLD_RIDER[dev]
+            dst.add_(src.sum())
+
+    torch.autograd.Variable._execution_engine.queue_callback(flush)
+
+
+def flush_fold_rider(dev):
+    """apply a rider nobody has taken (SdfValueGradFn.backward calls this in front of the data-parallel step's early gradient
+    exchange: the variance gradient has to be complete by then)"""
+    rec = _FOLD_RIDER.pop(dev, None)
+    if rec is not None:
+        rec[1].add_(rec[0].sum())
+
+
+def _take_fold_rider(dev):
+    rec = _FOLD_RIDER.pop(dev, None)
+    if rec is None:
+        return None, 0, None
+    src, dst = rec
+    return _ptr(src), int(src.numel()), _ptr(dst)
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -1001,7 +1038,8 @@ def stage1_loss(color, true_rgb, mask_in, wsum, eik_num, eik_den, diffuse, spec,
     for x, nm in ((color, "color"), (true_rgb, "true_rgb"), (mask_in, "mask"), (wsum, "wsum"), (eik_num, "eik_num"),
                   (eik_den, "eik_den"), (diffuse, "diffuse"), (spec, "spec"), (wpair, "wpair")):
         _chk_f32(x, nm)
-    o = {"losses": torch.empty(8, **f32), "surface_color": torch.empty(B, 3, **f32), "specular_color": torch.empty(B, 3, **f32),
+    both = torch.empty(9, **f32)          # losses[8] = the total once more: the loss tensor of its own (include/fneus.h)
+    o = {"losses": both[:8], "loss": both[8:].view(()), "surface_color": torch.empty(B, 3, **f32), "specular_color": torch.empty(B, 3, **f32),
          "diffuse_color": torch.empty(B, 3, **f32), "d_color": torch.empty(B, 3, **f32), "d_wsum": torch.empty(B, **f32),
          "d_eiknum": torch.empty(B, **f32), "d_wpair": torch.empty(B, 2, **f32), "d_diffuse": torch.empty(2 * B, 3, **f32),
          "d_spec": torch.empty(2 * B, 3, **f32)}

@@ -218,8 +218,11 @@ int fneus_color_bwd(const void* col_blob, long n_pts, const float* d_rgb, const 
  * (fp32 atomics).  It is the one product of a step whose bf16 operand rounding exceeds the exact mode's gradient bounds.          */
 /* scratch: fneus_color_out_dw_scratch_floats() floats, ZERO at the first call; the call leaves it zero (replicas of the sums: an
  * address receives 16 atomic adds, not one per workgroup; a second, one-workgroup launch folds them into dW / db).                */
+/* fold_src / fold_n / fold_dst (or NULL / 0 / NULL): the one-workgroup fold launch ALSO adds sum(fold_src[0 .. fold_n)) to *fold_dst --
+ * the step's other small reduction, the variance parameter's gradient (per-ray d inv_s of fneus_composite_bwd), rides along instead
+ * of costing a reduction launch and an accumulation launch of its own.                                                           */
 int fneus_color_out_dw(const void* u3_hi, const void* u3_lo, const float* d_rgb /*[n][3]*/, const float* rgb /*[n][3]*/, long n_pts,
-                       float* dW, float* db, float* scratch, fneus_stream_t stream);
+                       float* dW, float* db, float* scratch, const float* fold_src, int fold_n, float* fold_dst, fneus_stream_t stream);
 int fneus_color_out_dw_scratch_floats(void);
 
 /* ---- K4': RefColor.forward, the surface colour head  (fields.py:271-335 via renderer.py:330-339) ------------- */
@@ -280,7 +283,8 @@ int fneus_surface_scatter(const int32_t* sel /*[R]*/, const float* d_feat_heads 
 /* RefColor shading (linear->sRGB, clip: fields.py:262-268, 331-335), the two-sample blend (renderer.py:336-343), the
  * training losses (exp_runner.py:141-177: colour L1, surface L1, eikonal, mask BCE) and the gradient of the total loss
  * with respect to every differentiable input, in one launch.  diffuse / spec are the outputs of fneus_refcolor_fwd
- * heads 1 / 2 on the gathered samples.  losses[8] = total, colour, surface, eikonal, mask, psnr, mask_sum, mask_sdf_sum. */
+ * heads 1 / 2 on the gathered samples.  losses[9] = total, colour, surface, eikonal, mask, psnr, mask_sum, mask_sdf_sum, and the
+ * total once more (round 6: the slot a caller hands on as "the loss", a tensor of its own, without a copy launch).           */
 int fneus_stage1_loss(const float* color /*[B][3]*/, const float* true_rgb /*[B][3]*/, const float* mask_in /*[B]*/,
                       const float* wsum /*[B]*/, const float* eik_num /*[B]*/, const float* eik_den /*[B]*/,
                       const float* diffuse /*[2B][3]*/, const float* spec /*[2B][3], column 0*/, const float* wpair /*[B][2]*/,

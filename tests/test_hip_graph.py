@@ -109,3 +109,29 @@ def test_forward_only_render_replays_one_graph_per_chunk_shape():
     kept = first.clone()
     second = graphed.render_only(b)["color_fine"]
     assert second.data_ptr() == first.data_ptr() and not torch.equal(kept, second)
+
+
+def test_variance_gradient_riding_in_the_fold_launch_equals_the_plain_sum(monkeypatch):
+    """round 6: the sum of the per-ray inv_s gradients (fneus_composite_bwd) rides in the fold stage of fneus_color_out_dw and is added
+    to variance.grad there (ops.offer_fold_rider) instead of a reduction launch + autograd's accumulation launch; the loss tensor is
+    slot 8 of the loss kernel's output instead of a copy.  Same parameters after three steps as with both switched off (the sums
+    differ in their order only), eagerly and as a replayed graph."""
+    from fneus import ops
+    from fneus.trainer import Stage1Trainer, synthetic_batches
+    dev = torch.device("cuda:0")
+    batches = synthetic_batches(5, 256, dev, seed0=77)
+
+    def run(rider, graph):
+        monkeypatch.setattr(ops, "DEFAULT_FOLD_RIDER", rider)
+        torch.manual_seed(11)                                       # (the depth jitter of every step)
+        tr = Stage1Trainer(dev, seed=5, use_graph=graph)
+        losses = [float(tr.train_step(b)["loss"]) for b in batches]
+        return losses, float(tr.deviation_network.variance.detach()), tr.color_network.lin4.weight_v.detach().clone()
+
+    for graph in (False, True):
+        l0, v0, w0 = run(False, graph)
+        l1, v1, w1 = run(True, graph)
+        assert abs(l1[0] - l0[0]) <= 1e-6 * abs(l0[0])
+        assert abs(v1 - v0) <= 2e-6, (v1, v0)                       # the Adam steps of lr 5e-4 moved it by ~2e-3
+        assert abs(v1 - 0.3) > 1e-4
+        assert (w1 - w0).abs().max().item() <= 2e-3 * w0.abs().max().item()      # (atomics order -> Adam: a few elements by a fraction of lr)

@@ -9,11 +9,12 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-# gprec 3: fp32-accurate weight gradients (hi + lo planes): the trajectories overlay to 3 %.  gprec 1 (the default of the
-# training step: bf16 planes, 1e-3 relative gradient rounding): Adam's normalised updates turn that into visibly different
-# -- not worse -- trajectories on this 48-ray toy problem after ~8 steps; the bound is the spread two fp32 runs with
-# different atomics order show at 400 steps (tests/test_hip_scene.py)
-@pytest.mark.parametrize("gprec,later_tol", [(3, 3e-2), (1, 2.5e-1)])
+# gprec 3: fp32-accurate weight gradients (hi + lo planes): the trajectories overlay to 3 %.  gprec None = the DEFAULT of the
+# training step since round 6, gradient precision 2 (bf16 planes but for the colour network's output layer, whose product runs on
+# exact operands: fneus_color_out_dw): held to 5 %.  gprec 1 (bf16 planes everywhere, 1e-3 relative gradient rounding): Adam's
+# normalised updates turn that into visibly different -- not worse -- trajectories on this 48-ray toy problem after ~8 steps; the
+# bound is the spread two fp32 runs with different atomics order show at 400 steps (tests/test_hip_scene.py)
+@pytest.mark.parametrize("gprec,later_tol", [(3, 3e-2), (None, 5e-2), (1, 2.5e-1)])
 def test_loss_trajectory_matches_oracle_training(gprec, later_tol):
     from fneus import ops, synth
     from fneus.trainer import Stage1Trainer, WMASK_MODEL
@@ -30,6 +31,8 @@ def test_loss_trajectory_matches_oracle_training(gprec, later_tol):
         out = tr.train_step(b.to(dev))
         hip.append({k: float(v.detach()) for k, v in out.items()})
     assert len(tr._graphs) == 1                                    # most of the run is replayed graphs
+    if gprec is None:
+        assert ops.DEFAULT_GPREC == 2 and tr.color_network._ws.cache[("col_stash", B * 32, ops.PREC_PARITY)].gprec == 2
     # ---- oracle: same initial weights (synthetic streams), same batches, torch.optim.Adam
     T = lambda sd: {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in sd.items()}
     sd_sdf, sd_col, sd_ref = T(synth.sdf_state_dict(seed)), T(synth.color_state_dict(seed + 1)), T(synth.refcolor_state_dict(seed + 2))
