@@ -69,9 +69,12 @@ KERNEL_BYTES_PARITY_EXTRA = {
     "fneus_color_bwd": (64 + 12 + 4 * 512 + 64 + 1024 + 12) * SAMPLES_PER_STEP,
     "fneus_dw_gemm_pp:color": (8 * 512 + 512 + 128 + 64) * SAMPLES_PER_STEP,
     "fneus_sdf_fwd": 0.875 * 16 * SAMPLES_PER_STEP,
+    # gradient precision 2 (the default): the output layer's product reads the hi + lo planes of u_3 and d_rgb, rgb
+    "fneus_color_out_dw": (2 * 512 + 24) * SAMPLES_PER_STEP,
 }
 KERNEL_BYTES_PARITY["fneus_dw_gemm_pp:sdf+color"] = (KERNEL_BYTES_PARITY["fneus_dw_gemm_pp:sdf"]
                                                      + KERNEL_BYTES_PARITY_EXTRA["fneus_dw_gemm_pp:color"])
+ALGORITHMIC_STASH_BYTES_PER_SAMPLE = 11.0 * 1024 + 40      # ~11 KB activation stash + 40 B of API outputs
 HBM_ACHIEVABLE_GBS = 6300.0          # float4 copy on this part (MI355X_MICROARCH.md: 6.29 TB/s measured, 79 % of the 8 TB/s spec)
 MFMAS_PER_PRODUCT = {"fneus_dw_gemm_pp:sdf": 1, "fneus_dw_gemm_pp:color": 1, "fneus_dw_gemm_pp:sdf+color": 1}      # gprec 1: bf16 planes; the chains issue 3
 KERNEL_FLOPS_EXTRA = {"fneus_sdf_fwd": 0.875 * F_SDF * SAMPLES_PER_STEP}
@@ -172,7 +175,7 @@ def cpu_baseline(device=None):
 
 
 # newest first: the PMC passes are re-collected whenever a kernel's memory behaviour changes (tools/collect_profiles.sh)
-TRAFFIC_FILES = ("r05_e_traffic.json", "r05_d_traffic.json", "r05_c_traffic.json", "r05_b_traffic.json", "r05_a_traffic.json", "r04_h_traffic.json", "r04_f_traffic.json", "r04_e_traffic.json", "r04_d_traffic.json", "r04_c_traffic.json", "r04_b_traffic.json", "r04_a_traffic.json", "r03_h_traffic.json", "r03_g_traffic.json", "r03_f_traffic.json", "r03_e_traffic.json", "r03_d_traffic.json", "r03_c_traffic.json", "r03_b_traffic.json", "r03_a_traffic.json", "r02_e_traffic.json", "r02_d_traffic.json", "r02_c_traffic.json", "r02_b_traffic.json", "r02_a_traffic.json")
+TRAFFIC_FILES = ("r06_z_traffic.json", "r06_y_traffic.json", "r06_x_traffic.json", "r05_e_traffic.json", "r05_d_traffic.json", "r05_c_traffic.json", "r05_b_traffic.json", "r05_a_traffic.json", "r04_h_traffic.json", "r04_f_traffic.json", "r04_e_traffic.json", "r04_d_traffic.json", "r04_c_traffic.json", "r04_b_traffic.json", "r04_a_traffic.json", "r03_h_traffic.json", "r03_g_traffic.json", "r03_f_traffic.json", "r03_e_traffic.json", "r03_d_traffic.json", "r03_c_traffic.json", "r03_b_traffic.json", "r03_a_traffic.json", "r02_e_traffic.json", "r02_d_traffic.json", "r02_c_traffic.json", "r02_b_traffic.json", "r02_a_traffic.json")
 
 
 def main():
@@ -286,6 +289,14 @@ def main():
 
     prec = ops.PREC_PARITY if args.prec == "parity" else ops.PREC_FAST
     dt, prof, tr = run(prec, args.steps, args.warmup, profile=not args.no_profile)
+    box = None
+    if rank == 0:
+        try:        # what THIS lease delivers to two trivial kernels (the same code measured 5-8 % apart between boxes)
+            box = ops.box_probe(device)
+            box["device"] = torch.cuda.get_device_name(local)
+            box["reference"] = "builder's boxes, round 6: see DESIGN.md 5.0 (a box whose probes read lower runs every kernel of the step slower)"
+        except Exception as e:
+            box = {"error": repr(e)}
     ms_per_step = dt / args.steps * 1e3
     value = world * samples_rank * args.steps / dt
     gprec_run = ops.DEFAULT_GPREC if hasattr(ops, "DEFAULT_GPREC") else 1
@@ -304,7 +315,9 @@ def main():
         "vs_baseline": None,
         "dtype": (f"bf16x3 split MFMA (3 products per value, fp32 accumulate) in every forward and backward chain = the 1e-4 parity mode; "
                   f"weight-gradient GEMM operands: gradient precision {gprec_run} "
-                  f"({'bf16 planes' if gprec_run == 1 else 'bf16 hi + lo planes'})") if prec == 3 else "bf16 MFMA, fp32 accumulate",
+                  + {1: "(bf16 planes)", 2: "(bf16 planes; the colour network's output layer -- the one product whose bf16 rounding exceeds "
+                                          "the exact mode's gradient bounds -- on exact operands, fp32 FMAs)", 3: "(bf16 hi + lo planes)"}[gprec_run])
+                 if prec == 3 else "bf16 MFMA, fp32 accumulate",
         "data": "synthetic DTU-shaped rays (one camera per step), random-init weights of the reference distributions",
         "config": {"workload": (f"Shiny-Blender-shaped womask.conf stage-1 train step, {rays_rank * world} rays per step over {world} rank(s) x "
                                 f"(64+64+32) samples (BASELINE configs[4] shape)" if args.womask else
@@ -325,6 +338,7 @@ def main():
                               "one hipGraph replay per step")},
         **({"diagnostic": "FNEUS_DP_SINGLE=1: data-parallel step structure with one rank"} if dp_single else {}),
         "mfma_roofline_frac_step": value / world * FLOP_TRAIN_PER_SAMPLE / (PEAK_BF16_MFMA_TFLOPS * 1e12),
+        **({"box": box} if box is not None else {}),
     }
     standard = not strong and not args.womask          # the extras below describe the headline workload only
 
@@ -400,14 +414,39 @@ def main():
                                        "north_star's 2e8 ray-samples/s (0.33 ms per step) lies below this floor in parity mode"}
         if both:
             result["rooflines_by_kernel"] = both
-        result["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS,
-                              "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_MFMA_TFLOPS, "traffic": traffic,
-                              "traffic_source": traffic_src,
-                              "avg_launch_ms": per[dom]["avg_ms"],
-                              "note": "algorithmic (fp32-equivalent) FLOPs per launch / HIP-event launch duration; "
-                                      "parity mode issues 3 bf16 MFMAs per algorithmic product"
-                                      + ("; fneus_sdf_fwd_grad is two kernels since round 3 (forward chain with the stash, "
-                                         "reverse sweep): FLOPs and duration of the pair" if dom == "fneus_sdf_fwd_grad" else "")}
+        # the contract's `roofline`: the dominant kernel against the roof that BINDS it in this design (its own `floor` entry: the larger
+        # of design bytes / achievable HBM rate and MFMAs issued x algorithmic FLOPs / the dense peak), the other roof's fraction beside it
+        fl = kernel_floor_ms(dom, gprec_run) if prec == ops.PREC_PARITY else {"bound": "mfma"}
+        n_dom = max(round(per[dom]["launches_per_step"]), 1)
+        mfma_frac = achieved / PEAK_BF16_MFMA_TFLOPS
+        gbs_dom = (KERNEL_BYTES_PARITY.get(dom, KERNEL_BYTES_PARITY_EXTRA.get(dom, 0.0)) / n_dom / (per[dom]["avg_ms"] * 1e-3) / 1e9
+                   if prec == ops.PREC_PARITY else 0.0)
+        if fl["bound"] == "hbm" and gbs_dom > 0.0:
+            result["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": gbs_dom, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                  "frac": gbs_dom / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                                  "avg_launch_ms": per[dom]["avg_ms"],
+                                  "other_roof": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                                 "frac": mfma_frac, "mfma_issue_frac": mfma_frac * (MFMAS_PER_PRODUCT.get(dom, 3) if gprec_run != 3 else 3)},
+                                  "floor_ms": round(fl["floor_ms"], 4), "frac_of_floor": round(fl["floor_ms"] / per[dom]["avg_ms"] / n_dom, 3),
+                                  "note": "the dominant kernel against the roof that binds it: algorithmic (design) stash bytes per launch / "
+                                          "HIP-event launch duration against the 8 TB/s HBM3E peak (6.3 TB/s is what a copy reaches); "
+                                          "`traffic` = PMC bytes per launch from the committed file named in traffic_source; other_roof: "
+                                          "algorithmic FLOPs / duration against the dense bf16 MFMA peak (x 3 MFMAs issued per product in parity mode)"}
+        else:
+            result["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS,
+                                  "unit": "TFLOP/s", "frac": mfma_frac, "traffic": traffic,
+                                  "traffic_source": traffic_src, "avg_launch_ms": per[dom]["avg_ms"],
+                                  "other_roof": ({"bound": "hbm", "achieved": gbs_dom, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs_dom / PEAK_HBM_GBS}
+                                                 if gbs_dom > 0.0 else None),
+                                  "note": "algorithmic (fp32-equivalent) FLOPs per launch / HIP-event launch duration; "
+                                          "parity mode issues 3 bf16 MFMAs per algorithmic product"
+                                          + ("; fneus_sdf_fwd_grad is two kernels since round 3 (forward chain with the stash, "
+                                             "reverse sweep): FLOPs and duration of the pair" if dom == "fneus_sdf_fwd_grad" else "")}
+        # HBM traffic of the whole step per ray sample (PMC, committed file) against SURVEY 8(d)'s algorithmic stash
+        if prec == ops.PREC_PARITY and traffic_src and traffic_src.get("step_bytes_per_ray_sample"):
+            result["bytes_per_ray_sample"] = traffic_src["step_bytes_per_ray_sample"]
+            result["wasted_traffic_ratio"] = traffic_src["step_bytes_per_ray_sample"] / ALGORITHMIC_STASH_BYTES_PER_SAMPLE
+            result["bytes_per_ray_sample_source"] = traffic_src["file"] + " (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE over one step, builder's box; / SURVEY 8(d)'s ~11 KB stash + 40 B)"
 
     if rank == 0 and world == 1 and not args.no_fast_extra and standard:
         # forward-only render of the same batch (what validate_image runs per ray chunk), SURVEY.md section 8(d)
@@ -503,6 +542,41 @@ def main():
             dt = (time.perf_counter() - t0) / 10
             return dt, (float(hit_sum) / n_counted if n_counted else 0.0), bool(tr.use_graph)
 
+        STAGE_PMC_FILES = {"stage2": ("r06_z_stage2_pmc.json", "r06_y_stage2_pmc.json", "r06_x_stage2_pmc.json"),
+                           "stage3": ("r06_z_stage3_pmc.json", "r06_y_stage3_pmc.json", "r06_x_stage3_pmc.json")}
+        STAGE_KERNEL = {"fneus_sdf_fwd_rays": "sdf_fwd_p2_kernel", "fneus_sdf_fwd": "sdf_fwd_p2_kernel", "fneus_lvis_visibility": "lvis_visibility_p2_kernel"}
+
+        def stage_roofline(stage, make_trainer):
+            """the stage's dominant kernel: its launch duration measured HERE (HIP events around the eager fixed-shape step's launches),
+            its issued MFMA FLOP and HBM bytes per launch from the committed PMC passes (tools/collect_stage_pmc.sh)"""
+            tr = make_trainer()
+            for b in sb[:2]:
+                tr._fixed_shape_step(b)
+            ops.profile_begin()
+            for b in sb[2:4]:
+                tr._fixed_shape_step(b)
+            pr = ops.profile_end()
+            name = max((k for k in pr if k in STAGE_KERNEL), key=lambda k: pr[k][1])
+            n_l, ms = pr[name]
+            avg_s = ms / n_l * 1e-3
+            e = {"kernel": name, "launches_per_step": n_l / 2.0, "avg_launch_ms": ms / n_l, "ms_per_step": ms / 2.0}
+            for tag in STAGE_PMC_FILES[stage]:
+                try:
+                    pj = json.load(open(os.path.join(ROOT, "profiles", tag)))
+                    kname = next(k for k in pj["kernels"] if k.startswith(STAGE_KERNEL[name]))
+                    pk = pj["kernels"][kname]
+                    issued = pk["mfma_flop_issued_per_launch"]
+                    e.update({"bound": "mfma", "achieved": issued / 3.0 / avg_s / 1e12, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                              "frac": issued / 3.0 / avg_s / 1e12 / PEAK_BF16_MFMA_TFLOPS, "mfma_issue_frac": issued / avg_s / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                              "traffic": pk.get("hbm_bytes_per_launch"), "mfma_busy_pmc": pk.get("mfma_busy"),
+                              "traffic_source": "profiles/" + tag + " (" + kname + ")",
+                              "note": "algorithmic FLOP = issued bf16 MFMA FLOP (SQ_INSTS_VALU_MFMA_MOPS_BF16 x 512, committed PMC pass) / 3 products per "
+                                      "value, over this run's HIP-event launch duration; mfma_busy_pmc = the matrix pipe's busy fraction in that pass"})
+                    break
+                except Exception:
+                    continue
+            return e
+
         try:
             from fneus.trainer2 import Stage2Trainer
             dt_2, n_hit, graph2 = timed_stage(lambda: Stage2Trainer(device, prec=prec, use_graph=not args.no_graph))
@@ -512,6 +586,10 @@ def main():
                                                if graph2 else "eager launches, hit points compacted",
                                      "note": "lvis_render + L1 losses + backward + Adam (lvis.py:132-196): 4 secondary rays per hit "
                                              "point x 512 coarse samples through K1, 32 fine samples through K2, same precision mode"}
+            try:
+                result["stage2_step"]["roofline"] = stage_roofline("stage2", lambda: Stage2Trainer(device, prec=prec, use_graph=False))
+            except Exception as e:
+                result["stage2_step"]["roofline"] = {"error": repr(e)}
         except Exception as e:   # an extra must never take the headline number down with it
             result["stage2_step"] = {"value": None, "error": repr(e)}
         try:
@@ -525,6 +603,10 @@ def main():
                                              "128 light lobes x 32 directions per hit point (the nominal count `value` uses; the network "
                                              "runs on the directions that face the surface, as in the reference: about half), SG rendering "
                                              "of 128 + 24 lobes"}
+            try:
+                result["stage3_step"]["roofline"] = stage_roofline("stage3", lambda: Stage3Trainer(device, prec=prec, use_graph=False))
+            except Exception as e:
+                result["stage3_step"]["roofline"] = {"error": repr(e)}
         except Exception as e:
             result["stage3_step"] = {"value": None, "error": repr(e)}
         try:    # the lever this step has left, measured and NOT the default: its visibility launch with ONE fp16 product
@@ -549,15 +631,15 @@ def main():
             result["exact_gradients_gprec3"] = {"value": SAMPLES_PER_STEP * n_g / dt_g, "unit": "ray-samples/s", "ms_per_step": dt_g / n_g * 1e3}
         except Exception as e:
             result["exact_gradients_gprec3"] = {"value": None, "error": repr(e)}
-        try:    # gradient precision 2: lo planes for the two operands of the colour network's output layer alone -- the one product
-            # whose bf16 rounding exceeds the exact mode's bounds (tests/test_hip_render.py runs those bounds on this mode)
-            dt_m, _, _ = run(prec, max(args.steps // 2, 5), 3, profile=False, gprec=2)
+        try:    # gradient precision 1 (the default of rounds 2-5): bf16 planes for every product, the colour network's output layer included --
+            # its gradient bounds are looser (tests/test_hip_render.py: 8e-3 / 5e-3 of scale; the 12-step loss trajectory 25 %)
+            dt_m, _, _ = run(prec, max(args.steps // 2, 5), 3, profile=False, gprec=1)
             n_m = max(args.steps // 2, 5)
-            result["mixed_gradients_gprec2"] = {"value": SAMPLES_PER_STEP * n_m / dt_m, "unit": "ray-samples/s", "ms_per_step": dt_m / n_m * 1e3,
-                                                "note": "the gradient bounds of gprec 3 (5e-3 of scale per sampled element, 2e-3 of a tensor's norm) hold; "
-                                                        "hi planes everywhere but zout and slot 3 of u (0.6 KB per sample)"}
+            result["bf16_gradient_planes_gprec1"] = {"value": SAMPLES_PER_STEP * n_m / dt_m, "unit": "ray-samples/s", "ms_per_step": dt_m / n_m * 1e3,
+                                                     "note": "rounds 2-5 reported this mode as the headline; the headline's mode (gradient precision 2) "
+                                                             "holds the gradient bounds of gprec 3 (5e-3 of scale per sampled element, 2e-3 of a tensor's norm)"}
         except Exception as e:
-            result["mixed_gradients_gprec2"] = {"value": None, "error": repr(e)}
+            result["bf16_gradient_planes_gprec1"] = {"value": None, "error": repr(e)}
         try:    # config 5's per-GPU share of a 2048-ray batch at 8 ranks: 256 rays (womask shape), the strong-scaling point
             import copy
             from fneus.trainer import WMASK_MODEL
@@ -602,69 +684,15 @@ def main():
         except Exception as e:
             result["parity"] = {"error": repr(e)}
         try:
-            cj = json.load(open(os.path.join(ROOT, "profiles", "r05_chamfer.json")))
+            cj = json.load(open(os.path.join(ROOT, "profiles", "r06_chamfer.json" if os.path.exists(os.path.join(ROOT, "profiles", "r06_chamfer.json")) else "r05_chamfer.json")))
             result["chamfer"] = {k: cj[k] for k in ("what", "steps", "seeds", "hip_mean", "hip_sd", "oracle_mean", "oracle_sd",
                                                     "ratio_of_means", "sem_log_ratio_pct", "within_2_pct") if k in cj}
-            result["chamfer"]["source"] = "profiles/r05_chamfer.json (tests/checkers/chamfer_study.py on the builder's box, round-5 kernels; not measured in this run)"
+            result["chamfer"]["source"] = ("profiles/r06_chamfer.json (tests/checkers/chamfer_study.py on the builder's box, round-6 kernels at the default gradient "
+                                           "precision 2; not measured in this run)" if os.path.exists(os.path.join(ROOT, "profiles", "r06_chamfer.json")) else
+                                           "profiles/r05_chamfer.json (tests/checkers/chamfer_study.py on the builder's box, round-5 kernels, gradient precision 1; "
+                                           "not measured in this run)")
         except Exception:
             pass
-
-    if rank == 0 and world == 1 and standard and prec == ops.PREC_PARITY and not args.no_fast_extra:
-        # DESIGN.md section 4.4, plan (ii), the prototype: K1 with "h6" products -- hi.hi as ONE fp16 MFMA per 16 k, the cross terms
-        # as two block-scaled fp6 MFMAs per 64 k (csrc/h6_engine.h): 1.5 MFMA-times per product instead of 3.  Behind FNEUS_K1_H6 /
-        # ops.set_k1_h6; NOT the headline's arithmetic.  Reported: the launch beside the shipped one on the same points with both
-        # errors against fp64, and the steps whose K1 launches it replaces.
-        try:
-            from oracle import ref_torch as R
-            from fneus import synth
-            sd = {k: torch.from_numpy(v) for k, v in synth.sdf_state_dict(20).items()}
-            pr = R.sdf_params_from_state_dict(sd)
-            net6 = ops.PackedNet("sdf", device)
-            net6.set_raw_from_effective([w.to(device) for w in pr["W"]], [b.to(device) for b in pr["b"]])
-            net6.pack()
-            npt = RAYS * (N_SAMPLES + N_IMPORTANCE)
-            gq = torch.Generator(device=device).manual_seed(1)
-            xq = (torch.rand(npt, 3, device=device, generator=gq) * 2.2 - 1.1).contiguous()
-            ref64 = R.sdf_only(xq[:8192].cpu().double(), {"W": [w.double() for w in pr["W"]], "b": [b.double() for b in pr["b"]], "scale": 1.0})[:, 0]
-
-            def k1_time(fn):
-                for _ in range(5):
-                    fn()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(20):
-                    o = fn()
-                e1.record()
-                torch.cuda.synchronize()
-                return e0.elapsed_time(e1) / 20, float((o[:8192].cpu().double() - ref64).abs().max())
-
-            ops.h6_blob(net6.blob)
-            t3, e3 = k1_time(lambda: ops.sdf_fwd(net6.blob, npt, 3, pts=xq))
-            t6, e6 = k1_time(lambda: ops.sdf_fwd_h6(net6.blob, npt, pts=xq, repack=False))
-            h6 = {"what": "K1 (SDFNetwork.sdf) with fp16 hi.hi + two block-scaled fp6 cross terms: 1.5 MFMA-times per product",
-                  "k1_points": npt, "k1_ms_three_bf16_products": t3, "k1_ms_h6": t6,
-                  "k1_sdf_max_abs_error_vs_fp64": {"three_bf16_products": e3, "h6": e6, "tolerance": 1e-4}}
-            ops.set_k1_h6(True)
-            try:
-                trh = Stage1Trainer(device, prec=prec, use_graph=not args.no_graph)
-                hb_ = synthetic_batches(14, RAYS, device, rank=rank)
-                for b in hb_[:4]:
-                    trh.train_step(b)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for b in hb_[4:]:
-                    trh.train_step(b)
-                torch.cuda.synchronize()
-                h6["stage1_step_ms_sampler_k1_h6"] = (time.perf_counter() - t0) / 10 * 1e3
-                del trh
-                from fneus.trainer2 import Stage2Trainer
-                dt_2h, _, _ = timed_stage(lambda: Stage2Trainer(device, prec=prec, use_graph=not args.no_graph))
-                h6["stage2_step_ms_march_h6"] = dt_2h * 1e3
-            finally:
-                ops.set_k1_h6(False)
-            result["h6_products_prototype"] = h6
-        except Exception as e:
-            result["h6_products_prototype"] = {"value": None, "error": repr(e)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

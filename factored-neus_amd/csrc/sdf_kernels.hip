@@ -1113,20 +1113,18 @@ extern "C" int fneus_sdf_fwd(const void* blob, const float* pts, const float* ra
     static const bool no_tp = getenv("FNEUS_K1_NO_TP") != nullptr;
     const bool tp = tiles <= FNEUS_TP_MAX_TILES && !no_tp;
     static const bool tp8 = getenv("FNEUS_K1_TP_WAVES") ? atoi(getenv("FNEUS_K1_TP_WAVES")) == 8 : false;
-    // 8-wave workgroups (sdf_w8_kernels.hip; read at every call so that tests can switch): FNEUS_K1_W8_BIG = 4 | 2 | 0 for
-    // launches of >= 1024 tiles (HB tiles share one pass over the weight fragments), FNEUS_K1_W8_SMALL = 1 | 0 below
+    // Product forms (read at every call so that tests can switch): launches of >= 1024 tiles -- two-pass pipelined layers
+    // (sdf_p2_kernels.hip; FNEUS_K1_W8_BIG = 31: 8 waves, the default; 3: 4 waves; 0: the 4-wave kernels below); smaller launches -- one
+    // tile per 8-wave workgroup with primed layers (sdf_w8_kernels.hip; FNEUS_K1_W8_SMALL = 2, the default; 0: the kernels below).
+    // (Round 6 removed the forms no path selected: 8 waves in lockstep, staggered halves, 64-sample two-pass workgroups, h6 products --
+    // DESIGN.md 4.1b / 4.4b keep their measurements.)
     {
         const char* e_big = getenv("FNEUS_K1_W8_BIG");
         const char* e_small = getenv("FNEUS_K1_W8_SMALL");
         const int w8_big = e_big ? atoi(e_big) : FNEUS_K1_W8_BIG_DEFAULT;
         const int w8_small = e_small ? atoi(e_small) : FNEUS_K1_W8_SMALL_DEFAULT;
         if (tiles >= 1024 && (w8_big == 3 || w8_big == 31)) return fneus::sdf_fwd_p2(b, src, n_pts, sdf_out, prec, w8_big == 31 ? 1 : 2, stream);   // two-pass pipelined
-        if (tiles >= 1024 && w8_big == 32) return fneus::sdf_fwd_p2h(b, src, n_pts, sdf_out, prec, stream);             // two-pass, 64-sample workgroups
-        if (tiles >= 1024 && w8_big == 22) return fneus::sdf_fwd_s8(b, src, n_pts, sdf_out, prec, 2, stream);     // staggered halves
         if (tiles < 1024 && w8_small == 2) return fneus::sdf_fwd_w8p(b, src, n_pts, sdf_out, prec, stream);               // primed layers
-        if (tiles < 1024 && w8_small == 11) return fneus::sdf_fwd_s8(b, src, n_pts, sdf_out, prec, 1, stream);
-        if (tiles >= 1024 && (w8_big == 4 || w8_big == 2)) return fneus::sdf_fwd_w8(b, src, n_pts, sdf_out, prec, w8_big, stream);
-        if (tiles < 1024 && w8_small == 1) return fneus::sdf_fwd_w8(b, src, n_pts, sdf_out, prec, 1, stream);
     }
     // chip-filling launches: 64-sample workgroups (FNEUS_K1_HB=1 keeps one wave per tile)
     static const bool no_hb = getenv("FNEUS_K1_HB") && getenv("FNEUS_K1_HB")[0] == '1';

@@ -4,19 +4,10 @@
 
 namespace fneus {
 
-// K1 with HB 32-sample tiles per workgroup (1, 2 or 4)
-int sdf_fwd_w8(const unsigned char* blob, const PointSrc& src, long n_pts, float* sdf_out, int prec, int hb, hipStream_t stream);
-
-// K1 on staggered halves: two groups of 4 waves with HB tiles each (1 or 2), one phase apart
-int sdf_fwd_s8(const unsigned char* blob, const PointSrc& src, long n_pts, float* sdf_out, int prec, int hb, hipStream_t stream);
-
 // K1 in the two-pass pipelined form (sdf_p2_kernels.hip): 128 samples per 4-wave workgroup
 int sdf_fwd_p2(const unsigned char* blob, const PointSrc& src, long n_pts, float* sdf_out, int prec, int tn, hipStream_t stream);
 int sdf_fwd_p2_rays(const unsigned char* blob, const PointSrc& src, long n_pts, const unsigned char* ray_mask, float fill, int32_t* work,
                     float* sdf_out, int prec, hipStream_t stream);
-
-// K1 in the two-pass pipelined form on 64-sample workgroups, two per CU (sdf_p2h_kernels.hip)
-int sdf_fwd_p2h(const unsigned char* blob, const PointSrc& src, long n_pts, float* sdf_out, int prec, hipStream_t stream);
 
 // forward chain of K2 with the stash (sdf_p2_train_kernels.hip); mode 0: inference, 1 / 3: training with bf16 / hi + lo planes;
 // the launch covers the 128-sample units unit_begin .. unit_end - 1 of the n_pts samples

@@ -1,8 +1,8 @@
 // SDF-network kernels on 8-wave workgroups (w8_engine.h): the same maths, operands and summation order per sample as
 // sdf_kernels.hip (reference models/fields.py:74-111), another distribution of the work over the waves of a CU.
-//   K1 sdf_fwd_w8_kernel<PREC, HB>:  HB = 4 for chip-filling launches (128 samples per workgroup share one pass over the
-//                                     weight fragments), HB = 1 with a deep fragment ring for the latency-bound launches of the
-//                                     hierarchical sampler (renderer.py:430: 16 new depths per ray = 256 tiles).
+//   K1 sdf_fwd_w8p_kernel<PREC>: one tile per 8-wave workgroup with primed layers, for the latency-bound launches of the hierarchical
+//   sampler (renderer.py:430: 16 new depths per ray = 256 tiles).  (The lockstep and staggered chip-filling forms of round 3 were
+//   removed in round 6: no path selected them; DESIGN.md 4.1b keeps their measurements.)
 #include <stdlib.h>
 #include "w8_engine.h"
 #include "p2_engine.h"
@@ -28,251 +28,6 @@ FN_DEV void w8_softplus(f32x16 (&acc)[1][HB]) {
     for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][hb][r] = softplus100(acc[0][hb][r]);
-}
-
-// ---- K1 ------------------------------------------------------------------------------------------------------------------
-// Layer 8 of the reference is linear and only its sdf row is wanted (fields.py:93-95): every wave holds its 32 features of
-// h_8 as fp32 accumulators, so the row is a per-lane dot product with row 0 of W_8 (fp32, accumulator layout: the vector the
-// reverse sweep of K2 starts from) + a fixed-order sum over the 8 waves through LDS -- no ninth pass over weight fragments.
-template <int PREC, int HB>
-__global__ void __launch_bounds__(512, 2) sdf_fwd_w8_kernel(const unsigned char* blob, PointSrc src, long N,
-                                                            float* __restrict__ sdf_out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
-    unsigned char* frag = lds_;
-    float* red = reinterpret_cast<float*>(lds_ + HB * kW8Half);          // [HB][8 waves][32 samples]
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int r = lane & 31, h = lane >> 5;
-    const PPLane pl = pp_lane(lane);
-    constexpr auto& LY = kSdfLayout;
-    const long groups = (N + 32 * HB - 1) / (32 * HB);
-    unsigned char* none[HB];
-    bool valid[HB];
-#pragma unroll
-    for (int hb = 0; hb < HB; ++hb) none[hb] = nullptr;
-#ifdef FNEUS_W8_STAMPS
-    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(sdf_out + ((N + 3) & ~3L));
-#endif
-    for (long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
-#ifdef FNEUS_W8_STAMPS
-        const bool stamp_on = grp == blockIdx.x && blockIdx.x < 32;
-#endif
-        asm volatile("" : "+s"(blob));
-        w8_barrier();                                   // the previous group's fragments and sums are consumed
-        if (wave < HB) {                                // encoding of half `wave`: k-steps 0..2, parked again in 16..18
-            const long n = (grp * HB + wave) * 32 + r;
-            const long nc = n < N ? n : N - 1;
-            float x[3], pe[39], jc[39];
-            load_point(src, nc, x);
-            posenc<6, false>(x, pe, jc);
-            BFrag<PREC> pf[kMaxKS];
-            vec_to_bfrag<PREC, 39, 3, 0>(pe, pf, h);
-            frags_to_lds<PREC, 3>(frag + wave * kW8Half, lane, 0, pf);
-            frags_to_lds<PREC, 3>(frag + wave * kW8Half, lane, 16, pf);
-        }
-#pragma unroll
-        for (int hb = 0; hb < HB; ++hb) valid[hb] = true;       // (no planes are stored here)
-        w8_barrier();
-        f32x16 acc[1][HB];
-#pragma unroll 1
-        for (int l = 0; l <= 7; ++l) {
-            asm volatile("" : "+s"(blob));
-            const int tile = (l == 3 && wave == 7) ? 6 : wave;      // layer 3 has 7 tiles: wave 7 repeats tile 6 (not published)
-            W8_STAMP(0);
-            w8_bias<HB>(blob, LY.L[l].bias, acc, lane, tile);
-            if (l == 0)
-                w8_dense<PREC, 3, 8, true, HB>(blob, LY.L[0].fwd_hi, LY.L[0].fwd_lo, frag, acc, lane, tile);
-            else if (l == 3)
-                w8_dense<PREC, 16, 7, true, HB>(blob, LY.L[3].fwd_hi, LY.L[3].fwd_lo, frag, acc, lane, tile);
-            else if (l == 4)
-                w8_dense<PREC, 17, 8, true, HB>(blob, LY.L[4].fwd_hi, LY.L[4].fwd_lo, frag, acc, lane, tile);
-            else
-                w8_dense<PREC, 16, 8, true, HB>(blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, frag, acc, lane, tile);
-            W8_STAMP(1);
-            w8_softplus<HB>(acc);
-#ifdef FNEUS_W8_STAMPS
-            asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[0][HB - 1][15]));
-#endif
-            W8_STAMP(2);
-            if (l == 7) break;
-            if (l == 3 && wave == 7) {
-                w8_publish_skip<PREC, HB>(frag, lane);
-            } else {
-                w8_barrier();                               // everyone has read the previous layer's fragments
-                W8_STAMP(3);
-                w8_put_frags<PREC, HB, false>(frag, lane, wave, acc, none, none, pl, valid);
-                w8_barrier();                               // all fragments of the layer are in LDS
-            }
-            W8_STAMP(4);
-        }
-        {   // sdf = b_8[0] + W_8[0, :] . h_8
-            f32x16 cw[1];
-            load_accvec<8, 0, 1>(blob, LY.extra, cw, lane, wave);
-#pragma unroll
-            for (int hb = 0; hb < HB; ++hb) {
-                float p = 0.0f;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) p = fmaf(acc[0][hb][i], cw[0][i], p);
-                p += xor32(p);
-                if (lane < 32) red[(hb * 8 + wave) * 32 + lane] = p;
-            }
-            w8_barrier();
-            if (wave < HB && lane < 32) {
-                f32x16 b8[1];
-                load_accvec<9, 8, 1>(blob, LY.L[8].bias, b8, lane);
-                float s = b8[0][0];
-#pragma unroll
-                for (int w = 0; w < 8; ++w) s += red[(wave * 8 + w) * 32 + lane];
-                const long n = (grp * HB + wave) * 32 + r;
-                if (n < N) sdf_out[n] = s;
-            }
-        }
-    }
-}
-
-// ---- K1, staggered halves (w8_engine.h "s8") ---------------------------------------------------------------------------------
-// Two groups of 4 waves, each with its own HB tiles, group 1 one phase behind group 0.  Work unit = HB tiles; workgroup b takes
-// units (i * gridDim + b) * 2 + g.  Phases of a unit: [D0 P0 D1 P1 ... D7 P7]; P7 holds the sdf dot product (see above) and the
-// point encoding of the group's NEXT unit, whose sum / store happens at the start of that unit's D0.
-#ifndef FNEUS_S8_DEPTH
-#define FNEUS_S8_DEPTH 2
-#endif
-#ifndef FNEUS_S8_PRIO_P
-#define FNEUS_S8_PRIO_P 3
-#define FNEUS_S8_PRIO_D 0
-#endif
-template <int PREC, int HB>
-__global__ void __launch_bounds__(512, 2) sdf_fwd_s8_kernel(const unsigned char* blob, PointSrc src, long N,
-                                                            float* __restrict__ sdf_out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
-    constexpr int HALF = kW8Half, D = FNEUS_S8_DEPTH;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int g = wave >> 2, w = wave & 3, t0 = 2 * w;
-    unsigned char* frag = lds_ + g * HB * HALF;
-    float* red = reinterpret_cast<float*>(lds_ + 2 * HB * HALF) + g * HB * 4 * 32;          // [HB][4 waves][32 samples]
-    const int r = lane & 31, h = lane >> 5;
-    const PPLane pl = pp_lane(lane);
-    constexpr auto& LY = kSdfLayout;
-    const long units = (N + 32 * HB - 1) / (32 * HB);
-    const long iters = (units + 2 * gridDim.x - 1) / (2 * gridDim.x);
-    unsigned char* none[HB];
-    bool valid[HB];
-#pragma unroll
-    for (int hb = 0; hb < HB; ++hb) {
-        none[hb] = nullptr;
-        valid[hb] = true;
-    }
-    auto unit_of = [&](long i) { return (i * gridDim.x + blockIdx.x) * 2 + g; };
-    auto encode = [&](long unit) {          // waves 0 .. HB-1 of the group: encoding of half w -> k-steps 0..2, parked again in 16..18
-        if (w < HB) {
-            const long n = (unit * HB + w) * 32 + r;
-            const long nc = n < N ? n : N - 1;
-            float x[3], pe[39], jc[39];
-            load_point(src, nc, x);
-            posenc<6, false>(x, pe, jc);
-            BFrag<PREC> pf[kMaxKS];
-            vec_to_bfrag<PREC, 39, 3, 0>(pe, pf, h);
-            frags_to_lds<PREC, 3>(frag + w * HALF, lane, 0, pf);
-            frags_to_lds<PREC, 3>(frag + w * HALF, lane, 16, pf);
-        }
-    };
-    auto finish = [&](long unit) {          // sdf = b_8[0] + sum over the group's waves of their partial dot products
-        if (w < HB && lane < 32) {
-            f32x16 b8[1];
-            load_accvec<9, 8, 1>(blob, LY.L[8].bias, b8, lane);
-            float s = b8[0][0];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) s += red[(w * 4 + k) * 32 + lane];
-            const long n = (unit * HB + w) * 32 + r;
-            if (n < N) sdf_out[n] = s;
-        }
-    };
-#ifdef FNEUS_W8_STAMPS
-    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(sdf_out + ((N + 3) & ~3L));
-#endif
-    WRing<2, D> rg;
-    if (g == 1) w8_barrier();                           // group 1 runs one phase behind
-    encode(unit_of(0));
-    ring_prime<PREC, 2, D, true>(rg, blob, LY.L[0].fwd_hi, LY.L[0].fwd_lo, 3, 8, lane, t0);
-    w8_barrier();
-    f32x16 acc[2][HB];
-    for (long i = 0; i < iters; ++i) {
-#pragma unroll 1
-        for (int l = 0; l <= 7; ++l) {
-            asm volatile("" : "+s"(blob));
-#ifdef FNEUS_W8_STAMPS
-            const bool stamp_on = i == 0 && blockIdx.x < 32;
-#endif
-            W8_STAMP(0);
-            // ---------------- D phase ----------------
-            __builtin_amdgcn_s_setprio(FNEUS_S8_PRIO_D);
-            if (l == 0 && i > 0) finish(unit_of(i - 1));
-            s8_bias<2, HB>(blob, LY.L[l].bias, acc, lane, t0);
-            if (l == 0)
-                ring_dense<PREC, 3, 8, 2, D, true, HB, HALF>(rg, blob, LY.L[0].fwd_hi, LY.L[0].fwd_lo, frag, acc, lane, t0);
-            else if (l == 3)
-                ring_dense<PREC, 16, 7, 2, D, true, HB, HALF>(rg, blob, LY.L[3].fwd_hi, LY.L[3].fwd_lo, frag, acc, lane, t0);
-            else if (l == 4)
-                ring_dense<PREC, 17, 8, 2, D, true, HB, HALF>(rg, blob, LY.L[4].fwd_hi, LY.L[4].fwd_lo, frag, acc, lane, t0);
-            else
-                ring_dense<PREC, 16, 8, 2, D, true, HB, HALF>(rg, blob, LY.L[l].fwd_hi, LY.L[l].fwd_lo, frag, acc, lane, t0);
-            W8_STAMP(1);
-            w8_barrier();
-            W8_STAMP(2);
-            // ---------------- P phase ----------------
-            // vector work beside the partner's MFMA stream: at equal priority the arbiter serves the MFMA wave first and this
-            // phase crawls (measured: 18 cycles per vector instruction, tools/experiments/r03/k1_s8_stamps.py)
-            __builtin_amdgcn_s_setprio(FNEUS_S8_PRIO_P);
-#ifndef FNEUS_S8_NO_SOFTPLUS
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int hb = 0; hb < HB; ++hb)
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) acc[t][hb][k] = softplus100(acc[t][hb][k]);
-#endif
-            if (l < 7) {
-                if (l == 3 && w == 3) {      // 7 tiles: this wave owns tile 6 only (its second accumulator is padding) and moves the
-                                             // parked encoding to the skip input of layer 4 (k-steps 14..16, fields.py:83-84)
-                    s8_put_frags<PREC, 2, HB, HALF, false>(frag, lane, t0, 1, acc, none, none, pl, valid);
-#pragma unroll
-                    for (int hb = 0; hb < HB; ++hb) {
-                        BFrag<PREC> ex[3];
-                        lds_to_frags<PREC, 3>(frag + hb * HALF, lane, 16, ex);
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        frags_to_lds<PREC, 3>(frag + hb * HALF, lane, 14, ex);
-                    }
-                } else {
-                    s8_put_frags<PREC, 2, HB, HALF, false>(frag, lane, t0, 2, acc, none, none, pl, valid);
-                }
-                const int ln = l + 1;
-                ring_prime<PREC, 2, D, true>(rg, blob, LY.L[ln].fwd_hi, LY.L[ln].fwd_lo, 16, ln == 3 ? 7 : 8, lane, t0);
-            } else {
-                f32x16 cw[2];
-                load_accvec<8, 0, 2>(blob, LY.extra, cw, lane, t0);
-#pragma unroll
-                for (int hb = 0; hb < HB; ++hb) {
-                    float p = 0.0f;
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-#pragma unroll
-                        for (int k = 0; k < 16; ++k) p = fmaf(acc[t][hb][k], cw[t][k], p);
-                    p += xor32(p);
-                    if (lane < 32) red[(hb * 4 + w) * 32 + lane] = p;
-                }
-                if (i + 1 < iters) {
-                    encode(unit_of(i + 1));
-                    ring_prime<PREC, 2, D, true>(rg, blob, LY.L[0].fwd_hi, LY.L[0].fwd_lo, 3, 8, lane, t0);
-                }
-            }
-            W8_STAMP(3);
-            w8_barrier();
-            W8_STAMP(4);
-        }
-    }
-    finish(unit_of(iters - 1));
-    if (g == 0) w8_barrier();
 }
 
 // ---- K1 for the latency-bound launches of the hierarchical sampler (renderer.py:430: 16 new depths per ray = 8192 points = one
@@ -429,48 +184,6 @@ __global__ void __launch_bounds__(512, 2) sdf_fwd_w8p_kernel(const unsigned char
     }
 }
 
-template <int PREC, int HB>
-static int launch_k1(const unsigned char* b, const PointSrc& src, long n_pts, float* sdf_out, hipStream_t stream) {
-    static bool done = false;
-    if (!done) {
-        allow_big_lds(sdf_fwd_w8_kernel<PREC, HB>);
-        done = true;
-    }
-    const long groups = (n_pts + 32 * HB - 1) / (32 * HB);
-    const int lds = HB * kW8Half + HB * 8 * 32 * 4;
-    const long cap = lds > 80 * 1024 ? 256 : 1024;                // (more than the resident workgroups: the rest queues)
-    hipLaunchKernelGGL((sdf_fwd_w8_kernel<PREC, HB>), dim3((unsigned)(groups < cap ? groups : cap)), dim3(512), lds, stream, b,
-                       src, n_pts, sdf_out);
-    return launch_status();
-}
-
-template <int PREC, int HB>
-static int launch_k1_s8(const unsigned char* b, const PointSrc& src, long n_pts, float* sdf_out, hipStream_t stream) {
-    static bool done = false;
-    if (!done) {
-        allow_big_lds(sdf_fwd_s8_kernel<PREC, HB>);
-        done = true;
-    }
-    const long units = (n_pts + 32 * HB - 1) / (32 * HB);
-    const long wgs = (units + 1) / 2;
-    const int lds = 2 * HB * kW8Half + 2 * HB * 4 * 32 * 4;
-    const long cap = 256;
-    hipLaunchKernelGGL((sdf_fwd_s8_kernel<PREC, HB>), dim3((unsigned)(wgs < cap ? wgs : cap)), dim3(512), lds, stream, b, src, n_pts,
-                       sdf_out);
-    return launch_status();
-}
-
-int sdf_fwd_s8(const unsigned char* b, const PointSrc& src, long n_pts, float* sdf_out, int prec, int hb, hipStream_t stream) {
-    if (prec == 3) {
-        if (hb == 2) return launch_k1_s8<3, 2>(b, src, n_pts, sdf_out, stream);
-        if (hb == 1) return launch_k1_s8<3, 1>(b, src, n_pts, sdf_out, stream);
-    } else if (prec == 1) {
-        if (hb == 2) return launch_k1_s8<1, 2>(b, src, n_pts, sdf_out, stream);
-        if (hb == 1) return launch_k1_s8<1, 1>(b, src, n_pts, sdf_out, stream);
-    }
-    return -2;
-}
-
 int sdf_fwd_w8p(const unsigned char* b, const PointSrc& src, long n_pts, float* sdf_out, int prec, hipStream_t stream) {
     const long tiles = (n_pts + 31) / 32;
     const dim3 grid((unsigned)(tiles < 1024 ? tiles : 1024));
@@ -478,19 +191,6 @@ int sdf_fwd_w8p(const unsigned char* b, const PointSrc& src, long n_pts, float* 
     else if (prec == 1) hipLaunchKernelGGL(sdf_fwd_w8p_kernel<1>, grid, dim3(512), 0, stream, b, src, n_pts, sdf_out);
     else return -2;
     return launch_status();
-}
-
-int sdf_fwd_w8(const unsigned char* b, const PointSrc& src, long n_pts, float* sdf_out, int prec, int hb, hipStream_t stream) {
-    if (prec == 3) {
-        if (hb == 4) return launch_k1<3, 4>(b, src, n_pts, sdf_out, stream);
-        if (hb == 2) return launch_k1<3, 2>(b, src, n_pts, sdf_out, stream);
-        if (hb == 1) return launch_k1<3, 1>(b, src, n_pts, sdf_out, stream);
-    } else if (prec == 1) {
-        if (hb == 4) return launch_k1<1, 4>(b, src, n_pts, sdf_out, stream);
-        if (hb == 2) return launch_k1<1, 2>(b, src, n_pts, sdf_out, stream);
-        if (hb == 1) return launch_k1<1, 1>(b, src, n_pts, sdf_out, stream);
-    }
-    return -2;
 }
 
 }  // namespace fneus

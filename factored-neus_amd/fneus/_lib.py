@@ -95,6 +95,9 @@ def _load():
         "fneus_color_bwd": (C.c_int, [vp, l, vp, vp, C.POINTER(FneusColStash), vp, vp, ip, vp]),
         "fneus_color_out_dw": (C.c_int, [vp, vp, vp, vp, l, vp, vp, vp, vp, ip, vp, vp]),
         "fneus_color_out_dw_scratch_floats": (C.c_int, []),
+        "fneus_probe_mfma": (C.c_int, [vp, ip, vp, vp, vp]),
+        "fneus_probe_mfma_flops": (C.c_long, [ip]),
+        "fneus_probe_copy": (C.c_int, [vp, vp, l, vp]),
         "fneus_refcolor_fwd": (C.c_int, [vp, ip, vp, vp, vp, vp, ip, l, vp, vp, vp, C.POINTER(FneusColStash), vp, ip, ip, vp]),
         "fneus_refcolor_bwd": (C.c_int, [vp, ip, l, vp, ip, vp, vp, vp, vp, C.POINTER(FneusColStash), vp, vp, ip, vp]),
         "fneus_refcolor_fwd_both": (C.c_int, [vp, vp, vp, vp, vp, vp, ip, l, vp, vp, vp, C.POINTER(FneusColStash),
@@ -147,9 +150,6 @@ def _load():
         "fneus_mlp_forward": (C.c_int, [C.POINTER(FneusMlpJob), ip, vp]),
         "fneus_mlp_backward_input": (C.c_int, [C.POINTER(FneusMlpJob), ip, vp]),
         "fneus_mlp_backward_params": (C.c_int, [C.POINTER(FneusMlpJob), ip, vp]),
-        "fneus_h6_blob_bytes": (C.c_size_t, []),
-        "fneus_h6_pack": (C.c_int, [vp, vp, vp]),
-        "fneus_sdf_fwd_h6": (C.c_int, [vp, vp, vp, vp, vp, vp, ip, l, vp, f, vp, vp, vp]),
         "fneus_lvis_visibility": (C.c_int, [vp, vp, vp, vp, vp, vp, ip, ip, ip, vp, ip, vp]),
         "fneus_lvis_blob_bytes": (C.c_size_t, []),
         "fneus_lvis_h16_pack": (C.c_int, [vp, vp, vp]),

@@ -448,46 +448,6 @@ class SdfStash:
         return out.reshape(T * 32, 256)[:self.n]
 
 
-# Round-5 prototype (plan (ii)): K1's chip-filling launches with "h6" products -- one fp16 MFMA for hi.hi, two
-# block-scaled fp6 MFMAs per 64 k for the cross terms (csrc/h6_engine.h): 1.5 MFMA-times per product instead of 3, sdf still
-# within 1e-4 (tests/test_hip_sdf.py).  FNEUS_K1_H6=1 / set_k1_h6(True) routes parity-mode launches of >= K1_H6_MIN points there.
-K1_H6 = os.environ.get("FNEUS_K1_H6", "0") == "1"
-K1_H6_MIN = int(os.environ.get("FNEUS_K1_H6_MIN", "32768"))
-_H6_BLOBS = {}
-
-
-def set_k1_h6(on: bool):
-    global K1_H6
-    K1_H6 = bool(on)
-
-
-def h6_blob(blob, repack: bool = True):
-    """the h6 form of a packed SDF network's forward chain, derived from the bf16 hi + lo fragments of `blob` (fneus_h6_pack);
-    re-derived on every call by default (the weights change every training step; the kernel is a few microseconds)"""
-    key = (blob.data_ptr(), blob.device)
-    hb = _H6_BLOBS.get(key)
-    fresh = hb is None
-    if fresh:
-        hb = _H6_BLOBS[key] = torch.zeros(int(lib.fneus_h6_blob_bytes()), dtype=torch.uint8, device=blob.device)
-    if repack or fresh:
-        _launch("fneus_h6_pack", lib.fneus_h6_pack, _ptr(blob), _ptr(hb), _stream())
-    return hb
-
-
-def sdf_fwd_h6(blob, n_pts: int, pts=None, rays_o=None, rays_d=None, t=None, m: int = 1, out=None, repack: bool = True,
-               ray_mask=None, fill: float = 1.0):
-    if out is None:
-        out = torch.empty(n_pts, dtype=torch.float32, device=blob.device)
-    hb = h6_blob(blob, repack)
-    mask = work = None
-    if ray_mask is not None:
-        mask = (ray_mask.view(torch.uint8) if ray_mask.dtype == torch.bool else ray_mask).contiguous()
-        work = torch.empty(n_pts // 128 + 1, dtype=torch.int32, device=blob.device)
-    _launch("fneus_sdf_fwd_h6", lib.fneus_sdf_fwd_h6, _ptr(blob), _ptr(hb), _ptr(pts), _ptr(rays_o), _ptr(rays_d), _ptr(t), m, n_pts,
-            _ptr(mask), float(fill), _ptr(work), _ptr(out), _stream())
-    return out
-
-
 def sdf_fwd(blob, n_pts: int, prec: int, pts=None, rays_o=None, rays_d=None, t=None, m: int = 1, out=None, ray_mask=None,
             fill: float = 1.0):
     """ray_mask [n_pts / m] uint8 / bool (ray form, m a multiple of 128, >= 32 768 samples): only the marked rays are evaluated, the
@@ -495,10 +455,6 @@ def sdf_fwd(blob, n_pts: int, prec: int, pts=None, rays_o=None, rays_d=None, t=N
     dev = blob.device
     if out is None:
         out = torch.empty(n_pts, dtype=torch.float32, device=dev)
-    if K1_H6 and prec == PREC_PARITY and n_pts >= K1_H6_MIN:
-        masked = ray_mask is not None and pts is None and m % 128 == 0 and os.environ.get("FNEUS_K1_RAY_MASK", "1") != "0"
-        return sdf_fwd_h6(blob, n_pts, pts=pts, rays_o=rays_o, rays_d=rays_d, t=t, m=m, out=out,
-                          ray_mask=ray_mask if masked else None, fill=fill)
     if ray_mask is not None and pts is None and m % 128 == 0 and n_pts >= 32768 and os.environ.get("FNEUS_K1_RAY_MASK", "1") != "0":
         mask = ray_mask.view(torch.uint8) if ray_mask.dtype == torch.bool else ray_mask
         work = torch.empty(n_pts // 128 + 1, dtype=torch.int32, device=dev)
@@ -1561,3 +1517,38 @@ def composite_bwd(rays_o, rays_d, mid_z, dists, sdf, normal, rgb, inv_s, car, mi
             _ptr(sdf_mask), _ptr(d_color), _ptr(d_wsum), _ptr(d_weights), _ptr(d_wpair), _ptr(d_eiknum), _ptr(d_sdf),
             _ptr(d_normal), _ptr(d_rgb), _ptr(d_inv_s), _ptr(d_bga), _ptr(d_bgc), _ptr(back), back_rows, _stream())
     return d_sdf, d_normal, d_rgb, d_inv_s, d_bga, d_bgc
+
+
+# ------------------------------------------------------------------------------------------------------------
+# box calibration (bench.py `box`)
+# ------------------------------------------------------------------------------------------------------------
+def box_probe(device, mfma_iters: int = 100, copy_mib: int = 512, reps: int = 5):
+    """two ~100 us probes of THIS box: back-to-back bf16 MFMAs on random operands (TFLOP/s and the clock the chip held) and a float4
+    copy (TB/s, bytes read + written) -- fneus_probe_mfma / fneus_probe_copy (csrc/probe.hip)"""
+    g = torch.Generator(device=device).manual_seed(7)
+    operands = (torch.rand(16384, device=device, generator=g) * 2 - 1).to(torch.bfloat16)
+    ticks = torch.zeros(2, dtype=torch.int64, device=device)
+    sink = torch.zeros(1, dtype=torch.float32, device=device)
+    src = torch.rand(copy_mib << 18, device=device, generator=g)          # copy_mib MiB of fp32
+    dst = torch.empty_like(src)
+
+    def timed(fn):
+        fn()
+        best = 1e30
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) * 1e-3)
+        return best
+
+    t_m = timed(lambda: check(lib.fneus_probe_mfma(_ptr(operands), mfma_iters, _ptr(ticks), _ptr(sink), _stream()), "fneus_probe_mfma"))
+    cyc, rt = [int(v) for v in ticks.cpu()]
+    t_c = timed(lambda: check(lib.fneus_probe_copy(_ptr(src), _ptr(dst), src.numel() * 4, _stream()), "fneus_probe_copy"))
+    return {"mfma_bf16_tflops": float(lib.fneus_probe_mfma_flops(mfma_iters)) / t_m / 1e12,
+            "mfma_clock_ghz": (cyc / rt * 0.1) if rt > 0 else None,
+            "copy_tbs": 2.0 * src.numel() * 4 / t_c / 1e12,
+            "what": f"best of {reps}: {mfma_iters} x 16 back-to-back v_mfma_f32_32x32x16_bf16 per wave on random operands, 16 waves per CU "
+                    f"(TFLOP/s by HIP events, clock = shader cycles / 100 MHz ticks inside the loop); float4 copy of {copy_mib} MiB (read + written bytes)"}

@@ -300,15 +300,6 @@ int fneus_stage1_loss(const float* color /*[B][3]*/, const float* true_rgb /*[B]
 int fneus_stage1_norms(const float* mask_in, const unsigned char* sdf_mask, const float* eik_den, int n_rays,
                        float mask_weight, float* norms, fneus_stream_t stream);
 
-/* ---- round 5 prototype: K1 with "h6" products (csrc/h6_engine.h): hi.hi as ONE fp16 MFMA per 16 k, the cross terms hi.lo + lo.hi
- * as two block-scaled fp6 MFMAs per 64 k (v_mfma_scale_f32_32x32x64_f8f6f4) -- SDFNetwork.sdf, models/fields.py:93-95, at 1.5
- * MFMA-times per product.  hblob: fneus_h6_blob_bytes() bytes, derived from a packed SDF blob by fneus_h6_pack (again whenever
- * the blob is re-packed); same points / outputs as fneus_sdf_fwd (parity mode only). */
-size_t fneus_h6_blob_bytes(void);
-int fneus_h6_pack(const void* blob, void* hblob, fneus_stream_t stream);
-int fneus_sdf_fwd_h6(const void* blob, const void* hblob, const float* pts, const float* rays_o, const float* rays_d, const float* t,
-                     int m, long n_pts, const unsigned char* ray_mask, float fill, int32_t* work, float* sdf_out,
-                     fneus_stream_t stream);
 /* (ray_mask / fill / work as in fneus_sdf_fwd_rays; ray_mask NULL: every sample) */
 
 /* ---- K6: hierarchical sampler pieces (one wavefront per ray, 2 <= samples per ray <= 256; fneus_upsample: <= 512) -- */
@@ -589,6 +580,14 @@ int fneus_composite_bwd(const float* rays_o, const float* rays_d, const float* m
  * gradient after use. */
 int fneus_adam(const FneusAdamSegment* segs, int n_segs, const float* lr, float* step, double beta1, double beta2,
                double eps, int zero_grad, fneus_stream_t stream);
+
+/* ---- box calibration (bench.py `box`; not part of the reference's path) ------------------------------------------------------------
+ * fneus_probe_mfma: 1024 x 4 waves issue iters x 16 v_mfma_f32_32x32x16_bf16 back to back on the 32 KiB of bf16 operands given (random
+ * data: the clock the chip holds depends on it); fneus_probe_mfma_flops(iters) FLOP per launch; ticks[0] = shader cycles, ticks[1] =
+ * 100 MHz ticks of wave 0 over the loop.  fneus_probe_copy: float4 copy of `bytes` (a multiple of 16).                              */
+int fneus_probe_mfma(const void* operands_32kib, int iters, unsigned long long* ticks /*[2]*/, float* sink /*[1]*/, fneus_stream_t stream);
+long fneus_probe_mfma_flops(int iters);
+int fneus_probe_copy(const void* src, void* dst, long bytes, fneus_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--rays", type=int, default=512)
     ap.add_argument("--res", type=int, default=128)
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03_chamfer.json"))
-    ap.add_argument("--gprec", type=int, default=1)
+    ap.add_argument("--gprec", type=int, default=2)
     ap.add_argument("--seed0", type=int, default=100)
     args = ap.parse_args()
     summary = run_study(args)

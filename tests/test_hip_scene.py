@@ -40,7 +40,8 @@ def test_reconstruction_matches_oracle_training_on_the_synthetic_scene(monkeypat
     conf["neus_renderer"]["perturb"] = 0.0            # same depths on both sides (the jitter streams differ)
     # ---- HIP path (hipGraph replay), three runs: two with fp32-accurate weight gradients (gprec 3; the second measures the
     # path's own run-to-run spread: fp32 atomics in the weight-gradient GEMM are its only non-determinism, Adam then
-    # amplifies it like any other rounding difference) and one in the training default (gprec 1: bf16 gradient planes)
+    # amplifies it like any other rounding difference) and one in the training default (gprec 2 since round 6: bf16 gradient planes but for
+    # the colour network's output layer)
     def run_hip(gprec):
         tr = Stage1Trainer(dev, model_conf=conf, prec=ops.PREC_PARITY, seed=SEED, lr=LR, use_graph=True, gprec=gprec)
         u0 = tr.renderer.extract_sdf_grid([-1.01] * 3, [1.01] * 3, RES).clone()
@@ -53,7 +54,7 @@ def test_reconstruction_matches_oracle_training_on_the_synthetic_scene(monkeypat
     hip, u_hip, u_init = run_hip(3)
     hip2, u_hip2, _ = run_hip(3)
     assert np.array_equal(hip, hip2) and torch.equal(u_hip, u_hip2), "two deterministic runs of 1000 training steps differ"
-    hipd, u_hipd, _ = run_hip(1)
+    hipd, u_hipd, _ = run_hip(None)
     # ---- oracle: same weights, same batches, torch.optim.Adam, eager PyTorch-ROCm ops
     T = lambda sd: {k: torch.from_numpy(v).clone().to(dev).requires_grad_(True) for k, v in sd.items()}
     sd_sdf, sd_col, sd_ref = T(synth.sdf_state_dict(SEED)), T(synth.color_state_dict(SEED + 1)), T(synth.refcolor_state_dict(SEED + 2))
@@ -140,7 +141,7 @@ def test_chamfer_at_equal_steps_hip_vs_oracle_over_seeds():
     spec = importlib.util.spec_from_file_location("chamfer_study", os.path.join(os.path.dirname(__file__), "checkers", "chamfer_study.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    res = mod.run_study(types.SimpleNamespace(seeds=12, steps=1200, rays=512, res=96, gprec=1, seed0=300))
+    res = mod.run_study(types.SimpleNamespace(seeds=12, steps=1200, rays=512, res=96, gprec=2, seed0=300))     # (the default mode since round 6)
     print({k: v for k, v in res.items() if k != "runs"})
     assert res["hip_mean"] < 0.4 * np.mean([r["chamfer_init"] for r in res["runs"]])       # both reconstruct the scene ...
     assert res["oracle_mean"] < 0.4 * np.mean([r["chamfer_init"] for r in res["runs"]])

@@ -66,11 +66,11 @@ def test_sdf_fwd_chip_filling_launch_uses_64_sample_workgroups(env, prec, tol):
     assert torch.equal(out, again)                # repeatable
 
 
-@pytest.mark.parametrize("big", [31, 3, 32, 4, 22, 0])
+@pytest.mark.parametrize("big", [31, 3, 0])
 def test_sdf_fwd_every_chip_filling_kernel_form(env, big, monkeypatch):
     """the forms of K1 for launches of >= 1024 tiles that are in the tree (FNEUS_K1_W8_BIG, read at every call): 31 two-pass
-    pipelined layers on 8 waves (the default), 3 on 4 waves, 32 on 64-sample workgroups, 4 eight waves in lockstep, 22 staggered
-    halves, 0 the round-2 kernel -- all against the fp64 oracle at the 1e-4 bar, repeatable, ragged size"""
+    pipelined layers on 8 waves (the default), 3 on 4 waves, 0 the 4-wave kernel that also takes what the others do not --
+    all against the fp64 oracle at the 1e-4 bar, repeatable, ragged size"""
     ops, R = env["ops"], env["R"]
     monkeypatch.setenv("FNEUS_K1_W8_BIG", str(big))
     rs = np.random.RandomState(13)
@@ -169,50 +169,3 @@ def test_sdf_fwd_grad_multi_tile_workgroups(env, hb, monkeypatch):
         assert (st1.plane(st1.a, l)[:, :w] - st0.plane(st0.a, l)[:, :w]).abs().max().item() <= 2e-5
 
 
-@pytest.mark.parametrize("n", [128, 1000, 40003, 65536])
-def test_sdf_fwd_h6_products(env, n):
-    """round-5 prototype (csrc/h6_engine.h, DESIGN.md 4.4 plan (ii)): K1 with ONE fp16 MFMA per 16 k for hi.hi and two block-scaled
-    fp6 MFMAs per 64 k for the cross terms -- 1.5 MFMA-times per product.  Against the fp64 oracle at north_star's 1e-4
-    (tests/checkers/num_schemes.py predicts <= 2.4e-5 on three networks) and beside the shipped three-product kernel"""
-    ops, R = env["ops"], env["R"]
-    rs = np.random.RandomState(13)
-    x = T(rs.uniform(-1.1, 1.1, size=(n, 3)).astype(np.float32))
-    x[0] = 0.0
-    ref = R.sdf_only(x.double(), {"W": [w.double() for w in env["p"]["W"]], "b": [b.double() for b in env["p"]["b"]],
-                                  "scale": 1.0})[:, 0]
-    xd = x.to(env["dev"]).contiguous()
-    out = ops.sdf_fwd_h6(env["net"].blob, n, pts=xd)
-    bf3 = ops.sdf_fwd(env["net"].blob, n, 3, pts=xd)
-    err, err3 = (out.cpu().double() - ref).abs().max().item(), (bf3.cpu().double() - ref).abs().max().item()
-    print(f"sdf_fwd h6 n={n}: max abs err {err:.3e} (three bf16 products: {err3:.3e})")
-    assert err <= 1e-4
-    # ray form (points = o + d t) and repeated launches: bit-identical
-    again = ops.sdf_fwd_h6(env["net"].blob, n, pts=xd, repack=False)
-    assert torch.equal(out, again)
-
-
-def test_sdf_fwd_h6_switch_routes_the_samplers_big_launch(env, monkeypatch):
-    ops = env["ops"]
-    n = 65536
-    xd = (torch.rand(n, 3, device=env["dev"]) * 2 - 1).contiguous()
-    direct = ops.sdf_fwd_h6(env["net"].blob, n, pts=xd)
-    monkeypatch.setattr(ops, "K1_H6", True)
-    assert torch.equal(ops.sdf_fwd(env["net"].blob, n, 3, pts=xd), direct)
-    monkeypatch.setattr(ops, "K1_H6", False)
-    assert not torch.equal(ops.sdf_fwd(env["net"].blob, n, 3, pts=xd), direct)
-
-
-def test_sdf_fwd_h6_on_the_marked_rays_only(env):
-    """the ray-mask form of fneus_sdf_fwd_rays on the h6 kernel: unmarked rays get `fill`, marked ones the same values as the
-    unmasked launch (bit for bit)"""
-    ops = env["ops"]
-    B, m = 300, 128
-    g = torch.Generator().manual_seed(4)
-    ro = (torch.rand(B, 3, generator=g) * 0.4 - 0.2).to(env["dev"]).contiguous()
-    rd = torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=-1).to(env["dev"]).contiguous()
-    t = (torch.rand(B * m, generator=g) * 1.5).to(env["dev"]).contiguous()
-    mask = (torch.rand(B, generator=g) < 0.6).to(env["dev"])
-    full = ops.sdf_fwd_h6(env["net"].blob, B * m, rays_o=ro, rays_d=rd, t=t, m=m)
-    part = ops.sdf_fwd_h6(env["net"].blob, B * m, rays_o=ro, rays_d=rd, t=t, m=m, ray_mask=mask, fill=7.0, repack=False)
-    full, part = full.reshape(B, m), part.reshape(B, m)
-    assert torch.equal(part[mask], full[mask]) and bool((part[~mask] == 7.0).all())
