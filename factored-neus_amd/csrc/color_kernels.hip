@@ -695,9 +695,15 @@ static int launch_fwd(const void* blob, const float* pts, const float* rays_o, c
         // chip-filling launches: the two-pass pipelined kernel (color_p2_kernels.hip); FNEUS_COL_P2=0 keeps the 4-wave kernels
         const char* p2_env = getenv("FNEUS_COL_P2");
         if ((p2_env ? atoi(p2_env) : FNEUS_COL_P2_DEFAULT) != 0) {
+            // feat NULL (round 6): the features come as the planes stash.feat_hi / feat_lo (the SDF kernel's: fneus_sdf_fwd_grad)
+            if (feat == nullptr && !(st.feat_hi && (prec == 1 || st.feat_lo))) return -2;
             const int mode = !train ? 0 : ((st.u_lo != nullptr && prec == 3) ? 3 : 1);
             return fneus::color_fwd_p2(b, src, n_pts, dirs, normal, feat, st, out, prec, mode, stream);
         }
+    }
+    if (feat == nullptr) {
+        fneus::set_last_error("fneus_color_fwd: feat may be NULL only for launches of >= 1024 tiles on the two-pass kernel with feature planes in the stash");
+        return -2;
     }
     if (VAR == VAR_COLOR && col_use_hb2((n_pts + 31) / 32)) {
         dim3 g2(tp_grid((n_pts + 63) / 64));

@@ -48,6 +48,18 @@ __global__ void __launch_bounds__(512, 1) color_fwd_p2_kernel(const unsigned cha
             const long n = tile * 32 + r;
             const long nc = n < N ? n : N - 1;
             unsigned char* dst = lds_ + (ta + k) * kP2Half + lane * 16;
+            if (feat == nullptr) {
+                // round 6: the SDF kernel's feature PLANES (hi + lo fragments, what this loop would build from the fp32 rows -- the same
+                // split of the same values): 16-byte fragment loads straight into the k-steps, no conversion
+                const long tl = tile < tiles ? tile : tiles - 1;        // (a tile beyond the launch: any block, its samples are masked)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int ks = 2 * wave + q;
+                    *reinterpret_cast<bf16x8*>(dst + (ks * NPL) * kFragBytes) = pp_load(st.feat_hi + (size_t)tl * kPPBlock, ks, pl);
+                    if constexpr (PREC == 3) *reinterpret_cast<bf16x8*>(dst + (ks * NPL + 1) * kFragBytes) = pp_load(st.feat_lo + (size_t)tl * kPPBlock, ks, pl);
+                }
+                continue;
+            }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int ks = 2 * wave + q;

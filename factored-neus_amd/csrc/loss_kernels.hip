@@ -7,7 +7,7 @@
 // In PyTorch this tail was ~230 element-wise / reduction kernels on [512]-ray tensors (0.7 ms of a 5.2 ms step).
 // The loss needs batch-wide normalisers before any per-ray gradient can be formed, so it runs as ONE workgroup that
 // sweeps the rays twice (B is a few hundred to a few thousand); sums are reduced in a fixed order (deterministic).
-#include "fneus_common.h"
+#include "pp_engine.h"
 #include "fneus_kernels.h"
 
 namespace fneus {
@@ -51,7 +51,9 @@ static WarmList warm_list(const FneusWarmRanges* w) {
 __global__ void __launch_bounds__(64) surface_gather_kernel(const int32_t* __restrict__ min_idx,
                                                             const unsigned char* __restrict__ sdf_mask,
                                                             const float* __restrict__ mid_z,    // [B][n]
-                                                            const float* __restrict__ feat,     // [B*n][256]
+                                                            const float* __restrict__ feat,     // [B*n][256], or NULL: the planes
+                                                            const unsigned char* __restrict__ feat_hi,   // fragment planes of the
+                                                            const unsigned char* __restrict__ feat_lo,   // features (lo may be NULL)
                                                             const float* __restrict__ normal,   // [B*n][3]
                                                             int n, int32_t* __restrict__ sel, float* __restrict__ t_sel,
                                                             float* __restrict__ feat_sel, float* __restrict__ normal_sel,
@@ -66,8 +68,32 @@ __global__ void __launch_bounds__(64) surface_gather_kernel(const int32_t* __res
     for (int k = 0; k < 2; ++k) {
         const long src = (long)b * n + hi - 1 + k;
         const long dst = 2L * b + k;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(feat + src * 256 + lane * 4);
-        *reinterpret_cast<f32x4*>(feat_sel + dst * 256 + lane * 4) = v;
+        if (feat != nullptr) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(feat + src * 256 + lane * 4);
+            *reinterpret_cast<f32x4*>(feat_sel + dst * 256 + lane * 4) = v;
+        } else if (lane < 32) {
+            // the row from the feature planes (fneus_pp.h): lane = (k-step, lane half h) holds the 8 features phi(ks, h, 0..7) =
+            // 16 ks + 4 h + {0..3} and 16 ks + 8 + 4 h + {0..3} of sample r = src & 31 as hi + lo bf16: two float4 of the row
+            const int ks = lane >> 1, hh = lane & 1, rr = (int)(src & 31);
+            const size_t off = (size_t)(src >> 5) * kPPBlock + (size_t)ks * kFragBytes + pp_slot_bytes(rr + 32 * hh, ks);
+            const bf16x8 vh = *reinterpret_cast<const bf16x8*>(feat_hi + off);
+            f32x4 a, b2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] = (float)vh[j];
+                b2[j] = (float)vh[4 + j];
+            }
+            if (feat_lo != nullptr) {
+                const bf16x8 vl = *reinterpret_cast<const bf16x8*>(feat_lo + off);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a[j] += (float)vl[j];
+                    b2[j] += (float)vl[4 + j];
+                }
+            }
+            *reinterpret_cast<f32x4*>(feat_sel + dst * 256 + 16 * ks + 4 * hh) = a;
+            *reinterpret_cast<f32x4*>(feat_sel + dst * 256 + 16 * ks + 8 + 4 * hh) = b2;
+        }
         if (lane < 3) normal_sel[dst * 3 + lane] = normal[src * 3 + lane];
         if (lane == 3) t_sel[dst] = mid_z[src];
         if (lane == 4) sel[dst] = (int32_t)src;
@@ -329,15 +355,18 @@ extern "C" int fneus_surface_scatter(const int32_t* sel, const float* d_feat_hea
 }
 
 extern "C" int fneus_surface_gather(const int32_t* min_idx, const unsigned char* sdf_mask, const float* mid_z,
-                                    const float* feat, const float* normal, int n_rays, int n, int32_t* sel, float* t_sel,
-                                    float* feat_sel, float* normal_sel, const FneusWarmRanges* warm, fneus_stream_t stream_) {
+                                    const float* feat, const void* feat_hi, const void* feat_lo, const float* normal, int n_rays, int n,
+                                    int32_t* sel, float* t_sel, float* feat_sel, float* normal_sel, const FneusWarmRanges* warm,
+                                    fneus_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     fneus::clear_status();
     if (n_rays <= 0) return 0;
     if (n < 2) return -2;
     const WarmList W = warm_list(warm);
+    if (feat == nullptr && feat_hi == nullptr) return -2;
     hipLaunchKernelGGL(surface_gather_kernel, dim3(n_rays + (W.n > 0 ? 1024 : 0)), dim3(64), 0, stream, min_idx, sdf_mask, mid_z, feat,
-                       normal, n, sel, t_sel, feat_sel, normal_sel, n_rays, W);
+                       static_cast<const unsigned char*>(feat_hi), static_cast<const unsigned char*>(feat_lo), normal, n, sel, t_sel, feat_sel,
+                       normal_sel, n_rays, W);
     return fneus::launch_status();
 }
 

@@ -57,7 +57,9 @@ FN_DEV void p2_pass_st(const unsigned char* __restrict__ blob, __amdgpu_buffer_r
     constexpr int D = FNEUS_P2_DEPTH;
     constexpr int NV = TN * 32;
     constexpr bool TRAIN = MODE != 0;
-    constexpr bool LO = MODE == 3 && PREC == 3;
+    // ACT 6 (the linear output: the feature vector): hi + lo planes in EVERY training mode of the parity arithmetic -- they are the colour
+    // network's input (round 6: it reads the planes, the fp32 rows are optional); the h_l planes follow the gradient precision
+    constexpr bool LO = ACT == 6 ? (TRAIN && PREC == 3) : (MODE == 3 && PREC == 3);
     static_assert(KS >= D, "a pass consumes its D primed stages");
     const unsigned voff = (unsigned)(lane + t0 * 64) * 16u;
     accM[0][0] = pr.bias[0];
@@ -275,7 +277,7 @@ template <int PREC, int MODE>
 FN_DEV void p2_linear_out_only(int lane, int t0, f32x16 (&accV)[1][2], const P2St& so, unsigned voff_even, unsigned voff_odd,
                                unsigned voff_row) {
     constexpr bool TRAIN = MODE != 0;
-    constexpr bool LO = MODE == 3 && PREC == 3;
+    constexpr bool LO = TRAIN && PREC == 3;         // the feature planes are hi + lo in every training mode (as ACT 6 of p2_pass_st)
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
 #pragma unroll

@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(256, FNEUS_K2_OCC) sdf_fwd_grad_tp_kernel(cons
         store_f32<2>(acc, feat_out + 32 * t0, 256, nc, h, valid);
         if constexpr (TRAIN)        // the feature plane: the colour network's weight-gradient operand
             tp_exchange_pp<PREC, 2, false>(frag, lane, t0, acc, st.feat_hi + (size_t)tile * kPPBlock,
-                                           lo_planes ? st.feat_lo + (size_t)tile * kPPBlock : nullptr, pl, valid);
+                                           (PREC == 3 && st.feat_lo) ? st.feat_lo + (size_t)tile * kPPBlock : nullptr, pl, valid);      // (hi + lo whatever the gradient precision: the colour network's input, round 6)
         if (wave == 0) {
             f32x16 s1[1];
             load_accvec<9, 8, 1>(blob, LY.L[8].bias, s1, lane);
@@ -630,7 +630,7 @@ __global__ void __launch_bounds__(256, 2) sdf_fwd_grad_tph_kernel(const unsigned
 #pragma unroll
             for (int hb = 0; hb < HB; ++hb) {
                 f_hi[hb] = st.feat_hi + (size_t)tile[hb] * kPPBlock;
-                f_lo[hb] = LO ? st.feat_lo + (size_t)tile[hb] * kPPBlock : nullptr;
+                f_lo[hb] = (PREC == 3 && st.feat_lo) ? st.feat_lo + (size_t)tile[hb] * kPPBlock : nullptr;
             }
             tph_exchange<PREC, 2, false, HB, HALF>(frag, lane, t0, acc, f_hi, f_lo, pl, valid);
         }
@@ -1177,7 +1177,13 @@ extern "C" int fneus_sdf_fwd_grad(const void* blob, const float* pts, const floa
     // workgroups.  FNEUS_K2_P2=0 keeps the fused 32-sample kernel below (read at every call so that tests can switch it).
     const char* p2_env = getenv("FNEUS_K2_P2");
     const int k2p2 = p2_env ? atoi(p2_env) : FNEUS_K2_P2_DEFAULT;
-    if (k2p2 && tiles >= 1024 && st.qs && (prec == 3 || prec == 1)) {
+    const bool two_launches = k2p2 && tiles >= 1024 && st.qs && (prec == 3 || prec == 1);
+    // feat_out NULL (round 6): the caller takes the feature vector as the stash's hi + lo planes -- written by the two-launch form only
+    if (feat_out == nullptr && !(two_launches && train && st.feat_hi && (prec == 1 || st.feat_lo))) {
+        fneus::set_last_error("fneus_sdf_fwd_grad: feat_out may be NULL only for training launches of >= 1024 tiles with feature planes (hi + lo in parity mode)");
+        return -2;
+    }
+    if (two_launches) {
         const int gp = (train && st.h_lo != nullptr && prec == 3) ? 3 : 1;
         // FNEUS_K2_CHUNKS (experiment): forward and reverse launches alternate over C chunks of the samples, so that a chunk's
         // sigma' blocks are still in the memory-side cache when its reverse sweep reads them

@@ -82,10 +82,13 @@ __global__ void __launch_bounds__(512, 1) sdf_fwd_stash_p2_kernel(const unsigned
         if (lV == 8) {
             long rows = N - tile * 32;
             rows = rows < 0 ? 0 : (rows > 64 ? 64 : rows);
-            so.sig = p2_out_rsrc(reinterpret_cast<unsigned char*>(feat_out + tile * 32 * 256), (unsigned)rows * 1024u);
+            // (feat_out NULL: no fp32 rows -- an empty descriptor drops the stores; the feature planes are hi + lo whenever the stash
+            //  has a lo plane for them, whatever the gradient precision of the other planes: the colour network reads them)
+            so.sig = p2_out_rsrc(reinterpret_cast<unsigned char*>(feat_out ? feat_out + tile * 32 * 256 : nullptr), feat_out ? (unsigned)rows * 1024u : 0u);
             if constexpr (TRAIN) {
                 so.hi = p2_out_rsrc(st.feat_hi + (size_t)tile * kPPBlock, ok ? 2u * (unsigned)kPPBlock : 0u);
-                if constexpr (LO) so.lo = p2_out_rsrc(st.feat_lo + (size_t)tile * kPPBlock, ok ? 2u * (unsigned)kPPBlock : 0u);
+                if constexpr (PREC == 3)
+                    so.lo = p2_out_rsrc(st.feat_lo ? st.feat_lo + (size_t)tile * kPPBlock : nullptr, (ok && st.feat_lo) ? 2u * (unsigned)kPPBlock : 0u);
             }
         } else {
             so.sig = p2_out_rsrc(st.ps + ((size_t)tile * 8 + lV) * kPPBlock, ok ? 9u * (unsigned)kPPBlock : 0u);

@@ -109,7 +109,7 @@ def _load():
         "fneus_nerf_bg_fwd": (C.c_int, [vp, vp, vp, l, C.POINTER(FneusNerfStash), vp, vp, ip, ip, vp, vp]),
         "fneus_nerf_bg_bwd": (C.c_int, [vp, l, vp, vp, C.POINTER(FneusNerfStash), ip, vp, vp]),
         "fneus_adam": (C.c_int, [C.POINTER(FneusAdamSegment), ip, vp, vp, C.c_double, C.c_double, C.c_double, ip, vp]),
-        "fneus_surface_gather": (C.c_int, [vp, vp, vp, vp, vp, ip, ip, vp, vp, vp, vp, vp, vp]),
+        "fneus_surface_gather": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, ip, ip, vp, vp, vp, vp, vp, vp]),
         "fneus_surface_scatter": (C.c_int, [vp, vp, vp, ip, C.c_long, vp, vp, vp]),
         "fneus_stage1_loss": (C.c_int, [vp] * 11 + [ip, f, f, f] + [vp] * 10 + [vp, vp]),
         "fneus_stage1_norms": (C.c_int, [vp, vp, vp, ip, f, vp, vp]),

@@ -58,10 +58,13 @@ class SdfValueGradFn(torch.autograd.Function):
     alias); `anchor` is a dummy leaf that makes autograd call backward."""
 
     @staticmethod
-    def forward(ctx, anchor, net, samples: RaySamples, prec: int, ws: _Workspace, train: bool):
+    def forward(ctx, anchor, net, samples: RaySamples, prec: int, ws: _Workspace, train: bool, feat_rows: bool = True):
+        """feat_rows False (NeuSRenderer.render_core, whose consumers of the feature vector read the stash's planes: round 6): where the
+        launch allows it (ops.feat_planes_ok) the returned feature tensor is a placeholder no kernel wrote"""
         n = samples.n
         stash = ws.get(("sdf_stash", n, prec, train), lambda: ops.SdfStash(n, anchor.device, prec, train, gprec=ws.gprec))
-        sdf, feat, normal = ops.sdf_fwd_grad(net.blob, n, prec, stash, train, **samples.kw())
+        rows = feat_rows or not ops.feat_planes_ok(n, prec, train)
+        sdf, feat, normal = ops.sdf_fwd_grad(net.blob, n, prec, stash, train, feat_rows=rows, **samples.kw())
         ctx.net, ctx.samples, ctx.prec, ctx.ws, ctx.stash, ctx.n = net, samples, prec, ws, stash, n
         ctx.generation = ws.stamp(stash)
         if train:       # the forward whose backward is still to come (its stamp, not a count: a forward whose backward never runs
@@ -91,8 +94,10 @@ class SdfValueGradFn(torch.autograd.Function):
                 d_feat.index_add_(0, sel, dfs)
             if dns is not None:
                 d_normal.index_add_(0, sel, dns)
-        heads = ws.cache.pop("surface_head_grads", None)      # (RefHeadsFn.backward: per-head gradients of the gathered rows)
-        if heads is not None and heads[3] == (id(ws), ctx.generation):    # (a leftover of another forward does not ride along)
+        # RefHeadsFn.backward: per-head gradients of the gathered rows, filed under the stamp of the SDF forward the rows came from (two
+        # renders before one backward pass each find their own record, in whatever order autograd runs the nodes)
+        heads = ws.cache.get("surface_head_grads", {}).pop((id(ws), ctx.generation), None)
+        if heads is not None:
             ops.surface_scatter(heads[0], heads[1], heads[2], d_feat, d_normal)       # head sum + scatter-add in one launch
         bufs = ws.get(("sdf_bwd", n, prec), lambda: ops.SdfBwdBufs(n, dev, prec, gprec=ctx.stash.gprec))
         ops.sdf_bwd(net.blob, n, prec, ctx.stash, bufs, d_sdf, d_feat, d_normal, **ctx.samples.kw())
@@ -152,7 +157,7 @@ class SdfValueGradFn(torch.autograd.Function):
             jobs = ws.get(("sdf_jobs", n, prec), lambda: ops.sdf_dw_jobs(net, ctx.stash, bufs, grad, n))
             jobs.run()
         net.wn_backward(grad)
-        return None, None, None, None, None, None
+        return None, None, None, None, None, None, None
 
 
 def _record_alive(stash, gen):
@@ -522,7 +527,10 @@ class RefHeadsFn(torch.autograd.Function):
             # the rows came from surface_gather: their per-head gradients go to the SDF backward as they are (one launch adds the
             # heads and scatters the rows) instead of sum -> SurfaceGatherFn.backward -> index_add_ (four launches)
             sdf_ws, sel, made_for = ctx.gathered
-            sdf_ws.cache["surface_head_grads"] = (sel, d_feat2, d_normal2, made_for)
+            recs = sdf_ws.cache.setdefault("surface_head_grads", {})
+            recs[made_for] = (sel, d_feat2, d_normal2, made_for)
+            while len(recs) > 4:                         # (records of forwards whose backward never ran: oldest first)
+                recs.pop(next(iter(recs)))
             return None, None, None, None, None, None, None, None, None
         return None, d_normal2.sum(0), d_feat2.sum(0), None, None, None, None, None, None
 

@@ -416,7 +416,9 @@ class SdfStash:
         self.pe = torch.zeros((P, T, 4, 64, 8), dtype=bf, device=device) if train else None      # fragment 3 stays zero
         self.h = torch.empty((P, 8, T, 16, 64, 8), dtype=bf, device=device) if train else None
         self.a = torch.empty((P, 8, T, 16, 64, 8), dtype=bf, device=device) if train else None
-        self.feat = torch.empty((P, T, 16, 64, 8), dtype=bf, device=device) if train else None   # colour-network operand
+        # the feature vector: the colour network's INPUT (hi + lo planes in parity mode, whatever the gradient precision: round 6) and,
+        # as its first P planes, an operand of the colour network's weight-gradient products
+        self.feat = torch.empty((2 if prec == PREC_PARITY else 1, T, 16, 64, 8), dtype=bf, device=device) if train else None
         self.ps = torch.empty((T, 8, 16, 64, 8), dtype=torch.int16, device=device)      # sigma' as u16 fixed point
         self.qs = torch.empty((T, 2, 64, 16), dtype=torch.float32, device=device)       # q_skip scratch of the reverse sweep
         s = _lib.FneusSdfStash()
@@ -466,14 +468,29 @@ def sdf_fwd(blob, n_pts: int, prec: int, pts=None, rays_o=None, rays_d=None, t=N
     return out
 
 
+FEAT_PLANES = _os.environ.get("FNEUS_FEAT_PLANES", "1") != "0"
+
+
+def feat_planes_ok(n_pts: int, prec: int, train: bool) -> bool:
+    """may a K2 launch leave the fp32 feature rows out (the consumers read the stash's feature planes)?  The conditions of the two
+    kernels that implement it (csrc/sdf_kernels.hip fneus_sdf_fwd_grad, color_kernels.hip fneus_color_fwd): training launches of
+    >= 1024 sample tiles on the two-launch K2 and the two-pass colour forward"""
+    return (FEAT_PLANES and train and (n_pts + 31) // 32 >= 1024 and prec in (PREC_PARITY, PREC_FAST)
+            and _os.environ.get("FNEUS_K2_P2", "1") == "1" and _os.environ.get("FNEUS_COL_P2", "1") != "0")
+
+
 def sdf_fwd_grad(blob, n_pts: int, prec: int, stash: SdfStash, train: bool, pts=None, rays_o=None, rays_d=None,
-                 t=None, m: int = 1):
+                 t=None, m: int = 1, feat_rows: bool = True):
+    """feat_rows False (only where feat_planes_ok): the [n, 256] tensor returned for `feat` is a PLACEHOLDER that no kernel wrote --
+    the features are the stash's hi + lo planes (its `planes_of` attribute names the stash)"""
     dev = blob.device
     sdf = torch.empty(n_pts, dtype=torch.float32, device=dev)
     feat = torch.empty(n_pts, 256, dtype=torch.float32, device=dev)
     normal = torch.empty(n_pts, 3, dtype=torch.float32, device=dev)
     _launch("fneus_sdf_fwd_grad", lib.fneus_sdf_fwd_grad, _ptr(blob), _ptr(pts), _ptr(rays_o), _ptr(rays_d), _ptr(t), m, n_pts,
-                                 C.byref(stash.c), _ptr(sdf), _ptr(feat), _ptr(normal), prec, int(train), _stream())
+                                 C.byref(stash.c), _ptr(sdf), _ptr(feat) if feat_rows else None, _ptr(normal), prec, int(train), _stream())
+    if not feat_rows:
+        feat.planes_of = stash
     return sdf, feat, normal
 
 
@@ -557,10 +574,18 @@ def color_fwd(blob, n_pts, prec, normal, feat, stash: Optional[ColStash], train:
     _chk_f32(normal, "normal")
     _chk_f32(feat, "feat")
     rgb = torch.empty(n_pts, 3, dtype=torch.float32, device=blob.device)
+    src = getattr(feat, "planes_of", None)          # a placeholder of sdf_fwd_grad(feat_rows=False): the features are that stash's planes
+    if src is not None:
+        if head != HEAD_COLOR or stash is None:
+            raise ValueError("feature planes instead of rows: the colour network's training forward only")
+        if prec == PREC_PARITY and src.feat.shape[0] < 2:
+            raise ValueError("feature planes without a lo plane (an SDF network in bf16 mode) cannot feed a colour network in parity mode")
+        stash.c.feat_hi = src.feat[0].data_ptr()
+        stash.c.feat_lo = src.feat[1].data_ptr() if src.feat.shape[0] == 2 else None
     sp = C.byref(stash.c) if stash is not None else None
     if head == HEAD_COLOR:
         _launch("fneus_color_fwd", lib.fneus_color_fwd, _ptr(blob), _ptr(pts), _ptr(rays_o), _ptr(rays_d), _ptr(t), m, n_pts,
-                _ptr(dirs), _ptr(normal), _ptr(feat), sp, _ptr(rgb), prec, int(train), _stream())
+                _ptr(dirs), _ptr(normal), None if src is not None else _ptr(feat), sp, _ptr(rgb), prec, int(train), _stream())
     else:
         _launch("fneus_refcolor_fwd", lib.fneus_refcolor_fwd, _ptr(blob), head, _ptr(pts), _ptr(rays_o), _ptr(rays_d), _ptr(t),
                 m, n_pts, _ptr(dirs), _ptr(normal), _ptr(feat), sp, _ptr(rgb), prec, int(train), _stream())
@@ -789,7 +814,10 @@ def color_dw_jobs(net: PackedNet, feat_planes: torch.Tensor, stash: ColStash, gr
     offW, offb = net.desc["offW"], net.desc["offb"]
     n_side, ld0, n_out = net.desc["n_side"], net.desc["ins"][0], net.desc["outs"][4]
     base = grad_flat.data_ptr()
-    assert feat_planes.shape[0] == stash.zbar.shape[0], "feature planes and colour stash differ in gradient precision"
+    # (the SDF stash keeps the feature planes hi + lo in parity mode -- they are the colour network's input; the products take as many
+    #  planes as the colour stash's gradient precision has)
+    assert feat_planes.shape[0] >= stash.zbar.shape[0], "feature planes and colour stash differ in gradient precision"
+    feat_planes = feat_planes[:stash.zbar.shape[0]]
     nt = stash.tiles if own_tiles else 0         # own_tiles: these planes hold another number of samples than the launch's
     # layer 0: columns 0..n_side-1 = side inputs, then the 256 features
     g.add(O(stash.zbar[:, 0], 0, 8), O(feat_planes, 0, 8), base + 4 * (offW[0] + n_side), ld0, 256, 256, bias_ptr=base + 4 * offb[0],
@@ -962,7 +990,10 @@ def surface_gather(min_idx, sdf_mask, mid_z, feat, normal, warm=None):
     t_sel = torch.empty(2 * B, dtype=torch.float32, device=dev)
     feat_sel = torch.empty(2 * B, 256, dtype=torch.float32, device=dev)
     normal_sel = torch.empty(2 * B, 3, dtype=torch.float32, device=dev)
-    _launch("fneus_surface_gather", lib.fneus_surface_gather, _ptr(min_idx), _ptr(sdf_mask), _ptr(mid_z), _ptr(feat), _ptr(normal),
+    src = getattr(feat, "planes_of", None)          # a placeholder of sdf_fwd_grad(feat_rows=False): the rows are read from the planes
+    _launch("fneus_surface_gather", lib.fneus_surface_gather, _ptr(min_idx), _ptr(sdf_mask), _ptr(mid_z),
+            None if src is not None else _ptr(feat), None if src is None else _ptr(src.feat[0]),
+            None if (src is None or src.feat.shape[0] < 2) else _ptr(src.feat[1]), _ptr(normal),
             B, n, _ptr(sel), _ptr(t_sel), _ptr(feat_sel), _ptr(normal_sel), _warm_arg(warm), _stream())
     return sel, t_sel, feat_sel, normal_sel
 

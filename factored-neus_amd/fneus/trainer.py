@@ -433,8 +433,13 @@ class Stage1Trainer:
         import os
         if self.use_graph and data.is_cuda and ops.PROFILE is None and os.environ.get("FNEUS_RENDER_GRAPH", "1") != "0":
             cache = self.__dict__.setdefault("_render_graphs", {})
-            key = (tuple(data.shape), data.dtype)
+            # what a capture bakes in as host constants besides the shape: sample counts, precision modes, the modules' backends
+            r = self.renderer
+            key = (tuple(data.shape), data.dtype, r.n_samples, r.n_importance, r.n_outside, r.up_sample_steps,
+                   getattr(self.sdf_network, "prec", None), getattr(self.color_network, "prec", None), ops.DEFAULT_GPREC)
             ent = cache.get(key)
+            if ent is None and len(cache) >= 6:          # (bounded like the step graphs: a graph holds its memory pool)
+                cache.pop(next(iter(cache)))
             if ent is None:
                 self._render_eager(data, cos_anneal_ratio)          # allocations and lazy set-up outside the capture
                 static = data.clone()

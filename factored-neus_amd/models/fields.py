@@ -199,10 +199,12 @@ class SDFNetwork(_HipMLP):
         self._ensure()
         return ops.sdf_fwd(self._net.blob, samples.n, self.prec, ray_mask=ray_mask, **samples.kw())
 
-    def value_feature_normal(self, samples: RaySamples, train: bool):
-        """sdf [n], feature [n,256], normal [n,3] in one fused pass (K2), differentiable w.r.t. the parameters"""
+    def value_feature_normal(self, samples: RaySamples, train: bool, feat_rows: bool = True):
+        """sdf [n], feature [n,256], normal [n,3] in one fused pass (K2), differentiable w.r.t. the parameters.
+        feat_rows False: the caller hands `feature` to RenderingNetwork.color_samples / SurfaceGatherFn only -- they read the stash's
+        hi + lo feature planes, and a chip-filling training launch then leaves the fp32 rows out (the tensor is a placeholder)"""
         self._ensure()
-        return SdfValueGradFn.apply(self._anchor, self._net, samples, self.prec, self._ws, train)
+        return SdfValueGradFn.apply(self._anchor, self._net, samples, self.prec, self._ws, train, feat_rows)
 
     # ---- reference API (fields.py:74-111) ----
     def forward(self, inputs, iter_step=0):
@@ -692,6 +694,12 @@ def seq_group(items):
         spec = _mlp_spec(seq) if (ops.MLP_ROWS and x.is_cuda and x.dtype == torch.float32) else None
         if spec is not None and x.numel() // max(1, x.shape[-1]) * max(max(m.in_features, m.out_features) for m, _ in spec) * 4 >= 2 ** 31:
             spec = None            # (the kernels address an operand through 32-bit offsets: such a batch goes to torch's modules)
+        if spec is not None:
+            # what nn.Linear would reject: an input whose width is not the first layer's, or consecutive layers that do not fit -- the
+            # kernels would read rows of the wrong stride (the plain modules raise the error torch's users know)
+            widths_ok = x.shape[-1] == spec[0][0].in_features and all(a.out_features == b.in_features for (a, _), (b, _) in zip(spec, spec[1:]))
+            if not widths_ok:
+                spec = None
         if spec is not None and top_act is not None:
             if spec[-1][1] != ops.ACT_NONE:
                 raise ValueError("seq_group: top_act given for a network that ends in an activation")

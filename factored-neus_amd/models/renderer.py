@@ -179,7 +179,9 @@ class NeuSRenderer:
         train = torch.is_grad_enabled()
         dists, mid_z = self._sections(z_vals, sample_dist)
         samples = RaySamples(rays_o, rays_d, mid_z.reshape(-1), n)
-        sdf, feat, normal = sdf_network.value_feature_normal(samples, train)
+        # (feat goes to the colour network and the surface gather only: both read the SDF stash's feature planes, so a chip-filling
+        #  training launch writes no fp32 feature rows -- round 6)
+        sdf, feat, normal = sdf_network.value_feature_normal(samples, train, feat_rows=False)
         rgb = color_network.color_samples(samples, normal, feat, sdf_network, train)
         if background_fn is not None:
             background_alpha, background_sampled_color = background_fn()

@@ -172,7 +172,10 @@ int fneus_sdf_fwd_rays(const void* sdf_blob, const float* rays_o, const float* r
                        fneus_stream_t stream);
 
 /* ---- K2: SDFNetwork.forward + SDFNetwork.gradient  (fields.py:74-111 via renderer.py:238-242) ------------- */
-/* train != 0 additionally writes the a_l / feature planes needed by fneus_sdf_bwd. */
+/* train != 0 additionally writes the a_l / feature planes needed by fneus_sdf_bwd.  Round 6: the feature planes are hi + lo whenever
+ * the stash has a feat_lo plane (whatever the gradient precision of the other planes), and feat_out may be NULL for training launches of
+ * >= 1024 sample tiles: the consumers of the feature vector on the hot path (fneus_color_fwd with feat = NULL and the planes in its
+ * stash's feat_hi / feat_lo; fneus_surface_gather) read the planes -- 1 KiB per sample of fp32 rows neither written nor read.        */
 int fneus_sdf_fwd_grad(const void* sdf_blob, const float* pts, const float* rays_o, const float* rays_d,
                        const float* t, int m, long n_pts, const FneusSdfStash* stash /*host struct*/,
                        float* sdf_out /*[n]*/, float* feat_out /*[n][256]*/, float* normal_out /*[n][3]*/, int prec,
@@ -270,7 +273,9 @@ typedef struct FneusWarmRanges {
  * RefColor heads: sel [2B] (row index into the B*n samples), t_sel [2B], feat_sel [2B][256], normal_sel [2B][3].
  * Rays without a sign change (sdf_mask 0) select samples 0 and 1, as the reference's dense formulation does.           */
 int fneus_surface_gather(const int32_t* min_idx, const unsigned char* sdf_mask, const float* mid_z /*[B][n]*/,
-                         const float* feat /*[B*n][256]*/, const float* normal /*[B*n][3]*/, int n_rays, int n,
+                         const float* feat /*[B*n][256], or NULL: the rows are read from the planes*/,
+                         const void* feat_hi, const void* feat_lo /*FneusSdfStash.feat_hi / feat_lo (round 6); lo or both may be NULL*/,
+                         const float* normal /*[B*n][3]*/, int n_rays, int n,
                          int32_t* sel, float* t_sel, float* feat_sel, float* normal_sel, const FneusWarmRanges* warm /*or NULL*/,
                          fneus_stream_t stream);
 

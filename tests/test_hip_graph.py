@@ -135,3 +135,36 @@ def test_variance_gradient_riding_in_the_fold_launch_equals_the_plain_sum(monkey
         assert abs(v1 - v0) <= 2e-6, (v1, v0)                       # the Adam steps of lr 5e-4 moved it by ~2e-3
         assert abs(v1 - 0.3) > 1e-4
         assert (w1 - w0).abs().max().item() <= 2e-3 * w0.abs().max().item()      # (atomics order -> Adam: a few elements by a fraction of lr)
+
+
+def test_feature_planes_instead_of_rows_change_nothing(monkeypatch):
+    """round 6: in NeuSRenderer.render_core the feature vector goes to the colour network and to the surface gather only, and a
+    chip-filling training launch hands it over as the SDF stash's hi + lo planes (no fp32 rows written or read: ops.feat_planes_ok).
+    The colour network sees the same fragments bit for bit; the gathered rows are hi + lo (17 significant bits, what the RefColor heads
+    split them into anyway): same losses and same parameters after three steps as with the rows (FNEUS_FEAT_PLANES=0)."""
+    from fneus import ops
+    from fneus.trainer import Stage1Trainer, synthetic_batches
+    dev = torch.device("cuda:0")
+    batches = synthetic_batches(3, 512, dev, seed0=91)
+
+    def run(planes, graph):
+        monkeypatch.setattr(ops, "FEAT_PLANES", planes)
+        ops.set_deterministic(True)
+        try:
+            torch.manual_seed(13)
+            tr = Stage1Trainer(dev, seed=7, use_graph=graph)
+            losses = [float(tr.train_step(b)["loss"]) for b in batches]
+            stash = tr.sdf_network._ws.cache[("sdf_stash", 512 * 128, ops.PREC_PARITY, True)]
+            return losses, tr.color_network.lin0.weight_v.detach().clone(), tr.sdf_network.lin8.weight_v.detach().clone(), stash
+        finally:
+            ops.set_deterministic(None)
+
+    assert ops.feat_planes_ok(512 * 128, ops.PREC_PARITY, True)
+    for graph in (False, True):
+        l0, c0, s0, _ = run(False, graph)
+        l1, c1, s1, st = run(True, graph)
+        assert st.feat.shape[0] == 2
+        for a, b in zip(l0, l1):
+            assert abs(a - b) <= 2e-6 * abs(a), (l0, l1)
+        assert (c1 - c0).abs().max().item() <= 2e-3 * c0.abs().max().item()        # (Adam amplifies last-bit differences of a gradient)
+        assert (s1 - s0).abs().max().item() <= 2e-3 * s0.abs().max().item()

@@ -513,6 +513,34 @@ def test_colour_output_layer_gradient_with_exact_operands(n):
         assert float(dWs[l].abs().max()) == 0.0 and float(dbs[l].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("n", [65536, 40003, 32768 + 64, 1000])
+@pytest.mark.parametrize("gprec", [1, 3])
+def test_feature_planes_are_complete_in_every_training_mode(n, gprec):
+    """round 6: the SDF stash's feature planes are the colour network's INPUT -- hi + lo in every training mode of the parity
+    arithmetic, every sample tile written by every form of K2 (the two-launch form incl. the tail of each workgroup's last unit, the
+    fused kernel of small launches), with or without the fp32 rows.  The planes are poisoned with NaN before the launch."""
+    from fneus import ops, synth, pp
+    net = ops.PackedNet("sdf", DEV).load_state_dict({k: T(v) for k, v in synth.sdf_state_dict(25).items()})
+    net.pack()
+    x = (torch.rand(n, 3, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3)) * 2 - 1).contiguous()
+    st = ops.SdfStash(n, DEV, 3, True, gprec)
+    assert st.feat.shape[0] == 2
+    st.feat.fill_(float("nan"))
+    sdf, feat, nrm = ops.sdf_fwd_grad(net.blob, n, 3, st, True, pts=x)
+    torch.cuda.synchronize()
+    planes = st.feat[:, :st.tiles].float()
+    assert torch.isfinite(planes).all()
+    val = pp.value(st.feat[:, :st.tiles], n)
+    assert (val - feat).abs().max().item() <= 2.0 ** -15 * feat.abs().max().item()
+    if ops.feat_planes_ok(n, 3, True):
+        st2 = ops.SdfStash(n, DEV, 3, True, gprec)
+        st2.feat.fill_(float("nan"))
+        sdf2, ph, nrm2 = ops.sdf_fwd_grad(net.blob, n, 3, st2, True, pts=x, feat_rows=False)
+        torch.cuda.synchronize()
+        assert ph.planes_of is st2
+        assert torch.equal(st2.feat[:, :st2.tiles], st.feat[:, :st.tiles]) and torch.equal(sdf2, sdf) and torch.equal(nrm2, nrm)
+
+
 def test_k1_on_marked_rays_only_equals_k1_there_and_fills_the_rest():
     """fneus_sdf_fwd_rays (the stage-2 march of the fixed-shape step): marked rays get the values of the plain launch bit for bit,
     the samples of the others the fill value; nothing marked, everything marked and a ragged mix"""
