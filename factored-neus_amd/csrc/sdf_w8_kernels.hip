@@ -8,6 +8,7 @@
 #include "p2_engine.h"
 #include "fneus_kernels.h"
 #include "sdf_w8.h"
+#include "ray_sampler.h"
 
 namespace fneus {
 
@@ -84,10 +85,30 @@ FN_DEV void w8p_dense(bf16x8 (&wh)[17], bf16x8 (&wl)[17], const unsigned char* f
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 }
 
-template <int PREC>
-__global__ void __launch_bounds__(512, 2) sdf_fwd_w8p_kernel(const unsigned char* blob, PointSrc src, long N, float* __restrict__ sdf_out) {
+// MERGE (round 6): the launch carries a sampler step in its epilogue.  The samples are the k new depths of each ray (ray form, k = 16 or
+// 32: a tile = 32 / k whole rays); behind the tile's sdf values, wave w < 32 / k runs cat_z_vals + up_sample (+ the last step's merge and
+// sections) of ray tile * (32 / k) + w -- the body of merge_upsample_kernel (ray_sampler.h), bit for bit -- with the new sdf values taken
+// from LDS.  renderer.py:433-446 is a per-ray recurrence: nothing of it needs another workgroup, and a launch boundary + the merge
+// kernel's own ramp per up-sampling step go (3 launches of the training step's 31).
+struct W8Merge {
+    const float *z_old, *s_old;     // [B][m]
+    int m;
+    const float* z_new;             // [B][k] (= src.t)
+    int k, n_rays;
+    float inv_s;
+    int k_next;
+    float *z_out, *s_out, *z_next, *z_final;
+    float sample_dist;
+    float *dists, *mid_z;
+};
+
+template <int PREC, bool MERGE>
+__global__ void __launch_bounds__(512, 2) sdf_fwd_w8p_kernel(const unsigned char* blob, PointSrc src, long N, float* __restrict__ sdf_out,
+                                                             W8Merge mg) {
     __shared__ __attribute__((aligned(16))) unsigned char frag[kW8Half];
     __shared__ float red[8 * 32];
+    __shared__ float snew[MERGE ? 32 : 1];
+    __shared__ float rayb[MERGE ? 2 : 1][MERGE ? 6 * MAXN + 8 : 1];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int r = lane & 31, h = lane >> 5;
@@ -178,7 +199,21 @@ __global__ void __launch_bounds__(512, 2) sdf_fwd_w8p_kernel(const unsigned char
 #pragma unroll
                 for (int w = 0; w < 8; ++w) s += red[w * 32 + lane];
                 const long n = tile * 32 + r;
-                if (n < N) sdf_out[n] = s;
+                if (n < N && sdf_out != nullptr) sdf_out[n] = s;
+                if constexpr (MERGE) snew[lane] = s;
+            }
+        }
+        if constexpr (MERGE) {
+            w8_barrier();                               // the tile's values are in LDS
+            const int R = 32 / mg.k;
+            if (wave < R) {
+                const long ray = tile * R + wave;
+                if (ray < mg.n_rays) {
+                    float* b = rayb[wave];
+                    merge_upsample_ray<false>((int)ray, lane, src.rays_o, src.rays_d, mg.z_old, mg.s_old, mg.m, mg.z_new, snew + wave * mg.k, true,
+                                              mg.k, mg.inv_s, mg.k_next, mg.z_out, mg.s_out, mg.z_next, mg.z_final, mg.sample_dist, mg.dists,
+                                              mg.mid_z, b, b + MAXN, b + 2 * MAXN, b + 3 * MAXN, b + 4 * MAXN, b + 5 * MAXN + 4);
+                }
             }
         }
     }
@@ -187,10 +222,39 @@ __global__ void __launch_bounds__(512, 2) sdf_fwd_w8p_kernel(const unsigned char
 int sdf_fwd_w8p(const unsigned char* b, const PointSrc& src, long n_pts, float* sdf_out, int prec, hipStream_t stream) {
     const long tiles = (n_pts + 31) / 32;
     const dim3 grid((unsigned)(tiles < 1024 ? tiles : 1024));
-    if (prec == 3) hipLaunchKernelGGL(sdf_fwd_w8p_kernel<3>, grid, dim3(512), 0, stream, b, src, n_pts, sdf_out);
-    else if (prec == 1) hipLaunchKernelGGL(sdf_fwd_w8p_kernel<1>, grid, dim3(512), 0, stream, b, src, n_pts, sdf_out);
+    const W8Merge none{};
+    if (prec == 3) hipLaunchKernelGGL((sdf_fwd_w8p_kernel<3, false>), grid, dim3(512), 0, stream, b, src, n_pts, sdf_out, none);
+    else if (prec == 1) hipLaunchKernelGGL((sdf_fwd_w8p_kernel<1, false>), grid, dim3(512), 0, stream, b, src, n_pts, sdf_out, none);
     else return -2;
     return launch_status();
 }
+
+}  // namespace fneus
+
+using namespace fneus;
+
+// K1 on the new depths of an up-sampling step + that step's cat_z_vals / the next step's up_sample in ONE launch (renderer.py:430-446;
+// fneus_sdf_fwd followed by fneus_merge_upsample, bit for bit).  -3: a shape this form does not take (the caller runs the two launches).
+extern "C" int fneus_sdf_fwd_merge_upsample(const void* blob, const float* rays_o, const float* rays_d, const float* z_old, const float* s_old,
+                                            int m, const float* z_new, int k, int n_rays, float inv_s, int k_next, float* z_out, float* s_out,
+                                            float* z_next, float* z_final, float sample_dist, float* dists, float* mid_z, float* s_new_out,
+                                            int prec, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (n_rays <= 0) return 0;
+    if (!blob || !rays_o || !rays_d || !z_old || !s_old || !z_new || !z_out || !s_out || !z_next) return -2;
+    const long n_pts = (long)n_rays * k;
+    const long tiles = (n_pts + 31) / 32;
+    if ((k != 16 && k != 32) || tiles >= 1024 || m + k > MAXN || m + k + k_next > MAXN || k_next < 1 || (prec != 3 && prec != 1)) return -3;
+    PointSrc src{nullptr, rays_o, rays_d, z_new, k};
+    const W8Merge mg{z_old, s_old, m, z_new, k, n_rays, inv_s, k_next, z_out, s_out, z_next, z_final, sample_dist, (z_final && mid_z) ? dists : nullptr, mid_z};
+    const dim3 grid((unsigned)tiles);
+    const unsigned char* b = reinterpret_cast<const unsigned char*>(blob);
+    if (prec == 3) hipLaunchKernelGGL((sdf_fwd_w8p_kernel<3, true>), grid, dim3(512), 0, stream, b, src, n_pts, s_new_out, mg);
+    else hipLaunchKernelGGL((sdf_fwd_w8p_kernel<1, true>), grid, dim3(512), 0, stream, b, src, n_pts, s_new_out, mg);
+    return fneus::launch_status();
+}
+
+namespace fneus {
 
 }  // namespace fneus

@@ -116,6 +116,7 @@ def _load():
         "fneus_upsample": (C.c_int, [vp, vp, vp, vp, ip, ip, ip, f, vp, vp]),
         "fneus_merge": (C.c_int, [vp, vp, ip, vp, vp, ip, ip, vp, vp, vp]),
         "fneus_merge_upsample": (C.c_int, [vp, vp, vp, vp, ip, vp, vp, ip, ip, f, ip, vp, vp, vp, vp, f, vp, vp, vp]),
+        "fneus_sdf_fwd_merge_upsample": (C.c_int, [vp, vp, vp, vp, vp, ip, vp, ip, ip, f, ip, vp, vp, vp, vp, f, vp, vp, vp, ip, vp]),
         "fneus_sections": (C.c_int, [vp, ip, ip, f, vp, vp, vp]),
         "fneus_ray_setup": (C.c_int, [vp, vp, vp, vp, vp, ip, ip, vp, vp]),
         "fneus_split_batch": (C.c_int, [vp, ip, vp, vp, vp, vp, vp]),

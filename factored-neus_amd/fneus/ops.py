@@ -1463,6 +1463,34 @@ def merge_upsample(rays_o, rays_d, z_old, s_old, z_new, s_new, inv_s: float, k_n
     return z_out, s_out, z_next, z_final
 
 
+SAMPLER_K1_FUSED = _os.environ.get("FNEUS_SAMPLER_K1_FUSED", "1") != "0"
+
+
+def sdf_merge_upsample(blob, prec: int, rays_o, rays_d, z_old, s_old, z_new, inv_s: float, k_next: int, last: bool, sample_dist=None,
+                       want_s_new: bool = False):
+    """fneus_sdf_fwd on the new depths z_new [B, k] of an up-sampling step + merge_upsample(...) of that step in ONE launch
+    (fneus_sdf_fwd_merge_upsample; bit-identical to the two).  -> merge_upsample's result (+ s_new [B, k] with want_s_new), or None when
+    the launch does not take the shape (the caller then runs the two launches)."""
+    B, m = z_old.shape
+    k = z_new.shape[1]
+    if not SAMPLER_K1_FUSED or PROFILE is not None or k not in (16, 32) or (B * k + 31) // 32 >= 1024 or m + k + k_next > 256:
+        return None
+    dev = z_old.device
+    z_out = torch.empty(B, m + k, dtype=torch.float32, device=dev)
+    s_out = torch.empty_like(z_out)
+    z_next = torch.empty(B, k_next, dtype=torch.float32, device=dev)
+    z_final = torch.empty(B, m + k + k_next, dtype=torch.float32, device=dev) if last else None
+    sec = last and sample_dist is not None
+    dists = torch.empty_like(z_final) if sec else None
+    mid_z = torch.empty_like(z_final) if sec else None
+    s_new = torch.empty(B, k, dtype=torch.float32, device=dev) if want_s_new else None
+    _launch("fneus_sdf_fwd_merge_upsample", lib.fneus_sdf_fwd_merge_upsample, _ptr(blob), _ptr(rays_o), _ptr(rays_d), _ptr(z_old), _ptr(s_old), m,
+            _ptr(z_new), k, B, float(inv_s), int(k_next), _ptr(z_out), _ptr(s_out), _ptr(z_next), _ptr(z_final),
+            float(sample_dist) if sec else 0.0, _ptr(dists), _ptr(mid_z), _ptr(s_new), prec, _stream())
+    out = (z_out, s_out, z_next, z_final, dists, mid_z) if sample_dist is not None else (z_out, s_out, z_next, z_final)
+    return out + (s_new,) if want_s_new else out
+
+
 def split_batch(data: torch.Tensor):
     """[B,10] batch -> contiguous rays_o [B,3], rays_d [B,3], rgb [B,3], mask [B,1] in one launch"""
     _chk_f32(data, "data")

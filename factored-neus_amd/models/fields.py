@@ -199,6 +199,12 @@ class SDFNetwork(_HipMLP):
         self._ensure()
         return ops.sdf_fwd(self._net.blob, samples.n, self.prec, ray_mask=ray_mask, **samples.kw())
 
+    def sdf_merge_upsample(self, rays_o, rays_d, z_old, s_old, z_new, inv_s: float, k_next: int, last: bool, sample_dist=None):
+        """one step of the hierarchical sampler in one launch: no-grad SDF values at the new depths + cat_z_vals + the next up_sample
+        (ops.sdf_merge_upsample; None when the launch does not take the shape)"""
+        self._ensure()
+        return ops.sdf_merge_upsample(self._net.blob, self.prec, rays_o, rays_d, z_old, s_old, z_new, inv_s, k_next, last, sample_dist)
+
     def value_feature_normal(self, samples: RaySamples, train: bool, feat_rows: bool = True):
         """sdf [n], feature [n,256], normal [n,3] in one fused pass (K2), differentiable w.r.t. the parameters.
         feat_rows False: the caller hands `feature` to RenderingNetwork.color_samples / SurfaceGatherFn only -- they read the stash's

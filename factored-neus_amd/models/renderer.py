@@ -117,6 +117,13 @@ class NeuSRenderer:
             z_vals, sdf = z_vals.contiguous(), sdf.contiguous()
             new_z = ops.upsample(ro, rd, z_vals, sdf, k, 64.0)
             for i in range(1, steps):
+                # round 6: the SDF evaluation of the step's new depths and the merge + next up_sample in ONE launch (a tile of the
+                # evaluation is whole rays: the workgroup that evaluated it merges them); None: a shape that launch does not take
+                fused = self.sdf_network.sdf_merge_upsample(ro, rd, z_vals, sdf, new_z.contiguous(), float(64 * 2 ** i), k,
+                                                            last=(i + 1 == steps), sample_dist=2.0 / self.n_samples)
+                if fused is not None:
+                    z_vals, sdf, new_z, z_final, dists, mid_z = fused
+                    continue
                 new_sdf = self.sdf_network.sdf_samples(RaySamples(rays_o, rays_d, new_z.reshape(-1), k)).reshape(B, k)
                 # (the last launch also writes the sections of the final depths: render_core asks for them next)
                 z_vals, sdf, new_z, z_final, dists, mid_z = ops.merge_upsample(ro, rd, z_vals, sdf, new_z, new_sdf.contiguous(),

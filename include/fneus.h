@@ -325,6 +325,16 @@ int fneus_merge_upsample(const float* rays_o, const float* rays_d, const float* 
                          const float* z_new, const float* s_new, int k, int n_rays, float inv_s, int k_next, float* z_out,
                          float* s_out, float* z_next, float* z_final, float sample_dist, float* dists, float* mid_z,
                          fneus_stream_t stream);
+
+/* K1 on the k new depths of an up-sampling step (ray form, k = 16 or 32) AND that step's fneus_merge_upsample in ONE launch (round 6): the
+ * sampler of renderer.py:430-446 is a per-ray recurrence with one SDF evaluation per step, a 32-sample tile of the evaluation is 32 / k
+ * whole rays, and the workgroup that evaluated a tile runs the merge of its rays behind it (new sdf values from LDS) -- same values as
+ * fneus_sdf_fwd + fneus_merge_upsample, bit for bit.  s_new_out [B][k] or NULL.  Returns -3 for a shape this form does not take
+ * (k other than 16 / 32, >= 1024 tiles, more than 256 merged depths): the caller then runs the two launches.                       */
+int fneus_sdf_fwd_merge_upsample(const void* sdf_blob, const float* rays_o, const float* rays_d, const float* z_old, const float* s_old,
+                                 int m, const float* z_new, int k, int n_rays, float inv_s, int k_next, float* z_out, float* s_out,
+                                 float* z_next, float* z_final, float sample_dist, float* dists, float* mid_z, float* s_new_out, int prec,
+                                 fneus_stream_t stream);
 /* One training batch [B][10] = rays_o, rays_d, rgb, mask per row (what Dataset.gen_random_rays_at returns, dataset.py:133-151)
  * -> the four contiguous arrays the kernels take (exp_runner.py:134-139 slices the same columns). */
 int fneus_split_batch(const float* data /*[B][10]*/, int n_rays, float* rays_o /*[B][3]*/, float* rays_d /*[B][3]*/,

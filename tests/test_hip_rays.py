@@ -115,6 +115,35 @@ def test_fused_sampler_in_render_is_bit_identical():
     assert a.shape == (300, 128) and torch.equal(a, b)
 
 
+@pytest.mark.parametrize("B,k,last", [(512, 16, False), (512, 16, True), (301, 16, True), (64, 32, False), (7, 16, True)])
+def test_sampler_step_inside_the_k1_launch_is_bit_identical(B, k, last):
+    """round 6: fneus_sdf_fwd_merge_upsample = fneus_sdf_fwd on the step's new depths followed by fneus_merge_upsample, in ONE launch (a
+    32-sample tile of the evaluation is 32 / k whole rays; the workgroup that evaluated it merges them, the new sdf values from LDS):
+    every output bit for bit, ragged ray counts (a last tile with one ray), both tile shapes, with and without the last step's sections"""
+    from fneus import ops, synth
+    net = ops.PackedNet("sdf", DEV).load_state_dict({k_: T(v) for k_, v in synth.sdf_state_dict(26).items()})
+    net.pack()
+    data = T(synth.ray_batch(B, seed=B + k, n_miss=max(1, B // 20))).to(DEV)
+    ro, rd = data[:, :3].contiguous(), data[:, 3:6].contiguous()
+    m = 80
+    g = torch.Generator().manual_seed(B)
+    z = torch.sort(torch.rand(B, m, generator=g) * 2.0 + 0.5, dim=-1)[0].to(DEV).contiguous()
+    new_z = torch.sort(torch.rand(B, k, generator=g) * 2.0 + 0.5, dim=-1)[0].to(DEV).contiguous()
+    s = ops.sdf_fwd(net.blob, B * m, 3, rays_o=ro, rays_d=rd, t=z.reshape(-1), m=m).reshape(B, m)
+    new_s = ops.sdf_fwd(net.blob, B * k, 3, rays_o=ro, rays_d=rd, t=new_z.reshape(-1), m=k).reshape(B, k).contiguous()
+    sd = 2.0 / 64
+    ref = ops.merge_upsample(ro, rd, z, s, new_z, new_s, 256.0, 16, last, sample_dist=sd)
+    got = ops.sdf_merge_upsample(net.blob, 3, ro, rd, z, s, new_z, 256.0, 16, last, sample_dist=sd, want_s_new=True)
+    assert got is not None
+    assert torch.equal(got[-1], new_s)
+    for a, b, name in zip(got[:-1], ref, ("z_out", "s_out", "z_next", "z_final", "dists", "mid_z")):
+        assert (a is None) == (b is None), name
+        if a is not None:
+            assert torch.equal(a, b), name
+    # shapes the launch does not take: the caller falls back
+    assert ops.sdf_merge_upsample(net.blob, 3, ro, rd, z, s, new_z[:, :8].contiguous(), 256.0, 16, last, sample_dist=sd) is None
+
+
 def fops():
     from fneus import ops
     return ops
