@@ -77,7 +77,10 @@ KERNEL_BYTES_PARITY["fneus_dw_gemm_pp:sdf+color"] = (KERNEL_BYTES_PARITY["fneus_
                                                      + KERNEL_BYTES_PARITY_EXTRA["fneus_dw_gemm_pp:color"])
 ALGORITHMIC_STASH_BYTES_PER_SAMPLE = 11.0 * 1024 + 40      # ~11 KB activation stash + 40 B of API outputs
 HBM_ACHIEVABLE_GBS = 6300.0          # float4 copy on this part (MI355X_MICROARCH.md: 6.29 TB/s measured, 79 % of the 8 TB/s spec)
-MFMAS_PER_PRODUCT = {"fneus_dw_gemm_pp:sdf": 1, "fneus_dw_gemm_pp:color": 1, "fneus_dw_gemm_pp:sdf+color": 1}      # gprec 1: bf16 planes; the chains issue 3
+# gradient precision 1 / 2: the weight-gradient GEMM multiplies bf16 planes (1 MFMA per product); the cotangent chains (K3, the colour
+# network's backward) run on the bf16 values of those planes against W hi + lo (2 per product, round 6: DESIGN.md 4.1e); the forward
+# chains and K2's reverse sweep issue 3
+MFMAS_PER_PRODUCT = {"fneus_dw_gemm_pp:sdf": 1, "fneus_dw_gemm_pp:color": 1, "fneus_dw_gemm_pp:sdf+color": 1, "fneus_sdf_bwd": 2, "fneus_color_bwd": 2}
 KERNEL_FLOPS_EXTRA = {"fneus_sdf_fwd": 0.875 * F_SDF * SAMPLES_PER_STEP}
 
 
@@ -87,7 +90,7 @@ def kernel_floor_ms(name, gprec=1):
     weight-gradient GEMM 1 (gprec 1) or 3 (gprec 3)."""
     flops = KERNEL_FLOPS.get(name, KERNEL_FLOPS_EXTRA.get(name, 0.0))
     byts = KERNEL_BYTES_PARITY.get(name, KERNEL_BYTES_PARITY_EXTRA.get(name, 0.0))
-    k = MFMAS_PER_PRODUCT.get(name, 3) if gprec == 1 else 3
+    k = MFMAS_PER_PRODUCT.get(name, 3) if gprec in (1, 2) else 3
     t_mfma = k * flops / (PEAK_BF16_MFMA_TFLOPS * 1e12) * 1e3
     t_hbm = byts / (HBM_ACHIEVABLE_GBS * 1e9) * 1e3
     return {"floor_ms": max(t_mfma, t_hbm), "mfma_ms": t_mfma, "hbm_ms": t_hbm, "bound": "mfma" if t_mfma >= t_hbm else "hbm"}
@@ -314,7 +317,9 @@ def main():
         "higher_is_better": True,
         "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
-        "dtype": (f"bf16x3 split MFMA (3 products per value, fp32 accumulate) in every forward and backward chain = the 1e-4 parity mode; "
+        "dtype": (f"bf16x3 split MFMA (3 products per value, fp32 accumulate) in every chain whose result is a forward value (sdf, features, "
+                  f"normals, colours: the 1e-4 parity mode); the cotangent chains of the backward (K3, colour backward) on W hi + lo x the bf16 "
+                  f"cotangents their planes hold (2 products) unless the gradient precision is 3; "
                   f"weight-gradient GEMM operands: gradient precision {gprec_run} "
                   + {1: "(bf16 planes)", 2: "(bf16 planes; the colour network's output layer -- the one product whose bf16 rounding exceeds "
                                           "the exact mode's gradient bounds -- on exact operands, fp32 FMAs)", 3: "(bf16 hi + lo planes)"}[gprec_run])
@@ -641,6 +646,20 @@ def main():
                                                              "holds the gradient bounds of gprec 3 (5e-3 of scale per sampled element, 2e-3 of a tensor's norm)"}
         except Exception as e:
             result["bf16_gradient_planes_gprec1"] = {"value": None, "error": repr(e)}
+        try:    # the headline's mode with hi + lo cotangents inside the backward chains (three MFMAs per product there, as before round 6)
+            os.environ["FNEUS_BWD_XHI"] = "0"
+            os.environ["FNEUS_COLB_XHI"] = "0"
+            n_x = max(args.steps // 2, 5)
+            dt_x, _, _ = run(prec, n_x, 3, profile=False)
+            result["hi_lo_cotangent_chains"] = {"value": SAMPLES_PER_STEP * n_x / dt_x, "unit": "ray-samples/s", "ms_per_step": dt_x / n_x * 1e3,
+                                                "note": "FNEUS_BWD_XHI=0 FNEUS_COLB_XHI=0: K3 and the colour backward with hi + lo activation fragments "
+                                                        "(the gradients of the 512-ray fixture: 2.8e-4 / 2.7e-5 of scale / norm against 5.7e-4 / 3.2e-5 "
+                                                        "with the default's bf16 cotangents, bounds 5e-3 / 2e-3; DESIGN.md 4.1e)"}
+        except Exception as e:
+            result["hi_lo_cotangent_chains"] = {"value": None, "error": repr(e)}
+        finally:
+            os.environ.pop("FNEUS_BWD_XHI", None)
+            os.environ.pop("FNEUS_COLB_XHI", None)
         try:    # config 5's per-GPU share of a 2048-ray batch at 8 ranks: 256 rays (womask shape), the strong-scaling point
             import copy
             from fneus.trainer import WMASK_MODEL

@@ -34,14 +34,15 @@ FN_DEV __amdgpu_buffer_rsrc_t c8_array(const void* p, size_t bytes) {
 
 // this wave's tile half `sh` (8 values per lane) -> B fragment 2 w + sh of a half's LDS region and of a plane block (zeros for
 // samples beyond N; a NULL plane has a zero-sized descriptor: nothing is stored)
-template <int PREC, bool LO>
+// XP: the region's fragments (3: hi + lo, 1: bf16 values); LO: the plane has a lo part (whatever the region holds)
+template <int XP, bool LO>
 FN_DEV void c8_put_half(const float (&y)[8], int sh, int w, int lane, unsigned char* region, bool to_lds, __amdgpu_buffer_rsrc_t p_hi,
                         __amdgpu_buffer_rsrc_t p_lo, uint32_t p_off, const PPLane& pl, bool valid) {
-    constexpr int NPL = PREC == 3 ? 2 : 1;
+    constexpr int NPL = XP == 3 ? 2 : 1;
     bf16x8 hi, lo;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        if constexpr (PREC == 3) {
+        if constexpr (XP == 3 || LO) {
             __bf16 a, b2;
             split_bf16(y[e], a, b2);
             hi[e] = a;
@@ -53,7 +54,7 @@ FN_DEV void c8_put_half(const float (&y)[8], int sh, int w, int lane, unsigned c
     const int ks = 2 * w + sh;
     if (to_lds) {
         *reinterpret_cast<bf16x8*>(region + (ks * NPL) * kFragBytes + lane * 16) = hi;
-        if constexpr (PREC == 3) *reinterpret_cast<bf16x8*>(region + (ks * NPL + 1) * kFragBytes + lane * 16) = lo;
+        if constexpr (XP == 3) *reinterpret_cast<bf16x8*>(region + (ks * NPL + 1) * kFragBytes + lane * 16) = lo;
     }
     const unsigned vo = sh ? pl.odd : pl.even;                  // (ks & 1 == sh)
     p2_store128<true>(__builtin_bit_cast(p2_u32x4, valid ? hi : zero_bf16x8()), p_hi, vo, (int)(p_off + (uint32_t)ks * kFragBytes));
@@ -61,13 +62,15 @@ FN_DEV void c8_put_half(const float (&y)[8], int sh, int w, int lane, unsigned c
 }
 
 // GP 3: hi + lo planes everywhere (exact gradients); GP 1: hi planes (and zout_lo where the stash has one: gradient precision 2)
-template <int PREC, int GP, int NH>
+// XP 1 (with PREC 3, GP 1): the chain's activations are the bf16 values of the zbar planes (r8_dense) -- two MFMAs per product
+template <int PREC, int GP, int NH, int XP>
 __global__ void __launch_bounds__(512, 1) color_bwd_r8_kernel(const unsigned char* blob, long N, const float* __restrict__ d_rgb,
                                                                const float* __restrict__ rgb, ColStash st, float* __restrict__ d_feat,
                                                                float* __restrict__ d_normal) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
-    constexpr int HALF = kR8Half;
+    constexpr int HALF = XP == 3 ? kR8Half : kR8Half / 2;         // bf16 fragments: [k-step] x 1 KiB
     constexpr bool LO = PREC == 3 && GP == 3;
+    static_assert(XP == PREC || (PREC == 3 && XP == 1 && !LO), "XP 1: bf16 activations with bf16 planes only");
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int r = lane & 31, h = lane >> 5;
@@ -104,7 +107,7 @@ __global__ void __launch_bounds__(512, 1) color_bwd_r8_kernel(const unsigned cha
                 float y[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) y[e] = ((mm >> (8 * sh + e)) & 1u) ? acc[8 * sh + e] : 0.0f;
-                c8_put_half<PREC, LO>(y, sh, w, lane, lds_ + hb * HALF, true, rs_z_hi, rs_z_lo, blk_off(l, hb), pl, valid_of(hb));
+                c8_put_half<XP, LO>(y, sh, w, lane, lds_ + hb * HALF, true, rs_z_hi, rs_z_lo, blk_off(l, hb), pl, valid_of(hb));
             }
         };
         mask_load(mk[0], 3, 0);
@@ -127,8 +130,8 @@ __global__ void __launch_bounds__(512, 1) color_bwd_r8_kernel(const unsigned cha
                 }
             }
             const uint32_t zo = tile0 + hb < tiles ? (uint32_t)((size_t)(tile0 + hb) * 2 * kFragBytes) : 0x7ff00000u;
-            c8_put_half<PREC, PREC == 3>(y0, 0, 0, lane, lds_ + hb * HALF, true, rs_o_hi, rs_o_lo, zo, pl, valid);
-            c8_put_half<PREC, PREC == 3>(y1, 1, 0, lane, lds_ + hb * HALF, true, rs_o_hi, rs_o_lo, zo, pl, valid);
+            c8_put_half<XP, PREC == 3>(y0, 0, 0, lane, lds_ + hb * HALF, true, rs_o_hi, rs_o_lo, zo, pl, valid);
+            c8_put_half<XP, PREC == 3>(y1, 1, 0, lane, lds_ + hb * HALF, true, rs_o_hi, rs_o_lo, zo, pl, valid);
         }
         p2_barrier();
         f32x16 acc;
@@ -141,7 +144,7 @@ __global__ void __launch_bounds__(512, 1) color_bwd_r8_kernel(const unsigned cha
             static_for<0, NH>([&](auto HB_) {
                 constexpr int hb = decltype(HB_)::value;
                 r8_zero(acc);
-                r8_dense<PREC, KS, (hb == NH - 1 ? KSN : 0)>(W, lds_ + hb * HALF + lane * 16, acc, rsrc, voff, nx, blob);
+                r8_dense<PREC, KS, (hb == NH - 1 ? KSN : 0), 0, XP>(W, lds_ + hb * HALF + lane * 16, acc, rsrc, voff, nx, blob);
                 p2_barrier();                                       // every wave has read region hb
                 if constexpr (hb == NH - 1) r8_request_rest<PREC, KSN>(W, rsrc, voff, nx, blob);
                 post(acc, mk[hb & 1], L - 1, hb);
@@ -165,7 +168,7 @@ __global__ void __launch_bounds__(512, 1) color_bwd_r8_kernel(const unsigned cha
             static_for<0, NH>([&](auto HB_) {
                 constexpr int hb = decltype(HB_)::value;
                 r8_zero(acc);
-                r8_dense<PREC, 16, (hb == NH - 1 ? 2 : 0)>(W, lds_ + hb * HALF + lane * 16, acc, rsrc, voff, nx, blob);
+                r8_dense<PREC, 16, (hb == NH - 1 ? 2 : 0), 0, XP>(W, lds_ + hb * HALF + lane * 16, acc, rsrc, voff, nx, blob);
                 const long n = (tile0 + hb) * 32 + r;
                 const f32x16 one[1] = {acc};
                 store_f32<1>(one, d_feat + 32 * w, 256, n, h, n < N);
@@ -179,7 +182,7 @@ __global__ void __launch_bounds__(512, 1) color_bwd_r8_kernel(const unsigned cha
             f32x16 s2[2][1];
             zero_acc(s2[0]);
             zero_acc(s2[1]);
-            dense_ldsb_h<PREC, 16, 10, 8, 2, 2, true, 1, HALF>(blob, LY.L[0].rev_hi, LY.L[0].rev_lo, lds_ + hb * HALF, s2, lane);
+            dense_ldsb_h<PREC, 16, 10, 8, 2, 2, true, 1, HALF, XP>(blob, LY.L[0].rev_hi, LY.L[0].rev_lo, lds_ + hb * HALF, s2, lane);
             const f32x16 both[2] = {s2[0][0], s2[1][0]};
             const float g0 = acc_extract2<30>(both, h), g1 = acc_extract2<31>(both, h), g2 = acc_extract2<32>(both, h);
             if (valid && lane < 32) {
@@ -192,16 +195,16 @@ __global__ void __launch_bounds__(512, 1) color_bwd_r8_kernel(const unsigned cha
     }
 }
 
-template <int PREC, int GP, int NH>
+template <int PREC, int GP, int NH, int XP>
 static int launch_col_bwd_r8(const unsigned char* b, long n_pts, const float* d_rgb, const float* rgb, const ColStash& st, float* d_feat,
                              float* d_normal, hipStream_t stream) {
     static bool done = false;
     if (!done) {
-        allow_big_lds(color_bwd_r8_kernel<PREC, GP, NH>);
+        allow_big_lds(color_bwd_r8_kernel<PREC, GP, NH, XP>);
         done = true;
     }
     const long groups = (n_pts + 32 * NH - 1) / (32 * NH);
-    hipLaunchKernelGGL((color_bwd_r8_kernel<PREC, GP, NH>), dim3((unsigned)(groups < 256 ? groups : 256)), dim3(512), NH * kR8Half, stream, b,
+    hipLaunchKernelGGL((color_bwd_r8_kernel<PREC, GP, NH, XP>), dim3((unsigned)(groups < 256 ? groups : 256)), dim3(512), NH * (XP == 3 ? kR8Half : kR8Half / 2), stream, b,
                        n_pts, d_rgb, rgb, st, d_feat, d_normal);
     return launch_status();
 }
@@ -213,12 +216,17 @@ int color_bwd_r8(const unsigned char* b, long n_pts, const float* d_rgb, const f
     const long groups64 = (n_pts + 63) / 64;
     const bool nh4 = (f == 2 || f == 4) ? f == 4 : groups64 >= 2 * 256;
     const bool exact = st.zbar_lo != nullptr;
-#define FNEUS_COL_R8(P, G)                                                                                     \
-    return nh4 ? launch_col_bwd_r8<P, G, 4>(b, n_pts, d_rgb, rgb, st, d_feat, d_normal, stream)               \
-               : launch_col_bwd_r8<P, G, 2>(b, n_pts, d_rgb, rgb, st, d_feat, d_normal, stream)
-    if (prec == 3 && exact) FNEUS_COL_R8(3, 3);
-    if (prec == 3) FNEUS_COL_R8(3, 1);
-    if (prec == 1) FNEUS_COL_R8(1, 1);
+    // bf16 zbar planes (gradient precision 1 / 2): the chain runs on those bf16 values (FNEUS_COLB_XHI=0: hi + lo inside the chain)
+    const char* xe = getenv("FNEUS_COLB_XHI");
+    const bool xhi = xe ? atoi(xe) != 0 : true;
+#define FNEUS_COL_R8(P, G, X)                                                                                  \
+    return nh4 ? launch_col_bwd_r8<P, G, 4, X>(b, n_pts, d_rgb, rgb, st, d_feat, d_normal, stream)            \
+               : launch_col_bwd_r8<P, G, 2, X>(b, n_pts, d_rgb, rgb, st, d_feat, d_normal, stream)
+    if (prec == 3 && exact) FNEUS_COL_R8(3, 3, 3);
+    if (prec == 3 && xhi && (f == 8 || (f != 2 && f != 4 && (n_pts + 127) / 128 > 256))) return launch_col_bwd_r8<3, 1, 8, 1>(b, n_pts, d_rgb, rgb, st, d_feat, d_normal, stream);
+    if (prec == 3 && xhi) FNEUS_COL_R8(3, 1, 1);
+    if (prec == 3) FNEUS_COL_R8(3, 1, 3);
+    if (prec == 1) FNEUS_COL_R8(1, 1, 1);
 #undef FNEUS_COL_R8
     return -2;
 }

@@ -157,11 +157,12 @@ FN_DEV void dense_ldsb(const unsigned char* __restrict__ blob, uint32_t off_hi, 
 // the weight stream, half the barriers and twice the MFMA work per k-step and wave).  The B fragments of half hb live at
 // frag + hb * HALF_BYTES in the same [k-step][plane] order.  Accumulators are [tile][half]: the first row is a valid
 // one-tile view (a wave that owns a single tile of a short layer).
-template <int PREC, int KS, int NT_TOTAL, int T0, int TN, int DEPTH, bool WLO, int HB, int HALF_BYTES>
+// XP: as r8_dense (r8_engine.h) -- 1 with PREC == 3: the regions hold bf16 B fragments (no lo plane), the weights stay hi + lo
+template <int PREC, int KS, int NT_TOTAL, int T0, int TN, int DEPTH, bool WLO, int HB, int HALF_BYTES, int XP = PREC>
 FN_DEV void dense_ldsb_h(const unsigned char* __restrict__ blob, uint32_t off_hi, uint32_t off_lo,
                          const unsigned char* frag /*LDS*/, f32x16 (&acc)[TN][HB], int lane, int t0_rt = 0) {
     static_assert(TN <= 4, "one stage per k-step");
-    constexpr int NPL = PREC == 3 ? 2 : 1;
+    constexpr int NPL = XP == 3 ? 2 : 1;
     constexpr int D = DEPTH > 0 ? DEPTH : (PREC == 3 ? FNEUS_PREFETCH_X3 : FNEUS_PREFETCH_X1);
     const unsigned voff = (unsigned)(lane + t0_rt * 64) * 16u;
     const gblob_t bhi = (gblob_t)blob + off_hi, blo = (gblob_t)blob + off_lo;
@@ -190,7 +191,7 @@ FN_DEV void dense_ldsb_h(const unsigned char* __restrict__ blob, uint32_t off_hi
 #pragma unroll
     for (int hb = 0; hb < HB; ++hb) {
         bh[0][hb] = *reinterpret_cast<const bf16x8*>(fl + hb * HALF_BYTES);
-        if constexpr (PREC == 3) bl[0][hb] = *reinterpret_cast<const bf16x8*>(fl + hb * HALF_BYTES + kFragBytes);
+        if constexpr (XP == 3) bl[0][hb] = *reinterpret_cast<const bf16x8*>(fl + hb * HALF_BYTES + kFragBytes);
     }
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -206,7 +207,7 @@ FN_DEV void dense_ldsb_h(const unsigned char* __restrict__ blob, uint32_t off_hi
 #pragma unroll
             for (int hb = 0; hb < HB; ++hb) {
                 bh[(s + 1) % 3][hb] = *reinterpret_cast<const bf16x8*>(fl + hb * HALF_BYTES + ((s + 1) * NPL) * kFragBytes);
-                if constexpr (PREC == 3)
+                if constexpr (XP == 3)
                     bl[(s + 1) % 3][hb] = *reinterpret_cast<const bf16x8*>(fl + hb * HALF_BYTES + ((s + 1) * NPL + 1) * kFragBytes);
             }
         }
@@ -215,10 +216,8 @@ FN_DEV void dense_ldsb_h(const unsigned char* __restrict__ blob, uint32_t off_hi
         for (int i = 0; i < TN; ++i)
 #pragma unroll
             for (int hb = 0; hb < HB; ++hb) {
-                if constexpr (PREC == 3) {
-                    if constexpr (WLO) acc[i][hb] = mfma32(al[s % (D + 1)][i], bh[s % 3][hb], acc[i][hb]);
-                    acc[i][hb] = mfma32(ah[s % (D + 1)][i], bl[s % 3][hb], acc[i][hb]);
-                }
+                if constexpr (PREC == 3 && WLO) acc[i][hb] = mfma32(al[s % (D + 1)][i], bh[s % 3][hb], acc[i][hb]);
+                if constexpr (XP == 3) acc[i][hb] = mfma32(ah[s % (D + 1)][i], bl[s % 3][hb], acc[i][hb]);
                 acc[i][hb] = mfma32(ah[s % (D + 1)][i], bh[s % 3][hb], acc[i][hb]);
             }
         __builtin_amdgcn_sched_barrier(0);

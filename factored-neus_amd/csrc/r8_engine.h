@@ -70,10 +70,13 @@ FN_DEV void r8_wload_all(R8W& W, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, con
 // matrix pipe idles anyway, and is back before the next dense phase reaches those k-steps.
 template <int KSN> constexpr int r8_inside = KSN < FNEUS_R8_WSPLIT ? KSN : FNEUS_R8_WSPLIT;
 
-template <int PREC, int KS, int KSN, int LMAP = 0>
+// XP (activation products): PREC = the B fragments are hi + lo in parity mode; 1 with PREC == 3 = the B fragments of the half's
+// region are bf16 values ([k-step] x 1 KiB, no lo plane): W.lo . b, W.hi . b -- the cotangent chains of gradient precision 1 / 2,
+// whose activations are the values their planes hold.
+template <int PREC, int KS, int KSN, int LMAP = 0, int XP = PREC>
 FN_DEV void r8_dense(R8W& W, const unsigned char* fl, f32x16& acc, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, const R8Layer& nx,
                      const unsigned char* blob) {
-    constexpr int NPL = PREC == 3 ? 2 : 1;
+    constexpr int NPL = XP == 3 ? 2 : 1;
     // B ring.  A k-step is only 3 MFMAs here (96 cycles of this wave's matrix time), less than an LDS round trip with eight waves
     // reading: requested one k-step ahead (as the 12-MFMA k-steps of the other engines do) every k-step waited for its fragments
     // -- 286 cycles per k-step of a SIMD's two waves instead of 192 (FNEUS_R8_STAMPS).  Distance D, ring of D + 2 buffers:
@@ -85,13 +88,13 @@ FN_DEV void r8_dense(R8W& W, const unsigned char* fl, f32x16& acc, __amdgpu_buff
     static_for<0, D>([&](auto S_) {
         constexpr int s = decltype(S_)::value;
         bh[s % NB] = *reinterpret_cast<const bf16x8*>(fl + (p2_slot<LMAP>(s) * NPL) * kFragBytes);
-        if constexpr (PREC == 3) bl[s % NB] = *reinterpret_cast<const bf16x8*>(fl + (p2_slot<LMAP>(s) * NPL + 1) * kFragBytes);
+        if constexpr (XP == 3) bl[s % NB] = *reinterpret_cast<const bf16x8*>(fl + (p2_slot<LMAP>(s) * NPL + 1) * kFragBytes);
     });
     static_for<0, KS>([&](auto S_) {
         constexpr int s = decltype(S_)::value;
         if constexpr (s + D < KS) {
             bh[(s + D) % NB] = *reinterpret_cast<const bf16x8*>(fl + (p2_slot<LMAP>(s + D) * NPL) * kFragBytes);
-            if constexpr (PREC == 3) bl[(s + D) % NB] = *reinterpret_cast<const bf16x8*>(fl + (p2_slot<LMAP>(s + D) * NPL + 1) * kFragBytes);
+            if constexpr (XP == 3) bl[(s + D) % NB] = *reinterpret_cast<const bf16x8*>(fl + (p2_slot<LMAP>(s + D) * NPL + 1) * kFragBytes);
         }
         // The request for stage s' of the next layer goes out LAG k-steps after the MFMAs that read W[s'] were issued: a load
         // whose destination a queued MFMA still has to read stalls at issue until that MFMA has started (write-after-read), and
@@ -104,10 +107,8 @@ FN_DEV void r8_dense(R8W& W, const unsigned char* fl, f32x16& acc, __amdgpu_buff
             if constexpr (PREC == 3) W.lo[q] = p2_wload(rsrc, voff, nx.off_lo + f, blob);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (PREC == 3) {
-            acc = mfma32(W.lo[s], bh[s % NB], acc);
-            acc = mfma32(W.hi[s], bl[s % NB], acc);
-        }
+        if constexpr (PREC == 3) acc = mfma32(W.lo[s], bh[s % NB], acc);
+        if constexpr (XP == 3) acc = mfma32(W.hi[s], bl[s % NB], acc);
         acc = mfma32(W.hi[s], bh[s % NB], acc);
         __builtin_amdgcn_sched_barrier(0);
     });

@@ -304,13 +304,14 @@ struct R8Ops {                  // operands of one post phase: fragments 2 w, 2 
     bf16x8 hi[2], lo[2];
 };
 
-template <int PREC, int GP, int NH>
+template <int PREC, int GP, int NH, int XP>
 __global__ void __launch_bounds__(512, 1) sdf_bwd_r8_kernel(const unsigned char* blob, PointSrc src, long N, SdfStash st, SdfBwdBufs bb,
                                                              const float* __restrict__ d_sdf, const float* __restrict__ d_feat,
                                                              const float* __restrict__ d_normal) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
-    constexpr int HALF = kR8Half;
+    constexpr int HALF = XP == 3 ? kR8Half : kR8Half / 2;         // bf16 fragments: [k-step] x 1 KiB
     constexpr bool LO = PREC == 3 && GP == 3;          // lo planes exist (exact-gradient mode)
+    static_assert(XP == PREC || (PREC == 3 && XP == 1 && !LO), "XP 1: the chains' activations are the bf16 values of their planes");
     constexpr bool KEEP = NH == 2;                     // c_7 stays in the operand registers across the turn
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -397,7 +398,7 @@ __global__ void __launch_bounds__(512, 1) sdf_bwd_r8_kernel(const unsigned char*
                     const float abar = acc[8 * sh + e];
                     const float c = kBeta * (1.0f - sv) * av * abar;          // softplus'' * g_hat * abar  (a = s * g_hat)
                     y[e] = sv * abar;
-                    if constexpr (PREC == 3) {
+                    if constexpr (XP == 3) {
                         __bf16 x, yy;
                         split_bf16(c, x, yy);
                         chi[e] = x;
@@ -414,7 +415,7 @@ __global__ void __launch_bounds__(512, 1) sdf_bwd_r8_kernel(const unsigned char*
                     p2_store128<true>(__builtin_bit_cast(p2_u32x4, chi), rs_c_hi, lane16, (int)so);
                     if constexpr (LO) p2_store128<true>(__builtin_bit_cast(p2_u32x4, clo), rs_c_lo, lane16, (int)so);
                 }
-                r8_put_half<PREC, LO>(y, sh, w, lane, lds_ + hb * HALF, to_lds, rs_adj_hi, rs_adj_lo, blk_off(l, hb), pl, valid_of(hb));
+                r8_put_half<XP, LO>(y, sh, w, lane, lds_ + hb * HALF, to_lds, rs_adj_hi, rs_adj_lo, blk_off(l, hb), pl, valid_of(hb));
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -430,7 +431,7 @@ __global__ void __launch_bounds__(512, 1) sdf_bwd_r8_kernel(const unsigned char*
                     if constexpr (LO) c += (float)o.lo[sh][e];
                     y[e] = sv * acc[8 * sh + e] + c;
                 }
-                r8_put_half<PREC, LO>(y, sh, w, lane, lds_ + hb * HALF, to_lds, rs_zbar_hi, rs_zbar_lo, blk_off(l, hb), pl, valid_of(hb));
+                r8_put_half<XP, LO>(y, sh, w, lane, lds_ + hb * HALF, to_lds, rs_zbar_hi, rs_zbar_lo, blk_off(l, hb), pl, valid_of(hb));
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -453,12 +454,12 @@ __global__ void __launch_bounds__(512, 1) sdf_bwd_r8_kernel(const unsigned char*
             posenc<6, true>(x, pe, jc);
 #pragma unroll
             for (int f = 0; f < 39; ++f) qb[f] = jc[f] * nb[f % 3];
-            BFrag<PREC> qf[kMaxKS];
-            vec_to_bfrag<PREC, 39, 3, 0>(qb, qf, h);
-            frags_to_lds<PREC, 3>(lds_ + hb * HALF, lane, 0, qf);
-            frags_to_lds<PREC, 3>(lds_ + hb * HALF, lane, 16, qf);
+            BFrag<XP> qf[kMaxKS];
+            vec_to_bfrag<XP, 39, 3, 0>(qb, qf, h);
+            frags_to_lds<XP, 3>(lds_ + hb * HALF, lane, 0, qf);
+            frags_to_lds<XP, 3>(lds_ + hb * HALF, lane, 16, qf);
             if (tile0 + hb < tiles)
-                frags_to_plane<PREC, 3>(qf, 0, bb.qbar_hi + (size_t)(tile0 + hb) * 4 * kFragBytes,
+                frags_to_plane<XP, 3>(qf, 0, bb.qbar_hi + (size_t)(tile0 + hb) * 4 * kFragBytes,
                                         LO ? bb.qbar_lo + (size_t)(tile0 + hb) * 4 * kFragBytes : nullptr, pl, valid);
         }
         p2_barrier();
@@ -474,7 +475,7 @@ __global__ void __launch_bounds__(512, 1) sdf_bwd_r8_kernel(const unsigned char*
                 constexpr int hb = decltype(HB_)::value;
                 R8_STAMP(0);
                 r8_zero(acc);
-                r8_dense<PREC, KS, (hb == NH - 1 ? KSN : 0), LMAP>(W, lds_ + hb * HALF + lane * 16, acc, rsrc, vo_next, nx, blob);
+                r8_dense<PREC, KS, (hb == NH - 1 ? KSN : 0), LMAP, XP>(W, lds_ + hb * HALF + lane * 16, acc, rsrc, vo_next, nx, blob);
                 R8_STAMP(1);
                 p2_barrier();                                       // every wave has read region hb
                 R8_STAMP(2);
@@ -513,21 +514,21 @@ __global__ void __launch_bounds__(512, 1) sdf_bwd_r8_kernel(const unsigned char*
                 float y[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) y[e] = t2[0][8 * sh + e];
-                r8_put_half<PREC, LO>(y, sh, w, lane, lds_ + hb * HALF, true, rs_zbar_hi, rs_zbar_lo, blk_off(8, hb), pl, valid);
+                r8_put_half<XP, LO>(y, sh, w, lane, lds_ + hb * HALF, true, rs_zbar_hi, rs_zbar_lo, blk_off(8, hb), pl, valid);
             }
         });
         if (w < NH) {
             const int hb = w;
             const long n = (tile0 + hb) * 32 + r;
             const bool valid = n < N;
-            BFrag<PREC> sf[kMaxKS];
+            BFrag<XP> sf[kMaxKS];
             const float sv = (h == 0 && valid) ? d_sdf[n] : 0.0f;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 sf[i].hi = zero_bf16x8();
-                if constexpr (PREC == 3) sf[i].lo = zero_bf16x8();
+                if constexpr (XP == 3) sf[i].lo = zero_bf16x8();
             }
-            if constexpr (PREC == 3) {
+            if constexpr (XP == 3) {
                 __bf16 shi, slo;
                 split_bf16(sv, shi, slo);
                 sf[0].hi[0] = shi;
@@ -535,9 +536,9 @@ __global__ void __launch_bounds__(512, 1) sdf_bwd_r8_kernel(const unsigned char*
             } else {
                 sf[0].hi[0] = (__bf16)sv;
             }
-            frags_to_lds<PREC, 2>(lds_ + hb * HALF, lane, 16, sf);
+            frags_to_lds<XP, 2>(lds_ + hb * HALF, lane, 16, sf);
             if (tile0 + hb < tiles)
-                frags_to_plane<PREC, 2>(sf, 0, bb.zsdf_hi + (size_t)(tile0 + hb) * 2 * kFragBytes,
+                frags_to_plane<XP, 2>(sf, 0, bb.zsdf_hi + (size_t)(tile0 + hb) * 2 * kFragBytes,
                                         LO ? bb.zsdf_lo + (size_t)(tile0 + hb) * 2 * kFragBytes : nullptr, pl, valid);
         }
         p2_barrier();
@@ -551,13 +552,26 @@ __global__ void __launch_bounds__(512, 1) sdf_bwd_r8_kernel(const unsigned char*
                 constexpr int hb = decltype(HB_)::value;
                 R8_STAMP(0);
                 r8_zero(acc);
-                if constexpr (L == 8) {     // the sdf tile of zbar_8: k-steps 16, 17 of R8, streamed
+                if constexpr (L == 8 && XP == PREC) {     // the sdf tile of zbar_8: k-steps 16, 17 of R8, streamed
                     f32x16(&a1)[1][1] = reinterpret_cast<f32x16(&)[1][1]>(acc);
                     dense_ldsb_h<PREC, 2, 8, 0, 1, 2, true, 1, HALF>(blob, kSdfLayout.L[8].rev_hi + 16 * 8 * kFragBytes,
                                                                      kSdfLayout.L[8].rev_lo + 16 * 8 * kFragBytes,
                                                                      lds_ + hb * HALF + 16 * (PREC == 3 ? 2 : 1) * kFragBytes, a1, lane, w);
                 }
-                r8_dense<PREC, KS, (hb == NH - 1 ? KSN : 0)>(W, lds_ + hb * HALF + lane * 16, acc, rsrc, voff, nx, blob);
+                if constexpr (L == 8 && XP != PREC) {     // the same two k-steps on bf16 B fragments (slots 16, 17: hi only), W hi + lo
+                    const unsigned char* fl16 = lds_ + hb * HALF + lane * 16 + 16 * kFragBytes;
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const uint32_t f = (uint32_t)((16 + s) * 8 * 64) * 16u;
+                        const bf16x8 whi = p2_wload(rsrc, voff, kSdfLayout.L[8].rev_hi + f, blob);
+                        const bf16x8 wlo = p2_wload(rsrc, voff, kSdfLayout.L[8].rev_lo + f, blob);
+                        const bf16x8 b = *reinterpret_cast<const bf16x8*>(fl16 + s * kFragBytes);
+                        acc = mfma32(wlo, b, acc);
+                        acc = mfma32(whi, b, acc);
+                    }
+                    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");      // (r8_dense: B registers may be reloaded at once)
+                }
+                r8_dense<PREC, KS, (hb == NH - 1 ? KSN : 0), 0, XP>(W, lds_ + hb * HALF + lane * 16, acc, rsrc, voff, nx, blob);
                 R8_STAMP(5);
                 p2_barrier();
                 R8_STAMP(6);
@@ -589,16 +603,16 @@ __global__ void __launch_bounds__(512, 1) sdf_bwd_r8_kernel(const unsigned char*
 #endif
 }
 
-template <int PREC, int GP, int NH>
+template <int PREC, int GP, int NH, int XP>
 static int launch_bwd_r8(const unsigned char* b, const PointSrc& src, long n_pts, const SdfStash& st, const SdfBwdBufs& bb, const float* d_sdf,
                          const float* d_feat, const float* d_normal, hipStream_t stream) {
     static bool done = false;
     if (!done) {
-        allow_big_lds(sdf_bwd_r8_kernel<PREC, GP, NH>);
+        allow_big_lds(sdf_bwd_r8_kernel<PREC, GP, NH, XP>);
         done = true;
     }
     const long groups = (n_pts + 32 * NH - 1) / (32 * NH);
-    hipLaunchKernelGGL((sdf_bwd_r8_kernel<PREC, GP, NH>), dim3((unsigned)(groups < 256 ? groups : 256)), dim3(512), NH * kR8Half, stream, b, src,
+    hipLaunchKernelGGL((sdf_bwd_r8_kernel<PREC, GP, NH, XP>), dim3((unsigned)(groups < 256 ? groups : 256)), dim3(512), NH * (XP == 3 ? kR8Half : kR8Half / 2), stream, b, src,
                        n_pts, st, bb, d_sdf, d_feat, d_normal);
     return launch_status();
 }
@@ -606,12 +620,23 @@ static int launch_bwd_r8(const unsigned char* b, const PointSrc& src, long n_pts
 int sdf_bwd_r8(const unsigned char* b, const PointSrc& src, long n_pts, const SdfStash& st, const SdfBwdBufs& bb, const float* d_sdf,
                const float* d_feat, const float* d_normal, int prec, int gp, hipStream_t stream) {
     const bool nh4 = r8_halves((n_pts + 63) / 64) == 4;
-#define FNEUS_BWD_R8(P, G)                                                                                            \
-    return nh4 ? launch_bwd_r8<P, G, 4>(b, src, n_pts, st, bb, d_sdf, d_feat, d_normal, stream)                      \
-               : launch_bwd_r8<P, G, 2>(b, src, n_pts, st, bb, d_sdf, d_feat, d_normal, stream)
-    if (prec == 3 && gp == 3) FNEUS_BWD_R8(3, 3);
-    if (prec == 3) FNEUS_BWD_R8(3, 1);
-    if (prec == 1) FNEUS_BWD_R8(1, 1);
+    // 256 samples per workgroup (NH = 8) where the bf16 regions (19 KiB per half) allow it and 128-sample groups would need a second
+    // round on some CUs anyway: 65 536 points = one group per CU, every wave busy in the group's prologue (FNEUS_R8_NH=2 | 4 | 8 forces)
+    const char* nhe = getenv("FNEUS_R8_NH");
+    const int nhf = nhe ? atoi(nhe) : 0;
+    const bool nh8 = nhf == 8 || (nhf != 2 && nhf != 4 && (n_pts + 127) / 128 > 256);
+    // bf16 gradient planes (gradient precision 1 / 2): the chains' activations are the bf16 values of those planes -- two MFMAs per
+    // product (W hi + lo), hi-only B fragments in LDS.  FNEUS_BWD_XHI=0: hi + lo activations inside the chains as before round 6.
+    const char* xe = getenv("FNEUS_BWD_XHI");
+    const bool xhi = xe ? atoi(xe) != 0 : true;
+#define FNEUS_BWD_R8(P, G, X)                                                                                         \
+    return nh4 ? launch_bwd_r8<P, G, 4, X>(b, src, n_pts, st, bb, d_sdf, d_feat, d_normal, stream)                   \
+               : launch_bwd_r8<P, G, 2, X>(b, src, n_pts, st, bb, d_sdf, d_feat, d_normal, stream)
+    if (prec == 3 && gp == 3) FNEUS_BWD_R8(3, 3, 3);
+    if (prec == 3 && xhi && nh8) return launch_bwd_r8<3, 1, 8, 1>(b, src, n_pts, st, bb, d_sdf, d_feat, d_normal, stream);
+    if (prec == 3 && xhi) FNEUS_BWD_R8(3, 1, 1);
+    if (prec == 3) FNEUS_BWD_R8(3, 1, 3);
+    if (prec == 1) FNEUS_BWD_R8(1, 1, 1);
 #undef FNEUS_BWD_R8
     return -2;
 }

@@ -399,9 +399,11 @@ def test_k3_r8_equals_the_4_wave_kernel(monkeypatch, gprec, prec, n, nh):
     read at every call): same stash, same operands, same summation order per accumulator (the sdf tile's two k-steps of the seed
     are added in front of the other sixteen instead of behind them) -- every plane the weight-gradient GEMM reads (qbar, adj_1..8,
     zbar_0..8, zsdf) agrees to a step of its format, and the kernel is bit-reproducible.  64- and 128-sample workgroups
-    (FNEUS_R8_NH); ragged sizes as in the reverse sweep's test."""
+    (FNEUS_R8_NH); ragged sizes as in the reverse sweep's test.  (FNEUS_BWD_XHI=0: the chains on hi + lo activations, the arithmetic
+    of the 4-wave kernel; the bf16-activation chains of gradient precision 1 / 2 have their own test below.)"""
     from fneus import ops, synth, pp
     monkeypatch.setenv("FNEUS_R8_NH", str(nh))
+    monkeypatch.setenv("FNEUS_BWD_XHI", "0")
     net = ops.PackedNet("sdf", DEV).load_state_dict({k: T(v) for k, v in synth.sdf_state_dict(22).items()})
     net.pack()
     g = torch.Generator(device=DEV).manual_seed(7)
@@ -443,9 +445,11 @@ def test_colour_backward_r8_equals_the_4_wave_kernel(monkeypatch, gprec, prec, n
     """the colour network's backward on resident-weight 8-wave workgroups (csrc/color_r8_kernels.hip, round 6; FNEUS_COL_BWD_R8=0 keeps
     the 4-wave kernel of color_kernels.hip, read at every call): same masks, same operands, same summation order per accumulator --
     d_feat and d_normal agree to the rounding of a lo fragment's last bit, every plane the weight-gradient GEMM reads (zbar_0..3,
-    zout) to a step of its format, and the kernel is bit-reproducible.  64- and 128-sample workgroups (FNEUS_R8_NH); ragged sizes."""
+    zout) to a step of its format, and the kernel is bit-reproducible.  64- and 128-sample workgroups (FNEUS_R8_NH); ragged sizes.
+    (FNEUS_COLB_XHI=0: hi + lo activations inside the chain, the 4-wave kernel's arithmetic.)"""
     from fneus import ops, synth, pp
     monkeypatch.setenv("FNEUS_R8_NH", str(nh))
+    monkeypatch.setenv("FNEUS_COLB_XHI", "0")
     net = ops.PackedNet("color", DEV).load_state_dict({k: T(v) for k, v in synth.color_state_dict(23).items()})
     net.pack()
     g = torch.Generator(device=DEV).manual_seed(9)
@@ -485,6 +489,93 @@ def test_colour_backward_r8_equals_the_4_wave_kernel(monkeypatch, gprec, prec, n
         assert (v1 - v0).abs().max().item() <= tol * max(v0.abs().max().item(), 1e-9), l
     if b[2].shape[2] > st.tiles:                                        # an allocated tile without samples stays zero
         assert float(b[2][:, :, st.tiles:].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("gprec,n", [(1, 40003), (2, 65536), (1, 70001), (1, 40067)])
+def test_cotangent_chains_on_bf16_activations(monkeypatch, gprec, n):
+    """Round 6: with bf16 gradient planes (gradient precision 1 / 2) the two chains of K3 and the colour network's
+    backward run on the bf16 VALUES OF THOSE PLANES -- W hi + lo against one bf16 activation fragment, two MFMAs per product, no lo
+    fragments in LDS (FNEUS_BWD_XHI / FNEUS_COLB_XHI, default 1; resident-weight kernels = launches of >= 1024 sample tiles).
+    Per sample that is one more rounding of 2^-9 per layer, random in sign: every plane stays within 2e-2 of its scale of the
+    hi + lo chain's, 128- and 256-sample workgroups are BIT-identical (the same operands per sample in the same order; 64-sample
+    ones to a step of the planes' format), the kernels are bit-reproducible, allocated tiles without samples stay zero.  What the weight gradients lose is bounded against the
+    reference's gradients in tests/test_hip_render.py (512-ray fixture) and against fp64 in tests/test_hip_backward.py."""
+    from fneus import ops, synth, pp
+    net = ops.PackedNet("sdf", DEV).load_state_dict({k: T(v) for k, v in synth.sdf_state_dict(22).items()})
+    net.pack()
+    g = torch.Generator(device=DEV).manual_seed(7)
+    x = (torch.rand(n, 3, device=DEV, generator=g) * 2 - 1).contiguous()
+    ds = torch.randn(n, device=DEV, generator=g)
+    df = torch.randn(n, 256, device=DEV, generator=g) * 0.1
+    dn = torch.randn(n, 3, device=DEV, generator=g)
+    st = ops.SdfStash(n, DEV, 3, True, gprec)
+    ops.sdf_fwd_grad(net.blob, n, 3, st, True, pts=x)
+
+    def k3(xhi, nh):
+        monkeypatch.setenv("FNEUS_BWD_XHI", str(xhi))
+        monkeypatch.setenv("FNEUS_R8_NH", str(nh))
+        b = ops.SdfBwdBufs(n, DEV, 3, gprec)
+        ops.sdf_bwd(net.blob, n, 3, st, b, ds, df, dn, pts=x)
+        torch.cuda.synchronize()
+        return b
+
+    ref, b8, b8b, b4, b2 = k3(0, 4), k3(1, 8), k3(1, 8), k3(1, 4), k3(1, 2)
+    for name, slots in (("qbar", 0), ("zsdf", 0), ("adj", 8), ("zbar", 9)):
+        t = [getattr(b, name) for b in (b8, b8b, b4, b2)]
+        assert torch.equal(t[0], t[1]) and torch.equal(t[0], t[2]), name
+        assert torch.isfinite(t[0].float()).all(), name
+        # (64-sample workgroups keep c_7 in registers across the turn and hipcc contracts s * ubar + c differently there: a value
+        # at a rounding boundary lands on the other bf16 neighbour)
+        for l in range(max(slots, 1)):
+            u0 = pp.value(t[0][:, l] if slots else t[0], n)
+            u3 = pp.value(t[3][:, l] if slots else t[3], n)
+            assert (u3 - u0).abs().max().item() <= 8e-3 * max(u0.abs().max().item(), 1e-9), (name, l)
+        r = getattr(ref, name)
+        if slots == 0:
+            assert torch.equal(t[0], r), name                       # formed from the cotangents alone
+            continue
+        for l in range(slots):
+            v0, v1 = pp.value(r[:, l], n), pp.value(t[0][:, l], n)
+            assert (v1 - v0).abs().max().item() <= 2e-2 * max(v0.abs().max().item(), 1e-9), (name, l)
+            assert (v1 - v0).norm().item() <= 8e-3 * max(v0.norm().item(), 1e-9), (name, l)      # observed 2.7e-3 ... 5.0e-3
+        if t[0].shape[2] > b8.tiles:
+            assert float(t[0][:, :, b8.tiles:].float().abs().max()) == 0.0
+
+    cnet = ops.PackedNet("color", DEV).load_state_dict({k: T(v) for k, v in synth.color_state_dict(23).items()})
+    cnet.pack()
+    d = torch.randn(n, 3, device=DEV, generator=g)
+    d = (d / d.norm(dim=-1, keepdim=True)).contiguous()
+    nrm = torch.randn(n, 3, device=DEV, generator=g)
+    feat = (torch.randn(n, 256, device=DEV, generator=g) * 0.3).contiguous()
+    c_rgb = torch.randn(n, 3, device=DEV, generator=g)
+    cs = ops.ColStash(n, DEV, 3, gprec=gprec)
+    rgb = ops.color_fwd(cnet.blob, n, 3, nrm, feat, cs, True, pts=x, dirs=d)
+
+    def cb(xhi, nh):
+        monkeypatch.setenv("FNEUS_COLB_XHI", str(xhi))
+        monkeypatch.setenv("FNEUS_R8_NH", str(nh))
+        cs.zbar.zero_()
+        cs.zout.zero_()
+        if cs.zout_lo is not None:
+            cs.zout_lo.zero_()
+        dfe, dno = ops.color_bwd(cnet.blob, n, 3, c_rgb, rgb, cs)
+        torch.cuda.synchronize()
+        return dfe.clone(), dno.clone(), cs.zbar.clone(), cs.zout.clone(), None if cs.zout_lo is None else cs.zout_lo.clone()
+
+    ref, c8, c8b, c4, c2 = cb(0, 4), cb(1, 8), cb(1, 8), cb(1, 4), cb(1, 2)
+    for other in (c8b, c4, c2):
+        for u, v in zip(c8, other):
+            assert (u is None and v is None) or torch.equal(u, v)
+    assert torch.isfinite(c8[0]).all() and torch.isfinite(c8[1]).all()
+    assert torch.equal(c8[3], ref[3]) and (ref[4] is None or torch.equal(c8[4], ref[4]))          # zout hi (+ lo): from d_rgb and rgb alone
+    for i in (0, 1):                                                                                # d_feat, d_normal
+        assert (c8[i] - ref[i]).abs().max().item() <= 2e-2 * ref[i].abs().max().item()
+        assert (c8[i] - ref[i]).norm().item() <= 8e-3 * ref[i].norm().item()                     # observed 3.8e-3, 3.9e-3
+    for l in range(4):
+        v0, v1 = pp.value(ref[2][:, l], n), pp.value(c8[2][:, l], n)
+        assert (v1 - v0).abs().max().item() <= 2e-2 * max(v0.abs().max().item(), 1e-9), l
+    if c8[2].shape[2] > cs.tiles:
+        assert float(c8[2][:, :, cs.tiles:].float().abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("n", [40003, 65536, 100])
