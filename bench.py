@@ -52,10 +52,11 @@ PEAK_HBM_GBS = 8000.0                # HBM3E (MI355X_MICROARCH.md)
 #   K2 writes  h 8 x 512, a 8 x 512, sigma' 8 x 512, feature planes hi + lo 2 x 512 (round 6: no fp32 feature rows), PE plane 128, sdf + normal 16;
 #      reads   sigma' back once for its reverse sweep 8 x 512, 12 B of ray data
 #   K3 reads   sigma' twice (ascending + descending chain) 2 x 8 x 512, a 8 x 512, the coupling planes it wrote 8 x 512,
-#              d_feat fp32 1024, cotangents 16;  writes the coupling planes 8 x 512, adj 8 x 512, zbar 9 x 512, qbar 128
+#              d_feat as the bf16 fragments the colour backward wrote 512 (round 6; fp32 rows before: 1024), cotangents 16;
+#      writes  the coupling planes 8 x 512, adj 8 x 512, zbar 8 x 512 (slot 8 IS d_feat), qbar 128
 KERNEL_BYTES_PARITY = {
     "fneus_sdf_fwd_grad": (3 * 8 * 512 + 2 * 512 + 128 + 16 + 8 * 512 + 12) * SAMPLES_PER_STEP,
-    "fneus_sdf_bwd": (2 * 8 * 512 + 8 * 512 + 8 * 512 + 1024 + 16 + 8 * 512 + 8 * 512 + 9 * 512 + 128) * SAMPLES_PER_STEP,
+    "fneus_sdf_bwd": (2 * 8 * 512 + 8 * 512 + 8 * 512 + 512 + 16 + 8 * 512 + 8 * 512 + 8 * 512 + 128) * SAMPLES_PER_STEP,
     # four bf16 planes per layer (h, a, zbar, adj) + PE plane, read once
     "fneus_dw_gemm_pp:sdf": (4 * 8 * 512 + 512 + 128) * SAMPLES_PER_STEP,
 }
@@ -63,11 +64,11 @@ KERNEL_BYTES_PARITY = {
 
 # The colour network's design bytes per sample (gradient precision 2, the default): forward writes u 4 x 512 + the lo plane of u_3 512 +
 # the side plane 128 + the masks 64 and reads the feature planes hi + lo 1024 + the normal rows 12; backward reads masks + d_rgb and writes
-# zbar 4 x 512 + zout + d_feat fp32 1024 + d_normal 12;
+# zbar 4 x 512 + zout + d_feat as bf16 fragments 512 + d_normal 12;
 # its GEMM reads u, zbar (8 x 512), the feature and side planes (512 + 128).
 KERNEL_BYTES_PARITY_EXTRA = {
     "fneus_color_fwd": (4 * 512 + 512 + 128 + 64 + 1024 + 12 + 12) * SAMPLES_PER_STEP,
-    "fneus_color_bwd": (64 + 12 + 4 * 512 + 64 + 1024 + 12) * SAMPLES_PER_STEP,
+    "fneus_color_bwd": (64 + 12 + 4 * 512 + 64 + 512 + 12) * SAMPLES_PER_STEP,
     "fneus_dw_gemm_pp:color": (8 * 512 + 512 + 128 + 64) * SAMPLES_PER_STEP,
     "fneus_sdf_fwd": 0.875 * 16 * SAMPLES_PER_STEP,
     # gradient precision 2 (the default): the output layer's product reads the hi + lo planes of u_3 and d_rgb, rgb

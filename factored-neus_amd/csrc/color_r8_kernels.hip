@@ -85,6 +85,8 @@ __global__ void __launch_bounds__(512, 1) color_bwd_r8_kernel(const unsigned cha
     const __amdgpu_buffer_rsrc_t rs_o_hi = c8_array(st.zout_hi, (size_t)tiles * 2 * kFragBytes);
     const __amdgpu_buffer_rsrc_t rs_o_lo = c8_array(PREC == 3 ? st.zout_lo : nullptr, (size_t)tiles * 2 * kFragBytes);
     const __amdgpu_buffer_rsrc_t rs_mask = c8_array(st.mask, (size_t)tiles * 4 * 1024);
+    const __amdgpu_buffer_rsrc_t rs_df = c8_array(XP == 1 ? st.dfeat_hi : nullptr, (size_t)tiles * kPPBlock);      // d_feat as bf16 fragments
+    const bool df_plane = XP == 1 && st.dfeat_hi != nullptr;
     const unsigned voff_mask = (unsigned)lane * 16u + (unsigned)(w >> 1) * 4u;
     const int mshift = (w & 1) * 16;
     auto rev_of = [&](int l) { return R8Layer{LY.L[l].rev_hi, LY.L[l].rev_lo, l == 0 ? 10 : 8}; };
@@ -170,8 +172,19 @@ __global__ void __launch_bounds__(512, 1) color_bwd_r8_kernel(const unsigned cha
                 r8_zero(acc);
                 r8_dense<PREC, 16, (hb == NH - 1 ? 2 : 0), 0, XP>(W, lds_ + hb * HALF + lane * 16, acc, rsrc, voff, nx, blob);
                 const long n = (tile0 + hb) * 32 + r;
-                const f32x16 one[1] = {acc};
-                store_f32<1>(one, d_feat + 32 * w, 256, n, h, n < N);
+                if (df_plane) {         // this wave's tile as fragments 2 w, 2 w + 1 of the tile's block: what K3 reads as the seed zbar_8
+                    const uint32_t bo = tile0 + hb < tiles ? (uint32_t)((size_t)(tile0 + hb) * kPPBlock) : 0x7ff00000u;
+#pragma unroll
+                    for (int sh = 0; sh < 2; ++sh) {
+                        bf16x8 v;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = (__bf16)(n < N ? acc[8 * sh + e] : 0.0f);
+                        p2_store128<true>(__builtin_bit_cast(p2_u32x4, v), rs_df, sh ? pl.odd : pl.even, (int)(bo + (uint32_t)(2 * w + sh) * kFragBytes));
+                    }
+                } else {
+                    const f32x16 one[1] = {acc};
+                    store_f32<1>(one, d_feat + 32 * w, 256, n, h, n < N);
+                }
             });
         }
         // ---- the 2 side tiles of half hb (streamed, wave hb) -> d normal
@@ -219,6 +232,7 @@ int color_bwd_r8(const unsigned char* b, long n_pts, const float* d_rgb, const f
     // bf16 zbar planes (gradient precision 1 / 2): the chain runs on those bf16 values (FNEUS_COLB_XHI=0: hi + lo inside the chain)
     const char* xe = getenv("FNEUS_COLB_XHI");
     const bool xhi = xe ? atoi(xe) != 0 : true;
+    if (d_feat == nullptr && !(prec == 3 && !exact && xhi && st.dfeat_hi != nullptr)) return -2;       // no rows: the bf16-cotangent form only
 #define FNEUS_COL_R8(P, G, X)                                                                                  \
     return nh4 ? launch_col_bwd_r8<P, G, 4, X>(b, n_pts, d_rgb, rgb, st, d_feat, d_normal, stream)            \
                : launch_col_bwd_r8<P, G, 2, X>(b, n_pts, d_rgb, rgb, st, d_feat, d_normal, stream)

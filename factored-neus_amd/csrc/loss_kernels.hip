@@ -339,9 +339,51 @@ __global__ void __launch_bounds__(64) surface_scatter_kernel(const int32_t* __re
     }
 }
 
+// the same on the feature cotangent's bf16 fragments (fneus_pp.h): lane l holds features 4 l .. 4 l + 3 of the row = 8 contiguous
+// bytes of fragment ks = l >> 2 (h = l & 1, j0 = 4 ((l >> 1) & 1)) in slot (2 r + h) ^ 8 (ks & 1) of the row's tile
+__global__ void __launch_bounds__(64) surface_scatter_plane_kernel(const int32_t* __restrict__ sel, const float* __restrict__ dfh,
+                                                                   const float* __restrict__ dnh, int n_heads, long n_rows,
+                                                                   unsigned char* __restrict__ plane, float* __restrict__ d_normal) {
+    const long i = blockIdx.x;
+    const int lane = threadIdx.x;
+    const long dst = sel[i];
+    if (dfh != nullptr) {
+        const int ks = lane >> 2, hh = lane & 1, j0 = 4 * ((lane >> 1) & 1), r = (int)(dst & 31);
+        const unsigned slot = (unsigned)((2 * r + hh) ^ (8 * (ks & 1)));
+        __bf16* p = reinterpret_cast<__bf16*>(plane + (size_t)(dst >> 5) * kPPBlock + (size_t)ks * kFragBytes + slot * 16u) + j0;
+        float s[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] = (float)p[e];
+        for (int hd = 0; hd < n_heads; ++hd) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(dfh + ((long)hd * n_rows + i) * 256 + lane * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] += v[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) p[e] = (__bf16)s[e];
+    }
+    if (dnh != nullptr && lane < 3) {
+        float s = d_normal[dst * 3 + lane];
+        for (int hd = 0; hd < n_heads; ++hd) s += dnh[((long)hd * n_rows + i) * 3 + lane];
+        d_normal[dst * 3 + lane] = s;
+    }
+}
+
 }  // namespace fneus
 
 using namespace fneus;
+
+extern "C" int fneus_surface_scatter_plane(const int32_t* sel, const float* d_feat_heads, const float* d_normal_heads, int n_heads,
+                                           long n_rows, void* dfeat_hi, long n_pts, float* d_normal, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (n_rows <= 0 || n_heads <= 0) return 0;
+    if (sel == nullptr || n_pts <= 0 || (d_feat_heads != nullptr && dfeat_hi == nullptr) || (d_normal_heads != nullptr && d_normal == nullptr))
+        return -2;
+    hipLaunchKernelGGL(surface_scatter_plane_kernel, dim3((unsigned)n_rows), dim3(64), 0, stream, sel, d_feat_heads, d_normal_heads, n_heads,
+                       n_rows, reinterpret_cast<unsigned char*>(dfeat_hi), d_normal);
+    return fneus::launch_status();
+}
 
 extern "C" int fneus_surface_scatter(const int32_t* sel, const float* d_feat_heads, const float* d_normal_heads, int n_heads, long n_rows,
                                      float* d_feat, float* d_normal, fneus_stream_t stream_) {

@@ -1329,6 +1329,7 @@ extern "C" int fneus_sdf_bwd(const void* blob, const float* pts, const float* ra
         if (r8 && !whi && hb_env == 0 && n_tiles32 >= 1024 && tiles_pp * 9 * (long)kPPBlock < (1L << 31) && (prec == 3 || prec == 1))
             return fneus::sdf_bwd_r8(b, src, n_pts, st, bb, d_sdf, d_feat, d_normal, prec, exact ? 3 : 1, stream);
     }
+    if (d_feat == nullptr) return -2;       // the seed's feature rows as fragments in bufs->zbar_hi slot 8: the resident-weight kernel only
 #define FNEUS_K3H(P, W, H, G)                                                                                                \
     do {                                                                                                                     \
         static bool attr_done = false;                                                                                       \

@@ -501,6 +501,19 @@ __global__ void __launch_bounds__(512, 1) sdf_bwd_r8_kernel(const unsigned char*
         asc_step(IC(6), IC(16), IC(16), IC(0));
         asc_step(IC(7), IC(16), IC(16), IC(0));          // next: R8 (its first 16 k-steps)
         // ---- seed of the descending chain: zbar_8 = [fbar (tiles 0..7) ; sbar (row 0 of tile 8: k-steps 16, 17)]
+        if (XP == 1 && d_feat == nullptr) {
+            // the feature rows of the seed are in the plane already (slot 8 of zbar: the colour backward's bf16 fragments, heads added
+            // by fneus_surface_scatter_plane): this wave's fragments 2 w, 2 w + 1 of every half -> its region, nothing to store
+            static_for<0, NH>([&](auto HB_) {
+                constexpr int hb = decltype(HB_)::value;
+#pragma unroll
+                for (int sh = 0; sh < 2; ++sh) {
+                    const int ks = 2 * w + sh;
+                    const p2_u32x4 v = r8_ldb(rs_zbar_hi, sh ? pl.odd : pl.even, blk_off(8, hb) + (uint32_t)ks * kFragBytes);
+                    *reinterpret_cast<p2_u32x4*>(lds_ + hb * HALF + ks * kFragBytes + lane * 16) = v;
+                }
+            });
+        } else
         static_for<0, NH>([&](auto HB_) {
             constexpr int hb = decltype(HB_)::value;
             const long n = (tile0 + hb) * 32 + r;
@@ -629,6 +642,7 @@ int sdf_bwd_r8(const unsigned char* b, const PointSrc& src, long n_pts, const Sd
     // product (W hi + lo), hi-only B fragments in LDS.  FNEUS_BWD_XHI=0: hi + lo activations inside the chains as before round 6.
     const char* xe = getenv("FNEUS_BWD_XHI");
     const bool xhi = xe ? atoi(xe) != 0 : true;
+    if (d_feat == nullptr && !(prec == 3 && gp != 3 && xhi)) return -2;          // the seed from the plane: the bf16-cotangent form only
 #define FNEUS_BWD_R8(P, G, X)                                                                                         \
     return nh4 ? launch_bwd_r8<P, G, 4, X>(b, src, n_pts, st, bb, d_sdf, d_feat, d_normal, stream)                   \
                : launch_bwd_r8<P, G, 2, X>(b, src, n_pts, st, bb, d_sdf, d_feat, d_normal, stream)

@@ -30,7 +30,7 @@ class FneusSdfBwdBufs(C.Structure):
 
 class FneusColStash(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
-                ("side_hi", "side_lo", "u_hi", "u_lo", "zbar_hi", "zbar_lo", "zout_hi", "zout_lo", "mask", "feat_hi", "feat_lo")]
+                ("side_hi", "side_lo", "u_hi", "u_lo", "zbar_hi", "zbar_lo", "zout_hi", "zout_lo", "mask", "feat_hi", "feat_lo", "dfeat_hi")]
 
 
 class FneusNerfStash(C.Structure):
@@ -111,6 +111,7 @@ def _load():
         "fneus_adam": (C.c_int, [C.POINTER(FneusAdamSegment), ip, vp, vp, C.c_double, C.c_double, C.c_double, ip, vp]),
         "fneus_surface_gather": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, ip, ip, vp, vp, vp, vp, vp, vp]),
         "fneus_surface_scatter": (C.c_int, [vp, vp, vp, ip, C.c_long, vp, vp, vp]),
+        "fneus_surface_scatter_plane": (C.c_int, [vp, vp, vp, ip, C.c_long, vp, C.c_long, vp, vp]),
         "fneus_stage1_loss": (C.c_int, [vp] * 11 + [ip, f, f, f] + [vp] * 10 + [vp, vp]),
         "fneus_stage1_norms": (C.c_int, [vp, vp, vp, ip, f, vp, vp]),
         "fneus_upsample": (C.c_int, [vp, vp, vp, vp, ip, ip, ip, f, vp, vp]),

@@ -85,22 +85,38 @@ class SdfValueGradFn(torch.autograd.Function):
         d_sdf = torch.zeros(n, device=dev) if d_sdf is None else d_sdf.contiguous()
         d_feat = torch.zeros(n, 256, device=dev) if d_feat is None else d_feat.contiguous()
         d_normal = torch.zeros(n, 3, device=dev) if d_normal is None else d_normal.contiguous()
+        bufs = ws.get(("sdf_bwd", n, prec), lambda: ops.SdfBwdBufs(n, dev, prec, gprec=ctx.stash.gprec))
+        # Round 6: ColorFn.backward has written the feature cotangent straight into this kernel's seed plane (bf16 fragments, slot 8 of
+        # zbar) and filed the fact under this forward's stamp; the tensor autograd delivered is then its placeholder.  Anything else
+        # (another consumer of the features summed in by autograd, a record of another forward) falls back to rows.
+        plane = ws.cache.pop("dfeat_in_plane", None)
+        in_plane = (plane is not None and plane[0] == (id(ws), ctx.generation) and getattr(d_feat, "plane_of", None) is not None
+                    and d_feat.plane_of.data_ptr() == bufs.zbar[0, 8].data_ptr())
+        if plane is not None and not in_plane:
+            if getattr(d_feat, "plane_of", None) is not None or plane[0] == (id(ws), ctx.generation):
+                raise RuntimeError("SDFNetwork backward: the feature cotangent was left in a fragment plane this backward cannot use "
+                                   "(FNEUS_DFEAT_PLANE=0 keeps fp32 rows)")
         # gradients of the two gathered surface samples per ray arrive on the side (SurfaceGatherFn): 2B rows to add
         # instead of a dense, mostly zero [n,256] tensor for autograd to allocate and sum
         pending = ws.cache.pop("surface_grads", None)
         if pending is not None:
             sel, dfs, dns = pending
             if dfs is not None:
-                d_feat.index_add_(0, sel, dfs)
+                if in_plane:
+                    ops.surface_scatter_plane(sel, dfs[None].contiguous(), None, bufs.zbar[0, 8], n, d_normal)
+                else:
+                    d_feat.index_add_(0, sel, dfs)
             if dns is not None:
                 d_normal.index_add_(0, sel, dns)
         # RefHeadsFn.backward: per-head gradients of the gathered rows, filed under the stamp of the SDF forward the rows came from (two
         # renders before one backward pass each find their own record, in whatever order autograd runs the nodes)
         heads = ws.cache.get("surface_head_grads", {}).pop((id(ws), ctx.generation), None)
         if heads is not None:
-            ops.surface_scatter(heads[0], heads[1], heads[2], d_feat, d_normal)       # head sum + scatter-add in one launch
-        bufs = ws.get(("sdf_bwd", n, prec), lambda: ops.SdfBwdBufs(n, dev, prec, gprec=ctx.stash.gprec))
-        ops.sdf_bwd(net.blob, n, prec, ctx.stash, bufs, d_sdf, d_feat, d_normal, **ctx.samples.kw())
+            if in_plane:
+                ops.surface_scatter_plane(heads[0], heads[1], heads[2], bufs.zbar[0, 8], n, d_normal)
+            else:
+                ops.surface_scatter(heads[0], heads[1], heads[2], d_feat, d_normal)       # head sum + scatter-add in one launch
+        ops.sdf_bwd(net.blob, n, prec, ctx.stash, bufs, d_sdf, None if in_plane else d_feat, d_normal, **ctx.samples.kw())
         # zeroed once: fneus_wn_backward clears what it reads, so the buffer is zero again after every step
         grad = ws.get(("sdf_grad", n), lambda: torch.zeros(net.n_params, dtype=torch.float32, device=dev))
         # the colour network's products over the same samples wait here (ColorFn.backward): one launch for both networks
@@ -200,6 +216,7 @@ class ColorFn(torch.autograd.Function):
         # the SDF forward whose feature planes this call consumes: the latest one on that workspace NOW (by the time of the
         # backward a later render may have stamped it again)
         ctx.sdf_generation = getattr(sdf_ws, "generation", None) if sdf_ws is not None else None
+        ctx.from_planes = head == 0 and getattr(feat, "planes_of", None) is not None
         if head != 0:
             ctx.save_for_backward(rgb, normal)
         else:
@@ -219,7 +236,18 @@ class ColorFn(torch.autograd.Function):
         else:
             (rgb,) = ctx.saved_tensors
             d_rgb = d_rgb.contiguous()
-            d_feat, d_normal = ops.color_bwd(net.blob, n, prec, d_rgb, rgb, ctx.stash)
+            # the feature cotangent as the bf16 fragments the SDF network's backward seeds its descending chain with (round 6): where the
+            # features came to this call as the SDF stash's planes (their only dense consumer is this network, NeuSRenderer.render_core)
+            # and both backward kernels run on bf16 cotangents, no fp32 rows [n, 256] are written or read
+            plane = None
+            sdf_stash = ctx.sdf_ws.cache.get(("sdf_stash", n, prec, True)) if ctx.sdf_ws is not None else None
+            if (ctx.from_planes and ctx.needs_input_grad[2] and sdf_stash is not None and getattr(sdf_stash, "generation", None) == ctx.sdf_generation
+                    and ctx.stash.gprec == sdf_stash.gprec and ops.dfeat_plane_ok(n, prec, sdf_stash.gprec)):
+                sdf_ws = ctx.sdf_ws
+                bufs = sdf_ws.get(("sdf_bwd", n, prec), lambda: ops.SdfBwdBufs(n, rgb.device, prec, gprec=sdf_stash.gprec))
+                plane = bufs.zbar[0, 8]
+                sdf_ws.cache["dfeat_in_plane"] = ((id(sdf_ws), ctx.sdf_generation),)
+            d_feat, d_normal = ops.color_bwd(net.blob, n, prec, d_rgb, rgb, ctx.stash, dfeat_plane=plane)
             feat_planes = ctx.sdf_ws.cache[("sdf_stash", n, prec, True)].feat
         grad = ws.get(("col_grad", n), lambda: torch.zeros(net.n_params, dtype=torch.float32, device=rgb.device))
         if ctx.stash.gprec == 2:        # the output layer's product with exact operands (u_3 hi + lo from the forward, zout in fp32 from

@@ -559,7 +559,10 @@ class ColStash:
 
 def sdf_bwd(blob, n_pts, prec, stash: SdfStash, bufs: SdfBwdBufs, d_sdf, d_feat, d_normal, pts=None, rays_o=None,
             rays_d=None, t=None, m: int = 1):
+    """d_feat None (only where dfeat_plane_ok): the feature cotangent is in bufs.zbar[0, 8] already, as bf16 fragments"""
     for x, nm in ((d_sdf, "d_sdf"), (d_feat, "d_feat"), (d_normal, "d_normal")):
+        if x is None and nm == "d_feat":
+            continue
         _chk_f32(x, nm)
     _launch("fneus_sdf_bwd", lib.fneus_sdf_bwd, _ptr(blob), _ptr(pts), _ptr(rays_o), _ptr(rays_d), _ptr(t), m, n_pts, C.byref(stash.c),
                             C.byref(bufs.c), _ptr(d_sdf), _ptr(d_feat), _ptr(d_normal), prec, _stream())
@@ -592,14 +595,34 @@ def color_fwd(blob, n_pts, prec, normal, feat, stash: Optional[ColStash], train:
     return rgb
 
 
+DFEAT_PLANE = _os.environ.get("FNEUS_DFEAT_PLANE", "1") != "0"
+
+
+def dfeat_plane_ok(n_pts: int, prec: int, gprec: int) -> bool:
+    """may the colour network's backward hand its feature cotangent to the SDF network's backward as the bf16 fragments of that
+    kernel's seed plane (slot 8 of SdfBwdBufs.zbar) instead of fp32 rows [n, 256]?  The conditions under which BOTH kernels run their
+    chains on bf16 cotangents (csrc/color_r8_kernels.hip color_bwd_r8, csrc/sdf_r8_kernels.hip sdf_bwd_r8): parity arithmetic, bf16
+    gradient planes, launches of >= 1024 sample tiles within the 32-bit plane offsets, none of the switches that select another kernel"""
+    env = _os.environ.get
+    tiles_pp = 2 * ((n_pts + 63) // 64)
+    return (DFEAT_PLANE and prec == PREC_PARITY and gprec in (1, 2) and (n_pts + 31) // 32 >= 1024 and tiles_pp * 9 * 16384 < 2 ** 31
+            and env("FNEUS_K3_R8", "1") != "0" and env("FNEUS_COL_BWD_R8", "1") != "0" and env("FNEUS_BWD_XHI", "1") != "0"
+            and env("FNEUS_COLB_XHI", "1") != "0" and env("FNEUS_K3_HB") is None and env("FNEUS_BWD_WHI", "0") == "0")
+
+
 def color_bwd(blob, n_pts, prec, d_rgb, rgb, stash: ColStash, head: int = HEAD_COLOR, normal=None, dirs=None, rays_d=None,
-              m: int = 1):
+              m: int = 1, dfeat_plane=None):
+    """dfeat_plane (head 0, only where dfeat_plane_ok): the bf16 fragment plane [tiles, 16, 64, 8] that receives the feature cotangent --
+    the returned d_feat is then a PLACEHOLDER no kernel wrote (its `plane_of` attribute is the plane)"""
     _chk_f32(d_rgb, "d_rgb")
     d_feat = torch.empty(n_pts, 256, dtype=torch.float32, device=blob.device)
     d_normal = torch.empty(n_pts, 3, dtype=torch.float32, device=blob.device)
     if head == HEAD_COLOR:
+        stash.c.dfeat_hi = dfeat_plane.data_ptr() if dfeat_plane is not None else None
         _launch("fneus_color_bwd", lib.fneus_color_bwd, _ptr(blob), n_pts, _ptr(d_rgb), _ptr(rgb), C.byref(stash.c),
-                _ptr(d_feat), _ptr(d_normal), prec, _stream())
+                None if dfeat_plane is not None else _ptr(d_feat), _ptr(d_normal), prec, _stream())
+        if dfeat_plane is not None:
+            d_feat.plane_of = dfeat_plane
     else:
         _chk_f32(normal, "normal")
         _launch("fneus_refcolor_bwd", lib.fneus_refcolor_bwd, _ptr(blob), head, n_pts, _ptr(rays_d), m, _ptr(dirs), _ptr(normal),
@@ -1006,6 +1029,18 @@ def surface_scatter(sel, d_feat_heads, d_normal_heads, d_feat, d_normal):
             _chk_f32(x, nm)
     _launch("fneus_surface_scatter", lib.fneus_surface_scatter, _ptr(sel), _ptr(d_feat_heads), _ptr(d_normal_heads), int(H), int(R),
             _ptr(d_feat), _ptr(d_normal), _stream())
+
+
+def surface_scatter_plane(sel, d_feat_heads, d_normal_heads, dfeat_plane, n_pts, d_normal):
+    """surface_scatter with the feature cotangent as bf16 fragments [tiles, 16, 64, 8] (csrc/fneus_pp.h) instead of rows"""
+    H, R = (d_feat_heads if d_feat_heads is not None else d_normal_heads).shape[:2]
+    for x, nm in ((d_feat_heads, "d_feat_heads"), (d_normal_heads, "d_normal_heads"), (d_normal, "d_normal")):
+        if x is not None:
+            _chk_f32(x, nm)
+    if dfeat_plane.dtype != torch.bfloat16 or not dfeat_plane.is_contiguous():
+        raise ValueError("dfeat_plane: contiguous bf16 fragments expected")
+    _launch("fneus_surface_scatter_plane", lib.fneus_surface_scatter_plane, _ptr(sel), _ptr(d_feat_heads), _ptr(d_normal_heads), int(H), int(R),
+            _ptr(dfeat_plane), int(n_pts), _ptr(d_normal), _stream())
 
 
 def stage1_norms(mask_in, sdf_mask, eik_den, mask_weight):

@@ -56,6 +56,9 @@ typedef struct FneusColStash {
     void* mask;                           /* lane-private ReLU masks: [tiles][4][64] x 16 bytes                                */
     uint16_t* feat_hi; uint16_t* feat_lo; /* [tiles][16][512]     fneus_refcolor_* only: copy of the input features; NULL for
                                                                    the colour network (its features are FneusSdfStash.feat)    */
+    uint16_t* dfeat_hi;                   /* [tiles][16][512]     fneus_color_bwd with d_feat == NULL (round 6): the feature
+                                             cotangent as bf16 fragments -- slot 8 of FneusSdfBwdBufs.zbar_hi, where fneus_sdf_bwd
+                                             (d_feat == NULL) takes the seed of its descending chain from; NULL otherwise     */
 } FneusColStash;
 
 /* work buffers of fneus_sdf_bwd: the operands of the weight-gradient GEMM (fragment planes like FneusSdfStash, *_lo
@@ -184,6 +187,8 @@ int fneus_sdf_fwd_grad(const void* sdf_blob, const float* pts, const float* rays
 /* ---- K3: autograd of K2 w.r.t. the SDF weights, incl. the double backward through SDFNetwork.gradient
  *      (create_graph=True, fields.py:104-110).  Consumes the K2 stash, writes the planes in `bufs`; the weight
  *      gradients themselves are produced by fneus_dw_gemm_pp from those planes. */
+/* d_feat == NULL (round 6; bf16 gradient planes and >= 1024 sample tiles only, -2 otherwise): the feature rows of the seed are
+ * already in bufs->zbar_hi slot 8 as bf16 fragments (fneus_color_bwd with d_feat == NULL, fneus_surface_scatter_plane).        */
 int fneus_sdf_bwd(const void* sdf_blob, const float* pts, const float* rays_o, const float* rays_d, const float* t,
                   int m, long n_pts, const FneusSdfStash* stash, const FneusSdfBwdBufs* bufs, const float* d_sdf /*[n]*/,
                   const float* d_feat /*[n][256]*/, const float* d_normal /*[n][3]*/, int prec, fneus_stream_t stream);
@@ -210,7 +215,10 @@ int fneus_color_fwd(const void* col_blob, const float* pts, const float* rays_o,
                     const FneusColStash* stash /*host struct, may be NULL when !train*/, float* rgb_out /*[n][3]*/,
                     int prec, int train, fneus_stream_t stream);
 
-/* autograd of the above: d_rgb -> d_feat [n][256], d_normal [n][3]; writes zbar planes (weight-gradient operands). */
+/* autograd of the above: d_rgb -> d_feat [n][256], d_normal [n][3]; writes zbar planes (weight-gradient operands).
+ * d_feat == NULL (with stash->dfeat_hi set; bf16 gradient planes and a launch of >= 1024 sample tiles only, -2 otherwise): the
+ * feature cotangent leaves the launch as the bf16 fragments the SDF network's backward and weight-gradient product read anyway
+ * (fields.py:150-175 through autograd: the same values, rounded where fneus_sdf_bwd would round them).                     */
 int fneus_color_bwd(const void* col_blob, long n_pts, const float* d_rgb, const float* rgb, const FneusColStash* stash,
                     float* d_feat, float* d_normal, int prec, fneus_stream_t stream);
 
@@ -284,6 +292,12 @@ int fneus_surface_gather(const int32_t* min_idx, const unsigned char* sdf_mask, 
  * distinct.  Either heads pointer may be NULL.  Replaces two sums over the heads and two index_add_ launches.                    */
 int fneus_surface_scatter(const int32_t* sel /*[R]*/, const float* d_feat_heads /*[H][R][256]*/, const float* d_normal_heads /*[H][R][3]*/,
                           int n_heads, long n_rows, float* d_feat /*[N][256]*/, float* d_normal /*[N][3]*/, fneus_stream_t stream);
+/* The same with the feature cotangent held as bf16 FRAGMENTS (FneusColStash.dfeat_hi = slot 8 of FneusSdfBwdBufs.zbar_hi,
+ * [tiles][16][512], csrc/fneus_pp.h) instead of fp32 rows: the selected rows' elements are read, summed with the heads' in fp32 and
+ * rounded back (round 6: the feature cotangent never exists as rows in the training step).  d_normal stays rows.                */
+int fneus_surface_scatter_plane(const int32_t* sel /*[R]*/, const float* d_feat_heads /*[H][R][256]*/, const float* d_normal_heads /*[H][R][3]*/,
+                                int n_heads, long n_rows, void* dfeat_hi /*[tiles][16][512] bf16*/, long n_pts, float* d_normal /*[N][3]*/,
+                                fneus_stream_t stream);
 
 /* RefColor shading (linear->sRGB, clip: fields.py:262-268, 331-335), the two-sample blend (renderer.py:336-343), the
  * training losses (exp_runner.py:141-177: colour L1, surface L1, eikonal, mask BCE) and the gradient of the total loss

@@ -168,3 +168,38 @@ def test_feature_planes_instead_of_rows_change_nothing(monkeypatch):
             assert abs(a - b) <= 2e-6 * abs(a), (l0, l1)
         assert (c1 - c0).abs().max().item() <= 2e-3 * c0.abs().max().item()        # (Adam amplifies last-bit differences of a gradient)
         assert (s1 - s0).abs().max().item() <= 2e-3 * s0.abs().max().item()
+
+
+def test_feature_cotangent_as_fragments_instead_of_rows_changes_nothing(monkeypatch):
+    """round 6: where both backward kernels run on bf16 cotangents (ops.dfeat_plane_ok) the colour network's backward writes the
+    feature cotangent as the bf16 fragments K3 seeds its descending chain with (slot 8 of SdfBwdBufs.zbar: what K3 formed from the
+    fp32 rows itself) and K3 reads them there -- no [n, 256] fp32 rows written or read; the RefColor heads' rows are added into the
+    fragments (fneus_surface_scatter_plane).  Same losses, same parameters after three steps as with the rows (ops.DFEAT_PLANE off):
+    the 2 B gathered rows are rounded twice instead of once, everything else is the same bits."""
+    from fneus import ops
+    from fneus.trainer import Stage1Trainer, synthetic_batches
+    dev = torch.device("cuda:0")
+    batches = synthetic_batches(3, 512, dev, seed0=93)
+    n = 512 * 128
+
+    def run(plane, graph):
+        monkeypatch.setattr(ops, "DFEAT_PLANE", plane)
+        ops.set_deterministic(True)
+        try:
+            torch.manual_seed(17)
+            tr = Stage1Trainer(dev, seed=9, use_graph=graph)
+            losses = [float(tr.train_step(b)["loss"]) for b in batches]
+            return losses, tr.color_network.lin0.weight_v.detach().clone(), tr.sdf_network.lin8.weight_v.detach().clone(), \
+                tr.sdf_network.lin0.weight_v.detach().clone()
+        finally:
+            ops.set_deterministic(None)
+
+    monkeypatch.setattr(ops, "DFEAT_PLANE", True)
+    assert ops.dfeat_plane_ok(n, ops.PREC_PARITY, 2) and not ops.dfeat_plane_ok(n, ops.PREC_PARITY, 3) and not ops.dfeat_plane_ok(1000, ops.PREC_PARITY, 2)
+    for graph in (False, True):
+        l0, c0, s0, t0 = run(False, graph)
+        l1, c1, s1, t1 = run(True, graph)
+        for a, b in zip(l0, l1):
+            assert abs(a - b) <= 2e-6 * abs(a), (l0, l1)
+        for u, v in ((c0, c1), (s0, s1), (t0, t1)):
+            assert (v - u).abs().max().item() <= 2e-3 * u.abs().max().item()          # (Adam amplifies last-bit differences of a gradient)

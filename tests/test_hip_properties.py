@@ -651,3 +651,67 @@ def test_k1_on_marked_rays_only_equals_k1_there_and_fills_the_rest():
         got = ops.sdf_fwd(net.blob, R * m, 3, rays_o=o, rays_d=d, t=t, m=m, ray_mask=mask, fill=2.5)
         want = torch.where(mask[:, None], full.reshape(R, m), torch.full_like(full.reshape(R, m), 2.5))
         assert torch.equal(got.reshape(R, m), want), frac
+
+
+@pytest.mark.parametrize("n", [65536, 40003])
+def test_feature_cotangent_fragments_equal_the_rounded_rows(monkeypatch, n):
+    """fneus_color_bwd with d_feat == NULL (FneusColStash.dfeat_hi) stores bf16(d_feat) as fragments -- bit for bit the rows' rounding,
+    zeros behind a ragged end; fneus_sdf_bwd with d_feat == NULL seeds its descending chain from them: every plane it writes equals the
+    launch on the rows; fneus_surface_scatter_plane adds the heads' rows into the fragments (fp32 sum, rounded once more)."""
+    from fneus import ops, synth, pp
+    assert ops.dfeat_plane_ok(n, 3, 2)
+    g = torch.Generator(device=DEV).manual_seed(19)
+    x = (torch.rand(n, 3, device=DEV, generator=g) * 2 - 1).contiguous()
+    cnet = ops.PackedNet("color", DEV).load_state_dict({k: T(v) for k, v in synth.color_state_dict(23).items()})
+    cnet.pack()
+    d = torch.randn(n, 3, device=DEV, generator=g)
+    d = (d / d.norm(dim=-1, keepdim=True)).contiguous()
+    nrm = torch.randn(n, 3, device=DEV, generator=g)
+    feat = (torch.randn(n, 256, device=DEV, generator=g) * 0.3).contiguous()
+    c_rgb = torch.randn(n, 3, device=DEV, generator=g)
+    cs = ops.ColStash(n, DEV, 3, gprec=2)
+    rgb = ops.color_fwd(cnet.blob, n, 3, nrm, feat, cs, True, pts=x, dirs=d)
+    rows, dn_rows = ops.color_bwd(cnet.blob, n, 3, c_rgb, rgb, cs)
+    zb_rows = cs.zbar.clone()
+    T_al = 2 * ((n + 63) // 64)
+    plane = torch.full((T_al, 16, 64, 8), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ph, dn_plane = ops.color_bwd(cnet.blob, n, 3, c_rgb, rgb, cs, dfeat_plane=plane)
+    torch.cuda.synchronize()
+    assert ph.plane_of is plane and torch.equal(dn_plane, dn_rows) and torch.equal(cs.zbar, zb_rows)
+    got = pp.unpack(plane)                                           # [T_al * 32, 256]
+    assert torch.equal(got[:n], rows.bfloat16())
+    assert float(got[n:(n + 31) // 32 * 32].float().abs().max()) == 0.0 if n % 32 else True
+    # ---- K3 on the fragments against K3 on the rows
+    net = ops.PackedNet("sdf", DEV).load_state_dict({k: T(v) for k, v in synth.sdf_state_dict(22).items()})
+    net.pack()
+    ds, dnn = torch.randn(n, device=DEV, generator=g), torch.randn(n, 3, device=DEV, generator=g)
+    st = ops.SdfStash(n, DEV, 3, True, 2)
+    ops.sdf_fwd_grad(net.blob, n, 3, st, True, pts=x)
+    b0, b1 = ops.SdfBwdBufs(n, DEV, 3, 2), ops.SdfBwdBufs(n, DEV, 3, 2)
+    ops.sdf_bwd(net.blob, n, 3, st, b0, ds, rows, dnn, pts=x)
+    b1.zbar[0, 8].copy_(plane)
+    ops.sdf_bwd(net.blob, n, 3, st, b1, ds, None, dnn, pts=x)
+    torch.cuda.synchronize()
+    for name in ("qbar", "adj", "zbar", "zsdf"):
+        assert torch.equal(getattr(b0, name), getattr(b1, name)), name
+    # ---- the heads' rows into the fragments
+    R = 1024
+    sel = torch.randperm(n, device=DEV, generator=g)[:R].to(torch.int32).contiguous()
+    dfh = (torch.randn(2, R, 256, device=DEV, generator=g) * rows.abs().mean()).contiguous()
+    dnh = torch.randn(2, R, 3, device=DEV, generator=g).contiguous()
+    rows2, dn2 = rows.clone(), dnn.clone()
+    ops.surface_scatter(sel, dfh, dnh, rows2, dn2)
+    p2, dn3 = plane.clone(), dnn.clone()
+    ops.surface_scatter_plane(sel, dfh, dnh, p2, n, dn3)
+    torch.cuda.synchronize()
+    assert torch.equal(dn3, dn2)
+    got2 = pp.unpack(p2)[:n].float()
+    untouched = torch.ones(n, dtype=torch.bool, device=DEV)
+    untouched[sel.long()] = False
+    assert torch.equal(got2[untouched], got[:n].float()[untouched])
+    want = (rows.bfloat16().float()[sel.long()] + dfh.sum(0)).bfloat16().float()
+    assert torch.equal(got2[sel.long()], want)
+    # the kernels that cannot take the fragments refuse loudly
+    monkeypatch.setenv("FNEUS_BWD_XHI", "0")
+    with pytest.raises(RuntimeError):
+        ops.sdf_bwd(net.blob, n, 3, st, b1, ds, None, dnn, pts=x)
