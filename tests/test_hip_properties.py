@@ -709,7 +709,7 @@ def test_feature_cotangent_fragments_equal_the_rounded_rows(monkeypatch, n):
     untouched = torch.ones(n, dtype=torch.bool, device=DEV)
     untouched[sel.long()] = False
     assert torch.equal(got2[untouched], got[:n].float()[untouched])
-    want = (rows.bfloat16().float()[sel.long()] + dfh.sum(0)).bfloat16().float()
+    want = ((rows.bfloat16().float()[sel.long()] + dfh[0]) + dfh[1]).bfloat16().float()          # (the kernel's order of the fp32 sum)
     assert torch.equal(got2[sel.long()], want)
     # the kernels that cannot take the fragments refuse loudly
     monkeypatch.setenv("FNEUS_BWD_XHI", "0")
