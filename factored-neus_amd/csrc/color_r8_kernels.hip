@@ -17,6 +17,20 @@
 
 namespace fneus {
 
+#ifdef FNEUS_C8_STAMPS              // timing experiments only: cycles per phase kind of the pipelined form, block 0
+#define C8_STAMP(k)                                                              \
+    do {                                                                         \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();              \
+        stamp_sum[k] += t_ - stamp_last;                                         \
+        stamp_last = t_;                                                         \
+    } while (0)
+#else
+#define C8_STAMP(k) do { } while (0)
+#endif
+#ifndef FNEUS_COLB_PIPE
+#define FNEUS_COLB_PIPE 1           // bf16 cotangents: the post phase of a half inside the dense phase of the next one
+#endif
+
 // value of feature IDX (compile-time) of a two-tile accumulator-layout vector, valid in every lane of the sample pair
 template <int IDX>
 FN_DEV float acc_extract2(const f32x16 (&acc)[2], int h) {
@@ -71,6 +85,7 @@ __global__ void __launch_bounds__(512, 1) color_bwd_r8_kernel(const unsigned cha
     constexpr int HALF = XP == 3 ? kR8Half : kR8Half / 2;         // bf16 fragments: [k-step] x 1 KiB
     constexpr bool LO = PREC == 3 && GP == 3;
     static_assert(XP == PREC || (PREC == 3 && XP == 1 && !LO), "XP 1: bf16 activations with bf16 planes only");
+    constexpr bool PIPE = XP == 1 && PREC == 3 && FNEUS_COLB_PIPE;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int r = lane & 31, h = lane >> 5;
@@ -92,6 +107,10 @@ __global__ void __launch_bounds__(512, 1) color_bwd_r8_kernel(const unsigned cha
     auto rev_of = [&](int l) { return R8Layer{LY.L[l].rev_hi, LY.L[l].rev_lo, l == 0 ? 10 : 8}; };
     R8W W;
     uint32_t mk[2];                     // two operand sets: phase p (= step * NH + half) uses set p & 1
+#ifdef FNEUS_C8_STAMPS
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();
+    const unsigned long long stamp_t0 = stamp_last;
+#endif
     for (long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         asm volatile("" : "+s"(blob));
         const long tile0 = grp * NH;
@@ -137,6 +156,105 @@ __global__ void __launch_bounds__(512, 1) color_bwd_r8_kernel(const unsigned cha
         }
         p2_barrier();
         f32x16 acc;
+        // R0's output of half hb: this wave's feature tile -> d_feat rows, or -> fragments 2 w, 2 w + 1 of the tile's block in the
+        // plane K3 reads as the seed zbar_8 (st.dfeat_hi)
+        auto r0_out = [&](const f32x16& a16, int hb) {
+            const long n = (tile0 + hb) * 32 + r;
+            if (df_plane) {
+                const uint32_t bo = tile0 + hb < tiles ? (uint32_t)((size_t)(tile0 + hb) * kPPBlock) : 0x7ff00000u;
+#pragma unroll
+                for (int sh = 0; sh < 2; ++sh) {
+                    bf16x8 v;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (__bf16)(n < N ? a16[8 * sh + e] : 0.0f);
+                    p2_store128<true>(__builtin_bit_cast(p2_u32x4, v), rs_df, sh ? pl.odd : pl.even, (int)(bo + (uint32_t)(2 * w + sh) * kFragBytes));
+                }
+            } else {
+                const f32x16 one[1] = {a16};
+                store_f32<1>(one, d_feat + 32 * w, 256, n, h, n < N);
+            }
+        };
+        if constexpr (PIPE) {
+            // ---- pipelined form (bf16 cotangents): the post phase of a half runs INSIDE the dense phase of the next one, on the other
+            // of two accumulators -- four slices (select + convert of a fragment; its LDS and plane store; twice) in front of the first
+            // k-steps' MFMAs.  Phase P = step * NH + half (steps R4, R3, R2, R1); post(P) forms zbar_{3 - P / NH} of half P % NH with
+            // the mask in mk[P & 1]; ONE barrier per phase: behind it every wave has read region P % NH (dense P) and written region
+            // (P - 1) % NH (post P - 1), which the next layer reads NH - 1 phases later at the earliest.
+            f32x16 acc2[2];
+            bf16x8 frag;
+            auto post_slice = [&](auto PP_, auto M_) {
+                constexpr int PP = decltype(PP_)::value, M = decltype(M_)::value;
+                constexpr int l = 3 - PP / NH, hb = PP % NH, sh = M >> 1;
+                if constexpr ((M & 1) == 0) {
+                    const uint32_t mm = mk[PP & 1] >> mshift;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) frag[e] = (__bf16)(((mm >> (8 * sh + e)) & 1u) ? acc2[PP & 1][8 * sh + e] : 0.0f);
+                    asm volatile("" : "+v"(frag));
+                } else {
+                    const int ks = 2 * w + sh;
+                    *reinterpret_cast<bf16x8*>(lds_ + hb * HALF + ks * kFragBytes + lane * 16) = frag;
+                    p2_store128<true>(__builtin_bit_cast(p2_u32x4, valid_of(hb) ? frag : zero_bf16x8()), rs_z_hi, sh ? pl.odd : pl.even,
+                                      (int)(blk_off(l, hb) + (uint32_t)ks * kFragBytes));
+                }
+            };
+            // the slices of post(PP) inside a dense phase of KS k-steps: one per k-step from the second on (two per k-step where KS < 5)
+            auto side_of = [&](auto PP_, auto KS_) {
+                return [&](auto S_) {
+                    constexpr int PP = decltype(PP_)::value, KS = decltype(KS_)::value, sidx = decltype(S_)::value;
+                    if constexpr (PP >= 0) {
+                        static_for<0, 4>([&](auto M_) {
+                            constexpr int M = decltype(M_)::value;
+                            constexpr int slot = KS >= 5 ? M + 1 : (M * KS) / 4;
+                            if constexpr (slot == sidx) post_slice(PP_, M_);
+                        });
+                    }
+                };
+            };
+            auto pstep = [&](auto IDX_, auto KS_, auto KSN_) {
+                constexpr int IDX = decltype(IDX_)::value, KS = decltype(KS_)::value, KSN = decltype(KSN_)::value;
+                constexpr int L = 4 - IDX;
+                asm volatile("" : "+s"(blob));
+                const R8Layer nx = rev_of(L - 1);
+                static_for<0, NH>([&](auto HB_) {
+                    constexpr int hb = decltype(HB_)::value, P = IDX * NH + hb;
+                    C8_STAMP(0);
+                    r8_zero(acc2[P & 1]);
+                    r8_dense<PREC, KS, (hb == NH - 1 ? KSN : 0), 0, XP>(W, lds_ + hb * HALF + lane * 16, acc2[P & 1], rsrc, voff, nx, blob,
+                                                                           side_of(std::integral_constant<int, P - 1>{}, KS_));
+                    C8_STAMP(KS == 16 ? (hb == NH - 1 ? 2 : 1) : 3);
+                    if constexpr (hb == NH - 1) r8_request_rest<PREC, KSN>(W, rsrc, voff, nx, blob);
+                    // the mask set post(P - 1) has consumed: the mask of phase P + 1
+                    if constexpr (P >= 1 && P + 1 < 4 * NH) mask_load(mk[(P + 1) & 1], 3 - (P + 1) / NH, (P + 1) % NH);
+                    p2_barrier();
+                    C8_STAMP(4);
+                });
+            };
+            using std::integral_constant;
+#define IC(v) integral_constant<int, v>{}
+            pstep(IC(0), IC(2), IC(16));
+            pstep(IC(1), IC(16), IC(16));
+            pstep(IC(2), IC(16), IC(16));
+            pstep(IC(3), IC(16), IC(16));     // next: R0, 10 tiles
+            // ---- R0: the 8 feature tiles -> d_feat; half 0 carries the last post phase (zbar_0 of half NH - 1), a barrier publishes it
+            {
+                asm volatile("" : "+s"(blob));
+                const R8Layer nx = rev_of(4);
+                static_for<0, NH>([&](auto HB_) {
+                    constexpr int hb = decltype(HB_)::value;
+                    r8_zero(acc);
+                    if constexpr (hb == 0) {
+                        r8_dense<PREC, 16, 0, 0, XP>(W, lds_ + lane * 16, acc, rsrc, voff, nx, blob, side_of(IC(4 * NH - 1), IC(16)));
+                    } else {
+                        r8_dense<PREC, 16, (hb == NH - 1 ? 2 : 0), 0, XP>(W, lds_ + hb * HALF + lane * 16, acc, rsrc, voff, nx, blob);
+                    }
+                    C8_STAMP(5);
+                    r0_out(acc, hb);
+                    if constexpr (hb == 0) p2_barrier();
+                    C8_STAMP(6);
+                });
+            }
+#undef IC
+        } else {
         // one step: L = the layer whose reverse pack is multiplied, KS its k-steps; the post phase forms zbar_{L-1};
         // KSN = k-steps of the next step's pack (requested during the last half's dense phase)
         auto step = [&](auto L_, auto KS_, auto KSN_) {
@@ -171,22 +289,10 @@ __global__ void __launch_bounds__(512, 1) color_bwd_r8_kernel(const unsigned cha
                 constexpr int hb = decltype(HB_)::value;
                 r8_zero(acc);
                 r8_dense<PREC, 16, (hb == NH - 1 ? 2 : 0), 0, XP>(W, lds_ + hb * HALF + lane * 16, acc, rsrc, voff, nx, blob);
-                const long n = (tile0 + hb) * 32 + r;
-                if (df_plane) {         // this wave's tile as fragments 2 w, 2 w + 1 of the tile's block: what K3 reads as the seed zbar_8
-                    const uint32_t bo = tile0 + hb < tiles ? (uint32_t)((size_t)(tile0 + hb) * kPPBlock) : 0x7ff00000u;
-#pragma unroll
-                    for (int sh = 0; sh < 2; ++sh) {
-                        bf16x8 v;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = (__bf16)(n < N ? acc[8 * sh + e] : 0.0f);
-                        p2_store128<true>(__builtin_bit_cast(p2_u32x4, v), rs_df, sh ? pl.odd : pl.even, (int)(bo + (uint32_t)(2 * w + sh) * kFragBytes));
-                    }
-                } else {
-                    const f32x16 one[1] = {acc};
-                    store_f32<1>(one, d_feat + 32 * w, 256, n, h, n < N);
-                }
+                r0_out(acc, hb);
             });
         }
+        }   // (!PIPE)
         // ---- the 2 side tiles of half hb (streamed, wave hb) -> d normal
         if (w < NH) {
             const int hb = w;
@@ -204,8 +310,16 @@ __global__ void __launch_bounds__(512, 1) color_bwd_r8_kernel(const unsigned cha
                 d_normal[n * 3 + 2] = g2;
             }
         }
+        C8_STAMP(7);
         p2_barrier();                                               // the group's fragments are consumed
     }
+#ifdef FNEUS_C8_STAMPS
+    if (blockIdx.x == 0 && lane == 0 && (w == 0 || w == 4 || w == 7))
+        printf("col_bwd_r8 NH %d wave %d: total %llu cycles; 16-k-step dense %llu (the halves that request the next pack: %llu), R4 dense %llu, "
+               "after dense -> behind the barrier %llu, R0 dense %llu, R0 output %llu, side tiles %llu, the rest (seed, group edges) %llu\n", NH, w,
+               __builtin_amdgcn_s_memtime() - stamp_t0, stamp_sum[1], stamp_sum[2], stamp_sum[3], stamp_sum[4], stamp_sum[5], stamp_sum[6],
+               stamp_sum[7], stamp_sum[0]);
+#endif
 }
 
 template <int PREC, int GP, int NH, int XP>

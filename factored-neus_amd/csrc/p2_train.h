@@ -40,7 +40,9 @@ FN_DEV __amdgpu_buffer_rsrc_t p2_out_rsrc(unsigned char* p, unsigned bytes) {
 // offset restored from a spill by v_readlane needs wait states of its own.)
 template <bool NT>
 FN_DEV void p2_store128(p2_u32x4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+#ifndef FNEUS_DBG_NO_P2STORE            // (timing experiments only: what the stash stores of a two-pass kernel cost)
     __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, soff, NT ? 2 : 0);
+#endif
     asm volatile("s_nop 1" ::"v"(v) : "memory");
 }
 

@@ -60,6 +60,9 @@ FN_DEV void r8_wload_all(R8W& W, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, con
 #ifndef FNEUS_R8_BDIST
 #define FNEUS_R8_BDIST 2            // B fragments are requested this many k-steps ahead of their MFMAs
 #endif
+#ifndef FNEUS_R8_BDIST1
+#define FNEUS_R8_BDIST1 2           // the same for the chains on bf16 cotangents (XP 1)
+#endif
 #ifndef FNEUS_R8_WSPLIT
 #define FNEUS_R8_WSPLIT 10          // stages of the next layer requested inside the dense phase; the others behind its barrier
 #endif
@@ -73,16 +76,24 @@ template <int KSN> constexpr int r8_inside = KSN < FNEUS_R8_WSPLIT ? KSN : FNEUS
 // XP (activation products): PREC = the B fragments are hi + lo in parity mode; 1 with PREC == 3 = the B fragments of the half's
 // region are bf16 values ([k-step] x 1 KiB, no lo plane): W.lo . b, W.hi . b -- the cotangent chains of gradient precision 1 / 2,
 // whose activations are the values their planes hold.
-template <int PREC, int KS, int KSN, int LMAP = 0, int XP = PREC>
+// SIDE: side(integral_constant<int, s>) is called once per k-step in front of its MFMAs: a slice of the post phase of the half
+// BEFORE (another accumulator), so that its vector work runs beside this phase's MFMAs instead of beside an idle matrix pipe
+// (color_bwd_r8_kernel, PIPE).
+struct R8NoSide {
+    template <class S> FN_DEV void operator()(S) const {}
+};
+template <int PREC, int KS, int KSN, int LMAP = 0, int XP = PREC, class SIDE = R8NoSide>
 FN_DEV void r8_dense(R8W& W, const unsigned char* fl, f32x16& acc, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, const R8Layer& nx,
-                     const unsigned char* blob) {
+                     const unsigned char* blob, SIDE&& side = SIDE{}) {
     constexpr int NPL = XP == 3 ? 2 : 1;
     // B ring.  A k-step is only 3 MFMAs here (96 cycles of this wave's matrix time), less than an LDS round trip with eight waves
     // reading: requested one k-step ahead (as the 12-MFMA k-steps of the other engines do) every k-step waited for its fragments
     // -- 286 cycles per k-step of a SIMD's two waves instead of 192 (FNEUS_R8_STAMPS).  Distance D, ring of D + 2 buffers:
     // HAZARD (mlp_engine.h dense_ldsb): an LDS load must not land in the operand registers of an MFMA that is still queued; the
     // buffer written at k-step s last fed the MFMAs of k-step s - 2, and the requests are pinned in front of the MFMAs of k-step s.
-    constexpr int D = FNEUS_R8_BDIST < KS ? FNEUS_R8_BDIST : KS - 1, NB = D + 2;
+    // (bf16 regions, XP 1: a k-step is 2 MFMAs = 64 cycles of this wave's matrix time and a fragment 4 registers: a deeper ring)
+    constexpr int BD = (XP == 1 && PREC == 3) ? FNEUS_R8_BDIST1 : FNEUS_R8_BDIST;
+    constexpr int D = BD < KS ? BD : KS - 1, NB = D + 2;
     constexpr int LAG = FNEUS_R8_WLAG;
     bf16x8 bh[NB], bl[NB];
     static_for<0, D>([&](auto S_) {
@@ -106,6 +117,7 @@ FN_DEV void r8_dense(R8W& W, const unsigned char* fl, f32x16& acc, __amdgpu_buff
             W.hi[q] = p2_wload(rsrc, voff, nx.off_hi + f, blob);
             if constexpr (PREC == 3) W.lo[q] = p2_wload(rsrc, voff, nx.off_lo + f, blob);
         }
+        side(S_);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (PREC == 3) acc = mfma32(W.lo[s], bh[s % NB], acc);
         if constexpr (XP == 3) acc = mfma32(W.hi[s], bl[s % NB], acc);
