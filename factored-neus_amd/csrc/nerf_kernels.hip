@@ -693,7 +693,9 @@ __global__ void __launch_bounds__(256, 2) nerf_fwd_tph_kernel(const unsigned cha
     }
 }
 
-template <int PREC>
+// XP 1 (with PREC 3, bf16 zbar planes): the chain runs on the bf16 cotangents those planes hold -- W hi + lo against one bf16 fragment, two
+// MFMAs per product (FNEUS_NERF_XHI=0: hi + lo cotangents inside the chain)
+template <int PREC, int XP>
 __global__ void __launch_bounds__(256, 2) nerf_bwd_tph_kernel(const unsigned char* blob, long Ncap, const float* __restrict__ d_density,
                                                               const float* __restrict__ d_rgb, NerfStash st,
         const int32_t* __restrict__ n_dev) {
@@ -708,7 +710,7 @@ __global__ void __launch_bounds__(256, 2) nerf_bwd_tph_kernel(const unsigned cha
     const PPLane pl = pp_lane(lane);
     const long tiles = pp_tiles(Ncap);
     const long groups = (N + 32 * HB - 1) / (32 * HB);
-    const bool lo_planes = PREC == 3 && st.zbar_lo != nullptr;
+    const bool lo_planes = XP == 3 && st.zbar_lo != nullptr;
     constexpr auto& LY = kNerfLayout;
     for (long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         asm volatile("" : "+s"(blob));
@@ -723,7 +725,7 @@ __global__ void __launch_bounds__(256, 2) nerf_bwd_tph_kernel(const unsigned cha
             nc[hb] = valid[hb] ? n : N - 1;
             mrow[hb] = reinterpret_cast<const uint32_t*>(st.mask + (size_t)tile[hb] * 9 * 64 + lane);
         }
-        BFrag<PREC> bden[HB * 3];                         // the density tiles' fragments (wave 0), published with dL/d feature
+        BFrag<XP> bden[HB * 3];                         // the density tiles' fragments (wave 0), published with dL/d feature
         if (wave == 0) {
             f32x16 z0[1][HB];
             unsigned char *zh[HB], *zl[HB];
@@ -739,13 +741,13 @@ __global__ void __launch_bounds__(256, 2) nerf_bwd_tph_kernel(const unsigned cha
                 z0[0][hb] = zo[0];
                 zh[hb] = st.zout_hi + (size_t)tile[hb] * 4 * kFragBytes;
                 zl[hb] = lo_planes ? st.zout_lo + (size_t)tile[hb] * 4 * kFragBytes : nullptr;
-                BFrag<PREC> tmp[kMaxKS];
-                acc_to_bfrag<PREC, 1>(reinterpret_cast<f32x16(&)[1]>(zo[1]), tmp);
+                BFrag<XP> tmp[kMaxKS];
+                acc_to_bfrag<XP, 1>(reinterpret_cast<f32x16(&)[1]>(zo[1]), tmp);
                 bden[hb * 3] = tmp[0];
                 bden[hb * 3 + 1] = tmp[1];
-                frags_to_plane<PREC, 2>(&bden[hb * 3], 2, zh[hb], zl[hb], pl, valid[hb]);
+                frags_to_plane<XP, 2>(&bden[hb * 3], 2, zh[hb], zl[hb], pl, valid[hb]);
             }
-            tph_exchange<PREC, 1, true, HB, HALF>(frag, lane, 0, z0, zh, zl, pl, valid);
+            tph_exchange<XP, 1, true, HB, HALF>(frag, lane, 0, z0, zh, zl, pl, valid);
         } else {
             nerf_barrier();
             nerf_barrier();
@@ -756,7 +758,7 @@ __global__ void __launch_bounds__(256, 2) nerf_bwd_tph_kernel(const unsigned cha
         for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) v[0][hb][e] = 0.0f;
-        tph_dense<PREC, 2, 4, 0, 1, true, HB, HALF>(blob, LY.L[11].rev_hi, LY.L[11].rev_lo, frag, v, lane, wave);
+        tph_dense<PREC, 2, 4, 0, 1, true, HB, HALF, XP>(blob, LY.L[11].rev_hi, LY.L[11].rev_lo, frag, v, lane, wave);
         {
             unsigned char *ph[HB], *plo[HB];
 #pragma unroll
@@ -767,7 +769,7 @@ __global__ void __launch_bounds__(256, 2) nerf_bwd_tph_kernel(const unsigned cha
                 ph[hb] = st.zhv_hi + (size_t)tile[hb] * 8 * kFragBytes;
                 plo[hb] = lo_planes ? st.zhv_lo + (size_t)tile[hb] * 8 * kFragBytes : nullptr;
             }
-            tph_exchange<PREC, 1, true, HB, HALF>(frag, lane, wave, v, ph, plo, pl, valid);
+            tph_exchange<XP, 1, true, HB, HALF>(frag, lane, wave, v, ph, plo, pl, valid);
         }
         f32x16 acc[2][HB];
         auto zero2 = [&]() {
@@ -780,7 +782,7 @@ __global__ void __launch_bounds__(256, 2) nerf_bwd_tph_kernel(const unsigned cha
         };
         // views_linears.0 reverse onto its 256 feature inputs = dL/d feature
         zero2();
-        tph_dense<PREC, 8, 8, 0, 2, true, HB, HALF>(blob, LY.L[10].rev_hi, LY.L[10].rev_lo, frag, acc, lane, t0);
+        tph_dense<PREC, 8, 8, 0, 2, true, HB, HALF, XP>(blob, LY.L[10].rev_hi, LY.L[10].rev_lo, frag, acc, lane, t0);
         {
             unsigned char *ph[HB], *plo[HB];
 #pragma unroll
@@ -788,11 +790,11 @@ __global__ void __launch_bounds__(256, 2) nerf_bwd_tph_kernel(const unsigned cha
                 ph[hb] = st.zfeat_hi + (size_t)tile[hb] * kPPBlock;
                 plo[hb] = lo_planes ? st.zfeat_lo + (size_t)tile[hb] * kPPBlock : nullptr;
             }
-            tph_exchange<PREC, 2, true, HB, HALF>(frag, lane, t0, acc, ph, plo, pl, valid, wave == 0 ? bden : nullptr, 16, 2);
+            tph_exchange<XP, 2, true, HB, HALF>(frag, lane, t0, acc, ph, plo, pl, valid, wave == 0 ? bden : nullptr, 16, 2);
         }
         // feature_linear^T dfeature + alpha_linear^T ddensity -> dL/d h_7
         zero2();
-        tph_dense<PREC, 18, 8, 0, 2, true, HB, HALF>(blob, LY.L[9].rev_hi, LY.L[9].rev_lo, frag, acc, lane, t0);
+        tph_dense<PREC, 18, 8, 0, 2, true, HB, HALF, XP>(blob, LY.L[9].rev_hi, LY.L[9].rev_lo, frag, acc, lane, t0);
 #pragma unroll 1
         for (int l = 7; l >= 0; --l) {
             unsigned char *ph[HB], *plo[HB];
@@ -806,11 +808,11 @@ __global__ void __launch_bounds__(256, 2) nerf_bwd_tph_kernel(const unsigned cha
                 ph[hb] = st.zbar_hi + off;
                 plo[hb] = lo_planes ? st.zbar_lo + off : nullptr;
             }
-            tph_exchange<PREC, 2, true, HB, HALF>(frag, lane, t0, acc, ph, plo, pl, valid);
+            tph_exchange<XP, 2, true, HB, HALF>(frag, lane, t0, acc, ph, plo, pl, valid);
             if (l > 0) {
                 const int e = l < 6 ? l : l + 1;
                 zero2();
-                tph_dense<PREC, 16, 8, 0, 2, true, HB, HALF>(blob, LY.L[e].rev_hi, LY.L[e].rev_lo, frag, acc, lane, t0);
+                tph_dense<PREC, 16, 8, 0, 2, true, HB, HALF, XP>(blob, LY.L[e].rev_hi, LY.L[e].rev_lo, frag, acc, lane, t0);
             }
         }
     }
@@ -910,8 +912,11 @@ extern "C" int fneus_nerf_bg_bwd(const void* blob, long n_pts, const float* d_de
     if (nerf_use_hb2((n_pts + 31) / 32)) {
         const long ng = (n_pts + 63) / 64;
         dim3 g2((unsigned)(ng < 2048 ? ng : 2048)), b2(256);
-        if (prec == 3) FNEUS_NERF_TPH(nerf_bwd_tph_kernel<3>, b, n_pts, d_density, d_rgb, st, n_dev);
-        else if (prec == 1) FNEUS_NERF_TPH(nerf_bwd_tph_kernel<1>, b, n_pts, d_density, d_rgb, st, n_dev);
+        const char* xe = getenv("FNEUS_NERF_XHI");
+        const bool xhi = (xe ? atoi(xe) != 0 : true) && st.zbar_lo == nullptr;       // bf16 planes: the chain on the values they hold
+        if (prec == 3 && xhi) FNEUS_NERF_TPH((nerf_bwd_tph_kernel<3, 1>), b, n_pts, d_density, d_rgb, st, n_dev);
+        else if (prec == 3) FNEUS_NERF_TPH((nerf_bwd_tph_kernel<3, 3>), b, n_pts, d_density, d_rgb, st, n_dev);
+        else if (prec == 1) FNEUS_NERF_TPH((nerf_bwd_tph_kernel<1, 1>), b, n_pts, d_density, d_rgb, st, n_dev);
         else return -2;
         return fneus::launch_status();
     }

@@ -183,14 +183,15 @@ FN_DEV void lds_to_frags(const unsigned char* fh, int lane, int ks0, BFrag<PREC>
     }
 }
 
-template <int PREC, int KS, int NT_TOTAL, int T0, int TN, bool WLO, int HB, int HALF_BYTES>
+// XP: as dense_ldsb_h (1 with PREC 3: bf16 B fragments without a lo plane, weights hi + lo)
+template <int PREC, int KS, int NT_TOTAL, int T0, int TN, bool WLO, int HB, int HALF_BYTES, int XP = PREC>
 FN_DEV void tph_dense(const unsigned char* __restrict__ blob, uint32_t off_hi, uint32_t off_lo, const unsigned char* frag,
                       f32x16 (&acc)[TN][HB], int lane, int t0_rt = 0) {
     // a stage of HB = 2 carries twice the MFMA time of a 32-sample stage: half the prefetch distance covers the same latency
 #ifndef FNEUS_TPH_DEPTH
 #define FNEUS_TPH_DEPTH ((FNEUS_TP_DEPTH + 1) / 2)
 #endif
-    dense_ldsb_h<PREC, KS, NT_TOTAL, T0, TN, (HB >= 2 ? FNEUS_TPH_DEPTH : FNEUS_TP_DEPTH), WLO, HB, HALF_BYTES>(blob, off_hi, off_lo, frag, acc, lane, t0_rt);
+    dense_ldsb_h<PREC, KS, NT_TOTAL, T0, TN, (HB >= 2 ? FNEUS_TPH_DEPTH : FNEUS_TP_DEPTH), WLO, HB, HALF_BYTES, XP>(blob, off_hi, off_lo, frag, acc, lane, t0_rt);
 }
 
 // one-wave kernels: B fragments ks0 .. ks0+NK-1 (already split) -> plane block

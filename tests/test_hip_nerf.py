@@ -117,3 +117,39 @@ def test_nerf_matches_the_reference_outputs_in_the_golden_fixture(golden_dir):
     e_rgb = np.abs(rgb.detach().cpu().numpy() - g["nerf_rgb"]).max()
     print(f"  K7 vs the reference's NeRF.forward: density {e_a:.2e}, rgb {e_rgb:.2e}")
     assert e_a <= 1e-4 and e_rgb <= 1e-4
+
+
+@pytest.mark.parametrize("xhi,gtol", [(1, 8e-3), (0, 6e-3)])          # observed 5.1e-3 / 4.0e-3
+def test_nerf_backward_on_bf16_cotangents_at_a_chip_filling_size(monkeypatch, xhi, gtol):
+    """Round 6: with bf16 zbar planes the background network's backward (64-sample workgroups, launches of >= 1024
+    sample tiles) runs its chain on the bf16 cotangents those planes hold -- W hi + lo against one bf16 fragment, two MFMAs per product
+    (FNEUS_NERF_XHI, default 1; 0: hi + lo cotangents inside the chain).  40 003 samples with RANDOM cotangents (nothing cancels
+    against the sum: the worst case for the rounding) against fp64 autograd of the oracle."""
+    from oracle import ref_torch as R
+    monkeypatch.setenv("FNEUS_NERF_XHI", str(xhi))
+    n = 40003
+    net, sd = _module(33, 3, 1)
+    pts4, dirs = _inputs(n, 19)
+    rs = np.random.RandomState(5)
+    c_a = T(rs.standard_normal((n, 1)).astype(np.float32))
+    c_rgb = T(rs.standard_normal((n, 3)).astype(np.float32))
+    sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    ok = torch.ones(n, dtype=torch.bool)
+    for i in range(0, n, 8192):
+        sl = slice(i, i + 8192)
+        ok[sl] = _relu_margin(R, pts4[sl].double(), dirs[sl].double(), sd64) > 3e-6
+    c_a, c_rgb = c_a * ok[:, None].float(), c_rgb * ok[:, None].float()
+    for i in range(0, n, 8192):
+        sl = slice(i, i + 8192)
+        a_ref, rgb_ref = R.nerf_forward(pts4[sl].double(), dirs[sl].double(), sd64)
+        ((a_ref * c_a[sl].double()).sum() + (rgb_ref * c_rgb[sl].double()).sum()).backward()
+    a, rgb = net(pts4.to(DEV), dirs.to(DEV))
+    ((a * c_a.to(DEV)).sum() + (rgb * c_rgb.to(DEV)).sum()).backward()
+    torch.cuda.synchronize()
+    worst = 0.0
+    for name, p in net.named_parameters():
+        ref = sd64[name].grad
+        e = ((p.grad.detach().cpu().double() - ref).norm() / (ref.norm() + 1e-30)).item()
+        worst = max(worst, e)
+    print(f"nerf bwd (64-sample workgroups) xhi={xhi}: worst relative parameter-gradient error {worst:.2e}")
+    assert worst <= gtol
