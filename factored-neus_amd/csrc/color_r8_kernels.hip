@@ -84,12 +84,8 @@ __global__ void __launch_bounds__(512, 1) color_bwd_r8_kernel(const unsigned cha
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
     constexpr int HALF = XP == 3 ? kR8Half : kR8Half / 2;         // bf16 fragments: [k-step] x 1 KiB
     constexpr bool LO = PREC == 3 && GP == 3;
-    static_assert(XP == PREC || (PREC == 3 && (XP == 1 || XP == 2) && !LO), "XP 1 / 2: bf16 / fp16 cotangents with bf16 planes only");
-    constexpr bool H16 = XP == 2;                       // ONE fp16 product per multiplication on per-sample scaled cotangents
-    constexpr bool PIPE = (XP == 1 || XP == 2) && PREC == 3 && (FNEUS_COLB_PIPE || XP == 2);
-    // (H16) per sample of the group: [half][sample] {scale, 1 / scale} -- powers of two that put the seed's largest entry at 2^-6
-    float* const sc_tab = reinterpret_cast<float*>(lds_ + NH * HALF);
-    if constexpr (H16) blob = st.w16;                   // the weights: the blob's fp16 copy (same layout, hi fragments)
+    static_assert(XP == PREC || (PREC == 3 && XP == 1 && !LO), "XP 1: bf16 activations with bf16 planes only");
+    constexpr bool PIPE = XP == 1 && PREC == 3 && FNEUS_COLB_PIPE;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int r = lane & 31, h = lane >> 5;
@@ -104,8 +100,8 @@ __global__ void __launch_bounds__(512, 1) color_bwd_r8_kernel(const unsigned cha
     const __amdgpu_buffer_rsrc_t rs_o_hi = c8_array(st.zout_hi, (size_t)tiles * 2 * kFragBytes);
     const __amdgpu_buffer_rsrc_t rs_o_lo = c8_array(PREC == 3 ? st.zout_lo : nullptr, (size_t)tiles * 2 * kFragBytes);
     const __amdgpu_buffer_rsrc_t rs_mask = c8_array(st.mask, (size_t)tiles * 4 * 1024);
-    const __amdgpu_buffer_rsrc_t rs_df = c8_array(XP != 3 ? st.dfeat_hi : nullptr, (size_t)tiles * kPPBlock);      // d_feat as bf16 fragments
-    const bool df_plane = XP != 3 && st.dfeat_hi != nullptr;
+    const __amdgpu_buffer_rsrc_t rs_df = c8_array(XP == 1 ? st.dfeat_hi : nullptr, (size_t)tiles * kPPBlock);      // d_feat as bf16 fragments
+    const bool df_plane = XP == 1 && st.dfeat_hi != nullptr;
     const unsigned voff_mask = (unsigned)lane * 16u + (unsigned)(w >> 1) * 4u;
     const int mshift = (w & 1) * 16;
     auto rev_of = [&](int l) { return R8Layer{LY.L[l].rev_hi, LY.L[l].rev_lo, l == 0 ? 10 : 8}; };
@@ -137,7 +133,7 @@ __global__ void __launch_bounds__(512, 1) color_bwd_r8_kernel(const unsigned cha
         };
         mask_load(mk[0], 3, 0);
         mask_load(mk[1], 3, 1);
-        r8_wload_all<PREC, 2, XP>(W, rsrc, voff, rev_of(4), blob);
+        r8_wload_all<PREC, 2>(W, rsrc, voff, rev_of(4), blob);
         // ---- zbar_4 = d rgb * sigmoid' (rows 0..2 of one tile): wave hb publishes k-steps 0, 1 of half hb and stores the zout planes
         if (w < NH) {
             const int hb = w;
@@ -155,44 +151,15 @@ __global__ void __launch_bounds__(512, 1) color_bwd_r8_kernel(const unsigned cha
                 }
             }
             const uint32_t zo = tile0 + hb < tiles ? (uint32_t)((size_t)(tile0 + hb) * 2 * kFragBytes) : 0x7ff00000u;
-            if constexpr (H16) {
-                // the sample's scale: 2^(-6 - e) with 2^e <= max |zbar_4| < 2^(e+1) -- exact powers of two from the exponent field
-                // (a zero seed: 2^121, nothing to scale); the chain is linear in the seed, every product of it carries the factor
-                float m = fmaxf(fmaxf(fabsf(y0[0]), fabsf(y0[1])), fabsf(y0[2]));
-                m = fmaxf(m, xor32(m));                                      // (the values sit in the h = 0 lanes)
-                const int ex = (int)((__builtin_bit_cast(uint32_t, m) >> 23) & 0xffu);
-                const float scl = __builtin_bit_cast(float, (uint32_t)(248 - ex) << 23), uns = __builtin_bit_cast(float, (uint32_t)(ex + 6) << 23);
-                if (h == 0) {
-                    sc_tab[(hb * 32 + r) * 2] = scl;
-                    sc_tab[(hb * 32 + r) * 2 + 1] = uns;
-                }
-                bf16x8 f0, f1;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    f0[e] = to16<2>(y0[e] * scl);
-                    f1[e] = to16<2>(0.0f);
-                }
-                *reinterpret_cast<bf16x8*>(lds_ + hb * HALF + lane * 16) = f0;
-                *reinterpret_cast<bf16x8*>(lds_ + hb * HALF + kFragBytes + lane * 16) = f1;
-                c8_put_half<1, PREC == 3>(y0, 0, 0, lane, lds_ + hb * HALF, false, rs_o_hi, rs_o_lo, zo, pl, valid);      // the zout planes: as ever
-                c8_put_half<1, PREC == 3>(y1, 1, 0, lane, lds_ + hb * HALF, false, rs_o_hi, rs_o_lo, zo, pl, valid);
-            } else {
-                c8_put_half<XP, PREC == 3>(y0, 0, 0, lane, lds_ + hb * HALF, true, rs_o_hi, rs_o_lo, zo, pl, valid);
-                c8_put_half<XP, PREC == 3>(y1, 1, 0, lane, lds_ + hb * HALF, true, rs_o_hi, rs_o_lo, zo, pl, valid);
-            }
+            c8_put_half<XP, PREC == 3>(y0, 0, 0, lane, lds_ + hb * HALF, true, rs_o_hi, rs_o_lo, zo, pl, valid);
+            c8_put_half<XP, PREC == 3>(y1, 1, 0, lane, lds_ + hb * HALF, true, rs_o_hi, rs_o_lo, zo, pl, valid);
         }
         p2_barrier();
         f32x16 acc;
         // R0's output of half hb: this wave's feature tile -> d_feat rows, or -> fragments 2 w, 2 w + 1 of the tile's block in the
         // plane K3 reads as the seed zbar_8 (st.dfeat_hi)
-        auto r0_out = [&](const f32x16& a_in, int hb) {
+        auto r0_out = [&](const f32x16& a16, int hb) {
             const long n = (tile0 + hb) * 32 + r;
-            f32x16 a16 = a_in;
-            if constexpr (H16) {
-                const float uns = sc_tab[(hb * 32 + r) * 2 + 1];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) a16[e] *= uns;
-            }
             if (df_plane) {
                 const uint32_t bo = tile0 + hb < tiles ? (uint32_t)((size_t)(tile0 + hb) * kPPBlock) : 0x7ff00000u;
 #pragma unroll
@@ -214,31 +181,19 @@ __global__ void __launch_bounds__(512, 1) color_bwd_r8_kernel(const unsigned cha
             // the mask in mk[P & 1]; ONE barrier per phase: behind it every wave has read region P % NH (dense P) and written region
             // (P - 1) % NH (post P - 1), which the next layer reads NH - 1 phases later at the earliest.
             f32x16 acc2[2];
-            bf16x8 frag, pfrag;         // the fragment for LDS (H16: fp16, scaled) and for the plane (bf16; H16: unscaled)
+            bf16x8 frag;
             auto post_slice = [&](auto PP_, auto M_) {
                 constexpr int PP = decltype(PP_)::value, M = decltype(M_)::value;
                 constexpr int l = 3 - PP / NH, hb = PP % NH, sh = M >> 1;
                 if constexpr ((M & 1) == 0) {
                     const uint32_t mm = mk[PP & 1] >> mshift;
-                    if constexpr (H16) {
-                        const float uns = sc_tab[(hb * 32 + r) * 2 + 1];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const float v = ((mm >> (8 * sh + e)) & 1u) ? acc2[PP & 1][8 * sh + e] : 0.0f;
-                            frag[e] = to16<2>(fminf(fmaxf(v, -60000.0f), 60000.0f));
-                            pfrag[e] = (__bf16)(v * uns);
-                        }
-                        asm volatile("" : "+v"(frag), "+v"(pfrag));
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) frag[e] = (__bf16)(((mm >> (8 * sh + e)) & 1u) ? acc2[PP & 1][8 * sh + e] : 0.0f);
-                        asm volatile("" : "+v"(frag));
-                    }
+                    for (int e = 0; e < 8; ++e) frag[e] = (__bf16)(((mm >> (8 * sh + e)) & 1u) ? acc2[PP & 1][8 * sh + e] : 0.0f);
+                    asm volatile("" : "+v"(frag));
                 } else {
                     const int ks = 2 * w + sh;
                     *reinterpret_cast<bf16x8*>(lds_ + hb * HALF + ks * kFragBytes + lane * 16) = frag;
-                    const bf16x8 out = H16 ? pfrag : frag;
-                    p2_store128<true>(__builtin_bit_cast(p2_u32x4, valid_of(hb) ? out : zero_bf16x8()), rs_z_hi, sh ? pl.odd : pl.even,
+                    p2_store128<true>(__builtin_bit_cast(p2_u32x4, valid_of(hb) ? frag : zero_bf16x8()), rs_z_hi, sh ? pl.odd : pl.even,
                                       (int)(blk_off(l, hb) + (uint32_t)ks * kFragBytes));
                 }
             };
@@ -267,7 +222,7 @@ __global__ void __launch_bounds__(512, 1) color_bwd_r8_kernel(const unsigned cha
                     r8_dense<PREC, KS, (hb == NH - 1 ? KSN : 0), 0, XP>(W, lds_ + hb * HALF + lane * 16, acc2[P & 1], rsrc, voff, nx, blob,
                                                                            side_of(std::integral_constant<int, P - 1>{}, KS_));
                     C8_STAMP(KS == 16 ? (hb == NH - 1 ? 2 : 1) : 3);
-                    if constexpr (hb == NH - 1) r8_request_rest<PREC, KSN, XP>(W, rsrc, voff, nx, blob);
+                    if constexpr (hb == NH - 1) r8_request_rest<PREC, KSN>(W, rsrc, voff, nx, blob);
                     // the mask set post(P - 1) has consumed: the mask of phase P + 1
                     if constexpr (P >= 1 && P + 1 < 4 * NH) mask_load(mk[(P + 1) & 1], 3 - (P + 1) / NH, (P + 1) % NH);
                     p2_barrier();
@@ -348,13 +303,7 @@ __global__ void __launch_bounds__(512, 1) color_bwd_r8_kernel(const unsigned cha
             zero_acc(s2[1]);
             dense_ldsb_h<PREC, 16, 10, 8, 2, 2, true, 1, HALF, XP>(blob, LY.L[0].rev_hi, LY.L[0].rev_lo, lds_ + hb * HALF, s2, lane);
             const f32x16 both[2] = {s2[0][0], s2[1][0]};
-            float g0 = acc_extract2<30>(both, h), g1 = acc_extract2<31>(both, h), g2 = acc_extract2<32>(both, h);
-            if constexpr (H16) {
-                const float uns = sc_tab[(hb * 32 + r) * 2 + 1];
-                g0 *= uns;
-                g1 *= uns;
-                g2 *= uns;
-            }
+            const float g0 = acc_extract2<30>(both, h), g1 = acc_extract2<31>(both, h), g2 = acc_extract2<32>(both, h);
             if (valid && lane < 32) {
                 d_normal[n * 3 + 0] = g0;
                 d_normal[n * 3 + 1] = g1;
@@ -382,7 +331,7 @@ static int launch_col_bwd_r8(const unsigned char* b, long n_pts, const float* d_
         done = true;
     }
     const long groups = (n_pts + 32 * NH - 1) / (32 * NH);
-    hipLaunchKernelGGL((color_bwd_r8_kernel<PREC, GP, NH, XP>), dim3((unsigned)(groups < 256 ? groups : 256)), dim3(512), NH * (XP == 3 ? kR8Half : kR8Half / 2) + (XP == 2 ? NH * 32 * 8 : 0), stream, b,
+    hipLaunchKernelGGL((color_bwd_r8_kernel<PREC, GP, NH, XP>), dim3((unsigned)(groups < 256 ? groups : 256)), dim3(512), NH * (XP == 3 ? kR8Half : kR8Half / 2), stream, b,
                        n_pts, d_rgb, rgb, st, d_feat, d_normal);
     return launch_status();
 }
@@ -402,11 +351,6 @@ int color_bwd_r8(const unsigned char* b, long n_pts, const float* d_rgb, const f
     return nh4 ? launch_col_bwd_r8<P, G, 4, X>(b, n_pts, d_rgb, rgb, st, d_feat, d_normal, stream)            \
                : launch_col_bwd_r8<P, G, 2, X>(b, n_pts, d_rgb, rgb, st, d_feat, d_normal, stream)
     if (prec == 3 && exact) FNEUS_COL_R8(3, 3, 3);
-    // ... and ONE fp16 product per multiplication where the caller has given the weights' fp16 copy (FNEUS_COLB_H16=0: two bf16 products)
-    const char* he = getenv("FNEUS_COLB_H16");
-    const bool h16 = prec == 3 && !exact && xhi && st.w16 != nullptr && (he ? atoi(he) != 0 : true);
-    if (h16 && (f == 8 || (f != 2 && f != 4 && (n_pts + 127) / 128 > 256))) return launch_col_bwd_r8<3, 1, 8, 2>(b, n_pts, d_rgb, rgb, st, d_feat, d_normal, stream);
-    if (h16 && nh4) return launch_col_bwd_r8<3, 1, 4, 2>(b, n_pts, d_rgb, rgb, st, d_feat, d_normal, stream);
     if (prec == 3 && xhi && (f == 8 || (f != 2 && f != 4 && (n_pts + 127) / 128 > 256))) return launch_col_bwd_r8<3, 1, 8, 1>(b, n_pts, d_rgb, rgb, st, d_feat, d_normal, stream);
     if (prec == 3 && xhi) FNEUS_COL_R8(3, 1, 1);
     if (prec == 3) FNEUS_COL_R8(3, 1, 3);

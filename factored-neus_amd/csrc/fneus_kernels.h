@@ -35,13 +35,12 @@ struct SdfBwdBufs {
     unsigned char *zbar_hi, *zbar_lo;   // [9][tiles][16 KiB]  slot l = zbar_l (slot 8: feature rows of the last layer)
     unsigned char *zsdf_hi, *zsdf_lo;   // [tiles][2 KiB]      feature 0 = dL/dsdf
     unsigned char *c_hi, *c_lo;         // [tiles][8][16 KiB]  coupling terms, lane-private
-    const unsigned char* w16 = nullptr; // the network's blob as fp16 fragments (fneus_h16_pack), or NULL
     SdfBwdBufs() = default;
     SdfBwdBufs(const FneusSdfBwdBufs& s)
         : qbar_hi((unsigned char*)s.qbar_hi), qbar_lo((unsigned char*)s.qbar_lo), adj_hi((unsigned char*)s.adj_hi),
           adj_lo((unsigned char*)s.adj_lo), zbar_hi((unsigned char*)s.zbar_hi), zbar_lo((unsigned char*)s.zbar_lo),
           zsdf_hi((unsigned char*)s.zsdf_hi), zsdf_lo((unsigned char*)s.zsdf_lo), c_hi((unsigned char*)s.c_hi),
-          c_lo((unsigned char*)s.c_lo), w16((const unsigned char*)s.w16) {}
+          c_lo((unsigned char*)s.c_lo) {}
 };
 
 struct ColStash {                       // fragment planes (include/fneus.h FneusColStash)
@@ -52,14 +51,12 @@ struct ColStash {                       // fragment planes (include/fneus.h Fneu
     u32x4* mask;                        // lane-private ReLU masks: [tiles][4][64] x 128 bits
     unsigned char *feat_hi, *feat_lo;   // [tiles][16 KiB]     surface head only: its (gathered) input features
     unsigned char* dfeat_hi;            // [tiles][16 KiB]     color_bwd without d_feat rows: the feature cotangent as bf16 fragments
-    const unsigned char* w16;           // the network's blob as fp16 fragments (fneus_h16_pack), or NULL
     ColStash() { memset(this, 0, sizeof(*this)); }
     ColStash(const FneusColStash& s)
         : side_hi((unsigned char*)s.side_hi), side_lo((unsigned char*)s.side_lo), u_hi((unsigned char*)s.u_hi),
           u_lo((unsigned char*)s.u_lo), zbar_hi((unsigned char*)s.zbar_hi), zbar_lo((unsigned char*)s.zbar_lo),
           zout_hi((unsigned char*)s.zout_hi), zout_lo((unsigned char*)s.zout_lo), mask((u32x4*)s.mask),
-          feat_hi((unsigned char*)s.feat_hi), feat_lo((unsigned char*)s.feat_lo), dfeat_hi((unsigned char*)s.dfeat_hi),
-          w16((const unsigned char*)s.w16) {}
+          feat_hi((unsigned char*)s.feat_hi), feat_lo((unsigned char*)s.feat_lo), dfeat_hi((unsigned char*)s.dfeat_hi) {}
 };
 
 struct NerfStash {      // fragment planes (fneus_pp.h): [tiles][F fragments][64 slots][8 bf16]; *_lo NULL unless gradient precision 3

@@ -185,7 +185,7 @@ FN_DEV void dense_ldsb_h(const unsigned char* __restrict__ blob, uint32_t off_hi
             for (int i = 0; i < TN; ++i) {
                 const int f = (s * NT_TOTAL + T0 + i) * 64;
                 ah[s % (D + 1)][i] = whi(f);
-                if constexpr (PREC == 3 && WLO && XP != 2) al[s % (D + 1)][i] = wlo(f);
+                if constexpr (PREC == 3 && WLO) al[s % (D + 1)][i] = wlo(f);
             }
         }
 #pragma unroll
@@ -200,7 +200,7 @@ FN_DEV void dense_ldsb_h(const unsigned char* __restrict__ blob, uint32_t off_hi
             for (int i = 0; i < TN; ++i) {
                 const int f = ((s + D) * NT_TOTAL + T0 + i) * 64;
                 ah[(s + D) % (D + 1)][i] = whi(f);
-                if constexpr (PREC == 3 && WLO && XP != 2) al[(s + D) % (D + 1)][i] = wlo(f);
+                if constexpr (PREC == 3 && WLO) al[(s + D) % (D + 1)][i] = wlo(f);
             }
         }
         if (s + 1 < KS) {
@@ -216,10 +216,9 @@ FN_DEV void dense_ldsb_h(const unsigned char* __restrict__ blob, uint32_t off_hi
         for (int i = 0; i < TN; ++i)
 #pragma unroll
             for (int hb = 0; hb < HB; ++hb) {
-                if constexpr (PREC == 3 && WLO && XP != 2) acc[i][hb] = mfma32(al[s % (D + 1)][i], bh[s % 3][hb], acc[i][hb]);
+                if constexpr (PREC == 3 && WLO) acc[i][hb] = mfma32(al[s % (D + 1)][i], bh[s % 3][hb], acc[i][hb]);
                 if constexpr (XP == 3) acc[i][hb] = mfma32(ah[s % (D + 1)][i], bl[s % 3][hb], acc[i][hb]);
-                if constexpr (XP == 2) acc[i][hb] = mfma32p<2>(ah[s % (D + 1)][i], bh[s % 3][hb], acc[i][hb]);       // (blob: the fp16 copy)
-                else acc[i][hb] = mfma32(ah[s % (D + 1)][i], bh[s % 3][hb], acc[i][hb]);
+                acc[i][hb] = mfma32(ah[s % (D + 1)][i], bh[s % 3][hb], acc[i][hb]);
             }
         __builtin_amdgcn_sched_barrier(0);
     }

@@ -293,52 +293,3 @@ extern "C" int fneus_wn_backward_multi(const FneusWnTask* tasks, int n_tasks, fn
     if (blocks > 0) hipLaunchKernelGGL(fneus::wn_backward_multi_kernel, dim3(blocks), dim3(64), 0, stream, T);
     return fneus::launch_status();
 }
-
-// ---- fp16 copies of a network's weight fragments (round 6: the backward chains with ONE product per multiplication) ----------------
-// out = a blob of the same layout whose forward and reverse hi fragments hold fp16(hi + lo) of every weight -- the same element in
-// the same place, 11 significant bits instead of 8 + 8; lo fragments, biases and the extra rows are not written (the backward chains
-// read the hi fragments only).  One 16-byte unit per thread.
-namespace fneus {
-template <int NL>
-__global__ void __launch_bounds__(256) h16_pack_kernel(const unsigned char* __restrict__ blob, unsigned char* __restrict__ out, NetLayout<NL> LY,
-                                                       const LayerGeom* __restrict__ geom_unused, uint32_t total) {
-    const uint32_t off = (blockIdx.x * 256u + threadIdx.x) * 16u;
-    if (off >= total) return;
-    bool hit = false;
-    uint32_t lo_off = 0;
-#pragma unroll
-    for (int l = 0; l < NL; ++l) {
-        // (the lo pack follows its hi pack: fwd_lo - fwd_hi and rev_lo - rev_hi are the packs' sizes)
-        if (off >= LY.L[l].fwd_hi && off < LY.L[l].fwd_lo) { hit = true; lo_off = off + (LY.L[l].fwd_lo - LY.L[l].fwd_hi); }
-        if (off >= LY.L[l].rev_hi && off < LY.L[l].rev_lo) { hit = true; lo_off = off + (LY.L[l].rev_lo - LY.L[l].rev_hi); }
-    }
-    if (!hit) return;
-    bf16x8 v = *reinterpret_cast<const bf16x8*>(blob + off);
-    const bf16x8 lo = *reinterpret_cast<const bf16x8*>(blob + lo_off);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = to16<2>((float)v[e] + (float)lo[e]);
-    *reinterpret_cast<bf16x8*>(out + off) = v;
-}
-}  // namespace fneus
-
-extern "C" int fneus_h16_pack(int kind, const void* blob, void* out, fneus_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    fneus::clear_status();
-    if (!blob || !out) {
-        fneus::set_last_error("fneus_h16_pack: blob and out must be given");
-        return -2;
-    }
-    const unsigned char* b = reinterpret_cast<const unsigned char*>(blob);
-    unsigned char* o = reinterpret_cast<unsigned char*>(out);
-    if (kind == 0) {
-        const uint32_t total = fneus::kSdfLayout.total;
-        hipLaunchKernelGGL((fneus::h16_pack_kernel<fneus::kSdfLayers>), dim3((total / 16 + 255) / 256), dim3(256), 0, stream, b, o, fneus::kSdfLayout, nullptr, total);
-    } else if (kind == 1) {
-        const uint32_t total = fneus::kColLayout.total;
-        hipLaunchKernelGGL((fneus::h16_pack_kernel<fneus::kColLayers>), dim3((total / 16 + 255) / 256), dim3(256), 0, stream, b, o, fneus::kColLayout, nullptr, total);
-    } else {
-        fneus::set_last_error("fneus_h16_pack: kind 0 (SDF network) or 1 (colour network)");
-        return -2;
-    }
-    return fneus::launch_status();
-}

@@ -39,14 +39,13 @@ struct R8Layer {                                // where a layer's pack lies in 
 };
 
 // every stage of a layer at once (the first layer of a group)
-// XP 2 (round 6): rsrc / blob name the network's fp16 copy (fneus_h16_pack) -- ONE fragment per stage, no lo part
-template <int PREC, int KS, int XP = PREC>
+template <int PREC, int KS>
 FN_DEV void r8_wload_all(R8W& W, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, const R8Layer& ly, const unsigned char* blob) {
     static_for<0, KS>([&](auto S_) {
         constexpr int s = decltype(S_)::value;
         const uint32_t f = (uint32_t)(s * ly.nt * 64) * 16u;
         W.hi[s] = p2_wload(rsrc, voff, ly.off_hi + f, blob);
-        if constexpr (PREC == 3 && XP != 2) W.lo[s] = p2_wload(rsrc, voff, ly.off_lo + f, blob);
+        if constexpr (PREC == 3) W.lo[s] = p2_wload(rsrc, voff, ly.off_lo + f, blob);
     });
 }
 
@@ -64,9 +63,6 @@ FN_DEV void r8_wload_all(R8W& W, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, con
 #ifndef FNEUS_R8_BDIST1
 #define FNEUS_R8_BDIST1 2           // the same for the chains on bf16 cotangents (XP 1)
 #endif
-#ifndef FNEUS_R8_BDIST2
-#define FNEUS_R8_BDIST2 3           // the same for one fp16 product per k-step (XP 2: 32 cycles of this wave's matrix time per k-step)
-#endif
 #ifndef FNEUS_R8_WSPLIT
 #define FNEUS_R8_WSPLIT 10          // stages of the next layer requested inside the dense phase; the others behind its barrier
 #endif
@@ -79,8 +75,7 @@ template <int KSN> constexpr int r8_inside = KSN < FNEUS_R8_WSPLIT ? KSN : FNEUS
 
 // XP (activation products): PREC = the B fragments are hi + lo in parity mode; 1 with PREC == 3 = the B fragments of the half's
 // region are bf16 values ([k-step] x 1 KiB, no lo plane): W.lo . b, W.hi . b -- the cotangent chains of gradient precision 1 / 2,
-// whose activations are the values their planes hold.  XP 2: ONE fp16 product -- fp16 weights (the blob's fp16 copy)
-// against fp16 B fragments ([k-step] x 1 KiB like XP 1), v_mfma_f32_32x32x16_f16.
+// whose activations are the values their planes hold.
 // SIDE: side(integral_constant<int, s>) is called once per k-step in front of its MFMAs: a slice of the post phase of the half
 // BEFORE (another accumulator), so that its vector work runs beside this phase's MFMAs instead of beside an idle matrix pipe
 // (color_bwd_r8_kernel, PIPE).
@@ -97,8 +92,7 @@ FN_DEV void r8_dense(R8W& W, const unsigned char* fl, f32x16& acc, __amdgpu_buff
     // HAZARD (mlp_engine.h dense_ldsb): an LDS load must not land in the operand registers of an MFMA that is still queued; the
     // buffer written at k-step s last fed the MFMAs of k-step s - 2, and the requests are pinned in front of the MFMAs of k-step s.
     // (bf16 regions, XP 1: a k-step is 2 MFMAs = 64 cycles of this wave's matrix time and a fragment 4 registers: a deeper ring)
-    constexpr bool WLO = PREC == 3 && XP != 2;
-    constexpr int BD = (XP == 1 && PREC == 3) ? FNEUS_R8_BDIST1 : (XP == 2 ? FNEUS_R8_BDIST2 : FNEUS_R8_BDIST);
+    constexpr int BD = (XP == 1 && PREC == 3) ? FNEUS_R8_BDIST1 : FNEUS_R8_BDIST;
     constexpr int D = BD < KS ? BD : KS - 1, NB = D + 2;
     constexpr int LAG = FNEUS_R8_WLAG;
     bf16x8 bh[NB], bl[NB];
@@ -121,34 +115,33 @@ FN_DEV void r8_dense(R8W& W, const unsigned char* fl, f32x16& acc, __amdgpu_buff
             constexpr int q = s - LAG;
             const uint32_t f = (uint32_t)(q * nx.nt * 64) * 16u;
             W.hi[q] = p2_wload(rsrc, voff, nx.off_hi + f, blob);
-            if constexpr (WLO) W.lo[q] = p2_wload(rsrc, voff, nx.off_lo + f, blob);
+            if constexpr (PREC == 3) W.lo[q] = p2_wload(rsrc, voff, nx.off_lo + f, blob);
         }
         side(S_);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (WLO) acc = mfma32(W.lo[s], bh[s % NB], acc);
+        if constexpr (PREC == 3) acc = mfma32(W.lo[s], bh[s % NB], acc);
         if constexpr (XP == 3) acc = mfma32(W.hi[s], bl[s % NB], acc);
-        if constexpr (XP == 2) acc = mfma32p<2>(W.hi[s], bh[s % NB], acc);
-        else acc = mfma32(W.hi[s], bh[s % NB], acc);
+        acc = mfma32(W.hi[s], bh[s % NB], acc);
         __builtin_amdgcn_sched_barrier(0);
     });
     static_for<(KS > LAG ? KS - LAG : 0), r8_inside<KSN>>([&](auto S_) {
         constexpr int q = decltype(S_)::value;
         const uint32_t f = (uint32_t)(q * nx.nt * 64) * 16u;
         W.hi[q] = p2_wload(rsrc, voff, nx.off_hi + f, blob);
-        if constexpr (WLO) W.lo[q] = p2_wload(rsrc, voff, nx.off_lo + f, blob);
+        if constexpr (PREC == 3) W.lo[q] = p2_wload(rsrc, voff, nx.off_lo + f, blob);
     });
     // the caller may reuse the B registers at once (LDS loads): let the last MFMAs read them first
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 }
 
 // stages r8_inside<KSN> .. KSN-1 of the next layer: behind the barrier of the requesting dense phase
-template <int PREC, int KSN, int XP = PREC>
+template <int PREC, int KSN>
 FN_DEV void r8_request_rest(R8W& W, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, const R8Layer& nx, const unsigned char* blob) {
     static_for<r8_inside<KSN>, KSN>([&](auto S_) {
         constexpr int q = decltype(S_)::value;
         const uint32_t f = (uint32_t)(q * nx.nt * 64) * 16u;
         W.hi[q] = p2_wload(rsrc, voff, nx.off_hi + f, blob);
-        if constexpr (PREC == 3 && XP != 2) W.lo[q] = p2_wload(rsrc, voff, nx.off_lo + f, blob);
+        if constexpr (PREC == 3) W.lo[q] = p2_wload(rsrc, voff, nx.off_lo + f, blob);
     });
 }
 

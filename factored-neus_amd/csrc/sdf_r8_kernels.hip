@@ -311,15 +311,7 @@ __global__ void __launch_bounds__(512, 1) sdf_bwd_r8_kernel(const unsigned char*
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_[];
     constexpr int HALF = XP == 3 ? kR8Half : kR8Half / 2;         // bf16 fragments: [k-step] x 1 KiB
     constexpr bool LO = PREC == 3 && GP == 3;          // lo planes exist (exact-gradient mode)
-    static_assert(XP == PREC || (PREC == 3 && (XP == 1 || XP == 2) && !LO), "XP 1 / 2: bf16 / fp16 cotangents with bf16 planes only");
-    // H16 (XP 2): ONE fp16 product per multiplication.  Both chains are linear in the sample's cotangents (nbar, fbar,
-    // sbar), so every value of a sample carries ONE power-of-two factor -- 2^(-6 - e) with 2^e <= max(|qbar|, |fbar|, |sbar|) < 2^(e+1),
-    // found in the group's prologue -- inside the kernel (LDS fragments, the coupling planes c_l: fp16) and none outside it (the planes
-    // the GEMM reads: bf16 of the unscaled value).  Weights: the blob's fp16 copy (bb.w16).  The seed's feature rows come as
-    // fragments (d_feat == NULL) in this form.
-    constexpr bool H16 = XP == 2;
-    float* const sc_tab = reinterpret_cast<float*>(lds_ + NH * (XP == 3 ? kR8Half : kR8Half / 2));        // [half][sample] {scale, 1 / scale}
-    if constexpr (H16) blob = bb.w16;
+    static_assert(XP == PREC || (PREC == 3 && XP == 1 && !LO), "XP 1: the chains' activations are the bf16 values of their planes");
     constexpr bool KEEP = NH == 2;                     // c_7 stays in the operand registers across the turn
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -390,20 +382,6 @@ __global__ void __launch_bounds__(512, 1) sdf_bwd_r8_kernel(const unsigned char*
                 o.lo[1] = __builtin_bit_cast(bf16x8, r8_ldb(rs_c_lo, lane16, so + kFragBytes));
             }
         };
-        // (H16) this wave's tile half `sh` of half hb: fp16 of the scaled values -> the region, bf16 of the unscaled ones -> the plane
-        auto put_h16 = [&](const float (&y)[8], int sh, int hb, bool to_lds, __amdgpu_buffer_rsrc_t p_hi, uint32_t p_off) {
-            const float uns = sc_tab[(hb * 32 + r) * 2 + 1];
-            bf16x8 f16v, pv;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                f16v[e] = to16<2>(fminf(fmaxf(y[e], -60000.0f), 60000.0f));
-                pv[e] = (__bf16)(y[e] * uns);
-            }
-            const int ks = 2 * w + sh;
-            if (to_lds) *reinterpret_cast<bf16x8*>(lds_ + hb * HALF + ks * kFragBytes + lane * 16) = f16v;
-            p2_store128<true>(__builtin_bit_cast(p2_u32x4, valid_of(hb) ? pv : zero_bf16x8()), p_hi, sh ? pl.odd : pl.even,
-                              (int)(p_off + (uint32_t)ks * kFragBytes));
-        };
         // One fragment half (sh) at a time, fenced: the post phase runs with the resident weights (136 registers) and both operand
         // sets live -- converting all 16 values of a tile at once does not fit beside them.
         // ascending: adj_{l+1} = s_l * abar_l -> region, plane;  c_l = beta (1 - s_l) a_l abar_l -> the scratch (keep: -> o.hi / o.lo)
@@ -420,9 +398,7 @@ __global__ void __launch_bounds__(512, 1) sdf_bwd_r8_kernel(const unsigned char*
                     const float abar = acc[8 * sh + e];
                     const float c = kBeta * (1.0f - sv) * av * abar;          // softplus'' * g_hat * abar  (a = s * g_hat)
                     y[e] = sv * abar;
-                    if constexpr (H16) {
-                        chi[e] = to16<2>(fminf(fmaxf(c, -60000.0f), 60000.0f));        // (the coupling plane: fp16, scaled, private to this kernel)
-                    } else if constexpr (XP == 3) {
+                    if constexpr (XP == 3) {
                         __bf16 x, yy;
                         split_bf16(c, x, yy);
                         chi[e] = x;
@@ -439,8 +415,7 @@ __global__ void __launch_bounds__(512, 1) sdf_bwd_r8_kernel(const unsigned char*
                     p2_store128<true>(__builtin_bit_cast(p2_u32x4, chi), rs_c_hi, lane16, (int)so);
                     if constexpr (LO) p2_store128<true>(__builtin_bit_cast(p2_u32x4, clo), rs_c_lo, lane16, (int)so);
                 }
-                if constexpr (H16) put_h16(y, sh, hb, to_lds, rs_adj_hi, blk_off(l, hb));
-                else r8_put_half<XP, LO>(y, sh, w, lane, lds_ + hb * HALF, to_lds, rs_adj_hi, rs_adj_lo, blk_off(l, hb), pl, valid_of(hb));
+                r8_put_half<XP, LO>(y, sh, w, lane, lds_ + hb * HALF, to_lds, rs_adj_hi, rs_adj_lo, blk_off(l, hb), pl, valid_of(hb));
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -452,37 +427,19 @@ __global__ void __launch_bounds__(512, 1) sdf_bwd_r8_kernel(const unsigned char*
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float sv = (float)o.sg[sh][e] * (1.0f / 65535.0f);
-                    float c = H16 ? (float)__builtin_bit_cast(_Float16, o.hi[sh][e]) : (float)o.hi[sh][e];
+                    float c = (float)o.hi[sh][e];
                     if constexpr (LO) c += (float)o.lo[sh][e];
                     y[e] = sv * acc[8 * sh + e] + c;
                 }
-                if constexpr (H16) put_h16(y, sh, hb, to_lds, rs_zbar_hi, blk_off(l, hb));
-                else r8_put_half<XP, LO>(y, sh, w, lane, lds_ + hb * HALF, to_lds, rs_zbar_hi, rs_zbar_lo, blk_off(l, hb), pl, valid_of(hb));
+                r8_put_half<XP, LO>(y, sh, w, lane, lds_ + hb * HALF, to_lds, rs_zbar_hi, rs_zbar_lo, blk_off(l, hb), pl, valid_of(hb));
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
         if (first) {                    // (later groups: requested at the end of the group before)
             load_asc(ops[0], 0, 0);
             load_asc(ops[1], 0, 1);
-            r8_wload_all<PREC, 3, XP>(W, rsrc, voff, fwd_of(0), blob);
+            r8_wload_all<PREC, 3>(W, rsrc, voff, fwd_of(0), blob);
             first = false;
-        }
-        if constexpr (H16) {
-            // the samples' scales, first part: every wave's share of max |fbar| (its two fragments of the seed plane, per half) ->
-            // [wave][sample] floats in slot 8 of the half's region (free until F0's post phases)
-            static_for<0, NH>([&](auto HB_) {
-                constexpr int hb = decltype(HB_)::value;
-                float m = 0.0f;
-#pragma unroll
-                for (int sh = 0; sh < 2; ++sh) {
-                    const bf16x8 v = __builtin_bit_cast(bf16x8, r8_ldb(rs_zbar_hi, sh ? pl.odd : pl.even, blk_off(8, hb) + (uint32_t)(2 * w + sh) * kFragBytes));
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf((float)v[e]));
-                }
-                m = fmaxf(m, xor32(m));
-                if (h == 0) reinterpret_cast<float*>(lds_ + hb * HALF + 8 * kFragBytes)[w * 32 + r] = m;
-            });
-            p2_barrier();
         }
         // ---- qbar = J nbar (wave hb for half hb): k-steps 0..2 of F0, the qbar plane, and a copy parked in slots 16..18 (F4)
         if (w < NH) {
@@ -497,35 +454,13 @@ __global__ void __launch_bounds__(512, 1) sdf_bwd_r8_kernel(const unsigned char*
             posenc<6, true>(x, pe, jc);
 #pragma unroll
             for (int f = 0; f < 39; ++f) qb[f] = jc[f] * nb[f % 3];
-            if constexpr (H16) {
-                float m = valid ? fabsf(d_sdf[nc]) : 0.0f;
-#pragma unroll
-                for (int f = 0; f < 39; ++f) m = fmaxf(m, fabsf(qb[f]));
-                const float* red = reinterpret_cast<const float*>(lds_ + hb * HALF + 8 * kFragBytes);
-#pragma unroll
-                for (int ww = 0; ww < 8; ++ww) m = fmaxf(m, red[ww * 32 + r]);
-                const int ex = (int)((__builtin_bit_cast(uint32_t, m) >> 23) & 0xffu);
-                const float scl = __builtin_bit_cast(float, (uint32_t)(248 - ex) << 23), uns = __builtin_bit_cast(float, (uint32_t)(ex + 6) << 23);
-                if (h == 0) {
-                    sc_tab[(hb * 32 + r) * 2] = scl;
-                    sc_tab[(hb * 32 + r) * 2 + 1] = uns;
-                }
-                BFrag<1> qp[kMaxKS];
-                vec_to_bfrag<1, 39, 3, 0>(qb, qp, h);                                   // the plane: bf16 of the values themselves
-                if (tile0 + hb < tiles)
-                    frags_to_plane<1, 3>(qp, 0, bb.qbar_hi + (size_t)(tile0 + hb) * 4 * kFragBytes, nullptr, pl, valid);
-#pragma unroll
-                for (int f = 0; f < 39; ++f) qb[f] *= scl;
-            }
             BFrag<XP> qf[kMaxKS];
             vec_to_bfrag<XP, 39, 3, 0>(qb, qf, h);
             frags_to_lds<XP, 3>(lds_ + hb * HALF, lane, 0, qf);
             frags_to_lds<XP, 3>(lds_ + hb * HALF, lane, 16, qf);
-            if constexpr (!H16) {
-                if (tile0 + hb < tiles)
-                    frags_to_plane<XP, 3>(qf, 0, bb.qbar_hi + (size_t)(tile0 + hb) * 4 * kFragBytes,
-                                            LO ? bb.qbar_lo + (size_t)(tile0 + hb) * 4 * kFragBytes : nullptr, pl, valid);
-            }
+            if (tile0 + hb < tiles)
+                frags_to_plane<XP, 3>(qf, 0, bb.qbar_hi + (size_t)(tile0 + hb) * 4 * kFragBytes,
+                                        LO ? bb.qbar_lo + (size_t)(tile0 + hb) * 4 * kFragBytes : nullptr, pl, valid);
         }
         p2_barrier();
         f32x16 acc;
@@ -544,7 +479,7 @@ __global__ void __launch_bounds__(512, 1) sdf_bwd_r8_kernel(const unsigned char*
                 R8_STAMP(1);
                 p2_barrier();                                       // every wave has read region hb
                 R8_STAMP(2);
-                if constexpr (hb == NH - 1) r8_request_rest<PREC, KSN, XP>(W, rsrc, vo_next, nx, blob);
+                if constexpr (hb == NH - 1) r8_request_rest<PREC, KSN>(W, rsrc, vo_next, nx, blob);
                 constexpr bool keep = KEEP && L == 7;
                 if (active) asc_post(acc, ops[hb & 1], L, hb, keep, L < 7);     // adj_8: plane only
                 // the freed operand set -> the phase two further on (at the turn: s_7, c_7 of the first descending phases)
@@ -566,7 +501,7 @@ __global__ void __launch_bounds__(512, 1) sdf_bwd_r8_kernel(const unsigned char*
         asc_step(IC(6), IC(16), IC(16), IC(0));
         asc_step(IC(7), IC(16), IC(16), IC(0));          // next: R8 (its first 16 k-steps)
         // ---- seed of the descending chain: zbar_8 = [fbar (tiles 0..7) ; sbar (row 0 of tile 8: k-steps 16, 17)]
-        if (XP != 3 && d_feat == nullptr) {
+        if (XP == 1 && d_feat == nullptr) {
             // the feature rows of the seed are in the plane already (slot 8 of zbar: the colour backward's bf16 fragments, heads added
             // by fneus_surface_scatter_plane): this wave's fragments 2 w, 2 w + 1 of every half -> its region, nothing to store
             static_for<0, NH>([&](auto HB_) {
@@ -574,15 +509,7 @@ __global__ void __launch_bounds__(512, 1) sdf_bwd_r8_kernel(const unsigned char*
 #pragma unroll
                 for (int sh = 0; sh < 2; ++sh) {
                     const int ks = 2 * w + sh;
-                    p2_u32x4 v = r8_ldb(rs_zbar_hi, sh ? pl.odd : pl.even, blk_off(8, hb) + (uint32_t)ks * kFragBytes);
-                    if constexpr (H16) {
-                        const float scl = sc_tab[(hb * 32 + r) * 2];
-                        const bf16x8 bv = __builtin_bit_cast(bf16x8, v);
-                        bf16x8 hv;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) hv[e] = to16<2>((float)bv[e] * scl);
-                        v = __builtin_bit_cast(p2_u32x4, hv);
-                    }
+                    const p2_u32x4 v = r8_ldb(rs_zbar_hi, sh ? pl.odd : pl.even, blk_off(8, hb) + (uint32_t)ks * kFragBytes);
                     *reinterpret_cast<p2_u32x4*>(lds_ + hb * HALF + ks * kFragBytes + lane * 16) = v;
                 }
             });
@@ -619,19 +546,11 @@ __global__ void __launch_bounds__(512, 1) sdf_bwd_r8_kernel(const unsigned char*
                 split_bf16(sv, shi, slo);
                 sf[0].hi[0] = shi;
                 sf[0].lo[0] = slo;
-            } else if constexpr (H16) {
-                sf[0].hi[0] = to16<2>(sv * sc_tab[(hb * 32 + r) * 2]);
             } else {
                 sf[0].hi[0] = (__bf16)sv;
             }
             frags_to_lds<XP, 2>(lds_ + hb * HALF, lane, 16, sf);
-            if constexpr (H16) {
-                BFrag<1> sp[2];
-                sp[0].hi = zero_bf16x8();
-                sp[1].hi = zero_bf16x8();
-                sp[0].hi[0] = (__bf16)sv;
-                if (tile0 + hb < tiles) frags_to_plane<1, 2>(sp, 0, bb.zsdf_hi + (size_t)(tile0 + hb) * 2 * kFragBytes, nullptr, pl, valid);
-            } else if (tile0 + hb < tiles)
+            if (tile0 + hb < tiles)
                 frags_to_plane<XP, 2>(sf, 0, bb.zsdf_hi + (size_t)(tile0 + hb) * 2 * kFragBytes,
                                         LO ? bb.zsdf_lo + (size_t)(tile0 + hb) * 2 * kFragBytes : nullptr, pl, valid);
         }
@@ -658,14 +577,10 @@ __global__ void __launch_bounds__(512, 1) sdf_bwd_r8_kernel(const unsigned char*
                     for (int s = 0; s < 2; ++s) {
                         const uint32_t f = (uint32_t)((16 + s) * 8 * 64) * 16u;
                         const bf16x8 whi = p2_wload(rsrc, voff, kSdfLayout.L[8].rev_hi + f, blob);
+                        const bf16x8 wlo = p2_wload(rsrc, voff, kSdfLayout.L[8].rev_lo + f, blob);
                         const bf16x8 b = *reinterpret_cast<const bf16x8*>(fl16 + s * kFragBytes);
-                        if constexpr (H16) {
-                            acc = mfma32p<2>(whi, b, acc);
-                        } else {
-                            const bf16x8 wlo = p2_wload(rsrc, voff, kSdfLayout.L[8].rev_lo + f, blob);
-                            acc = mfma32(wlo, b, acc);
-                            acc = mfma32(whi, b, acc);
-                        }
+                        acc = mfma32(wlo, b, acc);
+                        acc = mfma32(whi, b, acc);
                     }
                     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");      // (r8_dense: B registers may be reloaded at once)
                 }
@@ -673,7 +588,7 @@ __global__ void __launch_bounds__(512, 1) sdf_bwd_r8_kernel(const unsigned char*
                 R8_STAMP(5);
                 p2_barrier();
                 R8_STAMP(6);
-                if constexpr (hb == NH - 1) r8_request_rest<PREC, KSN, XP>(W, rsrc, voff, nx, blob);
+                if constexpr (hb == NH - 1) r8_request_rest<PREC, KSN>(W, rsrc, voff, nx, blob);
                 if (active) desc_post(acc, ops[hb & 1], L - 1, hb, L > 1);          // zbar_0: plane only
                 if constexpr (hb + 2 < NH) load_desc(ops[hb & 1], L - 1, hb + 2);
                 else if constexpr (L >= 2) load_desc(ops[hb & 1], L - 2, hb + 2 - NH);
@@ -710,7 +625,7 @@ static int launch_bwd_r8(const unsigned char* b, const PointSrc& src, long n_pts
         done = true;
     }
     const long groups = (n_pts + 32 * NH - 1) / (32 * NH);
-    hipLaunchKernelGGL((sdf_bwd_r8_kernel<PREC, GP, NH, XP>), dim3((unsigned)(groups < 256 ? groups : 256)), dim3(512), NH * (XP == 3 ? kR8Half : kR8Half / 2) + (XP == 2 ? NH * 32 * 8 : 0), stream, b, src,
+    hipLaunchKernelGGL((sdf_bwd_r8_kernel<PREC, GP, NH, XP>), dim3((unsigned)(groups < 256 ? groups : 256)), dim3(512), NH * (XP == 3 ? kR8Half : kR8Half / 2), stream, b, src,
                        n_pts, st, bb, d_sdf, d_feat, d_normal);
     return launch_status();
 }
@@ -732,12 +647,6 @@ int sdf_bwd_r8(const unsigned char* b, const PointSrc& src, long n_pts, const Sd
     return nh4 ? launch_bwd_r8<P, G, 4, X>(b, src, n_pts, st, bb, d_sdf, d_feat, d_normal, stream)                   \
                : launch_bwd_r8<P, G, 2, X>(b, src, n_pts, st, bb, d_sdf, d_feat, d_normal, stream)
     if (prec == 3 && gp == 3) FNEUS_BWD_R8(3, 3, 3);
-    // ... and ONE fp16 product per multiplication where the caller has given the weights' fp16 copy and the seed as fragments
-    // (FNEUS_K3_H16=0: two bf16 products)
-    const char* he = getenv("FNEUS_K3_H16");
-    const bool h16 = prec == 3 && gp != 3 && xhi && bb.w16 != nullptr && d_feat == nullptr && (he ? atoi(he) != 0 : true);
-    if (h16 && nh8) return launch_bwd_r8<3, 1, 8, 2>(b, src, n_pts, st, bb, d_sdf, d_feat, d_normal, stream);
-    if (h16 && nh4) return launch_bwd_r8<3, 1, 4, 2>(b, src, n_pts, st, bb, d_sdf, d_feat, d_normal, stream);
     if (prec == 3 && xhi && nh8) return launch_bwd_r8<3, 1, 8, 1>(b, src, n_pts, st, bb, d_sdf, d_feat, d_normal, stream);
     if (prec == 3 && xhi) FNEUS_BWD_R8(3, 1, 1);
     if (prec == 3) FNEUS_BWD_R8(3, 1, 3);

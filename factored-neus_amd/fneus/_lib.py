@@ -25,12 +25,12 @@ class FneusSdfStash(C.Structure):
 
 class FneusSdfBwdBufs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
-                ("qbar_hi", "qbar_lo", "adj_hi", "adj_lo", "zbar_hi", "zbar_lo", "zsdf_hi", "zsdf_lo", "c_hi", "c_lo", "w16")]
+                ("qbar_hi", "qbar_lo", "adj_hi", "adj_lo", "zbar_hi", "zbar_lo", "zsdf_hi", "zsdf_lo", "c_hi", "c_lo")]
 
 
 class FneusColStash(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
-                ("side_hi", "side_lo", "u_hi", "u_lo", "zbar_hi", "zbar_lo", "zout_hi", "zout_lo", "mask", "feat_hi", "feat_lo", "dfeat_hi", "w16")]
+                ("side_hi", "side_lo", "u_hi", "u_lo", "zbar_hi", "zbar_lo", "zout_hi", "zout_lo", "mask", "feat_hi", "feat_lo", "dfeat_hi")]
 
 
 class FneusNerfStash(C.Structure):
@@ -155,7 +155,6 @@ def _load():
         "fneus_lvis_visibility": (C.c_int, [vp, vp, vp, vp, vp, vp, ip, ip, ip, vp, ip, vp]),
         "fneus_lvis_blob_bytes": (C.c_size_t, []),
         "fneus_lvis_h16_pack": (C.c_int, [vp, vp, vp]),
-        "fneus_h16_pack": (C.c_int, [ip, vp, vp, vp]),
         "fneus_ray_hit": (C.c_int, [vp] * 7 + [ip, ip, f] + [vp] * 5 + [vp]),
         "fneus_sample_dirs": (C.c_int, [vp] * 4 + [ip, ip, vp, vp, vp]),
         "fneus_composite_fwd": (C.c_int, [vp] * 8 + [ip, ip, ip, f, vp, vp, vp, ip] + [vp] * 10 + [vp, ip, vp]),

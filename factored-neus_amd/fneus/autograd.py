@@ -116,8 +116,6 @@ class SdfValueGradFn(torch.autograd.Function):
                 ops.surface_scatter_plane(heads[0], heads[1], heads[2], bufs.zbar[0, 8], n, d_normal)
             else:
                 ops.surface_scatter(heads[0], heads[1], heads[2], d_feat, d_normal)       # head sum + scatter-add in one launch
-        # (the seed as fragments: the form in which K3 runs ONE fp16 product per multiplication on the weights' fp16 copy)
-        bufs.c.w16 = ops.h16_blob(net, 0).data_ptr() if in_plane and ops.bwd_h16_ok(n, prec, ctx.stash.gprec) else None
         ops.sdf_bwd(net.blob, n, prec, ctx.stash, bufs, d_sdf, None if in_plane else d_feat, d_normal, **ctx.samples.kw())
         # zeroed once: fneus_wn_backward clears what it reads, so the buffer is zero again after every step
         grad = ws.get(("sdf_grad", n), lambda: torch.zeros(net.n_params, dtype=torch.float32, device=dev))
@@ -249,8 +247,7 @@ class ColorFn(torch.autograd.Function):
                 bufs = sdf_ws.get(("sdf_bwd", n, prec), lambda: ops.SdfBwdBufs(n, rgb.device, prec, gprec=sdf_stash.gprec))
                 plane = bufs.zbar[0, 8]
                 sdf_ws.cache["dfeat_in_plane"] = ((id(sdf_ws), ctx.sdf_generation),)
-            w16 = ops.h16_blob(net, 1) if ops.bwd_h16_ok(n, prec, ctx.stash.gprec) else None
-            d_feat, d_normal = ops.color_bwd(net.blob, n, prec, d_rgb, rgb, ctx.stash, dfeat_plane=plane, w16=w16)
+            d_feat, d_normal = ops.color_bwd(net.blob, n, prec, d_rgb, rgb, ctx.stash, dfeat_plane=plane)
             feat_planes = ctx.sdf_ws.cache[("sdf_stash", n, prec, True)].feat
         grad = ws.get(("col_grad", n), lambda: torch.zeros(net.n_params, dtype=torch.float32, device=rgb.device))
         if ctx.stash.gprec == 2:        # the output layer's product with exact operands (u_3 hi + lo from the forward, zout in fp32 from

@@ -596,26 +596,6 @@ def color_fwd(blob, n_pts, prec, normal, feat, stash: Optional[ColStash], train:
 
 
 DFEAT_PLANE = _os.environ.get("FNEUS_DFEAT_PLANE", "1") != "0"
-BWD_H16 = _os.environ.get("FNEUS_BWD_H16", "1") != "0"
-
-
-def bwd_h16_ok(n_pts: int, prec: int, gprec: int) -> bool:
-    """do the backward chains of a launch run ONE fp16 product per multiplication?  Where they run on bf16 cotangents
-    at all (parity arithmetic, bf16 gradient planes, resident-weight kernels: launches of >= 1024 sample tiles) and at least 128
-    samples per workgroup fill the chip"""
-    env = _os.environ.get
-    return (BWD_H16 and prec == PREC_PARITY and gprec in (1, 2) and (n_pts + 63) // 64 >= 512 and (n_pts + 31) // 32 >= 1024
-            and env("FNEUS_COL_BWD_R8", "1") != "0" and env("FNEUS_COLB_XHI", "1") != "0" and env("FNEUS_R8_NH", "0") != "2")
-
-
-def h16_blob(net, kind: int):
-    """the network's weight fragments as fp16 (fneus_h16_pack) in a buffer that lives with the network; launched at every call -- the
-    backward of a training step runs it once per step, after the step's pack"""
-    buf = getattr(net, "_blob16", None)
-    if buf is None or buf.numel() != net.blob.numel() or buf.device != net.blob.device:
-        buf = net._blob16 = torch.zeros_like(net.blob)
-    _launch("fneus_h16_pack", lib.fneus_h16_pack, int(kind), _ptr(net.blob), _ptr(buf), _stream())
-    return buf
 
 
 def dfeat_plane_ok(n_pts: int, prec: int, gprec: int) -> bool:
@@ -631,7 +611,7 @@ def dfeat_plane_ok(n_pts: int, prec: int, gprec: int) -> bool:
 
 
 def color_bwd(blob, n_pts, prec, d_rgb, rgb, stash: ColStash, head: int = HEAD_COLOR, normal=None, dirs=None, rays_d=None,
-              m: int = 1, dfeat_plane=None, w16=None):
+              m: int = 1, dfeat_plane=None):
     """dfeat_plane (head 0, only where dfeat_plane_ok): the bf16 fragment plane [tiles, 16, 64, 8] that receives the feature cotangent --
     the returned d_feat is then a PLACEHOLDER no kernel wrote (its `plane_of` attribute is the plane)"""
     _chk_f32(d_rgb, "d_rgb")
@@ -639,7 +619,6 @@ def color_bwd(blob, n_pts, prec, d_rgb, rgb, stash: ColStash, head: int = HEAD_C
     d_normal = torch.empty(n_pts, 3, dtype=torch.float32, device=blob.device)
     if head == HEAD_COLOR:
         stash.c.dfeat_hi = dfeat_plane.data_ptr() if dfeat_plane is not None else None
-        stash.c.w16 = w16.data_ptr() if w16 is not None else None          # (w16: h16_blob(net, 1), only where bwd_h16_ok)
         _launch("fneus_color_bwd", lib.fneus_color_bwd, _ptr(blob), n_pts, _ptr(d_rgb), _ptr(rgb), C.byref(stash.c),
                 None if dfeat_plane is not None else _ptr(d_feat), _ptr(d_normal), prec, _stream())
         if dfeat_plane is not None:

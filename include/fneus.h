@@ -59,9 +59,6 @@ typedef struct FneusColStash {
     uint16_t* dfeat_hi;                   /* [tiles][16][512]     fneus_color_bwd with d_feat == NULL (round 6): the feature
                                              cotangent as bf16 fragments -- slot 8 of FneusSdfBwdBufs.zbar_hi, where fneus_sdf_bwd
                                              (d_feat == NULL) takes the seed of its descending chain from; NULL otherwise     */
-    const void* w16;                      /* fneus_color_bwd: the colour network's blob as fp16 fragments (fneus_h16_pack kind 1), or
-                                             NULL.  Given, with bf16 zbar planes and >= 1024 sample tiles, the backward chain runs ONE
-                                             fp16 product per multiplication on per-sample scaled cotangents       */
 } FneusColStash;
 
 /* work buffers of fneus_sdf_bwd: the operands of the weight-gradient GEMM (fragment planes like FneusSdfStash, *_lo
@@ -72,8 +69,6 @@ typedef struct FneusSdfBwdBufs {
     uint16_t* zbar_hi; uint16_t* zbar_lo; /* [9][tiles][16][512]  slot l = dL/dz_l (slot 8: the 256 feature rows of layer 8) */
     uint16_t* zsdf_hi; uint16_t* zsdf_lo; /* [tiles][2][512]      feature 0 = dL/dsdf (the sdf row of layer 8)             */
     uint16_t* c_hi;    uint16_t* c_lo;    /* coupling terms between the two chains, lane-private: [tiles][8][16][64] x 16 bytes */
-    const void* w16;                      /* the SDF network's blob as fp16 fragments (fneus_h16_pack kind 0), or NULL: as
-                                             FneusColStash.w16, for fneus_sdf_bwd                                              */
 } FneusSdfBwdBufs;
 
 /* Activation planes of the background NeRF++ (fneus_nerf_bg_fwd / _bwd): FRAGMENT PLANES like every other stash since
@@ -138,13 +133,6 @@ int fneus_layout(int which /*0 SDF, 1 colour-shaped, 2 background NeRF, 3 Lvis*/
  * nn.utils.weight_norm, fields.py:67-68, happens inside the packer), rowscale: per-row g/||v|| or NULL. */
 int fneus_pack(const void* jobs, int n_jobs, int n_units, const int32_t* maps, const float* params,
                const float* rowscale, void* blob, fneus_stream_t stream);
-/* fp16 copies of a packed network's weight fragments (round 6): `out` (as large as the blob) receives, in the place of every forward
- * and reverse hi fragment, fp16(hi + lo) of the same weights -- what fneus_color_bwd / fneus_sdf_bwd multiply ONE product per
- * multiplication with when their stash / buffer struct names it (w16) and the gradient planes are bf16.  kind 0: SDF network blob,
- * 1: colour network blob.  Run after fneus_pack whenever the parameters changed.  (fields.py:150-175, 74-111 through autograd: the
- * weights those backward passes read, rounded to 11 significant bits.)                                                          */
-int fneus_h16_pack(int kind, const void* blob, void* out, fneus_stream_t stream);
-
 
 /* Weight-norm fold + packing of SEVERAL networks in one launch each (what a training step does at its start: four or five
  * networks, each pair of launches a few microseconds of work).  Task i = the arguments of fneus_rowscale (rows, n_rows,
