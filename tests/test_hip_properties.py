@@ -262,6 +262,8 @@ def test_64_sample_workgroups_equal_32_sample_workgroups(monkeypatch):
 
     def run_nerf(hb):
         monkeypatch.setenv("FNEUS_K7_HB", str(hb))
+        monkeypatch.setenv("FNEUS_NERF_XHI", "0")           # (the same arithmetic on both sides: hi + lo cotangents inside the chain;
+                                                            #  the bf16-cotangent form of the 64-sample kernel: tests/test_hip_nerf.py)
         for p in nerf.parameters():
             p.grad = None
         nerf.refresh()
