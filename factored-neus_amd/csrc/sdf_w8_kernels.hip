@@ -102,9 +102,19 @@ struct W8Merge {
     float *dists, *mid_z;
 };
 
+// Several sampler steps in ONE launch (n_steps > 1, MERGE): a workgroup's tile is the same 32 / k rays in every step -- it evaluates the
+// depths its own merge of the step before has written (z_next of step j = z_new of step j + 1, z_out / s_out = z_old / s_old), so the
+// recurrence of renderer.py:433-446 needs no other workgroup and no launch boundary; the stores of a step are made visible to the
+// workgroup (fence + the barrier at the top of the next step) before wave 0 encodes the new points.
+constexpr int kW8MaxSteps = 4;
+struct W8Steps {
+    W8Merge st[kW8MaxSteps];
+    int n;
+};
+
 template <int PREC, bool MERGE>
-__global__ void __launch_bounds__(512, 2) sdf_fwd_w8p_kernel(const unsigned char* blob, PointSrc src, long N, float* __restrict__ sdf_out,
-                                                             W8Merge mg) {
+__global__ void __launch_bounds__(512, 2) sdf_fwd_w8p_kernel(const unsigned char* blob, PointSrc src0, long N, float* __restrict__ sdf_out,
+                                                             W8Steps steps) {
     __shared__ __attribute__((aligned(16))) unsigned char frag[kW8Half];
     __shared__ float red[8 * 32];
     __shared__ float snew[MERGE ? 32 : 1];
@@ -123,9 +133,14 @@ __global__ void __launch_bounds__(512, 2) sdf_fwd_w8p_kernel(const unsigned char
 #ifdef FNEUS_W8_STAMPS
     unsigned long long* stamps = reinterpret_cast<unsigned long long*>(sdf_out + ((N + 3) & ~3L));
 #endif
-    for (long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int n_steps = MERGE ? steps.n : 1;
+    for (long tile = blockIdx.x; tile < tiles; tile += gridDim.x)
+    for (int step = 0; step < n_steps; ++step) {
+        const W8Merge& mg = steps.st[MERGE ? step : 0];
+        PointSrc src = src0;
+        if (MERGE) src.t = mg.z_new;
 #ifdef FNEUS_W8_STAMPS
-        const bool stamp_on = tile == blockIdx.x && blockIdx.x < 32;
+        const bool stamp_on = tile == blockIdx.x && blockIdx.x < 32 && step == 0;
 #endif
         asm volatile("" : "+s"(blob));
         w8_barrier();                                   // the previous tile's fragments and sums are consumed
@@ -215,6 +230,7 @@ __global__ void __launch_bounds__(512, 2) sdf_fwd_w8p_kernel(const unsigned char
                                               mg.mid_z, b, b + MAXN, b + 2 * MAXN, b + 3 * MAXN, b + 4 * MAXN, b + 5 * MAXN + 4);
                 }
             }
+            if (step + 1 < n_steps) __threadfence_block();          // the next step of this tile reads what the merge has stored
         }
     }
 }
@@ -222,7 +238,7 @@ __global__ void __launch_bounds__(512, 2) sdf_fwd_w8p_kernel(const unsigned char
 int sdf_fwd_w8p(const unsigned char* b, const PointSrc& src, long n_pts, float* sdf_out, int prec, hipStream_t stream) {
     const long tiles = (n_pts + 31) / 32;
     const dim3 grid((unsigned)(tiles < 1024 ? tiles : 1024));
-    const W8Merge none{};
+    const W8Steps none{};
     if (prec == 3) hipLaunchKernelGGL((sdf_fwd_w8p_kernel<3, false>), grid, dim3(512), 0, stream, b, src, n_pts, sdf_out, none);
     else if (prec == 1) hipLaunchKernelGGL((sdf_fwd_w8p_kernel<1, false>), grid, dim3(512), 0, stream, b, src, n_pts, sdf_out, none);
     else return -2;
@@ -247,11 +263,44 @@ extern "C" int fneus_sdf_fwd_merge_upsample(const void* blob, const float* rays_
     const long tiles = (n_pts + 31) / 32;
     if ((k != 16 && k != 32) || tiles >= 1024 || m + k > MAXN || m + k + k_next > MAXN || k_next < 1 || (prec != 3 && prec != 1)) return -3;
     PointSrc src{nullptr, rays_o, rays_d, z_new, k};
-    const W8Merge mg{z_old, s_old, m, z_new, k, n_rays, inv_s, k_next, z_out, s_out, z_next, z_final, sample_dist, (z_final && mid_z) ? dists : nullptr, mid_z};
+    W8Steps one{};
+    one.st[0] = W8Merge{z_old, s_old, m, z_new, k, n_rays, inv_s, k_next, z_out, s_out, z_next, z_final, sample_dist, (z_final && mid_z) ? dists : nullptr, mid_z};
+    one.n = 1;
     const dim3 grid((unsigned)tiles);
     const unsigned char* b = reinterpret_cast<const unsigned char*>(blob);
-    if (prec == 3) hipLaunchKernelGGL((sdf_fwd_w8p_kernel<3, true>), grid, dim3(512), 0, stream, b, src, n_pts, s_new_out, mg);
-    else hipLaunchKernelGGL((sdf_fwd_w8p_kernel<1, true>), grid, dim3(512), 0, stream, b, src, n_pts, s_new_out, mg);
+    if (prec == 3) hipLaunchKernelGGL((sdf_fwd_w8p_kernel<3, true>), grid, dim3(512), 0, stream, b, src, n_pts, s_new_out, one);
+    else hipLaunchKernelGGL((sdf_fwd_w8p_kernel<1, true>), grid, dim3(512), 0, stream, b, src, n_pts, s_new_out, one);
+    return fneus::launch_status();
+}
+
+// The same for ALL remaining steps of a render in one launch (renderer.py:433-446 for i = 1 .. up_sample_steps - 1): step j evaluates
+// z_new[j], merges it into (z_old[j], s_old[j]) -> (z_out[j], s_out[j]) and draws z_next[j]; the caller chains the buffers (z_old[j + 1] =
+// z_out[j], s_old[j + 1] = s_out[j], z_new[j + 1] = z_next[j]); the last step writes z_final (+ sections).  -3: shapes it does not take.
+extern "C" int fneus_sdf_fwd_merge_upsample_steps(const void* blob, const float* rays_o, const float* rays_d, int n_steps,
+                                                  const FneusSamplerStep* st, int k, int n_rays, int k_next, float* z_final,
+                                                  float sample_dist, float* dists, float* mid_z, int prec, fneus_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    fneus::clear_status();
+    if (n_rays <= 0 || n_steps <= 0) return 0;
+    if (!blob || !rays_o || !rays_d || !st || !z_final) return -2;
+    const long n_pts = (long)n_rays * k;
+    const long tiles = (n_pts + 31) / 32;
+    if (n_steps > fneus::kW8MaxSteps || (k != 16 && k != 32) || tiles >= 1024 || k_next < 1 || (prec != 3 && prec != 1)) return -3;
+    // (one tile per workgroup: a tile's steps must stay with their workgroup, and with tiles < 1024 the grid covers them all)
+    W8Steps all{};
+    all.n = n_steps;
+    for (int j = 0; j < n_steps; ++j) {
+        const bool last = j + 1 == n_steps;
+        if (!st[j].z_old || !st[j].s_old || !st[j].z_new || !st[j].z_out || !st[j].s_out || !st[j].z_next) return -2;
+        if (st[j].m + k > MAXN || st[j].m + k + k_next > MAXN) return -3;
+        all.st[j] = W8Merge{st[j].z_old, st[j].s_old, st[j].m, st[j].z_new, k, n_rays, st[j].inv_s, k_next, st[j].z_out, st[j].s_out, st[j].z_next,
+                            last ? z_final : nullptr, sample_dist, (last && mid_z) ? dists : nullptr, last ? mid_z : nullptr};
+    }
+    PointSrc src{nullptr, rays_o, rays_d, st[0].z_new, k};
+    const dim3 grid((unsigned)tiles);
+    const unsigned char* b = reinterpret_cast<const unsigned char*>(blob);
+    if (prec == 3) hipLaunchKernelGGL((sdf_fwd_w8p_kernel<3, true>), grid, dim3(512), 0, stream, b, src, n_pts, (float*)nullptr, all);
+    else hipLaunchKernelGGL((sdf_fwd_w8p_kernel<1, true>), grid, dim3(512), 0, stream, b, src, n_pts, (float*)nullptr, all);
     return fneus::launch_status();
 }
 

@@ -39,6 +39,11 @@ class FneusNerfStash(C.Structure):
                  "zbar_hi", "zbar_lo", "zfeat_hi", "zfeat_lo", "zhv_hi", "zhv_lo", "zout_hi", "zout_lo")]
 
 
+class FneusSamplerStep(C.Structure):
+    _fields_ = [("z_old", C.c_void_p), ("s_old", C.c_void_p), ("m", C.c_int), ("z_new", C.c_void_p), ("inv_s", C.c_float),
+                ("z_out", C.c_void_p), ("s_out", C.c_void_p), ("z_next", C.c_void_p)]
+
+
 class FneusAdamSegment(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("count", C.c_long)]
@@ -118,6 +123,7 @@ def _load():
         "fneus_merge": (C.c_int, [vp, vp, ip, vp, vp, ip, ip, vp, vp, vp]),
         "fneus_merge_upsample": (C.c_int, [vp, vp, vp, vp, ip, vp, vp, ip, ip, f, ip, vp, vp, vp, vp, f, vp, vp, vp]),
         "fneus_sdf_fwd_merge_upsample": (C.c_int, [vp, vp, vp, vp, vp, ip, vp, ip, ip, f, ip, vp, vp, vp, vp, f, vp, vp, vp, ip, vp]),
+        "fneus_sdf_fwd_merge_upsample_steps": (C.c_int, [vp, vp, vp, ip, C.POINTER(FneusSamplerStep), ip, ip, ip, vp, f, vp, vp, ip, vp]),
         "fneus_sections": (C.c_int, [vp, ip, ip, f, vp, vp, vp]),
         "fneus_ray_setup": (C.c_int, [vp, vp, vp, vp, vp, ip, ip, vp, vp]),
         "fneus_split_batch": (C.c_int, [vp, ip, vp, vp, vp, vp, vp]),

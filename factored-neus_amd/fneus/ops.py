@@ -1526,6 +1526,40 @@ def sdf_merge_upsample(blob, prec: int, rays_o, rays_d, z_old, s_old, z_new, inv
     return out + (s_new,) if want_s_new else out
 
 
+SAMPLER_STEPS_FUSED = _os.environ.get("FNEUS_SAMPLER_STEPS_FUSED", "1") != "0"
+
+
+def sdf_merge_upsample_steps(blob, prec: int, rays_o, rays_d, z_old, s_old, z_new, inv_s_list, k_next: int, sample_dist: float):
+    """every remaining step of the hierarchical sampler in ONE launch (fneus_sdf_fwd_merge_upsample_steps): step j evaluates its new depths,
+    merges them and draws the next ones; inv_s_list = the steps' 64 * 2^i.  -> (z_final, dists, mid_z), or None when the launch does
+    not take the shape (the caller then runs the steps one by one)."""
+    B, m = z_old.shape
+    k = z_new.shape[1]
+    n = len(inv_s_list)
+    if (not SAMPLER_STEPS_FUSED or not SAMPLER_K1_FUSED or PROFILE is not None or n < 2 or n > 4 or k not in (16, 32) or k_next != k
+            or (B * k + 31) // 32 >= 1024 or m + k * (n + 1) > 256):
+        return None
+    dev = z_old.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    steps = (_lib.FneusSamplerStep * n)()
+    keep = []
+    zo, so, zn = z_old, s_old, z_new
+    for j in range(n):
+        mj = m + j * k
+        z_out, s_out, z_next = torch.empty(B, mj + k, **f32), torch.empty(B, mj + k, **f32), torch.empty(B, k_next, **f32)
+        st = steps[j]
+        st.z_old, st.s_old, st.m, st.z_new, st.inv_s = zo.data_ptr(), so.data_ptr(), mj, zn.data_ptr(), float(inv_s_list[j])
+        st.z_out, st.s_out, st.z_next = z_out.data_ptr(), s_out.data_ptr(), z_next.data_ptr()
+        keep += [z_out, s_out, z_next]
+        zo, so, zn = z_out, s_out, z_next
+    z_final = torch.empty(B, m + n * k + k_next, **f32)
+    dists, mid_z = torch.empty_like(z_final), torch.empty_like(z_final)
+    _launch("fneus_sdf_fwd_merge_upsample", lib.fneus_sdf_fwd_merge_upsample_steps, _ptr(blob), _ptr(rays_o), _ptr(rays_d), n, steps, k, B,
+            int(k_next), _ptr(z_final), float(sample_dist), _ptr(dists), _ptr(mid_z), prec, _stream())
+    z_final._chain = keep              # (the intermediate arrays live as long as the result: the launch may still be queued)
+    return z_final, dists, mid_z
+
+
 def split_batch(data: torch.Tensor):
     """[B,10] batch -> contiguous rays_o [B,3], rays_d [B,3], rgb [B,3], mask [B,1] in one launch"""
     _chk_f32(data, "data")

@@ -205,6 +205,11 @@ class SDFNetwork(_HipMLP):
         self._ensure()
         return ops.sdf_merge_upsample(self._net.blob, self.prec, rays_o, rays_d, z_old, s_old, z_new, inv_s, k_next, last, sample_dist)
 
+    def sdf_merge_upsample_steps(self, rays_o, rays_d, z_old, s_old, z_new, inv_s_list, k_next: int, sample_dist: float):
+        """every remaining step of the hierarchical sampler in one launch (ops.sdf_merge_upsample_steps; None: not this shape)"""
+        self._ensure()
+        return ops.sdf_merge_upsample_steps(self._net.blob, self.prec, rays_o, rays_d, z_old, s_old, z_new, inv_s_list, k_next, sample_dist)
+
     def value_feature_normal(self, samples: RaySamples, train: bool, feat_rows: bool = True):
         """sdf [n], feature [n,256], normal [n,3] in one fused pass (K2), differentiable w.r.t. the parameters.
         feat_rows False: the caller hands `feature` to RenderingNetwork.color_samples / SurfaceGatherFn only -- they read the stash's

@@ -116,6 +116,13 @@ class NeuSRenderer:
             ro, rd = rays_o.contiguous(), rays_d.contiguous()
             z_vals, sdf = z_vals.contiguous(), sdf.contiguous()
             new_z = ops.upsample(ro, rd, z_vals, sdf, k, 64.0)
+            # round 6: ALL remaining steps in one launch -- a workgroup keeps its two rays through the steps (None: not this shape)
+            fused = self.sdf_network.sdf_merge_upsample_steps(ro, rd, z_vals, sdf, new_z.contiguous(), [float(64 * 2 ** i) for i in range(1, steps)],
+                                                              k, 2.0 / self.n_samples) if steps >= 3 else None
+            if fused is not None:
+                z_final, dists, mid_z = fused
+                self._final_sections = (z_final, 2.0 / self.n_samples, dists, mid_z)
+                return z_final
             for i in range(1, steps):
                 # round 6: the SDF evaluation of the step's new depths and the merge + next up_sample in ONE launch (a tile of the
                 # evaluation is whole rays: the workgroup that evaluated it merges them); None: a shape that launch does not take

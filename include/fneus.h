@@ -349,6 +349,24 @@ int fneus_sdf_fwd_merge_upsample(const void* sdf_blob, const float* rays_o, cons
                                  int m, const float* z_new, int k, int n_rays, float inv_s, int k_next, float* z_out, float* s_out,
                                  float* z_next, float* z_final, float sample_dist, float* dists, float* mid_z, float* s_new_out, int prec,
                                  fneus_stream_t stream);
+
+/* ALL remaining steps of the hierarchical sampler in one launch (renderer.py:433-446, steps i = 1 .. up_sample_steps - 1; round 6): a
+ * workgroup keeps its 32 / k rays through every step -- it evaluates the depths its own merge has just drawn -- so the per-ray recurrence
+ * costs one launch instead of one per step.  The caller chains the buffers: z_old[j + 1] = z_out[j], s_old[j + 1] = s_out[j],
+ * z_new[j + 1] = z_next[j]; the last step writes z_final [B][m_last + k + k_next] and, with mid_z given, its sections.  Bit-identical
+ * to n_steps calls of fneus_sdf_fwd_merge_upsample.  -3: a shape this form does not take (more than 4 steps, k not 16 / 32, >= 1024
+ * sample tiles).                                                                                                                 */
+typedef struct FneusSamplerStep {
+    const float *z_old, *s_old;   /* [B][m]      depths and sdf values merged so far                       */
+    int m;
+    const float* z_new;           /* [B][k]      the depths this step evaluates                            */
+    float inv_s;                  /*             64 * 2^i of the step                                      */
+    float *z_out, *s_out;         /* [B][m + k]  the merged arrays                                         */
+    float* z_next;                /* [B][k_next] the next step's (or, in the last step, the final) new depths */
+} FneusSamplerStep;
+int fneus_sdf_fwd_merge_upsample_steps(const void* sdf_blob, const float* rays_o, const float* rays_d, int n_steps,
+                                       const FneusSamplerStep* steps /*host array*/, int k, int n_rays, int k_next, float* z_final,
+                                       float sample_dist, float* dists, float* mid_z, int prec, fneus_stream_t stream);
 /* One training batch [B][10] = rays_o, rays_d, rgb, mask per row (what Dataset.gen_random_rays_at returns, dataset.py:133-151)
  * -> the four contiguous arrays the kernels take (exp_runner.py:134-139 slices the same columns). */
 int fneus_split_batch(const float* data /*[B][10]*/, int n_rays, float* rays_o /*[B][3]*/, float* rays_d /*[B][3]*/,

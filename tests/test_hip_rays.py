@@ -144,6 +144,37 @@ def test_sampler_step_inside_the_k1_launch_is_bit_identical(B, k, last):
     assert ops.sdf_merge_upsample(net.blob, 3, ro, rd, z, s, new_z[:, :8].contiguous(), 256.0, 16, last, sample_dist=sd) is None
 
 
+@pytest.mark.parametrize("B,k,steps", [(512, 16, 4), (37, 16, 4), (64, 32, 3), (512, 16, 3)])
+def test_all_sampler_steps_in_one_launch_are_bit_identical(monkeypatch, B, k, steps):
+    """round 6: fneus_sdf_fwd_merge_upsample_steps runs every remaining step of the hierarchical sampler in ONE launch (a workgroup keeps
+    its 32 / k rays through the steps and evaluates the depths its own merge has drawn): final depths and sections bit for bit those of
+    the step-by-step launches, ragged ray counts, both tile shapes."""
+    from fneus import ops, synth
+    net = ops.PackedNet("sdf", DEV).load_state_dict({k_: T(v) for k_, v in synth.sdf_state_dict(27).items()})
+    net.pack()
+    data = T(synth.ray_batch(B, seed=B + k, n_miss=max(1, B // 20))).to(DEV)
+    ro, rd = data[:, :3].contiguous(), data[:, 3:6].contiguous()
+    m = 64
+    z = ops.ray_setup(ro, rd, m)
+    s = ops.sdf_fwd(net.blob, B * m, 3, rays_o=ro, rays_d=rd, t=z.reshape(-1), m=m).reshape(B, m).contiguous()
+    new_z = ops.upsample(ro, rd, z, s, k, 64.0)
+    sd = 2.0 / 64
+    inv = [float(64 * 2 ** i) for i in range(1, steps)]
+    got = ops.sdf_merge_upsample_steps(net.blob, 3, ro, rd, z, s, new_z, inv, k, sd)
+    assert got is not None
+    zc, sc, nz = z, s, new_z
+    for j, inv_s in enumerate(inv):
+        ref = ops.sdf_merge_upsample(net.blob, 3, ro, rd, zc, sc, nz.contiguous(), inv_s, k, j + 1 == len(inv), sample_dist=sd)
+        assert ref is not None
+        zc, sc, nz = ref[0], ref[1], ref[2]
+    torch.cuda.synchronize()
+    for a, b, name in zip(got, ref[3:6], ("z_final", "dists", "mid_z")):
+        assert torch.equal(a, b), name
+    assert got[0].shape == (B, m + k * steps)
+    # one step alone is not this entry point's case
+    assert ops.sdf_merge_upsample_steps(net.blob, 3, ro, rd, z, s, new_z, inv[:1], k, sd) is None
+
+
 def fops():
     from fneus import ops
     return ops
