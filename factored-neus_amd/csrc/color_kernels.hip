@@ -744,7 +744,7 @@ static int launch_bwd(const void* blob, long n_pts, const float* d_out, const fl
         if ((r8_env ? atoi(r8_env) : 1) != 0 && tiles_pp * 4 * (long)kPPBlock < (1L << 31))
             return fneus::color_bwd_r8(b, n_pts, d_out, out, st, d_feat, d_normal, prec, stream);
     }
-    if (d_feat == nullptr) return -2;       // the feature cotangent as fragments (stash->dfeat_hi): the resident-weight kernel only
+    if (d_feat == nullptr || st.dnormal_add) return -2;       // fragments out (stash->dfeat_hi) / d_normal added into: the resident-weight kernel only
     if (VAR == VAR_COLOR && col_use_hb2((n_pts + 31) / 32)) {
         dim3 g2(tp_grid((n_pts + 63) / 64));
         if (prec == 3) FNEUS_TPH_LAUNCH((color_bwd_tph_kernel<3, 2>), g2, b, n_pts, d_out, out, st, d_feat, d_normal);

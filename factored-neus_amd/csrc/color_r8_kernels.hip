@@ -305,9 +305,15 @@ __global__ void __launch_bounds__(512, 1) color_bwd_r8_kernel(const unsigned cha
             const f32x16 both[2] = {s2[0][0], s2[1][0]};
             const float g0 = acc_extract2<30>(both, h), g1 = acc_extract2<31>(both, h), g2 = acc_extract2<32>(both, h);
             if (valid && lane < 32) {
-                d_normal[n * 3 + 0] = g0;
-                d_normal[n * 3 + 1] = g1;
-                d_normal[n * 3 + 2] = g2;
+                if (st.dnormal_add) {           // the compositing backward's gradient of the same normals is in the buffer: autograd's sum
+                    d_normal[n * 3 + 0] += g0;
+                    d_normal[n * 3 + 1] += g1;
+                    d_normal[n * 3 + 2] += g2;
+                } else {
+                    d_normal[n * 3 + 0] = g0;
+                    d_normal[n * 3 + 1] = g1;
+                    d_normal[n * 3 + 2] = g2;
+                }
             }
         }
         C8_STAMP(7);

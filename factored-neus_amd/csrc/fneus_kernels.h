@@ -51,12 +51,13 @@ struct ColStash {                       // fragment planes (include/fneus.h Fneu
     u32x4* mask;                        // lane-private ReLU masks: [tiles][4][64] x 128 bits
     unsigned char *feat_hi, *feat_lo;   // [tiles][16 KiB]     surface head only: its (gathered) input features
     unsigned char* dfeat_hi;            // [tiles][16 KiB]     color_bwd without d_feat rows: the feature cotangent as bf16 fragments
+    int dnormal_add;                    // color_bwd_r8: d_normal += instead of =
     ColStash() { memset(this, 0, sizeof(*this)); }
     ColStash(const FneusColStash& s)
         : side_hi((unsigned char*)s.side_hi), side_lo((unsigned char*)s.side_lo), u_hi((unsigned char*)s.u_hi),
           u_lo((unsigned char*)s.u_lo), zbar_hi((unsigned char*)s.zbar_hi), zbar_lo((unsigned char*)s.zbar_lo),
           zout_hi((unsigned char*)s.zout_hi), zout_lo((unsigned char*)s.zout_lo), mask((u32x4*)s.mask),
-          feat_hi((unsigned char*)s.feat_hi), feat_lo((unsigned char*)s.feat_lo), dfeat_hi((unsigned char*)s.dfeat_hi) {}
+          feat_hi((unsigned char*)s.feat_hi), feat_lo((unsigned char*)s.feat_lo), dfeat_hi((unsigned char*)s.dfeat_hi), dnormal_add(s.dnormal_add) {}
 };
 
 struct NerfStash {      // fragment planes (fneus_pp.h): [tiles][F fragments][64 slots][8 bf16]; *_lo NULL unless gradient precision 3

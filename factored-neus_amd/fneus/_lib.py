@@ -30,7 +30,8 @@ class FneusSdfBwdBufs(C.Structure):
 
 class FneusColStash(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
-                ("side_hi", "side_lo", "u_hi", "u_lo", "zbar_hi", "zbar_lo", "zout_hi", "zout_lo", "mask", "feat_hi", "feat_lo", "dfeat_hi")]
+                ("side_hi", "side_lo", "u_hi", "u_lo", "zbar_hi", "zbar_lo", "zout_hi", "zout_lo", "mask", "feat_hi", "feat_lo", "dfeat_hi")] + [
+                    ("dnormal_add", C.c_int32)]
 
 
 class FneusNerfStash(C.Structure):

@@ -217,6 +217,7 @@ class ColorFn(torch.autograd.Function):
         # backward a later render may have stamped it again)
         ctx.sdf_generation = getattr(sdf_ws, "generation", None) if sdf_ws is not None else None
         ctx.from_planes = head == 0 and getattr(feat, "planes_of", None) is not None
+        ctx.normal_key = (normal.data_ptr(), tuple(normal.shape)) if head == 0 else None
         if head != 0:
             ctx.save_for_backward(rgb, normal)
         else:
@@ -247,7 +248,12 @@ class ColorFn(torch.autograd.Function):
                 bufs = sdf_ws.get(("sdf_bwd", n, prec), lambda: ops.SdfBwdBufs(n, rgb.device, prec, gprec=sdf_stash.gprec))
                 plane = bufs.zbar[0, 8]
                 sdf_ws.cache["dfeat_in_plane"] = ((id(sdf_ws), ctx.sdf_generation),)
-            d_feat, d_normal = ops.color_bwd(net.blob, n, prec, d_rgb, rgb, ctx.stash, dfeat_plane=plane)
+            # the compositing backward has left ITS gradient of these normals for this launch to add into (round 6): autograd's sum of
+            # the two without the launch that forms it
+            acc = _DN_ACC.pop(ctx.normal_key, None) if ctx.normal_key is not None else None
+            if acc is not None and not (ctx.needs_input_grad[1] and ops.dnormal_accum_ok(n, prec)):
+                acc = None
+            d_feat, d_normal = ops.color_bwd(net.blob, n, prec, d_rgb, rgb, ctx.stash, dfeat_plane=plane, dn_accum=acc)
             feat_planes = ctx.sdf_ws.cache[("sdf_stash", n, prec, True)].feat
         grad = ws.get(("col_grad", n), lambda: torch.zeros(net.n_params, dtype=torch.float32, device=rgb.device))
         if ctx.stash.gprec == 2:        # the output layer's product with exact operands (u_3 hi + lo from the forward, zout in fp32 from
@@ -317,6 +323,7 @@ class NerfFn(torch.autograd.Function):
         return None, None, None, None, None, None, None, None
 
 
+_DN_ACC = {}            # (data_ptr, shape) of a normals tensor -> the compositing backward's gradient of it, for ColorFn.backward to add into
 _PENDING_NERF = {}      # device -> {id(network): record of NerfFn.backward waiting for the SDF network's weight-gradient launch}
 _PENDING_OPEN = {}      # device -> (id(workspace), stash stamp) of the latest SdfValueGradFn forward whose backward has not run
 
@@ -609,6 +616,13 @@ class CompositeFn(torch.autograd.Function):
         # the variance parameter's gradient = the sum of the per-ray terms.  With a persistent gradient buffer (the trainers' arena) and
         # the colour network's exact output-layer launch still to come in this backward pass, the sum rides in that launch's fold
         # stage and is added to variance.grad there: a reduction launch and autograd's accumulation launch less per step
+        # the colour network's backward follows in this pass (its d_rgb is formed here) and differentiates the same normals: it adds its
+        # gradient into this one instead of autograd summing the two in a launch of its own (ColorFn.backward takes the record; whatever
+        # is left when the pass ends is dropped -- the tensor itself goes to autograd as ever)
+        if ops.DNORMAL_ACC and d_normal is not None:
+            key = (normal.data_ptr(), tuple(normal.shape))
+            _DN_ACC[key] = d_normal
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: _DN_ACC.pop(key, None))
         var = ctx.var_param
         if (var is not None and var.grad is not None and var.grad.is_contiguous() and var.grad.dtype == torch.float32 and var.numel() == 1
                 and ops.DEFAULT_FOLD_RIDER and ops.PROFILE is None):

@@ -610,19 +610,39 @@ def dfeat_plane_ok(n_pts: int, prec: int, gprec: int) -> bool:
             and env("FNEUS_COLB_XHI", "1") != "0" and env("FNEUS_K3_HB") is None and env("FNEUS_BWD_WHI", "0") == "0")
 
 
+DNORMAL_ACC = _os.environ.get("FNEUS_DNORMAL_ACC", "1") != "0"
+
+
+def dnormal_accum_ok(n_pts: int, prec: int) -> bool:
+    """may fneus_color_bwd ADD its gradient of the normals into a buffer that already holds the compositing backward's (autograd's sum
+    of the two without a launch)?  Where the launch takes the resident-weight kernel (csrc/color_kernels.hip launch_bwd)"""
+    tiles_pp = 2 * ((n_pts + 63) // 64)
+    return (DNORMAL_ACC and prec in (PREC_PARITY, PREC_FAST) and (n_pts + 31) // 32 >= 1024 and tiles_pp * 4 * 16384 < 2 ** 31
+            and _os.environ.get("FNEUS_COL_BWD_R8", "1") != "0")
+
+
 def color_bwd(blob, n_pts, prec, d_rgb, rgb, stash: ColStash, head: int = HEAD_COLOR, normal=None, dirs=None, rays_d=None,
-              m: int = 1, dfeat_plane=None):
+              m: int = 1, dfeat_plane=None, dn_accum=None):
     """dfeat_plane (head 0, only where dfeat_plane_ok): the bf16 fragment plane [tiles, 16, 64, 8] that receives the feature cotangent --
-    the returned d_feat is then a PLACEHOLDER no kernel wrote (its `plane_of` attribute is the plane)"""
+    the returned d_feat is then a PLACEHOLDER no kernel wrote (its `plane_of` attribute is the plane).
+    dn_accum (head 0, only where dnormal_accum_ok): an fp32 [n, 3] tensor the gradient of the normals is ADDED into; the returned
+    d_normal is then None"""
     _chk_f32(d_rgb, "d_rgb")
     d_feat = torch.empty(n_pts, 256, dtype=torch.float32, device=blob.device)
-    d_normal = torch.empty(n_pts, 3, dtype=torch.float32, device=blob.device)
+    if dn_accum is not None:
+        if head != HEAD_COLOR or tuple(dn_accum.shape) != (n_pts, 3):
+            raise ValueError("dn_accum: the colour network's backward only, an [n, 3] tensor")
+        _chk_f32(dn_accum, "dn_accum")
+    d_normal = torch.empty(n_pts, 3, dtype=torch.float32, device=blob.device) if dn_accum is None else dn_accum
     if head == HEAD_COLOR:
+        stash.c.dnormal_add = 1 if dn_accum is not None else 0
         stash.c.dfeat_hi = dfeat_plane.data_ptr() if dfeat_plane is not None else None
         _launch("fneus_color_bwd", lib.fneus_color_bwd, _ptr(blob), n_pts, _ptr(d_rgb), _ptr(rgb), C.byref(stash.c),
                 None if dfeat_plane is not None else _ptr(d_feat), _ptr(d_normal), prec, _stream())
         if dfeat_plane is not None:
             d_feat.plane_of = dfeat_plane
+        if dn_accum is not None:
+            return d_feat, None
     else:
         _chk_f32(normal, "normal")
         _launch("fneus_refcolor_bwd", lib.fneus_refcolor_bwd, _ptr(blob), head, n_pts, _ptr(rays_d), m, _ptr(dirs), _ptr(normal),

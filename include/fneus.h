@@ -59,6 +59,9 @@ typedef struct FneusColStash {
     uint16_t* dfeat_hi;                   /* [tiles][16][512]     fneus_color_bwd with d_feat == NULL (round 6): the feature
                                              cotangent as bf16 fragments -- slot 8 of FneusSdfBwdBufs.zbar_hi, where fneus_sdf_bwd
                                              (d_feat == NULL) takes the seed of its descending chain from; NULL otherwise     */
+    int32_t dnormal_add;                  /* fneus_color_bwd, launches of >= 1024 sample tiles (-2 otherwise): non-zero = d_normal is
+                                             ADDED to what the buffer holds (the compositing backward's gradient of the same normals:
+                                             autograd's sum of the two, renderer.py:243 + fields.py:160, without a launch of its own) */
 } FneusColStash;
 
 /* work buffers of fneus_sdf_bwd: the operands of the weight-gradient GEMM (fragment planes like FneusSdfStash, *_lo

@@ -203,3 +203,32 @@ def test_feature_cotangent_as_fragments_instead_of_rows_changes_nothing(monkeypa
             assert abs(a - b) <= 2e-6 * abs(a), (l0, l1)
         for u, v in ((c0, c1), (s0, s1), (t0, t1)):
             assert (v - u).abs().max().item() <= 2e-3 * u.abs().max().item()          # (Adam amplifies last-bit differences of a gradient)
+
+
+def test_normals_gradient_added_in_place_equals_autograds_sum(monkeypatch):
+    """round 6: the compositing backward and the colour network's backward both differentiate the normals; the colour launch (resident-weight
+    kernel) ADDS its gradient into the compositing backward's tensor (FneusColStash.dnormal_add, ops.dnormal_accum_ok) instead of autograd
+    summing the two in a launch of its own.  fp32 addition commutes: the same parameters bit for bit after three deterministic steps."""
+    from fneus import ops
+    from fneus.trainer import Stage1Trainer, synthetic_batches
+    dev = torch.device("cuda:0")
+    batches = synthetic_batches(3, 512, dev, seed0=95)
+
+    def run(acc, graph):
+        monkeypatch.setattr(ops, "DNORMAL_ACC", acc)
+        ops.set_deterministic(True)
+        try:
+            torch.manual_seed(19)
+            tr = Stage1Trainer(dev, seed=11, use_graph=graph)
+            losses = [float(tr.train_step(b)["loss"]) for b in batches]
+            return losses, tr.sdf_network.lin0.weight_v.detach().clone(), tr.sdf_network.lin7.weight_v.detach().clone()
+        finally:
+            ops.set_deterministic(None)
+
+    monkeypatch.setattr(ops, "DNORMAL_ACC", True)
+    assert ops.dnormal_accum_ok(512 * 128, ops.PREC_PARITY) and not ops.dnormal_accum_ok(1000, ops.PREC_PARITY)
+    for graph in (False, True):
+        l0, a0, b0 = run(False, graph)
+        l1, a1, b1 = run(True, graph)
+        assert l0 == l1
+        assert torch.equal(a0, a1) and torch.equal(b0, b1)
