@@ -180,7 +180,7 @@ def cpu_baseline(device=None):
 
 
 # newest first: the PMC passes are re-collected whenever a kernel's memory behaviour changes (tools/collect_profiles.sh)
-TRAFFIC_FILES = ("r06_u_traffic.json", "r06_v_traffic.json", "r06_w_traffic.json", "r06_z_traffic.json", "r06_y_traffic.json", "r06_x_traffic.json", "r05_e_traffic.json", "r05_d_traffic.json", "r05_c_traffic.json", "r05_b_traffic.json", "r05_a_traffic.json", "r04_h_traffic.json", "r04_f_traffic.json", "r04_e_traffic.json", "r04_d_traffic.json", "r04_c_traffic.json", "r04_b_traffic.json", "r04_a_traffic.json", "r03_h_traffic.json", "r03_g_traffic.json", "r03_f_traffic.json", "r03_e_traffic.json", "r03_d_traffic.json", "r03_c_traffic.json", "r03_b_traffic.json", "r03_a_traffic.json", "r02_e_traffic.json", "r02_d_traffic.json", "r02_c_traffic.json", "r02_b_traffic.json", "r02_a_traffic.json")
+TRAFFIC_FILES = ("r06_t_traffic.json", "r06_u_traffic.json", "r06_v_traffic.json", "r06_w_traffic.json", "r06_z_traffic.json", "r06_y_traffic.json", "r06_x_traffic.json", "r05_e_traffic.json", "r05_d_traffic.json", "r05_c_traffic.json", "r05_b_traffic.json", "r05_a_traffic.json", "r04_h_traffic.json", "r04_f_traffic.json", "r04_e_traffic.json", "r04_d_traffic.json", "r04_c_traffic.json", "r04_b_traffic.json", "r04_a_traffic.json", "r03_h_traffic.json", "r03_g_traffic.json", "r03_f_traffic.json", "r03_e_traffic.json", "r03_d_traffic.json", "r03_c_traffic.json", "r03_b_traffic.json", "r03_a_traffic.json", "r02_e_traffic.json", "r02_d_traffic.json", "r02_c_traffic.json", "r02_b_traffic.json", "r02_a_traffic.json")
 
 
 def main():
@@ -549,8 +549,8 @@ def main():
             dt = (time.perf_counter() - t0) / 10
             return dt, (float(hit_sum) / n_counted if n_counted else 0.0), bool(tr.use_graph)
 
-        STAGE_PMC_FILES = {"stage2": ("r06_u_stage2_pmc.json", "r06_v_stage2_pmc.json", "r06_w_stage2_pmc.json", "r06_z_stage2_pmc.json", "r06_y_stage2_pmc.json", "r06_x_stage2_pmc.json"),
-                           "stage3": ("r06_u_stage3_pmc.json", "r06_v_stage3_pmc.json", "r06_w_stage3_pmc.json", "r06_z_stage3_pmc.json", "r06_y_stage3_pmc.json", "r06_x_stage3_pmc.json")}
+        STAGE_PMC_FILES = {"stage2": ("r06_t_stage2_pmc.json", "r06_u_stage2_pmc.json", "r06_v_stage2_pmc.json", "r06_w_stage2_pmc.json", "r06_z_stage2_pmc.json", "r06_y_stage2_pmc.json", "r06_x_stage2_pmc.json"),
+                           "stage3": ("r06_t_stage3_pmc.json", "r06_u_stage3_pmc.json", "r06_v_stage3_pmc.json", "r06_w_stage3_pmc.json", "r06_z_stage3_pmc.json", "r06_y_stage3_pmc.json", "r06_x_stage3_pmc.json")}
         STAGE_KERNEL = {"fneus_sdf_fwd_rays": "sdf_fwd_p2_kernel", "fneus_sdf_fwd": "sdf_fwd_p2_kernel", "fneus_lvis_visibility": "lvis_visibility_p2_kernel"}
 
         def stage_roofline(stage, make_trainer):
